@@ -1,0 +1,123 @@
+"""ctypes view of include/fesom_gpu.h (the C-ABI shared library libfesom_gpu.so).
+
+Only plumbing: struct layouts mirror the header field by field.  The library is
+built in-tree by fesom2_amd.build (hipcc --offload-arch=gfx950); importing this
+module never falls back to a CPU path: a missing library raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfesom_gpu.so")
+
+PI = C.POINTER(C.c_int)
+PD = C.POINTER(C.c_double)
+
+
+class MeshDesc(C.Structure):
+    _fields_ = (
+        [(n, C.c_int) for n in ("nod2D", "elem2D", "edge2D", "edge2D_in", "nl", "myDim_nod2D", "eDim_nod2D",
+                                 "myDim_elem2D", "eDim_elem2D", "eXDim_elem2D", "myDim_edge2D", "eDim_edge2D",
+                                 "max_nod_in_elem", "ssh_nza")]
+        + [("myList_nod2D", PI), ("myList_elem2D", PI), ("myList_edge2D", PI),
+           ("coord_nod2D", PD), ("geo_coord_nod2D", PD),
+           ("elem2D_nodes", PI), ("edges", PI), ("edge_tri", PI), ("elem_edges", PI), ("elem_neighbors", PI),
+           ("nod_in_elem2D", PI), ("nod_in_elem2D_num", PI),
+           ("nlevels", PI), ("ulevels", PI),
+           ("nlevels_nod2D", PI), ("ulevels_nod2D", PI), ("nlevels_nod2D_min", PI), ("ulevels_nod2D_max", PI),
+           ("zbar", PD), ("Z", PD), ("depth", PD), ("elem_area", PD),
+           ("area", PD), ("area_inv", PD), ("areasvol", PD), ("areasvol_inv", PD), ("mesh_resolution", PD),
+           ("gradient_sca", PD), ("gradient_vec", PD), ("edge_dxdy", PD), ("edge_cross_dxdy", PD),
+           ("elem_cos", PD), ("metric_factor", PD), ("coriolis", PD), ("coriolis_node", PD),
+           ("ssh_rowptr", PI), ("ssh_colind", PI), ("ssh_colind_loc", PI), ("ssh_values", PD),
+           ("edge_up_dn_tri", PI),
+           ("zbar_n_bot", PD), ("zbar_n_srf", PD), ("bottom_node_thickness", PD),
+           ("zbar_e_bot", PD), ("zbar_e_srf", PD), ("bottom_elem_thickness", PD)])
+
+
+class ComDesc(C.Structure):
+    _fields_ = [("rPEnum", C.c_int), ("sPEnum", C.c_int), ("rPE", PI), ("rptr", PI), ("rlist", PI),
+                ("sPE", PI), ("sptr", PI), ("slist", PI)]
+
+
+class PartDesc(C.Structure):
+    _fields_ = [("npes", C.c_int), ("mype", C.c_int), ("com_nod2D", ComDesc), ("com_elem2D", ComDesc),
+                ("com_elem2D_full", ComDesc)]
+
+
+class Params(C.Structure):
+    _fields_ = ([("dt", C.c_double)]
+                + [(n, C.c_int) for n in ("which_ale", "use_partial_cell", "state_equation", "num_tracers", "mom_adv",
+                                           "visc_option", "i_vert_visc", "i_vert_diff", "w_split", "mix_scheme",
+                                           "use_instabmix", "use_windmix", "windmix_nl", "toy_soufflet")]
+                + [(n, C.c_double) for n in ("alpha", "theta", "epsilon", "C_d", "A_ver", "K_ver", "K_hor", "gamma0",
+                                              "gamma1", "gamma2", "easy_bs_return", "w_max_cfl", "tra_adv_ph",
+                                              "tra_adv_pv", "instabmix_kv", "windmix_kv", "cyclic_length")]
+                + [("with_diffusion", C.c_int)])
+
+
+STATE_FIELDS = ("tr_arr", "tr_arr_old", "UV", "UV_rhsAB", "eta_n", "d_eta", "ssh_rhs", "ssh_rhs_old", "hbar",
+                "hbar_old", "dhe", "hnode", "hnode_new", "helem", "zbar_3d_n", "Z_3d_n", "Wvel", "Wvel_e", "Wvel_i",
+                "ssh_values")
+
+
+class StateDesc(C.Structure):
+    _fields_ = [(n, PD) for n in STATE_FIELDS]
+
+
+class ForcingDesc(C.Structure):
+    _fields_ = [(n, PD) for n in ("stress_surf", "heat_flux", "water_flux", "virtual_salt", "relax_salt",
+                                  "real_salt_flux")]
+
+
+class MeshOpts(C.Structure):
+    _fields_ = [("force_rotation", C.c_int), ("cyclic_length_deg", C.c_double), ("alphaEuler_deg", C.c_double),
+                ("betaEuler_deg", C.c_double), ("gammaEuler_deg", C.c_double), ("use_partial_cell", C.c_int),
+                ("which_ale", C.c_int), ("dt", C.c_double), ("alpha", C.c_double), ("theta", C.c_double),
+                ("K_hor", C.c_double), ("npes", C.c_int), ("mype", C.c_int)]
+
+
+# every symbol include/fesom_gpu.h declares
+EXPORTS = ("fesom_gpu_init", "fesom_gpu_upload_state", "fesom_gpu_download_state", "fesom_gpu_set_forcing",
+           "fesom_gpu_step", "fesom_gpu_run_steps", "fesom_gpu_finalize", "fesom_gpu_get_field",
+           "fesom_gpu_set_field", "fesom_gpu_call", "fesom_gpu_last_solver_iterations",
+           "fesom_gpu_last_solver_residual", "fesom_gpu_kernel_time_ms", "fesom_gpu_last_error",
+           "psolver_init", "psolve", "psolver_final",
+           "fesom_mesh_load", "fesom_mesh_get_desc", "fesom_mesh_get_part", "fesom_mesh_get_initial_state",
+           "fesom_mesh_free")
+
+_lib = None
+
+
+def load():
+    """Load libfesom_gpu.so (RTLD_GLOBAL not needed).  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the HIP extension is mandatory; there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    lib.fesom_mesh_load.restype = C.c_void_p
+    lib.fesom_mesh_load.argtypes = [C.c_char_p, C.POINTER(MeshOpts)]
+    lib.fesom_mesh_get_desc.restype = C.POINTER(MeshDesc)
+    lib.fesom_mesh_get_desc.argtypes = [C.c_void_p]
+    lib.fesom_mesh_get_part.restype = C.POINTER(PartDesc)
+    lib.fesom_mesh_get_part.argtypes = [C.c_void_p]
+    lib.fesom_mesh_get_initial_state.restype = C.POINTER(StateDesc)
+    lib.fesom_mesh_get_initial_state.argtypes = [C.c_void_p, C.c_int]
+    lib.fesom_mesh_free.argtypes = [C.c_void_p]
+    lib.fesom_gpu_init.argtypes = [C.POINTER(MeshDesc), C.POINTER(PartDesc), C.POINTER(Params)]
+    lib.fesom_gpu_upload_state.argtypes = [C.POINTER(StateDesc)]
+    lib.fesom_gpu_download_state.argtypes = [C.POINTER(StateDesc)]
+    lib.fesom_gpu_set_forcing.argtypes = [C.POINTER(ForcingDesc)]
+    lib.fesom_gpu_step.argtypes = [C.c_int]
+    lib.fesom_gpu_run_steps.argtypes = [C.c_int, C.c_int]
+    lib.fesom_gpu_get_field.argtypes = [C.c_char_p, PD, C.c_longlong]
+    lib.fesom_gpu_set_field.argtypes = [C.c_char_p, PD, C.c_longlong]
+    lib.fesom_gpu_call.argtypes = [C.c_char_p, C.c_int]
+    lib.fesom_gpu_last_solver_residual.restype = C.c_double
+    lib.fesom_gpu_kernel_time_ms.argtypes = [C.c_char_p, C.c_int, PD]
+    lib.fesom_gpu_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib

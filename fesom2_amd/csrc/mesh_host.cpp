@@ -1,0 +1,623 @@
+// Host mesh layer (setup, untimed).  Builds every array of the reference's t_mesh and
+// the static/initial ALE arrays from the ASCII mesh files, in the reference's operation
+// order so that the results are bit-identical to mesh_setup/ocean_setup:
+//   read_mesh              src/oce_mesh.F90:147-696      test_tri        :1353-1395
+//   load_edges             :1419-1642                    find_neighbors  :1650-1800
+//   find_levels(_min_e2n)  :699-815,1322-1350            mesh_areas      :1840-2090
+//   mesh_auxiliary_arrays  :2097-2300                    r2g/g2r         src/gen_modules_rotate_grid.F90
+//   init_ale / bottom thickness / init_thickness_ale     src/oce_ale.F90:82-795
+//   init_stiff_mat_ale     src/oce_ale.F90:1088-1354     find_up_downwind_triangles src/oce_muscl_adv.F90:124-281
+// Everything is computed on the GLOBAL mesh in global order; a rank's local arrays are an
+// extraction through dist_<npes>/my_list (owned lists are in increasing global order, so
+// owned values do not depend on the partition).
+#include "../../include/fesom_gpu.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include <fstream>
+#include <sstream>
+
+namespace {
+const double PI = 3.14159265358979;          // o_PARAM pi (src/oce_modules.F90:11), deliberately truncated
+const double RAD = PI / 180.0;
+const double R_EARTH = 6367500.0;
+const double G_ACC = 9.81;
+const double OMEGA = 2 * PI / (3600.0 * 24.0);
+
+typedef std::vector<double> dvec;
+typedef std::vector<int> ivec;
+
+struct Mesh {
+  fesom_mesh_opts o;
+  int N2 = 0, E2 = 0, D2 = 0, D2in = 0, nl = 0, maxk = 0, nza = 0;
+  double cyc = 0;
+  double r2g_m[3][3];
+  // global arrays (1-based content, 0-based storage)
+  dvec coord, geo, depth, zbar, Z;
+  ivec elem_nodes, edges, edge_tri, elem_edges, elem_nb, nie, nie_num;
+  ivec nlev, ulev, nlev_n, ulev_n, nlev_n_min, ulev_n_max;
+  dvec elem_area, area, area_inv, areasvol, areasvol_inv, resol;
+  dvec grad_sca, grad_vec, edge_dxdy, edge_cross, elem_cos, metric, cori, cori_n;
+  ivec rowptr, colind, colind_loc; dvec values;
+  ivec updn;
+  dvec zbar_n_bot, zbar_n_srf, bot_n_th, zbar_e_bot, zbar_e_srf, bot_e_th;
+  ivec list_n, list_e, list_d;
+  // initial state
+  dvec hnode, hnode_new, helem, zbar3, Z3, eta, d_eta, ssh_rhs, ssh_rhs_old, hbar, hbar_old, dhe;
+  dvec tr, tr_old, UV, UVab, W, We, Wi, values_state;
+  fesom_mesh_desc desc;
+  fesom_part_desc part;
+  fesom_state_desc st;
+  ivec com_dummy;
+};
+
+bool read_all_tokens(const std::string &fn, std::vector<std::string> &tok) {
+  std::ifstream f(fn);
+  if (!f) return false;
+  std::stringstream ss; ss << f.rdbuf();
+  std::string t;
+  while (ss >> t) tok.push_back(t);
+  return true;
+}
+
+inline void trim_cyclic(double &b, double cyc) {
+  if (b > cyc / 2.0) b = b - cyc;
+  if (b < -cyc / 2.0) b = b + cyc;
+}
+
+void set_rot(Mesh &m) {
+  double al = m.o.alphaEuler_deg * RAD, be = m.o.betaEuler_deg * RAD, ga = m.o.gammaEuler_deg * RAD;
+  m.r2g_m[0][0] = cos(ga) * cos(al) - sin(ga) * cos(be) * sin(al);
+  m.r2g_m[0][1] = cos(ga) * sin(al) + sin(ga) * cos(be) * cos(al);
+  m.r2g_m[0][2] = sin(ga) * sin(be);
+  m.r2g_m[1][0] = -sin(ga) * cos(al) - cos(ga) * cos(be) * sin(al);
+  m.r2g_m[1][1] = -sin(ga) * sin(al) + cos(ga) * cos(be) * cos(al);
+  m.r2g_m[1][2] = cos(ga) * sin(be);
+  m.r2g_m[2][0] = sin(be) * sin(al);
+  m.r2g_m[2][1] = -sin(be) * cos(al);
+  m.r2g_m[2][2] = cos(be);
+}
+void r2g(const Mesh &m, double &glon, double &glat, double rlon, double rlat) {
+  double xr = cos(rlat) * cos(rlon), yr = cos(rlat) * sin(rlon), zr = sin(rlat);
+  double xg = m.r2g_m[0][0] * xr + m.r2g_m[1][0] * yr + m.r2g_m[2][0] * zr;
+  double yg = m.r2g_m[0][1] * xr + m.r2g_m[1][1] * yr + m.r2g_m[2][1] * zr;
+  double zg = m.r2g_m[0][2] * xr + m.r2g_m[1][2] * yr + m.r2g_m[2][2] * zr;
+  glat = asin(zg);
+  if (yg == 0. && xg == 0.) glon = 0.0; else glon = atan2(yg, xg);
+}
+void g2r(const Mesh &m, double glon, double glat, double &rlon, double &rlat) {
+  double xg = cos(glat) * cos(glon), yg = cos(glat) * sin(glon), zg = sin(glat);
+  double xr = m.r2g_m[0][0] * xg + m.r2g_m[0][1] * yg + m.r2g_m[0][2] * zg;
+  double yr = m.r2g_m[1][0] * xg + m.r2g_m[1][1] * yg + m.r2g_m[1][2] * zg;
+  double zr = m.r2g_m[2][0] * xg + m.r2g_m[2][1] * yg + m.r2g_m[2][2] * zg;
+  rlat = asin(zr);
+  if (yr == 0. && xr == 0.) rlon = 0.0; else rlon = atan2(yr, xr);
+}
+
+#define CO(k, n) m.coord[2 * ((n) - 1) + (k) - 1]
+#define EN(j, e) m.elem_nodes[3 * ((e) - 1) + (j) - 1]
+#define ED(j, d) m.edges[2 * ((d) - 1) + (j) - 1]
+#define ET(j, d) m.edge_tri[2 * ((d) - 1) + (j) - 1]
+#define EE(j, e) m.elem_edges[3 * ((e) - 1) + (j) - 1]
+#define ENB(j, e) m.elem_nb[3 * ((e) - 1) + (j) - 1]
+#define NIE(j, n) m.nie[m.maxk * ((n) - 1) + (j) - 1]
+
+void edge_center(const Mesh &m, int n1, int n2, double &x, double &y) {
+  double a1 = CO(1, n1), a2 = CO(2, n1), b1 = CO(1, n2), b2 = CO(2, n2);
+  if (a1 - b1 > m.cyc / 2.0) a1 = a1 - m.cyc;
+  if (a1 - b1 < -m.cyc / 2.0) b1 = b1 - m.cyc;
+  x = 0.5 * (a1 + b1);
+  y = 0.5 * (a2 + b2);
+}
+void elem_center(const Mesh &m, int e, double &x, double &y) {
+  double ax[3];
+  for (int k = 0; k < 3; k++) ax[k] = CO(1, EN(k + 1, e));
+  double amin = std::min(ax[0], std::min(ax[1], ax[2]));
+  for (int k = 0; k < 3; k++) {
+    if (ax[k] - amin >= m.cyc / 2.0) ax[k] = ax[k] - m.cyc;
+    if (ax[k] - amin < -m.cyc / 2.0) ax[k] = ax[k] + m.cyc;
+  }
+  x = (ax[0] + ax[1] + ax[2]) / 3.0;
+  y = (CO(2, EN(1, e)) + CO(2, EN(2, e)) + CO(2, EN(3, e))) / 3.0;
+}
+
+bool load_files(Mesh &m, const std::string &dir) {
+  std::vector<std::string> t;
+  if (!read_all_tokens(dir + "/nod2d.out", t)) return false;
+  m.N2 = atoi(t[0].c_str());
+  m.coord.resize(2 * m.N2);
+  for (int n = 0; n < m.N2; n++) {
+    double lon = atof(t[1 + 4 * n + 1].c_str()), lat = atof(t[1 + 4 * n + 2].c_str());
+    double x = lon * RAD, y = lat * RAD;
+    if (m.o.force_rotation) { double rx = x, ry = y; g2r(m, rx, ry, x, y); }
+    m.coord[2 * n] = x; m.coord[2 * n + 1] = y;
+  }
+  t.clear();
+  if (!read_all_tokens(dir + "/elem2d.out", t)) return false;
+  m.E2 = atoi(t[0].c_str());
+  m.elem_nodes.resize(3 * m.E2);
+  for (int i = 0; i < 3 * m.E2; i++) m.elem_nodes[i] = atoi(t[1 + i].c_str());
+  t.clear();
+  if (!read_all_tokens(dir + "/aux3d.out", t)) return false;
+  m.nl = atoi(t[0].c_str());
+  m.zbar.resize(m.nl);
+  for (int i = 0; i < m.nl; i++) m.zbar[i] = atof(t[1 + i].c_str());
+  if (m.zbar[1] > 0) for (auto &z : m.zbar) z = -z;
+  m.Z.resize(m.nl - 1);
+  for (int i = 0; i < m.nl - 1; i++) { m.Z[i] = m.zbar[i] + m.zbar[i + 1]; m.Z[i] = 0.5 * m.Z[i]; }
+  m.depth.resize(m.N2);
+  for (int n = 0; n < m.N2; n++) {
+    double x = atof(t[1 + m.nl + n].c_str());
+    if (x > 0) x = -x;
+    if (x > m.zbar[4]) x = m.zbar[4];
+    m.depth[n] = x;
+  }
+  t.clear();
+  if (!read_all_tokens(dir + "/edgenum.out", t)) return false;
+  m.D2 = atoi(t[0].c_str()); m.D2in = atoi(t[1].c_str());
+  t.clear();
+  if (!read_all_tokens(dir + "/edges.out", t)) return false;
+  m.edges.resize(2 * m.D2);
+  for (int i = 0; i < 2 * m.D2; i++) m.edges[i] = atoi(t[i].c_str());
+  t.clear();
+  if (!read_all_tokens(dir + "/edge_tri.out", t)) return false;
+  m.edge_tri.resize(2 * m.D2);
+  for (int i = 0; i < 2 * m.D2; i++) { int v = atoi(t[i].c_str()); m.edge_tri[i] = v < 0 ? 0 : v; }
+  t.clear();
+  if (!read_all_tokens(dir + "/elvls.out", t)) return false;
+  m.nlev.resize(m.E2);
+  for (int i = 0; i < m.E2; i++) m.nlev[i] = atoi(t[i].c_str());
+  t.clear();
+  if (!read_all_tokens(dir + "/nlvls.out", t)) return false;
+  m.nlev_n.resize(m.N2);
+  for (int i = 0; i < m.N2; i++) m.nlev_n[i] = atoi(t[i].c_str());
+  m.ulev.assign(m.E2, 1);
+  m.ulev_n.assign(m.N2, 1);
+  return true;
+}
+
+void test_tri(Mesh &m) {
+  for (int e = 1; e <= m.E2; e++) {
+    int n1 = EN(1, e), n2 = EN(2, e), n3 = EN(3, e);
+    double a1 = CO(1, n1), a2 = CO(2, n1);
+    double b1 = CO(1, n2) - a1, b2 = CO(2, n2) - a2, c1 = CO(1, n3) - a1, c2 = CO(2, n3) - a2;
+    trim_cyclic(b1, m.cyc); trim_cyclic(c1, m.cyc);
+    double r = b1 * c2 - b2 * c1;
+    if (r > 0.0) { EN(2, e) = n3; EN(3, e) = n2; }
+  }
+}
+
+void topology(Mesh &m) {
+  // elem_edges (load_edges): edges appended in increasing edge index, then re-ordered so that edge q is opposite node q
+  m.elem_edges.assign(3 * m.E2, 0);
+  ivec aux(m.E2, 0);
+  for (int d = 1; d <= m.D2; d++)
+    for (int k = 1; k <= 2; k++) {
+      int q = ET(k, d);
+      if (q > 0) { aux[q - 1]++; EE(aux[q - 1], q) = d; }
+    }
+  for (int e = 1; e <= m.E2; e++) {
+    int el[3] = {EE(1, e), EE(2, e), EE(3, e)};
+    for (int q = 1; q <= 3; q++)
+      for (int k = 0; k < 3; k++)
+        if (ED(1, el[k]) != EN(q, e) && ED(2, el[k]) != EN(q, e)) { EE(q, e) = el[k]; break; }
+  }
+  m.elem_nb.assign(3 * m.E2, 0);
+  for (int e = 1; e <= m.E2; e++)
+    for (int j = 1; j <= 3; j++) {
+      int e1 = ET(1, EE(j, e));
+      if (e1 == e) e1 = ET(2, EE(j, e));
+      ENB(j, e) = e1;
+    }
+  m.nie_num.assign(m.N2, 0);
+  for (int e = 1; e <= m.E2; e++) for (int j = 1; j <= 3; j++) m.nie_num[EN(j, e) - 1]++;
+  m.maxk = *std::max_element(m.nie_num.begin(), m.nie_num.end());
+  m.nie.assign((size_t)m.maxk * m.N2, 0);
+  std::fill(m.nie_num.begin(), m.nie_num.end(), 0);
+  for (int e = 1; e <= m.E2; e++)
+    for (int j = 1; j <= 3; j++) {
+      int n = EN(j, e);
+      m.nie_num[n - 1]++;
+      NIE(m.nie_num[n - 1], n) = e;
+    }
+  m.nlev_n_min.resize(m.N2); m.ulev_n_max.resize(m.N2);
+  for (int n = 1; n <= m.N2; n++) {
+    int mn = 1 << 30, mx = 0;
+    for (int j = 1; j <= m.nie_num[n - 1]; j++) {
+      mn = std::min(mn, m.nlev[NIE(j, n) - 1]);
+      mx = std::max(mx, m.ulev[NIE(j, n) - 1]);
+    }
+    m.nlev_n_min[n - 1] = mn; m.ulev_n_max[n - 1] = mx;
+  }
+}
+
+void areas(Mesh &m) {
+  int nl = m.nl;
+  m.elem_area.resize(m.E2);
+  for (int e = 1; e <= m.E2; e++) {
+    int n1 = EN(1, e), n2 = EN(2, e), n3 = EN(3, e);
+    double ay = (CO(2, n1) + CO(2, n2) + CO(2, n3)) / 3.0;
+    ay = cos(ay);
+    double a1 = CO(1, n2) - CO(1, n1), a2 = CO(2, n2) - CO(2, n1);
+    double b1 = CO(1, n3) - CO(1, n1), b2 = CO(2, n3) - CO(2, n1);
+    trim_cyclic(a1, m.cyc); trim_cyclic(b1, m.cyc);
+    a1 = a1 * ay; b1 = b1 * ay;
+    m.elem_area[e - 1] = 0.5 * fabs(a1 * b2 - b1 * a2);
+  }
+  m.area.assign((size_t)nl * m.N2, 0.0);
+  for (int n = 1; n <= m.N2; n++)
+    for (int j = 1; j <= m.nie_num[n - 1]; j++) {
+      int e = NIE(j, n);
+      for (int nz = m.ulev[e - 1]; nz <= m.nlev[e - 1] - 1; nz++)
+        m.area[(size_t)nl * (n - 1) + nz - 1] += m.elem_area[e - 1] / 3.0;
+    }
+  m.areasvol.assign((size_t)nl * m.N2, 0.0);
+  for (int n = 1; n <= m.N2; n++)
+    for (int nz = m.ulev_n[n - 1]; nz <= m.nlev_n[n - 1] - 1; nz++)
+      m.areasvol[(size_t)nl * (n - 1) + nz - 1] = m.area[(size_t)nl * (n - 1) + nz - 1];
+  for (auto &a : m.elem_area) a = a * R_EARTH * R_EARTH;
+  for (auto &a : m.area) a = a * R_EARTH * R_EARTH;
+  for (auto &a : m.areasvol) a = a * R_EARTH * R_EARTH;
+  m.area_inv.assign((size_t)nl * m.N2, 0.0);
+  for (int n = 1; n <= m.N2; n++)
+    for (int nz = m.ulev_n[n - 1]; nz <= m.nlev_n[n - 1]; nz++) {
+      double a = m.area[(size_t)nl * (n - 1) + nz - 1];
+      m.area_inv[(size_t)nl * (n - 1) + nz - 1] = a > 0.0 ? 1.0 / a : 0.0;
+    }
+  m.areasvol_inv = m.area_inv;
+  m.resol.resize(m.N2);
+  for (int n = 1; n <= m.N2; n++)
+    m.resol[n - 1] = sqrt(m.areasvol[(size_t)nl * (n - 1) + m.ulev_n[n - 1] - 1] / PI) * 2.0;
+  dvec work(m.N2);
+  for (int q = 0; q < 3; q++) {
+    for (int n = 1; n <= m.N2; n++) {
+      double vol = 0.0; work[n - 1] = 0.0;
+      for (int j = 1; j <= m.nie_num[n - 1]; j++) {
+        int e = NIE(j, n);
+        double s = (m.resol[EN(1, e) - 1] + m.resol[EN(2, e) - 1] + m.resol[EN(3, e) - 1]);
+        work[n - 1] = work[n - 1] + s / 3.0 * m.elem_area[e - 1];
+        vol = vol + m.elem_area[e - 1];
+      }
+      work[n - 1] = work[n - 1] / vol;
+    }
+    m.resol = work;
+  }
+}
+
+void auxiliary(Mesh &m) {
+  m.cori_n.resize(m.N2); m.geo.resize(2 * m.N2);
+  for (int n = 1; n <= m.N2; n++) {
+    double lon, lat;
+    r2g(m, lon, lat, CO(1, n), CO(2, n));
+    m.cori_n[n - 1] = 2 * OMEGA * sin(lat);
+    if (lon > 2.0 * PI) lon = lon - 2.0 * PI;
+    if (lon < -2.0 * PI) lon = lon + 2.0 * PI;
+    m.geo[2 * (n - 1)] = lon; m.geo[2 * (n - 1) + 1] = lat;
+  }
+  m.cori.resize(m.E2); m.elem_cos.resize(m.E2); m.metric.resize(m.E2);
+  dvec cx(m.E2), cy(m.E2);
+  for (int e = 1; e <= m.E2; e++) {
+    double ax, ay, lon, lat;
+    elem_center(m, e, ax, ay);
+    r2g(m, lon, lat, ax, ay);
+    m.cori[e - 1] = 2 * OMEGA * sin(lat);
+    cx[e - 1] = ax; cy[e - 1] = ay;
+    m.elem_cos[e - 1] = cos(ay);
+  }
+  // reference quirk (oce_mesh.F90:2183): the whole metric_factor array is assigned in every iteration,
+  // so every entry ends up tan(center_y(last element))/r_earth
+  { double v = tan(cy[m.E2 - 1]) / R_EARTH; std::fill(m.metric.begin(), m.metric.end(), v); }
+  m.edge_dxdy.resize(2 * m.D2); m.edge_cross.resize(4 * m.D2);
+  for (int d = 1; d <= m.D2; d++) {
+    int n1 = ED(1, d), n2 = ED(2, d);
+    double a1 = CO(1, n2) - CO(1, n1), a2 = CO(2, n2) - CO(2, n1);
+    trim_cyclic(a1, m.cyc);
+    m.edge_dxdy[2 * (d - 1)] = a1; m.edge_dxdy[2 * (d - 1) + 1] = a2;
+    double ex, ey; edge_center(m, n1, n2, ex, ey);
+    for (int i = 0; i < 2; i++) {
+      int el = ET(i + 1, d);
+      if (el > 0) {
+        double b1 = cx[el - 1] - ex, b2 = cy[el - 1] - ey;
+        trim_cyclic(b1, m.cyc);
+        b1 = b1 * m.elem_cos[el - 1];
+        b1 = b1 * R_EARTH; b2 = b2 * R_EARTH;
+        m.edge_cross[4 * (d - 1) + 2 * i] = b1; m.edge_cross[4 * (d - 1) + 2 * i + 1] = b2;
+      } else {
+        m.edge_cross[4 * (d - 1) + 2 * i] = 0.0; m.edge_cross[4 * (d - 1) + 2 * i + 1] = 0.0;
+      }
+    }
+  }
+  m.grad_sca.resize(6 * m.E2); m.grad_vec.resize(6 * m.E2);
+  for (int e = 1; e <= m.E2; e++) {
+    int n1 = EN(1, e), n2 = EN(2, e), n3 = EN(3, e);
+    double dX31 = CO(1, n3) - CO(1, n1); trim_cyclic(dX31, m.cyc); dX31 = m.elem_cos[e - 1] * dX31;
+    double dX21 = CO(1, n2) - CO(1, n1); trim_cyclic(dX21, m.cyc); dX21 = m.elem_cos[e - 1] * dX21;
+    double dY31 = CO(2, n3) - CO(2, n1), dY21 = CO(2, n2) - CO(2, n1);
+    double df = -0.5 * R_EARTH / m.elem_area[e - 1];
+    double *gs = &m.grad_sca[6 * (e - 1)];
+    gs[0] = (-dY31 + dY21) * df; gs[1] = dY31 * df; gs[2] = -dY21 * df;
+    gs[3] = (dX31 - dX21) * df;  gs[4] = -dX31 * df; gs[5] = dX21 * df;
+  }
+  for (int e = 1; e <= m.E2; e++) {
+    double a1 = cx[e - 1], a2 = cy[e - 1], x[3], y[3];
+    for (int j = 1; j <= 3; j++) {
+      int el = ENB(j, e);
+      if (el > 0) {
+        x[j - 1] = cx[el - 1] - a1; trim_cyclic(x[j - 1], m.cyc);
+        y[j - 1] = cy[el - 1] - a2;
+      } else {
+        int d = EE(j, e); double b1, b2;
+        edge_center(m, ED(1, d), ED(2, d), b1, b2);
+        x[j - 1] = (b1 - a1); trim_cyclic(x[j - 1], m.cyc);
+        x[j - 1] = 2 * x[j - 1];
+        y[j - 1] = 2 * (b2 - a2);
+      }
+    }
+    for (int j = 0; j < 3; j++) { x[j] = x[j] * m.elem_cos[e - 1] * R_EARTH; y[j] = y[j] * R_EARTH; }
+    double cxx = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+    double cxy = x[0] * y[0] + x[1] * y[1] + x[2] * y[2];
+    double cyy = y[0] * y[0] + y[1] * y[1] + y[2] * y[2];
+    double dd = cxy * cxy - cxx * cyy;
+    for (int j = 0; j < 3; j++) {
+      m.grad_vec[6 * (e - 1) + j] = (cxy * y[j] - cyy * x[j]) / dd;
+      m.grad_vec[6 * (e - 1) + 3 + j] = (cxy * x[j] - cxx * y[j]) / dd;
+    }
+  }
+}
+
+void ale_init(Mesh &m) {
+  int nl = m.nl;
+  m.zbar_e_bot.assign(m.E2, 0.0); m.bot_e_th.assign(m.E2, 0.0);
+  for (int e = 1; e <= m.E2; e++) {
+    int nle = m.nlev[e - 1];
+    if (m.o.use_partial_cell) {
+      double dd = (m.depth[EN(1, e) - 1] + m.depth[EN(2, e) - 1] + m.depth[EN(3, e) - 1]) / 3.0;
+      if (m.zbar[nle - 2] - m.zbar[nle - 1] <= 0.0 /*partial_cell_thresh*/) {
+        m.zbar_e_bot[e - 1] = m.zbar[nle - 1];
+        m.bot_e_th[e - 1] = m.zbar[nle - 2] - m.zbar_e_bot[e - 1];
+        continue;
+      }
+      if (dd < m.zbar[nle - 1]) {
+        if (nle == nl) m.zbar_e_bot[e - 1] = std::max(dd, m.zbar[nle - 1] + (m.zbar[nle - 1] - m.Z[nle - 2]));
+        else m.zbar_e_bot[e - 1] = std::max(m.Z[nle - 1], dd);
+      } else {
+        m.zbar_e_bot[e - 1] = std::min(m.Z[nle - 2], dd);
+      }
+      m.bot_e_th[e - 1] = m.zbar[nle - 2] - m.zbar_e_bot[e - 1];
+    } else {
+      m.bot_e_th[e - 1] = m.zbar[nle - 2] - m.zbar[nle - 1];
+      m.zbar_e_bot[e - 1] = m.zbar[nle - 1];
+    }
+  }
+  m.zbar_n_bot.assign(m.N2, 0.0); m.bot_n_th.assign(m.N2, 0.0);
+  for (int n = 1; n <= m.N2; n++) {
+    int nln = m.nlev_n[n - 1];
+    if (m.o.use_partial_cell) {
+      double mn = m.zbar_e_bot[NIE(1, n) - 1];
+      for (int j = 2; j <= m.nie_num[n - 1]; j++) mn = std::min(mn, m.zbar_e_bot[NIE(j, n) - 1]);
+      m.zbar_n_bot[n - 1] = mn;
+    } else m.zbar_n_bot[n - 1] = m.zbar[nln - 1];
+    m.bot_n_th[n - 1] = m.zbar[nln - 2] - m.zbar_n_bot[n - 1];
+  }
+  m.zbar_n_srf.assign(m.N2, m.zbar[0]); m.zbar_e_srf.assign(m.E2, m.zbar[0]);
+  m.zbar3.assign((size_t)nl * m.N2, 0.0); m.Z3.assign((size_t)(nl - 1) * m.N2, 0.0);
+  for (int n = 1; n <= m.N2; n++) {
+    double *zb = &m.zbar3[(size_t)nl * (n - 1)] - 1;   // 1-based
+    double *zz = &m.Z3[(size_t)(nl - 1) * (n - 1)] - 1;
+    int nzmin = m.ulev_n[n - 1], nzmax = m.nlev_n[n - 1];
+    for (int k = 1; k <= nzmin - 1; k++) zb[k] = m.zbar[k - 1];
+    zb[nzmin] = m.zbar_n_srf[n - 1];
+    for (int k = nzmin + 1; k <= nzmax - 1; k++) zb[k] = m.zbar[k - 1];
+    zb[nzmax] = m.zbar_n_bot[n - 1];
+    for (int k = 1; k <= nzmin - 1; k++) zz[k] = m.Z[k - 1];
+    zz[nzmin] = zb[nzmin] + (zb[nzmin + 1] - m.zbar_n_srf[n - 1]) / 2;
+    for (int k = nzmin + 1; k <= nzmax - 2; k++) zz[k] = m.Z[k - 1];
+    zz[nzmax - 1] = zb[nzmax - 1] + (m.zbar_n_bot[n - 1] - zb[nzmax - 1]) / 2;
+  }
+  // init_thickness_ale (hbar = hbar_old = 0 at start)
+  m.hbar.assign(m.N2, 0.0); m.hbar_old.assign(m.N2, 0.0); m.dhe.assign(m.E2, 0.0);
+  m.ssh_rhs_old.assign(m.N2, 0.0); m.eta.assign(m.N2, 0.0); m.d_eta.assign(m.N2, 0.0); m.ssh_rhs.assign(m.N2, 0.0);
+  m.hnode.assign((size_t)(nl - 1) * m.N2, 0.0); m.helem.assign((size_t)(nl - 1) * m.E2, 0.0);
+  for (int n = 1; n <= m.N2; n++)
+    m.ssh_rhs_old[n - 1] = (m.hbar[n - 1] - m.hbar_old[n - 1]) * m.areasvol[(size_t)nl * (n - 1) + m.ulev_n[n - 1] - 1] / m.o.dt;
+  for (int n = 1; n <= m.N2; n++) m.eta[n - 1] = m.o.alpha * m.hbar_old[n - 1] + (1.0 - m.o.alpha) * m.hbar[n - 1];
+  for (int n = 1; n <= m.N2; n++) {
+    double *h = &m.hnode[(size_t)(nl - 1) * (n - 1)] - 1;
+    double *zb = &m.zbar3[(size_t)nl * (n - 1)] - 1;
+    int nzmin = m.ulev_n[n - 1], nzmax = m.nlev_n[n - 1] - 1;
+    if (m.o.which_ale == 0) {
+      for (int nz = nzmin; nz <= nzmax - 1; nz++) h[nz] = (zb[nz] - zb[nz + 1]);
+    } else {   // zstar
+      if (nzmin == 1) {
+        int nmin = m.nlev_n_min[n - 1];
+        double dd = m.zbar[nzmin - 1] - m.zbar[nmin - 2];
+        for (int nz = nzmin; nz <= nmin - 2; nz++) h[nz] = (m.zbar[nz - 1] - m.zbar[nz]) * (1.0 + m.hbar[n - 1] / dd);
+        for (int nz = nmin - 1; nz <= nzmax - 1; nz++) h[nz] = (m.zbar[nz - 1] - m.zbar[nz]);
+      } else
+        for (int nz = nzmin; nz <= nzmax - 1; nz++) h[nz] = (zb[nz] - zb[nz + 1]);
+    }
+    h[nzmax] = m.bot_n_th[n - 1];
+  }
+  for (int e = 1; e <= m.E2; e++) {
+    double *he = &m.helem[(size_t)(nl - 1) * (e - 1)] - 1;
+    int nzmin = m.ulev[e - 1], nzmax = m.nlev[e - 1] - 1;
+    int n1 = EN(1, e), n2 = EN(2, e), n3 = EN(3, e);
+    if (m.o.which_ale == 0) {
+      he[nzmin] = (m.zbar_e_srf[e - 1] - m.zbar[nzmin]);
+      for (int nz = nzmin + 1; nz <= nzmax - 1; nz++) he[nz] = (m.zbar[nz - 1] - m.zbar[nz]);
+    } else {
+      m.dhe[e - 1] = (m.hbar[n1 - 1] + m.hbar[n2 - 1] + m.hbar[n3 - 1]) / 3.0;
+      for (int nz = nzmin; nz <= nzmax - 1; nz++)
+        he[nz] = (m.hnode[(size_t)(nl - 1) * (n1 - 1) + nz - 1] + m.hnode[(size_t)(nl - 1) * (n2 - 1) + nz - 1] +
+                  m.hnode[(size_t)(nl - 1) * (n3 - 1) + nz - 1]) / 3.0;
+    }
+    he[nzmax] = m.bot_e_th[e - 1];
+  }
+  m.hnode_new = m.hnode;
+}
+
+void stiff_mat(Mesh &m) {
+  int N = m.N2;
+  ivec n_num(N, 1);
+  std::vector<ivec> n_pos(N);
+  for (int n = 1; n <= N; n++) n_pos[n - 1].push_back(n);
+  for (int d = 1; d <= m.D2; d++) {
+    int n1 = ED(1, d), n2 = ED(2, d);
+    n_pos[n1 - 1].push_back(n2); n_pos[n2 - 1].push_back(n1);
+  }
+  m.rowptr.resize(N + 1); m.rowptr[0] = 1;
+  for (int n = 1; n <= N; n++) m.rowptr[n] = m.rowptr[n - 1] + (int)n_pos[n - 1].size();
+  m.nza = m.rowptr[N] - 1;
+  m.colind.resize(m.nza); m.values.assign(m.nza, 0.0);
+  for (int n = 1; n <= N; n++)
+    for (size_t k = 0; k < n_pos[n - 1].size(); k++) m.colind[m.rowptr[n - 1] - 1 + k] = n_pos[n - 1][k];
+  m.colind_loc = m.colind;
+  ivec pos(N, 0);
+  double factor = G_ACC * m.o.dt * m.o.alpha * m.o.theta;
+  for (int d = 1; d <= m.D2; d++) {
+    for (int i = 1; i <= 2; i++) {
+      int el = ET(i, d);
+      if (el < 1) continue;
+      double fy[3];
+      const double *gs = &m.grad_sca[6 * (el - 1)];
+      double c2i = m.edge_cross[4 * (d - 1) + 2 * i - 1], c2im1 = m.edge_cross[4 * (d - 1) + 2 * i - 2];
+      for (int k = 0; k < 3; k++) fy[k] = (m.zbar_e_bot[el - 1] - m.zbar_e_srf[el - 1]) * (gs[k] * c2i - gs[3 + k] * c2im1);
+      if (i == 2) for (int k = 0; k < 3; k++) fy[k] = -fy[k];
+      for (int j = 1; j <= 2; j++) {
+        int row = ED(j, d);
+        for (int q = m.rowptr[row - 1]; q <= m.rowptr[row] - 1; q++) pos[m.colind[q - 1] - 1] = q;
+        for (int k = 0; k < 3; k++) {
+          int p = pos[EN(k + 1, el) - 1];
+          if (j == 1) m.values[p - 1] = m.values[p - 1] + fy[k] * factor;
+          else m.values[p - 1] = m.values[p - 1] - fy[k] * factor;
+        }
+      }
+    }
+  }
+  for (int row = 1; row <= N; row++) {
+    if (m.ulev_n[row - 1] > 1) continue;
+    int off = m.rowptr[row - 1];
+    m.values[off - 1] = m.values[off - 1] + m.areasvol[(size_t)m.nl * (row - 1) + m.ulev_n[row - 1] - 1] / m.o.dt;
+  }
+}
+
+void updn_tri(Mesh &m) {
+  m.updn.assign(2 * m.D2, 0);
+  for (int d = 1; d <= m.D2; d++) {
+    int en[2] = {ED(1, d), ED(2, d)};
+    double x1 = CO(1, en[1]) - CO(1, en[0]), x2 = CO(2, en[1]) - CO(2, en[0]);
+    if (x1 > m.cyc / 2.0) x1 = x1 - m.cyc;
+    if (x1 < -m.cyc / 2.0) x1 = x1 + m.cyc;
+    for (int side = 0; side < 2; side++) {
+      x1 = -x1; x2 = -x2;            // first node: x=-x ; second node: x=-x again
+      int nd = en[side];
+      for (int k = 1; k <= m.nie_num[nd - 1]; k++) {
+        int e = NIE(k, nd);
+        int p[3] = {EN(1, e), EN(2, e), EN(3, e)};
+        int i0, ib, ic;
+        if (p[0] == nd) { i0 = 0; ib = 1; ic = 2; }
+        else if (p[1] == nd) { i0 = 1; ib = 0; ic = 2; }
+        else { i0 = 2; ib = 0; ic = 1; }
+        double b1 = CO(1, p[ib]) - CO(1, p[i0]), b2 = CO(2, p[ib]) - CO(2, p[i0]);
+        double c1 = CO(1, p[ic]) - CO(1, p[i0]), c2 = CO(2, p[ic]) - CO(2, p[i0]);
+        if (b1 > m.cyc / 2.0) b1 = b1 - m.cyc;
+        if (b1 < -m.cyc / 2.0) b1 = b1 + m.cyc;
+        if (c1 > m.cyc / 2.0) c1 = c1 - m.cyc;
+        if (c1 < -m.cyc / 2.0) c1 = c1 + m.cyc;
+        double cr = c1 * c1 + c2 * c2;
+        double bx = (b1 * c1 + b2 * c2) / cr;
+        double by = (-b1 * c2 + b2 * c1) / cr;
+        double xx = (x1 * c1 + x2 * c2) / cr;
+        double xy = (-x1 * c2 + x2 * c1) / cr;
+        double ab = atan2(by, bx), ax = atan2(xy, xx);
+        bool hit = ((ab > 0.0) && (ax > 0.0) && (ax < ab)) || ((ab < 0.0) && (ax < 0.0) && (ax > ab)) ||
+                   ((ab == ax) || (ax == 0.0));
+        if (hit) m.updn[2 * (d - 1) + side] = e;   // no exit in the reference: the last matching element wins
+      }
+    }
+  }
+}
+
+void fill_desc(Mesh &m) {
+  fesom_mesh_desc &d = m.desc;
+  memset(&d, 0, sizeof(d));
+  d.nod2D = m.N2; d.elem2D = m.E2; d.edge2D = m.D2; d.edge2D_in = m.D2in; d.nl = m.nl;
+  d.myDim_nod2D = m.N2; d.eDim_nod2D = 0; d.myDim_elem2D = m.E2; d.eDim_elem2D = 0; d.eXDim_elem2D = 0;
+  d.myDim_edge2D = m.D2; d.eDim_edge2D = 0; d.max_nod_in_elem = m.maxk; d.ssh_nza = m.nza;
+  m.list_n.resize(m.N2); m.list_e.resize(m.E2); m.list_d.resize(m.D2);
+  for (int i = 0; i < m.N2; i++) m.list_n[i] = i + 1;
+  for (int i = 0; i < m.E2; i++) m.list_e[i] = i + 1;
+  for (int i = 0; i < m.D2; i++) m.list_d[i] = i + 1;
+  d.myList_nod2D = m.list_n.data(); d.myList_elem2D = m.list_e.data(); d.myList_edge2D = m.list_d.data();
+  d.coord_nod2D = m.coord.data(); d.geo_coord_nod2D = m.geo.data();
+  d.elem2D_nodes = m.elem_nodes.data(); d.edges = m.edges.data(); d.edge_tri = m.edge_tri.data();
+  d.elem_edges = m.elem_edges.data(); d.elem_neighbors = m.elem_nb.data();
+  d.nod_in_elem2D = m.nie.data(); d.nod_in_elem2D_num = m.nie_num.data();
+  d.nlevels = m.nlev.data(); d.ulevels = m.ulev.data(); d.nlevels_nod2D = m.nlev_n.data(); d.ulevels_nod2D = m.ulev_n.data();
+  d.nlevels_nod2D_min = m.nlev_n_min.data(); d.ulevels_nod2D_max = m.ulev_n_max.data();
+  d.zbar = m.zbar.data(); d.Z = m.Z.data(); d.depth = m.depth.data();
+  d.elem_area = m.elem_area.data(); d.area = m.area.data(); d.area_inv = m.area_inv.data();
+  d.areasvol = m.areasvol.data(); d.areasvol_inv = m.areasvol_inv.data(); d.mesh_resolution = m.resol.data();
+  d.gradient_sca = m.grad_sca.data(); d.gradient_vec = m.grad_vec.data(); d.edge_dxdy = m.edge_dxdy.data();
+  d.edge_cross_dxdy = m.edge_cross.data(); d.elem_cos = m.elem_cos.data(); d.metric_factor = m.metric.data();
+  d.coriolis = m.cori.data(); d.coriolis_node = m.cori_n.data();
+  d.ssh_rowptr = m.rowptr.data(); d.ssh_colind = m.colind.data(); d.ssh_colind_loc = m.colind_loc.data();
+  d.ssh_values = m.values.data(); d.edge_up_dn_tri = m.updn.data();
+  d.zbar_n_bot = m.zbar_n_bot.data(); d.zbar_n_srf = m.zbar_n_srf.data(); d.bottom_node_thickness = m.bot_n_th.data();
+  d.zbar_e_bot = m.zbar_e_bot.data(); d.zbar_e_srf = m.zbar_e_srf.data(); d.bottom_elem_thickness = m.bot_e_th.data();
+  memset(&m.part, 0, sizeof(m.part));
+  m.part.npes = 1; m.part.mype = 0;
+  m.com_dummy.assign(2, 1);
+  fesom_com_desc *cs[3] = {&m.part.com_nod2D, &m.part.com_elem2D, &m.part.com_elem2D_full};
+  for (auto c : cs) { c->rptr = m.com_dummy.data(); c->sptr = m.com_dummy.data(); }
+}
+}  // namespace
+
+extern "C" {
+
+void *fesom_mesh_load(const char *meshdir, const fesom_mesh_opts *opts) {
+  if (opts->npes != 1) { fprintf(stderr, "fesom_mesh_load: only npes=1 is implemented in the host mesh layer\n"); return nullptr; }
+  if (opts->which_ale != 0 && opts->which_ale != 2) { fprintf(stderr, "fesom_mesh_load: which_ale must be 0 (linfs) or 2 (zstar)\n"); return nullptr; }
+  Mesh *mp = new Mesh();
+  Mesh &m = *mp;
+  m.o = *opts;
+  m.cyc = opts->cyclic_length_deg * RAD;
+  set_rot(m);
+  if (!load_files(m, meshdir)) { fprintf(stderr, "fesom_mesh_load: cannot read mesh files in %s\n", meshdir); delete mp; return nullptr; }
+  test_tri(m);
+  topology(m);
+  areas(m);
+  auxiliary(m);
+  ale_init(m);
+  stiff_mat(m);
+  updn_tri(m);
+  fill_desc(m);
+  return mp;
+}
+
+const fesom_mesh_desc *fesom_mesh_get_desc(void *h) { return &((Mesh *)h)->desc; }
+const fesom_part_desc *fesom_mesh_get_part(void *h) { return &((Mesh *)h)->part; }
+
+const fesom_state_desc *fesom_mesh_get_initial_state(void *h, int ntr) {
+  Mesh &m = *(Mesh *)h;
+  size_t nl = m.nl, N = m.N2, E = m.E2;
+  m.tr.assign((nl - 1) * N * ntr, 0.0); m.tr_old.assign((nl - 1) * N * ntr, 0.0);
+  m.UV.assign(2 * (nl - 1) * E, 0.0); m.UVab.assign(2 * (nl - 1) * E, 0.0);
+  m.W.assign(nl * N, 0.0); m.We.assign(nl * N, 0.0); m.Wi.assign(nl * N, 0.0);
+  m.values_state = m.values;
+  fesom_state_desc &s = m.st;
+  s.tr_arr = m.tr.data(); s.tr_arr_old = m.tr_old.data(); s.UV = m.UV.data(); s.UV_rhsAB = m.UVab.data();
+  s.eta_n = m.eta.data(); s.d_eta = m.d_eta.data(); s.ssh_rhs = m.ssh_rhs.data(); s.ssh_rhs_old = m.ssh_rhs_old.data();
+  s.hbar = m.hbar.data(); s.hbar_old = m.hbar_old.data(); s.dhe = m.dhe.data();
+  s.hnode = m.hnode.data(); s.hnode_new = m.hnode_new.data(); s.helem = m.helem.data();
+  s.zbar_3d_n = m.zbar3.data(); s.Z_3d_n = m.Z3.data();
+  s.Wvel = m.W.data(); s.Wvel_e = m.We.data(); s.Wvel_i = m.Wi.data(); s.ssh_values = m.values_state.data();
+  return &s;
+}
+
+void fesom_mesh_free(void *h) { delete (Mesh *)h; }
+}

@@ -1,0 +1,56 @@
+"""Synthetic initial tracer fields for meshes that have no climatology file.
+
+The reference initialises T/S from NetCDF climatologies (gen_ic3d.F90), which are
+not available offline.  This analytic replacement uses only +,-,*,/ so that it is
+bit-reproducible on every host (no libm): both the reference oracle (through its
+`do_ic3d` stub, oracle/ref/stubs.F90) and this package start from these bits.
+
+    x   = lat_deg/90,  c2 = (1-x^2)^2            (~cos^2(lat))
+    e_H = 1/(1 - z/H)^2                          (z<=0 mid-level depth, decays with depth)
+    T   = 1 + 24*e_700*c2 + 0.5*e_500*w(lon)     w = x_l*(1-x_l^2)*2.598.., x_l = lon_deg/180
+    S   = 34.7 - 0.8*e_400*(2*c2-1)
+"""
+import os
+import numpy as np
+
+
+def read_nod2d(meshdir):
+    with open(os.path.join(meshdir, "nod2d.out")) as f:
+        n = int(f.readline().split()[0])
+        a = np.loadtxt(f, dtype=np.float64, max_rows=n)
+    return a[:, 1].copy(), a[:, 2].copy()   # lon, lat in degrees
+
+
+def read_zbar(meshdir):
+    with open(os.path.join(meshdir, "aux3d.out")) as f:
+        toks = f.read().split()
+    nl = int(toks[0])
+    zbar = np.array([float(t) for t in toks[1:1 + nl]], dtype=np.float64)
+    if zbar[1] > 0:
+        zbar = -zbar
+    return nl, zbar
+
+
+def analytic_ts(meshdir):
+    """Returns T, S as float64 arrays of shape (nod2D, nl-1) (level index fastest in memory)."""
+    lon, lat = read_nod2d(meshdir)
+    nl, zbar = read_zbar(meshdir)
+    Z = 0.5 * (zbar[:-1] + zbar[1:])
+    x = lat / 90.0
+    c2 = (1.0 - x * x) * (1.0 - x * x)
+    lon = np.where(lon > 180.0, lon - 360.0, lon)
+    xl = lon / 180.0
+    w = xl * (1.0 - xl * xl) * 2.598
+    def e(H):
+        q = 1.0 - Z / H
+        return 1.0 / (q * q)
+    T = 1.0 + 24.0 * e(700.0)[None, :] * c2[:, None] + 0.5 * e(500.0)[None, :] * w[:, None]
+    S = 34.7 - 0.8 * e(400.0)[None, :] * (2.0 * c2[:, None] - 1.0)
+    return np.ascontiguousarray(T), np.ascontiguousarray(S)
+
+
+def write_ic_files(meshdir, outdir):
+    T, S = analytic_ts(meshdir)
+    T.tofile(os.path.join(outdir, "ic_T.bin"))
+    S.tofile(os.path.join(outdir, "ic_S.bin"))
+    return T, S

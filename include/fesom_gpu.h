@@ -1,0 +1,183 @@
+/* fesom_gpu.h -- C ABI of the MI355X-native FESOM2 ocean dynamical core.
+ *
+ * Drop-in boundary for the hot path behind `oce_timestep_ale(n, mesh)`
+ * (reference: src/oce_ale.F90:2521-2799, called at src/fvom_main.F90:250).
+ * The reference has no plugin API: its state lives in Fortran module globals
+ * (o_ARRAYS src/oce_modules.F90:221-353, t_mesh src/MOD_MESH.F90:19-95,
+ * g_PARSUP src/gen_modules_partitioning.F90:2-76).  A Fortran caller hands those
+ * arrays over by `c_loc` in the descriptor structs below.
+ *
+ * Conventions (identical to the Fortran side):
+ *   - all reals are IEEE binary64, all integers 32 bit,
+ *   - arrays are column-major with the vertical index fastest: (nz, horiz) or (comp, nz, horiz),
+ *   - connectivity holds 1-based LOCAL indices (0 / <=0 = "none", e.g. edge_tri(2,ed) on boundary edges),
+ *   - node arrays span myDim_nod2D+eDim_nod2D, element arrays myDim_elem2D+eDim_elem2D
+ *     (+eXDim_elem2D where noted), edge arrays myDim_edge2D+eDim_edge2D.
+ * Host arrays stay owned by the caller; the library owns device mirrors.
+ * All entry points return 0 on success, non-zero on error (caller sets pe_status,
+ * src/gen_comm.F90:644-657).  One process <-> one GPU; not re-entrant.
+ */
+#ifndef FESOM_GPU_H
+#define FESOM_GPU_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- mesh + partition description: t_mesh (MOD_MESH.F90:19-95) and myDim/eDim
+ *      (gen_modules_partitioning.F90:30-60) ------------------------------------------- */
+typedef struct fesom_mesh_desc {
+  int nod2D, elem2D, edge2D, edge2D_in, nl;
+  int myDim_nod2D, eDim_nod2D;
+  int myDim_elem2D, eDim_elem2D, eXDim_elem2D;
+  int myDim_edge2D, eDim_edge2D;
+  int max_nod_in_elem;                 /* leading extent of nod_in_elem2D */
+  int ssh_nza;                         /* local number of CSR entries */
+  const int    *myList_nod2D, *myList_elem2D, *myList_edge2D;   /* global ids */
+  const double *coord_nod2D;           /* (2,N)  rotated lon/lat [rad] */
+  const double *geo_coord_nod2D;       /* (2,N)  geographic lon/lat [rad] */
+  const int    *elem2D_nodes;          /* (3,E+eX) */
+  const int    *edges;                 /* (2,D) */
+  const int    *edge_tri;              /* (2,D) second <=0 on boundary edges */
+  const int    *elem_edges;            /* (3,myE) */
+  const int    *elem_neighbors;        /* (3,myE) */
+  const int    *nod_in_elem2D;         /* (max_nod_in_elem,N) */
+  const int    *nod_in_elem2D_num;     /* (N) */
+  const int    *nlevels, *ulevels;     /* (E+eX) */
+  const int    *nlevels_nod2D, *ulevels_nod2D, *nlevels_nod2D_min, *ulevels_nod2D_max; /* (N) */
+  const double *zbar;                  /* (nl)   level interfaces, negative down */
+  const double *Z;                     /* (nl-1) mid-levels */
+  const double *depth;                 /* (N) */
+  const double *elem_area;             /* (E+eX) */
+  const double *area, *area_inv, *areasvol, *areasvol_inv;      /* (nl,N) */
+  const double *mesh_resolution;       /* (N) */
+  const double *gradient_sca;          /* (6,myE) */
+  const double *gradient_vec;          /* (6,myE) */
+  const double *edge_dxdy;             /* (2,D) */
+  const double *edge_cross_dxdy;       /* (4,D) */
+  const double *elem_cos, *metric_factor; /* (E+eX) */
+  const double *coriolis;              /* (myE)  o_ARRAYS */
+  const double *coriolis_node;         /* (N) */
+  const int    *ssh_rowptr;            /* (myN+1) 1-based, global offset as in oce_ale.F90:1297 */
+  const int    *ssh_colind;            /* (nza)  1-based PE-contiguous global columns (oce_ale.F90:1317-1344) */
+  const int    *ssh_colind_loc;        /* (nza)  1-based local columns */
+  const double *ssh_values;            /* (nza)  initial operator (init_stiff_mat_ale) */
+  const int    *edge_up_dn_tri;        /* (2,myD) o_MESH, oce_muscl_adv.F90:124-281 */
+  /* static ALE geometry (oce_ale.F90:82-420) */
+  const double *zbar_n_bot, *zbar_n_srf, *bottom_node_thickness;  /* (N) */
+  const double *zbar_e_bot, *zbar_e_srf;                          /* (myE+eE) */
+  const double *bottom_elem_thickness;                            /* (myE) */
+} fesom_mesh_desc;
+
+/* ---- halo exchange lists: com_struct (gen_modules_partitioning.F90:17-29), files
+ *      dist_N/com_infoNNNNN.out.  Lists hold 1-based local indices, ptr arrays are 1-based CSR. */
+typedef struct fesom_com_desc {
+  int rPEnum, sPEnum;
+  const int *rPE, *rptr, *rlist;
+  const int *sPE, *sptr, *slist;
+} fesom_com_desc;
+
+typedef struct fesom_part_desc {
+  int npes, mype;
+  fesom_com_desc com_nod2D, com_elem2D, com_elem2D_full;
+} fesom_part_desc;
+
+/* ---- namelist scalars the path reads (namelist.config / namelist.oce; defaults
+ *      src/oce_modules.F90:7-190, src/gen_modules_config.F90:8-127) ------------------- */
+typedef struct fesom_params {
+  double dt;                 /* 86400/step_per_day (gen_model_setup.F90:44) */
+  int    which_ale;          /* 0 linfs, 1 zlevel (unsupported), 2 zstar */
+  int    use_partial_cell;
+  int    state_equation;     /* 1 Jackett-McDougall, 0 linear */
+  int    num_tracers;
+  int    mom_adv;            /* 2 (scalar control volumes) */
+  int    visc_option;        /* 5 (easy backscatter) */
+  int    i_vert_visc, i_vert_diff, w_split;
+  int    mix_scheme;         /* 2 = PP ; 0 = constant A_ver/K_ver (no mixing scheme) */
+  int    use_instabmix, use_windmix, windmix_nl;
+  int    toy_soufflet;       /* 1: linear EOS branch of the Soufflet channel (oce_ale_pressure_bv.F90:2992) */
+  double alpha, theta, epsilon;
+  double C_d, A_ver, K_ver, K_hor;
+  double gamma0, gamma1, gamma2, easy_bs_return;
+  double w_max_cfl;
+  double tra_adv_ph, tra_adv_pv;
+  double instabmix_kv, windmix_kv;
+  double cyclic_length;      /* [rad] */
+  int    with_diffusion;     /* 1: run diff_tracers_ale closure (rows f-1 i); 0: advection only */
+} fesom_params;
+
+/* ---- prognostic state = restart set (io_restart.F90:99-155) + ALE thickness arrays -- */
+typedef struct fesom_state_desc {
+  double *tr_arr;        /* (nl-1,N,ntr) */
+  double *tr_arr_old;    /* (nl-1,N,ntr) */
+  double *UV;            /* (2,nl-1,E) */
+  double *UV_rhsAB;      /* (2,nl-1,E) */
+  double *eta_n, *d_eta, *ssh_rhs, *ssh_rhs_old, *hbar, *hbar_old;   /* (N) */
+  double *dhe;           /* (myE) */
+  double *hnode, *hnode_new;   /* (nl-1,N) */
+  double *helem;         /* (nl-1,myE) */
+  double *zbar_3d_n;     /* (nl,N) */
+  double *Z_3d_n;        /* (nl-1,N) */
+  double *Wvel, *Wvel_e, *Wvel_i;  /* (nl,N) */
+  double *ssh_values;    /* (nza) current SSH operator */
+} fesom_state_desc;
+
+/* ---- per-step surface forcing (all optional: NULL = zero) --------------------------- */
+typedef struct fesom_forcing_desc {
+  const double *stress_surf;     /* (2,myE) */
+  const double *heat_flux, *water_flux, *virtual_salt, *relax_salt, *real_salt_flux; /* (N) */
+} fesom_forcing_desc;
+
+/* Lifecycle.  fesom_gpu_init uploads the mesh and allocates every device mirror;
+ * fesom_gpu_upload_state / _download_state move the prognostic set;
+ * fesom_gpu_step(n) is `compute_vel_nodes` + `oce_timestep_ale(n, mesh)`
+ * (fvom_main.F90:216,250) for the configured options. */
+int  fesom_gpu_init(const fesom_mesh_desc *mesh, const fesom_part_desc *part, const fesom_params *par);
+int  fesom_gpu_upload_state(const fesom_state_desc *st);
+int  fesom_gpu_download_state(const fesom_state_desc *st);
+int  fesom_gpu_set_forcing(const fesom_forcing_desc *f);
+int  fesom_gpu_step(int n);
+int  fesom_gpu_run_steps(int n_first, int nsteps);      /* nsteps back-to-back, no host sync in between */
+int  fesom_gpu_finalize(void);
+
+/* Introspection used by the parity tests and bench.py (no reference counterpart):
+ * copy a named device field to the host; run one named routine of the step. */
+int  fesom_gpu_get_field(const char *name, double *out, long long count);
+int  fesom_gpu_set_field(const char *name, const double *in, long long count);
+int  fesom_gpu_call(const char *routine, int arg);
+int  fesom_gpu_last_solver_iterations(void);
+double fesom_gpu_last_solver_residual(void);
+int  fesom_gpu_kernel_time_ms(const char *kernel_group, int nrep, double *ms_per_launch);
+const char *fesom_gpu_last_error(void);
+
+/* SSH solver with the reference's own C signatures (src/psolve.c:16,117,152;
+ * Fortran interface blocks src/oce_ale.F90:2272-2291).  All by reference,
+ * 0-based CSR, part[0..npes] prefix of owned rows.  fcomm is ignored on one GPU. */
+void psolver_init(int *id, int *stype, int *pctype, int *pcilutype, int *ilulevel, int *fillin,
+                  double *droptol, int *maxits, int *restart, double *soltol,
+                  int *part, int *rptr, int *cols, double *vals, int *reuse, int *fcomm);
+void psolve(int *id, double *rhs, double *vals, double *sol, int *newvals);
+void psolver_final(void);
+
+/* ---- host mesh layer (setup, untimed): restates mesh_setup + ocean_setup geometry
+ *      (src/oce_mesh.F90:108-143, src/oce_ale.F90:82-795,1088-1354, src/oce_muscl_adv.F90:124-281)
+ *      for callers that have no Fortran host (tests, bench.py). --------------------------- */
+typedef struct fesom_mesh_opts {
+  int    force_rotation;     /* namelist geometry */
+  double cyclic_length_deg;
+  double alphaEuler_deg, betaEuler_deg, gammaEuler_deg;
+  int    use_partial_cell;
+  int    which_ale;          /* as fesom_params */
+  double dt, alpha, theta, K_hor;
+  int    npes, mype;         /* partition dist_<npes>/ ; npes==1 -> trivial partition, no files needed */
+} fesom_mesh_opts;
+
+void *fesom_mesh_load(const char *meshdir, const fesom_mesh_opts *opts);     /* NULL on error */
+const fesom_mesh_desc *fesom_mesh_get_desc(void *h);
+const fesom_part_desc *fesom_mesh_get_part(void *h);
+const fesom_state_desc *fesom_mesh_get_initial_state(void *h, int num_tracers); /* zeros + ALE thickness init */
+void  fesom_mesh_free(void *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,66 @@
+#!/bin/bash
+# Builds the REAL reference hot path (Fortran + pARMS C, sources compiled where
+# they lie under /root/reference) together with this repo's harness driver and
+# stub modules into oracle/_ref/fesom_oracle.x.  Test infrastructure only.
+# Nothing from /root/reference is copied into the repo; outputs go to oracle/_ref/
+# (git-ignored).  Needs: amdflang (ROCm), gcc, MPICH from /opt/conda.
+set -e
+REF=${REF:-/root/reference}
+HERE=$(cd "$(dirname "$0")" && pwd)
+OUT=$(cd "$HERE/.." && pwd)/_ref
+FC=${FC:-/opt/rocm/bin/amdflang}
+MPI_INC=/opt/conda/include
+MPI_LIB=/opt/conda/lib
+mkdir -p "$OUT/obj" "$OUT/parms_obj"
+if [ ! -d "$REF/src" ]; then
+  echo "build_ref.sh: $REF not present (GPU box?) - keeping prebuilt oracle/_ref as is"; exit 0
+fi
+if [ -x "$OUT/fesom_oracle.x" ] && [ "$OUT/fesom_oracle.x" -nt "$HERE/driver.F90" ] && [ "$OUT/fesom_oracle.x" -nt "$HERE/stubs.F90" ] && [ -z "$FORCE" ]; then
+  echo "build_ref.sh: up to date"; exit 0
+fi
+FFLAGS="-cpp -DPARMS -fdefault-real-8 -O2 -I$MPI_INC -I$REF/src -I$REF/lib/parms/include -module-dir $OUT/obj -I$OUT/obj"
+
+# ---- pARMS (C) ----
+cd "$OUT/parms_obj"
+if [ ! -f "$OUT/libparms.a" ]; then
+  for f in $REF/lib/parms/src/*.c $REF/lib/parms/src/DDPQ/*.c; do
+    b=$(basename $f .c)
+    [ "$(dirname $f)" = "$REF/lib/parms/src/DDPQ" ] && b=ddpq_$b
+    gcc -O2 -w -fPIC -DPARMS -DUSE_MPI -DREAL=double -DDBL -DFORTRAN_UNDERSCORE -DVOID_POINTER_SIZE_8 \
+      -I$REF/lib/parms/include -I$REF/lib/parms/src/include -I$REF/lib/parms/src -I$REF/src -I$MPI_INC \
+      -c $f -o $b.o &
+    while [ $(jobs -r | wc -l) -ge 8 ]; do sleep 0.05; done
+  done
+  wait
+  ar rcs "$OUT/libparms.a" *.o
+fi
+gcc -O2 -w -fPIC -DPARMS -DUSE_MPI -DREAL=double -DDBL -DFORTRAN_UNDERSCORE -DVOID_POINTER_SIZE_8 \
+  -I$REF/lib/parms/include -I$REF/lib/parms/src/include -I$REF/lib/parms/src -I$REF/src -I$MPI_INC \
+  -c $REF/src/psolve.c -o "$OUT/obj/psolve.o"
+
+# ---- Fortran, dependency order ----
+cd "$OUT/obj"
+S=$REF/src
+LIST="$S/oce_modules.F90 $S/MOD_MESH.F90 $S/gen_modules_config.F90 $S/gen_modules_partitioning.F90 $S/gen_modules_clock.F90
+$S/gen_modules_rotate_grid.F90 $S/gen_halo_exchange.F90 $S/ice_modules.F90 $S/gen_modules_forcing.F90 $S/gen_support.F90
+$HERE/stubs.F90
+$S/oce_ale_mixing_kpp.F90 $S/oce_adv_tra_hor.F90 $S/oce_adv_tra_ver.F90 $S/oce_adv_tra_fct.F90 $S/oce_adv_tra_driver.F90
+$S/gen_modules_diag.F90 $S/oce_ale_mixing_pp.F90 $S/oce_tracer_mod.F90
+$S/cvmix_kinds_and_types.F90 $S/cvmix_utils.F90 $S/cvmix_put_get.F90 $S/cvmix_tke.F90 $S/cvmix_idemix.F90
+$S/gen_modules_cvmix_idemix.F90 $S/gen_modules_cvmix_tke.F90 $S/cvmix_math.F90 $S/cvmix_kpp.F90 $S/gen_modules_cvmix_kpp.F90
+$S/cvmix_tidal.F90 $S/gen_modules_cvmix_tidal.F90 $S/cvmix_shear.F90 $S/gen_modules_cvmix_pp.F90
+$S/toy_channel_soufflet.F90 $S/gen_comm.F90 $S/oce_setup_step.F90 $S/oce_mesh.F90 $S/oce_dyn.F90 $S/oce_ale_vel_rhs.F90
+$S/oce_vel_rhs_vinv.F90 $S/oce_ale_pressure_bv.F90 $S/oce_fer_gm.F90 $S/oce_muscl_adv.F90 $S/oce_ale.F90 $S/oce_ale_tracer.F90
+$S/write_step_info.F90 $S/oce_mo_conv.F90 $S/oce_spp.F90 $S/cavity_param.F90
+$HERE/driver.F90"
+OBJS=""
+for f in $LIST; do
+  b=$(basename $f .F90)
+  if [ ! -f $b.o ] || [ $f -nt $b.o ] || [ -n "$FORCE" ]; then
+    echo "FC $b"
+    $FC $FFLAGS -c $f -o $b.o 2> $b.log || { cat $b.log | grep -v warning | head -40; exit 1; }
+  fi
+  OBJS="$OBJS $b.o"
+done
+$FC -O2 -o "$OUT/fesom_oracle.x" $OBJS psolve.o "$OUT/libparms.a" -L$MPI_LIB -lmpifort -lmpi -Wl,-rpath,$MPI_LIB
+echo "built $OUT/fesom_oracle.x"

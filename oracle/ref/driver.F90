@@ -1,0 +1,476 @@
+! Oracle harness driver (own code, NOT reference source).
+!
+! Replaces src/fvom_main.F90 of the reference for the ocean-only hot path:
+! reads the namelists, sets up mesh + ocean exactly through the reference's own
+! routines (mesh_setup, ocean_setup) and then either
+!   mode='step'   : calls the reference's oce_timestep_ale(n,mesh) per step, or
+!   mode='replay' : replays the call sequence of oce_timestep_ale
+!                   (src/oce_ale.F90:2556-2767) routine by routine and dumps
+!                   the fields each routine writes (used as per-routine goldens).
+! Dumps go to <dump_dir>/<tag>.r<rank>.bin in a simple record format read by
+! tests/golden/refdump.py:  name(32 bytes) kind(i4: 8 real, 4 int) ndim(i4) dims(3 x i4) data.
+module oracle_dump
+  use o_PARAM, only: WP
+  implicit none
+  integer :: du = -1
+  interface dump
+     module procedure dump_r1, dump_r2, dump_r3, dump_i1, dump_i2
+  end interface
+contains
+  subroutine dump_open(dir, tag, rank)
+    character(*), intent(in) :: dir, tag
+    integer, intent(in) :: rank
+    character(len=512) :: fn
+    write(fn,'(A,A,A,A,I5.5,A)') trim(dir), '/', trim(tag), '.r', rank, '.bin'
+    open(newunit=du, file=trim(fn), access='stream', form='unformatted', status='replace')
+  end subroutine
+  subroutine dump_close()
+    if (du/=-1) close(du)
+    du=-1
+  end subroutine
+  subroutine hdr(name, kind, ndim, d1, d2, d3)
+    character(*), intent(in) :: name
+    integer, intent(in) :: kind, ndim, d1, d2, d3
+    character(len=32) :: nm
+    nm = name
+    write(du) nm, int(kind,4), int(ndim,4), int(d1,4), int(d2,4), int(d3,4)
+  end subroutine
+  subroutine dump_r1(name, a)
+    character(*), intent(in) :: name
+    real(kind=WP), intent(in) :: a(:)
+    if (du==-1) return
+    call hdr(name, 8, 1, size(a,1), 1, 1)
+    write(du) a
+  end subroutine
+  subroutine dump_r2(name, a)
+    character(*), intent(in) :: name
+    real(kind=WP), intent(in) :: a(:,:)
+    if (du==-1) return
+    call hdr(name, 8, 2, size(a,1), size(a,2), 1)
+    write(du) a
+  end subroutine
+  subroutine dump_r3(name, a)
+    character(*), intent(in) :: name
+    real(kind=WP), intent(in) :: a(:,:,:)
+    if (du==-1) return
+    call hdr(name, 8, 3, size(a,1), size(a,2), size(a,3))
+    write(du) a
+  end subroutine
+  subroutine dump_i1(name, a)
+    character(*), intent(in) :: name
+    integer, intent(in) :: a(:)
+    if (du==-1) return
+    call hdr(name, 4, 1, size(a,1), 1, 1)
+    write(du) a
+  end subroutine
+  subroutine dump_i2(name, a)
+    character(*), intent(in) :: name
+    integer, intent(in) :: a(:,:)
+    if (du==-1) return
+    call hdr(name, 4, 2, size(a,1), size(a,2), 1)
+    write(du) a
+  end subroutine
+end module oracle_dump
+
+program oracle_driver
+  use MOD_MESH
+  use o_ARRAYS
+  use o_MESH
+  use o_PARAM
+  use g_PARSUP
+  use g_config
+  use g_comm_auto
+  use g_forcing_param
+  use g_forcing_arrays
+  use i_ARRAYS
+  use g_ic3d
+  use g_clock, only: timenew, daynew, yearnew
+  use diagnostics, only: diag_list
+  use Toy_Channel_Soufflet
+  use o_mixing_KPP_mod
+  use o_tracers
+  use oracle_dump
+  implicit none
+
+  type(t_mesh), target, save :: mesh
+  integer :: n, provided, ierr, nsteps, i, k, u
+  character(len=16) :: mode
+  character(len=256) :: dump_dir
+  integer :: dump_steps(64), ndump
+  logical :: dump_mesh, do_mean, debug
+  real(kind=WP) :: t0, t1, tloop
+  character(len=64) :: tag
+  namelist /clockinit/ timenew, daynew, yearnew
+  namelist /oracle/ nsteps, mode, dump_dir, dump_steps, dump_mesh, do_mean, debug
+  ! running sums for the fcheck-style known answer (setups/test_souf/setup.yml:82-88)
+  real(kind=WP), allocatable :: mT(:,:), mS(:,:), mU(:,:), mV(:,:)
+
+  call MPI_INIT_THREAD(MPI_THREAD_MULTIPLE, provided, ierr)
+  call par_init
+
+  ! ---- namelists (same groups / order as gen_model_setup.F90:28-79) ----
+  open (20,file='namelist.config')
+  read (20,NML=modelname)
+  read (20,NML=timestep)
+  read (20,NML=clockinit)
+  read (20,NML=paths)
+  read (20,NML=restart_log)
+  read (20,NML=ale_def)
+  read (20,NML=geometry)
+  read (20,NML=calendar)
+  read (20,NML=run_config)
+  close (20)
+  dt=86400._WP/real(step_per_day,WP)
+  cyclic_length=cyclic_length*rad
+  alphaEuler=alphaEuler*rad
+  betaEuler=betaEuler*rad
+  gammaEuler=gammaEuler*rad
+  open (20,file='namelist.oce')
+  read (20,NML=oce_dyn)
+  read (20,NML=oce_tra)
+  read (20,NML=oce_init3d)
+  close (20)
+  nsteps=1; mode='step'; dump_dir='dumps'; dump_steps=-1; dump_mesh=.false.; do_mean=.false.; debug=.false.
+  open (20,file='namelist.oracle')
+  read (20,NML=oracle)
+  close (20)
+  r_restart=.false.
+  mstep=0
+
+  call mesh_setup(mesh)
+  call check_mesh_consistency(mesh)
+  call ocean_setup(mesh)
+  ! ice loading and atmospheric pressure arrays are read by compute_vel_rhs (ice_modules / forcing arrays)
+  if (.not. allocated(press_air)) then
+     allocate(press_air(myDim_nod2D+eDim_nod2D)); press_air=0.0_WP
+  end if
+
+  if (dump_mesh) call dump_setup()
+
+  if (do_mean) then
+     allocate(mT(mesh%nl-1,myDim_nod2D), mS(mesh%nl-1,myDim_nod2D))
+     allocate(mU(mesh%nl-1,myDim_elem2D), mV(mesh%nl-1,myDim_elem2D))
+     mT=0; mS=0; mU=0; mV=0
+  end if
+
+  call MPI_BARRIER(MPI_COMM_FESOM, ierr)
+  tloop=0.0_WP
+  do n=1, nsteps
+     mstep=n
+     t0=MPI_Wtime()
+     if (trim(mode)=='step') then
+        call compute_vel_nodes(mesh)
+        call before_oce_step(mesh)
+        call oce_timestep_ale(n, mesh)
+        if (any(dump_steps==n)) then
+           write(tag,'(A,I4.4)') 'state', n
+           call dump_open(trim(dump_dir), trim(tag), mype)
+           call dump_state()
+           call dump_close()
+        end if
+     else
+        call replay_step(n, any(dump_steps==n))
+     end if
+     t1=MPI_Wtime()
+     tloop=tloop+(t1-t0)
+     if (do_mean) then
+        mT=mT+tr_arr(:,1:myDim_nod2D,1); mS=mS+tr_arr(:,1:myDim_nod2D,2)
+        mU=mU+UV(1,:,1:myDim_elem2D);    mV=mV+UV(2,:,1:myDim_elem2D)
+     end if
+  end do
+  call MPI_BARRIER(MPI_COMM_FESOM, ierr)
+  if (mype==0) then
+     write(*,'(A,I6,A,ES14.6,A,ES14.6)') 'ORACLE_TIMING steps=', nsteps, ' total_s=', tloop, ' s_per_step=', tloop/max(nsteps,1)
+     write(*,'(A,7ES12.4)') 'ORACLE_PHASES mixpres,dyn,dynssh,solvessh,GM,tra,tot =', rtime_oce_mixpres, rtime_oce_dyn, &
+          rtime_oce_dynssh, rtime_oce_solvessh, rtime_oce_GMRedi, rtime_oce_solvetra, rtime_oce
+  end if
+  if (do_mean) call report_means()
+  call par_ex
+
+contains
+
+  subroutine dump_setup()
+    call dump_open(trim(dump_dir), 'setup', mype)
+    call dump('dims', (/ mesh%nod2D, mesh%elem2D, mesh%edge2D, mesh%edge2D_in, mesh%nl, myDim_nod2D, eDim_nod2D, &
+         myDim_elem2D, eDim_elem2D, eXDim_elem2D, myDim_edge2D, eDim_edge2D /))
+    call dump('myList_nod2D', myList_nod2D)
+    call dump('myList_elem2D', myList_elem2D)
+    call dump('myList_edge2D', myList_edge2D)
+    call dump('coord_nod2D', mesh%coord_nod2D)
+    call dump('geo_coord_nod2D', mesh%geo_coord_nod2D)
+    call dump('elem2D_nodes', mesh%elem2D_nodes)
+    call dump('edges', mesh%edges)
+    call dump('edge_tri', mesh%edge_tri)
+    call dump('elem_edges', mesh%elem_edges)
+    call dump('elem_area', mesh%elem_area)
+    call dump('edge_dxdy', mesh%edge_dxdy)
+    call dump('edge_cross_dxdy', mesh%edge_cross_dxdy)
+    call dump('elem_cos', mesh%elem_cos)
+    call dump('metric_factor', mesh%metric_factor)
+    call dump('elem_neighbors', mesh%elem_neighbors)
+    call dump('nod_in_elem2D', mesh%nod_in_elem2D)
+    call dump('nod_in_elem2D_num', mesh%nod_in_elem2D_num)
+    call dump('depth', mesh%depth)
+    call dump('gradient_vec', mesh%gradient_vec)
+    call dump('gradient_sca', mesh%gradient_sca)
+    call dump('zbar', mesh%zbar)
+    call dump('Z', mesh%Z)
+    call dump('ulevels', mesh%ulevels)
+    call dump('ulevels_nod2D', mesh%ulevels_nod2D)
+    call dump('ulevels_nod2D_max', mesh%ulevels_nod2D_max)
+    call dump('nlevels', mesh%nlevels)
+    call dump('nlevels_nod2D', mesh%nlevels_nod2D)
+    call dump('nlevels_nod2D_min', mesh%nlevels_nod2D_min)
+    call dump('area', mesh%area)
+    call dump('area_inv', mesh%area_inv)
+    call dump('areasvol', mesh%areasvol)
+    call dump('areasvol_inv', mesh%areasvol_inv)
+    call dump('mesh_resolution', mesh%mesh_resolution)
+    call dump('ssh_rowptr', mesh%ssh_stiff%rowptr)
+    call dump('ssh_colind', mesh%ssh_stiff%colind)
+    call dump('ssh_values', mesh%ssh_stiff%values)
+    call dump('coriolis', coriolis)
+    call dump('coriolis_node', coriolis_node)
+    call dump('edge_up_dn_tri', edge_up_dn_tri)
+    call dump('nboundary_lay', nboundary_lay)
+    call dump('bottom_elem_thickness', bottom_elem_thickness)
+    call dump('bottom_node_thickness', bottom_node_thickness)
+    call dump('zbar_n_bot', zbar_n_bot)
+    call dump('zbar_e_bot', zbar_e_bot)
+    call dump('zbar_n_srf', zbar_n_srf)
+    call dump('zbar_e_srf', zbar_e_srf)
+    call dump('Ki', Ki)
+    call dump('density_ref', density_ref)
+    call dump_state()
+    call dump_close()
+  end subroutine dump_setup
+
+  ! prognostic + ALE state (= restart set, io_restart.F90:99-155, plus thickness arrays)
+  subroutine dump_state()
+    call dump('tr_arr', tr_arr)
+    call dump('tr_arr_old', tr_arr_old)
+    call dump('UV', UV)
+    call dump('UV_rhs', UV_rhs)
+    call dump('UV_rhsAB', UV_rhsAB)
+    call dump('eta_n', eta_n)
+    call dump('d_eta', d_eta)
+    call dump('ssh_rhs', ssh_rhs)
+    call dump('ssh_rhs_old', ssh_rhs_old)
+    call dump('hbar', hbar)
+    call dump('hbar_old', hbar_old)
+    call dump('dhe', dhe)
+    call dump('hnode', hnode)
+    call dump('hnode_new', hnode_new)
+    call dump('helem', helem)
+    call dump('zbar_3d_n', zbar_3d_n)
+    call dump('Z_3d_n', Z_3d_n)
+    call dump('Wvel', Wvel)
+    call dump('Wvel_e', Wvel_e)
+    call dump('Wvel_i', Wvel_i)
+    call dump('Av', Av)
+    call dump('Kv', Kv)
+    call dump('ssh_values', mesh%ssh_stiff%values)
+  end subroutine dump_state
+
+  ! Replays src/oce_ale.F90:2556-2767 (+ fvom_main.F90:216,245) with dumps.
+  subroutine replay_step(n, dmp)
+    integer, intent(in) :: n
+    logical, intent(in) :: dmp
+    integer :: tr_num, node, nzmax, nzmin
+    character(len=8) :: tn
+    if (dmp) then
+       write(tag,'(A,I4.4)') 'replay', n
+       call dump_open(trim(dump_dir), trim(tag), mype)
+       call dump('in.tr_arr', tr_arr); call dump('in.tr_arr_old', tr_arr_old)
+       call dump('in.UV', UV); call dump('in.UV_rhsAB', UV_rhsAB); call dump('in.eta_n', eta_n)
+       call dump('in.d_eta', d_eta); call dump('in.hnode', hnode); call dump('in.helem', helem)
+       call dump('in.hbar', hbar); call dump('in.hbar_old', hbar_old); call dump('in.ssh_rhs_old', ssh_rhs_old)
+       call dump('in.dhe', dhe); call dump('in.Wvel', Wvel); call dump('in.Wvel_e', Wvel_e); call dump('in.Wvel_i', Wvel_i)
+       call dump('in.zbar_3d_n', zbar_3d_n); call dump('in.Z_3d_n', Z_3d_n)
+       call dump('in.ssh_values', mesh%ssh_stiff%values)
+    end if
+    call mark('compute_vel_nodes')
+    call compute_vel_nodes(mesh)
+    call dump('compute_vel_nodes.Unode', Unode)
+    call mark('before_oce_step')
+    call before_oce_step(mesh)
+    call mark('pressure_bv')
+    call pressure_bv(mesh)
+    call dump('pressure_bv.density_m_rho0', density_m_rho0)
+    call dump('pressure_bv.bvfreq', bvfreq)
+    call dump('pressure_bv.hpressure', hpressure)
+    call dump('pressure_bv.MLD1', MLD1); call dump('pressure_bv.MLD2', MLD2)
+    if (trim(which_ale)=='linfs') then
+       call mark('pressure_force_4_linfs')
+       call pressure_force_4_linfs(mesh)
+    else
+       call mark('pressure_force_4_zxxxx')
+       call pressure_force_4_zxxxx(mesh)
+    end if
+    call dump('pressure_force.pgf_x', pgf_x); call dump('pressure_force.pgf_y', pgf_y)
+    call mark('sw_alpha_beta')
+    call sw_alpha_beta(tr_arr(:,:,1),tr_arr(:,:,2), mesh)
+    call dump('sw_alpha_beta.sw_alpha', sw_alpha); call dump('sw_alpha_beta.sw_beta', sw_beta)
+    call mark('compute_sigma_xy')
+    call compute_sigma_xy(tr_arr(:,:,1),tr_arr(:,:,2), mesh)
+    call dump('compute_sigma_xy.sigma_xy', sigma_xy)
+    call mark('compute_neutral_slope')
+    call compute_neutral_slope(mesh)
+    call dump('compute_neutral_slope.neutral_slope', neutral_slope)
+    call dump('compute_neutral_slope.slope_tapered', slope_tapered)
+    call status_check
+    if (mix_scheme_nmb==1 .or. mix_scheme_nmb==17) then
+       call mark('oce_mixing_KPP')
+       call oce_mixing_KPP(Av, Kv_double, mesh)
+       Kv=Kv_double(:,:,1)
+       call mark('mo_convect')
+       call mo_convect(mesh)
+    else if (mix_scheme_nmb==2 .or. mix_scheme_nmb==27) then
+       call mark('oce_mixing_PP')
+       call oce_mixing_PP(mesh)
+       call dump('oce_mixing_PP.Av', Av); call dump('oce_mixing_PP.Kv', Kv)
+       call mark('mo_convect')
+       call mo_convect(mesh)
+    end if
+    call dump('mixing.Av', Av); call dump('mixing.Kv', Kv)
+    if (mom_adv/=3) then
+       call mark('compute_vel_rhs')
+       call compute_vel_rhs(mesh)
+    else
+       call mark('compute_vel_rhs_vinv')
+       call compute_vel_rhs_vinv(mesh)
+    end if
+    call dump('compute_vel_rhs.UV_rhs', UV_rhs); call dump('compute_vel_rhs.UV_rhsAB', UV_rhsAB)
+    call mark('viscosity_filter')
+    call viscosity_filter(visc_option, mesh)
+    call dump('viscosity_filter.UV_rhs', UV_rhs)
+    call mark('impl_vert_visc_ale')
+    if (i_vert_visc) call impl_vert_visc_ale(mesh)
+    call dump('impl_vert_visc_ale.UV_rhs', UV_rhs)
+    call mark('update_stiff_mat_ale')
+    if (.not. trim(which_ale)=='linfs') call update_stiff_mat_ale(mesh)
+    call dump('update_stiff_mat_ale.values', mesh%ssh_stiff%values)
+    call mark('compute_ssh_rhs_ale')
+    call compute_ssh_rhs_ale(mesh)
+    call dump('compute_ssh_rhs_ale.ssh_rhs', ssh_rhs)
+    call mark('solve_ssh_ale')
+    call solve_ssh_ale(mesh)
+    call dump('solve_ssh_ale.d_eta', d_eta)
+    if ((toy_ocean) .AND. (TRIM(which_toy)=="soufflet")) then
+       call mark('relax_zonal_vel')
+       call relax_zonal_vel(mesh)
+       call dump('relax_zonal_vel.UV_rhs', UV_rhs)
+    end if
+    call mark('update_vel')
+    call update_vel(mesh)
+    call dump('update_vel.UV', UV); call dump('update_vel.eta_n', eta_n)
+    call mark('compute_hbar_ale')
+    call compute_hbar_ale(mesh)
+    call dump('compute_hbar_ale.hbar', hbar); call dump('compute_hbar_ale.hbar_old', hbar_old)
+    call dump('compute_hbar_ale.ssh_rhs_old', ssh_rhs_old); call dump('compute_hbar_ale.dhe', dhe)
+    where(mesh%ulevels_nod2D==1) eta_n=alpha*hbar+(1.0_WP-alpha)*hbar_old
+    call dump('eta_n_update.eta_n', eta_n)
+    call mark('init_Redi_GM')
+    if (Fer_GM .or. Redi) call init_Redi_GM(mesh)
+    if (Fer_GM) then
+       call mark('fer_solve_Gamma')
+       call fer_solve_Gamma(mesh)
+       call mark('fer_gamma2vel')
+       call fer_gamma2vel(mesh)
+    end if
+    call mark('vert_vel_ale')
+    call vert_vel_ale(mesh)
+    call dump('vert_vel_ale.Wvel', Wvel); call dump('vert_vel_ale.Wvel_e', Wvel_e); call dump('vert_vel_ale.Wvel_i', Wvel_i)
+    call dump('vert_vel_ale.hnode_new', hnode_new); call dump('vert_vel_ale.CFL_z', CFL_z)
+
+    ! ---- solve_tracers_ale replayed (src/oce_ale_tracer.F90:101-199) ----
+    if (Fer_GM) then
+       UV    =UV    +fer_UV
+       Wvel_e=Wvel_e+fer_Wvel
+       Wvel  =Wvel  +fer_Wvel
+    end if
+    do tr_num=1,num_tracers
+       write(tn,'(A,I1,A)') 'tr', tr_num, '.'
+       call mark('init_tracers_AB')
+       call init_tracers_AB(tr_num, mesh)
+       call dump(trim(tn)//'init_AB.tr_arr_old', tr_arr_old(:,:,tr_num))
+       call dump(trim(tn)//'init_AB.tr_xy', tr_xy)
+       call dump(trim(tn)//'init_AB.tr_z', tr_z)
+       call dump(trim(tn)//'init_AB.edge_up_dn_grad', edge_up_dn_grad)
+       call mark('adv_tracers_ale')
+       call adv_tracers_ale(tr_num, mesh)
+       call dump(trim(tn)//'adv.fct_LO', fct_LO)
+       call dump(trim(tn)//'adv.adv_flux_hor', adv_flux_hor)
+       call dump(trim(tn)//'adv.adv_flux_ver', adv_flux_ver)
+       call dump(trim(tn)//'adv.fct_ttf_max', fct_ttf_max)
+       call dump(trim(tn)//'adv.fct_ttf_min', fct_ttf_min)
+       call dump(trim(tn)//'adv.fct_plus', fct_plus)
+       call dump(trim(tn)//'adv.fct_minus', fct_minus)
+       call dump(trim(tn)//'adv.del_ttf_advhoriz', del_ttf_advhoriz)
+       call dump(trim(tn)//'adv.del_ttf_advvert', del_ttf_advvert)
+       call dump(trim(tn)//'adv.del_ttf', del_ttf)
+       call mark('diff_tracers_ale')
+       call diff_tracers_ale(tr_num, mesh)
+       call dump(trim(tn)//'diff.del_ttf', del_ttf)
+       call dump(trim(tn)//'diff.tr_arr', tr_arr(:,:,tr_num))
+       if ((toy_ocean) .AND. (TRIM(which_toy)=="soufflet")) then
+          call mark('relax_zonal_temp')
+          call relax_zonal_temp(mesh)
+       else
+          call mark('relax_to_clim')
+          call relax_to_clim(tr_num, mesh)
+       end if
+       call exchange_nod(tr_arr(:,:,tr_num))
+       call dump(trim(tn)//'end.tr_arr', tr_arr(:,:,tr_num))
+    end do
+    if (Fer_GM) then
+       UV    =UV    -fer_UV
+       Wvel_e=Wvel_e-fer_Wvel
+       Wvel  =Wvel  -fer_Wvel
+    end if
+    do node=1,myDim_nod2D+eDim_nod2D
+       nzmax=mesh%nlevels_nod2D(node)-1
+       nzmin=mesh%ulevels_nod2D(node)
+       where (tr_arr(nzmin:nzmax,node,2) > 45._WP) tr_arr(nzmin:nzmax,node,2)=45._WP
+       where (tr_arr(nzmin:nzmax,node,2) < 3._WP ) tr_arr(nzmin:nzmax,node,2)=3._WP
+    end do
+    call mark('update_thickness_ale')
+    call update_thickness_ale(mesh)
+    call dump('update_thickness_ale.hnode', hnode); call dump('update_thickness_ale.helem', helem)
+    call dump('update_thickness_ale.zbar_3d_n', zbar_3d_n); call dump('update_thickness_ale.Z_3d_n', Z_3d_n)
+    call dump('out.tr_arr', tr_arr); call dump('out.UV', UV); call dump('out.eta_n', eta_n)
+    if (dmp) call dump_close()
+  end subroutine replay_step
+
+  subroutine mark(msg)
+    character(*), intent(in) :: msg
+    if (debug) then
+       write(0,*) 'MARK ', mype, msg
+       flush(0)
+    end if
+  end subroutine mark
+
+  ! fcheck-style means: unweighted mean over (level x entity) of the time mean (SURVEY.md section 4)
+  subroutine report_means()
+    real(kind=WP) :: loc(10), glo(10)
+    integer :: nlm1
+    nlm1 = mesh%nl-1
+    loc=0
+    loc(1)=sum(mT)/nsteps; loc(2)=sum(mS)/nsteps; loc(3)=real(nlm1,WP)*myDim_nod2D
+    loc(4)=sum(mT(1,:))/nsteps; loc(5)=real(myDim_nod2D,WP)
+    ! each element once: count elements whose first node is owned
+    do i=1,myDim_elem2D
+       if (mesh%elem2D_nodes(1,i)<=myDim_nod2D) then
+          loc(6)=loc(6)+sum(mU(:,i))/nsteps; loc(7)=loc(7)+sum(mV(:,i))/nsteps; loc(8)=loc(8)+real(nlm1,WP)
+       end if
+    end do
+    call MPI_AllREDUCE(loc, glo, 10, MPI_DOUBLE_PRECISION, MPI_SUM, MPI_COMM_FESOM, ierr)
+    if (mype==0) then
+       write(*,'(A,ES24.16)') 'ORACLE_MEAN temp ', glo(1)/glo(3)
+       write(*,'(A,ES24.16)') 'ORACLE_MEAN salt ', glo(2)/glo(3)
+       write(*,'(A,ES24.16)') 'ORACLE_MEAN sst  ', glo(4)/glo(5)
+       write(*,'(A,ES24.16)') 'ORACLE_MEAN u    ', glo(6)/glo(8)
+       write(*,'(A,ES24.16)') 'ORACLE_MEAN v    ', glo(7)/glo(8)
+    end if
+  end subroutine report_means
+end program oracle_driver

@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Run the reference oracle binary (oracle/_ref/fesom_oracle.x) on a named configuration.
+
+Test infrastructure only.  Writes namelists (values = the reference's
+config/namelist.config + config/namelist.oce defaults with the overrides of
+setups/test_souf/setup.yml:9-49 where noted), initial-condition files and a
+1-rank partition if needed into oracle/_ref/run_<cfg>_<np>/ and starts
+mpiexec.  Usage: run_ref.py CFG NP NSTEPS [mode=step|replay] [dump=1,2,..] [mean]
+"""
+import os, sys, subprocess, shutil
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, REPO)
+OUT = os.path.join(REPO, "oracle", "_ref")
+MESHES = os.path.join(REPO, "tests", "golden", "meshes")
+
+CONFIG_TMPL = """&modelname
+runid='fesom'
+/
+&timestep
+step_per_day={step_per_day}
+run_length=1
+run_length_unit='d'
+/
+&clockinit
+timenew=0.0
+daynew=1
+yearnew=1958
+/
+&paths
+MeshPath='{meshpath}/'
+ClimateDataPath='./'
+ResultPath='./'
+/
+&restart_log
+restart_length=1
+restart_length_unit='y'
+logfile_outfreq=100000
+/
+&ale_def
+which_ALE='{which_ale}'
+use_partial_cell={use_partial_cell}
+/
+&geometry
+cartesian=.false.
+fplane=.false.
+cyclic_length={cyclic_length}
+rotated_grid={rotated_grid}
+force_rotation={force_rotation}
+alphaEuler=50.
+betaEuler=15.
+gammaEuler=-90.
+/
+&calendar
+include_fleapyear=.false.
+/
+&run_config
+use_ice=.false.
+use_cavity=.false.
+use_cavity_partial_cell=.false.
+use_floatice=.false.
+use_sw_pene=.false.
+toy_ocean={toy_ocean}
+which_toy='soufflet'
+flag_warn_cflz=.false.
+/
+"""
+
+OCE_TMPL = """&oce_dyn
+state_equation={state_equation}
+C_d=0.0025
+gamma0=0.003
+gamma1=0.1
+gamma2=0.285
+Div_c=.5
+Leith_c=.05
+visc_option=5
+easy_bs_return=1.5
+A_ver=1.e-4
+scale_area=5.8e9
+mom_adv=2
+free_slip=.false.
+i_vert_visc=.true.
+w_split=.false.
+w_max_cfl=1.0
+SPP=.false.
+Fer_GM={fer_gm}
+K_GM_max=2000.0
+K_GM_min=2.0
+K_GM_bvref=2
+K_GM_rampmax=-1.0
+K_GM_rampmin=-1.0
+K_GM_resscalorder=1
+scaling_Ferreira=.false.
+scaling_Rossby=.false.
+scaling_resolution=.true.
+scaling_FESOM14=.false.
+Redi={redi}
+visc_sh_limit=5.0e-3
+mix_scheme='{mix_scheme}'
+Ricr=0.3
+concv=1.6
+/
+&oce_tra
+use_momix=.false.
+momix_lat=-50.0
+momix_kv=0.01
+use_instabmix=.true.
+instabmix_kv=0.1
+use_windmix=.false.
+windmix_kv=1.e-3
+windmix_nl=2
+smooth_bh_tra=.false.
+gamma0_tra=0.0005
+gamma1_tra=0.0125
+gamma2_tra=0.
+diff_sh_limit=5.0e-3
+Kv0_const=.true.
+double_diffusion=.false.
+K_ver=1.0e-5
+K_hor={k_hor}
+surf_relax_T=0.0
+surf_relax_S={surf_relax_s}
+balance_salt_water={balance_salt_water}
+clim_relax=0.0
+ref_sss_local=.true.
+ref_sss=34.
+i_vert_diff=.true.
+tra_adv_hor='MFCT'
+tra_adv_ver='QR4C'
+tra_adv_lim='FCT'
+tra_adv_ph=1.
+tra_adv_pv=1.
+num_tracers=2
+tracer_ID=0,1
+/
+&oce_init3d
+n_ic3d=2
+idlist=1,0
+filelist='ic_S.bin','ic_T.bin'
+varlist='salt','temp'
+t_insitu=.false.
+/
+"""
+
+CFGS = {
+    # pi mesh, 47 layers, zstar + partial cells, JM EOS, PP mixing, no GM/Redi (round-1 closure config)
+    "pi_pp": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                  rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                  fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                  balance_salt_water=".true."),
+    # pi mesh with the reference's default physics (KPP + GM + Redi)
+    "pi_default": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                       rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                       fer_gm=".true.", redi=".true.", mix_scheme="KPP", k_hor="3000.", surf_relax_s="1.929e-06",
+                       balance_salt_water=".true."),
+    # Soufflet channel = setups/test_souf/setup.yml overrides
+    "souf": dict(mesh="soufflet", step_per_day=72, which_ale="zstar", use_partial_cell=".true.", cyclic_length=4.5,
+                 rotated_grid=".false.", force_rotation=".false.", toy_ocean=".true.", state_equation=0,
+                 fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="10", surf_relax_s="0.0",
+                 balance_salt_water=".false."),
+    "souf_linfs": dict(mesh="soufflet", step_per_day=72, which_ale="linfs", use_partial_cell=".false.", cyclic_length=4.5,
+                       rotated_grid=".false.", force_rotation=".false.", toy_ocean=".true.", state_equation=0,
+                       fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="10", surf_relax_s="0.0",
+                       balance_salt_water=".false."),
+}
+
+
+def prepare(cfg, np_):
+    c = CFGS[cfg]
+    rd = os.path.join(OUT, f"run_{cfg}_{np_}")
+    os.makedirs(os.path.join(rd, "dumps"), exist_ok=True)
+    meshdir = os.path.join(MESHES, c["mesh"])
+    if np_ == 1 and not os.path.isdir(os.path.join(meshdir, "dist_1")):
+        from oracle.ref.make_dist1 import make_dist1
+        make_dist1(meshdir)
+    open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **c))
+    open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**c))
+    if c["toy_ocean"] == ".false.":
+        from fesom2_amd.synthetic import write_ic_files
+        write_ic_files(meshdir, rd)
+    return rd
+
+
+def run(cfg, np_, nsteps, mode="step", dump=(), mean=False, dump_mesh=True, quiet=True):
+    rd = prepare(cfg, np_)
+    ds = ",".join(str(d) for d in dump) if dump else "-1"
+    open(os.path.join(rd, "namelist.oracle"), "w").write(
+        f"&oracle\nnsteps={nsteps}\nmode='{mode}'\ndump_dir='dumps'\ndump_steps={ds}\n"
+        f"dump_mesh={'.true.' if dump_mesh else '.false.'}\ndo_mean={'.true.' if mean else '.false.'}\n/\n")
+    exe = os.path.join(OUT, "fesom_oracle.x")
+    cmd = ["/opt/conda/bin/mpiexec", "-n", str(np_), exe]
+    r = subprocess.run(cmd, cwd=rd, capture_output=True, text=True)
+    open(os.path.join(rd, "stdout.log"), "w").write(r.stdout + "\n--- stderr ---\n" + r.stderr)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("ORACLE") or "ERROR" in l]
+    if not quiet or r.returncode != 0:
+        print(r.stdout[-3000:]); print(r.stderr[-2000:])
+    return rd, r.returncode, lines
+
+
+if __name__ == "__main__":
+    cfg, np_, nsteps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    mode, dump, mean = "step", (), False
+    for a in sys.argv[4:]:
+        if a.startswith("mode="): mode = a[5:]
+        elif a.startswith("dump="): dump = tuple(int(x) for x in a[5:].split(","))
+        elif a == "mean": mean = True
+    rd, rc, lines = run(cfg, np_, nsteps, mode, dump, mean)
+    print(rd, "rc=", rc)
+    print("\n".join(lines))
