@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfesom_gpu.so")
+LIB_PATH = os.environ.get("FESOM_GPU_LIB", os.path.join(HERE, "libfesom_gpu.so"))
 
 PI = C.POINTER(C.c_int)
 PD = C.POINTER(C.c_double)

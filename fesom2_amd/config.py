@@ -1,0 +1,34 @@
+"""Namelist-level options of the hot path (host-side mirror of namelist.config / namelist.oce keys
+read by oce_timestep_ale; defaults = config/namelist.oce of the reference)."""
+from . import _lib
+from .mesh import WHICH_ALE
+
+
+def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equation=1, num_tracers=2,
+                mix_scheme="PP", with_diffusion=True, toy_soufflet=False, K_hor=3000.0, A_ver=1.0e-4, K_ver=1.0e-5,
+                cyclic_length_deg=360.0, w_split=False, use_instabmix=True, use_windmix=False):
+    p = _lib.Params()
+    p.dt = dt
+    p.which_ale = WHICH_ALE[which_ale]
+    p.use_partial_cell = int(use_partial_cell)
+    p.state_equation = state_equation
+    p.num_tracers = num_tracers
+    p.mom_adv = 2
+    p.visc_option = 5
+    p.i_vert_visc = 1
+    p.i_vert_diff = 1
+    p.w_split = int(w_split)
+    p.mix_scheme = {"PP": 2, "none": 0}[mix_scheme]
+    p.use_instabmix = int(use_instabmix)
+    p.use_windmix = int(use_windmix)
+    p.windmix_nl = 2
+    p.toy_soufflet = int(toy_soufflet)
+    p.alpha, p.theta, p.epsilon = 1.0, 1.0, 0.1
+    p.C_d, p.A_ver, p.K_ver, p.K_hor = 0.0025, A_ver, K_ver, K_hor
+    p.gamma0, p.gamma1, p.gamma2, p.easy_bs_return = 0.003, 0.1, 0.285, 1.5
+    p.w_max_cfl = 1.0
+    p.tra_adv_ph, p.tra_adv_pv = 1.0, 1.0
+    p.instabmix_kv, p.windmix_kv = 0.1, 1.0e-3
+    p.cyclic_length = cyclic_length_deg * 3.14159265358979 / 180.0
+    p.with_diffusion = int(with_diffusion)
+    return p

@@ -1,0 +1,177 @@
+/* ORACLE (test infrastructure): context, field registry, SSH solver restatement, step driver. */
+#include "orc.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+orc_ctx C_;
+
+typedef struct { const char *name; double **p; size_t cnt; } field_t;
+static field_t F_[96];
+static int nF_ = 0;
+
+static void reg(const char *name, double **p, size_t cnt) {
+  *p = (double *)calloc(cnt ? cnt : 1, sizeof(double));
+  F_[nF_].name = name; F_[nF_].p = p; F_[nF_].cnt = cnt; nF_++;
+}
+
+int orc_init(const fesom_mesh_desc *m, const fesom_params *p) {
+  for (int i = 0; i < nF_; i++) free(*F_[i].p);
+  nF_ = 0;
+  memset(&C_, 0, sizeof(C_));
+  C_.m = *m; C_.p = *p;
+  C_.N = m->myDim_nod2D + m->eDim_nod2D; C_.E = m->myDim_elem2D + m->eDim_elem2D; C_.D = m->myDim_edge2D + m->eDim_edge2D;
+  C_.nl = m->nl; C_.nlm1 = m->nl - 1; C_.ntr = p->num_tracers;
+  size_t N = C_.N, E = C_.E, D = C_.D, nl = C_.nl, n1 = C_.nlm1;
+#define R(f, c) reg(#f, &C_.f, c)
+  R(tr_arr, n1 * N * C_.ntr); R(tr_arr_old, n1 * N * C_.ntr);
+  R(density_m_rho0, n1 * N); R(density_ref, n1 * N); R(hnode, n1 * N); R(hnode_new, n1 * N); R(Z_3d_n, n1 * N);
+  R(sw_alpha, n1 * N); R(sw_beta, n1 * N); R(del_ttf, n1 * N); R(del_ttf_advhoriz, n1 * N); R(del_ttf_advvert, n1 * N);
+  R(fct_LO, n1 * N); R(fct_ttf_max, n1 * N); R(fct_ttf_min, n1 * N); R(fct_plus, n1 * N); R(fct_minus, n1 * N);
+  R(Ki, n1 * N); R(Tclim, n1 * N); R(Sclim, n1 * N);
+  R(bvfreq, nl * N); R(hpressure, nl * N); R(zbar_3d_n, nl * N); R(Wvel, nl * N); R(Wvel_e, nl * N); R(Wvel_i, nl * N);
+  R(CFL_z, nl * N); R(Kv, nl * N); R(tr_z, nl * N); R(adv_flux_ver, nl * N); R(dbsfc, nl * N);
+  R(Unode, 2 * n1 * N); R(Unode_rhs, 2 * n1 * N); R(sigma_xy, 2 * n1 * N); R(neutral_slope, 3 * n1 * N); R(slope_tapered, 3 * n1 * N);
+  R(U_c, 2 * n1 * N);
+  R(eta_n, N); R(d_eta, N); R(ssh_rhs, N); R(ssh_rhs_old, N); R(hbar, N); R(hbar_old, N); R(MLD1, N); R(MLD2, N);
+  R(heat_flux, N); R(water_flux, N); R(virtual_salt, N); R(relax_salt, N); R(real_salt_flux, N);
+  R(UV, 2 * n1 * E); R(UV_rhs, 2 * n1 * E); R(UV_rhsAB, 2 * n1 * E); R(tr_xy, 2 * n1 * E); R(U_b, 2 * n1 * E); R(fct_ebnd, 2 * n1 * E);
+  R(pgf_x, n1 * E); R(pgf_y, n1 * E); R(helem, n1 * E); R(Av, nl * E); R(dhe, E); R(stress_surf, 2 * E);
+  R(adv_flux_hor, n1 * D); R(edge_up_dn_grad, 4 * n1 * D);
+  R(ssh_values, m->ssh_nza);
+#undef R
+  for (size_t i = 0; i < n1 * N; i++) C_.density_ref[i] = DENSITY_0;
+  memcpy(C_.ssh_values, m->ssh_values, sizeof(double) * m->ssh_nza);
+  /* Ki = K_hor*(mesh_resolution/100000)**2  (oce_setup_step.F90:328-331) */
+  for (size_t n = 0; n < N; n++) {
+    double r = m->mesh_resolution[n] / 100000.0;
+    for (size_t k = 0; k < n1; k++) C_.Ki[n * n1 + k] = p->K_hor * (r * r);
+  }
+  return 0;
+}
+
+static field_t *find(const char *name) {
+  for (int i = 0; i < nF_; i++) if (!strcmp(F_[i].name, name)) return &F_[i];
+  return NULL;
+}
+int orc_set_field(const char *name, const double *in, long long cnt) {
+  field_t *f = find(name);
+  if (!f || (size_t)cnt != f->cnt) { fprintf(stderr, "orc_set_field(%s): bad name or count %lld (want %zu)\n", name, cnt, f ? f->cnt : 0); return 1; }
+  memcpy(*f->p, in, sizeof(double) * cnt);
+  return 0;
+}
+int orc_get_field(const char *name, double *out, long long cnt) {
+  field_t *f = find(name);
+  if (!f || (size_t)cnt != f->cnt) { fprintf(stderr, "orc_get_field(%s): bad name or count %lld (want %zu)\n", name, cnt, f ? f->cnt : 0); return 1; }
+  memcpy(out, *f->p, sizeof(double) * cnt);
+  return 0;
+}
+long long orc_field_count(const char *name) { field_t *f = find(name); return f ? (long long)f->cnt : -1; }
+void orc_set_first_step_done(int v) { C_.first_step_done = v; }
+int orc_solver_iterations(void) { return C_.solver_iters; }
+double orc_solver_residual(void) { return C_.solver_resid; }
+
+/* ---- SSH solve.  Boundary: solve_ssh_ale src/oce_ale.F90:2210-2344 -> psolve src/psolve.c:152-221.
+ * Row scaling scale[i]=1/sum_j|a_ij| and y=rhs*scale, warm start x=d_eta, and the stopping rule
+ * ||r||^2 < tol^2 (tol=1e-10 absolute on the row-scaled residual, lib/parms/src/bicgstab_ras.c:78,146,220)
+ * follow the reference.  The preconditioner is this build's GPU design (Jacobi on the scaled operator
+ * instead of pARMS' RAS+ILU(2), which is sequential): the solution agrees with the reference to the
+ * solver tolerance, not bit for bit.  Dot products use the fixed reduction order of the HIP kernel
+ * (SOLVER_T partial sums with stride SOLVER_T, then a halving tree) so that oracle == HIP bitwise. */
+#define SOLVER_T 1024
+static double dot_fixed(const double *x, const double *y, int n) {
+  static double part[SOLVER_T];
+  for (int t = 0; t < SOLVER_T; t++) {
+    double s = 0.0;
+    for (int i = t; i < n; i += SOLVER_T) s = s + x[i] * y[i];
+    part[t] = s;
+  }
+  for (int s = SOLVER_T / 2; s >= 1; s >>= 1)
+    for (int t = 0; t < s; t++) part[t] = part[t] + part[t + s];
+  return part[0];
+}
+void orc_solve_ssh(void) {
+  int n = C_.m.myDim_nod2D;
+  const int *rp = C_.m.ssh_rowptr, *ci = C_.m.ssh_colind_loc;
+  int off = rp[0];
+  double *vals = malloc(sizeof(double) * C_.m.ssh_nza), *dinv = malloc(sizeof(double) * n * 9);
+  double *b = dinv + n, *r = b + n, *r0 = r + n, *pv = r0 + n, *v = pv + n, *s = v + n, *t = s + n, *ph = t + n;
+  double *x = C_.d_eta;
+  for (int i = 0; i < n; i++) {
+    double tmp = 0.;
+    for (int j = rp[i] - off; j < rp[i + 1] - off; j++) tmp += fabs(C_.ssh_values[j]);
+    double sc = 1. / tmp;
+    for (int j = rp[i] - off; j < rp[i + 1] - off; j++) vals[j] = C_.ssh_values[j] * sc;
+    b[i] = C_.ssh_rhs[i] * sc;
+    dinv[i] = 1.0 / vals[rp[i] - off];        /* first entry of a row is the diagonal (oce_ale.F90:1128-1151) */
+  }
+#define SPMV(out, in) for (int i = 0; i < n; i++) { double a = 0.0; for (int j = rp[i] - off; j < rp[i + 1] - off; j++) a = a + vals[j] * (in)[ci[j] - 1]; (out)[i] = a; }
+  const double tol2 = 1e-10 * 1e-10;
+  const int maxits = 2000;
+  SPMV(r, x);
+  for (int i = 0; i < n; i++) { r[i] = b[i] - r[i]; r0[i] = r[i]; pv[i] = 0.0; v[i] = 0.0; }
+  double rho = 1.0, alpha = 1.0, omega = 1.0;
+  double rr = dot_fixed(r, r, n);
+  int it = 0;
+  while (rr >= tol2 && it < maxits) {
+    double rho_new = dot_fixed(r0, r, n);
+    double beta = (rho_new / rho) * (alpha / omega);
+    for (int i = 0; i < n; i++) pv[i] = r[i] + beta * (pv[i] - omega * v[i]);
+    for (int i = 0; i < n; i++) ph[i] = pv[i] * dinv[i];
+    SPMV(v, ph);
+    alpha = rho_new / dot_fixed(r0, v, n);
+    for (int i = 0; i < n; i++) { s[i] = r[i] - alpha * v[i]; x[i] = x[i] + alpha * ph[i]; }
+    for (int i = 0; i < n; i++) ph[i] = s[i] * dinv[i];
+    SPMV(t, ph);
+    double tt = dot_fixed(t, t, n), ts = dot_fixed(t, s, n);
+    omega = (tt > 0.0) ? ts / tt : 0.0;
+    for (int i = 0; i < n; i++) { x[i] = x[i] + omega * ph[i]; r[i] = s[i] - omega * t[i]; }
+    rho = rho_new;
+    rr = dot_fixed(r, r, n);
+    it++;
+  }
+  C_.solver_iters = it; C_.solver_resid = sqrt(rr);
+  free(vals); free(dinv);
+}
+
+/* oce_timestep_ale sequence for the supported options: src/oce_ale.F90:2556-2767 (+ fvom_main.F90:216) */
+void orc_step(int n) {
+  (void)n;
+  orc_compute_vel_nodes();
+  orc_pressure_bv();
+  orc_pressure_force();
+  orc_sw_alpha_beta();
+  orc_compute_sigma_xy();
+  orc_compute_neutral_slope();
+  if (C_.p.mix_scheme == 2) { orc_mixing_pp(); orc_mo_convect(); }
+  orc_compute_vel_rhs();
+  orc_visc_filt_bcksct();
+  if (C_.p.i_vert_visc) orc_impl_vert_visc_ale();
+  if (C_.p.which_ale != 0) orc_update_stiff_mat_ale();
+  orc_compute_ssh_rhs_ale();
+  orc_solve_ssh();
+  orc_update_vel();
+  orc_compute_hbar_ale();
+  orc_eta_update();
+  orc_vert_vel_ale();
+  for (int tr = 1; tr <= C_.ntr; tr++) {
+    orc_init_tracers_AB(tr);
+    orc_adv_tracers_ale(tr);
+    orc_diff_tracers_ale(tr);
+  }
+  orc_salinity_clamp();
+  orc_update_thickness_ale();
+}
+
+int orc_call(const char *name, int arg) {
+#define CALL0(f) if (!strcmp(name, #f)) { orc_##f(); return 0; }
+#define CALL1(f) if (!strcmp(name, #f)) { orc_##f(arg); return 0; }
+  CALL0(compute_vel_nodes) CALL0(pressure_bv) CALL0(pressure_force) CALL0(sw_alpha_beta) CALL0(compute_sigma_xy)
+  CALL0(compute_neutral_slope) CALL0(mixing_pp) CALL0(mo_convect) CALL0(compute_vel_rhs) CALL0(visc_filt_bcksct)
+  CALL0(impl_vert_visc_ale) CALL0(update_stiff_mat_ale) CALL0(compute_ssh_rhs_ale) CALL0(solve_ssh) CALL0(update_vel)
+  CALL0(compute_hbar_ale) CALL0(eta_update) CALL0(vert_vel_ale) CALL1(init_tracers_AB) CALL1(adv_tracers_ale)
+  CALL1(diff_tracers_ale) CALL0(salinity_clamp) CALL0(update_thickness_ale) CALL1(step)
+  fprintf(stderr, "orc_call: unknown routine %s\n", name);
+  return 1;
+}

@@ -1,0 +1,483 @@
+/* ORACLE (test infrastructure): tracer part of the step (AB2, gradients, FCT advection,
+ * T* update, diffusion closure, PP mixing).  Reference loop/expression order throughout. */
+#include "orc.h"
+#include <math.h>
+#include <string.h>
+#include <stdlib.h>
+
+/* tracer_gradient_elements: src/oce_tracer_mod.F90:19-45 */
+static void tracer_gradient_elements(const double *ttf) {
+  for (int e = 1; e <= C_.m.myDim_elem2D; e++) {
+    int n1 = EN(1, e), n2 = EN(2, e), n3 = EN(3, e);
+    for (int nz = ULEV(e); nz <= NLEV(e) - 1; nz++) {
+      V2(C_.tr_xy, 1, nz, e) = GS(1, e) * A2(ttf, nz, n1) + GS(2, e) * A2(ttf, nz, n2) + GS(3, e) * A2(ttf, nz, n3);
+      V2(C_.tr_xy, 2, nz, e) = GS(4, e) * A2(ttf, nz, n1) + GS(5, e) * A2(ttf, nz, n2) + GS(6, e) * A2(ttf, nz, n3);
+    }
+  }
+}
+
+/* tracer_gradient_z: src/oce_tracer_mod.F90:124-153 */
+static void tracer_gradient_z(const double *ttf) {
+  for (int n = 1; n <= C_.N; n++) {
+    int nzmax = NLEVN(n), nzmin = ULEVN(n);
+    for (int nz = nzmin + 1; nz <= nzmax - 1; nz++) {
+      double dz = 0.5 * (A2(C_.hnode_new, nz - 1, n) + A2(C_.hnode_new, nz, n));
+      A2L(C_.tr_z, nz, n) = (A2(ttf, nz - 1, n) - A2(ttf, nz, n)) / dz;
+    }
+    A2L(C_.tr_z, nzmin, n) = 0.0;
+    A2L(C_.tr_z, nzmax, n) = 0.0;
+  }
+}
+
+/* fill_up_dn_grad: src/oce_muscl_adv.F90:285-447 */
+static void cluster_grad(int node, int nz, double *gx, double *gy) {
+  double tvol = 0.0, tx = 0.0, ty = 0.0;
+  for (int k = 1; k <= C_.m.nod_in_elem2D_num[node - 1]; k++) {
+    int e = NIE(k, node);
+    if (NLEV(e) - 1 < nz || nz < ULEV(e)) continue;
+    double ar = C_.m.elem_area[e - 1];
+    tvol = tvol + ar;
+    tx = tx + V2(C_.tr_xy, 1, nz, e) * ar;
+    ty = ty + V2(C_.tr_xy, 2, nz, e) * ar;
+  }
+  *gx = tx / tvol; *gy = ty / tvol;
+}
+static void fill_up_dn_grad(void) {
+  double *G = C_.edge_up_dn_grad;
+  for (int ed = 1; ed <= C_.m.myDim_edge2D; ed++) {
+    int n1 = EDG(1, ed), n2 = EDG(2, ed);
+    int t1 = C_.m.edge_up_dn_tri[2 * (ed - 1)], t2 = C_.m.edge_up_dn_tri[2 * (ed - 1) + 1];
+    double gx, gy;
+    if (t1 != 0 && t2 != 0) {
+      int u1 = C_.m.ulevels_nod2D_max[n1 - 1], u2 = C_.m.ulevels_nod2D_max[n2 - 1];
+      int l1 = C_.m.nlevels_nod2D_min[n1 - 1], l2 = C_.m.nlevels_nod2D_min[n2 - 1];
+      int nzmin = u1 > u2 ? u1 : u2, nzmax = l1 < l2 ? l1 : l2;
+      for (int nz = ULEVN(n1); nz <= nzmin - 1; nz++) { cluster_grad(n1, nz, &gx, &gy); V4(G, 1, nz, ed) = gx; V4(G, 3, nz, ed) = gy; }
+      for (int nz = ULEVN(n2); nz <= nzmin - 1; nz++) { cluster_grad(n2, nz, &gx, &gy); V4(G, 2, nz, ed) = gx; V4(G, 4, nz, ed) = gy; }
+      for (int nz = nzmin; nz <= nzmax - 1; nz++) {
+        V4(G, 1, nz, ed) = V2(C_.tr_xy, 1, nz, t1); V4(G, 2, nz, ed) = V2(C_.tr_xy, 1, nz, t2);
+        V4(G, 3, nz, ed) = V2(C_.tr_xy, 2, nz, t1); V4(G, 4, nz, ed) = V2(C_.tr_xy, 2, nz, t2);
+      }
+      for (int nz = nzmax; nz <= NLEVN(n1) - 1; nz++) { cluster_grad(n1, nz, &gx, &gy); V4(G, 1, nz, ed) = gx; V4(G, 3, nz, ed) = gy; }
+      for (int nz = nzmax; nz <= NLEVN(n2) - 1; nz++) { cluster_grad(n2, nz, &gx, &gy); V4(G, 2, nz, ed) = gx; V4(G, 4, nz, ed) = gy; }
+    } else {
+      for (int nz = ULEVN(n1); nz <= NLEVN(n1) - 1; nz++) { cluster_grad(n1, nz, &gx, &gy); V4(G, 1, nz, ed) = gx; V4(G, 3, nz, ed) = gy; }
+      for (int nz = ULEVN(n2); nz <= NLEVN(n2) - 1; nz++) { cluster_grad(n2, nz, &gx, &gy); V4(G, 2, nz, ed) = gx; V4(G, 4, nz, ed) = gy; }
+    }
+  }
+}
+
+/* init_tracers_AB: src/oce_tracer_mod.F90:49-83 */
+void orc_init_tracers_AB(int tr) {
+  size_t cnt = (size_t)NLM1 * C_.N;
+  memset(C_.del_ttf, 0, sizeof(double) * cnt);
+  double *old = &TRO(1, 1, tr), *cur = &TR(1, 1, tr);
+  double eps = C_.p.epsilon;
+  for (size_t i = 0; i < cnt; i++) old[i] = -(0.5 + eps) * old[i] + (1.5 + eps) * cur[i];
+  tracer_gradient_elements(old);
+  tracer_gradient_z(cur);
+  fill_up_dn_grad();
+  tracer_gradient_elements(cur);
+}
+
+/* adv_tra_hor_upw1: src/oce_adv_tra_hor.F90:57-211 ; adv_tra_hor_mfct: :485-733.
+ * mode 0: upwind with init_zero=.true. ; mode 1: MFCT with init_zero=.false. (flux = new - flux) */
+static void adv_tra_hor(const double *ttf, int mode, double num_ord) {
+  double *flux = C_.adv_flux_hor;
+  if (mode == 0) memset(flux, 0, sizeof(double) * (size_t)NLM1 * C_.m.myDim_edge2D);
+  for (int ed = 1; ed <= C_.m.myDim_edge2D; ed++) {
+    int n1 = EDG(1, ed), n2 = EDG(2, ed), e1 = ETRI(1, ed), e2 = ETRI(2, ed);
+    int nl1 = NLEV(e1) - 1, nu1 = ULEV(e1), nl2 = 0, nu2 = 0;
+    double dX1 = ECD(1, ed), dY1 = ECD(2, ed), dX2 = 0, dY2 = 0;
+    double a = R_EARTH * C_.m.elem_cos[e1 - 1];
+    if (e2 > 0) {
+      dX2 = ECD(3, ed); dY2 = ECD(4, ed);
+      nl2 = NLEV(e2) - 1; nu2 = ULEV(e2);
+      a = 0.5 * (a + R_EARTH * C_.m.elem_cos[e2 - 1]);
+    }
+    int nl12 = nl1 < nl2 ? nl1 : nl2, nu12 = nu1 > nu2 ? nu1 : nu2;
+    int lo = nu1, hi = nl1 > nl2 ? nl1 : nl2;
+    if (nu2 > 0 && nu2 < lo) lo = nu2;
+    for (int nz = lo; nz <= hi; nz++) {
+      /* which of the five sub-ranges (A..E) this level is in */
+      int use1, use2;
+      if (nz >= nu12 && nz <= nl12) { use1 = 1; use2 = 1; }
+      else if ((nz >= nu1 && nz <= nu12 - 1) || (nz >= nl12 + 1 && nz <= nl1)) { use1 = 1; use2 = 0; }
+      else if (nu2 > 0 && ((nz >= nu2 && nz <= nu12 - 1) || (nz >= nl12 + 1 && nz <= nl2))) { use1 = 0; use2 = 1; }
+      else continue;
+      double vflux;
+      if (use1 && use2)
+        vflux = (-V2(C_.UV, 2, nz, e1) * dX1 + V2(C_.UV, 1, nz, e1) * dY1) * A2(C_.helem, nz, e1) +
+                (V2(C_.UV, 2, nz, e2) * dX2 - V2(C_.UV, 1, nz, e2) * dY2) * A2(C_.helem, nz, e2);
+      else if (use1) vflux = (-V2(C_.UV, 2, nz, e1) * dX1 + V2(C_.UV, 1, nz, e1) * dY1) * A2(C_.helem, nz, e1);
+      else vflux = (V2(C_.UV, 2, nz, e2) * dX2 - V2(C_.UV, 1, nz, e2) * dY2) * A2(C_.helem, nz, e2);
+      double t1 = A2(ttf, nz, n1), t2 = A2(ttf, nz, n2);
+      if (mode == 0) {
+        A2(flux, nz, ed) = -0.5 * (t1 * (vflux + fabs(vflux)) + t2 * (vflux - fabs(vflux))) - A2(flux, nz, ed);
+      } else {
+        const double *G = C_.edge_up_dn_grad;
+        double Tmean2 = t2 - (2.0 * (t2 - t1) + EDXY(1, ed) * a * V4(G, 2, nz, ed) + EDXY(2, ed) * R_EARTH * V4(G, 4, nz, ed)) / 6.0;
+        double Tmean1 = t1 + (2.0 * (t2 - t1) + EDXY(1, ed) * a * V4(G, 1, nz, ed) + EDXY(2, ed) * R_EARTH * V4(G, 3, nz, ed)) / 6.0;
+        double cHO = (vflux + fabs(vflux)) * Tmean1 + (vflux - fabs(vflux)) * Tmean2;
+        A2(flux, nz, ed) = -0.5 * (1.0 - num_ord) * cHO - vflux * num_ord * (0.5 * (Tmean1 + Tmean2)) - A2(flux, nz, ed);
+      }
+    }
+  }
+}
+
+/* adv_tra_ver_upw1: src/oce_adv_tra_ver.F90:231-282 (init_zero=.true.) */
+static void adv_tra_ver_upw1(const double *ttf, const double *W) {
+  double *flux = C_.adv_flux_ver;
+  memset(flux, 0, sizeof(double) * (size_t)NL * C_.m.myDim_nod2D);
+  for (int n = 1; n <= C_.m.myDim_nod2D; n++) {
+    int nzmax = NLEVN(n), nzmin = ULEVN(n);
+    A2L(flux, nzmin, n) = -A2L(W, nzmin, n) * A2(ttf, nzmin, n) * AREA(nzmin, n) - A2L(flux, nzmin, n);
+    A2L(flux, nzmax, n) = 0.0 - A2L(flux, nzmax, n);
+    for (int nz = nzmin + 1; nz <= nzmax - 1; nz++) {
+      double w = A2L(W, nz, n);
+      A2L(flux, nz, n) = -0.5 * (A2(ttf, nz, n) * (w + fabs(w)) + A2(ttf, nz - 1, n) * (w - fabs(w))) * AREA(nz, n) - A2L(flux, nz, n);
+    }
+  }
+}
+
+/* adv_tra_ver_qr4c: src/oce_adv_tra_ver.F90:286-357 (init_zero=.false.) */
+static void adv_tra_ver_qr4c(const double *ttf, const double *W, double num_ord) {
+  double *flux = C_.adv_flux_ver;
+  for (int n = 1; n <= C_.m.myDim_nod2D; n++) {
+    int nzmax = NLEVN(n), nzmin = ULEVN(n), nz;
+    nz = nzmin;
+    A2L(flux, nz, n) = -A2(ttf, nz, n) * A2L(W, nz, n) * AREA(nz, n) - A2L(flux, nz, n);
+    nz = nzmin + 1;
+    A2L(flux, nz, n) = -0.5 * (A2(ttf, nz - 1, n) + A2(ttf, nz, n)) * A2L(W, nz, n) * AREA(nz, n) - A2L(flux, nz, n);
+    nz = nzmax - 1;
+    A2L(flux, nz, n) = -0.5 * (A2(ttf, nz - 1, n) + A2(ttf, nz, n)) * A2L(W, nz, n) * AREA(nz, n) - A2L(flux, nz, n);
+    nz = nzmax;
+    A2L(flux, nz, n) = 0.0 - A2L(flux, nz, n);
+    for (nz = nzmin + 2; nz <= nzmax - 2; nz++) {
+      double qc = (A2(ttf, nz - 1, n) - A2(ttf, nz, n)) / (A2(C_.Z_3d_n, nz - 1, n) - A2(C_.Z_3d_n, nz, n));
+      double qu = (A2(ttf, nz, n) - A2(ttf, nz + 1, n)) / (A2(C_.Z_3d_n, nz, n) - A2(C_.Z_3d_n, nz + 1, n));
+      double qd = (A2(ttf, nz - 2, n) - A2(ttf, nz - 1, n)) / (A2(C_.Z_3d_n, nz - 2, n) - A2(C_.Z_3d_n, nz - 1, n));
+      double Tmean1 = A2(ttf, nz, n) + (2 * qc + qu) * (A2L(C_.zbar_3d_n, nz, n) - A2(C_.Z_3d_n, nz, n)) / 3.0;
+      double Tmean2 = A2(ttf, nz - 1, n) + (2 * qc + qd) * (A2L(C_.zbar_3d_n, nz, n) - A2(C_.Z_3d_n, nz - 1, n)) / 3.0;
+      double w = A2L(W, nz, n);
+      double Tmean = (w + fabs(w)) * Tmean1 + (w - fabs(w)) * Tmean2;
+      A2L(flux, nz, n) = (-0.5 * (1.0 - num_ord) * Tmean - num_ord * (0.5 * (Tmean1 + Tmean2)) * w) * AREA(nz, n) - A2L(flux, nz, n);
+    }
+  }
+}
+
+static void edge_range(int ed, int *nu12, int *nl12) {
+  int e1 = ETRI(1, ed), e2 = ETRI(2, ed);
+  int nl1 = NLEV(e1) - 1, nu1 = ULEV(e1), nl2 = 0, nu2 = 0;
+  if (e2 > 0) { nl2 = NLEV(e2) - 1; nu2 = ULEV(e2); }
+  *nl12 = nl1 > nl2 ? nl1 : nl2;
+  *nu12 = nu1;
+  if (nu2 > 0) *nu12 = nu1 < nu2 ? nu1 : nu2;
+}
+
+/* oce_tra_adv_fct: src/oce_adv_tra_fct.F90:58-349 (vlimit=1).  The reference uses UV_rhs as
+ * scratch for the element bounds (:108-121); the oracle uses fct_ebnd instead. */
+static void oce_tra_adv_fct(const double *ttf) {
+  const double flux_eps = 1e-16, bignumber = 1e3;
+  double *LO = C_.fct_LO, *adf_h = C_.adv_flux_hor, *adf_v = C_.adv_flux_ver, *EB = C_.fct_ebnd;
+  double dt = C_.p.dt;
+  int nl = NL;
+  for (int n = 1; n <= C_.N; n++)
+    for (int nz = ULEVN(n); nz <= NLEVN(n) - 1; nz++) {
+      A2(C_.fct_ttf_max, nz, n) = dmax(A2(LO, nz, n), A2(ttf, nz, n));
+      A2(C_.fct_ttf_min, nz, n) = dmin(A2(LO, nz, n), A2(ttf, nz, n));
+    }
+  for (int e = 1; e <= C_.m.myDim_elem2D; e++) {
+    int n1 = EN(1, e), n2 = EN(2, e), n3 = EN(3, e), nl1 = NLEV(e);
+    for (int nz = ULEV(e); nz <= nl1 - 1; nz++) {
+      V2(EB, 1, nz, e) = dmax(dmax(A2(C_.fct_ttf_max, nz, n1), A2(C_.fct_ttf_max, nz, n2)), A2(C_.fct_ttf_max, nz, n3));
+      V2(EB, 2, nz, e) = dmin(dmin(A2(C_.fct_ttf_min, nz, n1), A2(C_.fct_ttf_min, nz, n2)), A2(C_.fct_ttf_min, nz, n3));
+    }
+    if (nl1 <= nl - 1)
+      for (int nz = nl1; nz <= nl - 1; nz++) { V2(EB, 1, nz, e) = -bignumber; V2(EB, 2, nz, e) = bignumber; }
+  }
+  double *tvmax = malloc(sizeof(double) * 2 * (nl + 1)), *tvmin = tvmax + nl + 1;
+  for (int n = 1; n <= C_.m.myDim_nod2D; n++) {
+    int nu1 = ULEVN(n), nl1 = NLEVN(n);
+    for (int nz = nu1; nz <= nl1 - 1; nz++) {
+      double mx = V2(EB, 1, nz, NIE(1, n)), mn = V2(EB, 2, nz, NIE(1, n));
+      for (int k = 2; k <= C_.m.nod_in_elem2D_num[n - 1]; k++) { mx = dmax(mx, V2(EB, 1, nz, NIE(k, n))); mn = dmin(mn, V2(EB, 2, nz, NIE(k, n))); }
+      tvmax[nz] = mx; tvmin[nz] = mn;
+    }
+    A2(C_.fct_ttf_max, nu1, n) = tvmax[nu1] - A2(LO, nu1, n);
+    A2(C_.fct_ttf_min, nu1, n) = tvmin[nu1] - A2(LO, nu1, n);
+    for (int nz = nu1 + 1; nz <= nl1 - 2; nz++) {
+      A2(C_.fct_ttf_max, nz, n) = dmax(dmax(tvmax[nz - 1], tvmax[nz]), tvmax[nz + 1]) - A2(LO, nz, n);
+      A2(C_.fct_ttf_min, nz, n) = dmin(dmin(tvmin[nz - 1], tvmin[nz]), tvmin[nz + 1]) - A2(LO, nz, n);
+    }
+    int nz = nl1 - 1;
+    A2(C_.fct_ttf_max, nz, n) = tvmax[nz] - A2(LO, nz, n);
+    A2(C_.fct_ttf_min, nz, n) = tvmin[nz] - A2(LO, nz, n);
+  }
+  free(tvmax);
+  for (int n = 1; n <= C_.m.myDim_nod2D; n++)
+    for (int nz = ULEVN(n); nz <= NLEVN(n) - 1; nz++) {
+      A2(C_.fct_plus, nz, n) = 0.0; A2(C_.fct_minus, nz, n) = 0.0;
+      A2(C_.fct_plus, nz, n) = A2(C_.fct_plus, nz, n) + (dmax(0.0, A2L(adf_v, nz, n)) + dmax(0.0, -A2L(adf_v, nz + 1, n)));
+      A2(C_.fct_minus, nz, n) = A2(C_.fct_minus, nz, n) + (dmin(0.0, A2L(adf_v, nz, n)) + dmin(0.0, -A2L(adf_v, nz + 1, n)));
+    }
+  for (int ed = 1; ed <= C_.m.myDim_edge2D; ed++) {
+    int n1 = EDG(1, ed), n2 = EDG(2, ed), nu12, nl12;
+    edge_range(ed, &nu12, &nl12);
+    for (int nz = nu12; nz <= nl12; nz++) {
+      double f = A2(adf_h, nz, ed);
+      A2(C_.fct_plus, nz, n1) = A2(C_.fct_plus, nz, n1) + dmax(0.0, f);
+      A2(C_.fct_minus, nz, n1) = A2(C_.fct_minus, nz, n1) + dmin(0.0, f);
+      A2(C_.fct_plus, nz, n2) = A2(C_.fct_plus, nz, n2) + dmax(0.0, -f);
+      A2(C_.fct_minus, nz, n2) = A2(C_.fct_minus, nz, n2) + dmin(0.0, -f);
+    }
+  }
+  for (int n = 1; n <= C_.m.myDim_nod2D; n++)
+    for (int nz = ULEVN(n); nz <= NLEVN(n) - 1; nz++) {
+      double flux = A2(C_.fct_plus, nz, n) * dt / AREASVOL(nz, n) + flux_eps;
+      A2(C_.fct_plus, nz, n) = dmin(1.0, A2(C_.fct_ttf_max, nz, n) / flux);
+      flux = A2(C_.fct_minus, nz, n) * dt / AREASVOL(nz, n) - flux_eps;
+      A2(C_.fct_minus, nz, n) = dmin(1.0, A2(C_.fct_ttf_min, nz, n) / flux);
+    }
+  for (int n = 1; n <= C_.m.myDim_nod2D; n++) {
+    int nu1 = ULEVN(n), nl1 = NLEVN(n);
+    int nz = nu1;
+    double ae = 1.0, flux = A2L(adf_v, nz, n);
+    if (flux >= 0.0) ae = dmin(ae, A2(C_.fct_plus, nz, n)); else ae = dmin(ae, A2(C_.fct_minus, nz, n));
+    A2L(adf_v, nz, n) = ae * A2L(adf_v, nz, n);
+    for (nz = nu1 + 1; nz <= nl1 - 1; nz++) {
+      ae = 1.0; flux = A2L(adf_v, nz, n);
+      if (flux >= 0.) { ae = dmin(ae, A2(C_.fct_minus, nz - 1, n)); ae = dmin(ae, A2(C_.fct_plus, nz, n)); }
+      else { ae = dmin(ae, A2(C_.fct_plus, nz - 1, n)); ae = dmin(ae, A2(C_.fct_minus, nz, n)); }
+      A2L(adf_v, nz, n) = ae * A2L(adf_v, nz, n);
+    }
+  }
+  for (int ed = 1; ed <= C_.m.myDim_edge2D; ed++) {
+    int n1 = EDG(1, ed), n2 = EDG(2, ed), nu12, nl12;
+    edge_range(ed, &nu12, &nl12);
+    for (int nz = nu12; nz <= nl12; nz++) {
+      double ae = 1.0, flux = A2(adf_h, nz, ed);
+      if (flux >= 0.) { ae = dmin(ae, A2(C_.fct_plus, nz, n1)); ae = dmin(ae, A2(C_.fct_minus, nz, n2)); }
+      else { ae = dmin(ae, A2(C_.fct_minus, nz, n1)); ae = dmin(ae, A2(C_.fct_plus, nz, n2)); }
+      A2(adf_h, nz, ed) = ae * A2(adf_h, nz, ed);
+    }
+  }
+}
+
+/* do_oce_adv_tra (FCT + MFCT + QR4C): src/oce_adv_tra_driver.F90:41-197 ;
+ * oce_tra_adv_flux2dtracer: :201-269 ; adv_tracers_ale: src/oce_ale_tracer.F90:203-249 */
+void orc_adv_tracers_ale(int tr) {
+  size_t cnt = (size_t)NLM1 * C_.N;
+  double dt = C_.p.dt;
+  const double *ttf = &TR(1, 1, tr), *ttfAB = &TRO(1, 1, tr);
+  double *dh = C_.del_ttf_advhoriz, *dv = C_.del_ttf_advvert, *LO = C_.fct_LO;
+  memset(dh, 0, sizeof(double) * cnt);
+  memset(dv, 0, sizeof(double) * cnt);
+  adv_tra_hor(ttf, 0, 0.0);
+  memset(LO, 0, sizeof(double) * cnt);
+  for (int ed = 1; ed <= C_.m.myDim_edge2D; ed++) {
+    int n1 = EDG(1, ed), n2 = EDG(2, ed), nu12, nl12;
+    edge_range(ed, &nu12, &nl12);
+    for (int nz = nu12; nz <= nl12; nz++) {
+      A2(LO, nz, n1) = A2(LO, nz, n1) + A2(C_.adv_flux_hor, nz, ed);
+      A2(LO, nz, n2) = A2(LO, nz, n2) - A2(C_.adv_flux_hor, nz, ed);
+    }
+  }
+  adv_tra_ver_upw1(ttf, C_.Wvel_e);
+  for (int n = 1; n <= C_.m.myDim_nod2D; n++)
+    for (int nz = ULEVN(n); nz <= NLEVN(n) - 1; nz++)
+      A2(LO, nz, n) = (A2(ttf, nz, n) * A2(C_.hnode, nz, n) +
+                       (A2(LO, nz, n) + (A2L(C_.adv_flux_ver, nz, n) - A2L(C_.adv_flux_ver, nz + 1, n))) * dt / AREASVOL(nz, n)) /
+                      A2(C_.hnode_new, nz, n);
+  adv_tra_hor(ttfAB, 1, C_.p.tra_adv_ph);
+  adv_tra_ver_qr4c(ttfAB, C_.Wvel, C_.p.tra_adv_pv);
+  oce_tra_adv_fct(ttf);
+  /* flux2dtracer with use_lo */
+  for (int n = 1; n <= C_.m.myDim_nod2D; n++)
+    for (int nz = ULEVN(n); nz <= NLEVN(n) - 1; nz++)
+      A2(dv, nz, n) = A2(dv, nz, n) - A2(ttf, nz, n) * A2(C_.hnode, nz, n) + A2(LO, nz, n) * A2(C_.hnode_new, nz, n);
+  for (int n = 1; n <= C_.m.myDim_nod2D; n++)
+    for (int nz = ULEVN(n); nz <= NLEVN(n) - 1; nz++)
+      A2(dv, nz, n) = A2(dv, nz, n) + (A2L(C_.adv_flux_ver, nz, n) - A2L(C_.adv_flux_ver, nz + 1, n)) * dt / AREASVOL(nz, n);
+  for (int ed = 1; ed <= C_.m.myDim_edge2D; ed++) {
+    int n1 = EDG(1, ed), n2 = EDG(2, ed), nu12, nl12;
+    edge_range(ed, &nu12, &nl12);
+    for (int nz = nu12; nz <= nl12; nz++) {
+      A2(dh, nz, n1) = A2(dh, nz, n1) + A2(C_.adv_flux_hor, nz, ed) * dt / AREASVOL(nz, n1);
+      A2(dh, nz, n2) = A2(dh, nz, n2) - A2(C_.adv_flux_hor, nz, ed) * dt / AREASVOL(nz, n2);
+    }
+  }
+  for (size_t i = 0; i < cnt; i++) C_.del_ttf[i] = C_.del_ttf[i] + dh[i] + dv[i];
+}
+
+/* diff_part_hor_redi with Redi=.false.: src/oce_ale_tracer.F90:929-1077 */
+static void diff_part_hor(void) {
+  double dt = C_.p.dt;
+  for (int ed = 1; ed <= C_.m.myDim_edge2D; ed++) {
+    int n1 = EDG(1, ed), n2 = EDG(2, ed), e1 = ETRI(1, ed), e2 = ETRI(2, ed);
+    double dX1 = ECD(1, ed), dY1 = ECD(2, ed), dX2 = 0, dY2 = 0;
+    int nl1 = NLEV(e1) - 1, ul1 = ULEV(e1), nl2 = 0, ul2 = 0;
+    if (e2 > 0) { nl2 = NLEV(e2) - 1; ul2 = ULEV(e2); dX2 = ECD(3, ed); dY2 = ECD(4, ed); }
+    int nl12 = nl1 < nl2 ? nl1 : nl2, ul12 = ul1 > ul2 ? ul1 : ul2;
+    int hi = nl1 > nl2 ? nl1 : nl2, lo = ul1;
+    if (ul2 > 0) lo = ul1 < ul2 ? ul1 : ul2;
+    for (int nz = lo; nz <= hi; nz++) {
+      double Kh = (A2(C_.Ki, nz, n1) + A2(C_.Ki, nz, n2)) / 2.0, c;
+      if (nz >= ul12 && nz <= nl12) {
+        double dz = (A2(C_.helem, nz, e1) + A2(C_.helem, nz, e2)) / 2.0;
+        double Tx = 0.5 * (V2(C_.tr_xy, 1, nz, e1) + V2(C_.tr_xy, 1, nz, e2));
+        double Ty = 0.5 * (V2(C_.tr_xy, 2, nz, e1) + V2(C_.tr_xy, 2, nz, e2));
+        double Fx = Kh * (Tx + 0.0), Fy = Kh * (Ty + 0.0);
+        c = ((dX2 - dX1) * Fy - (dY2 - dY1) * Fx) * dz;
+      } else if ((nz >= ul1 && nz <= ul12 - 1) || (nz >= nl12 + 1 && nz <= nl1)) {
+        double dz = A2(C_.helem, nz, e1);
+        double Fx = Kh * (V2(C_.tr_xy, 1, nz, e1) + 0.0), Fy = Kh * (V2(C_.tr_xy, 2, nz, e1) + 0.0);
+        c = (-dX1 * Fy + dY1 * Fx) * dz;
+      } else {
+        double dz = A2(C_.helem, nz, e2);
+        double Fx = Kh * (V2(C_.tr_xy, 1, nz, e2) + 0.0), Fy = Kh * (V2(C_.tr_xy, 2, nz, e2) + 0.0);
+        c = (dX2 * Fy - dY2 * Fx) * dz;
+      }
+      double rhs1 = 0.0 + c, rhs2 = 0.0 - c;
+      A2(C_.del_ttf, nz, n1) = A2(C_.del_ttf, nz, n1) + rhs1 * dt / AREASVOL(nz, n1);
+      A2(C_.del_ttf, nz, n2) = A2(C_.del_ttf, nz, n2) + rhs2 * dt / AREASVOL(nz, n2);
+    }
+  }
+}
+
+/* bc_surface: src/oce_ale_tracer.F90:1154-1195 */
+static double bc_surface(int n, int id) {
+  double dt = C_.p.dt, nonlin = (C_.p.which_ale == 0) ? 0.0 : 1.0;
+  if (id == 0) return -dt * (C_.heat_flux[n - 1] / VCPW + TR(ULEVN(n), n, 1) * C_.water_flux[n - 1] * nonlin);
+  if (id == 1) return dt * (C_.virtual_salt[n - 1] + C_.relax_salt[n - 1] - C_.real_salt_flux[n - 1] * nonlin);
+  return 0.0;
+}
+
+/* diff_ver_part_impl_ale with Redi=.false., no w_split, no KPP non-local, no SW penetration:
+ * src/oce_ale_tracer.F90:398-856 */
+static void diff_ver_part_impl_ale(int tr) {
+  int nl = NL;
+  double *buf = calloc((size_t)8 * (nl + 2), sizeof(double));
+  double *a = buf, *b = a + nl + 2, *c = b + nl + 2, *trv = c + nl + 2, *cp = trv + nl + 2, *tp = cp + nl + 2, *zbar_n = tp + nl + 2,
+         *Z_n = zbar_n + nl + 2;
+  double dt = C_.p.dt;
+  for (int n = 1; n <= C_.m.myDim_nod2D; n++) {
+    int nzmax = NLEVN(n), nzmin = ULEVN(n), nz;
+    zbar_n[nzmax] = C_.m.zbar_n_bot[n - 1];
+    Z_n[nzmax - 1] = zbar_n[nzmax] + A2(C_.hnode_new, nzmax - 1, n) / 2.0;
+    for (nz = nzmax - 1; nz >= nzmin + 1; nz--) {
+      zbar_n[nz] = zbar_n[nz + 1] + A2(C_.hnode_new, nz, n);
+      Z_n[nz - 1] = zbar_n[nz] + A2(C_.hnode_new, nz - 1, n) / 2.0;
+    }
+    zbar_n[nzmin] = zbar_n[nzmin + 1] + A2(C_.hnode_new, nzmin, n);
+    nz = nzmin;
+    double zinv2 = 1.0 / (Z_n[nz] - Z_n[nz + 1]), zinv = 1.0 * dt, zinv1;
+    double Ty = 0.0, Ty1 = 0.0;
+    a[nz] = 0.0;
+    c[nz] = -(A2L(C_.Kv, nz + 1, n) + Ty1) * zinv2 * zinv * AREA(nz + 1, n) / AREASVOL(nz, n);
+    b[nz] = -c[nz] + A2(C_.hnode_new, nz, n);
+    zinv1 = zinv2;
+    for (nz = nzmin + 1; nz <= nzmax - 2; nz++) {
+      zinv2 = 1.0 / (Z_n[nz] - Z_n[nz + 1]);
+      a[nz] = -(A2L(C_.Kv, nz, n) + Ty) * zinv1 * zinv * (AREA(nz, n) / AREASVOL(nz, n));
+      c[nz] = -(A2L(C_.Kv, nz + 1, n) + Ty1) * zinv2 * zinv * AREA(nz + 1, n) / AREASVOL(nz, n);
+      b[nz] = -a[nz] - c[nz] + A2(C_.hnode_new, nz, n);
+      zinv1 = zinv2;
+    }
+    nz = nzmax - 1;
+    zinv = 1.0 * dt;
+    a[nz] = -(A2L(C_.Kv, nz, n) + Ty) * zinv1 * zinv * (AREA(nz, n) / AREASVOL(nz, n));
+    c[nz] = 0.0;
+    b[nz] = -a[nz] + A2(C_.hnode_new, nz, n);
+    nz = nzmin;
+    double dz = A2(C_.hnode_new, nz, n);
+    trv[nz] = -(b[nz] - dz) * TR(nz, n, tr) - c[nz] * TR(nz + 1, n, tr);
+    for (nz = nzmin + 1; nz <= nzmax - 2; nz++) {
+      dz = A2(C_.hnode_new, nz, n);
+      trv[nz] = -a[nz] * TR(nz - 1, n, tr) - (b[nz] - dz) * TR(nz, n, tr) - c[nz] * TR(nz + 1, n, tr);
+    }
+    nz = nzmax - 1;
+    dz = A2(C_.hnode_new, nz, n);
+    trv[nz] = -a[nz] * TR(nz - 1, n, tr) - (b[nz] - dz) * TR(nz, n, tr);
+    trv[nzmin] = trv[nzmin] + bc_surface(n, tr - 1);
+    cp[nzmin] = c[nzmin] / b[nzmin];
+    tp[nzmin] = trv[nzmin] / b[nzmin];
+    for (nz = nzmin + 1; nz <= nzmax - 1; nz++) {
+      double m = b[nz] - cp[nz - 1] * a[nz];
+      cp[nz] = c[nz] / m;
+      tp[nz] = (trv[nz] - tp[nz - 1] * a[nz]) / m;
+    }
+    trv[nzmax - 1] = tp[nzmax - 1];
+    for (nz = nzmax - 2; nz >= nzmin; nz--) trv[nz] = tp[nz] - cp[nz] * trv[nz + 1];
+    for (nz = nzmin; nz <= nzmax - 1; nz++) TR(nz, n, tr) = TR(nz, n, tr) + trv[nz];
+  }
+  free(buf);
+}
+
+/* diff_tracers_ale: src/oce_ale_tracer.F90:253-325 */
+void orc_diff_tracers_ale(int tr) {
+  size_t cnt = (size_t)NLM1 * C_.N;
+  memcpy(&TRO(1, 1, tr), &TR(1, 1, tr), sizeof(double) * cnt);
+  if (C_.p.with_diffusion) diff_part_hor();
+  for (int n = 1; n <= C_.m.myDim_nod2D; n++)
+    for (int nz = ULEVN(n); nz <= NLEVN(n) - 1; nz++) {
+      A2(C_.del_ttf, nz, n) = A2(C_.del_ttf, nz, n) + TR(nz, n, tr) * (A2(C_.hnode, nz, n) - A2(C_.hnode_new, nz, n));
+      TR(nz, n, tr) = TR(nz, n, tr) + A2(C_.del_ttf, nz, n) / A2(C_.hnode_new, nz, n);
+    }
+  if (C_.p.with_diffusion && C_.p.i_vert_diff) diff_ver_part_impl_ale(tr);
+}
+
+/* solve_tracers_ale tail: salinity clamp, src/oce_ale_tracer.F90:176-198 */
+void orc_salinity_clamp(void) {
+  for (int n = 1; n <= C_.N; n++)
+    for (int nz = ULEVN(n); nz <= NLEVN(n) - 1; nz++) {
+      if (TR(nz, n, 2) > 45.0) TR(nz, n, 2) = 45.0;
+      if (TR(nz, n, 2) < 3.0) TR(nz, n, 2) = 3.0;
+    }
+}
+
+/* oce_mixing_PP: src/oce_ale_mixing_pp.F90:2-83 (Kv0_const) */
+void orc_mixing_pp(void) {
+  const double mix_coeff_PP = 0.01;
+  for (int n = 1; n <= C_.N; n++)
+    for (int nz = ULEVN(n) + 1; nz <= NLEVN(n) - 1; nz++) {
+      double dz_inv = 1.0 / (A2(C_.Z_3d_n, nz - 1, n) - A2(C_.Z_3d_n, nz, n));
+      double du = V2(C_.Unode, 1, nz - 1, n) - V2(C_.Unode, 1, nz, n), dv = V2(C_.Unode, 2, nz - 1, n) - V2(C_.Unode, 2, nz, n);
+      double shear = du * du + dv * dv;
+      shear = shear * dz_inv * dz_inv;
+      A2L(C_.Kv, nz, n) = shear / (shear + 5. * dmax(A2L(C_.bvfreq, nz, n), 0.0) + 1.0e-14);
+    }
+  for (int e = 1; e <= C_.m.myDim_elem2D; e++) {
+    int n1 = EN(1, e), n2 = EN(2, e), n3 = EN(3, e);
+    for (int nz = ULEV(e) + 1; nz <= NLEV(e) - 1; nz++) {
+      double k1 = A2L(C_.Kv, nz, n1), k2 = A2L(C_.Kv, nz, n2), k3 = A2L(C_.Kv, nz, n3);
+      A2L(C_.Av, nz, e) = mix_coeff_PP * (k1 * k1 + k2 * k2 + k3 * k3) / 3.0 + C_.p.A_ver;
+    }
+  }
+  for (int n = 1; n <= C_.N; n++)
+    for (int nz = ULEVN(n) + 1; nz <= NLEVN(n) - 1; nz++) {
+      double k = A2L(C_.Kv, nz, n);
+      A2L(C_.Kv, nz, n) = mix_coeff_PP * (k * k * k) + C_.p.K_ver;
+    }
+}
+
+/* mo_convect with use_momix=.false.: src/oce_mo_conv.F90:4-103 */
+void orc_mo_convect(void) {
+  for (int n = 1; n <= C_.N; n++) {
+    int nzmin = ULEVN(n);
+    for (int nz = nzmin + 1; nz <= NLEVN(n) - 1; nz++) {
+      if (C_.p.use_instabmix && A2L(C_.bvfreq, nz, n) < 0.) A2L(C_.Kv, nz, n) = dmax(A2L(C_.Kv, nz, n), C_.p.instabmix_kv);
+      if (nzmin > 1) continue;
+      if (C_.p.use_windmix && nz <= C_.p.windmix_nl + 1) A2L(C_.Kv, nz, n) = dmax(A2L(C_.Kv, nz, n), C_.p.windmix_kv);
+    }
+  }
+  for (int e = 1; e <= C_.m.myDim_elem2D; e++) {
+    int n1 = EN(1, e), n2 = EN(2, e), n3 = EN(3, e), nzmin = ULEV(e);
+    for (int nz = nzmin + 1; nz <= NLEV(e) - 1; nz++) {
+      if (C_.p.use_instabmix && (A2L(C_.bvfreq, nz, n1) < 0. || A2L(C_.bvfreq, nz, n2) < 0. || A2L(C_.bvfreq, nz, n3) < 0.))
+        A2L(C_.Av, nz, e) = dmax(A2L(C_.Av, nz, e), C_.p.instabmix_kv);
+      if (nzmin > 1) continue;
+      if (C_.p.use_windmix && nz <= C_.p.windmix_nl + 1) A2L(C_.Av, nz, e) = dmax(A2L(C_.Av, nz, e), C_.p.windmix_kv);
+    }
+  }
+}
