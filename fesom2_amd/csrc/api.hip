@@ -1,0 +1,399 @@
+// C-ABI of libfesom_gpu.so (include/fesom_gpu.h): device state manager, step orchestration, hipGraph replay.
+// Host side mirrors the call surface of oce_timestep_ale (src/oce_ale.F90:2521-2799): the order of kernel
+// groups in enqueue_step() is the order of subroutine calls there.
+#include "dev.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <map>
+#include <algorithm>
+
+int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int first_step);
+int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg);
+void solver_prepare();
+
+namespace {
+struct Field { void *p; size_t count; };
+struct Ctx {
+  bool ready = false;
+  DM m;
+  hipStream_t stream = nullptr;
+  std::map<std::string, Field> fields;
+  std::vector<void *> allocs;
+  int first_step = 1;
+  hipGraphExec_t graph[2] = {nullptr, nullptr};
+  bool use_graph = true;
+  std::string err;
+} G;
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { G.err = std::string(#x) + ": " + hipGetErrorString(e_); fprintf(stderr, "fesom_gpu: %s\n", G.err.c_str()); return 1; } } while (0)
+
+template <class T> T *dev_alloc(size_t n) {
+  void *p = nullptr;
+  if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+  hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T));
+  G.allocs.push_back(p);
+  return (T *)p;
+}
+template <class T> const T *dev_upload(const std::vector<T> &h) {
+  T *p = dev_alloc<T>(h.size());
+  if (p && !h.empty()) hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+  return p;
+}
+const double *dev_upload_d(const double *h, size_t n) {
+  double *p = dev_alloc<double>(n);
+  if (p && n) hipMemcpy(p, h, n * sizeof(double), hipMemcpyHostToDevice);
+  return p;
+}
+double *field(const char *name, size_t n) {
+  double *p = dev_alloc<double>(n);
+  G.fields[name] = Field{p, n};
+  return p;
+}
+std::vector<int> minus1(const int *a, size_t n) {
+  std::vector<int> v(n);
+  for (size_t i = 0; i < n; i++) v[i] = a[i] > 0 ? a[i] - 1 : -1;
+  return v;
+}
+
+void enqueue_step(hipStream_t s, int first_step) {
+  const DM &m = G.m;
+  launch_dynamics_pre(m, s, first_step);     // compute_vel_nodes .. impl_vert_visc_ale
+  launch_ssh_rhs(m, s);                      // update_stiff_mat_ale, compute_ssh_rhs_ale
+  launch_solver(m, s);                       // solve_ssh_ale
+  launch_dynamics_post(m, s);                // update_vel, compute_hbar_ale, eta_n, vert_vel_ale
+  for (int tr = 0; tr < m.ntr; tr++) launch_tracer(m, s, tr);   // solve_tracers_ale
+  launch_thickness(m, s);                    // update_thickness_ale
+}
+
+int build_graph(int which) {
+  hipGraph_t g;
+  HIPCHK(hipStreamBeginCapture(G.stream, hipStreamCaptureModeGlobal));
+  enqueue_step(G.stream, which);
+  HIPCHK(hipStreamEndCapture(G.stream, &g));
+  HIPCHK(hipGraphInstantiate(&G.graph[which], g, nullptr, nullptr, 0));
+  hipGraphDestroy(g);
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+const char *fesom_gpu_last_error(void) { return G.err.c_str(); }
+
+int fesom_gpu_finalize(void) {
+  if (G.stream) hipStreamSynchronize(G.stream);
+  for (int i = 0; i < 2; i++) if (G.graph[i]) { hipGraphExecDestroy(G.graph[i]); G.graph[i] = nullptr; }
+  for (void *p : G.allocs) hipFree(p);
+  G.allocs.clear(); G.fields.clear();
+  if (G.stream) { hipStreamDestroy(G.stream); G.stream = nullptr; }
+  G.ready = false;
+  return 0;
+}
+
+int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const fesom_params *par) {
+  if (G.ready) fesom_gpu_finalize();
+  G.err.clear();
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { G.err = "no HIP device: the MI355X path has no CPU fallback"; fprintf(stderr, "fesom_gpu: %s\n", G.err.c_str()); return 2; }
+  if (part && part->npes != 1) { G.err = "fesom_gpu_init: multi-partition halo exchange is not implemented in this round (npes must be 1)"; return 3; }
+  if (d->nl > 64) { G.err = "fesom_gpu_init: nl > 64 levels not supported by the one-wave-per-column kernels"; return 3; }
+  if (par->which_ale != 0 && par->which_ale != 2) { G.err = "fesom_gpu_init: which_ale must be linfs(0) or zstar(2)"; return 3; }
+  if (par->mom_adv != 2 || par->visc_option != 5) { G.err = "fesom_gpu_init: only mom_adv=2, visc_option=5 are implemented"; return 3; }
+  if (par->w_split) { G.err = "fesom_gpu_init: w_split=.true. (implicit vertical advection of tracers) is not implemented"; return 3; }
+  for (int e = 0; e < d->myDim_elem2D + d->eDim_elem2D; e++)
+    if (d->ulevels[e] != 1) { G.err = "fesom_gpu_init: cavities (ulevels>1) are not supported"; return 3; }
+  HIPCHK(hipStreamCreate(&G.stream));
+  G.use_graph = getenv("FESOM_GPU_NO_GRAPH") == nullptr;
+  DM &m = G.m;
+  memset(&m, 0, sizeof(m));
+  m.p = *par;
+  m.N = d->myDim_nod2D + d->eDim_nod2D; m.E = d->myDim_elem2D + d->eDim_elem2D; m.D = d->myDim_edge2D + d->eDim_edge2D;
+  m.myN = d->myDim_nod2D; m.myE = d->myDim_elem2D; m.myD = d->myDim_edge2D;
+  m.nl = d->nl; m.nlm1 = d->nl - 1; m.ntr = par->num_tracers; m.maxk = d->max_nod_in_elem; m.nza = d->ssh_nza; m.edge2D_in = d->edge2D_in;
+  const size_t N = m.N, E = m.E, D = m.D, nl = m.nl, n1 = m.nlm1;
+  const int EX = m.E + d->eXDim_elem2D;
+  // ---- connectivity (0-based)
+  std::vector<int> en = minus1(d->elem2D_nodes, 3 * (size_t)E), ed = minus1(d->edges, 2 * D), et = minus1(d->edge_tri, 2 * D);
+  m.elem_nodes = dev_upload(en); m.edges = dev_upload(ed); m.edge_tri = dev_upload(et);
+  m.nie = dev_upload(minus1(d->nod_in_elem2D, (size_t)m.maxk * N));
+  m.nie_num = dev_upload(std::vector<int>(d->nod_in_elem2D_num, d->nod_in_elem2D_num + N));
+  m.nlev = dev_upload(std::vector<int>(d->nlevels, d->nlevels + E)); m.ulev = dev_upload(std::vector<int>(d->ulevels, d->ulevels + E));
+  m.nlev_n = dev_upload(std::vector<int>(d->nlevels_nod2D, d->nlevels_nod2D + N));
+  m.ulev_n = dev_upload(std::vector<int>(d->ulevels_nod2D, d->ulevels_nod2D + N));
+  m.nlev_n_min = dev_upload(std::vector<int>(d->nlevels_nod2D_min, d->nlevels_nod2D_min + N));
+  m.ulev_n_max = dev_upload(std::vector<int>(d->ulevels_nod2D_max, d->ulevels_nod2D_max + N));
+  m.edge_glob = dev_upload(std::vector<int>(d->myList_edge2D, d->myList_edge2D + D));
+  m.updn = dev_upload(minus1(d->edge_up_dn_tri, 2 * (size_t)m.myD));
+  // node -> incident owned edges in increasing edge order (= order of the reference's scatter-adds)
+  {
+    std::vector<int> ptr(N + 1, 0), idx, sgn;
+    for (int e = 0; e < m.myD; e++) { ptr[ed[2 * e] + 1]++; ptr[ed[2 * e + 1] + 1]++; }
+    for (size_t n = 0; n < N; n++) ptr[n + 1] += ptr[n];
+    idx.resize(ptr[N]); sgn.resize(ptr[N]);
+    std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+    for (int e = 0; e < m.myD; e++) {
+      int a = ed[2 * e], b = ed[2 * e + 1];
+      idx[fill[a]] = e; sgn[fill[a]++] = 1;
+      idx[fill[b]] = e; sgn[fill[b]++] = -1;
+    }
+    m.ne_ptr = dev_upload(ptr); m.ne_idx = dev_upload(idx); m.ne_sgn = dev_upload(sgn);
+  }
+  // element -> its internal edges (increasing) with the edge_tri slot it occupies
+  {
+    std::vector<int> idx(3 * E, 0), side(3 * E, 0), cnt(E, 0);
+    for (size_t e = 0; e < D; e++) {
+      if (d->myList_edge2D[e] > d->edge2D_in) continue;
+      for (int k = 0; k < 2; k++) {
+        int el = et[2 * e + k];
+        if (el < 0 || el >= (int)E) continue;
+        if (cnt[el] < 3) { idx[3 * el + cnt[el]] = (int)e; side[3 * el + cnt[el]] = k + 1; cnt[el]++; }
+      }
+    }
+    m.ee_idx = dev_upload(idx); m.ee_side = dev_upload(side);
+  }
+  // SSH operator (local 0-based CSR) + stiffness update lists in the reference's scatter order (oce_ale.F90:1399-1450)
+  {
+    std::vector<int> rp(m.myN + 1), ci(m.nza);
+    for (int i = 0; i <= m.myN; i++) rp[i] = d->ssh_rowptr[i] - d->ssh_rowptr[0];
+    for (int j = 0; j < m.nza; j++) ci[j] = d->ssh_colind_loc[j] - 1;
+    m.rowptr = dev_upload(rp); m.colind = dev_upload(ci);
+    std::vector<std::vector<std::pair<int, double>>> lists(m.nza);
+    std::vector<int> pos(N, -1);
+    for (int e = 0; e < m.myD; e++)
+      for (int j = 0; j < 2; j++) {
+        int row = ed[2 * e + j];
+        if (row >= m.myN) continue;
+        for (int q = rp[row]; q < rp[row + 1]; q++) pos[ci[q]] = q;
+        for (int i = 0; i < 2; i++) {
+          int el = et[2 * e + i];
+          if (el < 0) continue;
+          const double *gs = d->gradient_sca + 6 * (size_t)el;
+          const double *ec = d->edge_cross_dxdy + 4 * (size_t)e;
+          for (int k = 0; k < 3; k++) {
+            double coef = gs[k] * ec[2 * i + 1] - gs[3 + k] * ec[2 * i];
+            int sg = ((i == 1) ? -1 : 1) * ((j == 1) ? -1 : 1);
+            lists[pos[en[3 * el + k]]].push_back({sg * (el + 1), coef});
+          }
+        }
+      }
+    std::vector<int> sp(m.nza + 1, 0), se; std::vector<double> sc;
+    for (int p = 0; p < m.nza; p++) {
+      sp[p + 1] = sp[p] + (int)lists[p].size();
+      for (auto &c : lists[p]) { se.push_back(c.first); sc.push_back(c.second); }
+    }
+    m.su_ptr = dev_upload(sp); m.su_elem = dev_upload(se); m.su_coef = dev_upload(sc);
+  }
+  // ---- geometry
+  m.elem_area = dev_upload_d(d->elem_area, E); m.area = dev_upload_d(d->area, nl * N); m.areasvol = dev_upload_d(d->areasvol, nl * N);
+  m.areasvol_inv = dev_upload_d(d->areasvol_inv, nl * N); m.gsca = dev_upload_d(d->gradient_sca, 6 * (size_t)m.myE);
+  m.ecd = dev_upload_d(d->edge_cross_dxdy, 4 * D); m.edxy = dev_upload_d(d->edge_dxdy, 2 * D); m.elem_cos = dev_upload_d(d->elem_cos, E);
+  m.coriolis = dev_upload_d(d->coriolis, m.myE); m.zbar_e_bot = dev_upload_d(d->zbar_e_bot, E); m.zbar_n_bot = dev_upload_d(d->zbar_n_bot, N);
+  m.zbar = dev_upload_d(d->zbar, nl); m.Z = dev_upload_d(d->Z, n1);
+  (void)EX;
+  // ---- fields
+#define F(f, c) m.f = field(#f, c)
+  F(tr_arr, n1 * N * m.ntr); F(tr_arr_old, n1 * N * m.ntr);
+  F(density_m_rho0, n1 * N); F(hnode, n1 * N); F(hnode_new, n1 * N); F(Z_3d_n, n1 * N); F(sw_alpha, n1 * N); F(sw_beta, n1 * N);
+  F(del_ttf, n1 * N); F(fct_LO, n1 * N); F(fct_ttf_max, n1 * N); F(fct_ttf_min, n1 * N); F(fct_plus, n1 * N); F(fct_minus, n1 * N); F(Ki, n1 * N);
+  F(bvfreq, nl * N); F(hpressure, nl * N); F(zbar_3d_n, nl * N); F(Wvel, nl * N); F(Wvel_e, nl * N); F(Wvel_i, nl * N); F(CFL_z, nl * N);
+  F(Kv, nl * N); F(tr_z, nl * N); F(adv_flux_ver, nl * N);
+  F(Unode, 2 * n1 * N); F(Unode_rhs, 2 * n1 * N); F(sigma_xy, 2 * n1 * N); F(neutral_slope, 3 * n1 * N); F(slope_tapered, 3 * n1 * N); F(U_c, 2 * n1 * N);
+  F(eta_n, N); F(d_eta, N); F(ssh_rhs, N); F(ssh_rhs_old, N); F(hbar, N); F(hbar_old, N); F(MLD1, N); F(MLD2, N);
+  F(heat_flux, N); F(water_flux, N); F(virtual_salt, N); F(relax_salt, N); F(real_salt_flux, N);
+  F(UV, 2 * n1 * E); F(UV_rhs, 2 * n1 * E); F(UV_rhsAB, 2 * n1 * E); F(tr_xy, 2 * n1 * E); F(tr_xy_ab, 2 * n1 * E); F(U_b, 2 * n1 * E);
+  F(fct_ebnd, 2 * n1 * E); F(pgf_x, n1 * E); F(pgf_y, n1 * E); F(helem, n1 * E); F(Av, nl * E); F(dhe, E); F(stress_surf, 2 * E);
+  F(adv_flux_hor, n1 * D); F(flux_lo_hor, n1 * D); F(edge_up_dn_grad, 4 * n1 * D); F(edge_c12, D);
+  F(ssh_values, m.nza);
+  F(sv_vals, m.nza); F(sv_dinv, N); F(sv_b, N); F(sv_r, N); F(sv_r0, N); F(sv_p, N); F(sv_v, N); F(sv_s, N); F(sv_t, N); F(sv_ph, N);
+  F(sv_resid, 1);
+#undef F
+  m.sv_info = dev_alloc<int>(4);
+  for (auto &kv : G.fields) if (!kv.second.p) { G.err = "device allocation failed"; return 1; }
+  HIPCHK(hipMemcpy(m.ssh_values, d->ssh_values, sizeof(double) * m.nza, hipMemcpyHostToDevice));
+  {   // Ki = K_hor*(mesh_resolution/100000)**2 (oce_setup_step.F90:328-331); Av/Kv constant when no mixing scheme is selected
+    std::vector<double> ki(n1 * N), av(nl * E, par->A_ver), kv(nl * N, par->K_ver);
+    for (size_t n = 0; n < N; n++) { double r = d->mesh_resolution[n] / 100000.0; for (size_t k = 0; k < n1; k++) ki[n * n1 + k] = par->K_hor * (r * r); }
+    HIPCHK(hipMemcpy(m.Ki, ki.data(), sizeof(double) * ki.size(), hipMemcpyHostToDevice));
+    if (par->mix_scheme == 0) {
+      HIPCHK(hipMemcpy(m.Av, av.data(), sizeof(double) * av.size(), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(m.Kv, kv.data(), sizeof(double) * kv.size(), hipMemcpyHostToDevice));
+    }
+  }
+  solver_prepare();
+  G.first_step = 1;
+  G.ready = true;
+  HIPCHK(hipDeviceSynchronize());
+  return 0;
+}
+
+#define NEED_READY() if (!G.ready) { G.err = "fesom_gpu: not initialised"; return 1; }
+
+static int copy_state(const fesom_state_desc *st, bool up) {
+  NEED_READY();
+  struct { const char *n; double *h; } tab[] = {
+      {"tr_arr", st->tr_arr}, {"tr_arr_old", st->tr_arr_old}, {"UV", st->UV}, {"UV_rhsAB", st->UV_rhsAB}, {"eta_n", st->eta_n},
+      {"d_eta", st->d_eta}, {"ssh_rhs", st->ssh_rhs}, {"ssh_rhs_old", st->ssh_rhs_old}, {"hbar", st->hbar}, {"hbar_old", st->hbar_old},
+      {"dhe", st->dhe}, {"hnode", st->hnode}, {"hnode_new", st->hnode_new}, {"helem", st->helem}, {"zbar_3d_n", st->zbar_3d_n},
+      {"Z_3d_n", st->Z_3d_n}, {"Wvel", st->Wvel}, {"Wvel_e", st->Wvel_e}, {"Wvel_i", st->Wvel_i}, {"ssh_values", st->ssh_values}};
+  HIPCHK(hipStreamSynchronize(G.stream));
+  for (auto &t : tab) {
+    if (!t.h) continue;
+    Field &f = G.fields[t.n];
+    if (up) HIPCHK(hipMemcpy(f.p, t.h, f.count * sizeof(double), hipMemcpyHostToDevice));
+    else HIPCHK(hipMemcpy(t.h, f.p, f.count * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+int fesom_gpu_upload_state(const fesom_state_desc *st) { return copy_state(st, true); }
+int fesom_gpu_download_state(const fesom_state_desc *st) { return copy_state(st, false); }
+
+int fesom_gpu_set_forcing(const fesom_forcing_desc *f) {
+  NEED_READY();
+  struct { const char *n; const double *h; } tab[] = {{"stress_surf", f->stress_surf}, {"heat_flux", f->heat_flux}, {"water_flux", f->water_flux},
+                                                      {"virtual_salt", f->virtual_salt}, {"relax_salt", f->relax_salt}, {"real_salt_flux", f->real_salt_flux}};
+  for (auto &t : tab) {
+    Field &fl = G.fields[t.n];
+    if (t.h) HIPCHK(hipMemcpyAsync(fl.p, t.h, fl.count * sizeof(double), hipMemcpyHostToDevice, G.stream));
+    else HIPCHK(hipMemsetAsync(fl.p, 0, fl.count * sizeof(double), G.stream));
+  }
+  return 0;
+}
+
+int fesom_gpu_get_field(const char *name, double *out, long long count) {
+  NEED_READY();
+  auto it = G.fields.find(name);
+  if (it == G.fields.end() || (size_t)count != it->second.count) { G.err = std::string("get_field: bad name/count ") + name; return 1; }
+  HIPCHK(hipStreamSynchronize(G.stream));
+  HIPCHK(hipMemcpy(out, it->second.p, sizeof(double) * count, hipMemcpyDeviceToHost));
+  return 0;
+}
+int fesom_gpu_set_field(const char *name, const double *in, long long count) {
+  NEED_READY();
+  auto it = G.fields.find(name);
+  if (it == G.fields.end() || (size_t)count != it->second.count) { G.err = std::string("set_field: bad name/count ") + name; return 1; }
+  HIPCHK(hipStreamSynchronize(G.stream));
+  HIPCHK(hipMemcpy(it->second.p, in, sizeof(double) * count, hipMemcpyHostToDevice));
+  return 0;
+}
+
+static int call_named(const char *name, int arg) {
+  const DM &m = G.m;
+  if (!strcmp(name, "first_step")) { G.first_step = arg; return 0; }
+  if (!strcmp(name, "solve_ssh")) { launch_solver(m, G.stream); return 0; }
+  if (!strcmp(name, "step")) { enqueue_step(G.stream, G.first_step); G.first_step = 0; return 0; }
+  int fs = G.first_step;
+  int rc = launch_named_dyn(m, G.stream, name, arg, fs);
+  if (rc == 0) { if (!strcmp(name, "compute_vel_rhs")) G.first_step = 0; return 0; }
+  rc = launch_named_tra(m, G.stream, name, arg);
+  if (rc == 0) return 0;
+  G.err = std::string("fesom_gpu_call: unknown routine ") + name;
+  return 1;
+}
+int fesom_gpu_call(const char *routine, int arg) {
+  NEED_READY();
+  int rc = call_named(routine, arg);
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int fesom_gpu_run_steps(int n_first, int nsteps) {
+  NEED_READY();
+  (void)n_first;
+  for (int k = 0; k < nsteps; k++) {
+    int which = G.first_step ? 1 : 0;
+    if (G.use_graph) {
+      if (!G.graph[which] && build_graph(which)) return 1;
+      HIPCHK(hipGraphLaunch(G.graph[which], G.stream));
+    } else enqueue_step(G.stream, which);
+    G.first_step = 0;
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int fesom_gpu_step(int n) {
+  int rc = fesom_gpu_run_steps(n, 1);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(G.stream));
+  return 0;
+}
+
+int fesom_gpu_last_solver_iterations(void) {
+  if (!G.ready) return -1;
+  int it = -1;
+  hipStreamSynchronize(G.stream);
+  hipMemcpy(&it, G.m.sv_info, sizeof(int), hipMemcpyDeviceToHost);
+  return it;
+}
+double fesom_gpu_last_solver_residual(void) {
+  if (!G.ready) return -1.0;
+  double r = -1.0;
+  hipStreamSynchronize(G.stream);
+  hipMemcpy(&r, G.m.sv_resid, sizeof(double), hipMemcpyDeviceToHost);
+  return r;
+}
+
+// Average device time of one launch of a routine group (or "step"), measured with HIP events on the
+// library's own stream; used by bench.py for the roofline object.
+int fesom_gpu_kernel_time_ms(const char *group, int nrep, double *ms_per_launch) {
+  NEED_READY();
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  int fs = G.first_step;
+  if (call_named(group, 1)) return 1;          // warm-up
+  HIPCHK(hipStreamSynchronize(G.stream));
+  HIPCHK(hipEventRecord(e0, G.stream));
+  for (int i = 0; i < nrep; i++) if (call_named(group, 1)) return 1;
+  HIPCHK(hipEventRecord(e1, G.stream));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  *ms_per_launch = ms / nrep;
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  (void)fs;
+  return 0;
+}
+
+// ---- psolver_init / psolve / psolver_final with the reference's signatures (src/psolve.c:16,117,152) -----
+static struct { bool ok = false; int n = 0, nza = 0; DM m; std::vector<void *> al; } PS;
+void psolver_final(void) { for (void *p : PS.al) hipFree(p); PS.al.clear(); PS.ok = false; }
+void psolver_init(int *id, int *stype, int *pctype, int *pcilutype, int *ilulevel, int *fillin, double *droptol, int *maxits,
+                  int *restart, double *soltol, int *part, int *rptr, int *cols, double *vals, int *reuse, int *fcomm) {
+  (void)id; (void)stype; (void)pctype; (void)pcilutype; (void)ilulevel; (void)fillin; (void)droptol; (void)maxits; (void)restart;
+  (void)soltol; (void)reuse; (void)fcomm;
+  psolver_final();
+  int n = part[1] - part[0];                 // one partition: owned rows = all rows
+  int nza = rptr[n];
+  memset(&PS.m, 0, sizeof(PS.m));
+  auto A = [&](size_t bytes) { void *p = nullptr; hipMalloc(&p, bytes ? bytes : 8); hipMemset(p, 0, bytes ? bytes : 8); PS.al.push_back(p); return p; };
+  DM &m = PS.m;
+  m.myN = m.N = n; m.nza = nza;
+  int *rp = (int *)A(sizeof(int) * (n + 1)), *ci = (int *)A(sizeof(int) * nza);
+  hipMemcpy(rp, rptr, sizeof(int) * (n + 1), hipMemcpyHostToDevice);
+  hipMemcpy(ci, cols, sizeof(int) * nza, hipMemcpyHostToDevice);
+  m.rowptr = rp; m.colind = ci;
+  m.ssh_values = (double *)A(sizeof(double) * nza);
+  hipMemcpy(m.ssh_values, vals, sizeof(double) * nza, hipMemcpyHostToDevice);
+  m.sv_vals = (double *)A(sizeof(double) * nza);
+  double **vecs[] = {&m.sv_dinv, &m.sv_b, &m.sv_r, &m.sv_r0, &m.sv_p, &m.sv_v, &m.sv_s, &m.sv_t, &m.sv_ph, &m.d_eta, &m.ssh_rhs};
+  for (auto v : vecs) *v = (double *)A(sizeof(double) * n);
+  m.sv_info = (int *)A(16); m.sv_resid = (double *)A(8);
+  solver_prepare();
+  PS.n = n; PS.nza = nza; PS.ok = true;
+}
+void psolve(int *id, double *rhs, double *vals, double *sol, int *newvals) {
+  (void)id;
+  if (!PS.ok) { fprintf(stderr, "psolve: psolver_init has not been called\n"); return; }
+  DM &m = PS.m;
+  if (*newvals) hipMemcpy(m.ssh_values, vals, sizeof(double) * PS.nza, hipMemcpyHostToDevice);
+  hipMemcpy(m.ssh_rhs, rhs, sizeof(double) * PS.n, hipMemcpyHostToDevice);
+  hipMemcpy(m.d_eta, sol, sizeof(double) * PS.n, hipMemcpyHostToDevice);
+  launch_solver(m, 0);
+  hipDeviceSynchronize();
+  hipMemcpy(sol, m.d_eta, sizeof(double) * PS.n, hipMemcpyDeviceToHost);
+}
+}

@@ -1,0 +1,106 @@
+// Device-side data model of the MI355X ocean core (gfx950 only).
+//
+// Layout in HBM = the reference's layout: column-major with the vertical
+// index fastest, so one wet column (<= nl-1 values of 8 B, 376 B on the pi mesh) is a contiguous
+// burst.  Kernels map ONE 64-lane wavefront to ONE column (lane = level), 4 columns per 256-thread
+// workgroup: gathers of neighbouring columns (3 nodes of an element, 2 elements of an edge, the
+// element/edge cluster of a node) are then whole-line reads.  Edge->node scatter-adds of the
+// reference are turned into node-centred gathers over a CSR of incident edges kept in increasing
+// edge order, which reproduces the reference's floating-point summation order bit for bit.
+// No FMA contraction (-ffp-contract=off): results are compared bitwise with the CPU oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/fesom_gpu.h"
+
+#define WAVE 64
+#define COLS_PER_BLOCK 4
+#define BLOCK (WAVE * COLS_PER_BLOCK)
+
+struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg segment, scalar loads)
+  int N, E, D, myN, myE, myD, nl, nlm1, ntr, maxk, nza, edge2D_in;
+  // ---- connectivity, 0-based (-1 = none)
+  const int *elem_nodes;      // (3,E)
+  const int *edges;           // (2,D)
+  const int *edge_tri;        // (2,D)
+  const int *nie, *nie_num;   // (maxk,N), (N)
+  const int *nlev, *ulev;     // (E)   1-based level counts as in the reference
+  const int *nlev_n, *ulev_n, *nlev_n_min, *ulev_n_max;   // (N)
+  const int *edge_glob;       // (D) global edge id (1-based) for the internal/boundary test
+  const int *ne_ptr, *ne_idx, *ne_sgn;     // node -> incident owned edges (increasing), sign +1 if node==edges(1)
+  const int *ee_idx, *ee_side;             // (3,E) element -> its edges sorted increasing; side 1/2 (=which edge_tri slot), 0 = skip
+  const int *updn;            // (2,myD) up/down-wind triangles, 0-based, -1 none
+  const int *rowptr, *colind; // SSH CSR, 0-based local
+  const int *su_ptr, *su_elem; const double *su_coef;   // stiffness update lists per CSR entry
+  // ---- geometry
+  const double *elem_area, *area, *areasvol, *areasvol_inv, *gsca, *ecd, *edxy, *elem_cos, *coriolis;
+  const double *zbar_e_bot, *zbar_n_bot, *zbar, *Z;
+  // ---- fields (same names as o_ARRAYS / o_MESH)
+  double *tr_arr, *tr_arr_old, *density_m_rho0, *hnode, *hnode_new, *Z_3d_n, *sw_alpha, *sw_beta;
+  double *del_ttf, *fct_LO, *fct_ttf_max, *fct_ttf_min, *fct_plus, *fct_minus, *Ki;
+  double *bvfreq, *hpressure, *zbar_3d_n, *Wvel, *Wvel_e, *Wvel_i, *CFL_z, *Kv, *tr_z, *adv_flux_ver;
+  double *Unode, *Unode_rhs, *sigma_xy, *neutral_slope, *slope_tapered, *U_c;
+  double *eta_n, *d_eta, *ssh_rhs, *ssh_rhs_old, *hbar, *hbar_old, *MLD1, *MLD2;
+  double *heat_flux, *water_flux, *virtual_salt, *relax_salt, *real_salt_flux;
+  double *UV, *UV_rhs, *UV_rhsAB, *tr_xy, *tr_xy_ab, *U_b, *fct_ebnd;
+  double *pgf_x, *pgf_y, *helem, *Av, *dhe, *stress_surf;
+  double *adv_flux_hor, *flux_lo_hor, *edge_up_dn_grad, *edge_c12;
+  double *ssh_values;
+  // solver workspace
+  double *sv_vals, *sv_dinv, *sv_b, *sv_r, *sv_r0, *sv_p, *sv_v, *sv_s, *sv_t, *sv_ph;
+  int *sv_info; double *sv_resid;
+  fesom_params p;
+};
+
+// 1-based level index nz, 0-based horizontal index (n / e / d)
+#define DA2(a, nz, n)      (a)[(size_t)(n) * m.nlm1 + ((nz) - 1)]
+#define DA2L(a, nz, n)     (a)[(size_t)(n) * m.nl + ((nz) - 1)]
+#define DV2(a, c, nz, e)   (a)[((size_t)(e) * m.nlm1 + ((nz) - 1)) * 2 + ((c) - 1)]
+#define DV3(a, c, nz, e)   (a)[((size_t)(e) * m.nlm1 + ((nz) - 1)) * 3 + ((c) - 1)]
+#define DV4(a, c, nz, e)   (a)[((size_t)(e) * m.nlm1 + ((nz) - 1)) * 4 + ((c) - 1)]
+#define DTR(a, nz, n, t)   (a)[((size_t)(t) * m.N + (n)) * m.nlm1 + ((nz) - 1)]     /* t 0-based */
+#define DGS(j, e)          m.gsca[6 * (size_t)(e) + (j) - 1]
+#define DECD(j, d)         m.ecd[4 * (size_t)(d) + (j) - 1]
+
+#define D_G 9.81
+#define D_RHO0 1030.0
+#define D_REARTH 6367500.0
+#define D_VCPW 4.2e6
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int col_id() { return blockIdx.x * COLS_PER_BLOCK + (threadIdx.x >> 6); }
+__device__ __forceinline__ double bcast(double x, int src) { return __shfl(x, src, 64); }
+__device__ __forceinline__ double shup(double x) { return __shfl_up(x, 1, 64); }     // value of lane-1
+__device__ __forceinline__ double shdn(double x) { return __shfl_down(x, 1, 64); }   // value of lane+1
+
+// Sequential (reference-order) running sums across the lanes of one wavefront.  All lanes execute
+// the same chain; lane j keeps the partial sum after element j.  O(n) broadcasts, bit-identical to
+// the scalar loop  acc = init; for j=first..last: acc = acc + x[j].
+__device__ __forceinline__ double seq_sum_up(double x, int first, int last, double init) {
+  double acc = init, mine = init;
+  int l = lane_id();
+  for (int j = first; j <= last; ++j) { acc = acc + bcast(x, j); if (l == j) mine = acc; }
+  return mine;
+}
+__device__ __forceinline__ double seq_sum_down(double x, int first, int last, double init) {   // j = first, first-1, ..., last
+  double acc = init, mine = init;
+  int l = lane_id();
+  for (int j = first; j >= last; --j) { acc = acc + bcast(x, j); if (l == j) mine = acc; }
+  return mine;
+}
+__device__ __forceinline__ double wave_max(double x) {
+  for (int s = 32; s >= 1; s >>= 1) x = fmax(x, __shfl_xor(x, s, 64));
+  return x;
+}
+__device__ __forceinline__ double dmin_(double a, double b) { return a < b ? a : b; }
+__device__ __forceinline__ double dmax_(double a, double b) { return a > b ? a : b; }
+
+static inline int nblocks(int ncol) { return (ncol + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK; }
+
+// launchers implemented in the kernel translation units
+void launch_dynamics_pre(const DM &m, hipStream_t s, int first_step);
+void launch_ssh_rhs(const DM &m, hipStream_t s);
+void launch_solver(const DM &m, hipStream_t s);
+void launch_dynamics_post(const DM &m, hipStream_t s);
+void launch_tracer(const DM &m, hipStream_t s, int tr);
+void launch_thickness(const DM &m, hipStream_t s);

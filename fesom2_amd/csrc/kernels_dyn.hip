@@ -1,0 +1,804 @@
+// Dynamics kernels of the ocean step (gfx950).  One wavefront = one vertical column, lane = level.
+// Every kernel cites the reference routine it replaces; arithmetic order follows the reference
+// (checked bitwise against the CPU oracle in tests/).
+#include "dev.h"
+#include <string.h>
+
+// ------------------------------------------------------------------------------------------------
+// compute_vel_nodes (src/oce_dyn.F90:133-169): node <- area-weighted mean of surrounding elements.
+// HBM-bound gather; algorithmic traffic 2 N3 + 2 E3 values.
+__global__ void __launch_bounds__(BLOCK) k_vel_nodes(DM m) {
+  int n = col_id(), nz = lane_id() + 1;
+  if (n >= m.myN) return;
+  if (nz < m.ulev_n[n] || nz > m.nlev_n[n] - 1) return;
+  double tvol = 0.0, tx = 0.0, ty = 0.0;
+  int num = m.nie_num[n];
+  for (int k = 0; k < num; k++) {
+    int e = m.nie[(size_t)m.maxk * n + k];
+    if (m.nlev[e] - 1 < nz || nz < m.ulev[e]) continue;
+    double a = m.elem_area[e];
+    tvol = tvol + a;
+    tx = tx + DV2(m.UV, 1, nz, e) * a;
+    ty = ty + DV2(m.UV, 2, nz, e) * a;
+  }
+  DV2(m.Unode, 1, nz, n) = tx / tvol;
+  DV2(m.Unode, 2, nz, n) = ty / tvol;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Equation of state: densityJM_components (src/oce_ale_pressure_bv.F90:2586-2654), density_linear (:2992-3019)
+__device__ __forceinline__ void eos(const fesom_params &p, double t, double s, double &bulk_0, double &bulk_pz, double &bulk_pz2,
+                                    double &rhopot) {
+  if (p.state_equation == 0) {
+    bulk_0 = 1; bulk_pz = 0; bulk_pz2 = 0;
+    if (p.toy_soufflet) rhopot = D_RHO0 - 0.00025 * (t - 10.0) * D_RHO0;
+    else rhopot = D_RHO0 + 0.8 * (s - 34.0) - 0.2 * (t - 20.0);
+    return;
+  }
+  const double a0 = 19092.56, at = 209.8925, at2 = -3.041638, at3 = -1.852732e-3, at4 = -1.361629e-5;
+  const double as = 104.4077, ast = -6.500517, ast2 = .1553190, ast3 = 2.326469e-4;
+  const double ass = -5.587545, asst = 0.7390729, asst2 = -1.909078e-2;
+  const double ap = -4.721788e-1, apt = -1.028859e-2, apt2 = 2.512549e-4, apt3 = 5.939910e-7;
+  const double aps = 1.571896e-2, apst = 2.598241e-4, apst2 = -7.267926e-6, apss = -2.042967e-3;
+  const double ap2 = 1.045941e-5, ap2t = -5.782165e-10, ap2t2 = 1.296821e-7;
+  const double ap2s = -2.595994e-7, ap2st = -1.248266e-9, ap2st2 = -3.508914e-9;
+  const double b0 = 999.842594, bt = 6.793952e-2, bt2 = -9.095290e-3, bt3 = 1.001685e-4, bt4 = -1.120083e-6, bt5 = 6.536332e-9;
+  const double bs = 0.824493, bst = -4.08990e-3, bst2 = 7.64380e-5, bst3 = -8.24670e-7, bst4 = 5.38750e-9;
+  const double bss = -5.72466e-3, bsst = 1.02270e-4, bsst2 = -1.65460e-6, bss2 = 4.8314e-4;
+  double s_sqrt = sqrt(s);
+  bulk_0 = a0 + t * (at + t * (at2 + t * (at3 + t * at4))) +
+           s * (as + t * (ast + t * (ast2 + t * ast3)) + s_sqrt * (ass + t * (asst + t * asst2)));
+  bulk_pz = ap + t * (apt + t * (apt2 + t * apt3)) + s * (aps + t * (apst + t * apst2) + s_sqrt * apss);
+  bulk_pz2 = ap2 + t * (ap2t + t * ap2t2) + s * (ap2s + t * (ap2st + t * ap2st2));
+  rhopot = b0 + t * (bt + t * (bt2 + t * (bt3 + t * (bt4 + t * bt5)))) +
+           s * (bs + t * (bst + t * (bst2 + t * (bst3 + t * bst4))) + s_sqrt * (bss + t * (bsst + t * bsst2)) + s * bss2);
+}
+
+// pressure_bv (src/oce_ale_pressure_bv.F90:106-365) fused with sw_alpha_beta (:2736-2821): both are
+// pointwise in (T,S,Z) per node column.  Vertical neighbours come from wave shuffles; MLD searches are
+// ballots.  ~150 flops/cell, 7+5 values/cell -> HBM-bound.
+__global__ void __launch_bounds__(BLOCK) k_pressure_bv(DM m) {
+  int n = col_id(), l = lane_id(), nz = l + 1;
+  if (n >= m.N) return;
+  const int nzmin = m.ulev_n[n], nzmax = m.nlev_n[n];
+  const bool wet = (nz >= nzmin && nz <= nzmax - 1);
+  const double seq = (double)m.p.state_equation;
+  double t = 0.0, s = 0.0, z = 0.0, b0 = 0.0, bpz = 0.0, bpz2 = 0.0, rpot = 0.0, rho = 0.0;
+  if (wet) { t = DTR(m.tr_arr, nz, n, 0); s = DTR(m.tr_arr, nz, n, 1); z = DA2(m.Z_3d_n, nz, n); eos(m.p, t, s, b0, bpz, bpz2, rpot); }
+  const double b0s = bcast(b0, nzmin - 1), bpzs = bcast(bpz, nzmin - 1), bpz2s = bcast(bpz2, nzmin - 1), rpots = bcast(rpot, nzmin - 1);
+  const double zmin = bcast(z, nzmin - 1);
+  double dbq = 0.0;
+  const double z2 = bcast(z, nzmin);          // Z_3d_n(nzmin+1)
+  if (wet) {
+    rho = b0 + z * (bpz + z * bpz2);
+    rho = rho * rpot / (rho + 0.1 * z * seq) - D_RHO0;          // density_ref == density_0 (use_density_ref=.false.)
+    DA2(m.density_m_rho0, nz, n) = rho;
+    double rho_surf = b0s + z * (bpzs + z * bpz2s);
+    rho_surf = rho_surf * rpots / (rho_surf + 0.1 * z * seq);
+    double rr = rho + D_RHO0;
+    double dbsfc1 = -D_G * (rho_surf - rr) / rr;
+    double zk = (nz > nzmin + 1) ? z : z2;                      // Z_3d_n(max(nz,nzmin+1))
+    dbq = dbsfc1 / fabs(zmin - zk);
+  }
+  double db_max = wave_max(wet ? dmax_(dbq, 0.0) : 0.0);
+  // linfs: hydrostatic pressure (sequential running sum, reference order)
+  if (m.p.which_ale == 0) {
+    double hn = wet ? DA2(m.hnode, nz, n) : 0.0;
+    double rh = rho * hn;                       // rho(nz)*hnode(nz)
+    double rh_up = shup(rh);
+    double a = (wet && nz > nzmin) ? 0.5 * D_G * (rh_up + rh) : 0.0;
+    double h0 = -zmin * bcast(rho, nzmin - 1) * D_G;
+    double hp = seq_sum_up(a, nzmin, nzmax - 2, h0);            // lanes nzmin..nzmax-2 <-> levels nzmin+1..nzmax-1
+    if (wet) DA2L(m.hpressure, nz, n) = (nz == nzmin) ? h0 : hp;
+  }
+  // N^2 at interfaces nz = nzmin+1..nzmax-1 (needs layer nz-1 -> shuffle up)
+  double b0u = shup(b0), bpzu = shup(bpz), bpz2u = shup(bpz2), rpotu = shup(rpot), zu = shup(z);
+  double bv = 0.0;
+  const bool inner = (nz >= nzmin + 1 && nz <= nzmax - 1);
+  if (inner) {
+    double zb = DA2L(m.zbar_3d_n, nz, n);
+    double bulk_up = b0u + zb * (bpzu + zb * bpz2u);
+    double bulk_dn = b0 + zb * (bpz + zb * bpz2);
+    double rho_up = bulk_up * rpotu / (bulk_up + 0.1 * zb * seq);
+    double rho_dn = bulk_dn * rpot / (bulk_dn + 0.1 * zb * seq);
+    double dz_inv = 1.0 / (zu - z);
+    bv = -D_G * dz_inv * (rho_up - rho_dn) / D_RHO0;
+    DA2L(m.bvfreq, nz, n) = bv;
+  }
+  double bv_first = bcast(bv, nzmin), bv_last = bcast(bv, nzmax - 2);
+  if (nz == nzmin) DA2L(m.bvfreq, nzmin, n) = bv_first;
+  if (nz == nzmax) DA2L(m.bvfreq, nzmax, n) = bv_last;
+  // mixed layer depths
+  unsigned long long b1 = __ballot(inner && bv > db_max);
+  double zsel = z;
+  int i1 = b1 ? (__ffsll((long long)b1) - 1) : nzmin;          // default: Z_3d_n(nzmin+1) = lane nzmin
+  double mld1 = bcast(zsel, i1);
+  unsigned long long b2 = __ballot(inner && (rpot - rpots > 0.125));
+  double rp1 = bcast(rpot, 0);                                  // reference quirk: rhopot(1), not rhopot(nzmin)
+  double mld2;
+  if (b2) {
+    int i2 = __ffsll((long long)b2) - 1;                        // lane of first level beyond the threshold
+    double prev = (i2 == nzmin) ? bcast(z, nzmin) : bcast(z, i2 - 1);   // MLD2 before the hit
+    double zi = bcast(z, i2), ri = bcast(rpot, i2), rim = bcast(rpot, i2 - 1);
+    mld2 = prev + (zi - prev) / (ri - rim + 1.e-20) * (rp1 + 0.125 - rim);
+  } else {
+    mld2 = bcast(z, (nzmax - 2 > nzmin) ? nzmax - 2 : nzmin);   // last Z visited (or the initial value)
+  }
+  if (l == 0) { m.MLD1[n] = mld1; m.MLD2[n] = mld2; }
+  // sw_alpha_beta (owned nodes)
+  if (wet && n < m.myN) {
+    double t1 = t * 1.00024, s1 = s, p1 = fabs(z);
+    double t1_2 = t1 * t1, t1_3 = t1_2 * t1, t1_4 = t1_3 * t1, p1_2 = p1 * p1, p1_3 = p1_2 * p1;
+    double s35 = s1 - 35.0, s35_2 = s35 * s35;
+    double beta = 0.785567e-3 - 0.301985e-5 * t1 + 0.555579e-7 * t1_2 - 0.415613e-9 * t1_3 +
+                  s35 * (-0.356603e-6 + 0.788212e-8 * t1 + 0.408195e-10 * p1 - 0.602281e-15 * p1_2) + s35_2 * (0.515032e-8) +
+                  p1 * (-0.121555e-7 + 0.192867e-9 * t1 - 0.213127e-11 * t1_2) + p1_2 * (0.176621e-12 - 0.175379e-14 * t1) +
+                  p1_3 * (0.121551e-17);
+    double a_over_b = 0.665157e-1 + 0.170907e-1 * t1 - 0.203814e-3 * t1_2 + 0.298357e-5 * t1_3 - 0.255019e-7 * t1_4 +
+                      s35 * (0.378110e-2 - 0.846960e-4 * t1 - 0.164759e-6 * p1 - 0.251520e-11 * p1_2) + s35_2 * (-0.678662e-5) +
+                      p1 * (0.380374e-4 - 0.933746e-6 * t1 + 0.791325e-8 * t1_2) + p1_2 * t1_2 * (0.512857e-12) -
+                      p1_3 * (0.302285e-13);
+    DA2(m.sw_beta, nz, n) = beta;
+    DA2(m.sw_alpha, nz, n) = a_over_b * beta;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pressure_force_4_zxxxx_shchepetkin (src/oce_ale_pressure_bv.F90:1878-2104) / _linfs_fullcell (:432-466).
+// Per element column: density-Jacobian terms per level in parallel, the two vertical integrals as
+// reference-order running sums.  Reads 3 node columns x (rho, Z) -> HBM-bound gather, 2 N3 + 3 E3 values.
+__global__ void __launch_bounds__(BLOCK) k_pgf(DM m) {
+  int e = col_id(), l = lane_id(), nlz = l + 1;
+  if (e >= m.myE) return;
+  const int nle = m.nlev[e] - 1, ule = m.ulev[e];
+  const bool wet = (nlz >= ule && nlz <= nle);
+  const int n0 = m.elem_nodes[3 * e], n1 = m.elem_nodes[3 * e + 1], n2 = m.elem_nodes[3 * e + 2];
+  if (m.p.which_ale == 0) {
+    if (wet) {
+      DA2(m.pgf_x, nlz, e) = DGS(1, e) * DA2L(m.hpressure, nlz, n0) / D_RHO0 + DGS(2, e) * DA2L(m.hpressure, nlz, n1) / D_RHO0 +
+                             DGS(3, e) * DA2L(m.hpressure, nlz, n2) / D_RHO0;
+      DA2(m.pgf_y, nlz, e) = DGS(4, e) * DA2L(m.hpressure, nlz, n0) / D_RHO0 + DGS(5, e) * DA2L(m.hpressure, nlz, n1) / D_RHO0 +
+                             DGS(6, e) * DA2L(m.hpressure, nlz, n2) / D_RHO0;
+    }
+    return;
+  }
+  double he = wet ? DA2(m.helem, nlz, e) : 0.0;
+  // zbar_n(nlz) = zbar_e_bot + sum_{k=nle..nlz} helem(k)  (bottom-up, reference order); lane l <-> level l+1
+  double zb_top = seq_sum_down(he, nle - 1, ule - 1, m.zbar_e_bot[e]);   // zbar_n(nlz)
+  double zb_bot = shdn(zb_top);                                          // zbar_n(nlz+1)
+  if (nlz == nle) zb_bot = m.zbar_e_bot[e];
+  double Zn = zb_bot + he * 0.5;                                         // Z_n(nlz)
+  double auxx = 0.0, auxy = 0.0;
+  if (wet) {
+    const int en[3] = {n0, n1, n2};
+    double drho_dz[3], rho_c[3], z_c[3];
+#pragma unroll
+    for (int ni = 0; ni < 3; ni++) {
+      int n = en[ni], k0;
+      if (nlz == ule && (nlz - m.ulev_n[n]) == 0) k0 = nlz + 1;
+      else if (nlz == nle && nlz != ule && (m.nlev_n[n] - 1 - nlz) == 0) k0 = nlz - 1;
+      else k0 = nlz;
+      double zm = DA2(m.Z_3d_n, k0 - 1, n), zc = DA2(m.Z_3d_n, k0, n), zp = DA2(m.Z_3d_n, k0 + 1, n);
+      double rm = DA2(m.density_m_rho0, k0 - 1, n), rc = DA2(m.density_m_rho0, k0, n), rp = DA2(m.density_m_rho0, k0 + 1, n);
+      double dx10 = zc - zm, dx21 = zp - zc, dx20 = zp - zm, df10 = rc - rm, df21 = rp - rc;
+      drho_dz[ni] = df10 / dx10 + (dx10 * df21 - dx21 * df10) / (dx20 * dx21 * dx10) * ((Zn - zc) + (Zn - zm));
+      rho_c[ni] = (k0 == nlz) ? rc : DA2(m.density_m_rho0, nlz, n);
+      z_c[ni] = (k0 == nlz) ? zc : DA2(m.Z_3d_n, nlz, n);
+    }
+    double s3 = (drho_dz[0] + drho_dz[1] + drho_dz[2]) / 3.0;
+    double drho_dx = DGS(1, e) * rho_c[0] + DGS(2, e) * rho_c[1] + DGS(3, e) * rho_c[2];
+    double dz_dx = DGS(1, e) * z_c[0] + DGS(2, e) * z_c[1] + DGS(3, e) * z_c[2];
+    auxx = (drho_dx - s3 * dz_dx) * he * D_G / D_RHO0;
+    double drho_dy = DGS(4, e) * rho_c[0] + DGS(5, e) * rho_c[1] + DGS(6, e) * rho_c[2];
+    double dz_dy = DGS(4, e) * z_c[0] + DGS(5, e) * z_c[1] + DGS(6, e) * z_c[2];
+    auxy = (drho_dy - s3 * dz_dy) * he * D_G / D_RHO0;
+  }
+  // int_dp_dx after level nlz: first level assigns aux, later levels add (reference order)
+  double ax0 = bcast(auxx, ule - 1), ay0 = bcast(auxy, ule - 1);
+  double ix = seq_sum_up(auxx, ule, nle - 1, ax0), iy = seq_sum_up(auxy, ule, nle - 1, ay0);   // inclusive sums
+  double ixp = shup(ix), iyp = shup(iy);                                                       // sum before this level
+  if (nlz == ule + 1) { ixp = ax0; iyp = ay0; }
+  if (wet) {
+    DA2(m.pgf_x, nlz, e) = (nlz == ule) ? auxx * 0.5 : ixp + auxx * 0.5;
+    DA2(m.pgf_y, nlz, e) = (nlz == ule) ? auxy * 0.5 : iyp + auxy * 0.5;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// compute_sigma_xy (:2826-2900) fused with compute_neutral_slope (:2905-2946): node gathers T,S at the
+// 3 nodes of each surrounding element.  20 N3 values.
+__global__ void __launch_bounds__(BLOCK) k_sigma_slope(DM m) {
+  int n = col_id(), l = lane_id(), nz = l + 1;
+  if (n >= m.myN) return;
+  const int nln = m.nlev_n[n] - 1, uln = m.ulev_n[n];
+  const bool wet = (nz >= uln && nz <= nln);
+  double vol = 0.0, tx = 0.0, ty = 0.0, sx = 0.0, sy = 0.0;
+  int num = m.nie_num[n];
+  for (int k = 0; k < num; k++) {
+    int el = m.nie[(size_t)m.maxk * n + k];
+    if (!(nz >= m.ulev[el] && nz <= m.nlev[el] - 1)) continue;
+    double ar = m.elem_area[el];
+    int e1 = m.elem_nodes[3 * el], e2 = m.elem_nodes[3 * el + 1], e3 = m.elem_nodes[3 * el + 2];
+    double T1 = DTR(m.tr_arr, nz, e1, 0), T2 = DTR(m.tr_arr, nz, e2, 0), T3 = DTR(m.tr_arr, nz, e3, 0);
+    double S1 = DTR(m.tr_arr, nz, e1, 1), S2 = DTR(m.tr_arr, nz, e2, 1), S3 = DTR(m.tr_arr, nz, e3, 1);
+    vol = vol + ar;
+    tx = tx + (DGS(1, el) * T1 + DGS(2, el) * T2 + DGS(3, el) * T3) * ar;
+    ty = ty + (DGS(4, el) * T1 + DGS(5, el) * T2 + DGS(6, el) * T3) * ar;
+    sx = sx + (DGS(1, el) * S1 + DGS(2, el) * S2 + DGS(3, el) * S3) * ar;
+    sy = sy + (DGS(4, el) * S1 + DGS(5, el) * S2 + DGS(6, el) * S3) * ar;
+  }
+  double sg1 = 0.0, sg2 = 0.0;
+  if (wet) {
+    double al = DA2(m.sw_alpha, nz, n), be = DA2(m.sw_beta, nz, n);
+    sg1 = (-al * tx + be * sx) / vol * D_RHO0;
+    sg2 = (-al * ty + be * sy) / vol * D_RHO0;
+    DV2(m.sigma_xy, 1, nz, n) = sg1;
+    DV2(m.sigma_xy, 2, nz, n) = sg2;
+  }
+  if (nz <= m.nlm1) {
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0, c = 0.0;
+    bool in = (nz >= uln + 1 && nz <= nln);
+    if (in) {
+      const double eps = 5.0e-6, S_cr = 1.0e-2, S_d = 1.0e-3;
+      double bv0 = DA2L(m.bvfreq, nz, n), bv1 = DA2L(m.bvfreq, nz + 1, n);
+      double ro_z_inv = 2.0 * D_G / D_RHO0 / dmax_(bv0 + bv1, eps * eps);
+      s1 = sg1 * ro_z_inv; s2 = sg2 * ro_z_inv;
+      s3 = sqrt(s1 * s1 + s2 * s2);
+      c = 0.5 * (1.0 + tanh((S_cr - s3) / S_d));
+      if ((bv0 <= 0.0) || (bv1 <= 0.0)) c = 0.0;
+      DV3(m.neutral_slope, 1, nz, n) = s1; DV3(m.neutral_slope, 2, nz, n) = s2; DV3(m.neutral_slope, 3, nz, n) = s3;
+    }
+    DV3(m.slope_tapered, 1, nz, n) = s1 * c; DV3(m.slope_tapered, 2, nz, n) = s2 * c; DV3(m.slope_tapered, 3, nz, n) = s3 * c;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// oce_mixing_PP (src/oce_ale_mixing_pp.F90:2-83) + mo_convect (src/oce_mo_conv.F90:4-103, use_momix=.false.)
+__global__ void __launch_bounds__(BLOCK) k_pp_node_raw(DM m) {       // Kv <- Ri-function (first node loop)
+  int n = col_id(), nz = lane_id() + 1;
+  if (n >= m.N) return;
+  if (nz < m.ulev_n[n] + 1 || nz > m.nlev_n[n] - 1) return;
+  double dz_inv = 1.0 / (DA2(m.Z_3d_n, nz - 1, n) - DA2(m.Z_3d_n, nz, n));
+  double du = DV2(m.Unode, 1, nz - 1, n) - DV2(m.Unode, 1, nz, n), dv = DV2(m.Unode, 2, nz - 1, n) - DV2(m.Unode, 2, nz, n);
+  double shear = du * du + dv * dv;
+  shear = shear * dz_inv * dz_inv;
+  DA2L(m.Kv, nz, n) = shear / (shear + 5. * dmax_(DA2L(m.bvfreq, nz, n), 0.0) + 1.0e-14);
+}
+__global__ void __launch_bounds__(BLOCK) k_pp_elem(DM m) {           // Av incl. mo_convect element part
+  int e = col_id(), nz = lane_id() + 1;
+  if (e >= m.myE) return;
+  int nzmin = m.ulev[e];
+  if (nz < nzmin + 1 || nz > m.nlev[e] - 1) return;
+  int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
+  double k1 = DA2L(m.Kv, nz, n1), k2 = DA2L(m.Kv, nz, n2), k3 = DA2L(m.Kv, nz, n3);
+  double av = 0.01 * (k1 * k1 + k2 * k2 + k3 * k3) / 3.0 + m.p.A_ver;
+  if (m.p.use_instabmix && (DA2L(m.bvfreq, nz, n1) < 0. || DA2L(m.bvfreq, nz, n2) < 0. || DA2L(m.bvfreq, nz, n3) < 0.))
+    av = dmax_(av, m.p.instabmix_kv);
+  if (nzmin <= 1 && m.p.use_windmix && nz <= m.p.windmix_nl + 1) av = dmax_(av, m.p.windmix_kv);
+  DA2L(m.Av, nz, e) = av;
+}
+__global__ void __launch_bounds__(BLOCK) k_pp_node_final(DM m) {     // Kv cubic + mo_convect node part
+  int n = col_id(), nz = lane_id() + 1;
+  if (n >= m.N) return;
+  int nzmin = m.ulev_n[n];
+  if (nz < nzmin + 1 || nz > m.nlev_n[n] - 1) return;
+  double k = DA2L(m.Kv, nz, n);
+  double kv = 0.01 * (k * k * k) + m.p.K_ver;
+  if (m.p.use_instabmix && DA2L(m.bvfreq, nz, n) < 0.) kv = dmax_(kv, m.p.instabmix_kv);
+  if (nzmin <= 1 && m.p.use_windmix && nz <= m.p.windmix_nl + 1) kv = dmax_(kv, m.p.windmix_kv);
+  DA2L(m.Kv, nz, n) = kv;
+}
+
+// ------------------------------------------------------------------------------------------------
+// momentum_adv_scalar, node part (src/oce_ale_vel_rhs.F90:154-331): vertical advection from the element
+// cluster + horizontal flux-form advection gathered over the incident edges (reference edge order).
+__global__ void __launch_bounds__(BLOCK) k_momadv_node(DM m) {
+  int n = col_id(), l = lane_id(), nz = l + 1;
+  if (n >= m.myN) return;
+  const int nl1 = m.nlev_n[n] - 1, ul1 = m.ulev_n[n];
+  double wu = 0.0, wv = 0.0;                 // wu(nz), nz = 1..nl1+1
+  int num = m.nie_num[n];
+  for (int k = 0; k < num; k++) {
+    int el = m.nie[(size_t)m.maxk * n + k];
+    int nle = m.nlev[el] - 1, ule = m.ulev[el];
+    double ar = m.elem_area[el];
+    if (ule == 1 && nz == ule) {
+      wu = wu + DV2(m.UV, 1, ule, el) * ar;
+      wv = wv + DV2(m.UV, 2, ule, el) * ar;
+    }
+    if (nz >= ule + 1 && nz <= nle) {
+      wu = wu + 0.5 * (DV2(m.UV, 1, nz, el) + DV2(m.UV, 1, nz - 1, el)) * ar;
+      wv = wv + 0.5 * (DV2(m.UV, 2, nz, el) + DV2(m.UV, 2, nz - 1, el)) * ar;
+    }
+  }
+  const bool wet = (nz >= ul1 && nz <= nl1);
+  if (wet) { double we = DA2L(m.Wvel_e, nz, n); wu = wu * we; wv = wv * we; }
+  double wu_dn = shdn(wu), wv_dn = shdn(wv);   // wu(nz+1); wu(nl1+1)=0 by construction
+  if (nz == nl1) { wu_dn = 0.0; wv_dn = 0.0; }
+  double ur = 0.0, vr = 0.0;
+  if (wet) {
+    double h3 = 3.0 * DA2(m.hnode, nz, n);
+    ur = -(wu - wu_dn) / h3;
+    vr = -(wv - wv_dn) / h3;
+  }
+  if (nz <= m.nlm1) {
+    for (int q = m.ne_ptr[n]; q < m.ne_ptr[n + 1]; q++) {
+      int ed = m.ne_idx[q], sg = m.ne_sgn[q];
+      int el1 = m.edge_tri[2 * ed], el2 = m.edge_tri[2 * ed + 1];
+      int l1 = m.nlev[el1] - 1, u1 = m.ulev[el1];
+      double un1 = 0.0, un2 = 0.0, a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0;
+      bool act;
+      a1 = DV2(m.UV, 1, nz, el1); b1 = DV2(m.UV, 2, nz, el1);
+      if (nz >= u1 && nz <= l1) un1 = b1 * DECD(1, ed) - a1 * DECD(2, ed);
+      if (el2 >= 0) {
+        int l2 = m.nlev[el2] - 1, u2 = m.ulev[el2];
+        a2 = DV2(m.UV, 1, nz, el2); b2 = DV2(m.UV, 2, nz, el2);
+        if (nz >= u2 && nz <= l2) un2 = -b2 * DECD(3, ed) + a2 * DECD(4, ed);
+        act = (nz >= (u1 < u2 ? u1 : u2) && nz <= (l1 > l2 ? l1 : l2));
+        if (act) {
+          if (sg > 0) { ur = ur + un1 * a1 + un2 * a2; vr = vr + un1 * b1 + un2 * b2; }
+          else        { ur = ur - un1 * a1 - un2 * a2; vr = vr - un1 * b1 - un2 * b2; }
+        }
+      } else {
+        act = (nz >= u1 && nz <= l1);
+        if (act) {
+          if (sg > 0) { ur = ur + un1 * a1; vr = vr + un1 * b1; }
+          else        { ur = ur - un1 * a1; vr = vr - un1 * b1; }
+        }
+      }
+    }
+    if (wet) { double ai = DA2L(m.areasvol_inv, nz, n); ur = ur * ai; vr = vr * ai; }
+    DV2(m.Unode_rhs, 1, nz, n) = ur;
+    DV2(m.Unode_rhs, 2, nz, n) = vr;
+  }
+}
+
+// compute_vel_rhs (src/oce_ale_vel_rhs.F90:13-148) incl. the element part of momentum_adv_scalar (:333-343):
+// one streaming pass per element column.  16 E3 values.
+__global__ void __launch_bounds__(BLOCK) k_vel_rhs(DM m, int first_step) {
+  int e = col_id(), nz = lane_id() + 1;
+  if (e >= m.myE) return;
+  if (nz < m.ulev[e] || nz > m.nlev[e] - 1) return;
+  const double eps = m.p.epsilon, dt = m.p.dt;
+  int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
+  double ar = m.elem_area[e];
+  double r1 = -(0.5 + eps) * DV2(m.UV_rhsAB, 1, nz, e), r2 = -(0.5 + eps) * DV2(m.UV_rhsAB, 2, nz, e);
+  double p0 = -(D_G * m.eta_n[n1] + 0.0 + 0.0), p1 = -(D_G * m.eta_n[n2] + 0.0 + 0.0), p2 = -(D_G * m.eta_n[n3] + 0.0 + 0.0);
+  double ff = m.coriolis[e] * ar;
+  double Fx = DGS(1, e) * p0 + DGS(2, e) * p1 + DGS(3, e) * p2;
+  double Fy = DGS(4, e) * p0 + DGS(5, e) * p1 + DGS(6, e) * p2;
+  r1 = r1 + (Fx - DA2(m.pgf_x, nz, e)) * ar;
+  r2 = r2 + (Fy - DA2(m.pgf_y, nz, e)) * ar;
+  double ab1 = DV2(m.UV, 2, nz, e) * ff, ab2 = -DV2(m.UV, 1, nz, e) * ff;
+  ab1 = ab1 + ar * (DV2(m.Unode_rhs, 1, nz, n1) + DV2(m.Unode_rhs, 1, nz, n2) + DV2(m.Unode_rhs, 1, nz, n3)) / 3.0;
+  ab2 = ab2 + ar * (DV2(m.Unode_rhs, 2, nz, n1) + DV2(m.Unode_rhs, 2, nz, n2) + DV2(m.Unode_rhs, 2, nz, n3)) / 3.0;
+  DV2(m.UV_rhsAB, 1, nz, e) = ab1;
+  DV2(m.UV_rhsAB, 2, nz, e) = ab2;
+  double f2 = first_step ? 1.0 : (1.5 + eps);
+  DV2(m.UV_rhs, 1, nz, e) = dt * (r1 + ab1 * f2) / ar;
+  DV2(m.UV_rhs, 2, nz, e) = dt * (r2 + ab2 * f2) / ar;
+}
+
+// ------------------------------------------------------------------------------------------------
+// visc_filt_bcksct (src/oce_dyn.F90:563-649): (1) element gather over its <=3 internal edges,
+// (2) node average, (3) apply (fused into k_impl_visc).  4 N3 + 12 E3 values.
+__global__ void __launch_bounds__(BLOCK) k_visc_elem(DM m) {
+  int e = col_id(), nz = lane_id() + 1;
+  if (e >= m.E) return;
+  if (nz > m.nlm1) return;
+  double ub = 0.0, vb = 0.0;
+  const double dt = m.p.dt, g0 = m.p.gamma0, g1 = m.p.gamma1, g2 = m.p.gamma2;
+  for (int q = 0; q < 3; q++) {
+    int side = m.ee_side[3 * e + q];
+    if (side == 0) continue;
+    int ed = m.ee_idx[3 * e + q];
+    int e1 = m.edge_tri[2 * ed], e2 = m.edge_tri[2 * ed + 1];
+    int nzmax = min(m.nlev[e1], m.nlev[e2]), nzmin = max(m.ulev[e1], m.ulev[e2]);
+    if (nz < nzmin || nz > nzmax - 1) continue;
+    double a1 = m.elem_area[e1], a2 = m.elem_area[e2];
+    double len = sqrt(a1 + a2);
+    double u1 = DV2(m.UV, 1, nz, e1) - DV2(m.UV, 1, nz, e2);
+    double v1 = DV2(m.UV, 2, nz, e1) - DV2(m.UV, 2, nz, e2);
+    double vi = dt * dmax_(g0, dmax_(g1 * sqrt(u1 * u1 + v1 * v1), g2 * (u1 * u1 + v1 * v1))) * len;
+    u1 = u1 * vi; v1 = v1 * vi;
+    if (side == 1) { ub = ub - u1 / a1; vb = vb - v1 / a1; }
+    else           { ub = ub + u1 / a2; vb = vb + v1 / a2; }
+  }
+  DV2(m.U_b, 1, nz, e) = ub;
+  DV2(m.U_b, 2, nz, e) = vb;
+}
+__global__ void __launch_bounds__(BLOCK) k_visc_node(DM m) {
+  int n = col_id(), nz = lane_id() + 1;
+  if (n >= m.myN) return;
+  if (nz < m.ulev_n[n] || nz > m.nlev_n[n] - 1) return;
+  double vi = 0.0, u1 = 0.0, v1 = 0.0;
+  int num = m.nie_num[n];
+  for (int k = 0; k < num; k++) {
+    int e = m.nie[(size_t)m.maxk * n + k];
+    double ar = m.elem_area[e];
+    vi = vi + ar;
+    u1 = u1 + DV2(m.U_b, 1, nz, e) * ar;
+    v1 = v1 + DV2(m.U_b, 2, nz, e) * ar;
+  }
+  DV2(m.U_c, 1, nz, n) = u1 / vi;
+  DV2(m.U_c, 2, nz, n) = v1 / vi;
+}
+
+// impl_vert_visc_ale (src/oce_ale.F90:2348-2517) with the last loop of visc_filt_bcksct (oce_dyn.F90:638-648)
+// fused in front.  Coefficients per level in parallel; the Thomas sweeps are executed by all lanes of the
+// wave on broadcast values (uniform control flow, reference order).  1 N3 + 8 E3 values.
+__global__ void __launch_bounds__(BLOCK) k_impl_visc(DM m, int apply_visc, int do_impl) {
+  int e = col_id(), l = lane_id(), nz = l + 1;
+  if (e >= m.myE) return;
+  const int nzmin = m.ulev[e], nzmax = m.nlev[e];
+  const bool wet = (nz >= nzmin && nz <= nzmax - 1);
+  const int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
+  const double dt = m.p.dt;
+  double ur = 0.0, vr = 0.0, u = 0.0, v = 0.0, he = 0.0;
+  if (wet) {
+    ur = DV2(m.UV_rhs, 1, nz, e); vr = DV2(m.UV_rhs, 2, nz, e);
+    u = DV2(m.UV, 1, nz, e); v = DV2(m.UV, 2, nz, e); he = DA2(m.helem, nz, e);
+    if (apply_visc) {
+      double bs = m.p.easy_bs_return;
+      ur = ur + DV2(m.U_b, 1, nz, e) - bs * (DV2(m.U_c, 1, nz, n1) + DV2(m.U_c, 1, nz, n2) + DV2(m.U_c, 1, nz, n3)) / 3.0;
+      vr = vr + DV2(m.U_b, 2, nz, e) - bs * (DV2(m.U_c, 2, nz, n1) + DV2(m.U_c, 2, nz, n2) + DV2(m.U_c, 2, nz, n3)) / 3.0;
+    }
+  }
+  if (!do_impl) {
+    if (wet) { DV2(m.UV_rhs, 1, nz, e) = ur; DV2(m.UV_rhs, 2, nz, e) = vr; }
+    return;
+  }
+  // zbar_n, Z_n of the element column
+  double zb_top = seq_sum_down(he, nzmax - 2, nzmin - 1, m.zbar_e_bot[e]);   // zbar_n(nz)
+  double zb_bot = shdn(zb_top);
+  if (nz == nzmax - 1) zb_bot = m.zbar_e_bot[e];
+  double Zn = zb_bot + he / 2.0;                                             // Z_n(nz)
+  double Zn_up = shup(Zn), Zn_dn = shdn(Zn);
+  double a = 0.0, b = 1.0, c = 0.0;
+  double wi_top = 0.0, wi_bot = 0.0, av_top = 0.0, av_bot = 0.0;
+  if (wet) {
+    wi_top = (DA2L(m.Wvel_i, nz, n1) + DA2L(m.Wvel_i, nz, n2) + DA2L(m.Wvel_i, nz, n3)) / 3.;
+    wi_bot = (DA2L(m.Wvel_i, nz + 1, n1) + DA2L(m.Wvel_i, nz + 1, n2) + DA2L(m.Wvel_i, nz + 1, n3)) / 3.;
+    av_top = DA2L(m.Av, nz, e); av_bot = DA2L(m.Av, nz + 1, e);
+    double zinv = 1.0 * dt / (zb_top - zb_bot);
+    if (nz > nzmin && nz < nzmax - 1) {
+      a = -av_top / (Zn_up - Zn) * zinv;
+      c = -av_bot / (Zn - Zn_dn) * zinv;
+      b = -a - c + 1.0;
+      a = a + dmin_(0., wi_top) * zinv;
+      b = b + dmax_(0., wi_top) * zinv;
+      b = b - dmin_(0., wi_bot) * zinv;
+      c = c - dmax_(0., wi_bot) * zinv;
+    } else if (nz == nzmax - 1 && nz != nzmin) {
+      a = -av_top / (Zn_up - Zn) * zinv;
+      b = -a + 1.0;
+      c = 0.0;
+      a = a + dmin_(0., wi_top) * zinv;
+      b = b + dmax_(0., wi_top) * zinv;
+    } else if (nz == nzmin) {
+      c = -av_bot / (Zn - Zn_dn) * zinv;
+      a = 0.0;
+      b = -c + 1.0;
+      b = b + wi_top * zinv;
+      b = b - dmin_(0., wi_bot) * zinv;
+      c = c - dmax_(0., wi_bot) * zinv;
+    }
+    if (nz == nzmin) {
+      ur = ur + zinv * m.stress_surf[2 * e] / D_RHO0;
+      vr = vr + zinv * m.stress_surf[2 * e + 1] / D_RHO0;
+    }
+    if (nz == nzmax - 1) {
+      double friction = -m.p.C_d * sqrt(u * u + v * v);
+      ur = ur + zinv * friction * u;
+      vr = vr + zinv * friction * v;
+    }
+  }
+  double u_up = shup(u), v_up = shup(v), u_dn = shdn(u), v_dn = shdn(v);
+  if (wet) {
+    if (nz > nzmin && nz < nzmax - 1) {
+      ur = ur - a * u_up - (b - 1.0) * u - c * u_dn;
+      vr = vr - a * v_up - (b - 1.0) * v - c * v_dn;
+    } else if (nz == nzmin) {
+      ur = ur - (b - 1.0) * u - c * u_dn;
+      vr = vr - (b - 1.0) * v - c * v_dn;
+    } else {
+      ur = ur - a * u_up - (b - 1.0) * u;
+      vr = vr - a * v_up - (b - 1.0) * v;
+    }
+  }
+  // Thomas algorithm, all lanes in lock-step on broadcast coefficients
+  double cp_m = 0.0, up_m = 0.0, vp_m = 0.0;     // this lane's cp/up/vp
+  {
+    int j = nzmin - 1;
+    double bj = bcast(b, j);
+    double cpp = bcast(c, j) / bj, upp = bcast(ur, j) / bj, vpp = bcast(vr, j) / bj;
+    if (l == j) { cp_m = cpp; up_m = upp; vp_m = vpp; }
+    for (j = nzmin; j <= nzmax - 2; ++j) {
+      double aj = bcast(a, j), mm = bcast(b, j) - cpp * aj;
+      double cpn = bcast(c, j) / mm;
+      double upn = (bcast(ur, j) - upp * aj) / mm;
+      double vpn = (bcast(vr, j) - vpp * aj) / mm;
+      cpp = cpn; upp = upn; vpp = vpn;
+      if (l == j) { cp_m = cpp; up_m = upp; vp_m = vpp; }
+    }
+    double un = upp, vn = vpp;                   // solution at nzmax-1
+    double us = un, vs = vn;
+    for (j = nzmax - 3; j >= nzmin - 1; --j) {
+      un = bcast(up_m, j) - bcast(cp_m, j) * un;
+      vn = bcast(vp_m, j) - bcast(cp_m, j) * vn;
+      if (l == j) { us = un; vs = vn; }
+    }
+    if (wet) { DV2(m.UV_rhs, 1, nz, e) = us; DV2(m.UV_rhs, 2, nz, e) = vs; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// update_stiff_mat_ale (src/oce_ale.F90:1371-1470) as a gather per CSR entry: the contribution list of every
+// entry (element, geometric coefficient incl. the i/j sign flips) is precomputed on the host in reference order.
+__global__ void k_stiff_update(DM m) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= m.nza) return;
+  double factor = D_G * m.p.dt * m.p.alpha * m.p.theta;
+  double v = m.ssh_values[p];
+  for (int q = m.su_ptr[p]; q < m.su_ptr[p + 1]; q++) {
+    int code = m.su_elem[q];               // +-(element+1): sign carries the reference's fy=-fy flips (i==2, j==2)
+    int el = (code > 0 ? code : -code) - 1;
+    double fy = -m.dhe[el] * m.su_coef[q]; // coef = GS(k)*ECD(2i) - GS(3+k)*ECD(2i-1), computed on the host
+    if (code < 0) fy = -fy;
+    v = v + fy * factor;
+  }
+  m.ssh_values[p] = v;
+}
+
+// compute_ssh_rhs_ale (:1478-1572) and compute_hbar_ale (:1585-1676): per-edge vertical integrals
+// (reference-order running sums), then a node gather.  mode 0: with UV_rhs and alpha; mode 1: UV only.
+__global__ void __launch_bounds__(BLOCK) k_edge_transport(DM m, int mode) {
+  int ed = col_id(), l = lane_id(), nz = l + 1;
+  if (ed >= m.myD) return;
+  int e1 = m.edge_tri[2 * ed], e2 = m.edge_tri[2 * ed + 1];
+  const double alpha = m.p.alpha;
+  double t1 = 0.0, t2 = 0.0;
+  int u1 = m.ulev[e1], l1 = m.nlev[e1] - 1, u2 = 1, l2 = 0;
+  if (nz >= u1 && nz <= l1) {
+    double uu = DV2(m.UV, 1, nz, e1), vv = DV2(m.UV, 2, nz, e1), h = DA2(m.helem, nz, e1);
+    if (mode == 0) t1 = alpha * ((vv + DV2(m.UV_rhs, 2, nz, e1)) * DECD(1, ed) - (uu + DV2(m.UV_rhs, 1, nz, e1)) * DECD(2, ed)) * h;
+    else t1 = (vv * DECD(1, ed) - uu * DECD(2, ed)) * h;
+  }
+  if (e2 >= 0) {
+    u2 = m.ulev[e2]; l2 = m.nlev[e2] - 1;
+    if (nz >= u2 && nz <= l2) {
+      double uu = DV2(m.UV, 1, nz, e2), vv = DV2(m.UV, 2, nz, e2), h = DA2(m.helem, nz, e2);
+      if (mode == 0) t2 = alpha * ((vv + DV2(m.UV_rhs, 2, nz, e2)) * DECD(3, ed) - (uu + DV2(m.UV_rhs, 1, nz, e2)) * DECD(4, ed)) * h;
+      else t2 = (vv * DECD(3, ed) - uu * DECD(4, ed)) * h;
+    }
+  }
+  // c1 = sum_{nz} t1 (top-down), c2 = -sum t2 (reference: c2 = c2 - term)
+  double c1 = 0.0, c2 = 0.0;
+  for (int j = u1 - 1; j <= l1 - 1; ++j) c1 = c1 + bcast(t1, j);
+  if (e2 >= 0) for (int j = u2 - 1; j <= l2 - 1; ++j) c2 = c2 - bcast(t2, j);
+  if (l == 0) m.edge_c12[ed] = c1 + c2;
+}
+__global__ void k_ssh_rhs_node(DM m) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= m.myN) return;
+  double s = 0.0;
+  for (int q = m.ne_ptr[n]; q < m.ne_ptr[n + 1]; q++) {
+    double c = m.edge_c12[m.ne_idx[q]];
+    s = (m.ne_sgn[q] > 0) ? s + c : s - c;
+  }
+  const double alpha = m.p.alpha;
+  int uln = m.ulev_n[n];
+  if (m.p.which_ale != 0) s = s - alpha * m.water_flux[n] * DA2L(m.areasvol, uln, n) + (1.0 - alpha) * m.ssh_rhs_old[n];
+  else s = s + (1.0 - alpha) * m.ssh_rhs_old[n];
+  m.ssh_rhs[n] = s;
+}
+// compute_hbar_ale node part + eta_n update (oce_ale.F90:2722)
+__global__ void k_hbar_node(DM m) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= m.myN) return;
+  double s = 0.0;
+  for (int q = m.ne_ptr[n]; q < m.ne_ptr[n + 1]; q++) {
+    double c = m.edge_c12[m.ne_idx[q]];
+    s = (m.ne_sgn[q] > 0) ? s + c : s - c;
+  }
+  int uln = m.ulev_n[n];
+  double asv = DA2L(m.areasvol, uln, n);
+  if (m.p.which_ale != 0) s = s - m.water_flux[n] * asv;
+  m.ssh_rhs_old[n] = s;
+  double hb_old = m.hbar[n];
+  m.hbar_old[n] = hb_old;
+  double hb = hb_old + s * m.p.dt / asv;
+  m.hbar[n] = hb;
+  if (uln == 1) m.eta_n[n] = m.p.alpha * hb + (1.0 - m.p.alpha) * hb_old;
+}
+__global__ void k_dhe(DM m) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m.myE) return;
+  int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
+  if (m.ulev[e] > 1) m.dhe[e] = 0.0;
+  else m.dhe[e] = ((m.hbar[n1] - m.hbar_old[n1]) + (m.hbar[n2] - m.hbar_old[n2]) + (m.hbar[n3] - m.hbar_old[n3])) / 3.0;
+}
+
+// update_vel (src/oce_dyn.F90:101-131); the 2-D eta_n += d_eta rides along on extra threads.
+__global__ void __launch_bounds__(BLOCK) k_update_vel(DM m) {
+  int e = col_id(), nz = lane_id() + 1;
+  int gid = blockIdx.x * BLOCK + threadIdx.x;
+  if (gid < m.N) m.eta_n[gid] = m.eta_n[gid] + m.d_eta[gid];
+  if (e >= m.myE) return;
+  if (nz < m.ulev[e] || nz > m.nlev[e] - 1) return;
+  double fac = -D_G * m.p.theta * m.p.dt;
+  double e0 = fac * m.d_eta[m.elem_nodes[3 * e]], e1 = fac * m.d_eta[m.elem_nodes[3 * e + 1]], e2 = fac * m.d_eta[m.elem_nodes[3 * e + 2]];
+  double Fx = DGS(1, e) * e0 + DGS(2, e) * e1 + DGS(3, e) * e2;
+  double Fy = DGS(4, e) * e0 + DGS(5, e) * e1 + DGS(6, e) * e2;
+  DV2(m.UV, 1, nz, e) = DV2(m.UV, 1, nz, e) + DV2(m.UV_rhs, 1, nz, e) + Fx;
+  DV2(m.UV, 2, nz, e) = DV2(m.UV, 2, nz, e) + DV2(m.UV_rhs, 2, nz, e) + Fy;
+}
+
+// ------------------------------------------------------------------------------------------------
+// vert_vel_ale (src/oce_ale.F90:1692-2204; linfs + zstar branches): divergence gathered over incident
+// edges, bottom-up running sum, /area, zstar distribution of d(hbar), CFL_z, explicit/implicit split.
+// 20 N3 + 3 E3 values.
+__global__ void __launch_bounds__(BLOCK) k_vert_vel(DM m) {
+  int n = col_id(), l = lane_id(), nz = l + 1;
+  if (n >= m.myN) return;
+  const int nzmin = m.ulev_n[n], nzmax = m.nlev_n[n] - 1;
+  const double dt = m.p.dt;
+  double w = 0.0;
+  if (nz <= m.nlm1) {
+    for (int q = m.ne_ptr[n]; q < m.ne_ptr[n + 1]; q++) {
+      int ed = m.ne_idx[q], sg = m.ne_sgn[q];
+      int e1 = m.edge_tri[2 * ed], e2 = m.edge_tri[2 * ed + 1];
+      if (nz >= m.ulev[e1] && nz <= m.nlev[e1] - 1) {
+        double c1 = (DV2(m.UV, 2, nz, e1) * DECD(1, ed) - DV2(m.UV, 1, nz, e1) * DECD(2, ed)) * DA2(m.helem, nz, e1);
+        w = (sg > 0) ? w + c1 : w - c1;
+      }
+      if (e2 >= 0 && nz >= m.ulev[e2] && nz <= m.nlev[e2] - 1) {
+        double c2 = -(DV2(m.UV, 2, nz, e2) * DECD(3, ed) - DV2(m.UV, 1, nz, e2) * DECD(4, ed)) * DA2(m.helem, nz, e2);
+        w = (sg > 0) ? w + c2 : w - c2;
+      }
+    }
+  }
+  // Wvel(nz) = Wvel(nz) + Wvel(nz+1), nz = nzmax..nzmin ; Wvel(nzmax+1) = 0
+  double wc = seq_sum_down((nz >= nzmin && nz <= nzmax) ? w : 0.0, nzmax - 1, nzmin - 1, 0.0);
+  const bool wet = (nz >= nzmin && nz <= nzmax);
+  double W = 0.0, hn_new = 0.0;
+  if (wet) { W = wc / DA2L(m.area, nz, n); hn_new = DA2(m.hnode_new, nz, n); }
+  if (m.p.which_ale == 2) {
+    int nzm = m.nlev_n_min[n] - 1;
+    if (nzmin == 1) {
+      double dd1 = DA2L(m.zbar_3d_n, nzm, n);
+      double dd = DA2L(m.zbar_3d_n, nzmin, n) - dd1;
+      dd = (m.hbar[n] - m.hbar_old[n]) / dd;
+      double dddt = dd / dt;
+      if (nz >= nzmin && nz <= nzm - 1) {
+        double zb = DA2L(m.zbar_3d_n, nz, n), zb1 = DA2L(m.zbar_3d_n, nz + 1, n);
+        W = W - (zb - dd1) * dddt;
+        hn_new = DA2(m.hnode, nz, n) + (zb - zb1) * dd;
+        DA2(m.hnode_new, nz, n) = hn_new;
+      }
+    }
+    if (nz == nzmin) W = W - m.water_flux[n];
+  }
+  // CFL_z(nz) = |W(nz-1 .. )| pieces: c2 of the layer above + c1 of this layer
+  double W_dn = shdn(W);                       // W(nz+1) ; W(nzmax+1) = 0
+  if (nz == nzmax) W_dn = 0.0;
+  double c1 = 0.0, c2 = 0.0;
+  if (wet) { c1 = fabs(W * dt / hn_new); c2 = fabs(W_dn * dt / hn_new); }
+  double c2_up = shup(c2);
+  double cfl = 0.0;
+  if (nz >= nzmin && nz <= nzmax + 1) {
+    if (nz == nzmin) cfl = 0.0 + c1;
+    else if (nz == nzmax + 1) cfl = c2_up;
+    else cfl = c2_up + c1;
+    double Wl = (nz == nzmax + 1) ? 0.0 : W;
+    double e1 = 1.0, e2 = 0.0;
+    if (m.p.w_split && (cfl > m.p.w_max_cfl)) {
+      double dd = dmax_((cfl - m.p.w_max_cfl), 0.0) / dmax_(m.p.w_max_cfl, 1.e-12);
+      e1 = 1.0 / (1.0 + dd);
+      e2 = dd / (1.0 + dd);
+    }
+    DA2L(m.Wvel, nz, n) = Wl;
+    DA2L(m.CFL_z, nz, n) = cfl;
+    DA2L(m.Wvel_e, nz, n) = e1 * Wl;
+    DA2L(m.Wvel_i, nz, n) = e2 * Wl;
+  }
+}
+
+// update_thickness_ale (src/oce_ale.F90:800-993, zstar branch)
+__global__ void __launch_bounds__(BLOCK) k_thick_node(DM m) {
+  int n = col_id(), l = lane_id(), nz = l + 1;
+  if (n >= m.N) return;
+  int nzmin = m.ulev_n[n], nzmax = m.nlev_n_min[n] - 2;
+  if (nzmin > 1) return;
+  bool in = (nz >= nzmin && nz <= nzmax);
+  double hn = in ? DA2(m.hnode_new, nz, n) : 0.0;
+  double zb0 = DA2L(m.zbar_3d_n, nzmax + 1, n);
+  double zb = seq_sum_down(hn, nzmax - 1, nzmin - 1, zb0);   // zbar_3d_n(nz) = zbar_3d_n(nz+1) + hnode_new(nz)
+  double zb_below = shdn(zb);
+  if (nz == nzmax) zb_below = zb0;
+  if (in) {
+    DA2(m.hnode, nz, n) = hn;
+    DA2L(m.zbar_3d_n, nz, n) = zb;
+    DA2(m.Z_3d_n, nz, n) = zb_below + hn / 2.0;
+  }
+}
+__global__ void __launch_bounds__(BLOCK) k_thick_elem(DM m) {
+  int e = col_id(), nz = lane_id() + 1;
+  if (e >= m.myE) return;
+  int nzmin = m.ulev[e], nzmax = m.nlev[e] - 1;
+  if (nzmin > 1) return;
+  if (nz < nzmin || nz > nzmax - 1) return;
+  int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
+  DA2(m.helem, nz, e) = (DA2(m.hnode, nz, n1) + DA2(m.hnode, nz, n2) + DA2(m.hnode, nz, n3)) / 3.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+#define LAUNCH_COL(k, ncol, ...) hipLaunchKernelGGL(k, dim3(nblocks(ncol)), dim3(BLOCK), 0, s, __VA_ARGS__)
+#define LAUNCH_FLAT(k, n, ...) hipLaunchKernelGGL(k, dim3(((n) + 255) / 256), dim3(256), 0, s, __VA_ARGS__)
+
+void launch_dynamics_pre(const DM &m, hipStream_t s, int first_step) {
+  LAUNCH_COL(k_vel_nodes, m.myN, m);
+  LAUNCH_COL(k_pressure_bv, m.N, m);
+  LAUNCH_COL(k_pgf, m.myE, m);
+  LAUNCH_COL(k_sigma_slope, m.myN, m);
+  if (m.p.mix_scheme == 2) {
+    LAUNCH_COL(k_pp_node_raw, m.N, m);
+    LAUNCH_COL(k_pp_elem, m.myE, m);
+    LAUNCH_COL(k_pp_node_final, m.N, m);
+  }
+  LAUNCH_COL(k_momadv_node, m.myN, m);
+  LAUNCH_COL(k_vel_rhs, m.myE, m, first_step);
+  LAUNCH_COL(k_visc_elem, m.E, m);
+  LAUNCH_COL(k_visc_node, m.myN, m);
+  LAUNCH_COL(k_impl_visc, m.myE, m, 1, m.p.i_vert_visc);
+}
+void launch_ssh_rhs(const DM &m, hipStream_t s) {
+  if (m.p.which_ale != 0) LAUNCH_FLAT(k_stiff_update, m.nza, m);
+  LAUNCH_COL(k_edge_transport, m.myD, m, 0);
+  LAUNCH_FLAT(k_ssh_rhs_node, m.myN, m);
+}
+void launch_dynamics_post(const DM &m, hipStream_t s) {
+  int ncol = m.myE > (m.N + BLOCK - 1) / BLOCK * COLS_PER_BLOCK ? m.myE : (m.N + BLOCK - 1) / BLOCK * COLS_PER_BLOCK;
+  LAUNCH_COL(k_update_vel, ncol, m);
+  LAUNCH_COL(k_edge_transport, m.myD, m, 1);
+  LAUNCH_FLAT(k_hbar_node, m.myN, m);
+  LAUNCH_FLAT(k_dhe, m.myE, m);
+  LAUNCH_COL(k_vert_vel, m.myN, m);
+}
+void launch_thickness(const DM &m, hipStream_t s) {
+  if (m.p.which_ale != 2) return;
+  LAUNCH_COL(k_thick_node, m.N, m);
+  LAUNCH_COL(k_thick_elem, m.myE, m);
+}
+
+int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int first_step) {
+  (void)arg;
+  if (!strcmp(name, "compute_vel_nodes")) { LAUNCH_COL(k_vel_nodes, m.myN, m); return 0; }
+  if (!strcmp(name, "pressure_bv")) { LAUNCH_COL(k_pressure_bv, m.N, m); return 0; }       // includes sw_alpha_beta
+  if (!strcmp(name, "sw_alpha_beta")) return 0;
+  if (!strcmp(name, "pressure_force")) { LAUNCH_COL(k_pgf, m.myE, m); return 0; }
+  if (!strcmp(name, "compute_sigma_xy")) { LAUNCH_COL(k_sigma_slope, m.myN, m); return 0; } // includes neutral slope
+  if (!strcmp(name, "compute_neutral_slope")) return 0;
+  if (!strcmp(name, "mixing_pp")) {
+    LAUNCH_COL(k_pp_node_raw, m.N, m); LAUNCH_COL(k_pp_elem, m.myE, m); LAUNCH_COL(k_pp_node_final, m.N, m); return 0;
+  }
+  if (!strcmp(name, "mo_convect")) return 0;                                                  // fused into mixing_pp
+  if (!strcmp(name, "compute_vel_rhs")) { LAUNCH_COL(k_momadv_node, m.myN, m); LAUNCH_COL(k_vel_rhs, m.myE, m, first_step); return 0; }
+  if (!strcmp(name, "visc_filt_bcksct")) {
+    LAUNCH_COL(k_visc_elem, m.E, m); LAUNCH_COL(k_visc_node, m.myN, m); LAUNCH_COL(k_impl_visc, m.myE, m, 1, 0); return 0;
+  }
+  if (!strcmp(name, "impl_vert_visc_ale")) { LAUNCH_COL(k_impl_visc, m.myE, m, 0, 1); return 0; }
+  if (!strcmp(name, "update_stiff_mat_ale")) { LAUNCH_FLAT(k_stiff_update, m.nza, m); return 0; }
+  if (!strcmp(name, "compute_ssh_rhs_ale")) { LAUNCH_COL(k_edge_transport, m.myD, m, 0); LAUNCH_FLAT(k_ssh_rhs_node, m.myN, m); return 0; }
+  if (!strcmp(name, "update_vel")) {
+    int ncol = m.myE > (m.N + BLOCK - 1) / BLOCK * COLS_PER_BLOCK ? m.myE : (m.N + BLOCK - 1) / BLOCK * COLS_PER_BLOCK;
+    LAUNCH_COL(k_update_vel, ncol, m); return 0;
+  }
+  if (!strcmp(name, "compute_hbar_ale")) {                                                    // includes the eta_n update
+    LAUNCH_COL(k_edge_transport, m.myD, m, 1); LAUNCH_FLAT(k_hbar_node, m.myN, m); LAUNCH_FLAT(k_dhe, m.myE, m); return 0;
+  }
+  if (!strcmp(name, "eta_update")) return 0;
+  if (!strcmp(name, "vert_vel_ale")) { LAUNCH_COL(k_vert_vel, m.myN, m); return 0; }
+  if (!strcmp(name, "update_thickness_ale")) { launch_thickness(m, s); return 0; }
+  return -1;
+}
