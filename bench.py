@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- SYPD of the MI355X ocean dynamical core on the pi mesh (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one pass of the hot path (compute_vel_nodes + oce_timestep_ale: EOS/PGF, momentum, SSH solve,
+ALE vertical velocity, 2x FCT tracer advection + diffusion, thickness update) over the pi mesh
+(3140 nodes, 47 layers, T/S, no sea ice), synthetic analytic initial state resident in HBM.
+SYPD = 86400 / (365*96 * seconds_per_step)  (pi: step_per_day=96, setups/pi/setup.yml:12).
+
+N>1: one process per GPU under torch.distributed.run.  The halo-exchange path is not built in
+this round, so N ranks run N independent replicas of the pi mesh ("replicas only", scaling "weak"): value is
+the aggregate simulated years/day of the ensemble, NOT strong-scaling SYPD of one simulation.
+
+Besides the contract fields the JSON line carries
+  roofline     : dominant kernel, algorithmic bytes (SURVEY 8d counting rule) / HIP-event time vs 8 TB/s
+  cpu_baseline : the reference Fortran/MPI build (oracle/_ref, kind "reference") timed on the host cores,
+                 or the scalar C restatement (kind "port") if the reference binary cannot run here.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+STEPS_PER_YEAR = 365 * 96
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured-achievable
+
+# algorithmic traffic per launch in 8-byte values per wet cell (N3 nodes, E3 prisms, D3 edge cells):
+# every distinct 3-D array once per read and once per write, gathers once per gathered value (SURVEY 8d rule)
+KERNEL_VALUES = {
+    "k_vel_nodes": (2, 2, 0), "k_pressure_bv": (8, 0, 0), "k_pgf": (2, 3, 0), "k_sigma_slope": (13, 0, 0),
+    "k_pp_node_raw": (5, 0, 0), "k_pp_elem": (2, 1, 0), "k_pp_node_final": (3, 0, 0), "k_momadv_node": (5, 2, 0),
+    "k_vel_rhs": (2, 10, 0), "k_visc_elem": (0, 4, 0), "k_visc_node": (2, 2, 0), "k_impl_visc": (3, 10, 0),
+    "k_edge_transport": (0, 5, 0), "k_update_vel": (0, 6, 0), "k_vert_vel": (8, 3, 0),
+    "k_tr_ab_z": (5, 0, 0), "k_tr_grad_elem": (2, 4, 0), "k_updn_grad": (0, 2, 4), "k_flux_hor": (2, 3, 6),
+    "k_fct_lo_node": (14, 0, 1), "k_fct_ebnd": (2, 2, 0), "k_fct_node": (8, 2, 1), "k_fct_edge_limit": (2, 0, 2),
+    "k_tr_update": (12, 3, 1), "k_thick_node": (5, 0, 0), "k_thick_elem": (1, 1, 0),
+}
+PER_TRACER = ("k_tr_ab_z", "k_tr_grad_elem", "k_updn_grad", "k_flux_hor", "k_fct_lo_node", "k_fct_ebnd", "k_fct_node",
+              "k_fct_edge_limit", "k_tr_update")
+
+
+def cpu_baseline(nsteps_ref=400):
+    """Reference Fortran/MPI hot path (oracle/_ref/fesom_oracle.x, built from the reference's own sources) on the
+    host cores: same mesh, same options (PP mixing, no GM/Redi), same initial state; 8 MPI ranks (dist_8)."""
+    ncpu = os.cpu_count() or 1
+    exe = os.path.join(REPO, "oracle", "_ref", "fesom_oracle.x")
+    try:
+        if not os.path.exists(exe):
+            raise RuntimeError("no reference binary")
+        from oracle.ref import run_ref
+        ranks = 8 if ncpu >= 8 else 2
+        rd, rc, lines = run_ref.run("pi_pp", ranks, nsteps_ref, mode="step", dump=(), dump_mesh=False)
+        tl = [l for l in lines if l.startswith("ORACLE_TIMING")]
+        if rc != 0 or not tl:
+            raise RuntimeError(f"reference run failed rc={rc}")
+        sps = float(tl[0].split("s_per_step=")[1])
+        return {"value": 86400.0 / (STEPS_PER_YEAR * sps), "unit": "simulated_years/day", "cores": ranks, "kind": "reference",
+                "sample": f"{nsteps_ref} steps of oce_timestep_ale on pi (PP mixing, no GM/Redi), {ranks} MPI ranks, {sps*1e3:.2f} ms/step"}
+    except Exception as e:          # reference cannot run here: time the scalar C restatement instead
+        from fesom2_amd.mesh import Mesh
+        from fesom2_amd.config import make_params
+        from fesom2_amd.synthetic import analytic_ts
+        from oracle_lib import Oracle
+        pi = os.path.join(REPO, "tests", "golden", "meshes", "pi")
+        mesh = Mesh.load(pi, dt=900.0)
+        orc = Oracle(mesh, make_params(dt=900.0))
+        st = mesh.initial_state(2)
+        st.tr_arr[0], st.tr_arr[1] = analytic_ts(pi)
+        st.tr_arr_old[...] = st.tr_arr
+        orc.set_state(st)
+        n = 40
+        orc.call("step", 1)
+        t0 = time.perf_counter()
+        for k in range(n):
+            orc.call("step", 2 + k)
+        sps = (time.perf_counter() - t0) / n
+        return {"value": 86400.0 / (STEPS_PER_YEAR * sps), "unit": "simulated_years/day", "cores": 1, "kind": "port",
+                "sample": f"{n} steps of the scalar C restatement on pi, {sps*1e3:.2f} ms/step (reference binary unavailable: {e})"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("FESOM_GPU_DEVICE", str(local_rank))
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    import __graft_entry__ as ge
+    if rank == 0 and not os.path.exists(os.path.join(REPO, "fesom2_amd", "libfesom_gpu.so")):
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.core import OceanCore
+    from fesom2_amd.synthetic import analytic_ts
+
+    pi = os.path.join(REPO, "tests", "golden", "meshes", "pi")
+    mesh = Mesh.load(pi, dt=900.0)
+    par = make_params(dt=900.0)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(pi)
+    st.tr_arr_old[...] = st.tr_arr
+    core = OceanCore(mesh, par)
+    core.upload_state(st)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    core.run_steps(1, args.warmup)
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    core.run_steps(1 + args.warmup, args.steps)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    its = core.solver_iterations
+    sps = elapsed / args.steps
+    sypd_one = 86400.0 / (STEPS_PER_YEAR * sps)
+
+    if rank == 0:
+        import numpy as np
+        eta = core.get("eta_n", mesh.myDim_nod2D)
+        T = core.get("tr_arr", 2 * mesh.myDim_nod2D * (mesh.nl - 1))
+        assert np.isfinite(eta).all() and np.isfinite(T).all(), "model state blew up"
+        # per-kernel device times (HIP events on the library's stream) -> dominant kernel + roofline
+        N3, E3, D3 = mesh.wet_counts()
+        times, kbytes = {}, {}
+        # SSH solve replayed on a real (operator, rhs, warm-start) triple of one more step
+        for r in ("compute_vel_nodes", "pressure_bv", "pressure_force", "compute_sigma_xy", "mixing_pp", "compute_vel_rhs",
+                  "visc_filt_bcksct", "impl_vert_visc_ale", "update_stiff_mat_ale", "compute_ssh_rhs_ale", "solver_snapshot"):
+            core.call(r)
+        times["k_solver"] = core.kernel_time_ms("k_solver_replay", 10) * 1e-3
+        its = core.solver_iterations
+        for k, (a, b, c) in KERNEL_VALUES.items():
+            times[k] = core.kernel_time_ms(k, 50) * 1e-3
+            kbytes[k] = 8.0 * (a * N3 + b * E3 + c * D3)
+        share = {k: t * (2 if k in PER_TRACER else 1) for k, t in times.items()}
+        share["k_edge_transport"] = times["k_edge_transport"] * 2
+        dom = max((k for k in share if k != "k_solver"), key=lambda k: share[k])
+        achieved = kbytes[dom] / times[dom] / 1e9
+        step_bytes = 8.0 * ((77 * N3 + 67 * E3) + 2 * (77 * N3 + 16 * E3 + 16 * D3))       # 0.405 GB on pi
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "kernel_us": round(times[dom] * 1e6, 2), "algorithmic_bytes_per_launch": kbytes[dom],
+                    "whole_step": {"algorithmic_GB_per_step": round(step_bytes / 1e9, 4),
+                                   "achieved_GBs": round(step_bytes / sps / 1e9, 1),
+                                   "frac": round(step_bytes / sps / 1e9 / HBM_PEAK_GBS, 4),
+                                   "sum_kernel_us": round(sum(share.values()) * 1e6, 1),
+                                   "solver_us": round(times["k_solver"] * 1e6, 1), "solver_iterations": its},
+                    "top5_us": {k: round(v * 1e6, 2) for k, v in sorted(share.items(), key=lambda kv: -kv[1])[:5]}}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline()
+        out = {"metric": "SYPD (simulated years/day) on pi mesh, 47 z-levels", "value": round(sypd_one * world, 2),
+               "unit": "simulated_years/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(sps * 1e3, 5), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "pi mesh (3140 nodes, 5839 elements, 47 layers), T/S tracers, zstar ALE, JM EOS, PP mixing, "
+                                      "MFCT/QR4C/FCT advection, no sea ice, no GM/Redi", "steps_per_day": 96,
+                          "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (halo exchange not built)",
+                          "wet_cells": {"N3": N3, "E3": E3, "D3": D3}},
+               "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    barrier()
+    core.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

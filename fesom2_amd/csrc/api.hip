@@ -106,6 +106,13 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   if (par->w_split) { G.err = "fesom_gpu_init: w_split=.true. (implicit vertical advection of tracers) is not implemented"; return 3; }
   for (int e = 0; e < d->myDim_elem2D + d->eDim_elem2D; e++)
     if (d->ulevels[e] != 1) { G.err = "fesom_gpu_init: cavities (ulevels>1) are not supported"; return 3; }
+  {
+    const char *dv = getenv("FESOM_GPU_DEVICE");
+    if (!dv) dv = getenv("LOCAL_RANK");
+    int dev = dv ? atoi(dv) : 0;
+    if (dev < 0 || dev >= ndev) dev = 0;
+    HIPCHK(hipSetDevice(dev));
+  }
   HIPCHK(hipStreamCreate(&G.stream));
   G.use_graph = getenv("FESOM_GPU_NO_GRAPH") == nullptr;
   DM &m = G.m;
@@ -161,6 +168,8 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     for (int i = 0; i <= m.myN; i++) rp[i] = d->ssh_rowptr[i] - d->ssh_rowptr[0];
     for (int j = 0; j < m.nza; j++) ci[j] = d->ssh_colind_loc[j] - 1;
     m.rowptr = dev_upload(rp); m.colind = dev_upload(ci);
+    m.ssh_maxnnz = 0;
+    for (int i = 0; i < m.myN; i++) m.ssh_maxnnz = std::max(m.ssh_maxnnz, rp[i + 1] - rp[i]);
     std::vector<std::vector<std::pair<int, double>>> lists(m.nza);
     std::vector<int> pos(N, -1);
     for (int e = 0; e < m.myD; e++)
@@ -208,7 +217,8 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   F(fct_ebnd, 2 * n1 * E); F(pgf_x, n1 * E); F(pgf_y, n1 * E); F(helem, n1 * E); F(Av, nl * E); F(dhe, E); F(stress_surf, 2 * E);
   F(adv_flux_hor, n1 * D); F(flux_lo_hor, n1 * D); F(edge_up_dn_grad, 4 * n1 * D); F(edge_c12, D);
   F(ssh_values, m.nza);
-  F(sv_vals, m.nza); F(sv_dinv, N); F(sv_b, N); F(sv_r, N); F(sv_r0, N); F(sv_p, N); F(sv_v, N); F(sv_s, N); F(sv_t, N); F(sv_ph, N);
+  F(sv_vals, 16 * (N + 64)); F(sv_dinv, N + 64); F(sv_b, N + 64); F(sv_r, N + 64); F(sv_r0, N + 64); F(sv_p, N + 64); F(sv_v, N + 64); F(sv_s, N + 64); F(sv_t, N + 64);
+  F(sv_ph, N + 64); F(sv_x0, 16 * (N + 64)); F(sv_snap, N);
   F(sv_resid, 1);
 #undef F
   m.sv_info = dev_alloc<int>(4);
@@ -283,8 +293,15 @@ int fesom_gpu_set_field(const char *name, const double *in, long long count) {
 static int call_named(const char *name, int arg) {
   const DM &m = G.m;
   if (!strcmp(name, "first_step")) { G.first_step = arg; return 0; }
-  if (!strcmp(name, "solve_ssh")) { launch_solver(m, G.stream); return 0; }
+  if (!strcmp(name, "solve_ssh") || !strcmp(name, "k_solver")) return launch_solver(m, G.stream);
   if (!strcmp(name, "step")) { enqueue_step(G.stream, G.first_step); G.first_step = 0; return 0; }
+  if (!strcmp(name, "solver_snapshot")) {       // keep the pre-solve iterate so that the solve can be replayed for timing
+    return hipMemcpyAsync(m.sv_snap, m.d_eta, sizeof(double) * m.N, hipMemcpyDeviceToDevice, G.stream) != hipSuccess;
+  }
+  if (!strcmp(name, "k_solver_replay")) {
+    if (hipMemcpyAsync(m.d_eta, m.sv_snap, sizeof(double) * m.N, hipMemcpyDeviceToDevice, G.stream) != hipSuccess) return 1;
+    return launch_solver(m, G.stream);
+  }
   int fs = G.first_step;
   int rc = launch_named_dyn(m, G.stream, name, arg, fs);
   if (rc == 0) { if (!strcmp(name, "compute_vel_rhs")) G.first_step = 0; return 0; }
@@ -337,24 +354,34 @@ double fesom_gpu_last_solver_residual(void) {
   return r;
 }
 
-// Average device time of one launch of a routine group (or "step"), measured with HIP events on the
-// library's own stream; used by bench.py for the roofline object.
+// Average device time of one launch of a routine / kernel (or "step"): nrep launches are captured into one
+// hipGraph (so the host launch rate does not bound short kernels) and timed with HIP events on the library's
+// own stream.  The figure includes the ~1.5 us dependent-launch boundary of back-to-back kernels.
 int fesom_gpu_kernel_time_ms(const char *group, int nrep, double *ms_per_launch) {
   NEED_READY();
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   int fs = G.first_step;
-  if (call_named(group, 1)) return 1;          // warm-up
+  G.first_step = 0;
+  hipGraph_t g; hipGraphExec_t ge;
+  HIPCHK(hipStreamSynchronize(G.stream));
+  HIPCHK(hipStreamBeginCapture(G.stream, hipStreamCaptureModeGlobal));
+  int bad = 0;
+  for (int i = 0; i < nrep; i++) bad |= call_named(group, 1);
+  HIPCHK(hipStreamEndCapture(G.stream, &g));
+  if (bad) { hipGraphDestroy(g); return 1; }
+  HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  HIPCHK(hipGraphLaunch(ge, G.stream));        // warm-up
   HIPCHK(hipStreamSynchronize(G.stream));
   HIPCHK(hipEventRecord(e0, G.stream));
-  for (int i = 0; i < nrep; i++) if (call_named(group, 1)) return 1;
+  HIPCHK(hipGraphLaunch(ge, G.stream));
   HIPCHK(hipEventRecord(e1, G.stream));
   HIPCHK(hipEventSynchronize(e1));
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, e0, e1));
   *ms_per_launch = ms / nrep;
-  hipEventDestroy(e0); hipEventDestroy(e1);
-  (void)fs;
+  hipEventDestroy(e0); hipEventDestroy(e1); hipGraphExecDestroy(ge); hipGraphDestroy(g);
+  G.first_step = fs;
   return 0;
 }
 
@@ -376,11 +403,14 @@ void psolver_init(int *id, int *stype, int *pctype, int *pcilutype, int *iluleve
   hipMemcpy(rp, rptr, sizeof(int) * (n + 1), hipMemcpyHostToDevice);
   hipMemcpy(ci, cols, sizeof(int) * nza, hipMemcpyHostToDevice);
   m.rowptr = rp; m.colind = ci;
+  m.ssh_maxnnz = 0;
+  for (int i = 0; i < n; i++) m.ssh_maxnnz = std::max(m.ssh_maxnnz, rptr[i + 1] - rptr[i]);
   m.ssh_values = (double *)A(sizeof(double) * nza);
   hipMemcpy(m.ssh_values, vals, sizeof(double) * nza, hipMemcpyHostToDevice);
-  m.sv_vals = (double *)A(sizeof(double) * nza);
+  m.sv_vals = (double *)A(sizeof(double) * 16 * (n + 64));
   double **vecs[] = {&m.sv_dinv, &m.sv_b, &m.sv_r, &m.sv_r0, &m.sv_p, &m.sv_v, &m.sv_s, &m.sv_t, &m.sv_ph, &m.d_eta, &m.ssh_rhs};
-  for (auto v : vecs) *v = (double *)A(sizeof(double) * n);
+  for (auto v : vecs) *v = (double *)A(sizeof(double) * (n + 64));
+  m.sv_x0 = (double *)A(sizeof(double) * 16 * (n + 64));
   m.sv_info = (int *)A(16); m.sv_resid = (double *)A(8);
   solver_prepare();
   PS.n = n; PS.nza = nza; PS.ok = true;

@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/fesom_gpu.h"
 
 #define WAVE 64
@@ -18,7 +19,7 @@
 #define BLOCK (WAVE * COLS_PER_BLOCK)
 
 struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg segment, scalar loads)
-  int N, E, D, myN, myE, myD, nl, nlm1, ntr, maxk, nza, edge2D_in;
+  int N, E, D, myN, myE, myD, nl, nlm1, ntr, maxk, nza, edge2D_in, ssh_maxnnz;
   // ---- connectivity, 0-based (-1 = none)
   const int *elem_nodes;      // (3,E)
   const int *edges;           // (2,D)
@@ -47,7 +48,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   double *adv_flux_hor, *flux_lo_hor, *edge_up_dn_grad, *edge_c12;
   double *ssh_values;
   // solver workspace
-  double *sv_vals, *sv_dinv, *sv_b, *sv_r, *sv_r0, *sv_p, *sv_v, *sv_s, *sv_t, *sv_ph;
+  double *sv_vals, *sv_dinv, *sv_b, *sv_r, *sv_r0, *sv_p, *sv_v, *sv_s, *sv_t, *sv_ph, *sv_x0, *sv_snap;
   int *sv_info; double *sv_resid;
   fesom_params p;
 };
@@ -100,7 +101,7 @@ static inline int nblocks(int ncol) { return (ncol + COLS_PER_BLOCK - 1) / COLS_
 // launchers implemented in the kernel translation units
 void launch_dynamics_pre(const DM &m, hipStream_t s, int first_step);
 void launch_ssh_rhs(const DM &m, hipStream_t s);
-void launch_solver(const DM &m, hipStream_t s);
+int  launch_solver(const DM &m, hipStream_t s);
 void launch_dynamics_post(const DM &m, hipStream_t s);
 void launch_tracer(const DM &m, hipStream_t s, int tr);
 void launch_thickness(const DM &m, hipStream_t s);

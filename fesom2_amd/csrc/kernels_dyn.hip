@@ -773,6 +773,32 @@ void launch_thickness(const DM &m, hipStream_t s) {
 
 int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int first_step) {
   (void)arg;
+  // single kernels (bench.py times each one for the roofline object)
+  if (!strncmp(name, "k_", 2)) {
+    int ncol_uv = m.myE > (m.N + BLOCK - 1) / BLOCK * COLS_PER_BLOCK ? m.myE : (m.N + BLOCK - 1) / BLOCK * COLS_PER_BLOCK;
+    if (!strcmp(name, "k_vel_nodes")) { LAUNCH_COL(k_vel_nodes, m.myN, m); return 0; }
+    if (!strcmp(name, "k_pressure_bv")) { LAUNCH_COL(k_pressure_bv, m.N, m); return 0; }
+    if (!strcmp(name, "k_pgf")) { LAUNCH_COL(k_pgf, m.myE, m); return 0; }
+    if (!strcmp(name, "k_sigma_slope")) { LAUNCH_COL(k_sigma_slope, m.myN, m); return 0; }
+    if (!strcmp(name, "k_pp_node_raw")) { LAUNCH_COL(k_pp_node_raw, m.N, m); return 0; }
+    if (!strcmp(name, "k_pp_elem")) { LAUNCH_COL(k_pp_elem, m.myE, m); return 0; }
+    if (!strcmp(name, "k_pp_node_final")) { LAUNCH_COL(k_pp_node_final, m.N, m); return 0; }
+    if (!strcmp(name, "k_momadv_node")) { LAUNCH_COL(k_momadv_node, m.myN, m); return 0; }
+    if (!strcmp(name, "k_vel_rhs")) { LAUNCH_COL(k_vel_rhs, m.myE, m, 0); return 0; }
+    if (!strcmp(name, "k_visc_elem")) { LAUNCH_COL(k_visc_elem, m.E, m); return 0; }
+    if (!strcmp(name, "k_visc_node")) { LAUNCH_COL(k_visc_node, m.myN, m); return 0; }
+    if (!strcmp(name, "k_impl_visc")) { LAUNCH_COL(k_impl_visc, m.myE, m, 1, 1); return 0; }
+    if (!strcmp(name, "k_stiff_update")) { LAUNCH_FLAT(k_stiff_update, m.nza, m); return 0; }
+    if (!strcmp(name, "k_edge_transport")) { LAUNCH_COL(k_edge_transport, m.myD, m, 0); return 0; }
+    if (!strcmp(name, "k_ssh_rhs_node")) { LAUNCH_FLAT(k_ssh_rhs_node, m.myN, m); return 0; }
+    if (!strcmp(name, "k_update_vel")) { LAUNCH_COL(k_update_vel, ncol_uv, m); return 0; }
+    if (!strcmp(name, "k_hbar_node")) { LAUNCH_FLAT(k_hbar_node, m.myN, m); return 0; }
+    if (!strcmp(name, "k_dhe")) { LAUNCH_FLAT(k_dhe, m.myE, m); return 0; }
+    if (!strcmp(name, "k_vert_vel")) { LAUNCH_COL(k_vert_vel, m.myN, m); return 0; }
+    if (!strcmp(name, "k_thick_node")) { LAUNCH_COL(k_thick_node, m.N, m); return 0; }
+    if (!strcmp(name, "k_thick_elem")) { LAUNCH_COL(k_thick_elem, m.myE, m); return 0; }
+    return -1;
+  }
   if (!strcmp(name, "compute_vel_nodes")) { LAUNCH_COL(k_vel_nodes, m.myN, m); return 0; }
   if (!strcmp(name, "pressure_bv")) { LAUNCH_COL(k_pressure_bv, m.N, m); return 0; }       // includes sw_alpha_beta
   if (!strcmp(name, "sw_alpha_beta")) return 0;

@@ -413,6 +413,18 @@ void launch_tracer(const DM &m, hipStream_t s, int tr) {   // tr 0-based
 
 int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
   int tr = arg - 1;
+  if (!strncmp(name, "k_", 2)) {
+    if (!strcmp(name, "k_tr_ab_z")) { LAUNCH_COL(k_tr_ab_z, m.N, m, tr); return 0; }
+    if (!strcmp(name, "k_tr_grad_elem")) { LAUNCH_COL(k_tr_grad_elem, m.myE, m, tr); return 0; }
+    if (!strcmp(name, "k_updn_grad")) { LAUNCH_COL(k_updn_grad, m.myD, m); return 0; }
+    if (!strcmp(name, "k_flux_hor")) { LAUNCH_COL(k_flux_hor, m.myD, m, tr); return 0; }
+    if (!strcmp(name, "k_fct_lo_node")) { LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); return 0; }
+    if (!strcmp(name, "k_fct_ebnd")) { LAUNCH_COL(k_fct_ebnd, m.myE, m); return 0; }
+    if (!strcmp(name, "k_fct_node")) { LAUNCH_COL(k_fct_node, m.myN, m); return 0; }
+    if (!strcmp(name, "k_fct_edge_limit")) { LAUNCH_COL(k_fct_edge_limit, m.myD, m); return 0; }
+    if (!strcmp(name, "k_tr_update")) { LAUNCH_COL(k_tr_update, m.myN, m, tr); return 0; }
+    return -1;
+  }
   if (!strcmp(name, "init_tracers_AB")) {
     LAUNCH_COL(k_tr_ab_z, m.N, m, tr); LAUNCH_COL(k_tr_grad_elem, m.myE, m, tr); LAUNCH_COL(k_updn_grad, m.myD, m); return 0;
   }

@@ -4,18 +4,21 @@
 // ILU triangular solves are sequential, so this build keeps what defines the answer -- row scaling
 // scale[i]=1/sum|a_ij| (psolve.c:58-65,180-188), warm start x=d_eta (psolve.c:206-212), stop when
 // ||r||^2 < tol^2 with tol=1e-10 absolute on the scaled residual (bicgstab_ras.c:78,146,220), maxits 2000 --
-// and replaces the preconditioner by Jacobi on the scaled operator.  The solution agrees with the
-// reference to solver tolerance (tests), not bit for bit.
+// and replaces the preconditioner by Jacobi, applied as a column scaling: BiCGstab runs on B = A_s D^-1,
+// y = D x (D = diag of the row-scaled operator A_s), so the residual b - B y is the reference's scaled residual.
+// The solution agrees with the reference to solver tolerance (tests), not bit for bit.
 //
-// N2 is tiny (3140 rows, 21112 nnz on pi): one launch, ONE 1024-thread workgroup runs the whole Krylov loop
-// (no host round trips, no grid barrier).  The search vector lives in LDS (SpMV gathers hit LDS), the other
-// vectors are own-row and stay in L2.  Dot products use a FIXED reduction order (1024 strided partial sums,
-// then a halving tree) that the CPU oracle reproduces, so oracle and HIP agree bitwise.
+// N2 is tiny (3140 rows, 21112 nnz on pi), far too small for a multi-kernel Krylov loop (8 launches per
+// iteration): ONE launch, ONE 1024-thread workgroup runs the whole loop without host round trips or grid
+// barriers.  The operator is stored ELL-transposed ([k][row]) so that every SpMV load is a coalesced wave read
+// from L2; column indices (uint16) and the two gathered vectors p, s live in LDS when they fit (they do up to
+// ~5k rows), own-row vectors are coalesced L2 traffic.  Dot products use a FIXED reduction order (1024 strided
+// partial sums, halving tree) that the CPU oracle reproduces: oracle and HIP agree bitwise.
 #include "dev.h"
 
 #define ST 1024
 
-// tree of  part[t] += part[t+s], s = 512..1  evaluated by wave 0; lane l combines part[l+64k], k=0..15
+// tree  part[t] += part[t+s], s = 512..1  evaluated by wave 0; lane l combines part[l+64k], k=0..15
 __device__ __forceinline__ double tree16(const double *p, int l) {
   double q[16];
 #pragma unroll
@@ -31,8 +34,6 @@ __device__ __forceinline__ double tree16(const double *p, int l) {
   for (int s = 32; s >= 1; s >>= 1) x = x + __shfl_down(x, s, 64);
   return x;                                                 // valid in lane 0
 }
-
-// reduce up to two partial sums per thread; result broadcast through LDS
 __device__ __forceinline__ void reduce2(double a, double b, double *red, double *out, double &ra, double &rb) {
   int t = threadIdx.x;
   red[t] = a; red[ST + t] = b;
@@ -45,95 +46,282 @@ __device__ __forceinline__ void reduce2(double a, double b, double *red, double 
   ra = out[0]; rb = out[1];
 }
 
-__global__ void __launch_bounds__(ST) k_solver(DM m, int maxits, double tol2, int ph_in_lds) {
+// IN_LDS is a template parameter on purpose: a run-time select between an LDS and a global pointer would turn every
+// gather into a flat_load (waits on both counters, serialises the SpMV).
+template <int W, bool IN_LDS>
+__device__ __forceinline__ void solver_body(const DM &m, int maxits, double tol2, int NP, double *red, double *out, double *pl, double *sl,
+                                            unsigned short *cl);
+
+template <int W>
+__global__ void __launch_bounds__(ST) k_solver_lds(DM m, int maxits, double tol2, int NP) {
   extern __shared__ double lds[];
-  double *red = lds;                 // 2*ST
-  double *out = lds + 2 * ST;        // 2 (+pad)
-  double *ph = ph_in_lds ? (lds + 2 * ST + 8) : m.sv_ph;
+  double *pl = lds + 2 * ST + 8, *sl = pl + NP;
+  solver_body<W, true>(m, maxits, tol2, NP, lds, lds + 2 * ST, pl, sl, (unsigned short *)(sl + NP));
+}
+template <int W>
+__global__ void __launch_bounds__(ST) k_solver_glb(DM m, int maxits, double tol2, int NP) {
+  extern __shared__ double lds[];
+  solver_body<W, false>(m, maxits, tol2, NP, lds, lds + 2 * ST, m.sv_ph, m.sv_s, (unsigned short *)m.sv_x0);
+}
+
+template <int W, bool IN_LDS>
+__device__ __forceinline__ void solver_body(const DM &m, int maxits, double tol2, int NP, double *red, double *out, double *pl, double *sl,
+                                            unsigned short *cl) {
+  // red: 2*ST, out: 8, pl: NP (p; scratch for D^-1 during setup), sl: NP (s; scratch for y0), cl: W*NP column indices [k][row]
   const int t = threadIdx.x, n = m.myN;
   const int *rp = m.rowptr, *ci = m.colind;
-  double *vals = m.sv_vals, *dinv = m.sv_dinv, *b = m.sv_b, *r = m.sv_r, *r0 = m.sv_r0, *pv = m.sv_p, *v = m.sv_v, *s = m.sv_s,
-         *tv = m.sv_t, *x = m.d_eta;
-  // row scaling + Jacobi diagonal
-  for (int i = t; i < n; i += ST) {
-    double tmp = 0.;
-    for (int j = rp[i]; j < rp[i + 1]; j++) tmp += fabs(m.ssh_values[j]);
-    double sc = 1. / tmp;
-    for (int j = rp[i]; j < rp[i + 1]; j++) vals[j] = m.ssh_values[j] * sc;
-    b[i] = m.ssh_rhs[i] * sc;
-    dinv[i] = 1.0 / vals[rp[i]];
-    ph[i] = x[i];
+  double *Bg = m.sv_vals;                                // ELL [k][row]
+  double *r = m.sv_r, *r0 = m.sv_r0, *y = m.sv_p, *v = m.sv_v, *tv = m.sv_t, *b = m.sv_b, *diagg = m.sv_dinv, *x = m.d_eta;
+  // ---- setup: row scaling (psolve.c:58-65), Jacobi diagonal
+  for (int i = t; i < NP; i += ST) {
+    double diag = 1.0, sc = 0.0;
+    int j0 = 0, j1 = 0;
+    if (i < n) {
+      j0 = rp[i]; j1 = rp[i + 1];
+      double tmp = 0.;
+      for (int j = j0; j < j1; j++) tmp += fabs(m.ssh_values[j]);
+      sc = 1. / tmp;
+      b[i] = m.ssh_rhs[i] * sc;
+      diag = m.ssh_values[j0] * sc;                        // first entry of a row is the diagonal (oce_ale.F90:1128-1151)
+      diagg[i] = diag;
+    }
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      bool in = (j0 + k < j1);
+      Bg[k * NP + i] = in ? m.ssh_values[j0 + k] * sc : 0.0;
+      cl[k * NP + i] = (unsigned short)(in ? ci[j0 + k] : (i < n ? i : 0));
+    }
+    pl[i] = 1.0 / diag;                                    // D^-1
+    sl[i] = (i < n) ? x[i] * diag : 0.0;                   // y0 = D x0
   }
   __syncthreads();
-  double prr = 0.0, prho = 0.0;
-  for (int i = t; i < n; i += ST) {
+  double prr = 0.0;
+  for (int i = t; i < NP; i += ST) {
     double a = 0.0;
-    for (int j = rp[i]; j < rp[i + 1]; j++) a = a + vals[j] * ph[ci[j]];
-    double ri = b[i] - a;
-    r[i] = ri; r0[i] = ri; pv[i] = 0.0; v[i] = 0.0;
-    prr = prr + ri * ri; prho = prho + ri * ri;
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      int c = cl[k * NP + i];
+      double bk = Bg[k * NP + i] * pl[c];                  // B = A_s D^-1
+      Bg[k * NP + i] = bk;
+      a = a + bk * sl[c];
+    }
+    if (i < n) {
+      double ri = b[i] - a;
+      r[i] = ri; r0[i] = ri; v[i] = 0.0; y[i] = sl[i];
+      prr = prr + ri * ri;
+    }
   }
+  __syncthreads();
+  for (int i = t; i < NP; i += ST) pl[i] = 0.0;           // p = 0
   double rr, rho_new;
-  reduce2(prr, prho, red, out, rr, rho_new);
+  reduce2(prr, prr, red, out, rr, rho_new);
   double rho = 1.0, alpha = 1.0, omega = 1.0;
   int it = 0;
   while (rr >= tol2 && it < maxits) {
     double beta = (rho_new / rho) * (alpha / omega);
-    for (int i = t; i < n; i += ST) {
-      double pi = r[i] + beta * (pv[i] - omega * v[i]);
-      pv[i] = pi;
-      ph[i] = pi * dinv[i];
-    }
+    for (int i = t; i < n; i += ST) pl[i] = r[i] + beta * (pl[i] - omega * v[i]);
     __syncthreads();
     double p1 = 0.0;
     for (int i = t; i < n; i += ST) {
       double a = 0.0;
-      for (int j = rp[i]; j < rp[i + 1]; j++) a = a + vals[j] * ph[ci[j]];
+#pragma unroll
+      for (int k = 0; k < W; k++) a = a + Bg[k * NP + i] * pl[cl[k * NP + i]];
       v[i] = a;
       p1 = p1 + r0[i] * a;
     }
     double r0v, dummy;
     reduce2(p1, 0.0, red, out, r0v, dummy);
     alpha = rho_new / r0v;
-    for (int i = t; i < n; i += ST) {
-      double si = r[i] - alpha * v[i];
-      s[i] = si;
-      x[i] = x[i] + alpha * ph[i];
-    }
-    // own rows only: every SpMV read of ph finished before reduce2's barriers
-    for (int i = t; i < n; i += ST) ph[i] = s[i] * dinv[i];
+    for (int i = t; i < n; i += ST) sl[i] = r[i] - alpha * v[i];
     __syncthreads();
     double ptt = 0.0, pts = 0.0;
     for (int i = t; i < n; i += ST) {
       double a = 0.0;
-      for (int j = rp[i]; j < rp[i + 1]; j++) a = a + vals[j] * ph[ci[j]];
+#pragma unroll
+      for (int k = 0; k < W; k++) a = a + Bg[k * NP + i] * sl[cl[k * NP + i]];
       tv[i] = a;
-      ptt = ptt + a * a; pts = pts + a * s[i];
+      ptt = ptt + a * a; pts = pts + a * sl[i];
     }
     double tt, ts;
     reduce2(ptt, pts, red, out, tt, ts);
     omega = (tt > 0.0) ? ts / tt : 0.0;
-    prr = 0.0; prho = 0.0;
+    double prho = 0.0;
+    prr = 0.0;
     for (int i = t; i < n; i += ST) {
-      x[i] = x[i] + omega * ph[i];
-      double ri = s[i] - omega * tv[i];
+      double si = sl[i];
+      double ri = si - omega * tv[i];
       r[i] = ri;
-      prr = prr + ri * ri; prho = prho + r0[i] * ri;
+      y[i] = (y[i] + alpha * pl[i]) + omega * si;
+      prho = prho + r0[i] * ri;
+      prr = prr + ri * ri;
     }
     rho = rho_new;
     reduce2(prr, prho, red, out, rr, rho_new);
     it++;
   }
+  for (int i = t; i < n; i += ST) x[i] = y[i] * (1.0 / diagg[i]);
+  if (t == 0) { m.sv_info[0] = it; m.sv_resid[0] = sqrt(rr); }
+}
+
+// ---- small systems (n <= ST*ROWS): own-row vectors r, r0, v, t, y stay in REGISTERS (row loop unrolled), so an
+// iteration reads only the ELL operator from L2 (all ROWS*W loads of a thread in flight at once).
+template <int W, int ROWS>
+__global__ void __launch_bounds__(ST) k_solver_small(DM m, int maxits, double tol2, int NP) {
+  extern __shared__ double lds[];
+  double *red = lds, *out = lds + 2 * ST, *pl = lds + 2 * ST + 8, *sl = pl + NP;
+  unsigned short *cl = (unsigned short *)(sl + NP);      // ST*ROWS*W indices
+  const int t = threadIdx.x, n = m.myN;
+  const int *rp = m.rowptr, *ci = m.colind;
+  double *Bg = m.sv_vals, *x = m.d_eta;
+  double r[ROWS], r0[ROWS], v[ROWS], y[ROWS], dg[ROWS];
+#define EIDX(k, q) (((k) * ROWS + (q)) * ST + t)      /* ELL [k][q][t]: compile-time strides -> scalar address offsets */
+#pragma unroll
+  for (int q = 0; q < ROWS; q++) {
+    int i = t + q * ST;
+    double diag = 1.0, sc = 0.0;
+    int j0 = 0, j1 = 0;
+    if (i < n) {
+      j0 = rp[i]; j1 = rp[i + 1];
+      double tmp = 0.;
+      for (int j = j0; j < j1; j++) tmp += fabs(m.ssh_values[j]);
+      sc = 1. / tmp;
+      m.sv_b[i] = m.ssh_rhs[i] * sc;
+      diag = m.ssh_values[j0] * sc;
+      m.sv_dinv[i] = diag;
+    }
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      bool in = (j0 + k < j1);
+      Bg[EIDX(k, q)] = in ? m.ssh_values[j0 + k] * sc : 0.0;
+      cl[EIDX(k, q)] = (unsigned short)(in ? ci[j0 + k] : (i < n ? i : 0));
+    }
+    if (i < NP) {
+      pl[i] = 1.0 / diag;
+      sl[i] = (i < n) ? x[i] * diag : 0.0;
+    }
+  }
+  __syncthreads();
+  double prr = 0.0;
+#pragma unroll
+  for (int q = 0; q < ROWS; q++) {
+    int i = t + q * ST;
+    r[q] = 0.0; r0[q] = 0.0; v[q] = 0.0; y[q] = 0.0; dg[q] = 1.0;
+    {
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < W; k++) {
+        int c = cl[EIDX(k, q)];
+        double bk = Bg[EIDX(k, q)] * pl[c];
+        Bg[EIDX(k, q)] = bk;
+        a = a + bk * sl[c];
+      }
+      if (i < n) {
+        double ri = m.sv_b[i] - a;
+        r[q] = ri; r0[q] = ri; y[q] = sl[i]; dg[q] = m.sv_dinv[i];
+        prr = prr + ri * ri;
+      }
+    }
+    asm volatile("" ::: "memory");
+  }
+  __syncthreads();
+  for (int i = t; i < NP; i += ST) pl[i] = 0.0;
+  double rr, rho_new;
+  reduce2(prr, prr, red, out, rr, rho_new);
+  double rho = 1.0, alpha = 1.0, omega = 1.0;
+  int it = 0;
+  while (rr >= tol2 && it < maxits) {
+    double beta = (rho_new / rho) * (alpha / omega);
+#pragma unroll
+    for (int q = 0; q < ROWS; q++) { int i = t + q * ST; if (i < n) pl[i] = r[q] + beta * (pl[i] - omega * v[q]); }
+    __syncthreads();
+    double p1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < ROWS; q++) {
+      int i = t + q * ST;
+      if (i < n) {
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < W; k++) a = a + Bg[EIDX(k, q)] * pl[cl[EIDX(k, q)]];
+        v[q] = a;
+        p1 = p1 + r0[q] * a;
+      }
+      asm volatile("" ::: "memory");      // one row's W loads in flight at a time: keeps the kernel inside 128 VGPRs
+    }
+    double r0v, dummy;
+    reduce2(p1, 0.0, red, out, r0v, dummy);
+    alpha = rho_new / r0v;
+#pragma unroll
+    for (int q = 0; q < ROWS; q++) { int i = t + q * ST; if (i < n) sl[i] = r[q] - alpha * v[q]; }
+    __syncthreads();
+    double ptt = 0.0, pts = 0.0, tq[ROWS];
+#pragma unroll
+    for (int q = 0; q < ROWS; q++) {
+      int i = t + q * ST;
+      tq[q] = 0.0;
+      if (i < n) {
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < W; k++) a = a + Bg[EIDX(k, q)] * sl[cl[EIDX(k, q)]];
+        tq[q] = a;
+        ptt = ptt + a * a; pts = pts + a * sl[i];
+      }
+      asm volatile("" ::: "memory");
+    }
+    double tt, ts;
+    reduce2(ptt, pts, red, out, tt, ts);
+    omega = (tt > 0.0) ? ts / tt : 0.0;
+    double prho = 0.0;
+    prr = 0.0;
+#pragma unroll
+    for (int q = 0; q < ROWS; q++) {
+      int i = t + q * ST;
+      if (i < n) {
+        double si = sl[i];
+        double ri = si - omega * tq[q];
+        r[q] = ri;
+        y[q] = (y[q] + alpha * pl[i]) + omega * si;
+        prho = prho + r0[q] * ri;
+        prr = prr + ri * ri;
+      }
+    }
+    rho = rho_new;
+    reduce2(prr, prho, red, out, rr, rho_new);
+    it++;
+  }
+#pragma unroll
+  for (int q = 0; q < ROWS; q++) { int i = t + q * ST; if (i < n) x[i] = y[q] * (1.0 / dg[q]); }
   if (t == 0) { m.sv_info[0] = it; m.sv_resid[0] = sqrt(rr); }
 }
 
 void solver_prepare() {
   static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void *)k_solver, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)k_solver_lds<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_solver_lds<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_solver_small<10, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
 }
-void launch_solver(const DM &m, hipStream_t s) {
-  size_t need = (size_t)(2 * ST + 8 + m.myN) * sizeof(double);
-  int in_lds = need <= 150 * 1024;
-  size_t shm = in_lds ? need : (size_t)(2 * ST + 8) * sizeof(double);
-  hipLaunchKernelGGL(k_solver, dim3(1), dim3(ST), shm, s, m, 2000, 1e-10 * 1e-10, in_lds);
+// Returns non-zero if the operator is wider than the widest instantiated ELL kernel.
+int launch_solver(const DM &m, hipStream_t s) {
+  int W = m.ssh_maxnnz <= 10 ? 10 : 16;
+  if (m.ssh_maxnnz > 16 || m.myN >= 65536) return 1;     // uint16 columns / ELL width limits of this round
+  int NP = (m.myN + 63) / 64 * 64;
+  size_t fixed = (size_t)(2 * ST + 8) * sizeof(double);
+  size_t need = fixed + (size_t)NP * (2 * sizeof(double) + W * sizeof(unsigned short));
+  int in_lds = need <= 158 * 1024;
+  size_t shm = in_lds ? need : fixed;
+  static int dbg_maxits = getenv("FESOM_SOLVER_MAXITS") ? atoi(getenv("FESOM_SOLVER_MAXITS")) : 2000;   // diagnostics only
+  const double tol2 = 1e-10 * 1e-10;
+  size_t shm_small = fixed + (size_t)NP * 2 * sizeof(double) + (size_t)ST * 4 * 10 * sizeof(unsigned short);
+  if (W == 10 && NP <= 4 * ST && shm_small <= 158 * 1024 && getenv("FESOM_GPU_SMALL_SOLVER")) {   // experimental: slower on gfx950 (register spills)
+    hipLaunchKernelGGL((k_solver_small<10, 4>), dim3(1), dim3(ST), shm_small, s, m, dbg_maxits, tol2, NP);
+  } else if (in_lds) {
+    if (W == 10) hipLaunchKernelGGL(k_solver_lds<10>, dim3(1), dim3(ST), shm, s, m, dbg_maxits, tol2, NP);
+    else hipLaunchKernelGGL(k_solver_lds<16>, dim3(1), dim3(ST), shm, s, m, dbg_maxits, tol2, NP);
+  } else {
+    if (W == 10) hipLaunchKernelGGL(k_solver_glb<10>, dim3(1), dim3(ST), shm, s, m, dbg_maxits, tol2, NP);
+    else hipLaunchKernelGGL(k_solver_glb<16>, dim3(1), dim3(ST), shm, s, m, dbg_maxits, tol2, NP);
+  }
+  return 0;
 }

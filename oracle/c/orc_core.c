@@ -75,9 +75,9 @@ double orc_solver_residual(void) { return C_.solver_resid; }
 /* ---- SSH solve.  Boundary: solve_ssh_ale src/oce_ale.F90:2210-2344 -> psolve src/psolve.c:152-221.
  * Row scaling scale[i]=1/sum_j|a_ij| and y=rhs*scale, warm start x=d_eta, and the stopping rule
  * ||r||^2 < tol^2 (tol=1e-10 absolute on the row-scaled residual, lib/parms/src/bicgstab_ras.c:78,146,220)
- * follow the reference.  The preconditioner is this build's GPU design (Jacobi on the scaled operator
- * instead of pARMS' RAS+ILU(2), which is sequential): the solution agrees with the reference to the
- * solver tolerance, not bit for bit.  Dot products use the fixed reduction order of the HIP kernel
+ * follow the reference.  The preconditioner is this build's GPU design (Jacobi, applied as the column scaling
+ * B = A_s D^-1, y = D x, instead of pARMS' sequential RAS+ILU(2)): the solution agrees with the reference to
+ * the solver tolerance, not bit for bit.  Dot products use the fixed reduction order of the HIP kernel
  * (SOLVER_T partial sums with stride SOLVER_T, then a halving tree) so that oracle == HIP bitwise. */
 #define SOLVER_T 1024
 static double dot_fixed(const double *x, const double *y, int n) {
@@ -95,44 +95,48 @@ void orc_solve_ssh(void) {
   int n = C_.m.myDim_nod2D;
   const int *rp = C_.m.ssh_rowptr, *ci = C_.m.ssh_colind_loc;
   int off = rp[0];
-  double *vals = malloc(sizeof(double) * C_.m.ssh_nza), *dinv = malloc(sizeof(double) * n * 9);
-  double *b = dinv + n, *r = b + n, *r0 = r + n, *pv = r0 + n, *v = pv + n, *s = v + n, *t = s + n, *ph = t + n;
+  double *B = malloc(sizeof(double) * C_.m.ssh_nza), *diag = malloc(sizeof(double) * n * 10);
+  double *dinv = diag + n, *b = dinv + n, *r = b + n, *r0 = r + n, *pv = r0 + n, *v = pv + n, *s = v + n, *t = s + n, *y = t + n;
   double *x = C_.d_eta;
   for (int i = 0; i < n; i++) {
     double tmp = 0.;
     for (int j = rp[i] - off; j < rp[i + 1] - off; j++) tmp += fabs(C_.ssh_values[j]);
     double sc = 1. / tmp;
-    for (int j = rp[i] - off; j < rp[i + 1] - off; j++) vals[j] = C_.ssh_values[j] * sc;
+    for (int j = rp[i] - off; j < rp[i + 1] - off; j++) B[j] = C_.ssh_values[j] * sc;
     b[i] = C_.ssh_rhs[i] * sc;
-    dinv[i] = 1.0 / vals[rp[i] - off];        /* first entry of a row is the diagonal (oce_ale.F90:1128-1151) */
+    diag[i] = B[rp[i] - off];                   /* first entry of a row is the diagonal (oce_ale.F90:1128-1151) */
+    dinv[i] = 1.0 / diag[i];
+    y[i] = x[i] * diag[i];
   }
-#define SPMV(out, in) for (int i = 0; i < n; i++) { double a = 0.0; for (int j = rp[i] - off; j < rp[i + 1] - off; j++) a = a + vals[j] * (in)[ci[j] - 1]; (out)[i] = a; }
+  for (int i = 0; i < n; i++)
+    for (int j = rp[i] - off; j < rp[i + 1] - off; j++) B[j] = B[j] * dinv[ci[j] - 1];
+#define SPMV(out, in) for (int i = 0; i < n; i++) { double a = 0.0; for (int j = rp[i] - off; j < rp[i + 1] - off; j++) a = a + B[j] * (in)[ci[j] - 1]; (out)[i] = a; }
   const double tol2 = 1e-10 * 1e-10;
   const int maxits = 2000;
-  SPMV(r, x);
+  SPMV(r, y);
   for (int i = 0; i < n; i++) { r[i] = b[i] - r[i]; r0[i] = r[i]; pv[i] = 0.0; v[i] = 0.0; }
   double rho = 1.0, alpha = 1.0, omega = 1.0;
   double rr = dot_fixed(r, r, n);
+  double rho_new = rr;
   int it = 0;
   while (rr >= tol2 && it < maxits) {
-    double rho_new = dot_fixed(r0, r, n);
     double beta = (rho_new / rho) * (alpha / omega);
     for (int i = 0; i < n; i++) pv[i] = r[i] + beta * (pv[i] - omega * v[i]);
-    for (int i = 0; i < n; i++) ph[i] = pv[i] * dinv[i];
-    SPMV(v, ph);
+    SPMV(v, pv);
     alpha = rho_new / dot_fixed(r0, v, n);
-    for (int i = 0; i < n; i++) { s[i] = r[i] - alpha * v[i]; x[i] = x[i] + alpha * ph[i]; }
-    for (int i = 0; i < n; i++) ph[i] = s[i] * dinv[i];
-    SPMV(t, ph);
+    for (int i = 0; i < n; i++) s[i] = r[i] - alpha * v[i];
+    SPMV(t, s);
     double tt = dot_fixed(t, t, n), ts = dot_fixed(t, s, n);
     omega = (tt > 0.0) ? ts / tt : 0.0;
-    for (int i = 0; i < n; i++) { x[i] = x[i] + omega * ph[i]; r[i] = s[i] - omega * t[i]; }
+    for (int i = 0; i < n; i++) { y[i] = (y[i] + alpha * pv[i]) + omega * s[i]; r[i] = s[i] - omega * t[i]; }
     rho = rho_new;
     rr = dot_fixed(r, r, n);
+    rho_new = dot_fixed(r0, r, n);
     it++;
   }
+  for (int i = 0; i < n; i++) x[i] = y[i] * (1.0 / diag[i]);
   C_.solver_iters = it; C_.solver_resid = sqrt(rr);
-  free(vals); free(dinv);
+  free(B); free(diag);
 }
 
 /* oce_timestep_ale sequence for the supported options: src/oce_ale.F90:2556-2767 (+ fvom_main.F90:216) */
