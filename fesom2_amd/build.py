@@ -30,7 +30,12 @@ def build(force=False, verbose=True):
         obj = os.path.join(objdir, s.rsplit(".", 1)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", src, "-o", obj]
+            if s.endswith(".hip"):
+                cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+            else:
+                # host-only geometry code: g++ keeps sin/cos/asin/atan2 as separate glibc calls, which is what the
+                # reference's Fortran does; clang's sincos folding changes 7 of 6280 coordinates in the last bit
+                cmd = [os.environ.get("CXX", "g++"), "-O2", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
