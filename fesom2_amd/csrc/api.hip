@@ -16,11 +16,14 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg);
 void solver_prepare();
 
 namespace {
-struct Field { void *p; size_t count; };
+struct Field { void *p; size_t count; int slabs; };   // slabs>1: one slab of `count` values per tracer
 struct Ctx {
   bool ready = false;
   DM m;
   hipStream_t stream = nullptr;
+  hipStream_t side[3] = {nullptr, nullptr, nullptr};   // forked branches of the step DAG
+  int cur_tr = 0;
+  bool serial = false;
   std::map<std::string, Field> fields;
   std::vector<void *> allocs;
   int first_step = 1;
@@ -48,10 +51,22 @@ const double *dev_upload_d(const double *h, size_t n) {
   if (p && n) hipMemcpy(p, h, n * sizeof(double), hipMemcpyHostToDevice);
   return p;
 }
-double *field(const char *name, size_t n) {
-  double *p = dev_alloc<double>(n);
-  G.fields[name] = Field{p, n};
+double *field(const char *name, size_t n, int slabs = 1) {
+  double *p = dev_alloc<double>(n * slabs);
+  G.fields[name] = Field{p, n, slabs};
   return p;
+}
+// static ELL column pattern [k][NP] (uint16), padding entries point to the row itself (their B entry is 0)
+std::vector<unsigned short> ell_cols(const int *rp, const int *ci, int n, int maxnnz) {
+  int W = maxnnz <= 10 ? 10 : 16, NP = (n + 63) / 64 * 64;
+  std::vector<unsigned short> c((size_t)W * NP, 0);
+  for (int i = 0; i < NP; i++)
+    for (int k = 0; k < W; k++) {
+      unsigned short v = (unsigned short)(i < n ? i : 0);
+      if (i < n && rp[i] + k < rp[i + 1]) v = (unsigned short)ci[rp[i] + k];
+      c[(size_t)k * NP + i] = v;
+    }
+  return c;
 }
 std::vector<int> minus1(const int *a, size_t n) {
   std::vector<int> v(n);
@@ -69,10 +84,77 @@ void enqueue_step(hipStream_t s, int first_step) {
   launch_thickness(m, s);                    // update_thickness_ale
 }
 
+// One step as a DAG over 4 streams (captured into one hipGraph).  pi is latency-bound (42+ dependent launches, each a
+// few thousand wavefronts), so independent branches run concurrently: the four pre-solver branches of the momentum
+// equation, the tracer preparation of T and S (hidden under the SSH solve) and the T and S advection chains.
+struct Dag {
+  std::vector<hipEvent_t> evs;
+  size_t next = 0;
+  void reset() { next = 0; }                         // eager replay: the same events are re-recorded every step
+  hipEvent_t ev() {
+    if (next == evs.size()) { hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming); evs.push_back(e); }
+    return evs[next++];
+  }
+  void dep(hipStream_t to, hipStream_t from) { hipEvent_t e = ev(); hipEventRecord(e, from); hipStreamWaitEvent(to, e, 0); }
+  ~Dag() { for (auto e : evs) hipEventDestroy(e); }
+};
+int K(hipStream_t s, const char *k, int arg = 0, int fs = 0) {
+  int rc = launch_named_dyn(G.m, s, k, arg, fs);
+  if (rc < 0) rc = launch_named_tra(G.m, s, k, arg);
+  return rc;
+}
+void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d) {
+  const DM &m = G.m;
+  hipStream_t s1 = G.side[0], s2 = G.side[1], s3 = G.side[2];
+  d.dep(s1, s0); d.dep(s2, s0); d.dep(s3, s0);
+  // --- pre-solver momentum branches
+  K(s0, "k_vel_nodes");
+  K(s1, "k_pressure_bv");
+  d.dep(s0, s1);                                   // PP mixing needs Unode (s0) and bvfreq (s1)
+  d.dep(s3, s1);                                   // sigma/slope needs sw_alpha/beta, bvfreq
+  K(s1, "k_pgf");
+  K(s2, "k_momadv_node");
+  d.dep(s1, s2);
+  K(s1, "k_vel_rhs", 0, first_step);
+  K(s3, "k_visc_elem"); K(s3, "k_visc_node");
+  hipEvent_t ev_visc = d.ev(); hipEventRecord(ev_visc, s3);
+  K(s3, "k_sigma_slope");                          // leaf of this step (consumed by GM/Redi/KPP only)
+  if (m.p.mix_scheme == 2) { K(s0, "k_pp_node_raw"); K(s0, "k_pp_elem"); K(s0, "k_pp_node_final"); }
+  // tracer preparation: only needs the tracers -> overlaps everything up to vert_vel_ale (incl. the SSH solve)
+  for (int tr = 0; tr < m.ntr; tr++) {
+    hipStream_t st = (tr % 2 == 0) ? s2 : s3;
+    K(st, "k_tr_ab", tr + 1); K(st, "k_tr_grad_elem", tr + 1); K(st, "k_updn_grad", tr + 1);
+  }
+  d.dep(s0, s1); hipStreamWaitEvent(s0, ev_visc, 0);
+  K(s0, "k_impl_visc");
+  if (m.p.i_vert_visc) K(s0, "k_thomas_visc");
+  d.dep(s1, s0);
+  if (m.p.which_ale != 0) K(s1, "k_stiff_update");
+  K(s0, "k_edge_transport");
+  K(s0, "k_ssh_rhs_node");
+  d.dep(s0, s1);
+  launch_solver(m, s0);
+  K(s0, "k_update_vel"); K(s0, "k_edge_transport1"); K(s0, "k_hbar_node");
+  d.dep(s1, s0);
+  K(s1, "k_dhe");
+  K(s0, "k_vert_vel");
+  // --- tracer chains, one stream each (T on s2, S on s3, further tracers alternate)
+  d.dep(s2, s0); d.dep(s3, s0);
+  for (int tr = 0; tr < m.ntr; tr++) {
+    hipStream_t st = (tr % 2 == 0) ? s2 : s3;
+    K(st, "k_tr_z", tr + 1); K(st, "k_flux_hor", tr + 1); K(st, "k_fct_lo_node", tr + 1); K(st, "k_fct_ebnd", tr + 1);
+    K(st, "k_fct_node", tr + 1); K(st, "k_fct_edge_limit", tr + 1); K(st, "k_tr_update", tr + 1);
+    if (m.p.with_diffusion && m.p.i_vert_diff) K(st, "k_thomas_tracer", tr + 1);
+  }
+  d.dep(s0, s1); d.dep(s0, s2); d.dep(s0, s3);
+  launch_thickness(m, s0);
+}
+
 int build_graph(int which) {
   hipGraph_t g;
+  Dag d;                                            // events must outlive the capture
   HIPCHK(hipStreamBeginCapture(G.stream, hipStreamCaptureModeGlobal));
-  enqueue_step(G.stream, which);
+  if (G.serial) enqueue_step(G.stream, which); else enqueue_step_dag(G.stream, which, d);
   HIPCHK(hipStreamEndCapture(G.stream, &g));
   HIPCHK(hipGraphInstantiate(&G.graph[which], g, nullptr, nullptr, 0));
   hipGraphDestroy(g);
@@ -90,6 +172,7 @@ int fesom_gpu_finalize(void) {
   for (void *p : G.allocs) hipFree(p);
   G.allocs.clear(); G.fields.clear();
   if (G.stream) { hipStreamDestroy(G.stream); G.stream = nullptr; }
+  for (int i = 0; i < 3; i++) if (G.side[i]) { hipStreamDestroy(G.side[i]); G.side[i] = nullptr; }
   G.ready = false;
   return 0;
 }
@@ -114,7 +197,11 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     HIPCHK(hipSetDevice(dev));
   }
   HIPCHK(hipStreamCreate(&G.stream));
-  G.use_graph = getenv("FESOM_GPU_NO_GRAPH") == nullptr;
+  for (int i = 0; i < 3; i++) HIPCHK(hipStreamCreateWithFlags(&G.side[i], hipStreamNonBlocking));
+  G.serial = getenv("FESOM_GPU_SERIAL") != nullptr;
+  // Measured on MI355X/ROCm 7.2 (pi): eager 4-stream DAG 0.80 ms/step, hipGraph of the same DAG 0.86, serial chain 0.90
+  // (graph replay serialises most branches; kernels are >= 5 us so the host launch rate is not the limit).
+  G.use_graph = getenv("FESOM_GPU_GRAPH") != nullptr;
   DM &m = G.m;
   memset(&m, 0, sizeof(m));
   m.p = *par;
@@ -170,6 +257,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     m.rowptr = dev_upload(rp); m.colind = dev_upload(ci);
     m.ssh_maxnnz = 0;
     for (int i = 0; i < m.myN; i++) m.ssh_maxnnz = std::max(m.ssh_maxnnz, rp[i + 1] - rp[i]);
+    m.sv_cols = (unsigned short *)dev_upload(ell_cols(rp.data(), ci.data(), m.myN, m.ssh_maxnnz));
     std::vector<std::vector<std::pair<int, double>>> lists(m.nza);
     std::vector<int> pos(N, -1);
     for (int e = 0; e < m.myD; e++)
@@ -205,22 +293,26 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   (void)EX;
   // ---- fields
 #define F(f, c) m.f = field(#f, c)
+#define FT(f, c) m.f = field(#f, c, m.ntr)
   F(tr_arr, n1 * N * m.ntr); F(tr_arr_old, n1 * N * m.ntr);
   F(density_m_rho0, n1 * N); F(hnode, n1 * N); F(hnode_new, n1 * N); F(Z_3d_n, n1 * N); F(sw_alpha, n1 * N); F(sw_beta, n1 * N);
-  F(del_ttf, n1 * N); F(fct_LO, n1 * N); F(fct_ttf_max, n1 * N); F(fct_ttf_min, n1 * N); F(fct_plus, n1 * N); F(fct_minus, n1 * N); F(Ki, n1 * N);
+  FT(del_ttf, n1 * N); FT(fct_LO, n1 * N); FT(fct_ttf_max, n1 * N); FT(fct_ttf_min, n1 * N); FT(fct_plus, n1 * N); FT(fct_minus, n1 * N); F(Ki, n1 * N);
   F(bvfreq, nl * N); F(hpressure, nl * N); F(zbar_3d_n, nl * N); F(Wvel, nl * N); F(Wvel_e, nl * N); F(Wvel_i, nl * N); F(CFL_z, nl * N);
-  F(Kv, nl * N); F(tr_z, nl * N); F(adv_flux_ver, nl * N);
+  F(Kv, nl * N); FT(tr_z, nl * N); FT(adv_flux_ver, nl * N);
   F(Unode, 2 * n1 * N); F(Unode_rhs, 2 * n1 * N); F(sigma_xy, 2 * n1 * N); F(neutral_slope, 3 * n1 * N); F(slope_tapered, 3 * n1 * N); F(U_c, 2 * n1 * N);
   F(eta_n, N); F(d_eta, N); F(ssh_rhs, N); F(ssh_rhs_old, N); F(hbar, N); F(hbar_old, N); F(MLD1, N); F(MLD2, N);
   F(heat_flux, N); F(water_flux, N); F(virtual_salt, N); F(relax_salt, N); F(real_salt_flux, N);
-  F(UV, 2 * n1 * E); F(UV_rhs, 2 * n1 * E); F(UV_rhsAB, 2 * n1 * E); F(tr_xy, 2 * n1 * E); F(tr_xy_ab, 2 * n1 * E); F(U_b, 2 * n1 * E);
-  F(fct_ebnd, 2 * n1 * E); F(pgf_x, n1 * E); F(pgf_y, n1 * E); F(helem, n1 * E); F(Av, nl * E); F(dhe, E); F(stress_surf, 2 * E);
-  F(adv_flux_hor, n1 * D); F(flux_lo_hor, n1 * D); F(edge_up_dn_grad, 4 * n1 * D); F(edge_c12, D);
+  F(UV, 2 * n1 * E); F(UV_rhs, 2 * n1 * E); F(UV_rhsAB, 2 * n1 * E); FT(tr_xy, 2 * n1 * E); FT(tr_xy_ab, 2 * n1 * E); F(U_b, 2 * n1 * E);
+  FT(fct_ebnd, 2 * n1 * E); F(pgf_x, n1 * E); F(pgf_y, n1 * E); F(helem, n1 * E); F(Av, nl * E); F(dhe, E); F(stress_surf, 2 * E);
+  FT(adv_flux_hor, n1 * D); FT(flux_lo_hor, n1 * D); FT(edge_up_dn_grad, 4 * n1 * D); F(edge_c12, D);
   F(ssh_values, m.nza);
+  { size_t mx = n1 * std::max(N, E); F(th_a, mx); F(th_b, mx); F(th_c, mx); F(th_r1, mx); F(th_r2, mx); }
+  FT(tt_a, n1 * N); FT(tt_b, n1 * N); FT(tt_c, n1 * N); FT(tt_r, n1 * N);
   F(sv_vals, 16 * (N + 64)); F(sv_dinv, N + 64); F(sv_b, N + 64); F(sv_r, N + 64); F(sv_r0, N + 64); F(sv_p, N + 64); F(sv_v, N + 64); F(sv_s, N + 64); F(sv_t, N + 64);
   F(sv_ph, N + 64); F(sv_x0, 16 * (N + 64)); F(sv_snap, N);
   F(sv_resid, 1);
 #undef F
+#undef FT
   m.sv_info = dev_alloc<int>(4);
   for (auto &kv : G.fields) if (!kv.second.p) { G.err = "device allocation failed"; return 1; }
   HIPCHK(hipMemcpy(m.ssh_values, d->ssh_values, sizeof(double) * m.nza, hipMemcpyHostToDevice));
@@ -234,6 +326,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     }
   }
   solver_prepare();
+  thomas_prepare();
   G.first_step = 1;
   G.ready = true;
   HIPCHK(hipDeviceSynchronize());
@@ -277,16 +370,18 @@ int fesom_gpu_get_field(const char *name, double *out, long long count) {
   NEED_READY();
   auto it = G.fields.find(name);
   if (it == G.fields.end() || (size_t)count != it->second.count) { G.err = std::string("get_field: bad name/count ") + name; return 1; }
-  HIPCHK(hipStreamSynchronize(G.stream));
-  HIPCHK(hipMemcpy(out, it->second.p, sizeof(double) * count, hipMemcpyDeviceToHost));
+  HIPCHK(hipDeviceSynchronize());
+  const double *src = (const double *)it->second.p + (it->second.slabs > 1 ? (size_t)G.cur_tr * it->second.count : 0);   // slab of the tracer last worked on
+  HIPCHK(hipMemcpy(out, src, sizeof(double) * count, hipMemcpyDeviceToHost));
   return 0;
 }
 int fesom_gpu_set_field(const char *name, const double *in, long long count) {
   NEED_READY();
   auto it = G.fields.find(name);
   if (it == G.fields.end() || (size_t)count != it->second.count) { G.err = std::string("set_field: bad name/count ") + name; return 1; }
-  HIPCHK(hipStreamSynchronize(G.stream));
-  HIPCHK(hipMemcpy(it->second.p, in, sizeof(double) * count, hipMemcpyHostToDevice));
+  HIPCHK(hipDeviceSynchronize());
+  double *dst = (double *)it->second.p + (it->second.slabs > 1 ? (size_t)G.cur_tr * it->second.count : 0);
+  HIPCHK(hipMemcpy(dst, in, sizeof(double) * count, hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -303,6 +398,9 @@ static int call_named(const char *name, int arg) {
     return launch_solver(m, G.stream);
   }
   int fs = G.first_step;
+  if (!strcmp(name, "init_tracers_AB") || !strcmp(name, "adv_tracers_ale") || !strcmp(name, "diff_tracers_ale") || !strncmp(name, "k_t", 3) ||
+      !strncmp(name, "k_f", 3) || !strcmp(name, "k_updn_grad"))
+    G.cur_tr = (arg >= 1 && arg <= m.ntr) ? arg - 1 : 0;
   int rc = launch_named_dyn(m, G.stream, name, arg, fs);
   if (rc == 0) { if (!strcmp(name, "compute_vel_rhs")) G.first_step = 0; return 0; }
   rc = launch_named_tra(m, G.stream, name, arg);
@@ -326,6 +424,10 @@ int fesom_gpu_run_steps(int n_first, int nsteps) {
     if (G.use_graph) {
       if (!G.graph[which] && build_graph(which)) return 1;
       HIPCHK(hipGraphLaunch(G.graph[which], G.stream));
+    } else if (!G.serial) {
+      static Dag dag;                                   // pooled events
+      dag.reset();
+      enqueue_step_dag(G.stream, which, dag);
     } else enqueue_step(G.stream, which);
     G.first_step = 0;
   }
@@ -412,6 +514,11 @@ void psolver_init(int *id, int *stype, int *pctype, int *pcilutype, int *iluleve
   for (auto v : vecs) *v = (double *)A(sizeof(double) * (n + 64));
   m.sv_x0 = (double *)A(sizeof(double) * 16 * (n + 64));
   m.sv_info = (int *)A(16); m.sv_resid = (double *)A(8);
+  {
+    std::vector<unsigned short> ec = ell_cols(rptr, cols, n, m.ssh_maxnnz);
+    m.sv_cols = (unsigned short *)A(ec.size() * sizeof(unsigned short));
+    hipMemcpy(m.sv_cols, ec.data(), ec.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
+  }
   solver_prepare();
   PS.n = n; PS.nza = nza; PS.ok = true;
 }

@@ -47,9 +47,12 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   double *pgf_x, *pgf_y, *helem, *Av, *dhe, *stress_surf;
   double *adv_flux_hor, *flux_lo_hor, *edge_up_dn_grad, *edge_c12;
   double *ssh_values;
+  double *th_a, *th_b, *th_c, *th_r1, *th_r2;   // column-major scratch of the batched Thomas solve (momentum)
+  double *tt_a, *tt_b, *tt_c, *tt_r;            // same, one slab per tracer
   // solver workspace
   double *sv_vals, *sv_dinv, *sv_b, *sv_r, *sv_r0, *sv_p, *sv_v, *sv_s, *sv_t, *sv_ph, *sv_x0, *sv_snap;
   int *sv_info; double *sv_resid;
+  unsigned short *sv_cols;    // static ELL column pattern [k][NP] of the SSH operator (padding -> own row)
   fesom_params p;
 };
 
@@ -105,3 +108,6 @@ int  launch_solver(const DM &m, hipStream_t s);
 void launch_dynamics_post(const DM &m, hipStream_t s);
 void launch_tracer(const DM &m, hipStream_t s, int tr);
 void launch_thickness(const DM &m, hipStream_t s);
+void launch_thomas_visc(const DM &m, hipStream_t s);
+void launch_thomas_tracer(const DM &m, hipStream_t s, int tr);
+void thomas_prepare();

@@ -425,8 +425,8 @@ __global__ void __launch_bounds__(BLOCK) k_visc_node(DM m) {
 }
 
 // impl_vert_visc_ale (src/oce_ale.F90:2348-2517) with the last loop of visc_filt_bcksct (oce_dyn.F90:638-648)
-// fused in front.  Coefficients per level in parallel; the Thomas sweeps are executed by all lanes of the
-// wave on broadcast values (uniform control flow, reference order).  1 N3 + 8 E3 values.
+// fused in front.  Coefficients per level in parallel (this kernel); the Thomas sweep runs one lane per column in
+// k_thomas<2>.  1 N3 + 8 E3 values (+ 5 E3 scratch written, 5 read).
 __global__ void __launch_bounds__(BLOCK) k_impl_visc(DM m, int apply_visc, int do_impl) {
   int e = col_id(), l = lane_id(), nz = l + 1;
   if (e >= m.myE) return;
@@ -506,29 +506,10 @@ __global__ void __launch_bounds__(BLOCK) k_impl_visc(DM m, int apply_visc, int d
       vr = vr - a * v_up - (b - 1.0) * v;
     }
   }
-  // Thomas algorithm, all lanes in lock-step on broadcast coefficients
-  double cp_m = 0.0, up_m = 0.0, vp_m = 0.0;     // this lane's cp/up/vp
-  {
-    int j = nzmin - 1;
-    double bj = bcast(b, j);
-    double cpp = bcast(c, j) / bj, upp = bcast(ur, j) / bj, vpp = bcast(vr, j) / bj;
-    if (l == j) { cp_m = cpp; up_m = upp; vp_m = vpp; }
-    for (j = nzmin; j <= nzmax - 2; ++j) {
-      double aj = bcast(a, j), mm = bcast(b, j) - cpp * aj;
-      double cpn = bcast(c, j) / mm;
-      double upn = (bcast(ur, j) - upp * aj) / mm;
-      double vpn = (bcast(vr, j) - vpp * aj) / mm;
-      cpp = cpn; upp = upn; vpp = vpn;
-      if (l == j) { cp_m = cpp; up_m = upp; vp_m = vpp; }
-    }
-    double un = upp, vn = vpp;                   // solution at nzmax-1
-    double us = un, vs = vn;
-    for (j = nzmax - 3; j >= nzmin - 1; --j) {
-      un = bcast(up_m, j) - bcast(cp_m, j) * un;
-      vn = bcast(vp_m, j) - bcast(cp_m, j) * vn;
-      if (l == j) { us = un; vs = vn; }
-    }
-    if (wet) { DV2(m.UV_rhs, 1, nz, e) = us; DV2(m.UV_rhs, 2, nz, e) = vs; }
+  // coefficients and right-hand sides go to column-major scratch; the sweep itself is k_thomas<2> (kernels_thomas.hip)
+  if (wet) {
+    DA2(m.th_a, nz, e) = a; DA2(m.th_b, nz, e) = b; DA2(m.th_c, nz, e) = c;
+    DA2(m.th_r1, nz, e) = ur; DA2(m.th_r2, nz, e) = vr;
   }
 }
 
@@ -751,6 +732,7 @@ void launch_dynamics_pre(const DM &m, hipStream_t s, int first_step) {
   LAUNCH_COL(k_visc_elem, m.E, m);
   LAUNCH_COL(k_visc_node, m.myN, m);
   LAUNCH_COL(k_impl_visc, m.myE, m, 1, m.p.i_vert_visc);
+  if (m.p.i_vert_visc) launch_thomas_visc(m, s);
 }
 void launch_ssh_rhs(const DM &m, hipStream_t s) {
   if (m.p.which_ale != 0) LAUNCH_FLAT(k_stiff_update, m.nza, m);
@@ -784,12 +766,14 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
     if (!strcmp(name, "k_pp_elem")) { LAUNCH_COL(k_pp_elem, m.myE, m); return 0; }
     if (!strcmp(name, "k_pp_node_final")) { LAUNCH_COL(k_pp_node_final, m.N, m); return 0; }
     if (!strcmp(name, "k_momadv_node")) { LAUNCH_COL(k_momadv_node, m.myN, m); return 0; }
-    if (!strcmp(name, "k_vel_rhs")) { LAUNCH_COL(k_vel_rhs, m.myE, m, 0); return 0; }
+    if (!strcmp(name, "k_vel_rhs")) { LAUNCH_COL(k_vel_rhs, m.myE, m, first_step); return 0; }
     if (!strcmp(name, "k_visc_elem")) { LAUNCH_COL(k_visc_elem, m.E, m); return 0; }
     if (!strcmp(name, "k_visc_node")) { LAUNCH_COL(k_visc_node, m.myN, m); return 0; }
-    if (!strcmp(name, "k_impl_visc")) { LAUNCH_COL(k_impl_visc, m.myE, m, 1, 1); return 0; }
+    if (!strcmp(name, "k_impl_visc")) { LAUNCH_COL(k_impl_visc, m.myE, m, 1, m.p.i_vert_visc); return 0; }
+    if (!strcmp(name, "k_thomas_visc")) { launch_thomas_visc(m, s); return 0; }
     if (!strcmp(name, "k_stiff_update")) { LAUNCH_FLAT(k_stiff_update, m.nza, m); return 0; }
     if (!strcmp(name, "k_edge_transport")) { LAUNCH_COL(k_edge_transport, m.myD, m, 0); return 0; }
+    if (!strcmp(name, "k_edge_transport1")) { LAUNCH_COL(k_edge_transport, m.myD, m, 1); return 0; }
     if (!strcmp(name, "k_ssh_rhs_node")) { LAUNCH_FLAT(k_ssh_rhs_node, m.myN, m); return 0; }
     if (!strcmp(name, "k_update_vel")) { LAUNCH_COL(k_update_vel, ncol_uv, m); return 0; }
     if (!strcmp(name, "k_hbar_node")) { LAUNCH_FLAT(k_hbar_node, m.myN, m); return 0; }
@@ -813,7 +797,7 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
   if (!strcmp(name, "visc_filt_bcksct")) {
     LAUNCH_COL(k_visc_elem, m.E, m); LAUNCH_COL(k_visc_node, m.myN, m); LAUNCH_COL(k_impl_visc, m.myE, m, 1, 0); return 0;
   }
-  if (!strcmp(name, "impl_vert_visc_ale")) { LAUNCH_COL(k_impl_visc, m.myE, m, 0, 1); return 0; }
+  if (!strcmp(name, "impl_vert_visc_ale")) { LAUNCH_COL(k_impl_visc, m.myE, m, 0, 1); launch_thomas_visc(m, s); return 0; }
   if (!strcmp(name, "update_stiff_mat_ale")) { LAUNCH_FLAT(k_stiff_update, m.nza, m); return 0; }
   if (!strcmp(name, "compute_ssh_rhs_ale")) { LAUNCH_COL(k_edge_transport, m.myD, m, 0); LAUNCH_FLAT(k_ssh_rhs_node, m.myN, m); return 0; }
   if (!strcmp(name, "update_vel")) {

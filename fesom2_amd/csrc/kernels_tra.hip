@@ -4,39 +4,63 @@
 #include "dev.h"
 #include <string.h>
 
-// init_tracers_AB head (src/oce_tracer_mod.F90:49-83): AB2 extrapolation + tracer_gradient_z (:124-153)
-__global__ void __launch_bounds__(BLOCK) k_tr_ab_z(DM m, int tr) {
+// Per-tracer scratch: every tracer has its own slab of the FCT / gradient / Thomas work arrays, so the T and S chains
+// are independent and can run concurrently on two streams (they only share read-only velocities and thicknesses).
+struct TV {
+  double *del_ttf, *fct_LO, *fct_ttf_max, *fct_ttf_min, *fct_plus, *fct_minus, *tr_z, *adv_flux_ver, *tr_xy_ab, *tr_xy, *fct_ebnd,
+         *adv_flux_hor, *flux_lo_hor, *edge_up_dn_grad, *th_a, *th_b, *th_c, *th_r1;
+};
+__device__ __forceinline__ TV tracer_view(const DM &m, int tr) {
+  size_t n1N = (size_t)m.nlm1 * m.N, nlN = (size_t)m.nl * m.N, n1E = (size_t)m.nlm1 * m.E, n1D = (size_t)m.nlm1 * m.D;
+  TV t;
+  t.del_ttf = m.del_ttf + tr * n1N; t.fct_LO = m.fct_LO + tr * n1N; t.fct_ttf_max = m.fct_ttf_max + tr * n1N;
+  t.fct_ttf_min = m.fct_ttf_min + tr * n1N; t.fct_plus = m.fct_plus + tr * n1N; t.fct_minus = m.fct_minus + tr * n1N;
+  t.tr_z = m.tr_z + tr * nlN; t.adv_flux_ver = m.adv_flux_ver + tr * nlN;
+  t.tr_xy_ab = m.tr_xy_ab + tr * 2 * n1E; t.tr_xy = m.tr_xy + tr * 2 * n1E; t.fct_ebnd = m.fct_ebnd + tr * 2 * n1E;
+  t.adv_flux_hor = m.adv_flux_hor + tr * n1D; t.flux_lo_hor = m.flux_lo_hor + tr * n1D; t.edge_up_dn_grad = m.edge_up_dn_grad + tr * 4 * n1D;
+  t.th_a = m.tt_a + tr * n1N; t.th_b = m.tt_b + tr * n1N; t.th_c = m.tt_c + tr * n1N; t.th_r1 = m.tt_r + tr * n1N;
+  return t;
+}
+
+// init_tracers_AB head (src/oce_tracer_mod.F90:49-83): AB2 extrapolation (k_tr_ab) and tracer_gradient_z (:124-153, k_tr_z).
+// Split in two kernels because the AB part only needs the tracers (it is hoisted to the start of the step and overlaps
+// the SSH solve) while tr_z needs hnode_new of this step's vert_vel_ale.
+__global__ void __launch_bounds__(BLOCK) k_tr_ab(DM m, int tr) {
+  int n = col_id(), nz = lane_id() + 1;
+  if (n >= m.N || nz > m.nlm1) return;
+  const double eps = m.p.epsilon;
+  double cur = DTR(m.tr_arr, nz, n, tr);
+  DTR(m.tr_arr_old, nz, n, tr) = -(0.5 + eps) * DTR(m.tr_arr_old, nz, n, tr) + (1.5 + eps) * cur;
+}
+__global__ void __launch_bounds__(BLOCK) k_tr_z(DM m, int tr) {
+  const TV t = tracer_view(m, tr);
   int n = col_id(), nz = lane_id() + 1;
   if (n >= m.N) return;
-  const double eps = m.p.epsilon;
   int nzmax = m.nlev_n[n], nzmin = m.ulev_n[n];
-  if (nz <= m.nlm1) {
-    double cur = DTR(m.tr_arr, nz, n, tr);
-    DTR(m.tr_arr_old, nz, n, tr) = -(0.5 + eps) * DTR(m.tr_arr_old, nz, n, tr) + (1.5 + eps) * cur;
-  }
   if (nz >= nzmin + 1 && nz <= nzmax - 1) {
     double dz = 0.5 * (DA2(m.hnode_new, nz - 1, n) + DA2(m.hnode_new, nz, n));
-    DA2L(m.tr_z, nz, n) = (DTR(m.tr_arr, nz - 1, n, tr) - DTR(m.tr_arr, nz, n, tr)) / dz;
+    DA2L(t.tr_z, nz, n) = (DTR(m.tr_arr, nz - 1, n, tr) - DTR(m.tr_arr, nz, n, tr)) / dz;
   }
-  if (nz == nzmin || nz == nzmax) DA2L(m.tr_z, nz, n) = 0.0;
+  if (nz == nzmin || nz == nzmax) DA2L(t.tr_z, nz, n) = 0.0;
 }
 
 // tracer_gradient_elements (src/oce_tracer_mod.F90:19-45) for the AB field and the current field in one pass
 __global__ void __launch_bounds__(BLOCK) k_tr_grad_elem(DM m, int tr) {
+  const TV t = tracer_view(m, tr);
   int e = col_id(), nz = lane_id() + 1;
   if (e >= m.myE) return;
   if (nz < m.ulev[e] || nz > m.nlev[e] - 1) return;
   int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
   double a1 = DTR(m.tr_arr_old, nz, n1, tr), a2 = DTR(m.tr_arr_old, nz, n2, tr), a3 = DTR(m.tr_arr_old, nz, n3, tr);
   double c1 = DTR(m.tr_arr, nz, n1, tr), c2 = DTR(m.tr_arr, nz, n2, tr), c3 = DTR(m.tr_arr, nz, n3, tr);
-  DV2(m.tr_xy_ab, 1, nz, e) = DGS(1, e) * a1 + DGS(2, e) * a2 + DGS(3, e) * a3;
-  DV2(m.tr_xy_ab, 2, nz, e) = DGS(4, e) * a1 + DGS(5, e) * a2 + DGS(6, e) * a3;
-  DV2(m.tr_xy, 1, nz, e) = DGS(1, e) * c1 + DGS(2, e) * c2 + DGS(3, e) * c3;
-  DV2(m.tr_xy, 2, nz, e) = DGS(4, e) * c1 + DGS(5, e) * c2 + DGS(6, e) * c3;
+  DV2(t.tr_xy_ab, 1, nz, e) = DGS(1, e) * a1 + DGS(2, e) * a2 + DGS(3, e) * a3;
+  DV2(t.tr_xy_ab, 2, nz, e) = DGS(4, e) * a1 + DGS(5, e) * a2 + DGS(6, e) * a3;
+  DV2(t.tr_xy, 1, nz, e) = DGS(1, e) * c1 + DGS(2, e) * c2 + DGS(3, e) * c3;
+  DV2(t.tr_xy, 2, nz, e) = DGS(4, e) * c1 + DGS(5, e) * c2 + DGS(6, e) * c3;
 }
 
 // fill_up_dn_grad (src/oce_muscl_adv.F90:285-447)
-__device__ __forceinline__ void cluster_grad(const DM &m, int node, int nz, double &gx, double &gy) {
+__device__ __forceinline__ void cluster_grad(const DM &m, const TV &t, int node, int nz, double &gx, double &gy) {
   double tvol = 0.0, tx = 0.0, ty = 0.0;
   int num = m.nie_num[node];
   for (int k = 0; k < num; k++) {
@@ -44,12 +68,13 @@ __device__ __forceinline__ void cluster_grad(const DM &m, int node, int nz, doub
     if (m.nlev[e] - 1 < nz || nz < m.ulev[e]) continue;
     double ar = m.elem_area[e];
     tvol = tvol + ar;
-    tx = tx + DV2(m.tr_xy_ab, 1, nz, e) * ar;
-    ty = ty + DV2(m.tr_xy_ab, 2, nz, e) * ar;
+    tx = tx + DV2(t.tr_xy_ab, 1, nz, e) * ar;
+    ty = ty + DV2(t.tr_xy_ab, 2, nz, e) * ar;
   }
   gx = tx / tvol; gy = ty / tvol;
 }
-__global__ void __launch_bounds__(BLOCK) k_updn_grad(DM m) {
+__global__ void __launch_bounds__(BLOCK) k_updn_grad(DM m, int tr) {
+  const TV t = tracer_view(m, tr);
   int ed = col_id(), nz = lane_id() + 1;
   if (ed >= m.myD) return;
   if (nz > m.nlm1) return;
@@ -61,24 +86,25 @@ __global__ void __launch_bounds__(BLOCK) k_updn_grad(DM m) {
   if (t1 >= 0 && t2 >= 0) {
     int nzmin = max(m.ulev_n_max[n1], m.ulev_n_max[n2]), nzmax = min(m.nlev_n_min[n1], m.nlev_n_min[n2]);
     if (nz >= nzmin && nz <= nzmax - 1) {
-      g1 = DV2(m.tr_xy_ab, 1, nz, t1); g2 = DV2(m.tr_xy_ab, 1, nz, t2);
-      g3 = DV2(m.tr_xy_ab, 2, nz, t1); g4 = DV2(m.tr_xy_ab, 2, nz, t2);
+      g1 = DV2(t.tr_xy_ab, 1, nz, t1); g2 = DV2(t.tr_xy_ab, 1, nz, t2);
+      g3 = DV2(t.tr_xy_ab, 2, nz, t1); g4 = DV2(t.tr_xy_ab, 2, nz, t2);
       w1 = w2 = true;
     } else {
-      if ((nz >= ul1 && nz <= nzmin - 1) || (nz >= nzmax && nz <= nl1)) { cluster_grad(m, n1, nz, g1, g3); w1 = true; }
-      if ((nz >= ul2 && nz <= nzmin - 1) || (nz >= nzmax && nz <= nl2)) { cluster_grad(m, n2, nz, g2, g4); w2 = true; }
+      if ((nz >= ul1 && nz <= nzmin - 1) || (nz >= nzmax && nz <= nl1)) { cluster_grad(m, t, n1, nz, g1, g3); w1 = true; }
+      if ((nz >= ul2 && nz <= nzmin - 1) || (nz >= nzmax && nz <= nl2)) { cluster_grad(m, t, n2, nz, g2, g4); w2 = true; }
     }
   } else {
-    if (nz >= ul1 && nz <= nl1) { cluster_grad(m, n1, nz, g1, g3); w1 = true; }
-    if (nz >= ul2 && nz <= nl2) { cluster_grad(m, n2, nz, g2, g4); w2 = true; }
+    if (nz >= ul1 && nz <= nl1) { cluster_grad(m, t, n1, nz, g1, g3); w1 = true; }
+    if (nz >= ul2 && nz <= nl2) { cluster_grad(m, t, n2, nz, g2, g4); w2 = true; }
   }
-  if (w1) { DV4(m.edge_up_dn_grad, 1, nz, ed) = g1; DV4(m.edge_up_dn_grad, 3, nz, ed) = g3; }
-  if (w2) { DV4(m.edge_up_dn_grad, 2, nz, ed) = g2; DV4(m.edge_up_dn_grad, 4, nz, ed) = g4; }
+  if (w1) { DV4(t.edge_up_dn_grad, 1, nz, ed) = g1; DV4(t.edge_up_dn_grad, 3, nz, ed) = g3; }
+  if (w2) { DV4(t.edge_up_dn_grad, 2, nz, ed) = g2; DV4(t.edge_up_dn_grad, 4, nz, ed) = g4; }
 }
 
 // adv_tra_hor_upw1 (src/oce_adv_tra_hor.F90:57-211) + adv_tra_hor_mfct (:485-733) in one edge pass:
 // flux_lo_hor = low-order flux, adv_flux_hor = high-order minus low-order (the init_zero=.false. convention).
 __global__ void __launch_bounds__(BLOCK) k_flux_hor(DM m, int tr) {
+  const TV t = tracer_view(m, tr);
   int ed = col_id(), nz = lane_id() + 1;
   if (ed >= m.myD) return;
   if (nz > m.nlm1) return;
@@ -96,7 +122,7 @@ __global__ void __launch_bounds__(BLOCK) k_flux_hor(DM m, int tr) {
   if (nz >= nu12 && nz <= nl12) { use1 = true; use2 = true; }
   else if ((nz >= nu1 && nz <= nu12 - 1) || (nz >= nl12 + 1 && nz <= nl1)) { use1 = true; use2 = false; }
   else if (nu2 > 0 && ((nz >= nu2 && nz <= nu12 - 1) || (nz >= nl12 + 1 && nz <= nl2))) { use1 = false; use2 = true; }
-  else { DA2(m.flux_lo_hor, nz, ed) = 0.0; DA2(m.adv_flux_hor, nz, ed) = 0.0; return; }
+  else { DA2(t.flux_lo_hor, nz, ed) = 0.0; DA2(t.adv_flux_hor, nz, ed) = 0.0; return; }
   double vflux;
   if (use1 && use2)
     vflux = (-DV2(m.UV, 2, nz, e1) * dX1 + DV2(m.UV, 1, nz, e1) * dY1) * DA2(m.helem, nz, e1) +
@@ -106,19 +132,20 @@ __global__ void __launch_bounds__(BLOCK) k_flux_hor(DM m, int tr) {
   double av = fabs(vflux);
   double t1 = DTR(m.tr_arr, nz, n1, tr), t2 = DTR(m.tr_arr, nz, n2, tr);
   double lo = -0.5 * (t1 * (vflux + av) + t2 * (vflux - av)) - 0.0;
-  DA2(m.flux_lo_hor, nz, ed) = lo;
+  DA2(t.flux_lo_hor, nz, ed) = lo;
   double s1 = DTR(m.tr_arr_old, nz, n1, tr), s2 = DTR(m.tr_arr_old, nz, n2, tr);
   double num_ord = m.p.tra_adv_ph;
   double ex = m.edxy[2 * ed], ey = m.edxy[2 * ed + 1];
-  double Tmean2 = s2 - (2.0 * (s2 - s1) + ex * a * DV4(m.edge_up_dn_grad, 2, nz, ed) + ey * D_REARTH * DV4(m.edge_up_dn_grad, 4, nz, ed)) / 6.0;
-  double Tmean1 = s1 + (2.0 * (s2 - s1) + ex * a * DV4(m.edge_up_dn_grad, 1, nz, ed) + ey * D_REARTH * DV4(m.edge_up_dn_grad, 3, nz, ed)) / 6.0;
+  double Tmean2 = s2 - (2.0 * (s2 - s1) + ex * a * DV4(t.edge_up_dn_grad, 2, nz, ed) + ey * D_REARTH * DV4(t.edge_up_dn_grad, 4, nz, ed)) / 6.0;
+  double Tmean1 = s1 + (2.0 * (s2 - s1) + ex * a * DV4(t.edge_up_dn_grad, 1, nz, ed) + ey * D_REARTH * DV4(t.edge_up_dn_grad, 3, nz, ed)) / 6.0;
   double cHO = (vflux + av) * Tmean1 + (vflux - av) * Tmean2;
-  DA2(m.adv_flux_hor, nz, ed) = -0.5 * (1.0 - num_ord) * cHO - vflux * num_ord * (0.5 * (Tmean1 + Tmean2)) - lo;
+  DA2(t.adv_flux_hor, nz, ed) = -0.5 * (1.0 - num_ord) * cHO - vflux * num_ord * (0.5 * (Tmean1 + Tmean2)) - lo;
 }
 
 // low-order solution (src/oce_adv_tra_driver.F90:97-133) with adv_tra_ver_upw1 (src/oce_adv_tra_ver.F90:231-282)
 // and adv_tra_ver_qr4c (:286-357) evaluated in registers; also the nodal bounds of oce_tra_adv_fct (:94-101).
 __global__ void __launch_bounds__(BLOCK) k_fct_lo_node(DM m, int tr) {
+  const TV t = tracer_view(m, tr);
   int n = col_id(), l = lane_id(), nz = l + 1;
   if (n >= m.myN) return;
   const int nzmin = m.ulev_n[n], nzmax = m.nlev_n[n];
@@ -151,7 +178,7 @@ __global__ void __launch_bounds__(BLOCK) k_fct_lo_node(DM m, int tr) {
         adf = (-0.5 * (1.0 - num_ord) * Tmean - num_ord * (0.5 * (Tmean1 + Tmean2)) * w) * ar - fv;
       }
     }
-    DA2L(m.adv_flux_ver, nz, n) = adf;
+    DA2L(t.adv_flux_ver, nz, n) = adf;
   }
   double fv_dn = shdn(fv);
   if (nz >= nzmin && nz <= nzmax - 1) {
@@ -162,36 +189,38 @@ __global__ void __launch_bounds__(BLOCK) k_fct_lo_node(DM m, int tr) {
       int nl12 = m.nlev[e1] - 1, nu12 = m.ulev[e1];
       if (e2 >= 0) { nl12 = max(nl12, m.nlev[e2] - 1); nu12 = min(nu12, m.ulev[e2]); }
       if (nz < nu12 || nz > nl12) continue;
-      double f = DA2(m.flux_lo_hor, nz, ed);
+      double f = DA2(t.flux_lo_hor, nz, ed);
       lo = (m.ne_sgn[q] > 0) ? lo + f : lo - f;
     }
     double ttf = DTR(m.tr_arr, nz, n, tr);
     lo = (ttf * DA2(m.hnode, nz, n) + (lo + (fv - fv_dn)) * dt / DA2L(m.areasvol, nz, n)) / DA2(m.hnode_new, nz, n);
-    DA2(m.fct_LO, nz, n) = lo;
-    DA2(m.fct_ttf_max, nz, n) = dmax_(lo, ttf);
-    DA2(m.fct_ttf_min, nz, n) = dmin_(lo, ttf);
+    DA2(t.fct_LO, nz, n) = lo;
+    DA2(t.fct_ttf_max, nz, n) = dmax_(lo, ttf);
+    DA2(t.fct_ttf_min, nz, n) = dmin_(lo, ttf);
   }
 }
 
 // element bounds (src/oce_adv_tra_fct.F90:108-121; the reference parks them in UV_rhs)
-__global__ void __launch_bounds__(BLOCK) k_fct_ebnd(DM m) {
+__global__ void __launch_bounds__(BLOCK) k_fct_ebnd(DM m, int tr) {
+  const TV t = tracer_view(m, tr);
   int e = col_id(), nz = lane_id() + 1;
   if (e >= m.myE) return;
   if (nz > m.nlm1) return;
   int nl1 = m.nlev[e];
   if (nz >= m.ulev[e] && nz <= nl1 - 1) {
     int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
-    DV2(m.fct_ebnd, 1, nz, e) = dmax_(dmax_(DA2(m.fct_ttf_max, nz, n1), DA2(m.fct_ttf_max, nz, n2)), DA2(m.fct_ttf_max, nz, n3));
-    DV2(m.fct_ebnd, 2, nz, e) = dmin_(dmin_(DA2(m.fct_ttf_min, nz, n1), DA2(m.fct_ttf_min, nz, n2)), DA2(m.fct_ttf_min, nz, n3));
+    DV2(t.fct_ebnd, 1, nz, e) = dmax_(dmax_(DA2(t.fct_ttf_max, nz, n1), DA2(t.fct_ttf_max, nz, n2)), DA2(t.fct_ttf_max, nz, n3));
+    DV2(t.fct_ebnd, 2, nz, e) = dmin_(dmin_(DA2(t.fct_ttf_min, nz, n1), DA2(t.fct_ttf_min, nz, n2)), DA2(t.fct_ttf_min, nz, n3));
   } else if (nz >= nl1) {
-    DV2(m.fct_ebnd, 1, nz, e) = -1e3;
-    DV2(m.fct_ebnd, 2, nz, e) = 1e3;
+    DV2(t.fct_ebnd, 1, nz, e) = -1e3;
+    DV2(t.fct_ebnd, 2, nz, e) = 1e3;
   }
 }
 
 // cluster bounds, sums of positive/negative antidiffusive fluxes, limiting factors and the limiting of the
 // vertical antidiffusive flux (src/oce_adv_tra_fct.F90:127-311, vlimit=1)
-__global__ void __launch_bounds__(BLOCK) k_fct_node(DM m) {
+__global__ void __launch_bounds__(BLOCK) k_fct_node(DM m, int tr) {
+  const TV t = tracer_view(m, tr);
   int n = col_id(), l = lane_id(), nz = l + 1;
   if (n >= m.myN) return;
   const int nu1 = m.ulev_n[n], nl1 = m.nlev_n[n];
@@ -201,26 +230,26 @@ __global__ void __launch_bounds__(BLOCK) k_fct_node(DM m) {
   if (wet) {
     int num = m.nie_num[n];
     int e0 = m.nie[(size_t)m.maxk * n];
-    tvmax = DV2(m.fct_ebnd, 1, nz, e0); tvmin = DV2(m.fct_ebnd, 2, nz, e0);
+    tvmax = DV2(t.fct_ebnd, 1, nz, e0); tvmin = DV2(t.fct_ebnd, 2, nz, e0);
     for (int k = 1; k < num; k++) {
       int e = m.nie[(size_t)m.maxk * n + k];
-      tvmax = dmax_(tvmax, DV2(m.fct_ebnd, 1, nz, e));
-      tvmin = dmin_(tvmin, DV2(m.fct_ebnd, 2, nz, e));
+      tvmax = dmax_(tvmax, DV2(t.fct_ebnd, 1, nz, e));
+      tvmin = dmin_(tvmin, DV2(t.fct_ebnd, 2, nz, e));
     }
   }
   double mx_u = shup(tvmax), mx_d = shdn(tvmax), mn_u = shup(tvmin), mn_d = shdn(tvmin);
-  double adv = (nz >= nu1 && nz <= nl1) ? DA2L(m.adv_flux_ver, nz, n) : 0.0;
+  double adv = (nz >= nu1 && nz <= nl1) ? DA2L(t.adv_flux_ver, nz, n) : 0.0;
   double adv_dn = shdn(adv);
   double plus = 0.0, minus = 0.0;
   if (wet) {
-    double lo = DA2(m.fct_LO, nz, n);
+    double lo = DA2(t.fct_LO, nz, n);
     double bmax, bmin;
     if (nz >= nu1 + 1 && nz <= nl1 - 2) {
       bmax = dmax_(dmax_(mx_u, tvmax), mx_d) - lo;
       bmin = dmin_(dmin_(mn_u, tvmin), mn_d) - lo;
     } else { bmax = tvmax - lo; bmin = tvmin - lo; }
-    DA2(m.fct_ttf_max, nz, n) = bmax;
-    DA2(m.fct_ttf_min, nz, n) = bmin;
+    DA2(t.fct_ttf_max, nz, n) = bmax;
+    DA2(t.fct_ttf_min, nz, n) = bmin;
     plus = 0.0 + (dmax_(0.0, adv) + dmax_(0.0, -adv_dn));
     minus = 0.0 + (dmin_(0.0, adv) + dmin_(0.0, -adv_dn));
     for (int q = m.ne_ptr[n]; q < m.ne_ptr[n + 1]; q++) {
@@ -229,7 +258,7 @@ __global__ void __launch_bounds__(BLOCK) k_fct_node(DM m) {
       int nl12 = m.nlev[e1] - 1, nu12 = m.ulev[e1];
       if (e2 >= 0) { nl12 = max(nl12, m.nlev[e2] - 1); nu12 = min(nu12, m.ulev[e2]); }
       if (nz < nu12 || nz > nl12) continue;
-      double f = DA2(m.adv_flux_hor, nz, ed);
+      double f = DA2(t.adv_flux_hor, nz, ed);
       if (m.ne_sgn[q] < 0) f = -f;
       plus = plus + dmax_(0.0, f);
       minus = minus + dmin_(0.0, f);
@@ -239,8 +268,8 @@ __global__ void __launch_bounds__(BLOCK) k_fct_node(DM m) {
     plus = dmin_(1.0, bmax / flux);
     flux = minus * dt / asv - flux_eps;
     minus = dmin_(1.0, bmin / flux);
-    DA2(m.fct_plus, nz, n) = plus;
-    DA2(m.fct_minus, nz, n) = minus;
+    DA2(t.fct_plus, nz, n) = plus;
+    DA2(t.fct_minus, nz, n) = minus;
   }
   double plus_u = shup(plus), minus_u = shup(minus);
   if (wet) {
@@ -251,22 +280,23 @@ __global__ void __launch_bounds__(BLOCK) k_fct_node(DM m) {
       if (adv >= 0.) { ae = dmin_(ae, minus_u); ae = dmin_(ae, plus); }
       else { ae = dmin_(ae, plus_u); ae = dmin_(ae, minus); }
     }
-    DA2L(m.adv_flux_ver, nz, n) = ae * adv;
+    DA2L(t.adv_flux_ver, nz, n) = ae * adv;
   }
 }
 
 // limiting of the horizontal antidiffusive flux (src/oce_adv_tra_fct.F90:318-347)
-__global__ void __launch_bounds__(BLOCK) k_fct_edge_limit(DM m) {
+__global__ void __launch_bounds__(BLOCK) k_fct_edge_limit(DM m, int tr) {
+  const TV t = tracer_view(m, tr);
   int ed = col_id(), nz = lane_id() + 1;
   if (ed >= m.myD) return;
   int n1 = m.edges[2 * ed], n2 = m.edges[2 * ed + 1], e1 = m.edge_tri[2 * ed], e2 = m.edge_tri[2 * ed + 1];
   int nl12 = m.nlev[e1] - 1, nu12 = m.ulev[e1];
   if (e2 >= 0) { nl12 = max(nl12, m.nlev[e2] - 1); nu12 = min(nu12, m.ulev[e2]); }
   if (nz < nu12 || nz > nl12) return;
-  double ae = 1.0, flux = DA2(m.adv_flux_hor, nz, ed);
-  if (flux >= 0.) { ae = dmin_(ae, DA2(m.fct_plus, nz, n1)); ae = dmin_(ae, DA2(m.fct_minus, nz, n2)); }
-  else { ae = dmin_(ae, DA2(m.fct_minus, nz, n1)); ae = dmin_(ae, DA2(m.fct_plus, nz, n2)); }
-  DA2(m.adv_flux_hor, nz, ed) = ae * flux;
+  double ae = 1.0, flux = DA2(t.adv_flux_hor, nz, ed);
+  if (flux >= 0.) { ae = dmin_(ae, DA2(t.fct_plus, nz, n1)); ae = dmin_(ae, DA2(t.fct_minus, nz, n2)); }
+  else { ae = dmin_(ae, DA2(t.fct_minus, nz, n1)); ae = dmin_(ae, DA2(t.fct_plus, nz, n2)); }
+  DA2(t.adv_flux_hor, nz, ed) = ae * flux;
 }
 
 // oce_tra_adv_flux2dtracer (src/oce_adv_tra_driver.F90:201-269) + adv_tracers_ale tail (src/oce_ale_tracer.F90:241)
@@ -274,17 +304,18 @@ __global__ void __launch_bounds__(BLOCK) k_fct_edge_limit(DM m) {
 // T* update, implicit vertical diffusion (diff_ver_part_impl_ale :398-856) as a lock-step Thomas solve, salinity
 // clamp (:176-198).  22 N3 + 1 D3 values (+ closure).
 __global__ void __launch_bounds__(BLOCK) k_tr_update(DM m, int tr) {
+  const TV t = tracer_view(m, tr);
   int n = col_id(), l = lane_id(), nz = l + 1;
   if (n >= m.myN) return;
   const int nzmin = m.ulev_n[n], nzmax = m.nlev_n[n];
   const double dt = m.p.dt;
   const bool wet = (nz >= nzmin && nz <= nzmax - 1);
-  double adv = (nz >= nzmin && nz <= nzmax) ? DA2L(m.adv_flux_ver, nz, n) : 0.0;
+  double adv = (nz >= nzmin && nz <= nzmax) ? DA2L(t.adv_flux_ver, nz, n) : 0.0;
   double adv_dn = shdn(adv);
   double T = 0.0, hn = 0.0, hnn = 1.0, del = 0.0, asv = 1.0;
   if (wet) {
     T = DTR(m.tr_arr, nz, n, tr); hn = DA2(m.hnode, nz, n); hnn = DA2(m.hnode_new, nz, n); asv = DA2L(m.areasvol, nz, n);
-    double dv = 0.0 - T * hn + DA2(m.fct_LO, nz, n) * hnn;
+    double dv = 0.0 - T * hn + DA2(t.fct_LO, nz, n) * hnn;
     dv = dv + (adv - adv_dn) * dt / asv;
     double dh = 0.0;
     for (int q = m.ne_ptr[n]; q < m.ne_ptr[n + 1]; q++) {
@@ -293,7 +324,7 @@ __global__ void __launch_bounds__(BLOCK) k_tr_update(DM m, int tr) {
       int nl12 = m.nlev[e1] - 1, nu12 = m.ulev[e1];
       if (e2 >= 0) { nl12 = max(nl12, m.nlev[e2] - 1); nu12 = min(nu12, m.ulev[e2]); }
       if (nz < nu12 || nz > nl12) continue;
-      double f = DA2(m.adv_flux_hor, nz, ed) * dt / asv;
+      double f = DA2(t.adv_flux_hor, nz, ed) * dt / asv;
       dh = (m.ne_sgn[q] > 0) ? dh + f : dh - f;
     }
     del = 0.0 + dh + dv;
@@ -311,17 +342,17 @@ __global__ void __launch_bounds__(BLOCK) k_tr_update(DM m, int tr) {
         double Kh = (DA2(m.Ki, nz, n1) + DA2(m.Ki, nz, n2)) / 2.0, c;
         if (nz >= ul12 && nz <= nl12) {
           double dz = (DA2(m.helem, nz, e1) + DA2(m.helem, nz, e2)) / 2.0;
-          double Tx = 0.5 * (DV2(m.tr_xy, 1, nz, e1) + DV2(m.tr_xy, 1, nz, e2));
-          double Ty = 0.5 * (DV2(m.tr_xy, 2, nz, e1) + DV2(m.tr_xy, 2, nz, e2));
+          double Tx = 0.5 * (DV2(t.tr_xy, 1, nz, e1) + DV2(t.tr_xy, 1, nz, e2));
+          double Ty = 0.5 * (DV2(t.tr_xy, 2, nz, e1) + DV2(t.tr_xy, 2, nz, e2));
           double Fx = Kh * (Tx + 0.0), Fy = Kh * (Ty + 0.0);
           c = ((dX2 - dX1) * Fy - (dY2 - dY1) * Fx) * dz;
         } else if ((nz >= ul1 && nz <= ul12 - 1) || (nz >= nl12 + 1 && nz <= nl1)) {
           double dz = DA2(m.helem, nz, e1);
-          double Fx = Kh * (DV2(m.tr_xy, 1, nz, e1) + 0.0), Fy = Kh * (DV2(m.tr_xy, 2, nz, e1) + 0.0);
+          double Fx = Kh * (DV2(t.tr_xy, 1, nz, e1) + 0.0), Fy = Kh * (DV2(t.tr_xy, 2, nz, e1) + 0.0);
           c = (-dX1 * Fy + dY1 * Fx) * dz;
         } else {
           double dz = DA2(m.helem, nz, e2);
-          double Fx = Kh * (DV2(m.tr_xy, 1, nz, e2) + 0.0), Fy = Kh * (DV2(m.tr_xy, 2, nz, e2) + 0.0);
+          double Fx = Kh * (DV2(t.tr_xy, 1, nz, e2) + 0.0), Fy = Kh * (DV2(t.tr_xy, 2, nz, e2) + 0.0);
           c = (dX2 * Fy - dY2 * Fx) * dz;
         }
         double rhs = (m.ne_sgn[q] > 0) ? 0.0 + c : 0.0 - c;
@@ -330,7 +361,7 @@ __global__ void __launch_bounds__(BLOCK) k_tr_update(DM m, int tr) {
     }
     DTR(m.tr_arr_old, nz, n, tr) = T;          // tr_arr_old(:,:,tr) = tr_arr(:,:,tr)  (oce_ale_tracer.F90:274)
     del = del + T * (hn - hnn);
-    DA2(m.del_ttf, nz, n) = del;
+    DA2(t.del_ttf, nz, n) = del;
     T = T + del / hnn;
   }
   if (!wet && nz <= m.nlm1) DTR(m.tr_arr_old, nz, n, tr) = DTR(m.tr_arr, nz, n, tr);   // whole-array copy incl. dry cells
@@ -372,24 +403,12 @@ __global__ void __launch_bounds__(BLOCK) k_tr_update(DM m, int tr) {
         rhs = rhs + bc;
       }
     }
-    double cp_m = 0.0, tp_m = 0.0;
-    int j = nzmin - 1;
-    double bj = bcast(b, j);
-    double cpp = bcast(c, j) / bj, tpp = bcast(rhs, j) / bj;
-    if (l == j) { cp_m = cpp; tp_m = tpp; }
-    for (j = nzmin; j <= nzmax - 2; ++j) {
-      double aj = bcast(a, j), mm = bcast(b, j) - cpp * aj;
-      double cpn = bcast(c, j) / mm;
-      double tpn = (bcast(rhs, j) - tpp * aj) / mm;
-      cpp = cpn; tpp = tpn;
-      if (l == j) { cp_m = cpp; tp_m = tpp; }
+    // coefficients to scratch, T* to tr_arr; the sweep + clamp is k_thomas<1> (kernels_thomas.hip)
+    if (wet) {
+      DA2(t.th_a, nz, n) = a; DA2(t.th_b, nz, n) = b; DA2(t.th_c, nz, n) = c; DA2(t.th_r1, nz, n) = rhs;
+      DTR(m.tr_arr, nz, n, tr) = T;
     }
-    double tn = tpp, ts = tn;
-    for (j = nzmax - 3; j >= nzmin - 1; --j) {
-      tn = bcast(tp_m, j) - bcast(cp_m, j) * tn;
-      if (l == j) ts = tn;
-    }
-    if (wet) T = T + ts;
+    return;
   }
   if (wet) {
     if (tr == 1) { if (T > 45.0) T = 45.0; if (T < 3.0) T = 3.0; }
@@ -400,39 +419,48 @@ __global__ void __launch_bounds__(BLOCK) k_tr_update(DM m, int tr) {
 #define LAUNCH_COL(k, ncol, ...) hipLaunchKernelGGL(k, dim3(nblocks(ncol)), dim3(BLOCK), 0, s, __VA_ARGS__)
 
 void launch_tracer(const DM &m, hipStream_t s, int tr) {   // tr 0-based
-  LAUNCH_COL(k_tr_ab_z, m.N, m, tr);
+  LAUNCH_COL(k_tr_ab, m.N, m, tr);
+  LAUNCH_COL(k_tr_z, m.N, m, tr);
   LAUNCH_COL(k_tr_grad_elem, m.myE, m, tr);
-  LAUNCH_COL(k_updn_grad, m.myD, m);
+  LAUNCH_COL(k_updn_grad, m.myD, m, tr);
   LAUNCH_COL(k_flux_hor, m.myD, m, tr);
   LAUNCH_COL(k_fct_lo_node, m.myN, m, tr);
-  LAUNCH_COL(k_fct_ebnd, m.myE, m);
-  LAUNCH_COL(k_fct_node, m.myN, m);
-  LAUNCH_COL(k_fct_edge_limit, m.myD, m);
+  LAUNCH_COL(k_fct_ebnd, m.myE, m, tr);
+  LAUNCH_COL(k_fct_node, m.myN, m, tr);
+  LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr);
   LAUNCH_COL(k_tr_update, m.myN, m, tr);
+  if (m.p.with_diffusion && m.p.i_vert_diff) launch_thomas_tracer(m, s, tr);
 }
 
 int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
   int tr = arg - 1;
   if (!strncmp(name, "k_", 2)) {
-    if (!strcmp(name, "k_tr_ab_z")) { LAUNCH_COL(k_tr_ab_z, m.N, m, tr); return 0; }
+    if (!strcmp(name, "k_tr_ab")) { LAUNCH_COL(k_tr_ab, m.N, m, tr); return 0; }
+    if (!strcmp(name, "k_tr_z")) { LAUNCH_COL(k_tr_z, m.N, m, tr); return 0; }
     if (!strcmp(name, "k_tr_grad_elem")) { LAUNCH_COL(k_tr_grad_elem, m.myE, m, tr); return 0; }
-    if (!strcmp(name, "k_updn_grad")) { LAUNCH_COL(k_updn_grad, m.myD, m); return 0; }
+    if (!strcmp(name, "k_updn_grad")) { LAUNCH_COL(k_updn_grad, m.myD, m, tr); return 0; }
     if (!strcmp(name, "k_flux_hor")) { LAUNCH_COL(k_flux_hor, m.myD, m, tr); return 0; }
     if (!strcmp(name, "k_fct_lo_node")) { LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); return 0; }
-    if (!strcmp(name, "k_fct_ebnd")) { LAUNCH_COL(k_fct_ebnd, m.myE, m); return 0; }
-    if (!strcmp(name, "k_fct_node")) { LAUNCH_COL(k_fct_node, m.myN, m); return 0; }
-    if (!strcmp(name, "k_fct_edge_limit")) { LAUNCH_COL(k_fct_edge_limit, m.myD, m); return 0; }
+    if (!strcmp(name, "k_fct_ebnd")) { LAUNCH_COL(k_fct_ebnd, m.myE, m, tr); return 0; }
+    if (!strcmp(name, "k_fct_node")) { LAUNCH_COL(k_fct_node, m.myN, m, tr); return 0; }
+    if (!strcmp(name, "k_fct_edge_limit")) { LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr); return 0; }
     if (!strcmp(name, "k_tr_update")) { LAUNCH_COL(k_tr_update, m.myN, m, tr); return 0; }
+    if (!strcmp(name, "k_thomas_tracer")) { launch_thomas_tracer(m, s, tr); return 0; }
     return -1;
   }
   if (!strcmp(name, "init_tracers_AB")) {
-    LAUNCH_COL(k_tr_ab_z, m.N, m, tr); LAUNCH_COL(k_tr_grad_elem, m.myE, m, tr); LAUNCH_COL(k_updn_grad, m.myD, m); return 0;
+    LAUNCH_COL(k_tr_ab, m.N, m, tr); LAUNCH_COL(k_tr_z, m.N, m, tr); LAUNCH_COL(k_tr_grad_elem, m.myE, m, tr);
+    LAUNCH_COL(k_updn_grad, m.myD, m, tr); return 0;
   }
   if (!strcmp(name, "adv_tracers_ale")) {
-    LAUNCH_COL(k_flux_hor, m.myD, m, tr); LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); LAUNCH_COL(k_fct_ebnd, m.myE, m);
-    LAUNCH_COL(k_fct_node, m.myN, m); LAUNCH_COL(k_fct_edge_limit, m.myD, m); return 0;
+    LAUNCH_COL(k_flux_hor, m.myD, m, tr); LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); LAUNCH_COL(k_fct_ebnd, m.myE, m, tr);
+    LAUNCH_COL(k_fct_node, m.myN, m, tr); LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr); return 0;
   }
-  if (!strcmp(name, "diff_tracers_ale")) { LAUNCH_COL(k_tr_update, m.myN, m, tr); return 0; }   // incl. flux2dtracer + clamp
+  if (!strcmp(name, "diff_tracers_ale")) {                                                    // incl. flux2dtracer + clamp
+    LAUNCH_COL(k_tr_update, m.myN, m, tr);
+    if (m.p.with_diffusion && m.p.i_vert_diff) launch_thomas_tracer(m, s, tr);
+    return 0;
+  }
   if (!strcmp(name, "salinity_clamp")) return 0;
   return -1;
 }

@@ -61,55 +61,68 @@ __global__ void __launch_bounds__(ST) k_solver_lds(DM m, int maxits, double tol2
 template <int W>
 __global__ void __launch_bounds__(ST) k_solver_glb(DM m, int maxits, double tol2, int NP) {
   extern __shared__ double lds[];
-  solver_body<W, false>(m, maxits, tol2, NP, lds, lds + 2 * ST, m.sv_ph, m.sv_s, (unsigned short *)m.sv_x0);
+  solver_body<W, false>(m, maxits, tol2, NP, lds, lds + 2 * ST, m.sv_ph, m.sv_s, m.sv_cols);
+}
+
+// Set-up of one solve on the whole GPU (thread per row, coalesced ELL writes): row scaling (psolve.c:58-65), Jacobi
+// diagonal, B = A_s D^-1 in ELL [k][row], b = rhs*scale, y0 = D x0.  The column pattern (ELL, uint16) is static and
+// built once at init (m.sv_cols).
+template <int W>
+__global__ void k_solver_setup(DM m, int NP) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NP) return;
+  const int n = m.myN;
+  const int *rp = m.rowptr, *ci = m.colind;
+  double *Bg = m.sv_vals;
+  if (i >= n) {
+#pragma unroll
+    for (int k = 0; k < W; k++) Bg[k * NP + i] = 0.0;
+    m.sv_s[i] = 0.0;
+    return;
+  }
+  int j0 = rp[i], j1 = rp[i + 1];
+  double tmp = 0.;
+  for (int j = j0; j < j1; j++) tmp += fabs(m.ssh_values[j]);
+  double sc = 1. / tmp;
+  m.sv_b[i] = m.ssh_rhs[i] * sc;
+  double diag = m.ssh_values[j0] * sc;                    // first entry of a row is the diagonal (oce_ale.F90:1128-1151)
+  m.sv_dinv[i] = diag;
+  m.sv_s[i] = m.d_eta[i] * diag;                          // y0 = D x0
+#pragma unroll
+  for (int k = 0; k < W; k++) {
+    double bk = 0.0;
+    if (j0 + k < j1) {
+      int c = ci[j0 + k];
+      int c0 = rp[c], c1 = rp[c + 1];
+      double tc = 0.;
+      for (int j = c0; j < c1; j++) tc += fabs(m.ssh_values[j]);
+      double dinv_c = 1.0 / (m.ssh_values[c0] * (1. / tc));
+      bk = (m.ssh_values[j0 + k] * sc) * dinv_c;           // B = A_s D^-1
+    }
+    Bg[k * NP + i] = bk;
+  }
 }
 
 template <int W, bool IN_LDS>
 __device__ __forceinline__ void solver_body(const DM &m, int maxits, double tol2, int NP, double *red, double *out, double *pl, double *sl,
                                             unsigned short *cl) {
-  // red: 2*ST, out: 8, pl: NP (p; scratch for D^-1 during setup), sl: NP (s; scratch for y0), cl: W*NP column indices [k][row]
+  // red: 2*ST, out: 8, pl: NP (p), sl: NP (s; y0 at entry), cl: W*NP column indices [k][row]
   const int t = threadIdx.x, n = m.myN;
-  const int *rp = m.rowptr, *ci = m.colind;
-  double *Bg = m.sv_vals;                                // ELL [k][row]
+  double *Bg = m.sv_vals;                                // ELL [k][row], prepared by k_solver_setup
   double *r = m.sv_r, *r0 = m.sv_r0, *y = m.sv_p, *v = m.sv_v, *tv = m.sv_t, *b = m.sv_b, *diagg = m.sv_dinv, *x = m.d_eta;
-  // ---- setup: row scaling (psolve.c:58-65), Jacobi diagonal
-  for (int i = t; i < NP; i += ST) {
-    double diag = 1.0, sc = 0.0;
-    int j0 = 0, j1 = 0;
-    if (i < n) {
-      j0 = rp[i]; j1 = rp[i + 1];
-      double tmp = 0.;
-      for (int j = j0; j < j1; j++) tmp += fabs(m.ssh_values[j]);
-      sc = 1. / tmp;
-      b[i] = m.ssh_rhs[i] * sc;
-      diag = m.ssh_values[j0] * sc;                        // first entry of a row is the diagonal (oce_ale.F90:1128-1151)
-      diagg[i] = diag;
-    }
-#pragma unroll
-    for (int k = 0; k < W; k++) {
-      bool in = (j0 + k < j1);
-      Bg[k * NP + i] = in ? m.ssh_values[j0 + k] * sc : 0.0;
-      cl[k * NP + i] = (unsigned short)(in ? ci[j0 + k] : (i < n ? i : 0));
-    }
-    pl[i] = 1.0 / diag;                                    // D^-1
-    sl[i] = (i < n) ? x[i] * diag : 0.0;                   // y0 = D x0
+  if (IN_LDS) {
+    for (int e = t; e < W * NP; e += ST) cl[e] = m.sv_cols[e];
+    for (int i = t; i < NP; i += ST) sl[i] = m.sv_s[i];
+    __syncthreads();
   }
-  __syncthreads();
   double prr = 0.0;
-  for (int i = t; i < NP; i += ST) {
+  for (int i = t; i < n; i += ST) {
     double a = 0.0;
 #pragma unroll
-    for (int k = 0; k < W; k++) {
-      int c = cl[k * NP + i];
-      double bk = Bg[k * NP + i] * pl[c];                  // B = A_s D^-1
-      Bg[k * NP + i] = bk;
-      a = a + bk * sl[c];
-    }
-    if (i < n) {
-      double ri = b[i] - a;
-      r[i] = ri; r0[i] = ri; v[i] = 0.0; y[i] = sl[i];
-      prr = prr + ri * ri;
-    }
+    for (int k = 0; k < W; k++) a = a + Bg[k * NP + i] * sl[cl[k * NP + i]];
+    double ri = b[i] - a;
+    r[i] = ri; r0[i] = ri; v[i] = 0.0; y[i] = sl[i];
+    prr = prr + ri * ri;
   }
   __syncthreads();
   for (int i = t; i < NP; i += ST) pl[i] = 0.0;           // p = 0
@@ -163,142 +176,11 @@ __device__ __forceinline__ void solver_body(const DM &m, int maxits, double tol2
   if (t == 0) { m.sv_info[0] = it; m.sv_resid[0] = sqrt(rr); }
 }
 
-// ---- small systems (n <= ST*ROWS): own-row vectors r, r0, v, t, y stay in REGISTERS (row loop unrolled), so an
-// iteration reads only the ELL operator from L2 (all ROWS*W loads of a thread in flight at once).
-template <int W, int ROWS>
-__global__ void __launch_bounds__(ST) k_solver_small(DM m, int maxits, double tol2, int NP) {
-  extern __shared__ double lds[];
-  double *red = lds, *out = lds + 2 * ST, *pl = lds + 2 * ST + 8, *sl = pl + NP;
-  unsigned short *cl = (unsigned short *)(sl + NP);      // ST*ROWS*W indices
-  const int t = threadIdx.x, n = m.myN;
-  const int *rp = m.rowptr, *ci = m.colind;
-  double *Bg = m.sv_vals, *x = m.d_eta;
-  double r[ROWS], r0[ROWS], v[ROWS], y[ROWS], dg[ROWS];
-#define EIDX(k, q) (((k) * ROWS + (q)) * ST + t)      /* ELL [k][q][t]: compile-time strides -> scalar address offsets */
-#pragma unroll
-  for (int q = 0; q < ROWS; q++) {
-    int i = t + q * ST;
-    double diag = 1.0, sc = 0.0;
-    int j0 = 0, j1 = 0;
-    if (i < n) {
-      j0 = rp[i]; j1 = rp[i + 1];
-      double tmp = 0.;
-      for (int j = j0; j < j1; j++) tmp += fabs(m.ssh_values[j]);
-      sc = 1. / tmp;
-      m.sv_b[i] = m.ssh_rhs[i] * sc;
-      diag = m.ssh_values[j0] * sc;
-      m.sv_dinv[i] = diag;
-    }
-#pragma unroll
-    for (int k = 0; k < W; k++) {
-      bool in = (j0 + k < j1);
-      Bg[EIDX(k, q)] = in ? m.ssh_values[j0 + k] * sc : 0.0;
-      cl[EIDX(k, q)] = (unsigned short)(in ? ci[j0 + k] : (i < n ? i : 0));
-    }
-    if (i < NP) {
-      pl[i] = 1.0 / diag;
-      sl[i] = (i < n) ? x[i] * diag : 0.0;
-    }
-  }
-  __syncthreads();
-  double prr = 0.0;
-#pragma unroll
-  for (int q = 0; q < ROWS; q++) {
-    int i = t + q * ST;
-    r[q] = 0.0; r0[q] = 0.0; v[q] = 0.0; y[q] = 0.0; dg[q] = 1.0;
-    {
-      double a = 0.0;
-#pragma unroll
-      for (int k = 0; k < W; k++) {
-        int c = cl[EIDX(k, q)];
-        double bk = Bg[EIDX(k, q)] * pl[c];
-        Bg[EIDX(k, q)] = bk;
-        a = a + bk * sl[c];
-      }
-      if (i < n) {
-        double ri = m.sv_b[i] - a;
-        r[q] = ri; r0[q] = ri; y[q] = sl[i]; dg[q] = m.sv_dinv[i];
-        prr = prr + ri * ri;
-      }
-    }
-    asm volatile("" ::: "memory");
-  }
-  __syncthreads();
-  for (int i = t; i < NP; i += ST) pl[i] = 0.0;
-  double rr, rho_new;
-  reduce2(prr, prr, red, out, rr, rho_new);
-  double rho = 1.0, alpha = 1.0, omega = 1.0;
-  int it = 0;
-  while (rr >= tol2 && it < maxits) {
-    double beta = (rho_new / rho) * (alpha / omega);
-#pragma unroll
-    for (int q = 0; q < ROWS; q++) { int i = t + q * ST; if (i < n) pl[i] = r[q] + beta * (pl[i] - omega * v[q]); }
-    __syncthreads();
-    double p1 = 0.0;
-#pragma unroll
-    for (int q = 0; q < ROWS; q++) {
-      int i = t + q * ST;
-      if (i < n) {
-        double a = 0.0;
-#pragma unroll
-        for (int k = 0; k < W; k++) a = a + Bg[EIDX(k, q)] * pl[cl[EIDX(k, q)]];
-        v[q] = a;
-        p1 = p1 + r0[q] * a;
-      }
-      asm volatile("" ::: "memory");      // one row's W loads in flight at a time: keeps the kernel inside 128 VGPRs
-    }
-    double r0v, dummy;
-    reduce2(p1, 0.0, red, out, r0v, dummy);
-    alpha = rho_new / r0v;
-#pragma unroll
-    for (int q = 0; q < ROWS; q++) { int i = t + q * ST; if (i < n) sl[i] = r[q] - alpha * v[q]; }
-    __syncthreads();
-    double ptt = 0.0, pts = 0.0, tq[ROWS];
-#pragma unroll
-    for (int q = 0; q < ROWS; q++) {
-      int i = t + q * ST;
-      tq[q] = 0.0;
-      if (i < n) {
-        double a = 0.0;
-#pragma unroll
-        for (int k = 0; k < W; k++) a = a + Bg[EIDX(k, q)] * sl[cl[EIDX(k, q)]];
-        tq[q] = a;
-        ptt = ptt + a * a; pts = pts + a * sl[i];
-      }
-      asm volatile("" ::: "memory");
-    }
-    double tt, ts;
-    reduce2(ptt, pts, red, out, tt, ts);
-    omega = (tt > 0.0) ? ts / tt : 0.0;
-    double prho = 0.0;
-    prr = 0.0;
-#pragma unroll
-    for (int q = 0; q < ROWS; q++) {
-      int i = t + q * ST;
-      if (i < n) {
-        double si = sl[i];
-        double ri = si - omega * tq[q];
-        r[q] = ri;
-        y[q] = (y[q] + alpha * pl[i]) + omega * si;
-        prho = prho + r0[q] * ri;
-        prr = prr + ri * ri;
-      }
-    }
-    rho = rho_new;
-    reduce2(prr, prho, red, out, rr, rho_new);
-    it++;
-  }
-#pragma unroll
-  for (int q = 0; q < ROWS; q++) { int i = t + q * ST; if (i < n) x[i] = y[q] * (1.0 / dg[q]); }
-  if (t == 0) { m.sv_info[0] = it; m.sv_resid[0] = sqrt(rr); }
-}
-
 void solver_prepare() {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)k_solver_lds<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_solver_lds<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_solver_small<10, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
 }
@@ -311,12 +193,11 @@ int launch_solver(const DM &m, hipStream_t s) {
   size_t need = fixed + (size_t)NP * (2 * sizeof(double) + W * sizeof(unsigned short));
   int in_lds = need <= 158 * 1024;
   size_t shm = in_lds ? need : fixed;
+  if (W == 10) hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP);
+  else hipLaunchKernelGGL(k_solver_setup<16>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP);
   static int dbg_maxits = getenv("FESOM_SOLVER_MAXITS") ? atoi(getenv("FESOM_SOLVER_MAXITS")) : 2000;   // diagnostics only
   const double tol2 = 1e-10 * 1e-10;
-  size_t shm_small = fixed + (size_t)NP * 2 * sizeof(double) + (size_t)ST * 4 * 10 * sizeof(unsigned short);
-  if (W == 10 && NP <= 4 * ST && shm_small <= 158 * 1024 && getenv("FESOM_GPU_SMALL_SOLVER")) {   // experimental: slower on gfx950 (register spills)
-    hipLaunchKernelGGL((k_solver_small<10, 4>), dim3(1), dim3(ST), shm_small, s, m, dbg_maxits, tol2, NP);
-  } else if (in_lds) {
+  if (in_lds) {
     if (W == 10) hipLaunchKernelGGL(k_solver_lds<10>, dim3(1), dim3(ST), shm, s, m, dbg_maxits, tol2, NP);
     else hipLaunchKernelGGL(k_solver_lds<16>, dim3(1), dim3(ST), shm, s, m, dbg_maxits, tol2, NP);
   } else {
