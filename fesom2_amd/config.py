@@ -6,7 +6,7 @@ from .mesh import WHICH_ALE
 
 def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equation=1, num_tracers=2,
                 mix_scheme="PP", with_diffusion=True, toy_soufflet=False, K_hor=3000.0, A_ver=1.0e-4, K_ver=1.0e-5,
-                cyclic_length_deg=360.0, w_split=False, use_instabmix=True, use_windmix=False):
+                cyclic_length_deg=360.0, w_split=False, use_instabmix=True, use_windmix=False, solver_x0_order=2):
     p = _lib.Params()
     p.dt = dt
     p.which_ale = WHICH_ALE[which_ale]
@@ -31,4 +31,5 @@ def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equati
     p.instabmix_kv, p.windmix_kv = 0.1, 1.0e-3
     p.cyclic_length = cyclic_length_deg * 3.14159265358979 / 180.0
     p.with_diffusion = int(with_diffusion)
+    p.solver_x0_order = int(solver_x0_order)
     return p

@@ -310,7 +310,8 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   FT(tt_a, n1 * N); FT(tt_b, n1 * N); FT(tt_c, n1 * N); FT(tt_r, n1 * N);
   F(sv_vals, 16 * (N + 64)); F(sv_dinv, N + 64); F(sv_b, N + 64); F(sv_r, N + 64); F(sv_r0, N + 64); F(sv_p, N + 64); F(sv_v, N + 64); F(sv_s, N + 64); F(sv_t, N + 64);
   F(sv_ph, N + 64); F(sv_x0, 16 * (N + 64)); F(sv_snap, N);
-  F(sv_resid, 1);
+  F(sv_resid, 1); F(sv_h1, N); F(sv_h2, N);
+  m.sv_extrap = 1;
 #undef F
 #undef FT
   m.sv_info = dev_alloc<int>(4);

@@ -55,18 +55,32 @@ __device__ __forceinline__ void solver_body(const DM &m, int maxits, double tol2
 template <int W>
 __global__ void __launch_bounds__(ST) k_solver_lds(DM m, int maxits, double tol2, int NP) {
   extern __shared__ double lds[];
-  double *pl = lds + 2 * ST + 8, *sl = pl + NP;
-  solver_body<W, true>(m, maxits, tol2, NP, lds, lds + 2 * ST, pl, sl, (unsigned short *)(sl + NP));
+  double *pl = lds + 4 * ST + 8, *sl = pl + NP;
+  solver_body<W, true>(m, maxits, tol2, NP, lds, lds + 4 * ST, pl, sl, (unsigned short *)(sl + NP));
 }
 template <int W>
 __global__ void __launch_bounds__(ST) k_solver_glb(DM m, int maxits, double tol2, int NP) {
   extern __shared__ double lds[];
-  solver_body<W, false>(m, maxits, tol2, NP, lds, lds + 2 * ST, m.sv_ph, m.sv_s, m.sv_cols);
+  solver_body<W, false>(m, maxits, tol2, NP, lds, lds + 4 * ST, m.sv_ph, m.sv_s, m.sv_cols);
 }
 
 // Set-up of one solve on the whole GPU (thread per row, coalesced ELL writes): row scaling (psolve.c:58-65), Jacobi
 // diagonal, B = A_s D^-1 in ELL [k][row], b = rhs*scale, y0 = D x0.  The column pattern (ELL, uint16) is static and
 // built once at init (m.sv_cols).
+__device__ __forceinline__ void reduce4(double a, double b, double c, double d, double *red, double *out, double &ra, double &rb, double &rc,
+                                        double &rd) {
+  int t = threadIdx.x;
+  red[t] = a; red[ST + t] = b; red[2 * ST + t] = c; red[3 * ST + t] = d;
+  __syncthreads();
+  if (t < 256) {                                  // waves 0..3 reduce one quantity each (same tree as reduce2)
+    int q = t >> 6, l = t & 63;
+    double xv = tree16(red + q * ST, l);
+    if (l == 0) out[q] = xv;
+  }
+  __syncthreads();
+  ra = out[0]; rb = out[1]; rc = out[2]; rd = out[3];
+}
+
 template <int W>
 __global__ void k_solver_setup(DM m, int NP) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -87,7 +101,10 @@ __global__ void k_solver_setup(DM m, int NP) {
   m.sv_b[i] = m.ssh_rhs[i] * sc;
   double diag = m.ssh_values[j0] * sc;                    // first entry of a row is the diagonal (oce_ale.F90:1128-1151)
   m.sv_dinv[i] = diag;
-  m.sv_s[i] = m.d_eta[i] * diag;                          // y0 = D x0
+  double xi = m.d_eta[i], x0 = xi;                       // initial guess: previous solution or quadratic extrapolation
+  if (m.p.solver_x0_order == 2 && m.sv_extrap && m.sv_info[1] >= 2) x0 = (3.0 * xi - 3.0 * m.sv_h1[i]) + m.sv_h2[i];
+  if (m.sv_extrap) { m.sv_h2[i] = m.sv_h1[i]; m.sv_h1[i] = xi; }
+  m.sv_s[i] = x0 * diag;                                  // y0 = D x0
 #pragma unroll
   for (int k = 0; k < W; k++) {
     double bk = 0.0;
@@ -130,9 +147,13 @@ __device__ __forceinline__ void solver_body(const DM &m, int maxits, double tol2
   reduce2(prr, prr, red, out, rr, rho_new);
   double rho = 1.0, alpha = 1.0, omega = 1.0;
   int it = 0;
-  while (rr >= tol2 && it < maxits) {
+  // BiCGstab with TWO reduction points per iteration (rho and ||r||^2 from recurrences, see the oracle) and the
+  // y/r update of iteration k fused with the p update of iteration k+1 (own rows, no barrier in between).
+  if (rr >= tol2 && it < maxits) {
     double beta = (rho_new / rho) * (alpha / omega);
     for (int i = t; i < n; i += ST) pl[i] = r[i] + beta * (pl[i] - omega * v[i]);
+  }
+  while (rr >= tol2 && it < maxits) {
     __syncthreads();
     double p1 = 0.0;
     for (int i = t; i < n; i += ST) {
@@ -147,33 +168,34 @@ __device__ __forceinline__ void solver_body(const DM &m, int maxits, double tol2
     alpha = rho_new / r0v;
     for (int i = t; i < n; i += ST) sl[i] = r[i] - alpha * v[i];
     __syncthreads();
-    double ptt = 0.0, pts = 0.0;
+    double ptt = 0.0, pts = 0.0, pr0t = 0.0, pss = 0.0;
     for (int i = t; i < n; i += ST) {
       double a = 0.0;
 #pragma unroll
       for (int k = 0; k < W; k++) a = a + Bg[k * NP + i] * sl[cl[k * NP + i]];
       tv[i] = a;
-      ptt = ptt + a * a; pts = pts + a * sl[i];
-    }
-    double tt, ts;
-    reduce2(ptt, pts, red, out, tt, ts);
-    omega = (tt > 0.0) ? ts / tt : 0.0;
-    double prho = 0.0;
-    prr = 0.0;
-    for (int i = t; i < n; i += ST) {
       double si = sl[i];
+      ptt = ptt + a * a; pts = pts + a * si; pr0t = pr0t + r0[i] * a; pss = pss + si * si;
+    }
+    double tt, ts, r0t, ss;
+    reduce4(ptt, pts, pr0t, pss, red, out, tt, ts, r0t, ss);
+    omega = (tt > 0.0) ? ts / tt : 0.0;
+    rho = rho_new;
+    rho_new = -omega * r0t;
+    rr = ss - omega * (2.0 * ts - omega * tt);
+    it++;
+    bool more = (rr >= tol2 && it < maxits);
+    double beta = more ? (rho_new / rho) * (alpha / omega) : 0.0;
+    for (int i = t; i < n; i += ST) {
+      double si = sl[i], pi = pl[i];
       double ri = si - omega * tv[i];
       r[i] = ri;
-      y[i] = (y[i] + alpha * pl[i]) + omega * si;
-      prho = prho + r0[i] * ri;
-      prr = prr + ri * ri;
+      y[i] = (y[i] + alpha * pi) + omega * si;
+      if (more) pl[i] = ri + beta * (pi - omega * v[i]);
     }
-    rho = rho_new;
-    reduce2(prr, prho, red, out, rr, rho_new);
-    it++;
   }
   for (int i = t; i < n; i += ST) x[i] = y[i] * (1.0 / diagg[i]);
-  if (t == 0) { m.sv_info[0] = it; m.sv_resid[0] = sqrt(rr); }
+  if (t == 0) { m.sv_info[0] = it; m.sv_resid[0] = sqrt(rr > 0.0 ? rr : 0.0); if (m.sv_extrap && m.sv_info[1] < 2) m.sv_info[1] = m.sv_info[1] + 1; }
 }
 
 void solver_prepare() {
@@ -189,7 +211,7 @@ int launch_solver(const DM &m, hipStream_t s) {
   int W = m.ssh_maxnnz <= 10 ? 10 : 16;
   if (m.ssh_maxnnz > 16 || m.myN >= 65536) return 1;     // uint16 columns / ELL width limits of this round
   int NP = (m.myN + 63) / 64 * 64;
-  size_t fixed = (size_t)(2 * ST + 8) * sizeof(double);
+  size_t fixed = (size_t)(4 * ST + 8) * sizeof(double);
   size_t need = fixed + (size_t)NP * (2 * sizeof(double) + W * sizeof(unsigned short));
   int in_lds = need <= 158 * 1024;
   size_t shm = in_lds ? need : fixed;

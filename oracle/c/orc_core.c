@@ -39,7 +39,7 @@ int orc_init(const fesom_mesh_desc *m, const fesom_params *p) {
   R(UV, 2 * n1 * E); R(UV_rhs, 2 * n1 * E); R(UV_rhsAB, 2 * n1 * E); R(tr_xy, 2 * n1 * E); R(U_b, 2 * n1 * E); R(fct_ebnd, 2 * n1 * E);
   R(pgf_x, n1 * E); R(pgf_y, n1 * E); R(helem, n1 * E); R(Av, nl * E); R(dhe, E); R(stress_surf, 2 * E);
   R(adv_flux_hor, n1 * D); R(edge_up_dn_grad, 4 * n1 * D);
-  R(ssh_values, m->ssh_nza);
+  R(ssh_values, m->ssh_nza); R(sv_h1, N); R(sv_h2, N);
 #undef R
   for (size_t i = 0; i < n1 * N; i++) C_.density_ref[i] = DENSITY_0;
   memcpy(C_.ssh_values, m->ssh_values, sizeof(double) * m->ssh_nza);
@@ -98,6 +98,14 @@ void orc_solve_ssh(void) {
   double *B = malloc(sizeof(double) * C_.m.ssh_nza), *diag = malloc(sizeof(double) * n * 10);
   double *dinv = diag + n, *b = dinv + n, *r = b + n, *r0 = r + n, *pv = r0 + n, *v = pv + n, *s = v + n, *t = s + n, *y = t + n;
   double *x = C_.d_eta;
+  /* initial guess: previous solution (reference) or quadratic extrapolation of the last three solutions */
+  for (int i = 0; i < n; i++) {
+    double xi = x[i], x0 = xi;
+    if (C_.p.solver_x0_order == 2 && C_.sv_nhist >= 2) x0 = (3.0 * xi - 3.0 * C_.sv_h1[i]) + C_.sv_h2[i];
+    C_.sv_h2[i] = C_.sv_h1[i]; C_.sv_h1[i] = xi;
+    x[i] = x0;
+  }
+  if (C_.sv_nhist < 2) C_.sv_nhist++;
   for (int i = 0; i < n; i++) {
     double tmp = 0.;
     for (int j = rp[i] - off; j < rp[i + 1] - off; j++) tmp += fabs(C_.ssh_values[j]);
@@ -119,6 +127,8 @@ void orc_solve_ssh(void) {
   double rr = dot_fixed(r, r, n);
   double rho_new = rr;
   int it = 0;
+  /* BiCGstab with two reduction points per iteration: rho and ||r||^2 come from recurrences
+   * (r0.s = 0 by construction  =>  r0.r = -omega r0.t ;  r = s - omega t  =>  r.r = s.s - omega(2 t.s - omega t.t)) */
   while (rr >= tol2 && it < maxits) {
     double beta = (rho_new / rho) * (alpha / omega);
     for (int i = 0; i < n; i++) pv[i] = r[i] + beta * (pv[i] - omega * v[i]);
@@ -126,16 +136,16 @@ void orc_solve_ssh(void) {
     alpha = rho_new / dot_fixed(r0, v, n);
     for (int i = 0; i < n; i++) s[i] = r[i] - alpha * v[i];
     SPMV(t, s);
-    double tt = dot_fixed(t, t, n), ts = dot_fixed(t, s, n);
+    double tt = dot_fixed(t, t, n), ts = dot_fixed(t, s, n), r0t = dot_fixed(r0, t, n), ss = dot_fixed(s, s, n);
     omega = (tt > 0.0) ? ts / tt : 0.0;
     for (int i = 0; i < n; i++) { y[i] = (y[i] + alpha * pv[i]) + omega * s[i]; r[i] = s[i] - omega * t[i]; }
     rho = rho_new;
-    rr = dot_fixed(r, r, n);
-    rho_new = dot_fixed(r0, r, n);
+    rho_new = -omega * r0t;
+    rr = ss - omega * (2.0 * ts - omega * tt);
     it++;
   }
   for (int i = 0; i < n; i++) x[i] = y[i] * (1.0 / diag[i]);
-  C_.solver_iters = it; C_.solver_resid = sqrt(rr);
+  C_.solver_iters = it; C_.solver_resid = sqrt(rr > 0.0 ? rr : 0.0);
   free(B); free(diag);
 }
 

@@ -10,14 +10,14 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PI = os.path.join(REPO, "tests", "golden", "meshes", "pi")
 
 
-def make(which_ale="zstar", state_equation=1, with_diffusion=True, mix="PP"):
+def make(which_ale="zstar", state_equation=1, with_diffusion=True, mix="PP", x0=2):
     from fesom2_amd.mesh import Mesh
     from fesom2_amd.config import make_params
     from fesom2_amd.synthetic import analytic_ts
     from oracle_lib import Oracle
     mesh = Mesh.load(PI, dt=900.0, which_ale=which_ale, use_partial_cell=(which_ale != "linfs"))
     par = make_params(dt=900.0, which_ale=which_ale, use_partial_cell=(which_ale != "linfs"), state_equation=state_equation,
-                      with_diffusion=with_diffusion, mix_scheme=mix)
+                      with_diffusion=with_diffusion, mix_scheme=mix, solver_x0_order=x0)
     st = mesh.initial_state(2)
     st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
     st.tr_arr_old[...] = st.tr_arr
@@ -79,7 +79,7 @@ def test_variants_run(built, which_ale, eos):
 
 def test_solver_zero_rhs_and_idempotence(built):
     """a converged iterate is a fixed point: solving again from the solution performs zero iterations"""
-    mesh, orc = make()
+    mesh, orc = make(x0=0)                   # reference initial guess (x0 = previous d_eta)
     orc.call("step", 1)
     for r in ("compute_vel_nodes", "pressure_bv", "pressure_force", "sw_alpha_beta", "compute_sigma_xy", "compute_neutral_slope",
               "mixing_pp", "mo_convect", "compute_vel_rhs", "visc_filt_bcksct", "impl_vert_visc_ale", "update_stiff_mat_ale",
