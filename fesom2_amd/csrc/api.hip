@@ -8,6 +8,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <chrono>
 #include <map>
 #include <algorithm>
 
@@ -103,7 +104,63 @@ int K(hipStream_t s, const char *k, int arg = 0, int fs = 0) {
   if (rc < 0) rc = launch_named_tra(G.m, s, k, arg);
   return rc;
 }
-void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d) {
+static void enqueue_step_dag_b(hipStream_t s0, int first_step, Dag &d) {
+  // Cross-stream event waits cost ~15 us on this stack, same-stream boundaries ~2 us: the critical chain stays on s0
+  // (momentum -> SSH solve -> W -> T advection -> thickness); side streams carry what only has to be READY by then.
+  const DM &m = G.m;
+  hipStream_t s1 = G.side[0], s2 = G.side[1], s3 = G.side[2];
+  d.dep(s1, s0); d.dep(s2, s0); d.dep(s3, s0);
+  // s1: pressure -> PGF -> velocity rhs ; SSH operator update + row scales ; later dhe
+  K(s1, "k_pressure_bv");
+  hipEvent_t ev_pb = d.ev(); hipEventRecord(ev_pb, s1);
+  K(s1, "k_pgf");
+  K(s2, "k_momadv_node");
+  d.dep(s1, s2);
+  K(s1, "k_vel_rhs", 0, first_step);
+  hipEvent_t ev_rhs = d.ev(); hipEventRecord(ev_rhs, s1);
+  if (m.p.which_ale != 0) K(s1, "k_stiff_update");
+  launch_row_scale(m, s1);
+  hipEvent_t ev_op = d.ev(); hipEventRecord(ev_op, s1);
+  // s3: viscosity stencil, then everything nobody waits for soon (sigma/slope, tracer preparation)
+  K(s3, "k_visc_elem"); K(s3, "k_visc_node");
+  hipEvent_t ev_visc = d.ev(); hipEventRecord(ev_visc, s3);
+  hipStreamWaitEvent(s3, ev_pb, 0);
+  K(s3, "k_sigma_slope");
+  std::vector<hipEvent_t> ev_prep(m.ntr);
+  for (int tr = 0; tr < m.ntr; tr++) {
+    K(s3, "k_tr_ab", tr + 1); K(s3, "k_tr_grad_elem", tr + 1); K(s3, "k_updn_grad", tr + 1);
+    ev_prep[tr] = d.ev(); hipEventRecord(ev_prep[tr], s3);
+  }
+  // s0: critical chain
+  K(s0, "k_vel_nodes");
+  hipStreamWaitEvent(s0, ev_pb, 0);
+  if (m.p.mix_scheme == 2) { K(s0, "k_pp_node_raw"); K(s0, "k_pp_elem"); K(s0, "k_pp_node_final"); }
+  hipStreamWaitEvent(s0, ev_rhs, 0); hipStreamWaitEvent(s0, ev_visc, 0);
+  K(s0, "k_impl_visc");
+  if (m.p.i_vert_visc) K(s0, "k_thomas_visc");
+  K(s0, "k_edge_transport");
+  hipStreamWaitEvent(s0, ev_op, 0);
+  launch_solver(m, s0, 1, 1);                      // set-up gathers ssh_rhs (k_ssh_rhs_node fused); row scales from s1
+  K(s0, "k_update_vel"); K(s0, "k_edge_transport1");
+  K(s0, "k_vert_vel_hbar");                        // k_hbar_node fused
+  hipEvent_t ev_w = d.ev(); hipEventRecord(ev_w, s0);
+  hipStreamWaitEvent(s1, ev_w, 0);
+  K(s1, "k_dhe");
+  // tracers: tracer 0 continues on s0, the others on s2 (independent chains, own scratch slabs)
+  hipStreamWaitEvent(s2, ev_w, 0);
+  for (int tr = m.ntr - 1; tr >= 0; tr--) {
+    static const int tv = getenv("FESOM_DAG_TV") ? atoi(getenv("FESOM_DAG_TV")) : 0;
+    hipStream_t st = tv == 0 ? ((tr == 0) ? s0 : s2) : tv == 1 ? s0 : ((tr == 0) ? s2 : s1);
+    hipStreamWaitEvent(st, ev_prep[tr], 0);
+    K(st, "k_tr_z", tr + 1); K(st, "k_flux_hor", tr + 1); K(st, "k_fct_lo_node", tr + 1); K(st, "k_fct_ebnd", tr + 1);
+    K(st, "k_fct_node", tr + 1); K(st, "k_fct_edge_limit", tr + 1); K(st, "k_tr_update", tr + 1);
+    if (m.p.with_diffusion && m.p.i_vert_diff) K(st, "k_thomas_tracer", tr + 1);
+  }
+  d.dep(s0, s1); d.dep(s0, s2); d.dep(s0, s3);
+  launch_thickness(m, s0);
+}
+
+static void enqueue_step_dag_a(hipStream_t s0, int first_step, Dag &d, int v) {
   const DM &m = G.m;
   hipStream_t s1 = G.side[0], s2 = G.side[1], s3 = G.side[2];
   d.dep(s1, s0); d.dep(s2, s0); d.dep(s3, s0);
@@ -121,23 +178,26 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d) {
   K(s3, "k_sigma_slope");                          // leaf of this step (consumed by GM/Redi/KPP only)
   if (m.p.mix_scheme == 2) { K(s0, "k_pp_node_raw"); K(s0, "k_pp_elem"); K(s0, "k_pp_node_final"); }
   // tracer preparation: only needs the tracers -> overlaps everything up to vert_vel_ale (incl. the SSH solve)
-  for (int tr = 0; tr < m.ntr; tr++) {
-    hipStream_t st = (tr % 2 == 0) ? s2 : s3;
-    K(st, "k_tr_ab", tr + 1); K(st, "k_tr_grad_elem", tr + 1); K(st, "k_updn_grad", tr + 1);
-  }
+  auto prep = [&]() {
+    for (int tr = 0; tr < m.ntr; tr++) {
+      hipStream_t st = (tr % 2 == 0) ? s2 : s3;
+      K(st, "k_tr_ab", tr + 1); K(st, "k_tr_grad_elem", tr + 1); K(st, "k_updn_grad", tr + 1);
+    }
+  };
+  if (v == 0) prep();
   d.dep(s0, s1); hipStreamWaitEvent(s0, ev_visc, 0);
   K(s0, "k_impl_visc");
   if (m.p.i_vert_visc) K(s0, "k_thomas_visc");
-  d.dep(s1, s0);
   if (m.p.which_ale != 0) K(s1, "k_stiff_update");
+  launch_row_scale(m, s1);
   K(s0, "k_edge_transport");
-  K(s0, "k_ssh_rhs_node");
   d.dep(s0, s1);
-  launch_solver(m, s0);
-  K(s0, "k_update_vel"); K(s0, "k_edge_transport1"); K(s0, "k_hbar_node");
+  launch_solver(m, s0, 1, 1);
+  if (v == 3) prep();
+  K(s0, "k_update_vel"); K(s0, "k_edge_transport1");
+  K(s0, "k_vert_vel_hbar");
   d.dep(s1, s0);
   K(s1, "k_dhe");
-  K(s0, "k_vert_vel");
   // --- tracer chains, one stream each (T on s2, S on s3, further tracers alternate)
   d.dep(s2, s0); d.dep(s3, s0);
   for (int tr = 0; tr < m.ntr; tr++) {
@@ -148,6 +208,11 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d) {
   }
   d.dep(s0, s1); d.dep(s0, s2); d.dep(s0, s3);
   launch_thickness(m, s0);
+}
+
+void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d) {
+  static const int v = getenv("FESOM_DAG_V") ? atoi(getenv("FESOM_DAG_V")) : 0;
+  if (v == 1) enqueue_step_dag_b(s0, first_step, d); else enqueue_step_dag_a(s0, first_step, d, v);
 }
 
 int build_graph(int which) {
@@ -196,8 +261,18 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     if (dev < 0 || dev >= ndev) dev = 0;
     HIPCHK(hipSetDevice(dev));
   }
-  HIPCHK(hipStreamCreate(&G.stream));
-  for (int i = 0; i < 3; i++) HIPCHK(hipStreamCreateWithFlags(&G.side[i], hipStreamNonBlocking));
+  {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);         // hi = numerically lowest = highest priority
+    const char *pe = getenv("FESOM_DAG_PRIO"); int pm = pe ? atoi(pe) : 3;
+    if (pm == 3) {
+      HIPCHK(hipStreamCreate(&G.stream));
+      for (int i = 0; i < 3; i++) HIPCHK(hipStreamCreateWithFlags(&G.side[i], hipStreamNonBlocking));
+    } else {
+      HIPCHK(hipStreamCreateWithPriority(&G.stream, hipStreamDefault, pm ? hi : lo));
+      for (int i = 0; i < 3; i++) HIPCHK(hipStreamCreateWithPriority(&G.side[i], hipStreamNonBlocking, (pm == 1 && i == 2) || pm == 0 ? lo : hi));
+    }
+  }
   G.serial = getenv("FESOM_GPU_SERIAL") != nullptr;
   // Measured on MI355X/ROCm 7.2 (pi): eager 4-stream DAG 0.80 ms/step, hipGraph of the same DAG 0.86, serial chain 0.90
   // (graph replay serialises most branches; kernels are >= 5 us so the host launch rate is not the limit).
@@ -310,7 +385,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   FT(tt_a, n1 * N); FT(tt_b, n1 * N); FT(tt_c, n1 * N); FT(tt_r, n1 * N);
   F(sv_vals, 16 * (N + 64)); F(sv_dinv, N + 64); F(sv_b, N + 64); F(sv_r, N + 64); F(sv_r0, N + 64); F(sv_p, N + 64); F(sv_v, N + 64); F(sv_s, N + 64); F(sv_t, N + 64);
   F(sv_ph, N + 64); F(sv_x0, 16 * (N + 64)); F(sv_snap, N);
-  F(sv_resid, 1); F(sv_h1, N); F(sv_h2, N);
+  F(sv_resid, 1); F(sv_h1, N); F(sv_h2, N); F(sv_scale, N + 64);
   m.sv_extrap = 1;
 #undef F
 #undef FT
@@ -420,6 +495,8 @@ int fesom_gpu_call(const char *routine, int arg) {
 int fesom_gpu_run_steps(int n_first, int nsteps) {
   NEED_READY();
   (void)n_first;
+  static const bool timing = getenv("FESOM_GPU_TIMING") != nullptr;
+  auto t0 = std::chrono::steady_clock::now();
   for (int k = 0; k < nsteps; k++) {
     int which = G.first_step ? 1 : 0;
     if (G.use_graph) {
@@ -431,6 +508,10 @@ int fesom_gpu_run_steps(int n_first, int nsteps) {
       enqueue_step_dag(G.stream, which, dag);
     } else enqueue_step(G.stream, which);
     G.first_step = 0;
+  }
+  if (timing) {
+    double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    fprintf(stderr, "[fesom_gpu] host enqueue: %d steps in %.1f us (%.1f us/step)\n", nsteps, us, us / (nsteps ? nsteps : 1));
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -511,7 +592,7 @@ void psolver_init(int *id, int *stype, int *pctype, int *pcilutype, int *iluleve
   m.ssh_values = (double *)A(sizeof(double) * nza);
   hipMemcpy(m.ssh_values, vals, sizeof(double) * nza, hipMemcpyHostToDevice);
   m.sv_vals = (double *)A(sizeof(double) * 16 * (n + 64));
-  double **vecs[] = {&m.sv_dinv, &m.sv_b, &m.sv_r, &m.sv_r0, &m.sv_p, &m.sv_v, &m.sv_s, &m.sv_t, &m.sv_ph, &m.d_eta, &m.ssh_rhs};
+  double **vecs[] = {&m.sv_scale, &m.sv_dinv, &m.sv_b, &m.sv_r, &m.sv_r0, &m.sv_p, &m.sv_v, &m.sv_s, &m.sv_t, &m.sv_ph, &m.d_eta, &m.ssh_rhs};
   for (auto v : vecs) *v = (double *)A(sizeof(double) * (n + 64));
   m.sv_x0 = (double *)A(sizeof(double) * 16 * (n + 64));
   m.sv_info = (int *)A(16); m.sv_resid = (double *)A(8);

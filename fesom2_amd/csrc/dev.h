@@ -52,6 +52,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   // solver workspace
   double *sv_vals, *sv_dinv, *sv_b, *sv_r, *sv_r0, *sv_p, *sv_v, *sv_s, *sv_t, *sv_ph, *sv_x0, *sv_snap;
   int *sv_info; double *sv_resid;   // sv_info[0] iterations of the last solve, [1] number of stored previous solutions
+  double *sv_scale;
   double *sv_h1, *sv_h2; int sv_extrap;   // previous SSH solutions (extrapolated initial guess), only on the step path
   unsigned short *sv_cols;    // static ELL column pattern [k][NP] of the SSH operator (padding -> own row)
   fesom_params p;
@@ -105,7 +106,8 @@ static inline int nblocks(int ncol) { return (ncol + COLS_PER_BLOCK - 1) / COLS_
 // launchers implemented in the kernel translation units
 void launch_dynamics_pre(const DM &m, hipStream_t s, int first_step);
 void launch_ssh_rhs(const DM &m, hipStream_t s);
-int  launch_solver(const DM &m, hipStream_t s);
+int  launch_solver(const DM &m, hipStream_t s, int fuse_rhs = 0, int scale_done = 0);
+void launch_row_scale(const DM &m, hipStream_t s);
 void launch_dynamics_post(const DM &m, hipStream_t s);
 void launch_tracer(const DM &m, hipStream_t s, int tr);
 void launch_thickness(const DM &m, hipStream_t s);

@@ -553,10 +553,14 @@ __global__ void __launch_bounds__(BLOCK) k_edge_transport(DM m, int mode) {
       else t2 = (vv * DECD(3, ed) - uu * DECD(4, ed)) * h;
     }
   }
-  // c1 = sum_{nz} t1 (top-down), c2 = -sum t2 (reference: c2 = c2 - term)
+  // c1 = sum_{nz} t1 (top-down), c2 = -sum t2 (reference: c2 = c2 - term); one pass over the levels for both
   double c1 = 0.0, c2 = 0.0;
-  for (int j = u1 - 1; j <= l1 - 1; ++j) c1 = c1 + bcast(t1, j);
-  if (e2 >= 0) for (int j = u2 - 1; j <= l2 - 1; ++j) c2 = c2 - bcast(t2, j);
+  int jhi = (l1 > l2 ? l1 : l2) - 1;
+  for (int j = 0; j <= jhi; ++j) {
+    double a1 = bcast(t1, j), a2 = bcast(t2, j);
+    if (j >= u1 - 1 && j <= l1 - 1) c1 = c1 + a1;
+    if (j >= u2 - 1 && j <= l2 - 1) c2 = c2 - a2;
+  }
   if (l == 0) m.edge_c12[ed] = c1 + c2;
 }
 __global__ void k_ssh_rhs_node(DM m) {
@@ -619,11 +623,27 @@ __global__ void __launch_bounds__(BLOCK) k_update_vel(DM m) {
 // vert_vel_ale (src/oce_ale.F90:1692-2204; linfs + zstar branches): divergence gathered over incident
 // edges, bottom-up running sum, /area, zstar distribution of d(hbar), CFL_z, explicit/implicit split.
 // 20 N3 + 3 E3 values.
-__global__ void __launch_bounds__(BLOCK) k_vert_vel(DM m) {
+__global__ void __launch_bounds__(BLOCK) k_vert_vel(DM m, int fuse_hbar) {
   int n = col_id(), l = lane_id(), nz = l + 1;
   if (n >= m.myN) return;
   const int nzmin = m.ulev_n[n], nzmax = m.nlev_n[n] - 1;
   const double dt = m.p.dt;
+  double hb_new = 0.0, hb_old = 0.0;
+  if (fuse_hbar) {       // node part of compute_hbar_ale + eta_n update (k_hbar_node) fused in; every lane computes the same scalars
+    double sacc = 0.0;
+    for (int q = m.ne_ptr[n]; q < m.ne_ptr[n + 1]; q++) {
+      double c = m.edge_c12[m.ne_idx[q]];
+      sacc = (m.ne_sgn[q] > 0) ? sacc + c : sacc - c;
+    }
+    double asv = DA2L(m.areasvol, nzmin, n);
+    if (m.p.which_ale != 0) sacc = sacc - m.water_flux[n] * asv;
+    hb_old = m.hbar[n];
+    hb_new = hb_old + sacc * dt / asv;
+    if (l == 0) {
+      m.ssh_rhs_old[n] = sacc; m.hbar_old[n] = hb_old; m.hbar[n] = hb_new;
+      if (nzmin == 1) m.eta_n[n] = m.p.alpha * hb_new + (1.0 - m.p.alpha) * hb_old;
+    }
+  } else { hb_new = m.hbar[n]; hb_old = m.hbar_old[n]; }
   double w = 0.0;
   if (nz <= m.nlm1) {
     for (int q = m.ne_ptr[n]; q < m.ne_ptr[n + 1]; q++) {
@@ -649,7 +669,7 @@ __global__ void __launch_bounds__(BLOCK) k_vert_vel(DM m) {
     if (nzmin == 1) {
       double dd1 = DA2L(m.zbar_3d_n, nzm, n);
       double dd = DA2L(m.zbar_3d_n, nzmin, n) - dd1;
-      dd = (m.hbar[n] - m.hbar_old[n]) / dd;
+      dd = (hb_new - hb_old) / dd;
       double dddt = dd / dt;
       if (nz >= nzmin && nz <= nzm - 1) {
         double zb = DA2L(m.zbar_3d_n, nz, n), zb1 = DA2L(m.zbar_3d_n, nz + 1, n);
@@ -745,7 +765,7 @@ void launch_dynamics_post(const DM &m, hipStream_t s) {
   LAUNCH_COL(k_edge_transport, m.myD, m, 1);
   LAUNCH_FLAT(k_hbar_node, m.myN, m);
   LAUNCH_FLAT(k_dhe, m.myE, m);
-  LAUNCH_COL(k_vert_vel, m.myN, m);
+  LAUNCH_COL(k_vert_vel, m.myN, m, 0);
 }
 void launch_thickness(const DM &m, hipStream_t s) {
   if (m.p.which_ale != 2) return;
@@ -778,7 +798,8 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
     if (!strcmp(name, "k_update_vel")) { LAUNCH_COL(k_update_vel, ncol_uv, m); return 0; }
     if (!strcmp(name, "k_hbar_node")) { LAUNCH_FLAT(k_hbar_node, m.myN, m); return 0; }
     if (!strcmp(name, "k_dhe")) { LAUNCH_FLAT(k_dhe, m.myE, m); return 0; }
-    if (!strcmp(name, "k_vert_vel")) { LAUNCH_COL(k_vert_vel, m.myN, m); return 0; }
+    if (!strcmp(name, "k_vert_vel")) { LAUNCH_COL(k_vert_vel, m.myN, m, 0); return 0; }
+    if (!strcmp(name, "k_vert_vel_hbar")) { LAUNCH_COL(k_vert_vel, m.myN, m, 1); return 0; }
     if (!strcmp(name, "k_thick_node")) { LAUNCH_COL(k_thick_node, m.N, m); return 0; }
     if (!strcmp(name, "k_thick_elem")) { LAUNCH_COL(k_thick_elem, m.myE, m); return 0; }
     return -1;
@@ -808,7 +829,7 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
     LAUNCH_COL(k_edge_transport, m.myD, m, 1); LAUNCH_FLAT(k_hbar_node, m.myN, m); LAUNCH_FLAT(k_dhe, m.myE, m); return 0;
   }
   if (!strcmp(name, "eta_update")) return 0;
-  if (!strcmp(name, "vert_vel_ale")) { LAUNCH_COL(k_vert_vel, m.myN, m); return 0; }
+  if (!strcmp(name, "vert_vel_ale")) { LAUNCH_COL(k_vert_vel, m.myN, m, 0); return 0; }
   if (!strcmp(name, "update_thickness_ale")) { launch_thickness(m, s); return 0; }
   return -1;
 }

@@ -25,18 +25,19 @@ __global__ void __launch_bounds__(64 * TWAVES) k_thomas(DM m, int ncol, const in
                         mode == 0 ? m.th_r1 : m.tt_r + toff, m.th_r2};
   const int NARR = 3 + NRHS;
 #define SH(arr, j, c) sh[((arr) * nl1 + ((j) - 1)) * TPAD + (c)]
-  // ---- stage in (lane = level)
+  // ---- stage in (lane = level); loads of different columns are independent -> unrolled, many in flight
+#pragma unroll 4
   for (int cc = 0; cc < TCOLS / TWAVES; cc++) {
     int cl = w * (TCOLS / TWAVES) + cc, c = col0 + cl;
-    if (c >= ncol) break;
     int nz = l + 1;
-    if (nz >= lev_lo[c] && nz <= lev_hi[c] - 1) {
+    if (c < ncol && nz >= lev_lo[c] && nz <= lev_hi[c] - 1) {
 #pragma unroll
       for (int a = 0; a < NARR; a++) SH(a, nz, cl) = G[a][(size_t)c * nl1 + l];
     }
   }
   __syncthreads();
-  // ---- solve (lane = column), wave 0
+  // ---- solve (lane = column), wave 0.  Software-pipelined: the coefficients of level j+1 are read from LDS before the
+  // results of level j are stored, so the dependent divide chain is the only serial part.
   if (w == 0) {
     int c = col0 + l;
     int kmin = 1, kmax = 0;
@@ -44,9 +45,11 @@ __global__ void __launch_bounds__(64 * TWAVES) k_thomas(DM m, int ncol, const in
     int kmx = kmax;
     for (int s = 32; s >= 1; s >>= 1) kmx = max(kmx, __shfl_xor(kmx, s, 64));
     double cpp = 0.0, x1p = 0.0, x2p = 0.0;
+    double a = SH(0, 1, l), b = SH(1, 1, l), cc = SH(2, 1, l), r1 = SH(3, 1, l), r2 = (NRHS == 2) ? SH(4, 1, l) : 0.0;
     for (int j = 1; j <= kmx; j++) {
+      int jn = (j < kmx) ? j + 1 : j;
+      double na = SH(0, jn, l), nb = SH(1, jn, l), nc = SH(2, jn, l), nr1 = SH(3, jn, l), nr2 = (NRHS == 2) ? SH(4, jn, l) : 0.0;
       if (j >= kmin && j <= kmax) {
-        double a = SH(0, j, l), b = SH(1, j, l), cc = SH(2, j, l), r1 = SH(3, j, l), r2 = (NRHS == 2) ? SH(4, j, l) : 0.0;
         if (j == kmin) {
           cpp = cc / b; x1p = r1 / b;
           if (NRHS == 2) x2p = r2 / b;
@@ -59,28 +62,32 @@ __global__ void __launch_bounds__(64 * TWAVES) k_thomas(DM m, int ncol, const in
         SH(2, j, l) = cpp; SH(3, j, l) = x1p;
         if (NRHS == 2) SH(4, j, l) = x2p;
       }
+      a = na; b = nb; cc = nc; r1 = nr1; r2 = nr2;
     }
     double x1 = 0.0, x2 = 0.0;
+    double cp = SH(2, kmx, l), u1 = SH(3, kmx, l), u2 = (NRHS == 2) ? SH(4, kmx, l) : 0.0;
     for (int j = kmx; j >= 1; j--) {
+      int jn = (j > 1) ? j - 1 : j;
+      double ncp = SH(2, jn, l), nu1 = SH(3, jn, l), nu2 = (NRHS == 2) ? SH(4, jn, l) : 0.0;
       if (j >= kmin && j <= kmax) {
-        if (j == kmax) { x1 = SH(3, j, l); if (NRHS == 2) x2 = SH(4, j, l); }
+        if (j == kmax) { x1 = u1; if (NRHS == 2) x2 = u2; }
         else {
-          double cp = SH(2, j, l);
-          x1 = SH(3, j, l) - cp * x1;
-          if (NRHS == 2) x2 = SH(4, j, l) - cp * x2;
+          x1 = u1 - cp * x1;
+          if (NRHS == 2) x2 = u2 - cp * x2;
         }
         SH(3, j, l) = x1;
         if (NRHS == 2) SH(4, j, l) = x2;
       }
+      cp = ncp; u1 = nu1; u2 = nu2;
     }
   }
   __syncthreads();
   // ---- stage out (lane = level)
+#pragma unroll 4
   for (int cc = 0; cc < TCOLS / TWAVES; cc++) {
     int cl = w * (TCOLS / TWAVES) + cc, c = col0 + cl;
-    if (c >= ncol) break;
     int nz = l + 1;
-    if (nz >= lev_lo[c] && nz <= lev_hi[c] - 1) {
+    if (c < ncol && nz >= lev_lo[c] && nz <= lev_hi[c] - 1) {
       if (mode == 0) {                       // impl_vert_visc_ale: UV_rhs = (du, dv)
         DV2(m.UV_rhs, 1, nz, c) = SH(3, nz, cl);
         DV2(m.UV_rhs, 2, nz, c) = SH(4, nz, cl);

@@ -18,32 +18,53 @@
 
 #define ST 1024
 
-// tree  part[t] += part[t+s], s = 512..1  evaluated by wave 0; lane l combines part[l+64k], k=0..15
-__device__ __forceinline__ double tree16(const double *p, int l) {
-  double q[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) q[k] = p[l + 64 * k];
-#pragma unroll
-  for (int k = 0; k < 8; k++) q[k] = q[k] + q[k + 8];      // stride 512
-#pragma unroll
-  for (int k = 0; k < 4; k++) q[k] = q[k] + q[k + 4];      // stride 256
-#pragma unroll
-  for (int k = 0; k < 2; k++) q[k] = q[k] + q[k + 2];      // stride 128
-  double x = q[0] + q[1];                                   // stride 64
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) x = x + __shfl_down(x, s, 64);
-  return x;                                                 // valid in lane 0
+// Block reduction of NQ quantities in a FIXED order that the CPU checker used by the tests reproduces: thread t holds the
+// partial sum of rows t, t+1024, ...
+//   inside a wave (DPP, no LDS traffic): in every 16-lane row  x[l] += x[l-s]  for s = 8,4,2,1 (row total in lane 15),
+//   then rows: (R0+R1) and (R2+R3) (row_bcast:15), then their sum (row_bcast:31) -> wave total in lane 63;
+//   the 16 wave totals go through LDS and the same 16-lane row tree, evaluated redundantly by every wave:
+//   ONE barrier per reduction.
+// `buf` (NQ*16 doubles) must not be reused by the next reduction (callers alternate two buffers).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  int l2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);   // lanes without a source add +0.0
+  int h2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return x + __hiloint2double(h2, l2);
 }
-__device__ __forceinline__ void reduce2(double a, double b, double *red, double *out, double &ra, double &rb) {
-  int t = threadIdx.x;
-  red[t] = a; red[ST + t] = b;
-  __syncthreads();
-  if (t < 64) {
-    double xa = tree16(red, t), xb = tree16(red + ST, t);
-    if (t == 0) { out[0] = xa; out[1] = xb; }
+template <int NQ>
+__device__ __forceinline__ void block_reduce(double (&v)[NQ], double *buf) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < NQ; q++) v[q] = dpp_add<0x118, 0xf>(v[q]);   // row_shr:8
+#pragma unroll
+  for (int q = 0; q < NQ; q++) v[q] = dpp_add<0x114, 0xf>(v[q]);   // row_shr:4
+#pragma unroll
+  for (int q = 0; q < NQ; q++) v[q] = dpp_add<0x112, 0xf>(v[q]);   // row_shr:2
+#pragma unroll
+  for (int q = 0; q < NQ; q++) v[q] = dpp_add<0x111, 0xf>(v[q]);   // row_shr:1
+#pragma unroll
+  for (int q = 0; q < NQ; q++) v[q] = dpp_add<0x142, 0xa>(v[q]);   // row_bcast:15 into rows 1 and 3
+#pragma unroll
+  for (int q = 0; q < NQ; q++) v[q] = dpp_add<0x143, 0xc>(v[q]);   // row_bcast:31 into rows 2 and 3
+  if ((t & 63) == 63) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) buf[q * 16 + (t >> 6)] = v[q];
   }
   __syncthreads();
-  ra = out[0]; rb = out[1];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) v[q] = buf[q * 16 + (t & 15)];      // every 16-lane row holds the 16 wave totals
+#pragma unroll
+  for (int q = 0; q < NQ; q++) v[q] = dpp_add<0x118, 0xf>(v[q]);
+#pragma unroll
+  for (int q = 0; q < NQ; q++) v[q] = dpp_add<0x114, 0xf>(v[q]);
+#pragma unroll
+  for (int q = 0; q < NQ; q++) v[q] = dpp_add<0x112, 0xf>(v[q]);
+#pragma unroll
+  for (int q = 0; q < NQ; q++) v[q] = dpp_add<0x111, 0xf>(v[q]);
+#pragma unroll
+  for (int q = 0; q < NQ; q++)                                       // lane 15 -> uniform
+    v[q] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v[q]), 15), __builtin_amdgcn_readlane(__double2loint(v[q]), 15));
 }
 
 // IN_LDS is a template parameter on purpose: a run-time select between an LDS and a global pointer would turn every
@@ -55,34 +76,34 @@ __device__ __forceinline__ void solver_body(const DM &m, int maxits, double tol2
 template <int W>
 __global__ void __launch_bounds__(ST) k_solver_lds(DM m, int maxits, double tol2, int NP) {
   extern __shared__ double lds[];
-  double *pl = lds + 4 * ST + 8, *sl = pl + NP;
-  solver_body<W, true>(m, maxits, tol2, NP, lds, lds + 4 * ST, pl, sl, (unsigned short *)(sl + NP));
+  double *pl = lds + 128, *sl = pl + NP;
+  solver_body<W, true>(m, maxits, tol2, NP, lds, lds + 64, pl, sl, (unsigned short *)(sl + NP));
 }
 template <int W>
 __global__ void __launch_bounds__(ST) k_solver_glb(DM m, int maxits, double tol2, int NP) {
   extern __shared__ double lds[];
-  solver_body<W, false>(m, maxits, tol2, NP, lds, lds + 4 * ST, m.sv_ph, m.sv_s, m.sv_cols);
+  solver_body<W, false>(m, maxits, tol2, NP, lds, lds + 64, m.sv_ph, m.sv_s, m.sv_cols);
 }
 
 // Set-up of one solve on the whole GPU (thread per row, coalesced ELL writes): row scaling (psolve.c:58-65), Jacobi
 // diagonal, B = A_s D^-1 in ELL [k][row], b = rhs*scale, y0 = D x0.  The column pattern (ELL, uint16) is static and
 // built once at init (m.sv_cols).
-__device__ __forceinline__ void reduce4(double a, double b, double c, double d, double *red, double *out, double &ra, double &rb, double &rc,
-                                        double &rd) {
-  int t = threadIdx.x;
-  red[t] = a; red[ST + t] = b; red[2 * ST + t] = c; red[3 * ST + t] = d;
-  __syncthreads();
-  if (t < 256) {                                  // waves 0..3 reduce one quantity each (same tree as reduce2)
-    int q = t >> 6, l = t & 63;
-    double xv = tree16(red + q * ST, l);
-    if (l == 0) out[q] = xv;
-  }
-  __syncthreads();
-  ra = out[0]; rb = out[1]; rc = out[2]; rd = out[3];
+// Row scale 1/sum|a_ij| and scaled diagonal of every row (psolve.c:58-65).  Depends only on the operator, so it runs
+// right after k_stiff_update on a side stream, off the critical path.
+__global__ void k_row_scale(DM m) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.myN) return;
+  int j0 = m.rowptr[i], j1 = m.rowptr[i + 1];
+  double tmp = 0.;
+  for (int j = j0; j < j1; j++) tmp += fabs(m.ssh_values[j]);
+  double sc = 1. / tmp;
+  m.sv_scale[i] = sc;
+  m.sv_dinv[i] = m.ssh_values[j0] * sc;                  // D (first entry of a row is the diagonal, oce_ale.F90:1128-1151)
 }
+void launch_row_scale(const DM &m, hipStream_t s) { hipLaunchKernelGGL(k_row_scale, dim3((m.myN + 255) / 256), dim3(256), 0, s, m); }
 
 template <int W>
-__global__ void k_solver_setup(DM m, int NP) {
+__global__ void k_solver_setup(DM m, int NP, int fuse_rhs) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= NP) return;
   const int n = m.myN;
@@ -95,12 +116,22 @@ __global__ void k_solver_setup(DM m, int NP) {
     return;
   }
   int j0 = rp[i], j1 = rp[i + 1];
-  double tmp = 0.;
-  for (int j = j0; j < j1; j++) tmp += fabs(m.ssh_values[j]);
-  double sc = 1. / tmp;
-  m.sv_b[i] = m.ssh_rhs[i] * sc;
-  double diag = m.ssh_values[j0] * sc;                    // first entry of a row is the diagonal (oce_ale.F90:1128-1151)
-  m.sv_dinv[i] = diag;
+  double sc = m.sv_scale[i];
+  double rhs;
+  if (fuse_rhs) {          // node part of compute_ssh_rhs_ale (oce_ale.F90:1548-1570) fused in: gather of the edge transports
+    double sacc = 0.0;
+    for (int q = m.ne_ptr[i]; q < m.ne_ptr[i + 1]; q++) {
+      double c = m.edge_c12[m.ne_idx[q]];
+      sacc = (m.ne_sgn[q] > 0) ? sacc + c : sacc - c;
+    }
+    const double al = m.p.alpha;
+    if (m.p.which_ale != 0) sacc = sacc - al * m.water_flux[i] * m.areasvol[(size_t)i * m.nl + m.ulev_n[i] - 1] + (1.0 - al) * m.ssh_rhs_old[i];
+    else sacc = sacc + (1.0 - al) * m.ssh_rhs_old[i];
+    m.ssh_rhs[i] = sacc;
+    rhs = sacc;
+  } else rhs = m.ssh_rhs[i];
+  m.sv_b[i] = rhs * sc;
+  double diag = m.sv_dinv[i];
   double xi = m.d_eta[i], x0 = xi;                       // initial guess: previous solution or quadratic extrapolation
   if (m.p.solver_x0_order == 2 && m.sv_extrap && m.sv_info[1] >= 2) x0 = (3.0 * xi - 3.0 * m.sv_h1[i]) + m.sv_h2[i];
   if (m.sv_extrap) { m.sv_h2[i] = m.sv_h1[i]; m.sv_h1[i] = xi; }
@@ -110,10 +141,7 @@ __global__ void k_solver_setup(DM m, int NP) {
     double bk = 0.0;
     if (j0 + k < j1) {
       int c = ci[j0 + k];
-      int c0 = rp[c], c1 = rp[c + 1];
-      double tc = 0.;
-      for (int j = c0; j < c1; j++) tc += fabs(m.ssh_values[j]);
-      double dinv_c = 1.0 / (m.ssh_values[c0] * (1. / tc));
+      double dinv_c = 1.0 / m.sv_dinv[c];
       bk = (m.ssh_values[j0 + k] * sc) * dinv_c;           // B = A_s D^-1
     }
     Bg[k * NP + i] = bk;
@@ -123,7 +151,7 @@ __global__ void k_solver_setup(DM m, int NP) {
 template <int W, bool IN_LDS>
 __device__ __forceinline__ void solver_body(const DM &m, int maxits, double tol2, int NP, double *red, double *out, double *pl, double *sl,
                                             unsigned short *cl) {
-  // red: 2*ST, out: 8, pl: NP (p), sl: NP (s; y0 at entry), cl: W*NP column indices [k][row]
+  // red/out: two 64-double reduction buffers, pl: NP (p), sl: NP (s; y0 at entry), cl: W*NP column indices [k][row]
   const int t = threadIdx.x, n = m.myN;
   double *Bg = m.sv_vals;                                // ELL [k][row], prepared by k_solver_setup
   double *r = m.sv_r, *r0 = m.sv_r0, *y = m.sv_p, *v = m.sv_v, *tv = m.sv_t, *b = m.sv_b, *diagg = m.sv_dinv, *x = m.d_eta;
@@ -144,7 +172,7 @@ __device__ __forceinline__ void solver_body(const DM &m, int maxits, double tol2
   __syncthreads();
   for (int i = t; i < NP; i += ST) pl[i] = 0.0;           // p = 0
   double rr, rho_new;
-  reduce2(prr, prr, red, out, rr, rho_new);
+  { double q1[1] = {prr}; block_reduce<1>(q1, out); rr = q1[0]; rho_new = q1[0]; }
   double rho = 1.0, alpha = 1.0, omega = 1.0;
   int it = 0;
   // BiCGstab with TWO reduction points per iteration (rho and ||r||^2 from recurrences, see the oracle) and the
@@ -163,8 +191,8 @@ __device__ __forceinline__ void solver_body(const DM &m, int maxits, double tol2
       v[i] = a;
       p1 = p1 + r0[i] * a;
     }
-    double r0v, dummy;
-    reduce2(p1, 0.0, red, out, r0v, dummy);
+    double r0v;
+    { double q1[1] = {p1}; block_reduce<1>(q1, red); r0v = q1[0]; }
     alpha = rho_new / r0v;
     for (int i = t; i < n; i += ST) sl[i] = r[i] - alpha * v[i];
     __syncthreads();
@@ -178,7 +206,7 @@ __device__ __forceinline__ void solver_body(const DM &m, int maxits, double tol2
       ptt = ptt + a * a; pts = pts + a * si; pr0t = pr0t + r0[i] * a; pss = pss + si * si;
     }
     double tt, ts, r0t, ss;
-    reduce4(ptt, pts, pr0t, pss, red, out, tt, ts, r0t, ss);
+    { double q4[4] = {ptt, pts, pr0t, pss}; block_reduce<4>(q4, out); tt = q4[0]; ts = q4[1]; r0t = q4[2]; ss = q4[3]; }
     omega = (tt > 0.0) ? ts / tt : 0.0;
     rho = rho_new;
     rho_new = -omega * r0t;
@@ -198,28 +226,154 @@ __device__ __forceinline__ void solver_body(const DM &m, int maxits, double tol2
   if (t == 0) { m.sv_info[0] = it; m.sv_resid[0] = sqrt(rr > 0.0 ? rr : 0.0); if (m.sv_extrap && m.sv_info[1] < 2) m.sv_info[1] = m.sv_info[1] + 1; }
 }
 
+// Register-resident variant for n <= 4*ST rows: thread t owns rows t, t+1024, t+2048, t+3072.  Own-row vectors r, v, t
+// and the (pre-shifted, packed) column indices stay in registers for the whole solve; p, s, y, r~ live in LDS with a fixed
+// row stride (own-row accesses are immediate-offset, conflict-free); the operator values are the only L2 traffic in
+// the loop (coalesced, scalar base + lane offset).  Same arithmetic and reduction order as solver_body.
+template <int W>
+__global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2, int NP, int dbg) {
+  extern __shared__ double lds[];
+  constexpr int R = 4, NP4 = R * ST;
+  double *bufA = lds, *bufB = lds + 64;
+  double *pl = lds + 128, *sl = pl + NP4, *yl = sl + NP4, *r0l = yl + NP4;
+  const unsigned t = threadIdx.x;
+  const unsigned n = (unsigned)m.myN;
+  const double *Bg = m.sv_vals;
+  const unsigned short *cg = m.sv_cols;
+  unsigned cpk[R][W / 2];                                  // two byte offsets (col*8 < 65536) per register
+  bool ok[R];
+  double r[R], v[R], tv[R];
+#pragma unroll
+  for (int k = 0; k < R; k++) {
+    const unsigned i = t + k * ST;
+    ok[k] = i < n;
+    r[k] = v[k] = tv[k] = 0.0;
+#pragma unroll
+    for (int w2 = 0; w2 < W / 2; w2++) {
+      unsigned c0 = 0, c1 = 0;
+      if (ok[k]) { c0 = cg[(unsigned)(2 * w2) * NP + i]; c1 = cg[(unsigned)(2 * w2 + 1) * NP + i]; }
+      cpk[k][w2] = (c0 << 3) | (c1 << 19);
+    }
+    sl[i] = ok[k] ? m.sv_s[i] : 0.0;                       // y0 = D x0 from the set-up kernel
+    pl[i] = 0.0;
+  }
+  __syncthreads();
+#define SPMV_ROW(acc, vec, k)                                                                    \
+  {                                                                                              \
+    acc = 0.0;                                                                                   \
+    unsigned o_ = t + k * ST;                                                                    \
+    asm volatile("" : "+v"(o_)); /* keeps the 40 operand addresses from being hoisted out of the loop and spilled */ \
+    _Pragma("unroll") for (int w = 0; w < W; w++) {                                              \
+      const double *Bw = Bg + (size_t)w * (unsigned)NP;                                          \
+      const unsigned c8 = (w & 1) ? (cpk[k][w >> 1] >> 16) : (cpk[k][w >> 1] & 0xffffu);         \
+      acc = acc + ((dbg & 1) ? 0.1 : Bw[o_]) * *(const double *)((const char *)(vec) + ((dbg & 2) ? (o_ << 3) : c8));                  \
+    }                                                                                            \
+  }
+  double prr = 0.0;
+#pragma unroll
+  for (int k = 0; k < R; k++)
+    if (ok[k]) {
+      const unsigned i = t + k * ST;
+      double a;
+      SPMV_ROW(a, sl, k);
+      double ri = m.sv_b[i] - a;
+      r[k] = ri; r0l[i] = ri; yl[i] = sl[i];
+      prr = prr + ri * ri;
+    }
+  double rr, rho_new;
+  { double q1[1] = {prr}; block_reduce<1>(q1, bufB); rr = q1[0]; rho_new = q1[0]; }
+  double rho = 1.0, alpha = 1.0, omega = 1.0;
+  int it = 0;
+  if ((dbg || rr >= tol2) && it < maxits) {
+    double beta = (rho_new / rho) * (alpha / omega);
+#pragma unroll
+    for (int k = 0; k < R; k++)
+      if (ok[k]) pl[t + k * ST] = r[k] + beta * (0.0 - omega * v[k]);
+  }
+  while ((dbg || rr >= tol2) && it < maxits) {
+    __syncthreads();                                       // p complete in LDS
+    double p1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < R; k++)
+      if (ok[k]) {
+        double a;
+        SPMV_ROW(a, pl, k);
+        v[k] = a;
+        p1 = p1 + r0l[t + k * ST] * a;
+      }
+    double r0v;
+    if (dbg & 4) r0v = p1; else { double q1[1] = {p1}; block_reduce<1>(q1, bufA); r0v = q1[0]; }
+    alpha = rho_new / r0v;
+#pragma unroll
+    for (int k = 0; k < R; k++)
+      if (ok[k]) sl[t + k * ST] = r[k] - alpha * v[k];
+    __syncthreads();                                       // s complete in LDS
+    double ptt = 0.0, pts = 0.0, pr0t = 0.0, pss = 0.0;
+#pragma unroll
+    for (int k = 0; k < R; k++)
+      if (ok[k]) {
+        double a;
+        SPMV_ROW(a, sl, k);
+        tv[k] = a;
+        double si = sl[t + k * ST];
+        ptt = ptt + a * a; pts = pts + a * si; pr0t = pr0t + r0l[t + k * ST] * a; pss = pss + si * si;
+      }
+    double tt, ts, r0t, ss;
+    if (dbg & 4) { tt = ptt; ts = pts; r0t = pr0t; ss = pss; } else { double q4[4] = {ptt, pts, pr0t, pss}; block_reduce<4>(q4, bufB); tt = q4[0]; ts = q4[1]; r0t = q4[2]; ss = q4[3]; }
+    omega = (tt > 0.0) ? ts / tt : 0.0;
+    rho = rho_new;
+    rho_new = -omega * r0t;
+    rr = ss - omega * (2.0 * ts - omega * tt);
+    it++;
+    bool more = ((dbg || rr >= tol2) && it < maxits);
+    double beta = more ? (rho_new / rho) * (alpha / omega) : 0.0;
+#pragma unroll
+    for (int k = 0; k < R; k++)
+      if (ok[k]) {
+        const unsigned i = t + k * ST;
+        double si = sl[i], pi = pl[i];
+        double ri = si - omega * tv[k];
+        r[k] = ri;
+        yl[i] = (yl[i] + alpha * pi) + omega * si;
+        if (more) pl[i] = ri + beta * (pi - omega * v[k]);
+      }
+  }
+#undef SPMV_ROW
+#pragma unroll
+  for (int k = 0; k < R; k++)
+    if (ok[k]) { const unsigned i = t + k * ST; m.d_eta[i] = yl[i] * (1.0 / m.sv_dinv[i]); }
+  if (t == 0) { m.sv_info[0] = it; m.sv_resid[0] = sqrt(rr > 0.0 ? rr : 0.0); if (m.sv_extrap && m.sv_info[1] < 2) m.sv_info[1] = m.sv_info[1] + 1; }
+}
+
 void solver_prepare() {
   static bool attr_set = false;
   if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)k_solver_reg<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_solver_lds<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_solver_lds<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
 }
 // Returns non-zero if the operator is wider than the widest instantiated ELL kernel.
-int launch_solver(const DM &m, hipStream_t s) {
+int launch_solver(const DM &m, hipStream_t s, int fuse_rhs, int scale_done) {
   int W = m.ssh_maxnnz <= 10 ? 10 : 16;
   if (m.ssh_maxnnz > 16 || m.myN >= 65536) return 1;     // uint16 columns / ELL width limits of this round
   int NP = (m.myN + 63) / 64 * 64;
-  size_t fixed = (size_t)(4 * ST + 8) * sizeof(double);
+  size_t fixed = (size_t)128 * sizeof(double);
   size_t need = fixed + (size_t)NP * (2 * sizeof(double) + W * sizeof(unsigned short));
   int in_lds = need <= 158 * 1024;
   size_t shm = in_lds ? need : fixed;
-  if (W == 10) hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP);
-  else hipLaunchKernelGGL(k_solver_setup<16>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP);
+  if (!scale_done) launch_row_scale(m, s);
+  if (W == 10) hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs);
+  else hipLaunchKernelGGL(k_solver_setup<16>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs);
   static int dbg_maxits = getenv("FESOM_SOLVER_MAXITS") ? atoi(getenv("FESOM_SOLVER_MAXITS")) : 2000;   // diagnostics only
   const double tol2 = 1e-10 * 1e-10;
-  if (in_lds) {
+  static int no_reg = getenv("FESOM_SOLVER_NOREG") != nullptr;                                        // diagnostics only
+  if (m.myN <= 4 * ST && W == 10 && !no_reg) {         // (the 16-wide instance of the register kernel spills: use the LDS one)
+    shm = (size_t)(128 + 4 * 4 * ST) * sizeof(double);
+    static int dbg = getenv("FESOM_SOLVER_DBG") ? atoi(getenv("FESOM_SOLVER_DBG")) : 0;
+    hipLaunchKernelGGL(k_solver_reg<10>, dim3(1), dim3(ST), shm, s, m, dbg_maxits, dbg ? -1.0 : tol2, NP, dbg);
+  } else if (in_lds) {
     if (W == 10) hipLaunchKernelGGL(k_solver_lds<10>, dim3(1), dim3(ST), shm, s, m, dbg_maxits, tol2, NP);
     else hipLaunchKernelGGL(k_solver_lds<16>, dim3(1), dim3(ST), shm, s, m, dbg_maxits, tol2, NP);
   } else {

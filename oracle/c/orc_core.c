@@ -78,18 +78,27 @@ double orc_solver_residual(void) { return C_.solver_resid; }
  * follow the reference.  The preconditioner is this build's GPU design (Jacobi, applied as the column scaling
  * B = A_s D^-1, y = D x, instead of pARMS' sequential RAS+ILU(2)): the solution agrees with the reference to
  * the solver tolerance, not bit for bit.  Dot products use the fixed reduction order of the HIP kernel
- * (SOLVER_T partial sums with stride SOLVER_T, then a halving tree) so that oracle == HIP bitwise. */
+ * (SOLVER_T partial sums with stride SOLVER_T, a fixed tree inside each block of 64, then the same 16-wide tree over the 16 block sums) so that oracle == HIP bitwise. */
 #define SOLVER_T 1024
+static double row_tree16(double *x) {                    /* x[l] += x[l-s], s = 8,4,2,1 ; total in x[15] */
+  for (int s = 8; s >= 1; s >>= 1)
+    for (int l = 15; l >= 16 - s; l--) x[l] = x[l] + x[l - s];
+  return x[15];
+}
 static double dot_fixed(const double *x, const double *y, int n) {
   static double part[SOLVER_T];
+  double wave[16];
   for (int t = 0; t < SOLVER_T; t++) {
     double s = 0.0;
     for (int i = t; i < n; i += SOLVER_T) s = s + x[i] * y[i];
     part[t] = s;
   }
-  for (int s = SOLVER_T / 2; s >= 1; s >>= 1)
-    for (int t = 0; t < s; t++) part[t] = part[t] + part[t + s];
-  return part[0];
+  for (int w = 0; w < 16; w++) {                         /* one wave = 4 rows of 16 partial sums */
+    double r0 = row_tree16(part + 64 * w), r1 = row_tree16(part + 64 * w + 16), r2 = row_tree16(part + 64 * w + 32),
+           r3 = row_tree16(part + 64 * w + 48);
+    wave[w] = (r3 + r2) + (r1 + r0);
+  }
+  return row_tree16(wave);
 }
 void orc_solve_ssh(void) {
   int n = C_.m.myDim_nod2D;
