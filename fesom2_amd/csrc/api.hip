@@ -129,6 +129,7 @@ static void enqueue_step_dag_b(hipStream_t s0, int first_step, Dag &d) {
   std::vector<hipEvent_t> ev_prep(m.ntr);
   for (int tr = 0; tr < m.ntr; tr++) {
     K(s3, "k_tr_ab", tr + 1); K(s3, "k_tr_grad_elem", tr + 1); K(s3, "k_updn_grad", tr + 1);
+    if (m.p.with_diffusion) K(s3, "k_diff_flux", tr + 1);
     ev_prep[tr] = d.ev(); hipEventRecord(ev_prep[tr], s3);
   }
   // s0: critical chain
@@ -182,6 +183,7 @@ static void enqueue_step_dag_a(hipStream_t s0, int first_step, Dag &d, int v) {
     for (int tr = 0; tr < m.ntr; tr++) {
       hipStream_t st = (tr % 2 == 0) ? s2 : s3;
       K(st, "k_tr_ab", tr + 1); K(st, "k_tr_grad_elem", tr + 1); K(st, "k_updn_grad", tr + 1);
+      if (m.p.with_diffusion) K(st, "k_diff_flux", tr + 1);
     }
   };
   if (v == 0) prep();
@@ -310,6 +312,14 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
       idx[fill[b]] = e; sgn[fill[b]++] = -1;
     }
     m.ne_ptr = dev_upload(ptr); m.ne_idx = dev_upload(idx); m.ne_sgn = dev_upload(sgn);
+    std::vector<unsigned> rng(idx.size());
+    for (size_t q = 0; q < idx.size(); q++) {
+      int e = idx[q], e1 = et[2 * e], e2 = et[2 * e + 1];
+      int lo = d->ulevels[e1], hi = d->nlevels[e1] - 1;
+      if (e2 >= 0) { lo = std::min(lo, d->ulevels[e2]); hi = std::max(hi, d->nlevels[e2] - 1); }
+      rng[q] = (unsigned)lo | ((unsigned)hi << 8);
+    }
+    m.ne_rng = dev_upload(rng);
   }
   // element -> its internal edges (increasing) with the edge_tri slot it occupies
   {
@@ -379,7 +389,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   F(heat_flux, N); F(water_flux, N); F(virtual_salt, N); F(relax_salt, N); F(real_salt_flux, N);
   F(UV, 2 * n1 * E); F(UV_rhs, 2 * n1 * E); F(UV_rhsAB, 2 * n1 * E); FT(tr_xy, 2 * n1 * E); FT(tr_xy_ab, 2 * n1 * E); F(U_b, 2 * n1 * E);
   FT(fct_ebnd, 2 * n1 * E); F(pgf_x, n1 * E); F(pgf_y, n1 * E); F(helem, n1 * E); F(Av, nl * E); F(dhe, E); F(stress_surf, 2 * E);
-  FT(adv_flux_hor, n1 * D); FT(flux_lo_hor, n1 * D); FT(edge_up_dn_grad, 4 * n1 * D); F(edge_c12, D);
+  FT(adv_flux_hor, n1 * D); FT(flux_lo_hor, n1 * D); FT(diff_flux, n1 * D); FT(edge_up_dn_grad, 4 * n1 * D); F(edge_c12, D);
   F(ssh_values, m.nza);
   { size_t mx = n1 * std::max(N, E); F(th_a, mx); F(th_b, mx); F(th_c, mx); F(th_r1, mx); F(th_r2, mx); }
   FT(tt_a, n1 * N); FT(tt_b, n1 * N); FT(tt_c, n1 * N); FT(tt_r, n1 * N);
@@ -475,7 +485,7 @@ static int call_named(const char *name, int arg) {
   }
   int fs = G.first_step;
   if (!strcmp(name, "init_tracers_AB") || !strcmp(name, "adv_tracers_ale") || !strcmp(name, "diff_tracers_ale") || !strncmp(name, "k_t", 3) ||
-      !strncmp(name, "k_f", 3) || !strcmp(name, "k_updn_grad"))
+      !strncmp(name, "k_f", 3) || !strcmp(name, "k_updn_grad") || !strcmp(name, "k_diff_flux"))
     G.cur_tr = (arg >= 1 && arg <= m.ntr) ? arg - 1 : 0;
   int rc = launch_named_dyn(m, G.stream, name, arg, fs);
   if (rc == 0) { if (!strcmp(name, "compute_vel_rhs")) G.first_step = 0; return 0; }

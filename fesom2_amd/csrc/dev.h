@@ -29,6 +29,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   const int *nlev_n, *ulev_n, *nlev_n_min, *ulev_n_max;   // (N)
   const int *edge_glob;       // (D) global edge id (1-based) for the internal/boundary test
   const int *ne_ptr, *ne_idx, *ne_sgn;     // node -> incident owned edges (increasing), sign +1 if node==edges(1)
+  const unsigned *ne_rng;                  // per entry: level range of the edge, lo | hi<<8 (min ulevels / max nlevels-1 of its triangles)
   const int *ee_idx, *ee_side;             // (3,E) element -> its edges sorted increasing; side 1/2 (=which edge_tri slot), 0 = skip
   const int *updn;            // (2,myD) up/down-wind triangles, 0-based, -1 none
   const int *rowptr, *colind; // SSH CSR, 0-based local
@@ -45,7 +46,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   double *heat_flux, *water_flux, *virtual_salt, *relax_salt, *real_salt_flux;
   double *UV, *UV_rhs, *UV_rhsAB, *tr_xy, *tr_xy_ab, *U_b, *fct_ebnd;
   double *pgf_x, *pgf_y, *helem, *Av, *dhe, *stress_surf;
-  double *adv_flux_hor, *flux_lo_hor, *edge_up_dn_grad, *edge_c12;
+  double *adv_flux_hor, *flux_lo_hor, *edge_up_dn_grad, *edge_c12, *diff_flux;
   double *ssh_values;
   double *th_a, *th_b, *th_c, *th_r1, *th_r2;   // column-major scratch of the batched Thomas solve (momentum)
   double *tt_a, *tt_b, *tt_c, *tt_r;            // same, one slab per tracer
@@ -74,8 +75,14 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
 #define D_VCPW 4.2e6
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-__device__ __forceinline__ int col_id() { return blockIdx.x * COLS_PER_BLOCK + (threadIdx.x >> 6); }
-__device__ __forceinline__ double bcast(double x, int src) { return __shfl(x, src, 64); }
+// one wavefront = one column: the column index is wave-uniform, say so to the compiler (scalar loads / scalar address math)
+__device__ __forceinline__ int col_id() { return __builtin_amdgcn_readfirstlane(blockIdx.x * COLS_PER_BLOCK + (threadIdx.x >> 6)); }
+// broadcast of lane `src`; src must be wave-uniform (it always is a level index of the wave's column): v_readlane, no LDS
+__device__ __forceinline__ double bcast(double x, int src) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(x), src), hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int rdlane(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }   // lane must be wave-uniform
 __device__ __forceinline__ double shup(double x) { return __shfl_up(x, 1, 64); }     // value of lane-1
 __device__ __forceinline__ double shdn(double x) { return __shfl_down(x, 1, 64); }   // value of lane+1
 

@@ -15,7 +15,7 @@
 
 template <int NRHS>
 __global__ void __launch_bounds__(64 * TWAVES) k_thomas(DM m, int ncol, const int *__restrict__ lev_hi /* kmax = lev_hi[c]-1 */,
-                                                         const int *__restrict__ lev_lo /* kmin = lev_lo[c] */, int mode, int tr) {
+                                                         const int *__restrict__ lev_lo /* kmin = lev_lo[c] */, int mode, int tr, int dbg) {
   extern __shared__ double sh[];
   const int nl1 = m.nlm1;
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -36,52 +36,59 @@ __global__ void __launch_bounds__(64 * TWAVES) k_thomas(DM m, int ncol, const in
     }
   }
   __syncthreads();
-  // ---- solve (lane = column), wave 0.  Software-pipelined: the coefficients of level j+1 are read from LDS before the
-  // results of level j are stored, so the dependent divide chain is the only serial part.
-  if (w == 0) {
+  // ---- solve (lane = column), wave 0.  Branch-free and software-pipelined: the first active level uses a = 0
+  // (b - cp*0 = b and r - x*0 = r exactly, i.e. the reference's c/b, r/b start), inactive levels compute on garbage and
+  // are discarded by selects, so the independent divide chains (cp, x1, x2) interleave in straight-line code and the
+  // dependent chain  cp_j = c_j / (b_j - cp_{j-1} a_j)  is the only serial part.
+  if (w == 0 && !(dbg & 1)) {
     int c = col0 + l;
     int kmin = 1, kmax = 0;
     if (c < ncol) { kmin = lev_lo[c]; kmax = lev_hi[c] - 1; }
     int kmx = kmax;
     for (int s = 32; s >= 1; s >>= 1) kmx = max(kmx, __shfl_xor(kmx, s, 64));
+    const int astr = nl1 * TPAD;                              // array stride in doubles
+    double *p0 = sh + l;                                      // level 1 of array 0, this lane's column
     double cpp = 0.0, x1p = 0.0, x2p = 0.0;
-    double a = SH(0, 1, l), b = SH(1, 1, l), cc = SH(2, 1, l), r1 = SH(3, 1, l), r2 = (NRHS == 2) ? SH(4, 1, l) : 0.0;
+    double a = p0[0], b = p0[astr], cc = p0[2 * astr], r1 = p0[3 * astr], r2 = (NRHS == 2) ? p0[4 * astr] : 0.0;
+    double *pj = p0;
     for (int j = 1; j <= kmx; j++) {
-      int jn = (j < kmx) ? j + 1 : j;
-      double na = SH(0, jn, l), nb = SH(1, jn, l), nc = SH(2, jn, l), nr1 = SH(3, jn, l), nr2 = (NRHS == 2) ? SH(4, jn, l) : 0.0;
-      if (j >= kmin && j <= kmax) {
-        if (j == kmin) {
-          cpp = cc / b; x1p = r1 / b;
-          if (NRHS == 2) x2p = r2 / b;
-        } else {
-          double mm = b - cpp * a;
-          cpp = cc / mm;
-          x1p = (r1 - x1p * a) / mm;
-          if (NRHS == 2) x2p = (r2 - x2p * a) / mm;
-        }
-        SH(2, j, l) = cpp; SH(3, j, l) = x1p;
-        if (NRHS == 2) SH(4, j, l) = x2p;
+      double *pn = (j < kmx) ? pj + TPAD : pj;
+      double na = pn[0], nb = pn[astr], nc = pn[2 * astr], nr1 = pn[3 * astr], nr2 = (NRHS == 2) ? pn[4 * astr] : 0.0;
+      const bool act = (j >= kmin) && (j <= kmax);
+      const double am = (j == kmin) ? 0.0 : a;
+      double mm = b - cpp * am;
+      double ncp = cc / mm;
+      double nx1 = (r1 - x1p * am) / mm;
+      double nx2 = (NRHS == 2) ? (r2 - x2p * am) / mm : 0.0;
+      if (act) {
+        cpp = ncp; x1p = nx1; x2p = nx2;
+        pj[2 * astr] = ncp; pj[3 * astr] = nx1;
+        if (NRHS == 2) pj[4 * astr] = nx2;
       }
       a = na; b = nb; cc = nc; r1 = nr1; r2 = nr2;
+      pj = pn;
     }
     double x1 = 0.0, x2 = 0.0;
-    double cp = SH(2, kmx, l), u1 = SH(3, kmx, l), u2 = (NRHS == 2) ? SH(4, kmx, l) : 0.0;
+    pj = p0 + (size_t)(kmx > 0 ? kmx - 1 : 0) * TPAD;
+    double cp = pj[2 * astr], u1 = pj[3 * astr], u2 = (NRHS == 2) ? pj[4 * astr] : 0.0;
     for (int j = kmx; j >= 1; j--) {
-      int jn = (j > 1) ? j - 1 : j;
-      double ncp = SH(2, jn, l), nu1 = SH(3, jn, l), nu2 = (NRHS == 2) ? SH(4, jn, l) : 0.0;
+      double *pn = (j > 1) ? pj - TPAD : pj;
+      double ncp = pn[2 * astr], nu1 = pn[3 * astr], nu2 = (NRHS == 2) ? pn[4 * astr] : 0.0;
       if (j >= kmin && j <= kmax) {
         if (j == kmax) { x1 = u1; if (NRHS == 2) x2 = u2; }
         else {
           x1 = u1 - cp * x1;
           if (NRHS == 2) x2 = u2 - cp * x2;
         }
-        SH(3, j, l) = x1;
-        if (NRHS == 2) SH(4, j, l) = x2;
+        pj[3 * astr] = x1;
+        if (NRHS == 2) pj[4 * astr] = x2;
       }
       cp = ncp; u1 = nu1; u2 = nu2;
+      pj = pn;
     }
   }
   __syncthreads();
+  if (dbg & 2) return;
   // ---- stage out (lane = level)
 #pragma unroll 4
   for (int cc = 0; cc < TCOLS / TWAVES; cc++) {
@@ -101,6 +108,7 @@ __global__ void __launch_bounds__(64 * TWAVES) k_thomas(DM m, int ncol, const in
 }
 
 static size_t thomas_lds(const DM &m, int nrhs) { return (size_t)(3 + nrhs) * m.nlm1 * TPAD * sizeof(double); }
+static int thomas_dbg() { static int d = getenv("FESOM_THOMAS_DBG") ? atoi(getenv("FESOM_THOMAS_DBG")) : 0; return d; }
 void thomas_prepare() {
   static bool done = false;
   if (done) return;
@@ -109,8 +117,8 @@ void thomas_prepare() {
   done = true;
 }
 void launch_thomas_visc(const DM &m, hipStream_t s) {
-  hipLaunchKernelGGL(k_thomas<2>, dim3((m.myE + TCOLS - 1) / TCOLS), dim3(64 * TWAVES), thomas_lds(m, 2), s, m, m.myE, m.nlev, m.ulev, 0, 0);
+  hipLaunchKernelGGL(k_thomas<2>, dim3((m.myE + TCOLS - 1) / TCOLS), dim3(64 * TWAVES), thomas_lds(m, 2), s, m, m.myE, m.nlev, m.ulev, 0, 0, thomas_dbg());
 }
 void launch_thomas_tracer(const DM &m, hipStream_t s, int tr) {
-  hipLaunchKernelGGL(k_thomas<1>, dim3((m.myN + TCOLS - 1) / TCOLS), dim3(64 * TWAVES), thomas_lds(m, 1), s, m, m.myN, m.nlev_n, m.ulev_n, 1, tr);
+  hipLaunchKernelGGL(k_thomas<1>, dim3((m.myN + TCOLS - 1) / TCOLS), dim3(64 * TWAVES), thomas_lds(m, 1), s, m, m.myN, m.nlev_n, m.ulev_n, 1, tr, thomas_dbg());
 }

@@ -8,7 +8,7 @@
 // are independent and can run concurrently on two streams (they only share read-only velocities and thicknesses).
 struct TV {
   double *del_ttf, *fct_LO, *fct_ttf_max, *fct_ttf_min, *fct_plus, *fct_minus, *tr_z, *adv_flux_ver, *tr_xy_ab, *tr_xy, *fct_ebnd,
-         *adv_flux_hor, *flux_lo_hor, *edge_up_dn_grad, *th_a, *th_b, *th_c, *th_r1;
+         *adv_flux_hor, *flux_lo_hor, *diff_flux, *edge_up_dn_grad, *th_a, *th_b, *th_c, *th_r1;
 };
 __device__ __forceinline__ TV tracer_view(const DM &m, int tr) {
   size_t n1N = (size_t)m.nlm1 * m.N, nlN = (size_t)m.nl * m.N, n1E = (size_t)m.nlm1 * m.E, n1D = (size_t)m.nlm1 * m.D;
@@ -17,7 +17,7 @@ __device__ __forceinline__ TV tracer_view(const DM &m, int tr) {
   t.fct_ttf_min = m.fct_ttf_min + tr * n1N; t.fct_plus = m.fct_plus + tr * n1N; t.fct_minus = m.fct_minus + tr * n1N;
   t.tr_z = m.tr_z + tr * nlN; t.adv_flux_ver = m.adv_flux_ver + tr * nlN;
   t.tr_xy_ab = m.tr_xy_ab + tr * 2 * n1E; t.tr_xy = m.tr_xy + tr * 2 * n1E; t.fct_ebnd = m.fct_ebnd + tr * 2 * n1E;
-  t.adv_flux_hor = m.adv_flux_hor + tr * n1D; t.flux_lo_hor = m.flux_lo_hor + tr * n1D; t.edge_up_dn_grad = m.edge_up_dn_grad + tr * 4 * n1D;
+  t.adv_flux_hor = m.adv_flux_hor + tr * n1D; t.flux_lo_hor = m.flux_lo_hor + tr * n1D; t.diff_flux = m.diff_flux + tr * n1D; t.edge_up_dn_grad = m.edge_up_dn_grad + tr * 4 * n1D;
   t.th_a = m.tt_a + tr * n1N; t.th_b = m.tt_b + tr * n1N; t.th_c = m.tt_c + tr * n1N; t.th_r1 = m.tt_r + tr * n1N;
   return t;
 }
@@ -299,10 +299,47 @@ __global__ void __launch_bounds__(BLOCK) k_fct_edge_limit(DM m, int tr) {
   DA2(t.adv_flux_hor, nz, ed) = ae * flux;
 }
 
+// Horizontal diffusive flux through every edge (diff_part_hor_redi src/oce_ale_tracer.F90:929-1077, Redi off): the value
+// the reference adds to / subtracts from the two end nodes.  It only needs T^n gradients, Ki and helem of the current
+// step, so it is computed edge-parallel during tracer preparation (hidden under the SSH solve) and k_tr_update just
+// gathers it in reference order.
+__global__ void __launch_bounds__(BLOCK) k_diff_flux(DM m, int tr) {
+  const TV t = tracer_view(m, tr);
+  int ed = col_id(), nz = lane_id() + 1;
+  if (ed >= m.myD || nz > m.nlm1) return;
+  int n1 = m.edges[2 * ed], n2 = m.edges[2 * ed + 1], e1 = m.edge_tri[2 * ed], e2 = m.edge_tri[2 * ed + 1];
+  int nl1 = m.nlev[e1] - 1, ul1 = m.ulev[e1], nl2 = 0, ul2 = 0;
+  double dX1 = DECD(1, ed), dY1 = DECD(2, ed), dX2 = 0, dY2 = 0;
+  if (e2 >= 0) { nl2 = m.nlev[e2] - 1; ul2 = m.ulev[e2]; dX2 = DECD(3, ed); dY2 = DECD(4, ed); }
+  int nl12 = min(nl1, nl2), ul12 = max(ul1, ul2);
+  int hi = max(nl1, nl2), lo = ul1;
+  if (ul2 > 0) lo = min(ul1, ul2);
+  if (nz < lo || nz > hi) return;
+  double Kh = (DA2(m.Ki, nz, n1) + DA2(m.Ki, nz, n2)) / 2.0, c;
+  if (nz >= ul12 && nz <= nl12) {
+    double dz = (DA2(m.helem, nz, e1) + DA2(m.helem, nz, e2)) / 2.0;
+    double Tx = 0.5 * (DV2(t.tr_xy, 1, nz, e1) + DV2(t.tr_xy, 1, nz, e2));
+    double Ty = 0.5 * (DV2(t.tr_xy, 2, nz, e1) + DV2(t.tr_xy, 2, nz, e2));
+    double Fx = Kh * (Tx + 0.0), Fy = Kh * (Ty + 0.0);
+    c = ((dX2 - dX1) * Fy - (dY2 - dY1) * Fx) * dz;
+  } else if ((nz >= ul1 && nz <= ul12 - 1) || (nz >= nl12 + 1 && nz <= nl1)) {
+    double dz = DA2(m.helem, nz, e1);
+    double Fx = Kh * (DV2(t.tr_xy, 1, nz, e1) + 0.0), Fy = Kh * (DV2(t.tr_xy, 2, nz, e1) + 0.0);
+    c = (-dX1 * Fy + dY1 * Fx) * dz;
+  } else {
+    double dz = DA2(m.helem, nz, e2);
+    double Fx = Kh * (DV2(t.tr_xy, 1, nz, e2) + 0.0), Fy = Kh * (DV2(t.tr_xy, 2, nz, e2) + 0.0);
+    c = (dX2 * Fy - dY2 * Fx) * dz;
+  }
+  DA2(t.diff_flux, nz, ed) = c;
+}
+
 // oce_tra_adv_flux2dtracer (src/oce_adv_tra_driver.F90:201-269) + adv_tracers_ale tail (src/oce_ale_tracer.F90:241)
-// + diff_tracers_ale (:253-325): horizontal diffusion (diff_part_hor_redi :929-1077, Redi off) gathered over edges,
-// T* update, implicit vertical diffusion (diff_ver_part_impl_ale :398-856) as a lock-step Thomas solve, salinity
-// clamp (:176-198).  22 N3 + 1 D3 values (+ closure).
+// + diff_tracers_ale (:253-325): horizontal diffusion (k_diff_flux) gathered over edges, T* update, coefficients of the
+// implicit vertical diffusion (diff_ver_part_impl_ale :398-856; the sweep is k_thomas<1>), salinity clamp (:176-198).
+// The kernel is latency-bound, not bandwidth-bound: the edge list of the node is read lane-parallel (lane q = q-th
+// incident edge), broadcast with v_readlane, and all edge values are fetched in one batch before the ordered sums.
+#define TRU_MAXD 12
 __global__ void __launch_bounds__(BLOCK) k_tr_update(DM m, int tr) {
   const TV t = tracer_view(m, tr);
   int n = col_id(), l = lane_id(), nz = l + 1;
@@ -310,55 +347,65 @@ __global__ void __launch_bounds__(BLOCK) k_tr_update(DM m, int tr) {
   const int nzmin = m.ulev_n[n], nzmax = m.nlev_n[n];
   const double dt = m.p.dt;
   const bool wet = (nz >= nzmin && nz <= nzmax - 1);
+  const int q0 = m.ne_ptr[n], deg = m.ne_ptr[n + 1] - q0;
+  int ed_l = 0, sg_l = 0;
+  unsigned rg_l = 1u;                                       // lo = 1, hi = 0: empty range
+  if (l < deg) { ed_l = m.ne_idx[q0 + l]; sg_l = m.ne_sgn[q0 + l]; rg_l = m.ne_rng[q0 + l]; }
+  const int nzc = min(nz, m.nlm1);
+  const bool dif = m.p.with_diffusion != 0;
+  double fa[TRU_MAXD], fd[TRU_MAXD];
+#pragma unroll
+  for (int q = 0; q < TRU_MAXD; q++) {                      // one batch of independent loads
+    int ed = rdlane(ed_l, q);
+    fa[q] = DA2(t.adv_flux_hor, nzc, ed);
+    fd[q] = dif ? DA2(t.diff_flux, nzc, ed) : 0.0;
+  }
   double adv = (nz >= nzmin && nz <= nzmax) ? DA2L(t.adv_flux_ver, nz, n) : 0.0;
   double adv_dn = shdn(adv);
   double T = 0.0, hn = 0.0, hnn = 1.0, del = 0.0, asv = 1.0;
   if (wet) {
     T = DTR(m.tr_arr, nz, n, tr); hn = DA2(m.hnode, nz, n); hnn = DA2(m.hnode_new, nz, n); asv = DA2L(m.areasvol, nz, n);
-    double dv = 0.0 - T * hn + DA2(t.fct_LO, nz, n) * hnn;
-    dv = dv + (adv - adv_dn) * dt / asv;
-    double dh = 0.0;
-    for (int q = m.ne_ptr[n]; q < m.ne_ptr[n + 1]; q++) {
-      int ed = m.ne_idx[q];
-      int e1 = m.edge_tri[2 * ed], e2 = m.edge_tri[2 * ed + 1];
-      int nl12 = m.nlev[e1] - 1, nu12 = m.ulev[e1];
-      if (e2 >= 0) { nl12 = max(nl12, m.nlev[e2] - 1); nu12 = min(nu12, m.ulev[e2]); }
-      if (nz < nu12 || nz > nl12) continue;
-      double f = DA2(t.adv_flux_hor, nz, ed) * dt / asv;
-      dh = (m.ne_sgn[q] > 0) ? dh + f : dh - f;
+  }
+  double dv = 0.0 - T * hn + (wet ? DA2(t.fct_LO, nz, n) : 0.0) * hnn;
+  dv = dv + (adv - adv_dn) * dt / asv;
+  double dh = 0.0;
+#pragma unroll
+  for (int q = 0; q < TRU_MAXD; q++) {
+    unsigned rg = (unsigned)rdlane((int)rg_l, q);
+    int sg = rdlane(sg_l, q);
+    bool on = nz >= (int)(rg & 0xffu) && nz <= (int)((rg >> 8) & 0xffu);
+    double f = fa[q] * dt / asv;
+    double nh = (sg > 0) ? dh + f : dh - f;
+    dh = on ? nh : dh;
+  }
+  for (int q = TRU_MAXD; q < deg; q++) {                    // nodes with more incident edges than the batch (rare)
+    int ed = m.ne_idx[q0 + q];
+    unsigned rg = m.ne_rng[q0 + q];
+    if (nz < (int)(rg & 0xffu) || nz > (int)((rg >> 8) & 0xffu)) continue;
+    double f = DA2(t.adv_flux_hor, nz, ed) * dt / asv;
+    dh = (m.ne_sgn[q0 + q] > 0) ? dh + f : dh - f;
+  }
+  del = 0.0 + dh + dv;
+  if (dif) {
+#pragma unroll
+    for (int q = 0; q < TRU_MAXD; q++) {
+      unsigned rg = (unsigned)rdlane((int)rg_l, q);
+      int sg = rdlane(sg_l, q);
+      bool on = nz >= (int)(rg & 0xffu) && nz <= (int)((rg >> 8) & 0xffu);
+      double rhs = (sg > 0) ? 0.0 + fd[q] : 0.0 - fd[q];
+      double nd = del + rhs * dt / asv;
+      del = on ? nd : del;
     }
-    del = 0.0 + dh + dv;
-    if (m.p.with_diffusion) {
-      for (int q = m.ne_ptr[n]; q < m.ne_ptr[n + 1]; q++) {
-        int ed = m.ne_idx[q];
-        int n1 = m.edges[2 * ed], n2 = m.edges[2 * ed + 1], e1 = m.edge_tri[2 * ed], e2 = m.edge_tri[2 * ed + 1];
-        int nl1 = m.nlev[e1] - 1, ul1 = m.ulev[e1], nl2 = 0, ul2 = 0;
-        double dX1 = DECD(1, ed), dY1 = DECD(2, ed), dX2 = 0, dY2 = 0;
-        if (e2 >= 0) { nl2 = m.nlev[e2] - 1; ul2 = m.ulev[e2]; dX2 = DECD(3, ed); dY2 = DECD(4, ed); }
-        int nl12 = min(nl1, nl2), ul12 = max(ul1, ul2);
-        int hi = max(nl1, nl2), lo = ul1;
-        if (ul2 > 0) lo = min(ul1, ul2);
-        if (nz < lo || nz > hi) continue;
-        double Kh = (DA2(m.Ki, nz, n1) + DA2(m.Ki, nz, n2)) / 2.0, c;
-        if (nz >= ul12 && nz <= nl12) {
-          double dz = (DA2(m.helem, nz, e1) + DA2(m.helem, nz, e2)) / 2.0;
-          double Tx = 0.5 * (DV2(t.tr_xy, 1, nz, e1) + DV2(t.tr_xy, 1, nz, e2));
-          double Ty = 0.5 * (DV2(t.tr_xy, 2, nz, e1) + DV2(t.tr_xy, 2, nz, e2));
-          double Fx = Kh * (Tx + 0.0), Fy = Kh * (Ty + 0.0);
-          c = ((dX2 - dX1) * Fy - (dY2 - dY1) * Fx) * dz;
-        } else if ((nz >= ul1 && nz <= ul12 - 1) || (nz >= nl12 + 1 && nz <= nl1)) {
-          double dz = DA2(m.helem, nz, e1);
-          double Fx = Kh * (DV2(t.tr_xy, 1, nz, e1) + 0.0), Fy = Kh * (DV2(t.tr_xy, 2, nz, e1) + 0.0);
-          c = (-dX1 * Fy + dY1 * Fx) * dz;
-        } else {
-          double dz = DA2(m.helem, nz, e2);
-          double Fx = Kh * (DV2(t.tr_xy, 1, nz, e2) + 0.0), Fy = Kh * (DV2(t.tr_xy, 2, nz, e2) + 0.0);
-          c = (dX2 * Fy - dY2 * Fx) * dz;
-        }
-        double rhs = (m.ne_sgn[q] > 0) ? 0.0 + c : 0.0 - c;
-        del = del + rhs * dt / asv;
-      }
+    for (int q = TRU_MAXD; q < deg; q++) {
+      int ed = m.ne_idx[q0 + q];
+      unsigned rg = m.ne_rng[q0 + q];
+      if (nz < (int)(rg & 0xffu) || nz > (int)((rg >> 8) & 0xffu)) continue;
+      double c = DA2(t.diff_flux, nz, ed);
+      double rhs = (m.ne_sgn[q0 + q] > 0) ? 0.0 + c : 0.0 - c;
+      del = del + rhs * dt / asv;
     }
+  }
+  if (wet) {
     DTR(m.tr_arr_old, nz, n, tr) = T;          // tr_arr_old(:,:,tr) = tr_arr(:,:,tr)  (oce_ale_tracer.F90:274)
     del = del + T * (hn - hnn);
     DA2(t.del_ttf, nz, n) = del;
@@ -428,6 +475,7 @@ void launch_tracer(const DM &m, hipStream_t s, int tr) {   // tr 0-based
   LAUNCH_COL(k_fct_ebnd, m.myE, m, tr);
   LAUNCH_COL(k_fct_node, m.myN, m, tr);
   LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr);
+  if (m.p.with_diffusion) LAUNCH_COL(k_diff_flux, m.myD, m, tr);
   LAUNCH_COL(k_tr_update, m.myN, m, tr);
   if (m.p.with_diffusion && m.p.i_vert_diff) launch_thomas_tracer(m, s, tr);
 }
@@ -444,6 +492,7 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
     if (!strcmp(name, "k_fct_ebnd")) { LAUNCH_COL(k_fct_ebnd, m.myE, m, tr); return 0; }
     if (!strcmp(name, "k_fct_node")) { LAUNCH_COL(k_fct_node, m.myN, m, tr); return 0; }
     if (!strcmp(name, "k_fct_edge_limit")) { LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr); return 0; }
+    if (!strcmp(name, "k_diff_flux")) { LAUNCH_COL(k_diff_flux, m.myD, m, tr); return 0; }
     if (!strcmp(name, "k_tr_update")) { LAUNCH_COL(k_tr_update, m.myN, m, tr); return 0; }
     if (!strcmp(name, "k_thomas_tracer")) { launch_thomas_tracer(m, s, tr); return 0; }
     return -1;
@@ -457,6 +506,7 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
     LAUNCH_COL(k_fct_node, m.myN, m, tr); LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr); return 0;
   }
   if (!strcmp(name, "diff_tracers_ale")) {                                                    // incl. flux2dtracer + clamp
+    if (m.p.with_diffusion) LAUNCH_COL(k_diff_flux, m.myD, m, tr);
     LAUNCH_COL(k_tr_update, m.myN, m, tr);
     if (m.p.with_diffusion && m.p.i_vert_diff) launch_thomas_tracer(m, s, tr);
     return 0;
