@@ -40,10 +40,10 @@ KERNEL_VALUES = {
     "k_edge_transport": (0, 5, 0), "k_update_vel": (0, 6, 0), "k_vert_vel": (8, 3, 0),
     "k_tr_ab": (3, 0, 0), "k_tr_z": (3, 0, 0), "k_tr_grad_elem": (2, 4, 0), "k_updn_grad": (0, 2, 4), "k_flux_hor": (2, 3, 6),
     "k_fct_lo_node": (14, 0, 1), "k_fct_ebnd": (2, 2, 0), "k_fct_node": (8, 2, 1), "k_fct_edge_limit": (2, 0, 2),
-    "k_tr_update": (16, 3, 1), "k_thomas_tracer": (6, 0, 0), "k_thomas_visc": (0, 7, 0), "k_thick_node": (5, 0, 0), "k_thick_elem": (1, 1, 0),
+    "k_tr_update": (16, 0, 2), "k_diff_flux": (2, 6, 1), "k_thick_node": (5, 0, 0), "k_thick_elem": (1, 1, 0),
 }
 PER_TRACER = ("k_tr_ab", "k_tr_z", "k_tr_grad_elem", "k_updn_grad", "k_flux_hor", "k_fct_lo_node", "k_fct_ebnd", "k_fct_node",
-              "k_fct_edge_limit", "k_tr_update", "k_thomas_tracer")
+              "k_fct_edge_limit", "k_tr_update", "k_diff_flux")
 
 
 def cpu_baseline(nsteps_ref=400):

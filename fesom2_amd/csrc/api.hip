@@ -138,7 +138,6 @@ static void enqueue_step_dag_b(hipStream_t s0, int first_step, Dag &d) {
   if (m.p.mix_scheme == 2) { K(s0, "k_pp_node_raw"); K(s0, "k_pp_elem"); K(s0, "k_pp_node_final"); }
   hipStreamWaitEvent(s0, ev_rhs, 0); hipStreamWaitEvent(s0, ev_visc, 0);
   K(s0, "k_impl_visc");
-  if (m.p.i_vert_visc) K(s0, "k_thomas_visc");
   K(s0, "k_edge_transport");
   hipStreamWaitEvent(s0, ev_op, 0);
   launch_solver(m, s0, 1, 1);                      // set-up gathers ssh_rhs (k_ssh_rhs_node fused); row scales from s1
@@ -155,7 +154,6 @@ static void enqueue_step_dag_b(hipStream_t s0, int first_step, Dag &d) {
     hipStreamWaitEvent(st, ev_prep[tr], 0);
     K(st, "k_tr_z", tr + 1); K(st, "k_flux_hor", tr + 1); K(st, "k_fct_lo_node", tr + 1); K(st, "k_fct_ebnd", tr + 1);
     K(st, "k_fct_node", tr + 1); K(st, "k_fct_edge_limit", tr + 1); K(st, "k_tr_update", tr + 1);
-    if (m.p.with_diffusion && m.p.i_vert_diff) K(st, "k_thomas_tracer", tr + 1);
   }
   d.dep(s0, s1); d.dep(s0, s2); d.dep(s0, s3);
   launch_thickness(m, s0);
@@ -189,7 +187,6 @@ static void enqueue_step_dag_a(hipStream_t s0, int first_step, Dag &d, int v) {
   if (v == 0) prep();
   d.dep(s0, s1); hipStreamWaitEvent(s0, ev_visc, 0);
   K(s0, "k_impl_visc");
-  if (m.p.i_vert_visc) K(s0, "k_thomas_visc");
   if (m.p.which_ale != 0) K(s1, "k_stiff_update");
   launch_row_scale(m, s1);
   K(s0, "k_edge_transport");
@@ -206,7 +203,6 @@ static void enqueue_step_dag_a(hipStream_t s0, int first_step, Dag &d, int v) {
     hipStream_t st = (tr % 2 == 0) ? s2 : s3;
     K(st, "k_tr_z", tr + 1); K(st, "k_flux_hor", tr + 1); K(st, "k_fct_lo_node", tr + 1); K(st, "k_fct_ebnd", tr + 1);
     K(st, "k_fct_node", tr + 1); K(st, "k_fct_edge_limit", tr + 1); K(st, "k_tr_update", tr + 1);
-    if (m.p.with_diffusion && m.p.i_vert_diff) K(st, "k_thomas_tracer", tr + 1);
   }
   d.dep(s0, s1); d.dep(s0, s2); d.dep(s0, s3);
   launch_thickness(m, s0);
@@ -391,8 +387,6 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   FT(fct_ebnd, 2 * n1 * E); F(pgf_x, n1 * E); F(pgf_y, n1 * E); F(helem, n1 * E); F(Av, nl * E); F(dhe, E); F(stress_surf, 2 * E);
   FT(adv_flux_hor, n1 * D); FT(flux_lo_hor, n1 * D); FT(diff_flux, n1 * D); FT(edge_up_dn_grad, 4 * n1 * D); F(edge_c12, D);
   F(ssh_values, m.nza);
-  { size_t mx = n1 * std::max(N, E); F(th_a, mx); F(th_b, mx); F(th_c, mx); F(th_r1, mx); F(th_r2, mx); }
-  FT(tt_a, n1 * N); FT(tt_b, n1 * N); FT(tt_c, n1 * N); FT(tt_r, n1 * N);
   F(sv_vals, 16 * (N + 64)); F(sv_dinv, N + 64); F(sv_b, N + 64); F(sv_r, N + 64); F(sv_r0, N + 64); F(sv_p, N + 64); F(sv_v, N + 64); F(sv_s, N + 64); F(sv_t, N + 64);
   F(sv_ph, N + 64); F(sv_x0, 16 * (N + 64)); F(sv_snap, N);
   F(sv_resid, 1); F(sv_h1, N); F(sv_h2, N); F(sv_scale, N + 64);
@@ -412,7 +406,6 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     }
   }
   solver_prepare();
-  thomas_prepare();
   G.first_step = 1;
   G.ready = true;
   HIPCHK(hipDeviceSynchronize());

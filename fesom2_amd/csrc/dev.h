@@ -48,8 +48,6 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   double *pgf_x, *pgf_y, *helem, *Av, *dhe, *stress_surf;
   double *adv_flux_hor, *flux_lo_hor, *edge_up_dn_grad, *edge_c12, *diff_flux;
   double *ssh_values;
-  double *th_a, *th_b, *th_c, *th_r1, *th_r2;   // column-major scratch of the batched Thomas solve (momentum)
-  double *tt_a, *tt_b, *tt_c, *tt_r;            // same, one slab per tracer
   // solver workspace
   double *sv_vals, *sv_dinv, *sv_b, *sv_r, *sv_r0, *sv_p, *sv_v, *sv_s, *sv_t, *sv_ph, *sv_x0, *sv_snap;
   int *sv_info; double *sv_resid;   // sv_info[0] iterations of the last solve, [1] number of stored previous solutions
@@ -108,6 +106,92 @@ __device__ __forceinline__ double wave_max(double x) {
 __device__ __forceinline__ double dmin_(double a, double b) { return a < b ? a : b; }
 __device__ __forceinline__ double dmax_(double a, double b) { return a > b ? a : b; }
 
+// ---- in-block Thomas sweep (impl_vert_visc_ale src/oce_ale.F90:2491-2510, diff_ver_part_impl_ale
+// src/oce_ale_tracer.F90:838-852).  The sweep is sequential in z and latency-bound (a dependent fp64 divide per level),
+// so its duration does not depend on how many columns a wavefront solves: the kernels that assemble the coefficients
+// (wave per column, lane = level) hand them over in LDS, wave 0 of the block solves the block's TH_COLS columns (lane =
+// column) and every wave picks its solution up again -- no extra launch, no round trip through global memory.
+// Arithmetic order is the reference's.  Must be called by every thread of the block.
+#define TH_COLS 8
+#define TH_CP (TH_COLS + 1)
+#define TH_BLOCK (WAVE * TH_COLS)
+__device__ __forceinline__ int col_id_th() { return __builtin_amdgcn_readfirstlane(blockIdx.x * TH_COLS + (threadIdx.x >> 6)); }
+static inline size_t thomas_lds_bytes(int nlm1, int nrhs) { return (size_t)(3 + nrhs) * nlm1 * TH_CP * sizeof(double) + 2 * TH_COLS * sizeof(int); }
+static inline int nblocks_th(int ncol) { return (ncol + TH_COLS - 1) / TH_COLS; }
+#define LAUNCH_TH(k, ncol, nrhs, ...) hipLaunchKernelGGL(k, dim3(nblocks_th(ncol)), dim3(TH_BLOCK), thomas_lds_bytes(m.nlm1, nrhs), s, __VA_ARGS__)
+
+template <int NRHS>
+__device__ __forceinline__ void thomas_inblock(double *sh, int nl1, bool valid, int kmin, int kmax, double a, double b, double c, double r1,
+                                               double r2, double &x1, double &x2) {
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nz = l + 1;
+  const int astr = nl1 * TH_CP;                              // array stride (doubles); layout [arr][level][column]
+  int *rng = (int *)(sh + (size_t)(3 + NRHS) * astr);
+  if (l == 0) { rng[2 * w] = valid ? kmin : 1; rng[2 * w + 1] = valid ? kmax : 0; }
+  if (nz <= nl1) {
+    double *p = sh + (nz - 1) * TH_CP + w;
+    p[0] = a; p[astr] = b; p[2 * astr] = c; p[3 * astr] = r1;
+    if (NRHS == 2) p[4 * astr] = r2;
+  }
+  __syncthreads();
+  if (w == 0) {
+    // Branch-free and software-pipelined: the first active level uses a = 0 (b - cp*0 = b, r - x*0 = r exactly, i.e. the
+    // reference's c/b, r/b start), inactive levels are discarded by selects, so the independent divide chains (cp, x1,
+    // x2) interleave in straight-line code and  cp_j = c_j / (b_j - cp_{j-1} a_j)  is the only serial part.
+    const int lc = l < TH_COLS ? l : TH_COLS - 1;
+    int kmn = 1, kmxl = 0;
+    if (l < TH_COLS) { kmn = rng[2 * l]; kmxl = rng[2 * l + 1]; }
+    int kmx = kmxl;
+    for (int s = 4; s >= 1; s >>= 1) kmx = max(kmx, __shfl_xor(kmx, s, 64));
+    kmx = __builtin_amdgcn_readfirstlane(kmx);
+    double *p0 = sh + lc;
+    double cpp = 0.0, x1p = 0.0, x2p = 0.0;
+    double ca = p0[0], cb = p0[astr], cc = p0[2 * astr], c1 = p0[3 * astr], c2 = (NRHS == 2) ? p0[4 * astr] : 0.0;
+    double *pj = p0;
+    for (int j = 1; j <= kmx; j++) {
+      double *pn = (j < kmx) ? pj + TH_CP : pj;
+      double na = pn[0], nb = pn[astr], nc = pn[2 * astr], n1 = pn[3 * astr], n2 = (NRHS == 2) ? pn[4 * astr] : 0.0;
+      const bool act = (j >= kmn) && (j <= kmxl);
+      const double am = (j == kmn) ? 0.0 : ca;
+      double mm = cb - cpp * am;
+      double ncp = cc / mm;
+      double nx1 = (c1 - x1p * am) / mm;
+      double nx2 = (NRHS == 2) ? (c2 - x2p * am) / mm : 0.0;
+      if (act) {
+        cpp = ncp; x1p = nx1; x2p = nx2;
+        pj[2 * astr] = ncp; pj[3 * astr] = nx1;
+        if (NRHS == 2) pj[4 * astr] = nx2;
+      }
+      ca = na; cb = nb; cc = nc; c1 = n1; c2 = n2;
+      pj = pn;
+    }
+    double y1 = 0.0, y2 = 0.0;
+    pj = p0 + (kmx > 0 ? kmx - 1 : 0) * TH_CP;
+    double cp = pj[2 * astr], u1 = pj[3 * astr], u2 = (NRHS == 2) ? pj[4 * astr] : 0.0;
+    for (int j = kmx; j >= 1; j--) {
+      double *pn = (j > 1) ? pj - TH_CP : pj;
+      double ncp = pn[2 * astr], nu1 = pn[3 * astr], nu2 = (NRHS == 2) ? pn[4 * astr] : 0.0;
+      if (j >= kmn && j <= kmxl) {
+        if (j == kmxl) { y1 = u1; if (NRHS == 2) y2 = u2; }
+        else {
+          y1 = u1 - cp * y1;
+          if (NRHS == 2) y2 = u2 - cp * y2;
+        }
+        pj[3 * astr] = y1;
+        if (NRHS == 2) pj[4 * astr] = y2;
+      }
+      cp = ncp; u1 = nu1; u2 = nu2;
+      pj = pn;
+    }
+  }
+  __syncthreads();
+  x1 = 0.0; x2 = 0.0;
+  if (nz <= nl1) {
+    const double *p = sh + (nz - 1) * TH_CP + w;
+    x1 = p[3 * astr];
+    if (NRHS == 2) x2 = p[4 * astr];
+  }
+}
+
 static inline int nblocks(int ncol) { return (ncol + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK; }
 
 // launchers implemented in the kernel translation units
@@ -118,6 +202,3 @@ void launch_row_scale(const DM &m, hipStream_t s);
 void launch_dynamics_post(const DM &m, hipStream_t s);
 void launch_tracer(const DM &m, hipStream_t s, int tr);
 void launch_thickness(const DM &m, hipStream_t s);
-void launch_thomas_visc(const DM &m, hipStream_t s);
-void launch_thomas_tracer(const DM &m, hipStream_t s, int tr);
-void thomas_prepare();

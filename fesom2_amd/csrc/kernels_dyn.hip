@@ -427,11 +427,13 @@ __global__ void __launch_bounds__(BLOCK) k_visc_node(DM m) {
 // impl_vert_visc_ale (src/oce_ale.F90:2348-2517) with the last loop of visc_filt_bcksct (oce_dyn.F90:638-648)
 // fused in front.  Coefficients per level in parallel (this kernel); the Thomas sweep runs one lane per column in
 // k_thomas<2>.  1 N3 + 8 E3 values (+ 5 E3 scratch written, 5 read).
-__global__ void __launch_bounds__(BLOCK) k_impl_visc(DM m, int apply_visc, int do_impl) {
-  int e = col_id(), l = lane_id(), nz = l + 1;
-  if (e >= m.myE) return;
+__global__ void __launch_bounds__(TH_BLOCK) k_impl_visc(DM m, int apply_visc, int do_impl) {
+  extern __shared__ double th_sh[];
+  int e = col_id_th(), l = lane_id(), nz = l + 1;
+  const bool valid = e < m.myE;                            // no early exit: the block meets at the barriers of the sweep
+  if (!valid) e = m.myE - 1;
   const int nzmin = m.ulev[e], nzmax = m.nlev[e];
-  const bool wet = (nz >= nzmin && nz <= nzmax - 1);
+  const bool wet = valid && (nz >= nzmin && nz <= nzmax - 1);
   const int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
   const double dt = m.p.dt;
   double ur = 0.0, vr = 0.0, u = 0.0, v = 0.0, he = 0.0;
@@ -506,11 +508,9 @@ __global__ void __launch_bounds__(BLOCK) k_impl_visc(DM m, int apply_visc, int d
       vr = vr - a * v_up - (b - 1.0) * v;
     }
   }
-  // coefficients and right-hand sides go to column-major scratch; the sweep itself is k_thomas<2> (kernels_thomas.hip)
-  if (wet) {
-    DA2(m.th_a, nz, e) = a; DA2(m.th_b, nz, e) = b; DA2(m.th_c, nz, e) = c;
-    DA2(m.th_r1, nz, e) = ur; DA2(m.th_r2, nz, e) = vr;
-  }
+  double du, dv;
+  thomas_inblock<2>(th_sh, m.nlm1, valid, nzmin, nzmax - 1, a, b, c, ur, vr, du, dv);
+  if (wet) { DV2(m.UV_rhs, 1, nz, e) = du; DV2(m.UV_rhs, 2, nz, e) = dv; }     // UV_rhs = (du, dv), oce_ale.F90:2505-2510
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -751,8 +751,7 @@ void launch_dynamics_pre(const DM &m, hipStream_t s, int first_step) {
   LAUNCH_COL(k_vel_rhs, m.myE, m, first_step);
   LAUNCH_COL(k_visc_elem, m.E, m);
   LAUNCH_COL(k_visc_node, m.myN, m);
-  LAUNCH_COL(k_impl_visc, m.myE, m, 1, m.p.i_vert_visc);
-  if (m.p.i_vert_visc) launch_thomas_visc(m, s);
+  LAUNCH_TH(k_impl_visc, m.myE, 2, m, 1, m.p.i_vert_visc);
 }
 void launch_ssh_rhs(const DM &m, hipStream_t s) {
   if (m.p.which_ale != 0) LAUNCH_FLAT(k_stiff_update, m.nza, m);
@@ -789,8 +788,7 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
     if (!strcmp(name, "k_vel_rhs")) { LAUNCH_COL(k_vel_rhs, m.myE, m, first_step); return 0; }
     if (!strcmp(name, "k_visc_elem")) { LAUNCH_COL(k_visc_elem, m.E, m); return 0; }
     if (!strcmp(name, "k_visc_node")) { LAUNCH_COL(k_visc_node, m.myN, m); return 0; }
-    if (!strcmp(name, "k_impl_visc")) { LAUNCH_COL(k_impl_visc, m.myE, m, 1, m.p.i_vert_visc); return 0; }
-    if (!strcmp(name, "k_thomas_visc")) { launch_thomas_visc(m, s); return 0; }
+    if (!strcmp(name, "k_impl_visc")) { LAUNCH_TH(k_impl_visc, m.myE, 2, m, 1, m.p.i_vert_visc); return 0; }
     if (!strcmp(name, "k_stiff_update")) { LAUNCH_FLAT(k_stiff_update, m.nza, m); return 0; }
     if (!strcmp(name, "k_edge_transport")) { LAUNCH_COL(k_edge_transport, m.myD, m, 0); return 0; }
     if (!strcmp(name, "k_edge_transport1")) { LAUNCH_COL(k_edge_transport, m.myD, m, 1); return 0; }
@@ -816,9 +814,9 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
   if (!strcmp(name, "mo_convect")) return 0;                                                  // fused into mixing_pp
   if (!strcmp(name, "compute_vel_rhs")) { LAUNCH_COL(k_momadv_node, m.myN, m); LAUNCH_COL(k_vel_rhs, m.myE, m, first_step); return 0; }
   if (!strcmp(name, "visc_filt_bcksct")) {
-    LAUNCH_COL(k_visc_elem, m.E, m); LAUNCH_COL(k_visc_node, m.myN, m); LAUNCH_COL(k_impl_visc, m.myE, m, 1, 0); return 0;
+    LAUNCH_COL(k_visc_elem, m.E, m); LAUNCH_COL(k_visc_node, m.myN, m); LAUNCH_TH(k_impl_visc, m.myE, 2, m, 1, 0); return 0;
   }
-  if (!strcmp(name, "impl_vert_visc_ale")) { LAUNCH_COL(k_impl_visc, m.myE, m, 0, 1); launch_thomas_visc(m, s); return 0; }
+  if (!strcmp(name, "impl_vert_visc_ale")) { LAUNCH_TH(k_impl_visc, m.myE, 2, m, 0, 1); return 0; }
   if (!strcmp(name, "update_stiff_mat_ale")) { LAUNCH_FLAT(k_stiff_update, m.nza, m); return 0; }
   if (!strcmp(name, "compute_ssh_rhs_ale")) { LAUNCH_COL(k_edge_transport, m.myD, m, 0); LAUNCH_FLAT(k_ssh_rhs_node, m.myN, m); return 0; }
   if (!strcmp(name, "update_vel")) {

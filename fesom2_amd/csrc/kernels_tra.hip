@@ -8,7 +8,7 @@
 // are independent and can run concurrently on two streams (they only share read-only velocities and thicknesses).
 struct TV {
   double *del_ttf, *fct_LO, *fct_ttf_max, *fct_ttf_min, *fct_plus, *fct_minus, *tr_z, *adv_flux_ver, *tr_xy_ab, *tr_xy, *fct_ebnd,
-         *adv_flux_hor, *flux_lo_hor, *diff_flux, *edge_up_dn_grad, *th_a, *th_b, *th_c, *th_r1;
+         *adv_flux_hor, *flux_lo_hor, *diff_flux, *edge_up_dn_grad;
 };
 __device__ __forceinline__ TV tracer_view(const DM &m, int tr) {
   size_t n1N = (size_t)m.nlm1 * m.N, nlN = (size_t)m.nl * m.N, n1E = (size_t)m.nlm1 * m.E, n1D = (size_t)m.nlm1 * m.D;
@@ -18,7 +18,6 @@ __device__ __forceinline__ TV tracer_view(const DM &m, int tr) {
   t.tr_z = m.tr_z + tr * nlN; t.adv_flux_ver = m.adv_flux_ver + tr * nlN;
   t.tr_xy_ab = m.tr_xy_ab + tr * 2 * n1E; t.tr_xy = m.tr_xy + tr * 2 * n1E; t.fct_ebnd = m.fct_ebnd + tr * 2 * n1E;
   t.adv_flux_hor = m.adv_flux_hor + tr * n1D; t.flux_lo_hor = m.flux_lo_hor + tr * n1D; t.diff_flux = m.diff_flux + tr * n1D; t.edge_up_dn_grad = m.edge_up_dn_grad + tr * 4 * n1D;
-  t.th_a = m.tt_a + tr * n1N; t.th_b = m.tt_b + tr * n1N; t.th_c = m.tt_c + tr * n1N; t.th_r1 = m.tt_r + tr * n1N;
   return t;
 }
 
@@ -336,17 +335,19 @@ __global__ void __launch_bounds__(BLOCK) k_diff_flux(DM m, int tr) {
 
 // oce_tra_adv_flux2dtracer (src/oce_adv_tra_driver.F90:201-269) + adv_tracers_ale tail (src/oce_ale_tracer.F90:241)
 // + diff_tracers_ale (:253-325): horizontal diffusion (k_diff_flux) gathered over edges, T* update, coefficients of the
-// implicit vertical diffusion (diff_ver_part_impl_ale :398-856; the sweep is k_thomas<1>), salinity clamp (:176-198).
+// implicit vertical diffusion (diff_ver_part_impl_ale :398-856) with its in-block Thomas sweep, salinity clamp (:176-198).
 // The kernel is latency-bound, not bandwidth-bound: the edge list of the node is read lane-parallel (lane q = q-th
 // incident edge), broadcast with v_readlane, and all edge values are fetched in one batch before the ordered sums.
 #define TRU_MAXD 12
-__global__ void __launch_bounds__(BLOCK) k_tr_update(DM m, int tr) {
+__global__ void __launch_bounds__(TH_BLOCK) k_tr_update(DM m, int tr) {
+  extern __shared__ double th_sh[];
   const TV t = tracer_view(m, tr);
-  int n = col_id(), l = lane_id(), nz = l + 1;
-  if (n >= m.myN) return;
+  int n = col_id_th(), l = lane_id(), nz = l + 1;
+  const bool valid = n < m.myN;                            // no early exit: the block meets at the barriers of the sweep
+  if (!valid) n = m.myN - 1;
   const int nzmin = m.ulev_n[n], nzmax = m.nlev_n[n];
   const double dt = m.p.dt;
-  const bool wet = (nz >= nzmin && nz <= nzmax - 1);
+  const bool wet = valid && (nz >= nzmin && nz <= nzmax - 1);
   const int q0 = m.ne_ptr[n], deg = m.ne_ptr[n + 1] - q0;
   int ed_l = 0, sg_l = 0;
   unsigned rg_l = 1u;                                       // lo = 1, hi = 0: empty range
@@ -411,7 +412,7 @@ __global__ void __launch_bounds__(BLOCK) k_tr_update(DM m, int tr) {
     DA2(t.del_ttf, nz, n) = del;
     T = T + del / hnn;
   }
-  if (!wet && nz <= m.nlm1) DTR(m.tr_arr_old, nz, n, tr) = DTR(m.tr_arr, nz, n, tr);   // whole-array copy incl. dry cells
+  if (valid && !wet && nz <= m.nlm1) DTR(m.tr_arr_old, nz, n, tr) = DTR(m.tr_arr, nz, n, tr);   // whole-array copy incl. dry cells
   if (m.p.with_diffusion && m.p.i_vert_diff) {
     // zbar_n / Z_n of the node column from hnode_new (bottom-up, reference order)
     double zb_top = seq_sum_down(wet ? hnn : 0.0, nzmax - 2, nzmin - 1, m.zbar_n_bot[n]);
@@ -450,9 +451,11 @@ __global__ void __launch_bounds__(BLOCK) k_tr_update(DM m, int tr) {
         rhs = rhs + bc;
       }
     }
-    // coefficients to scratch, T* to tr_arr; the sweep + clamp is k_thomas<1> (kernels_thomas.hip)
-    if (wet) {
-      DA2(t.th_a, nz, n) = a; DA2(t.th_b, nz, n) = b; DA2(t.th_c, nz, n) = c; DA2(t.th_r1, nz, n) = rhs;
+    double dT, unused;
+    thomas_inblock<1>(th_sh, m.nlm1, valid, nzmin, nzmax - 1, a, b, c, rhs, 0.0, dT, unused);
+    if (wet) {                                 // tr_arr = T* + dT ; salinity clamp (oce_ale_tracer.F90:176-198)
+      T = T + dT;
+      if (tr == 1) { if (T > 45.0) T = 45.0; if (T < 3.0) T = 3.0; }
       DTR(m.tr_arr, nz, n, tr) = T;
     }
     return;
@@ -476,8 +479,7 @@ void launch_tracer(const DM &m, hipStream_t s, int tr) {   // tr 0-based
   LAUNCH_COL(k_fct_node, m.myN, m, tr);
   LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr);
   if (m.p.with_diffusion) LAUNCH_COL(k_diff_flux, m.myD, m, tr);
-  LAUNCH_COL(k_tr_update, m.myN, m, tr);
-  if (m.p.with_diffusion && m.p.i_vert_diff) launch_thomas_tracer(m, s, tr);
+  LAUNCH_TH(k_tr_update, m.myN, 1, m, tr);
 }
 
 int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
@@ -493,8 +495,7 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
     if (!strcmp(name, "k_fct_node")) { LAUNCH_COL(k_fct_node, m.myN, m, tr); return 0; }
     if (!strcmp(name, "k_fct_edge_limit")) { LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr); return 0; }
     if (!strcmp(name, "k_diff_flux")) { LAUNCH_COL(k_diff_flux, m.myD, m, tr); return 0; }
-    if (!strcmp(name, "k_tr_update")) { LAUNCH_COL(k_tr_update, m.myN, m, tr); return 0; }
-    if (!strcmp(name, "k_thomas_tracer")) { launch_thomas_tracer(m, s, tr); return 0; }
+    if (!strcmp(name, "k_tr_update")) { LAUNCH_TH(k_tr_update, m.myN, 1, m, tr); return 0; }
     return -1;
   }
   if (!strcmp(name, "init_tracers_AB")) {
@@ -507,8 +508,7 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
   }
   if (!strcmp(name, "diff_tracers_ale")) {                                                    // incl. flux2dtracer + clamp
     if (m.p.with_diffusion) LAUNCH_COL(k_diff_flux, m.myD, m, tr);
-    LAUNCH_COL(k_tr_update, m.myN, m, tr);
-    if (m.p.with_diffusion && m.p.i_vert_diff) launch_thomas_tracer(m, s, tr);
+    LAUNCH_TH(k_tr_update, m.myN, 1, m, tr);
     return 0;
   }
   if (!strcmp(name, "salinity_clamp")) return 0;
