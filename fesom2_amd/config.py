@@ -6,7 +6,7 @@ from .mesh import WHICH_ALE
 
 def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equation=1, num_tracers=2,
                 mix_scheme="PP", with_diffusion=True, toy_soufflet=False, K_hor=3000.0, A_ver=1.0e-4, K_ver=1.0e-5,
-                cyclic_length_deg=360.0, w_split=False, use_instabmix=True, use_windmix=False, solver_x0_order=2):
+                cyclic_length_deg=360.0, w_split=False, use_instabmix=True, use_windmix=False, solver_x0_order=3):
     p = _lib.Params()
     p.dt = dt
     p.which_ale = WHICH_ALE[which_ale]

@@ -81,7 +81,7 @@ void enqueue_step(hipStream_t s, int first_step) {
   launch_ssh_rhs(m, s);                      // update_stiff_mat_ale, compute_ssh_rhs_ale
   launch_solver(m, s);                       // solve_ssh_ale
   launch_dynamics_post(m, s);                // update_vel, compute_hbar_ale, eta_n, vert_vel_ale
-  for (int tr = 0; tr < m.ntr; tr++) launch_tracer(m, s, tr);   // solve_tracers_ale
+  launch_tracer(m, s, -1);                                       // solve_tracers_ale, all tracers per launch
   launch_thickness(m, s);                    // update_thickness_ale
 }
 
@@ -104,9 +104,9 @@ int K(hipStream_t s, const char *k, int arg = 0, int fs = 0) {
   if (rc < 0) rc = launch_named_tra(G.m, s, k, arg);
   return rc;
 }
-static void enqueue_step_dag_b(hipStream_t s0, int first_step, Dag &d) {
-  // Cross-stream event waits cost ~15 us on this stack, same-stream boundaries ~2 us: the critical chain stays on s0
-  // (momentum -> SSH solve -> W -> T advection -> thickness); side streams carry what only has to be READY by then.
+void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d) {
+  // The critical chain stays on s0 (momentum -> SSH solve -> W -> tracer advection/diffusion -> thickness); side streams
+  // carry what only has to be READY by then.  All tracers go through the same launches (grid.y = tracer).
   const DM &m = G.m;
   hipStream_t s1 = G.side[0], s2 = G.side[1], s3 = G.side[2];
   d.dep(s1, s0); d.dep(s2, s0); d.dep(s3, s0);
@@ -126,18 +126,15 @@ static void enqueue_step_dag_b(hipStream_t s0, int first_step, Dag &d) {
   hipEvent_t ev_visc = d.ev(); hipEventRecord(ev_visc, s3);
   hipStreamWaitEvent(s3, ev_pb, 0);
   K(s3, "k_sigma_slope");
-  std::vector<hipEvent_t> ev_prep(m.ntr);
-  for (int tr = 0; tr < m.ntr; tr++) {
-    K(s3, "k_tr_ab", tr + 1); K(s3, "k_tr_grad_elem", tr + 1); K(s3, "k_updn_grad", tr + 1);
-    if (m.p.with_diffusion) K(s3, "k_diff_flux", tr + 1);
-    ev_prep[tr] = d.ev(); hipEventRecord(ev_prep[tr], s3);
-  }
+  K(s3, "k_tr_ab", 0); K(s3, "k_tr_grad_elem", 0); K(s3, "k_updn_grad", 0);
+  if (m.p.with_diffusion) K(s3, "k_diff_flux", 0);
+  hipEvent_t ev_prep = d.ev(); hipEventRecord(ev_prep, s3);
   // s0: critical chain
   K(s0, "k_vel_nodes");
   hipStreamWaitEvent(s0, ev_pb, 0);
   if (m.p.mix_scheme == 2) { K(s0, "k_pp_node_raw"); K(s0, "k_pp_elem"); K(s0, "k_pp_node_final"); }
   hipStreamWaitEvent(s0, ev_rhs, 0); hipStreamWaitEvent(s0, ev_visc, 0);
-  K(s0, "k_impl_visc");
+  K(s0, "k_impl_visc");                            // incl. the Thomas sweep
   K(s0, "k_edge_transport");
   hipStreamWaitEvent(s0, ev_op, 0);
   launch_solver(m, s0, 1, 1);                      // set-up gathers ssh_rhs (k_ssh_rhs_node fused); row scales from s1
@@ -146,71 +143,11 @@ static void enqueue_step_dag_b(hipStream_t s0, int first_step, Dag &d) {
   hipEvent_t ev_w = d.ev(); hipEventRecord(ev_w, s0);
   hipStreamWaitEvent(s1, ev_w, 0);
   K(s1, "k_dhe");
-  // tracers: tracer 0 continues on s0, the others on s2 (independent chains, own scratch slabs)
-  hipStreamWaitEvent(s2, ev_w, 0);
-  for (int tr = m.ntr - 1; tr >= 0; tr--) {
-    static const int tv = getenv("FESOM_DAG_TV") ? atoi(getenv("FESOM_DAG_TV")) : 0;
-    hipStream_t st = tv == 0 ? ((tr == 0) ? s0 : s2) : tv == 1 ? s0 : ((tr == 0) ? s2 : s1);
-    hipStreamWaitEvent(st, ev_prep[tr], 0);
-    K(st, "k_tr_z", tr + 1); K(st, "k_flux_hor", tr + 1); K(st, "k_fct_lo_node", tr + 1); K(st, "k_fct_ebnd", tr + 1);
-    K(st, "k_fct_node", tr + 1); K(st, "k_fct_edge_limit", tr + 1); K(st, "k_tr_update", tr + 1);
-  }
+  hipStreamWaitEvent(s0, ev_prep, 0);
+  K(s0, "k_tr_z", 0); K(s0, "k_flux_hor", 0); K(s0, "k_fct_lo_node", 0); K(s0, "k_fct_ebnd", 0);
+  K(s0, "k_fct_node", 0); K(s0, "k_fct_edge_limit", 0); K(s0, "k_tr_update", 0);   // incl. the Thomas sweep
   d.dep(s0, s1); d.dep(s0, s2); d.dep(s0, s3);
   launch_thickness(m, s0);
-}
-
-static void enqueue_step_dag_a(hipStream_t s0, int first_step, Dag &d, int v) {
-  const DM &m = G.m;
-  hipStream_t s1 = G.side[0], s2 = G.side[1], s3 = G.side[2];
-  d.dep(s1, s0); d.dep(s2, s0); d.dep(s3, s0);
-  // --- pre-solver momentum branches
-  K(s0, "k_vel_nodes");
-  K(s1, "k_pressure_bv");
-  d.dep(s0, s1);                                   // PP mixing needs Unode (s0) and bvfreq (s1)
-  d.dep(s3, s1);                                   // sigma/slope needs sw_alpha/beta, bvfreq
-  K(s1, "k_pgf");
-  K(s2, "k_momadv_node");
-  d.dep(s1, s2);
-  K(s1, "k_vel_rhs", 0, first_step);
-  K(s3, "k_visc_elem"); K(s3, "k_visc_node");
-  hipEvent_t ev_visc = d.ev(); hipEventRecord(ev_visc, s3);
-  K(s3, "k_sigma_slope");                          // leaf of this step (consumed by GM/Redi/KPP only)
-  if (m.p.mix_scheme == 2) { K(s0, "k_pp_node_raw"); K(s0, "k_pp_elem"); K(s0, "k_pp_node_final"); }
-  // tracer preparation: only needs the tracers -> overlaps everything up to vert_vel_ale (incl. the SSH solve)
-  auto prep = [&]() {
-    for (int tr = 0; tr < m.ntr; tr++) {
-      hipStream_t st = (tr % 2 == 0) ? s2 : s3;
-      K(st, "k_tr_ab", tr + 1); K(st, "k_tr_grad_elem", tr + 1); K(st, "k_updn_grad", tr + 1);
-      if (m.p.with_diffusion) K(st, "k_diff_flux", tr + 1);
-    }
-  };
-  if (v == 0) prep();
-  d.dep(s0, s1); hipStreamWaitEvent(s0, ev_visc, 0);
-  K(s0, "k_impl_visc");
-  if (m.p.which_ale != 0) K(s1, "k_stiff_update");
-  launch_row_scale(m, s1);
-  K(s0, "k_edge_transport");
-  d.dep(s0, s1);
-  launch_solver(m, s0, 1, 1);
-  if (v == 3) prep();
-  K(s0, "k_update_vel"); K(s0, "k_edge_transport1");
-  K(s0, "k_vert_vel_hbar");
-  d.dep(s1, s0);
-  K(s1, "k_dhe");
-  // --- tracer chains, one stream each (T on s2, S on s3, further tracers alternate)
-  d.dep(s2, s0); d.dep(s3, s0);
-  for (int tr = 0; tr < m.ntr; tr++) {
-    hipStream_t st = (tr % 2 == 0) ? s2 : s3;
-    K(st, "k_tr_z", tr + 1); K(st, "k_flux_hor", tr + 1); K(st, "k_fct_lo_node", tr + 1); K(st, "k_fct_ebnd", tr + 1);
-    K(st, "k_fct_node", tr + 1); K(st, "k_fct_edge_limit", tr + 1); K(st, "k_tr_update", tr + 1);
-  }
-  d.dep(s0, s1); d.dep(s0, s2); d.dep(s0, s3);
-  launch_thickness(m, s0);
-}
-
-void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d) {
-  static const int v = getenv("FESOM_DAG_V") ? atoi(getenv("FESOM_DAG_V")) : 0;
-  if (v == 1) enqueue_step_dag_b(s0, first_step, d); else enqueue_step_dag_a(s0, first_step, d, v);
 }
 
 int build_graph(int which) {
@@ -259,18 +196,8 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     if (dev < 0 || dev >= ndev) dev = 0;
     HIPCHK(hipSetDevice(dev));
   }
-  {
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);         // hi = numerically lowest = highest priority
-    const char *pe = getenv("FESOM_DAG_PRIO"); int pm = pe ? atoi(pe) : 3;
-    if (pm == 3) {
-      HIPCHK(hipStreamCreate(&G.stream));
-      for (int i = 0; i < 3; i++) HIPCHK(hipStreamCreateWithFlags(&G.side[i], hipStreamNonBlocking));
-    } else {
-      HIPCHK(hipStreamCreateWithPriority(&G.stream, hipStreamDefault, pm ? hi : lo));
-      for (int i = 0; i < 3; i++) HIPCHK(hipStreamCreateWithPriority(&G.side[i], hipStreamNonBlocking, (pm == 1 && i == 2) || pm == 0 ? lo : hi));
-    }
-  }
+  HIPCHK(hipStreamCreate(&G.stream));
+  for (int i = 0; i < 3; i++) HIPCHK(hipStreamCreateWithFlags(&G.side[i], hipStreamNonBlocking));   // (stream priorities: no effect, measured)
   G.serial = getenv("FESOM_GPU_SERIAL") != nullptr;
   // Measured on MI355X/ROCm 7.2 (pi): eager 4-stream DAG 0.80 ms/step, hipGraph of the same DAG 0.86, serial chain 0.90
   // (graph replay serialises most branches; kernels are >= 5 us so the host launch rate is not the limit).
@@ -389,7 +316,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   F(ssh_values, m.nza);
   F(sv_vals, 16 * (N + 64)); F(sv_dinv, N + 64); F(sv_b, N + 64); F(sv_r, N + 64); F(sv_r0, N + 64); F(sv_p, N + 64); F(sv_v, N + 64); F(sv_s, N + 64); F(sv_t, N + 64);
   F(sv_ph, N + 64); F(sv_x0, 16 * (N + 64)); F(sv_snap, N);
-  F(sv_resid, 1); F(sv_h1, N); F(sv_h2, N); F(sv_scale, N + 64);
+  F(sv_resid, 1); F(sv_h1, N); F(sv_h2, N); F(sv_h3, N); F(sv_scale, N + 64);
   m.sv_extrap = 1;
 #undef F
 #undef FT

@@ -24,14 +24,16 @@ __device__ __forceinline__ TV tracer_view(const DM &m, int tr) {
 // init_tracers_AB head (src/oce_tracer_mod.F90:49-83): AB2 extrapolation (k_tr_ab) and tracer_gradient_z (:124-153, k_tr_z).
 // Split in two kernels because the AB part only needs the tracers (it is hoisted to the start of the step and overlaps
 // the SSH solve) while tr_z needs hnode_new of this step's vert_vel_ale.
-__global__ void __launch_bounds__(BLOCK) k_tr_ab(DM m, int tr) {
+__global__ void __launch_bounds__(BLOCK) k_tr_ab(DM m, int tr0) {
+  const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   int n = col_id(), nz = lane_id() + 1;
   if (n >= m.N || nz > m.nlm1) return;
   const double eps = m.p.epsilon;
   double cur = DTR(m.tr_arr, nz, n, tr);
   DTR(m.tr_arr_old, nz, n, tr) = -(0.5 + eps) * DTR(m.tr_arr_old, nz, n, tr) + (1.5 + eps) * cur;
 }
-__global__ void __launch_bounds__(BLOCK) k_tr_z(DM m, int tr) {
+__global__ void __launch_bounds__(BLOCK) k_tr_z(DM m, int tr0) {
+  const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   const TV t = tracer_view(m, tr);
   int n = col_id(), nz = lane_id() + 1;
   if (n >= m.N) return;
@@ -44,7 +46,8 @@ __global__ void __launch_bounds__(BLOCK) k_tr_z(DM m, int tr) {
 }
 
 // tracer_gradient_elements (src/oce_tracer_mod.F90:19-45) for the AB field and the current field in one pass
-__global__ void __launch_bounds__(BLOCK) k_tr_grad_elem(DM m, int tr) {
+__global__ void __launch_bounds__(BLOCK) k_tr_grad_elem(DM m, int tr0) {
+  const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   const TV t = tracer_view(m, tr);
   int e = col_id(), nz = lane_id() + 1;
   if (e >= m.myE) return;
@@ -72,7 +75,8 @@ __device__ __forceinline__ void cluster_grad(const DM &m, const TV &t, int node,
   }
   gx = tx / tvol; gy = ty / tvol;
 }
-__global__ void __launch_bounds__(BLOCK) k_updn_grad(DM m, int tr) {
+__global__ void __launch_bounds__(BLOCK) k_updn_grad(DM m, int tr0) {
+  const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   const TV t = tracer_view(m, tr);
   int ed = col_id(), nz = lane_id() + 1;
   if (ed >= m.myD) return;
@@ -102,7 +106,8 @@ __global__ void __launch_bounds__(BLOCK) k_updn_grad(DM m, int tr) {
 
 // adv_tra_hor_upw1 (src/oce_adv_tra_hor.F90:57-211) + adv_tra_hor_mfct (:485-733) in one edge pass:
 // flux_lo_hor = low-order flux, adv_flux_hor = high-order minus low-order (the init_zero=.false. convention).
-__global__ void __launch_bounds__(BLOCK) k_flux_hor(DM m, int tr) {
+__global__ void __launch_bounds__(BLOCK) k_flux_hor(DM m, int tr0) {
+  const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   const TV t = tracer_view(m, tr);
   int ed = col_id(), nz = lane_id() + 1;
   if (ed >= m.myD) return;
@@ -143,7 +148,8 @@ __global__ void __launch_bounds__(BLOCK) k_flux_hor(DM m, int tr) {
 
 // low-order solution (src/oce_adv_tra_driver.F90:97-133) with adv_tra_ver_upw1 (src/oce_adv_tra_ver.F90:231-282)
 // and adv_tra_ver_qr4c (:286-357) evaluated in registers; also the nodal bounds of oce_tra_adv_fct (:94-101).
-__global__ void __launch_bounds__(BLOCK) k_fct_lo_node(DM m, int tr) {
+__global__ void __launch_bounds__(BLOCK) k_fct_lo_node(DM m, int tr0) {
+  const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   const TV t = tracer_view(m, tr);
   int n = col_id(), l = lane_id(), nz = l + 1;
   if (n >= m.myN) return;
@@ -200,7 +206,8 @@ __global__ void __launch_bounds__(BLOCK) k_fct_lo_node(DM m, int tr) {
 }
 
 // element bounds (src/oce_adv_tra_fct.F90:108-121; the reference parks them in UV_rhs)
-__global__ void __launch_bounds__(BLOCK) k_fct_ebnd(DM m, int tr) {
+__global__ void __launch_bounds__(BLOCK) k_fct_ebnd(DM m, int tr0) {
+  const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   const TV t = tracer_view(m, tr);
   int e = col_id(), nz = lane_id() + 1;
   if (e >= m.myE) return;
@@ -218,7 +225,8 @@ __global__ void __launch_bounds__(BLOCK) k_fct_ebnd(DM m, int tr) {
 
 // cluster bounds, sums of positive/negative antidiffusive fluxes, limiting factors and the limiting of the
 // vertical antidiffusive flux (src/oce_adv_tra_fct.F90:127-311, vlimit=1)
-__global__ void __launch_bounds__(BLOCK) k_fct_node(DM m, int tr) {
+__global__ void __launch_bounds__(BLOCK) k_fct_node(DM m, int tr0) {
+  const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   const TV t = tracer_view(m, tr);
   int n = col_id(), l = lane_id(), nz = l + 1;
   if (n >= m.myN) return;
@@ -284,7 +292,8 @@ __global__ void __launch_bounds__(BLOCK) k_fct_node(DM m, int tr) {
 }
 
 // limiting of the horizontal antidiffusive flux (src/oce_adv_tra_fct.F90:318-347)
-__global__ void __launch_bounds__(BLOCK) k_fct_edge_limit(DM m, int tr) {
+__global__ void __launch_bounds__(BLOCK) k_fct_edge_limit(DM m, int tr0) {
+  const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   const TV t = tracer_view(m, tr);
   int ed = col_id(), nz = lane_id() + 1;
   if (ed >= m.myD) return;
@@ -302,7 +311,8 @@ __global__ void __launch_bounds__(BLOCK) k_fct_edge_limit(DM m, int tr) {
 // the reference adds to / subtracts from the two end nodes.  It only needs T^n gradients, Ki and helem of the current
 // step, so it is computed edge-parallel during tracer preparation (hidden under the SSH solve) and k_tr_update just
 // gathers it in reference order.
-__global__ void __launch_bounds__(BLOCK) k_diff_flux(DM m, int tr) {
+__global__ void __launch_bounds__(BLOCK) k_diff_flux(DM m, int tr0) {
+  const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   const TV t = tracer_view(m, tr);
   int ed = col_id(), nz = lane_id() + 1;
   if (ed >= m.myD || nz > m.nlm1) return;
@@ -339,7 +349,8 @@ __global__ void __launch_bounds__(BLOCK) k_diff_flux(DM m, int tr) {
 // The kernel is latency-bound, not bandwidth-bound: the edge list of the node is read lane-parallel (lane q = q-th
 // incident edge), broadcast with v_readlane, and all edge values are fetched in one batch before the ordered sums.
 #define TRU_MAXD 12
-__global__ void __launch_bounds__(TH_BLOCK) k_tr_update(DM m, int tr) {
+__global__ void __launch_bounds__(TH_BLOCK) k_tr_update(DM m, int tr0) {
+  const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   extern __shared__ double th_sh[];
   const TV t = tracer_view(m, tr);
   int n = col_id_th(), l = lane_id(), nz = l + 1;
@@ -466,7 +477,9 @@ __global__ void __launch_bounds__(TH_BLOCK) k_tr_update(DM m, int tr) {
   }
 }
 
-#define LAUNCH_COL(k, ncol, ...) hipLaunchKernelGGL(k, dim3(nblocks(ncol)), dim3(BLOCK), 0, s, __VA_ARGS__)
+// tr >= 0: that tracer only; tr < 0: all tracers in one launch (grid.y), their chains are independent
+#define LAUNCH_COL(k, ncol, m_, tr_) hipLaunchKernelGGL(k, dim3(nblocks(ncol), (tr_) < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m_, (tr_) < 0 ? 0 : (tr_))
+#define LAUNCH_TRU(m_, tr_) hipLaunchKernelGGL(k_tr_update, dim3(nblocks_th(m.myN), (tr_) < 0 ? m.ntr : 1), dim3(TH_BLOCK), thomas_lds_bytes(m.nlm1, 1), s, m_, (tr_) < 0 ? 0 : (tr_))
 
 void launch_tracer(const DM &m, hipStream_t s, int tr) {   // tr 0-based
   LAUNCH_COL(k_tr_ab, m.N, m, tr);
@@ -479,7 +492,7 @@ void launch_tracer(const DM &m, hipStream_t s, int tr) {   // tr 0-based
   LAUNCH_COL(k_fct_node, m.myN, m, tr);
   LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr);
   if (m.p.with_diffusion) LAUNCH_COL(k_diff_flux, m.myD, m, tr);
-  LAUNCH_TH(k_tr_update, m.myN, 1, m, tr);
+  LAUNCH_TRU(m, tr);
 }
 
 int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
@@ -495,7 +508,7 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
     if (!strcmp(name, "k_fct_node")) { LAUNCH_COL(k_fct_node, m.myN, m, tr); return 0; }
     if (!strcmp(name, "k_fct_edge_limit")) { LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr); return 0; }
     if (!strcmp(name, "k_diff_flux")) { LAUNCH_COL(k_diff_flux, m.myD, m, tr); return 0; }
-    if (!strcmp(name, "k_tr_update")) { LAUNCH_TH(k_tr_update, m.myN, 1, m, tr); return 0; }
+    if (!strcmp(name, "k_tr_update")) { LAUNCH_TRU(m, tr); return 0; }
     return -1;
   }
   if (!strcmp(name, "init_tracers_AB")) {
@@ -508,7 +521,7 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
   }
   if (!strcmp(name, "diff_tracers_ale")) {                                                    // incl. flux2dtracer + clamp
     if (m.p.with_diffusion) LAUNCH_COL(k_diff_flux, m.myD, m, tr);
-    LAUNCH_TH(k_tr_update, m.myN, 1, m, tr);
+    LAUNCH_TRU(m, tr);
     return 0;
   }
   if (!strcmp(name, "salinity_clamp")) return 0;

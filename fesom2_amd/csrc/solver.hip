@@ -133,8 +133,13 @@ __global__ void k_solver_setup(DM m, int NP, int fuse_rhs) {
   m.sv_b[i] = rhs * sc;
   double diag = m.sv_dinv[i];
   double xi = m.d_eta[i], x0 = xi;                       // initial guess: previous solution or quadratic extrapolation
-  if (m.p.solver_x0_order == 2 && m.sv_extrap && m.sv_info[1] >= 2) x0 = (3.0 * xi - 3.0 * m.sv_h1[i]) + m.sv_h2[i];
-  if (m.sv_extrap) { m.sv_h2[i] = m.sv_h1[i]; m.sv_h1[i] = xi; }
+  const int nh = m.sv_info[1];                          // solutions in the history (the final thread of the solve counts them up)
+  if (m.sv_extrap) {
+    if (m.p.solver_x0_order == 2 && nh >= 2) x0 = (3.0 * xi - 3.0 * m.sv_h1[i]) + m.sv_h2[i];
+    if (m.p.solver_x0_order == 3 && nh >= 3) x0 = ((4.0 * xi - 6.0 * m.sv_h1[i]) + 4.0 * m.sv_h2[i]) - m.sv_h3[i];
+    if (m.p.solver_x0_order == 3 && nh == 2) x0 = (3.0 * xi - 3.0 * m.sv_h1[i]) + m.sv_h2[i];
+    m.sv_h3[i] = m.sv_h2[i]; m.sv_h2[i] = m.sv_h1[i]; m.sv_h1[i] = xi;
+  }
   m.sv_s[i] = x0 * diag;                                  // y0 = D x0
 #pragma unroll
   for (int k = 0; k < W; k++) {
@@ -223,7 +228,7 @@ __device__ __forceinline__ void solver_body(const DM &m, int maxits, double tol2
     }
   }
   for (int i = t; i < n; i += ST) x[i] = y[i] * (1.0 / diagg[i]);
-  if (t == 0) { m.sv_info[0] = it; m.sv_resid[0] = sqrt(rr > 0.0 ? rr : 0.0); if (m.sv_extrap && m.sv_info[1] < 2) m.sv_info[1] = m.sv_info[1] + 1; }
+  if (t == 0) { m.sv_info[0] = it; m.sv_resid[0] = sqrt(rr > 0.0 ? rr : 0.0); if (m.sv_extrap && m.sv_info[1] < 3) m.sv_info[1] = m.sv_info[1] + 1; }
 }
 
 // Register-resident variant for n <= 4*ST rows: thread t owns rows t, t+1024, t+2048, t+3072.  Own-row vectors r, v, t
@@ -342,7 +347,7 @@ __global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2
 #pragma unroll
   for (int k = 0; k < R; k++)
     if (ok[k]) { const unsigned i = t + k * ST; m.d_eta[i] = yl[i] * (1.0 / m.sv_dinv[i]); }
-  if (t == 0) { m.sv_info[0] = it; m.sv_resid[0] = sqrt(rr > 0.0 ? rr : 0.0); if (m.sv_extrap && m.sv_info[1] < 2) m.sv_info[1] = m.sv_info[1] + 1; }
+  if (t == 0) { m.sv_info[0] = it; m.sv_resid[0] = sqrt(rr > 0.0 ? rr : 0.0); if (m.sv_extrap && m.sv_info[1] < 3) m.sv_info[1] = m.sv_info[1] + 1; }
 }
 
 void solver_prepare() {

@@ -104,7 +104,8 @@ typedef struct fesom_params {
   double cyclic_length;      /* [rad] */
   int    with_diffusion;     /* 1: run diff_tracers_ale closure (rows f-1 i); 0: advection only */
   int    solver_x0_order;    /* SSH solver initial guess: 0 = previous d_eta (reference, psolve.c:206-212);
-                                2 = quadratic extrapolation of the last three solutions (fewer iterations, same tolerance) */
+                                2 / 3 = quadratic / cubic extrapolation of the last three / four solutions (fewer
+                                iterations, same tolerance) */
 } fesom_params;
 
 /* ---- prognostic state = restart set (io_restart.F90:99-155) + ALE thickness arrays -- */

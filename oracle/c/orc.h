@@ -39,7 +39,7 @@ typedef struct {
   double *edge_up_dn_grad;                       /* (4,nl-1,D) */
   /* ssh operator + solver */
   double *ssh_values;
-  double *sv_h1, *sv_h2; int sv_nhist;      /* previous SSH solutions for the extrapolated initial guess */
+  double *sv_h1, *sv_h2, *sv_h3; int sv_nhist;      /* previous SSH solutions for the extrapolated initial guess */
   int solver_iters; double solver_resid;
 } orc_ctx;
 

@@ -39,7 +39,7 @@ int orc_init(const fesom_mesh_desc *m, const fesom_params *p) {
   R(UV, 2 * n1 * E); R(UV_rhs, 2 * n1 * E); R(UV_rhsAB, 2 * n1 * E); R(tr_xy, 2 * n1 * E); R(U_b, 2 * n1 * E); R(fct_ebnd, 2 * n1 * E);
   R(pgf_x, n1 * E); R(pgf_y, n1 * E); R(helem, n1 * E); R(Av, nl * E); R(dhe, E); R(stress_surf, 2 * E);
   R(adv_flux_hor, n1 * D); R(edge_up_dn_grad, 4 * n1 * D);
-  R(ssh_values, m->ssh_nza); R(sv_h1, N); R(sv_h2, N);
+  R(ssh_values, m->ssh_nza); R(sv_h1, N); R(sv_h2, N); R(sv_h3, N);
 #undef R
   for (size_t i = 0; i < n1 * N; i++) C_.density_ref[i] = DENSITY_0;
   memcpy(C_.ssh_values, m->ssh_values, sizeof(double) * m->ssh_nza);
@@ -107,14 +107,16 @@ void orc_solve_ssh(void) {
   double *B = malloc(sizeof(double) * C_.m.ssh_nza), *diag = malloc(sizeof(double) * n * 10);
   double *dinv = diag + n, *b = dinv + n, *r = b + n, *r0 = r + n, *pv = r0 + n, *v = pv + n, *s = v + n, *t = s + n, *y = t + n;
   double *x = C_.d_eta;
-  /* initial guess: previous solution (reference) or quadratic extrapolation of the last three solutions */
+  /* initial guess: previous solution (reference) or quadratic / cubic extrapolation of the last solutions */
   for (int i = 0; i < n; i++) {
     double xi = x[i], x0 = xi;
     if (C_.p.solver_x0_order == 2 && C_.sv_nhist >= 2) x0 = (3.0 * xi - 3.0 * C_.sv_h1[i]) + C_.sv_h2[i];
-    C_.sv_h2[i] = C_.sv_h1[i]; C_.sv_h1[i] = xi;
+    if (C_.p.solver_x0_order == 3 && C_.sv_nhist >= 3) x0 = ((4.0 * xi - 6.0 * C_.sv_h1[i]) + 4.0 * C_.sv_h2[i]) - C_.sv_h3[i];
+    if (C_.p.solver_x0_order == 3 && C_.sv_nhist == 2) x0 = (3.0 * xi - 3.0 * C_.sv_h1[i]) + C_.sv_h2[i];
+    C_.sv_h3[i] = C_.sv_h2[i]; C_.sv_h2[i] = C_.sv_h1[i]; C_.sv_h1[i] = xi;
     x[i] = x0;
   }
-  if (C_.sv_nhist < 2) C_.sv_nhist++;
+  if (C_.sv_nhist < 3) C_.sv_nhist++;
   for (int i = 0; i < n; i++) {
     double tmp = 0.;
     for (int j = rp[i] - off; j < rp[i + 1] - off; j++) tmp += fabs(C_.ssh_values[j]);
