@@ -39,10 +39,10 @@ KERNEL_VALUES = {
     "k_vel_rhs": (2, 10, 0), "k_visc_elem": (0, 4, 0), "k_visc_node": (2, 2, 0), "k_impl_visc": (3, 13, 0),
     "k_edge_transport": (0, 5, 0), "k_update_vel": (0, 6, 0), "k_vert_vel": (8, 3, 0),
     "k_tr_ab": (3, 0, 0), "k_tr_z": (3, 0, 0), "k_tr_grad_elem": (2, 4, 0), "k_updn_grad": (0, 2, 4), "k_flux_hor": (2, 3, 6),
-    "k_fct_lo_node": (14, 0, 1), "k_fct_ebnd": (2, 2, 0), "k_fct_node": (8, 2, 1), "k_fct_edge_limit": (2, 0, 2),
-    "k_tr_update": (16, 0, 2), "k_diff_flux": (2, 6, 1), "k_thick_node": (5, 0, 0), "k_thick_elem": (1, 1, 0),
+    "k_fct_lo_node": (12, 0, 1), "k_fct_node": (10, 0, 1), "k_fct_edge_limit": (2, 0, 2),
+    "k_tr_update": (18, 0, 2), "k_diff_flux": (2, 6, 1), "k_thick_node": (5, 0, 0), "k_thick_elem": (1, 1, 0),
 }
-PER_TRACER = ("k_tr_ab", "k_tr_z", "k_tr_grad_elem", "k_updn_grad", "k_flux_hor", "k_fct_lo_node", "k_fct_ebnd", "k_fct_node",
+PER_TRACER = ("k_tr_ab", "k_tr_z", "k_tr_grad_elem", "k_updn_grad", "k_flux_hor", "k_fct_lo_node", "k_fct_node",
               "k_fct_edge_limit", "k_tr_update", "k_diff_flux")
 
 

@@ -143,9 +143,13 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d) {
   hipEvent_t ev_w = d.ev(); hipEventRecord(ev_w, s0);
   hipStreamWaitEvent(s1, ev_w, 0);
   K(s1, "k_dhe");
+  K(s1, "k_tr_z", 0);                              // vertical tracer gradient: only consumed by Redi/GM, off the chain
   hipStreamWaitEvent(s0, ev_prep, 0);
-  K(s0, "k_tr_z", 0); K(s0, "k_flux_hor", 0); K(s0, "k_fct_lo_node", 0); K(s0, "k_fct_ebnd", 0);
-  K(s0, "k_fct_node", 0); K(s0, "k_fct_edge_limit", 0); K(s0, "k_tr_update", 0);   // incl. the Thomas sweep
+  K(s0, "k_flux_hor", 0); K(s0, "k_fct_lo_node", 0); K(s0, "k_fct_node", 0);
+  hipEvent_t ev_fct = d.ev(); hipEventRecord(ev_fct, s0);
+  hipStreamWaitEvent(s1, ev_fct, 0);
+  K(s1, "k_fct_edge_limit", 0);                    // materialises the limited flux field; k_tr_update limits on the fly
+  K(s0, "k_tr_update", 0);                         // incl. the Thomas sweep
   d.dep(s0, s1); d.dep(s0, s2); d.dep(s0, s3);
   launch_thickness(m, s0);
 }
@@ -311,8 +315,8 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   F(eta_n, N); F(d_eta, N); F(ssh_rhs, N); F(ssh_rhs_old, N); F(hbar, N); F(hbar_old, N); F(MLD1, N); F(MLD2, N);
   F(heat_flux, N); F(water_flux, N); F(virtual_salt, N); F(relax_salt, N); F(real_salt_flux, N);
   F(UV, 2 * n1 * E); F(UV_rhs, 2 * n1 * E); F(UV_rhsAB, 2 * n1 * E); FT(tr_xy, 2 * n1 * E); FT(tr_xy_ab, 2 * n1 * E); F(U_b, 2 * n1 * E);
-  FT(fct_ebnd, 2 * n1 * E); F(pgf_x, n1 * E); F(pgf_y, n1 * E); F(helem, n1 * E); F(Av, nl * E); F(dhe, E); F(stress_surf, 2 * E);
-  FT(adv_flux_hor, n1 * D); FT(flux_lo_hor, n1 * D); FT(diff_flux, n1 * D); FT(edge_up_dn_grad, 4 * n1 * D); F(edge_c12, D);
+  F(pgf_x, n1 * E); F(pgf_y, n1 * E); F(helem, n1 * E); F(Av, nl * E); F(dhe, E); F(stress_surf, 2 * E);
+  FT(adv_flux_hor, n1 * D); FT(adv_flux_raw, n1 * D); FT(flux_lo_hor, n1 * D); FT(diff_flux, n1 * D); FT(edge_up_dn_grad, 4 * n1 * D); F(edge_c12, D);
   F(ssh_values, m.nza);
   F(sv_vals, 16 * (N + 64)); F(sv_dinv, N + 64); F(sv_b, N + 64); F(sv_r, N + 64); F(sv_r0, N + 64); F(sv_p, N + 64); F(sv_v, N + 64); F(sv_s, N + 64); F(sv_t, N + 64);
   F(sv_ph, N + 64); F(sv_x0, 16 * (N + 64)); F(sv_snap, N);

@@ -44,9 +44,9 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   double *Unode, *Unode_rhs, *sigma_xy, *neutral_slope, *slope_tapered, *U_c;
   double *eta_n, *d_eta, *ssh_rhs, *ssh_rhs_old, *hbar, *hbar_old, *MLD1, *MLD2;
   double *heat_flux, *water_flux, *virtual_salt, *relax_salt, *real_salt_flux;
-  double *UV, *UV_rhs, *UV_rhsAB, *tr_xy, *tr_xy_ab, *U_b, *fct_ebnd;
+  double *UV, *UV_rhs, *UV_rhsAB, *tr_xy, *tr_xy_ab, *U_b;
   double *pgf_x, *pgf_y, *helem, *Av, *dhe, *stress_surf;
-  double *adv_flux_hor, *flux_lo_hor, *edge_up_dn_grad, *edge_c12, *diff_flux;
+  double *adv_flux_hor, *adv_flux_raw, *flux_lo_hor, *edge_up_dn_grad, *edge_c12, *diff_flux;
   double *ssh_values;
   // solver workspace
   double *sv_vals, *sv_dinv, *sv_b, *sv_r, *sv_r0, *sv_p, *sv_v, *sv_s, *sv_t, *sv_ph, *sv_x0, *sv_snap;
@@ -112,6 +112,7 @@ __device__ __forceinline__ double dmax_(double a, double b) { return a > b ? a :
 // (wave per column, lane = level) hand them over in LDS, wave 0 of the block solves the block's TH_COLS columns (lane =
 // column) and every wave picks its solution up again -- no extra launch, no round trip through global memory.
 // Arithmetic order is the reference's.  Must be called by every thread of the block.
+#define GATHER_MAXD 12                  // incident edges fetched in one batch by the node-gather kernels (more: remainder loop)
 #define TH_COLS 8
 #define TH_CP (TH_COLS + 1)
 #define TH_BLOCK (WAVE * TH_COLS)

@@ -7,8 +7,8 @@
 // Per-tracer scratch: every tracer has its own slab of the FCT / gradient / Thomas work arrays, so the T and S chains
 // are independent and can run concurrently on two streams (they only share read-only velocities and thicknesses).
 struct TV {
-  double *del_ttf, *fct_LO, *fct_ttf_max, *fct_ttf_min, *fct_plus, *fct_minus, *tr_z, *adv_flux_ver, *tr_xy_ab, *tr_xy, *fct_ebnd,
-         *adv_flux_hor, *flux_lo_hor, *diff_flux, *edge_up_dn_grad;
+  double *del_ttf, *fct_LO, *fct_ttf_max, *fct_ttf_min, *fct_plus, *fct_minus, *tr_z, *adv_flux_ver, *tr_xy_ab, *tr_xy,
+         *adv_flux_hor, *adv_flux_raw, *flux_lo_hor, *diff_flux, *edge_up_dn_grad;
 };
 __device__ __forceinline__ TV tracer_view(const DM &m, int tr) {
   size_t n1N = (size_t)m.nlm1 * m.N, nlN = (size_t)m.nl * m.N, n1E = (size_t)m.nlm1 * m.E, n1D = (size_t)m.nlm1 * m.D;
@@ -16,8 +16,8 @@ __device__ __forceinline__ TV tracer_view(const DM &m, int tr) {
   t.del_ttf = m.del_ttf + tr * n1N; t.fct_LO = m.fct_LO + tr * n1N; t.fct_ttf_max = m.fct_ttf_max + tr * n1N;
   t.fct_ttf_min = m.fct_ttf_min + tr * n1N; t.fct_plus = m.fct_plus + tr * n1N; t.fct_minus = m.fct_minus + tr * n1N;
   t.tr_z = m.tr_z + tr * nlN; t.adv_flux_ver = m.adv_flux_ver + tr * nlN;
-  t.tr_xy_ab = m.tr_xy_ab + tr * 2 * n1E; t.tr_xy = m.tr_xy + tr * 2 * n1E; t.fct_ebnd = m.fct_ebnd + tr * 2 * n1E;
-  t.adv_flux_hor = m.adv_flux_hor + tr * n1D; t.flux_lo_hor = m.flux_lo_hor + tr * n1D; t.diff_flux = m.diff_flux + tr * n1D; t.edge_up_dn_grad = m.edge_up_dn_grad + tr * 4 * n1D;
+  t.tr_xy_ab = m.tr_xy_ab + tr * 2 * n1E; t.tr_xy = m.tr_xy + tr * 2 * n1E;
+  t.adv_flux_hor = m.adv_flux_hor + tr * n1D; t.adv_flux_raw = m.adv_flux_raw + tr * n1D; t.flux_lo_hor = m.flux_lo_hor + tr * n1D; t.diff_flux = m.diff_flux + tr * n1D; t.edge_up_dn_grad = m.edge_up_dn_grad + tr * 4 * n1D;
   return t;
 }
 
@@ -105,7 +105,8 @@ __global__ void __launch_bounds__(BLOCK) k_updn_grad(DM m, int tr0) {
 }
 
 // adv_tra_hor_upw1 (src/oce_adv_tra_hor.F90:57-211) + adv_tra_hor_mfct (:485-733) in one edge pass:
-// flux_lo_hor = low-order flux, adv_flux_hor = high-order minus low-order (the init_zero=.false. convention).
+// flux_lo_hor = low-order flux, adv_flux_raw = high-order minus low-order (the init_zero=.false. convention), not yet
+// limited; k_fct_edge_limit turns it into adv_flux_hor.
 __global__ void __launch_bounds__(BLOCK) k_flux_hor(DM m, int tr0) {
   const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   const TV t = tracer_view(m, tr);
@@ -126,7 +127,7 @@ __global__ void __launch_bounds__(BLOCK) k_flux_hor(DM m, int tr0) {
   if (nz >= nu12 && nz <= nl12) { use1 = true; use2 = true; }
   else if ((nz >= nu1 && nz <= nu12 - 1) || (nz >= nl12 + 1 && nz <= nl1)) { use1 = true; use2 = false; }
   else if (nu2 > 0 && ((nz >= nu2 && nz <= nu12 - 1) || (nz >= nl12 + 1 && nz <= nl2))) { use1 = false; use2 = true; }
-  else { DA2(t.flux_lo_hor, nz, ed) = 0.0; DA2(t.adv_flux_hor, nz, ed) = 0.0; return; }
+  else { DA2(t.flux_lo_hor, nz, ed) = 0.0; DA2(t.adv_flux_raw, nz, ed) = 0.0; return; }
   double vflux;
   if (use1 && use2)
     vflux = (-DV2(m.UV, 2, nz, e1) * dX1 + DV2(m.UV, 1, nz, e1) * dY1) * DA2(m.helem, nz, e1) +
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(BLOCK) k_flux_hor(DM m, int tr0) {
   double Tmean2 = s2 - (2.0 * (s2 - s1) + ex * a * DV4(t.edge_up_dn_grad, 2, nz, ed) + ey * D_REARTH * DV4(t.edge_up_dn_grad, 4, nz, ed)) / 6.0;
   double Tmean1 = s1 + (2.0 * (s2 - s1) + ex * a * DV4(t.edge_up_dn_grad, 1, nz, ed) + ey * D_REARTH * DV4(t.edge_up_dn_grad, 3, nz, ed)) / 6.0;
   double cHO = (vflux + av) * Tmean1 + (vflux - av) * Tmean2;
-  DA2(t.adv_flux_hor, nz, ed) = -0.5 * (1.0 - num_ord) * cHO - vflux * num_ord * (0.5 * (Tmean1 + Tmean2)) - lo;
+  DA2(t.adv_flux_raw, nz, ed) = -0.5 * (1.0 - num_ord) * cHO - vflux * num_ord * (0.5 * (Tmean1 + Tmean2)) - lo;
 }
 
 // low-order solution (src/oce_adv_tra_driver.F90:97-133) with adv_tra_ver_upw1 (src/oce_adv_tra_ver.F90:231-282)
@@ -186,45 +187,43 @@ __global__ void __launch_bounds__(BLOCK) k_fct_lo_node(DM m, int tr0) {
     DA2L(t.adv_flux_ver, nz, n) = adf;
   }
   double fv_dn = shdn(fv);
+  // low-order horizontal fluxes of the incident edges: lane-parallel edge list, one batch of loads, ordered sum
+  const int q0 = m.ne_ptr[n], deg = m.ne_ptr[n + 1] - q0;
+  int ed_l = 0, sg_l = 0;
+  unsigned rg_l = 1u;
+  if (l < deg) { ed_l = m.ne_idx[q0 + l]; sg_l = m.ne_sgn[q0 + l]; rg_l = m.ne_rng[q0 + l]; }
+  const int nzc = min(nz, m.nlm1);
+  double fl[GATHER_MAXD];
+#pragma unroll
+  for (int q = 0; q < GATHER_MAXD; q++) fl[q] = DA2(t.flux_lo_hor, nzc, rdlane(ed_l, q));
+  double lo = 0.0;
+#pragma unroll
+  for (int q = 0; q < GATHER_MAXD; q++) {
+    unsigned rg = (unsigned)rdlane((int)rg_l, q);
+    bool on = nz >= (int)(rg & 0xffu) && nz <= (int)((rg >> 8) & 0xffu);
+    double nlo = (rdlane(sg_l, q) > 0) ? lo + fl[q] : lo - fl[q];
+    lo = on ? nlo : lo;
+  }
+  for (int q = GATHER_MAXD; q < deg; q++) {                  // nodes with more incident edges than the batch (rare)
+    unsigned rg = m.ne_rng[q0 + q];
+    if (nz < (int)(rg & 0xffu) || nz > (int)((rg >> 8) & 0xffu)) continue;
+    double f = DA2(t.flux_lo_hor, nz, m.ne_idx[q0 + q]);
+    lo = (m.ne_sgn[q0 + q] > 0) ? lo + f : lo - f;
+  }
   if (nz >= nzmin && nz <= nzmax - 1) {
-    double lo = 0.0;
-    for (int q = m.ne_ptr[n]; q < m.ne_ptr[n + 1]; q++) {
-      int ed = m.ne_idx[q];
-      int e1 = m.edge_tri[2 * ed], e2 = m.edge_tri[2 * ed + 1];
-      int nl12 = m.nlev[e1] - 1, nu12 = m.ulev[e1];
-      if (e2 >= 0) { nl12 = max(nl12, m.nlev[e2] - 1); nu12 = min(nu12, m.ulev[e2]); }
-      if (nz < nu12 || nz > nl12) continue;
-      double f = DA2(t.flux_lo_hor, nz, ed);
-      lo = (m.ne_sgn[q] > 0) ? lo + f : lo - f;
-    }
     double ttf = DTR(m.tr_arr, nz, n, tr);
     lo = (ttf * DA2(m.hnode, nz, n) + (lo + (fv - fv_dn)) * dt / DA2L(m.areasvol, nz, n)) / DA2(m.hnode_new, nz, n);
-    DA2(t.fct_LO, nz, n) = lo;
-    DA2(t.fct_ttf_max, nz, n) = dmax_(lo, ttf);
-    DA2(t.fct_ttf_min, nz, n) = dmin_(lo, ttf);
+    DA2(t.fct_LO, nz, n) = lo;            // the nodal bounds max/min(LO, ttf) (oce_adv_tra_fct.F90:94-101) are formed by their consumer
   }
 }
 
-// element bounds (src/oce_adv_tra_fct.F90:108-121; the reference parks them in UV_rhs)
-__global__ void __launch_bounds__(BLOCK) k_fct_ebnd(DM m, int tr0) {
-  const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
-  const TV t = tracer_view(m, tr);
-  int e = col_id(), nz = lane_id() + 1;
-  if (e >= m.myE) return;
-  if (nz > m.nlm1) return;
-  int nl1 = m.nlev[e];
-  if (nz >= m.ulev[e] && nz <= nl1 - 1) {
-    int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
-    DV2(t.fct_ebnd, 1, nz, e) = dmax_(dmax_(DA2(t.fct_ttf_max, nz, n1), DA2(t.fct_ttf_max, nz, n2)), DA2(t.fct_ttf_max, nz, n3));
-    DV2(t.fct_ebnd, 2, nz, e) = dmin_(dmin_(DA2(t.fct_ttf_min, nz, n1), DA2(t.fct_ttf_min, nz, n2)), DA2(t.fct_ttf_min, nz, n3));
-  } else if (nz >= nl1) {
-    DV2(t.fct_ebnd, 1, nz, e) = -1e3;
-    DV2(t.fct_ebnd, 2, nz, e) = 1e3;
-  }
-}
-
-// cluster bounds, sums of positive/negative antidiffusive fluxes, limiting factors and the limiting of the
-// vertical antidiffusive flux (src/oce_adv_tra_fct.F90:127-311, vlimit=1)
+// nodal bounds max/min(LO, ttf) (src/oce_adv_tra_fct.F90:94-101), element bounds (:108-121, max/min over the 3 nodes;
+// the reference parks them in UV_rhs), cluster bounds, sums of positive/negative antidiffusive fluxes, limiting factors
+// and the limiting of the vertical antidiffusive flux (:127-311, vlimit=1).  max/min are exact and order-free, so the
+// bound "max over the elements around the node that are wet at this level of the max over their 3 nodes" is formed as
+// max over the node itself and the far-end nodes of its incident edges that are wet at this level (an edge is wet
+// where one of its triangles is): no element array, one launch less on the critical chain, the edge list is shared
+// with the flux sums, and fct_ttf_max/min can take their final value (bound - LO) without a race.
 __global__ void __launch_bounds__(BLOCK) k_fct_node(DM m, int tr0) {
   const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   const TV t = tracer_view(m, tr);
@@ -233,21 +232,63 @@ __global__ void __launch_bounds__(BLOCK) k_fct_node(DM m, int tr0) {
   const int nu1 = m.ulev_n[n], nl1 = m.nlev_n[n];
   const double dt = m.p.dt, flux_eps = 1e-16;
   const bool wet = (nz >= nu1 && nz <= nl1 - 1);
-  double tvmax = 0.0, tvmin = 0.0;
-  if (wet) {
-    int num = m.nie_num[n];
-    int e0 = m.nie[(size_t)m.maxk * n];
-    tvmax = DV2(t.fct_ebnd, 1, nz, e0); tvmin = DV2(t.fct_ebnd, 2, nz, e0);
-    for (int k = 1; k < num; k++) {
-      int e = m.nie[(size_t)m.maxk * n + k];
-      tvmax = dmax_(tvmax, DV2(t.fct_ebnd, 1, nz, e));
-      tvmin = dmin_(tvmin, DV2(t.fct_ebnd, 2, nz, e));
-    }
+  const int nzc = min(nz, m.nlm1);
+  // lane-parallel edge list of the node: edge, sign, level range, far-end node
+  const int q0 = m.ne_ptr[n], deg = m.ne_ptr[n + 1] - q0;
+  int ed_l = 0, sg_l = 0, fn_l = 0;
+  unsigned rg_l = 1u;
+  if (l < deg) {
+    ed_l = m.ne_idx[q0 + l]; sg_l = m.ne_sgn[q0 + l]; rg_l = m.ne_rng[q0 + l];
+    fn_l = (sg_l > 0) ? m.edges[2 * ed_l + 1] : m.edges[2 * ed_l];
+  }
+  const double *LOp = t.fct_LO, *Tp = m.tr_arr + (size_t)tr * m.N * m.nlm1;
+  // one batch of loads
+  double bx[GATHER_MAXD], bn[GATHER_MAXD], fh[GATHER_MAXD];
+#pragma unroll
+  for (int q = 0; q < GATHER_MAXD; q++) {
+    int k = rdlane(fn_l, q);
+    double lk = DA2(LOp, nzc, k), tk = DA2(Tp, nzc, k);
+    bx[q] = dmax_(lk, tk); bn[q] = dmin_(lk, tk);
+    fh[q] = DA2(t.adv_flux_raw, nzc, rdlane(ed_l, q));
+  }
+  double lo_own = DA2(LOp, nzc, n), t_own = DA2(Tp, nzc, n);
+  double tvmax = wet ? dmax_(lo_own, t_own) : -1e3, tvmin = wet ? dmin_(lo_own, t_own) : 1e3;   // dry: the reference's -1e3 / 1e3
+#pragma unroll
+  for (int q = 0; q < GATHER_MAXD; q++) {
+    unsigned rg = (unsigned)rdlane((int)rg_l, q);
+    bool on = nz >= (int)(rg & 0xffu) && nz <= (int)((rg >> 8) & 0xffu);     // q >= deg: empty range
+    tvmax = on ? dmax_(tvmax, bx[q]) : tvmax;
+    tvmin = on ? dmin_(tvmin, bn[q]) : tvmin;
+  }
+  for (int q = GATHER_MAXD; q < deg; q++) {                  // nodes with more incident edges than the batch (rare)
+    unsigned rg = m.ne_rng[q0 + q];
+    if (nz < (int)(rg & 0xffu) || nz > (int)((rg >> 8) & 0xffu)) continue;
+    int ed = m.ne_idx[q0 + q];
+    int k = (m.ne_sgn[q0 + q] > 0) ? m.edges[2 * ed + 1] : m.edges[2 * ed];
+    double lk = DA2(LOp, nzc, k), tk = DA2(Tp, nzc, k);
+    tvmax = dmax_(tvmax, dmax_(lk, tk)); tvmin = dmin_(tvmin, dmin_(lk, tk));
   }
   double mx_u = shup(tvmax), mx_d = shdn(tvmax), mn_u = shup(tvmin), mn_d = shdn(tvmin);
   double adv = (nz >= nu1 && nz <= nl1) ? DA2L(t.adv_flux_ver, nz, n) : 0.0;
   double adv_dn = shdn(adv);
-  double plus = 0.0, minus = 0.0;
+  double plus = 0.0 + (dmax_(0.0, adv) + dmax_(0.0, -adv_dn));
+  double minus = 0.0 + (dmin_(0.0, adv) + dmin_(0.0, -adv_dn));
+#pragma unroll
+  for (int q = 0; q < GATHER_MAXD; q++) {
+    unsigned rg = (unsigned)rdlane((int)rg_l, q);
+    bool on = nz >= (int)(rg & 0xffu) && nz <= (int)((rg >> 8) & 0xffu);
+    double f = (rdlane(sg_l, q) < 0) ? -fh[q] : fh[q];
+    double np = plus + dmax_(0.0, f), nm = minus + dmin_(0.0, f);
+    plus = on ? np : plus; minus = on ? nm : minus;
+  }
+  for (int q = GATHER_MAXD; q < deg; q++) {
+    unsigned rg = m.ne_rng[q0 + q];
+    if (nz < (int)(rg & 0xffu) || nz > (int)((rg >> 8) & 0xffu)) continue;
+    double f = DA2(t.adv_flux_raw, nz, m.ne_idx[q0 + q]);
+    if (m.ne_sgn[q0 + q] < 0) f = -f;
+    plus = plus + dmax_(0.0, f);
+    minus = minus + dmin_(0.0, f);
+  }
   if (wet) {
     double lo = DA2(t.fct_LO, nz, n);
     double bmax, bmin;
@@ -257,19 +298,6 @@ __global__ void __launch_bounds__(BLOCK) k_fct_node(DM m, int tr0) {
     } else { bmax = tvmax - lo; bmin = tvmin - lo; }
     DA2(t.fct_ttf_max, nz, n) = bmax;
     DA2(t.fct_ttf_min, nz, n) = bmin;
-    plus = 0.0 + (dmax_(0.0, adv) + dmax_(0.0, -adv_dn));
-    minus = 0.0 + (dmin_(0.0, adv) + dmin_(0.0, -adv_dn));
-    for (int q = m.ne_ptr[n]; q < m.ne_ptr[n + 1]; q++) {
-      int ed = m.ne_idx[q];
-      int e1 = m.edge_tri[2 * ed], e2 = m.edge_tri[2 * ed + 1];
-      int nl12 = m.nlev[e1] - 1, nu12 = m.ulev[e1];
-      if (e2 >= 0) { nl12 = max(nl12, m.nlev[e2] - 1); nu12 = min(nu12, m.ulev[e2]); }
-      if (nz < nu12 || nz > nl12) continue;
-      double f = DA2(t.adv_flux_hor, nz, ed);
-      if (m.ne_sgn[q] < 0) f = -f;
-      plus = plus + dmax_(0.0, f);
-      minus = minus + dmin_(0.0, f);
-    }
     double asv = DA2L(m.areasvol, nz, n);
     double flux = plus * dt / asv + flux_eps;
     plus = dmin_(1.0, bmax / flux);
@@ -277,7 +305,7 @@ __global__ void __launch_bounds__(BLOCK) k_fct_node(DM m, int tr0) {
     minus = dmin_(1.0, bmin / flux);
     DA2(t.fct_plus, nz, n) = plus;
     DA2(t.fct_minus, nz, n) = minus;
-  }
+  } else { plus = 0.0; minus = 0.0; }
   double plus_u = shup(plus), minus_u = shup(minus);
   if (wet) {
     double ae = 1.0;
@@ -291,7 +319,8 @@ __global__ void __launch_bounds__(BLOCK) k_fct_node(DM m, int tr0) {
   }
 }
 
-// limiting of the horizontal antidiffusive flux (src/oce_adv_tra_fct.F90:318-347)
+// limiting of the horizontal antidiffusive flux (src/oce_adv_tra_fct.F90:318-347): adv_flux_hor = ae * adv_flux_raw.
+// Off the critical chain: k_tr_update applies the same factors on the fly; this kernel only materialises the field.
 __global__ void __launch_bounds__(BLOCK) k_fct_edge_limit(DM m, int tr0) {
   const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   const TV t = tracer_view(m, tr);
@@ -301,7 +330,7 @@ __global__ void __launch_bounds__(BLOCK) k_fct_edge_limit(DM m, int tr0) {
   int nl12 = m.nlev[e1] - 1, nu12 = m.ulev[e1];
   if (e2 >= 0) { nl12 = max(nl12, m.nlev[e2] - 1); nu12 = min(nu12, m.ulev[e2]); }
   if (nz < nu12 || nz > nl12) return;
-  double ae = 1.0, flux = DA2(t.adv_flux_hor, nz, ed);
+  double ae = 1.0, flux = DA2(t.adv_flux_raw, nz, ed);
   if (flux >= 0.) { ae = dmin_(ae, DA2(t.fct_plus, nz, n1)); ae = dmin_(ae, DA2(t.fct_minus, nz, n2)); }
   else { ae = dmin_(ae, DA2(t.fct_minus, nz, n1)); ae = dmin_(ae, DA2(t.fct_plus, nz, n2)); }
   DA2(t.adv_flux_hor, nz, ed) = ae * flux;
@@ -348,7 +377,7 @@ __global__ void __launch_bounds__(BLOCK) k_diff_flux(DM m, int tr0) {
 // implicit vertical diffusion (diff_ver_part_impl_ale :398-856) with its in-block Thomas sweep, salinity clamp (:176-198).
 // The kernel is latency-bound, not bandwidth-bound: the edge list of the node is read lane-parallel (lane q = q-th
 // incident edge), broadcast with v_readlane, and all edge values are fetched in one batch before the ordered sums.
-#define TRU_MAXD 12
+#define TRU_MAXD 10                     // batch of this kernel (4 loads per edge): keeps it at <= 128 VGPRs, 2 blocks per CU
 __global__ void __launch_bounds__(TH_BLOCK) k_tr_update(DM m, int tr0) {
   const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   extern __shared__ double th_sh[];
@@ -360,16 +389,26 @@ __global__ void __launch_bounds__(TH_BLOCK) k_tr_update(DM m, int tr0) {
   const double dt = m.p.dt;
   const bool wet = valid && (nz >= nzmin && nz <= nzmax - 1);
   const int q0 = m.ne_ptr[n], deg = m.ne_ptr[n + 1] - q0;
-  int ed_l = 0, sg_l = 0;
+  int ed_l = 0, sg_l = 0, fn_l = 0;
   unsigned rg_l = 1u;                                       // lo = 1, hi = 0: empty range
-  if (l < deg) { ed_l = m.ne_idx[q0 + l]; sg_l = m.ne_sgn[q0 + l]; rg_l = m.ne_rng[q0 + l]; }
+  if (l < deg) {
+    ed_l = m.ne_idx[q0 + l]; sg_l = m.ne_sgn[q0 + l]; rg_l = m.ne_rng[q0 + l];
+    fn_l = (sg_l > 0) ? m.edges[2 * ed_l + 1] : m.edges[2 * ed_l];       // far-end node of the edge
+  }
   const int nzc = min(nz, m.nlm1);
   const bool dif = m.p.with_diffusion != 0;
+  const double p_own = DA2(t.fct_plus, nzc, n), m_own = DA2(t.fct_minus, nzc, n);
   double fa[TRU_MAXD], fd[TRU_MAXD];
 #pragma unroll
-  for (int q = 0; q < TRU_MAXD; q++) {                      // one batch of independent loads
-    int ed = rdlane(ed_l, q);
-    fa[q] = DA2(t.adv_flux_hor, nzc, ed);
+  for (int q = 0; q < TRU_MAXD; q++) {                   // one batch of independent loads
+    int ed = rdlane(ed_l, q), k = rdlane(fn_l, q);
+    const bool first = rdlane(sg_l, q) > 0;                 // this node is edges(1,ed)
+    // limited antidiffusive flux ae * flux with the factors of oce_adv_tra_fct.F90:318-347 applied on the fly:
+    // flux >= 0: min(1, plus(n1), minus(n2)); flux < 0: min(1, minus(n1), plus(n2))
+    double fr = DA2(t.adv_flux_raw, nzc, ed), p_far = DA2(t.fct_plus, nzc, k), m_far = DA2(t.fct_minus, nzc, k);
+    double p1 = first ? p_own : p_far, m1 = first ? m_own : m_far, p2 = first ? p_far : p_own, m2 = first ? m_far : m_own;
+    double ae = dmin_(dmin_(1.0, (fr >= 0.) ? p1 : m1), (fr >= 0.) ? m2 : p2);
+    fa[q] = ae * fr;
     fd[q] = dif ? DA2(t.diff_flux, nzc, ed) : 0.0;
   }
   double adv = (nz >= nzmin && nz <= nzmax) ? DA2L(t.adv_flux_ver, nz, n) : 0.0;
@@ -394,7 +433,10 @@ __global__ void __launch_bounds__(TH_BLOCK) k_tr_update(DM m, int tr0) {
     int ed = m.ne_idx[q0 + q];
     unsigned rg = m.ne_rng[q0 + q];
     if (nz < (int)(rg & 0xffu) || nz > (int)((rg >> 8) & 0xffu)) continue;
-    double f = DA2(t.adv_flux_hor, nz, ed) * dt / asv;
+    int n1 = m.edges[2 * ed], n2 = m.edges[2 * ed + 1];
+    double fr = DA2(t.adv_flux_raw, nz, ed);
+    double ae = dmin_(dmin_(1.0, (fr >= 0.) ? DA2(t.fct_plus, nz, n1) : DA2(t.fct_minus, nz, n1)), (fr >= 0.) ? DA2(t.fct_minus, nz, n2) : DA2(t.fct_plus, nz, n2));
+    double f = (ae * fr) * dt / asv;
     dh = (m.ne_sgn[q0 + q] > 0) ? dh + f : dh - f;
   }
   del = 0.0 + dh + dv;
@@ -488,7 +530,6 @@ void launch_tracer(const DM &m, hipStream_t s, int tr) {   // tr 0-based
   LAUNCH_COL(k_updn_grad, m.myD, m, tr);
   LAUNCH_COL(k_flux_hor, m.myD, m, tr);
   LAUNCH_COL(k_fct_lo_node, m.myN, m, tr);
-  LAUNCH_COL(k_fct_ebnd, m.myE, m, tr);
   LAUNCH_COL(k_fct_node, m.myN, m, tr);
   LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr);
   if (m.p.with_diffusion) LAUNCH_COL(k_diff_flux, m.myD, m, tr);
@@ -504,7 +545,6 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
     if (!strcmp(name, "k_updn_grad")) { LAUNCH_COL(k_updn_grad, m.myD, m, tr); return 0; }
     if (!strcmp(name, "k_flux_hor")) { LAUNCH_COL(k_flux_hor, m.myD, m, tr); return 0; }
     if (!strcmp(name, "k_fct_lo_node")) { LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); return 0; }
-    if (!strcmp(name, "k_fct_ebnd")) { LAUNCH_COL(k_fct_ebnd, m.myE, m, tr); return 0; }
     if (!strcmp(name, "k_fct_node")) { LAUNCH_COL(k_fct_node, m.myN, m, tr); return 0; }
     if (!strcmp(name, "k_fct_edge_limit")) { LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr); return 0; }
     if (!strcmp(name, "k_diff_flux")) { LAUNCH_COL(k_diff_flux, m.myD, m, tr); return 0; }
@@ -516,7 +556,7 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
     LAUNCH_COL(k_updn_grad, m.myD, m, tr); return 0;
   }
   if (!strcmp(name, "adv_tracers_ale")) {
-    LAUNCH_COL(k_flux_hor, m.myD, m, tr); LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); LAUNCH_COL(k_fct_ebnd, m.myE, m, tr);
+    LAUNCH_COL(k_flux_hor, m.myD, m, tr); LAUNCH_COL(k_fct_lo_node, m.myN, m, tr);
     LAUNCH_COL(k_fct_node, m.myN, m, tr); LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr); return 0;
   }
   if (!strcmp(name, "diff_tracers_ale")) {                                                    // incl. flux2dtracer + clamp
