@@ -75,13 +75,18 @@ std::vector<int> minus1(const int *a, size_t n) {
   return v;
 }
 
-void enqueue_step(hipStream_t s, int first_step) {
+// `n` = step number (mstep of the reference); only the Soufflet toy hooks look at it (zonal means every 10th step)
+void enqueue_step(hipStream_t s, int first_step, int n) {
   const DM &m = G.m;
+  const bool toy = m.p.toy_soufflet != 0;
+  if (toy && n % 10 == 0) launch_named_toy(m, s, "compute_zonal_mean");    // before_oce_step (oce_setup_step.F90:625-630)
   launch_dynamics_pre(m, s, first_step);     // compute_vel_nodes .. impl_vert_visc_ale
   launch_ssh_rhs(m, s);                      // update_stiff_mat_ale, compute_ssh_rhs_ale
   launch_solver(m, s);                       // solve_ssh_ale
+  if (toy) launch_named_toy(m, s, "relax_zonal_vel");                      // oce_ale.F90:2696
   launch_dynamics_post(m, s);                // update_vel, compute_hbar_ale, eta_n, vert_vel_ale
-  launch_tracer(m, s, -1);                                       // solve_tracers_ale, all tracers per launch
+  launch_tracer(m, s, -1);                   // solve_tracers_ale, all tracers per launch
+  if (toy) for (int tr = 0; tr < m.ntr; tr++) launch_named_toy(m, s, "relax_zonal_temp");   // once per tracer, oce_ale_tracer.F90:150
   launch_thickness(m, s);                    // update_thickness_ale
 }
 
@@ -104,11 +109,13 @@ int K(hipStream_t s, const char *k, int arg = 0, int fs = 0) {
   if (rc < 0) rc = launch_named_tra(G.m, s, k, arg);
   return rc;
 }
-void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d) {
+void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   // The critical chain stays on s0 (momentum -> SSH solve -> W -> tracer advection/diffusion -> thickness); side streams
   // carry what only has to be READY by then.  All tracers go through the same launches (grid.y = tracer).
   const DM &m = G.m;
   hipStream_t s1 = G.side[0], s2 = G.side[1], s3 = G.side[2];
+  const bool toy = m.p.toy_soufflet != 0;
+  if (toy && n % 10 == 0) launch_named_toy(m, s0, "compute_zonal_mean");   // before_oce_step (oce_setup_step.F90:625-630)
   d.dep(s1, s0); d.dep(s2, s0); d.dep(s3, s0);
   // s1: pressure -> PGF -> velocity rhs ; SSH operator update + row scales ; later dhe
   K(s1, "k_pressure_bv");
@@ -138,6 +145,7 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d) {
   K(s0, "k_edge_transport");
   hipStreamWaitEvent(s0, ev_op, 0);
   launch_solver(m, s0, 1, 1);                      // set-up gathers ssh_rhs (k_ssh_rhs_node fused); row scales from s1
+  if (toy) launch_named_toy(m, s0, "relax_zonal_vel");                     // oce_ale.F90:2696
   K(s0, "k_update_vel"); K(s0, "k_edge_transport1");
   K(s0, "k_vert_vel_hbar");                        // k_hbar_node fused
   hipEvent_t ev_w = d.ev(); hipEventRecord(ev_w, s0);
@@ -150,6 +158,7 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d) {
   hipStreamWaitEvent(s1, ev_fct, 0);
   K(s1, "k_fct_edge_limit", 0);                    // materialises the limited flux field; k_tr_update limits on the fly
   K(s0, "k_tr_update", 0);                         // incl. the Thomas sweep
+  if (toy) for (int tr = 0; tr < m.ntr; tr++) launch_named_toy(m, s0, "relax_zonal_temp");   // once per tracer
   d.dep(s0, s1); d.dep(s0, s2); d.dep(s0, s3);
   launch_thickness(m, s0);
 }
@@ -158,7 +167,7 @@ int build_graph(int which) {
   hipGraph_t g;
   Dag d;                                            // events must outlive the capture
   HIPCHK(hipStreamBeginCapture(G.stream, hipStreamCaptureModeGlobal));
-  if (G.serial) enqueue_step(G.stream, which); else enqueue_step_dag(G.stream, which, d);
+  if (G.serial) enqueue_step(G.stream, which, 1); else enqueue_step_dag(G.stream, which, d, 1);
   HIPCHK(hipStreamEndCapture(G.stream, &g));
   HIPCHK(hipGraphInstantiate(&G.graph[which], g, nullptr, nullptr, 0));
   hipGraphDestroy(g);
@@ -318,6 +327,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   F(pgf_x, n1 * E); F(pgf_y, n1 * E); F(helem, n1 * E); F(Av, nl * E); F(dhe, E); F(stress_surf, 2 * E);
   FT(adv_flux_hor, n1 * D); FT(adv_flux_raw, n1 * D); FT(flux_lo_hor, n1 * D); FT(diff_flux, n1 * D); FT(edge_up_dn_grad, 4 * n1 * D); F(edge_c12, D);
   F(ssh_values, m.nza);
+  if (par->toy_soufflet) { F(Tclim, n1 * N); F(Uclim, n1 * E); F(toy_zvel, n1 * 100); F(toy_ztem, n1 * 100); }
   F(sv_vals, 16 * (N + 64)); F(sv_dinv, N + 64); F(sv_b, N + 64); F(sv_r, N + 64); F(sv_r0, N + 64); F(sv_p, N + 64); F(sv_v, N + 64); F(sv_s, N + 64); F(sv_t, N + 64);
   F(sv_ph, N + 64); F(sv_x0, 16 * (N + 64)); F(sv_snap, N);
   F(sv_resid, 1); F(sv_h1, N); F(sv_h2, N); F(sv_h3, N); F(sv_scale, N + 64);
@@ -325,6 +335,34 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
 #undef F
 #undef FT
   m.sv_info = dev_alloc<int>(4);
+  if (par->toy_soufflet) {
+    // static tables of the Soufflet hooks: compute_zonal_mean_ini (toy_channel_soufflet.F90:104-155) and the interpolation
+    // headers of relax_zonal_vel / relax_zonal_temp (:57-70, :89-100); module constants :19-23
+    const double lat0 = 0.0, ysize = 2000000.0;
+    const double Ly = ysize / D_REARTH, dy = Ly / 100.0;
+    auto interp = [&](double yy, int &nn, int &nn1, double &a) {
+      a = 0;
+      if (yy < dy / 2) { nn = 1; nn1 = 1; }
+      else { nn = (int)floor(yy / dy - 0.5) + 1; nn1 = nn + 1; if (nn1 > 100) nn1 = nn; a = yy / dy + 0.5 - (double)nn; }
+    };
+    std::vector<int> bpos(m.myE), enn(2 * (size_t)m.myE), nnn(2 * N), bptr(101, 0), bidx;
+    std::vector<double> ea(m.myE), na(N), znum(100, 0.0);
+    const double *cn = d->coord_nod2D;
+    for (int e = 0; e < m.myE; e++) {
+      double ymean = ((cn[2 * en[3 * e] + 1] + cn[2 * en[3 * e + 1] + 1]) + cn[2 * en[3 * e + 2] + 1]) / 3.0;
+      bpos[e] = (int)floor((ymean - lat0) / dy) + 1;
+      if (bpos[e] < 1 || bpos[e] > 100) { G.err = "toy_soufflet: element outside the 100 latitude bins of the channel"; return 1; }
+      interp(ymean - lat0, enn[2 * e], enn[2 * e + 1], ea[e]);
+      if (en[3 * e] < m.myN) { bptr[bpos[e]]++; znum[bpos[e] - 1] += 1.0; }        // each element once: first node owned
+    }
+    for (int b = 0; b < 100; b++) bptr[b + 1] += bptr[b];
+    bidx.resize(bptr[100]);
+    { std::vector<int> fill(bptr.begin(), bptr.end() - 1);
+      for (int e = 0; e < m.myE; e++) if (en[3 * e] < m.myN) bidx[fill[bpos[e] - 1]++] = e; }
+    for (size_t n = 0; n < N; n++) interp(cn[2 * n + 1] - lat0, nnn[2 * n], nnn[2 * n + 1], na[n]);
+    m.toy_bptr = dev_upload(bptr); m.toy_bidx = dev_upload(bidx); m.toy_e_nn = dev_upload(enn); m.toy_n_nn = dev_upload(nnn);
+    m.toy_e_a = dev_upload(ea); m.toy_n_a = dev_upload(na); m.toy_znum = dev_upload(znum);
+  }
   for (auto &kv : G.fields) if (!kv.second.p) { G.err = "device allocation failed"; return 1; }
   HIPCHK(hipMemcpy(m.ssh_values, d->ssh_values, sizeof(double) * m.nza, hipMemcpyHostToDevice));
   {   // Ki = K_hor*(mesh_resolution/100000)**2 (oce_setup_step.F90:328-331); Av/Kv constant when no mixing scheme is selected
@@ -399,7 +437,7 @@ static int call_named(const char *name, int arg) {
   const DM &m = G.m;
   if (!strcmp(name, "first_step")) { G.first_step = arg; return 0; }
   if (!strcmp(name, "solve_ssh") || !strcmp(name, "k_solver")) return launch_solver(m, G.stream);
-  if (!strcmp(name, "step")) { enqueue_step(G.stream, G.first_step); G.first_step = 0; return 0; }
+  if (!strcmp(name, "step")) { enqueue_step(G.stream, G.first_step, arg); G.first_step = 0; return 0; }
   if (!strcmp(name, "solver_snapshot")) {       // keep the pre-solve iterate so that the solve can be replayed for timing
     return hipMemcpyAsync(m.sv_snap, m.d_eta, sizeof(double) * m.N, hipMemcpyDeviceToDevice, G.stream) != hipSuccess;
   }
@@ -415,6 +453,8 @@ static int call_named(const char *name, int arg) {
   if (rc == 0) { if (!strcmp(name, "compute_vel_rhs")) G.first_step = 0; return 0; }
   rc = launch_named_tra(m, G.stream, name, arg);
   if (rc == 0) return 0;
+  rc = launch_named_toy(m, G.stream, name);
+  if (rc == 0) return 0;
   G.err = std::string("fesom_gpu_call: unknown routine ") + name;
   return 1;
 }
@@ -428,19 +468,19 @@ int fesom_gpu_call(const char *routine, int arg) {
 
 int fesom_gpu_run_steps(int n_first, int nsteps) {
   NEED_READY();
-  (void)n_first;
   static const bool timing = getenv("FESOM_GPU_TIMING") != nullptr;
   auto t0 = std::chrono::steady_clock::now();
   for (int k = 0; k < nsteps; k++) {
     int which = G.first_step ? 1 : 0;
-    if (G.use_graph) {
+    const int n = n_first + k;
+    if (G.use_graph && !G.m.p.toy_soufflet) {          // (the toy hooks depend on the step number: no fixed graph)
       if (!G.graph[which] && build_graph(which)) return 1;
       HIPCHK(hipGraphLaunch(G.graph[which], G.stream));
     } else if (!G.serial) {
       static Dag dag;                                   // pooled events
       dag.reset();
-      enqueue_step_dag(G.stream, which, dag);
-    } else enqueue_step(G.stream, which);
+      enqueue_step_dag(G.stream, which, dag, n);
+    } else enqueue_step(G.stream, which, n);
     G.first_step = 0;
   }
   if (timing) {

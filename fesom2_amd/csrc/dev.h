@@ -48,6 +48,10 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   double *pgf_x, *pgf_y, *helem, *Av, *dhe, *stress_surf;
   double *adv_flux_hor, *adv_flux_raw, *flux_lo_hor, *edge_up_dn_grad, *edge_c12, *diff_flux;
   double *ssh_values;
+  // Soufflet toy channel (kernels_toy.hip): relaxation targets, zonal means per (level, latitude bin), static bin tables
+  double *Tclim, *Uclim, *toy_zvel, *toy_ztem;
+  const double *toy_znum, *toy_e_a, *toy_n_a;
+  const int *toy_bptr, *toy_bidx, *toy_e_nn, *toy_n_nn;
   // solver workspace
   double *sv_vals, *sv_dinv, *sv_b, *sv_r, *sv_r0, *sv_p, *sv_v, *sv_s, *sv_t, *sv_ph, *sv_x0, *sv_snap;
   int *sv_info; double *sv_resid;   // sv_info[0] iterations of the last solve, [1] number of stored previous solutions
@@ -203,3 +207,4 @@ void launch_row_scale(const DM &m, hipStream_t s);
 void launch_dynamics_post(const DM &m, hipStream_t s);
 void launch_tracer(const DM &m, hipStream_t s, int tr);
 void launch_thickness(const DM &m, hipStream_t s);
+int  launch_named_toy(const DM &m, hipStream_t s, const char *name);

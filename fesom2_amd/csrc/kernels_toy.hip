@@ -1,0 +1,58 @@
+// Soufflet channel hooks of the reference's toy set-up (src/toy_channel_soufflet.F90), gfx950.  They sit on the step path
+// when toy_ocean / which_toy='soufflet' (the reference's CI known-answer case setups/test_souf):
+//   compute_zonal_mean   before_oce_step every 10 steps (forcing-update period of the toy module) (oce_setup_step.F90:625-630)
+//   relax_zonal_vel      after solve_ssh_ale (oce_ale.F90:2696)
+//   relax_zonal_temp     after diff_tracers_ale of EVERY tracer of the loop, always on tracer 1 (oce_ale_tracer.F90:150-151)
+// The element -> latitude-bin map, the per-bin element counts and the interpolation weights are static and prepared on the
+// host at fesom_gpu_init (compute_zonal_mean_ini :104-155 and the interpolation headers of :57-70, :89-100).
+#include "dev.h"
+#include <string.h>
+
+// compute_zonal_mean (:157-217): one wavefront per latitude bin, lane = level; the elements of the bin are summed in
+// element order (the reference's loop order on one partition), then divided by (count + 0.001).
+__global__ void __launch_bounds__(BLOCK) k_toy_zonal_mean(DM m) {
+  int b = col_id(), nz = lane_id() + 1;
+  if (b >= 100 || nz > m.nlm1) return;
+  double zt = 0.0, zv = 0.0;
+  for (int q = m.toy_bptr[b]; q < m.toy_bptr[b + 1]; q++) {
+    int e = m.toy_bidx[q];
+    if (nz > m.nlev[e] - 1) continue;
+    int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
+    zt = zt + ((DTR(m.tr_arr, nz, n1, 0) + DTR(m.tr_arr, nz, n2, 0)) + DTR(m.tr_arr, nz, n3, 0)) / 3.0;
+    zv = zv + DV2(m.UV, 1, nz, e);
+  }
+  double cnt = m.toy_znum[b];
+  m.toy_zvel[(size_t)b * m.nlm1 + nz - 1] = zv / (cnt + 0.001);
+  m.toy_ztem[(size_t)b * m.nlm1 + nz - 1] = zt / (cnt + 0.001);
+}
+
+// relax_zonal_vel (:46-79)
+__global__ void __launch_bounds__(BLOCK) k_toy_relax_vel(DM m) {
+  int e = col_id(), nz = lane_id() + 1;
+  if (e >= m.myE || nz > m.nlev[e] - 1) return;
+  const double tau_inv = 1.0 / 50.0 / 24.0 / 3600.0;
+  int nn = m.toy_e_nn[2 * e], nn1 = m.toy_e_nn[2 * e + 1];
+  double a = m.toy_e_a[e];
+  double Uzon = (1.0 - a) * m.toy_zvel[(size_t)(nn - 1) * m.nlm1 + nz - 1] + a * m.toy_zvel[(size_t)(nn1 - 1) * m.nlm1 + nz - 1];
+  DV2(m.UV_rhs, 1, nz, e) = DV2(m.UV_rhs, 1, nz, e) + m.p.dt * tau_inv * (DA2(m.Uclim, nz, e) - Uzon);
+}
+
+// relax_zonal_temp (:81-103), owned + halo nodes
+__global__ void __launch_bounds__(BLOCK) k_toy_relax_temp(DM m) {
+  int n = col_id(), nz = lane_id() + 1;
+  if (n >= m.N || nz > m.nlev_n[n] - 1) return;
+  const double tau_inv = 1.0 / 50.0 / 24.0 / 3600.0;
+  int nn = m.toy_n_nn[2 * n], nn1 = m.toy_n_nn[2 * n + 1];
+  double a = m.toy_n_a[n];
+  double Tzon = (1.0 - a) * m.toy_ztem[(size_t)(nn - 1) * m.nlm1 + nz - 1] + a * m.toy_ztem[(size_t)(nn1 - 1) * m.nlm1 + nz - 1];
+  DTR(m.tr_arr, nz, n, 0) = DTR(m.tr_arr, nz, n, 0) + m.p.dt * tau_inv * (DA2(m.Tclim, nz, n) - Tzon);
+}
+
+#define LAUNCH_COL(k, ncol, ...) hipLaunchKernelGGL(k, dim3(nblocks(ncol)), dim3(BLOCK), 0, s, __VA_ARGS__)
+int launch_named_toy(const DM &m, hipStream_t s, const char *name) {
+  if (!m.p.toy_soufflet) return -1;
+  if (!strcmp(name, "compute_zonal_mean") || !strcmp(name, "k_toy_zonal_mean")) { LAUNCH_COL(k_toy_zonal_mean, 100, m); return 0; }
+  if (!strcmp(name, "relax_zonal_vel") || !strcmp(name, "k_toy_relax_vel")) { LAUNCH_COL(k_toy_relax_vel, m.myE, m); return 0; }
+  if (!strcmp(name, "relax_zonal_temp") || !strcmp(name, "k_toy_relax_temp")) { LAUNCH_COL(k_toy_relax_temp, m.N, m); return 0; }
+  return -1;
+}

@@ -37,6 +37,9 @@ typedef struct {
   /* edge */
   double *adv_flux_hor;                          /* (nl-1,D) */
   double *edge_up_dn_grad;                       /* (4,nl-1,D) */
+  /* Soufflet toy channel (orc_toy.c) */
+  double *Uclim, *toy_zvel, *toy_ztem, *toy_znum;  /* (nl-1,E), (nl-1,100) x3 */
+  int *toy_bpos, *toy_owner, toy_nranks;
   /* ssh operator + solver */
   double *ssh_values;
   double *sv_h1, *sv_h2, *sv_h3; int sv_nhist;      /* previous SSH solutions for the extrapolated initial guess */
@@ -102,5 +105,10 @@ void orc_adv_tracers_ale(int tr);
 void orc_diff_tracers_ale(int tr);
 void orc_salinity_clamp(void);
 void orc_update_thickness_ale(void);
+void orc_compute_zonal_mean_ini(void);
+void orc_compute_zonal_mean(void);
+void orc_relax_zonal_vel(void);
+void orc_relax_zonal_temp(void);
+void orc_toy_set_partition(const int *owner, int nranks);
 void orc_step(int n);
 #endif

@@ -19,6 +19,7 @@ static void reg(const char *name, double **p, size_t cnt) {
 int orc_init(const fesom_mesh_desc *m, const fesom_params *p) {
   for (int i = 0; i < nF_; i++) free(*F_[i].p);
   nF_ = 0;
+  free(C_.toy_bpos); free(C_.toy_owner);
   memset(&C_, 0, sizeof(C_));
   C_.m = *m; C_.p = *p;
   C_.N = m->myDim_nod2D + m->eDim_nod2D; C_.E = m->myDim_elem2D + m->eDim_elem2D; C_.D = m->myDim_edge2D + m->eDim_edge2D;
@@ -39,8 +40,10 @@ int orc_init(const fesom_mesh_desc *m, const fesom_params *p) {
   R(UV, 2 * n1 * E); R(UV_rhs, 2 * n1 * E); R(UV_rhsAB, 2 * n1 * E); R(tr_xy, 2 * n1 * E); R(U_b, 2 * n1 * E); R(fct_ebnd, 2 * n1 * E);
   R(pgf_x, n1 * E); R(pgf_y, n1 * E); R(helem, n1 * E); R(Av, nl * E); R(dhe, E); R(stress_surf, 2 * E);
   R(adv_flux_hor, n1 * D); R(edge_up_dn_grad, 4 * n1 * D);
+  R(Uclim, n1 * E); R(toy_zvel, n1 * 100); R(toy_ztem, n1 * 100); R(toy_znum, n1 * 100);
   R(ssh_values, m->ssh_nza); R(sv_h1, N); R(sv_h2, N); R(sv_h3, N);
 #undef R
+  C_.toy_bpos = calloc(E ? E : 1, sizeof(int));
   for (size_t i = 0; i < n1 * N; i++) C_.density_ref[i] = DENSITY_0;
   memcpy(C_.ssh_values, m->ssh_values, sizeof(double) * m->ssh_nza);
   /* Ki = K_hor*(mesh_resolution/100000)**2  (oce_setup_step.F90:328-331) */
@@ -162,8 +165,8 @@ void orc_solve_ssh(void) {
 
 /* oce_timestep_ale sequence for the supported options: src/oce_ale.F90:2556-2767 (+ fvom_main.F90:216) */
 void orc_step(int n) {
-  (void)n;
   orc_compute_vel_nodes();
+  if (C_.p.toy_soufflet && n % 10 == 0) orc_compute_zonal_mean();      /* before_oce_step, oce_setup_step.F90:625-630 */
   orc_pressure_bv();
   orc_pressure_force();
   orc_sw_alpha_beta();
@@ -176,6 +179,7 @@ void orc_step(int n) {
   if (C_.p.which_ale != 0) orc_update_stiff_mat_ale();
   orc_compute_ssh_rhs_ale();
   orc_solve_ssh();
+  if (C_.p.toy_soufflet) orc_relax_zonal_vel();                          /* oce_ale.F90:2696 */
   orc_update_vel();
   orc_compute_hbar_ale();
   orc_eta_update();
@@ -184,6 +188,7 @@ void orc_step(int n) {
     orc_init_tracers_AB(tr);
     orc_adv_tracers_ale(tr);
     orc_diff_tracers_ale(tr);
+    if (C_.p.toy_soufflet) orc_relax_zonal_temp();                       /* oce_ale_tracer.F90:150-151, once per tracer */
   }
   orc_salinity_clamp();
   orc_update_thickness_ale();
@@ -197,6 +202,7 @@ int orc_call(const char *name, int arg) {
   CALL0(impl_vert_visc_ale) CALL0(update_stiff_mat_ale) CALL0(compute_ssh_rhs_ale) CALL0(solve_ssh) CALL0(update_vel)
   CALL0(compute_hbar_ale) CALL0(eta_update) CALL0(vert_vel_ale) CALL1(init_tracers_AB) CALL1(adv_tracers_ale)
   CALL1(diff_tracers_ale) CALL0(salinity_clamp) CALL0(update_thickness_ale) CALL1(step)
+  CALL0(compute_zonal_mean_ini) CALL0(compute_zonal_mean) CALL0(relax_zonal_vel) CALL0(relax_zonal_temp)
   fprintf(stderr, "orc_call: unknown routine %s\n", name);
   return 1;
 }

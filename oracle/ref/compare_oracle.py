@@ -92,6 +92,22 @@ def main():
     for k in ("tr_arr", "tr_arr_old", "UV"):
         st.a[k][...] = assemble(setups, setups, k)
     orc.set_state(st)
+    toy = c["toy_ocean"] == ".true."
+    if toy:
+        # Soufflet channel: Coriolis is redefined by initial_state_soufflet, Tclim/Uclim are the relaxation targets
+        # (Uclim is private to the reference's toy module; it is the initial UV(1,:,:), toy_channel_soufflet.F90:327-328);
+        # zonal sums are formed per rank and added in rank order like MPI_Allreduce does
+        import ctypes as C
+        mesh.coriolis[...] = assemble(setups, setups, "coriolis")
+        orc.set("Tclim", assemble(setups, setups, "Tclim"))
+        orc.set("Uclim", np.ascontiguousarray(st.a["UV"][:, :, 0]))
+        rank_of_node = np.zeros(mesh.nod2D, dtype=np.int32)
+        for r, s_ in enumerate(setups):
+            myN = int(s_["dims"][5])
+            rank_of_node[s_["myList_nod2D"][:myN] - 1] = r
+        owner = np.ascontiguousarray(rank_of_node[mesh.elem2D_nodes[:, 0] - 1], dtype=np.int32)
+        orc.lib.orc_toy_set_partition(owner.ctypes.data_as(C.POINTER(C.c_int)), np_)
+        orc.call("compute_zonal_mean_ini"); orc.call("compute_zonal_mean")
     allok = True
     nlm1 = mesh.nl - 1
     lev = np.arange(nlm1)[None, :]
@@ -110,6 +126,8 @@ def main():
         # inputs check
         for f in ("tr_arr", "UV", "eta_n", "hnode", "helem", "Wvel_e", "zbar_3d_n", "Z_3d_n", "ssh_rhs_old"):
             chk("in", f, "in." + f)
+        if toy and step % 10 == 0:
+            orc.call("compute_zonal_mean")               # before_oce_step
         orc.call("compute_vel_nodes"); chk("compute_vel_nodes", "Unode", "compute_vel_nodes.Unode", np.repeat(wet_n[:, :, None], 2, 2))
         orc.call("pressure_bv")
         chk("pressure_bv", "density_m_rho0", "pressure_bv.density_m_rho0", wet_n)
@@ -141,6 +159,8 @@ def main():
         mine, ref = orc.get("d_eta"), g("solve_ssh_ale.d_eta")
         print(f"  solve_ssh: iterations={orc.solver_iterations} resid={orc.solver_residual:.3e} max|d_eta-ref|={np.abs(mine-ref).max():.3e} max|ref|={np.abs(ref).max():.3e}")
         orc.set("d_eta", ref)
+        if toy:
+            orc.call("relax_zonal_vel"); chk("relax_zonal_vel", "UV_rhs", "relax_zonal_vel.UV_rhs", we2)
         orc.call("update_vel"); chk("update_vel", "UV", "update_vel.UV", we2); chk("update_vel", "eta_n", "update_vel.eta_n")
         orc.call("compute_hbar_ale")
         for f in ("hbar", "hbar_old", "ssh_rhs_old", "dhe"):
@@ -166,6 +186,8 @@ def main():
             chk(f"adv{tr}", "del_ttf", p + "adv.del_ttf", wet_n)
             orc.call("diff_tracers_ale", tr)
             chk(f"diff{tr}", "del_ttf", p + "diff.del_ttf", wet_n)
+            if toy:
+                orc.call("relax_zonal_temp")              # after every tracer, always on tracer 1
             allok &= report(f"diff{tr}:tr_arr", orc.get("tr_arr").reshape(2, -1, nlm1)[tr - 1], g(p + "end.tr_arr"), wet_n)
         orc.call("salinity_clamp")
         orc.call("update_thickness_ale")

@@ -249,6 +249,7 @@ contains
   subroutine dump_state()
     call dump('tr_arr', tr_arr)
     call dump('tr_arr_old', tr_arr_old)
+    if (allocated(Tclim)) call dump('Tclim', Tclim)
     call dump('UV', UV)
     call dump('UV_rhs', UV_rhs)
     call dump('UV_rhsAB', UV_rhsAB)

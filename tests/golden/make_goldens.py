@@ -2,7 +2,7 @@
 """Generate the committed golden fixtures from the REAL reference (oracle/_ref/fesom_oracle.x, built from the
 sources under /root/reference by oracle/ref/build_ref.sh).  Runs only in the build container.
 
-Output: tests/golden/pi_pp_reference.npz
+Output: tests/golden/pi_pp_reference.npz and tests/golden/souf_reference.npz (Soufflet channel = the reference's CI case)
   - the reference runs the pi mesh (config pi_pp: zstar, partial cells, JM EOS, PP mixing, MFCT/QR4C/FCT, no GM/Redi)
     on 2 MPI ranks in replay mode for NSTEPS steps from the analytic initial state of fesom2_amd/synthetic.py;
   - every field each routine writes is reassembled to global numbering (owned parts) and stored as a DIGEST:
@@ -34,14 +34,14 @@ def digest(a):
     return np.concatenate([stats, a[::stride]])
 
 
-def main():
-    rd, rc, lines = run_ref.run("pi_pp", NP, NSTEPS, mode="replay", dump=tuple(range(1, NSTEPS + 1)))
+def make(cfg, outname):
+    rd, rc, lines = run_ref.run(cfg, NP, NSTEPS, mode="replay", dump=tuple(range(1, NSTEPS + 1)))
     assert rc == 0
     setups = [read_dump(os.path.join(rd, "dumps", f"setup.r{r:05d}.bin")) for r in range(NP)]
     out = {}
     # setup arrays from a 1-rank run of the reference (connectivity holds rank-local indices, so only the trivial
     # partition is directly comparable; nsteps=0 because pARMS' RAS solver cannot run on one rank)
-    rd1, rc1, _ = run_ref.run("pi_pp", 1, 0, mode="replay", dump=())
+    rd1, rc1, _ = run_ref.run(cfg, 1, 0, mode="replay", dump=())
     assert rc1 == 0
     s1 = read_dump(os.path.join(rd1, "dumps", "setup.r00000.bin"))
     skip = {"dims", "myList_nod2D", "myList_elem2D", "myList_edge2D", "nod_in_elem2D"}
@@ -49,6 +49,18 @@ def main():
         if k in skip or k.startswith("_"):
             continue
         out["setup/" + k] = digest(s1[k])
+    if run_ref.CFGS[cfg]["toy_ocean"] == ".true.":
+        # rank that owns the first node of every element (global element order): the zonal sums of the Soufflet toy are
+        # formed per rank and added in rank order by MPI_Allreduce, the oracle emulates that order for this comparison
+        nod2D, elem2D = int(setups[0]["dims"][0]), int(setups[0]["dims"][1])
+        rank_of_node = np.zeros(nod2D, dtype=np.int32)
+        first_node = np.zeros(elem2D, dtype=np.int64)
+        for r, s_ in enumerate(setups):
+            myN, myE = int(s_["dims"][5]), int(s_["dims"][7])
+            rank_of_node[s_["myList_nod2D"][:myN] - 1] = r
+            first_node[s_["myList_elem2D"][:myE] - 1] = s_["myList_nod2D"][s_["elem2D_nodes"][:myE, 0] - 1]
+        out["toy/owner"] = rank_of_node[first_node - 1].astype(np.int32)
+        out["toy/nranks"] = np.array([NP], dtype=np.int32)
     for step in range(1, NSTEPS + 1):
         d = [read_dump(os.path.join(rd, "dumps", f"replay{step:04d}.r{r:05d}.bin")) for r in range(NP)]
         for k in d[0]:
@@ -60,8 +72,13 @@ def main():
             out[f"s{step}/{k}"] = digest(g)
             if k == "solve_ssh_ale.d_eta":
                 out[f"s{step}/full.d_eta"] = g.astype(np.float64)
-    np.savez_compressed(os.path.join(HERE, "pi_pp_reference.npz"), **out)
-    print("wrote pi_pp_reference.npz with", len(out), "entries")
+    np.savez_compressed(os.path.join(HERE, outname), **out)
+    print("wrote", outname, "with", len(out), "entries")
+
+
+def main():
+    make("pi_pp", "pi_pp_reference.npz")
+    make("souf", "souf_reference.npz")
     # known answers of the reference's own CI
     rd, rc, lines = run_ref.run("souf", 8, 72, mode="step", mean=True, dump_mesh=False)
     means = {l.split()[1]: float(l.split()[2]) for l in lines if l.startswith("ORACLE_MEAN")}
