@@ -53,6 +53,14 @@ struct Mesh {
   fesom_part_desc part;
   fesom_state_desc st;
   ivec com_dummy;
+  // ---- partition (npes > 1): node owner, local lists, communication lists, local copies of every array
+  struct Com { ivec rPE, rptr, rlist, sPE, sptr, slist; };
+  ivec owner;                                   // rank of every global node (0-based ranks)
+  int myN = 0, eN = 0, myE = 0, eE = 0, eX = 0, myD = 0, eD = 0;
+  Com cn, ce, cf;                               // com_nod2D, com_elem2D, com_elem2D_full (local 1-based lists after localisation)
+  std::vector<dvec> ld;                         // local double arrays (kept alive for desc / state pointers)
+  std::vector<ivec> li;
+  bool local = false;
 };
 
 bool read_all_tokens(const std::string &fn, std::vector<std::string> &tok) {
@@ -542,6 +550,246 @@ void updn_tri(Mesh &m) {
   }
 }
 
+
+// =====================================================================================================================
+// Partition layer (npes > 1).  The node -> rank map comes from the reference's own partition files
+// (dist_<npes>/my_list*.out: owned nodes), from a coarser merge of a finer one (ranks r/k of dist_<k*npes>), or from a
+// recursive coordinate bisection when no file fits.  Everything else follows the reference's rules:
+//   communication_nodn  src/gen_comm.F90:12-215     halo nodes = foreign nodes of the elements around owned nodes
+//   communication_elemn :218-515                    my elements = any node owned; small halo = edge neighbours without
+//                                                   owned node; full halo (+eXDim) = node-patch neighbours
+//   mymesh              :517-641                    my edges = any node owned; external edges of my elements
+//   com_global2local    src/oce_local.F90:11-117    lists -> local indices
+// Local arrays are extractions of the global ones (owned lists are in increasing global order and halo values are the
+// owners' values, so owned results do not depend on the partition); connectivity is translated to local indices, 0 = not
+// local (load_edges src/oce_mesh.F90:1419-1642, find_neighbors :1650-1800).
+// =====================================================================================================================
+bool read_ints(const std::string &fn, ivec &v) {
+  std::vector<std::string> tok;
+  if (!read_all_tokens(fn, tok)) return false;
+  v.resize(tok.size());
+  for (size_t i = 0; i < tok.size(); i++) v[i] = atoi(tok[i].c_str());
+  return true;
+}
+
+bool owner_from_files(Mesh &m, const std::string &dir, int np, ivec &own) {
+  own.assign(m.N2, -1);
+  for (int r = 0; r < np; r++) {
+    char fn[64]; snprintf(fn, sizeof(fn), "/dist_%d/my_list%05d.out", np, r);
+    ivec v;
+    if (!read_ints(dir + fn, v) || v.size() < 3) return false;
+    int myN = v[1];
+    if ((int)v.size() < 3 + myN) return false;
+    for (int k = 0; k < myN; k++) { int g = v[3 + k]; if (g < 1 || g > m.N2) return false; own[g - 1] = r; }
+  }
+  for (int n = 0; n < m.N2; n++) if (own[n] < 0) return false;
+  return true;
+}
+
+void rcb(const Mesh &m, ivec &idx, int lo, int hi, int r0, int nr, ivec &own) {        // recursive coordinate bisection
+  if (nr == 1) { for (int i = lo; i < hi; i++) own[idx[i]] = r0; return; }
+  double mn[2] = {1e300, 1e300}, mx[2] = {-1e300, -1e300};
+  for (int i = lo; i < hi; i++) for (int k = 0; k < 2; k++) { double c = m.coord[2 * idx[i] + k]; mn[k] = std::min(mn[k], c); mx[k] = std::max(mx[k], c); }
+  int ax = (mx[0] - mn[0]) * cos(0.5 * (mn[1] + mx[1])) > (mx[1] - mn[1]) ? 0 : 1;
+  int nl = nr / 2, cut = lo + (int)((long long)(hi - lo) * nl / nr);
+  std::nth_element(idx.begin() + lo, idx.begin() + cut, idx.begin() + hi, [&](int a, int b) {
+    double ca = m.coord[2 * a + ax], cb = m.coord[2 * b + ax];
+    return ca < cb || (ca == cb && a < b);
+  });
+  rcb(m, idx, lo, cut, r0, nl, own);
+  rcb(m, idx, cut, hi, r0 + nl, nr - nl, own);
+}
+
+bool make_owner(Mesh &m, const std::string &dir, int np) {
+  if (owner_from_files(m, dir, np, m.owner)) return true;
+  for (int k = 2; k <= 64; k++) {                              // merge a finer reference partition: rank = r / k
+    ivec fine;
+    if (owner_from_files(m, dir, np * k, fine)) { m.owner.resize(m.N2); for (int n = 0; n < m.N2; n++) m.owner[n] = fine[n] / k; return true; }
+  }
+  ivec idx(m.N2);
+  for (int n = 0; n < m.N2; n++) idx[n] = n;
+  m.owner.assign(m.N2, 0);
+  rcb(m, idx, 0, m.N2, 0, np, m.owner);
+  return true;
+}
+
+void build_com(int np, const ivec &recv_from, int nglob, const std::vector<std::vector<int>> &send_to, const ivec &mylist, Mesh::Com &c) {
+  c = Mesh::Com();
+  c.rptr.push_back(1); c.sptr.push_back(1);
+  for (int r = 0; r < np; r++) {
+    int nr = 0, ns = 0;
+    for (int g = 0; g < nglob; g++) if (recv_from[g] == r) nr++;
+    for (size_t l = 0; l < mylist.size(); l++) if (std::find(send_to[l].begin(), send_to[l].end(), r) != send_to[l].end()) ns++;
+    if (nr) { c.rPE.push_back(r); c.rptr.push_back(c.rptr.back() + nr); for (int g = 0; g < nglob; g++) if (recv_from[g] == r) c.rlist.push_back(g + 1); }
+    if (ns) {
+      c.sPE.push_back(r); c.sptr.push_back(c.sptr.back() + ns);
+      for (size_t l = 0; l < mylist.size(); l++) if (std::find(send_to[l].begin(), send_to[l].end(), r) != send_to[l].end()) c.slist.push_back(mylist[l]);
+    }
+  }
+}
+
+void partition(Mesh &m, int np, int me) {
+  const ivec &own = m.owner;
+  auto add = [](std::vector<int> &v, int r) { if (std::find(v.begin(), v.end(), r) == v.end()) v.push_back(r); };
+  // ---- nodes (communication_nodn)
+  m.list_n.clear();
+  for (int n = 1; n <= m.N2; n++) if (own[n - 1] == me) m.list_n.push_back(n);
+  m.myN = (int)m.list_n.size();
+  {
+    ivec recv(m.N2, -1);
+    std::vector<std::vector<int>> send(m.myN);
+    for (int l = 0; l < m.myN; l++) {
+      int n = m.list_n[l];
+      for (int i = 1; i <= m.nie_num[n - 1]; i++) {
+        int el = NIE(i, n);
+        for (int j = 1; j <= 3; j++) {
+          int nod = EN(j, el);
+          if (own[nod - 1] != me) { recv[nod - 1] = own[nod - 1]; add(send[l], own[nod - 1]); }
+        }
+      }
+    }
+    build_com(np, recv, m.N2, send, m.list_n, m.cn);
+    m.eN = (int)m.cn.rlist.size();
+  }
+  // ---- elements (communication_elemn)
+  ivec mye;
+  for (int el = 1; el <= m.E2; el++) if (own[EN(1, el) - 1] == me || own[EN(2, el) - 1] == me || own[EN(3, el) - 1] == me) mye.push_back(el);
+  m.myE = (int)mye.size();
+  {
+    ivec recv(m.E2, -1);
+    std::vector<std::vector<int>> send(m.myE);
+    auto none_mine = [&](int e) { return own[EN(1, e) - 1] != me && own[EN(2, e) - 1] != me && own[EN(3, e) - 1] != me; };
+    auto any_foreign = [&](int e) { return own[EN(1, e) - 1] != me || own[EN(2, e) - 1] != me || own[EN(3, e) - 1] != me; };
+    auto visit = [&](int l, int el, int elem) {
+      if (none_mine(elem) && recv[elem - 1] == -1) recv[elem - 1] = own[EN(1, elem) - 1];     // first node's rank is the "main" owner
+      if (own[EN(1, el) - 1] == me && any_foreign(elem))
+        for (int i = 1; i <= 3; i++) {
+          int ep = own[EN(i, elem) - 1];
+          if (own[EN(1, el) - 1] == ep || own[EN(2, el) - 1] == ep || own[EN(3, el) - 1] == ep) continue;
+          add(send[l], ep);
+        }
+    };
+    for (int l = 0; l < m.myE; l++)
+      for (int n = 1; n <= 3; n++) { int elem = ENB(n, mye[l]); if (elem >= 1) visit(l, mye[l], elem); }
+    build_com(np, recv, m.E2, send, mye, m.ce);
+    m.eE = (int)m.ce.rlist.size();
+    for (int l = 0; l < m.myE; l++)
+      for (int n = 1; n <= 3; n++) {
+        int nod = EN(n, mye[l]);
+        for (int j = 1; j <= m.nie_num[nod - 1]; j++) visit(l, mye[l], NIE(j, nod));
+      }
+    build_com(np, recv, m.E2, send, mye, m.cf);
+  }
+  m.list_e = mye;
+  for (int g : m.ce.rlist) m.list_e.push_back(g);
+  m.eX = 0;
+  for (int g : m.cf.rlist) if (std::find(m.ce.rlist.begin(), m.ce.rlist.end(), g) == m.ce.rlist.end()) { m.list_e.push_back(g); m.eX++; }
+  // ---- edges (mymesh)
+  m.list_d.clear();
+  for (int d = 1; d <= m.D2; d++) if (own[ED(1, d) - 1] == me || own[ED(2, d) - 1] == me) m.list_d.push_back(d);
+  m.myD = (int)m.list_d.size();
+  {
+    std::vector<char> have(m.D2, 0);
+    for (int l = 0; l < m.myE; l++)
+      for (int q = 1; q <= 3; q++) {
+        int e = EE(q, mye[l]);
+        if (own[ED(1, e) - 1] != me && own[ED(2, e) - 1] != me && !have[e - 1]) { have[e - 1] = 1; m.list_d.push_back(e); }
+      }
+  }
+  m.eD = (int)m.list_d.size() - m.myD;
+  for (int g : m.cn.rlist) m.list_n.push_back(g);
+  // ---- com_global2local
+  ivec gn(m.N2 + 1, 0), ge(m.E2 + 1, 0);
+  for (int l = 0; l < m.myN; l++) gn[m.list_n[l]] = l + 1;
+  for (int k = 0; k < m.eN; k++) m.cn.rlist[k] = m.myN + k + 1;
+  for (auto &v : m.cn.slist) v = gn[v];
+  for (int l = 0; l < m.myE; l++) ge[mye[l]] = l + 1;
+  for (int k = 0; k < m.eE; k++) { ge[m.ce.rlist[k]] = m.myE + k + 1; m.ce.rlist[k] = m.myE + k + 1; }
+  for (auto &v : m.ce.slist) v = ge[v];
+  { int x = 0; for (auto &v : m.cf.rlist) { if (ge[v] > 0) v = ge[v]; else { x++; v = m.myE + m.eE + x; } } }
+  for (auto &v : m.cf.slist) v = ge[v];
+}
+
+template <class T> std::vector<T> gather(const std::vector<T> &src, int width, const ivec &list, int count) {
+  std::vector<T> out((size_t)width * count);
+  for (int l = 0; l < count; l++) memcpy(&out[(size_t)width * l], &src[(size_t)width * (list[l] - 1)], sizeof(T) * width);
+  return out;
+}
+
+void make_local(Mesh &m, int np, int me) {
+  const int Nl = m.myN + m.eN, El = m.myE + m.eE, EX = El + m.eX, Dl = m.myD + m.eD, nl = m.nl, n1 = nl - 1;
+  ivec gn(m.N2 + 1, 0), ge(m.E2 + 1, 0), gd(m.D2 + 1, 0);
+  for (int l = 0; l < Nl; l++) gn[m.list_n[l]] = l + 1;
+  for (int l = 0; l < EX; l++) ge[m.list_e[l]] = l + 1;
+  for (int l = 0; l < Dl; l++) gd[m.list_d[l]] = l + 1;
+  m.li.reserve(64); m.ld.reserve(96);
+  auto KI = [&](ivec v) -> const int * { m.li.push_back(std::move(v)); return m.li.back().data(); };
+  auto KD = [&](dvec v) -> const double * { m.ld.push_back(std::move(v)); return m.ld.back().data(); };
+  auto tr = [&](ivec v, const ivec &map) { for (auto &x : v) x = (x > 0) ? map[x] : 0; return v; };
+  fesom_mesh_desc &d = m.desc;
+  d.myDim_nod2D = m.myN; d.eDim_nod2D = m.eN; d.myDim_elem2D = m.myE; d.eDim_elem2D = m.eE; d.eXDim_elem2D = m.eX;
+  d.myDim_edge2D = m.myD; d.eDim_edge2D = m.eD;
+  d.myList_nod2D = m.list_n.data(); d.myList_elem2D = m.list_e.data(); d.myList_edge2D = m.list_d.data();
+  d.coord_nod2D = KD(gather(m.coord, 2, m.list_n, Nl)); d.geo_coord_nod2D = KD(gather(m.geo, 2, m.list_n, Nl));
+  d.elem2D_nodes = KI(tr(gather(m.elem_nodes, 3, m.list_e, EX), gn));
+  d.edges = KI(tr(gather(m.edges, 2, m.list_d, Dl), gn));
+  d.edge_tri = KI(tr(gather(m.edge_tri, 2, m.list_d, Dl), ge));
+  d.elem_edges = KI(tr(gather(m.elem_edges, 3, m.list_e, m.myE), gd));
+  d.elem_neighbors = KI(tr(gather(m.elem_nb, 3, m.list_e, m.myE), ge));
+  d.nod_in_elem2D = KI(tr(gather(m.nie, m.maxk, m.list_n, Nl), ge));
+  d.nod_in_elem2D_num = KI(gather(m.nie_num, 1, m.list_n, Nl));
+  d.nlevels = KI(gather(m.nlev, 1, m.list_e, EX)); d.ulevels = KI(gather(m.ulev, 1, m.list_e, EX));
+  d.nlevels_nod2D = KI(gather(m.nlev_n, 1, m.list_n, Nl)); d.ulevels_nod2D = KI(gather(m.ulev_n, 1, m.list_n, Nl));
+  d.nlevels_nod2D_min = KI(gather(m.nlev_n_min, 1, m.list_n, Nl)); d.ulevels_nod2D_max = KI(gather(m.ulev_n_max, 1, m.list_n, Nl));
+  d.depth = KD(gather(m.depth, 1, m.list_n, Nl));
+  d.elem_area = KD(gather(m.elem_area, 1, m.list_e, EX));
+  d.area = KD(gather(m.area, nl, m.list_n, Nl)); d.area_inv = KD(gather(m.area_inv, nl, m.list_n, Nl));
+  d.areasvol = KD(gather(m.areasvol, nl, m.list_n, Nl)); d.areasvol_inv = KD(gather(m.areasvol_inv, nl, m.list_n, Nl));
+  d.mesh_resolution = KD(gather(m.resol, 1, m.list_n, Nl));
+  d.gradient_sca = KD(gather(m.grad_sca, 6, m.list_e, m.myE)); d.gradient_vec = KD(gather(m.grad_vec, 6, m.list_e, m.myE));
+  d.edge_dxdy = KD(gather(m.edge_dxdy, 2, m.list_d, Dl)); d.edge_cross_dxdy = KD(gather(m.edge_cross, 4, m.list_d, Dl));
+  d.elem_cos = KD(gather(m.elem_cos, 1, m.list_e, EX)); d.metric_factor = KD(gather(m.metric, 1, m.list_e, EX));
+  d.coriolis = KD(gather(m.cori, 1, m.list_e, m.myE)); d.coriolis_node = KD(gather(m.cori_n, 1, m.list_n, Nl));
+  d.edge_up_dn_tri = KI(tr(gather(m.updn, 2, m.list_d, m.myD), ge));
+  d.zbar_n_bot = KD(gather(m.zbar_n_bot, 1, m.list_n, Nl)); d.zbar_n_srf = KD(gather(m.zbar_n_srf, 1, m.list_n, Nl));
+  d.bottom_node_thickness = KD(gather(m.bot_n_th, 1, m.list_n, Nl));
+  d.zbar_e_bot = KD(gather(m.zbar_e_bot, 1, m.list_e, El)); d.zbar_e_srf = KD(gather(m.zbar_e_srf, 1, m.list_e, El));
+  d.bottom_elem_thickness = KD(gather(m.bot_e_th, 1, m.list_e, m.myE));
+  // SSH operator rows of the owned nodes: columns in local numbering and in the PE-contiguous global numbering of the
+  // reference (oce_ale.F90:1297-1344: rank r owns positions part(r) .. part(r+1)-1 in owned order)
+  {
+    ivec cnt(np + 1, 0), pos(m.N2 + 1, 0), nnz_before(np + 1, 0);
+    for (int n = 1; n <= m.N2; n++) { int r = m.owner[n - 1]; pos[n] = ++cnt[r + 1]; nnz_before[r + 1] += m.rowptr[n] - m.rowptr[n - 1]; }
+    for (int r = 1; r <= np; r++) { cnt[r] += cnt[r - 1]; nnz_before[r] += nnz_before[r - 1]; }
+    for (int n = 1; n <= m.N2; n++) pos[n] += cnt[m.owner[n - 1]];
+    ivec rp(m.myN + 1), cg, cl; dvec va;
+    rp[0] = nnz_before[me] + 1;
+    for (int l = 0; l < m.myN; l++) {
+      int g = m.list_n[l];
+      for (int q = m.rowptr[g - 1]; q < m.rowptr[g]; q++) { int c = m.colind[q - 1]; cg.push_back(pos[c]); cl.push_back(gn[c]); va.push_back(m.values[q - 1]); }
+      rp[l + 1] = rp[l] + (m.rowptr[g] - m.rowptr[g - 1]);
+    }
+    d.ssh_nza = (int)va.size();
+    d.ssh_rowptr = KI(rp); d.ssh_colind = KI(cg); d.ssh_colind_loc = KI(cl); d.ssh_values = KD(va);
+    m.values_state = m.ld.back();
+  }
+  // initial ALE state (sizes as fesom_state_desc)
+  m.hnode = gather(m.hnode, n1, m.list_n, Nl); m.hnode_new = gather(m.hnode_new, n1, m.list_n, Nl);
+  m.helem = gather(m.helem, n1, m.list_e, m.myE);
+  m.zbar3 = gather(m.zbar3, nl, m.list_n, Nl); m.Z3 = gather(m.Z3, n1, m.list_n, Nl);
+  m.eta = gather(m.eta, 1, m.list_n, Nl); m.d_eta = gather(m.d_eta, 1, m.list_n, Nl); m.ssh_rhs = gather(m.ssh_rhs, 1, m.list_n, Nl);
+  m.ssh_rhs_old = gather(m.ssh_rhs_old, 1, m.list_n, Nl); m.hbar = gather(m.hbar, 1, m.list_n, Nl); m.hbar_old = gather(m.hbar_old, 1, m.list_n, Nl);
+  m.dhe = gather(m.dhe, 1, m.list_e, m.myE);
+  // communication descriptors
+  m.part.npes = np; m.part.mype = me;
+  auto setc = [&](fesom_com_desc &c, const Mesh::Com &s) {
+    c.rPEnum = (int)s.rPE.size(); c.sPEnum = (int)s.sPE.size();
+    c.rPE = s.rPE.data(); c.rptr = s.rptr.data(); c.rlist = s.rlist.data(); c.sPE = s.sPE.data(); c.sptr = s.sptr.data(); c.slist = s.slist.data();
+  };
+  setc(m.part.com_nod2D, m.cn); setc(m.part.com_elem2D, m.ce); setc(m.part.com_elem2D_full, m.cf);
+  m.local = true;
+}
+
 void fill_desc(Mesh &m) {
   fesom_mesh_desc &d = m.desc;
   memset(&d, 0, sizeof(d));
@@ -580,7 +828,7 @@ void fill_desc(Mesh &m) {
 extern "C" {
 
 void *fesom_mesh_load(const char *meshdir, const fesom_mesh_opts *opts) {
-  if (opts->npes != 1) { fprintf(stderr, "fesom_mesh_load: only npes=1 is implemented in the host mesh layer\n"); return nullptr; }
+  if (opts->npes < 1 || opts->mype < 0 || opts->mype >= opts->npes) { fprintf(stderr, "fesom_mesh_load: bad npes/mype\n"); return nullptr; }
   if (opts->which_ale != 0 && opts->which_ale != 2) { fprintf(stderr, "fesom_mesh_load: which_ale must be 0 (linfs) or 2 (zstar)\n"); return nullptr; }
   Mesh *mp = new Mesh();
   Mesh &m = *mp;
@@ -596,6 +844,11 @@ void *fesom_mesh_load(const char *meshdir, const fesom_mesh_opts *opts) {
   stiff_mat(m);
   updn_tri(m);
   fill_desc(m);
+  if (opts->npes > 1) {
+    make_owner(m, meshdir, opts->npes);
+    partition(m, opts->npes, opts->mype);
+    make_local(m, opts->npes, opts->mype);
+  }
   return mp;
 }
 
@@ -604,11 +857,11 @@ const fesom_part_desc *fesom_mesh_get_part(void *h) { return &((Mesh *)h)->part;
 
 const fesom_state_desc *fesom_mesh_get_initial_state(void *h, int ntr) {
   Mesh &m = *(Mesh *)h;
-  size_t nl = m.nl, N = m.N2, E = m.E2;
+  size_t nl = m.nl, N = m.local ? m.myN + m.eN : m.N2, E = m.local ? m.myE + m.eE : m.E2;
   m.tr.assign((nl - 1) * N * ntr, 0.0); m.tr_old.assign((nl - 1) * N * ntr, 0.0);
   m.UV.assign(2 * (nl - 1) * E, 0.0); m.UVab.assign(2 * (nl - 1) * E, 0.0);
   m.W.assign(nl * N, 0.0); m.We.assign(nl * N, 0.0); m.Wi.assign(nl * N, 0.0);
-  m.values_state = m.values;
+  if (!m.local) m.values_state = m.values;
   fesom_state_desc &s = m.st;
   s.tr_arr = m.tr.data(); s.tr_arr_old = m.tr_old.data(); s.UV = m.UV.data(); s.UV_rhsAB = m.UVab.data();
   s.eta_n = m.eta.data(); s.d_eta = m.d_eta.data(); s.ssh_rhs = m.ssh_rhs.data(); s.ssh_rhs_old = m.ssh_rhs_old.data();

@@ -49,6 +49,15 @@ def make(cfg, outname):
         if k in skip or k.startswith("_"):
             continue
         out["setup/" + k] = digest(s1[k])
+    # rank-local arrays of the NP-rank run (local numbering, halo included): pins the partition layer of the host mesh code
+    for r, s_ in enumerate(setups):
+        for k in s_:
+            if k.startswith("_") or k in ("nod_in_elem2D", "metric_factor"):      # (stale padding / rank-dependent leftover in the reference)
+                continue
+            out[f"setup_r{r}/{k}"] = digest(s_[k])
+        num = s_["nod_in_elem2D_num"]
+        nie = np.where(np.arange(s_["nod_in_elem2D"].shape[1])[None, :] < num[:, None], s_["nod_in_elem2D"], 0)
+        out[f"setup_r{r}/nod_in_elem2D"] = digest(nie)
     if run_ref.CFGS[cfg]["toy_ocean"] == ".true.":
         # rank that owns the first node of every element (global element order): the zonal sums of the Soufflet toy are
         # formed per rank and added in rank order by MPI_Allreduce, the oracle emulates that order for this comparison
