@@ -31,6 +31,10 @@ struct Ctx {
   hipGraphExec_t graph[2] = {nullptr, nullptr};
   bool use_graph = true;
   std::string err;
+  // partition + halo exchange (npes > 1)
+  int npes = 1, mype = 0;
+  struct Halo { std::vector<int> rPE, rptr, sPE, sptr; const int *rlist = nullptr, *slist = nullptr; const int *rptr_d = nullptr, *sptr_d = nullptr; int nrecv = 0, nsend = 0; } halo[3];
+  double *hsend = nullptr, *hrecv = nullptr; size_t hcap = 0;
 } G;
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { G.err = std::string(#x) + ": " + hipGetErrorString(e_); fprintf(stderr, "fesom_gpu: %s\n", G.err.c_str()); return 1; } } while (0)
@@ -195,7 +199,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   G.err.clear();
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { G.err = "no HIP device: the MI355X path has no CPU fallback"; fprintf(stderr, "fesom_gpu: %s\n", G.err.c_str()); return 2; }
-  if (part && part->npes != 1) { G.err = "fesom_gpu_init: multi-partition halo exchange is not implemented in this round (npes must be 1)"; return 3; }
+  if (part && part->npes > 1 && par->toy_soufflet) { G.err = "fesom_gpu_init: the Soufflet toy hooks (global zonal means) are single-partition only"; return 3; }
   if (d->nl > 64) { G.err = "fesom_gpu_init: nl > 64 levels not supported by the one-wave-per-column kernels"; return 3; }
   if (par->which_ale != 0 && par->which_ale != 2) { G.err = "fesom_gpu_init: which_ale must be linfs(0) or zstar(2)"; return 3; }
   if (par->mom_adv != 2 || par->visc_option != 5) { G.err = "fesom_gpu_init: only mom_adv=2, visc_option=5 are implemented"; return 3; }
@@ -223,12 +227,13 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   m.nl = d->nl; m.nlm1 = d->nl - 1; m.ntr = par->num_tracers; m.maxk = d->max_nod_in_elem; m.nza = d->ssh_nza; m.edge2D_in = d->edge2D_in;
   const size_t N = m.N, E = m.E, D = m.D, nl = m.nl, n1 = m.nlm1;
   const int EX = m.E + d->eXDim_elem2D;
+  m.EX = EX;
   // ---- connectivity (0-based)
-  std::vector<int> en = minus1(d->elem2D_nodes, 3 * (size_t)E), ed = minus1(d->edges, 2 * D), et = minus1(d->edge_tri, 2 * D);
+  std::vector<int> en = minus1(d->elem2D_nodes, 3 * (size_t)EX), ed = minus1(d->edges, 2 * D), et = minus1(d->edge_tri, 2 * D);
   m.elem_nodes = dev_upload(en); m.edges = dev_upload(ed); m.edge_tri = dev_upload(et);
   m.nie = dev_upload(minus1(d->nod_in_elem2D, (size_t)m.maxk * N));
   m.nie_num = dev_upload(std::vector<int>(d->nod_in_elem2D_num, d->nod_in_elem2D_num + N));
-  m.nlev = dev_upload(std::vector<int>(d->nlevels, d->nlevels + E)); m.ulev = dev_upload(std::vector<int>(d->ulevels, d->ulevels + E));
+  m.nlev = dev_upload(std::vector<int>(d->nlevels, d->nlevels + EX)); m.ulev = dev_upload(std::vector<int>(d->ulevels, d->ulevels + EX));   // incl. the extended element halo
   m.nlev_n = dev_upload(std::vector<int>(d->nlevels_nod2D, d->nlevels_nod2D + N));
   m.ulev_n = dev_upload(std::vector<int>(d->ulevels_nod2D, d->ulevels_nod2D + N));
   m.nlev_n_min = dev_upload(std::vector<int>(d->nlevels_nod2D_min, d->nlevels_nod2D_min + N));
@@ -306,12 +311,11 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     m.su_ptr = dev_upload(sp); m.su_elem = dev_upload(se); m.su_coef = dev_upload(sc);
   }
   // ---- geometry
-  m.elem_area = dev_upload_d(d->elem_area, E); m.area = dev_upload_d(d->area, nl * N); m.areasvol = dev_upload_d(d->areasvol, nl * N);
+  m.elem_area = dev_upload_d(d->elem_area, EX); m.area = dev_upload_d(d->area, nl * N); m.areasvol = dev_upload_d(d->areasvol, nl * N);
   m.areasvol_inv = dev_upload_d(d->areasvol_inv, nl * N); m.gsca = dev_upload_d(d->gradient_sca, 6 * (size_t)m.myE);
-  m.ecd = dev_upload_d(d->edge_cross_dxdy, 4 * D); m.edxy = dev_upload_d(d->edge_dxdy, 2 * D); m.elem_cos = dev_upload_d(d->elem_cos, E);
+  m.ecd = dev_upload_d(d->edge_cross_dxdy, 4 * D); m.edxy = dev_upload_d(d->edge_dxdy, 2 * D); m.elem_cos = dev_upload_d(d->elem_cos, EX);
   m.coriolis = dev_upload_d(d->coriolis, m.myE); m.zbar_e_bot = dev_upload_d(d->zbar_e_bot, E); m.zbar_n_bot = dev_upload_d(d->zbar_n_bot, N);
   m.zbar = dev_upload_d(d->zbar, nl); m.Z = dev_upload_d(d->Z, n1);
-  (void)EX;
   // ---- fields
 #define F(f, c) m.f = field(#f, c)
 #define FT(f, c) m.f = field(#f, c, m.ntr)
@@ -323,18 +327,33 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   F(Unode, 2 * n1 * N); F(Unode_rhs, 2 * n1 * N); F(sigma_xy, 2 * n1 * N); F(neutral_slope, 3 * n1 * N); F(slope_tapered, 3 * n1 * N); F(U_c, 2 * n1 * N);
   F(eta_n, N); F(d_eta, N); F(ssh_rhs, N); F(ssh_rhs_old, N); F(hbar, N); F(hbar_old, N); F(MLD1, N); F(MLD2, N);
   F(heat_flux, N); F(water_flux, N); F(virtual_salt, N); F(relax_salt, N); F(real_salt_flux, N);
-  F(UV, 2 * n1 * E); F(UV_rhs, 2 * n1 * E); F(UV_rhsAB, 2 * n1 * E); FT(tr_xy, 2 * n1 * E); FT(tr_xy_ab, 2 * n1 * E); F(U_b, 2 * n1 * E);
+  F(UV, 2 * n1 * E); F(UV_rhs, 2 * n1 * E); F(UV_rhsAB, 2 * n1 * E); FT(tr_xy, 2 * n1 * EX); FT(tr_xy_ab, 2 * n1 * EX); F(U_b, 2 * n1 * E);
   F(pgf_x, n1 * E); F(pgf_y, n1 * E); F(helem, n1 * E); F(Av, nl * E); F(dhe, E); F(stress_surf, 2 * E);
   FT(adv_flux_hor, n1 * D); FT(adv_flux_raw, n1 * D); FT(flux_lo_hor, n1 * D); FT(diff_flux, n1 * D); FT(edge_up_dn_grad, 4 * n1 * D); F(edge_c12, D);
   F(ssh_values, m.nza);
   if (par->toy_soufflet) { F(Tclim, n1 * N); F(Uclim, n1 * E); F(toy_zvel, n1 * 100); F(toy_ztem, n1 * 100); }
   F(sv_vals, 16 * (N + 64)); F(sv_dinv, N + 64); F(sv_b, N + 64); F(sv_r, N + 64); F(sv_r0, N + 64); F(sv_p, N + 64); F(sv_v, N + 64); F(sv_s, N + 64); F(sv_t, N + 64);
   F(sv_ph, N + 64); F(sv_x0, 16 * (N + 64)); F(sv_snap, N);
+  F(sv_part, 4 * ((N + 255) / 256 + 1)); F(sv_red, 8); F(sv_scal, 4);
   F(sv_resid, 1); F(sv_h1, N); F(sv_h2, N); F(sv_h3, N); F(sv_scale, N + 64);
   m.sv_extrap = 1;
 #undef F
 #undef FT
   m.sv_info = dev_alloc<int>(4);
+  G.npes = part ? part->npes : 1; G.mype = part ? part->mype : 0;
+  G.hsend = G.hrecv = nullptr; G.hcap = 0;
+  if (part && part->npes > 1) {
+    const fesom_com_desc *cs[3] = {&part->com_nod2D, &part->com_elem2D, &part->com_elem2D_full};
+    for (int k = 0; k < 3; k++) {
+      Ctx::Halo &h = G.halo[k];
+      const fesom_com_desc &c = *cs[k];
+      h.rPE.assign(c.rPE, c.rPE + c.rPEnum); h.rptr.assign(c.rptr, c.rptr + c.rPEnum + 1);
+      h.sPE.assign(c.sPE, c.sPE + c.sPEnum); h.sptr.assign(c.sptr, c.sptr + c.sPEnum + 1);
+      h.nrecv = h.rptr.back() - 1; h.nsend = h.sptr.back() - 1;
+      h.rlist = dev_upload(minus1(c.rlist, h.nrecv)); h.slist = dev_upload(minus1(c.slist, h.nsend));
+      h.rptr_d = dev_upload(h.rptr); h.sptr_d = dev_upload(h.sptr);
+    }
+  }
   if (par->toy_soufflet) {
     // static tables of the Soufflet hooks: compute_zonal_mean_ini (toy_channel_soufflet.F90:104-155) and the interpolation
     // headers of relax_zonal_vel / relax_zonal_temp (:57-70, :89-100); module constants :19-23
@@ -454,6 +473,8 @@ static int call_named(const char *name, int arg) {
   rc = launch_named_tra(m, G.stream, name, arg);
   if (rc == 0) return 0;
   rc = launch_named_toy(m, G.stream, name);
+  if (rc == 0) return 0;
+  rc = launch_named_dsolve(m, G.stream, name);
   if (rc == 0) return 0;
   G.err = std::string("fesom_gpu_call: unknown routine ") + name;
   return 1;
@@ -589,4 +610,113 @@ void psolve(int *id, double *rhs, double *vals, double *sol, int *newvals) {
   hipDeviceSynchronize();
   hipMemcpy(sol, m.d_eta, sizeof(double) * PS.n, hipMemcpyDeviceToHost);
 }
+}
+
+// =====================================================================================================================
+// Halo exchange (row e).  The library packs / unpacks, the HOST moves the bytes: an MPI host calls MPI_Isend/Irecv on
+// the device buffers (GPU-aware MPI), this repository's Python host uses torch.distributed (RCCL over xGMI on a multi-GPU
+// node, gloo with host staging in the 2-rank tests).  Mirrors exchange_nod / exchange_elem of the reference
+// (src/gen_halo_exchange.F90:58-1035): `kind` 0 = com_nod2D, 1 = com_elem2D, 2 = com_elem2D_full; several fields that
+// are exchanged at the same point of the step travel in ONE message per neighbour.
+// Message layout: for every neighbour p (order of sPE / rPE) a contiguous block; inside it field after field, each
+// [items of p][values per item] (an item is a node / element column, contiguous in memory: vertical index fastest).
+// =====================================================================================================================
+namespace {
+struct Sub { double *p; int W; };
+__global__ void k_halo_pack(const double *__restrict__ f, int W, const int *__restrict__ list, const int *__restrict__ ptr, int npe, int nitems,
+                            int Wtot, int Woff, double *__restrict__ buf) {
+  long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (long long)nitems * W) return;
+  int i = (int)(g / W), w = (int)(g % W);
+  int p = 0;
+  while (p + 1 < npe && i >= ptr[p + 1] - 1) p++;
+  int first = ptr[p] - 1, cnt = ptr[p + 1] - ptr[p];
+  buf[(size_t)first * Wtot + (size_t)cnt * Woff + (size_t)(i - first) * W + w] = f[(size_t)list[i] * W + w];
+}
+__global__ void k_halo_unpack(double *__restrict__ f, int W, const int *__restrict__ list, const int *__restrict__ ptr, int npe, int nitems,
+                              int Wtot, int Woff, const double *__restrict__ buf) {
+  long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (long long)nitems * W) return;
+  int i = (int)(g / W), w = (int)(g % W);
+  int p = 0;
+  while (p + 1 < npe && i >= ptr[p + 1] - 1) p++;
+  int first = ptr[p] - 1, cnt = ptr[p + 1] - ptr[p];
+  f[(size_t)list[i] * W + w] = buf[(size_t)first * Wtot + (size_t)cnt * Woff + (size_t)(i - first) * W + w];
+}
+int halo_subfields(int kind, int nf, const char *const *names, std::vector<Sub> &subs, int &Wtot) {
+  const DM &m = G.m;
+  const size_t items = kind == 0 ? m.N : kind == 1 ? m.E : m.EX;
+  subs.clear(); Wtot = 0;
+  for (int k = 0; k < nf; k++) {
+    auto it = G.fields.find(names[k]);
+    if (it == G.fields.end()) { G.err = std::string("halo: unknown field ") + names[k]; return 1; }
+    size_t cnt = it->second.count; int slabs = it->second.slabs;
+    if (!strcmp(names[k], "tr_arr") || !strcmp(names[k], "tr_arr_old")) { slabs = m.ntr; cnt /= m.ntr; }   // (nz, node, tracer)
+    if (!strncmp(names[k], "sv_", 3)) cnt = items;                                                        // solver vectors are padded
+    if (cnt % items) { G.err = std::string("halo: field size does not match the exchange kind: ") + names[k]; return 1; }
+    for (int sl = 0; sl < slabs; sl++) { subs.push_back(Sub{(double *)it->second.p + (size_t)sl * cnt, (int)(cnt / items)}); Wtot += (int)(cnt / items); }
+  }
+  return 0;
+}
+int halo_reserve(size_t doubles) {
+  if (doubles <= G.hcap) return 0;
+  size_t cap = doubles * 2;
+  G.hsend = dev_alloc<double>(cap); G.hrecv = dev_alloc<double>(cap);      // (old buffers are released at finalize)
+  if (!G.hsend || !G.hrecv) { G.err = "halo: buffer allocation failed"; return 1; }
+  G.hcap = cap;
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+int fesom_gpu_halo_info(int kind, int *npes, int *mype, int *nr, int *rPE, int *rcnt, int *ns, int *sPE, int *scnt) {
+  NEED_READY();
+  if (kind < 0 || kind > 2) { G.err = "halo: bad kind"; return 1; }
+  const Ctx::Halo &h = G.halo[kind];
+  *npes = G.npes; *mype = G.mype; *nr = (int)h.rPE.size(); *ns = (int)h.sPE.size();
+  for (size_t p = 0; p < h.rPE.size(); p++) { rPE[p] = h.rPE[p]; rcnt[p] = h.rptr[p + 1] - h.rptr[p]; }
+  for (size_t p = 0; p < h.sPE.size(); p++) { sPE[p] = h.sPE[p]; scnt[p] = h.sptr[p + 1] - h.sptr[p]; }
+  return 0;
+}
+// packs the send halo of `names` into the device send buffer; returns both device buffers and the number of values per
+// item (a neighbour's block holds count(p) * values_per_item doubles, blocks are consecutive in sPE / rPE order)
+int fesom_gpu_halo_pack(int kind, int nfields, const char *const *names, void **send_dev, void **recv_dev, int *values_per_item) {
+  NEED_READY();
+  if (G.npes < 2) { G.err = "halo: single partition"; return 1; }
+  const Ctx::Halo &h = G.halo[kind];
+  std::vector<Sub> subs; int Wtot = 0;
+  if (halo_subfields(kind, nfields, names, subs, Wtot)) return 1;
+  if (halo_reserve((size_t)std::max(h.nsend, h.nrecv) * Wtot)) return 1;
+  int off = 0;
+  for (auto &sb : subs) {
+    long long tot = (long long)h.nsend * sb.W;
+    if (tot > 0) hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, G.stream, sb.p, sb.W, h.slist, h.sptr_d, (int)h.sPE.size(), h.nsend, Wtot, off, G.hsend);
+    off += sb.W;
+  }
+  HIPCHK(hipStreamSynchronize(G.stream));               // the host transport may read the buffer now
+  *send_dev = G.hsend; *recv_dev = G.hrecv; *values_per_item = Wtot;
+  return 0;
+}
+int fesom_gpu_halo_unpack(int kind, int nfields, const char *const *names) {
+  NEED_READY();
+  const Ctx::Halo &h = G.halo[kind];
+  std::vector<Sub> subs; int Wtot = 0;
+  if (halo_subfields(kind, nfields, names, subs, Wtot)) return 1;
+  int off = 0;
+  for (auto &sb : subs) {
+    long long tot = (long long)h.nrecv * sb.W;
+    if (tot > 0) hipLaunchKernelGGL(k_halo_unpack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, G.stream, sb.p, sb.W, h.rlist, h.rptr_d, (int)h.rPE.size(), h.nrecv, Wtot, off, G.hrecv);
+    off += sb.W;
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// plain copies for hosts that stage through host memory (dir 0: device -> host, 1: host -> device); synchronous
+int fesom_gpu_copy(void *dst, const void *src, long long bytes, int dir) {
+  NEED_READY();
+  HIPCHK(hipStreamSynchronize(G.stream));
+  HIPCHK(hipMemcpy(dst, src, (size_t)bytes, dir == 0 ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice));
+  return 0;
+}
+int fesom_gpu_sync(void) { NEED_READY(); HIPCHK(hipStreamSynchronize(G.stream)); return 0; }
 }

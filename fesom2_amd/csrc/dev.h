@@ -19,7 +19,7 @@
 #define BLOCK (WAVE * COLS_PER_BLOCK)
 
 struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg segment, scalar loads)
-  int N, E, D, myN, myE, myD, nl, nlm1, ntr, maxk, nza, edge2D_in, ssh_maxnnz;
+  int N, E, EX, D, myN, myE, myD, nl, nlm1, ntr, maxk, nza, edge2D_in, ssh_maxnnz;   // EX = E + extended element halo
   // ---- connectivity, 0-based (-1 = none)
   const int *elem_nodes;      // (3,E)
   const int *edges;           // (2,D)
@@ -56,6 +56,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   double *sv_vals, *sv_dinv, *sv_b, *sv_r, *sv_r0, *sv_p, *sv_v, *sv_s, *sv_t, *sv_ph, *sv_x0, *sv_snap;
   int *sv_info; double *sv_resid;   // sv_info[0] iterations of the last solve, [1] number of stored previous solutions
   double *sv_scale;
+  double *sv_part, *sv_red, *sv_scal;   // partitioned solve: block partial sums, reduced sums, Krylov scalars (alpha, omega, beta)
   double *sv_h1, *sv_h2, *sv_h3; int sv_extrap;   // previous SSH solutions (extrapolated initial guess), only on the step path
   unsigned short *sv_cols;    // static ELL column pattern [k][NP] of the SSH operator (padding -> own row)
   fesom_params p;
@@ -208,3 +209,4 @@ void launch_dynamics_post(const DM &m, hipStream_t s);
 void launch_tracer(const DM &m, hipStream_t s, int tr);
 void launch_thickness(const DM &m, hipStream_t s);
 int  launch_named_toy(const DM &m, hipStream_t s, const char *name);
+int  launch_named_dsolve(const DM &m, hipStream_t s, const char *name);

@@ -11,7 +11,7 @@ struct TV {
          *adv_flux_hor, *adv_flux_raw, *flux_lo_hor, *diff_flux, *edge_up_dn_grad;
 };
 __device__ __forceinline__ TV tracer_view(const DM &m, int tr) {
-  size_t n1N = (size_t)m.nlm1 * m.N, nlN = (size_t)m.nl * m.N, n1E = (size_t)m.nlm1 * m.E, n1D = (size_t)m.nlm1 * m.D;
+  size_t n1N = (size_t)m.nlm1 * m.N, nlN = (size_t)m.nl * m.N, n1E = (size_t)m.nlm1 * m.EX, n1D = (size_t)m.nlm1 * m.D;
   TV t;
   t.del_ttf = m.del_ttf + tr * n1N; t.fct_LO = m.fct_LO + tr * n1N; t.fct_ttf_max = m.fct_ttf_max + tr * n1N;
   t.fct_ttf_min = m.fct_ttf_min + tr * n1N; t.fct_plus = m.fct_plus + tr * n1N; t.fct_minus = m.fct_minus + tr * n1N;
@@ -384,6 +384,8 @@ __global__ void __launch_bounds__(TH_BLOCK) k_tr_update(DM m, int tr0) {
   const TV t = tracer_view(m, tr);
   int n = col_id_th(), l = lane_id(), nz = l + 1;
   const bool valid = n < m.myN;                            // no early exit: the block meets at the barriers of the sweep
+  if (n >= m.myN && n < m.N && nz <= m.nlm1)               // halo columns: only tr_arr_old(:,:,tr) = tr_arr(:,:,tr) (whole-array copy, :274)
+    DTR(m.tr_arr_old, nz, n, tr) = DTR(m.tr_arr, nz, n, tr);
   if (!valid) n = m.myN - 1;
   const int nzmin = m.ulev_n[n], nzmax = m.nlev_n[n];
   const double dt = m.p.dt;
@@ -521,7 +523,7 @@ __global__ void __launch_bounds__(TH_BLOCK) k_tr_update(DM m, int tr0) {
 
 // tr >= 0: that tracer only; tr < 0: all tracers in one launch (grid.y), their chains are independent
 #define LAUNCH_COL(k, ncol, m_, tr_) hipLaunchKernelGGL(k, dim3(nblocks(ncol), (tr_) < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m_, (tr_) < 0 ? 0 : (tr_))
-#define LAUNCH_TRU(m_, tr_) hipLaunchKernelGGL(k_tr_update, dim3(nblocks_th(m.myN), (tr_) < 0 ? m.ntr : 1), dim3(TH_BLOCK), thomas_lds_bytes(m.nlm1, 1), s, m_, (tr_) < 0 ? 0 : (tr_))
+#define LAUNCH_TRU(m_, tr_) hipLaunchKernelGGL(k_tr_update, dim3(nblocks_th(m.N), (tr_) < 0 ? m.ntr : 1), dim3(TH_BLOCK), thomas_lds_bytes(m.nlm1, 1), s, m_, (tr_) < 0 ? 0 : (tr_))
 
 void launch_tracer(const DM &m, hipStream_t s, int tr) {   // tr 0-based
   LAUNCH_COL(k_tr_ab, m.N, m, tr);

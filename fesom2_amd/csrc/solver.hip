@@ -15,6 +15,7 @@
 // ~5k rows), own-row vectors are coalesced L2 traffic.  Dot products use a FIXED reduction order (1024 strided
 // partial sums, halving tree) that the CPU oracle reproduces: oracle and HIP agree bitwise.
 #include "dev.h"
+#include <string.h>
 
 #define ST 1024
 
@@ -386,4 +387,122 @@ int launch_solver(const DM &m, hipStream_t s, int fuse_rhs, int scale_done) {
     else hipLaunchKernelGGL(k_solver_glb<16>, dim3(1), dim3(ST), shm, s, m, dbg_maxits, tol2, NP);
   }
   return 0;
+}
+
+// =====================================================================================================================
+// Partitioned SSH solve (npes > 1): the same Jacobi-scaled BiCGstab, one short kernel per phase over the rank's owned
+// rows.  The host (fesom2_amd/parallel.py, or an MPI host behind the C ABI) exchanges the halo of the gathered vector
+// before each SpMV and all-reduces the partial sums after it; the Krylov scalars come back through sv_scal.
+// Reference: the row partition of psolve (src/psolve.c:16-115, part[]) and the halo exchange + MPI_Allreduce inside
+// pARMS' bicgstab_ras (lib/parms/src/bicgstab_ras.c:49-259).  Partial sums: per block, then over blocks in block order.
+// =====================================================================================================================
+#define DSB 256
+template <int NQ>
+__device__ __forceinline__ void ds_block_partials(double (&v)[NQ], double *part, int nblk) {
+  __shared__ double sh[NQ][DSB];
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < NQ; q++) sh[q][t] = v[q];
+  __syncthreads();
+  for (int s = DSB / 2; s >= 1; s >>= 1) {
+    if (t < s) {
+#pragma unroll
+      for (int q = 0; q < NQ; q++) sh[q][t] = sh[q][t] + sh[q][t + s];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) part[(size_t)q * nblk + blockIdx.x] = sh[q][0];
+  }
+}
+__global__ void k_ds_reduce(DM m, int nq, int nblk) {
+  int q = threadIdx.x;
+  if (q >= nq) return;
+  double a = 0.0;
+  for (int b = 0; b < nblk; b++) a = a + m.sv_part[(size_t)q * nblk + b];
+  m.sv_red[q] = a;
+}
+template <int W>
+__device__ __forceinline__ double ds_row(const DM &m, int NP, int i, const double *x) {
+  double a = 0.0;
+#pragma unroll
+  for (int k = 0; k < W; k++) a = a + m.sv_vals[(size_t)k * NP + i] * x[m.sv_cols[(size_t)k * NP + i]];
+  return a;
+}
+template <int W>
+__global__ void __launch_bounds__(DSB) k_ds_init(DM m, int NP, int nblk) {
+  int i = blockIdx.x * DSB + threadIdx.x;
+  double q[1] = {0.0};
+  if (i < m.myN) {
+    double ri = m.sv_b[i] - ds_row<W>(m, NP, i, m.sv_s);
+    m.sv_r[i] = ri; m.sv_r0[i] = ri; m.sv_v[i] = 0.0; m.sv_p[i] = m.sv_s[i]; m.sv_ph[i] = 0.0;
+    q[0] = ri * ri;
+  }
+  ds_block_partials<1>(q, m.sv_part, nblk);
+}
+__global__ void __launch_bounds__(DSB) k_ds_p(DM m) {             // p = r + beta (p - omega v)
+  int i = blockIdx.x * DSB + threadIdx.x;
+  if (i >= m.myN) return;
+  const double beta = m.sv_scal[2], omega = m.sv_scal[1];
+  m.sv_ph[i] = m.sv_r[i] + beta * (m.sv_ph[i] - omega * m.sv_v[i]);
+}
+template <int W>
+__global__ void __launch_bounds__(DSB) k_ds_spmv1(DM m, int NP, int nblk) {   // v = B p ; r0.v
+  int i = blockIdx.x * DSB + threadIdx.x;
+  double q[1] = {0.0};
+  if (i < m.myN) { double a = ds_row<W>(m, NP, i, m.sv_ph); m.sv_v[i] = a; q[0] = m.sv_r0[i] * a; }
+  ds_block_partials<1>(q, m.sv_part, nblk);
+}
+__global__ void __launch_bounds__(DSB) k_ds_s(DM m) {             // s = r - alpha v
+  int i = blockIdx.x * DSB + threadIdx.x;
+  if (i >= m.myN) return;
+  m.sv_s[i] = m.sv_r[i] - m.sv_scal[0] * m.sv_v[i];
+}
+template <int W>
+__global__ void __launch_bounds__(DSB) k_ds_spmv2(DM m, int NP, int nblk) {   // t = B s ; t.t, t.s, r0.t, s.s
+  int i = blockIdx.x * DSB + threadIdx.x;
+  double q[4] = {0.0, 0.0, 0.0, 0.0};
+  if (i < m.myN) {
+    double a = ds_row<W>(m, NP, i, m.sv_s), si = m.sv_s[i];
+    m.sv_t[i] = a;
+    q[0] = a * a; q[1] = a * si; q[2] = m.sv_r0[i] * a; q[3] = si * si;
+  }
+  ds_block_partials<4>(q, m.sv_part, nblk);
+}
+__global__ void __launch_bounds__(DSB) k_ds_update(DM m) {        // y += alpha p + omega s ; r = s - omega t
+  int i = blockIdx.x * DSB + threadIdx.x;
+  if (i >= m.myN) return;
+  const double alpha = m.sv_scal[0], omega = m.sv_scal[1];
+  double si = m.sv_s[i];
+  m.sv_r[i] = si - omega * m.sv_t[i];
+  m.sv_p[i] = (m.sv_p[i] + alpha * m.sv_ph[i]) + omega * si;
+}
+__global__ void __launch_bounds__(DSB) k_ds_finish(DM m) {        // x = D^-1 y
+  int i = blockIdx.x * DSB + threadIdx.x;
+  if (i < m.myN) m.d_eta[i] = m.sv_p[i] * (1.0 / m.sv_dinv[i]);
+  if (i == 0 && m.sv_extrap && m.sv_info[1] < 3) m.sv_info[1] = m.sv_info[1] + 1;
+}
+
+// named phases of the partitioned solve (fesom_gpu_call): ds_scale, ds_setup, ds_init, ds_p, ds_spmv1, ds_s, ds_spmv2,
+// ds_update, ds_finish
+int launch_named_dsolve(const DM &m, hipStream_t s, const char *name) {
+  if (strncmp(name, "ds_", 3)) return -1;
+  const int W = m.ssh_maxnnz <= 10 ? 10 : 16, NP = (m.myN + 63) / 64 * 64, nblk = (m.myN + DSB - 1) / DSB;
+  if (m.ssh_maxnnz > 16 || m.N >= 65536) return 1;
+#define DSW(k, ...) do { if (W == 10) hipLaunchKernelGGL(k<10>, dim3(nblk), dim3(DSB), 0, s, __VA_ARGS__); else hipLaunchKernelGGL(k<16>, dim3(nblk), dim3(DSB), 0, s, __VA_ARGS__); } while (0)
+  if (!strcmp(name, "ds_scale")) { launch_row_scale(m, s); return 0; }
+  if (!strcmp(name, "ds_setup")) {
+    if (W == 10) hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, 0);
+    else hipLaunchKernelGGL(k_solver_setup<16>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, 0);
+    return 0;
+  }
+  if (!strcmp(name, "ds_init")) { DSW(k_ds_init, m, NP, nblk); hipLaunchKernelGGL(k_ds_reduce, dim3(1), dim3(64), 0, s, m, 1, nblk); return 0; }
+  if (!strcmp(name, "ds_p")) { hipLaunchKernelGGL(k_ds_p, dim3(nblk), dim3(DSB), 0, s, m); return 0; }
+  if (!strcmp(name, "ds_spmv1")) { DSW(k_ds_spmv1, m, NP, nblk); hipLaunchKernelGGL(k_ds_reduce, dim3(1), dim3(64), 0, s, m, 1, nblk); return 0; }
+  if (!strcmp(name, "ds_s")) { hipLaunchKernelGGL(k_ds_s, dim3(nblk), dim3(DSB), 0, s, m); return 0; }
+  if (!strcmp(name, "ds_spmv2")) { DSW(k_ds_spmv2, m, NP, nblk); hipLaunchKernelGGL(k_ds_reduce, dim3(1), dim3(64), 0, s, m, 4, nblk); return 0; }
+  if (!strcmp(name, "ds_update")) { hipLaunchKernelGGL(k_ds_update, dim3(nblk), dim3(DSB), 0, s, m); return 0; }
+  if (!strcmp(name, "ds_finish")) { hipLaunchKernelGGL(k_ds_finish, dim3(nblk), dim3(DSB), 0, s, m); return 0; }
+  return -1;
 }

@@ -1,0 +1,193 @@
+"""Partitioned (multi-GPU) ocean step: one process per GPU, the reference's node partition, halo exchange at the
+reference's exchange points (src/gen_halo_exchange.F90; call sites listed below), partitioned SSH solve.
+
+The library (libfesom_gpu.so) packs / unpacks halos and runs the kernels; this host moves the bytes with
+`torch.distributed`: backend "nccl" = RCCL over xGMI directly on the device buffers, backend "gloo" = staging through host
+memory (used by the 2-rank tests, where both ranks may even share one GPU).  A Fortran/MPI host would drive the same C ABI
+phases and call MPI_Isend/Irecv on the device buffers instead.
+
+Sequence = `oce_timestep_ale` (src/oce_ale.F90:2556-2767) for the supported options, with the exchanges the reference
+performs where a later phase reads halo values:
+  Unode               exchange_nod   oce_dyn.F90:168            Unode_rhs   exchange_nod  oce_ale_vel_rhs.F90:330
+  U_b (V_b)           exchange_elem  oce_dyn.F90:613-614        U_c (V_c)   exchange_nod  oce_dyn.F90:636-637
+  SSH solve: halo of p, s per SpMV + all-reduce of the dot products (pARMS bicgstab_ras.c)
+  d_eta               exchange_nod   oce_ale.F90:2342           UV          exchange_elem oce_dyn.F90:130
+  ssh_rhs_old, hbar   exchange_nod   oce_ale.F90:1654,1663      Wvel, hnode_new exchange_nod oce_ale.F90:2135-2136
+  tr_xy               exchange_elem (full element halo) oce_tracer_mod.F90:68-72
+  fct_LO              exchange_nod   oce_adv_tra_driver.F90:134 fct_plus/minus exchange_nod oce_adv_tra_fct.F90:279
+  tr_arr              exchange_nod   oce_ale_tracer.F90:155
+(sw_alpha/beta need no exchange here: they are evaluated on halo nodes from the halo T, S; sigma_xy / neutral slope are
+leaves without GM/Redi and stay owned-only; Wvel_e, Wvel_i, eta_n, hbar_old travel with Wvel / hbar because the fused node
+kernel computes them for owned nodes only.)  Owned values do not depend on the partition except through the SSH solve, whose
+dot products are summed in a different order (agreement to the solver tolerance, like the reference across partitions).
+"""
+import ctypes as C
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .core import OceanCore
+from .mesh import Mesh
+
+NOD, ELEM, ELEM_FULL = 0, 1, 2
+TOL2 = 1e-10 * 1e-10
+MAXITS = 2000
+
+
+def run_step(core, par, X, solve, first, probe=None):
+    """One step, phase by phase (kernel names of libfesom_gpu.so).  X(kind, fields) = halo exchange, solve() = SSH solve;
+    `probe(label)` (optional) is called after the phases whose results the tests compare across partitions."""
+    c, p = core.call, par
+    P = probe if probe is not None else (lambda label: None)
+    c("first_step", 1 if first else 0)
+    c("k_vel_nodes"); X(NOD, ["Unode"]); P("vel_nodes")
+    c("k_pressure_bv"); c("k_pgf"); c("k_sigma_slope"); P("pressure")
+    if p.mix_scheme == 2:
+        c("k_pp_node_raw"); c("k_pp_elem"); c("k_pp_node_final"); P("mixing")
+    c("k_momadv_node"); X(NOD, ["Unode_rhs"])
+    c("k_vel_rhs"); P("vel_rhs")
+    c("k_visc_elem"); X(ELEM, ["U_b"])
+    c("k_visc_node"); X(NOD, ["U_c"])
+    c("k_impl_visc"); P("impl_visc")
+    if p.which_ale != 0:
+        c("k_stiff_update")
+    c("k_edge_transport"); c("k_ssh_rhs_node"); P("ssh_rhs")
+    solve(); X(NOD, ["d_eta"]); P("solve")
+    c("k_update_vel"); X(ELEM, ["UV"])
+    c("k_edge_transport1"); c("k_vert_vel_hbar")
+    X(NOD, ["Wvel", "Wvel_e", "Wvel_i", "hnode_new", "hbar", "hbar_old", "eta_n", "ssh_rhs_old"])
+    c("k_dhe"); P("vert_vel")
+    c("k_tr_ab", 0); c("k_tr_grad_elem", 0); X(ELEM_FULL, ["tr_xy_ab"])
+    c("k_updn_grad", 0)
+    if p.with_diffusion:
+        c("k_diff_flux", 0)
+    c("k_tr_z", 0)
+    c("k_flux_hor", 0); c("k_fct_lo_node", 0); X(NOD, ["fct_LO"])
+    c("k_fct_node", 0); X(NOD, ["fct_plus", "fct_minus"])
+    c("k_fct_edge_limit", 0); c("k_tr_update", 0); X(NOD, ["tr_arr"]); P("tracers")
+    c("k_thick_node"); c("k_thick_elem"); P("thickness")
+
+
+class _DevBuf:
+    """device buffer exposed to torch through __cuda_array_interface__ (no copy)"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+class HaloExchanger:
+    def __init__(self, core):
+        self.lib = core.lib
+        lib = self.lib
+        lib.fesom_gpu_halo_info.argtypes = [C.c_int] + [C.POINTER(C.c_int)] * 8
+        lib.fesom_gpu_halo_pack.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+        lib.fesom_gpu_halo_unpack.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_char_p)]
+        lib.fesom_gpu_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int]
+        self.device = dist.get_backend() == "nccl"
+        self.info = []
+        for kind in range(3):
+            npes, mype, nr, ns = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            rPE, rc, sPE, sc = ((C.c_int * 64)() for _ in range(4))
+            rcode = lib.fesom_gpu_halo_info(kind, C.byref(npes), C.byref(mype), C.byref(nr), rPE, rc, C.byref(ns), sPE, sc)
+            assert rcode == 0, lib.fesom_gpu_last_error().decode()
+            self.info.append(dict(rPE=list(rPE[: nr.value]), rcnt=list(rc[: nr.value]), sPE=list(sPE[: ns.value]), scnt=list(sc[: ns.value])))
+        self.npes, self.mype = npes.value, mype.value
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self.lib.fesom_gpu_last_error().decode()}")
+
+    def exchange(self, kind, names):
+        inf = self.info[kind]
+        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        sp, rp, W = C.c_void_p(), C.c_void_p(), C.c_int()
+        self._chk(self.lib.fesom_gpu_halo_pack(kind, len(names), arr, C.byref(sp), C.byref(rp), C.byref(W)), "halo_pack")
+        W = W.value
+        ns, nr = sum(inf["scnt"]) * W, sum(inf["rcnt"]) * W
+        if self.device:                       # RCCL directly on the device buffers
+            send = torch.as_tensor(_DevBuf(sp.value, max(ns, 1)), device="cuda")
+            recv = torch.as_tensor(_DevBuf(rp.value, max(nr, 1)), device="cuda")
+        else:                                 # host staging (gloo)
+            send_h, recv_h = np.empty(max(ns, 1)), np.empty(max(nr, 1))
+            if ns:
+                self._chk(self.lib.fesom_gpu_copy(send_h.ctypes.data, sp, ns * 8, 0), "copy d2h")
+            send, recv = torch.from_numpy(send_h), torch.from_numpy(recv_h)
+        ops, off = [], 0
+        for pe, cnt in zip(inf["rPE"], inf["rcnt"]):
+            ops.append(dist.P2POp(dist.irecv, recv[off: off + cnt * W], pe)); off += cnt * W
+        off = 0
+        for pe, cnt in zip(inf["sPE"], inf["scnt"]):
+            ops.append(dist.P2POp(dist.isend, send[off: off + cnt * W], pe)); off += cnt * W
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+        if self.device:
+            torch.cuda.current_stream().synchronize()
+        elif nr:
+            self._chk(self.lib.fesom_gpu_copy(rp, recv_h.ctypes.data, nr * 8, 1), "copy h2d")
+        self._chk(self.lib.fesom_gpu_halo_unpack(kind, len(names), arr), "halo_unpack")
+
+
+class PartitionedCore:
+    """One rank of a partitioned run.  `torch.distributed` must be initialised (rank = partition index)."""
+
+    def __init__(self, meshdir, params, **mesh_kw):
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.mesh = Mesh.load(meshdir, npes=self.world, mype=self.rank, **mesh_kw)
+        self.par = params
+        self.core = OceanCore(self.mesh, params)
+        self.halo = HaloExchanger(self.core)
+        self.first = True
+        self.solver_iterations = 0
+        self.red_dev = torch.zeros(4, dtype=torch.float64, device="cuda") if dist.get_backend() == "nccl" else None
+
+    # -- global sums of the partial dot products
+    def _allreduce(self, n):
+        v = self.core.get("sv_red", 8)[:n].copy()
+        if self.red_dev is not None:
+            t = self.red_dev[:n]; t.copy_(torch.from_numpy(v)); dist.all_reduce(t); return t.cpu().numpy()
+        t = torch.from_numpy(v); dist.all_reduce(t); return t.numpy()
+
+    def _scal(self, alpha, omega, beta):
+        self.core.set("sv_scal", np.array([alpha, omega, beta, 0.0]))
+
+    def solve_ssh(self):
+        """Jacobi-scaled BiCGstab over the partitioned rows (same recurrences as the single-GPU kernel, solver.hip)."""
+        c, X = self.core.call, self.halo.exchange
+        c("ds_scale"); X(NOD, ["sv_dinv"])
+        c("ds_setup"); X(NOD, ["sv_s"])
+        c("ds_init")
+        rr = float(self._allreduce(1)[0])
+        rho_new, rho, alpha, omega, it = rr, 1.0, 1.0, 1.0, 0
+        if rr >= TOL2:
+            self._scal(alpha, omega, (rho_new / rho) * (alpha / omega)); c("ds_p")
+        while rr >= TOL2 and it < MAXITS:
+            X(NOD, ["sv_ph"]); c("ds_spmv1")
+            alpha = rho_new / float(self._allreduce(1)[0])
+            self._scal(alpha, omega, 0.0); c("ds_s")
+            X(NOD, ["sv_s"]); c("ds_spmv2")
+            tt, ts, r0t, ss = (float(x) for x in self._allreduce(4))
+            omega = ts / tt if tt > 0.0 else 0.0
+            rho, rho_new = rho_new, -omega * r0t
+            rr = ss - omega * (2.0 * ts - omega * tt)
+            it += 1
+            self._scal(alpha, omega, 0.0); c("ds_update")
+            if rr >= TOL2 and it < MAXITS:
+                self._scal(alpha, omega, (rho_new / rho) * (alpha / omega)); c("ds_p")
+        c("ds_finish")
+        self.solver_iterations = it
+
+    def step(self, n=1, probe=None):
+        run_step(self.core, self.par, self.halo.exchange, self.solve_ssh, self.first, probe)
+        self.first = False
+
+    def owned(self, name, width):
+        """(global ids, values) of the owned part of a node field with `width` values per node"""
+        n = self.mesh.myDim_nod2D
+        N = n + self.mesh.eDim_nod2D
+        a = self.core.get(name, N * width).reshape(N, width)
+        return self.mesh.myList_nod2D[:n].copy(), a[:n].copy()
+
+    def close(self):
+        self.core.close()

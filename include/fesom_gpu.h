@@ -152,6 +152,19 @@ double fesom_gpu_last_solver_residual(void);
 int  fesom_gpu_kernel_time_ms(const char *kernel_group, int nrep, double *ms_per_launch);
 const char *fesom_gpu_last_error(void);
 
+/* Halo exchange (multi-GPU, one rank per GPU; reference: exchange_nod / exchange_elem, src/gen_halo_exchange.F90:58-1035,
+ * lists = com_struct of fesom_part_desc).  The library packs and unpacks on the device, the HOST moves the bytes between
+ * ranks (MPI_Isend/Irecv on the device buffers in a Fortran/MPI host; torch.distributed in this repository's Python host).
+ * kind: 0 com_nod2D, 1 com_elem2D, 2 com_elem2D_full.  Fields exchanged at the same point of the step share one message
+ * per neighbour: block of neighbour p = count(p) * values_per_item doubles, blocks consecutive in sPE (send) / rPE (recv)
+ * order.  With npes > 1 the step is driven phase by phase through fesom_gpu_call (kernel names "k_*", partitioned SSH solve
+ * "ds_*"); the sequence with its exchange points is fesom2_amd/parallel.py. */
+int  fesom_gpu_halo_info(int kind, int *npes, int *mype, int *nr, int *rPE, int *rcnt, int *ns, int *sPE, int *scnt);
+int  fesom_gpu_halo_pack(int kind, int nfields, const char *const *names, void **send_dev, void **recv_dev, int *values_per_item);
+int  fesom_gpu_halo_unpack(int kind, int nfields, const char *const *names);
+int  fesom_gpu_copy(void *dst, const void *src, long long bytes, int dir);   /* 0: device->host, 1: host->device */
+int  fesom_gpu_sync(void);
+
 /* SSH solver with the reference's own C signatures (src/psolve.c:16,117,152;
  * Fortran interface blocks src/oce_ale.F90:2272-2291).  All by reference,
  * 0-based CSR, part[0..npes] prefix of owned rows.  fcomm is ignored on one GPU. */

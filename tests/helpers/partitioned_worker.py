@@ -1,0 +1,112 @@
+"""Worker of tests/test_gpu_partitioned.py (one process per rank, torch.distributed "gloo", all ranks may share GPU 0).
+Each rank first runs the SINGLE-partition step on the whole pi mesh (phase by phase, same kernel sequence) and records the
+global fields after every phase, then runs its part of the partitioned step and compares its OWNED values:
+  * step 1 up to the SSH right-hand side: bit for bit (no global reduction involved yet);
+  * everything after the SSH solve and the state after NSTEPS steps: to the solver tolerance (the partitioned dot products
+    are summed in another order, exactly like the reference run on another number of ranks)."""
+import json, os, sys
+import numpy as np
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+from fesom2_amd.mesh import Mesh
+from fesom2_amd.config import make_params
+from fesom2_amd.core import OceanCore
+from fesom2_amd.synthetic import analytic_ts
+from fesom2_amd import parallel
+
+PI = os.path.join(REPO, "tests", "golden", "meshes", "pi")
+NSTEPS = int(os.environ.get("PART_NSTEPS", "4"))
+# (field, kind, values per item as multiple of nl-1 / nl / 1)
+NODE3 = ["Unode", "density_m_rho0", "Unode_rhs", "U_c", "hnode_new", "hnode"]
+PROBES = {
+    "vel_nodes": [("Unode", "n", "2*n1")],
+    "pressure": [("density_m_rho0", "n", "n1"), ("bvfreq", "n", "nl"), ("pgf_x", "e", "n1"), ("pgf_y", "e", "n1")],
+    "mixing": [("Kv", "n", "nl"), ("Av", "e", "nl")],
+    "vel_rhs": [("UV_rhs", "e", "2*n1"), ("UV_rhsAB", "e", "2*n1")],
+    "impl_visc": [("UV_rhs", "e", "2*n1"), ("U_b", "e", "2*n1"), ("U_c", "n", "2*n1")],
+    "ssh_rhs": [("ssh_rhs", "n", "1"), ("ssh_values", "z", "1")],
+    "solve": [("d_eta", "n", "1")],
+    "vert_vel": [("UV", "e", "2*n1"), ("eta_n", "n", "1"), ("hbar", "n", "1"), ("Wvel", "n", "nl"), ("hnode_new", "n", "n1"), ("dhe", "e", "1")],
+    "tracers": [("tr_arr", "t", "n1"), ("fct_LO", "n", "n1")],
+    "thickness": [("hnode", "n", "n1"), ("helem", "e", "n1"), ("zbar_3d_n", "n", "nl")],
+}
+
+
+def widths(mesh):
+    n1 = mesh.nl - 1
+    return {"n1": n1, "nl": mesh.nl, "2*n1": 2 * n1, "1": 1}
+
+
+def grab(core, mesh, label, store, step):
+    W = widths(mesh)
+    N = mesh.myDim_nod2D + mesh.eDim_nod2D
+    E = mesh.myDim_elem2D + mesh.eDim_elem2D
+    for f, kind, w in PROBES[label]:
+        w = W[w]
+        if kind == "n":
+            a = core.get(f, N * w).reshape(N, w)
+        elif kind == "e":
+            a = core.get(f, E * w).reshape(E, w)
+        elif kind == "t":
+            a = core.get(f, 2 * N * w).reshape(2, N, w)
+        else:
+            a = core.get(f, mesh.ssh_nza)
+        store[(step, label, f)] = a
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    par = make_params(dt=900.0)
+    T, S = analytic_ts(PI)
+    # ---- single partition (whole mesh) on this rank
+    gm = Mesh.load(PI, dt=900.0)
+    st = gm.initial_state(2); st.tr_arr[0], st.tr_arr[1] = T, S; st.tr_arr_old[...] = st.tr_arr
+    g = OceanCore(gm, par); g.upload_state(st)
+    ref = {}
+    first = True
+    for n in range(1, NSTEPS + 1):
+        parallel.run_step(g, par, lambda kind, names: None, lambda: g.call("solve_ssh"), first, lambda lab, n=n: grab(g, gm, lab, ref, n))
+        first = False
+    g.close()
+    # ---- this rank's partition
+    pc = parallel.PartitionedCore(PI, par, dt=900.0)
+    lm = pc.mesh
+    ln = lm.myList_nod2D - 1
+    st = lm.initial_state(2); st.tr_arr[0], st.tr_arr[1] = T[ln], S[ln]; st.tr_arr_old[...] = st.tr_arr
+    pc.core.upload_state(st)
+    mine = {}
+    for n in range(1, NSTEPS + 1):
+        pc.step(n, probe=lambda lab, n=n: grab(pc.core, lm, lab, mine, n))
+    myN, myE = lm.myDim_nod2D, lm.myDim_elem2D
+    le = lm.myList_elem2D - 1
+    report = {"rank": rank, "bitwise_fail": [], "maxdiff": {}, "iters": pc.solver_iterations}
+    pre_solver = ("vel_nodes", "pressure", "mixing", "vel_rhs", "impl_visc", "ssh_rhs")
+    for (step, label, f), a in mine.items():
+        r = ref[(step, label, f)]
+        if f == "ssh_values":
+            continue
+        if a.ndim == 3:
+            a, r = a[:, :myN], r[:, ln[:myN]]
+        elif a.shape[0] == myN + lm.eDim_nod2D:
+            a, r = a[:myN], r[ln[:myN]]
+        else:
+            a, r = a[:myE], r[le[:myE]]
+        d = float(np.abs(a - r).max()) if a.size else 0.0
+        if step == 1 and label in pre_solver:
+            eq = (a.view(np.int64) == r.view(np.int64)) | ((a == 0) & (r == 0))
+            if not eq.all():
+                report["bitwise_fail"].append(f"{label}:{f} {int((~eq).sum())}/{eq.size} max {d:.3e}")
+        key = f"{label}:{f}"
+        report["maxdiff"][key] = max(report["maxdiff"].get(key, 0.0), d)
+    # halo consistency at the end: halo values of T equal the owners' values
+    Tfin = mine[(NSTEPS, "tracers", "tr_arr")]
+    report["halo_T_maxdiff"] = float(np.abs(Tfin[:, myN:] - ref[(NSTEPS, "tracers", "tr_arr")][:, ln[myN:]]).max()) if lm.eDim_nod2D else 0.0
+    pc.close()
+    sys.stdout.write("PARTREPORT " + json.dumps(report) + chr(10)); sys.stdout.flush()
+    dist.destroy_process_group()
+
+
+main()

@@ -1,0 +1,31 @@
+"""GPU: the partitioned step (fesom2_amd/parallel.py: reference node partition, halo exchange at the reference's exchange
+points, partitioned SSH solve) against the single-partition step, with world_size 2 and 4 on the gloo backend (host-staged
+transport; the ranks share the one GPU of the test box).  See tests/helpers/partitioned_worker.py for what is compared."""
+import json
+import os
+import re
+import subprocess
+import sys
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_partitioned_step_matches_single_partition(built, world):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", FESOM_GPU_DEVICE="0", PART_NSTEPS="4")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                        "--master-port", str(29620 + world), os.path.join(REPO, "tests", "helpers", "partitioned_worker.py")],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    reps = [json.loads(x) for x in re.findall(r"PARTREPORT (\{.*\})", r.stdout)]
+    assert len(reps) == world
+    for rep in reps:
+        assert not rep["bitwise_fail"], rep["bitwise_fail"]          # step 1 up to the SSH rhs: bit for bit
+        md = rep["maxdiff"]
+        assert md["solve:d_eta"] < 5e-9, md                            # both solves stop at ||scaled residual|| < 1e-10
+        assert md["vert_vel:eta_n"] < 1e-8 and md["tracers:tr_arr"] < 1e-8 and md["vert_vel:UV"] < 1e-8, md
+        assert md["thickness:hnode"] < 1e-8, md
+        assert rep["halo_T_maxdiff"] < 1e-8
+        assert 5 < rep["iters"] < 60
