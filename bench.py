@@ -23,6 +23,7 @@ import os
 import subprocess
 import sys
 import time
+import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
@@ -96,16 +97,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    os.environ.setdefault("FESOM_GPU_DEVICE", str(local_rank))
-
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    local_rank %= max(1, torch.cuda.device_count())        # (identity on a node with >= N GPUs; lets N ranks rehearse on one GPU)
+    os.environ.setdefault("FESOM_GPU_DEVICE", str(local_rank))
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        # a wedged point-to-point in the partitioned leg must raise (and fall back to the replicas line), not abort the job
+        os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+        dist.init_process_group(backend=os.environ.get("FESOM_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)   # (gloo: 1-GPU rehearsal)
 
     import __graft_entry__ as ge
     if rank == 0 and not os.path.exists(os.path.join(REPO, "fesom2_amd", "libfesom_gpu.so")):
@@ -146,8 +150,51 @@ def main():
     sps = elapsed / args.steps
     sypd_one = 86400.0 / (STEPS_PER_YEAR * sps)
 
+    # ---- N > 1: additionally ONE simulation partitioned over the N GPUs (reference node partition, halo exchange over
+    # RCCL, partitioned SSH solve; fesom2_amd/parallel.py).  pi has 3140 surface nodes, i.e. ~390 per GPU at N = 8: the step
+    # is launch/latency-bound and every one of its ~110 exchanges costs more than the kernels between them, so this leg is
+    # reported next to the replicas line, not instead of it.  Any failure here leaves the replicas line intact.
+    partitioned = None
+    if world > 1 and os.environ.get("FESOM_BENCH_PARTITIONED", "1") != "0":
+        core.close()
+        try:
+            import datetime
+            from fesom2_amd import parallel
+            pg = dist.new_group(timeout=datetime.timedelta(seconds=90))
+            pc = parallel.PartitionedCore(pi, par, group=pg, dt=900.0)
+            ln = pc.mesh.myList_nod2D - 1
+            T0, S0 = analytic_ts(pi)
+            lst = pc.mesh.initial_state(2)
+            lst.tr_arr[0], lst.tr_arr[1] = T0[ln], S0[ln]
+            lst.tr_arr_old[...] = lst.tr_arr
+            pc.core.upload_state(lst)
+            pw, pk = 5, max(10, min(100, args.steps))
+            for n in range(1, pw + 1):
+                pc.step(n)
+            torch.cuda.synchronize(); dist.barrier(group=pg)
+            tp = time.perf_counter()
+            for n in range(pw + 1, pw + pk + 1):
+                pc.step(n)
+            pc.core.lib.fesom_gpu_sync(); torch.cuda.synchronize(); dist.barrier(group=pg)
+            pel = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device="cuda")
+            dist.all_reduce(pel, op=dist.ReduceOp.MAX, group=pg)
+            psps = float(pel.item()) / pk
+            eta_own = pc.owned("eta_n", 1)[1]
+            assert np.isfinite(eta_own).all()
+            partitioned = {"ms_per_step": round(psps * 1e3, 4), "value": round(86400.0 / (STEPS_PER_YEAR * psps), 2), "unit": "simulated_years/day",
+                           "scaling": "strong", "steps": pk, "warmup": pw, "solver_iterations": pc.solver_iterations, "transport": "rccl (torch.distributed nccl)" if dist.get_backend() == "nccl" else "gloo, host-staged",
+                           "owned_nodes_per_gpu": int(pc.mesh.myDim_nod2D), "error": None}
+            pc.close()
+        except Exception as e:          # noqa: BLE001 - keep the replicas line whatever happens in this leg
+            partitioned = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if rank != 0:
+            os._exit(0)                 # no further collective: rank 0 finishes the report alone
+        core = OceanCore(mesh, par)
+        core.upload_state(st)
+        core.run_steps(1, 60)
+        torch.cuda.synchronize()
+
     if rank == 0:
-        import numpy as np
         eta = core.get("eta_n", mesh.myDim_nod2D)
         T = core.get("tr_arr", 2 * mesh.myDim_nod2D * (mesh.nl - 1))
         assert np.isfinite(eta).all() and np.isfinite(T).all(), "model state blew up"
@@ -186,10 +233,15 @@ def main():
                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "pi mesh (3140 nodes, 5839 elements, 47 layers), T/S tracers, zstar ALE, JM EOS, PP mixing, "
                                       "MFCT/QR4C/FCT advection, no sea ice, no GM/Redi", "steps_per_day": 96,
-                          "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (halo exchange not built)",
+                          "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (value); one simulation partitioned over the {world} GPUs is timed in 'partitioned'",
                           "wet_cells": {"N3": N3, "E3": E3, "D3": D3}},
                "roofline": roofline, "cpu_baseline": cpu}
+        if world > 1:
+            out["partitioned"] = partitioned
         print(json.dumps(out), flush=True)
+    if world > 1 and partitioned is not None:
+        sys.stdout.flush()
+        os._exit(0)                     # the other ranks left after the partitioned leg
     barrier()
     core.close()
     if world > 1:

@@ -77,7 +77,8 @@ class _DevBuf:
 
 
 class HaloExchanger:
-    def __init__(self, core):
+    def __init__(self, core, group=None):
+        self.group = group
         self.lib = core.lib
         lib = self.lib
         lib.fesom_gpu_halo_info.argtypes = [C.c_int] + [C.POINTER(C.c_int)] * 8
@@ -115,10 +116,10 @@ class HaloExchanger:
             send, recv = torch.from_numpy(send_h), torch.from_numpy(recv_h)
         ops, off = [], 0
         for pe, cnt in zip(inf["rPE"], inf["rcnt"]):
-            ops.append(dist.P2POp(dist.irecv, recv[off: off + cnt * W], pe)); off += cnt * W
+            ops.append(dist.P2POp(dist.irecv, recv[off: off + cnt * W], pe, self.group)); off += cnt * W
         off = 0
         for pe, cnt in zip(inf["sPE"], inf["scnt"]):
-            ops.append(dist.P2POp(dist.isend, send[off: off + cnt * W], pe)); off += cnt * W
+            ops.append(dist.P2POp(dist.isend, send[off: off + cnt * W], pe, self.group)); off += cnt * W
         if ops:
             for r in dist.batch_isend_irecv(ops):
                 r.wait()
@@ -132,12 +133,13 @@ class HaloExchanger:
 class PartitionedCore:
     """One rank of a partitioned run.  `torch.distributed` must be initialised (rank = partition index)."""
 
-    def __init__(self, meshdir, params, **mesh_kw):
+    def __init__(self, meshdir, params, group=None, **mesh_kw):
+        self.group = group
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.mesh = Mesh.load(meshdir, npes=self.world, mype=self.rank, **mesh_kw)
         self.par = params
         self.core = OceanCore(self.mesh, params)
-        self.halo = HaloExchanger(self.core)
+        self.halo = HaloExchanger(self.core, group)
         self.first = True
         self.solver_iterations = 0
         self.red_dev = torch.zeros(4, dtype=torch.float64, device="cuda") if dist.get_backend() == "nccl" else None
@@ -146,8 +148,8 @@ class PartitionedCore:
     def _allreduce(self, n):
         v = self.core.get("sv_red", 8)[:n].copy()
         if self.red_dev is not None:
-            t = self.red_dev[:n]; t.copy_(torch.from_numpy(v)); dist.all_reduce(t); return t.cpu().numpy()
-        t = torch.from_numpy(v); dist.all_reduce(t); return t.numpy()
+            t = self.red_dev[:n]; t.copy_(torch.from_numpy(v)); dist.all_reduce(t, group=self.group); return t.cpu().numpy()
+        t = torch.from_numpy(v); dist.all_reduce(t, group=self.group); return t.numpy()
 
     def _scal(self, alpha, omega, beta):
         self.core.set("sv_scal", np.array([alpha, omega, beta, 0.0]))
