@@ -88,6 +88,7 @@ def make(cfg, outname):
 def main():
     make("pi_pp", "pi_pp_reference.npz")
     make("souf", "souf_reference.npz")
+    make("souf_linfs", "souf_linfs_reference.npz")      # linear free surface, full cells
     # known answers of the reference's own CI
     rd, rc, lines = run_ref.run("souf", 8, 72, mode="step", mean=True, dump_mesh=False)
     means = {l.split()[1]: float(l.split()[2]) for l in lines if l.startswith("ORACLE_MEAN")}

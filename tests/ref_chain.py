@@ -42,7 +42,8 @@ def run_reference_chain(orc, mesh, g, steps=(1, 2, 3), toy=False, skip=()):
         orc.call("compute_vel_rhs"); chk(step, "UV_rhs", "compute_vel_rhs.UV_rhs", "e2"); chk(step, "UV_rhsAB", "compute_vel_rhs.UV_rhsAB", "e2")
         orc.call("visc_filt_bcksct"); chk(step, "UV_rhs", "viscosity_filter.UV_rhs", "e2")
         orc.call("impl_vert_visc_ale"); chk(step, "UV_rhs", "impl_vert_visc_ale.UV_rhs", "e2")
-        orc.call("update_stiff_mat_ale")
+        if orc.params.which_ale != 0:
+            orc.call("update_stiff_mat_ale")
         orc.call("compute_ssh_rhs_ale"); chk(step, "ssh_rhs", "compute_ssh_rhs_ale.ssh_rhs")
         orc.call("solve_ssh")
         ref = g[f"s{step}/full.d_eta"]

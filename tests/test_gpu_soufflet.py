@@ -60,6 +60,34 @@ def test_soufflet_chain_bitwise(setup):
     assert gpu.solver_iterations == orc.solver_iterations
 
 
+def test_soufflet_linfs_chain_bitwise(built):
+    """linear free surface + full cells on the same channel (pinned against the reference in tests/test_soufflet.py)"""
+    from fesom2_amd.core import OceanCore
+    from oracle_lib import Oracle
+    mesh, par, st, aux = soufflet_setup("linfs", False)
+    gpu = OceanCore(mesh, par)
+    orc = Oracle(mesh, par)
+    gpu.upload_state(st); orc.set_state(st)
+    for k in ("Tclim", "Uclim"):
+        gpu.set(k, aux[k]); orc.set(k, aux[k])
+    orc.call("compute_zonal_mean_ini")
+    gpu.call("compute_zonal_mean"); orc.call("compute_zonal_mean")
+    failures = []
+    for step in range(1, 3):
+        for routine, arg, fields in toy_chain():
+            if routine == "update_stiff_mat_ale":
+                continue
+            gpu.call(routine, arg); orc.call(routine, arg)
+            for f in fields:
+                ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+                if not ok:
+                    failures.append(f"step {step} {routine}({arg}) {msg}")
+        if failures:
+            break
+    gpu.close()
+    assert not failures, "\n".join(failures[:10])
+
+
 def test_soufflet_known_answer(setup):
     """fresh start, 72 steps (1 day): time means of T, S, u, v == the reference CI's fcheck values; HIP == oracle bitwise"""
     from fesom2_amd import toy_soufflet

@@ -22,12 +22,12 @@ DT = 1200.0
 TOL = {"temp": 2e-13, "sst": 2e-13, "salt": 1e-15, "u": 2e-9, "v": 2e-8}
 
 
-def soufflet_setup():
+def soufflet_setup(which_ale="zstar", partial=True):
     from fesom2_amd.mesh import Mesh
     from fesom2_amd.config import make_params
     from fesom2_amd import toy_soufflet
-    mesh = Mesh.load(SOUF, which_ale="zstar", use_partial_cell=True, force_rotation=False, cyclic_length_deg=4.5, dt=DT, K_hor=10.0)
-    par = make_params(dt=DT, which_ale="zstar", use_partial_cell=True, state_equation=0, mix_scheme="PP", with_diffusion=True,
+    mesh = Mesh.load(SOUF, which_ale=which_ale, use_partial_cell=partial, force_rotation=False, cyclic_length_deg=4.5, dt=DT, K_hor=10.0)
+    par = make_params(dt=DT, which_ale=which_ale, use_partial_cell=partial, state_equation=0, mix_scheme="PP", with_diffusion=True,
                       toy_soufflet=True, K_hor=10.0, cyclic_length_deg=4.5)
     st = mesh.initial_state(2)
     aux = toy_soufflet.initial_state(mesh, st)
@@ -73,6 +73,25 @@ def test_oracle_chain_bitwise_soufflet(env):
     # next to the partition boundary of the 2-rank reference run (edge order of the local numbering); UV after update_vel
     # and everything later is bit-identical again
     skip = {(1, "viscosity_filter.UV_rhs"), (1, "impl_vert_visc_ale.UV_rhs"), (1, "relax_zonal_vel.UV_rhs")}
+    bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3), toy=True, skip=skip)
+    orc.lib.orc_toy_set_partition(None, 0)
+    assert not bad, "\n".join(bad[:20])
+
+
+def test_oracle_chain_bitwise_soufflet_linfs(built):
+    """the same channel with the linear free surface and full cells (which_ALE='linfs', use_partial_cell=.false.):
+    pins the linfs branches (hpressure / fullcell PGF, W without layer motion) against a reference run"""
+    from oracle_lib import Oracle
+    from ref_chain import run_reference_chain
+    mesh, par, st, aux = soufflet_setup("linfs", False)
+    orc = Oracle(mesh, par)
+    orc.set_state(st)
+    orc.set("Tclim", aux["Tclim"]); orc.set("Uclim", aux["Uclim"])
+    g = gold("souf_linfs")
+    owner = np.ascontiguousarray(g["toy/owner"], dtype=np.int32)
+    orc.lib.orc_toy_set_partition(owner.ctypes.data_as(C.POINTER(C.c_int)), int(g["toy/nranks"][0]))
+    orc.call("compute_zonal_mean_ini"); orc.call("compute_zonal_mean")
+    skip = {(1, "viscosity_filter.UV_rhs"), (1, "impl_vert_visc_ale.UV_rhs"), (1, "relax_zonal_vel.UV_rhs")}   # see above
     bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3), toy=True, skip=skip)
     orc.lib.orc_toy_set_partition(None, 0)
     assert not bad, "\n".join(bad[:20])
