@@ -215,8 +215,19 @@ def main():
         dom = max((k for k in share if k != "k_solver"), key=lambda k: share[k])
         achieved = kbytes[dom] / times[dom] / 1e9
         step_bytes = 8.0 * ((77 * N3 + 67 * E3) + 2 * (77 * N3 + 16 * E3 + 16 * D3))       # 0.405 GB on pi
+        # HBM-side bytes per launch of that kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes,
+        # gfx950 correction): they cannot be read from inside the process, so they come from the committed summary of the
+        # last profiled run of this same command (tools/pmc_summary.py -> profiles/*pmc_summary.json); null when absent
+        traffic = None
+        try:
+            import glob
+            pm = sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_summary.json")))
+            if pm:
+                traffic = json.load(open(pm[-1]))["kernels"][dom]["traffic_bytes_min"]      # one tracer per launch, like times[dom]
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "kernel_us": round(times[dom] * 1e6, 2), "algorithmic_bytes_per_launch": kbytes[dom],
                     "whole_step": {"algorithmic_GB_per_step": round(step_bytes / 1e9, 4),
                                    "achieved_GBs": round(step_bytes / sps / 1e9, 1),
