@@ -79,7 +79,14 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // one wavefront = one column: the column index is wave-uniform, say so to the compiler (scalar loads / scalar address math)
-__device__ __forceinline__ int col_id() { return __builtin_amdgcn_readfirstlane(blockIdx.x * COLS_PER_BLOCK + (threadIdx.x >> 6)); }
+// Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with its own L2.  Consecutive columns are
+// neighbours on the mesh (partition-sorted numbering) and share most of their gathers, so every XCD gets a CONTIGUOUS range
+// of column blocks instead of every 8th one: bijective remap of blockIdx.x, affinity for speed only (nothing relies on it).
+__device__ __forceinline__ int xcd_block() {
+  const unsigned b = blockIdx.x, nb = gridDim.x, q = nb >> 3, r = nb & 7u, x = b & 7u, j = b >> 3;
+  return (int)(x * q + (x < r ? x : r) + j);
+}
+__device__ __forceinline__ int col_id() { return __builtin_amdgcn_readfirstlane(xcd_block() * COLS_PER_BLOCK + (threadIdx.x >> 6)); }
 // broadcast of lane `src`; src must be wave-uniform (it always is a level index of the wave's column): v_readlane, no LDS
 __device__ __forceinline__ double bcast(double x, int src) {
   int lo = __builtin_amdgcn_readlane(__double2loint(x), src), hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
@@ -121,7 +128,7 @@ __device__ __forceinline__ double dmax_(double a, double b) { return a > b ? a :
 #define TH_COLS 8
 #define TH_CP (TH_COLS + 1)
 #define TH_BLOCK (WAVE * TH_COLS)
-__device__ __forceinline__ int col_id_th() { return __builtin_amdgcn_readfirstlane(blockIdx.x * TH_COLS + (threadIdx.x >> 6)); }
+__device__ __forceinline__ int col_id_th() { return __builtin_amdgcn_readfirstlane(xcd_block() * TH_COLS + (threadIdx.x >> 6)); }
 static inline size_t thomas_lds_bytes(int nlm1, int nrhs) { return (size_t)(3 + nrhs) * nlm1 * TH_CP * sizeof(double) + 2 * TH_COLS * sizeof(int); }
 static inline int nblocks_th(int ncol) { return (ncol + TH_COLS - 1) / TH_COLS; }
 #define LAUNCH_TH(k, ncol, nrhs, ...) hipLaunchKernelGGL(k, dim3(nblocks_th(ncol)), dim3(TH_BLOCK), thomas_lds_bytes(m.nlm1, nrhs), s, __VA_ARGS__)
