@@ -83,7 +83,7 @@ EXPORTS = ("fesom_gpu_init", "fesom_gpu_upload_state", "fesom_gpu_download_state
            "fesom_gpu_set_field", "fesom_gpu_call", "fesom_gpu_last_solver_iterations",
            "fesom_gpu_last_solver_residual", "fesom_gpu_kernel_time_ms", "fesom_gpu_last_error",
            "psolver_init", "psolve", "psolver_final",
-           "fesom_gpu_halo_info", "fesom_gpu_halo_pack", "fesom_gpu_halo_unpack", "fesom_gpu_copy", "fesom_gpu_sync",
+           "fesom_gpu_halo_info", "fesom_gpu_halo_pack", "fesom_gpu_halo_unpack", "fesom_gpu_copy", "fesom_gpu_sync", "fesom_gpu_set_stream", "fesom_gpu_field_ptr",
            "fesom_mesh_load", "fesom_mesh_get_desc", "fesom_mesh_get_part", "fesom_mesh_get_initial_state",
            "fesom_mesh_free")
 

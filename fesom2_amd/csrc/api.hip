@@ -22,6 +22,7 @@ struct Ctx {
   bool ready = false;
   DM m;
   hipStream_t stream = nullptr;
+  bool ext_stream = false;                              // stream handed in by the host (fesom_gpu_set_stream): not ours to destroy
   hipStream_t side[3] = {nullptr, nullptr, nullptr};   // forked branches of the step DAG
   int cur_tr = 0;
   bool serial = false;
@@ -188,7 +189,8 @@ int fesom_gpu_finalize(void) {
   for (int i = 0; i < 2; i++) if (G.graph[i]) { hipGraphExecDestroy(G.graph[i]); G.graph[i] = nullptr; }
   for (void *p : G.allocs) hipFree(p);
   G.allocs.clear(); G.fields.clear();
-  if (G.stream) { hipStreamDestroy(G.stream); G.stream = nullptr; }
+  if (G.stream && !G.ext_stream) hipStreamDestroy(G.stream);
+  G.stream = nullptr; G.ext_stream = false;
   for (int i = 0; i < 3; i++) if (G.side[i]) { hipStreamDestroy(G.side[i]); G.side[i] = nullptr; }
   G.ready = false;
   return 0;
@@ -334,7 +336,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   if (par->toy_soufflet) { F(Tclim, n1 * N); F(Uclim, n1 * E); F(toy_zvel, n1 * 100); F(toy_ztem, n1 * 100); }
   F(sv_vals, 16 * (N + 64)); F(sv_dinv, N + 64); F(sv_b, N + 64); F(sv_r, N + 64); F(sv_r0, N + 64); F(sv_p, N + 64); F(sv_v, N + 64); F(sv_s, N + 64); F(sv_t, N + 64);
   F(sv_ph, N + 64); F(sv_x0, 16 * (N + 64)); F(sv_snap, N);
-  F(sv_part, 4 * ((N + 255) / 256 + 1)); F(sv_red, 8); F(sv_scal, 4);
+  F(sv_part, 4 * ((N + 255) / 256 + 1)); F(sv_red, 8); F(sv_kry, 16);
   F(sv_resid, 1); F(sv_h1, N); F(sv_h2, N); F(sv_h3, N); F(sv_scale, N + 64);
   m.sv_extrap = 1;
 #undef F
@@ -693,7 +695,9 @@ int fesom_gpu_halo_pack(int kind, int nfields, const char *const *names, void **
     if (tot > 0) hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, G.stream, sb.p, sb.W, h.slist, h.sptr_d, (int)h.sPE.size(), h.nsend, Wtot, off, G.hsend);
     off += sb.W;
   }
-  HIPCHK(hipStreamSynchronize(G.stream));               // the host transport may read the buffer now
+  // stream-ordered: fesom_gpu_copy / fesom_gpu_sync wait for the pack kernels; a transport on the same stream
+  // (fesom_gpu_set_stream) needs no host wait at all
+  HIPCHK(hipGetLastError());
   *send_dev = G.hsend; *recv_dev = G.hrecv; *values_per_item = Wtot;
   return 0;
 }
@@ -718,5 +722,22 @@ int fesom_gpu_copy(void *dst, const void *src, long long bytes, int dir) {
   HIPCHK(hipMemcpy(dst, src, (size_t)bytes, dir == 0 ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice));
   return 0;
 }
+// device address of a named field (for a host transport that works on device memory, e.g. an all-reduce of sv_red)
+int fesom_gpu_field_ptr(const char *name, void **dev, long long *count) {
+  NEED_READY();
+  auto it = G.fields.find(name);
+  if (it == G.fields.end()) { G.err = std::string("field_ptr: unknown field ") + name; return 1; }
+  *dev = it->second.p; *count = (long long)it->second.count;
+  return 0;
+}
 int fesom_gpu_sync(void) { NEED_READY(); HIPCHK(hipStreamSynchronize(G.stream)); return 0; }
+// run every kernel of the library on the host's stream (e.g. torch.cuda.current_stream().cuda_stream), so that the host's
+// stream-ordered transport (RCCL) and the library's pack / unpack / compute kernels need no host synchronisation
+int fesom_gpu_set_stream(void *hip_stream) {
+  NEED_READY();
+  HIPCHK(hipStreamSynchronize(G.stream));
+  if (!G.ext_stream) hipStreamDestroy(G.stream);
+  G.stream = (hipStream_t)hip_stream; G.ext_stream = true;
+  return 0;
+}
 }

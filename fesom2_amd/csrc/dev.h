@@ -56,7 +56,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   double *sv_vals, *sv_dinv, *sv_b, *sv_r, *sv_r0, *sv_p, *sv_v, *sv_s, *sv_t, *sv_ph, *sv_x0, *sv_snap;
   int *sv_info; double *sv_resid;   // sv_info[0] iterations of the last solve, [1] number of stored previous solutions
   double *sv_scale;
-  double *sv_part, *sv_red, *sv_scal;   // partitioned solve: block partial sums, reduced sums, Krylov scalars (alpha, omega, beta)
+  double *sv_part, *sv_red, *sv_kry;    // partitioned solve: block partial sums, reduced sums, Krylov scalars + flags (solver.hip)
   double *sv_h1, *sv_h2, *sv_h3; int sv_extrap;   // previous SSH solutions (extrapolated initial guess), only on the step path
   unsigned short *sv_cols;    // static ELL column pattern [k][NP] of the SSH operator (padding -> own row)
   fesom_params p;

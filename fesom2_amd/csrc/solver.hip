@@ -441,29 +441,57 @@ __global__ void __launch_bounds__(DSB) k_ds_init(DM m, int NP, int nblk) {
   }
   ds_block_partials<1>(q, m.sv_part, nblk);
 }
+// Krylov scalars live on the device (sv_kry: 0 alpha, 1 omega, 2 beta, 3 rho, 4 rho_new, 5 ||r||^2, 6 iterations, 7 done) so that
+// a stream-ordered host (RCCL on the same stream) never has to read them back inside the loop; once `done` is set every
+// phase is a no-op, so polling the flag only every few iterations leaves the result unchanged.
+#define KRY_DONE(m) ((m).sv_kry[7] != 0.0)
+__global__ void k_ds_scal_init(DM m, double tol2, int maxits) {   // after the all-reduce of ||r0||^2
+  if (threadIdx.x) return;
+  double rr = m.sv_red[0];
+  m.sv_kry[0] = 1.0; m.sv_kry[1] = 1.0; m.sv_kry[3] = 1.0; m.sv_kry[4] = rr; m.sv_kry[5] = rr; m.sv_kry[6] = 0.0;
+  m.sv_kry[7] = (rr >= tol2 && 0 < maxits) ? 0.0 : 1.0;
+  m.sv_kry[2] = (rr / 1.0) * (1.0 / 1.0);                        // beta = (rho_new/rho)*(alpha/omega)
+}
+__global__ void k_ds_scal_alpha(DM m) {                           // after the all-reduce of r0.v
+  if (threadIdx.x || KRY_DONE(m)) return;
+  m.sv_kry[0] = m.sv_kry[4] / m.sv_red[0];
+}
+__global__ void k_ds_scal_omega(DM m, double tol2, int maxits) {  // after the all-reduce of (t.t, t.s, r0.t, s.s)
+  if (threadIdx.x || KRY_DONE(m)) return;
+  const double tt = m.sv_red[0], ts = m.sv_red[1], r0t = m.sv_red[2], ss = m.sv_red[3];
+  const double alpha = m.sv_kry[0];
+  const double omega = (tt > 0.0) ? ts / tt : 0.0;
+  const double rho = m.sv_kry[4], rho_new = -omega * r0t;
+  const double rr = ss - omega * (2.0 * ts - omega * tt);
+  const double it = m.sv_kry[6] + 1.0;
+  m.sv_kry[1] = omega; m.sv_kry[3] = rho; m.sv_kry[4] = rho_new; m.sv_kry[5] = rr; m.sv_kry[6] = it;
+  const bool more = (rr >= tol2 && it < (double)maxits);
+  m.sv_kry[2] = more ? (rho_new / rho) * (alpha / omega) : 0.0;
+  m.sv_kry[8] = more ? 0.0 : 1.0;                                // becomes `done` after this iteration's update (k_ds_update)
+}
 __global__ void __launch_bounds__(DSB) k_ds_p(DM m) {             // p = r + beta (p - omega v)
   int i = blockIdx.x * DSB + threadIdx.x;
-  if (i >= m.myN) return;
-  const double beta = m.sv_scal[2], omega = m.sv_scal[1];
+  if (i >= m.myN || KRY_DONE(m)) return;
+  const double beta = m.sv_kry[2], omega = m.sv_kry[1];
   m.sv_ph[i] = m.sv_r[i] + beta * (m.sv_ph[i] - omega * m.sv_v[i]);
 }
 template <int W>
 __global__ void __launch_bounds__(DSB) k_ds_spmv1(DM m, int NP, int nblk) {   // v = B p ; r0.v
   int i = blockIdx.x * DSB + threadIdx.x;
   double q[1] = {0.0};
-  if (i < m.myN) { double a = ds_row<W>(m, NP, i, m.sv_ph); m.sv_v[i] = a; q[0] = m.sv_r0[i] * a; }
+  if (i < m.myN && !KRY_DONE(m)) { double a = ds_row<W>(m, NP, i, m.sv_ph); m.sv_v[i] = a; q[0] = m.sv_r0[i] * a; }
   ds_block_partials<1>(q, m.sv_part, nblk);
 }
 __global__ void __launch_bounds__(DSB) k_ds_s(DM m) {             // s = r - alpha v
   int i = blockIdx.x * DSB + threadIdx.x;
-  if (i >= m.myN) return;
-  m.sv_s[i] = m.sv_r[i] - m.sv_scal[0] * m.sv_v[i];
+  if (i >= m.myN || KRY_DONE(m)) return;
+  m.sv_s[i] = m.sv_r[i] - m.sv_kry[0] * m.sv_v[i];
 }
 template <int W>
 __global__ void __launch_bounds__(DSB) k_ds_spmv2(DM m, int NP, int nblk) {   // t = B s ; t.t, t.s, r0.t, s.s
   int i = blockIdx.x * DSB + threadIdx.x;
   double q[4] = {0.0, 0.0, 0.0, 0.0};
-  if (i < m.myN) {
+  if (i < m.myN && !KRY_DONE(m)) {
     double a = ds_row<W>(m, NP, i, m.sv_s), si = m.sv_s[i];
     m.sv_t[i] = a;
     q[0] = a * a; q[1] = a * si; q[2] = m.sv_r0[i] * a; q[3] = si * si;
@@ -472,20 +500,26 @@ __global__ void __launch_bounds__(DSB) k_ds_spmv2(DM m, int NP, int nblk) {   //
 }
 __global__ void __launch_bounds__(DSB) k_ds_update(DM m) {        // y += alpha p + omega s ; r = s - omega t
   int i = blockIdx.x * DSB + threadIdx.x;
-  if (i >= m.myN) return;
-  const double alpha = m.sv_scal[0], omega = m.sv_scal[1];
-  double si = m.sv_s[i];
-  m.sv_r[i] = si - omega * m.sv_t[i];
-  m.sv_p[i] = (m.sv_p[i] + alpha * m.sv_ph[i]) + omega * si;
+  if (KRY_DONE(m)) return;
+  if (i < m.myN) {
+    const double alpha = m.sv_kry[0], omega = m.sv_kry[1];
+    double si = m.sv_s[i];
+    m.sv_r[i] = si - omega * m.sv_t[i];
+    m.sv_p[i] = (m.sv_p[i] + alpha * m.sv_ph[i]) + omega * si;
+  }
 }
+__global__ void k_ds_latch(DM m) { if (!threadIdx.x && m.sv_kry[8] != 0.0) m.sv_kry[7] = 1.0; }   // after k_ds_update of the last iteration
 __global__ void __launch_bounds__(DSB) k_ds_finish(DM m) {        // x = D^-1 y
   int i = blockIdx.x * DSB + threadIdx.x;
   if (i < m.myN) m.d_eta[i] = m.sv_p[i] * (1.0 / m.sv_dinv[i]);
-  if (i == 0 && m.sv_extrap && m.sv_info[1] < 3) m.sv_info[1] = m.sv_info[1] + 1;
+  if (i == 0) {
+    m.sv_info[0] = (int)m.sv_kry[6]; m.sv_resid[0] = sqrt(m.sv_kry[5] > 0.0 ? m.sv_kry[5] : 0.0);
+    if (m.sv_extrap && m.sv_info[1] < 3) m.sv_info[1] = m.sv_info[1] + 1;
+  }
 }
 
-// named phases of the partitioned solve (fesom_gpu_call): ds_scale, ds_setup, ds_init, ds_p, ds_spmv1, ds_s, ds_spmv2,
-// ds_update, ds_finish
+// named phases of the partitioned solve (fesom_gpu_call): ds_scale, ds_setup, ds_init, ds_scal_init, ds_p, ds_spmv1,
+// ds_scal_alpha, ds_s, ds_spmv2, ds_scal_omega, ds_update, ds_finish
 int launch_named_dsolve(const DM &m, hipStream_t s, const char *name) {
   if (strncmp(name, "ds_", 3)) return -1;
   const int W = m.ssh_maxnnz <= 10 ? 10 : 16, NP = (m.myN + 63) / 64 * 64, nblk = (m.myN + DSB - 1) / DSB;
@@ -497,12 +531,22 @@ int launch_named_dsolve(const DM &m, hipStream_t s, const char *name) {
     else hipLaunchKernelGGL(k_solver_setup<16>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, 0);
     return 0;
   }
-  if (!strcmp(name, "ds_init")) { DSW(k_ds_init, m, NP, nblk); hipLaunchKernelGGL(k_ds_reduce, dim3(1), dim3(64), 0, s, m, 1, nblk); return 0; }
+  const double tol2 = 1e-10 * 1e-10; const int maxits = 2000;      // bicgstab_ras.c:78,146,220 / solve_ssh_ale
+  if (!strcmp(name, "ds_init")) {
+    hipMemsetAsync(m.sv_kry, 0, 16 * sizeof(double), s);
+    DSW(k_ds_init, m, NP, nblk); hipLaunchKernelGGL(k_ds_reduce, dim3(1), dim3(64), 0, s, m, 1, nblk); return 0;
+  }
+  if (!strcmp(name, "ds_scal_init")) { hipLaunchKernelGGL(k_ds_scal_init, dim3(1), dim3(64), 0, s, m, tol2, maxits); return 0; }
+  if (!strcmp(name, "ds_scal_alpha")) { hipLaunchKernelGGL(k_ds_scal_alpha, dim3(1), dim3(64), 0, s, m); return 0; }
+  if (!strcmp(name, "ds_scal_omega")) { hipLaunchKernelGGL(k_ds_scal_omega, dim3(1), dim3(64), 0, s, m, tol2, maxits); return 0; }
   if (!strcmp(name, "ds_p")) { hipLaunchKernelGGL(k_ds_p, dim3(nblk), dim3(DSB), 0, s, m); return 0; }
   if (!strcmp(name, "ds_spmv1")) { DSW(k_ds_spmv1, m, NP, nblk); hipLaunchKernelGGL(k_ds_reduce, dim3(1), dim3(64), 0, s, m, 1, nblk); return 0; }
   if (!strcmp(name, "ds_s")) { hipLaunchKernelGGL(k_ds_s, dim3(nblk), dim3(DSB), 0, s, m); return 0; }
   if (!strcmp(name, "ds_spmv2")) { DSW(k_ds_spmv2, m, NP, nblk); hipLaunchKernelGGL(k_ds_reduce, dim3(1), dim3(64), 0, s, m, 4, nblk); return 0; }
-  if (!strcmp(name, "ds_update")) { hipLaunchKernelGGL(k_ds_update, dim3(nblk), dim3(DSB), 0, s, m); return 0; }
+  if (!strcmp(name, "ds_update")) {
+    hipLaunchKernelGGL(k_ds_update, dim3(nblk), dim3(DSB), 0, s, m);
+    hipLaunchKernelGGL(k_ds_latch, dim3(1), dim3(64), 0, s, m); return 0;
+  }
   if (!strcmp(name, "ds_finish")) { hipLaunchKernelGGL(k_ds_finish, dim3(nblk), dim3(DSB), 0, s, m); return 0; }
   return -1;
 }

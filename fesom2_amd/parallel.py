@@ -31,7 +31,6 @@ from .core import OceanCore
 from .mesh import Mesh
 
 NOD, ELEM, ELEM_FULL = 0, 1, 2
-TOL2 = 1e-10 * 1e-10
 MAXITS = 2000
 
 
@@ -85,7 +84,11 @@ class HaloExchanger:
         lib.fesom_gpu_halo_pack.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
         lib.fesom_gpu_halo_unpack.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_char_p)]
         lib.fesom_gpu_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int]
+        lib.fesom_gpu_set_stream.argtypes = [C.c_void_p]
         self.device = dist.get_backend() == "nccl"
+        self._tens = {}
+        if self.device:                       # library kernels and RCCL on the same stream: no host synchronisation anywhere
+            self._chk(lib.fesom_gpu_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)), "set_stream")
         self.info = []
         for kind in range(3):
             npes, mype, nr, ns = C.c_int(), C.c_int(), C.c_int(), C.c_int()
@@ -99,16 +102,23 @@ class HaloExchanger:
         if rc != 0:
             raise RuntimeError(f"{what}: {self.lib.fesom_gpu_last_error().decode()}")
 
+    def dev_tensor(self, ptr, n):
+        key = (ptr, n)
+        if key not in self._tens:
+            self._tens[key] = torch.as_tensor(_DevBuf(ptr, n), device="cuda")
+        return self._tens[key]
+
     def exchange(self, kind, names):
         inf = self.info[kind]
+        if not inf["rPE"] and not inf["sPE"]:
+            return
         arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
         sp, rp, W = C.c_void_p(), C.c_void_p(), C.c_int()
         self._chk(self.lib.fesom_gpu_halo_pack(kind, len(names), arr, C.byref(sp), C.byref(rp), C.byref(W)), "halo_pack")
         W = W.value
         ns, nr = sum(inf["scnt"]) * W, sum(inf["rcnt"]) * W
         if self.device:                       # RCCL directly on the device buffers
-            send = torch.as_tensor(_DevBuf(sp.value, max(ns, 1)), device="cuda")
-            recv = torch.as_tensor(_DevBuf(rp.value, max(nr, 1)), device="cuda")
+            send, recv = self.dev_tensor(sp.value, max(ns, 1)), self.dev_tensor(rp.value, max(nr, 1))
         else:                                 # host staging (gloo)
             send_h, recv_h = np.empty(max(ns, 1)), np.empty(max(nr, 1))
             if ns:
@@ -123,9 +133,7 @@ class HaloExchanger:
         if ops:
             for r in dist.batch_isend_irecv(ops):
                 r.wait()
-        if self.device:
-            torch.cuda.current_stream().synchronize()
-        elif nr:
+        if not self.device and nr:
             self._chk(self.lib.fesom_gpu_copy(rp, recv_h.ctypes.data, nr * 8, 1), "copy h2d")
         self._chk(self.lib.fesom_gpu_halo_unpack(kind, len(names), arr), "halo_unpack")
 
@@ -142,43 +150,40 @@ class PartitionedCore:
         self.halo = HaloExchanger(self.core, group)
         self.first = True
         self.solver_iterations = 0
-        self.red_dev = torch.zeros(4, dtype=torch.float64, device="cuda") if dist.get_backend() == "nccl" else None
+        self.red_dev = None
+        if self.halo.device:
+            lib = self.core.lib
+            lib.fesom_gpu_field_ptr.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_longlong)]
+            ptr, cnt = C.c_void_p(), C.c_longlong()
+            assert lib.fesom_gpu_field_ptr(b"sv_red", C.byref(ptr), C.byref(cnt)) == 0
+            self.red_dev = self.halo.dev_tensor(ptr.value, int(cnt.value))
 
-    # -- global sums of the partial dot products
+    # -- global sums of the partial dot products (in place in the device buffer sv_red)
     def _allreduce(self, n):
-        v = self.core.get("sv_red", 8)[:n].copy()
-        if self.red_dev is not None:
-            t = self.red_dev[:n]; t.copy_(torch.from_numpy(v)); dist.all_reduce(t, group=self.group); return t.cpu().numpy()
-        t = torch.from_numpy(v); dist.all_reduce(t, group=self.group); return t.numpy()
+        if self.halo.device:
+            dist.all_reduce(self.red_dev[:n], group=self.group)
+        else:
+            v = self.core.get("sv_red", 8)
+            t = torch.from_numpy(v[:n].copy()); dist.all_reduce(t, group=self.group)
+            v[:n] = t.numpy(); self.core.set("sv_red", v)
 
-    def _scal(self, alpha, omega, beta):
-        self.core.set("sv_scal", np.array([alpha, omega, beta, 0.0]))
-
-    def solve_ssh(self):
-        """Jacobi-scaled BiCGstab over the partitioned rows (same recurrences as the single-GPU kernel, solver.hip)."""
-        c, X = self.core.call, self.halo.exchange
+    def solve_ssh(self, poll=4):
+        """Jacobi-scaled BiCGstab over the partitioned rows: the recurrences of the single-GPU kernel (solver.hip), Krylov
+        scalars and the convergence flag on the device; the host only polls the flag every `poll` iterations (phases after
+        convergence are no-ops on the device, so the result does not depend on `poll`)."""
+        c, X, AR = self.core.call, self.halo.exchange, self._allreduce
         c("ds_scale"); X(NOD, ["sv_dinv"])
         c("ds_setup"); X(NOD, ["sv_s"])
-        c("ds_init")
-        rr = float(self._allreduce(1)[0])
-        rho_new, rho, alpha, omega, it = rr, 1.0, 1.0, 1.0, 0
-        if rr >= TOL2:
-            self._scal(alpha, omega, (rho_new / rho) * (alpha / omega)); c("ds_p")
-        while rr >= TOL2 and it < MAXITS:
-            X(NOD, ["sv_ph"]); c("ds_spmv1")
-            alpha = rho_new / float(self._allreduce(1)[0])
-            self._scal(alpha, omega, 0.0); c("ds_s")
-            X(NOD, ["sv_s"]); c("ds_spmv2")
-            tt, ts, r0t, ss = (float(x) for x in self._allreduce(4))
-            omega = ts / tt if tt > 0.0 else 0.0
-            rho, rho_new = rho_new, -omega * r0t
-            rr = ss - omega * (2.0 * ts - omega * tt)
-            it += 1
-            self._scal(alpha, omega, 0.0); c("ds_update")
-            if rr >= TOL2 and it < MAXITS:
-                self._scal(alpha, omega, (rho_new / rho) * (alpha / omega)); c("ds_p")
+        c("ds_init"); AR(1); c("ds_scal_init"); c("ds_p")
+        while True:
+            for _ in range(poll):
+                X(NOD, ["sv_ph"]); c("ds_spmv1"); AR(1); c("ds_scal_alpha"); c("ds_s")
+                X(NOD, ["sv_s"]); c("ds_spmv2"); AR(4); c("ds_scal_omega"); c("ds_update"); c("ds_p")
+            kry = self.core.get("sv_kry", 16)
+            if kry[7] != 0.0 or kry[6] >= MAXITS:
+                break
         c("ds_finish")
-        self.solver_iterations = it
+        self.solver_iterations = int(kry[6])
 
     def step(self, n=1, probe=None):
         run_step(self.core, self.par, self.halo.exchange, self.solve_ssh, self.first, probe)

@@ -164,6 +164,8 @@ int  fesom_gpu_halo_pack(int kind, int nfields, const char *const *names, void *
 int  fesom_gpu_halo_unpack(int kind, int nfields, const char *const *names);
 int  fesom_gpu_copy(void *dst, const void *src, long long bytes, int dir);   /* 0: device->host, 1: host->device */
 int  fesom_gpu_sync(void);
+int  fesom_gpu_field_ptr(const char *name, void **dev, long long *count);   /* device address of a named field */
+int  fesom_gpu_set_stream(void *hip_stream);   /* run the library's kernels on the host's stream (stream-ordered transport) */
 
 /* SSH solver with the reference's own C signatures (src/psolve.c:16,117,152;
  * Fortran interface blocks src/oce_ale.F90:2272-2291).  All by reference,

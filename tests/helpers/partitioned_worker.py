@@ -57,7 +57,10 @@ def grab(core, mesh, label, store, step):
 
 
 def main():
-    dist.init_process_group("gloo")
+    dist.init_process_group(os.environ.get("PART_BACKEND", "gloo"))
+    if dist.get_backend() == "nccl":
+        import torch
+        torch.cuda.set_device(0)
     rank, world = dist.get_rank(), dist.get_world_size()
     par = make_params(dt=900.0)
     T, S = analytic_ts(PI)
