@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--refine", type=int, default=0, help="supplementary workload: pi refined uniformly L times (4^L x the cells, same dt = 900 s); the headline metric is L = 0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,8 +123,16 @@ def main():
     from fesom2_amd.synthetic import analytic_ts
 
     pi = os.path.join(REPO, "tests", "golden", "meshes", "pi")
-    mesh = Mesh.load(pi, dt=900.0)
-    par = make_params(dt=900.0)
+    dt = 900.0
+    if args.refine > 0:
+        import tempfile
+        from fesom2_amd import mesh_refine
+        pi_r = os.path.join(tempfile.gettempdir(), f"fesom_pi_refined_{args.refine}_{os.getpid()}")
+        mesh_refine.refine(pi, pi_r, args.refine)
+        pi = pi_r                      # dt stays 900 s: the untuned viscosity of this synthetic set-up is unstable for shorter steps
+    steps_per_year = 365 * 86400.0 / dt
+    mesh = Mesh.load(pi, dt=dt)
+    par = make_params(dt=dt)
     st = mesh.initial_state(2)
     st.tr_arr[0], st.tr_arr[1] = analytic_ts(pi)
     st.tr_arr_old[...] = st.tr_arr
@@ -148,7 +157,7 @@ def main():
         elapsed = float(t.item())
     its = core.solver_iterations
     sps = elapsed / args.steps
-    sypd_one = 86400.0 / (STEPS_PER_YEAR * sps)
+    sypd_one = 86400.0 / (steps_per_year * sps)
 
     # ---- N > 1: additionally ONE simulation partitioned over the N GPUs (reference node partition, halo exchange over
     # RCCL, partitioned SSH solve; fesom2_amd/parallel.py).  pi has 3140 surface nodes, i.e. ~390 per GPU at N = 8: the step
@@ -161,7 +170,7 @@ def main():
             import datetime
             from fesom2_amd import parallel
             pg = dist.new_group(timeout=datetime.timedelta(seconds=90))
-            pc = parallel.PartitionedCore(pi, par, group=pg, dt=900.0)
+            pc = parallel.PartitionedCore(pi, par, group=pg, dt=dt)
             ln = pc.mesh.myList_nod2D - 1
             T0, S0 = analytic_ts(pi)
             lst = pc.mesh.initial_state(2)
@@ -181,7 +190,7 @@ def main():
             psps = float(pel.item()) / pk
             eta_own = pc.owned("eta_n", 1)[1]
             assert np.isfinite(eta_own).all()
-            partitioned = {"ms_per_step": round(psps * 1e3, 4), "value": round(86400.0 / (STEPS_PER_YEAR * psps), 2), "unit": "simulated_years/day",
+            partitioned = {"ms_per_step": round(psps * 1e3, 4), "value": round(86400.0 / (steps_per_year * psps), 2), "unit": "simulated_years/day",
                            "scaling": "strong", "steps": pk, "warmup": pw, "solver_iterations": pc.solver_iterations, "transport": "rccl (torch.distributed nccl)" if dist.get_backend() == "nccl" else "gloo, host-staged",
                            "owned_nodes_per_gpu": int(pc.mesh.myDim_nod2D), "error": None}
             pc.close()
@@ -236,14 +245,16 @@ def main():
                                    "solver_us": round(times["k_solver"] * 1e6, 1), "solver_iterations": its},
                     "top5_us": {k: round(v * 1e6, 2) for k, v in sorted(share.items(), key=lambda kv: -kv[1])[:5]}}
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.refine == 0:
             cpu = cpu_baseline()
         out = {"metric": "SYPD (simulated years/day) on pi mesh, 47 z-levels", "value": round(sypd_one * world, 2),
                "unit": "simulated_years/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(sps * 1e3, 5), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "pi mesh (3140 nodes, 5839 elements, 47 layers), T/S tracers, zstar ALE, JM EOS, PP mixing, "
-                                      "MFCT/QR4C/FCT advection, no sea ice, no GM/Redi", "steps_per_day": 96,
+               "config": {"workload": ("pi mesh (3140 nodes, 5839 elements, 47 layers)" if args.refine == 0 else
+                                       f"pi mesh refined {args.refine}x ({mesh.nod2D} nodes, {mesh.elem2D} elements, 47 layers)") +
+                                      ", T/S tracers, zstar ALE, JM EOS, PP mixing, MFCT/QR4C/FCT advection, no sea ice, no GM/Redi",
+                          "steps_per_day": int(round(86400.0 / dt)),
                           "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (value); one simulation partitioned over the {world} GPUs is timed in 'partitioned'",
                           "wet_cells": {"N3": N3, "E3": E3, "D3": D3}},
                "roofline": roofline, "cpu_baseline": cpu}

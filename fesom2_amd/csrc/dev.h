@@ -59,6 +59,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   double *sv_part, *sv_red, *sv_kry;    // partitioned solve: block partial sums, reduced sums, Krylov scalars + flags (solver.hip)
   double *sv_h1, *sv_h2, *sv_h3; int sv_extrap;   // previous SSH solutions (extrapolated initial guess), only on the step path
   unsigned short *sv_cols;    // static ELL column pattern [k][NP] of the SSH operator (padding -> own row)
+  const int *sv_colsi;        // the same with 32-bit indices (multi-workgroup / partitioned phases)
   fesom_params p;
 };
 

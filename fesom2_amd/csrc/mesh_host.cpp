@@ -133,6 +133,51 @@ void elem_center(const Mesh &m, int e, double &x, double &y) {
   y = (CO(2, EN(1, e)) + CO(2, EN(2, e)) + CO(2, EN(3, e))) / 3.0;
 }
 
+
+// Edge list of a mesh that comes without edges.out / edge_tri.out / edgenum.out (generated meshes): restatement of the
+// reference partitioner's find_edges_ini (src/fvom_init.F90:315-650).  Internal edges first, then boundary edges; within
+// each group in the order (lower node ascending, neighbours in order of discovery over the node's elements); edge_tri(1)
+// is the triangle to the left of the edge.  For the reference's own meshes it reproduces their edge files entry for entry
+// (tests/test_abi_and_host.py::test_generated_edges_equal_mesh_files).
+void generate_edges(Mesh &m) {
+  const int N = m.N2, E = m.E2;
+  std::vector<std::vector<int>> ne(N + 1), nn(N + 1);
+  for (int e = 1; e <= E; e++) for (int q = 1; q <= 3; q++) ne[EN(q, e)].push_back(e);
+  std::vector<char> seen(N + 1, 0);
+  for (int n = 1; n <= N; n++) {
+    for (int e : ne[n]) for (int q = 1; q <= 3; q++) { int k = EN(q, e); if (k != n && !seen[k]) { seen[k] = 1; nn[n].push_back(k); } }
+    for (int k : nn[n]) seen[k] = 0;
+  }
+  m.edges.clear(); m.edge_tri.clear();
+  for (int pass = 0; pass < 2; pass++) {               // 0: internal (two triangles), 1: boundary (one)
+    for (int n = 1; n <= N; n++)
+      for (int node : nn[n]) {
+        if (node < n) continue;
+        int flag = 0, el[2] = {0, 0};
+        for (int e : ne[n]) for (int q = 1; q <= 3; q++) if (EN(q, e) == node) { if (flag < 2) el[flag] = e; flag++; break; }
+        if ((pass == 0 && flag == 2) || (pass == 1 && flag == 1)) {
+          m.edges.push_back(n); m.edges.push_back(node);
+          m.edge_tri.push_back(el[0]); m.edge_tri.push_back(pass == 0 ? el[1] : -999);
+        }
+      }
+    if (pass == 0) m.D2in = (int)m.edges.size() / 2;
+  }
+  m.D2 = (int)m.edges.size() / 2;
+  for (int d = 1; d <= m.D2; d++) {                     // orientation: first triangle on the left of (edges(1) -> edges(2))
+    if (ET(1, d) <= 0) std::swap(ET(1, d), ET(2, d));
+    double xc[2], xe[2];
+    elem_center(m, ET(1, d), xc[0], xc[1]);
+    xc[0] -= CO(1, ED(1, d)); xc[1] -= CO(2, ED(1, d));
+    xe[0] = CO(1, ED(2, d)) - CO(1, ED(1, d)); xe[1] = CO(2, ED(2, d)) - CO(2, ED(1, d));
+    trim_cyclic(xe[0], m.cyc); trim_cyclic(xc[0], m.cyc);
+    if (xc[0] * xe[1] - xc[1] * xe[0] > 0.0) {
+      if (ET(2, d) > 0) std::swap(ET(1, d), ET(2, d));
+      else std::swap(ED(1, d), ED(2, d));
+    }
+  }
+  for (auto &v : m.edge_tri) if (v < 0) v = 0;
+}
+
 bool load_files(Mesh &m, const std::string &dir) {
   std::vector<std::string> t;
   if (!read_all_tokens(dir + "/nod2d.out", t)) return false;
@@ -165,17 +210,22 @@ bool load_files(Mesh &m, const std::string &dir) {
     m.depth[n] = x;
   }
   t.clear();
-  if (!read_all_tokens(dir + "/edgenum.out", t)) return false;
-  m.D2 = atoi(t[0].c_str()); m.D2in = atoi(t[1].c_str());
-  t.clear();
-  if (!read_all_tokens(dir + "/edges.out", t)) return false;
-  m.edges.resize(2 * m.D2);
-  for (int i = 0; i < 2 * m.D2; i++) m.edges[i] = atoi(t[i].c_str());
-  t.clear();
-  if (!read_all_tokens(dir + "/edge_tri.out", t)) return false;
-  m.edge_tri.resize(2 * m.D2);
-  for (int i = 0; i < 2 * m.D2; i++) { int v = atoi(t[i].c_str()); m.edge_tri[i] = v < 0 ? 0 : v; }
-  t.clear();
+  const bool gen_edges = getenv("FESOM_MESH_GENERATE_EDGES") != nullptr;      // (tests: ignore the edge files)
+  if (gen_edges || !read_all_tokens(dir + "/edgenum.out", t)) {
+    t.clear();
+    generate_edges(m);
+  } else {
+    m.D2 = atoi(t[0].c_str()); m.D2in = atoi(t[1].c_str());
+    t.clear();
+    if (!read_all_tokens(dir + "/edges.out", t)) return false;
+    m.edges.resize(2 * m.D2);
+    for (int i = 0; i < 2 * m.D2; i++) m.edges[i] = atoi(t[i].c_str());
+    t.clear();
+    if (!read_all_tokens(dir + "/edge_tri.out", t)) return false;
+    m.edge_tri.resize(2 * m.D2);
+    for (int i = 0; i < 2 * m.D2; i++) { int v = atoi(t[i].c_str()); m.edge_tri[i] = v < 0 ? 0 : v; }
+    t.clear();
+  }
   if (!read_all_tokens(dir + "/elvls.out", t)) return false;
   m.nlev.resize(m.E2);
   for (int i = 0; i < m.E2; i++) m.nlev[i] = atoi(t[i].c_str());

@@ -68,24 +68,6 @@ __device__ __forceinline__ void block_reduce(double (&v)[NQ], double *buf) {
     v[q] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v[q]), 15), __builtin_amdgcn_readlane(__double2loint(v[q]), 15));
 }
 
-// IN_LDS is a template parameter on purpose: a run-time select between an LDS and a global pointer would turn every
-// gather into a flat_load (waits on both counters, serialises the SpMV).
-template <int W, bool IN_LDS>
-__device__ __forceinline__ void solver_body(const DM &m, int maxits, double tol2, int NP, double *red, double *out, double *pl, double *sl,
-                                            unsigned short *cl);
-
-template <int W>
-__global__ void __launch_bounds__(ST) k_solver_lds(DM m, int maxits, double tol2, int NP) {
-  extern __shared__ double lds[];
-  double *pl = lds + 128, *sl = pl + NP;
-  solver_body<W, true>(m, maxits, tol2, NP, lds, lds + 64, pl, sl, (unsigned short *)(sl + NP));
-}
-template <int W>
-__global__ void __launch_bounds__(ST) k_solver_glb(DM m, int maxits, double tol2, int NP) {
-  extern __shared__ double lds[];
-  solver_body<W, false>(m, maxits, tol2, NP, lds, lds + 64, m.sv_ph, m.sv_s, m.sv_cols);
-}
-
 // Set-up of one solve on the whole GPU (thread per row, coalesced ELL writes): row scaling (psolve.c:58-65), Jacobi
 // diagonal, B = A_s D^-1 in ELL [k][row], b = rhs*scale, y0 = D x0.  The column pattern (ELL, uint16) is static and
 // built once at init (m.sv_cols).
@@ -152,84 +134,6 @@ __global__ void k_solver_setup(DM m, int NP, int fuse_rhs) {
     }
     Bg[k * NP + i] = bk;
   }
-}
-
-template <int W, bool IN_LDS>
-__device__ __forceinline__ void solver_body(const DM &m, int maxits, double tol2, int NP, double *red, double *out, double *pl, double *sl,
-                                            unsigned short *cl) {
-  // red/out: two 64-double reduction buffers, pl: NP (p), sl: NP (s; y0 at entry), cl: W*NP column indices [k][row]
-  const int t = threadIdx.x, n = m.myN;
-  double *Bg = m.sv_vals;                                // ELL [k][row], prepared by k_solver_setup
-  double *r = m.sv_r, *r0 = m.sv_r0, *y = m.sv_p, *v = m.sv_v, *tv = m.sv_t, *b = m.sv_b, *diagg = m.sv_dinv, *x = m.d_eta;
-  if (IN_LDS) {
-    for (int e = t; e < W * NP; e += ST) cl[e] = m.sv_cols[e];
-    for (int i = t; i < NP; i += ST) sl[i] = m.sv_s[i];
-    __syncthreads();
-  }
-  double prr = 0.0;
-  for (int i = t; i < n; i += ST) {
-    double a = 0.0;
-#pragma unroll
-    for (int k = 0; k < W; k++) a = a + Bg[k * NP + i] * sl[cl[k * NP + i]];
-    double ri = b[i] - a;
-    r[i] = ri; r0[i] = ri; v[i] = 0.0; y[i] = sl[i];
-    prr = prr + ri * ri;
-  }
-  __syncthreads();
-  for (int i = t; i < NP; i += ST) pl[i] = 0.0;           // p = 0
-  double rr, rho_new;
-  { double q1[1] = {prr}; block_reduce<1>(q1, out); rr = q1[0]; rho_new = q1[0]; }
-  double rho = 1.0, alpha = 1.0, omega = 1.0;
-  int it = 0;
-  // BiCGstab with TWO reduction points per iteration (rho and ||r||^2 from recurrences, see the oracle) and the
-  // y/r update of iteration k fused with the p update of iteration k+1 (own rows, no barrier in between).
-  if (rr >= tol2 && it < maxits) {
-    double beta = (rho_new / rho) * (alpha / omega);
-    for (int i = t; i < n; i += ST) pl[i] = r[i] + beta * (pl[i] - omega * v[i]);
-  }
-  while (rr >= tol2 && it < maxits) {
-    __syncthreads();
-    double p1 = 0.0;
-    for (int i = t; i < n; i += ST) {
-      double a = 0.0;
-#pragma unroll
-      for (int k = 0; k < W; k++) a = a + Bg[k * NP + i] * pl[cl[k * NP + i]];
-      v[i] = a;
-      p1 = p1 + r0[i] * a;
-    }
-    double r0v;
-    { double q1[1] = {p1}; block_reduce<1>(q1, red); r0v = q1[0]; }
-    alpha = rho_new / r0v;
-    for (int i = t; i < n; i += ST) sl[i] = r[i] - alpha * v[i];
-    __syncthreads();
-    double ptt = 0.0, pts = 0.0, pr0t = 0.0, pss = 0.0;
-    for (int i = t; i < n; i += ST) {
-      double a = 0.0;
-#pragma unroll
-      for (int k = 0; k < W; k++) a = a + Bg[k * NP + i] * sl[cl[k * NP + i]];
-      tv[i] = a;
-      double si = sl[i];
-      ptt = ptt + a * a; pts = pts + a * si; pr0t = pr0t + r0[i] * a; pss = pss + si * si;
-    }
-    double tt, ts, r0t, ss;
-    { double q4[4] = {ptt, pts, pr0t, pss}; block_reduce<4>(q4, out); tt = q4[0]; ts = q4[1]; r0t = q4[2]; ss = q4[3]; }
-    omega = (tt > 0.0) ? ts / tt : 0.0;
-    rho = rho_new;
-    rho_new = -omega * r0t;
-    rr = ss - omega * (2.0 * ts - omega * tt);
-    it++;
-    bool more = (rr >= tol2 && it < maxits);
-    double beta = more ? (rho_new / rho) * (alpha / omega) : 0.0;
-    for (int i = t; i < n; i += ST) {
-      double si = sl[i], pi = pl[i];
-      double ri = si - omega * tv[i];
-      r[i] = ri;
-      y[i] = (y[i] + alpha * pi) + omega * si;
-      if (more) pl[i] = ri + beta * (pi - omega * v[i]);
-    }
-  }
-  for (int i = t; i < n; i += ST) x[i] = y[i] * (1.0 / diagg[i]);
-  if (t == 0) { m.sv_info[0] = it; m.sv_resid[0] = sqrt(rr > 0.0 ? rr : 0.0); if (m.sv_extrap && m.sv_info[1] < 3) m.sv_info[1] = m.sv_info[1] + 1; }
 }
 
 // Register-resident variant for n <= 4*ST rows: thread t owns rows t, t+1024, t+2048, t+3072.  Own-row vectors r, v, t
@@ -355,37 +259,25 @@ void solver_prepare() {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)k_solver_reg<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_solver_lds<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_solver_lds<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
 }
+int launch_solver_multi(const DM &m, hipStream_t s, int fuse_rhs, int scale_done);
 // Returns non-zero if the operator is wider than the widest instantiated ELL kernel.
 int launch_solver(const DM &m, hipStream_t s, int fuse_rhs, int scale_done) {
-  int W = m.ssh_maxnnz <= 10 ? 10 : 16;
-  if (m.ssh_maxnnz > 16 || m.myN >= 65536) return 1;     // uint16 columns / ELL width limits of this round
-  int NP = (m.myN + 63) / 64 * 64;
-  size_t fixed = (size_t)128 * sizeof(double);
-  size_t need = fixed + (size_t)NP * (2 * sizeof(double) + W * sizeof(unsigned short));
-  int in_lds = need <= 158 * 1024;
-  size_t shm = in_lds ? need : fixed;
+  if (m.ssh_maxnnz > 16) return 1;
+  // one workgroup holds up to 4096 rows of <= 10 entries in registers/LDS; larger (or wider) operators take the
+  // multi-workgroup phases
+  if (m.myN > 4 * ST || m.ssh_maxnnz > 10) return launch_solver_multi(m, s, fuse_rhs, scale_done);
+  const int W = 10, NP = (m.myN + 63) / 64 * 64;
   if (!scale_done) launch_row_scale(m, s);
-  if (W == 10) hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs);
-  else hipLaunchKernelGGL(k_solver_setup<16>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs);
+  hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs);
   static int dbg_maxits = getenv("FESOM_SOLVER_MAXITS") ? atoi(getenv("FESOM_SOLVER_MAXITS")) : 2000;   // diagnostics only
+  static int dbg = getenv("FESOM_SOLVER_DBG") ? atoi(getenv("FESOM_SOLVER_DBG")) : 0;
   const double tol2 = 1e-10 * 1e-10;
-  static int no_reg = getenv("FESOM_SOLVER_NOREG") != nullptr;                                        // diagnostics only
-  if (m.myN <= 4 * ST && W == 10 && !no_reg) {         // (the 16-wide instance of the register kernel spills: use the LDS one)
-    shm = (size_t)(128 + 4 * 4 * ST) * sizeof(double);
-    static int dbg = getenv("FESOM_SOLVER_DBG") ? atoi(getenv("FESOM_SOLVER_DBG")) : 0;
-    hipLaunchKernelGGL(k_solver_reg<10>, dim3(1), dim3(ST), shm, s, m, dbg_maxits, dbg ? -1.0 : tol2, NP, dbg);
-  } else if (in_lds) {
-    if (W == 10) hipLaunchKernelGGL(k_solver_lds<10>, dim3(1), dim3(ST), shm, s, m, dbg_maxits, tol2, NP);
-    else hipLaunchKernelGGL(k_solver_lds<16>, dim3(1), dim3(ST), shm, s, m, dbg_maxits, tol2, NP);
-  } else {
-    if (W == 10) hipLaunchKernelGGL(k_solver_glb<10>, dim3(1), dim3(ST), shm, s, m, dbg_maxits, tol2, NP);
-    else hipLaunchKernelGGL(k_solver_glb<16>, dim3(1), dim3(ST), shm, s, m, dbg_maxits, tol2, NP);
-  }
+  size_t shm = (size_t)(128 + 4 * 4 * ST) * sizeof(double);
+  (void)W;
+  hipLaunchKernelGGL(k_solver_reg<10>, dim3(1), dim3(ST), shm, s, m, dbg_maxits, dbg ? -1.0 : tol2, NP, dbg);
   return 0;
 }
 
@@ -421,13 +313,13 @@ __global__ void k_ds_reduce(DM m, int nq, int nblk) {
   if (q >= nq) return;
   double a = 0.0;
   for (int b = 0; b < nblk; b++) a = a + m.sv_part[(size_t)q * nblk + b];
-  m.sv_red[q] = a;
+  m.sv_red[q] = a;                                       // (rank-local partial; the ranks' sums are combined by the host all-reduce)
 }
 template <int W>
 __device__ __forceinline__ double ds_row(const DM &m, int NP, int i, const double *x) {
   double a = 0.0;
 #pragma unroll
-  for (int k = 0; k < W; k++) a = a + m.sv_vals[(size_t)k * NP + i] * x[m.sv_cols[(size_t)k * NP + i]];
+  for (int k = 0; k < W; k++) a = a + m.sv_vals[(size_t)k * NP + i] * x[m.sv_colsi[(size_t)k * NP + i]];
   return a;
 }
 template <int W>
@@ -523,7 +415,7 @@ __global__ void __launch_bounds__(DSB) k_ds_finish(DM m) {        // x = D^-1 y
 int launch_named_dsolve(const DM &m, hipStream_t s, const char *name) {
   if (strncmp(name, "ds_", 3)) return -1;
   const int W = m.ssh_maxnnz <= 10 ? 10 : 16, NP = (m.myN + 63) / 64 * 64, nblk = (m.myN + DSB - 1) / DSB;
-  if (m.ssh_maxnnz > 16 || m.N >= 65536) return 1;
+  if (m.ssh_maxnnz > 16) return 1;
 #define DSW(k, ...) do { if (W == 10) hipLaunchKernelGGL(k<10>, dim3(nblk), dim3(DSB), 0, s, __VA_ARGS__); else hipLaunchKernelGGL(k<16>, dim3(nblk), dim3(DSB), 0, s, __VA_ARGS__); } while (0)
   if (!strcmp(name, "ds_scale")) { launch_row_scale(m, s); return 0; }
   if (!strcmp(name, "ds_setup")) {
@@ -549,4 +441,136 @@ int launch_named_dsolve(const DM &m, hipStream_t s, const char *name) {
   }
   if (!strcmp(name, "ds_finish")) { hipLaunchKernelGGL(k_ds_finish, dim3(nblk), dim3(DSB), 0, s, m); return 0; }
   return -1;
+}
+
+// Single GPU, operator too large for one workgroup (> 4096 rows): the same recurrences and the same summation order as the
+// phases above, 4 launches per iteration instead of 9 -- there is no host all-reduce between the phases here, so every block
+// sums the block partials itself (in block order) and evaluates the Krylov scalars redundantly.  The scalar state ping-pongs
+// between two slots of sv_kry (a block must not read what block 0 of the same launch is about to write); the convergence
+// flag is read back between chunks of iterations (launches after convergence are no-ops).
+//   state slot (16 doubles): 0 alpha, 1 omega, 2 beta, 3 rho, 4 rho_new, 5 ||r||^2, 6 iterations, 7 done
+// sum of the nblk block partials, evaluated by every block in the same fixed order: thread t adds part[t], part[t+256], ...
+// in that order, then the halving tree over the 256 threads (strides 128..1).  Must be called by the whole block.
+__device__ __forceinline__ double dm_sum_blocks(const double *part, int nblk, double *sh /* DSB doubles */) {
+  const int t = threadIdx.x;
+  double a = 0.0;
+  for (int b = t; b < nblk; b += DSB) a = a + part[b];
+  sh[t] = a;
+  __syncthreads();
+  for (int s2 = DSB / 2; s2 >= 1; s2 >>= 1) {
+    if (t < s2) sh[t] = sh[t] + sh[t + s2];
+    __syncthreads();
+  }
+  double r = sh[0];
+  __syncthreads();
+  return r;
+}
+__global__ void __launch_bounds__(DSB) k_dm_start(DM m, int nblk, double tol2, int maxits) {   // after k_ds_init: state + first p
+  __shared__ double sh[DSB];
+  const double rr = dm_sum_blocks(m.sv_part, nblk, sh);
+  const bool go = (rr >= tol2 && 0 < maxits);
+  int i = blockIdx.x * DSB + threadIdx.x;
+  if (go && i < m.myN) m.sv_ph[i] = m.sv_r[i] + ((rr / 1.0) * (1.0 / 1.0)) * (m.sv_ph[i] - 1.0 * m.sv_v[i]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double *st = m.sv_kry;                                 // slot 0
+    st[0] = 1.0; st[1] = 1.0; st[2] = rr; st[3] = 1.0; st[4] = rr; st[5] = rr; st[6] = 0.0; st[7] = go ? 0.0 : 1.0;
+  }
+}
+__global__ void __launch_bounds__(DSB) k_dm_s(DM m, int nblk, int slot) {                        // alpha ; s = r - alpha v
+  const double *st = m.sv_kry + 16 * slot;
+  if (st[7] != 0.0) return;
+  __shared__ double sh[DSB];
+  const double alpha = st[4] / dm_sum_blocks(m.sv_part, nblk, sh);
+  int i = blockIdx.x * DSB + threadIdx.x;
+  if (i < m.myN) m.sv_s[i] = m.sv_r[i] - alpha * m.sv_v[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) m.sv_kry[32] = alpha;
+}
+template <int W>
+__global__ void __launch_bounds__(DSB) k_dm_spmv(DM m, int NP, int nblk, int slot, int which) { // which 1: v = B p ; 2: t = B s
+  const double *st = m.sv_kry + 16 * slot;
+  const bool done = st[7] != 0.0;
+  int i = blockIdx.x * DSB + threadIdx.x;
+  if (which == 1) {
+    double q[1] = {0.0};
+    if (i < m.myN && !done) { double a = ds_row<W>(m, NP, i, m.sv_ph); m.sv_v[i] = a; q[0] = m.sv_r0[i] * a; }
+    ds_block_partials<1>(q, m.sv_part, nblk);
+  } else {
+    double q[4] = {0.0, 0.0, 0.0, 0.0};
+    if (i < m.myN && !done) {
+      double a = ds_row<W>(m, NP, i, m.sv_s), si = m.sv_s[i];
+      m.sv_t[i] = a;
+      q[0] = a * a; q[1] = a * si; q[2] = m.sv_r0[i] * a; q[3] = si * si;
+    }
+    ds_block_partials<4>(q, m.sv_part, nblk);
+  }
+}
+__global__ void __launch_bounds__(DSB) k_dm_upd(DM m, int nblk, int slot, double tol2, int maxits) {  // scalars ; y, r ; next p
+  const double *st = m.sv_kry + 16 * slot;
+  double *so = m.sv_kry + 16 * (1 - slot);
+  if (st[7] != 0.0) {
+    if (blockIdx.x == 0 && threadIdx.x < 16) so[threadIdx.x] = st[threadIdx.x];
+    return;
+  }
+  __shared__ double sh[DSB];
+  const double tt = dm_sum_blocks(m.sv_part, nblk, sh), ts = dm_sum_blocks(m.sv_part + (size_t)nblk, nblk, sh);
+  const double r0t = dm_sum_blocks(m.sv_part + 2 * (size_t)nblk, nblk, sh), ss = dm_sum_blocks(m.sv_part + 3 * (size_t)nblk, nblk, sh);
+  const double alpha = m.sv_kry[32];
+  const double omega = (tt > 0.0) ? ts / tt : 0.0;
+  const double rho = st[4], rho_new = -omega * r0t;
+  const double rr = ss - omega * (2.0 * ts - omega * tt);
+  const double it = st[6] + 1.0;
+  const bool more = (rr >= tol2 && it < (double)maxits);
+  const double beta = more ? (rho_new / rho) * (alpha / omega) : 0.0;
+  int i = blockIdx.x * DSB + threadIdx.x;
+  if (i < m.myN) {
+    double si = m.sv_s[i], pi = m.sv_ph[i];
+    double ri = si - omega * m.sv_t[i];
+    m.sv_r[i] = ri;
+    m.sv_p[i] = (m.sv_p[i] + alpha * pi) + omega * si;
+    if (more) m.sv_ph[i] = ri + beta * (pi - omega * m.sv_v[i]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    so[0] = alpha; so[1] = omega; so[2] = beta; so[3] = rho; so[4] = rho_new; so[5] = rr; so[6] = it; so[7] = more ? 0.0 : 1.0;
+  }
+}
+__global__ void __launch_bounds__(DSB) k_dm_finish(DM m, int slot) {
+  const double *st = m.sv_kry + 16 * slot;
+  int i = blockIdx.x * DSB + threadIdx.x;
+  if (i < m.myN) m.d_eta[i] = m.sv_p[i] * (1.0 / m.sv_dinv[i]);
+  if (i == 0) {
+    m.sv_info[0] = (int)st[6]; m.sv_resid[0] = sqrt(st[5] > 0.0 ? st[5] : 0.0);
+    if (m.sv_extrap && m.sv_info[1] < 3) m.sv_info[1] = m.sv_info[1] + 1;
+  }
+}
+int launch_solver_multi(const DM &m, hipStream_t s, int fuse_rhs, int scale_done) {
+  if (m.ssh_maxnnz > 16) return 1;
+  const int W = m.ssh_maxnnz <= 10 ? 10 : 16, NP = (m.myN + 63) / 64 * 64, nblk = (m.myN + DSB - 1) / DSB;
+  const double tol2 = 1e-10 * 1e-10; const int maxits = 2000;
+  if (!scale_done) launch_row_scale(m, s);
+  if (W == 10) hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs);
+  else hipLaunchKernelGGL(k_solver_setup<16>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs);
+  static double *hk = nullptr;                                   // pinned copy of the scalar state
+  static int last_its = 24;
+  if (!hk && hipHostMalloc((void **)&hk, 16 * sizeof(double)) != hipSuccess) return 1;
+#define DMW(k, ...) do { if (W == 10) hipLaunchKernelGGL(k<10>, dim3(nblk), dim3(DSB), 0, s, __VA_ARGS__); else hipLaunchKernelGGL(k<16>, dim3(nblk), dim3(DSB), 0, s, __VA_ARGS__); } while (0)
+  DMW(k_ds_init, m, NP, nblk);
+  hipLaunchKernelGGL(k_dm_start, dim3(nblk), dim3(DSB), 0, s, m, nblk, tol2, maxits);
+  int slot = 0, total = 0, chunk = last_its > 6 ? last_its - 2 : 4;
+  for (;;) {
+    for (int k = 0; k < chunk; k++) {
+      DMW(k_dm_spmv, m, NP, nblk, slot, 1);
+      hipLaunchKernelGGL(k_dm_s, dim3(nblk), dim3(DSB), 0, s, m, nblk, slot);
+      DMW(k_dm_spmv, m, NP, nblk, slot, 2);
+      hipLaunchKernelGGL(k_dm_upd, dim3(nblk), dim3(DSB), 0, s, m, nblk, slot, tol2, maxits);
+      slot = 1 - slot;
+    }
+    total += chunk;
+    if (hipMemcpyAsync(hk, m.sv_kry + 16 * slot, 16 * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
+    if (hipStreamSynchronize(s) != hipSuccess) return 1;
+    if (hk[7] != 0.0 || total >= maxits) break;
+    chunk = 4;
+  }
+  last_its = (int)hk[6];
+  hipLaunchKernelGGL(k_dm_finish, dim3(nblk), dim3(DSB), 0, s, m, slot);
+  return 0;
 }

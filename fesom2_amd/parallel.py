@@ -179,7 +179,7 @@ class PartitionedCore:
             for _ in range(poll):
                 X(NOD, ["sv_ph"]); c("ds_spmv1"); AR(1); c("ds_scal_alpha"); c("ds_s")
                 X(NOD, ["sv_s"]); c("ds_spmv2"); AR(4); c("ds_scal_omega"); c("ds_update"); c("ds_p")
-            kry = self.core.get("sv_kry", 16)
+            kry = self.core.get("sv_kry", 48)
             if kry[7] != 0.0 or kry[6] >= MAXITS:
                 break
         c("ds_finish")

@@ -103,6 +103,23 @@ static double dot_fixed(const double *x, const double *y, int n) {
   }
   return row_tree16(wave);
 }
+/* operators with more than 4096 rows take the multi-workgroup phases of the HIP path: one product per thread, halving tree
+ * inside every block of 256 threads (strides 128..1); the block sums are then added 256-strided and tree-reduced the same way */
+static double dot_blocks(const double *x, const double *y, int n) {
+  double sh[256], col[256];
+  int nb = 0;
+  for (int t = 0; t < 256; t++) col[t] = 0.0;
+  for (int b0 = 0; b0 < n; b0 += 256, nb++) {
+    for (int t = 0; t < 256; t++) sh[t] = (b0 + t < n) ? x[b0 + t] * y[b0 + t] : 0.0;
+    for (int s = 128; s >= 1; s >>= 1)
+      for (int t = 0; t < s; t++) sh[t] = sh[t] + sh[t + s];
+    col[nb % 256] = col[nb % 256] + sh[0];                 /* thread nb%256 of the summing block adds block nb's partial */
+  }
+  for (int s = 128; s >= 1; s >>= 1)
+    for (int t = 0; t < s; t++) col[t] = col[t] + col[t + s];
+  return col[0];
+}
+static double dot_sel(const double *x, const double *y, int n) { return n > 4 * SOLVER_T ? dot_blocks(x, y, n) : dot_fixed(x, y, n); }
 void orc_solve_ssh(void) {
   int n = C_.m.myDim_nod2D;
   const int *rp = C_.m.ssh_rowptr, *ci = C_.m.ssh_colind_loc;
@@ -138,7 +155,7 @@ void orc_solve_ssh(void) {
   SPMV(r, y);
   for (int i = 0; i < n; i++) { r[i] = b[i] - r[i]; r0[i] = r[i]; pv[i] = 0.0; v[i] = 0.0; }
   double rho = 1.0, alpha = 1.0, omega = 1.0;
-  double rr = dot_fixed(r, r, n);
+  double rr = dot_sel(r, r, n);
   double rho_new = rr;
   int it = 0;
   /* BiCGstab with two reduction points per iteration: rho and ||r||^2 come from recurrences
@@ -147,10 +164,10 @@ void orc_solve_ssh(void) {
     double beta = (rho_new / rho) * (alpha / omega);
     for (int i = 0; i < n; i++) pv[i] = r[i] + beta * (pv[i] - omega * v[i]);
     SPMV(v, pv);
-    alpha = rho_new / dot_fixed(r0, v, n);
+    alpha = rho_new / dot_sel(r0, v, n);
     for (int i = 0; i < n; i++) s[i] = r[i] - alpha * v[i];
     SPMV(t, s);
-    double tt = dot_fixed(t, t, n), ts = dot_fixed(t, s, n), r0t = dot_fixed(r0, t, n), ss = dot_fixed(s, s, n);
+    double tt = dot_sel(t, t, n), ts = dot_sel(t, s, n), r0t = dot_sel(r0, t, n), ss = dot_sel(s, s, n);
     omega = (tt > 0.0) ? ts / tt : 0.0;
     for (int i = 0; i < n; i++) { y[i] = (y[i] + alpha * pv[i]) + omega * s[i]; r[i] = s[i] - omega * t[i]; }
     rho = rho_new;

@@ -86,3 +86,35 @@ def test_mesh_counts_and_wet_cells(built):
     s = Mesh.load(os.path.join(REPO, "tests", "golden", "meshes", "soufflet"), force_rotation=False, cyclic_length_deg=4.5, dt=1200.0)
     assert (s.nod2D, s.elem2D, s.edge2D, s.nl) == (2875, 5700, 8575, 41)
     assert s.wet_counts() == (115000, 228000, 343000)
+
+
+def test_generated_edges_equal_mesh_files(built, monkeypatch):
+    """edge generation of the host mesh layer (for generated meshes that ship without edge files) = the reference
+    partitioner's find_edges_ini (src/fvom_init.F90:315-650): on the reference's own meshes it must reproduce their
+    edges.out / edge_tri.out / edgenum.out entry for entry"""
+    from fesom2_amd.mesh import Mesh
+    for name, kw in (("pi", dict(dt=900.0)), ("soufflet", dict(force_rotation=False, cyclic_length_deg=4.5, dt=1200.0))):
+        d = os.path.join(REPO, "tests", "golden", "meshes", name)
+        a = Mesh.load(d, **kw)
+        ea, ta, da = a.edges.copy(), a.edge_tri.copy(), (a.edge2D, a.edge2D_in)
+        monkeypatch.setenv("FESOM_MESH_GENERATE_EDGES", "1")
+        b = Mesh.load(d, **kw)
+        monkeypatch.delenv("FESOM_MESH_GENERATE_EDGES")
+        assert (b.edge2D, b.edge2D_in) == da and (ea == b.edges).all() and (ta == b.edge_tri).all(), name
+        a.free(); b.free()
+
+
+def test_refined_mesh_is_consistent(built, tmp_path):
+    """uniform refinement (fesom2_amd/mesh_refine.py): 4x the elements, Euler characteristic and total area preserved"""
+    import numpy as np
+    from fesom2_amd import mesh_refine
+    from fesom2_amd.mesh import Mesh
+    pi = os.path.join(REPO, "tests", "golden", "meshes", "pi")
+    a = Mesh.load(pi, dt=900.0)
+    N, E = mesh_refine.refine(pi, str(tmp_path / "r1"), 1)
+    b = Mesh.load(str(tmp_path / "r1"), dt=900.0)
+    assert E == 4 * a.elem2D and b.elem2D == E and b.nod2D == N == a.nod2D + a.edge2D
+    assert b.edge2D == 2 * a.edge2D + 3 * a.elem2D
+    assert abs(b.elem_area.sum() / a.elem_area.sum() - 1.0) < 2e-3          # (flat triangles on the sphere: not exactly additive)
+    assert (b.nlevels_nod2D >= 2).all() and b.nl == a.nl
+    a.free(); b.free()
