@@ -6,7 +6,9 @@ from .mesh import WHICH_ALE
 
 def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equation=1, num_tracers=2,
                 mix_scheme="PP", with_diffusion=True, toy_soufflet=False, K_hor=3000.0, A_ver=1.0e-4, K_ver=1.0e-5,
-                cyclic_length_deg=360.0, w_split=False, use_instabmix=True, use_windmix=False, solver_x0_order=3):
+                cyclic_length_deg=360.0, w_split=False, use_instabmix=True, use_windmix=False, solver_x0_order=3,
+                Fer_GM=False, K_GM_max=2000.0, K_GM_min=2.0, K_GM_bvref=2, K_GM_rampmax=-1.0, K_GM_rampmin=-1.0,
+                K_GM_resscalorder=1.0, scaling_Ferreira=False, scaling_resolution=True, scaling_FESOM14=False):
     p = _lib.Params()
     p.dt = dt
     p.which_ale = WHICH_ALE[which_ale]
@@ -32,4 +34,9 @@ def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equati
     p.cyclic_length = cyclic_length_deg * 3.14159265358979 / 180.0
     p.with_diffusion = int(with_diffusion)
     p.solver_x0_order = int(solver_x0_order)
+    p.Fer_GM = int(Fer_GM)
+    p.K_GM_max, p.K_GM_min, p.K_GM_bvref = K_GM_max, K_GM_min, int(K_GM_bvref)
+    p.K_GM_rampmax, p.K_GM_rampmin, p.K_GM_resscalorder = K_GM_rampmax, K_GM_rampmin, K_GM_resscalorder
+    p.scaling_Ferreira, p.scaling_Rossby = int(scaling_Ferreira), 0
+    p.scaling_resolution, p.scaling_FESOM14 = int(scaling_resolution), int(scaling_FESOM14)
     return p

@@ -141,7 +141,7 @@ __global__ void k_solver_setup(DM m, int NP, int fuse_rhs) {
 // row stride (own-row accesses are immediate-offset, conflict-free); the operator values are the only L2 traffic in
 // the loop (coalesced, scalar base + lane offset).  Same arithmetic and reduction order as solver_body.
 template <int W>
-__global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2, int NP, int dbg) {
+__global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2, int NP) {
   extern __shared__ double lds[];
   constexpr int R = 4, NP4 = R * ST;
   double *bufA = lds, *bufB = lds + 64;
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2
     _Pragma("unroll") for (int w = 0; w < W; w++) {                                              \
       const double *Bw = Bg + (size_t)w * (unsigned)NP;                                          \
       const unsigned c8 = (w & 1) ? (cpk[k][w >> 1] >> 16) : (cpk[k][w >> 1] & 0xffffu);         \
-      acc = acc + ((dbg & 1) ? 0.1 : Bw[o_]) * *(const double *)((const char *)(vec) + ((dbg & 2) ? (o_ << 3) : c8));                  \
+      acc = acc + Bw[o_] * *(const double *)((const char *)(vec) + c8);                                            \
     }                                                                                            \
   }
   double prr = 0.0;
@@ -194,13 +194,13 @@ __global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2
   { double q1[1] = {prr}; block_reduce<1>(q1, bufB); rr = q1[0]; rho_new = q1[0]; }
   double rho = 1.0, alpha = 1.0, omega = 1.0;
   int it = 0;
-  if ((dbg || rr >= tol2) && it < maxits) {
+  if (rr >= tol2 && it < maxits) {
     double beta = (rho_new / rho) * (alpha / omega);
 #pragma unroll
     for (int k = 0; k < R; k++)
       if (ok[k]) pl[t + k * ST] = r[k] + beta * (0.0 - omega * v[k]);
   }
-  while ((dbg || rr >= tol2) && it < maxits) {
+  while (rr >= tol2 && it < maxits) {
     __syncthreads();                                       // p complete in LDS
     double p1 = 0.0;
 #pragma unroll
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2
         p1 = p1 + r0l[t + k * ST] * a;
       }
     double r0v;
-    if (dbg & 4) r0v = p1; else { double q1[1] = {p1}; block_reduce<1>(q1, bufA); r0v = q1[0]; }
+    { double q1[1] = {p1}; block_reduce<1>(q1, bufA); r0v = q1[0]; }
     alpha = rho_new / r0v;
 #pragma unroll
     for (int k = 0; k < R; k++)
@@ -229,13 +229,13 @@ __global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2
         ptt = ptt + a * a; pts = pts + a * si; pr0t = pr0t + r0l[t + k * ST] * a; pss = pss + si * si;
       }
     double tt, ts, r0t, ss;
-    if (dbg & 4) { tt = ptt; ts = pts; r0t = pr0t; ss = pss; } else { double q4[4] = {ptt, pts, pr0t, pss}; block_reduce<4>(q4, bufB); tt = q4[0]; ts = q4[1]; r0t = q4[2]; ss = q4[3]; }
+    { double q4[4] = {ptt, pts, pr0t, pss}; block_reduce<4>(q4, bufB); tt = q4[0]; ts = q4[1]; r0t = q4[2]; ss = q4[3]; }
     omega = (tt > 0.0) ? ts / tt : 0.0;
     rho = rho_new;
     rho_new = -omega * r0t;
     rr = ss - omega * (2.0 * ts - omega * tt);
     it++;
-    bool more = ((dbg || rr >= tol2) && it < maxits);
+    bool more = (rr >= tol2 && it < maxits);
     double beta = more ? (rho_new / rho) * (alpha / omega) : 0.0;
 #pragma unroll
     for (int k = 0; k < R; k++)
@@ -272,12 +272,10 @@ int launch_solver(const DM &m, hipStream_t s, int fuse_rhs, int scale_done) {
   const int W = 10, NP = (m.myN + 63) / 64 * 64;
   if (!scale_done) launch_row_scale(m, s);
   hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs);
-  static int dbg_maxits = getenv("FESOM_SOLVER_MAXITS") ? atoi(getenv("FESOM_SOLVER_MAXITS")) : 2000;   // diagnostics only
-  static int dbg = getenv("FESOM_SOLVER_DBG") ? atoi(getenv("FESOM_SOLVER_DBG")) : 0;
-  const double tol2 = 1e-10 * 1e-10;
+  const double tol2 = 1e-10 * 1e-10;                     // bicgstab_ras.c:78,146,220
   size_t shm = (size_t)(128 + 4 * 4 * ST) * sizeof(double);
   (void)W;
-  hipLaunchKernelGGL(k_solver_reg<10>, dim3(1), dim3(ST), shm, s, m, dbg_maxits, dbg ? -1.0 : tol2, NP, dbg);
+  hipLaunchKernelGGL(k_solver_reg<10>, dim3(1), dim3(ST), shm, s, m, 2000, tol2, NP);
   return 0;
 }
 

@@ -106,6 +106,12 @@ typedef struct fesom_params {
   int    solver_x0_order;    /* SSH solver initial guess: 0 = previous d_eta (reference, psolve.c:206-212);
                                 2 / 3 = quadratic / cubic extrapolation of the last three / four solutions (fewer
                                 iterations, same tolerance) */
+  /* Gent-McWilliams bolus velocities after Ferrari et al. 2010 (src/oce_fer_gm.F90; namelist.oce &oce_dyn) */
+  int    Fer_GM;
+  double K_GM_max, K_GM_min;
+  int    K_GM_bvref;         /* reference N^2 of the Ferreira scaling: 0 surface, 1 below the mixed layer, 2 mean over it */
+  double K_GM_rampmax, K_GM_rampmin, K_GM_resscalorder;
+  int    scaling_Ferreira, scaling_Rossby /* unsupported */, scaling_resolution, scaling_FESOM14;
 } fesom_params;
 
 /* ---- prognostic state = restart set (io_restart.F90:99-155) + ALE thickness arrays -- */

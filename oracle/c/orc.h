@@ -37,6 +37,11 @@ typedef struct {
   /* edge */
   double *adv_flux_hor;                          /* (nl-1,D) */
   double *edge_up_dn_grad;                       /* (4,nl-1,D) */
+  /* Gent-McWilliams bolus velocities (orc_gm.c) */
+  double *fer_K, *fer_gamma, *fer_Wvel;      /* (nl,N), (2,nl,N), (nl,N) */
+  double *fer_c, *fer_scal, *gm_scal_static;  /* (N) */
+  double *fer_UV;                            /* (2,nl-1,E) */
+  int *MLD1_ind;                             /* (N) */
   /* Soufflet toy channel (orc_toy.c) */
   double *Uclim, *toy_zvel, *toy_ztem, *toy_znum;  /* (nl-1,E), (nl-1,100) x3 */
   int *toy_bpos, *toy_owner, toy_nranks;
@@ -105,6 +110,12 @@ void orc_adv_tracers_ale(int tr);
 void orc_diff_tracers_ale(int tr);
 void orc_salinity_clamp(void);
 void orc_update_thickness_ale(void);
+void orc_init_Redi_GM(void);
+void orc_fer_solve_Gamma(void);
+void orc_fer_gamma2vel(void);
+void orc_fer_wvel(void);
+void orc_bolus_add(void);
+void orc_bolus_remove(void);
 void orc_compute_zonal_mean_ini(void);
 void orc_compute_zonal_mean(void);
 void orc_relax_zonal_vel(void);

@@ -19,7 +19,7 @@ static void reg(const char *name, double **p, size_t cnt) {
 int orc_init(const fesom_mesh_desc *m, const fesom_params *p) {
   for (int i = 0; i < nF_; i++) free(*F_[i].p);
   nF_ = 0;
-  free(C_.toy_bpos); free(C_.toy_owner);
+  free(C_.toy_bpos); free(C_.toy_owner); free(C_.MLD1_ind);
   memset(&C_, 0, sizeof(C_));
   C_.m = *m; C_.p = *p;
   C_.N = m->myDim_nod2D + m->eDim_nod2D; C_.E = m->myDim_elem2D + m->eDim_elem2D; C_.D = m->myDim_edge2D + m->eDim_edge2D;
@@ -40,10 +40,12 @@ int orc_init(const fesom_mesh_desc *m, const fesom_params *p) {
   R(UV, 2 * n1 * E); R(UV_rhs, 2 * n1 * E); R(UV_rhsAB, 2 * n1 * E); R(tr_xy, 2 * n1 * E); R(U_b, 2 * n1 * E); R(fct_ebnd, 2 * n1 * E);
   R(pgf_x, n1 * E); R(pgf_y, n1 * E); R(helem, n1 * E); R(Av, nl * E); R(dhe, E); R(stress_surf, 2 * E);
   R(adv_flux_hor, n1 * D); R(edge_up_dn_grad, 4 * n1 * D);
+  R(fer_K, nl * N); R(fer_gamma, 2 * nl * N); R(fer_Wvel, nl * N); R(fer_c, N); R(fer_scal, N); R(gm_scal_static, N); R(fer_UV, 2 * n1 * E);
   R(Uclim, n1 * E); R(toy_zvel, n1 * 100); R(toy_ztem, n1 * 100); R(toy_znum, n1 * 100);
   R(ssh_values, m->ssh_nza); R(sv_h1, N); R(sv_h2, N); R(sv_h3, N);
 #undef R
   C_.toy_bpos = calloc(E ? E : 1, sizeof(int));
+  C_.MLD1_ind = calloc(N ? N : 1, sizeof(int));
   for (size_t i = 0; i < n1 * N; i++) C_.density_ref[i] = DENSITY_0;
   memcpy(C_.ssh_values, m->ssh_values, sizeof(double) * m->ssh_nza);
   /* Ki = K_hor*(mesh_resolution/100000)**2  (oce_setup_step.F90:328-331) */
@@ -51,6 +53,7 @@ int orc_init(const fesom_mesh_desc *m, const fesom_params *p) {
     double r = m->mesh_resolution[n] / 100000.0;
     for (size_t k = 0; k < n1; k++) C_.Ki[n * n1 + k] = p->K_hor * (r * r);
   }
+  { extern void orc_gm_static(void); if (p->Fer_GM) orc_gm_static(); }
   return 0;
 }
 
@@ -200,13 +203,16 @@ void orc_step(int n) {
   orc_update_vel();
   orc_compute_hbar_ale();
   orc_eta_update();
+  if (C_.p.Fer_GM) { orc_init_Redi_GM(); orc_fer_solve_Gamma(); orc_fer_gamma2vel(); }   /* oce_ale.F90:2729-2739 */
   orc_vert_vel_ale();
+  if (C_.p.Fer_GM) { orc_fer_wvel(); orc_bolus_add(); }                                   /* oce_ale.F90:1720-1811, oce_ale_tracer.F90:127-131 */
   for (int tr = 1; tr <= C_.ntr; tr++) {
     orc_init_tracers_AB(tr);
     orc_adv_tracers_ale(tr);
     orc_diff_tracers_ale(tr);
     if (C_.p.toy_soufflet) orc_relax_zonal_temp();                       /* oce_ale_tracer.F90:150-151, once per tracer */
   }
+  if (C_.p.Fer_GM) orc_bolus_remove();                                  /* oce_ale_tracer.F90:165-169 */
   orc_salinity_clamp();
   orc_update_thickness_ale();
 }
@@ -219,6 +225,7 @@ int orc_call(const char *name, int arg) {
   CALL0(impl_vert_visc_ale) CALL0(update_stiff_mat_ale) CALL0(compute_ssh_rhs_ale) CALL0(solve_ssh) CALL0(update_vel)
   CALL0(compute_hbar_ale) CALL0(eta_update) CALL0(vert_vel_ale) CALL1(init_tracers_AB) CALL1(adv_tracers_ale)
   CALL1(diff_tracers_ale) CALL0(salinity_clamp) CALL0(update_thickness_ale) CALL1(step)
+  CALL0(init_Redi_GM) CALL0(fer_solve_Gamma) CALL0(fer_gamma2vel) CALL0(fer_wvel) CALL0(bolus_add) CALL0(bolus_remove)
   CALL0(compute_zonal_mean_ini) CALL0(compute_zonal_mean) CALL0(relax_zonal_vel) CALL0(relax_zonal_temp)
   fprintf(stderr, "orc_call: unknown routine %s\n", name);
   return 1;

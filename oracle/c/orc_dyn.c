@@ -87,6 +87,7 @@ void orc_pressure_bv(void) {
     }
     C_.MLD1[n - 1] = A2(C_.Z_3d_n, nzmin + 1, n);
     C_.MLD2[n - 1] = A2(C_.Z_3d_n, nzmin + 1, n);
+    C_.MLD1_ind[n - 1] = nzmin + 1;
     int flag1 = 1, flag2 = 1;
     for (int nz = nzmin + 1; nz <= nzmax - 1; nz++) {
       double zb = A2L(C_.zbar_3d_n, nz, n);
@@ -96,7 +97,7 @@ void orc_pressure_bv(void) {
       double rho_dn = bulk_dn * rhopot[nz] / (bulk_dn + 0.1 * zb * seq);
       double dz_inv = 1.0 / (A2(C_.Z_3d_n, nz - 1, n) - A2(C_.Z_3d_n, nz, n));
       A2L(C_.bvfreq, nz, n) = -G_ACC * dz_inv * (rho_up - rho_dn) / DENSITY_0;
-      if (A2L(C_.bvfreq, nz, n) > db_max && flag1) { C_.MLD1[n - 1] = A2(C_.Z_3d_n, nz, n); flag1 = 0; }
+      if (A2L(C_.bvfreq, nz, n) > db_max && flag1) { C_.MLD1[n - 1] = A2(C_.Z_3d_n, nz, n); C_.MLD1_ind[n - 1] = nz; flag1 = 0; }
       if ((rhopot[nz] - rhopot[nzmin] > sigma_theta_crit) && flag2) {
         C_.MLD2[n - 1] = C_.MLD2[n - 1] + (A2(C_.Z_3d_n, nz, n) - C_.MLD2[n - 1]) / (rhopot[nz] - rhopot[nz - 1] + 1.e-20) *
                                               (rhopot[1] + sigma_theta_crit - rhopot[nz - 1]);

@@ -84,7 +84,7 @@ def main():
                      K_hor=float(c["k_hor"]))
     par = make_params(dt=dt, which_ale=c["which_ale"], use_partial_cell=c["use_partial_cell"] == ".true.",
                       state_equation=c["state_equation"], mix_scheme=c["mix_scheme"], with_diffusion=True,
-                      toy_soufflet=c["toy_ocean"] == ".true.", K_hor=float(c["k_hor"]),
+                      toy_soufflet=c["toy_ocean"] == ".true.", K_hor=float(c["k_hor"]), Fer_GM=c["fer_gm"] == ".true.",
                       cyclic_length_deg=float(c["cyclic_length"]))
     orc = Oracle(mesh, par)
     st = mesh.initial_state(2)
@@ -166,10 +166,17 @@ def main():
         for f in ("hbar", "hbar_old", "ssh_rhs_old", "dhe"):
             chk("compute_hbar_ale", f, "compute_hbar_ale." + f)
         orc.call("eta_update"); chk("eta_update", "eta_n", "eta_n_update.eta_n")
+        if par.Fer_GM:
+            orc.call("init_Redi_GM"); chk("gm", "fer_K", "gm.fer_K", wet_nl); chk("gm", "fer_c", "gm.fer_c")
+            orc.call("fer_solve_Gamma"); chk("gm", "fer_gamma", "gm.fer_gamma", np.repeat(wet_nl[:, :, None], 2, 2))
+            orc.call("fer_gamma2vel"); chk("gm", "fer_UV", "gm.fer_UV", we2)
         orc.call("vert_vel_ale")
         for f in ("Wvel", "Wvel_e", "Wvel_i", "CFL_z"):
             chk("vert_vel_ale", f, "vert_vel_ale." + f, wet_nl)
         chk("vert_vel_ale", "hnode_new", "vert_vel_ale.hnode_new", wet_n)
+        if par.Fer_GM:
+            orc.call("fer_wvel"); chk("gm", "fer_Wvel", "gm.fer_Wvel", wet_nl)
+            orc.call("bolus_add")
         for tr in (1, 2):
             p = f"tr{tr}."
             orc.call("init_tracers_AB", tr)
@@ -189,6 +196,8 @@ def main():
             if toy:
                 orc.call("relax_zonal_temp")              # after every tracer, always on tracer 1
             allok &= report(f"diff{tr}:tr_arr", orc.get("tr_arr").reshape(2, -1, nlm1)[tr - 1], g(p + "end.tr_arr"), wet_n)
+        if par.Fer_GM:
+            orc.call("bolus_remove")
         orc.call("salinity_clamp")
         orc.call("update_thickness_ale")
         for f in ("hnode", "helem", "zbar_3d_n", "Z_3d_n"):

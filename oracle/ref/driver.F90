@@ -374,15 +374,19 @@ contains
     call mark('init_Redi_GM')
     if (Fer_GM .or. Redi) call init_Redi_GM(mesh)
     if (Fer_GM) then
+       call dump('gm.fer_K', fer_k); call dump('gm.fer_c', fer_c)
        call mark('fer_solve_Gamma')
        call fer_solve_Gamma(mesh)
+       call dump('gm.fer_gamma', fer_gamma)
        call mark('fer_gamma2vel')
        call fer_gamma2vel(mesh)
+       call dump('gm.fer_UV', fer_UV)
     end if
     call mark('vert_vel_ale')
     call vert_vel_ale(mesh)
     call dump('vert_vel_ale.Wvel', Wvel); call dump('vert_vel_ale.Wvel_e', Wvel_e); call dump('vert_vel_ale.Wvel_i', Wvel_i)
     call dump('vert_vel_ale.hnode_new', hnode_new); call dump('vert_vel_ale.CFL_z', CFL_z)
+    if (Fer_GM) call dump('gm.fer_Wvel', fer_Wvel)
 
     ! ---- solve_tracers_ale replayed (src/oce_ale_tracer.F90:101-199) ----
     if (Fer_GM) then

@@ -59,10 +59,18 @@ def run_reference_chain(orc, mesh, g, steps=(1, 2, 3), toy=False, skip=()):
         for f in ("hbar", "hbar_old", "ssh_rhs_old", "dhe"):
             chk(step, f, "compute_hbar_ale." + f)
         orc.call("eta_update"); chk(step, "eta_n", "eta_n_update.eta_n")
+        gm = bool(orc.params.Fer_GM)
+        if gm:                                              # oce_ale.F90:2729-2739
+            orc.call("init_Redi_GM"); chk(step, "fer_K", "gm.fer_K", "nl"); chk(step, "fer_c", "gm.fer_c")
+            orc.call("fer_solve_Gamma"); chk(step, "fer_gamma", "gm.fer_gamma", "nl2")
+            orc.call("fer_gamma2vel"); chk(step, "fer_UV", "gm.fer_UV", "e2")
         orc.call("vert_vel_ale")
         for f in ("Wvel", "Wvel_e", "Wvel_i", "CFL_z"):
             chk(step, f, "vert_vel_ale." + f, "nl")
         chk(step, "hnode_new", "vert_vel_ale.hnode_new", "n")
+        if gm:
+            orc.call("fer_wvel"); chk(step, "fer_Wvel", "gm.fer_Wvel", "nl")
+            orc.call("bolus_add")                           # solve_tracers_ale: UV, Wvel(_e) += bolus velocities around the tracer loop
         for tr in (1, 2):
             p = f"tr{tr}."
             orc.call("init_tracers_AB", tr)
@@ -78,6 +86,8 @@ def run_reference_chain(orc, mesh, g, steps=(1, 2, 3), toy=False, skip=()):
             if toy:
                 orc.call("relax_zonal_temp")             # after every tracer of the loop, always on tracer 1
             chk(step, "tr_arr", p + "end.tr_arr", "n", sub=tr - 1)
+        if gm:
+            orc.call("bolus_remove")
         orc.call("salinity_clamp")
         orc.call("update_thickness_ale")
         for f in ("hnode", "helem", "zbar_3d_n", "Z_3d_n"):
