@@ -89,8 +89,15 @@ void enqueue_step(hipStream_t s, int first_step, int n) {
   launch_ssh_rhs(m, s);                      // update_stiff_mat_ale, compute_ssh_rhs_ale
   launch_solver(m, s);                       // solve_ssh_ale
   if (toy) launch_named_toy(m, s, "relax_zonal_vel");                      // oce_ale.F90:2696
+  const bool gm = m.p.Fer_GM != 0;
+  if (gm) {                                  // before vert_vel_ale touches hnode_new (oce_ale.F90:2729-2739)
+    launch_named_gm(m, s, "init_Redi_GM"); launch_named_gm(m, s, "fer_solve_Gamma"); launch_named_gm(m, s, "fer_gamma2vel");
+    launch_named_gm(m, s, "fer_wvel");
+  }
   launch_dynamics_post(m, s);                // update_vel, compute_hbar_ale, eta_n, vert_vel_ale
+  if (gm) launch_named_gm(m, s, "bolus_add");                               // solve_tracers_ale :127-131
   launch_tracer(m, s, -1);                   // solve_tracers_ale, all tracers per launch
+  if (gm) launch_named_gm(m, s, "bolus_remove");                            // :165-169
   if (toy) for (int tr = 0; tr < m.ntr; tr++) launch_named_toy(m, s, "relax_zonal_temp");   // once per tracer, oce_ale_tracer.F90:150
   launch_thickness(m, s);                    // update_thickness_ale
 }
@@ -138,6 +145,13 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   hipEvent_t ev_visc = d.ev(); hipEventRecord(ev_visc, s3);
   hipStreamWaitEvent(s3, ev_pb, 0);
   K(s3, "k_sigma_slope");
+  const bool gm = m.p.Fer_GM != 0;
+  hipEvent_t ev_gm = nullptr;
+  if (gm) {            // bolus velocities: need bvfreq, sigma_xy, helem and the OLD hnode_new -> before vert_vel_ale on s0
+    launch_named_gm(m, s3, "init_Redi_GM"); launch_named_gm(m, s3, "fer_solve_Gamma"); launch_named_gm(m, s3, "fer_gamma2vel");
+    launch_named_gm(m, s3, "fer_wvel");
+    ev_gm = d.ev(); hipEventRecord(ev_gm, s3);
+  }
   K(s3, "k_tr_ab", 0); K(s3, "k_tr_grad_elem", 0); K(s3, "k_updn_grad", 0);
   if (m.p.with_diffusion) K(s3, "k_diff_flux", 0);
   hipEvent_t ev_prep = d.ev(); hipEventRecord(ev_prep, s3);
@@ -152,7 +166,9 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   launch_solver(m, s0, 1, 1);                      // set-up gathers ssh_rhs (k_ssh_rhs_node fused); row scales from s1
   if (toy) launch_named_toy(m, s0, "relax_zonal_vel");                     // oce_ale.F90:2696
   K(s0, "k_update_vel"); K(s0, "k_edge_transport1");
+  if (gm) hipStreamWaitEvent(s0, ev_gm, 0);
   K(s0, "k_vert_vel_hbar");                        // k_hbar_node fused
+  if (gm) launch_named_gm(m, s0, "bolus_add");     // solve_tracers_ale :127-131
   hipEvent_t ev_w = d.ev(); hipEventRecord(ev_w, s0);
   hipStreamWaitEvent(s1, ev_w, 0);
   K(s1, "k_dhe");
@@ -164,6 +180,7 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   K(s1, "k_fct_edge_limit", 0);                    // materialises the limited flux field; k_tr_update limits on the fly
   K(s0, "k_tr_update", 0);                         // incl. the Thomas sweep
   if (toy) for (int tr = 0; tr < m.ntr; tr++) launch_named_toy(m, s0, "relax_zonal_temp");   // once per tracer
+  if (gm) { d.dep(s0, s1); launch_named_gm(m, s0, "bolus_remove"); }       // :165-169 (k_fct_edge_limit on s1 still reads nothing of it)
   d.dep(s0, s1); d.dep(s0, s2); d.dep(s0, s3);
   launch_thickness(m, s0);
 }
@@ -205,6 +222,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   if (d->nl > 64) { G.err = "fesom_gpu_init: nl > 64 levels not supported by the one-wave-per-column kernels"; return 3; }
   if (par->which_ale != 0 && par->which_ale != 2) { G.err = "fesom_gpu_init: which_ale must be linfs(0) or zstar(2)"; return 3; }
   if (par->mom_adv != 2 || par->visc_option != 5) { G.err = "fesom_gpu_init: only mom_adv=2, visc_option=5 are implemented"; return 3; }
+  if (par->Fer_GM && par->scaling_Rossby) { G.err = "fesom_gpu_init: scaling_Rossby=.true. (GM cut-off by the Rossby radius) is not implemented"; return 3; }
   if (par->w_split) { G.err = "fesom_gpu_init: w_split=.true. (implicit vertical advection of tracers) is not implemented"; return 3; }
   for (int e = 0; e < d->myDim_elem2D + d->eDim_elem2D; e++)
     if (d->ulevels[e] != 1) { G.err = "fesom_gpu_init: cavities (ulevels>1) are not supported"; return 3; }
@@ -340,6 +358,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   F(pgf_x, n1 * E); F(pgf_y, n1 * E); F(helem, n1 * E); F(Av, nl * E); F(dhe, E); F(stress_surf, 2 * E);
   FT(adv_flux_hor, n1 * D); FT(adv_flux_raw, n1 * D); FT(flux_lo_hor, n1 * D); FT(diff_flux, n1 * D); FT(edge_up_dn_grad, 4 * n1 * D); F(edge_c12, D);
   F(ssh_values, m.nza);
+  if (par->Fer_GM) { F(fer_K, nl * N); F(fer_gamma, 2 * nl * N); F(fer_Wvel, nl * N); F(fer_c, N); F(fer_UV, 2 * n1 * E); }
   if (par->toy_soufflet) { F(Tclim, n1 * N); F(Uclim, n1 * E); F(toy_zvel, n1 * 100); F(toy_ztem, n1 * 100); }
   F(sv_vals, 16 * (N + 64)); F(sv_dinv, N + 64); F(sv_b, N + 64); F(sv_r, N + 64); F(sv_r0, N + 64); F(sv_p, N + 64); F(sv_v, N + 64); F(sv_s, N + 64); F(sv_t, N + 64);
   F(sv_ph, N + 64); F(sv_x0, 16 * (N + 64)); F(sv_snap, N);
@@ -349,6 +368,18 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
 #undef F
 #undef FT
   m.sv_info = dev_alloc<int>(4);
+  if (par->Fer_GM) {
+    // mesh-only part of the horizontal GM scaling (init_Redi_GM, src/oce_fer_gm.F90:204-232; scaling_Rossby is rejected above)
+    std::vector<double> sc(N, 1.0);
+    for (size_t n = 0; n < N; n++) {
+      double reso = d->mesh_resolution[n], scaling = 1.;
+      if (par->scaling_resolution) scaling = scaling * pow(reso / 100000., par->K_GM_resscalorder);
+      if (reso / 1000.0 < par->K_GM_rampmax) scaling = scaling * std::max((reso / 1000.0 - par->K_GM_rampmin) / (par->K_GM_rampmax - par->K_GM_rampmin), 0.);
+      sc[n] = scaling;
+    }
+    m.gm_scal_static = dev_upload(sc);
+    m.MLD1_ind = dev_alloc<int>(N);
+  }
   G.npes = part ? part->npes : 1; G.mype = part ? part->mype : 0;
   G.hsend = G.hrecv = nullptr; G.hcap = 0;
   if (part && part->npes > 1) {
@@ -482,6 +513,8 @@ static int call_named(const char *name, int arg) {
   rc = launch_named_tra(m, G.stream, name, arg);
   if (rc == 0) return 0;
   rc = launch_named_toy(m, G.stream, name);
+  if (rc == 0) return 0;
+  rc = launch_named_gm(m, G.stream, name);
   if (rc == 0) return 0;
   rc = launch_named_dsolve(m, G.stream, name);
   if (rc == 0) return 0;

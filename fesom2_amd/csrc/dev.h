@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <algorithm>
 #include "../../include/fesom_gpu.h"
 
 #define WAVE 64
@@ -48,6 +49,10 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   double *pgf_x, *pgf_y, *helem, *Av, *dhe, *stress_surf;
   double *adv_flux_hor, *adv_flux_raw, *flux_lo_hor, *edge_up_dn_grad, *edge_c12, *diff_flux;
   double *ssh_values;
+  // Gent-McWilliams bolus velocities (kernels_gm.hip)
+  double *fer_K, *fer_gamma, *fer_Wvel, *fer_c, *fer_UV;   // (nl,N), (2,nl,N), (nl,N), (N), (2,nl-1,E)
+  const double *gm_scal_static;                           // (N) mesh-only part of the horizontal GM scaling
+  int *MLD1_ind;                                          // (N) level index of MLD1 (pressure_bv)
   // Soufflet toy channel (kernels_toy.hip): relaxation targets, zonal means per (level, latitude bin), static bin tables
   double *Tclim, *Uclim, *toy_zvel, *toy_ztem;
   const double *toy_znum, *toy_e_a, *toy_n_a;
@@ -217,4 +222,5 @@ void launch_dynamics_post(const DM &m, hipStream_t s);
 void launch_tracer(const DM &m, hipStream_t s, int tr);
 void launch_thickness(const DM &m, hipStream_t s);
 int  launch_named_toy(const DM &m, hipStream_t s, const char *name);
+int  launch_named_gm(const DM &m, hipStream_t s, const char *name);
 int  launch_named_dsolve(const DM &m, hipStream_t s, const char *name);

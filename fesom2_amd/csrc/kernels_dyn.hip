@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(BLOCK) k_pressure_bv(DM m) {
   } else {
     mld2 = bcast(z, (nzmax - 2 > nzmin) ? nzmax - 2 : nzmin);   // last Z visited (or the initial value)
   }
-  if (l == 0) { m.MLD1[n] = mld1; m.MLD2[n] = mld2; }
+  if (l == 0) { m.MLD1[n] = mld1; m.MLD2[n] = mld2; if (m.MLD1_ind) m.MLD1_ind[n] = i1 + 1; }
   // sw_alpha_beta (owned nodes)
   if (wet && n < m.myN) {
     double t1 = t * 1.00024, s1 = s, p1 = fabs(z);

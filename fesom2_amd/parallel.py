@@ -53,10 +53,17 @@ def run_step(core, par, X, solve, first, probe=None):
         c("k_stiff_update")
     c("k_edge_transport"); c("k_ssh_rhs_node"); P("ssh_rhs")
     solve(); X(NOD, ["d_eta"]); P("solve")
+    if p.Fer_GM:                                      # bolus velocities (oce_fer_gm.F90), before vert_vel_ale moves hnode_new
+        c("init_Redi_GM"); X(NOD, ["fer_c", "fer_K"])
+        c("fer_solve_Gamma"); X(NOD, ["fer_gamma"])
+        c("fer_gamma2vel"); X(ELEM, ["fer_UV"])
+        c("fer_wvel"); X(NOD, ["fer_Wvel"])
     c("k_update_vel"); X(ELEM, ["UV"])
     c("k_edge_transport1"); c("k_vert_vel_hbar")
     X(NOD, ["Wvel", "Wvel_e", "Wvel_i", "hnode_new", "hbar", "hbar_old", "eta_n", "ssh_rhs_old"])
     c("k_dhe"); P("vert_vel")
+    if p.Fer_GM:
+        c("bolus_add")
     c("k_tr_ab", 0); c("k_tr_grad_elem", 0); X(ELEM_FULL, ["tr_xy_ab"])
     c("k_updn_grad", 0)
     if p.with_diffusion:
@@ -65,6 +72,8 @@ def run_step(core, par, X, solve, first, probe=None):
     c("k_flux_hor", 0); c("k_fct_lo_node", 0); X(NOD, ["fct_LO"])
     c("k_fct_node", 0); X(NOD, ["fct_plus", "fct_minus"])
     c("k_fct_edge_limit", 0); c("k_tr_update", 0); X(NOD, ["tr_arr"]); P("tracers")
+    if p.Fer_GM:
+        c("bolus_remove")
     c("k_thick_node"); c("k_thick_elem"); P("thickness")
 
 

@@ -39,10 +39,22 @@ TAIL = [("salinity_clamp", 0, ["tr_arr"]), ("update_thickness_ale", 0, ["hnode",
 ULP_FIELDS = {"slope_tapered": 1e-12}
 
 
-def full_chain(ntr=2):
-    ch = list(DYN_PRE)
+GM_BEFORE_W = [("init_Redi_GM", 0, ["fer_K", "fer_c"]), ("fer_solve_Gamma", 0, ["fer_gamma"]), ("fer_gamma2vel", 0, ["fer_UV"])]
+GM_AFTER_W = [("fer_wvel", 0, ["fer_Wvel"]), ("bolus_add", 0, ["UV", "Wvel", "Wvel_e"])]
+
+
+def full_chain(ntr=2, gm=False):
+    ch = []
+    for item in DYN_PRE:
+        if gm and item[0] == "vert_vel_ale":
+            ch += GM_BEFORE_W                      # oce_ale.F90:2729-2739: before vert_vel_ale
+        ch.append(item)
+        if gm and item[0] == "vert_vel_ale":
+            ch += GM_AFTER_W                       # fer_Wvel is part of vert_vel_ale; bolus added around the tracer loop
     for tr in range(1, ntr + 1):
         ch += tracer_chain(tr)
+    if gm:
+        ch.append(("bolus_remove", 0, ["UV", "Wvel", "Wvel_e"]))
     return ch + TAIL
 
 

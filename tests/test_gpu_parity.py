@@ -109,3 +109,38 @@ def test_psolve_abi(setup):
     res = np.array([(vals[rp[i]:rp[i + 1]] * sol[ci[rp[i]:rp[i + 1]]]).sum() for i in range(n)]) - rhs
     assert np.sqrt(((res * scale) ** 2).sum()) < 2e-10
     assert np.abs(sol - xt).max() < 1e-6 * np.abs(xt).max()
+
+
+def test_gm_chain_and_steps_bitwise(built):
+    """Gent-McWilliams bolus velocities (Fer_GM=.true.): routine chain over 3 steps and 10 whole steps, HIP == oracle bitwise
+    (the oracle is pinned against a reference run with the same options, tests/test_oracle_vs_reference.py)"""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.core import OceanCore
+    from fesom2_amd.synthetic import analytic_ts
+    from oracle_lib import Oracle
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, Fer_GM=True, scaling_Ferreira=True)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    gpu, orc = OceanCore(mesh, par), Oracle(mesh, par)
+    gpu.upload_state(st); orc.set_state(st)
+    failures = []
+    for step in range(1, 4):
+        for routine, arg, fields in full_chain(2, gm=True):
+            gpu.call(routine, arg); orc.call(routine, arg)
+            for f in fields:
+                ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+                if not ok:
+                    failures.append(f"step {step} {routine}({arg}) {msg}")
+        if failures:
+            break
+    assert not failures, "\n".join(failures[:10])
+    gpu.run_steps(4, 10)
+    for n in range(10):
+        orc.call("step", 4 + n)
+    for f in ("tr_arr", "UV", "eta_n", "hnode", "fer_UV", "fer_Wvel"):
+        ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+        assert ok, msg
+    gpu.close()
