@@ -56,7 +56,7 @@ class Params(C.Structure):
                 + [("with_diffusion", C.c_int), ("solver_x0_order", C.c_int), ("Fer_GM", C.c_int), ("K_GM_max", C.c_double),
                    ("K_GM_min", C.c_double), ("K_GM_bvref", C.c_int), ("K_GM_rampmax", C.c_double), ("K_GM_rampmin", C.c_double),
                    ("K_GM_resscalorder", C.c_double), ("scaling_Ferreira", C.c_int), ("scaling_Rossby", C.c_int),
-                   ("scaling_resolution", C.c_int), ("scaling_FESOM14", C.c_int)])
+                   ("scaling_resolution", C.c_int), ("scaling_FESOM14", C.c_int), ("Redi", C.c_int)])
 
 
 STATE_FIELDS = ("tr_arr", "tr_arr_old", "UV", "UV_rhsAB", "eta_n", "d_eta", "ssh_rhs", "ssh_rhs_old", "hbar",

@@ -8,7 +8,7 @@ def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equati
                 mix_scheme="PP", with_diffusion=True, toy_soufflet=False, K_hor=3000.0, A_ver=1.0e-4, K_ver=1.0e-5,
                 cyclic_length_deg=360.0, w_split=False, use_instabmix=True, use_windmix=False, solver_x0_order=3,
                 Fer_GM=False, K_GM_max=2000.0, K_GM_min=2.0, K_GM_bvref=2, K_GM_rampmax=-1.0, K_GM_rampmin=-1.0,
-                K_GM_resscalorder=1.0, scaling_Ferreira=False, scaling_resolution=True, scaling_FESOM14=False):
+                K_GM_resscalorder=1.0, scaling_Ferreira=False, scaling_resolution=True, scaling_FESOM14=False, Redi=False):
     p = _lib.Params()
     p.dt = dt
     p.which_ale = WHICH_ALE[which_ale]
@@ -39,4 +39,5 @@ def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equati
     p.K_GM_rampmax, p.K_GM_rampmin, p.K_GM_resscalorder = K_GM_rampmax, K_GM_rampmin, K_GM_resscalorder
     p.scaling_Ferreira, p.scaling_Rossby = int(scaling_Ferreira), 0
     p.scaling_resolution, p.scaling_FESOM14 = int(scaling_resolution), int(scaling_FESOM14)
+    p.Redi = int(Redi)
     return p

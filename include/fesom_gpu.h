@@ -112,6 +112,7 @@ typedef struct fesom_params {
   int    K_GM_bvref;         /* reference N^2 of the Ferreira scaling: 0 surface, 1 below the mixed layer, 2 mean over it */
   double K_GM_rampmax, K_GM_rampmin, K_GM_resscalorder;
   int    scaling_Ferreira, scaling_Rossby /* unsupported */, scaling_resolution, scaling_FESOM14;
+  int    Redi;               /* isoneutral (Redi) diffusion: rotated horizontal + explicit/implicit vertical parts (oce_ale_tracer.F90) */
 } fesom_params;
 
 /* ---- prognostic state = restart set (io_restart.F90:99-155) + ALE thickness arrays -- */

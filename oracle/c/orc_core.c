@@ -203,7 +203,8 @@ void orc_step(int n) {
   orc_update_vel();
   orc_compute_hbar_ale();
   orc_eta_update();
-  if (C_.p.Fer_GM) { orc_init_Redi_GM(); orc_fer_solve_Gamma(); orc_fer_gamma2vel(); }   /* oce_ale.F90:2729-2739 */
+  if (C_.p.Fer_GM || C_.p.Redi) orc_init_Redi_GM();                                        /* oce_ale.F90:2729-2739 */
+  if (C_.p.Fer_GM) { orc_fer_solve_Gamma(); orc_fer_gamma2vel(); }
   orc_vert_vel_ale();
   if (C_.p.Fer_GM) { orc_fer_wvel(); orc_bolus_add(); }                                   /* oce_ale.F90:1720-1811, oce_ale_tracer.F90:127-131 */
   for (int tr = 1; tr <= C_.ntr; tr++) {

@@ -18,21 +18,28 @@ void orc_gm_static(void) {
   }
 }
 
-/* init_Redi_GM (:159-340), GM part */
+/* init_Redi_GM (:159-340) */
 void orc_init_Redi_GM(void) {
   const double c_min = 0.5, pi = 3.14159265358979;
   double zscaling[80];
+  const int gm = C_.p.Fer_GM, redi = C_.p.Redi;
   for (int n = 1; n <= C_.m.myDim_nod2D; n++) {
     int nzmax = C_.m.nlevels_nod2D_min[n - 1], nzmin = C_.m.ulevels_nod2D_max[n - 1];   /* min / max over the node's elements */
-    double c1 = 0.;
-    for (int nz = nzmin; nz <= nzmax - 1; nz++)
-      c1 = c1 + A2(C_.hnode_new, nz, n) * (sqrt(fabs(dmax(A2L(C_.bvfreq, nz, n), 0.))) + sqrt(fabs(dmax(A2L(C_.bvfreq, nz + 1, n), 0.)))) / 2.;
-    c1 = dmax(c_min, c1 / pi);
-    C_.fer_scal[n - 1] = dmin(C_.gm_scal_static[n - 1], 1.0);
-    A2L(C_.fer_K, nzmin, n) = C_.fer_scal[n - 1] * C_.p.K_GM_max;
-    A2L(C_.fer_K, nzmin, n) = dmax(A2L(C_.fer_K, nzmin, n), C_.p.K_GM_min);
-    C_.fer_c[n - 1] = c1 * c1;
+    double reso = C_.m.mesh_resolution[n - 1];
+    if (gm) {
+      double c1 = 0.;
+      for (int nz = nzmin; nz <= nzmax - 1; nz++)
+        c1 = c1 + A2(C_.hnode_new, nz, n) * (sqrt(fabs(dmax(A2L(C_.bvfreq, nz, n), 0.))) + sqrt(fabs(dmax(A2L(C_.bvfreq, nz + 1, n), 0.)))) / 2.;
+      c1 = dmax(c_min, c1 / pi);
+      C_.fer_scal[n - 1] = dmin(C_.gm_scal_static[n - 1], 1.0);
+      A2L(C_.fer_K, nzmin, n) = C_.fer_scal[n - 1] * C_.p.K_GM_max;
+      A2L(C_.fer_K, nzmin, n) = dmax(A2L(C_.fer_K, nzmin, n), C_.p.K_GM_min);
+      C_.fer_c[n - 1] = c1 * c1;
+    }
+    if (redi) { double q = reso / 100000.0; A2(C_.Ki, nzmin, n) = C_.p.K_hor * (q * q); }
   }
+  if (redi && gm)                                          /* "like in FESOM 1.4 we make Redi equal GM" (whole array) */
+    for (int n = 1; n <= C_.N; n++) A2(C_.Ki, ULEVN(n), n) = A2L(C_.fer_K, ULEVN(n), n);
   for (int n = 1; n <= C_.m.myDim_nod2D; n++) {
     int nzmax = NLEVN(n), nzmin = ULEVN(n);
     if (C_.p.scaling_Ferreira) {
@@ -49,8 +56,14 @@ void orc_init_Redi_GM(void) {
     } else for (int nz = 0; nz < 80; nz++) zscaling[nz] = 1.0;
     if (C_.p.scaling_FESOM14)
       for (int nz = nzmin; nz <= nzmax; nz++) { int k = nz < NL - 1 ? nz : NL - 1; if (V3(C_.neutral_slope, 3, k, n) > 5.e-3) zscaling[nz] = 0.0; }
-    for (int nz = nzmin + 1; nz <= nzmax; nz++) A2L(C_.fer_K, nz, n) = A2L(C_.fer_K, nzmin, n) * zscaling[nz];
-    A2L(C_.fer_K, nzmin, n) = A2L(C_.fer_K, nzmin, n) * zscaling[nzmin];
+    if (gm) {
+      for (int nz = nzmin + 1; nz <= nzmax; nz++) A2L(C_.fer_K, nz, n) = A2L(C_.fer_K, nzmin, n) * zscaling[nz];
+      A2L(C_.fer_K, nzmin, n) = A2L(C_.fer_K, nzmin, n) * zscaling[nzmin];
+    }
+    if (redi) {
+      for (int nz = nzmin + 1; nz <= nzmax - 1; nz++) A2(C_.Ki, nz, n) = A2(C_.Ki, nzmin, n) * 0.5 * (zscaling[nz] + zscaling[nz + 1]);
+      A2(C_.Ki, nzmin, n) = A2(C_.Ki, nzmin, n) * 0.5 * (zscaling[nzmin] + zscaling[nzmin + 1]);
+    }
   }
 }
 

@@ -321,21 +321,30 @@ static void diff_part_hor(void) {
     int nl12 = nl1 < nl2 ? nl1 : nl2, ul12 = ul1 > ul2 ? ul1 : ul2;
     int hi = nl1 > nl2 ? nl1 : nl2, lo = ul1;
     if (ul2 > 0) lo = ul1 < ul2 ? ul1 : ul2;
+    const double isredi = C_.p.Redi ? 1.0 : 0.0;
     for (int nz = lo; nz <= hi; nz++) {
       double Kh = (A2(C_.Ki, nz, n1) + A2(C_.Ki, nz, n2)) / 2.0, c;
+      /* Redi: slope * vertical gradient at the two edge nodes (:990-993); with Redi off the reference still forms S*Tz*0 */
+      double sxtz = 0.0, sytz = 0.0;
+      if (C_.p.Redi) {
+        double Tz1 = 0.5 * (A2L(C_.tr_z, nz, n1) + A2L(C_.tr_z, nz + 1, n1)), Tz2 = 0.5 * (A2L(C_.tr_z, nz, n2) + A2L(C_.tr_z, nz + 1, n2));
+        sxtz = (Tz1 * V3(C_.slope_tapered, 1, nz, n1) + Tz2 * V3(C_.slope_tapered, 1, nz, n2)) / 2.0;
+        sytz = (Tz1 * V3(C_.slope_tapered, 2, nz, n1) + Tz2 * V3(C_.slope_tapered, 2, nz, n2)) / 2.0;
+      }
+      const double ax = sxtz * isredi, ay = sytz * isredi;
       if (nz >= ul12 && nz <= nl12) {
         double dz = (A2(C_.helem, nz, e1) + A2(C_.helem, nz, e2)) / 2.0;
         double Tx = 0.5 * (V2(C_.tr_xy, 1, nz, e1) + V2(C_.tr_xy, 1, nz, e2));
         double Ty = 0.5 * (V2(C_.tr_xy, 2, nz, e1) + V2(C_.tr_xy, 2, nz, e2));
-        double Fx = Kh * (Tx + 0.0), Fy = Kh * (Ty + 0.0);
+        double Fx = Kh * (Tx + ax), Fy = Kh * (Ty + ay);
         c = ((dX2 - dX1) * Fy - (dY2 - dY1) * Fx) * dz;
       } else if ((nz >= ul1 && nz <= ul12 - 1) || (nz >= nl12 + 1 && nz <= nl1)) {
         double dz = A2(C_.helem, nz, e1);
-        double Fx = Kh * (V2(C_.tr_xy, 1, nz, e1) + 0.0), Fy = Kh * (V2(C_.tr_xy, 2, nz, e1) + 0.0);
+        double Fx = Kh * (V2(C_.tr_xy, 1, nz, e1) + ax), Fy = Kh * (V2(C_.tr_xy, 2, nz, e1) + ay);
         c = (-dX1 * Fy + dY1 * Fx) * dz;
       } else {
         double dz = A2(C_.helem, nz, e2);
-        double Fx = Kh * (V2(C_.tr_xy, 1, nz, e2) + 0.0), Fy = Kh * (V2(C_.tr_xy, 2, nz, e2) + 0.0);
+        double Fx = Kh * (V2(C_.tr_xy, 1, nz, e2) + ax), Fy = Kh * (V2(C_.tr_xy, 2, nz, e2) + ay);
         c = (dX2 * Fy - dY2 * Fx) * dz;
       }
       double rhs1 = 0.0 + c, rhs2 = 0.0 - c;
@@ -343,6 +352,42 @@ static void diff_part_hor(void) {
       A2(C_.del_ttf, nz, n2) = A2(C_.del_ttf, nz, n2) + rhs2 * dt / AREASVOL(nz, n2);
     }
   }
+}
+
+/* diff_ver_part_redi_expl: src/oce_ale_tracer.F90:860-927 */
+static void diff_ver_part_redi_expl(void) {
+  int nl = NL;
+  double dt = C_.p.dt;
+  double *txn = calloc((size_t)2 * NLM1 * C_.N, sizeof(double));
+  double *buf = calloc((size_t)3 * (nl + 2), sizeof(double)), *zbar_n = buf, *Z_n = buf + nl + 2, *vd = Z_n + nl + 2;
+  for (int n = 1; n <= C_.m.myDim_nod2D; n++)
+    for (int nz = ULEVN(n); nz <= NLEVN(n) - 1; nz++) {
+      double Tx = 0.0, Ty = 0.0;
+      for (int k = 1; k <= C_.m.nod_in_elem2D_num[n - 1]; k++) {
+        int el = NIE(k, n);
+        if (nz <= NLEV(el) - 1 && nz >= ULEV(el)) { Tx = Tx + V2(C_.tr_xy, 1, nz, el) * C_.m.elem_area[el - 1]; Ty = Ty + V2(C_.tr_xy, 2, nz, el) * C_.m.elem_area[el - 1]; }
+      }
+      V2(txn, 1, nz, n) = Tx / 3.0 / AREASVOL(nz, n);
+      V2(txn, 2, nz, n) = Ty / 3.0 / AREASVOL(nz, n);
+    }
+  for (int n = 1; n <= C_.m.myDim_nod2D; n++) {
+    int nl1 = NLEVN(n) - 1, ul1 = ULEVN(n);
+    for (int k = 0; k < nl + 2; k++) { vd[k] = 0.; zbar_n[k] = 0.; Z_n[k] = 0.; }
+    zbar_n[nl1 + 1] = C_.m.zbar_n_bot[n - 1];
+    Z_n[nl1] = zbar_n[nl1 + 1] + A2(C_.hnode_new, nl1, n) / 2.0;
+    for (int nz = nl1; nz >= ul1 + 1; nz--) {
+      zbar_n[nz] = zbar_n[nz + 1] + A2(C_.hnode_new, nz, n);
+      Z_n[nz - 1] = zbar_n[nz] + A2(C_.hnode_new, nz - 1, n) / 2.0;
+    }
+    zbar_n[ul1] = zbar_n[ul1 + 1] + A2(C_.hnode_new, ul1, n);
+    for (int nz = ul1 + 1; nz <= nl1; nz++) {
+      vd[nz] = (Z_n[nz - 1] - zbar_n[nz]) * (V3(C_.slope_tapered, 1, nz - 1, n) * V2(txn, 1, nz - 1, n) + V3(C_.slope_tapered, 2, nz - 1, n) * V2(txn, 2, nz - 1, n)) * A2(C_.Ki, nz - 1, n);
+      vd[nz] = vd[nz] + (zbar_n[nz] - Z_n[nz]) * (V3(C_.slope_tapered, 1, nz, n) * V2(txn, 1, nz, n) + V3(C_.slope_tapered, 2, nz, n) * V2(txn, 2, nz, n)) * A2(C_.Ki, nz, n);
+      vd[nz] = vd[nz] / (Z_n[nz - 1] - Z_n[nz]) * AREA(nz, n);
+    }
+    for (int nz = ul1; nz <= nl1; nz++) A2(C_.del_ttf, nz, n) = A2(C_.del_ttf, nz, n) + (vd[nz] - vd[nz + 1]) * dt / AREASVOL(nz, n);
+  }
+  free(txn); free(buf);
 }
 
 /* bc_surface: src/oce_ale_tracer.F90:1154-1195 */
@@ -353,7 +398,7 @@ static double bc_surface(int n, int id) {
   return 0.0;
 }
 
-/* diff_ver_part_impl_ale with Redi=.false., no w_split, no KPP non-local, no SW penetration:
+/* diff_ver_part_impl_ale (Redi optional), no w_split, no KPP non-local, no SW penetration:
  * src/oce_ale_tracer.F90:398-856 */
 static void diff_ver_part_impl_ale(int tr) {
   int nl = NL;
@@ -372,13 +417,22 @@ static void diff_ver_part_impl_ale(int tr) {
     zbar_n[nzmin] = zbar_n[nzmin + 1] + A2(C_.hnode_new, nzmin, n);
     nz = nzmin;
     double zinv2 = 1.0 / (Z_n[nz] - Z_n[nz + 1]), zinv = 1.0 * dt, zinv1;
+    const double isredi = C_.p.Redi ? 1.0 : 0.0;
+#define K33(k) * (V3(C_.slope_tapered, 3, k, n) * V3(C_.slope_tapered, 3, k, n)) * A2(C_.Ki, k, n)    /* a*zinv*S**2*Ki, left to right */
     double Ty = 0.0, Ty1 = 0.0;
+    if (C_.p.Redi) Ty1 = (Z_n[nz] - zbar_n[nz + 1]) * zinv2 K33(nz) + (zbar_n[nz + 1] - Z_n[nz + 1]) * zinv2 K33(nz + 1);
+    Ty1 = Ty1 * isredi;
     a[nz] = 0.0;
     c[nz] = -(A2L(C_.Kv, nz + 1, n) + Ty1) * zinv2 * zinv * AREA(nz + 1, n) / AREASVOL(nz, n);
     b[nz] = -c[nz] + A2(C_.hnode_new, nz, n);
     zinv1 = zinv2;
     for (nz = nzmin + 1; nz <= nzmax - 2; nz++) {
       zinv2 = 1.0 / (Z_n[nz] - Z_n[nz + 1]);
+      if (C_.p.Redi) {
+        Ty = (Z_n[nz - 1] - zbar_n[nz]) * zinv1 K33(nz - 1) + (zbar_n[nz] - Z_n[nz]) * zinv1 K33(nz);
+        Ty1 = (Z_n[nz] - zbar_n[nz + 1]) * zinv2 K33(nz) + (zbar_n[nz + 1] - Z_n[nz + 1]) * zinv2 K33(nz + 1);
+      }
+      Ty = Ty * isredi; Ty1 = Ty1 * isredi;
       a[nz] = -(A2L(C_.Kv, nz, n) + Ty) * zinv1 * zinv * (AREA(nz, n) / AREASVOL(nz, n));
       c[nz] = -(A2L(C_.Kv, nz + 1, n) + Ty1) * zinv2 * zinv * AREA(nz + 1, n) / AREASVOL(nz, n);
       b[nz] = -a[nz] - c[nz] + A2(C_.hnode_new, nz, n);
@@ -386,6 +440,9 @@ static void diff_ver_part_impl_ale(int tr) {
     }
     nz = nzmax - 1;
     zinv = 1.0 * dt;
+    if (C_.p.Redi) Ty = (Z_n[nz - 1] - zbar_n[nz]) * zinv1 K33(nz - 1) + (zbar_n[nz] - Z_n[nz]) * zinv1 K33(nz);
+    Ty = Ty * isredi;
+#undef K33
     a[nz] = -(A2L(C_.Kv, nz, n) + Ty) * zinv1 * zinv * (AREA(nz, n) / AREASVOL(nz, n));
     c[nz] = 0.0;
     b[nz] = -a[nz] + A2(C_.hnode_new, nz, n);
@@ -419,6 +476,7 @@ void orc_diff_tracers_ale(int tr) {
   size_t cnt = (size_t)NLM1 * C_.N;
   memcpy(&TRO(1, 1, tr), &TR(1, 1, tr), sizeof(double) * cnt);
   if (C_.p.with_diffusion) diff_part_hor();
+  if (C_.p.with_diffusion && C_.p.Redi) diff_ver_part_redi_expl();
   for (int n = 1; n <= C_.m.myDim_nod2D; n++)
     for (int nz = ULEVN(n); nz <= NLEVN(n) - 1; nz++) {
       A2(C_.del_ttf, nz, n) = A2(C_.del_ttf, nz, n) + TR(nz, n, tr) * (A2(C_.hnode, nz, n) - A2(C_.hnode_new, nz, n));

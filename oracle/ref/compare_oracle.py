@@ -84,7 +84,7 @@ def main():
                      K_hor=float(c["k_hor"]))
     par = make_params(dt=dt, which_ale=c["which_ale"], use_partial_cell=c["use_partial_cell"] == ".true.",
                       state_equation=c["state_equation"], mix_scheme=c["mix_scheme"], with_diffusion=True,
-                      toy_soufflet=c["toy_ocean"] == ".true.", K_hor=float(c["k_hor"]), Fer_GM=c["fer_gm"] == ".true.",
+                      toy_soufflet=c["toy_ocean"] == ".true.", K_hor=float(c["k_hor"]), Fer_GM=c["fer_gm"] == ".true.", Redi=c["redi"] == ".true.",
                       cyclic_length_deg=float(c["cyclic_length"]))
     orc = Oracle(mesh, par)
     st = mesh.initial_state(2)
@@ -166,6 +166,8 @@ def main():
         for f in ("hbar", "hbar_old", "ssh_rhs_old", "dhe"):
             chk("compute_hbar_ale", f, "compute_hbar_ale." + f)
         orc.call("eta_update"); chk("eta_update", "eta_n", "eta_n_update.eta_n")
+        if par.Redi and not par.Fer_GM:
+            orc.call("init_Redi_GM")
         if par.Fer_GM:
             orc.call("init_Redi_GM"); chk("gm", "fer_K", "gm.fer_K", wet_nl); chk("gm", "fer_c", "gm.fer_c")
             orc.call("fer_solve_Gamma"); chk("gm", "fer_gamma", "gm.fer_gamma", np.repeat(wet_nl[:, :, None], 2, 2))

@@ -155,6 +155,11 @@ CFGS = {
                      rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                      fer_gm=".true.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
                      balance_salt_water=".true."),
+    # ... and with isoneutral (Redi) diffusion on top
+    "pi_pp_gm_redi": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                          rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                          fer_gm=".true.", redi=".true.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                          balance_salt_water=".true."),
     # pi mesh with the reference's default physics (KPP + GM + Redi)
     "pi_default": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,

@@ -88,6 +88,7 @@ def make(cfg, outname):
 def main():
     make("pi_pp", "pi_pp_reference.npz")
     make("pi_pp_gm", "pi_pp_gm_reference.npz")          # + Gent-McWilliams bolus velocities
+    make("pi_pp_gm_redi", "pi_pp_gm_redi_reference.npz")  # + isoneutral (Redi) diffusion
     make("souf", "souf_reference.npz")
     make("souf_linfs", "souf_linfs_reference.npz")      # linear free surface, full cells
     # known answers of the reference's own CI

@@ -60,6 +60,8 @@ def run_reference_chain(orc, mesh, g, steps=(1, 2, 3), toy=False, skip=()):
             chk(step, f, "compute_hbar_ale." + f)
         orc.call("eta_update"); chk(step, "eta_n", "eta_n_update.eta_n")
         gm = bool(orc.params.Fer_GM)
+        if orc.params.Redi and not gm:
+            orc.call("init_Redi_GM")
         if gm:                                              # oce_ale.F90:2729-2739
             orc.call("init_Redi_GM"); chk(step, "fer_K", "gm.fer_K", "nl"); chk(step, "fer_c", "gm.fer_c")
             orc.call("fer_solve_Gamma"); chk(step, "fer_gamma", "gm.fer_gamma", "nl2")

@@ -58,20 +58,23 @@ def test_oracle_chain_bitwise(env):
     assert not bad, "\n".join(bad[:20])
 
 
-def test_oracle_chain_bitwise_gm(built):
+@pytest.mark.parametrize("redi", [False, True])
+def test_oracle_chain_bitwise_gm(built, redi):
     """pi with the Gent-McWilliams bolus velocities (Fer_GM=.true., src/oce_fer_gm.F90): init_Redi_GM, fer_solve_Gamma,
-    fer_gamma2vel, fer_Wvel of vert_vel_ale and the bolus velocities around the tracer loop, against a reference run"""
+    fer_gamma2vel, fer_Wvel of vert_vel_ale and the bolus velocities around the tracer loop, against a reference run; with
+    `redi` also the isoneutral diffusion (rotated horizontal fluxes, explicit and implicit vertical parts,
+    src/oce_ale_tracer.F90:398-1077)"""
     from fesom2_amd.mesh import Mesh
     from fesom2_amd.config import make_params
     from fesom2_amd.synthetic import analytic_ts
     from oracle_lib import Oracle
     from ref_chain import run_reference_chain
     mesh = Mesh.load(PI, dt=900.0)
-    par = make_params(dt=900.0, Fer_GM=True)
+    par = make_params(dt=900.0, Fer_GM=True, Redi=redi)
     st = mesh.initial_state(2)
     st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
     st.tr_arr_old[...] = st.tr_arr
     orc = Oracle(mesh, par)
     orc.set_state(st)
-    bad = run_reference_chain(orc, mesh, gold("pi_pp_gm"), steps=(1, 2, 3))
+    bad = run_reference_chain(orc, mesh, gold("pi_pp_gm_redi" if redi else "pi_pp_gm"), steps=(1, 2, 3))
     assert not bad, "\n".join(bad[:20])
