@@ -90,10 +90,8 @@ void enqueue_step(hipStream_t s, int first_step, int n) {
   launch_solver(m, s);                       // solve_ssh_ale
   if (toy) launch_named_toy(m, s, "relax_zonal_vel");                      // oce_ale.F90:2696
   const bool gm = m.p.Fer_GM != 0;
-  if (gm) {                                  // before vert_vel_ale touches hnode_new (oce_ale.F90:2729-2739)
-    launch_named_gm(m, s, "init_Redi_GM"); launch_named_gm(m, s, "fer_solve_Gamma"); launch_named_gm(m, s, "fer_gamma2vel");
-    launch_named_gm(m, s, "fer_wvel");
-  }
+  if (gm || m.p.Redi) launch_named_gm(m, s, "init_Redi_GM");               // before vert_vel_ale touches hnode_new (oce_ale.F90:2729-2739)
+  if (gm) { launch_named_gm(m, s, "fer_solve_Gamma"); launch_named_gm(m, s, "fer_gamma2vel"); launch_named_gm(m, s, "fer_wvel"); }
   launch_dynamics_post(m, s);                // update_vel, compute_hbar_ale, eta_n, vert_vel_ale
   if (gm) launch_named_gm(m, s, "bolus_add");                               // solve_tracers_ale :127-131
   launch_tracer(m, s, -1);                   // solve_tracers_ale, all tracers per launch
@@ -147,13 +145,14 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   K(s3, "k_sigma_slope");
   const bool gm = m.p.Fer_GM != 0;
   hipEvent_t ev_gm = nullptr;
-  if (gm) {            // bolus velocities: need bvfreq, sigma_xy, helem and the OLD hnode_new -> before vert_vel_ale on s0
-    launch_named_gm(m, s3, "init_Redi_GM"); launch_named_gm(m, s3, "fer_solve_Gamma"); launch_named_gm(m, s3, "fer_gamma2vel");
-    launch_named_gm(m, s3, "fer_wvel");
+  const bool redi = m.p.Redi != 0;
+  if (gm || redi) {    // bolus velocities / Ki: need bvfreq, sigma_xy, helem and the OLD hnode_new -> before vert_vel_ale on s0
+    launch_named_gm(m, s3, "init_Redi_GM");
+    if (gm) { launch_named_gm(m, s3, "fer_solve_Gamma"); launch_named_gm(m, s3, "fer_gamma2vel"); launch_named_gm(m, s3, "fer_wvel"); }
     ev_gm = d.ev(); hipEventRecord(ev_gm, s3);
   }
   K(s3, "k_tr_ab", 0); K(s3, "k_tr_grad_elem", 0); K(s3, "k_updn_grad", 0);
-  if (m.p.with_diffusion) K(s3, "k_diff_flux", 0);
+  if (m.p.with_diffusion && !redi) K(s3, "k_diff_flux", 0);        // with Redi it needs tr_z of the new thicknesses: see s1 below
   hipEvent_t ev_prep = d.ev(); hipEventRecord(ev_prep, s3);
   // s0: critical chain
   K(s0, "k_vel_nodes");
@@ -166,18 +165,21 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   launch_solver(m, s0, 1, 1);                      // set-up gathers ssh_rhs (k_ssh_rhs_node fused); row scales from s1
   if (toy) launch_named_toy(m, s0, "relax_zonal_vel");                     // oce_ale.F90:2696
   K(s0, "k_update_vel"); K(s0, "k_edge_transport1");
-  if (gm) hipStreamWaitEvent(s0, ev_gm, 0);
+  if (ev_gm) hipStreamWaitEvent(s0, ev_gm, 0);
   K(s0, "k_vert_vel_hbar");                        // k_hbar_node fused
   if (gm) launch_named_gm(m, s0, "bolus_add");     // solve_tracers_ale :127-131
   hipEvent_t ev_w = d.ev(); hipEventRecord(ev_w, s0);
   hipStreamWaitEvent(s1, ev_w, 0);
   K(s1, "k_dhe");
-  K(s1, "k_tr_z", 0);                              // vertical tracer gradient: only consumed by Redi/GM, off the chain
+  K(s1, "k_tr_z", 0);                              // vertical tracer gradient: only consumed by Redi, off the chain
   hipStreamWaitEvent(s0, ev_prep, 0);
+  hipEvent_t ev_df = nullptr;
+  if (redi && m.p.with_diffusion) { hipStreamWaitEvent(s1, ev_prep, 0); K(s1, "k_diff_flux", 0); ev_df = d.ev(); hipEventRecord(ev_df, s1); }
   K(s0, "k_flux_hor", 0); K(s0, "k_fct_lo_node", 0); K(s0, "k_fct_node", 0);
   hipEvent_t ev_fct = d.ev(); hipEventRecord(ev_fct, s0);
   hipStreamWaitEvent(s1, ev_fct, 0);
   K(s1, "k_fct_edge_limit", 0);                    // materialises the limited flux field; k_tr_update limits on the fly
+  if (ev_df) hipStreamWaitEvent(s0, ev_df, 0);
   K(s0, "k_tr_update", 0);                         // incl. the Thomas sweep
   if (toy) for (int tr = 0; tr < m.ntr; tr++) launch_named_toy(m, s0, "relax_zonal_temp");   // once per tracer
   if (gm) { d.dep(s0, s1); launch_named_gm(m, s0, "bolus_remove"); }       // :165-169 (k_fct_edge_limit on s1 still reads nothing of it)
@@ -368,7 +370,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
 #undef F
 #undef FT
   m.sv_info = dev_alloc<int>(4);
-  if (par->Fer_GM) {
+  if (par->Fer_GM || par->Redi) {
     // mesh-only part of the horizontal GM scaling (init_Redi_GM, src/oce_fer_gm.F90:204-232; scaling_Rossby is rejected above)
     std::vector<double> sc(N, 1.0);
     for (size_t n = 0; n < N; n++) {
@@ -378,6 +380,8 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
       sc[n] = scaling;
     }
     m.gm_scal_static = dev_upload(sc);
+    for (size_t n = 0; n < N; n++) { double q = d->mesh_resolution[n] / 100000.0; sc[n] = par->K_hor * (q * q); }
+    m.redi_k0 = dev_upload(sc);
     m.MLD1_ind = dev_alloc<int>(N);
   }
   G.npes = part ? part->npes : 1; G.mype = part ? part->mype : 0;

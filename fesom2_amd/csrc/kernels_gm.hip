@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(BLOCK) k_gm_coef(DM m) {
   const double scal = dmin_(m.gm_scal_static[n], 1.0);
   double base = scal * m.p.K_GM_max;
   base = dmax_(base, m.p.K_GM_min);
-  if (l == 0) m.fer_c[n] = c1 * c1;
+  if (l == 0 && m.p.Fer_GM) m.fer_c[n] = c1 * c1;
   const int nzmax = m.nlev_n[n], nzmin = m.ulev_n[n];
   double zs = 1.0;
   if (m.p.scaling_Ferreira) {
@@ -42,7 +42,13 @@ __global__ void __launch_bounds__(BLOCK) k_gm_coef(DM m) {
     int k = nz < m.nl - 1 ? nz : m.nl - 1;
     if (DV3(m.neutral_slope, 3, k, n) > 5.e-3) zs = 0.0;
   }
-  if (nz >= nzmin && nz <= nzmax) DA2L(m.fer_K, nz, n) = base * zs;
+  if (m.p.Fer_GM && nz >= nzmin && nz <= nzmax) DA2L(m.fer_K, nz, n) = base * zs;
+  if (m.p.Redi) {                                          // Ki: K_hor*(reso/100km)^2, or the GM coefficient when both are on (:179-186)
+    double kb = base;
+    if (!m.p.Fer_GM) kb = m.redi_k0[n];
+    const double zs_dn = shdn(zs);
+    if (nz >= nzmin && nz <= nzmax - 1) DA2(m.Ki, nz, n) = kb * 0.5 * (zs + zs_dn);
+  }
 }
 
 // fer_solve_Gamma (:8-120): tridiagonal problem per node column with two right-hand sides; the sweep runs in the block
@@ -131,7 +137,8 @@ __global__ void k_bolus(DM m, double sign) {
 
 #define LAUNCH_COL(k, ncol, ...) hipLaunchKernelGGL(k, dim3(nblocks(ncol)), dim3(BLOCK), 0, s, __VA_ARGS__)
 int launch_named_gm(const DM &m, hipStream_t s, const char *name) {
-  if (!m.p.Fer_GM) return -1;
+  if (!m.p.Fer_GM && !m.p.Redi) return -1;
+  if (!m.p.Fer_GM && strcmp(name, "init_Redi_GM") && strcmp(name, "k_gm_coef")) return -1;
   if (!strcmp(name, "init_Redi_GM") || !strcmp(name, "k_gm_coef")) { LAUNCH_COL(k_gm_coef, m.myN, m); return 0; }
   if (!strcmp(name, "fer_solve_Gamma") || !strcmp(name, "k_fer_gamma")) {
     hipLaunchKernelGGL(k_fer_gamma, dim3(nblocks_th(m.myN)), dim3(TH_BLOCK), thomas_lds_bytes(m.nl, 2), s, m); return 0;

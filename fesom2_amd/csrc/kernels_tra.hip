@@ -340,6 +340,7 @@ __global__ void __launch_bounds__(BLOCK) k_fct_edge_limit(DM m, int tr0) {
 // the reference adds to / subtracts from the two end nodes.  It only needs T^n gradients, Ki and helem of the current
 // step, so it is computed edge-parallel during tracer preparation (hidden under the SSH solve) and k_tr_update just
 // gathers it in reference order.
+template <bool REDI>
 __global__ void __launch_bounds__(BLOCK) k_diff_flux(DM m, int tr0) {
   const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   const TV t = tracer_view(m, tr);
@@ -354,19 +355,26 @@ __global__ void __launch_bounds__(BLOCK) k_diff_flux(DM m, int tr0) {
   if (ul2 > 0) lo = min(ul1, ul2);
   if (nz < lo || nz > hi) return;
   double Kh = (DA2(m.Ki, nz, n1) + DA2(m.Ki, nz, n2)) / 2.0, c;
+  double ax = 0.0, ay = 0.0;                              // Redi: slope * vertical gradient at the two edge nodes (:990-993)
+  if (REDI) {
+    double Tz1 = 0.5 * (DA2L(t.tr_z, nz, n1) + DA2L(t.tr_z, nz + 1, n1)), Tz2 = 0.5 * (DA2L(t.tr_z, nz, n2) + DA2L(t.tr_z, nz + 1, n2));
+    ax = (Tz1 * DV3(m.slope_tapered, 1, nz, n1) + Tz2 * DV3(m.slope_tapered, 1, nz, n2)) / 2.0;
+    ay = (Tz1 * DV3(m.slope_tapered, 2, nz, n1) + Tz2 * DV3(m.slope_tapered, 2, nz, n2)) / 2.0;
+    ax = ax * 1.0; ay = ay * 1.0;
+  }
   if (nz >= ul12 && nz <= nl12) {
     double dz = (DA2(m.helem, nz, e1) + DA2(m.helem, nz, e2)) / 2.0;
     double Tx = 0.5 * (DV2(t.tr_xy, 1, nz, e1) + DV2(t.tr_xy, 1, nz, e2));
     double Ty = 0.5 * (DV2(t.tr_xy, 2, nz, e1) + DV2(t.tr_xy, 2, nz, e2));
-    double Fx = Kh * (Tx + 0.0), Fy = Kh * (Ty + 0.0);
+    double Fx = Kh * (Tx + ax), Fy = Kh * (Ty + ay);
     c = ((dX2 - dX1) * Fy - (dY2 - dY1) * Fx) * dz;
   } else if ((nz >= ul1 && nz <= ul12 - 1) || (nz >= nl12 + 1 && nz <= nl1)) {
     double dz = DA2(m.helem, nz, e1);
-    double Fx = Kh * (DV2(t.tr_xy, 1, nz, e1) + 0.0), Fy = Kh * (DV2(t.tr_xy, 2, nz, e1) + 0.0);
+    double Fx = Kh * (DV2(t.tr_xy, 1, nz, e1) + ax), Fy = Kh * (DV2(t.tr_xy, 2, nz, e1) + ay);
     c = (-dX1 * Fy + dY1 * Fx) * dz;
   } else {
     double dz = DA2(m.helem, nz, e2);
-    double Fx = Kh * (DV2(t.tr_xy, 1, nz, e2) + 0.0), Fy = Kh * (DV2(t.tr_xy, 2, nz, e2) + 0.0);
+    double Fx = Kh * (DV2(t.tr_xy, 1, nz, e2) + ax), Fy = Kh * (DV2(t.tr_xy, 2, nz, e2) + ay);
     c = (dX2 * Fy - dY2 * Fx) * dz;
   }
   DA2(t.diff_flux, nz, ed) = c;
@@ -378,6 +386,7 @@ __global__ void __launch_bounds__(BLOCK) k_diff_flux(DM m, int tr0) {
 // The kernel is latency-bound, not bandwidth-bound: the edge list of the node is read lane-parallel (lane q = q-th
 // incident edge), broadcast with v_readlane, and all edge values are fetched in one batch before the ordered sums.
 #define TRU_MAXD 10                     // batch of this kernel (4 loads per edge): keeps it at <= 128 VGPRs, 2 blocks per CU
+template <bool REDI>
 __global__ void __launch_bounds__(TH_BLOCK) k_tr_update(DM m, int tr0) {
   const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   extern __shared__ double th_sh[];
@@ -461,6 +470,38 @@ __global__ void __launch_bounds__(TH_BLOCK) k_tr_update(DM m, int tr0) {
       del = del + rhs * dt / asv;
     }
   }
+  // zbar_n / Z_n of the node column from hnode_new (bottom-up, reference order)
+  double zb_top = seq_sum_down(wet ? hnn : 0.0, nzmax - 2, nzmin - 1, m.zbar_n_bot[n]);
+  double zb_bot = shdn(zb_top);
+  if (nz == nzmax - 1) zb_bot = m.zbar_n_bot[n];
+  double Zn = zb_bot + hnn / 2.0;
+  double Zn_up = shup(Zn), Zn_dn = shdn(Zn);
+  double ki = 0.0, s3sq = 0.0;
+  if (REDI) {            // diff_ver_part_redi_expl (:860-927): vertical flux of the isoneutral tensor's off-diagonal part
+    double Tx = 0.0, Ty = 0.0, s1 = 0.0, s2 = 0.0, G = 0.0;
+    if (wet) {
+      const int num = m.nie_num[n];
+      for (int k = 0; k < num; k++) {
+        int el = m.nie[(size_t)m.maxk * n + k];
+        if (nz <= m.nlev[el] - 1 && nz >= m.ulev[el]) { double ar = m.elem_area[el]; Tx = Tx + DV2(t.tr_xy, 1, nz, el) * ar; Ty = Ty + DV2(t.tr_xy, 2, nz, el) * ar; }
+      }
+      Tx = Tx / 3.0 / asv; Ty = Ty / 3.0 / asv;
+      s1 = DV3(m.slope_tapered, 1, nz, n); s2 = DV3(m.slope_tapered, 2, nz, n);
+      double s3 = DV3(m.slope_tapered, 3, nz, n);
+      s3sq = s3 * s3; ki = DA2(m.Ki, nz, n);
+      G = s1 * Tx + s2 * Ty;
+    }
+    double G_up = shup(G), ki_up = shup(ki);
+    double vd = 0.0;
+    if (nz >= nzmin + 1 && nz <= nzmax - 1) {
+      vd = (Zn_up - zb_top) * G_up * ki_up;
+      vd = vd + (zb_top - Zn) * G * ki;
+      vd = vd / (Zn_up - Zn) * DA2L(m.area, nz, n);
+    }
+    double vd_dn = shdn(vd);
+    if (nz == nzmax - 1) vd_dn = 0.0;
+    if (wet) del = del + (vd - vd_dn) * dt / asv;
+  }
   if (wet) {
     DTR(m.tr_arr_old, nz, n, tr) = T;          // tr_arr_old(:,:,tr) = tr_arr(:,:,tr)  (oce_ale_tracer.F90:274)
     del = del + T * (hn - hnn);
@@ -469,31 +510,33 @@ __global__ void __launch_bounds__(TH_BLOCK) k_tr_update(DM m, int tr0) {
   }
   if (valid && !wet && nz <= m.nlm1) DTR(m.tr_arr_old, nz, n, tr) = DTR(m.tr_arr, nz, n, tr);   // whole-array copy incl. dry cells
   if (m.p.with_diffusion && m.p.i_vert_diff) {
-    // zbar_n / Z_n of the node column from hnode_new (bottom-up, reference order)
-    double zb_top = seq_sum_down(wet ? hnn : 0.0, nzmax - 2, nzmin - 1, m.zbar_n_bot[n]);
-    double zb_bot = shdn(zb_top);
-    if (nz == nzmax - 1) zb_bot = m.zbar_n_bot[n];
-    double Zn = zb_bot + hnn / 2.0;
-    double Zn_up = shup(Zn), Zn_dn = shdn(Zn);
     double a = 0.0, b = 1.0, c = 0.0, rhs = 0.0;
     double T_up = shup(T), T_dn = shdn(T);
+    const double ki_up = shup(ki), ki_dn = shdn(ki), sq_up = shup(s3sq), sq_dn = shdn(s3sq), zb_bb = shdn(zb_bot);
     if (wet) {
       double zinv = 1.0 * dt;
       double zinv1 = 1.0 / (Zn_up - Zn), zinv2 = 1.0 / (Zn - Zn_dn);
+      double Ty = 0.0, Ty1 = 0.0;              // K33 = slope^2 * Ki of the isoneutral tensor (:528-599), isredi = 1
+      if (REDI) {
+        if (nz > nzmin) Ty = (Zn_up - zb_top) * zinv1 * sq_up * ki_up + (zb_top - Zn) * zinv1 * s3sq * ki;
+        if (nz <= nzmax - 2) Ty1 = (Zn - zb_bot) * zinv2 * s3sq * ki + (zb_bot - Zn_dn) * zinv2 * sq_dn * ki_dn;
+        Ty = Ty * 1.0; Ty1 = Ty1 * 1.0;
+        (void)zb_bb;
+      }
       double ar = DA2L(m.area, nz, n), ar_dn = DA2L(m.area, nz + 1, n);
       double kv = DA2L(m.Kv, nz, n), kv_dn = DA2L(m.Kv, nz + 1, n);
       if (nz == nzmin) {
         a = 0.0;
-        c = -(kv_dn + 0.0) * zinv2 * zinv * ar_dn / asv;
+        c = -(kv_dn + Ty1) * zinv2 * zinv * ar_dn / asv;
         b = -c + hnn;
         rhs = -(b - hnn) * T - c * T_dn;
       } else if (nz <= nzmax - 2) {
-        a = -(kv + 0.0) * zinv1 * zinv * (ar / asv);
-        c = -(kv_dn + 0.0) * zinv2 * zinv * ar_dn / asv;
+        a = -(kv + Ty) * zinv1 * zinv * (ar / asv);
+        c = -(kv_dn + Ty1) * zinv2 * zinv * ar_dn / asv;
         b = -a - c + hnn;
         rhs = -a * T_up - (b - hnn) * T - c * T_dn;
       } else {
-        a = -(kv + 0.0) * zinv1 * zinv * (ar / asv);
+        a = -(kv + Ty) * zinv1 * zinv * (ar / asv);
         c = 0.0;
         b = -a + hnn;
         rhs = -a * T_up - (b - hnn) * T;
@@ -523,7 +566,9 @@ __global__ void __launch_bounds__(TH_BLOCK) k_tr_update(DM m, int tr0) {
 
 // tr >= 0: that tracer only; tr < 0: all tracers in one launch (grid.y), their chains are independent
 #define LAUNCH_COL(k, ncol, m_, tr_) hipLaunchKernelGGL(k, dim3(nblocks(ncol), (tr_) < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m_, (tr_) < 0 ? 0 : (tr_))
-#define LAUNCH_TRU(m_, tr_) hipLaunchKernelGGL(k_tr_update, dim3(nblocks_th(m.N), (tr_) < 0 ? m.ntr : 1), dim3(TH_BLOCK), thomas_lds_bytes(m.nlm1, 1), s, m_, (tr_) < 0 ? 0 : (tr_))
+#define LAUNCH_TRU(m_, tr_) do { if (m.p.Redi) hipLaunchKernelGGL(k_tr_update<true>, dim3(nblocks_th(m.N), (tr_) < 0 ? m.ntr : 1), dim3(TH_BLOCK), thomas_lds_bytes(m.nlm1, 1), s, m_, (tr_) < 0 ? 0 : (tr_)); \
+  else hipLaunchKernelGGL(k_tr_update<false>, dim3(nblocks_th(m.N), (tr_) < 0 ? m.ntr : 1), dim3(TH_BLOCK), thomas_lds_bytes(m.nlm1, 1), s, m_, (tr_) < 0 ? 0 : (tr_)); } while (0)
+#define LAUNCH_DFX(m_, tr_) do { if (m.p.Redi) LAUNCH_COL(k_diff_flux<true>, m.myD, m_, tr_); else LAUNCH_COL(k_diff_flux<false>, m.myD, m_, tr_); } while (0)
 
 void launch_tracer(const DM &m, hipStream_t s, int tr) {   // tr 0-based
   LAUNCH_COL(k_tr_ab, m.N, m, tr);
@@ -534,7 +579,7 @@ void launch_tracer(const DM &m, hipStream_t s, int tr) {   // tr 0-based
   LAUNCH_COL(k_fct_lo_node, m.myN, m, tr);
   LAUNCH_COL(k_fct_node, m.myN, m, tr);
   LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr);
-  if (m.p.with_diffusion) LAUNCH_COL(k_diff_flux, m.myD, m, tr);
+  if (m.p.with_diffusion) LAUNCH_DFX(m, tr);
   LAUNCH_TRU(m, tr);
 }
 
@@ -549,7 +594,7 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
     if (!strcmp(name, "k_fct_lo_node")) { LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); return 0; }
     if (!strcmp(name, "k_fct_node")) { LAUNCH_COL(k_fct_node, m.myN, m, tr); return 0; }
     if (!strcmp(name, "k_fct_edge_limit")) { LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr); return 0; }
-    if (!strcmp(name, "k_diff_flux")) { LAUNCH_COL(k_diff_flux, m.myD, m, tr); return 0; }
+    if (!strcmp(name, "k_diff_flux")) { LAUNCH_DFX(m, tr); return 0; }
     if (!strcmp(name, "k_tr_update")) { LAUNCH_TRU(m, tr); return 0; }
     return -1;
   }
@@ -562,7 +607,7 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
     LAUNCH_COL(k_fct_node, m.myN, m, tr); LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr); return 0;
   }
   if (!strcmp(name, "diff_tracers_ale")) {                                                    // incl. flux2dtracer + clamp
-    if (m.p.with_diffusion) LAUNCH_COL(k_diff_flux, m.myD, m, tr);
+    if (m.p.with_diffusion) LAUNCH_DFX(m, tr);
     LAUNCH_TRU(m, tr);
     return 0;
   }

@@ -42,6 +42,8 @@ def run_step(core, par, X, solve, first, probe=None):
     c("first_step", 1 if first else 0)
     c("k_vel_nodes"); X(NOD, ["Unode"]); P("vel_nodes")
     c("k_pressure_bv"); c("k_pgf"); c("k_sigma_slope"); P("pressure")
+    if p.Redi:
+        X(NOD, ["slope_tapered"])
     if p.mix_scheme == 2:
         c("k_pp_node_raw"); c("k_pp_elem"); c("k_pp_node_final"); P("mixing")
     c("k_momadv_node"); X(NOD, ["Unode_rhs"])
@@ -53,8 +55,10 @@ def run_step(core, par, X, solve, first, probe=None):
         c("k_stiff_update")
     c("k_edge_transport"); c("k_ssh_rhs_node"); P("ssh_rhs")
     solve(); X(NOD, ["d_eta"]); P("solve")
+    if p.Redi and not p.Fer_GM:
+        c("init_Redi_GM"); X(NOD, ["Ki"])
     if p.Fer_GM:                                      # bolus velocities (oce_fer_gm.F90), before vert_vel_ale moves hnode_new
-        c("init_Redi_GM"); X(NOD, ["fer_c", "fer_K"])
+        c("init_Redi_GM"); X(NOD, ["fer_c", "fer_K"] + (["Ki"] if p.Redi else []))
         c("fer_solve_Gamma"); X(NOD, ["fer_gamma"])
         c("fer_gamma2vel"); X(ELEM, ["fer_UV"])
         c("fer_wvel"); X(NOD, ["fer_Wvel"])
@@ -66,9 +70,11 @@ def run_step(core, par, X, solve, first, probe=None):
         c("bolus_add")
     c("k_tr_ab", 0); c("k_tr_grad_elem", 0); X(ELEM_FULL, ["tr_xy_ab"])
     c("k_updn_grad", 0)
+    c("k_tr_z", 0)
+    if p.Redi:
+        X(NOD, ["tr_z"])
     if p.with_diffusion:
         c("k_diff_flux", 0)
-    c("k_tr_z", 0)
     c("k_flux_hor", 0); c("k_fct_lo_node", 0); X(NOD, ["fct_LO"])
     c("k_fct_node", 0); X(NOD, ["fct_plus", "fct_minus"])
     c("k_fct_edge_limit", 0); c("k_tr_update", 0); X(NOD, ["tr_arr"]); P("tracers")

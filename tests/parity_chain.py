@@ -43,11 +43,13 @@ GM_BEFORE_W = [("init_Redi_GM", 0, ["fer_K", "fer_c"]), ("fer_solve_Gamma", 0, [
 GM_AFTER_W = [("fer_wvel", 0, ["fer_Wvel"]), ("bolus_add", 0, ["UV", "Wvel", "Wvel_e"])]
 
 
-def full_chain(ntr=2, gm=False):
+def full_chain(ntr=2, gm=False, redi=False):
     ch = []
     for item in DYN_PRE:
+        if redi and not gm and item[0] == "vert_vel_ale":
+            ch.append(("init_Redi_GM", 0, ["Ki"]))
         if gm and item[0] == "vert_vel_ale":
-            ch += GM_BEFORE_W                      # oce_ale.F90:2729-2739: before vert_vel_ale
+            ch += [(r, a, f + (["Ki"] if redi and r == "init_Redi_GM" else [])) for r, a, f in GM_BEFORE_W]   # oce_ale.F90:2729-2739
         ch.append(item)
         if gm and item[0] == "vert_vel_ale":
             ch += GM_AFTER_W                       # fer_Wvel is part of vert_vel_ale; bolus added around the tracer loop
