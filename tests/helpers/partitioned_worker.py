@@ -62,7 +62,8 @@ def main():
         import torch
         torch.cuda.set_device(0)
     rank, world = dist.get_rank(), dist.get_world_size()
-    par = make_params(dt=900.0)
+    opts = os.environ.get("PART_OPTS", "").split(",")
+    par = make_params(dt=900.0, Fer_GM="gm" in opts, Redi="redi" in opts, scaling_Ferreira="gm" in opts or "redi" in opts)
     T, S = analytic_ts(PI)
     # ---- single partition (whole mesh) on this rank
     gm = Mesh.load(PI, dt=900.0)
