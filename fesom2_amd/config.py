@@ -8,7 +8,8 @@ def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equati
                 mix_scheme="PP", with_diffusion=True, toy_soufflet=False, K_hor=3000.0, A_ver=1.0e-4, K_ver=1.0e-5,
                 cyclic_length_deg=360.0, w_split=False, use_instabmix=True, use_windmix=False, solver_x0_order=3,
                 Fer_GM=False, K_GM_max=2000.0, K_GM_min=2.0, K_GM_bvref=2, K_GM_rampmax=-1.0, K_GM_rampmin=-1.0,
-                K_GM_resscalorder=1.0, scaling_Ferreira=False, scaling_resolution=True, scaling_FESOM14=False, Redi=False):
+                K_GM_resscalorder=1.0, scaling_Ferreira=False, scaling_resolution=True, scaling_FESOM14=False, Redi=False,
+                visc_sh_limit=5.0e-3, diff_sh_limit=5.0e-3, Ricr=0.3, concv=1.6):
     p = _lib.Params()
     p.dt = dt
     p.which_ale = WHICH_ALE[which_ale]
@@ -20,7 +21,7 @@ def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equati
     p.i_vert_visc = 1
     p.i_vert_diff = 1
     p.w_split = int(w_split)
-    p.mix_scheme = {"PP": 2, "none": 0}[mix_scheme]
+    p.mix_scheme = {"KPP": 1, "PP": 2, "none": 0}[mix_scheme]
     p.use_instabmix = int(use_instabmix)
     p.use_windmix = int(use_windmix)
     p.windmix_nl = 2
@@ -40,4 +41,5 @@ def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equati
     p.scaling_Ferreira, p.scaling_Rossby = int(scaling_Ferreira), 0
     p.scaling_resolution, p.scaling_FESOM14 = int(scaling_resolution), int(scaling_FESOM14)
     p.Redi = int(Redi)
+    p.visc_sh_limit, p.diff_sh_limit, p.Ricr, p.concv = visc_sh_limit, diff_sh_limit, Ricr, concv
     return p

@@ -92,7 +92,7 @@ typedef struct fesom_params {
   int    mom_adv;            /* 2 (scalar control volumes) */
   int    visc_option;        /* 5 (easy backscatter) */
   int    i_vert_visc, i_vert_diff, w_split;
-  int    mix_scheme;         /* 2 = PP ; 0 = constant A_ver/K_ver (no mixing scheme) */
+  int    mix_scheme;         /* 1 = KPP (oce_ale_mixing_kpp.F90) ; 2 = PP ; 0 = constant A_ver/K_ver (no mixing scheme) */
   int    use_instabmix, use_windmix, windmix_nl;
   int    toy_soufflet;       /* 1: linear EOS branch of the Soufflet channel (oce_ale_pressure_bv.F90:2992) */
   double alpha, theta, epsilon;
@@ -113,6 +113,9 @@ typedef struct fesom_params {
   double K_GM_rampmax, K_GM_rampmin, K_GM_resscalorder;
   int    scaling_Ferreira, scaling_Rossby /* unsupported */, scaling_resolution, scaling_FESOM14;
   int    Redi;               /* isoneutral (Redi) diffusion: rotated horizontal + explicit/implicit vertical parts (oce_ale_tracer.F90) */
+  /* KPP (mix_scheme=1; namelist.oce: visc_sh_limit, diff_sh_limit, Ricr, concv; Kv0_const=.true., double_diffusion=.false.,
+     use_sw_pene=.false., use_kpp_nonlclflx=.false. are the only supported settings of those switches) */
+  double visc_sh_limit, diff_sh_limit, Ricr, concv;
 } fesom_params;
 
 /* ---- prognostic state = restart set (io_restart.F90:99-155) + ALE thickness arrays -- */
@@ -135,6 +138,7 @@ typedef struct fesom_state_desc {
 typedef struct fesom_forcing_desc {
   const double *stress_surf;     /* (2,myE) */
   const double *heat_flux, *water_flux, *virtual_salt, *relax_salt, *real_salt_flux; /* (N) */
+  const double *stress_atmoce_x, *stress_atmoce_y;   /* (N) wind stress at nodes (KPP friction velocity, oce_ale_mixing_kpp.F90:341) */
 } fesom_forcing_desc;
 
 /* Lifecycle.  fesom_gpu_init uploads the mesh and allocates every device mirror;

@@ -42,6 +42,13 @@ typedef struct {
   double *fer_c, *fer_scal, *gm_scal_static;  /* (N) */
   double *fer_UV;                            /* (2,nl-1,E) */
   int *MLD1_ind;                             /* (N) */
+  /* KPP (orc_kpp.c) */
+  double *stress_atmoce_x, *stress_atmoce_y;                                  /* (N) wind stress at nodes */
+  double *kpp_Kv1, *kpp_Kv2, *kpp_viscA, *kpp_dVsq, *kpp_blmc[3];            /* (nl,N) */
+  double *kpp_ghats;                                                          /* (nl-1,N) */
+  double *kpp_hbl, *kpp_bfsfc, *kpp_caseA, *kpp_stable, *kpp_ustar, *kpp_Bo, *kpp_dkm1;   /* (N), dkm1 (3,N) */
+  double *kpp_wmt, *kpp_wst, *kpp_work, *kpp_vol, kpp_deltaz, kpp_deltau, kpp_Vtc, kpp_cg;
+  int *kpp_kbl;
   /* Soufflet toy channel (orc_toy.c) */
   double *Uclim, *toy_zvel, *toy_ztem, *toy_znum;  /* (nl-1,E), (nl-1,100) x3 */
   int *toy_bpos, *toy_owner, toy_nranks;
@@ -95,6 +102,8 @@ void orc_compute_sigma_xy(void);
 void orc_compute_neutral_slope(void);
 void orc_mixing_pp(void);
 void orc_mo_convect(void);
+void orc_mixing_kpp(void);
+void orc_kpp_tables(double *wmt, double *wst, double *deltaz, double *deltau);
 void orc_compute_vel_rhs(void);
 void orc_visc_filt_bcksct(void);
 void orc_impl_vert_visc_ale(void);

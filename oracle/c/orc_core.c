@@ -20,6 +20,7 @@ int orc_init(const fesom_mesh_desc *m, const fesom_params *p) {
   for (int i = 0; i < nF_; i++) free(*F_[i].p);
   nF_ = 0;
   free(C_.toy_bpos); free(C_.toy_owner); free(C_.MLD1_ind);
+  free(C_.kpp_wmt); free(C_.kpp_wst); free(C_.kpp_work); free(C_.kpp_vol); free(C_.kpp_kbl);
   memset(&C_, 0, sizeof(C_));
   C_.m = *m; C_.p = *p;
   C_.N = m->myDim_nod2D + m->eDim_nod2D; C_.E = m->myDim_elem2D + m->eDim_elem2D; C_.D = m->myDim_edge2D + m->eDim_edge2D;
@@ -41,6 +42,10 @@ int orc_init(const fesom_mesh_desc *m, const fesom_params *p) {
   R(pgf_x, n1 * E); R(pgf_y, n1 * E); R(helem, n1 * E); R(Av, nl * E); R(dhe, E); R(stress_surf, 2 * E);
   R(adv_flux_hor, n1 * D); R(edge_up_dn_grad, 4 * n1 * D);
   R(fer_K, nl * N); R(fer_gamma, 2 * nl * N); R(fer_Wvel, nl * N); R(fer_c, N); R(fer_scal, N); R(gm_scal_static, N); R(fer_UV, 2 * n1 * E);
+  R(stress_atmoce_x, N); R(stress_atmoce_y, N);
+  R(kpp_Kv1, nl * N); R(kpp_Kv2, nl * N); R(kpp_viscA, nl * N); R(kpp_dVsq, nl * N); R(kpp_ghats, n1 * N);
+  reg("kpp_blmc1", &C_.kpp_blmc[0], nl * N); reg("kpp_blmc2", &C_.kpp_blmc[1], nl * N); reg("kpp_blmc3", &C_.kpp_blmc[2], nl * N);
+  R(kpp_hbl, N); R(kpp_bfsfc, N); R(kpp_caseA, N); R(kpp_stable, N); R(kpp_ustar, N); R(kpp_Bo, N); R(kpp_dkm1, 3 * N);
   R(Uclim, n1 * E); R(toy_zvel, n1 * 100); R(toy_ztem, n1 * 100); R(toy_znum, n1 * 100);
   R(ssh_values, m->ssh_nza); R(sv_h1, N); R(sv_h2, N); R(sv_h3, N);
 #undef R
@@ -193,6 +198,7 @@ void orc_step(int n) {
   orc_compute_sigma_xy();
   orc_compute_neutral_slope();
   if (C_.p.mix_scheme == 2) { orc_mixing_pp(); orc_mo_convect(); }
+  if (C_.p.mix_scheme == 1) { orc_mixing_kpp(); orc_mo_convect(); }                  /* oce_ale.F90:2607-2611 */
   orc_compute_vel_rhs();
   orc_visc_filt_bcksct();
   if (C_.p.i_vert_visc) orc_impl_vert_visc_ale();
@@ -222,7 +228,7 @@ int orc_call(const char *name, int arg) {
 #define CALL0(f) if (!strcmp(name, #f)) { orc_##f(); return 0; }
 #define CALL1(f) if (!strcmp(name, #f)) { orc_##f(arg); return 0; }
   CALL0(compute_vel_nodes) CALL0(pressure_bv) CALL0(pressure_force) CALL0(sw_alpha_beta) CALL0(compute_sigma_xy)
-  CALL0(compute_neutral_slope) CALL0(mixing_pp) CALL0(mo_convect) CALL0(compute_vel_rhs) CALL0(visc_filt_bcksct)
+  CALL0(compute_neutral_slope) CALL0(mixing_pp) CALL0(mixing_kpp) CALL0(mo_convect) CALL0(compute_vel_rhs) CALL0(visc_filt_bcksct)
   CALL0(impl_vert_visc_ale) CALL0(update_stiff_mat_ale) CALL0(compute_ssh_rhs_ale) CALL0(solve_ssh) CALL0(update_vel)
   CALL0(compute_hbar_ale) CALL0(eta_update) CALL0(vert_vel_ale) CALL1(init_tracers_AB) CALL1(adv_tracers_ale)
   CALL1(diff_tracers_ale) CALL0(salinity_clamp) CALL0(update_thickness_ale) CALL1(step)

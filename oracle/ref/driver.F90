@@ -97,11 +97,13 @@ program oracle_driver
   character(len=16) :: mode
   character(len=256) :: dump_dir
   integer :: dump_steps(64), ndump
-  logical :: dump_mesh, do_mean, debug
+  logical :: dump_mesh, do_mean, debug, synth_forcing
+  real(kind=WP) :: flon, flat
+  integer :: fel(3)
   real(kind=WP) :: t0, t1, tloop
   character(len=64) :: tag
   namelist /clockinit/ timenew, daynew, yearnew
-  namelist /oracle/ nsteps, mode, dump_dir, dump_steps, dump_mesh, do_mean, debug
+  namelist /oracle/ nsteps, mode, dump_dir, dump_steps, dump_mesh, do_mean, debug, synth_forcing
   ! running sums for the fcheck-style known answer (setups/test_souf/setup.yml:82-88)
   real(kind=WP), allocatable :: mT(:,:), mS(:,:), mU(:,:), mV(:,:)
 
@@ -130,7 +132,7 @@ program oracle_driver
   read (20,NML=oce_tra)
   read (20,NML=oce_init3d)
   close (20)
-  nsteps=1; mode='step'; dump_dir='dumps'; dump_steps=-1; dump_mesh=.false.; do_mean=.false.; debug=.false.
+  nsteps=1; mode='step'; dump_dir='dumps'; dump_steps=-1; dump_mesh=.false.; do_mean=.false.; debug=.false.; synth_forcing=.false.
   open (20,file='namelist.oracle')
   read (20,NML=oracle)
   close (20)
@@ -143,6 +145,28 @@ program oracle_driver
   ! ice loading and atmospheric pressure arrays are read by compute_vel_rhs (ice_modules / forcing arrays)
   if (.not. allocated(press_air)) then
      allocate(press_air(myDim_nod2D+eDim_nod2D)); press_air=0.0_WP
+  end if
+
+  ! wind stress at nodes lives in the forcing/ice set-up of the full model (not part of this harness)
+  if (.not. allocated(stress_atmoce_x)) then
+     allocate(stress_atmoce_x(myDim_nod2D+eDim_nod2D), stress_atmoce_y(myDim_nod2D+eDim_nod2D))
+     stress_atmoce_x=0.0_WP; stress_atmoce_y=0.0_WP
+  end if
+  if (synth_forcing) then
+     ! analytic surface forcing (harness's own choice; both signs of the buoyancy flux, wind everywhere), constant in time
+     do i=1, myDim_nod2D+eDim_nod2D
+        flon=mesh%geo_coord_nod2D(1,i); flat=mesh%geo_coord_nod2D(2,i)
+        stress_atmoce_x(i)=0.1_WP*cos(3.0_WP*flat)
+        stress_atmoce_y(i)=0.03_WP*sin(2.0_WP*flon)
+        heat_flux(i)=150.0_WP*sin(2.0_WP*flon+1.0_WP)*cos(flat)
+        water_flux(i)=2.0e-8_WP*cos(3.0_WP*flon)
+     end do
+     stress_node_surf(1,:)=stress_atmoce_x; stress_node_surf(2,:)=stress_atmoce_y
+     do i=1, myDim_elem2D
+        fel=mesh%elem2D_nodes(:,i)
+        stress_surf(1,i)=sum(stress_atmoce_x(fel))/3.0_WP
+        stress_surf(2,i)=sum(stress_atmoce_y(fel))/3.0_WP
+     end do
   end if
 
   if (dump_mesh) call dump_setup()
@@ -241,6 +265,9 @@ contains
     call dump('zbar_e_srf', zbar_e_srf)
     call dump('Ki', Ki)
     call dump('density_ref', density_ref)
+    call dump('forcing.stress_atmoce_x', stress_atmoce_x); call dump('forcing.stress_atmoce_y', stress_atmoce_y)
+    call dump('forcing.heat_flux', heat_flux); call dump('forcing.water_flux', water_flux)
+    call dump('forcing.stress_surf', stress_surf)
     call dump_state()
     call dump_close()
   end subroutine dump_setup
@@ -324,6 +351,9 @@ contains
        call mark('oce_mixing_KPP')
        call oce_mixing_KPP(Av, Kv_double, mesh)
        Kv=Kv_double(:,:,1)
+       call dump('kpp.dbsfc', dbsfc); call dump('kpp.hbl', hbl); call dump('kpp.ghats', ghats)
+       call dump('kpp.blmc1', blmc(:,:,1)); call dump('kpp.blmc2', blmc(:,:,2)); call dump('kpp.blmc3', blmc(:,:,3))
+       call dump('kpp.Kv1', Kv_double(:,:,1)); call dump('kpp.Kv2', Kv_double(:,:,2)); call dump('kpp.Av', Av)
        call mark('mo_convect')
        call mo_convect(mesh)
     else if (mix_scheme_nmb==2 .or. mix_scheme_nmb==27) then

@@ -160,11 +160,16 @@ CFGS = {
                           rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                           fer_gm=".true.", redi=".true.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
                           balance_salt_water=".true."),
-    # pi mesh with the reference's default physics (KPP + GM + Redi)
+    # pi mesh with the reference's default physics (KPP + GM + Redi) and the harness's analytic surface forcing
     "pi_default": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                        fer_gm=".true.", redi=".true.", mix_scheme="KPP", k_hor="3000.", surf_relax_s="1.929e-06",
-                       balance_salt_water=".true."),
+                       balance_salt_water=".true.", synth_forcing=True),
+    # KPP alone (no GM/Redi) with the same forcing
+    "pi_kpp": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                   rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                   fer_gm=".false.", redi=".false.", mix_scheme="KPP", k_hor="3000.", surf_relax_s="1.929e-06",
+                   balance_salt_water=".true.", synth_forcing=True),
     # Soufflet channel = setups/test_souf/setup.yml overrides
     "souf": dict(mesh="soufflet", step_per_day=72, which_ale="zstar", use_partial_cell=".true.", cyclic_length=4.5,
                  rotated_grid=".false.", force_rotation=".false.", toy_ocean=".true.", state_equation=0,
@@ -194,11 +199,13 @@ def prepare(cfg, np_):
 
 
 def run(cfg, np_, nsteps, mode="step", dump=(), mean=False, dump_mesh=True, quiet=True):
+    forcing = CFGS[cfg].get("synth_forcing", False)
     rd = prepare(cfg, np_)
     ds = ",".join(str(d) for d in dump) if dump else "-1"
     open(os.path.join(rd, "namelist.oracle"), "w").write(
         f"&oracle\nnsteps={nsteps}\nmode='{mode}'\ndump_dir='dumps'\ndump_steps={ds}\n"
-        f"dump_mesh={'.true.' if dump_mesh else '.false.'}\ndo_mean={'.true.' if mean else '.false.'}\n/\n")
+        f"dump_mesh={'.true.' if dump_mesh else '.false.'}\ndo_mean={'.true.' if mean else '.false.'}\n"
+        f"synth_forcing={'.true.' if forcing else '.false.'}\n/\n")
     exe = os.path.join(OUT, "fesom_oracle.x")
     cmd = ["/opt/conda/bin/mpiexec", "-n", str(np_), exe]
     r = subprocess.run(cmd, cwd=rd, capture_output=True, text=True)

@@ -70,6 +70,10 @@ def make(cfg, outname):
             first_node[s_["myList_elem2D"][:myE] - 1] = s_["myList_nod2D"][s_["elem2D_nodes"][:myE, 0] - 1]
         out["toy/owner"] = rank_of_node[first_node - 1].astype(np.int32)
         out["toy/nranks"] = np.array([NP], dtype=np.int32)
+    if run_ref.CFGS[cfg].get("synth_forcing"):
+        # the harness's analytic surface forcing, in full (global numbering): the tests hand it to the oracle / HIP path
+        for k in ("stress_atmoce_x", "stress_atmoce_y", "heat_flux", "water_flux", "stress_surf"):
+            out["forcing/" + k] = assemble(setups, setups, "forcing." + k).astype(np.float64)
     for step in range(1, NSTEPS + 1):
         d = [read_dump(os.path.join(rd, "dumps", f"replay{step:04d}.r{r:05d}.bin")) for r in range(NP)]
         for k in d[0]:
@@ -86,6 +90,12 @@ def make(cfg, outname):
 
 
 def main():
+    if len(sys.argv) > 1:                                 # only the named configurations
+        for cfg in sys.argv[1:]:
+            make(cfg, cfg + "_reference.npz")
+        return
+    make("pi_default", "pi_default_reference.npz")      # KPP + GM + Redi (the reference's default physics) with surface forcing
+    make("pi_kpp", "pi_kpp_reference.npz")              # KPP alone with surface forcing
     make("pi_pp", "pi_pp_reference.npz")
     make("pi_pp_gm", "pi_pp_gm_reference.npz")          # + Gent-McWilliams bolus velocities
     make("pi_pp_gm_redi", "pi_pp_gm_redi_reference.npz")  # + isoneutral (Redi) diffusion

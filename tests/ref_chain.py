@@ -37,7 +37,15 @@ def run_reference_chain(orc, mesh, g, steps=(1, 2, 3), toy=False, skip=()):
         orc.call("compute_sigma_xy"); chk(step, "sigma_xy", "compute_sigma_xy.sigma_xy", "n2")
         orc.call("compute_neutral_slope")
         chk(step, "neutral_slope", "compute_neutral_slope.neutral_sl", "n3"); chk(step, "slope_tapered", "compute_neutral_slope.slope_tape", "n3")
-        orc.call("mixing_pp"); chk(step, "Av", "oce_mixing_PP.Av"); chk(step, "Kv", "oce_mixing_PP.Kv")
+        if orc.params.mix_scheme == 1:                      # KPP (src/oce_ale_mixing_kpp.F90)
+            chk(step, "dbsfc", "kpp.dbsfc", "nl")
+            orc.call("mixing_kpp")
+            chk(step, "kpp_hbl", "kpp.hbl"); chk(step, "kpp_ghats", "kpp.ghats")
+            for j in (1, 2, 3):
+                chk(step, f"kpp_blmc{j}", f"kpp.blmc{j}")
+            chk(step, "kpp_Kv1", "kpp.Kv1"); chk(step, "kpp_Kv2", "kpp.Kv2"); chk(step, "Av", "kpp.Av")
+        else:
+            orc.call("mixing_pp"); chk(step, "Av", "oce_mixing_PP.Av"); chk(step, "Kv", "oce_mixing_PP.Kv")
         orc.call("mo_convect"); chk(step, "Av", "mixing.Av"); chk(step, "Kv", "mixing.Kv")
         orc.call("compute_vel_rhs"); chk(step, "UV_rhs", "compute_vel_rhs.UV_rhs", "e2"); chk(step, "UV_rhsAB", "compute_vel_rhs.UV_rhsAB", "e2")
         orc.call("visc_filt_bcksct"); chk(step, "UV_rhs", "viscosity_filter.UV_rhs", "e2")

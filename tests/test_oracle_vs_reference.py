@@ -78,3 +78,32 @@ def test_oracle_chain_bitwise_gm(built, redi):
     orc.set_state(st)
     bad = run_reference_chain(orc, mesh, gold("pi_pp_gm_redi" if redi else "pi_pp_gm"), steps=(1, 2, 3))
     assert not bad, "\n".join(bad[:20])
+
+
+FORCING = ("stress_atmoce_x", "stress_atmoce_y", "heat_flux", "water_flux", "stress_surf")
+
+
+@pytest.mark.parametrize("cfg", ["pi_kpp", "pi_default"])
+def test_oracle_chain_bitwise_kpp_forced(built, cfg):
+    """KPP vertical mixing (src/oce_ale_mixing_kpp.F90: ri_iwmix, bldepth, wscale tables, blmix_kpp, enhance, smoothing of blmc)
+    under the harness's analytic wind stress / heat / fresh-water forcing, which also pins the surface boundary terms of
+    impl_vert_visc_ale, compute_ssh_rhs_ale, compute_hbar_ale and the tracer diffusion; `pi_default` = the reference's
+    default physics (KPP + GM + Redi)."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.synthetic import analytic_ts
+    from oracle_lib import Oracle
+    from ref_chain import run_reference_chain
+    full = cfg == "pi_default"
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, mix_scheme="KPP", Fer_GM=full, Redi=full)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    orc = Oracle(mesh, par)
+    orc.set_state(st)
+    g = gold(cfg)
+    for f in FORCING:
+        orc.set(f, g["forcing/" + f])
+    bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
+    assert not bad, "\n".join(bad[:20])
