@@ -117,6 +117,7 @@ struct Dag {
 int K(hipStream_t s, const char *k, int arg = 0, int fs = 0) {
   int rc = launch_named_dyn(G.m, s, k, arg, fs);
   if (rc < 0) rc = launch_named_tra(G.m, s, k, arg);
+  if (rc < 0) rc = launch_named_kpp(G.m, s, k);
   return rc;
 }
 void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
@@ -158,6 +159,7 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   K(s0, "k_vel_nodes");
   hipStreamWaitEvent(s0, ev_pb, 0);
   if (m.p.mix_scheme == 2) { K(s0, "k_pp_node_raw"); K(s0, "k_pp_elem"); K(s0, "k_pp_node_final"); }
+  if (m.p.mix_scheme == 1) K(s0, "mixing_kpp");       // k_kpp_col, 3 smoothing sweeps, k_kpp_final, k_kpp_elem
   hipStreamWaitEvent(s0, ev_rhs, 0); hipStreamWaitEvent(s0, ev_visc, 0);
   K(s0, "k_impl_visc");                            // incl. the Thomas sweep
   K(s0, "k_edge_transport");
@@ -225,6 +227,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   if (par->which_ale != 0 && par->which_ale != 2) { G.err = "fesom_gpu_init: which_ale must be linfs(0) or zstar(2)"; return 3; }
   if (par->mom_adv != 2 || par->visc_option != 5) { G.err = "fesom_gpu_init: only mom_adv=2, visc_option=5 are implemented"; return 3; }
   if (par->Fer_GM && par->scaling_Rossby) { G.err = "fesom_gpu_init: scaling_Rossby=.true. (GM cut-off by the Rossby radius) is not implemented"; return 3; }
+  if (par->mix_scheme < 0 || par->mix_scheme > 2) { G.err = "fesom_gpu_init: mix_scheme must be 0 (constant), 1 (KPP) or 2 (PP); the cvmix schemes are not implemented"; return 3; }
   if (par->w_split) { G.err = "fesom_gpu_init: w_split=.true. (implicit vertical advection of tracers) is not implemented"; return 3; }
   for (int e = 0; e < d->myDim_elem2D + d->eDim_elem2D; e++)
     if (d->ulevels[e] != 1) { G.err = "fesom_gpu_init: cavities (ulevels>1) are not supported"; return 3; }
@@ -361,6 +364,37 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   FT(adv_flux_hor, n1 * D); FT(adv_flux_raw, n1 * D); FT(flux_lo_hor, n1 * D); FT(diff_flux, n1 * D); FT(edge_up_dn_grad, 4 * n1 * D); F(edge_c12, D);
   F(ssh_values, m.nza);
   if (par->Fer_GM) { F(fer_K, nl * N); F(fer_gamma, 2 * nl * N); F(fer_Wvel, nl * N); F(fer_c, N); F(fer_UV, 2 * n1 * E); }
+  if (par->mix_scheme == 1) {
+    F(dbsfc, nl * N); F(stress_atmoce_x, N); F(stress_atmoce_y, N);
+    F(kpp_viscA, nl * N); F(kpp_Kv1, nl * N); F(kpp_Kv2, nl * N); F(kpp_ghats, n1 * N); F(kpp_hbl, N); F(kpp_caseA, N); F(kpp_dkm1, 3 * N);
+    m.kpp_blmc = field("kpp_blmc", nl * N, 3); m.kpp_sA = field("kpp_sA", nl * N, 3); m.kpp_sB = field("kpp_sB", nl * N, 3);
+    for (int j = 0; j < 3; j++) G.fields[std::string("kpp_blmc") + char('1' + j)] = Field{m.kpp_blmc + (size_t)j * nl * N, nl * N, 1};
+    m.kpp_kbl = dev_alloc<int>(N);
+    m.coriolis_node = dev_upload_d(d->coriolis_node, N);
+    // constants and look-up tables of oce_mixing_kpp_init (oce_ale_mixing_kpp.F90:97-201).  Which library call the reference's
+    // build makes for each power is pinned on the reference run of tests/golden (sqrt for **(1/2), pow otherwise; cg as cbrt)
+    const double epsln = 1.0e-40, eps_kpp = 0.1, vonk = 0.4, conc1 = 5.0, zmin = -4.e-7, zmax = 0.0, umin = 0.0, umax = 0.04;
+    const double conam = 1.257, concm = 8.380, conc2 = 16.0, zetam = -0.2, conas = -28.86, concs = 98.96, conc3 = 16.0, zetas = -1.0;
+    const int nni = 890, nnj = 480;
+    m.kpp_deltaz = (zmax - zmin) / (double)(nni + 1); m.kpp_deltau = (umax - umin) / (double)(nnj + 1);
+    m.kpp_Vtc = par->concv * sqrt(0.2 / concs / eps_kpp) / (vonk * vonk) / par->Ricr;
+    m.kpp_cg = 10.0 * vonk * cbrt(concs * vonk * eps_kpp);
+    std::vector<double> wmt((size_t)(nni + 2) * (nnj + 2)), wst(wmt.size());
+    for (int i = 0; i <= nni + 1; i++) {
+      const double zehat = m.kpp_deltaz * (double)i + zmin;
+      for (int j = 0; j <= nnj + 1; j++) {
+        const double usta = m.kpp_deltau * (double)j + umin, u3 = usta * usta * usta, zeta = zehat / (u3 + epsln);
+        double wm, ws;
+        if (zehat >= 0.) { wm = vonk * usta / (1. + conc1 * zeta); ws = wm; }
+        else {
+          wm = zeta > zetam ? vonk * usta * pow(1. - conc2 * zeta, 1. / 4.) : vonk * pow(conam * u3 - concm * zehat, 1. / 3.);
+          ws = zeta > zetas ? vonk * usta * sqrt(1. - conc3 * zeta) : vonk * pow(conas * u3 - concs * zehat, 1. / 3.);
+        }
+        wmt[(size_t)j * (nni + 2) + i] = wm; wst[(size_t)j * (nni + 2) + i] = ws;
+      }
+    }
+    m.kpp_wmt = dev_upload(wmt); m.kpp_wst = dev_upload(wst);
+  }
   if (par->toy_soufflet) { F(Tclim, n1 * N); F(Uclim, n1 * E); F(toy_zvel, n1 * 100); F(toy_ztem, n1 * 100); }
   F(sv_vals, 16 * (N + 64)); F(sv_dinv, N + 64); F(sv_b, N + 64); F(sv_r, N + 64); F(sv_r0, N + 64); F(sv_p, N + 64); F(sv_v, N + 64); F(sv_s, N + 64); F(sv_t, N + 64);
   F(sv_ph, N + 64); F(sv_x0, 16 * (N + 64)); F(sv_snap, N);
@@ -468,8 +502,10 @@ int fesom_gpu_download_state(const fesom_state_desc *st) { return copy_state(st,
 int fesom_gpu_set_forcing(const fesom_forcing_desc *f) {
   NEED_READY();
   struct { const char *n; const double *h; } tab[] = {{"stress_surf", f->stress_surf}, {"heat_flux", f->heat_flux}, {"water_flux", f->water_flux},
-                                                      {"virtual_salt", f->virtual_salt}, {"relax_salt", f->relax_salt}, {"real_salt_flux", f->real_salt_flux}};
+                                                      {"virtual_salt", f->virtual_salt}, {"relax_salt", f->relax_salt}, {"real_salt_flux", f->real_salt_flux},
+                                                      {"stress_atmoce_x", f->stress_atmoce_x}, {"stress_atmoce_y", f->stress_atmoce_y}};
   for (auto &t : tab) {
+    if (!G.fields.count(t.n)) continue;                 // (nodal wind stress only exists with KPP)
     Field &fl = G.fields[t.n];
     if (t.h) HIPCHK(hipMemcpyAsync(fl.p, t.h, fl.count * sizeof(double), hipMemcpyHostToDevice, G.stream));
     else HIPCHK(hipMemsetAsync(fl.p, 0, fl.count * sizeof(double), G.stream));
@@ -517,6 +553,8 @@ static int call_named(const char *name, int arg) {
   rc = launch_named_tra(m, G.stream, name, arg);
   if (rc == 0) return 0;
   rc = launch_named_toy(m, G.stream, name);
+  if (rc == 0) return 0;
+  rc = launch_named_kpp(m, G.stream, name);
   if (rc == 0) return 0;
   rc = launch_named_gm(m, G.stream, name);
   if (rc == 0) return 0;

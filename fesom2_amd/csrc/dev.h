@@ -54,6 +54,13 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   const double *redi_k0;                                  // (N) K_hor*(mesh_resolution/100km)^2: surface Ki of Redi without GM
   const double *gm_scal_static;                           // (N) mesh-only part of the horizontal GM scaling
   int *MLD1_ind;                                          // (N) level index of MLD1 (pressure_bv)
+  // KPP (kernels_kpp.hip): interior values, boundary layer coefficients (3 slabs of (nl,N)) + two smoothing buffers, tables
+  double *dbsfc, *stress_atmoce_x, *stress_atmoce_y;
+  const double *coriolis_node;
+  double *kpp_viscA, *kpp_Kv1, *kpp_Kv2, *kpp_blmc, *kpp_sA, *kpp_sB, *kpp_ghats, *kpp_hbl, *kpp_caseA, *kpp_dkm1;
+  int *kpp_kbl;
+  const double *kpp_wmt, *kpp_wst;
+  double kpp_deltaz, kpp_deltau, kpp_Vtc, kpp_cg;
   // Soufflet toy channel (kernels_toy.hip): relaxation targets, zonal means per (level, latitude bin), static bin tables
   double *Tclim, *Uclim, *toy_zvel, *toy_ztem;
   const double *toy_znum, *toy_e_a, *toy_n_a;
@@ -224,4 +231,5 @@ void launch_tracer(const DM &m, hipStream_t s, int tr);
 void launch_thickness(const DM &m, hipStream_t s);
 int  launch_named_toy(const DM &m, hipStream_t s, const char *name);
 int  launch_named_gm(const DM &m, hipStream_t s, const char *name);
+int  launch_named_kpp(const DM &m, hipStream_t s, const char *name);
 int  launch_named_dsolve(const DM &m, hipStream_t s, const char *name);

@@ -79,6 +79,7 @@ __global__ void __launch_bounds__(BLOCK) k_pressure_bv(DM m) {
     double dbsfc1 = -D_G * (rho_surf - rr) / rr;
     double zk = (nz > nzmin + 1) ? z : z2;                      // Z_3d_n(max(nz,nzmin+1))
     dbq = dbsfc1 / fabs(zmin - zk);
+    if (m.dbsfc) { DA2L(m.dbsfc, nz, n) = dbsfc1; if (nz == nzmax - 1) DA2L(m.dbsfc, nzmax, n) = dbsfc1; }   // KPP: buoyancy difference to the surface
   }
   double db_max = wave_max(wet ? dmax_(dbq, 0.0) : 0.0);
   // linfs: hydrostatic pressure (sequential running sum, reference order)
@@ -747,6 +748,7 @@ void launch_dynamics_pre(const DM &m, hipStream_t s, int first_step) {
     LAUNCH_COL(k_pp_elem, m.myE, m);
     LAUNCH_COL(k_pp_node_final, m.N, m);
   }
+  if (m.p.mix_scheme == 1) launch_named_kpp(m, s, "mixing_kpp");
   LAUNCH_COL(k_momadv_node, m.myN, m);
   LAUNCH_COL(k_vel_rhs, m.myE, m, first_step);
   LAUNCH_COL(k_visc_elem, m.E, m);

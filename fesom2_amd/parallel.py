@@ -46,6 +46,13 @@ def run_step(core, par, X, solve, first, probe=None):
         X(NOD, ["slope_tapered"])
     if p.mix_scheme == 2:
         c("k_pp_node_raw"); c("k_pp_elem"); c("k_pp_node_final"); P("mixing")
+    if p.mix_scheme == 1:                             # KPP: smoothing of blmc needs the neighbours' values after every sweep
+        c("k_kpp_col"); X(NOD, ["kpp_blmc"])
+        c("k_kpp_smooth1"); X(NOD, ["kpp_sA"])
+        c("k_kpp_smooth2"); X(NOD, ["kpp_sB"])
+        c("k_kpp_smooth3")
+        c("k_kpp_final"); X(NOD, ["kpp_viscA", "Kv"])
+        c("k_kpp_elem"); P("mixing")
     c("k_momadv_node"); X(NOD, ["Unode_rhs"])
     c("k_vel_rhs"); P("vel_rhs")
     c("k_visc_elem"); X(ELEM, ["U_b"])

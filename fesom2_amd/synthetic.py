@@ -54,3 +54,15 @@ def write_ic_files(meshdir, outdir):
     T.tofile(os.path.join(outdir, "ic_T.bin"))
     S.tofile(os.path.join(outdir, "ic_S.bin"))
     return T, S
+
+
+def analytic_forcing(mesh):
+    """Analytic surface forcing on a (global or rank-local) mesh: nodal wind stress, heat flux (W/m2, positive up) and fresh-water
+    flux (m/s) with both signs of the surface buoyancy flux, and the element wind stress as the mean of the nodal one
+    (ice_oce_coupling.F90:62-68 with a_ice = 0).  Same formulas as the reference harness uses for the golden runs."""
+    lon, lat = mesh.geo_coord_nod2D[:, 0], mesh.geo_coord_nod2D[:, 1]
+    f = {"stress_atmoce_x": 0.1 * np.cos(3.0 * lat), "stress_atmoce_y": 0.03 * np.sin(2.0 * lon),
+         "heat_flux": 150.0 * np.sin(2.0 * lon + 1.0) * np.cos(lat), "water_flux": 2.0e-8 * np.cos(3.0 * lon)}
+    en = mesh.elem2D_nodes[:mesh.myDim_elem2D] - 1
+    f["stress_surf"] = np.stack([f["stress_atmoce_x"][en].sum(1) / 3.0, f["stress_atmoce_y"][en].sum(1) / 3.0], axis=1)
+    return {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in f.items()}

@@ -63,12 +63,15 @@ def main():
         torch.cuda.set_device(0)
     rank, world = dist.get_rank(), dist.get_world_size()
     opts = os.environ.get("PART_OPTS", "").split(",")
-    par = make_params(dt=900.0, Fer_GM="gm" in opts, Redi="redi" in opts, scaling_Ferreira="gm" in opts or "redi" in opts)
+    par = make_params(dt=900.0, mix_scheme="KPP" if "kpp" in opts else "PP", Fer_GM="gm" in opts, Redi="redi" in opts, scaling_Ferreira="gm" in opts or "redi" in opts)
     T, S = analytic_ts(PI)
     # ---- single partition (whole mesh) on this rank
     gm = Mesh.load(PI, dt=900.0)
     st = gm.initial_state(2); st.tr_arr[0], st.tr_arr[1] = T, S; st.tr_arr_old[...] = st.tr_arr
     g = OceanCore(gm, par); g.upload_state(st)
+    if "kpp" in opts:
+        from fesom2_amd.synthetic import analytic_forcing
+        g.set_forcing(**analytic_forcing(gm))
     ref = {}
     first = True
     for n in range(1, NSTEPS + 1):
@@ -81,6 +84,8 @@ def main():
     ln = lm.myList_nod2D - 1
     st = lm.initial_state(2); st.tr_arr[0], st.tr_arr[1] = T[ln], S[ln]; st.tr_arr_old[...] = st.tr_arr
     pc.core.upload_state(st)
+    if "kpp" in opts:
+        pc.core.set_forcing(**analytic_forcing(lm))
     mine = {}
     for n in range(1, NSTEPS + 1):
         pc.step(n, probe=lambda lab, n=n: grab(pc.core, lm, lab, mine, n))

@@ -43,9 +43,18 @@ GM_BEFORE_W = [("init_Redi_GM", 0, ["fer_K", "fer_c"]), ("fer_solve_Gamma", 0, [
 GM_AFTER_W = [("fer_wvel", 0, ["fer_Wvel"]), ("bolus_add", 0, ["UV", "Wvel", "Wvel_e"])]
 
 
-def full_chain(ntr=2, gm=False, redi=False):
+KPP_MIX = [("mixing_kpp", 0, ["kpp_hbl", "kpp_ghats", "kpp_blmc1", "kpp_blmc2", "kpp_blmc3", "kpp_viscA", "kpp_Kv1", "kpp_Kv2"]),
+           ("mo_convect", 0, ["Av", "Kv"])]
+
+
+def full_chain(ntr=2, gm=False, redi=False, kpp=False):
     ch = []
     for item in DYN_PRE:
+        if kpp and item[0] == "mixing_pp":
+            ch += KPP_MIX
+            continue
+        if kpp and item[0] == "mo_convect":
+            continue
         if redi and not gm and item[0] == "vert_vel_ale":
             ch.append(("init_Redi_GM", 0, ["Ki"]))
         if gm and item[0] == "vert_vel_ale":

@@ -187,3 +187,52 @@ def test_redi_chain_bitwise_and_steps(built, gm):
         err = np.abs(a - b).max() / np.abs(b).max()
         assert err < 1e-9, (f, err)
     gpu.close()
+
+
+@pytest.mark.parametrize("full", [False, True])
+def test_kpp_chain_and_steps(built, full):
+    """KPP vertical mixing under surface forcing (full = with GM + Redi, the reference's default physics): routine chain over
+    3 steps, HIP == oracle bitwise (with Redi the oracle's tapered slopes are handed over, see the Redi test), then 10 whole
+    steps through the step graph: bitwise without Redi, 1e-9 relative with it."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.core import OceanCore
+    from fesom2_amd.synthetic import analytic_ts
+    from oracle_lib import Oracle
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, mix_scheme="KPP", Fer_GM=full, Redi=full, scaling_Ferreira=full)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    gpu, orc = OceanCore(mesh, par), Oracle(mesh, par)
+    gpu.upload_state(st); orc.set_state(st)
+    from fesom2_amd.synthetic import analytic_forcing
+    forcing = analytic_forcing(mesh)
+    gpu.set_forcing(**forcing)
+    for k, v in forcing.items():
+        orc.set(k, v)
+    failures = []
+    for step in range(1, 4):
+        for routine, arg, fields in full_chain(2, gm=full, redi=full, kpp=True):
+            gpu.call(routine, arg); orc.call(routine, arg)
+            for f in fields:
+                ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+                if not ok:
+                    failures.append(f"step {step} {routine}({arg}) {msg}")
+            if full and routine == "compute_neutral_slope":
+                gpu.set("slope_tapered", orc.get("slope_tapered"))
+        if failures:
+            break
+    assert not failures, "\n".join(failures[:10])
+    gpu.run_steps(4, 10)
+    for n in range(10):
+        orc.call("step", 4 + n)
+    for f in ("tr_arr", "UV", "eta_n", "hnode", "Kv", "Av", "kpp_hbl"):
+        a, b = gpu.get(f, orc.count(f)), orc.get(f)
+        if full:
+            err = np.abs(a - b).max() / np.abs(b).max()
+            assert err < (1e-9 if f != "kpp_hbl" else 1e-6), (f, err)
+        else:
+            ok, msg = compare(f, a, b)
+            assert ok, msg
+    gpu.close()
