@@ -8,9 +8,13 @@ ALE vertical velocity, 2x FCT tracer advection + diffusion, thickness update) ov
 (3140 nodes, 47 layers, T/S, no sea ice), synthetic analytic initial state resident in HBM.
 SYPD = 86400 / (365*96 * seconds_per_step)  (pi: step_per_day=96, setups/pi/setup.yml:12).
 
-N>1: one process per GPU under torch.distributed.run.  The halo-exchange path is not built in
-this round, so N ranks run N independent replicas of the pi mesh ("replicas only", scaling "weak"): value is
-the aggregate simulated years/day of the ensemble, NOT strong-scaling SYPD of one simulation.
+N>1: one process per GPU under torch.distributed.run.  `value` is the aggregate of N independent replicas of the pi mesh
+(scaling "weak"); ONE simulation partitioned over the N GPUs (reference node partition, halo exchange over RCCL,
+partitioned SSH solve; fesom2_amd/parallel.py) is timed next to it in "partitioned" (scaling "strong"): pi has ~390
+surface nodes per GPU at N = 8 and is latency-bound, so that leg is reported, not promoted to `value`.
+
+--physics pp (default, the workload of this round's profiles) | default (KPP + GM + Redi + surface forcing, the
+reference's namelist defaults); at N = 1 a short run of the other set is reported in "other_physics".
 
 Besides the contract fields the JSON line carries
   roofline     : dominant kernel, algorithmic bytes (SURVEY 8d counting rule) / HIP-event time vs 8 TB/s
@@ -47,9 +51,16 @@ PER_TRACER = ("k_tr_ab", "k_tr_z", "k_tr_grad_elem", "k_updn_grad", "k_flux_hor"
               "k_fct_edge_limit", "k_tr_update", "k_diff_flux")
 
 
-def cpu_baseline(nsteps_ref=400):
+PHYSICS = {   # --physics: options of the hot path; "pp" is the headline workload of this round's profiles, "default" the reference's
+    "pp": dict(kw=dict(), ref_cfg="pi_pp", text="PP mixing, no GM/Redi, no surface forcing"),
+    "default": dict(kw=dict(mix_scheme="KPP", Fer_GM=True, Redi=True), ref_cfg="pi_default",
+                    text="KPP mixing + GM + Redi (namelist.oce defaults), analytic wind/heat/fresh-water forcing"),
+}
+
+
+def cpu_baseline(nsteps_ref=400, physics="pp"):
     """Reference Fortran/MPI hot path (oracle/_ref/fesom_oracle.x, built from the reference's own sources) on the
-    host cores: same mesh, same options (PP mixing, no GM/Redi), same initial state; 8 MPI ranks (dist_8)."""
+    host cores: same mesh, same options, same initial state; 8 MPI ranks (dist_8)."""
     ncpu = os.cpu_count() or 1
     exe = os.path.join(REPO, "oracle", "_ref", "fesom_oracle.x")
     try:
@@ -57,13 +68,13 @@ def cpu_baseline(nsteps_ref=400):
             raise RuntimeError("no reference binary")
         from oracle.ref import run_ref
         ranks = 8 if ncpu >= 8 else 2
-        rd, rc, lines = run_ref.run("pi_pp", ranks, nsteps_ref, mode="step", dump=(), dump_mesh=False)
+        rd, rc, lines = run_ref.run(PHYSICS[physics]["ref_cfg"], ranks, nsteps_ref, mode="step", dump=(), dump_mesh=False)
         tl = [l for l in lines if l.startswith("ORACLE_TIMING")]
         if rc != 0 or not tl:
             raise RuntimeError(f"reference run failed rc={rc}")
         sps = float(tl[0].split("s_per_step=")[1])
         return {"value": 86400.0 / (STEPS_PER_YEAR * sps), "unit": "simulated_years/day", "cores": ranks, "kind": "reference",
-                "sample": f"{nsteps_ref} steps of oce_timestep_ale on pi (PP mixing, no GM/Redi), {ranks} MPI ranks, {sps*1e3:.2f} ms/step"}
+                "sample": f"{nsteps_ref} steps of oce_timestep_ale on pi ({PHYSICS[physics]['text']}), {ranks} MPI ranks, {sps*1e3:.2f} ms/step"}
     except Exception as e:          # reference cannot run here: time the scalar C restatement instead
         from fesom2_amd.mesh import Mesh
         from fesom2_amd.config import make_params
@@ -71,7 +82,11 @@ def cpu_baseline(nsteps_ref=400):
         from oracle_lib import Oracle
         pi = os.path.join(REPO, "tests", "golden", "meshes", "pi")
         mesh = Mesh.load(pi, dt=900.0)
-        orc = Oracle(mesh, make_params(dt=900.0))
+        orc = Oracle(mesh, make_params(dt=900.0, **PHYSICS[physics]["kw"]))
+        if physics == "default":
+            from fesom2_amd.synthetic import analytic_forcing
+            for k, v in analytic_forcing(mesh).items():
+                orc.set(k, v)
         st = mesh.initial_state(2)
         st.tr_arr[0], st.tr_arr[1] = analytic_ts(pi)
         st.tr_arr_old[...] = st.tr_arr
@@ -92,6 +107,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--physics", choices=sorted(PHYSICS), default="pp", help="options of the timed step (default: pp; a short run of the other set is reported in 'other_physics' at N=1)")
     ap.add_argument("--refine", type=int, default=0, help="supplementary workload: pi refined uniformly L times (4^L x the cells, same dt = 900 s); the headline metric is L = 0")
     args = ap.parse_args()
 
@@ -120,7 +136,7 @@ def main():
     from fesom2_amd.mesh import Mesh
     from fesom2_amd.config import make_params
     from fesom2_amd.core import OceanCore
-    from fesom2_amd.synthetic import analytic_ts
+    from fesom2_amd.synthetic import analytic_ts, analytic_forcing
 
     pi = os.path.join(REPO, "tests", "golden", "meshes", "pi")
     dt = 900.0
@@ -132,12 +148,19 @@ def main():
         pi = pi_r                      # dt stays 900 s: the untuned viscosity of this synthetic set-up is unstable for shorter steps
     steps_per_year = 365 * 86400.0 / dt
     mesh = Mesh.load(pi, dt=dt)
-    par = make_params(dt=dt)
+    par = make_params(dt=dt, **PHYSICS[args.physics]["kw"])
     st = mesh.initial_state(2)
     st.tr_arr[0], st.tr_arr[1] = analytic_ts(pi)
     st.tr_arr_old[...] = st.tr_arr
-    core = OceanCore(mesh, par)
-    core.upload_state(st)
+
+    def new_core(physics):
+        c = OceanCore(mesh, make_params(dt=dt, **PHYSICS[physics]["kw"]))
+        c.upload_state(st)
+        if physics == "default":
+            c.set_forcing(**analytic_forcing(mesh))
+        return c
+
+    core = new_core(args.physics)
 
     def barrier():
         if world > 1:
@@ -177,6 +200,8 @@ def main():
             lst.tr_arr[0], lst.tr_arr[1] = T0[ln], S0[ln]
             lst.tr_arr_old[...] = lst.tr_arr
             pc.core.upload_state(lst)
+            if args.physics == "default":
+                pc.core.set_forcing(**analytic_forcing(pc.mesh))
             pw, pk = 5, max(10, min(100, args.steps))
             for n in range(1, pw + 1):
                 pc.step(n)
@@ -198,8 +223,7 @@ def main():
             partitioned = {"error": f"{type(e).__name__}: {e}"[:300]}
         if rank != 0:
             os._exit(0)                 # no further collective: rank 0 finishes the report alone
-        core = OceanCore(mesh, par)
-        core.upload_state(st)
+        core = new_core(args.physics)
         core.run_steps(1, 60)
         torch.cuda.synchronize()
 
@@ -211,12 +235,14 @@ def main():
         N3, E3, D3 = mesh.wet_counts()
         times, kbytes = {}, {}
         # SSH solve replayed on a real (operator, rhs, warm-start) triple of one more step
-        for r in ("compute_vel_nodes", "pressure_bv", "pressure_force", "compute_sigma_xy", "mixing_pp", "compute_vel_rhs",
+        for r in ("compute_vel_nodes", "pressure_bv", "pressure_force", "compute_sigma_xy", "mixing_pp" if args.physics == "pp" else "mixing_kpp", "compute_vel_rhs",
                   "visc_filt_bcksct", "impl_vert_visc_ale", "update_stiff_mat_ale", "compute_ssh_rhs_ale", "solver_snapshot"):
             core.call(r)
         times["k_solver"] = core.kernel_time_ms("k_solver_replay", 10) * 1e-3
         its = core.solver_iterations
         for k, (a, b, c) in KERNEL_VALUES.items():
+            if args.physics != "pp" and k.startswith("k_pp_"):
+                continue
             times[k] = core.kernel_time_ms(k, 50) * 1e-3
             kbytes[k] = 8.0 * (a * N3 + b * E3 + c * D3)
         share = {k: t * (2 if k in PER_TRACER else 1) for k, t in times.items()}
@@ -246,20 +272,37 @@ def main():
                     "top5_us": {k: round(v * 1e6, 2) for k, v in sorted(share.items(), key=lambda kv: -kv[1])[:5]}}
         cpu = None
         if world == 1 and not args.no_cpu_baseline and args.refine == 0:
-            cpu = cpu_baseline()
+            cpu = cpu_baseline(physics=args.physics)
+        # the other option set, short run (N = 1 only): same mesh and state, its own CPU reference timing
+        other = None
+        if world == 1 and args.refine == 0:
+            oph = "default" if args.physics == "pp" else "pp"
+            core.close()
+            core = new_core(oph)
+            ow, ok_ = 100, 500
+            core.run_steps(1, ow); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            core.run_steps(1 + ow, ok_); torch.cuda.synchronize()
+            osps = (time.perf_counter() - t1) / ok_
+            assert np.isfinite(core.get("eta_n", mesh.myDim_nod2D)).all(), "model state blew up (other physics)"
+            other = {"physics": PHYSICS[oph]["text"], "ms_per_step": round(osps * 1e3, 5), "value": round(86400.0 / (steps_per_year * osps), 2),
+                     "unit": "simulated_years/day", "steps": ok_, "warmup": ow, "solver_iterations": core.solver_iterations,
+                     "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(200, oph)}
         out = {"metric": "SYPD (simulated years/day) on pi mesh, 47 z-levels", "value": round(sypd_one * world, 2),
                "unit": "simulated_years/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(sps * 1e3, 5), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": ("pi mesh (3140 nodes, 5839 elements, 47 layers)" if args.refine == 0 else
                                        f"pi mesh refined {args.refine}x ({mesh.nod2D} nodes, {mesh.elem2D} elements, 47 layers)") +
-                                      ", T/S tracers, zstar ALE, JM EOS, PP mixing, MFCT/QR4C/FCT advection, no sea ice, no GM/Redi",
+                                      ", T/S tracers, zstar ALE, JM EOS, MFCT/QR4C/FCT advection, no sea ice, " + PHYSICS[args.physics]["text"],
                           "steps_per_day": int(round(86400.0 / dt)),
                           "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (value); one simulation partitioned over the {world} GPUs is timed in 'partitioned'",
                           "wet_cells": {"N3": N3, "E3": E3, "D3": D3}},
                "roofline": roofline, "cpu_baseline": cpu}
         if world > 1:
             out["partitioned"] = partitioned
+        if other is not None:
+            out["other_physics"] = other
         print(json.dumps(out), flush=True)
     if world > 1 and partitioned is not None:
         sys.stdout.flush()
