@@ -491,8 +491,11 @@ static int copy_state(const fesom_state_desc *st, bool up) {
   for (auto &t : tab) {
     if (!t.h) continue;
     Field &f = G.fields[t.n];
-    if (up) HIPCHK(hipMemcpy(f.p, t.h, f.count * sizeof(double), hipMemcpyHostToDevice));
-    else HIPCHK(hipMemcpy(t.h, f.p, f.count * sizeof(double), hipMemcpyDeviceToHost));
+    size_t cnt = f.count;                 // the reference allocates these two for owned elements only (oce_ale.F90:108,112)
+    if (!strcmp(t.n, "helem")) cnt = (size_t)G.m.nlm1 * G.m.myE;
+    if (!strcmp(t.n, "dhe")) cnt = (size_t)G.m.myE;
+    if (up) HIPCHK(hipMemcpy(f.p, t.h, cnt * sizeof(double), hipMemcpyHostToDevice));
+    else HIPCHK(hipMemcpy(t.h, f.p, cnt * sizeof(double), hipMemcpyDeviceToHost));
   }
   return 0;
 }
@@ -507,7 +510,8 @@ int fesom_gpu_set_forcing(const fesom_forcing_desc *f) {
   for (auto &t : tab) {
     if (!G.fields.count(t.n)) continue;                 // (nodal wind stress only exists with KPP)
     Field &fl = G.fields[t.n];
-    if (t.h) HIPCHK(hipMemcpyAsync(fl.p, t.h, fl.count * sizeof(double), hipMemcpyHostToDevice, G.stream));
+    const size_t cnt = !strcmp(t.n, "stress_surf") ? (size_t)2 * G.m.myE : fl.count;     // (2,myDim_elem2D), oce_setup_step.F90:249
+    if (t.h) HIPCHK(hipMemcpyAsync(fl.p, t.h, cnt * sizeof(double), hipMemcpyHostToDevice, G.stream));
     else HIPCHK(hipMemsetAsync(fl.p, 0, fl.count * sizeof(double), G.stream));
   }
   return 0;

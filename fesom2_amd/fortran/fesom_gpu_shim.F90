@@ -1,0 +1,275 @@
+! Host side of the MI355X ocean core in the reference's own language: the thin Fortran layer a FESOM2 build adds to call
+! libfesom_gpu.so (include/fesom_gpu.h) in place of its CPU time step.
+!
+!   call fesom_gpu_setup(mesh)            once, after mesh_setup + ocean_setup (src/fvom_main.F90:92-97)
+!   call oce_timestep_ale_gpu(n, mesh)    instead of compute_vel_nodes + oce_timestep_ale(n, mesh)  (fvom_main.F90:216,250)
+!   call fesom_gpu_fetch_state(mesh)      when the host needs the fields (output, restart, diagnostics)
+!   call fesom_gpu_shutdown()
+!
+! Everything is handed over by address (ISO_C_BINDING): the mesh from t_mesh (src/MOD_MESH.F90:19-95) and o_MESH/o_ARRAYS
+! (src/oce_modules.F90:196-353), the partition from g_PARSUP (src/gen_modules_partitioning.F90), the options from the
+! namelist variables of o_PARAM / g_config.  Fortran keeps owning every host array.  Errors follow the reference's
+! convention: message on the rank, pe_status = 1, status_check aborts (src/gen_comm.F90:644-657).
+! One MPI rank <-> one GPU.  This file compiles against the reference's module files (it `use`s them), nothing else.
+module fesom_gpu_shim
+  use iso_c_binding
+  use o_PARAM
+  use MOD_MESH
+  use o_MESH
+  use o_ARRAYS
+  use g_PARSUP
+  use g_config
+  use g_forcing_arrays, only: real_salt_flux
+  implicit none
+  private
+  public :: fesom_gpu_setup, oce_timestep_ale_gpu, fesom_gpu_fetch_state, fesom_gpu_push_state, fesom_gpu_shutdown
+
+  ! ---- struct layouts = include/fesom_gpu.h, field by field
+  type, bind(C) :: fesom_mesh_desc
+     integer(c_int) :: nod2D, elem2D, edge2D, edge2D_in, nl
+     integer(c_int) :: myDim_nod2D, eDim_nod2D, myDim_elem2D, eDim_elem2D, eXDim_elem2D, myDim_edge2D, eDim_edge2D
+     integer(c_int) :: max_nod_in_elem, ssh_nza
+     type(c_ptr) :: myList_nod2D, myList_elem2D, myList_edge2D, coord_nod2D, geo_coord_nod2D
+     type(c_ptr) :: elem2D_nodes, edges, edge_tri, elem_edges, elem_neighbors, nod_in_elem2D, nod_in_elem2D_num
+     type(c_ptr) :: nlevels, ulevels, nlevels_nod2D, ulevels_nod2D, nlevels_nod2D_min, ulevels_nod2D_max
+     type(c_ptr) :: zbar, Z, depth, elem_area, area, area_inv, areasvol, areasvol_inv, mesh_resolution
+     type(c_ptr) :: gradient_sca, gradient_vec, edge_dxdy, edge_cross_dxdy, elem_cos, metric_factor, coriolis, coriolis_node
+     type(c_ptr) :: ssh_rowptr, ssh_colind, ssh_colind_loc, ssh_values, edge_up_dn_tri
+     type(c_ptr) :: zbar_n_bot, zbar_n_srf, bottom_node_thickness, zbar_e_bot, zbar_e_srf, bottom_elem_thickness
+  end type
+  type, bind(C) :: fesom_com_desc
+     integer(c_int) :: rPEnum, sPEnum
+     type(c_ptr) :: rPE, rptr, rlist, sPE, sptr, slist
+  end type
+  type, bind(C) :: fesom_part_desc
+     integer(c_int) :: npes, mype
+     type(fesom_com_desc) :: com_nod2D, com_elem2D, com_elem2D_full
+  end type
+  type, bind(C) :: fesom_params
+     real(c_double) :: dt
+     integer(c_int) :: which_ale, use_partial_cell, state_equation, num_tracers, mom_adv, visc_option, i_vert_visc, i_vert_diff, &
+                       w_split, mix_scheme, use_instabmix, use_windmix, windmix_nl, toy_soufflet
+     real(c_double) :: alpha, theta, epsilon, C_d, A_ver, K_ver, K_hor, gamma0, gamma1, gamma2, easy_bs_return, w_max_cfl, &
+                       tra_adv_ph, tra_adv_pv, instabmix_kv, windmix_kv, cyclic_length
+     integer(c_int) :: with_diffusion, solver_x0_order, Fer_GM
+     real(c_double) :: K_GM_max, K_GM_min
+     integer(c_int) :: K_GM_bvref
+     real(c_double) :: K_GM_rampmax, K_GM_rampmin, K_GM_resscalorder
+     integer(c_int) :: scaling_Ferreira, scaling_Rossby, scaling_resolution, scaling_FESOM14, Redi
+     real(c_double) :: visc_sh_limit, diff_sh_limit, Ricr, concv
+  end type
+  type, bind(C) :: fesom_state_desc
+     type(c_ptr) :: tr_arr, tr_arr_old, UV, UV_rhsAB, eta_n, d_eta, ssh_rhs, ssh_rhs_old, hbar, hbar_old, dhe, hnode, hnode_new, &
+                    helem, zbar_3d_n, Z_3d_n, Wvel, Wvel_e, Wvel_i, ssh_values
+  end type
+  type, bind(C) :: fesom_forcing_desc
+     type(c_ptr) :: stress_surf, heat_flux, water_flux, virtual_salt, relax_salt, real_salt_flux, stress_atmoce_x, stress_atmoce_y
+  end type
+
+  interface
+     integer(c_int) function c_fesom_gpu_init(mesh, part, par) bind(C, name='fesom_gpu_init')
+       import
+       type(fesom_mesh_desc), intent(in) :: mesh
+       type(c_ptr), value :: part
+       type(fesom_params), intent(in) :: par
+     end function
+     integer(c_int) function c_fesom_gpu_upload_state(st) bind(C, name='fesom_gpu_upload_state')
+       import
+       type(fesom_state_desc), intent(in) :: st
+     end function
+     integer(c_int) function c_fesom_gpu_download_state(st) bind(C, name='fesom_gpu_download_state')
+       import
+       type(fesom_state_desc), intent(in) :: st
+     end function
+     integer(c_int) function c_fesom_gpu_set_forcing(f) bind(C, name='fesom_gpu_set_forcing')
+       import
+       type(fesom_forcing_desc), intent(in) :: f
+     end function
+     integer(c_int) function c_fesom_gpu_step(n) bind(C, name='fesom_gpu_step')
+       import
+       integer(c_int), value :: n
+     end function
+     integer(c_int) function c_fesom_gpu_finalize() bind(C, name='fesom_gpu_finalize')
+       import
+     end function
+     type(c_ptr) function c_fesom_gpu_last_error() bind(C, name='fesom_gpu_last_error')
+       import
+     end function
+     integer(c_size_t) function c_strlen(s) bind(C, name='strlen')
+       import
+       type(c_ptr), value :: s
+     end function
+  end interface
+
+  type(fesom_part_desc), target, save :: gpart
+  logical, save :: is_setup = .false.
+
+contains
+
+  ! address of a (contiguous) module array; the reference declares its arrays without TARGET, sequence association hands
+  ! over the base address without a copy
+  type(c_ptr) function ar(a)
+    real(kind=WP), target, intent(in) :: a(*)
+    ar = c_loc(a)
+  end function
+  type(c_ptr) function ai(a)
+    integer, target, intent(in) :: a(*)
+    ai = c_loc(a)
+  end function
+  integer(c_int) function l2i(l)
+    logical, intent(in) :: l
+    l2i = merge(1_c_int, 0_c_int, l)
+  end function
+
+  subroutine check(rc, what)
+    integer(c_int), intent(in) :: rc
+    character(*), intent(in) :: what
+    type(c_ptr) :: cmsg
+    character(kind=c_char), pointer :: fmsg(:)
+    integer :: n, i
+    character(len=512) :: msg
+    if (rc == 0) return
+    msg = ''
+    cmsg = c_fesom_gpu_last_error()
+    if (c_associated(cmsg)) then
+       n = int(min(c_strlen(cmsg), int(len(msg), c_size_t)))
+       call c_f_pointer(cmsg, fmsg, (/ n /))
+       do i = 1, n
+          msg(i:i) = fmsg(i)
+       end do
+    end if
+    write(*,*) 'fesom_gpu: ', what, ' failed on rank ', mype, ' rc=', rc, ': ', trim(msg)
+    pe_status = 1
+  end subroutine
+
+  subroutine fill_com(c, f)
+    type(com_struct), intent(in) :: c
+    type(fesom_com_desc), intent(out) :: f
+    f%rPEnum = c%rPEnum; f%sPEnum = c%sPEnum
+    f%rPE = ai(c%rPE); f%rptr = ai(c%rptr); f%rlist = ai(c%rlist)
+    f%sPE = ai(c%sPE); f%sptr = ai(c%sptr); f%slist = ai(c%slist)
+  end subroutine
+
+  subroutine state_desc(mesh, st)
+    type(t_mesh), intent(in), target :: mesh
+    type(fesom_state_desc), intent(out) :: st
+    st%tr_arr = ar(tr_arr); st%tr_arr_old = ar(tr_arr_old); st%UV = ar(UV); st%UV_rhsAB = ar(UV_rhsAB)
+    st%eta_n = ar(eta_n); st%d_eta = ar(d_eta); st%ssh_rhs = ar(ssh_rhs); st%ssh_rhs_old = ar(ssh_rhs_old)
+    st%hbar = ar(hbar); st%hbar_old = ar(hbar_old); st%dhe = ar(dhe); st%hnode = ar(hnode); st%hnode_new = ar(hnode_new)
+    st%helem = ar(helem); st%zbar_3d_n = ar(zbar_3d_n); st%Z_3d_n = ar(Z_3d_n)
+    st%Wvel = ar(Wvel); st%Wvel_e = ar(Wvel_e); st%Wvel_i = ar(Wvel_i); st%ssh_values = ar(mesh%ssh_stiff%values)
+  end subroutine
+
+  subroutine fesom_gpu_setup(mesh)
+    type(t_mesh), intent(in), target :: mesh
+    type(fesom_mesh_desc) :: d
+    type(fesom_params) :: p
+    type(fesom_state_desc) :: st
+    type(c_ptr) :: pp
+    d%nod2D = mesh%nod2D; d%elem2D = mesh%elem2D; d%edge2D = mesh%edge2D; d%edge2D_in = mesh%edge2D_in; d%nl = mesh%nl
+    d%myDim_nod2D = myDim_nod2D; d%eDim_nod2D = eDim_nod2D; d%myDim_elem2D = myDim_elem2D; d%eDim_elem2D = eDim_elem2D
+    d%eXDim_elem2D = eXDim_elem2D; d%myDim_edge2D = myDim_edge2D; d%eDim_edge2D = eDim_edge2D
+    d%max_nod_in_elem = size(mesh%nod_in_elem2D, 1); d%ssh_nza = size(mesh%ssh_stiff%values)
+    d%myList_nod2D = ai(myList_nod2D); d%myList_elem2D = ai(myList_elem2D); d%myList_edge2D = ai(myList_edge2D)
+    d%coord_nod2D = ar(mesh%coord_nod2D); d%geo_coord_nod2D = ar(mesh%geo_coord_nod2D)
+    d%elem2D_nodes = ai(mesh%elem2D_nodes); d%edges = ai(mesh%edges); d%edge_tri = ai(mesh%edge_tri)
+    d%elem_edges = ai(mesh%elem_edges); d%elem_neighbors = ai(mesh%elem_neighbors)
+    d%nod_in_elem2D = ai(mesh%nod_in_elem2D); d%nod_in_elem2D_num = ai(mesh%nod_in_elem2D_num)
+    d%nlevels = ai(mesh%nlevels); d%ulevels = ai(mesh%ulevels)
+    d%nlevels_nod2D = ai(mesh%nlevels_nod2D); d%ulevels_nod2D = ai(mesh%ulevels_nod2D)
+    d%nlevels_nod2D_min = ai(mesh%nlevels_nod2D_min); d%ulevels_nod2D_max = ai(mesh%ulevels_nod2D_max)
+    d%zbar = ar(mesh%zbar); d%Z = ar(mesh%Z); d%depth = ar(mesh%depth); d%elem_area = ar(mesh%elem_area)
+    d%area = ar(mesh%area); d%area_inv = ar(mesh%area_inv); d%areasvol = ar(mesh%areasvol); d%areasvol_inv = ar(mesh%areasvol_inv)
+    d%mesh_resolution = ar(mesh%mesh_resolution)
+    d%gradient_sca = ar(mesh%gradient_sca); d%gradient_vec = ar(mesh%gradient_vec)
+    d%edge_dxdy = ar(mesh%edge_dxdy); d%edge_cross_dxdy = ar(mesh%edge_cross_dxdy)
+    d%elem_cos = ar(mesh%elem_cos); d%metric_factor = ar(mesh%metric_factor)
+    d%coriolis = ar(coriolis); d%coriolis_node = ar(coriolis_node)
+    d%ssh_rowptr = ai(mesh%ssh_stiff%rowptr); d%ssh_colind = ai(mesh%ssh_stiff%colind)
+    d%ssh_colind_loc = ai(mesh%ssh_stiff%colind_loc); d%ssh_values = ar(mesh%ssh_stiff%values)
+    d%edge_up_dn_tri = ai(edge_up_dn_tri)
+    d%zbar_n_bot = ar(zbar_n_bot); d%zbar_n_srf = ar(zbar_n_srf); d%bottom_node_thickness = ar(bottom_node_thickness)
+    d%zbar_e_bot = ar(zbar_e_bot); d%zbar_e_srf = ar(zbar_e_srf); d%bottom_elem_thickness = ar(bottom_elem_thickness)
+
+    pp = c_null_ptr
+    if (npes > 1) then
+       gpart%npes = npes; gpart%mype = mype
+       call fill_com(com_nod2D, gpart%com_nod2D)
+       call fill_com(com_elem2D, gpart%com_elem2D)
+       call fill_com(com_elem2D_full, gpart%com_elem2D_full)
+       pp = c_loc(gpart)
+    end if
+
+    p%dt = dt
+    select case (trim(which_ALE))
+    case ('linfs');  p%which_ale = 0
+    case ('zlevel'); p%which_ale = 1
+    case default;    p%which_ale = 2        ! 'zstar'
+    end select
+    p%use_partial_cell = l2i(use_partial_cell); p%state_equation = state_equation; p%num_tracers = num_tracers
+    p%mom_adv = mom_adv; p%visc_option = visc_option; p%i_vert_visc = l2i(i_vert_visc); p%i_vert_diff = l2i(i_vert_diff)
+    p%w_split = l2i(w_split)
+    p%mix_scheme = mix_scheme_nmb                  ! 1 KPP, 2 PP (oce_setup_step.F90:69-82); others are rejected by the library
+    p%use_instabmix = l2i(use_instabmix); p%use_windmix = l2i(use_windmix); p%windmix_nl = windmix_nl
+    p%toy_soufflet = l2i(toy_ocean .and. trim(which_toy) == 'soufflet')
+    p%alpha = alpha; p%theta = theta; p%epsilon = epsilon; p%C_d = C_d; p%A_ver = A_ver; p%K_ver = K_ver; p%K_hor = K_hor
+    p%gamma0 = gamma0; p%gamma1 = gamma1; p%gamma2 = gamma2; p%easy_bs_return = easy_bs_return; p%w_max_cfl = w_max_cfl
+    p%tra_adv_ph = tra_adv_ph; p%tra_adv_pv = tra_adv_pv; p%instabmix_kv = instabmix_kv; p%windmix_kv = windmix_kv
+    p%cyclic_length = cyclic_length
+    p%with_diffusion = 1; p%solver_x0_order = 3
+    p%Fer_GM = l2i(Fer_GM); p%K_GM_max = K_GM_max; p%K_GM_min = K_GM_min; p%K_GM_bvref = K_GM_bvref
+    p%K_GM_rampmax = K_GM_rampmax; p%K_GM_rampmin = K_GM_rampmin; p%K_GM_resscalorder = K_GM_resscalorder
+    p%scaling_Ferreira = l2i(scaling_Ferreira); p%scaling_Rossby = l2i(scaling_Rossby)
+    p%scaling_resolution = l2i(scaling_resolution); p%scaling_FESOM14 = l2i(scaling_FESOM14); p%Redi = l2i(Redi)
+    p%visc_sh_limit = visc_sh_limit; p%diff_sh_limit = diff_sh_limit; p%Ricr = Ricr; p%concv = concv
+
+    call check(c_fesom_gpu_init(d, pp, p), 'fesom_gpu_init')
+    call status_check
+    call state_desc(mesh, st)
+    call check(c_fesom_gpu_upload_state(st), 'fesom_gpu_upload_state')
+    call status_check
+    is_setup = .true.
+  end subroutine
+
+  ! = compute_vel_nodes(mesh) + oce_timestep_ale(n, mesh) of the reference, on the GPU.  The surface forcing of this step
+  ! (the arrays the reference's forcing/ice layer filled on the host) is uploaded first.
+  subroutine oce_timestep_ale_gpu(n, mesh)
+    integer, intent(in) :: n
+    type(t_mesh), intent(in), target :: mesh
+    type(fesom_forcing_desc) :: f
+    if (.not. is_setup) call fesom_gpu_setup(mesh)
+    f%stress_surf = ar(stress_surf); f%heat_flux = ar(heat_flux); f%water_flux = ar(water_flux)
+    f%virtual_salt = ar(virtual_salt); f%relax_salt = ar(relax_salt)
+    f%real_salt_flux = c_null_ptr
+    if (allocated(real_salt_flux)) f%real_salt_flux = ar(real_salt_flux)
+    f%stress_atmoce_x = c_null_ptr; f%stress_atmoce_y = c_null_ptr
+    if (allocated(stress_atmoce_x)) then
+       f%stress_atmoce_x = ar(stress_atmoce_x); f%stress_atmoce_y = ar(stress_atmoce_y)
+    end if
+    call check(c_fesom_gpu_set_forcing(f), 'fesom_gpu_set_forcing')
+    call check(c_fesom_gpu_step(int(n, c_int)), 'fesom_gpu_step')
+    call status_check
+  end subroutine
+
+  subroutine fesom_gpu_fetch_state(mesh)
+    type(t_mesh), intent(in), target :: mesh
+    type(fesom_state_desc) :: st
+    call state_desc(mesh, st)
+    call check(c_fesom_gpu_download_state(st), 'fesom_gpu_download_state')
+    call status_check
+  end subroutine
+
+  subroutine fesom_gpu_push_state(mesh)       ! after the host changed the fields (restart read, nudging)
+    type(t_mesh), intent(in), target :: mesh
+    type(fesom_state_desc) :: st
+    call state_desc(mesh, st)
+    call check(c_fesom_gpu_upload_state(st), 'fesom_gpu_upload_state')
+    call status_check
+  end subroutine
+
+  subroutine fesom_gpu_shutdown()
+    integer(c_int) :: rc
+    if (is_setup) rc = c_fesom_gpu_finalize()
+    is_setup = .false.
+  end subroutine
+end module fesom_gpu_shim

@@ -15,7 +15,8 @@ mkdir -p "$OUT/obj" "$OUT/parms_obj"
 if [ ! -d "$REF/src" ]; then
   echo "build_ref.sh: $REF not present (GPU box?) - keeping prebuilt oracle/_ref as is"; exit 0
 fi
-if [ -x "$OUT/fesom_oracle.x" ] && [ "$OUT/fesom_oracle.x" -nt "$HERE/driver.F90" ] && [ "$OUT/fesom_oracle.x" -nt "$HERE/stubs.F90" ] && [ -z "$FORCE" ]; then
+if [ -x "$OUT/fesom_oracle.x" ] && [ "$OUT/fesom_oracle.x" -nt "$HERE/driver.F90" ] && [ "$OUT/fesom_oracle.x" -nt "$HERE/stubs.F90" ] && [ -x "$OUT/fesom_gpu_dropin.x" ] && \
+   [ "$OUT/fesom_gpu_dropin.x" -nt "$HERE/../../fesom2_amd/fortran/fesom_gpu_shim.F90" ] && [ "$OUT/fesom_gpu_dropin.x" -nt "$HERE/driver.F90" ] && [ -z "$FORCE" ]; then
   echo "build_ref.sh: up to date"; exit 0
 fi
 FFLAGS="-cpp -DPARMS -fdefault-real-8 -O2 -I$MPI_INC -I$REF/src -I$REF/lib/parms/include -module-dir $OUT/obj -I$OUT/obj"
@@ -64,3 +65,17 @@ for f in $LIST; do
 done
 $FC -O2 -o "$OUT/fesom_oracle.x" $OBJS psolve.o "$OUT/libparms.a" -L$MPI_LIB -lmpifort -lmpi -Wl,-rpath,$MPI_LIB
 echo "built $OUT/fesom_oracle.x"
+
+# ---- the same harness with the GPU drop-in: the repo's Fortran host layer (fesom2_amd/fortran/fesom_gpu_shim.F90) compiled
+#      against the reference's modules and linked to libfesom_gpu.so; driver mode 'gpu' steps through it
+REPO=$(cd "$HERE/../.." && pwd)
+GPULIB=$REPO/fesom2_amd
+if [ -f "$GPULIB/libfesom_gpu.so" ]; then
+  echo "FC fesom_gpu_shim"
+  $FC $FFLAGS -c $GPULIB/fortran/fesom_gpu_shim.F90 -o fesom_gpu_shim.o 2> fesom_gpu_shim.log || { grep -v warning fesom_gpu_shim.log | head -40; exit 1; }
+  $FC $FFLAGS -DWITH_GPU_SHIM -c $HERE/driver.F90 -o driver_gpu.o 2> driver_gpu.log || { grep -v warning driver_gpu.log | head -40; exit 1; }
+  GOBJS=$(echo $OBJS | sed 's/ driver.o/ fesom_gpu_shim.o driver_gpu.o/')
+  $FC -O2 -o "$OUT/fesom_gpu_dropin.x" $GOBJS psolve.o "$OUT/libparms.a" -L$MPI_LIB -lmpifort -lmpi -L$GPULIB -lfesom_gpu \
+    -Wl,-rpath,$MPI_LIB -Wl,-rpath,/root/repo/fesom2_amd -Wl,-rpath,$GPULIB
+  echo "built $OUT/fesom_gpu_dropin.x"
+fi

@@ -89,6 +89,9 @@ program oracle_driver
   use Toy_Channel_Soufflet
   use o_mixing_KPP_mod
   use o_tracers
+#ifdef WITH_GPU_SHIM
+  use fesom_gpu_shim
+#endif
   use oracle_dump
   implicit none
 
@@ -192,6 +195,18 @@ program oracle_driver
            call dump_state()
            call dump_close()
         end if
+#ifdef WITH_GPU_SHIM
+     else if (trim(mode)=='gpu') then
+        ! the drop-in: the repo's Fortran host layer in place of compute_vel_nodes + oce_timestep_ale (fvom_main.F90:216,250)
+        call oce_timestep_ale_gpu(n, mesh)
+        if (any(dump_steps==n)) then
+           call fesom_gpu_fetch_state(mesh)
+           write(tag,'(A,I4.4)') 'state', n
+           call dump_open(trim(dump_dir), trim(tag), mype)
+           call dump_state()
+           call dump_close()
+        end if
+#endif
      else
         call replay_step(n, any(dump_steps==n))
      end if
@@ -209,6 +224,9 @@ program oracle_driver
           rtime_oce_dynssh, rtime_oce_solvessh, rtime_oce_GMRedi, rtime_oce_solvetra, rtime_oce
   end if
   if (do_mean) call report_means()
+#ifdef WITH_GPU_SHIM
+  call fesom_gpu_shutdown()
+#endif
   call par_ex
 
 contains

@@ -1,0 +1,56 @@
+"""GPU: the drop-in itself.  The reference's own Fortran set-up (mesh_setup + ocean_setup, compiled from /root/reference into
+oracle/_ref/fesom_gpu_dropin.x by oracle/ref/build_ref.sh) fills its module arrays, the repo's Fortran host layer
+(fesom2_amd/fortran/fesom_gpu_shim.F90, ISO_C_BINDING) hands them to libfesom_gpu.so and steps on the MI355X in place of
+compute_vel_nodes + oce_timestep_ale; the result is compared with the reference's CPU time step (oracle/_ref/fesom_oracle.x,
+2 MPI ranks) from the same namelists, initial state and forcing.
+
+Tolerance: the reference is not bit-reproducible across partitions and its pARMS solve stops at the same
+1e-10 residual from a different iterate; after 10 steps of the default physics (KPP + GM + Redi, surface forcing):
+max|d eta| < 1e-8 m, max|dT|,|dS| < 1e-8, max|dU| < 1e-8 m/s, max|d hnode| < 1e-8 m."""
+import os
+import sys
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
+pytestmark = pytest.mark.gpu
+NSTEPS = 10
+
+
+@pytest.mark.parametrize("cfg", ["pi_default", "pi_pp"])
+def test_fortran_dropin_matches_reference_cpu_step(built, cfg):
+    from oracle.ref import run_ref
+    from oracle.ref.compare_oracle import assemble
+    from refdump import read_dump
+    for exe in ("fesom_gpu_dropin.x", "fesom_oracle.x"):
+        assert os.path.exists(os.path.join(REPO, "oracle", "_ref", exe)), f"oracle/_ref/{exe} missing: run __graft_entry__.build() where /root/reference is mounted"
+    env_dev = os.environ.get("FESOM_GPU_DEVICE")
+    os.environ["FESOM_GPU_DEVICE"] = "0"
+    try:
+        rd_g, rc_g, lines_g = run_ref.run(cfg, 1, NSTEPS, mode="gpu", dump=(NSTEPS,), exe_name="fesom_gpu_dropin.x")
+    finally:
+        if env_dev is None:
+            os.environ.pop("FESOM_GPU_DEVICE", None)
+    assert rc_g == 0, open(os.path.join(rd_g, "stdout.log")).read()[-3000:]
+    rd_c, rc_c, lines_c = run_ref.run(cfg, 2, NSTEPS, mode="step", dump=(NSTEPS,))
+    assert rc_c == 0, open(os.path.join(rd_c, "stdout.log")).read()[-3000:]
+    sg = [read_dump(os.path.join(rd_g, "dumps", "setup.r00000.bin"))]
+    dg = [read_dump(os.path.join(rd_g, "dumps", f"state{NSTEPS:04d}.r00000.bin"))]
+    sc = [read_dump(os.path.join(rd_c, "dumps", f"setup.r{r:05d}.bin")) for r in range(2)]
+    dc = [read_dump(os.path.join(rd_c, "dumps", f"state{NSTEPS:04d}.r{r:05d}.bin")) for r in range(2)]
+    worst = {}
+    for f in ("eta_n", "tr_arr", "UV", "hnode", "hbar", "Wvel"):
+        a, b = assemble(dg, sg, f), assemble(dc, sc, f)
+        assert a is not None and b is not None and a.shape == b.shape, f
+        assert np.isfinite(a).all(), f
+        worst[f] = float(np.abs(a - b).max())
+        assert np.abs(b).max() > 0
+    out = os.path.join(REPO, "gpurun_out")
+    if os.path.isdir(out):                                    # evidence for DESIGN.md: the measured differences and the host-side timing line
+        import json
+        json.dump({"cfg": cfg, "steps": NSTEPS, "max_abs_diff": worst, "gpu_timing": [l for l in lines_g if "TIMING" in l],
+                   "cpu_timing": [l for l in lines_c if "TIMING" in l]}, open(os.path.join(out, f"dropin_{cfg}.json"), "w"), indent=1)
+    assert worst["eta_n"] < 1e-8 and worst["tr_arr"] < 1e-8 and worst["UV"] < 1e-8 and worst["hnode"] < 1e-8 and worst["hbar"] < 1e-8, worst
+    assert worst["Wvel"] < 1e-10, worst
