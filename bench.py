@@ -243,9 +243,10 @@ def main():
         for k, (a, b, c) in KERNEL_VALUES.items():
             if args.physics != "pp" and k.startswith("k_pp_"):
                 continue
-            times[k] = core.kernel_time_ms(k, 50) * 1e-3
-            kbytes[k] = 8.0 * (a * N3 + b * E3 + c * D3)
-        share = {k: t * (2 if k in PER_TRACER else 1) for k, t in times.items()}
+            # per-tracer kernels: timed as the step launches them, T and S in one launch (grid.y = 2)
+            times[k] = core.kernel_time_ms(k + (":all" if k in PER_TRACER else ""), 50) * 1e-3
+            kbytes[k] = 8.0 * (a * N3 + b * E3 + c * D3) * (2 if k in PER_TRACER else 1)
+        share = dict(times)
         share["k_edge_transport"] = times["k_edge_transport"] * 2
         dom = max((k for k in share if k != "k_solver"), key=lambda k: share[k])
         achieved = kbytes[dom] / times[dom] / 1e9
@@ -258,7 +259,9 @@ def main():
             import glob
             pm = sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_summary.json")))
             if pm:
-                traffic = json.load(open(pm[-1]))["kernels"][dom]["traffic_bytes_min"]      # one tracer per launch, like times[dom]
+                kern = json.load(open(pm[-1]))["kernels"]
+                key = dom if dom in kern else dom + ("<false>" if args.physics == "pp" else "<true>")      # templated on Redi
+                traffic = kern[key]["traffic_bytes_max"]      # both tracers per launch, like times[dom]
         except Exception:
             traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -624,8 +624,13 @@ double fesom_gpu_last_solver_residual(void) {
 // Average device time of one launch of a routine / kernel (or "step"): nrep launches are captured into one
 // hipGraph (so the host launch rate does not bound short kernels) and timed with HIP events on the library's
 // own stream.  The figure includes the ~1.5 us dependent-launch boundary of back-to-back kernels.
-int fesom_gpu_kernel_time_ms(const char *group, int nrep, double *ms_per_launch) {
+int fesom_gpu_kernel_time_ms(const char *group_in, int nrep, double *ms_per_launch) {
   NEED_READY();
+  // "<name>:all" = the per-tracer kernels as the step launches them (all tracers in one launch, grid.y)
+  std::string gname(group_in);
+  int targ = 1;
+  if (gname.size() > 4 && gname.compare(gname.size() - 4, 4, ":all") == 0) { gname.resize(gname.size() - 4); targ = 0; }
+  const char *group = gname.c_str();
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   int fs = G.first_step;
@@ -647,7 +652,7 @@ int fesom_gpu_kernel_time_ms(const char *group, int nrep, double *ms_per_launch)
   }
   HIPCHK(hipStreamBeginCapture(G.stream, hipStreamCaptureModeGlobal));
   int bad = 0;
-  for (int i = 0; i < nrep; i++) bad |= call_named(group, 1);
+  for (int i = 0; i < nrep; i++) bad |= call_named(group, targ);
   HIPCHK(hipStreamEndCapture(G.stream, &g));
   if (bad) { hipGraphDestroy(g); return 1; }
   HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));

@@ -25,7 +25,7 @@ def main():
         # per-tracer kernels are launched for one tracer (bench.py's per-kernel timing) and for both (the step): min / max
         tab[k] = {"launches": len(fv), "fetch_KiB_min": min(fv), "fetch_KiB_max": max(fv), "write_KiB_min": min(wv), "write_KiB_max": max(wv),
                   "traffic_bytes_min": (2.0 * min(fv) + min(wv)) * 1024.0, "traffic_bytes_max": (2.0 * max(fv) + max(wv)) * 1024.0}
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around bench.py --steps 60 --warmup 20",
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_round.sh) around bench.py --steps 60 --warmup 20; templated kernels keep their arguments (<false> = without Redi, <true> = with: the other_physics leg)",
                "correction": "traffic = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes); gfx950 FETCH_SIZE counts 128-B requests as 64 B",
                "kernels": tab}, open(out, "w"), indent=1)
     ab = tab.get("k_tr_ab")
