@@ -74,6 +74,18 @@ class ForcingDesc(C.Structure):
                                   "real_salt_flux", "stress_atmoce_x", "stress_atmoce_y")]
 
 
+STEP_INFO_FIELDS = ("sum_eta", "sum_hbar", "sum_deta", "sum_dhbar", "sum_wflux", "sum_area",
+                    "min_eta", "min_hbar", "min_wflux", "min_hflux", "min_temp", "min_salt", "min_wvel", "min_wvel2", "min_uvel", "min_uvel2",
+                    "min_vvel", "min_vvel2", "min_deta", "min_hnode", "min_hnode2",
+                    "max_eta", "max_hbar", "max_wflux", "max_hflux", "max_temp", "max_salt", "max_wvel", "max_wvel2", "max_uvel", "max_uvel2",
+                    "max_vvel", "max_vvel2", "max_deta", "max_hnode", "max_hnode2", "max_cfl_z", "max_pgfx", "max_pgfy", "max_av", "max_kv",
+                    "blowup")
+
+
+class StepInfo(C.Structure):
+    _fields_ = [(n, C.c_double) for n in STEP_INFO_FIELDS]
+
+
 class MeshOpts(C.Structure):
     _fields_ = [("force_rotation", C.c_int), ("cyclic_length_deg", C.c_double), ("alphaEuler_deg", C.c_double),
                 ("betaEuler_deg", C.c_double), ("gammaEuler_deg", C.c_double), ("use_partial_cell", C.c_int),
@@ -85,7 +97,7 @@ class MeshOpts(C.Structure):
 EXPORTS = ("fesom_gpu_init", "fesom_gpu_upload_state", "fesom_gpu_download_state", "fesom_gpu_set_forcing",
            "fesom_gpu_step", "fesom_gpu_run_steps", "fesom_gpu_finalize", "fesom_gpu_get_field",
            "fesom_gpu_set_field", "fesom_gpu_call", "fesom_gpu_last_solver_iterations",
-           "fesom_gpu_last_solver_residual", "fesom_gpu_kernel_time_ms", "fesom_gpu_last_error",
+           "fesom_gpu_last_solver_residual", "fesom_gpu_kernel_time_ms", "fesom_gpu_last_error", "fesom_gpu_step_info",
            "psolver_init", "psolve", "psolver_final",
            "fesom_gpu_halo_info", "fesom_gpu_halo_pack", "fesom_gpu_halo_unpack", "fesom_gpu_copy", "fesom_gpu_sync", "fesom_gpu_set_stream", "fesom_gpu_field_ptr",
            "fesom_mesh_load", "fesom_mesh_get_desc", "fesom_mesh_get_part", "fesom_mesh_get_initial_state",
@@ -124,5 +136,6 @@ def load():
     lib.fesom_gpu_last_solver_residual.restype = C.c_double
     lib.fesom_gpu_kernel_time_ms.argtypes = [C.c_char_p, C.c_int, PD]
     lib.fesom_gpu_last_error.restype = C.c_char_p
+    lib.fesom_gpu_step_info.argtypes = [C.POINTER(StepInfo)]
     _lib = lib
     return lib

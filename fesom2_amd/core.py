@@ -55,6 +55,12 @@ class OceanCore:
         """Enqueue nsteps steps back to back (no host synchronisation)."""
         self._chk(self.lib.fesom_gpu_run_steps(int(n_first), int(nsteps)), "run_steps")
 
+    def step_info(self):
+        """device-side step monitor (write_step_info + check_blowup of the reference) over the owned nodes; returns a dict"""
+        si = _lib.StepInfo()
+        self._chk(self.lib.fesom_gpu_step_info(C.byref(si)), "step_info")
+        return {n: getattr(si, n) for n in _lib.STEP_INFO_FIELDS}
+
     def kernel_time_ms(self, group, nrep=20):
         ms = C.c_double(0.0)
         self._chk(self.lib.fesom_gpu_kernel_time_ms(group.encode(), int(nrep), C.byref(ms)), f"kernel_time_ms({group})")

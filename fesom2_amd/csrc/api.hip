@@ -25,6 +25,7 @@ struct Ctx {
   bool ext_stream = false;                              // stream handed in by the host (fesom_gpu_set_stream): not ours to destroy
   hipStream_t side[3] = {nullptr, nullptr, nullptr};   // forked branches of the step DAG
   int cur_tr = 0;
+  double *mon_col = nullptr, *mon_out = nullptr;       // step monitor scratch (fesom_gpu_step_info)
   bool serial = false;
   std::map<std::string, Field> fields;
   std::vector<void *> allocs;
@@ -209,7 +210,7 @@ int fesom_gpu_finalize(void) {
   if (G.stream) hipStreamSynchronize(G.stream);
   for (int i = 0; i < 2; i++) if (G.graph[i]) { hipGraphExecDestroy(G.graph[i]); G.graph[i] = nullptr; }
   for (void *p : G.allocs) hipFree(p);
-  G.allocs.clear(); G.fields.clear();
+  G.allocs.clear(); G.fields.clear(); G.mon_col = G.mon_out = nullptr;
   if (G.stream && !G.ext_stream) hipStreamDestroy(G.stream);
   G.stream = nullptr; G.ext_stream = false;
   for (int i = 0; i < 3; i++) if (G.side[i]) { hipStreamDestroy(G.side[i]); G.side[i] = nullptr; }
@@ -514,6 +515,17 @@ int fesom_gpu_set_forcing(const fesom_forcing_desc *f) {
     if (t.h) HIPCHK(hipMemcpyAsync(fl.p, t.h, cnt * sizeof(double), hipMemcpyHostToDevice, G.stream));
     else HIPCHK(hipMemsetAsync(fl.p, 0, fl.count * sizeof(double), G.stream));
   }
+  return 0;
+}
+
+int fesom_gpu_step_info(fesom_step_info *out) {
+  NEED_READY();
+  static_assert(sizeof(fesom_step_info) == 42 * sizeof(double), "fesom_step_info = 42 doubles");
+  if (!G.mon_col) { G.mon_col = dev_alloc<double>((size_t)10 * G.m.N); G.mon_out = dev_alloc<double>(64); }
+  launch_step_info(G.m, G.stream, G.mon_col, G.mon_out);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, G.mon_out, sizeof(fesom_step_info), hipMemcpyDeviceToHost, G.stream));
+  HIPCHK(hipStreamSynchronize(G.stream));
   return 0;
 }
 

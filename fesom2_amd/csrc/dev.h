@@ -232,4 +232,5 @@ void launch_thickness(const DM &m, hipStream_t s);
 int  launch_named_toy(const DM &m, hipStream_t s, const char *name);
 int  launch_named_gm(const DM &m, hipStream_t s, const char *name);
 int  launch_named_kpp(const DM &m, hipStream_t s, const char *name);
+void launch_step_info(const DM &m, hipStream_t s, double *col, double *out);
 int  launch_named_dsolve(const DM &m, hipStream_t s, const char *name);

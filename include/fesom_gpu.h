@@ -158,6 +158,21 @@ int  fesom_gpu_finalize(void);
 int  fesom_gpu_get_field(const char *name, double *out, long long count);
 int  fesom_gpu_set_field(const char *name, const double *in, long long count);
 int  fesom_gpu_call(const char *routine, int arg);
+/* Device-side step monitor = write_step_info + check_blowup of the reference (src/write_step_info.F90:14-222, :225-447),
+ * evaluated on the device over this rank's OWNED nodes, no per-step host synchronisation needed: call it at the logging
+ * cadence.  The sums are the rank-local parts (sum over owned nodes of areasvol(ulevels,n)*x(n)); the host adds them over
+ * the ranks and divides by the summed area (MPI_Allreduce in the reference), min/max likewise.  Field order = NAMES below.
+ * Reference quirks kept: pgf_x/pgf_y/Av are scanned over the first myDim_nod2D ELEMENT columns (:154-163), T/S extrema
+ * only where S /= 0, hnode extrema only where hnode /= 0. */
+typedef struct fesom_step_info {
+  double sum_eta, sum_hbar, sum_deta, sum_dhbar, sum_wflux, sum_area;
+  double min_eta, min_hbar, min_wflux, min_hflux, min_temp, min_salt, min_wvel, min_wvel2, min_uvel, min_uvel2, min_vvel,
+         min_vvel2, min_deta, min_hnode, min_hnode2;
+  double max_eta, max_hbar, max_wflux, max_hflux, max_temp, max_salt, max_wvel, max_wvel2, max_uvel, max_uvel2, max_vvel,
+         max_vvel2, max_deta, max_hnode, max_hnode2, max_cfl_z, max_pgfx, max_pgfy, max_av, max_kv;
+  double blowup;             /* 1.0 if any owned node fails check_blowup's tests (NaN, |eta|>50, T outside -5..60, S outside 0..50, ...) */
+} fesom_step_info;
+int  fesom_gpu_step_info(fesom_step_info *out);
 int  fesom_gpu_last_solver_iterations(void);
 double fesom_gpu_last_solver_residual(void);
 int  fesom_gpu_kernel_time_ms(const char *kernel_group, int nrep, double *ms_per_launch);

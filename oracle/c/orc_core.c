@@ -237,3 +237,52 @@ int orc_call(const char *name, int arg) {
   fprintf(stderr, "orc_call: unknown routine %s\n", name);
   return 1;
 }
+
+
+/* write_step_info + check_blowup, src/write_step_info.F90:14-222, :225-447 (single partition: the owned nodes are all nodes).
+ * out[42] in the field order of fesom_step_info (include/fesom_gpu.h). */
+int orc_step_info(double *out) {
+  const int myN = C_.m.myDim_nod2D;
+  double s[6] = {0, 0, 0, 0, 0, 0}, mn[15], mx[20], blow = 0.0;
+  for (int i = 0; i < 15; i++) mn[i] = 1.0e300;
+  for (int i = 0; i < 20; i++) mx[i] = -1.0e300;
+#define MN(i, v) do { double v_ = (v); if (v_ < mn[i]) mn[i] = v_; } while (0)
+#define MX(i, v) do { double v_ = (v); if (v_ > mx[i]) mx[i] = v_; } while (0)
+#define MM(i, v) do { MN(i, v); MX(i, v); } while (0)
+  for (int n = 1; n <= myN; n++) {
+    const double a = AREASVOL(ULEVN(n), n);
+    s[0] = s[0] + a * C_.eta_n[n - 1]; s[1] = s[1] + a * C_.hbar[n - 1]; s[2] = s[2] + a * C_.d_eta[n - 1];
+    s[3] = s[3] + a * (C_.hbar[n - 1] - C_.hbar_old[n - 1]); s[4] = s[4] + a * C_.water_flux[n - 1];
+    s[5] = s[5] + AREA(ULEVN(n), n);
+    MM(0, C_.eta_n[n - 1]); MM(1, C_.hbar[n - 1]); MM(2, C_.water_flux[n - 1]); MM(3, C_.heat_flux[n - 1]);
+    for (int nz = 1; nz <= NLM1; nz++) if (TR(nz, n, 2) != 0.0) { MM(4, TR(nz, n, 1)); MM(5, TR(nz, n, 2)); }
+    MM(6, A2L(C_.Wvel, 1, n)); MM(7, A2L(C_.Wvel, 2, n));
+    MM(8, V2(C_.Unode, 1, 1, n)); MM(9, V2(C_.Unode, 1, 2, n)); MM(10, V2(C_.Unode, 2, 1, n)); MM(11, V2(C_.Unode, 2, 2, n));
+    MM(12, C_.d_eta[n - 1]);
+    if (A2(C_.hnode, 1, n) != 0.0) MM(13, A2(C_.hnode, 1, n));
+    if (A2(C_.hnode, 2, n) != 0.0) MM(14, A2(C_.hnode, 2, n));
+    for (int nz = 1; nz <= NL; nz++) { MX(15, A2L(C_.CFL_z, nz, n)); MX(19, fabs(A2L(C_.Kv, nz, n))); }
+    if (n <= C_.E) {                                  /* element arrays scanned with the node count (reference quirk) */
+      for (int nz = 1; nz <= NLM1; nz++) { MX(16, fabs(A2(C_.pgf_x, nz, n))); MX(17, fabs(A2(C_.pgf_y, nz, n))); }
+      for (int nz = 1; nz <= NL; nz++) MX(18, fabs(A2L(C_.Av, nz, n)));
+    }
+    /* check_blowup */
+    double e = C_.eta_n[n - 1], de = C_.d_eta[n - 1];
+    if (e != e || e < -50.0 || e > 50.0 || de != de) blow = 1.0;
+    if (C_.p.which_ale != 0) {
+      double w = A2L(C_.Wvel, 1, n), h = A2(C_.hnode, 1, n);
+      if (w != w) blow = 1.0;
+      if (h != h || h < 0) blow = 1.0;
+    }
+    for (int nz = 1; nz <= NLEVN(n) - 1; nz++) {
+      double t = TR(nz, n, 1), sa = TR(nz, n, 2);
+      if (t != t || t < -5.0 || t > 60) blow = 1.0;
+      if (sa != sa || sa < 0 || sa > 50) blow = 1.0;
+    }
+  }
+  for (int i = 0; i < 6; i++) out[i] = s[i];
+  for (int i = 0; i < 15; i++) out[6 + i] = mn[i];
+  for (int i = 0; i < 20; i++) out[21 + i] = mx[i];
+  out[41] = blow;
+  return 0;
+}

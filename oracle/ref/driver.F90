@@ -100,13 +100,13 @@ program oracle_driver
   character(len=16) :: mode
   character(len=256) :: dump_dir
   integer :: dump_steps(64), ndump
-  logical :: dump_mesh, do_mean, debug, synth_forcing
+  logical :: dump_mesh, do_mean, debug, synth_forcing, step_info
   real(kind=WP) :: flon, flat
   integer :: fel(3)
   real(kind=WP) :: t0, t1, tloop
   character(len=64) :: tag
   namelist /clockinit/ timenew, daynew, yearnew
-  namelist /oracle/ nsteps, mode, dump_dir, dump_steps, dump_mesh, do_mean, debug, synth_forcing
+  namelist /oracle/ nsteps, mode, dump_dir, dump_steps, dump_mesh, do_mean, debug, synth_forcing, step_info
   ! running sums for the fcheck-style known answer (setups/test_souf/setup.yml:82-88)
   real(kind=WP), allocatable :: mT(:,:), mS(:,:), mU(:,:), mV(:,:)
 
@@ -135,7 +135,7 @@ program oracle_driver
   read (20,NML=oce_tra)
   read (20,NML=oce_init3d)
   close (20)
-  nsteps=1; mode='step'; dump_dir='dumps'; dump_steps=-1; dump_mesh=.false.; do_mean=.false.; debug=.false.; synth_forcing=.false.
+  nsteps=1; mode='step'; dump_dir='dumps'; dump_steps=-1; dump_mesh=.false.; do_mean=.false.; debug=.false.; synth_forcing=.false.; step_info=.false.
   open (20,file='namelist.oracle')
   read (20,NML=oracle)
   close (20)
@@ -189,6 +189,7 @@ program oracle_driver
         call compute_vel_nodes(mesh)
         call before_oce_step(mesh)
         call oce_timestep_ale(n, mesh)
+        if (step_info) call write_step_info(n, 1, mesh)      ! the reference's own step monitor (src/write_step_info.F90:14-222), to stdout
         if (any(dump_steps==n)) then
            write(tag,'(A,I4.4)') 'state', n
            call dump_open(trim(dump_dir), trim(tag), mype)

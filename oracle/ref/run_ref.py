@@ -198,14 +198,14 @@ def prepare(cfg, np_):
     return rd
 
 
-def run(cfg, np_, nsteps, mode="step", dump=(), mean=False, dump_mesh=True, quiet=True, exe_name="fesom_oracle.x"):
+def run(cfg, np_, nsteps, mode="step", dump=(), mean=False, dump_mesh=True, quiet=True, exe_name="fesom_oracle.x", step_info=False):
     forcing = CFGS[cfg].get("synth_forcing", False)
     rd = prepare(cfg, np_)
     ds = ",".join(str(d) for d in dump) if dump else "-1"
     open(os.path.join(rd, "namelist.oracle"), "w").write(
         f"&oracle\nnsteps={nsteps}\nmode='{mode}'\ndump_dir='dumps'\ndump_steps={ds}\n"
         f"dump_mesh={'.true.' if dump_mesh else '.false.'}\ndo_mean={'.true.' if mean else '.false.'}\n"
-        f"synth_forcing={'.true.' if forcing else '.false.'}\n/\n")
+        f"synth_forcing={'.true.' if forcing else '.false.'}\nstep_info={'.true.' if step_info else '.false.'}\n/\n")
     exe = os.path.join(OUT, exe_name)
     cmd = ["/opt/conda/bin/mpiexec", "-n", str(np_), exe]
     r = subprocess.run(cmd, cwd=rd, capture_output=True, text=True)

@@ -49,6 +49,12 @@ class Oracle:
         rc = self.lib.orc_call(name.encode(), int(arg))
         assert rc == 0, name
 
+    def step_info(self):
+        """write_step_info + check_blowup (42 values, field order of fesom_step_info)"""
+        out = np.empty(42, dtype=np.float64)
+        assert self.lib.orc_step_info(out.ctypes.data_as(PD)) == 0
+        return out
+
     def set_state(self, st):
         for k, v in st.a.items():
             self.set(k, v)

@@ -6,7 +6,7 @@ import numpy as np
 from golden_util import check_digest, wet_masks
 
 
-def run_reference_chain(orc, mesh, g, steps=(1, 2, 3), toy=False, skip=()):
+def run_reference_chain(orc, mesh, g, steps=(1, 2, 3), toy=False, skip=(), after_step=None):
     """returns the list of mismatches (empty = bit-identical on every sampled value).  `skip` = set of (step, key)
     entries that are known to differ (documented where used)."""
     W = wet_masks(mesh)
@@ -103,6 +103,8 @@ def run_reference_chain(orc, mesh, g, steps=(1, 2, 3), toy=False, skip=()):
         for f in ("hnode", "helem", "zbar_3d_n", "Z_3d_n"):
             chk(step, f, "update_thickness_ale." + f)
         chk(step, "tr_arr", "out.tr_arr"); chk(step, "UV", "out.UV", "e2"); chk(step, "eta_n", "out.eta_n")
+        if after_step is not None:
+            after_step(step)
         if bad:
             break
     return bad

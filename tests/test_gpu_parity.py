@@ -236,3 +236,50 @@ def test_kpp_chain_and_steps(built, full):
             ok, msg = compare(f, a, b)
             assert ok, msg
     gpu.close()
+
+
+def test_step_info_device_monitor(built):
+    """fesom_gpu_step_info (write_step_info + check_blowup on the device) against the oracle's restatement after 5 steps of the
+    default physics: extrema and the blow-up flag exact, the area-weighted sums to 1e-13 relative of sum|terms| (different, fixed
+    summation order); then a NaN / an out-of-range temperature planted in the device state must raise the flag."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.core import OceanCore
+    from fesom2_amd.synthetic import analytic_ts, analytic_forcing
+    from fesom2_amd._lib import STEP_INFO_FIELDS
+    from oracle_lib import Oracle
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, mix_scheme="KPP", Fer_GM=True)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    gpu, orc = OceanCore(mesh, par), Oracle(mesh, par)
+    gpu.upload_state(st); orc.set_state(st)
+    forcing = analytic_forcing(mesh)
+    gpu.set_forcing(**forcing)
+    for k, v in forcing.items():
+        orc.set(k, v)
+    gpu.run_steps(1, 5)
+    for n in range(1, 6):
+        orc.call("step", n)
+    a, b = gpu.step_info(), dict(zip(STEP_INFO_FIELDS, orc.step_info()))
+    area = mesh.areasvol[:, 0]
+    for k in STEP_INFO_FIELDS:
+        if k.startswith("sum_"):
+            scale = {"sum_eta": np.abs(area * orc.get("eta_n")).sum(), "sum_hbar": np.abs(area * orc.get("hbar")).sum(),
+                     "sum_deta": np.abs(area * orc.get("d_eta")).sum(), "sum_dhbar": np.abs(area * orc.get("d_eta")).sum(),
+                     "sum_wflux": np.abs(area * forcing["water_flux"]).sum(), "sum_area": area.sum()}[k]
+            assert abs(a[k] - b[k]) <= 1e-13 * scale, (k, a[k], b[k])
+        else:
+            assert a[k] == b[k], (k, a[k], b[k])
+    assert a["blowup"] == 0.0 and a["min_temp"] > -2 and a["max_salt"] < 40 and a["max_cfl_z"] > 0
+    T = gpu.get("tr_arr", orc.count("tr_arr"))          # (nl-1, N, 2): first level of node 262 = a wet temperature value
+    T2 = T.copy(); T2[262 * (mesh.nl - 1)] = 75.0
+    gpu.set("tr_arr", T2)
+    assert gpu.step_info()["blowup"] == 1.0
+    gpu.set("tr_arr", T)
+    assert gpu.step_info()["blowup"] == 0.0
+    e = gpu.get("eta_n", mesh.myDim_nod2D); e[7] = np.nan
+    gpu.set("eta_n", e)
+    assert gpu.step_info()["blowup"] == 1.0
+    gpu.close()
