@@ -86,6 +86,14 @@ class StepInfo(C.Structure):
     _fields_ = [(n, C.c_double) for n in STEP_INFO_FIELDS]
 
 
+TRANSPORT_EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+TRANSPORT_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+
+
+class Transport(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("exchange", TRANSPORT_EXCHANGE), ("allreduce_sum", TRANSPORT_ALLREDUCE)]
+
+
 class MeshOpts(C.Structure):
     _fields_ = [("force_rotation", C.c_int), ("cyclic_length_deg", C.c_double), ("alphaEuler_deg", C.c_double),
                 ("betaEuler_deg", C.c_double), ("gammaEuler_deg", C.c_double), ("use_partial_cell", C.c_int),
@@ -97,7 +105,7 @@ class MeshOpts(C.Structure):
 EXPORTS = ("fesom_gpu_init", "fesom_gpu_upload_state", "fesom_gpu_download_state", "fesom_gpu_set_forcing",
            "fesom_gpu_step", "fesom_gpu_run_steps", "fesom_gpu_finalize", "fesom_gpu_get_field",
            "fesom_gpu_set_field", "fesom_gpu_call", "fesom_gpu_last_solver_iterations",
-           "fesom_gpu_last_solver_residual", "fesom_gpu_kernel_time_ms", "fesom_gpu_last_error", "fesom_gpu_step_info",
+           "fesom_gpu_last_solver_residual", "fesom_gpu_kernel_time_ms", "fesom_gpu_last_error", "fesom_gpu_step_info", "fesom_gpu_step_partitioned",
            "psolver_init", "psolve", "psolver_final",
            "fesom_gpu_halo_info", "fesom_gpu_halo_pack", "fesom_gpu_halo_unpack", "fesom_gpu_copy", "fesom_gpu_sync", "fesom_gpu_set_stream", "fesom_gpu_field_ptr",
            "fesom_mesh_load", "fesom_mesh_get_desc", "fesom_mesh_get_part", "fesom_mesh_get_initial_state",
@@ -137,5 +145,6 @@ def load():
     lib.fesom_gpu_kernel_time_ms.argtypes = [C.c_char_p, C.c_int, PD]
     lib.fesom_gpu_last_error.restype = C.c_char_p
     lib.fesom_gpu_step_info.argtypes = [C.POINTER(StepInfo)]
+    lib.fesom_gpu_step_partitioned.argtypes = [C.c_int, C.POINTER(Transport)]
     _lib = lib
     return lib

@@ -25,6 +25,7 @@ struct Ctx {
   bool ext_stream = false;                              // stream handed in by the host (fesom_gpu_set_stream): not ours to destroy
   hipStream_t side[3] = {nullptr, nullptr, nullptr};   // forked branches of the step DAG
   int cur_tr = 0;
+  int part_iters = -1;
   double *mon_col = nullptr, *mon_out = nullptr;       // step monitor scratch (fesom_gpu_step_info)
   bool serial = false;
   std::map<std::string, Field> fields;
@@ -518,6 +519,101 @@ int fesom_gpu_set_forcing(const fesom_forcing_desc *f) {
   return 0;
 }
 
+static int call_named(const char *name, int arg);
+// ---- partitioned step driven by the library (phase order = fesom2_amd/parallel.py:run_step, which the tests probe phase by
+// phase; both call the same kernels in the same order, so their results are bit-identical for the same transport)
+namespace {
+struct PStep {
+  const fesom_transport *t;
+  int rc = 0;
+  void c(const char *name, int arg = 0) { if (!rc && call_named(name, arg)) { rc = 1; if (G.err.empty()) G.err = std::string("step_partitioned: unknown phase ") + name; } }
+  void X(int kind, std::initializer_list<const char *> names) {
+    if (rc) return;
+    const Ctx::Halo &h = G.halo[kind];
+    if (h.rPE.empty() && h.sPE.empty()) return;
+    std::vector<const char *> nm(names);
+    void *sd = nullptr, *rd = nullptr; int W = 0;
+    if (fesom_gpu_halo_pack(kind, (int)nm.size(), nm.data(), &sd, &rd, &W)) { rc = 1; return; }
+    if (t->exchange(t->ctx, kind, sd, rd, W)) { rc = 1; G.err = "step_partitioned: transport exchange failed"; return; }
+    if (fesom_gpu_halo_unpack(kind, (int)nm.size(), nm.data())) rc = 1;
+  }
+  void AR(int n) { if (!rc && t->allreduce_sum(t->ctx, G.m.sv_red, n)) { rc = 1; G.err = "step_partitioned: transport allreduce failed"; } }
+};
+}  // namespace
+
+int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
+  NEED_READY();
+  if (G.npes < 2) return fesom_gpu_step(n);
+  if (!t || !t->exchange || !t->allreduce_sum) { G.err = "step_partitioned: transport callbacks missing"; return 1; }
+  const fesom_params &p = G.m.p;
+  PStep S{t};
+  (void)n;
+  S.c("k_vel_nodes"); S.X(0, {"Unode"});
+  S.c("k_pressure_bv"); S.c("k_pgf"); S.c("k_sigma_slope");
+  if (p.Redi) S.X(0, {"slope_tapered"});
+  if (p.mix_scheme == 2) { S.c("k_pp_node_raw"); S.c("k_pp_elem"); S.c("k_pp_node_final"); }
+  if (p.mix_scheme == 1) {
+    S.c("k_kpp_col"); S.X(0, {"kpp_blmc"});
+    S.c("k_kpp_smooth1"); S.X(0, {"kpp_sA"});
+    S.c("k_kpp_smooth2"); S.X(0, {"kpp_sB"});
+    S.c("k_kpp_smooth3");
+    S.c("k_kpp_final"); S.X(0, {"kpp_viscA", "Kv"});
+    S.c("k_kpp_elem");
+  }
+  S.c("k_momadv_node"); S.X(0, {"Unode_rhs"});
+  S.c("k_vel_rhs");
+  S.c("k_visc_elem"); S.X(1, {"U_b"});
+  S.c("k_visc_node"); S.X(0, {"U_c"});
+  S.c("k_impl_visc");
+  if (p.which_ale != 0) S.c("k_stiff_update");
+  S.c("k_edge_transport"); S.c("k_ssh_rhs_node");
+  {   // partitioned SSH solve: recurrences of the single-GPU kernel, Krylov scalars + convergence flag on the device
+    S.c("ds_scale"); S.X(0, {"sv_dinv"});
+    S.c("ds_setup"); S.X(0, {"sv_s"});
+    S.c("ds_init"); S.AR(1); S.c("ds_scal_init"); S.c("ds_p");
+    const int poll = 4;
+    double kry[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    while (!S.rc) {
+      for (int k = 0; k < poll; k++) {
+        S.X(0, {"sv_ph"}); S.c("ds_spmv1"); S.AR(1); S.c("ds_scal_alpha"); S.c("ds_s");
+        S.X(0, {"sv_s"}); S.c("ds_spmv2"); S.AR(4); S.c("ds_scal_omega"); S.c("ds_update"); S.c("ds_p");
+      }
+      HIPCHK(hipMemcpyAsync(kry, G.m.sv_kry, sizeof(kry), hipMemcpyDeviceToHost, G.stream));
+      HIPCHK(hipStreamSynchronize(G.stream));
+      if (kry[7] != 0.0 || kry[6] >= 2000) break;
+    }
+    G.part_iters = (int)kry[6];
+    S.c("ds_finish");
+  }
+  S.X(0, {"d_eta"});
+  if (p.Redi && !p.Fer_GM) { S.c("init_Redi_GM"); S.X(0, {"Ki"}); }
+  if (p.Fer_GM) {
+    S.c("init_Redi_GM");
+    if (p.Redi) S.X(0, {"fer_c", "fer_K", "Ki"}); else S.X(0, {"fer_c", "fer_K"});
+    S.c("fer_solve_Gamma"); S.X(0, {"fer_gamma"});
+    S.c("fer_gamma2vel"); S.X(1, {"fer_UV"});
+    S.c("fer_wvel"); S.X(0, {"fer_Wvel"});
+  }
+  S.c("k_update_vel"); S.X(1, {"UV"});
+  S.c("k_edge_transport1"); S.c("k_vert_vel_hbar");
+  S.X(0, {"Wvel", "Wvel_e", "Wvel_i", "hnode_new", "hbar", "hbar_old", "eta_n", "ssh_rhs_old"});
+  S.c("k_dhe");
+  if (p.Fer_GM) S.c("bolus_add");
+  S.c("k_tr_ab", 0); S.c("k_tr_grad_elem", 0); S.X(2, {"tr_xy_ab"});
+  S.c("k_updn_grad", 0);
+  S.c("k_tr_z", 0);
+  if (p.Redi) S.X(0, {"tr_z"});
+  if (p.with_diffusion) S.c("k_diff_flux", 0);
+  S.c("k_flux_hor", 0); S.c("k_fct_lo_node", 0); S.X(0, {"fct_LO"});
+  S.c("k_fct_node", 0); S.X(0, {"fct_plus", "fct_minus"});
+  S.c("k_fct_edge_limit", 0); S.c("k_tr_update", 0); S.X(0, {"tr_arr"});
+  if (p.Fer_GM) S.c("bolus_remove");
+  S.c("k_thick_node"); S.c("k_thick_elem");
+  G.first_step = 0;
+  HIPCHK(hipGetLastError());
+  return S.rc;
+}
+
 int fesom_gpu_step_info(fesom_step_info *out) {
   NEED_READY();
   static_assert(sizeof(fesom_step_info) == 42 * sizeof(double), "fesom_step_info = 42 doubles");
@@ -620,6 +716,7 @@ int fesom_gpu_step(int n) {
 
 int fesom_gpu_last_solver_iterations(void) {
   if (!G.ready) return -1;
+  if (G.npes > 1 && G.part_iters >= 0) return G.part_iters;      // partitioned solve (fesom_gpu_step_partitioned)
   int it = -1;
   hipStreamSynchronize(G.stream);
   hipMemcpy(&it, G.m.sv_info, sizeof(int), hipMemcpyDeviceToHost);

@@ -137,7 +137,13 @@ class HaloExchanger:
         arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
         sp, rp, W = C.c_void_p(), C.c_void_p(), C.c_int()
         self._chk(self.lib.fesom_gpu_halo_pack(kind, len(names), arr, C.byref(sp), C.byref(rp), C.byref(W)), "halo_pack")
-        W = W.value
+        self.move(kind, sp, rp, W.value)
+        self._chk(self.lib.fesom_gpu_halo_unpack(kind, len(names), arr), "halo_unpack")
+
+    def move(self, kind, sp, rp, W):
+        """the transport proper: the packed send buffer of the library to the neighbours, their blocks into its receive buffer
+        (sp, rp: device addresses as c_void_p; W values per item)"""
+        inf = self.info[kind]
         ns, nr = sum(inf["scnt"]) * W, sum(inf["rcnt"]) * W
         if self.device:                       # RCCL directly on the device buffers
             send, recv = self.dev_tensor(sp.value, max(ns, 1)), self.dev_tensor(rp.value, max(nr, 1))
@@ -157,7 +163,6 @@ class HaloExchanger:
                 r.wait()
         if not self.device and nr:
             self._chk(self.lib.fesom_gpu_copy(rp, recv_h.ctypes.data, nr * 8, 1), "copy h2d")
-        self._chk(self.lib.fesom_gpu_halo_unpack(kind, len(names), arr), "halo_unpack")
 
 
 class PartitionedCore:
@@ -210,6 +215,42 @@ class PartitionedCore:
     def step(self, n=1, probe=None):
         run_step(self.core, self.par, self.halo.exchange, self.solve_ssh, self.first, probe)
         self.first = False
+
+    def step_native(self, n=1):
+        """The same step driven by the library (fesom_gpu_step_partitioned, include/fesom_gpu.h): the phase loop and the solver
+        loop run in C++, this host only supplies the two transport callbacks -- what a Fortran/MPI host does as well
+        (fesom2_amd/fortran/fesom_gpu_shim.F90)."""
+        if not hasattr(self, "_transport"):
+            halo, lib, grp = self.halo, self.core.lib, self.group
+
+            def exchange(ctx, kind, sp, rp, W):
+                try:
+                    halo.move(kind, C.c_void_p(sp), C.c_void_p(rp), W)
+                    return 0
+                except Exception as e:          # noqa: BLE001 - must not propagate through the C frame
+                    print("transport exchange failed:", e, flush=True)
+                    return 1
+
+            def allreduce(ctx, buf, n):
+                try:
+                    if halo.device:
+                        dist.all_reduce(halo.dev_tensor(buf, 8)[:n], group=grp)
+                    else:
+                        h = np.empty(n)
+                        halo._chk(lib.fesom_gpu_copy(h.ctypes.data, C.c_void_p(buf), n * 8, 0), "copy d2h")
+                        t = torch.from_numpy(h); dist.all_reduce(t, group=grp)
+                        halo._chk(lib.fesom_gpu_copy(C.c_void_p(buf), h.ctypes.data, n * 8, 1), "copy h2d")
+                    return 0
+                except Exception as e:          # noqa: BLE001
+                    print("transport allreduce failed:", e, flush=True)
+                    return 1
+
+            self._cb = (_lib.TRANSPORT_EXCHANGE(exchange), _lib.TRANSPORT_ALLREDUCE(allreduce))     # keep the thunks alive
+            self._transport = _lib.Transport(None, self._cb[0], self._cb[1])
+        self.core.call("first_step", 1 if self.first else 0)
+        self.core._chk(self.core.lib.fesom_gpu_step_partitioned(int(n), C.byref(self._transport)), "step_partitioned")
+        self.first = False
+        self.solver_iterations = self.core.lib.fesom_gpu_last_solver_iterations()
 
     def owned(self, name, width):
         """(global ids, values) of the owned part of a node field with `width` values per node"""

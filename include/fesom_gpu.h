@@ -158,6 +158,24 @@ int  fesom_gpu_finalize(void);
 int  fesom_gpu_get_field(const char *name, double *out, long long count);
 int  fesom_gpu_set_field(const char *name, const double *in, long long count);
 int  fesom_gpu_call(const char *routine, int arg);
+/* ---- one step of a PARTITIONED run driven by the library, bytes moved by the host's transport ---------------------
+ * The library runs the phases of the step in the reference's order (src/oce_ale.F90:2556-2767) with a halo exchange at
+ * each of the reference's exchange points and the partitioned SSH solve (halo of the gathered vector before each SpMV,
+ * global sums of the partial dot products after it); the HOST supplies how bytes move between ranks:
+ *   exchange      : `send_dev` / `recv_dev` are the library's DEVICE buffers, already packed; a neighbour's block holds
+ *                   count(p) * values_per_item doubles, blocks consecutive in the sPE / rPE order of fesom_gpu_halo_info(kind).
+ *                   Fortran/MPI: fesom_gpu_copy to a host buffer, MPI_Isend/Irecv, copy back (or GPU-aware MPI on the device
+ *                   pointers); Python: torch.distributed (RCCL) on the device buffers.
+ *   allreduce_sum : global sum over the ranks of n doubles at the DEVICE address `buf_dev`, in place.
+ * Both return 0 on success.  The library's kernels are stream-ordered on its stream (fesom_gpu_set_stream); a transport that
+ * is not on that stream synchronises through fesom_gpu_copy / fesom_gpu_sync.  fvom_main equivalent: one call per step. */
+typedef struct fesom_transport {
+  void *ctx;
+  int (*exchange)(void *ctx, int kind, void *send_dev, void *recv_dev, int values_per_item);
+  int (*allreduce_sum)(void *ctx, void *buf_dev, int n);
+} fesom_transport;
+int  fesom_gpu_step_partitioned(int n, const fesom_transport *t);
+
 /* Device-side step monitor = write_step_info + check_blowup of the reference (src/write_step_info.F90:14-222, :225-447),
  * evaluated on the device over this rank's OWNED nodes, no per-step host synchronisation needed: call it at the logging
  * cadence.  The sums are the rank-local parts (sum over owned nodes of areasvol(ulevels,n)*x(n)); the host adds them over

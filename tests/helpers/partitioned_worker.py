@@ -113,6 +113,20 @@ def main():
     # halo consistency at the end: halo values of T equal the owners' values
     Tfin = mine[(NSTEPS, "tracers", "tr_arr")]
     report["halo_T_maxdiff"] = float(np.abs(Tfin[:, myN:] - ref[(NSTEPS, "tracers", "tr_arr")][:, ln[myN:]]).max()) if lm.eDim_nod2D else 0.0
+    # ---- the same steps driven by the library (fesom_gpu_step_partitioned + transport callbacks): bit-identical to the
+    # phase-by-phase Python loop above (same kernels, same order, same transport)
+    fin = {f: pc.core.get(f, cnt).copy() for f, cnt in (("tr_arr", 2 * (lm.nl - 1) * (myN + lm.eDim_nod2D)), ("eta_n", myN + lm.eDim_nod2D),
+                                                           ("UV", 2 * (lm.nl - 1) * (myE + lm.eDim_elem2D)))}
+    its_py = pc.solver_iterations
+    pc.close()
+    pc = parallel.PartitionedCore(PI, par, dt=900.0)
+    pc.core.upload_state(st)
+    if "kpp" in opts:
+        pc.core.set_forcing(**analytic_forcing(lm))
+    for n in range(1, NSTEPS + 1):
+        pc.step_native(n)
+    report["native_mismatch"] = [f for f, a in fin.items() if not np.array_equal(a.view(np.int64), pc.core.get(f, a.size).view(np.int64))]
+    report["native_iters"] = [int(its_py), int(pc.solver_iterations)]
     pc.close()
     sys.stdout.write("PARTREPORT " + json.dumps(report) + chr(10)); sys.stdout.flush()
     dist.destroy_process_group()

@@ -31,3 +31,6 @@ def test_partitioned_step_matches_single_partition(built, world, backend, opts):
         assert md["thickness:hnode"] < 1e-8, md
         assert rep["halo_T_maxdiff"] < 1e-8
         assert 5 < rep["iters"] < 60
+        if world > 1:        # library-driven step == Python-driven step, bit for bit (one rank: the library takes the single-GPU solver)
+            assert rep["native_mismatch"] == [], rep["native_mismatch"]
+            assert rep["native_iters"][0] == rep["native_iters"][1], rep["native_iters"]
