@@ -62,6 +62,10 @@ module fesom_gpu_shim
      type(c_ptr) :: tr_arr, tr_arr_old, UV, UV_rhsAB, eta_n, d_eta, ssh_rhs, ssh_rhs_old, hbar, hbar_old, dhe, hnode, hnode_new, &
                     helem, zbar_3d_n, Z_3d_n, Wvel, Wvel_e, Wvel_i, ssh_values
   end type
+  type, bind(C) :: fesom_transport
+     type(c_ptr) :: ctx
+     type(c_funptr) :: exchange, allreduce_sum
+  end type
   type, bind(C) :: fesom_forcing_desc
      type(c_ptr) :: stress_surf, heat_flux, water_flux, virtual_salt, relax_salt, real_salt_flux, stress_atmoce_x, stress_atmoce_y
   end type
@@ -89,6 +93,17 @@ module fesom_gpu_shim
        import
        integer(c_int), value :: n
      end function
+     integer(c_int) function c_fesom_gpu_step_partitioned(n, t) bind(C, name='fesom_gpu_step_partitioned')
+       import
+       integer(c_int), value :: n
+       type(fesom_transport), intent(in) :: t
+     end function
+     integer(c_int) function c_fesom_gpu_copy(dst, src, bytes, dir) bind(C, name='fesom_gpu_copy')
+       import
+       type(c_ptr), value :: dst, src
+       integer(c_long_long), value :: bytes
+       integer(c_int), value :: dir              ! 0: device -> host, 1: host -> device
+     end function
      integer(c_int) function c_fesom_gpu_finalize() bind(C, name='fesom_gpu_finalize')
        import
      end function
@@ -102,6 +117,9 @@ module fesom_gpu_shim
   end interface
 
   type(fesom_part_desc), target, save :: gpart
+  type(fesom_transport), save :: transport
+  real(kind=WP), allocatable, target, save :: hsend(:), hrecv(:)      ! host staging of the packed halo messages
+  real(kind=WP), target, save :: hred(8)
   logical, save :: is_setup = .false.
 
 contains
@@ -223,6 +241,9 @@ contains
     p%scaling_resolution = l2i(scaling_resolution); p%scaling_FESOM14 = l2i(scaling_FESOM14); p%Redi = l2i(Redi)
     p%visc_sh_limit = visc_sh_limit; p%diff_sh_limit = diff_sh_limit; p%Ricr = Ricr; p%concv = concv
 
+    transport%ctx = c_null_ptr
+    transport%exchange = c_funloc(mpi_exchange)
+    transport%allreduce_sum = c_funloc(mpi_allreduce_sum)
     call check(c_fesom_gpu_init(d, pp, p), 'fesom_gpu_init')
     call status_check
     call state_desc(mesh, st)
@@ -247,9 +268,73 @@ contains
        f%stress_atmoce_x = ar(stress_atmoce_x); f%stress_atmoce_y = ar(stress_atmoce_y)
     end if
     call check(c_fesom_gpu_set_forcing(f), 'fesom_gpu_set_forcing')
-    call check(c_fesom_gpu_step(int(n, c_int)), 'fesom_gpu_step')
+    if (npes > 1) then     ! the library runs the phases and the partitioned SSH solve, this layer moves the halo bytes with MPI
+       call check(c_fesom_gpu_step_partitioned(int(n, c_int), transport), 'fesom_gpu_step_partitioned')
+    else
+       call check(c_fesom_gpu_step(int(n, c_int)), 'fesom_gpu_step')
+    end if
     call status_check
   end subroutine
+
+  ! ---- transport callbacks of fesom_gpu_step_partitioned (include/fesom_gpu.h: fesom_transport).  Host-staged MPI: the packed
+  ! device buffer is copied to the host, exchanged with MPI_Isend/Irecv along the reference's own com_struct lists
+  ! (src/gen_halo_exchange.F90 does the same per field), and copied back.  With a GPU-aware MPI the two copies disappear:
+  ! pass send_dev / recv_dev (converted with c_f_pointer) to MPI directly.
+  integer(c_int) function mpi_exchange(ctx, kind, send_dev, recv_dev, values_per_item) bind(C)
+    type(c_ptr), value :: ctx, send_dev, recv_dev
+    integer(c_int), value :: kind, values_per_item
+    integer :: W, ns, nr, p, first, cnt, nreq, ierr
+    integer :: req(2*(npes+1))
+    W = values_per_item
+    mpi_exchange = 0
+    select case (kind)
+    case (0); call do_exchange(com_nod2D)
+    case (1); call do_exchange(com_elem2D)
+    case default; call do_exchange(com_elem2D_full)
+    end select
+  contains
+    subroutine do_exchange(c)
+      type(com_struct), intent(in) :: c
+      ns = (c%sptr(c%sPEnum+1) - 1) * W
+      nr = (c%rptr(c%rPEnum+1) - 1) * W
+      if (.not. allocated(hsend)) allocate(hsend(max(ns,1)), hrecv(max(nr,1)))
+      if (size(hsend) < ns) then
+         deallocate(hsend); allocate(hsend(2*ns))
+      end if
+      if (size(hrecv) < nr) then
+         deallocate(hrecv); allocate(hrecv(2*nr))
+      end if
+      if (ns > 0) then
+         if (c_fesom_gpu_copy(c_loc(hsend), send_dev, int(ns, c_long_long)*8_c_long_long, 0_c_int) /= 0) mpi_exchange = 1
+      end if
+      nreq = 0
+      do p = 1, c%rPEnum
+         first = (c%rptr(p) - 1) * W + 1; cnt = (c%rptr(p+1) - c%rptr(p)) * W
+         nreq = nreq + 1
+         call MPI_IRECV(hrecv(first), cnt, MPI_DOUBLE_PRECISION, c%rPE(p), 100 + kind, MPI_COMM_FESOM, req(nreq), ierr)
+      end do
+      do p = 1, c%sPEnum
+         first = (c%sptr(p) - 1) * W + 1; cnt = (c%sptr(p+1) - c%sptr(p)) * W
+         nreq = nreq + 1
+         call MPI_ISEND(hsend(first), cnt, MPI_DOUBLE_PRECISION, c%sPE(p), 100 + kind, MPI_COMM_FESOM, req(nreq), ierr)
+      end do
+      if (nreq > 0) call MPI_WAITALL(nreq, req, MPI_STATUSES_IGNORE, ierr)
+      if (nr > 0) then
+         if (c_fesom_gpu_copy(recv_dev, c_loc(hrecv), int(nr, c_long_long)*8_c_long_long, 1_c_int) /= 0) mpi_exchange = 1
+      end if
+    end subroutine
+  end function
+
+  integer(c_int) function mpi_allreduce_sum(ctx, buf_dev, n) bind(C)
+    type(c_ptr), value :: ctx, buf_dev
+    integer(c_int), value :: n
+    real(kind=WP) :: loc(8)
+    integer :: ierr
+    mpi_allreduce_sum = c_fesom_gpu_copy(c_loc(hred), buf_dev, int(n, c_long_long)*8_c_long_long, 0_c_int)
+    loc(1:n) = hred(1:n)
+    call MPI_ALLREDUCE(loc, hred, n, MPI_DOUBLE_PRECISION, MPI_SUM, MPI_COMM_FESOM, ierr)
+    if (c_fesom_gpu_copy(buf_dev, c_loc(hred), int(n, c_long_long)*8_c_long_long, 1_c_int) /= 0) mpi_allreduce_sum = 1
+  end function
 
   subroutine fesom_gpu_fetch_state(mesh)
     type(t_mesh), intent(in), target :: mesh

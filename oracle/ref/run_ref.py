@@ -182,9 +182,9 @@ CFGS = {
 }
 
 
-def prepare(cfg, np_):
+def prepare(cfg, np_, tag=""):
     c = CFGS[cfg]
-    rd = os.path.join(OUT, f"run_{cfg}_{np_}")
+    rd = os.path.join(OUT, f"run_{cfg}_{np_}{tag}")
     os.makedirs(os.path.join(rd, "dumps"), exist_ok=True)
     meshdir = os.path.join(MESHES, c["mesh"])
     if np_ == 1 and not os.path.isdir(os.path.join(meshdir, "dist_1")):
@@ -200,7 +200,7 @@ def prepare(cfg, np_):
 
 def run(cfg, np_, nsteps, mode="step", dump=(), mean=False, dump_mesh=True, quiet=True, exe_name="fesom_oracle.x", step_info=False):
     forcing = CFGS[cfg].get("synth_forcing", False)
-    rd = prepare(cfg, np_)
+    rd = prepare(cfg, np_, "" if exe_name == "fesom_oracle.x" else "_" + exe_name.split(".")[0])
     ds = ",".join(str(d) for d in dump) if dump else "-1"
     open(os.path.join(rd, "namelist.oracle"), "w").write(
         f"&oracle\nnsteps={nsteps}\nmode='{mode}'\ndump_dir='dumps'\ndump_steps={ds}\n"

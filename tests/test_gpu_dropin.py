@@ -19,8 +19,11 @@ pytestmark = pytest.mark.gpu
 NSTEPS = 10
 
 
-@pytest.mark.parametrize("cfg", ["pi_default", "pi_pp"])
-def test_fortran_dropin_matches_reference_cpu_step(built, cfg):
+@pytest.mark.parametrize("cfg,ranks", [("pi_default", 1), ("pi_pp", 1), ("pi_default", 2)])
+def test_fortran_dropin_matches_reference_cpu_step(built, cfg, ranks):
+    """ranks = 2: two MPI ranks of the reference's own partition (dist_2) share the box's GPU; the Fortran layer hands the
+    reference's com_struct lists to the library and moves the packed halo messages with MPI_Isend/Irecv (host-staged), the
+    library drives the phases and the partitioned SSH solve (fesom_gpu_step_partitioned)."""
     from oracle.ref import run_ref
     from oracle.ref.compare_oracle import assemble
     from refdump import read_dump
@@ -29,15 +32,15 @@ def test_fortran_dropin_matches_reference_cpu_step(built, cfg):
     env_dev = os.environ.get("FESOM_GPU_DEVICE")
     os.environ["FESOM_GPU_DEVICE"] = "0"
     try:
-        rd_g, rc_g, lines_g = run_ref.run(cfg, 1, NSTEPS, mode="gpu", dump=(NSTEPS,), exe_name="fesom_gpu_dropin.x")
+        rd_g, rc_g, lines_g = run_ref.run(cfg, ranks, NSTEPS, mode="gpu", dump=(NSTEPS,), exe_name="fesom_gpu_dropin.x")
     finally:
         if env_dev is None:
             os.environ.pop("FESOM_GPU_DEVICE", None)
     assert rc_g == 0, open(os.path.join(rd_g, "stdout.log")).read()[-3000:]
     rd_c, rc_c, lines_c = run_ref.run(cfg, 2, NSTEPS, mode="step", dump=(NSTEPS,))
     assert rc_c == 0, open(os.path.join(rd_c, "stdout.log")).read()[-3000:]
-    sg = [read_dump(os.path.join(rd_g, "dumps", "setup.r00000.bin"))]
-    dg = [read_dump(os.path.join(rd_g, "dumps", f"state{NSTEPS:04d}.r00000.bin"))]
+    sg = [read_dump(os.path.join(rd_g, "dumps", f"setup.r{r:05d}.bin")) for r in range(ranks)]
+    dg = [read_dump(os.path.join(rd_g, "dumps", f"state{NSTEPS:04d}.r{r:05d}.bin")) for r in range(ranks)]
     sc = [read_dump(os.path.join(rd_c, "dumps", f"setup.r{r:05d}.bin")) for r in range(2)]
     dc = [read_dump(os.path.join(rd_c, "dumps", f"state{NSTEPS:04d}.r{r:05d}.bin")) for r in range(2)]
     worst = {}
@@ -50,7 +53,8 @@ def test_fortran_dropin_matches_reference_cpu_step(built, cfg):
     out = os.path.join(REPO, "gpurun_out")
     if os.path.isdir(out):                                    # evidence for DESIGN.md: the measured differences and the host-side timing line
         import json
-        json.dump({"cfg": cfg, "steps": NSTEPS, "max_abs_diff": worst, "gpu_timing": [l for l in lines_g if "TIMING" in l],
-                   "cpu_timing": [l for l in lines_c if "TIMING" in l]}, open(os.path.join(out, f"dropin_{cfg}.json"), "w"), indent=1)
+        json.dump({"cfg": cfg, "gpu_ranks": ranks, "steps": NSTEPS, "max_abs_diff": worst, "gpu_timing": [l for l in lines_g if "TIMING" in l],
+                   "cpu_timing": [l for l in lines_c if "TIMING" in l]}, open(os.path.join(out, f"dropin_{cfg}_{ranks}rank.json"), "w"), indent=1)
     assert worst["eta_n"] < 1e-8 and worst["tr_arr"] < 1e-8 and worst["UV"] < 1e-8 and worst["hnode"] < 1e-8 and worst["hbar"] < 1e-8, worst
     assert worst["Wvel"] < 1e-10, worst
+    assert worst["eta_n"] > 0.0, "GPU and CPU runs are bit-identical: the two runs did not use different code paths"
