@@ -26,6 +26,10 @@ struct Ctx {
   hipStream_t side[3] = {nullptr, nullptr, nullptr};   // forked branches of the step DAG
   int cur_tr = 0;
   int part_iters = -1;
+  double *frc_dev = nullptr, *frc_pin[2] = {nullptr, nullptr};     // surface forcing: device block + pinned staging
+  hipEvent_t frc_ev[2] = {nullptr, nullptr};
+  size_t frc_count = 0;
+  int frc_cur = 0;
   double *mon_col = nullptr, *mon_out = nullptr;       // step monitor scratch (fesom_gpu_step_info)
   bool serial = false;
   std::map<std::string, Field> fields;
@@ -212,6 +216,8 @@ int fesom_gpu_finalize(void) {
   for (int i = 0; i < 2; i++) if (G.graph[i]) { hipGraphExecDestroy(G.graph[i]); G.graph[i] = nullptr; }
   for (void *p : G.allocs) hipFree(p);
   G.allocs.clear(); G.fields.clear(); G.mon_col = G.mon_out = nullptr;
+  for (int b = 0; b < 2; b++) { if (G.frc_pin[b]) { hipHostFree(G.frc_pin[b]); G.frc_pin[b] = nullptr; hipEventDestroy(G.frc_ev[b]); G.frc_ev[b] = nullptr; } }
+  G.frc_dev = nullptr;
   if (G.stream && !G.ext_stream) hipStreamDestroy(G.stream);
   G.stream = nullptr; G.ext_stream = false;
   for (int i = 0; i < 3; i++) if (G.side[i]) { hipStreamDestroy(G.side[i]); G.side[i] = nullptr; }
@@ -360,14 +366,22 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   F(Kv, nl * N); FT(tr_z, nl * N); FT(adv_flux_ver, nl * N);
   F(Unode, 2 * n1 * N); F(Unode_rhs, 2 * n1 * N); F(sigma_xy, 2 * n1 * N); F(neutral_slope, 3 * n1 * N); F(slope_tapered, 3 * n1 * N); F(U_c, 2 * n1 * N);
   F(eta_n, N); F(d_eta, N); F(ssh_rhs, N); F(ssh_rhs_old, N); F(hbar, N); F(hbar_old, N); F(MLD1, N); F(MLD2, N);
-  F(heat_flux, N); F(water_flux, N); F(virtual_salt, N); F(relax_salt, N); F(real_salt_flux, N);
   F(UV, 2 * n1 * E); F(UV_rhs, 2 * n1 * E); F(UV_rhsAB, 2 * n1 * E); FT(tr_xy, 2 * n1 * EX); FT(tr_xy_ab, 2 * n1 * EX); F(U_b, 2 * n1 * E);
-  F(pgf_x, n1 * E); F(pgf_y, n1 * E); F(helem, n1 * E); F(Av, nl * E); F(dhe, E); F(stress_surf, 2 * E);
+  F(pgf_x, n1 * E); F(pgf_y, n1 * E); F(helem, n1 * E); F(Av, nl * E); F(dhe, E);
   FT(adv_flux_hor, n1 * D); FT(adv_flux_raw, n1 * D); FT(flux_lo_hor, n1 * D); FT(diff_flux, n1 * D); FT(edge_up_dn_grad, 4 * n1 * D); F(edge_c12, D);
   F(ssh_values, m.nza);
   if (par->Fer_GM) { F(fer_K, nl * N); F(fer_gamma, 2 * nl * N); F(fer_Wvel, nl * N); F(fer_c, N); F(fer_UV, 2 * n1 * E); }
+  {   // surface forcing: ONE device block (one host->device copy per fesom_gpu_set_forcing), fields are views into it
+    G.frc_count = 2 * E + 7 * N;
+    G.frc_dev = dev_alloc<double>(G.frc_count);
+    double *q = G.frc_dev;
+    auto view = [&](const char *name, size_t cnt) { double *r = q; G.fields[name] = Field{r, cnt, 1}; q += cnt; return r; };
+    m.stress_surf = view("stress_surf", 2 * E); m.heat_flux = view("heat_flux", N); m.water_flux = view("water_flux", N);
+    m.virtual_salt = view("virtual_salt", N); m.relax_salt = view("relax_salt", N); m.real_salt_flux = view("real_salt_flux", N);
+    m.stress_atmoce_x = view("stress_atmoce_x", N); m.stress_atmoce_y = view("stress_atmoce_y", N);
+  }
   if (par->mix_scheme == 1) {
-    F(dbsfc, nl * N); F(stress_atmoce_x, N); F(stress_atmoce_y, N);
+    F(dbsfc, nl * N);
     F(kpp_viscA, nl * N); F(kpp_Kv1, nl * N); F(kpp_Kv2, nl * N); F(kpp_ghats, n1 * N); F(kpp_hbl, N); F(kpp_caseA, N); F(kpp_dkm1, 3 * N);
     m.kpp_blmc = field("kpp_blmc", nl * N, 3); m.kpp_sA = field("kpp_sA", nl * N, 3); m.kpp_sB = field("kpp_sB", nl * N, 3);
     for (int j = 0; j < 3; j++) G.fields[std::string("kpp_blmc") + char('1' + j)] = Field{m.kpp_blmc + (size_t)j * nl * N, nl * N, 1};
@@ -506,16 +520,28 @@ int fesom_gpu_download_state(const fesom_state_desc *st) { return copy_state(st,
 
 int fesom_gpu_set_forcing(const fesom_forcing_desc *f) {
   NEED_READY();
-  struct { const char *n; const double *h; } tab[] = {{"stress_surf", f->stress_surf}, {"heat_flux", f->heat_flux}, {"water_flux", f->water_flux},
-                                                      {"virtual_salt", f->virtual_salt}, {"relax_salt", f->relax_salt}, {"real_salt_flux", f->real_salt_flux},
-                                                      {"stress_atmoce_x", f->stress_atmoce_x}, {"stress_atmoce_y", f->stress_atmoce_y}};
-  for (auto &t : tab) {
-    if (!G.fields.count(t.n)) continue;                 // (nodal wind stress only exists with KPP)
-    Field &fl = G.fields[t.n];
-    const size_t cnt = !strcmp(t.n, "stress_surf") ? (size_t)2 * G.m.myE : fl.count;     // (2,myDim_elem2D), oce_setup_step.F90:249
-    if (t.h) HIPCHK(hipMemcpyAsync(fl.p, t.h, cnt * sizeof(double), hipMemcpyHostToDevice, G.stream));
-    else HIPCHK(hipMemsetAsync(fl.p, 0, fl.count * sizeof(double), G.stream));
+  // The host arrays are pageable: they are gathered into one of two pinned staging buffers and go to the device block in ONE
+  // asynchronous copy on the library's stream, so the caller is not synchronised with the previous step (the event of a
+  // staging buffer, recorded two calls ago, bounds how far the host may run ahead).
+  if (!G.frc_pin[0]) {
+    for (int b = 0; b < 2; b++) {
+      HIPCHK(hipHostMalloc((void **)&G.frc_pin[b], G.frc_count * sizeof(double), hipHostMallocDefault));
+      HIPCHK(hipEventCreateWithFlags(&G.frc_ev[b], hipEventDisableTiming));
+    }
   }
+  const int b = (G.frc_cur ^= 1);
+  HIPCHK(hipEventSynchronize(G.frc_ev[b]));
+  const size_t N = G.m.N, E2 = (size_t)2 * G.m.E, myE2 = (size_t)2 * G.m.myE;     // stress_surf is (2,myDim_elem2D) on the host (oce_setup_step.F90:249)
+  double *q = G.frc_pin[b];
+  auto put = [&](const double *h, size_t host_cnt, size_t dev_cnt) {
+    if (h) memcpy(q, h, host_cnt * sizeof(double)); else memset(q, 0, host_cnt * sizeof(double));
+    if (dev_cnt > host_cnt) memset(q + host_cnt, 0, (dev_cnt - host_cnt) * sizeof(double));
+    q += dev_cnt;
+  };
+  put(f->stress_surf, myE2, E2); put(f->heat_flux, N, N); put(f->water_flux, N, N); put(f->virtual_salt, N, N);
+  put(f->relax_salt, N, N); put(f->real_salt_flux, N, N); put(f->stress_atmoce_x, N, N); put(f->stress_atmoce_y, N, N);
+  HIPCHK(hipMemcpyAsync(G.frc_dev, G.frc_pin[b], G.frc_count * sizeof(double), hipMemcpyHostToDevice, G.stream));
+  HIPCHK(hipEventRecord(G.frc_ev[b], G.stream));
   return 0;
 }
 
@@ -707,11 +733,8 @@ int fesom_gpu_run_steps(int n_first, int nsteps) {
   HIPCHK(hipGetLastError());
   return 0;
 }
-int fesom_gpu_step(int n) {
-  int rc = fesom_gpu_run_steps(n, 1);
-  if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(G.stream));
-  return 0;
+int fesom_gpu_step(int n) {          // asynchronous: the step is enqueued on the library's stream (graph replay); download_state,
+  return fesom_gpu_run_steps(n, 1);  // get_field, step_info and fesom_gpu_sync synchronise
 }
 
 int fesom_gpu_last_solver_iterations(void) {

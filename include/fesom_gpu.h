@@ -149,7 +149,7 @@ int  fesom_gpu_init(const fesom_mesh_desc *mesh, const fesom_part_desc *part, co
 int  fesom_gpu_upload_state(const fesom_state_desc *st);
 int  fesom_gpu_download_state(const fesom_state_desc *st);
 int  fesom_gpu_set_forcing(const fesom_forcing_desc *f);
-int  fesom_gpu_step(int n);
+int  fesom_gpu_step(int n);                             /* asynchronous (stream-ordered); download_state / get_field / step_info / fesom_gpu_sync wait */
 int  fesom_gpu_run_steps(int n_first, int nsteps);      /* nsteps back-to-back, no host sync in between */
 int  fesom_gpu_finalize(void);
 
