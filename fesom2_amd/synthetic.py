@@ -31,8 +31,10 @@ def read_zbar(meshdir):
     return nl, zbar
 
 
-def analytic_ts(meshdir):
-    """Returns T, S as float64 arrays of shape (nod2D, nl-1) (level index fastest in memory)."""
+def analytic_ts(meshdir, contrast=1.0):
+    """Returns T, S as float64 arrays of shape (nod2D, nl-1) (level index fastest in memory).  `contrast` scales the horizontal
+    variations around the profile of 30 degrees latitude (1.0 = the fields of the golden runs; small values give a nearly
+    balanced, weakly forced ocean for the large synthetic meshes, whose untuned set-up is unstable under the full contrast)."""
     lon, lat = read_nod2d(meshdir)
     nl, zbar = read_zbar(meshdir)
     Z = 0.5 * (zbar[:-1] + zbar[1:])
@@ -44,6 +46,10 @@ def analytic_ts(meshdir):
     def e(H):
         q = 1.0 - Z / H
         return 1.0 / (q * q)
+    if contrast != 1.0:
+        c0 = (1.0 - 1.0 / 9.0) ** 2
+        c2 = c0 + contrast * (c2 - c0)
+        w = contrast * w
     T = 1.0 + 24.0 * e(700.0)[None, :] * c2[:, None] + 0.5 * e(500.0)[None, :] * w[:, None]
     S = 34.7 - 0.8 * e(400.0)[None, :] * (2.0 * c2[:, None] - 1.0)
     return np.ascontiguousarray(T), np.ascontiguousarray(S)
