@@ -10,7 +10,7 @@ def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equati
                 Fer_GM=False, K_GM_max=2000.0, K_GM_min=2.0, K_GM_bvref=2, K_GM_rampmax=-1.0, K_GM_rampmin=-1.0,
                 K_GM_resscalorder=1.0, scaling_Ferreira=False, scaling_resolution=True, scaling_FESOM14=False, Redi=False,
                 visc_sh_limit=5.0e-3, diff_sh_limit=5.0e-3, Ricr=0.3, concv=1.6,
-                gamma0=0.003, gamma1=0.1, gamma2=0.285, easy_bs_return=1.5, C_d=0.0025):
+                gamma0=0.003, gamma1=0.1, gamma2=0.285, easy_bs_return=1.5, C_d=0.0025, w_max_cfl=1.0):
     p = _lib.Params()
     p.dt = dt
     p.which_ale = WHICH_ALE[which_ale]
@@ -30,7 +30,7 @@ def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equati
     p.alpha, p.theta, p.epsilon = 1.0, 1.0, 0.1
     p.C_d, p.A_ver, p.K_ver, p.K_hor = C_d, A_ver, K_ver, K_hor
     p.gamma0, p.gamma1, p.gamma2, p.easy_bs_return = gamma0, gamma1, gamma2, easy_bs_return
-    p.w_max_cfl = 1.0
+    p.w_max_cfl = w_max_cfl
     p.tra_adv_ph, p.tra_adv_pv = 1.0, 1.0
     p.instabmix_kv, p.windmix_kv = 0.1, 1.0e-3
     p.cyclic_length = cyclic_length_deg * 3.14159265358979 / 180.0

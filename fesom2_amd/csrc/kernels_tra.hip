@@ -157,12 +157,16 @@ __global__ void __launch_bounds__(BLOCK) k_fct_lo_node(DM m, int tr0) {
   const int nzmin = m.ulev_n[n], nzmax = m.nlev_n[n];
   const double dt = m.p.dt, num_ord = m.p.tra_adv_pv;
   // vertical fluxes at interface nz (lane nz-1)
+  // with w_split the low-order solution takes the explicit part of w (Wvel_e), the low-order part of the anti-diffusive flux
+  // the full w (oce_adv_tra_driver.F90:111,124-131); without it the two are the same array values
   double fv = 0.0, adf = 0.0;
+  const bool split = m.p.w_split != 0;
   if (nz >= nzmin && nz <= nzmax) {
     double ar = DA2L(m.area, nz, n);
     if (nz == nzmin) {
       fv = -DA2L(m.Wvel_e, nz, n) * DTR(m.tr_arr, nz, n, tr) * ar - 0.0;
-      adf = -DTR(m.tr_arr_old, nz, n, tr) * DA2L(m.Wvel, nz, n) * ar - fv;
+      const double fvw = split ? -DA2L(m.Wvel, nz, n) * DTR(m.tr_arr, nz, n, tr) * ar - 0.0 : fv;
+      adf = -DTR(m.tr_arr_old, nz, n, tr) * DA2L(m.Wvel, nz, n) * ar - fvw;
     } else if (nz == nzmax) {
       fv = 0.0 - 0.0;
       adf = 0.0 - fv;
@@ -170,9 +174,10 @@ __global__ void __launch_bounds__(BLOCK) k_fct_lo_node(DM m, int tr0) {
       double we = DA2L(m.Wvel_e, nz, n);
       fv = -0.5 * (DTR(m.tr_arr, nz, n, tr) * (we + fabs(we)) + DTR(m.tr_arr, nz - 1, n, tr) * (we - fabs(we))) * ar - 0.0;
       double w = DA2L(m.Wvel, nz, n);
+      const double fvw = split ? -0.5 * (DTR(m.tr_arr, nz, n, tr) * (w + fabs(w)) + DTR(m.tr_arr, nz - 1, n, tr) * (w - fabs(w))) * ar - 0.0 : fv;
       double s0 = DTR(m.tr_arr_old, nz, n, tr), sm1 = DTR(m.tr_arr_old, nz - 1, n, tr);
       if (nz == nzmin + 1 || nz == nzmax - 1) {
-        adf = -0.5 * (sm1 + s0) * w * ar - fv;
+        adf = -0.5 * (sm1 + s0) * w * ar - fvw;
       } else {
         double sp1 = DTR(m.tr_arr_old, nz + 1, n, tr), sm2 = DTR(m.tr_arr_old, nz - 2, n, tr);
         double z0 = DA2(m.Z_3d_n, nz, n), zm1 = DA2(m.Z_3d_n, nz - 1, n), zp1 = DA2(m.Z_3d_n, nz + 1, n), zm2 = DA2(m.Z_3d_n, nz - 2, n);
@@ -181,7 +186,7 @@ __global__ void __launch_bounds__(BLOCK) k_fct_lo_node(DM m, int tr0) {
         double Tmean1 = s0 + (2 * qc + qu) * (zb - z0) / 3.0;
         double Tmean2 = sm1 + (2 * qc + qd) * (zb - zm1) / 3.0;
         double Tmean = (w + fabs(w)) * Tmean1 + (w - fabs(w)) * Tmean2;
-        adf = (-0.5 * (1.0 - num_ord) * Tmean - num_ord * (0.5 * (Tmean1 + Tmean2)) * w) * ar - fv;
+        adf = (-0.5 * (1.0 - num_ord) * Tmean - num_ord * (0.5 * (Tmean1 + Tmean2)) * w) * ar - fvw;
       }
     }
     DA2L(t.adv_flux_ver, nz, n) = adf;
@@ -215,6 +220,52 @@ __global__ void __launch_bounds__(BLOCK) k_fct_lo_node(DM m, int tr0) {
     lo = (ttf * DA2(m.hnode, nz, n) + (lo + (fv - fv_dn)) * dt / DA2L(m.areasvol, nz, n)) / DA2(m.hnode_new, nz, n);
     DA2(t.fct_LO, nz, n) = lo;            // the nodal bounds max/min(LO, ttf) (oce_adv_tra_fct.F90:94-101) are formed by their consumer
   }
+}
+
+// adv_tra_vert_impl (src/oce_adv_tra_ver.F90:83-227), w_split only: implicit vertical advection by Wvel_i applied to the low-order
+// solution (oce_adv_tra_driver.F90:124-126); tridiagonal problem per node column through the in-block Thomas sweep.
+__global__ void __launch_bounds__(TH_BLOCK) k_fct_lo_wimpl(DM m, int tr0) {
+  extern __shared__ double th_sh[];
+  const int tr = tr0 + blockIdx.y;
+  const TV t = tracer_view(m, tr);
+  int n = col_id_th(), l = lane_id(), nz = l + 1;
+  const bool valid = n < m.myN;
+  if (!valid) n = m.myN - 1;
+  const int nzmin = m.ulev_n[n], nzmax = m.nlev_n[n];
+  const bool wet = valid && nz >= nzmin && nz <= nzmax - 1;
+  const double dt = m.p.dt;
+  double W = (nz >= nzmin && nz <= nzmax) ? DA2L(m.Wvel_i, nz, n) : 0.0, ar = (nz >= nzmin && nz <= nzmax) ? DA2L(m.area, nz, n) : 0.0;
+  const double W_dn = shdn(W), ar_dn = shdn(ar);
+  double lo = wet ? DA2(t.fct_LO, nz, n) : 0.0;
+  const double lo_up = shup(lo), lo_dn = shdn(lo);
+  double a = 0.0, b = 1.0, c = 0.0, rhs = 0.0;
+  if (wet) {
+    const double zinv = 1.0 * dt, asv = DA2L(m.areasvol, nz, n), hn = DA2(m.hnode_new, nz, n);
+    const double v1 = zinv * ar / asv, v2 = zinv * ar_dn / asv;
+    if (nz == nzmin) {
+      a = 0.0;
+      b = hn + W * v1;
+      b = b - dmin_(0., W_dn) * v2;
+      c = -dmax_(0., W_dn) * v2;
+    } else {
+      a = dmin_(0., W) * v1;
+      b = hn + dmax_(0., W) * v1;
+      b = b - dmin_(0., W_dn) * v2;
+      c = -dmax_(0., W_dn) * v2;
+    }
+    if (nz == nzmax - 1) {
+      a = dmin_(0., W) * v1;
+      b = hn + dmax_(0., W) * v1;
+      c = 0.0;
+    }
+    const double dz = hn;
+    if (nz == nzmax - 1) rhs = -a * lo_up - (b - dz) * lo;
+    else if (nz == nzmin) rhs = -(b - dz) * lo - c * lo_dn;
+    else rhs = -a * lo_up - (b - dz) * lo - c * lo_dn;
+  }
+  double x, unused;
+  thomas_inblock<1>(th_sh, m.nlm1, valid, nzmin, nzmax - 1, a, b, c, rhs, 0.0, x, unused);
+  if (wet) DA2(t.fct_LO, nz, n) = lo + x;
 }
 
 // nodal bounds max/min(LO, ttf) (src/oce_adv_tra_fct.F90:94-101), element bounds (:108-121, max/min over the 3 nodes;
@@ -568,6 +619,7 @@ __global__ void __launch_bounds__(TH_BLOCK) k_tr_update(DM m, int tr0) {
 #define LAUNCH_COL(k, ncol, m_, tr_) hipLaunchKernelGGL(k, dim3(nblocks(ncol), (tr_) < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m_, (tr_) < 0 ? 0 : (tr_))
 #define LAUNCH_TRU(m_, tr_) do { if (m.p.Redi) hipLaunchKernelGGL(k_tr_update<true>, dim3(nblocks_th(m.N), (tr_) < 0 ? m.ntr : 1), dim3(TH_BLOCK), thomas_lds_bytes(m.nlm1, 1), s, m_, (tr_) < 0 ? 0 : (tr_)); \
   else hipLaunchKernelGGL(k_tr_update<false>, dim3(nblocks_th(m.N), (tr_) < 0 ? m.ntr : 1), dim3(TH_BLOCK), thomas_lds_bytes(m.nlm1, 1), s, m_, (tr_) < 0 ? 0 : (tr_)); } while (0)
+#define LAUNCH_WIMPL(m_, tr_) do { if (m.p.w_split) hipLaunchKernelGGL(k_fct_lo_wimpl, dim3(nblocks_th(m.myN), (tr_) < 0 ? m.ntr : 1), dim3(TH_BLOCK), thomas_lds_bytes(m.nlm1, 1), s, m_, (tr_) < 0 ? 0 : (tr_)); } while (0)
 #define LAUNCH_DFX(m_, tr_) do { if (m.p.Redi) LAUNCH_COL(k_diff_flux<true>, m.myD, m_, tr_); else LAUNCH_COL(k_diff_flux<false>, m.myD, m_, tr_); } while (0)
 
 void launch_tracer(const DM &m, hipStream_t s, int tr) {   // tr 0-based
@@ -576,7 +628,7 @@ void launch_tracer(const DM &m, hipStream_t s, int tr) {   // tr 0-based
   LAUNCH_COL(k_tr_grad_elem, m.myE, m, tr);
   LAUNCH_COL(k_updn_grad, m.myD, m, tr);
   LAUNCH_COL(k_flux_hor, m.myD, m, tr);
-  LAUNCH_COL(k_fct_lo_node, m.myN, m, tr);
+  LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); LAUNCH_WIMPL(m, tr);
   LAUNCH_COL(k_fct_node, m.myN, m, tr);
   LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr);
   if (m.p.with_diffusion) LAUNCH_DFX(m, tr);
@@ -591,7 +643,7 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
     if (!strcmp(name, "k_tr_grad_elem")) { LAUNCH_COL(k_tr_grad_elem, m.myE, m, tr); return 0; }
     if (!strcmp(name, "k_updn_grad")) { LAUNCH_COL(k_updn_grad, m.myD, m, tr); return 0; }
     if (!strcmp(name, "k_flux_hor")) { LAUNCH_COL(k_flux_hor, m.myD, m, tr); return 0; }
-    if (!strcmp(name, "k_fct_lo_node")) { LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); return 0; }
+    if (!strcmp(name, "k_fct_lo_node")) { LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); LAUNCH_WIMPL(m, tr); return 0; }   // (+ implicit part with w_split)
     if (!strcmp(name, "k_fct_node")) { LAUNCH_COL(k_fct_node, m.myN, m, tr); return 0; }
     if (!strcmp(name, "k_fct_edge_limit")) { LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr); return 0; }
     if (!strcmp(name, "k_diff_flux")) { LAUNCH_DFX(m, tr); return 0; }
@@ -603,7 +655,7 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
     LAUNCH_COL(k_updn_grad, m.myD, m, tr); return 0;
   }
   if (!strcmp(name, "adv_tracers_ale")) {
-    LAUNCH_COL(k_flux_hor, m.myD, m, tr); LAUNCH_COL(k_fct_lo_node, m.myN, m, tr);
+    LAUNCH_COL(k_flux_hor, m.myD, m, tr); LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); LAUNCH_WIMPL(m, tr);
     LAUNCH_COL(k_fct_node, m.myN, m, tr); LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr); return 0;
   }
   if (!strcmp(name, "diff_tracers_ale")) {                                                    // incl. flux2dtracer + clamp

@@ -264,6 +264,61 @@ static void oce_tra_adv_fct(const double *ttf) {
   }
 }
 
+/* adv_tra_vert_impl: src/oce_adv_tra_ver.F90:83-227 -- implicit part of the vertical advection (w_split), applied to the
+ * low-order solution (oce_adv_tra_driver.F90:124-127) */
+static void adv_tra_vert_impl(double *ttf, const double *W) {
+  int nl = NL;
+  double *a = malloc(sizeof(double) * (nl + 2) * 6), *b = a + nl + 2, *c = b + nl + 2, *tr = c + nl + 2, *cp = tr + nl + 2, *tp = cp + nl + 2;
+  const double dt = C_.p.dt;
+  for (int n = 1; n <= C_.m.myDim_nod2D; n++) {
+    int nzmax = NLEVN(n), nzmin = ULEVN(n), nz;
+    for (int k = 0; k < (nl + 2) * 6; k++) a[k] = 0.0;
+    double zinv = 1.0 * dt, v_adv;
+    nz = nzmin;
+    a[nz] = 0.0;
+    v_adv = zinv * AREA(nz, n) / AREASVOL(nz, n);
+    b[nz] = A2(C_.hnode_new, nz, n) + A2L(W, nz, n) * v_adv;
+    v_adv = zinv * AREA(nz + 1, n) / AREASVOL(nz, n);
+    b[nz] = b[nz] - dmin(0., A2L(W, nz + 1, n)) * v_adv;
+    c[nz] = -dmax(0., A2L(W, nz + 1, n)) * v_adv;
+    for (nz = nzmin + 1; nz <= nzmax - 2; nz++) {
+      v_adv = zinv * AREA(nz, n) / AREASVOL(nz, n);
+      a[nz] = dmin(0., A2L(W, nz, n)) * v_adv;
+      b[nz] = A2(C_.hnode_new, nz, n) + dmax(0., A2L(W, nz, n)) * v_adv;
+      v_adv = zinv * AREA(nz + 1, n) / AREASVOL(nz, n);
+      b[nz] = b[nz] - dmin(0., A2L(W, nz + 1, n)) * v_adv;
+      c[nz] = -dmax(0., A2L(W, nz + 1, n)) * v_adv;
+    }
+    nz = nzmax - 1;
+    v_adv = zinv * AREA(nz, n) / AREASVOL(nz, n);
+    a[nz] = dmin(0., A2L(W, nz, n)) * v_adv;
+    b[nz] = A2(C_.hnode_new, nz, n) + dmax(0., A2L(W, nz, n)) * v_adv;
+    c[nz] = 0.0;
+    nz = nzmin;
+    double dz = A2(C_.hnode_new, nz, n);
+    tr[nz] = -(b[nz] - dz) * A2(ttf, nz, n) - c[nz] * A2(ttf, nz + 1, n);
+    for (nz = nzmin + 1; nz <= nzmax - 2; nz++) {
+      dz = A2(C_.hnode_new, nz, n);
+      tr[nz] = -a[nz] * A2(ttf, nz - 1, n) - (b[nz] - dz) * A2(ttf, nz, n) - c[nz] * A2(ttf, nz + 1, n);
+    }
+    nz = nzmax - 1;
+    dz = A2(C_.hnode_new, nz, n);
+    tr[nz] = -a[nz] * A2(ttf, nz - 1, n) - (b[nz] - dz) * A2(ttf, nz, n);
+    nz = nzmin;
+    cp[nz] = c[nz] / b[nz];
+    tp[nz] = tr[nz] / b[nz];
+    for (nz = nzmin + 1; nz <= nzmax - 1; nz++) {
+      double m = b[nz] - cp[nz - 1] * a[nz];
+      cp[nz] = c[nz] / m;
+      tp[nz] = (tr[nz] - tp[nz - 1] * a[nz]) / m;
+    }
+    tr[nzmax - 1] = tp[nzmax - 1];
+    for (nz = nzmax - 2; nz >= nzmin; nz--) tr[nz] = tp[nz] - cp[nz] * tr[nz + 1];
+    for (nz = nzmin; nz <= nzmax - 1; nz++) A2(ttf, nz, n) = A2(ttf, nz, n) + tr[nz];
+  }
+  free(a);
+}
+
 /* do_oce_adv_tra (FCT + MFCT + QR4C): src/oce_adv_tra_driver.F90:41-197 ;
  * oce_tra_adv_flux2dtracer: :201-269 ; adv_tracers_ale: src/oce_ale_tracer.F90:203-249 */
 void orc_adv_tracers_ale(int tr) {
@@ -289,6 +344,10 @@ void orc_adv_tracers_ale(int tr) {
       A2(LO, nz, n) = (A2(ttf, nz, n) * A2(C_.hnode, nz, n) +
                        (A2(LO, nz, n) + (A2L(C_.adv_flux_ver, nz, n) - A2L(C_.adv_flux_ver, nz + 1, n))) * dt / AREASVOL(nz, n)) /
                       A2(C_.hnode_new, nz, n);
+  if (C_.p.w_split) {                      /* oce_adv_tra_driver.F90:124-132 */
+    adv_tra_vert_impl(LO, C_.Wvel_i);
+    adv_tra_ver_upw1(ttf, C_.Wvel);        /* low-order part of the anti-diffusive vertical fluxes: on the full w */
+  }
   adv_tra_hor(ttfAB, 1, C_.p.tra_adv_ph);
   adv_tra_ver_qr4c(ttfAB, C_.Wvel, C_.p.tra_adv_pv);
   oce_tra_adv_fct(ttf);

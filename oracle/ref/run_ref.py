@@ -82,8 +82,8 @@ scale_area=5.8e9
 mom_adv=2
 free_slip=.false.
 i_vert_visc=.true.
-w_split=.false.
-w_max_cfl=1.0
+w_split={w_split}
+w_max_cfl={w_max_cfl}
 SPP=.false.
 Fer_GM={fer_gm}
 K_GM_max=2000.0
@@ -165,6 +165,12 @@ CFGS = {
                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                        fer_gm=".true.", redi=".true.", mix_scheme="KPP", k_hor="3000.", surf_relax_s="1.929e-06",
                        balance_salt_water=".true.", synth_forcing=True),
+    # PP + w_split: vertical velocity split into an explicit and an implicit part where CFL_z > w_max_cfl (threshold lowered so that
+    # the split is active on pi from the first steps)
+    "pi_pp_wsplit": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                         rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                         fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                         balance_salt_water=".true.", synth_forcing=True, w_split=".true.", w_max_cfl="0.0003"),
     # KPP alone (no GM/Redi) with the same forcing
     "pi_kpp": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
                    rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
@@ -191,7 +197,7 @@ def prepare(cfg, np_, tag=""):
         from oracle.ref.make_dist1 import make_dist1
         make_dist1(meshdir)
     open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **c))
-    open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**c))
+    open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0"), **c)))
     if c["toy_ocean"] == ".false.":
         from fesom2_amd.synthetic import write_ic_files
         write_ic_files(meshdir, rd)

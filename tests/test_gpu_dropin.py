@@ -50,6 +50,17 @@ def test_fortran_dropin_matches_reference_cpu_step(built, cfg, ranks):
         assert np.isfinite(a).all(), f
         worst[f] = float(np.abs(a - b).max())
         assert np.abs(b).max() > 0
+    # tracer content: sum over owned cells of T * hnode * areasvol (heat / salt content up to constants), GPU run vs reference CPU run:
+    # the north-star bar is conservation within 1e-12 (relative) of the reference
+    cons = {}
+    vol_g = assemble(dg, sg, "hnode") * assemble(sg, sg, "areasvol")[:, :-1]
+    vol_c = assemble(dc, sc, "hnode") * assemble(sc, sc, "areasvol")[:, :-1]
+    tg, tc = assemble(dg, sg, "tr_arr"), assemble(dc, sc, "tr_arr")
+    for k, name in ((0, "heat"), (1, "salt")):
+        cg_, cc_ = float((tg[k] * vol_g).sum()), float((tc[k] * vol_c).sum())
+        cons[name] = abs(cg_ - cc_) / abs(cc_)
+        assert cons[name] < 1e-12, cons
+    worst["tracer_content_rel"] = cons
     out = os.path.join(REPO, "gpurun_out")
     if os.path.isdir(out):                                    # evidence for DESIGN.md: the measured differences and the host-side timing line
         import json

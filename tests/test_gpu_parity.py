@@ -283,3 +283,44 @@ def test_step_info_device_monitor(built):
     gpu.set("eta_n", e)
     assert gpu.step_info()["blowup"] == 1.0
     gpu.close()
+
+
+def test_w_split_chain_and_steps_bitwise(built):
+    """w_split=.true. with a threshold that makes the split active on pi (w_max_cfl = 0.0003): explicit/implicit vertical velocity,
+    implicit vertical advection in the momentum solve and in the low-order FCT solution (adv_tra_vert_impl); HIP == oracle bitwise
+    over the routine chain (3 steps) and 10 graph-replayed steps, under surface forcing."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.core import OceanCore
+    from fesom2_amd.synthetic import analytic_ts, analytic_forcing
+    from oracle_lib import Oracle
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, w_split=True, w_max_cfl=0.0003)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    gpu, orc = OceanCore(mesh, par), Oracle(mesh, par)
+    gpu.upload_state(st); orc.set_state(st)
+    forcing = analytic_forcing(mesh)
+    gpu.set_forcing(**forcing)
+    for k, v in forcing.items():
+        orc.set(k, v)
+    failures = []
+    for step in range(1, 4):
+        for routine, arg, fields in full_chain(2):
+            gpu.call(routine, arg); orc.call(routine, arg)
+            for f in fields:
+                ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+                if not ok:
+                    failures.append(f"step {step} {routine}({arg}) {msg}")
+        if failures:
+            break
+    assert not failures, "\n".join(failures[:10])
+    assert np.count_nonzero(orc.get("Wvel_i")) > 1000
+    gpu.run_steps(4, 10)
+    for n in range(10):
+        orc.call("step", 4 + n)
+    for f in ("tr_arr", "UV", "eta_n", "hnode", "Wvel_i"):
+        ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+        assert ok, msg
+    gpu.close()

@@ -173,3 +173,28 @@ def test_oracle_step_info_vs_reference_printout(built):
 
     chain_bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3), after_step=after)
     assert not chain_bad and not bad, "\n".join((chain_bad + bad)[:20])
+
+
+def test_oracle_chain_bitwise_w_split(built):
+    """w_split=.true. (namelist.oce): vertical velocity split by CFL_z > w_max_cfl in vert_vel_ale (src/oce_ale.F90:2189-2203), implicit
+    part in impl_vert_visc_ale and -- adv_tra_vert_impl, src/oce_adv_tra_ver.F90:83-227 -- in the low-order solution of the FCT
+    advection; reference run with w_max_cfl = 0.0003 so that the split is active on pi, with surface forcing."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.synthetic import analytic_ts
+    from oracle_lib import Oracle
+    from ref_chain import run_reference_chain
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, w_split=True, w_max_cfl=0.0003)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    orc = Oracle(mesh, par)
+    orc.set_state(st)
+    g = gold("pi_pp_wsplit")
+    for f in FORCING:
+        orc.set(f, g["forcing/" + f])
+    bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
+    assert not bad, "\n".join(bad[:20])
+    wi = orc.get("Wvel_i")
+    assert np.count_nonzero(wi) > 1000                     # the split is really active
