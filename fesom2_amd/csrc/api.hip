@@ -554,9 +554,7 @@ struct PStep {
   void c(const char *name, int arg = 0) { if (!rc && call_named(name, arg)) { rc = 1; if (G.err.empty()) G.err = std::string("step_partitioned: unknown phase ") + name; } }
   void X(int kind, std::initializer_list<const char *> names) {
     if (rc) return;
-    const Ctx::Halo &h = G.halo[kind];
-    if (h.rPE.empty() && h.sPE.empty()) return;
-    std::vector<const char *> nm(names);
+    std::vector<const char *> nm(names);        // (no early-out for a rank without neighbours: the transport may be a collective)
     void *sd = nullptr, *rd = nullptr; int W = 0;
     if (fesom_gpu_halo_pack(kind, (int)nm.size(), nm.data(), &sd, &rd, &W)) { rc = 1; return; }
     if (t->exchange(t->ctx, kind, sd, rd, W)) { rc = 1; G.err = "step_partitioned: transport exchange failed"; return; }

@@ -228,24 +228,45 @@ __global__ void __launch_bounds__(BLOCK) k_kpp_col(DM m) {
 // value 0 they have in blmc.  The patch areas are summed again in every sweep, in the same order (same value as `vol`).
 __global__ void __launch_bounds__(BLOCK) k_kpp_smooth(DM m, const double *src, double *dst) {
   const int n = col_id(), l = lane_id(), nz = l + 1;
-  if (n >= m.myN || nz > m.nl) return;
+  if (n >= m.myN) return;
   const size_t off = (size_t)blockIdx.y * m.nl * m.N;
   const double *a = src + off;
   const int uln = m.ulev_n[n], nln = m.nlev_n[n] < m.nl ? m.nlev_n[n] : m.nl;
-  double work = 0.0, vol = 0.0;
   const int num = m.nie_num[n];
-  for (int k = 0; k < num; k++) {
-    const int el = m.nie[(size_t)m.maxk * n + k];
-    const int ule = uln > m.ulev[el] ? uln : m.ulev[el];
-    int nle = m.nlev[el] < m.nl ? m.nlev[el] : m.nl;
-    nle = nln < nle ? nln : nle;
-    if (nz >= ule && nz <= nle) {
-      const double ar = m.elem_area[el];
-      const int n1 = m.elem_nodes[3 * el], n2 = m.elem_nodes[3 * el + 1], n3 = m.elem_nodes[3 * el + 2];
-      vol = vol + ar;
-      work = work + ar * (DA2L(a, nz, n1) + DA2L(a, nz, n2) + DA2L(a, nz, n3));
+  // element cluster of the node, lane-parallel (lane k = k-th element): ids, level range, area, the 3 nodes; then ONE batch of
+  // loads for all elements and the sums in the reference's element order (pi is latency-bound: no dependent load chains)
+  int el_l = 0, n1_l = 0, n2_l = 0, n3_l = 0, lo_l = 1, hi_l = 0;
+  double ar_l = 0.0;
+  if (l < num) {
+    el_l = m.nie[(size_t)m.maxk * n + l];
+    n1_l = m.elem_nodes[3 * el_l]; n2_l = m.elem_nodes[3 * el_l + 1]; n3_l = m.elem_nodes[3 * el_l + 2];
+    lo_l = uln > m.ulev[el_l] ? uln : m.ulev[el_l];
+    int nle = m.nlev[el_l] < m.nl ? m.nlev[el_l] : m.nl;
+    hi_l = nln < nle ? nln : nle;
+    ar_l = m.elem_area[el_l];
+  }
+  const int nzc = nz <= m.nl ? nz : m.nl;
+  constexpr int KB = 8;                                   // elements per batch (pi: at most 8 around a node; more: second batch)
+  double work = 0.0, vol = 0.0;
+  for (int k0 = 0; k0 < num; k0 += KB) {
+    double v1[KB], v2[KB], v3[KB];
+#pragma unroll
+    for (int k = 0; k < KB; k++) {
+      const int kk = (k0 + k < num) ? k0 + k : 0;
+      v1[k] = DA2L(a, nzc, rdlane(n1_l, kk)); v2[k] = DA2L(a, nzc, rdlane(n2_l, kk)); v3[k] = DA2L(a, nzc, rdlane(n3_l, kk));
+    }
+#pragma unroll
+    for (int k = 0; k < KB; k++) {
+      const int kk = k0 + k;
+      if (kk < num) {
+        const double ar = bcast(ar_l, kk);
+        const bool on = nz >= rdlane(lo_l, kk) && nz <= rdlane(hi_l, kk);
+        const double nv = vol + ar, nw = work + ar * (v1[k] + v2[k] + v3[k]);
+        vol = on ? nv : vol; work = on ? nw : work;
+      }
     }
   }
+  if (nz > m.nl) return;
   double out = 0.0;
   if (nz >= uln && nz <= nln) { vol = 1. / (3. * vol); out = work * vol; }
   dst[off + (size_t)n * m.nl + l] = out;

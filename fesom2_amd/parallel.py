@@ -109,6 +109,7 @@ class HaloExchanger:
         lib.fesom_gpu_set_stream.argtypes = [C.c_void_p]
         self.device = dist.get_backend() == "nccl"
         self._tens = {}
+        self._splits = {}
         if self.device:                       # library kernels and RCCL on the same stream: no host synchronisation anywhere
             self._chk(lib.fesom_gpu_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)), "set_stream")
         self.info = []
@@ -131,8 +132,7 @@ class HaloExchanger:
         return self._tens[key]
 
     def exchange(self, kind, names):
-        inf = self.info[kind]
-        if not inf["rPE"] and not inf["sPE"]:
+        if self.npes < 2:
             return
         arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
         sp, rp, W = C.c_void_p(), C.c_void_p(), C.c_int()
@@ -142,27 +142,31 @@ class HaloExchanger:
 
     def move(self, kind, sp, rp, W):
         """the transport proper: the packed send buffer of the library to the neighbours, their blocks into its receive buffer
-        (sp, rp: device addresses as c_void_p; W values per item)"""
+        (sp, rp: device addresses as c_void_p; W values per item).  ONE collective per exchange: the packed buffers hold the
+        neighbours' blocks in ascending rank order (the order of the reference's com lists), which is the layout of
+        all_to_all_single with per-rank split sizes (zero for non-neighbours) -- RCCL turns it into grouped send/recv."""
         inf = self.info[kind]
         ns, nr = sum(inf["scnt"]) * W, sum(inf["rcnt"]) * W
+        key = (kind, W)
+        if key not in self._splits:
+            assert inf["sPE"] == sorted(inf["sPE"]) and inf["rPE"] == sorted(inf["rPE"])
+            ss, rs = [0] * self.npes, [0] * self.npes
+            for pe, cnt in zip(inf["sPE"], inf["scnt"]):
+                ss[pe] = cnt * W
+            for pe, cnt in zip(inf["rPE"], inf["rcnt"]):
+                rs[pe] = cnt * W
+            self._splits[key] = (ss, rs)
+        ss, rs = self._splits[key]
         if self.device:                       # RCCL directly on the device buffers
             send, recv = self.dev_tensor(sp.value, max(ns, 1)), self.dev_tensor(rp.value, max(nr, 1))
+            dist.all_to_all_single(recv[:nr], send[:ns], rs, ss, group=self.group)
         else:                                 # host staging (gloo)
             send_h, recv_h = np.empty(max(ns, 1)), np.empty(max(nr, 1))
             if ns:
                 self._chk(self.lib.fesom_gpu_copy(send_h.ctypes.data, sp, ns * 8, 0), "copy d2h")
-            send, recv = torch.from_numpy(send_h), torch.from_numpy(recv_h)
-        ops, off = [], 0
-        for pe, cnt in zip(inf["rPE"], inf["rcnt"]):
-            ops.append(dist.P2POp(dist.irecv, recv[off: off + cnt * W], pe, self.group)); off += cnt * W
-        off = 0
-        for pe, cnt in zip(inf["sPE"], inf["scnt"]):
-            ops.append(dist.P2POp(dist.isend, send[off: off + cnt * W], pe, self.group)); off += cnt * W
-        if ops:
-            for r in dist.batch_isend_irecv(ops):
-                r.wait()
-        if not self.device and nr:
-            self._chk(self.lib.fesom_gpu_copy(rp, recv_h.ctypes.data, nr * 8, 1), "copy h2d")
+            dist.all_to_all_single(torch.from_numpy(recv_h)[:nr], torch.from_numpy(send_h)[:ns], rs, ss, group=self.group)
+            if nr:
+                self._chk(self.lib.fesom_gpu_copy(rp, recv_h.ctypes.data, nr * 8, 1), "copy h2d")
 
 
 class PartitionedCore:
