@@ -57,7 +57,8 @@ class Params(C.Structure):
                    ("K_GM_min", C.c_double), ("K_GM_bvref", C.c_int), ("K_GM_rampmax", C.c_double), ("K_GM_rampmin", C.c_double),
                    ("K_GM_resscalorder", C.c_double), ("scaling_Ferreira", C.c_int), ("scaling_Rossby", C.c_int),
                    ("scaling_resolution", C.c_int), ("scaling_FESOM14", C.c_int), ("Redi", C.c_int),
-                   ("visc_sh_limit", C.c_double), ("diff_sh_limit", C.c_double), ("Ricr", C.c_double), ("concv", C.c_double)])
+                   ("visc_sh_limit", C.c_double), ("diff_sh_limit", C.c_double), ("Ricr", C.c_double), ("concv", C.c_double),
+                   ("use_sw_pene", C.c_int)])
 
 
 STATE_FIELDS = ("tr_arr", "tr_arr_old", "UV", "UV_rhsAB", "eta_n", "d_eta", "ssh_rhs", "ssh_rhs_old", "hbar",
@@ -71,7 +72,7 @@ class StateDesc(C.Structure):
 
 class ForcingDesc(C.Structure):
     _fields_ = [(n, PD) for n in ("stress_surf", "heat_flux", "water_flux", "virtual_salt", "relax_salt",
-                                  "real_salt_flux", "stress_atmoce_x", "stress_atmoce_y")]
+                                  "real_salt_flux", "stress_atmoce_x", "stress_atmoce_y", "sw_3d")]
 
 
 STEP_INFO_FIELDS = ("sum_eta", "sum_hbar", "sum_deta", "sum_dhbar", "sum_wflux", "sum_area",

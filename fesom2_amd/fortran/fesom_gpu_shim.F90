@@ -19,7 +19,7 @@ module fesom_gpu_shim
   use o_ARRAYS
   use g_PARSUP
   use g_config
-  use g_forcing_arrays, only: real_salt_flux
+  use g_forcing_arrays, only: real_salt_flux, sw_3d
   implicit none
   private
   public :: fesom_gpu_setup, oce_timestep_ale_gpu, fesom_gpu_fetch_state, fesom_gpu_push_state, fesom_gpu_shutdown
@@ -57,6 +57,7 @@ module fesom_gpu_shim
      real(c_double) :: K_GM_rampmax, K_GM_rampmin, K_GM_resscalorder
      integer(c_int) :: scaling_Ferreira, scaling_Rossby, scaling_resolution, scaling_FESOM14, Redi
      real(c_double) :: visc_sh_limit, diff_sh_limit, Ricr, concv
+     integer(c_int) :: use_sw_pene
   end type
   type, bind(C) :: fesom_state_desc
      type(c_ptr) :: tr_arr, tr_arr_old, UV, UV_rhsAB, eta_n, d_eta, ssh_rhs, ssh_rhs_old, hbar, hbar_old, dhe, hnode, hnode_new, &
@@ -67,7 +68,7 @@ module fesom_gpu_shim
      type(c_funptr) :: exchange, allreduce_sum
   end type
   type, bind(C) :: fesom_forcing_desc
-     type(c_ptr) :: stress_surf, heat_flux, water_flux, virtual_salt, relax_salt, real_salt_flux, stress_atmoce_x, stress_atmoce_y
+     type(c_ptr) :: stress_surf, heat_flux, water_flux, virtual_salt, relax_salt, real_salt_flux, stress_atmoce_x, stress_atmoce_y, sw_3d
   end type
 
   interface
@@ -240,6 +241,7 @@ contains
     p%scaling_Ferreira = l2i(scaling_Ferreira); p%scaling_Rossby = l2i(scaling_Rossby)
     p%scaling_resolution = l2i(scaling_resolution); p%scaling_FESOM14 = l2i(scaling_FESOM14); p%Redi = l2i(Redi)
     p%visc_sh_limit = visc_sh_limit; p%diff_sh_limit = diff_sh_limit; p%Ricr = Ricr; p%concv = concv
+    p%use_sw_pene = l2i(use_sw_pene)
 
     transport%ctx = c_null_ptr
     transport%exchange = c_funloc(mpi_exchange)
@@ -267,6 +269,8 @@ contains
     if (allocated(stress_atmoce_x)) then
        f%stress_atmoce_x = ar(stress_atmoce_x); f%stress_atmoce_y = ar(stress_atmoce_y)
     end if
+    f%sw_3d = c_null_ptr
+    if (use_sw_pene .and. allocated(sw_3d)) f%sw_3d = ar(sw_3d)
     call check(c_fesom_gpu_set_forcing(f), 'fesom_gpu_set_forcing')
     if (npes > 1) then     ! the library runs the phases and the partitioned SSH solve, this layer moves the halo bytes with MPI
        call check(c_fesom_gpu_step_partitioned(int(n, c_int), transport), 'fesom_gpu_step_partitioned')

@@ -72,3 +72,12 @@ def analytic_forcing(mesh):
     en = mesh.elem2D_nodes[:mesh.myDim_elem2D] - 1
     f["stress_surf"] = np.stack([f["stress_atmoce_x"][en].sum(1) / 3.0, f["stress_atmoce_y"][en].sum(1) / 3.0], axis=1)
     return {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in f.items()}
+
+
+def analytic_sw_3d(mesh, heat_flux):
+    """Penetrating short-wave flux / vcpw [K m/s] (nl, N) for use_sw_pene: half of the positive part of `heat_flux`, decaying
+    over ~15 m; +,-,*,/ only, the same operations as the reference harness (bit-identical values)."""
+    q = 1.0 - mesh.zbar / 15.0
+    sw = (np.maximum(heat_flux, 0.0) / 4.2e6 * 0.5)[:, None] / (q * q)[None, :]
+    lev = np.arange(1, mesh.nl + 1)[None, :]
+    return np.ascontiguousarray(np.where(lev <= mesh.nlevels_nod2D[:, None], sw, 0.0))

@@ -116,6 +116,8 @@ typedef struct fesom_params {
   /* KPP (mix_scheme=1; namelist.oce: visc_sh_limit, diff_sh_limit, Ricr, concv; Kv0_const=.true., double_diffusion=.false.,
      use_sw_pene=.false., use_kpp_nonlclflx=.false. are the only supported settings of those switches) */
   double visc_sh_limit, diff_sh_limit, Ricr, concv;
+  int    use_sw_pene;        /* short-wave penetration (namelist.config run_config): sw_3d of the forcing enters the temperature
+                                equation (oce_ale_tracer.F90:785-791) and the KPP surface buoyancy forcing (oce_ale_mixing_kpp.F90:508-640) */
 } fesom_params;
 
 /* ---- prognostic state = restart set (io_restart.F90:99-155) + ALE thickness arrays -- */
@@ -139,6 +141,7 @@ typedef struct fesom_forcing_desc {
   const double *stress_surf;     /* (2,myE) */
   const double *heat_flux, *water_flux, *virtual_salt, *relax_salt, *real_salt_flux; /* (N) */
   const double *stress_atmoce_x, *stress_atmoce_y;   /* (N) wind stress at nodes (KPP friction velocity, oce_ale_mixing_kpp.F90:341) */
+  const double *sw_3d;           /* (nl,N) penetrating short-wave flux / vcpw [K m/s], positive down (gen_modules_forcing.F90:76); use_sw_pene only */
 } fesom_forcing_desc;
 
 /* Lifecycle.  fesom_gpu_init uploads the mesh and allocates every device mirror;

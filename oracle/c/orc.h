@@ -44,6 +44,8 @@ typedef struct {
   int *MLD1_ind;                             /* (N) */
   /* KPP (orc_kpp.c) */
   double *stress_atmoce_x, *stress_atmoce_y;                                  /* (N) wind stress at nodes */
+  double *kpp_sw_node;                                                        /* (N) see orc_kpp.c, second pass of bldepth */
+  double *sw_3d;                                                              /* (nl,N) penetrating short-wave flux / vcpw */
   double *kpp_Kv1, *kpp_Kv2, *kpp_viscA, *kpp_dVsq, *kpp_blmc[3];            /* (nl,N) */
   double *kpp_ghats;                                                          /* (nl-1,N) */
   double *kpp_hbl, *kpp_bfsfc, *kpp_caseA, *kpp_stable, *kpp_ustar, *kpp_Bo, *kpp_dkm1;   /* (N), dkm1 (3,N) */

@@ -42,7 +42,7 @@ int orc_init(const fesom_mesh_desc *m, const fesom_params *p) {
   R(pgf_x, n1 * E); R(pgf_y, n1 * E); R(helem, n1 * E); R(Av, nl * E); R(dhe, E); R(stress_surf, 2 * E);
   R(adv_flux_hor, n1 * D); R(edge_up_dn_grad, 4 * n1 * D);
   R(fer_K, nl * N); R(fer_gamma, 2 * nl * N); R(fer_Wvel, nl * N); R(fer_c, N); R(fer_scal, N); R(gm_scal_static, N); R(fer_UV, 2 * n1 * E);
-  R(stress_atmoce_x, N); R(stress_atmoce_y, N);
+  R(stress_atmoce_x, N); R(stress_atmoce_y, N); R(sw_3d, nl * N); R(kpp_sw_node, N);
   R(kpp_Kv1, nl * N); R(kpp_Kv2, nl * N); R(kpp_viscA, nl * N); R(kpp_dVsq, nl * N); R(kpp_ghats, n1 * N);
   reg("kpp_blmc1", &C_.kpp_blmc[0], nl * N); reg("kpp_blmc2", &C_.kpp_blmc[1], nl * N); reg("kpp_blmc3", &C_.kpp_blmc[2], nl * N);
   R(kpp_hbl, N); R(kpp_bfsfc, N); R(kpp_caseA, N); R(kpp_stable, N); R(kpp_ustar, N); R(kpp_Bo, N); R(kpp_dkm1, 3 * N);
@@ -58,6 +58,7 @@ int orc_init(const fesom_mesh_desc *m, const fesom_params *p) {
     double r = m->mesh_resolution[n] / 100000.0;
     for (size_t k = 0; k < n1; k++) C_.Ki[n * n1 + k] = p->K_hor * (r * r);
   }
+  for (size_t n = 0; n < N; n++) C_.kpp_sw_node[n] = (double)m->myDim_nod2D;
   { extern void orc_gm_static(void); if (p->Fer_GM) orc_gm_static(); }
   return 0;
 }

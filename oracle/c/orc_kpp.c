@@ -10,8 +10,8 @@
  *   blmix_kpp           :958-1145  boundary layer profiles, nonlocal coefficient ghats
  *   enhance             :1152-1191 enhanced diffusivity at the kbl-1 interface
  *   smooth_nod3D        src/gen_support.F90:78-178
- * Supported options: use_sw_pene=.false., double_diffusion=.false., Kv0_const=.true., use_kpp_nonlclflx=.false.
- * (the reference's defaults except use_sw_pene, which needs the short-wave forcing of the ice/atmosphere layer);
+ * Supported options: use_sw_pene (sw_3d from the forcing), double_diffusion=.false., Kv0_const=.true., use_kpp_nonlclflx=.false.
+ * (the reference's defaults);
  * module switches smooth_blmc=.true., smooth_hbl/smooth_Ri_hor/smooth_Ri_ver/limit_hbl_ekmmob=.false. as in the source.
  */
 #include "orc.h"
@@ -139,9 +139,12 @@ static void bldepth(void) {
   for (int n = 1; n <= C_.m.myDim_nod2D; n++) {
     int nzmin = ULEVN(n), nzmax = NLEVN(n);
     double Rib_km1 = 0.0;
+    const int sw = C_.p.use_sw_pene;
+    const double coeff_sw = sw ? G_ACC * A2(C_.sw_alpha, nzmin, n) : 0.0;
     C_.kpp_bfsfc[n - 1] = C_.kpp_Bo[n - 1];
     for (int nz = nzmin + 1; nz <= nzmax; nz++) {
       double zk = fabs(A2L(C_.zbar_3d_n, nz, n)), zkm1 = fabs(A2L(C_.zbar_3d_n, nz - 1, n));
+      if (sw) C_.kpp_bfsfc[n - 1] = C_.kpp_Bo[n - 1] + coeff_sw * (A2L(C_.sw_3d, nzmin, n) - A2L(C_.sw_3d, nz, n));
       C_.kpp_stable[n - 1] = 0.5 + copysign(0.5, C_.kpp_bfsfc[n - 1]);
       double sigma = C_.kpp_stable[n - 1] + (1.0 - C_.kpp_stable[n - 1]) * epsilon_kpp;
       double zehat = vonk * sigma * zk * C_.kpp_bfsfc[n - 1], wm, ws;
@@ -156,6 +159,12 @@ static void bldepth(void) {
         C_.kpp_kbl[n - 1] = nz;
         break;
       } else Rib_km1 = Rib_k;
+      if (sw) {                                          /* :573-584 */
+        C_.kpp_bfsfc[n - 1] = C_.kpp_Bo[n - 1] + coeff_sw * (A2L(C_.sw_3d, nzmin, n) -
+                              (A2L(C_.sw_3d, nz - 1, n) + (A2L(C_.sw_3d, nz, n) - A2L(C_.sw_3d, nz - 1, n)) * (C_.kpp_hbl[n - 1] - zkm1) / dzup));
+        C_.kpp_stable[n - 1] = 0.5 + copysign(0.5, C_.kpp_bfsfc[n - 1]);
+        C_.kpp_bfsfc[n - 1] = C_.kpp_bfsfc[n - 1] + C_.kpp_stable[n - 1] * epsln;
+      }
     }
     if (C_.kpp_bfsfc[n - 1] > 0.0 && nzmin == 1) {
       double us = C_.kpp_ustar[n - 1];
@@ -172,6 +181,18 @@ static void bldepth(void) {
     for (int nz = nzmin + 1; nz <= nzmax; nz++)
       if (fabs(A2L(C_.zbar_3d_n, nz, n)) > C_.kpp_hbl[n - 1]) { kbl = nz; break; }
     C_.kpp_kbl[n - 1] = kbl;
+    if (C_.p.use_sw_pene) {                              /* :627-640 */
+      /* Reference quirk: this second node loop does not set coeff_sw again, it still holds the value of the LAST node of the
+       * first loop (the rank's last owned node).  kpp_sw_node(n) names that node: the last node on one partition; the tests
+       * that compare with a 2-rank reference run set it to the last owned node of the rank that owns n. */
+      const int nl_ = (int)C_.kpp_sw_node[n - 1];
+      const double coeff_sw = G_ACC * A2(C_.sw_alpha, ULEVN(nl_), nl_);
+      C_.kpp_bfsfc[n - 1] = C_.kpp_Bo[n - 1] + coeff_sw * (A2L(C_.sw_3d, nzmin, n) -
+                            (A2L(C_.sw_3d, kbl - 1, n) + (A2L(C_.sw_3d, kbl, n) - A2L(C_.sw_3d, kbl - 1, n)) * (C_.kpp_hbl[n - 1] + A2L(C_.zbar_3d_n, kbl - 1, n)) /
+                                                              (A2L(C_.zbar_3d_n, kbl - 1, n) - A2L(C_.zbar_3d_n, kbl, n))));
+      C_.kpp_stable[n - 1] = 0.5 + copysign(0.5, C_.kpp_bfsfc[n - 1]);
+      C_.kpp_bfsfc[n - 1] = C_.kpp_bfsfc[n - 1] + C_.kpp_stable[n - 1] * epsln;
+    }
     double dzup = A2L(C_.zbar_3d_n, kbl - 1, n) - A2L(C_.zbar_3d_n, kbl, n);
     C_.kpp_caseA[n - 1] = 0.5 + copysign(0.5, fabs(A2L(C_.zbar_3d_n, kbl, n)) - 0.5 * dzup - C_.kpp_hbl[n - 1]);
   }

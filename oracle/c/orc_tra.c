@@ -515,6 +515,9 @@ static void diff_ver_part_impl_ale(int tr) {
     nz = nzmax - 1;
     dz = A2(C_.hnode_new, nz, n);
     trv[nz] = -a[nz] * TR(nz - 1, n, tr) - (b[nz] - dz) * TR(nz, n, tr);
+    if (C_.p.use_sw_pene && tr == 1)                   /* short-wave penetration, oce_ale_tracer.F90:785-791 */
+      for (nz = nzmin; nz <= nzmax - 1; nz++)
+        trv[nz] = trv[nz] + (A2L(C_.sw_3d, nz, n) - A2L(C_.sw_3d, nz + 1, n) * AREA(nz + 1, n) / AREASVOL(nz, n)) * (1.0 * dt);
     trv[nzmin] = trv[nzmin] + bc_surface(n, tr - 1);
     cp[nzmin] = c[nzmin] / b[nzmin];
     tp[nzmin] = trv[nzmin] / b[nzmin];

@@ -164,6 +164,16 @@ program oracle_driver
         heat_flux(i)=150.0_WP*sin(2.0_WP*flon+1.0_WP)*cos(flat)
         water_flux(i)=2.0e-8_WP*cos(3.0_WP*flon)
      end do
+     if (use_sw_pene) then      ! penetrating short-wave flux / vcpw [K m/s]: +,-,*,/ only (bit-reproducible), decays over ~15 m
+        if (.not. allocated(sw_3d)) allocate(sw_3d(mesh%nl, myDim_nod2D+eDim_nod2D))
+        sw_3d=0.0_WP
+        do i=1, myDim_nod2D+eDim_nod2D
+           do k=1, mesh%nlevels_nod2D(i)
+              flon=1.0_WP-mesh%zbar(k)/15.0_WP
+              sw_3d(k,i)=max(heat_flux(i), 0.0_WP)/4.2e6_WP*0.5_WP/(flon*flon)
+           end do
+        end do
+     end if
      stress_node_surf(1,:)=stress_atmoce_x; stress_node_surf(2,:)=stress_atmoce_y
      do i=1, myDim_elem2D
         fel=mesh%elem2D_nodes(:,i)
@@ -287,6 +297,7 @@ contains
     call dump('forcing.stress_atmoce_x', stress_atmoce_x); call dump('forcing.stress_atmoce_y', stress_atmoce_y)
     call dump('forcing.heat_flux', heat_flux); call dump('forcing.water_flux', water_flux)
     call dump('forcing.stress_surf', stress_surf)
+    if (use_sw_pene .and. allocated(sw_3d)) call dump('forcing.sw_3d', sw_3d)
     call dump_state()
     call dump_close()
   end subroutine dump_setup

@@ -60,7 +60,7 @@ use_ice=.false.
 use_cavity=.false.
 use_cavity_partial_cell=.false.
 use_floatice=.false.
-use_sw_pene=.false.
+use_sw_pene={use_sw_pene}
 toy_ocean={toy_ocean}
 which_toy='soufflet'
 flag_warn_cflz=.false.
@@ -171,6 +171,11 @@ CFGS = {
                          rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                          fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
                          balance_salt_water=".true.", synth_forcing=True, w_split=".true.", w_max_cfl="0.0003"),
+    # the default physics with short-wave penetration (use_sw_pene=.true., the default of namelist.config), sw_3d from the harness
+    "pi_default_sw": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                          rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                          fer_gm=".true.", redi=".true.", mix_scheme="KPP", k_hor="3000.", surf_relax_s="1.929e-06",
+                          balance_salt_water=".true.", synth_forcing=True, use_sw_pene=".true."),
     # KPP alone (no GM/Redi) with the same forcing
     "pi_kpp": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
                    rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
@@ -196,7 +201,7 @@ def prepare(cfg, np_, tag=""):
     if np_ == 1 and not os.path.isdir(os.path.join(meshdir, "dist_1")):
         from oracle.ref.make_dist1 import make_dist1
         make_dist1(meshdir)
-    open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **c))
+    open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **dict(dict(use_sw_pene=".false."), **c)))
     open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0"), **c)))
     if c["toy_ocean"] == ".false.":
         from fesom2_amd.synthetic import write_ic_files

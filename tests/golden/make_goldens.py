@@ -74,6 +74,14 @@ def make(cfg, outname):
         # the harness's analytic surface forcing, in full (global numbering): the tests hand it to the oracle / HIP path
         for k in ("stress_atmoce_x", "stress_atmoce_y", "heat_flux", "water_flux", "stress_surf"):
             out["forcing/" + k] = assemble(setups, setups, "forcing." + k).astype(np.float64)
+        if "forcing.sw_3d" in setups[0]:                   # (nl, N): only a digest; fesom2_amd.synthetic.analytic_sw_3d reproduces the bits
+            out["forcing_digest/sw_3d"] = digest(assemble(setups, setups, "forcing.sw_3d"))
+            # last owned node (global id) of the rank that owns each node: KPP's second pass reuses that node's coeff_sw (reference quirk)
+            last = np.zeros(int(setups[0]["dims"][0]), dtype=np.int32)
+            for s_ in setups:
+                own = s_["myList_nod2D"][:int(s_["dims"][5])]
+                last[own - 1] = own[-1]
+            out["part/last_owned_node"] = last
     for step in range(1, NSTEPS + 1):
         d = [read_dump(os.path.join(rd, "dumps", f"replay{step:04d}.r{r:05d}.bin")) for r in range(NP)]
         for k in d[0]:

@@ -39,11 +39,11 @@ def test_gfx950_code_object(built):
 def test_struct_layout_matches_header(built):
     """ctypes mirrors must have the size the C compiler gives the header structs"""
     from fesom2_amd import _lib
-    src = '#include <stdio.h>\n#include "fesom_gpu.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(fesom_mesh_desc), sizeof(fesom_com_desc), sizeof(fesom_part_desc), sizeof(fesom_params), sizeof(fesom_state_desc), sizeof(fesom_forcing_desc), sizeof(fesom_mesh_opts));return 0;}'
+    src = '#include <stdio.h>\n#include "fesom_gpu.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(fesom_mesh_desc), sizeof(fesom_com_desc), sizeof(fesom_part_desc), sizeof(fesom_params), sizeof(fesom_state_desc), sizeof(fesom_forcing_desc), sizeof(fesom_mesh_opts), sizeof(fesom_step_info), sizeof(fesom_transport));return 0;}'
     exe = "/tmp/_fesom_sizes"
     subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), "-x", "c", "-", "-o", exe], input=src, text=True, check=True)
     sizes = [int(x) for x in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
-    mine = [C.sizeof(t) for t in (_lib.MeshDesc, _lib.ComDesc, _lib.PartDesc, _lib.Params, _lib.StateDesc, _lib.ForcingDesc, _lib.MeshOpts)]
+    mine = [C.sizeof(t) for t in (_lib.MeshDesc, _lib.ComDesc, _lib.PartDesc, _lib.Params, _lib.StateDesc, _lib.ForcingDesc, _lib.MeshOpts, _lib.StepInfo, _lib.Transport)]
     assert sizes == mine, (sizes, mine)
 
 

@@ -83,7 +83,7 @@ def test_oracle_chain_bitwise_gm(built, redi):
 FORCING = ("stress_atmoce_x", "stress_atmoce_y", "heat_flux", "water_flux", "stress_surf")
 
 
-@pytest.mark.parametrize("cfg", ["pi_kpp", "pi_default"])
+@pytest.mark.parametrize("cfg", ["pi_kpp", "pi_default", "pi_default_sw"])
 def test_oracle_chain_bitwise_kpp_forced(built, cfg):
     """KPP vertical mixing (src/oce_ale_mixing_kpp.F90: ri_iwmix, bldepth, wscale tables, blmix_kpp, enhance, smoothing of blmc)
     under the harness's analytic wind stress / heat / fresh-water forcing, which also pins the surface boundary terms of
@@ -94,9 +94,10 @@ def test_oracle_chain_bitwise_kpp_forced(built, cfg):
     from fesom2_amd.synthetic import analytic_ts
     from oracle_lib import Oracle
     from ref_chain import run_reference_chain
-    full = cfg == "pi_default"
+    full = cfg != "pi_kpp"
+    sw = cfg == "pi_default_sw"                 # + short-wave penetration (use_sw_pene=.true., the default of namelist.config)
     mesh = Mesh.load(PI, dt=900.0)
-    par = make_params(dt=900.0, mix_scheme="KPP", Fer_GM=full, Redi=full)
+    par = make_params(dt=900.0, mix_scheme="KPP", Fer_GM=full, Redi=full, use_sw_pene=sw)
     st = mesh.initial_state(2)
     st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
     st.tr_arr_old[...] = st.tr_arr
@@ -105,6 +106,13 @@ def test_oracle_chain_bitwise_kpp_forced(built, cfg):
     g = gold(cfg)
     for f in FORCING:
         orc.set(f, g["forcing/" + f])
+    if sw:
+        from fesom2_amd.synthetic import analytic_sw_3d
+        sw3 = analytic_sw_3d(mesh, g["forcing/heat_flux"])
+        ok, msg = check_digest(sw3, g["forcing_digest/sw_3d"])     # the Python restatement of the harness's sw_3d: same bits
+        assert ok, msg
+        orc.set("sw_3d", sw3)
+        orc.set("kpp_sw_node", g["part/last_owned_node"].astype(np.float64))      # rank-dependent quirk of the reference, see orc_kpp.c
     bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
     assert not bad, "\n".join(bad[:20])
 
