@@ -371,13 +371,14 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   F(ssh_values, m.nza);
   if (par->Fer_GM) { F(fer_K, nl * N); F(fer_gamma, 2 * nl * N); F(fer_Wvel, nl * N); F(fer_c, N); F(fer_UV, 2 * n1 * E); }
   {   // surface forcing: ONE device block (one host->device copy per fesom_gpu_set_forcing), fields are views into it
-    G.frc_count = 2 * E + 7 * N;
+    G.frc_count = 2 * E + 7 * N + (par->use_sw_pene ? nl * N : 0);
     G.frc_dev = dev_alloc<double>(G.frc_count);
     double *q = G.frc_dev;
     auto view = [&](const char *name, size_t cnt) { double *r = q; G.fields[name] = Field{r, cnt, 1}; q += cnt; return r; };
     m.stress_surf = view("stress_surf", 2 * E); m.heat_flux = view("heat_flux", N); m.water_flux = view("water_flux", N);
     m.virtual_salt = view("virtual_salt", N); m.relax_salt = view("relax_salt", N); m.real_salt_flux = view("real_salt_flux", N);
     m.stress_atmoce_x = view("stress_atmoce_x", N); m.stress_atmoce_y = view("stress_atmoce_y", N);
+    m.sw_3d = par->use_sw_pene ? view("sw_3d", nl * N) : nullptr;
   }
   if (par->mix_scheme == 1) {
     F(dbsfc, nl * N);
@@ -539,6 +540,7 @@ int fesom_gpu_set_forcing(const fesom_forcing_desc *f) {
   };
   put(f->stress_surf, myE2, E2); put(f->heat_flux, N, N); put(f->water_flux, N, N); put(f->virtual_salt, N, N);
   put(f->relax_salt, N, N); put(f->real_salt_flux, N, N); put(f->stress_atmoce_x, N, N); put(f->stress_atmoce_y, N, N);
+  if (G.m.sw_3d) put(f->sw_3d, (size_t)G.m.nl * N, (size_t)G.m.nl * N);
   HIPCHK(hipMemcpyAsync(G.frc_dev, G.frc_pin[b], G.frc_count * sizeof(double), hipMemcpyHostToDevice, G.stream));
   HIPCHK(hipEventRecord(G.frc_ev[b], G.stream));
   return 0;

@@ -55,7 +55,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   const double *gm_scal_static;                           // (N) mesh-only part of the horizontal GM scaling
   int *MLD1_ind;                                          // (N) level index of MLD1 (pressure_bv)
   // KPP (kernels_kpp.hip): interior values, boundary layer coefficients (3 slabs of (nl,N)) + two smoothing buffers, tables
-  double *dbsfc, *stress_atmoce_x, *stress_atmoce_y;
+  double *dbsfc, *stress_atmoce_x, *stress_atmoce_y, *sw_3d;
   const double *coriolis_node;
   double *kpp_viscA, *kpp_Kv1, *kpp_Kv2, *kpp_blmc, *kpp_sA, *kpp_sB, *kpp_ghats, *kpp_hbl, *kpp_caseA, *kpp_dkm1;
   int *kpp_kbl;

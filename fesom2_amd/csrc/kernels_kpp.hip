@@ -5,7 +5,7 @@
 // One wavefront per node column, lane = level.  Everything the reference does with sequential searches over a column
 // (first level whose bulk Richardson number exceeds Ricr, first interface below hbl) is a ballot + find-first over the lanes;
 // per-column scalars (ustar, Bo, hbl, kbl, caseA, the matching coefficients at hbl) are computed redundantly by all lanes.
-// Supported switches: use_sw_pene=.false., double_diffusion=.false., Kv0_const=.true., use_kpp_nonlclflx=.false.;
+// Supported switches: use_sw_pene (sw_3d from the forcing), double_diffusion=.false., Kv0_const=.true., use_kpp_nonlclflx=.false.;
 // module switches as in the source (smooth_blmc=.true., the others .false.).
 //   k_kpp_col     dVsq, ustar, Bo, ri_iwmix, bldepth, blmix_kpp, enhance          (owned nodes)
 //   k_kpp_smooth  one sweep of smooth_nod3D for the three blmc fields (grid.y)    (owned nodes; halo by exchange)
@@ -100,20 +100,26 @@ __global__ void __launch_bounds__(BLOCK) k_kpp_col(DM m) {
     if (nz == nzmax) { visc = vl; kv1 = kl; }
   }
   double kv2 = kv1;
-  // ---- bldepth (:446-650), use_sw_pene=.false.: bfsfc = Bo throughout
-  const double bfsfc = Bo;
-  const double stable = 0.5 + copysign(0.5, bfsfc);
+  // ---- bldepth (:446-650).  Without short-wave penetration bfsfc = Bo throughout; with it (use_sw_pene) the buoyancy forcing
+  // at level nz includes the short-wave flux absorbed above it, so bfsfc / stable depend on the lane inside the search.
+  const bool sw = m.p.use_sw_pene != 0;
+  const double sw_l = (sw && ifc) ? DA2L(m.sw_3d, nz, n) : 0.0;
+  const double sw_min = bcast(sw_l, nzmin - 1);
+  const double coeff_sw = sw ? D_G * DA2(m.sw_alpha, nzmin, n) : 0.0;
+  double bfsfc = Bo, stable;
   double hbl, caseA;
   int kbl;
   {
     const bool rng = (nz >= nzmin + 1 && nz <= nzmax);
-    double sigma = stable + (1.0 - stable) * K_EPS;
-    double zehat = K_VONK * sigma * zk * bfsfc, wm, ws;
+    const double bf_l = sw ? Bo + coeff_sw * (sw_min - sw_l) : Bo;                // bfsfc at the top of iteration nz (:525)
+    const double st_l = 0.5 + copysign(0.5, bf_l);
+    double sigma = st_l + (1.0 - st_l) * K_EPS;
+    double zehat = K_VONK * sigma * zk * bf_l, wm, ws;
     kpp_wscale(m, zehat, ustar, wm, ws);
     double Vtsq = zk * ws * sqrt(fabs(bv)) * m.kpp_Vtc;
     double Ritop = zk * (rng ? DA2L(m.dbsfc, nz, n) : 0.0);
     double Rib_k = Ritop / (dVsq + Vtsq + K_EPSLN);
-    const double zkm1 = shup(zk);
+    const double zkm1 = shup(zk), sw_up = shup(sw_l);
     unsigned long long hit = __ballot(rng && Rib_k > m.p.Ricr);
     if (hit) {
       const int f = __ffsll((long long)hit) - 1;
@@ -121,7 +127,20 @@ __global__ void __launch_bounds__(BLOCK) k_kpp_col(DM m) {
       const double Rf = bcast(Rib_k, f), zf = bcast(zk, f), zfm1 = bcast(zkm1, f);
       const double dzup = zf - zfm1;
       hbl = zfm1 + dzup * (m.p.Ricr - Rib_km1) / (Rf - Rib_km1 + K_EPSLN);
-    } else hbl = bcast(zk, nzmax - 1);
+      bfsfc = bcast(bf_l, f); stable = bcast(st_l, f);
+    } else {
+      hbl = bcast(zk, nzmax - 1);
+      bfsfc = Bo; stable = 0.5 + copysign(0.5, bfsfc);
+      if (nzmax >= nzmin + 1) {
+        if (sw) {                     // the loop ran to its end: bfsfc of the last iteration's interpolation to hbl (:573-584)
+          const double zk_l = bcast(zk, nzmax - 1), zkm1_l = bcast(zkm1, nzmax - 1), dzup = zk_l - zkm1_l;
+          const double s_k = bcast(sw_l, nzmax - 1), s_km1 = bcast(sw_up, nzmax - 1);
+          bfsfc = Bo + coeff_sw * (sw_min - (s_km1 + (s_k - s_km1) * (hbl - zkm1_l) / dzup));
+          stable = 0.5 + copysign(0.5, bfsfc);
+          bfsfc = bfsfc + stable * K_EPSLN;
+        } else stable = bcast(st_l, nzmax - 1);
+      }
+    }
     if (bfsfc > 0.0 && nzmin == 1) {
       double hekman = 0.7 * ustar / dmax_(fabs(m.coriolis_node[n]), K_EPSLN);
       double hmonob = 1.0 * ustar * ustar * ustar / K_VONK / (bfsfc + K_EPSLN);
@@ -132,6 +151,14 @@ __global__ void __launch_bounds__(BLOCK) k_kpp_col(DM m) {
     unsigned long long below = __ballot(rng && zk > hbl);
     kbl = below ? __ffsll((long long)below) : nzmax;                 // lane index + 1 = level
     const double zb_k = bcast(zbs, kbl - 1), zb_km1 = bcast(zbs, kbl - 2);
+    if (sw) {     // :627-640.  Reference quirk: coeff_sw here is still that of the LAST node of the first loop = the last owned node
+      const int nlast = m.myN - 1;
+      const double coeff_last = D_G * DA2(m.sw_alpha, m.ulev_n[nlast], nlast);
+      const double s_k = bcast(sw_l, kbl - 1), s_km1 = bcast(sw_l, kbl - 2);
+      bfsfc = Bo + coeff_last * (sw_min - (s_km1 + (s_k - s_km1) * (hbl + zb_km1) / (zb_km1 - zb_k)));
+      stable = 0.5 + copysign(0.5, bfsfc);
+      bfsfc = bfsfc + stable * K_EPSLN;
+    }
     const double dzup = zb_km1 - zb_k;
     caseA = 0.5 + copysign(0.5, fabs(zb_k) - 0.5 * dzup - hbl);
   }

@@ -592,6 +592,8 @@ __global__ void __launch_bounds__(TH_BLOCK) k_tr_update(DM m, int tr0) {
         b = -a + hnn;
         rhs = -a * T_up - (b - hnn) * T;
       }
+      if (m.p.use_sw_pene && tr == 0)            // short-wave penetration (oce_ale_tracer.F90:785-791)
+        rhs = rhs + (DA2L(m.sw_3d, nz, n) - DA2L(m.sw_3d, nz + 1, n) * ar_dn / asv) * zinv;
       if (nz == nzmin) {
         double nonlin = (m.p.which_ale == 0) ? 0.0 : 1.0, bc;
         if (tr == 0) bc = -dt * (m.heat_flux[n] / D_VCPW + T * m.water_flux[n] * nonlin);

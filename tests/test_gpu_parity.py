@@ -189,8 +189,8 @@ def test_redi_chain_bitwise_and_steps(built, gm):
     gpu.close()
 
 
-@pytest.mark.parametrize("full", [False, True])
-def test_kpp_chain_and_steps(built, full):
+@pytest.mark.parametrize("full,sw", [(False, False), (True, False), (True, True), (False, True)])
+def test_kpp_chain_and_steps(built, full, sw):
     """KPP vertical mixing under surface forcing (full = with GM + Redi, the reference's default physics): routine chain over
     3 steps, HIP == oracle bitwise (with Redi the oracle's tapered slopes are handed over, see the Redi test), then 10 whole
     steps through the step graph: bitwise without Redi, 1e-9 relative with it."""
@@ -200,14 +200,16 @@ def test_kpp_chain_and_steps(built, full):
     from fesom2_amd.synthetic import analytic_ts
     from oracle_lib import Oracle
     mesh = Mesh.load(PI, dt=900.0)
-    par = make_params(dt=900.0, mix_scheme="KPP", Fer_GM=full, Redi=full, scaling_Ferreira=full)
+    par = make_params(dt=900.0, mix_scheme="KPP", Fer_GM=full, Redi=full, scaling_Ferreira=full, use_sw_pene=sw)   # sw: short-wave penetration
     st = mesh.initial_state(2)
     st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
     st.tr_arr_old[...] = st.tr_arr
     gpu, orc = OceanCore(mesh, par), Oracle(mesh, par)
     gpu.upload_state(st); orc.set_state(st)
-    from fesom2_amd.synthetic import analytic_forcing
+    from fesom2_amd.synthetic import analytic_forcing, analytic_sw_3d
     forcing = analytic_forcing(mesh)
+    if sw:
+        forcing["sw_3d"] = analytic_sw_3d(mesh, forcing["heat_flux"])
     gpu.set_forcing(**forcing)
     for k, v in forcing.items():
         orc.set(k, v)
