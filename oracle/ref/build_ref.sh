@@ -15,7 +15,7 @@ mkdir -p "$OUT/obj" "$OUT/parms_obj"
 if [ ! -d "$REF/src" ]; then
   echo "build_ref.sh: $REF not present (GPU box?) - keeping prebuilt oracle/_ref as is"; exit 0
 fi
-if [ -x "$OUT/fesom_oracle.x" ] && [ "$OUT/fesom_oracle.x" -nt "$HERE/driver.F90" ] && [ "$OUT/fesom_oracle.x" -nt "$HERE/stubs.F90" ] && [ -x "$OUT/fesom_gpu_dropin.x" ] && \
+if [ -x "$OUT/fesom_oracle.x" ] && [ "$OUT/fesom_oracle.x" -nt "$HERE/driver.F90" ] && [ "$OUT/fesom_oracle.x" -nt "$HERE/stubs.F90" ] && [ -x "$OUT/fesom_gpu_dropin.x" ] && [ -x "$OUT/fesom_psolve_gpu.x" ] && \
    [ "$OUT/fesom_gpu_dropin.x" -nt "$HERE/../../fesom2_amd/fortran/fesom_gpu_shim.F90" ] && [ "$OUT/fesom_gpu_dropin.x" -nt "$HERE/driver.F90" ] && [ -z "$FORCE" ]; then
   echo "build_ref.sh: up to date"; exit 0
 fi
@@ -78,4 +78,9 @@ if [ -f "$GPULIB/libfesom_gpu.so" ]; then
   $FC -O2 -o "$OUT/fesom_gpu_dropin.x" $GOBJS psolve.o "$OUT/libparms.a" -L$MPI_LIB -lmpifort -lmpi -L$GPULIB -lfesom_gpu \
     -Wl,-rpath,$MPI_LIB -Wl,-rpath,/root/repo/fesom2_amd -Wl,-rpath,$GPULIB
   echo "built $OUT/fesom_gpu_dropin.x"
+  # ---- the reference's CPU time step with ONLY the SSH solve replaced: same objects, no psolve.c / pARMS, the three psolve
+  #      entry points (src/psolve.c:16,117,152) resolved by libfesom_gpu.so
+  $FC -O2 -o "$OUT/fesom_psolve_gpu.x" $OBJS -L$MPI_LIB -lmpifort -lmpi -L$GPULIB -lfesom_gpu \
+    -Wl,-rpath,$MPI_LIB -Wl,-rpath,/root/repo/fesom2_amd -Wl,-rpath,$GPULIB
+  echo "built $OUT/fesom_psolve_gpu.x"
 fi
