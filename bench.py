@@ -274,6 +274,16 @@ def main():
                                    "sum_kernel_us": round(sum(share.values()) * 1e6, 1),
                                    "solver_us": round(times["k_solver"] * 1e6, 1), "solver_iterations": its},
                     "top5_us": {k: round(v * 1e6, 2) for k, v in sorted(share.items(), key=lambda kv: -kv[1])[:5]}}
+        # the SSH solve is the largest single launch by time, but it is a 2-D problem (N2 rows) solved by ONE workgroup on ONE CU:
+        # its traffic is the ELL operator re-read from L2 twice per iteration, bounded by one CU's L2 port, not by HBM
+        if mesh.myDim_nod2D <= 4096:
+            ell_bytes = 8.0 * 10 * ((mesh.myDim_nod2D + 63) // 64 * 64)
+            sol_bytes = its * 2 * ell_bytes
+            roofline["solver"] = {"kernel": "k_solver_reg", "us": round(times["k_solver"] * 1e6, 1), "iterations": its,
+                                  "operator_bytes_per_spmv": ell_bytes, "algorithmic_bytes": sol_bytes,
+                                  "achieved_GBs": round(sol_bytes / times["k_solver"] / 1e9, 1),
+                                  "bound": "latency / one CU's L2 port (64 B/clk ~ 134 GB/s): one 1024-thread workgroup, 2 barriers-separated reductions per iteration",
+                                  "frac_of_one_cu_l2": round(sol_bytes / times["k_solver"] / 1e9 / 134.0, 3)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline and args.refine == 0:
             cpu = cpu_baseline(physics=args.physics)
