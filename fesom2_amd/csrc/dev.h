@@ -116,12 +116,14 @@ __device__ __forceinline__ double shdn(double x) { return __shfl_down(x, 1, 64);
 __device__ __forceinline__ double seq_sum_up(double x, int first, int last, double init) {
   double acc = init, mine = init;
   int l = lane_id();
+  first = __builtin_amdgcn_readfirstlane(first); last = __builtin_amdgcn_readfirstlane(last);      // level bounds of the wave's column: uniform
   for (int j = first; j <= last; ++j) { acc = acc + bcast(x, j); if (l == j) mine = acc; }
   return mine;
 }
 __device__ __forceinline__ double seq_sum_down(double x, int first, int last, double init) {   // j = first, first-1, ..., last
   double acc = init, mine = init;
   int l = lane_id();
+  first = __builtin_amdgcn_readfirstlane(first); last = __builtin_amdgcn_readfirstlane(last);
   for (int j = first; j >= last; --j) { acc = acc + bcast(x, j); if (l == j) mine = acc; }
   return mine;
 }

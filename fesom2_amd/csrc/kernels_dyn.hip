@@ -555,13 +555,12 @@ __global__ void __launch_bounds__(BLOCK) k_edge_transport(DM m, int mode) {
     }
   }
   // c1 = sum_{nz} t1 (top-down), c2 = -sum t2 (reference: c2 = c2 - term); one pass over the levels for both
+  // (wave-uniform trip counts, one readlane pair + one add per level: the serial sums are what this kernel's time is made of)
   double c1 = 0.0, c2 = 0.0;
-  int jhi = (l1 > l2 ? l1 : l2) - 1;
-  for (int j = 0; j <= jhi; ++j) {
-    double a1 = bcast(t1, j), a2 = bcast(t2, j);
-    if (j >= u1 - 1 && j <= l1 - 1) c1 = c1 + a1;
-    if (j >= u2 - 1 && j <= l2 - 1) c2 = c2 - a2;
-  }
+  u1 = __builtin_amdgcn_readfirstlane(u1); l1 = __builtin_amdgcn_readfirstlane(l1);
+  u2 = __builtin_amdgcn_readfirstlane(u2); l2 = __builtin_amdgcn_readfirstlane(l2);
+  for (int j = u1 - 1; j <= l1 - 1; ++j) c1 = c1 + bcast(t1, j);
+  for (int j = u2 - 1; j <= l2 - 1; ++j) c2 = c2 - bcast(t2, j);
   if (l == 0) m.edge_c12[ed] = c1 + c2;
 }
 __global__ void k_ssh_rhs_node(DM m) {
