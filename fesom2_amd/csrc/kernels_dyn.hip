@@ -644,18 +644,50 @@ __global__ void __launch_bounds__(BLOCK) k_vert_vel(DM m, int fuse_hbar) {
       if (nzmin == 1) m.eta_n[n] = m.p.alpha * hb_new + (1.0 - m.p.alpha) * hb_old;
     }
   } else { hb_new = m.hbar[n]; hb_old = m.hbar_old[n]; }
+  // divergence of the edge transports in the layer: incident edges in list order (= reference's edge loop order).  The edge list
+  // of the node is read lane-parallel (lane q = q-th incident edge: edge, sign, its triangles with their level ranges, the four
+  // cross-edge coefficients), broadcast with v_readlane, and the field loads of VW_B edges are issued as one batch before the
+  // ordered sums: no chain of dependent loads per edge.
   double w = 0.0;
-  if (nz <= m.nlm1) {
-    for (int q = m.ne_ptr[n]; q < m.ne_ptr[n + 1]; q++) {
-      int ed = m.ne_idx[q], sg = m.ne_sgn[q];
-      int e1 = m.edge_tri[2 * ed], e2 = m.edge_tri[2 * ed + 1];
-      if (nz >= m.ulev[e1] && nz <= m.nlev[e1] - 1) {
-        double c1 = (DV2(m.UV, 2, nz, e1) * DECD(1, ed) - DV2(m.UV, 1, nz, e1) * DECD(2, ed)) * DA2(m.helem, nz, e1);
-        w = (sg > 0) ? w + c1 : w - c1;
+  {
+    const int q0 = m.ne_ptr[n], deg = m.ne_ptr[n + 1] - q0;
+    int sg_l = 0, e1_l = 0, e2_l = 0, r1_l = 1, r2_l = 1;            // ranges packed lo | hi << 8 ; (1, 0) = empty
+    double x1_l = 0.0, x2_l = 0.0, x3_l = 0.0, x4_l = 0.0;
+    if (l < deg) {
+      const int ed = m.ne_idx[q0 + l];
+      sg_l = m.ne_sgn[q0 + l];
+      e1_l = m.edge_tri[2 * ed];
+      const int e2 = m.edge_tri[2 * ed + 1];
+      r1_l = m.ulev[e1_l] | ((m.nlev[e1_l] - 1) << 8);
+      e2_l = e2 >= 0 ? e2 : e1_l;
+      r2_l = e2 >= 0 ? (m.ulev[e2] | ((m.nlev[e2] - 1) << 8)) : 1;
+      x1_l = DECD(1, ed); x2_l = DECD(2, ed); x3_l = DECD(3, ed); x4_l = DECD(4, ed);
+    }
+    const int nzc = nz <= m.nlm1 ? nz : m.nlm1;
+    constexpr int VW_B = 6;
+    for (int k0 = 0; k0 < deg; k0 += VW_B) {
+      double u1[VW_B], v1[VW_B], h1[VW_B], u2[VW_B], v2[VW_B], h2[VW_B];
+#pragma unroll
+      for (int k = 0; k < VW_B; k++) {
+        const int kk = (k0 + k < deg) ? k0 + k : 0;
+        const int e1 = rdlane(e1_l, kk), e2 = rdlane(e2_l, kk);
+        u1[k] = DV2(m.UV, 1, nzc, e1); v1[k] = DV2(m.UV, 2, nzc, e1); h1[k] = DA2(m.helem, nzc, e1);
+        u2[k] = DV2(m.UV, 1, nzc, e2); v2[k] = DV2(m.UV, 2, nzc, e2); h2[k] = DA2(m.helem, nzc, e2);
       }
-      if (e2 >= 0 && nz >= m.ulev[e2] && nz <= m.nlev[e2] - 1) {
-        double c2 = -(DV2(m.UV, 2, nz, e2) * DECD(3, ed) - DV2(m.UV, 1, nz, e2) * DECD(4, ed)) * DA2(m.helem, nz, e2);
-        w = (sg > 0) ? w + c2 : w - c2;
+#pragma unroll
+      for (int k = 0; k < VW_B; k++) {
+        const int kk = k0 + k;
+        if (kk < deg) {
+          const int r1 = rdlane(r1_l, kk), r2 = rdlane(r2_l, kk);
+          const bool pos = rdlane(sg_l, kk) > 0;
+          const bool on1 = nz >= (r1 & 0xff) && nz <= (r1 >> 8), on2 = nz >= (r2 & 0xff) && nz <= (r2 >> 8);
+          const double c1 = (v1[k] * bcast(x1_l, kk) - u1[k] * bcast(x2_l, kk)) * h1[k];
+          const double w1 = pos ? w + c1 : w - c1;
+          w = on1 ? w1 : w;
+          const double c2 = -(v2[k] * bcast(x3_l, kk) - u2[k] * bcast(x4_l, kk)) * h2[k];
+          const double w2 = pos ? w + c2 : w - c2;
+          w = on2 ? w2 : w;
+        }
       }
     }
   }
