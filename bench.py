@@ -59,7 +59,7 @@ PHYSICS = {   # --physics: options of the hot path; "pp" is the headline workloa
 }
 
 
-def cpu_baseline(nsteps_ref=400, physics="pp"):
+def cpu_baseline(nsteps_ref=400, physics="pp", refine=0):
     """Reference Fortran/MPI hot path (oracle/_ref/fesom_oracle.x, built from the reference's own sources) on the
     host cores: same mesh, same options, same initial state; 8 MPI ranks (dist_8)."""
     ncpu = os.cpu_count() or 1
@@ -69,13 +69,17 @@ def cpu_baseline(nsteps_ref=400, physics="pp"):
             raise RuntimeError("no reference binary")
         from oracle.ref import run_ref
         ranks = 8 if ncpu >= 8 else 2
-        rd, rc, lines = run_ref.run(PHYSICS[physics]["ref_cfg"], ranks, nsteps_ref, mode="step", dump=(), dump_mesh=False)
+        cfg = PHYSICS[physics]["ref_cfg"]
+        if refine > 0:            # the reference on the same refined mesh: edge files + partition written in its own formats
+            cfg, _ = run_ref.refined_case(refine, ranks, base=cfg)
+            nsteps_ref = max(20, nsteps_ref // 4 ** refine)
+        rd, rc, lines = run_ref.run(cfg, ranks, nsteps_ref, mode="step", dump=(), dump_mesh=False)
         tl = [l for l in lines if l.startswith("ORACLE_TIMING")]
         if rc != 0 or not tl:
             raise RuntimeError(f"reference run failed rc={rc}")
         sps = float(tl[0].split("s_per_step=")[1])
         return {"value": 86400.0 / (STEPS_PER_YEAR * sps), "unit": "simulated_years/day", "cores": ranks, "kind": "reference",
-                "sample": f"{nsteps_ref} steps of oce_timestep_ale on pi ({PHYSICS[physics]['text']}), {ranks} MPI ranks, {sps*1e3:.2f} ms/step"}
+                "sample": f"{nsteps_ref} steps of oce_timestep_ale on pi{' refined ' + str(refine) + 'x' if refine else ''} ({PHYSICS[physics]['text']}), {ranks} MPI ranks, {sps*1e3:.2f} ms/step"}
     except Exception as e:          # reference cannot run here: time the scalar C restatement instead
         from fesom2_amd.mesh import Mesh
         from fesom2_amd.config import make_params
@@ -285,8 +289,8 @@ def main():
                                   "bound": "latency / one CU's L2 port (64 B/clk ~ 134 GB/s): one 1024-thread workgroup, 2 barriers-separated reductions per iteration",
                                   "frac_of_one_cu_l2": round(sol_bytes / times["k_solver"] / 1e9 / 134.0, 3)}
         cpu = None
-        if world == 1 and not args.no_cpu_baseline and args.refine == 0:
-            cpu = cpu_baseline(physics=args.physics)
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(physics=args.physics, refine=args.refine)
         # the other option set, short run (N = 1 only): same mesh and state, its own CPU reference timing
         other = None
         if world == 1 and args.refine == 0:

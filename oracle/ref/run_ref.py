@@ -193,11 +193,29 @@ CFGS = {
 }
 
 
+def refined_case(levels, npes, base="pi_pp", workdir=None):
+    """registers configuration `<base>_r<levels>`: the pi mesh refined `levels` times (fesom2_amd.mesh_refine), with the edge files
+    and a `dist_<npes>` partition written in the reference's formats by fesom2_amd.partition_io -- so that the REFERENCE runs on
+    the same large mesh as the GPU path (CPU baseline / parity at sizes beyond pi)."""
+    import tempfile
+    from fesom2_amd import mesh_refine, partition_io
+    d = os.path.join(workdir or tempfile.gettempdir(), f"fesom_pi_r{levels}")
+    if not os.path.exists(os.path.join(d, "edgenum.out")):
+        mesh_refine.refine(os.path.join(MESHES, "pi"), d, levels)
+        partition_io.write_edge_files(d)
+    for n in sorted({npes, 1}):
+        if n > 1 and not os.path.isdir(os.path.join(d, f"dist_{n}")):
+            partition_io.write_dist(d, n)
+    name = f"{base}_r{levels}"
+    CFGS[name] = dict(CFGS[base], mesh=d)
+    return name, d
+
+
 def prepare(cfg, np_, tag=""):
     c = CFGS[cfg]
     rd = os.path.join(OUT, f"run_{cfg}_{np_}{tag}")
     os.makedirs(os.path.join(rd, "dumps"), exist_ok=True)
-    meshdir = os.path.join(MESHES, c["mesh"])
+    meshdir = c["mesh"] if os.path.isabs(c["mesh"]) else os.path.join(MESHES, c["mesh"])
     if np_ == 1 and not os.path.isdir(os.path.join(meshdir, "dist_1")):
         from oracle.ref.make_dist1 import make_dist1
         make_dist1(meshdir)

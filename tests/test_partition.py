@@ -100,3 +100,25 @@ def test_generated_partitions_are_consistent(built, npes):
                 assert sent == recv, (kind, r, pe)
     for m in meshes:
         m.free()
+
+
+def test_partition_and_edge_files_written_in_reference_format(built, tmp_path):
+    """fesom2_amd/partition_io.py writes dist_<npes>/ (rpart.out, my_list*, com_info*) and the edge files in the formats the
+    reference reads: for the partitions / edges the reference ships with the pi mesh the written files equal the reference's own
+    files token for token (so the reference can run on meshes and partitions produced here, e.g. the refined meshes)."""
+    import shutil
+    from fesom2_amd.partition_io import write_dist, write_edge_files
+    pi = os.path.join(REPO, "tests", "golden", "meshes", "pi")
+    for npes in (2, 8):
+        out = write_dist(pi, npes, outdir=str(tmp_path / f"d{npes}"))
+        names = sorted(os.listdir(os.path.join(pi, f"dist_{npes}")))
+        assert sorted(os.listdir(out)) == names
+        for fn in names:
+            assert open(os.path.join(out, fn)).read().split() == open(os.path.join(pi, f"dist_{npes}", fn)).read().split(), (npes, fn)
+    cp = str(tmp_path / "pi_noedges")
+    shutil.copytree(pi, cp)
+    for f in ("edgenum.out", "edges.out", "edge_tri.out"):
+        os.remove(os.path.join(cp, f))
+    write_edge_files(cp)
+    for f in ("edgenum.out", "edges.out", "edge_tri.out"):
+        assert open(os.path.join(cp, f)).read().split() == open(os.path.join(pi, f)).read().split(), f
