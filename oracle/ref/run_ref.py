@@ -237,7 +237,13 @@ def run(cfg, np_, nsteps, mode="step", dump=(), mean=False, dump_mesh=True, quie
         f"synth_forcing={'.true.' if forcing else '.false.'}\nstep_info={'.true.' if step_info else '.false.'}\n/\n")
     exe = os.path.join(OUT, exe_name)
     cmd = ["/opt/conda/bin/mpiexec", "-n", str(np_), exe]
-    r = subprocess.run(cmd, cwd=rd, capture_output=True, text=True)
+    def big_stack():        # the reference keeps (nl, nodes) work arrays on the stack: larger meshes overflow the default 8 MB
+        import resource
+        try:
+            resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
+        except (ValueError, OSError):
+            pass
+    r = subprocess.run(cmd, cwd=rd, capture_output=True, text=True, preexec_fn=big_stack)
     open(os.path.join(rd, "stdout.log"), "w").write(r.stdout + "\n--- stderr ---\n" + r.stderr)
     lines = [l for l in r.stdout.splitlines() if l.startswith("ORACLE") or "ERROR" in l]
     if not quiet or r.returncode != 0:
