@@ -219,6 +219,18 @@ def prepare(cfg, np_, tag=""):
     if np_ == 1 and not os.path.isdir(os.path.join(meshdir, "dist_1")):
         from oracle.ref.make_dist1 import make_dist1
         make_dist1(meshdir)
+    if np_ > 1 and not os.path.isdir(os.path.join(meshdir, f"dist_{np_}")):
+        # a partition count the mesh does not ship: written in the reference's format by this package's partition layer into a
+        # scratch copy of the mesh directory (the committed fixtures stay as they are)
+        import tempfile
+        from fesom2_amd import partition_io
+        cp = os.path.join(tempfile.gettempdir(), f"fesom_{os.path.basename(meshdir.rstrip('/'))}_dist{np_}")
+        if not os.path.isdir(os.path.join(cp, f"dist_{np_}")):
+            shutil.copytree(meshdir, cp, dirs_exist_ok=True, copy_function=shutil.copyfile)
+            for root, dirs, _ in os.walk(cp):                       # (the source tree may be read-only)
+                os.chmod(root, 0o755)
+            partition_io.write_dist(cp, np_)
+        meshdir = cp
     open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **dict(dict(use_sw_pene=".false."), **c)))
     open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0"), **c)))
     if c["toy_ocean"] == ".false.":

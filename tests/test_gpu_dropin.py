@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 NSTEPS = 10
 
 
-@pytest.mark.parametrize("cfg,ranks", [("pi_default", 1), ("pi_pp", 1), ("pi_default", 2), ("pi_default_sw", 2)])
+@pytest.mark.parametrize("cfg,ranks", [("pi_default", 1), ("pi_pp", 1), ("pi_default", 2), ("pi_default_sw", 2), ("pi_default", 4)])
 def test_fortran_dropin_matches_reference_cpu_step(built, cfg, ranks):
     """ranks = 2: two MPI ranks of the reference's own partition (dist_2) share the box's GPU; the Fortran layer hands the
     reference's com_struct lists to the library and moves the packed halo messages with MPI_Isend/Irecv (host-staged), the
@@ -39,6 +39,7 @@ def test_fortran_dropin_matches_reference_cpu_step(built, cfg, ranks):
     assert rc_g == 0, open(os.path.join(rd_g, "stdout.log")).read()[-3000:]
     rd_c, rc_c, lines_c = run_ref.run(cfg, 2, NSTEPS, mode="step", dump=(NSTEPS,))
     assert rc_c == 0, open(os.path.join(rd_c, "stdout.log")).read()[-3000:]
+    # (ranks = 4: pi ships no dist_4; it is written in the reference's format by fesom2_amd/partition_io.py)
     sg = [read_dump(os.path.join(rd_g, "dumps", f"setup.r{r:05d}.bin")) for r in range(ranks)]
     dg = [read_dump(os.path.join(rd_g, "dumps", f"state{NSTEPS:04d}.r{r:05d}.bin")) for r in range(ranks)]
     sc = [read_dump(os.path.join(rd_c, "dumps", f"setup.r{r:05d}.bin")) for r in range(2)]
