@@ -69,14 +69,34 @@ double *field(const char *name, size_t n, int slabs = 1) {
   return p;
 }
 // static ELL column pattern [k][NP] (uint16), padding entries point to the row itself (their B entry is 0)
-std::vector<unsigned short> ell_cols(const int *rp, const int *ci, int n, int maxnnz) {
+// Row order of the one-workgroup solve: stable sort by the number of entries, descending (rows of equal width keep their order);
+// `sorted` = false gives the identity.  perm[position] = row, inv[row] = position, wid[position/64] = widest row of the group.
+void solver_row_order(const int *rp, int n, int maxnnz, bool sorted, std::vector<int> &perm, std::vector<int> &inv, std::vector<int> &wid) {
+  const int NP = (n + 63) / 64 * 64, W = maxnnz <= 10 ? 10 : 16;
+  perm.assign(NP, 0); inv.assign(NP, 0); wid.assign(NP / 64, W);
+  int q = 0;
+  if (sorted) for (int w = maxnnz; w >= 0; w--) for (int i = 0; i < n; i++) if (rp[i + 1] - rp[i] == w) perm[q++] = i;
+  for (; q < n; q++) perm[q] = q;                      // (sorted == false)
+  if (!sorted) for (int i = 0; i < n; i++) perm[i] = i;
+  for (int i = n; i < NP; i++) perm[i] = i;
+  for (int i = 0; i < NP; i++) inv[perm[i]] = i;
+  if (sorted)
+    for (int g = 0; g < NP / 64; g++) {
+      int w = 0;
+      for (int i = 64 * g; i < 64 * g + 64 && i < n; i++) w = std::max(w, rp[perm[i] + 1] - rp[perm[i]]);
+      wid[g] = w;
+    }
+}
+// static ELL column pattern in the solver's row order: entry k of the row at position q, column ids as positions
+std::vector<unsigned short> ell_cols(const int *rp, const int *ci, int n, int maxnnz, const std::vector<int> &perm, const std::vector<int> &inv) {
   int W = maxnnz <= 10 ? 10 : 16, NP = (n + 63) / 64 * 64;
   std::vector<unsigned short> c((size_t)W * NP, 0);
-  for (int i = 0; i < NP; i++)
+  for (int q = 0; q < NP; q++)
     for (int k = 0; k < W; k++) {
-      unsigned short v = (unsigned short)(i < n ? i : 0);
-      if (i < n && rp[i] + k < rp[i + 1]) v = (unsigned short)ci[rp[i] + k];
-      c[(size_t)k * NP + i] = v;
+      const int i = perm[q];
+      unsigned short v = (unsigned short)(q < n ? q : 0);
+      if (q < n && rp[i] + k < rp[i + 1]) v = (unsigned short)inv[ci[rp[i] + k]];
+      c[(size_t)k * NP + q] = v;
     }
   return c;
 }
@@ -315,7 +335,13 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     m.rowptr = dev_upload(rp); m.colind = dev_upload(ci);
     m.ssh_maxnnz = 0;
     for (int i = 0; i < m.myN; i++) m.ssh_maxnnz = std::max(m.ssh_maxnnz, rp[i + 1] - rp[i]);
-    m.sv_cols = (unsigned short *)dev_upload(ell_cols(rp.data(), ci.data(), m.myN, m.ssh_maxnnz));
+    {   // natural order wherever other phases read the ELL operator: partitioned runs, multi-workgroup solve
+      const bool one_wg = (!part || part->npes <= 1) && m.myN <= 4096 && m.ssh_maxnnz <= 10;
+      std::vector<int> perm, inv, wid;
+      solver_row_order(rp.data(), m.myN, m.ssh_maxnnz, one_wg, perm, inv, wid);
+      m.sv_cols = (unsigned short *)dev_upload(ell_cols(rp.data(), ci.data(), m.myN, m.ssh_maxnnz, perm, inv));
+      m.sv_perm = dev_upload(perm); m.sv_inv = dev_upload(inv); m.sv_wid = dev_upload(wid);
+    }
     {
       const int W = m.ssh_maxnnz <= 10 ? 10 : 16, NP = (m.myN + 63) / 64 * 64;
       std::vector<int> c32((size_t)W * NP, 0);
@@ -829,7 +855,14 @@ void psolver_init(int *id, int *stype, int *pctype, int *pcilutype, int *iluleve
   m.sv_x0 = (double *)A(sizeof(double) * 16 * (n + 64));
   m.sv_info = (int *)A(16); m.sv_resid = (double *)A(8);
   {
-    std::vector<unsigned short> ec = ell_cols(rptr, cols, n, m.ssh_maxnnz);
+    std::vector<int> perm, inv, wid;
+    solver_row_order(rptr, n, m.ssh_maxnnz, n <= 4096 && m.ssh_maxnnz <= 10, perm, inv, wid);
+    for (auto pv : {std::make_pair(&perm, &m.sv_perm), std::make_pair(&inv, &m.sv_inv), std::make_pair(&wid, &m.sv_wid)}) {
+      int *dp = (int *)A(pv.first->size() * sizeof(int));
+      hipMemcpy(dp, pv.first->data(), pv.first->size() * sizeof(int), hipMemcpyHostToDevice);
+      *pv.second = dp;
+    }
+    std::vector<unsigned short> ec = ell_cols(rptr, cols, n, m.ssh_maxnnz, perm, inv);
     m.sv_cols = (unsigned short *)A(ec.size() * sizeof(unsigned short));
     hipMemcpy(m.sv_cols, ec.data(), ec.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
     const int W = m.ssh_maxnnz <= 10 ? 10 : 16, NP = (n + 63) / 64 * 64;      // 32-bit pattern + work space of the multi-workgroup phases

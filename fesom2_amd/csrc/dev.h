@@ -73,6 +73,10 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   double *sv_h1, *sv_h2, *sv_h3; int sv_extrap;   // previous SSH solutions (extrapolated initial guess), only on the step path
   unsigned short *sv_cols;    // static ELL column pattern [k][NP] of the SSH operator (padding -> own row)
   const int *sv_colsi;        // the same with 32-bit indices (multi-workgroup / partitioned phases)
+  // one-workgroup solve: rows sorted by their number of entries (stable, descending) so that the 64 rows of a wavefront have the
+  // same ELL width and the padding is skipped.  sv_perm[position] = row, sv_inv[row] = position, sv_wid[position / 64] = width.
+  // Identity / full width wherever the natural order is needed (multi-workgroup and partitioned phases).
+  const int *sv_perm, *sv_inv, *sv_wid;
   fesom_params p;
 };
 

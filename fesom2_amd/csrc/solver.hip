@@ -86,18 +86,19 @@ __global__ void k_row_scale(DM m) {
 void launch_row_scale(const DM &m, hipStream_t s) { hipLaunchKernelGGL(k_row_scale, dim3((m.myN + 255) / 256), dim3(256), 0, s, m); }
 
 template <int W>
-__global__ void k_solver_setup(DM m, int NP, int fuse_rhs) {
+__global__ void k_solver_setup(DM m, int NP, int fuse_rhs, int sorted) {      // sorted: write in the one-workgroup solver's row order
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= NP) return;
   const int n = m.myN;
   const int *rp = m.rowptr, *ci = m.colind;
   double *Bg = m.sv_vals;
-  if (i >= n) {
+  if (i >= n) {                                            // padding rows keep their position
 #pragma unroll
     for (int k = 0; k < W; k++) Bg[k * NP + i] = 0.0;
     m.sv_s[i] = 0.0;
     return;
   }
+  const int q = sorted ? m.sv_inv[i] : i;                  // position of row i in the solver's row order
   int j0 = rp[i], j1 = rp[i + 1];
   double sc = m.sv_scale[i];
   double rhs;
@@ -113,7 +114,7 @@ __global__ void k_solver_setup(DM m, int NP, int fuse_rhs) {
     m.ssh_rhs[i] = sacc;
     rhs = sacc;
   } else rhs = m.ssh_rhs[i];
-  m.sv_b[i] = rhs * sc;
+  m.sv_b[q] = rhs * sc;
   double diag = m.sv_dinv[i];
   double xi = m.d_eta[i], x0 = xi;                       // initial guess: previous solution or quadratic extrapolation
   const int nh = m.sv_info[1];                          // solutions in the history (the final thread of the solve counts them up)
@@ -123,7 +124,7 @@ __global__ void k_solver_setup(DM m, int NP, int fuse_rhs) {
     if (m.p.solver_x0_order == 3 && nh == 2) x0 = (3.0 * xi - 3.0 * m.sv_h1[i]) + m.sv_h2[i];
     m.sv_h3[i] = m.sv_h2[i]; m.sv_h2[i] = m.sv_h1[i]; m.sv_h1[i] = xi;
   }
-  m.sv_s[i] = x0 * diag;                                  // y0 = D x0
+  m.sv_s[q] = x0 * diag;                                  // y0 = D x0
 #pragma unroll
   for (int k = 0; k < W; k++) {
     double bk = 0.0;
@@ -132,7 +133,7 @@ __global__ void k_solver_setup(DM m, int NP, int fuse_rhs) {
       double dinv_c = 1.0 / m.sv_dinv[c];
       bk = (m.ssh_values[j0 + k] * sc) * dinv_c;           // B = A_s D^-1
     }
-    Bg[k * NP + i] = bk;
+    Bg[k * NP + q] = bk;
   }
 }
 
@@ -152,11 +153,13 @@ __global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2
   const unsigned short *cg = m.sv_cols;
   unsigned cpk[R][W / 2];                                  // two byte offsets (col*8 < 65536) per register
   bool ok[R];
+  int wk[R];                                               // ELL width of this wavefront's rows in slab k (rows are sorted by width)
   double r[R], v[R], tv[R];
 #pragma unroll
   for (int k = 0; k < R; k++) {
     const unsigned i = t + k * ST;
     ok[k] = i < n;
+    wk[k] = __builtin_amdgcn_readfirstlane(m.sv_wid[i >> 6]);
     r[k] = v[k] = tv[k] = 0.0;
 #pragma unroll
     for (int w2 = 0; w2 < W / 2; w2++) {
@@ -176,7 +179,7 @@ __global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2
     _Pragma("unroll") for (int w = 0; w < W; w++) {                                              \
       const double *Bw = Bg + (size_t)w * (unsigned)NP;                                          \
       const unsigned c8 = (w & 1) ? (cpk[k][w >> 1] >> 16) : (cpk[k][w >> 1] & 0xffffu);         \
-      acc = acc + Bw[o_] * *(const double *)((const char *)(vec) + c8);                                            \
+      if (w < wk[k]) acc = acc + Bw[o_] * *(const double *)((const char *)(vec) + c8);           /* beyond the width: + 0.0 * x, skipped */ \
     }                                                                                            \
   }
   double prr = 0.0;
@@ -251,7 +254,7 @@ __global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2
 #undef SPMV_ROW
 #pragma unroll
   for (int k = 0; k < R; k++)
-    if (ok[k]) { const unsigned i = t + k * ST; m.d_eta[i] = yl[i] * (1.0 / m.sv_dinv[i]); }
+    if (ok[k]) { const unsigned i = t + k * ST; const int row = m.sv_perm[i]; m.d_eta[row] = yl[i] * (1.0 / m.sv_dinv[row]); }
   if (t == 0) { m.sv_info[0] = it; m.sv_resid[0] = sqrt(rr > 0.0 ? rr : 0.0); if (m.sv_extrap && m.sv_info[1] < 3) m.sv_info[1] = m.sv_info[1] + 1; }
 }
 
@@ -271,7 +274,7 @@ int launch_solver(const DM &m, hipStream_t s, int fuse_rhs, int scale_done) {
   if (m.myN > 4 * ST || m.ssh_maxnnz > 10) return launch_solver_multi(m, s, fuse_rhs, scale_done);
   const int W = 10, NP = (m.myN + 63) / 64 * 64;
   if (!scale_done) launch_row_scale(m, s);
-  hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs);
+  hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs, 1);
   const double tol2 = 1e-10 * 1e-10;                     // bicgstab_ras.c:78,146,220
   size_t shm = (size_t)(128 + 4 * 4 * ST) * sizeof(double);
   (void)W;
@@ -417,8 +420,8 @@ int launch_named_dsolve(const DM &m, hipStream_t s, const char *name) {
 #define DSW(k, ...) do { if (W == 10) hipLaunchKernelGGL(k<10>, dim3(nblk), dim3(DSB), 0, s, __VA_ARGS__); else hipLaunchKernelGGL(k<16>, dim3(nblk), dim3(DSB), 0, s, __VA_ARGS__); } while (0)
   if (!strcmp(name, "ds_scale")) { launch_row_scale(m, s); return 0; }
   if (!strcmp(name, "ds_setup")) {
-    if (W == 10) hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, 0);
-    else hipLaunchKernelGGL(k_solver_setup<16>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, 0);
+    if (W == 10) hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, 0, 0);
+    else hipLaunchKernelGGL(k_solver_setup<16>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, 0, 0);
     return 0;
   }
   const double tol2 = 1e-10 * 1e-10; const int maxits = 2000;      // bicgstab_ras.c:78,146,220 / solve_ssh_ale
@@ -545,8 +548,8 @@ int launch_solver_multi(const DM &m, hipStream_t s, int fuse_rhs, int scale_done
   const int W = m.ssh_maxnnz <= 10 ? 10 : 16, NP = (m.myN + 63) / 64 * 64, nblk = (m.myN + DSB - 1) / DSB;
   const double tol2 = 1e-10 * 1e-10; const int maxits = 2000;
   if (!scale_done) launch_row_scale(m, s);
-  if (W == 10) hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs);
-  else hipLaunchKernelGGL(k_solver_setup<16>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs);
+  if (W == 10) hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs, 0);
+  else hipLaunchKernelGGL(k_solver_setup<16>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs, 0);
   static double *hk = nullptr;                                   // pinned copy of the scalar state
   static int last_its = 24;
   if (!hk && hipHostMalloc((void **)&hk, 16 * sizeof(double)) != hipSuccess) return 1;

@@ -8,11 +8,13 @@
 orc_ctx C_;
 
 typedef struct { const char *name; double **p; size_t cnt; } field_t;
-static field_t F_[96];
+#define ORC_MAXF 192
+static field_t F_[ORC_MAXF];
 static int nF_ = 0;
 
 static void reg(const char *name, double **p, size_t cnt) {
   *p = (double *)calloc(cnt ? cnt : 1, sizeof(double));
+  if (nF_ >= ORC_MAXF) { fprintf(stderr, "orc: field registry full\n"); abort(); }
   F_[nF_].name = name; F_[nF_].p = p; F_[nF_].cnt = cnt; nF_++;
 }
 
@@ -92,6 +94,9 @@ double orc_solver_residual(void) { return C_.solver_resid; }
  * the solver tolerance, not bit for bit.  Dot products use the fixed reduction order of the HIP kernel
  * (SOLVER_T partial sums with stride SOLVER_T, a fixed tree inside each block of 64, then the same 16-wide tree over the 16 block sums) so that oracle == HIP bitwise. */
 #define SOLVER_T 1024
+/* Row order of the one-workgroup HIP solve: rows sorted by their number of entries (stable, descending), thread t owns the rows
+ * at positions t, t+1024, ...; NULL = natural order.  Only the dot products depend on it. */
+static const int *solver_perm = NULL;
 static double row_tree16(double *x) {                    /* x[l] += x[l-s], s = 8,4,2,1 ; total in x[15] */
   for (int s = 8; s >= 1; s >>= 1)
     for (int l = 15; l >= 16 - s; l--) x[l] = x[l] + x[l - s];
@@ -102,7 +107,7 @@ static double dot_fixed(const double *x, const double *y, int n) {
   double wave[16];
   for (int t = 0; t < SOLVER_T; t++) {
     double s = 0.0;
-    for (int i = t; i < n; i += SOLVER_T) s = s + x[i] * y[i];
+    for (int i = t; i < n; i += SOLVER_T) { const int r_ = solver_perm ? solver_perm[i] : i; s = s + x[r_] * y[r_]; }
     part[t] = s;
   }
   for (int w = 0; w < 16; w++) {                         /* one wave = 4 rows of 16 partial sums */
@@ -133,6 +138,17 @@ void orc_solve_ssh(void) {
   int n = C_.m.myDim_nod2D;
   const int *rp = C_.m.ssh_rowptr, *ci = C_.m.ssh_colind_loc;
   int off = rp[0];
+  int *perm = NULL;
+  {
+    int maxnnz = 0;
+    for (int i = 0; i < n; i++) maxnnz = rp[i + 1] - rp[i] > maxnnz ? rp[i + 1] - rp[i] : maxnnz;
+    if (n <= 4 * SOLVER_T && maxnnz <= 10) {               /* (csrc/api.hip: solver_row_order) */
+      perm = malloc(sizeof(int) * n);
+      int q = 0;
+      for (int w = maxnnz; w >= 0; w--) for (int i = 0; i < n; i++) if (rp[i + 1] - rp[i] == w) perm[q++] = i;
+    }
+  }
+  solver_perm = perm;
   double *B = malloc(sizeof(double) * C_.m.ssh_nza), *diag = malloc(sizeof(double) * n * 10);
   double *dinv = diag + n, *b = dinv + n, *r = b + n, *r0 = r + n, *pv = r0 + n, *v = pv + n, *s = v + n, *t = s + n, *y = t + n;
   double *x = C_.d_eta;
@@ -186,7 +202,7 @@ void orc_solve_ssh(void) {
   }
   for (int i = 0; i < n; i++) x[i] = y[i] * (1.0 / diag[i]);
   C_.solver_iters = it; C_.solver_resid = sqrt(rr > 0.0 ? rr : 0.0);
-  free(B); free(diag);
+  free(B); free(diag); free(perm); solver_perm = NULL;
 }
 
 /* oce_timestep_ale sequence for the supported options: src/oce_ale.F90:2556-2767 (+ fvom_main.F90:216) */
