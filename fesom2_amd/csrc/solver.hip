@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2
   extern __shared__ double lds[];
   constexpr int R = 4, NP4 = R * ST;
   double *bufA = lds, *bufB = lds + 64;
-  double *pl = lds + 128, *sl = pl + NP4, *yl = sl + NP4, *r0l = yl + NP4;
+  double *pl = lds + 128, *sl = pl + NP4;                 // gathered vectors p, s in LDS; r~ and y are only read by their owner: registers
   const unsigned t = threadIdx.x;
   const unsigned n = (unsigned)m.myN;
   const double *Bg = m.sv_vals;
@@ -154,13 +154,13 @@ __global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2
   unsigned cpk[R][W / 2];                                  // two byte offsets (col*8 < 65536) per register
   bool ok[R];
   int wk[R];                                               // ELL width of this wavefront's rows in slab k (rows are sorted by width)
-  double r[R], v[R], tv[R];
+  double r[R], v[R], tv[R], r0[R], y[R];
 #pragma unroll
   for (int k = 0; k < R; k++) {
     const unsigned i = t + k * ST;
     ok[k] = i < n;
     wk[k] = __builtin_amdgcn_readfirstlane(m.sv_wid[i >> 6]);
-    r[k] = v[k] = tv[k] = 0.0;
+    r[k] = v[k] = tv[k] = r0[k] = y[k] = 0.0;
 #pragma unroll
     for (int w2 = 0; w2 < W / 2; w2++) {
       unsigned c0 = 0, c1 = 0;
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2
       double a;
       SPMV_ROW(a, sl, k);
       double ri = m.sv_b[i] - a;
-      r[k] = ri; r0l[i] = ri; yl[i] = sl[i];
+      r[k] = ri; r0[k] = ri; y[k] = sl[i];
       prr = prr + ri * ri;
     }
   double rr, rho_new;
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2
         double a;
         SPMV_ROW(a, pl, k);
         v[k] = a;
-        p1 = p1 + r0l[t + k * ST] * a;
+        p1 = p1 + r0[k] * a;
       }
     double r0v;
     { double q1[1] = {p1}; block_reduce<1>(q1, bufA); r0v = q1[0]; }
@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2
         SPMV_ROW(a, sl, k);
         tv[k] = a;
         double si = sl[t + k * ST];
-        ptt = ptt + a * a; pts = pts + a * si; pr0t = pr0t + r0l[t + k * ST] * a; pss = pss + si * si;
+        ptt = ptt + a * a; pts = pts + a * si; pr0t = pr0t + r0[k] * a; pss = pss + si * si;
       }
     double tt, ts, r0t, ss;
     { double q4[4] = {ptt, pts, pr0t, pss}; block_reduce<4>(q4, bufB); tt = q4[0]; ts = q4[1]; r0t = q4[2]; ss = q4[3]; }
@@ -247,14 +247,14 @@ __global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2
         double si = sl[i], pi = pl[i];
         double ri = si - omega * tv[k];
         r[k] = ri;
-        yl[i] = (yl[i] + alpha * pi) + omega * si;
+        y[k] = (y[k] + alpha * pi) + omega * si;
         if (more) pl[i] = ri + beta * (pi - omega * v[k]);
       }
   }
 #undef SPMV_ROW
 #pragma unroll
   for (int k = 0; k < R; k++)
-    if (ok[k]) { const unsigned i = t + k * ST; const int row = m.sv_perm[i]; m.d_eta[row] = yl[i] * (1.0 / m.sv_dinv[row]); }
+    if (ok[k]) { const unsigned i = t + k * ST; const int row = m.sv_perm[i]; m.d_eta[row] = y[k] * (1.0 / m.sv_dinv[row]); }
   if (t == 0) { m.sv_info[0] = it; m.sv_resid[0] = sqrt(rr > 0.0 ? rr : 0.0); if (m.sv_extrap && m.sv_info[1] < 3) m.sv_info[1] = m.sv_info[1] + 1; }
 }
 
@@ -276,7 +276,7 @@ int launch_solver(const DM &m, hipStream_t s, int fuse_rhs, int scale_done) {
   if (!scale_done) launch_row_scale(m, s);
   hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs, 1);
   const double tol2 = 1e-10 * 1e-10;                     // bicgstab_ras.c:78,146,220
-  size_t shm = (size_t)(128 + 4 * 4 * ST) * sizeof(double);
+  size_t shm = (size_t)(128 + 2 * 4 * ST) * sizeof(double);       // reduction scratch + p, s
   (void)W;
   hipLaunchKernelGGL(k_solver_reg<10>, dim3(1), dim3(ST), shm, s, m, 2000, tol2, NP);
   return 0;
