@@ -141,12 +141,12 @@ __global__ void k_solver_setup(DM m, int NP, int fuse_rhs, int sorted) {      //
 // and the (pre-shifted, packed) column indices stay in registers for the whole solve; p, s, y, r~ live in LDS with a fixed
 // row stride (own-row accesses are immediate-offset, conflict-free); the operator values are the only L2 traffic in
 // the loop (coalesced, scalar base + lane offset).  Same arithmetic and reduction order as solver_body.
-template <int W>
+template <int W, int NP4, int WL, int WR>  // NP4: LDS stride of the vectors (>= rows); entries [0,WL) of every row in LDS, [WL,WL+WR) in registers
 __global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2, int NP) {
   extern __shared__ double lds[];
-  constexpr int R = 4, NP4 = R * ST;
+  constexpr int R = 4;
   double *bufA = lds, *bufB = lds + 64;
-  double *pl = lds + 128, *sl = pl + NP4;                 // gathered vectors p, s in LDS; r~ and y are only read by their owner: registers
+  double *pl = lds + 128, *sl = pl + NP4, *bl = sl + NP4;                 // gathered vectors p, s in LDS; r~ and y are only read by their owner: registers
   const unsigned t = threadIdx.x;
   const unsigned n = (unsigned)m.myN;
   const double *Bg = m.sv_vals;
@@ -155,6 +155,7 @@ __global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2
   bool ok[R];
   int wk[R];                                               // ELL width of this wavefront's rows in slab k (rows are sorted by width)
   double r[R], v[R], tv[R], r0[R], y[R];
+  double breg[R][WR > 0 ? WR : 1];
 #pragma unroll
   for (int k = 0; k < R; k++) {
     const unsigned i = t + k * ST;
@@ -167,8 +168,14 @@ __global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2
       if (ok[k]) { c0 = cg[(unsigned)(2 * w2) * NP + i]; c1 = cg[(unsigned)(2 * w2 + 1) * NP + i]; }
       cpk[k][w2] = (c0 << 3) | (c1 << 19);
     }
-    sl[i] = ok[k] ? m.sv_s[i] : 0.0;                       // y0 = D x0 from the set-up kernel
-    pl[i] = 0.0;
+    if (i < (unsigned)NP4) {
+      sl[i] = ok[k] ? m.sv_s[i] : 0.0;                     // y0 = D x0 from the set-up kernel
+#pragma unroll
+      for (int w = 0; w < WL; w++) bl[w * NP4 + i] = ok[k] ? Bg[(size_t)w * (unsigned)NP + i] : 0.0;
+      pl[i] = 0.0;
+    }
+#pragma unroll
+    for (int w = 0; w < WR; w++) breg[k][w] = ok[k] ? Bg[(size_t)(WL + w) * (unsigned)NP + i] : 0.0;
   }
   __syncthreads();
 #define SPMV_ROW(acc, vec, k)                                                                    \
@@ -179,7 +186,7 @@ __global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2
     _Pragma("unroll") for (int w = 0; w < W; w++) {                                              \
       const double *Bw = Bg + (size_t)w * (unsigned)NP;                                          \
       const unsigned c8 = (w & 1) ? (cpk[k][w >> 1] >> 16) : (cpk[k][w >> 1] & 0xffffu);         \
-      if (w < wk[k]) acc = acc + Bw[o_] * *(const double *)((const char *)(vec) + c8);           /* beyond the width: + 0.0 * x, skipped */ \
+      if (w < wk[k]) acc = acc + (w < WL ? bl[w * NP4 + o_] : (w < WL + WR ? breg[k][w - WL < 0 ? 0 : (w - WL < WR ? w - WL : 0)] : Bw[o_])) * *(const double *)((const char *)(vec) + c8);   /* beyond the width: + 0.0 * x, skipped */ \
     }                                                                                            \
   }
   double prr = 0.0;
@@ -261,7 +268,8 @@ __global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2
 void solver_prepare() {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)k_solver_reg<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_solver_reg<10, 4096, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_solver_reg<10, 3200, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
 }
@@ -276,9 +284,10 @@ int launch_solver(const DM &m, hipStream_t s, int fuse_rhs, int scale_done) {
   if (!scale_done) launch_row_scale(m, s);
   hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs, 1);
   const double tol2 = 1e-10 * 1e-10;                     // bicgstab_ras.c:78,146,220
-  size_t shm = (size_t)(128 + 2 * 4 * ST) * sizeof(double);       // reduction scratch + p, s
   (void)W;
-  hipLaunchKernelGGL(k_solver_reg<10>, dim3(1), dim3(ST), shm, s, m, 2000, tol2, NP);
+  // LDS: reduction scratch + p, s + the leading entries of every row; up to 3200 rows (pi: 3140) four of them fit, else two
+  if (m.myN <= 3200) hipLaunchKernelGGL((k_solver_reg<10, 3200, 4, 3>), dim3(1), dim3(ST), (size_t)(128 + (2 + 4) * 3200) * sizeof(double), s, m, 2000, tol2, NP);
+  else hipLaunchKernelGGL((k_solver_reg<10, 4096, 2, 3>), dim3(1), dim3(ST), (size_t)(128 + (2 + 2) * 4096) * sizeof(double), s, m, 2000, tol2, NP);
   return 0;
 }
 
