@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 
 # every distinct 3-D array once per read and once per write, gathers once per gathered value (SURVEY 8d rule)
 KERNEL_VALUES = {
     "k_vel_nodes": (2, 2, 0), "k_pressure_bv": (8, 0, 0), "k_pgf": (2, 3, 0), "k_sigma_slope": (13, 0, 0),
-    "k_pp_node_raw": (5, 0, 0), "k_pp_elem": (2, 1, 0), "k_pp_node_final": (3, 0, 0), "k_momadv_node": (5, 2, 0),
+    "k_pp": (5, 22, 0), "k_momadv_node": (5, 2, 0),
     "k_vel_rhs": (2, 10, 0), "k_visc_elem": (0, 4, 0), "k_visc_node": (2, 2, 0), "k_impl_visc": (3, 13, 0),
     "k_edge_transport": (0, 5, 0), "k_update_vel": (0, 6, 0), "k_vert_vel": (8, 3, 0),
     "k_tr_ab": (3, 0, 0), "k_tr_z": (3, 0, 0), "k_tr_grad_elem": (2, 4, 0), "k_updn_grad": (0, 2, 4), "k_flux_hor": (2, 3, 6),
@@ -246,7 +246,7 @@ def main():
         times["k_solver"] = core.kernel_time_ms("k_solver_replay", 10) * 1e-3
         its = core.solver_iterations
         for k, (a, b, c) in KERNEL_VALUES.items():
-            if args.physics != "pp" and k.startswith("k_pp_"):
+            if args.physics != "pp" and k == "k_pp":
                 continue
             # per-tracer kernels: timed as the step launches them, T and S in one launch (grid.y = 2)
             times[k] = core.kernel_time_ms(k + (":all" if k in PER_TRACER else ""), 50) * 1e-3

@@ -184,7 +184,7 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   // s0: critical chain
   K(s0, "k_vel_nodes");
   hipStreamWaitEvent(s0, ev_pb, 0);
-  if (m.p.mix_scheme == 2) { K(s0, "k_pp_node_raw"); K(s0, "k_pp_elem"); K(s0, "k_pp_node_final"); }
+  if (m.p.mix_scheme == 2) K(s0, "k_pp");          // element (Av) and node (Kv) part in one launch
   if (m.p.mix_scheme == 1) K(s0, "mixing_kpp");       // k_kpp_col, 3 smoothing sweeps, k_kpp_final, k_kpp_elem
   hipStreamWaitEvent(s0, ev_rhs, 0); hipStreamWaitEvent(s0, ev_visc, 0);
   K(s0, "k_impl_visc");                            // incl. the Thomas sweep
@@ -602,7 +602,7 @@ int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
   S.c("k_vel_nodes"); S.X(0, {"Unode"});
   S.c("k_pressure_bv"); S.c("k_pgf"); S.c("k_sigma_slope");
   if (p.Redi) S.X(0, {"slope_tapered"});
-  if (p.mix_scheme == 2) { S.c("k_pp_node_raw"); S.c("k_pp_elem"); S.c("k_pp_node_final"); }
+  if (p.mix_scheme == 2) S.c("k_pp");
   if (p.mix_scheme == 1) {
     S.c("k_kpp_col"); S.X(0, {"kpp_blmc"});
     S.c("k_kpp_smooth1"); S.X(0, {"kpp_sA"});

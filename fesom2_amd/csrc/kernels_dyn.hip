@@ -255,39 +255,46 @@ __global__ void __launch_bounds__(BLOCK) k_sigma_slope(DM m) {
 
 // ------------------------------------------------------------------------------------------------
 // oce_mixing_PP (src/oce_ale_mixing_pp.F90:2-83) + mo_convect (src/oce_mo_conv.F90:4-103, use_momix=.false.)
-__global__ void __launch_bounds__(BLOCK) k_pp_node_raw(DM m) {       // Kv <- Ri-function (first node loop)
-  int n = col_id(), nz = lane_id() + 1;
-  if (n >= m.N) return;
-  if (nz < m.ulev_n[n] + 1 || nz > m.nlev_n[n] - 1) return;
+// Ri-dependent factor of oce_mixing_PP's first node loop (:27-43) at interface nz of node n: shear^2 / (shear^2 + 5 max(N^2,0) + 1e-14)
+__device__ __forceinline__ double pp_raw(const DM &m, int nz, int n) {
   double dz_inv = 1.0 / (DA2(m.Z_3d_n, nz - 1, n) - DA2(m.Z_3d_n, nz, n));
   double du = DV2(m.Unode, 1, nz - 1, n) - DV2(m.Unode, 1, nz, n), dv = DV2(m.Unode, 2, nz - 1, n) - DV2(m.Unode, 2, nz, n);
   double shear = du * du + dv * dv;
   shear = shear * dz_inv * dz_inv;
-  DA2L(m.Kv, nz, n) = shear / (shear + 5. * dmax_(DA2L(m.bvfreq, nz, n), 0.0) + 1.0e-14);
+  return shear / (shear + 5. * dmax_(DA2L(m.bvfreq, nz, n), 0.0) + 1.0e-14);
 }
-__global__ void __launch_bounds__(BLOCK) k_pp_elem(DM m) {           // Av incl. mo_convect element part
-  int e = col_id(), nz = lane_id() + 1;
+// Av incl. mo_convect element part.  The factor of the three nodes is evaluated here again instead of read from Kv, which makes the
+// element and the node part independent of each other: both run in ONE launch (k_pp).
+__device__ __forceinline__ void pp_elem_body(const DM &m, int e) {
+  int nz = lane_id() + 1;
   if (e >= m.myE) return;
   int nzmin = m.ulev[e];
   if (nz < nzmin + 1 || nz > m.nlev[e] - 1) return;
   int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
-  double k1 = DA2L(m.Kv, nz, n1), k2 = DA2L(m.Kv, nz, n2), k3 = DA2L(m.Kv, nz, n3);
+  double k1 = pp_raw(m, nz, n1), k2 = pp_raw(m, nz, n2), k3 = pp_raw(m, nz, n3);
   double av = 0.01 * (k1 * k1 + k2 * k2 + k3 * k3) / 3.0 + m.p.A_ver;
   if (m.p.use_instabmix && (DA2L(m.bvfreq, nz, n1) < 0. || DA2L(m.bvfreq, nz, n2) < 0. || DA2L(m.bvfreq, nz, n3) < 0.))
     av = dmax_(av, m.p.instabmix_kv);
   if (nzmin <= 1 && m.p.use_windmix && nz <= m.p.windmix_nl + 1) av = dmax_(av, m.p.windmix_kv);
   DA2L(m.Av, nz, e) = av;
 }
-__global__ void __launch_bounds__(BLOCK) k_pp_node_final(DM m) {     // Kv cubic + mo_convect node part
-  int n = col_id(), nz = lane_id() + 1;
+__device__ __forceinline__ void pp_node_body(const DM &m, int n) {     // Kv: Ri factor, cubic + mo_convect node part
+  int nz = lane_id() + 1;
   if (n >= m.N) return;
   int nzmin = m.ulev_n[n];
   if (nz < nzmin + 1 || nz > m.nlev_n[n] - 1) return;
-  double k = DA2L(m.Kv, nz, n);
+  double k = pp_raw(m, nz, n);
   double kv = 0.01 * (k * k * k) + m.p.K_ver;
   if (m.p.use_instabmix && DA2L(m.bvfreq, nz, n) < 0.) kv = dmax_(kv, m.p.instabmix_kv);
   if (nzmin <= 1 && m.p.use_windmix && nz <= m.p.windmix_nl + 1) kv = dmax_(kv, m.p.windmix_kv);
   DA2L(m.Kv, nz, n) = kv;
+}
+__global__ void __launch_bounds__(BLOCK) k_pp_elem(DM m) { pp_elem_body(m, col_id()); }
+__global__ void __launch_bounds__(BLOCK) k_pp_node_final(DM m) { pp_node_body(m, col_id()); }
+// oce_mixing_PP + mo_convect in one launch: the first ncolE column slots are element columns, the rest node columns
+__global__ void __launch_bounds__(BLOCK) k_pp(DM m, int ncolE) {
+  const int c = col_id();
+  if (c < ncolE) pp_elem_body(m, c); else pp_node_body(m, c - ncolE);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -738,8 +745,8 @@ __global__ void __launch_bounds__(BLOCK) k_vert_vel(DM m, int fuse_hbar) {
 }
 
 // update_thickness_ale (src/oce_ale.F90:800-993, zstar branch)
-__global__ void __launch_bounds__(BLOCK) k_thick_node(DM m) {
-  int n = col_id(), l = lane_id(), nz = l + 1;
+__device__ __forceinline__ void thick_node_body(const DM &m, int n) {
+  int l = lane_id(), nz = l + 1;
   if (n >= m.N) return;
   int nzmin = m.ulev_n[n], nzmax = m.nlev_n_min[n] - 2;
   if (nzmin > 1) return;
@@ -755,14 +762,23 @@ __global__ void __launch_bounds__(BLOCK) k_thick_node(DM m) {
     DA2(m.Z_3d_n, nz, n) = zb_below + hn / 2.0;
   }
 }
-__global__ void __launch_bounds__(BLOCK) k_thick_elem(DM m) {
-  int e = col_id(), nz = lane_id() + 1;
+__device__ __forceinline__ void thick_elem_body(const DM &m, int e) {
+  int nz = lane_id() + 1;
   if (e >= m.myE) return;
   int nzmin = m.ulev[e], nzmax = m.nlev[e] - 1;
   if (nzmin > 1) return;
   if (nz < nzmin || nz > nzmax - 1) return;
   int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
-  DA2(m.helem, nz, e) = (DA2(m.hnode, nz, n1) + DA2(m.hnode, nz, n2) + DA2(m.hnode, nz, n3)) / 3.0;
+  // hnode after the update = hnode_new on every level the update touches, and the two are equal elsewhere: reading hnode_new
+  // makes the element part independent of the node part, so both run in ONE launch (k_thick)
+  DA2(m.helem, nz, e) = (DA2(m.hnode_new, nz, n1) + DA2(m.hnode_new, nz, n2) + DA2(m.hnode_new, nz, n3)) / 3.0;
+}
+__global__ void __launch_bounds__(BLOCK) k_thick_node(DM m) { thick_node_body(m, col_id()); }
+__global__ void __launch_bounds__(BLOCK) k_thick_elem(DM m) { thick_elem_body(m, col_id()); }
+// update_thickness_ale in one launch: the first ncolN column slots are node columns, the rest element columns
+__global__ void __launch_bounds__(BLOCK) k_thick(DM m, int ncolN) {
+  const int c = col_id();
+  if (c < ncolN) thick_node_body(m, c); else thick_elem_body(m, c - ncolN);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -775,9 +791,7 @@ void launch_dynamics_pre(const DM &m, hipStream_t s, int first_step) {
   LAUNCH_COL(k_pgf, m.myE, m);
   LAUNCH_COL(k_sigma_slope, m.myN, m);
   if (m.p.mix_scheme == 2) {
-    LAUNCH_COL(k_pp_node_raw, m.N, m);
-    LAUNCH_COL(k_pp_elem, m.myE, m);
-    LAUNCH_COL(k_pp_node_final, m.N, m);
+    hipLaunchKernelGGL(k_pp, dim3(nblocks(m.myE) + nblocks(m.N)), dim3(BLOCK), 0, s, m, nblocks(m.myE) * COLS_PER_BLOCK);
   }
   if (m.p.mix_scheme == 1) launch_named_kpp(m, s, "mixing_kpp");
   LAUNCH_COL(k_momadv_node, m.myN, m);
@@ -801,8 +815,8 @@ void launch_dynamics_post(const DM &m, hipStream_t s) {
 }
 void launch_thickness(const DM &m, hipStream_t s) {
   if (m.p.which_ale != 2) return;
-  LAUNCH_COL(k_thick_node, m.N, m);
-  LAUNCH_COL(k_thick_elem, m.myE, m);
+  const int ncolN = nblocks(m.N) * COLS_PER_BLOCK;
+  hipLaunchKernelGGL(k_thick, dim3(nblocks(m.N) + nblocks(m.myE)), dim3(BLOCK), 0, s, m, ncolN);
 }
 
 int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int first_step) {
@@ -814,7 +828,7 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
     if (!strcmp(name, "k_pressure_bv")) { LAUNCH_COL(k_pressure_bv, m.N, m); return 0; }
     if (!strcmp(name, "k_pgf")) { LAUNCH_COL(k_pgf, m.myE, m); return 0; }
     if (!strcmp(name, "k_sigma_slope")) { LAUNCH_COL(k_sigma_slope, m.myN, m); return 0; }
-    if (!strcmp(name, "k_pp_node_raw")) { LAUNCH_COL(k_pp_node_raw, m.N, m); return 0; }
+    if (!strcmp(name, "k_pp")) { hipLaunchKernelGGL(k_pp, dim3(nblocks(m.myE) + nblocks(m.N)), dim3(BLOCK), 0, s, m, nblocks(m.myE) * COLS_PER_BLOCK); return 0; }
     if (!strcmp(name, "k_pp_elem")) { LAUNCH_COL(k_pp_elem, m.myE, m); return 0; }
     if (!strcmp(name, "k_pp_node_final")) { LAUNCH_COL(k_pp_node_final, m.N, m); return 0; }
     if (!strcmp(name, "k_momadv_node")) { LAUNCH_COL(k_momadv_node, m.myN, m); return 0; }
@@ -842,7 +856,7 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
   if (!strcmp(name, "compute_sigma_xy")) { LAUNCH_COL(k_sigma_slope, m.myN, m); return 0; } // includes neutral slope
   if (!strcmp(name, "compute_neutral_slope")) return 0;
   if (!strcmp(name, "mixing_pp")) {
-    LAUNCH_COL(k_pp_node_raw, m.N, m); LAUNCH_COL(k_pp_elem, m.myE, m); LAUNCH_COL(k_pp_node_final, m.N, m); return 0;
+    hipLaunchKernelGGL(k_pp, dim3(nblocks(m.myE) + nblocks(m.N)), dim3(BLOCK), 0, s, m, nblocks(m.myE) * COLS_PER_BLOCK); return 0;
   }
   if (!strcmp(name, "mo_convect")) return 0;                                                  // fused into mixing_pp
   if (!strcmp(name, "compute_vel_rhs")) { LAUNCH_COL(k_momadv_node, m.myN, m); LAUNCH_COL(k_vel_rhs, m.myE, m, first_step); return 0; }

@@ -45,7 +45,7 @@ def run_step(core, par, X, solve, first, probe=None):
     if p.Redi:
         X(NOD, ["slope_tapered"])
     if p.mix_scheme == 2:
-        c("k_pp_node_raw"); c("k_pp_elem"); c("k_pp_node_final"); P("mixing")
+        c("k_pp"); P("mixing")
     if p.mix_scheme == 1:                             # KPP: smoothing of blmc needs the neighbours' values after every sweep
         c("k_kpp_col"); X(NOD, ["kpp_blmc"])
         c("k_kpp_smooth1"); X(NOD, ["kpp_sA"])
