@@ -270,6 +270,9 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   G.serial = getenv("FESOM_GPU_SERIAL") != nullptr;
   // Measured on MI355X/ROCm 7.2 (pi): eager 4-stream DAG 0.80 ms/step, hipGraph of the same DAG 0.86, serial chain 0.90
   // (graph replay serialises most branches; kernels are >= 5 us so the host launch rate is not the limit).
+  // Default: the eager 4-stream DAG (pooled events).  FESOM_GPU_GRAPH=1 replays the same DAG as ONE hipGraph; it is no faster on pi
+  // and the HIP runtime bundled with PyTorch 2.10 (ROCm 7.0) recurses without bound in hipStreamEndCapture for this multi-stream
+  // capture (the ROCm 7.2 runtime of /opt/rocm is fine), so it stays opt-in for hosts that link the system runtime.
   G.use_graph = getenv("FESOM_GPU_GRAPH") != nullptr;
   DM &m = G.m;
   memset(&m, 0, sizeof(m));

@@ -1,0 +1,12 @@
+import sys, os
+sys.path.insert(0, os.getcwd())
+from fesom2_amd.mesh import Mesh
+from fesom2_amd.config import make_params
+from fesom2_amd.core import OceanCore
+from fesom2_amd.synthetic import analytic_ts
+PI = os.path.join(os.getcwd(), "tests", "golden", "meshes", "pi")
+mesh = Mesh.load(PI, dt=900.0)
+st = mesh.initial_state(2); st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI); st.tr_arr_old[...] = st.tr_arr
+core = OceanCore(mesh, make_params(dt=900.0)); core.upload_state(st)
+core.run_steps(1, 5)
+print("ok", core.get("eta_n", 3140)[:3])
