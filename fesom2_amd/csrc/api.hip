@@ -199,18 +199,17 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   hipEvent_t ev_w = d.ev(); hipEventRecord(ev_w, s0);
   hipStreamWaitEvent(s1, ev_w, 0);
   K(s1, "k_dhe");
-  K(s1, "k_tr_z", 0);                              // vertical tracer gradient: only consumed by Redi, off the chain
+  if (redi) K(s1, "k_tr_z", 0);                    // vertical tracer gradient: only the Redi terms read it (the named routine init_tracers_AB always forms it)
   hipStreamWaitEvent(s0, ev_prep, 0);
   hipEvent_t ev_df = nullptr;
   if (redi && m.p.with_diffusion) { hipStreamWaitEvent(s1, ev_prep, 0); K(s1, "k_diff_flux", 0); ev_df = d.ev(); hipEventRecord(ev_df, s1); }
   K(s0, "k_flux_hor", 0); K(s0, "k_fct_lo_node", 0); K(s0, "k_fct_node", 0);
-  hipEvent_t ev_fct = d.ev(); hipEventRecord(ev_fct, s0);
-  hipStreamWaitEvent(s1, ev_fct, 0);
-  K(s1, "k_fct_edge_limit", 0);                    // materialises the limited flux field; k_tr_update limits on the fly
+  // (k_fct_edge_limit only materialises the limited flux field adv_flux_hor, which no kernel of the step reads -- k_tr_update limits on
+  // the fly: it is part of the named routine adv_tracers_ale, not of the running step)
   if (ev_df) hipStreamWaitEvent(s0, ev_df, 0);
   K(s0, "k_tr_update", 0);                         // incl. the Thomas sweep
   if (toy) for (int tr = 0; tr < m.ntr; tr++) launch_named_toy(m, s0, "relax_zonal_temp");   // once per tracer
-  if (gm) { d.dep(s0, s1); launch_named_gm(m, s0, "bolus_remove"); }       // :165-169 (k_fct_edge_limit on s1 still reads nothing of it)
+  if (gm) launch_named_gm(m, s0, "bolus_remove");                          // :165-169
   d.dep(s0, s1); d.dep(s0, s2); d.dep(s0, s3);
   launch_thickness(m, s0);
 }
