@@ -61,6 +61,10 @@ int orc_init(const fesom_mesh_desc *m, const fesom_params *p) {
     for (size_t k = 0; k < n1; k++) C_.Ki[n * n1 + k] = p->K_hor * (r * r);
   }
   for (size_t n = 0; n < N; n++) C_.kpp_sw_node[n] = (double)m->myDim_nod2D;
+  if (p->mix_scheme == 0) {               /* no mixing scheme (an option of this build, not of the reference): constant A_ver / K_ver */
+    for (size_t i = 0; i < nl * E; i++) C_.Av[i] = p->A_ver;
+    for (size_t i = 0; i < nl * N; i++) C_.Kv[i] = p->K_ver;
+  }
   { extern void orc_gm_static(void); if (p->Fer_GM) orc_gm_static(); }
   return 0;
 }

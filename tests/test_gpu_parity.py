@@ -326,3 +326,49 @@ def test_w_split_chain_and_steps_bitwise(built):
         ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
         assert ok, msg
     gpu.close()
+
+
+FUZZ = [
+    dict(dt=450.0, which_ale="zstar", use_partial_cell=False, state_equation=1, mix_scheme="PP", w_split=True, w_max_cfl=0.0005),
+    dict(dt=1200.0, which_ale="zstar", use_partial_cell=True, state_equation=0, mix_scheme="KPP", Fer_GM=True, scaling_Ferreira=True),
+    dict(dt=900.0, which_ale="linfs", use_partial_cell=False, state_equation=1, mix_scheme="KPP", use_sw_pene=True),
+    dict(dt=900.0, which_ale="linfs", use_partial_cell=True, state_equation=0, mix_scheme="PP", Fer_GM=True, scaling_FESOM14=True, K_GM_bvref=1),
+    dict(dt=600.0, which_ale="zstar", use_partial_cell=True, state_equation=1, mix_scheme="none", use_windmix=True, K_hor=500.0),
+    dict(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equation=1, mix_scheme="KPP", Fer_GM=True, K_GM_bvref=0, scaling_Ferreira=True,
+         w_split=True, w_max_cfl=0.001, use_sw_pene=True, solver_x0_order=0),
+]
+
+
+@pytest.mark.parametrize("case", range(len(FUZZ)))
+def test_option_combinations_bitwise(built, case):
+    """Combinations of the options the library accepts (ALE variant, partial cells, EOS, mixing scheme, GM scalings, w_split, short-wave
+    penetration, time step, initial-guess order), 8 whole steps under scaled surface forcing: HIP == oracle bit for bit.  (Redi stays
+    out: tanh, see test_redi_chain_bitwise_and_steps.)  The oracle is pinned on reference runs for the configurations of
+    tests/test_oracle_vs_reference.py; here the point is that every option path of the HIP code agrees with its restatement."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.core import OceanCore
+    from fesom2_amd.synthetic import analytic_ts, analytic_forcing, analytic_sw_3d
+    from oracle_lib import Oracle
+    kw = dict(FUZZ[case])
+    dt, ale, pc = kw.pop("dt"), kw.pop("which_ale"), kw.pop("use_partial_cell")
+    mesh = Mesh.load(PI, dt=dt, which_ale=ale, use_partial_cell=pc)
+    par = make_params(dt=dt, which_ale=ale, use_partial_cell=pc, **kw)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    gpu, orc = OceanCore(mesh, par), Oracle(mesh, par)
+    gpu.upload_state(st); orc.set_state(st)
+    forcing = {k: v * (0.5 + 0.25 * case) for k, v in analytic_forcing(mesh).items()}
+    if kw.get("use_sw_pene"):
+        forcing["sw_3d"] = analytic_sw_3d(mesh, forcing["heat_flux"])
+    gpu.set_forcing(**forcing)
+    for k, v in forcing.items():
+        orc.set(k, v)
+    gpu.run_steps(1, 8)
+    for n in range(1, 9):
+        orc.call("step", n)
+    for f in ("tr_arr", "UV", "eta_n", "hnode", "Wvel", "Kv", "Av"):
+        ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+        assert ok, (FUZZ[case], msg)
+    gpu.close()
