@@ -86,6 +86,30 @@ class Mesh:
         shp = state_shapes(self.d, num_tracers)
         return State({k: _view(getattr(s, k), shp[k]).copy() for k in _lib.STATE_FIELDS}, self, num_tracers)
 
+    def level_area_test(self):
+        """check_mesh_consistency of the reference (src/oce_mesh.F90:2452-2494): per level, the sum of the nodal control-volume
+        areas (areasvol) over the owned wet nodes and the sum of the areas of the wet elements whose first node is owned; the two
+        agree to round-off on a consistent mesh.  Returns (vol_n, vol_e), arrays of length nl; rank-local sums on a partition."""
+        nl, myN, myE = self.nl, self.myDim_nod2D, self.d.myDim_elem2D
+        lev = np.arange(1, nl + 1)[None, :]
+        wet_n = (lev >= self.ulevels_nod2D[:myN, None]) & (lev <= self.nlevels_nod2D[:myN, None] - 1)
+        vol_n = np.where(wet_n, self.areasvol[:myN], 0.0).sum(axis=0)
+        first_owned = self.elem2D_nodes[:myE, 0] <= myN
+        wet_e = (lev >= self.ulevels[:myE, None]) & (lev <= self.nlevels[:myE, None] - 1) & first_owned[:, None]
+        vol_e = np.where(wet_e, self.elem_area[:myE, None], 0.0).sum(axis=0)
+        return vol_n, vol_e
+
+    def total_volume(self, state):
+        """check_total_volume (src/oce_mesh.F90:2509-2550): ocean volume from the node columns and from the element columns"""
+        nl, myN, myE = self.nl, self.myDim_nod2D, self.d.myDim_elem2D
+        lev = np.arange(1, nl)[None, :]
+        wet_n = (lev >= self.ulevels_nod2D[:myN, None]) & (lev <= self.nlevels_nod2D[:myN, None] - 1)
+        vn = float(np.where(wet_n, self.areasvol[:myN, :nl - 1] * state.hnode[:myN], 0.0).sum())
+        first_owned = self.elem2D_nodes[:myE, 0] <= myN
+        wet_e = (lev >= self.ulevels[:myE, None]) & (lev <= self.nlevels[:myE, None] - 1) & first_owned[:, None]
+        ve = float(np.where(wet_e, self.elem_area[:myE, None] * state.helem[:myE], 0.0).sum())
+        return vn, ve
+
     def wet_counts(self):
         """(N3, E3, D3) = wet node cells, prism cells, edge cells (SURVEY.md conventions)."""
         n3 = int((self.nlevels_nod2D[: self.myDim_nod2D] - 1).sum())

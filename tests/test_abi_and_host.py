@@ -118,3 +118,17 @@ def test_refined_mesh_is_consistent(built, tmp_path):
     assert abs(b.elem_area.sum() / a.elem_area.sum() - 1.0) < 2e-3          # (flat triangles on the sphere: not exactly additive)
     assert (b.nlevels_nod2D >= 2).all() and b.nl == a.nl
     a.free(); b.free()
+
+
+def test_level_area_and_volume_checks_match_reference_printout(built):
+    """check_mesh_consistency / check_total_volume (src/oce_mesh.F90:2452-2550) restated on the host mesh layer, against the numbers
+    the reference itself printed on the pi mesh (tests/golden/level_area_test_pi.json)"""
+    import json
+    from fesom2_amd.mesh import Mesh
+    mesh = Mesh.load(PI, dt=900.0)
+    ref = json.load(open(os.path.join(REPO, "tests", "golden", "level_area_test_pi.json")))
+    vn, ve = mesh.level_area_test()
+    assert np.allclose(vn, ref["vol_n"], rtol=1e-13, atol=0) and np.allclose(ve, ref["vol_e"], rtol=1e-13, atol=0)
+    assert np.allclose(vn, ve, rtol=1e-13)
+    tn, te = mesh.total_volume(mesh.initial_state(2))
+    assert abs(tn - te) < 1e-3 * tn and tn > 1e17        # (node and element columns differ in their partial bottom cells)
