@@ -169,6 +169,26 @@ contains
     f%sPE = ai(c%sPE); f%sptr = ai(c%sptr); f%slist = ai(c%slist)
   end subroutine
 
+  ! every message this rank sends is one its neighbour expects, item for item (the reference's DEBUG check, check_mpi_comm in
+  ! src/gen_halo_exchange.F90:25-55): an inconsistent partition stops here through status_check instead of hanging in the first exchange
+  subroutine check_plan(c, what)
+    type(com_struct), intent(in) :: c
+    character(*), intent(in) :: what
+    integer :: scnt(0:npes-1), rexp(0:npes-1), got(0:npes-1), p, ierr
+    scnt = 0; rexp = 0
+    do p = 1, c%sPEnum
+       scnt(c%sPE(p)) = c%sptr(p+1) - c%sptr(p)
+    end do
+    do p = 1, c%rPEnum
+       rexp(c%rPE(p)) = c%rptr(p+1) - c%rptr(p)
+    end do
+    call MPI_ALLTOALL(scnt, 1, MPI_INTEGER, got, 1, MPI_INTEGER, MPI_COMM_FESOM, ierr)
+    if (any(got /= rexp)) then
+       write(*,*) 'fesom_gpu: halo plan mismatch (', what, ') on rank ', mype
+       pe_status = 1
+    end if
+  end subroutine
+
   subroutine state_desc(mesh, st)
     type(t_mesh), intent(in), target :: mesh
     type(fesom_state_desc), intent(out) :: st
@@ -217,6 +237,8 @@ contains
        call fill_com(com_elem2D, gpart%com_elem2D)
        call fill_com(com_elem2D_full, gpart%com_elem2D_full)
        pp = c_loc(gpart)
+       call check_plan(com_nod2D, 'nod2D'); call check_plan(com_elem2D, 'elem2D'); call check_plan(com_elem2D_full, 'elem2D_full')
+       call status_check
     end if
 
     p%dt = dt

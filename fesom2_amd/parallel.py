@@ -120,6 +120,24 @@ class HaloExchanger:
             assert rcode == 0, lib.fesom_gpu_last_error().decode()
             self.info.append(dict(rPE=list(rPE[: nr.value]), rcnt=list(rc[: nr.value]), sPE=list(sPE[: ns.value]), scnt=list(sc[: ns.value])))
         self.npes, self.mype = npes.value, mype.value
+        if self.npes > 1:
+            self.check_plan()
+
+    def check_plan(self):
+        """every message this rank will send is a message its neighbour expects, item for item (the reference's DEBUG check of the
+        halo exchange, check_mpi_comm in src/gen_halo_exchange.F90:25-55): an inconsistent partition fails here, not as a hang"""
+        mine = [(dict(zip(i["sPE"], i["scnt"])), dict(zip(i["rPE"], i["rcnt"]))) for i in self.info]
+        plans = [None] * self.npes
+        dist.all_gather_object(plans, mine, group=self.group)
+        for kind in range(3):
+            for pe, cnt in mine[kind][0].items():
+                got = plans[pe][kind][1].get(self.mype)
+                if got != cnt:
+                    raise RuntimeError(f"halo plan mismatch (kind {kind}): rank {self.mype} sends {cnt} items to {pe}, which expects {got}")
+            for pe, cnt in mine[kind][1].items():
+                got = plans[pe][kind][0].get(self.mype)
+                if got != cnt:
+                    raise RuntimeError(f"halo plan mismatch (kind {kind}): rank {self.mype} expects {cnt} items from {pe}, which sends {got}")
 
     def _chk(self, rc, what):
         if rc != 0:
