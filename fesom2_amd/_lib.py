@@ -106,7 +106,7 @@ class MeshOpts(C.Structure):
 EXPORTS = ("fesom_gpu_init", "fesom_gpu_upload_state", "fesom_gpu_download_state", "fesom_gpu_set_forcing",
            "fesom_gpu_step", "fesom_gpu_run_steps", "fesom_gpu_finalize", "fesom_gpu_get_field",
            "fesom_gpu_set_field", "fesom_gpu_call", "fesom_gpu_last_solver_iterations",
-           "fesom_gpu_last_solver_residual", "fesom_gpu_kernel_time_ms", "fesom_gpu_last_error", "fesom_gpu_step_info", "fesom_gpu_step_partitioned",
+           "fesom_gpu_last_solver_residual", "fesom_gpu_kernel_time_ms", "fesom_gpu_last_error", "fesom_gpu_step_info", "fesom_gpu_step_partitioned", "fesom_gpu_profile_step",
            "psolver_init", "psolve", "psolver_final",
            "fesom_gpu_halo_info", "fesom_gpu_halo_pack", "fesom_gpu_halo_unpack", "fesom_gpu_copy", "fesom_gpu_sync", "fesom_gpu_set_stream", "fesom_gpu_field_ptr",
            "fesom_mesh_load", "fesom_mesh_get_desc", "fesom_mesh_get_part", "fesom_mesh_get_initial_state",
@@ -147,5 +147,6 @@ def load():
     lib.fesom_gpu_last_error.restype = C.c_char_p
     lib.fesom_gpu_step_info.argtypes = [C.POINTER(StepInfo)]
     lib.fesom_gpu_step_partitioned.argtypes = [C.c_int, C.POINTER(Transport)]
+    lib.fesom_gpu_profile_step.argtypes = [C.c_int, PD]
     _lib = lib
     return lib

@@ -61,6 +61,12 @@ class OceanCore:
         self._chk(self.lib.fesom_gpu_step_info(C.byref(si)), "step_info")
         return {n: getattr(si, n) for n in _lib.STEP_INFO_FIELDS}
 
+    def profile_step(self, n=1):
+        """one step, phase by phase; returns the device ms of the reference's phase timers (mixpres, dyn, dynssh, solvessh, GMRedi, solvetra, total)"""
+        ms = (C.c_double * 7)()
+        self._chk(self.lib.fesom_gpu_profile_step(int(n), ms), "profile_step")
+        return dict(zip(("mixpres", "dyn", "dynssh", "solvessh", "GMRedi", "solvetra", "total"), list(ms)))
+
     def kernel_time_ms(self, group, nrep=20):
         ms = C.c_double(0.0)
         self._chk(self.lib.fesom_gpu_kernel_time_ms(group.encode(), int(nrep), C.byref(ms)), f"kernel_time_ms({group})")

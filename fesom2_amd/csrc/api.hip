@@ -667,6 +667,59 @@ int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
   return S.rc;
 }
 
+int fesom_gpu_profile_step(int n, double ms[7]) {
+  NEED_READY();
+  if (G.npes > 1 || G.m.p.toy_soufflet) { G.err = "profile_step: single partition without the toy hooks only"; return 1; }
+  (void)n;
+  const fesom_params &p = G.m.p;
+  hipEvent_t t[11];
+  for (auto &e : t) HIPCHK(hipEventCreate(&e));
+  int bad = 0;
+  auto c = [&](const char *name, int arg = 0) { bad |= call_named(name, arg); };
+  auto T = [&](int i) { hipEventRecord(t[i], G.stream); };
+  c("compute_vel_nodes");                                                   // fvom_main.F90:216, outside the reference's t0..t10
+  T(0);
+  c("pressure_bv"); c("pressure_force"); c("sw_alpha_beta"); c("compute_sigma_xy"); c("compute_neutral_slope");
+  if (p.mix_scheme == 2) { c("mixing_pp"); c("mo_convect"); }
+  if (p.mix_scheme == 1) { c("mixing_kpp"); c("mo_convect"); }
+  T(1);
+  c("compute_vel_rhs"); c("visc_filt_bcksct"); if (p.i_vert_visc) c("impl_vert_visc_ale");
+  T(2);
+  if (p.which_ale != 0) c("update_stiff_mat_ale");
+  c("compute_ssh_rhs_ale");
+  T(10);                                                                    // t30
+  c("solve_ssh");
+  T(3);
+  c("update_vel");
+  T(4);
+  c("compute_hbar_ale"); c("eta_update");
+  T(5);
+  if (p.Fer_GM || p.Redi) c("init_Redi_GM");
+  if (p.Fer_GM) { c("fer_solve_Gamma"); c("fer_gamma2vel"); }
+  T(6);
+  c("vert_vel_ale"); if (p.Fer_GM) c("fer_wvel");
+  T(7);
+  if (p.Fer_GM) c("bolus_add");
+  for (int tr = 1; tr <= G.m.ntr; tr++) { c("init_tracers_AB", tr); c("adv_tracers_ale", tr); c("diff_tracers_ale", tr); }
+  if (p.Fer_GM) c("bolus_remove");
+  c("salinity_clamp");
+  T(8);
+  c("update_thickness_ale");
+  T(9);
+  HIPCHK(hipEventSynchronize(t[9]));
+  auto dtm = [&](int a, int b) { float x = 0; hipEventElapsedTime(&x, t[a], t[b]); return (double)x; };
+  ms[0] = dtm(0, 1);                                  // rtime_oce_mixpres
+  ms[1] = dtm(1, 2) + dtm(6, 7) + dtm(3, 4);          // rtime_oce_dyn
+  ms[2] = dtm(2, 3) + dtm(4, 5);                      // rtime_oce_dynssh (includes the solve, as in the reference)
+  ms[3] = dtm(10, 3);                                 // rtime_oce_solvessh
+  ms[4] = dtm(5, 6);                                  // rtime_oce_GMRedi
+  ms[5] = dtm(7, 8);                                  // rtime_oce_solvetra
+  ms[6] = dtm(0, 9);                                  // rtime_oce
+  for (auto &e : t) hipEventDestroy(e);
+  if (bad) { if (G.err.empty()) G.err = "profile_step: a routine of the chain is unknown"; return 1; }
+  return 0;
+}
+
 int fesom_gpu_step_info(fesom_step_info *out) {
   NEED_READY();
   static_assert(sizeof(fesom_step_info) == 42 * sizeof(double), "fesom_step_info = 42 doubles");

@@ -22,7 +22,10 @@ module fesom_gpu_shim
   use g_forcing_arrays, only: real_salt_flux, sw_3d
   implicit none
   private
-  public :: fesom_gpu_setup, oce_timestep_ale_gpu, fesom_gpu_fetch_state, fesom_gpu_push_state, fesom_gpu_shutdown
+  public :: fesom_gpu_setup, oce_timestep_ale_gpu, fesom_gpu_fetch_state, fesom_gpu_push_state, fesom_gpu_shutdown, fesom_gpu_profile
+  ! .true.: every step runs phase by phase (fesom_gpu_profile_step) and its device times are added to the reference's own phase
+  ! statistics rtime_oce* (src/oce_ale.F90:2771-2777, printed by fvom_main's BENCHMARK RUNTIME block); slower than the normal step
+  logical, save :: fesom_gpu_profile = .false.
 
   ! ---- struct layouts = include/fesom_gpu.h, field by field
   type, bind(C) :: fesom_mesh_desc
@@ -104,6 +107,11 @@ module fesom_gpu_shim
        type(c_ptr), value :: dst, src
        integer(c_long_long), value :: bytes
        integer(c_int), value :: dir              ! 0: device -> host, 1: host -> device
+     end function
+     integer(c_int) function c_fesom_gpu_profile_step(n, ms) bind(C, name='fesom_gpu_profile_step')
+       import
+       integer(c_int), value :: n
+       real(c_double), intent(out) :: ms(7)
      end function
      integer(c_int) function c_fesom_gpu_finalize() bind(C, name='fesom_gpu_finalize')
        import
@@ -282,6 +290,7 @@ contains
     integer, intent(in) :: n
     type(t_mesh), intent(in), target :: mesh
     type(fesom_forcing_desc) :: f
+    real(c_double) :: pms(7)
     if (.not. is_setup) call fesom_gpu_setup(mesh)
     f%stress_surf = ar(stress_surf); f%heat_flux = ar(heat_flux); f%water_flux = ar(water_flux)
     f%virtual_salt = ar(virtual_salt); f%relax_salt = ar(relax_salt)
@@ -294,7 +303,13 @@ contains
     f%sw_3d = c_null_ptr
     if (use_sw_pene .and. allocated(sw_3d)) f%sw_3d = ar(sw_3d)
     call check(c_fesom_gpu_set_forcing(f), 'fesom_gpu_set_forcing')
-    if (npes > 1) then     ! the library runs the phases and the partitioned SSH solve, this layer moves the halo bytes with MPI
+    if (fesom_gpu_profile .and. npes == 1) then
+       call check(c_fesom_gpu_profile_step(int(n, c_int), pms), 'fesom_gpu_profile_step')
+       rtime_oce_mixpres = rtime_oce_mixpres + pms(1)*1.0e-3_WP; rtime_oce_dyn = rtime_oce_dyn + pms(2)*1.0e-3_WP
+       rtime_oce_dynssh = rtime_oce_dynssh + pms(3)*1.0e-3_WP; rtime_oce_solvessh = rtime_oce_solvessh + pms(4)*1.0e-3_WP
+       rtime_oce_GMRedi = rtime_oce_GMRedi + pms(5)*1.0e-3_WP; rtime_oce_solvetra = rtime_oce_solvetra + pms(6)*1.0e-3_WP
+       rtime_oce = rtime_oce + pms(7)*1.0e-3_WP
+    else if (npes > 1) then     ! the library runs the phases and the partitioned SSH solve, this layer moves the halo bytes with MPI
        call check(c_fesom_gpu_step_partitioned(int(n, c_int), transport), 'fesom_gpu_step_partitioned')
     else
        call check(c_fesom_gpu_step(int(n, c_int)), 'fesom_gpu_step')

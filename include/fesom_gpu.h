@@ -194,6 +194,12 @@ typedef struct fesom_step_info {
   double blowup;             /* 1.0 if any owned node fails check_blowup's tests (NaN, |eta|>50, T outside -5..60, S outside 0..50, ...) */
 } fesom_step_info;
 int  fesom_gpu_step_info(fesom_step_info *out);
+/* One step executed phase by phase on one stream with HIP events at the points where oce_timestep_ale reads MPI_Wtime
+ * (src/oce_ale.F90:2546-2768): ms[0..6] = the device time of rtime_oce_mixpres, _dyn, _dynssh, _solvessh, _GMRedi, _solvetra and
+ * rtime_oce (same sums of intervals as :2771-2777), so that the host can keep filling the reference's own phase statistics
+ * ("BENCHMARK RUNTIME", src/fvom_main.F90:281-326).  A profiling aid: the phases do not overlap here, the step is slower than
+ * fesom_gpu_step.  Single partition, no toy hooks. */
+int  fesom_gpu_profile_step(int n, double ms[7]);
 int  fesom_gpu_last_solver_iterations(void);
 double fesom_gpu_last_solver_residual(void);
 int  fesom_gpu_kernel_time_ms(const char *kernel_group, int nrep, double *ms_per_launch);

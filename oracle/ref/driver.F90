@@ -100,13 +100,13 @@ program oracle_driver
   character(len=16) :: mode
   character(len=256) :: dump_dir
   integer :: dump_steps(64), ndump
-  logical :: dump_mesh, do_mean, debug, synth_forcing, step_info
+  logical :: dump_mesh, do_mean, debug, synth_forcing, step_info, gpu_profile
   real(kind=WP) :: flon, flat
   integer :: fel(3)
   real(kind=WP) :: t0, t1, tloop
   character(len=64) :: tag
   namelist /clockinit/ timenew, daynew, yearnew
-  namelist /oracle/ nsteps, mode, dump_dir, dump_steps, dump_mesh, do_mean, debug, synth_forcing, step_info
+  namelist /oracle/ nsteps, mode, dump_dir, dump_steps, dump_mesh, do_mean, debug, synth_forcing, step_info, gpu_profile
   ! running sums for the fcheck-style known answer (setups/test_souf/setup.yml:82-88)
   real(kind=WP), allocatable :: mT(:,:), mS(:,:), mU(:,:), mV(:,:)
 
@@ -135,7 +135,7 @@ program oracle_driver
   read (20,NML=oce_tra)
   read (20,NML=oce_init3d)
   close (20)
-  nsteps=1; mode='step'; dump_dir='dumps'; dump_steps=-1; dump_mesh=.false.; do_mean=.false.; debug=.false.; synth_forcing=.false.; step_info=.false.
+  nsteps=1; mode='step'; dump_dir='dumps'; dump_steps=-1; dump_mesh=.false.; do_mean=.false.; debug=.false.; synth_forcing=.false.; step_info=.false.; gpu_profile=.false.
   open (20,file='namelist.oracle')
   read (20,NML=oracle)
   close (20)
@@ -209,6 +209,7 @@ program oracle_driver
 #ifdef WITH_GPU_SHIM
      else if (trim(mode)=='gpu') then
         ! the drop-in: the repo's Fortran host layer in place of compute_vel_nodes + oce_timestep_ale (fvom_main.F90:216,250)
+        fesom_gpu_profile = gpu_profile
         call oce_timestep_ale_gpu(n, mesh)
         if (any(dump_steps==n)) then
            call fesom_gpu_fetch_state(mesh)

@@ -96,3 +96,32 @@ def test_psolve_only_dropin(built):
     if os.path.isdir(out):
         import json
         json.dump({"max_abs_diff": worst, "timing_gpu_solver": [l for l in lines_g if "TIMING" in l]}, open(os.path.join(out, "dropin_psolve_only.json"), "w"), indent=1)
+
+
+def test_fortran_phase_timers_from_the_gpu(built):
+    """fesom_gpu_profile = .true. in the Fortran layer: every step goes through fesom_gpu_profile_step and its device times land in
+    the reference's own rtime_oce* statistics (src/oce_ale.F90:2771-2777), which the harness prints as the reference prints them.
+    The profiled run ends in the same state, bit for bit, as the normal GPU run of the same executable."""
+    from oracle.ref import run_ref
+    from refdump import read_dump
+    import shutil
+    assert os.path.exists(os.path.join(REPO, "oracle", "_ref", "fesom_gpu_dropin.x"))
+    os.environ["FESOM_GPU_DEVICE"] = "0"
+    rd_a, rc_a, lines_a = run_ref.run("pi_default", 1, NSTEPS, mode="gpu", dump=(NSTEPS,), exe_name="fesom_gpu_dropin.x", gpu_profile=True)
+    assert rc_a == 0, open(os.path.join(rd_a, "stdout.log")).read()[-3000:]
+    a = read_dump(os.path.join(rd_a, "dumps", f"state{NSTEPS:04d}.r00000.bin"))
+    a = {k: np.array(v) for k, v in a.items()}
+    ph = [l for l in lines_a if l.startswith("ORACLE_PHASES")]
+    assert ph, lines_a
+    vals = [float(x) for x in ph[0].split("=")[1].split()]
+    assert len(vals) == 7 and all(v > 0 for v in vals), ph
+    assert vals[3] < vals[2] and vals[6] < 0.1, ph               # solver inside dynssh; 10 steps of pi take far less than 0.1 s on the device
+    rd_b, rc_b, lines_b = run_ref.run("pi_default", 1, NSTEPS, mode="gpu", dump=(NSTEPS,), exe_name="fesom_gpu_dropin.x")
+    assert rc_b == 0
+    b = read_dump(os.path.join(rd_b, "dumps", f"state{NSTEPS:04d}.r00000.bin"))
+    for f in ("eta_n", "tr_arr", "UV", "hnode", "Wvel"):
+        assert np.array_equal(a[f], np.array(b[f])), f
+    out = os.path.join(REPO, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "dropin_phase_timers.txt"), "w") as fh:
+            fh.write("pi_default, 10 steps, seconds summed over the steps (reference's rtime_oce* from fesom_gpu_profile_step)\n" + ph[0] + "\n")

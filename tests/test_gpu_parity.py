@@ -372,3 +372,43 @@ def test_option_combinations_bitwise(built, case):
         ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
         assert ok, (FUZZ[case], msg)
     gpu.close()
+
+
+@pytest.mark.parametrize("case", [1, 5])
+def test_profile_step_is_the_same_step(built, case):
+    """fesom_gpu_profile_step (the reference's rtime_oce_* phase timers, oce_ale.F90:2771-2777, taken with HIP events around the
+    named routines run one after the other) advances the model exactly as fesom_gpu_step does: 6 profiled steps == oracle bit
+    for bit; the phase times are positive, the solver is part of dynssh, and the phases add up to the total."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.core import OceanCore
+    from fesom2_amd.synthetic import analytic_ts, analytic_forcing, analytic_sw_3d
+    from oracle_lib import Oracle
+    kw = dict(FUZZ[case])
+    dt, ale, pc = kw.pop("dt"), kw.pop("which_ale"), kw.pop("use_partial_cell")
+    mesh = Mesh.load(PI, dt=dt, which_ale=ale, use_partial_cell=pc)
+    par = make_params(dt=dt, which_ale=ale, use_partial_cell=pc, **kw)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    gpu, orc = OceanCore(mesh, par), Oracle(mesh, par)
+    gpu.upload_state(st); orc.set_state(st)
+    forcing = analytic_forcing(mesh)
+    if kw.get("use_sw_pene"):
+        forcing["sw_3d"] = analytic_sw_3d(mesh, forcing["heat_flux"])
+    gpu.set_forcing(**forcing)
+    for k, v in forcing.items():
+        orc.set(k, v)
+    gpu.run_steps(1, 2)                      # normal and profiled steps may be mixed freely
+    for n in range(3, 9):
+        t = gpu.profile_step(n)
+        assert all(v > 0.0 for v in t.values()), t
+        assert t["solvessh"] < t["dynssh"], t
+        parts = t["mixpres"] + t["dyn"] + t["dynssh"] + t["GMRedi"] + t["solvetra"]
+        assert parts <= t["total"] * 1.0001 and parts > 0.8 * t["total"], t
+    for n in range(1, 9):
+        orc.call("step", n)
+    for f in ("tr_arr", "UV", "eta_n", "hnode", "Wvel", "Kv", "Av"):
+        ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+        assert ok, (FUZZ[case], msg)
+    gpu.close()
