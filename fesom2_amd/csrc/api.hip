@@ -442,7 +442,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   if (par->toy_soufflet) { F(Tclim, n1 * N); F(Uclim, n1 * E); F(toy_zvel, n1 * 100); F(toy_ztem, n1 * 100); }
   F(sv_vals, 16 * (N + 64)); F(sv_dinv, N + 64); F(sv_b, N + 64); F(sv_r, N + 64); F(sv_r0, N + 64); F(sv_p, N + 64); F(sv_v, N + 64); F(sv_s, N + 64); F(sv_t, N + 64);
   F(sv_ph, N + 64); F(sv_x0, 16 * (N + 64)); F(sv_snap, N);
-  F(sv_part, 4 * ((N + 255) / 256 + 1)); F(sv_red, 8); F(sv_kry, 48);
+  F(sv_part, 8 * ((N + 255) / 256 + 1)); F(sv_red, 8); F(sv_kry, 48);
   F(sv_resid, 1); F(sv_h1, N); F(sv_h2, N); F(sv_h3, N); F(sv_scale, N + 64);
   m.sv_extrap = 1;
 #undef F
@@ -927,7 +927,7 @@ void psolver_init(int *id, int *stype, int *pctype, int *pcilutype, int *iluleve
     int *c32d = (int *)A(c32.size() * sizeof(int));
     hipMemcpy(c32d, c32.data(), c32.size() * sizeof(int), hipMemcpyHostToDevice);
     m.sv_colsi = c32d;
-    m.sv_part = (double *)A(sizeof(double) * 4 * ((n + 255) / 256 + 1)); m.sv_red = (double *)A(64); m.sv_kry = (double *)A(48 * sizeof(double));
+    m.sv_part = (double *)A(sizeof(double) * 8 * ((n + 255) / 256 + 1)); m.sv_red = (double *)A(64); m.sv_kry = (double *)A(48 * sizeof(double));
   }
   solver_prepare();
   PS.n = n; PS.nza = nza; PS.ok = true;

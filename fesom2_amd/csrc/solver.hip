@@ -454,7 +454,7 @@ int launch_named_dsolve(const DM &m, hipStream_t s, const char *name) {
 }
 
 // Single GPU, operator too large for one workgroup (> 4096 rows): the same recurrences and the same summation order as the
-// phases above, 4 launches per iteration instead of 9 -- there is no host all-reduce between the phases here, so every block
+// phases above, 3 launches per iteration instead of 9 -- there is no host all-reduce between the phases here, so every block
 // sums the block partials itself (in block order) and evaluates the Krylov scalars redundantly.  The scalar state ping-pongs
 // between two slots of sv_kry (a block must not read what block 0 of the same launch is about to write); the convergence
 // flag is read back between chunks of iterations (launches after convergence are no-ops).
@@ -486,33 +486,42 @@ __global__ void __launch_bounds__(DSB) k_dm_start(DM m, int nblk, double tol2, i
     st[0] = 1.0; st[1] = 1.0; st[2] = rr; st[3] = 1.0; st[4] = rr; st[5] = rr; st[6] = 0.0; st[7] = go ? 0.0 : 1.0;
   }
 }
-__global__ void __launch_bounds__(DSB) k_dm_s(DM m, int nblk, int slot) {                        // alpha ; s = r - alpha v
-  const double *st = m.sv_kry + 16 * slot;
-  if (st[7] != 0.0) return;
-  __shared__ double sh[DSB];
-  const double alpha = st[4] / dm_sum_blocks(m.sv_part, nblk, sh);
-  int i = blockIdx.x * DSB + threadIdx.x;
-  if (i < m.myN) m.sv_s[i] = m.sv_r[i] - alpha * m.sv_v[i];
-  if (blockIdx.x == 0 && threadIdx.x == 0) m.sv_kry[32] = alpha;
-}
 template <int W>
-__global__ void __launch_bounds__(DSB) k_dm_spmv(DM m, int NP, int nblk, int slot, int which) { // which 1: v = B p ; 2: t = B s
+__global__ void __launch_bounds__(DSB) k_dm_spmv1(DM m, int NP, int nblk, int slot) {          // v = B p^ ; r0.v
   const double *st = m.sv_kry + 16 * slot;
   const bool done = st[7] != 0.0;
   int i = blockIdx.x * DSB + threadIdx.x;
-  if (which == 1) {
-    double q[1] = {0.0};
-    if (i < m.myN && !done) { double a = ds_row<W>(m, NP, i, m.sv_ph); m.sv_v[i] = a; q[0] = m.sv_r0[i] * a; }
-    ds_block_partials<1>(q, m.sv_part, nblk);
-  } else {
-    double q[4] = {0.0, 0.0, 0.0, 0.0};
-    if (i < m.myN && !done) {
-      double a = ds_row<W>(m, NP, i, m.sv_s), si = m.sv_s[i];
-      m.sv_t[i] = a;
+  double q[1] = {0.0};
+  if (i < m.myN && !done) { double a = ds_row<W>(m, NP, i, m.sv_ph); m.sv_v[i] = a; q[0] = m.sv_r0[i] * a; }
+  ds_block_partials<1>(q, m.sv_part, nblk);
+}
+// alpha ; s = r - alpha v ; t = B s ; t.t, t.s, r0.t, s.s.  s at the neighbour columns is evaluated on the fly from r and v (the
+// same expression, hence the same bits, as the stored s_i), which saves the launch that used to sit between the two products.
+// The partials go to the second half of sv_part: other blocks may still be summing the r0.v partials of the first half.
+template <int W>
+__global__ void __launch_bounds__(DSB) k_dm_spmv2(DM m, int NP, int nblk, int slot) {
+  const double *st = m.sv_kry + 16 * slot;
+  const bool done = st[7] != 0.0;
+  __shared__ double sh[DSB];
+  double *part2 = m.sv_part + 4 * (size_t)nblk;
+  int i = blockIdx.x * DSB + threadIdx.x;
+  double q[4] = {0.0, 0.0, 0.0, 0.0};
+  if (!done) {
+    const double alpha = st[4] / dm_sum_blocks(m.sv_part, nblk, sh);
+    if (i < m.myN) {
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < W; k++) {
+        int j = m.sv_colsi[(size_t)k * NP + i];
+        a = a + m.sv_vals[(size_t)k * NP + i] * (m.sv_r[j] - alpha * m.sv_v[j]);
+      }
+      double si = m.sv_r[i] - alpha * m.sv_v[i];
+      m.sv_s[i] = si; m.sv_t[i] = a;
       q[0] = a * a; q[1] = a * si; q[2] = m.sv_r0[i] * a; q[3] = si * si;
     }
-    ds_block_partials<4>(q, m.sv_part, nblk);
+    if (blockIdx.x == 0 && threadIdx.x == 0) m.sv_kry[32] = alpha;
   }
+  ds_block_partials<4>(q, part2, nblk);
 }
 __global__ void __launch_bounds__(DSB) k_dm_upd(DM m, int nblk, int slot, double tol2, int maxits) {  // scalars ; y, r ; next p
   const double *st = m.sv_kry + 16 * slot;
@@ -522,8 +531,9 @@ __global__ void __launch_bounds__(DSB) k_dm_upd(DM m, int nblk, int slot, double
     return;
   }
   __shared__ double sh[DSB];
-  const double tt = dm_sum_blocks(m.sv_part, nblk, sh), ts = dm_sum_blocks(m.sv_part + (size_t)nblk, nblk, sh);
-  const double r0t = dm_sum_blocks(m.sv_part + 2 * (size_t)nblk, nblk, sh), ss = dm_sum_blocks(m.sv_part + 3 * (size_t)nblk, nblk, sh);
+  const double *part2 = m.sv_part + 4 * (size_t)nblk;
+  const double tt = dm_sum_blocks(part2, nblk, sh), ts = dm_sum_blocks(part2 + (size_t)nblk, nblk, sh);
+  const double r0t = dm_sum_blocks(part2 + 2 * (size_t)nblk, nblk, sh), ss = dm_sum_blocks(part2 + 3 * (size_t)nblk, nblk, sh);
   const double alpha = m.sv_kry[32];
   const double omega = (tt > 0.0) ? ts / tt : 0.0;
   const double rho = st[4], rho_new = -omega * r0t;
@@ -552,6 +562,7 @@ __global__ void __launch_bounds__(DSB) k_dm_finish(DM m, int slot) {
     if (m.sv_extrap && m.sv_info[1] < 3) m.sv_info[1] = m.sv_info[1] + 1;
   }
 }
+
 int launch_solver_multi(const DM &m, hipStream_t s, int fuse_rhs, int scale_done) {
   if (m.ssh_maxnnz > 16) return 1;
   const int W = m.ssh_maxnnz <= 10 ? 10 : 16, NP = (m.myN + 63) / 64 * 64, nblk = (m.myN + DSB - 1) / DSB;
@@ -568,9 +579,8 @@ int launch_solver_multi(const DM &m, hipStream_t s, int fuse_rhs, int scale_done
   int slot = 0, total = 0, chunk = last_its > 6 ? last_its - 2 : 4;
   for (;;) {
     for (int k = 0; k < chunk; k++) {
-      DMW(k_dm_spmv, m, NP, nblk, slot, 1);
-      hipLaunchKernelGGL(k_dm_s, dim3(nblk), dim3(DSB), 0, s, m, nblk, slot);
-      DMW(k_dm_spmv, m, NP, nblk, slot, 2);
+      DMW(k_dm_spmv1, m, NP, nblk, slot);
+      DMW(k_dm_spmv2, m, NP, nblk, slot);
       hipLaunchKernelGGL(k_dm_upd, dim3(nblk), dim3(DSB), 0, s, m, nblk, slot, tol2, maxits);
       slot = 1 - slot;
     }
