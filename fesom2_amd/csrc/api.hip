@@ -166,7 +166,7 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   launch_row_scale(m, s1);
   hipEvent_t ev_op = d.ev(); hipEventRecord(ev_op, s1);
   // s3: viscosity stencil, then everything nobody waits for soon (sigma/slope, tracer preparation)
-  K(s3, "k_visc_elem"); K(s3, "k_visc_node");
+  K(s3, "k_visc_elem"); if (m.p.visc_option == 5) K(s3, "k_visc_node");
   hipEvent_t ev_visc = d.ev(); hipEventRecord(ev_visc, s3);
   hipStreamWaitEvent(s3, ev_pb, 0);
   K(s3, "k_sigma_slope");
@@ -187,6 +187,7 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   if (m.p.mix_scheme == 2) K(s0, "k_pp");          // element (Av) and node (Kv) part in one launch
   if (m.p.mix_scheme == 1) K(s0, "mixing_kpp");       // k_kpp_col, 3 smoothing sweeps, k_kpp_final, k_kpp_elem
   hipStreamWaitEvent(s0, ev_rhs, 0); hipStreamWaitEvent(s0, ev_visc, 0);
+  if (m.p.visc_option != 5) K(s0, "k_visc_apply");  // second stage of the biharmonic filters (visc_option 6, 7): in place on UV_rhs
   K(s0, "k_impl_visc");                            // incl. the Thomas sweep
   K(s0, "k_edge_transport");
   hipStreamWaitEvent(s0, ev_op, 0);
@@ -252,7 +253,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   if (part && part->npes > 1 && par->toy_soufflet) { G.err = "fesom_gpu_init: the Soufflet toy hooks (global zonal means) are single-partition only"; return 3; }
   if (d->nl > 64) { G.err = "fesom_gpu_init: nl > 64 levels not supported by the one-wave-per-column kernels"; return 3; }
   if (par->which_ale != 0 && par->which_ale != 2) { G.err = "fesom_gpu_init: which_ale must be linfs(0) or zstar(2)"; return 3; }
-  if (par->mom_adv != 2 || par->visc_option != 5) { G.err = "fesom_gpu_init: only mom_adv=2, visc_option=5 are implemented"; return 3; }
+  if (par->mom_adv != 2 || par->visc_option < 5 || par->visc_option > 7) { G.err = "fesom_gpu_init: only mom_adv=2, visc_option=5,6,7 are implemented"; return 3; }
   if (par->Fer_GM && par->scaling_Rossby) { G.err = "fesom_gpu_init: scaling_Rossby=.true. (GM cut-off by the Rossby radius) is not implemented"; return 3; }
   if (par->mix_scheme < 0 || par->mix_scheme > 2) { G.err = "fesom_gpu_init: mix_scheme must be 0 (constant), 1 (KPP) or 2 (PP); the cvmix schemes are not implemented"; return 3; }
   for (int e = 0; e < d->myDim_elem2D + d->eDim_elem2D; e++)
@@ -616,7 +617,8 @@ int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
   S.c("k_momadv_node"); S.X(0, {"Unode_rhs"});
   S.c("k_vel_rhs");
   S.c("k_visc_elem"); S.X(1, {"U_b"});
-  S.c("k_visc_node"); S.X(0, {"U_c"});
+  if (p.visc_option == 5) { S.c("k_visc_node"); S.X(0, {"U_c"}); }
+  else S.c("k_visc_apply");
   S.c("k_impl_visc");
   if (p.which_ale != 0) S.c("k_stiff_update");
   S.c("k_edge_transport"); S.c("k_ssh_rhs_node");
@@ -683,7 +685,7 @@ int fesom_gpu_profile_step(int n, double ms[7]) {
   if (p.mix_scheme == 2) { c("mixing_pp"); c("mo_convect"); }
   if (p.mix_scheme == 1) { c("mixing_kpp"); c("mo_convect"); }
   T(1);
-  c("compute_vel_rhs"); c("visc_filt_bcksct"); if (p.i_vert_visc) c("impl_vert_visc_ale");
+  c("compute_vel_rhs"); c("viscosity_filter"); if (p.i_vert_visc) c("impl_vert_visc_ale");
   T(2);
   if (p.which_ale != 0) c("update_stiff_mat_ale");
   c("compute_ssh_rhs_ale");

@@ -390,12 +390,15 @@ __global__ void __launch_bounds__(BLOCK) k_vel_rhs(DM m, int first_step) {
 // ------------------------------------------------------------------------------------------------
 // visc_filt_bcksct (src/oce_dyn.F90:563-649): (1) element gather over its <=3 internal edges,
 // (2) node average, (3) apply (fused into k_impl_visc).  4 N3 + 12 E3 values.
+// visc_option 6 / 7 (visc_filt_bilapl :658-726, visc_filt_bidiff :734-801): the same gather is the first stage of the
+// biharmonic operator (the result lives in U_b, the reference's U_c/V_c), the second stage is k_visc_apply.
 __global__ void __launch_bounds__(BLOCK) k_visc_elem(DM m) {
   int e = col_id(), nz = lane_id() + 1;
   if (e >= m.E) return;
   if (nz > m.nlm1) return;
   double ub = 0.0, vb = 0.0;
   const double dt = m.p.dt, g0 = m.p.gamma0, g1 = m.p.gamma1, g2 = m.p.gamma2;
+  const int opt = m.p.visc_option;
   for (int q = 0; q < 3; q++) {
     int side = m.ee_side[3 * e + q];
     if (side == 0) continue;
@@ -407,13 +410,62 @@ __global__ void __launch_bounds__(BLOCK) k_visc_elem(DM m) {
     double len = sqrt(a1 + a2);
     double u1 = DV2(m.UV, 1, nz, e1) - DV2(m.UV, 1, nz, e2);
     double v1 = DV2(m.UV, 2, nz, e1) - DV2(m.UV, 2, nz, e2);
-    double vi = dt * dmax_(g0, dmax_(g1 * sqrt(u1 * u1 + v1 * v1), g2 * (u1 * u1 + v1 * v1))) * len;
-    u1 = u1 * vi; v1 = v1 * vi;
-    if (side == 1) { ub = ub - u1 / a1; vb = vb - v1 / a1; }
-    else           { ub = ub + u1 / a2; vb = vb + v1 / a2; }
+    if (opt == 5) {
+      double vi = dt * dmax_(g0, dmax_(g1 * sqrt(u1 * u1 + v1 * v1), g2 * (u1 * u1 + v1 * v1))) * len;
+      u1 = u1 * vi; v1 = v1 * vi;
+      if (side == 1) { ub = ub - u1 / a1; vb = vb - v1 / a1; }
+      else           { ub = ub + u1 / a2; vb = vb + v1 / a2; }
+    } else {
+      if (opt == 7) {
+        double vi = u1 * u1 + v1 * v1;
+        vi = sqrt(dmax_(g0, dmax_(g1 * sqrt(vi), g2 * vi)) * len);
+        u1 = u1 * vi; v1 = v1 * vi;
+      }
+      if (side == 1) { ub = ub - u1; vb = vb - v1; }
+      else           { ub = ub + u1; vb = vb + v1; }
+    }
+  }
+  if (opt == 6 && nz >= m.ulev[e] && nz <= m.nlev[e] - 1) {    // :694-706 (owned elements; halo values arrive by exchange)
+    double len = sqrt(m.elem_area[e]);
+    double u1 = ub * ub + vb * vb;
+    double vi = dmax_(g0, dmax_(g1 * sqrt(u1), g2 * u1)) * len * dt;
+    ub = -ub * vi; vb = -vb * vi;
   }
   DV2(m.U_b, 1, nz, e) = ub;
   DV2(m.U_b, 2, nz, e) = vb;
+}
+// second stage of visc_option 6 / 7 (:709-724, :781-799): UV_rhs += differences of the first-stage field over the internal
+// edges of the element, in the reference's edge order
+__global__ void __launch_bounds__(BLOCK) k_visc_apply(DM m) {
+  int e = col_id(), nz = lane_id() + 1;
+  if (e >= m.myE) return;
+  if (nz > m.nlm1) return;
+  const double dt = m.p.dt, g0 = m.p.gamma0, g1 = m.p.gamma1, g2 = m.p.gamma2;
+  const int opt = m.p.visc_option;
+  double ur = DV2(m.UV_rhs, 1, nz, e), vr = DV2(m.UV_rhs, 2, nz, e);
+  for (int q = 0; q < 3; q++) {
+    int side = m.ee_side[3 * e + q];
+    if (side == 0) continue;
+    int ed = m.ee_idx[3 * e + q];
+    int e1 = m.edge_tri[2 * ed], e2 = m.edge_tri[2 * ed + 1];
+    int nzmax = min(m.nlev[e1], m.nlev[e2]), nzmin = max(m.ulev[e1], m.ulev[e2]);
+    if (nz < nzmin || nz > nzmax - 1) continue;
+    double a1 = m.elem_area[e1], a2 = m.elem_area[e2];
+    double u1 = DV2(m.U_b, 1, nz, e1) - DV2(m.U_b, 1, nz, e2);
+    double v1 = DV2(m.U_b, 2, nz, e1) - DV2(m.U_b, 2, nz, e2);
+    if (opt == 7) {
+      double len = sqrt(a1 + a2);
+      double du = DV2(m.UV, 1, nz, e1) - DV2(m.UV, 1, nz, e2);
+      double dv = DV2(m.UV, 2, nz, e1) - DV2(m.UV, 2, nz, e2);
+      double vi = du * du + dv * dv;
+      vi = -dt * sqrt(dmax_(g0, dmax_(g1 * sqrt(vi), g2 * vi)) * len);
+      u1 = vi * u1; v1 = vi * v1;
+    }
+    if (side == 1) { ur = ur - u1 / a1; vr = vr - v1 / a1; }
+    else           { ur = ur + u1 / a2; vr = vr + v1 / a2; }
+  }
+  DV2(m.UV_rhs, 1, nz, e) = ur;
+  DV2(m.UV_rhs, 2, nz, e) = vr;
 }
 __global__ void __launch_bounds__(BLOCK) k_visc_node(DM m) {
   int n = col_id(), nz = lane_id() + 1;
@@ -797,8 +849,9 @@ void launch_dynamics_pre(const DM &m, hipStream_t s, int first_step) {
   LAUNCH_COL(k_momadv_node, m.myN, m);
   LAUNCH_COL(k_vel_rhs, m.myE, m, first_step);
   LAUNCH_COL(k_visc_elem, m.E, m);
-  LAUNCH_COL(k_visc_node, m.myN, m);
-  LAUNCH_TH(k_impl_visc, m.myE, 2, m, 1, m.p.i_vert_visc);
+  if (m.p.visc_option == 5) LAUNCH_COL(k_visc_node, m.myN, m);
+  else LAUNCH_COL(k_visc_apply, m.myE, m);
+  LAUNCH_TH(k_impl_visc, m.myE, 2, m, m.p.visc_option == 5, m.p.i_vert_visc);
 }
 void launch_ssh_rhs(const DM &m, hipStream_t s) {
   if (m.p.which_ale != 0) LAUNCH_FLAT(k_stiff_update, m.nza, m);
@@ -835,7 +888,8 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
     if (!strcmp(name, "k_vel_rhs")) { LAUNCH_COL(k_vel_rhs, m.myE, m, first_step); return 0; }
     if (!strcmp(name, "k_visc_elem")) { LAUNCH_COL(k_visc_elem, m.E, m); return 0; }
     if (!strcmp(name, "k_visc_node")) { LAUNCH_COL(k_visc_node, m.myN, m); return 0; }
-    if (!strcmp(name, "k_impl_visc")) { LAUNCH_TH(k_impl_visc, m.myE, 2, m, 1, m.p.i_vert_visc); return 0; }
+    if (!strcmp(name, "k_visc_apply")) { LAUNCH_COL(k_visc_apply, m.myE, m); return 0; }
+    if (!strcmp(name, "k_impl_visc")) { LAUNCH_TH(k_impl_visc, m.myE, 2, m, m.p.visc_option == 5, m.p.i_vert_visc); return 0; }
     if (!strcmp(name, "k_stiff_update")) { LAUNCH_FLAT(k_stiff_update, m.nza, m); return 0; }
     if (!strcmp(name, "k_edge_transport")) { LAUNCH_COL(k_edge_transport, m.myD, m, 0); return 0; }
     if (!strcmp(name, "k_edge_transport1")) { LAUNCH_COL(k_edge_transport, m.myD, m, 1); return 0; }
@@ -860,8 +914,10 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
   }
   if (!strcmp(name, "mo_convect")) return 0;                                                  // fused into mixing_pp
   if (!strcmp(name, "compute_vel_rhs")) { LAUNCH_COL(k_momadv_node, m.myN, m); LAUNCH_COL(k_vel_rhs, m.myE, m, first_step); return 0; }
-  if (!strcmp(name, "visc_filt_bcksct")) {
-    LAUNCH_COL(k_visc_elem, m.E, m); LAUNCH_COL(k_visc_node, m.myN, m); LAUNCH_TH(k_impl_visc, m.myE, 2, m, 1, 0); return 0;
+  if (!strcmp(name, "visc_filt_bcksct") || !strcmp(name, "viscosity_filter")) {      // viscosity_filter(visc_option): 5, 6 or 7
+    LAUNCH_COL(k_visc_elem, m.E, m);
+    if (m.p.visc_option != 5) { LAUNCH_COL(k_visc_apply, m.myE, m); return 0; }
+    LAUNCH_COL(k_visc_node, m.myN, m); LAUNCH_TH(k_impl_visc, m.myE, 2, m, 1, 0); return 0;
   }
   if (!strcmp(name, "impl_vert_visc_ale")) { LAUNCH_TH(k_impl_visc, m.myE, 2, m, 0, 1); return 0; }
   if (!strcmp(name, "update_stiff_mat_ale")) { LAUNCH_FLAT(k_stiff_update, m.nza, m); return 0; }

@@ -56,7 +56,10 @@ def run_step(core, par, X, solve, first, probe=None):
     c("k_momadv_node"); X(NOD, ["Unode_rhs"])
     c("k_vel_rhs"); P("vel_rhs")
     c("k_visc_elem"); X(ELEM, ["U_b"])
-    c("k_visc_node"); X(NOD, ["U_c"])
+    if p.visc_option == 5:
+        c("k_visc_node"); X(NOD, ["U_c"])
+    else:
+        c("k_visc_apply")
     c("k_impl_visc"); P("impl_visc")
     if p.which_ale != 0:
         c("k_stiff_update")

@@ -90,7 +90,7 @@ typedef struct fesom_params {
   int    state_equation;     /* 1 Jackett-McDougall, 0 linear */
   int    num_tracers;
   int    mom_adv;            /* 2 (scalar control volumes) */
-  int    visc_option;        /* 5 (easy backscatter) */
+  int    visc_option;        /* 5 (easy backscatter, visc_filt_bcksct), 6 (visc_filt_bilapl), 7 (visc_filt_bidiff); oce_dyn.F90:196-228 */
   int    i_vert_visc, i_vert_diff, w_split;
   int    mix_scheme;         /* 1 = KPP (oce_ale_mixing_kpp.F90) ; 2 = PP ; 0 = constant A_ver/K_ver (no mixing scheme) */
   int    use_instabmix, use_windmix, windmix_nl;

@@ -108,6 +108,7 @@ void orc_mixing_kpp(void);
 void orc_kpp_tables(double *wmt, double *wst, double *deltaz, double *deltau);
 void orc_compute_vel_rhs(void);
 void orc_visc_filt_bcksct(void);
+void orc_viscosity_filter(void);
 void orc_impl_vert_visc_ale(void);
 void orc_update_stiff_mat_ale(void);
 void orc_compute_ssh_rhs_ale(void);

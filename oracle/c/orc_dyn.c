@@ -403,6 +403,74 @@ void orc_visc_filt_bcksct(void) {
   }
 }
 
+/* visc_filt_bilapl (option 6, src/oce_dyn.F90:658-726) and visc_filt_bidiff (option 7, :734-801): both stages of the
+ * biharmonic filter; U_b holds the reference's U_c / V_c */
+static void visc_filt_biharmonic(int opt) {
+  double *Uc = C_.U_b;
+  memset(Uc, 0, sizeof(double) * 2 * NLM1 * C_.E);
+  double dt = C_.p.dt, g0 = C_.p.gamma0, g1 = C_.p.gamma1, g2 = C_.p.gamma2;
+  for (int ed = 1; ed <= C_.D; ed++) {
+    if (C_.m.myList_edge2D[ed - 1] > C_.m.edge2D_in) continue;
+    int e1 = ETRI(1, ed), e2 = ETRI(2, ed);
+    double len = sqrt(C_.m.elem_area[e1 - 1] + C_.m.elem_area[e2 - 1]);
+    int nzmax = NLEV(e1) < NLEV(e2) ? NLEV(e1) : NLEV(e2);
+    int nzmin = ULEV(e1) > ULEV(e2) ? ULEV(e1) : ULEV(e2);
+    for (int nz = nzmin; nz <= nzmax - 1; nz++) {
+      double u1 = V2(C_.UV, 1, nz, e1) - V2(C_.UV, 1, nz, e2);
+      double v1 = V2(C_.UV, 2, nz, e1) - V2(C_.UV, 2, nz, e2);
+      if (opt == 7) {
+        double vi = u1 * u1 + v1 * v1;
+        vi = sqrt(dmax(g0, dmax(g1 * sqrt(vi), g2 * vi)) * len);
+        u1 = u1 * vi; v1 = v1 * vi;
+      }
+      V2(Uc, 1, nz, e1) = V2(Uc, 1, nz, e1) - u1;
+      V2(Uc, 1, nz, e2) = V2(Uc, 1, nz, e2) + u1;
+      V2(Uc, 2, nz, e1) = V2(Uc, 2, nz, e1) - v1;
+      V2(Uc, 2, nz, e2) = V2(Uc, 2, nz, e2) + v1;
+    }
+  }
+  if (opt == 6)
+    for (int e = 1; e <= C_.m.myDim_elem2D; e++) {
+      double len = sqrt(C_.m.elem_area[e - 1]);
+      for (int nz = ULEV(e); nz <= NLEV(e) - 1; nz++) {
+        double u1 = V2(Uc, 1, nz, e) * V2(Uc, 1, nz, e) + V2(Uc, 2, nz, e) * V2(Uc, 2, nz, e);
+        double vi = dmax(g0, dmax(g1 * sqrt(u1), g2 * u1)) * len * dt;
+        V2(Uc, 1, nz, e) = -V2(Uc, 1, nz, e) * vi;
+        V2(Uc, 2, nz, e) = -V2(Uc, 2, nz, e) * vi;
+      }
+    }
+  /* (exchange_elem(U_c), exchange_elem(V_c): single partition) */
+  for (int ed = 1; ed <= C_.D; ed++) {
+    if (C_.m.myList_edge2D[ed - 1] > C_.m.edge2D_in) continue;
+    int e1 = ETRI(1, ed), e2 = ETRI(2, ed);
+    double a1 = C_.m.elem_area[e1 - 1], a2 = C_.m.elem_area[e2 - 1];
+    double len = sqrt(a1 + a2);
+    int nzmax = NLEV(e1) < NLEV(e2) ? NLEV(e1) : NLEV(e2);
+    int nzmin = ULEV(e1) > ULEV(e2) ? ULEV(e1) : ULEV(e2);
+    for (int nz = nzmin; nz <= nzmax - 1; nz++) {
+      double u1 = V2(Uc, 1, nz, e1) - V2(Uc, 1, nz, e2);
+      double v1 = V2(Uc, 2, nz, e1) - V2(Uc, 2, nz, e2);
+      if (opt == 7) {
+        double du = V2(C_.UV, 1, nz, e1) - V2(C_.UV, 1, nz, e2);
+        double dv = V2(C_.UV, 2, nz, e1) - V2(C_.UV, 2, nz, e2);
+        double vi = du * du + dv * dv;
+        vi = -dt * sqrt(dmax(g0, dmax(g1 * sqrt(vi), g2 * vi)) * len);
+        u1 = vi * u1; v1 = vi * v1;
+      }
+      V2(C_.UV_rhs, 1, nz, e1) = V2(C_.UV_rhs, 1, nz, e1) - u1 / a1;
+      V2(C_.UV_rhs, 1, nz, e2) = V2(C_.UV_rhs, 1, nz, e2) + u1 / a2;
+      V2(C_.UV_rhs, 2, nz, e1) = V2(C_.UV_rhs, 2, nz, e1) - v1 / a1;
+      V2(C_.UV_rhs, 2, nz, e2) = V2(C_.UV_rhs, 2, nz, e2) + v1 / a2;
+    }
+  }
+}
+
+/* viscosity_filter(visc_option): src/oce_dyn.F90:196-228 (options 5, 6, 7) */
+void orc_viscosity_filter(void) {
+  if (C_.p.visc_option == 5) orc_visc_filt_bcksct();
+  else visc_filt_biharmonic(C_.p.visc_option);
+}
+
 /* impl_vert_visc_ale: src/oce_ale.F90:2348-2517 */
 void orc_impl_vert_visc_ale(void) {
   int nl = NL;

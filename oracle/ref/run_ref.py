@@ -75,7 +75,7 @@ gamma1=0.1
 gamma2=0.285
 Div_c=.5
 Leith_c=.05
-visc_option=5
+visc_option={visc_option}
 easy_bs_return=1.5
 A_ver=1.e-4
 scale_area=5.8e9
@@ -176,6 +176,15 @@ CFGS = {
                           rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                           fer_gm=".true.", redi=".true.", mix_scheme="KPP", k_hor="3000.", surf_relax_s="1.929e-06",
                           balance_salt_water=".true.", synth_forcing=True, use_sw_pene=".true."),
+    # the biharmonic viscosity filters instead of the easy backscatter: visc_option = 6 (visc_filt_bilapl), 7 (visc_filt_bidiff)
+    "pi_pp_visc6": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                        fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                        balance_salt_water=".true.", synth_forcing=True, visc_option=6),
+    "pi_pp_visc7": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                        fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                        balance_salt_water=".true.", synth_forcing=True, visc_option=7),
     # KPP alone (no GM/Redi) with the same forcing
     "pi_kpp": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
                    rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
@@ -232,7 +241,7 @@ def prepare(cfg, np_, tag=""):
             partition_io.write_dist(cp, np_)
         meshdir = cp
     open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **dict(dict(use_sw_pene=".false."), **c)))
-    open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0"), **c)))
+    open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0", visc_option=5), **c)))
     if c["toy_ocean"] == ".false.":
         from fesom2_amd.synthetic import write_ic_files
         write_ic_files(meshdir, rd)

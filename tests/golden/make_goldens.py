@@ -107,6 +107,10 @@ def main():
     make("pi_pp", "pi_pp_reference.npz")
     make("pi_pp_gm", "pi_pp_gm_reference.npz")          # + Gent-McWilliams bolus velocities
     make("pi_pp_gm_redi", "pi_pp_gm_redi_reference.npz")  # + isoneutral (Redi) diffusion
+    make("pi_pp_wsplit", "pi_pp_wsplit_reference.npz")  # PP + w_split with surface forcing
+    make("pi_default_sw", "pi_default_sw_reference.npz")  # default physics + short-wave penetration
+    make("pi_pp_visc6", "pi_pp_visc6_reference.npz")    # visc_option = 6 (visc_filt_bilapl)
+    make("pi_pp_visc7", "pi_pp_visc7_reference.npz")    # visc_option = 7 (visc_filt_bidiff)
     make("souf", "souf_reference.npz")
     make("souf_linfs", "souf_linfs_reference.npz")      # linear free surface, full cells
     # known answers of the reference's own CI

@@ -63,7 +63,8 @@ def main():
         torch.cuda.set_device(0)
     rank, world = dist.get_rank(), dist.get_world_size()
     opts = os.environ.get("PART_OPTS", "").split(",")
-    par = make_params(dt=900.0, mix_scheme="KPP" if "kpp" in opts else "PP", Fer_GM="gm" in opts, Redi="redi" in opts, scaling_Ferreira="gm" in opts or "redi" in opts)
+    par = make_params(dt=900.0, mix_scheme="KPP" if "kpp" in opts else "PP", Fer_GM="gm" in opts, Redi="redi" in opts, scaling_Ferreira="gm" in opts or "redi" in opts,
+                      visc_option=7 if "visc7" in opts else 6 if "visc6" in opts else 5)
     T, S = analytic_ts(PI)
     # ---- single partition (whole mesh) on this rank
     gm = Mesh.load(PI, dt=900.0)

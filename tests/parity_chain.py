@@ -13,7 +13,7 @@ DYN_PRE = [
     ("mixing_pp", 0, []),
     ("mo_convect", 0, ["Av", "Kv"]),
     ("compute_vel_rhs", 0, ["UV_rhs", "UV_rhsAB"]),
-    ("visc_filt_bcksct", 0, ["UV_rhs"]),
+    ("viscosity_filter", 0, ["UV_rhs"]),
     ("impl_vert_visc_ale", 0, ["UV_rhs"]),
     ("update_stiff_mat_ale", 0, ["ssh_values"]),
     ("compute_ssh_rhs_ale", 0, ["ssh_rhs"]),

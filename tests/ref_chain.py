@@ -48,7 +48,7 @@ def run_reference_chain(orc, mesh, g, steps=(1, 2, 3), toy=False, skip=(), after
             orc.call("mixing_pp"); chk(step, "Av", "oce_mixing_PP.Av"); chk(step, "Kv", "oce_mixing_PP.Kv")
         orc.call("mo_convect"); chk(step, "Av", "mixing.Av"); chk(step, "Kv", "mixing.Kv")
         orc.call("compute_vel_rhs"); chk(step, "UV_rhs", "compute_vel_rhs.UV_rhs", "e2"); chk(step, "UV_rhsAB", "compute_vel_rhs.UV_rhsAB", "e2")
-        orc.call("visc_filt_bcksct"); chk(step, "UV_rhs", "viscosity_filter.UV_rhs", "e2")
+        orc.call("viscosity_filter"); chk(step, "UV_rhs", "viscosity_filter.UV_rhs", "e2")
         orc.call("impl_vert_visc_ale"); chk(step, "UV_rhs", "impl_vert_visc_ale.UV_rhs", "e2")
         if orc.params.which_ale != 0:
             orc.call("update_stiff_mat_ale")

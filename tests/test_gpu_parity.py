@@ -336,6 +336,9 @@ FUZZ = [
     dict(dt=600.0, which_ale="zstar", use_partial_cell=True, state_equation=1, mix_scheme="none", use_windmix=True, K_hor=500.0),
     dict(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equation=1, mix_scheme="KPP", Fer_GM=True, K_GM_bvref=0, scaling_Ferreira=True,
          w_split=True, w_max_cfl=0.001, use_sw_pene=True, solver_x0_order=0),
+    dict(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equation=1, mix_scheme="PP", visc_option=6),
+    dict(dt=900.0, which_ale="linfs", use_partial_cell=False, state_equation=1, mix_scheme="KPP", visc_option=7, Fer_GM=True, scaling_Ferreira=True),
+    dict(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equation=1, mix_scheme="PP", visc_option=7, w_split=True, w_max_cfl=0.0005),
 ]
 
 
@@ -411,4 +414,38 @@ def test_profile_step_is_the_same_step(built, case):
     for f in ("tr_arr", "UV", "eta_n", "hnode", "Wvel", "Kv", "Av"):
         ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
         assert ok, (FUZZ[case], msg)
+    gpu.close()
+
+
+@pytest.mark.parametrize("opt", [6, 7])
+def test_biharmonic_viscosity_chain_bitwise(built, opt):
+    """visc_option 6 / 7 (visc_filt_bilapl, visc_filt_bidiff; oracle pinned on the reference runs pi_pp_visc6 / pi_pp_visc7): HIP == oracle
+    bit for bit after every routine of 3 steps under surface forcing."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.core import OceanCore
+    from fesom2_amd.synthetic import analytic_ts, analytic_forcing
+    from oracle_lib import Oracle
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, visc_option=opt)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    gpu, orc = OceanCore(mesh, par), Oracle(mesh, par)
+    gpu.upload_state(st); orc.set_state(st)
+    forcing = analytic_forcing(mesh)
+    gpu.set_forcing(**forcing)
+    for k, v in forcing.items():
+        orc.set(k, v)
+    failures = []
+    for step in range(1, 4):
+        for routine, arg, fields in full_chain(2):
+            gpu.call(routine, arg); orc.call(routine, arg)
+            for f in fields:
+                ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+                if not ok:
+                    failures.append(f"step {step} {routine}({arg}) {msg}")
+        if failures:
+            break
+    assert not failures, "\n".join(failures[:10])
     gpu.close()

@@ -206,3 +206,29 @@ def test_oracle_chain_bitwise_w_split(built):
     assert not bad, "\n".join(bad[:20])
     wi = orc.get("Wvel_i")
     assert np.count_nonzero(wi) > 1000                     # the split is really active
+
+
+@pytest.mark.parametrize("opt", [6, 7])
+def test_oracle_chain_bitwise_biharmonic_viscosity(built, opt):
+    """visc_option = 6 (visc_filt_bilapl, src/oce_dyn.F90:658-726) and 7 (visc_filt_bidiff, :734-801) instead of the easy backscatter:
+    reference runs `pi_pp_visc6` / `pi_pp_visc7` (PP mixing, surface forcing), every routine of 3 steps bit for bit."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.synthetic import analytic_ts
+    from oracle_lib import Oracle
+    from ref_chain import run_reference_chain
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, visc_option=opt)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    orc = Oracle(mesh, par)
+    orc.set_state(st)
+    g = gold(f"pi_pp_visc{opt}")
+    for f in FORCING:
+        orc.set(f, g["forcing/" + f])
+    bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
+    assert not bad, "\n".join(bad[:20])
+    # the filter really differs from the default one: UV_rhs after viscosity_filter is not the backscatter result
+    g5 = gold("pi_pp_wsplit")
+    assert not np.array_equal(g["s2/viscosity_filter.UV_rhs"], g5["s2/viscosity_filter.UV_rhs"])
