@@ -176,7 +176,10 @@ __global__ void __launch_bounds__(BLOCK) k_fct_lo_node(DM m, int tr0) {
       double w = DA2L(m.Wvel, nz, n);
       const double fvw = split ? -0.5 * (DTR(m.tr_arr, nz, n, tr) * (w + fabs(w)) + DTR(m.tr_arr, nz - 1, n, tr) * (w - fabs(w))) * ar - 0.0 : fv;
       double s0 = DTR(m.tr_arr_old, nz, n, tr), sm1 = DTR(m.tr_arr_old, nz - 1, n, tr);
-      if (nz == nzmin + 1 || nz == nzmax - 1) {
+      const int ver = m.p.tra_adv_ver;                        // 0 QR4C, 1 CDIFF (adv_tra_ver_cdiff :542-590), 2 UPW1 (:231-282)
+      if (ver == 2) {
+        adf = -0.5 * (s0 * (w + fabs(w)) + sm1 * (w - fabs(w))) * ar - fvw;
+      } else if (nz == nzmin + 1 || nz == nzmax - 1 || ver == 1) {
         adf = -0.5 * (sm1 + s0) * w * ar - fvw;
       } else {
         double sp1 = DTR(m.tr_arr_old, nz + 1, n, tr), sm2 = DTR(m.tr_arr_old, nz - 2, n, tr);

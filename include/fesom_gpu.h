@@ -118,6 +118,8 @@ typedef struct fesom_params {
   double visc_sh_limit, diff_sh_limit, Ricr, concv;
   int    use_sw_pene;        /* short-wave penetration (namelist.config run_config): sw_3d of the forcing enters the temperature
                                 equation (oce_ale_tracer.F90:785-791) and the KPP surface buoyancy forcing (oce_ale_mixing_kpp.F90:508-640) */
+  int    tra_adv_ver;        /* high-order vertical tracer advection under FCT (namelist.oce tra_adv_ver, oce_adv_tra_driver.F90:162-177):
+                                0 'QR4C' (default), 1 'CDIFF', 2 'UPW1'; tra_adv_hor='MFCT', tra_adv_lim='FCT' are fixed */
 } fesom_params;
 
 /* ---- prognostic state = restart set (io_restart.F90:99-155) + ALE thickness arrays -- */

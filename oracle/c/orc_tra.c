@@ -140,6 +140,31 @@ static void adv_tra_ver_upw1(const double *ttf, const double *W) {
   }
 }
 
+/* adv_tra_ver_cdiff: src/oce_adv_tra_ver.F90:542-590 and adv_tra_ver_upw1 :231-282 as the high-order scheme (init_zero=.false.) */
+static void adv_tra_ver_cdiff(const double *ttf, const double *W) {
+  double *flux = C_.adv_flux_ver;
+  for (int n = 1; n <= C_.m.myDim_nod2D; n++) {
+    int nzmax = NLEVN(n) - 1, nzmin = ULEVN(n);
+    A2L(flux, nzmin, n) = -A2L(W, nzmin, n) * A2(ttf, nzmin, n) * AREA(nzmin, n) - A2L(flux, nzmin, n);
+    for (int nz = nzmin + 1; nz <= nzmax; nz++) {
+      double tv = 0.5 * (A2(ttf, nz - 1, n) + A2(ttf, nz, n));
+      A2L(flux, nz, n) = -tv * A2L(W, nz, n) * AREA(nz, n) - A2L(flux, nz, n);
+    }
+  }
+}
+static void adv_tra_ver_upw1_ho(const double *ttf, const double *W) {
+  double *flux = C_.adv_flux_ver;
+  for (int n = 1; n <= C_.m.myDim_nod2D; n++) {
+    int nzmax = NLEVN(n), nzmin = ULEVN(n);
+    A2L(flux, nzmin, n) = -A2L(W, nzmin, n) * A2(ttf, nzmin, n) * AREA(nzmin, n) - A2L(flux, nzmin, n);
+    A2L(flux, nzmax, n) = 0.0 - A2L(flux, nzmax, n);
+    for (int nz = nzmin + 1; nz <= nzmax - 1; nz++) {
+      double w = A2L(W, nz, n);
+      A2L(flux, nz, n) = -0.5 * (A2(ttf, nz, n) * (w + fabs(w)) + A2(ttf, nz - 1, n) * (w - fabs(w))) * AREA(nz, n) - A2L(flux, nz, n);
+    }
+  }
+}
+
 /* adv_tra_ver_qr4c: src/oce_adv_tra_ver.F90:286-357 (init_zero=.false.) */
 static void adv_tra_ver_qr4c(const double *ttf, const double *W, double num_ord) {
   double *flux = C_.adv_flux_ver;
@@ -349,7 +374,9 @@ void orc_adv_tracers_ale(int tr) {
     adv_tra_ver_upw1(ttf, C_.Wvel);        /* low-order part of the anti-diffusive vertical fluxes: on the full w */
   }
   adv_tra_hor(ttfAB, 1, C_.p.tra_adv_ph);
-  adv_tra_ver_qr4c(ttfAB, C_.Wvel, C_.p.tra_adv_pv);
+  if (C_.p.tra_adv_ver == 1) adv_tra_ver_cdiff(ttfAB, C_.Wvel);
+  else if (C_.p.tra_adv_ver == 2) adv_tra_ver_upw1_ho(ttfAB, C_.Wvel);
+  else adv_tra_ver_qr4c(ttfAB, C_.Wvel, C_.p.tra_adv_pv);
   oce_tra_adv_fct(ttf);
   /* flux2dtracer with use_lo */
   for (int n = 1; n <= C_.m.myDim_nod2D; n++)

@@ -111,6 +111,8 @@ def main():
     make("pi_default_sw", "pi_default_sw_reference.npz")  # default physics + short-wave penetration
     make("pi_pp_visc6", "pi_pp_visc6_reference.npz")    # visc_option = 6 (visc_filt_bilapl)
     make("pi_pp_visc7", "pi_pp_visc7_reference.npz")    # visc_option = 7 (visc_filt_bidiff)
+    make("pi_pp_cdiff", "pi_pp_cdiff_reference.npz")    # tra_adv_ver = 'CDIFF'
+    make("pi_pp_upw1v", "pi_pp_upw1v_reference.npz")    # tra_adv_ver = 'UPW1' with w_split
     make("souf", "souf_reference.npz")
     make("souf_linfs", "souf_linfs_reference.npz")      # linear free surface, full cells
     # known answers of the reference's own CI

@@ -232,3 +232,26 @@ def test_oracle_chain_bitwise_biharmonic_viscosity(built, opt):
     # the filter really differs from the default one: UV_rhs after viscosity_filter is not the backscatter result
     g5 = gold("pi_pp_wsplit")
     assert not np.array_equal(g["s2/viscosity_filter.UV_rhs"], g5["s2/viscosity_filter.UV_rhs"])
+
+
+@pytest.mark.parametrize("ver,cfg,kw", [("CDIFF", "pi_pp_cdiff", {}), ("UPW1", "pi_pp_upw1v", dict(w_split=True, w_max_cfl=0.0003))])
+def test_oracle_chain_bitwise_vertical_advection_variants(built, ver, cfg, kw):
+    """tra_adv_ver = 'CDIFF' (adv_tra_ver_cdiff, src/oce_adv_tra_ver.F90:542-590) and 'UPW1' (:231-282, here together with w_split) as
+    the high-order vertical scheme under FCT: reference runs `pi_pp_cdiff` / `pi_pp_upw1v`, every routine of 3 steps bit for bit."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.synthetic import analytic_ts
+    from oracle_lib import Oracle
+    from ref_chain import run_reference_chain
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, tra_adv_ver=ver, **kw)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    orc = Oracle(mesh, par)
+    orc.set_state(st)
+    g = gold(cfg)
+    for f in FORCING:
+        orc.set(f, g["forcing/" + f])
+    bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
+    assert not bad, "\n".join(bad[:20])
