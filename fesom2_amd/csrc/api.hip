@@ -255,7 +255,9 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   if (par->which_ale != 0 && par->which_ale != 2) { G.err = "fesom_gpu_init: which_ale must be linfs(0) or zstar(2)"; return 3; }
   if (par->mom_adv != 2 || par->visc_option < 5 || par->visc_option > 7) { G.err = "fesom_gpu_init: only mom_adv=2, visc_option=5,6,7 are implemented"; return 3; }
   if (par->Fer_GM && par->scaling_Rossby) { G.err = "fesom_gpu_init: scaling_Rossby=.true. (GM cut-off by the Rossby radius) is not implemented"; return 3; }
-  if (par->tra_adv_ver < 0 || par->tra_adv_ver > 2) { G.err = "fesom_gpu_init: tra_adv_ver must be QR4C (0), CDIFF (1) or UPW1 (2) with tra_adv_hor='MFCT', tra_adv_lim='FCT'"; return 3; }
+  if (par->tra_adv_ver < 0 || par->tra_adv_ver > 2 || par->tra_adv_hor < 0 || par->tra_adv_hor > 2) {
+    G.err = "fesom_gpu_init: tra_adv_ver must be QR4C (0), CDIFF (1) or UPW1 (2), tra_adv_hor MFCT (0), MUSCL (1) or UPW1 (2), tra_adv_lim='FCT'"; return 3;
+  }
   if (par->mix_scheme < 0 || par->mix_scheme > 2) { G.err = "fesom_gpu_init: mix_scheme must be 0 (constant), 1 (KPP) or 2 (PP); the cvmix schemes are not implemented"; return 3; }
   for (int e = 0; e < d->myDim_elem2D + d->eDim_elem2D; e++)
     if (d->ulevels[e] != 1) { G.err = "fesom_gpu_init: cavities (ulevels>1) are not supported"; return 3; }
@@ -450,6 +452,19 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
 #undef F
 #undef FT
   m.sv_info = dev_alloc<int>(4);
+  m.nb_lay = nullptr;
+  if (par->tra_adv_hor == 1) {          // nboundary_lay: the layer below which a node touches the boundary (oce_muscl_adv.F90:74-104, owned edges)
+    std::vector<int> nb(N, (int)nl - 1);
+    for (size_t e = 0; e < (size_t)d->myDim_edge2D; e++) {
+      const int n1 = d->edges[2 * e] - 1, n2 = d->edges[2 * e + 1] - 1, t1 = d->edge_tri[2 * e], t2 = d->edge_tri[2 * e + 1];
+      if (t1 <= 0 || t2 <= 0) { nb[n1] = 0; nb[n2] = 0; }
+      else {
+        const int lv = std::min(d->nlevels[t1 - 1], d->nlevels[t2 - 1]) - 1;
+        nb[n1] = std::min(nb[n1], lv); nb[n2] = std::min(nb[n2], lv);
+      }
+    }
+    m.nb_lay = dev_upload(nb);
+  }
   if (par->Fer_GM || par->Redi) {
     // mesh-only part of the horizontal GM scaling (init_Redi_GM, src/oce_fer_gm.F90:204-232; scaling_Rossby is rejected above)
     std::vector<double> sc(N, 1.0);

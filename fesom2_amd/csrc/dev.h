@@ -51,6 +51,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   double *ssh_values;
   // Gent-McWilliams bolus velocities (kernels_gm.hip)
   double *fer_K, *fer_gamma, *fer_Wvel, *fer_c, *fer_UV;   // (nl,N), (2,nl,N), (nl,N), (N), (2,nl-1,E)
+  const int *nb_lay;                                      // (N) nboundary_lay (oce_muscl_adv.F90:74-104), tra_adv_hor = MUSCL only
   const double *redi_k0;                                  // (N) K_hor*(mesh_resolution/100km)^2: surface Ki of Redi without GM
   const double *gm_scal_static;                           // (N) mesh-only part of the horizontal GM scaling
   int *MLD1_ind;                                          // (N) level index of MLD1 (pressure_bv)

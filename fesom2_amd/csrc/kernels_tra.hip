@@ -141,8 +141,20 @@ __global__ void __launch_bounds__(BLOCK) k_flux_hor(DM m, int tr0) {
   double s1 = DTR(m.tr_arr_old, nz, n1, tr), s2 = DTR(m.tr_arr_old, nz, n2, tr);
   double num_ord = m.p.tra_adv_ph;
   double ex = m.edxy[2 * ed], ey = m.edxy[2 * ed + 1];
-  double Tmean2 = s2 - (2.0 * (s2 - s1) + ex * a * DV4(t.edge_up_dn_grad, 2, nz, ed) + ey * D_REARTH * DV4(t.edge_up_dn_grad, 4, nz, ed)) / 6.0;
-  double Tmean1 = s1 + (2.0 * (s2 - s1) + ex * a * DV4(t.edge_up_dn_grad, 1, nz, ed) + ey * D_REARTH * DV4(t.edge_up_dn_grad, 3, nz, ed)) / 6.0;
+  const int hor = m.p.tra_adv_hor;                          // 0 MFCT, 1 MUSCL (:215-481), 2 UPW1 (:57-211) as the high-order scheme
+  if (hor == 2) {
+    DA2(t.adv_flux_raw, nz, ed) = -0.5 * (s1 * (vflux + av) + s2 * (vflux - av)) - lo;
+    return;
+  }
+  double Tmean2 = s2, Tmean1 = s1;
+  if (hor == 1) {   // MUSCL: the gradient correction is switched off below nboundary_lay of the node (c_lo = 0 or 1)
+    const double c1 = (m.nb_lay[n1] - nz >= 0) ? 1.0 : 0.0, c2 = (m.nb_lay[n2] - nz >= 0) ? 1.0 : 0.0;
+    Tmean2 = s2 - (2.0 * (s2 - s1) + ex * a * DV4(t.edge_up_dn_grad, 2, nz, ed) + ey * D_REARTH * DV4(t.edge_up_dn_grad, 4, nz, ed)) / 6.0 * c2;
+    Tmean1 = s1 + (2.0 * (s2 - s1) + ex * a * DV4(t.edge_up_dn_grad, 1, nz, ed) + ey * D_REARTH * DV4(t.edge_up_dn_grad, 3, nz, ed)) / 6.0 * c1;
+  } else {
+    Tmean2 = s2 - (2.0 * (s2 - s1) + ex * a * DV4(t.edge_up_dn_grad, 2, nz, ed) + ey * D_REARTH * DV4(t.edge_up_dn_grad, 4, nz, ed)) / 6.0;
+    Tmean1 = s1 + (2.0 * (s2 - s1) + ex * a * DV4(t.edge_up_dn_grad, 1, nz, ed) + ey * D_REARTH * DV4(t.edge_up_dn_grad, 3, nz, ed)) / 6.0;
+  }
   double cHO = (vflux + av) * Tmean1 + (vflux - av) * Tmean2;
   DA2(t.adv_flux_raw, nz, ed) = -0.5 * (1.0 - num_ord) * cHO - vflux * num_ord * (0.5 * (Tmean1 + Tmean2)) - lo;
 }

@@ -82,8 +82,25 @@ void orc_init_tracers_AB(int tr) {
 
 /* adv_tra_hor_upw1: src/oce_adv_tra_hor.F90:57-211 ; adv_tra_hor_mfct: :485-733.
  * mode 0: upwind with init_zero=.true. ; mode 1: MFCT with init_zero=.false. (flux = new - flux) */
+static const int *muscl_nboundary_lay(void) {    /* oce_muscl_adv.F90:74-104 (owned edges, no exchange: as the reference) */
+  static int *nb = NULL;
+  if (nb) return nb;
+  nb = malloc(sizeof(int) * C_.N);
+  for (int n = 0; n < C_.N; n++) nb[n] = NL - 1;
+  for (int ed = 1; ed <= C_.m.myDim_edge2D; ed++) {
+    int n1 = EDG(1, ed), n2 = EDG(2, ed), e1 = ETRI(1, ed), e2 = ETRI(2, ed);
+    if (e1 <= 0 || e2 <= 0) { nb[n1 - 1] = 0; nb[n2 - 1] = 0; }
+    else {
+      int lv = (NLEV(e1) < NLEV(e2) ? NLEV(e1) : NLEV(e2)) - 1;
+      if (lv < nb[n1 - 1]) nb[n1 - 1] = lv;
+      if (lv < nb[n2 - 1]) nb[n2 - 1] = lv;
+    }
+  }
+  return nb;
+}
 static void adv_tra_hor(const double *ttf, int mode, double num_ord) {
   double *flux = C_.adv_flux_hor;
+  const int *nb_lay = (mode == 3) ? muscl_nboundary_lay() : NULL;
   if (mode == 0) memset(flux, 0, sizeof(double) * (size_t)NLM1 * C_.m.myDim_edge2D);
   for (int ed = 1; ed <= C_.m.myDim_edge2D; ed++) {
     int n1 = EDG(1, ed), n2 = EDG(2, ed), e1 = ETRI(1, ed), e2 = ETRI(2, ed);
@@ -114,10 +131,17 @@ static void adv_tra_hor(const double *ttf, int mode, double num_ord) {
       double t1 = A2(ttf, nz, n1), t2 = A2(ttf, nz, n2);
       if (mode == 0) {
         A2(flux, nz, ed) = -0.5 * (t1 * (vflux + fabs(vflux)) + t2 * (vflux - fabs(vflux))) - A2(flux, nz, ed);
+      } else if (mode == 2) {                      /* adv_tra_hor_upw1 as the high-order scheme, init_zero=.false. */
+        A2(flux, nz, ed) = -0.5 * (t1 * (vflux + fabs(vflux)) + t2 * (vflux - fabs(vflux))) - A2(flux, nz, ed);
       } else {
         const double *G = C_.edge_up_dn_grad;
         double Tmean2 = t2 - (2.0 * (t2 - t1) + EDXY(1, ed) * a * V4(G, 2, nz, ed) + EDXY(2, ed) * R_EARTH * V4(G, 4, nz, ed)) / 6.0;
         double Tmean1 = t1 + (2.0 * (t2 - t1) + EDXY(1, ed) * a * V4(G, 1, nz, ed) + EDXY(2, ed) * R_EARTH * V4(G, 3, nz, ed)) / 6.0;
+        if (mode == 3) {                           /* adv_tra_hor_muscl :215-481: c_lo = real(max(sign(1, nboundary_lay - nz), 0)) */
+          double c1 = (nb_lay[n1 - 1] - nz >= 0) ? 1.0 : 0.0, c2 = (nb_lay[n2 - 1] - nz >= 0) ? 1.0 : 0.0;
+          Tmean2 = t2 - (2.0 * (t2 - t1) + EDXY(1, ed) * a * V4(G, 2, nz, ed) + EDXY(2, ed) * R_EARTH * V4(G, 4, nz, ed)) / 6.0 * c2;
+          Tmean1 = t1 + (2.0 * (t2 - t1) + EDXY(1, ed) * a * V4(G, 1, nz, ed) + EDXY(2, ed) * R_EARTH * V4(G, 3, nz, ed)) / 6.0 * c1;
+        }
         double cHO = (vflux + fabs(vflux)) * Tmean1 + (vflux - fabs(vflux)) * Tmean2;
         A2(flux, nz, ed) = -0.5 * (1.0 - num_ord) * cHO - vflux * num_ord * (0.5 * (Tmean1 + Tmean2)) - A2(flux, nz, ed);
       }
@@ -373,7 +397,7 @@ void orc_adv_tracers_ale(int tr) {
     adv_tra_vert_impl(LO, C_.Wvel_i);
     adv_tra_ver_upw1(ttf, C_.Wvel);        /* low-order part of the anti-diffusive vertical fluxes: on the full w */
   }
-  adv_tra_hor(ttfAB, 1, C_.p.tra_adv_ph);
+  adv_tra_hor(ttfAB, C_.p.tra_adv_hor == 1 ? 3 : C_.p.tra_adv_hor == 2 ? 2 : 1, C_.p.tra_adv_ph);
   if (C_.p.tra_adv_ver == 1) adv_tra_ver_cdiff(ttfAB, C_.Wvel);
   else if (C_.p.tra_adv_ver == 2) adv_tra_ver_upw1_ho(ttfAB, C_.Wvel);
   else adv_tra_ver_qr4c(ttfAB, C_.Wvel, C_.p.tra_adv_pv);

@@ -127,7 +127,7 @@ clim_relax=0.0
 ref_sss_local=.true.
 ref_sss=34.
 i_vert_diff=.true.
-tra_adv_hor='MFCT'
+tra_adv_hor='{tra_adv_hor}'
 tra_adv_ver='{tra_adv_ver}'
 tra_adv_lim='FCT'
 tra_adv_ph=1.
@@ -194,6 +194,15 @@ CFGS = {
                         rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                         fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
                         balance_salt_water=".true.", synth_forcing=True, tra_adv_ver="UPW1", w_split=".true.", w_max_cfl="0.0003"),
+    # horizontal high-order advection variants under FCT: tra_adv_hor = 'MUSCL', 'UPW1'
+    "pi_pp_muscl": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                        fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                        balance_salt_water=".true.", synth_forcing=True, tra_adv_hor="MUSCL"),
+    "pi_pp_upw1h": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                        fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                        balance_salt_water=".true.", synth_forcing=True, tra_adv_hor="UPW1", tra_adv_ver="CDIFF"),
     # KPP alone (no GM/Redi) with the same forcing
     "pi_kpp": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
                    rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
@@ -250,7 +259,7 @@ def prepare(cfg, np_, tag=""):
             partition_io.write_dist(cp, np_)
         meshdir = cp
     open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **dict(dict(use_sw_pene=".false."), **c)))
-    open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0", visc_option=5, tra_adv_ver="QR4C"), **c)))
+    open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0", visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT"), **c)))
     if c["toy_ocean"] == ".false.":
         from fesom2_amd.synthetic import write_ic_files
         write_ic_files(meshdir, rd)

@@ -342,6 +342,9 @@ FUZZ = [
     dict(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equation=1, mix_scheme="PP", tra_adv_ver="CDIFF"),
     dict(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equation=1, mix_scheme="KPP", tra_adv_ver="UPW1", w_split=True, w_max_cfl=0.0003),
     dict(dt=900.0, which_ale="linfs", use_partial_cell=False, state_equation=0, mix_scheme="PP", tra_adv_ver="CDIFF", Fer_GM=True, scaling_Ferreira=True, visc_option=6),
+    dict(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equation=1, mix_scheme="PP", tra_adv_hor="MUSCL"),
+    dict(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equation=1, mix_scheme="KPP", tra_adv_hor="UPW1", tra_adv_ver="CDIFF"),
+    dict(dt=900.0, which_ale="linfs", use_partial_cell=True, state_equation=1, mix_scheme="PP", tra_adv_hor="MUSCL", tra_adv_ver="UPW1", w_split=True, w_max_cfl=0.0005),
 ]
 
 

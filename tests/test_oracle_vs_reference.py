@@ -234,10 +234,16 @@ def test_oracle_chain_bitwise_biharmonic_viscosity(built, opt):
     assert not np.array_equal(g["s2/viscosity_filter.UV_rhs"], g5["s2/viscosity_filter.UV_rhs"])
 
 
-@pytest.mark.parametrize("ver,cfg,kw", [("CDIFF", "pi_pp_cdiff", {}), ("UPW1", "pi_pp_upw1v", dict(w_split=True, w_max_cfl=0.0003))])
+@pytest.mark.parametrize("ver,cfg,kw", [("CDIFF", "pi_pp_cdiff", {}), ("UPW1", "pi_pp_upw1v", dict(w_split=True, w_max_cfl=0.0003)),
+                                        ("CDIFF", "pi_pp_upw1h", dict(tra_adv_hor="UPW1"))])
 def test_oracle_chain_bitwise_vertical_advection_variants(built, ver, cfg, kw):
     """tra_adv_ver = 'CDIFF' (adv_tra_ver_cdiff, src/oce_adv_tra_ver.F90:542-590) and 'UPW1' (:231-282, here together with w_split) as
-    the high-order vertical scheme under FCT: reference runs `pi_pp_cdiff` / `pi_pp_upw1v`, every routine of 3 steps bit for bit."""
+    the high-order vertical scheme under FCT, tra_adv_hor = 'UPW1' (src/oce_adv_tra_hor.F90:57-211) as the horizontal one: reference runs
+    `pi_pp_cdiff`, `pi_pp_upw1v`, `pi_pp_upw1h`, every routine of 3 steps bit for bit.
+    (tra_adv_hor = 'MUSCL' cannot be pinned this way: the reference forms nboundary_lay from the rank's own edges and never exchanges it
+    (oce_muscl_adv.F90:74-104), so on 2 ranks 5 halo nodes of pi carry incomplete values and the two ranks disagree about the flux on shared
+    edges -- its result depends on the partition.  The library forms the array by the same rank-local rule; MUSCL is pinned by the
+    2-rank Fortran drop-in run against the reference's 2-rank CPU run, tests/test_gpu_dropin.py[pi_pp_muscl-2].)"""
     from fesom2_amd.mesh import Mesh
     from fesom2_amd.config import make_params
     from fesom2_amd.synthetic import analytic_ts
