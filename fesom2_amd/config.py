@@ -43,7 +43,7 @@ def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equati
     p.scaling_resolution, p.scaling_FESOM14 = int(scaling_resolution), int(scaling_FESOM14)
     p.Redi = int(Redi)
     p.use_sw_pene = int(use_sw_pene)
-    p.tra_adv_ver = {"QR4C": 0, "CDIFF": 1, "UPW1": 2}[tra_adv_ver]
+    p.tra_adv_ver = {"QR4C": 0, "CDIFF": 1, "UPW1": 2, "PPM": 3}[tra_adv_ver]
     p.tra_adv_hor = {"MFCT": 0, "MUSCL": 1, "UPW1": 2}[tra_adv_hor]
     p.visc_sh_limit, p.diff_sh_limit, p.Ricr, p.concv = visc_sh_limit, diff_sh_limit, Ricr, concv
     return p

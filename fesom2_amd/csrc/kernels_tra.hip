@@ -173,12 +173,64 @@ __global__ void __launch_bounds__(BLOCK) k_fct_lo_node(DM m, int tr0) {
   // the full w (oce_adv_tra_driver.F90:111,124-131); without it the two are the same array values
   double fv = 0.0, adf = 0.0;
   const bool split = m.p.w_split != 0;
+  const int ver = m.p.tra_adv_ver;                          // 0 QR4C, 1 CDIFF (adv_tra_ver_cdiff :542-590), 2 UPW1 (:231-282), 3 PPM (:361-538)
+  double ppm = 0.0;
+  if (ver == 3) {
+    // adv_tra_vert_ppm: lane nz holds layer nz and interface nz; interface values tv and the two one-sided fluxes of a layer
+    // travel between neighbouring lanes (the whole wave takes part: no divergent exit above)
+    const bool lay = nz >= nzmin && nz <= nzmax - 1;
+    const double T0 = lay ? DTR(m.tr_arr_old, nz, n, tr) : 0.0, h0 = lay ? DA2(m.hnode_new, nz, n) : 1.0;
+    const double Tm1 = shup(T0), Tp1 = shdn(T0), Tp2 = shdn(Tp1);
+    const double hm1 = shup(h0), hp1 = shdn(h0), hp2 = shdn(hp1);
+    const double Wk = (nz >= nzmin && nz <= nzmax) ? DA2L(m.Wvel, nz, n) : 0.0, Wk1 = shdn(Wk);
+    const double d0 = Tp1 - T0, dm = T0 - Tm1, dp = Tp2 - Tp1;
+    double deltaj = h0 / (hm1 + h0 + hp1) * ((2. * hm1 + h0) / (hp1 + h0) * d0 + (h0 + 2. * hp1) / (hm1 + h0) * dm);
+    double deltajp1 = hp1 / (h0 + hp1 + hp2) * ((2. * h0 + hp1) / (hp2 + hp1) * dp + (hp1 + 2. * hp2) / (h0 + hp1) * d0);
+    if (d0 * dm > 0.) deltaj = fmin(fmin(fabs(deltaj), 2. * fabs(d0)), 2. * fabs(dm)) * copysign(1.0, deltaj);
+    else deltaj = 0.0;
+    if (dp * d0 > 0.) deltajp1 = fmin(fmin(fabs(deltajp1), 2. * fabs(dp)), 2. * fabs(d0)) * copysign(1.0, deltajp1);
+    else deltajp1 = 0.0;
+    const double tvn = T0 + h0 / (h0 + hp1) * d0 +
+                       1. / (hm1 + h0 + hp1 + hp2) *
+                           ((2. * hp1 * h0) / (h0 + hp1) * ((hm1 + h0) / (2. * h0 + hp1) - (hp2 + hp1) / (2. * hp1 + h0)) * d0 -
+                            h0 * (hm1 + h0) / (2. * h0 + hp1) * deltajp1 + hp1 * (hp1 + hp2) / (h0 + 2. * hp1) * deltaj);
+    double tvk = shup(tvn);                                   // tv(nz) was formed by layer nz-1 (nz = nzmin+2 .. nzmax-2)
+    if (!(nz >= nzmin + 2 && nz <= nzmax - 2)) tvk = 0.0;
+    if (nz == nzmin) tvk = T0;                                // the reference's assignment order: a later one wins on short columns
+    if (nz == nzmin + 1) tvk = 0.5 * (Tm1 + T0);
+    if (nz == nzmax - 1) { const double sg = copysign(1.0, Wk); tvk = -Tm1 * (sg < 0. ? sg : 0.) + T0 * (sg > 0. ? sg : 0.); }
+    if (nz == nzmax) tvk = Tm1;
+    double aL = tvk, aR = shdn(tvk);
+    const double t = T0;
+    if ((aR - t) * (t - aL) <= 0.) { aL = t; aR = t; }
+    if ((aR - aL) * (t - 0.5 * (aL + aR)) > (aR - aL) * (aR - aL) / 6.) aL = 3. * t - 2. * aR;
+    if ((aR - aL) * (t - 0.5 * (aR + aL)) < -((aR - aL) * (aR - aL)) / 6.) aR = 3. * t - 2. * aL;
+    const double dz = lay ? DA2(m.hnode, nz, n) : 1.0;
+    const double aj = 6.0 * (t - 0.5 * (aL + aR));
+    double ftop = 0.0, fbot = 0.0;
+    if (lay && Wk > 0.) {
+      const double x = fmin(Wk * dt / dz, 1.);
+      ftop = (-aL - 0.5 * x * (aR - aL + (1. - 2. / 3. * x) * aj));
+      ftop = ftop * DA2L(m.area, nz, n) * Wk;
+    }
+    if (lay && Wk1 < 0.) {
+      const double x = fmin(-Wk1 * dt / dz, 1.);
+      fbot = (-aR + 0.5 * x * (aR - aL - (1. - 2. / 3. * x) * aj));
+      fbot = fbot * DA2L(m.area, nz + 1, n) * Wk1;
+    }
+    const double fb_up = shup(fbot);                          // interface nz seen from layer nz-1
+    if (lay && Wk > 0.) ppm = ftop;
+    if (nz >= nzmin + 1 && nz <= nzmax && Wk < 0.) ppm = fb_up;
+    if (nz == nzmin) ppm = -tvk * Wk * DA2L(m.area, nz, n);
+    if (nz == nzmax) ppm = 0.0;
+  }
   if (nz >= nzmin && nz <= nzmax) {
     double ar = DA2L(m.area, nz, n);
     if (nz == nzmin) {
       fv = -DA2L(m.Wvel_e, nz, n) * DTR(m.tr_arr, nz, n, tr) * ar - 0.0;
       const double fvw = split ? -DA2L(m.Wvel, nz, n) * DTR(m.tr_arr, nz, n, tr) * ar - 0.0 : fv;
       adf = -DTR(m.tr_arr_old, nz, n, tr) * DA2L(m.Wvel, nz, n) * ar - fvw;
+      if (ver == 3) adf = ppm - fvw;
     } else if (nz == nzmax) {
       fv = 0.0 - 0.0;
       adf = 0.0 - fv;
@@ -188,8 +240,9 @@ __global__ void __launch_bounds__(BLOCK) k_fct_lo_node(DM m, int tr0) {
       double w = DA2L(m.Wvel, nz, n);
       const double fvw = split ? -0.5 * (DTR(m.tr_arr, nz, n, tr) * (w + fabs(w)) + DTR(m.tr_arr, nz - 1, n, tr) * (w - fabs(w))) * ar - 0.0 : fv;
       double s0 = DTR(m.tr_arr_old, nz, n, tr), sm1 = DTR(m.tr_arr_old, nz - 1, n, tr);
-      const int ver = m.p.tra_adv_ver;                        // 0 QR4C, 1 CDIFF (adv_tra_ver_cdiff :542-590), 2 UPW1 (:231-282)
-      if (ver == 2) {
+      if (ver == 3) {
+        adf = ppm - fvw;
+      } else if (ver == 2) {
         adf = -0.5 * (s0 * (w + fabs(w)) + sm1 * (w - fabs(w))) * ar - fvw;
       } else if (nz == nzmin + 1 || nz == nzmax - 1 || ver == 1) {
         adf = -0.5 * (sm1 + s0) * w * ar - fvw;

@@ -276,7 +276,8 @@ contains
     case ('QR4C'); p%tra_adv_ver = 0
     case ('CDIFF'); p%tra_adv_ver = 1
     case ('UPW1'); p%tra_adv_ver = 2
-    case default; p%tra_adv_ver = -1             ! (PPM: not implemented, fesom_gpu_init refuses it)
+    case ('PPM'); p%tra_adv_ver = 3
+    case default; p%tra_adv_ver = -1
     end select
     select case (trim(tra_adv_hor))
     case ('MFCT'); p%tra_adv_hor = 0

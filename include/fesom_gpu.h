@@ -119,7 +119,7 @@ typedef struct fesom_params {
   int    use_sw_pene;        /* short-wave penetration (namelist.config run_config): sw_3d of the forcing enters the temperature
                                 equation (oce_ale_tracer.F90:785-791) and the KPP surface buoyancy forcing (oce_ale_mixing_kpp.F90:508-640) */
   int    tra_adv_ver;        /* high-order vertical tracer advection under FCT (namelist.oce tra_adv_ver, oce_adv_tra_driver.F90:162-177):
-                                0 'QR4C' (default), 1 'CDIFF', 2 'UPW1'; tra_adv_lim='FCT' is fixed */
+                                0 'QR4C' (default), 1 'CDIFF', 2 'UPW1', 3 'PPM'; tra_adv_lim='FCT' is fixed */
   int    tra_adv_hor;        /* high-order horizontal tracer advection under FCT (tra_adv_hor, oce_adv_tra_driver.F90:140-153):
                                 0 'MFCT' (default), 1 'MUSCL' (nboundary_lay of oce_muscl_adv.F90:74-104 is formed inside the library), 2 'UPW1' */
 } fesom_params;

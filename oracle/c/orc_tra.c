@@ -189,6 +189,64 @@ static void adv_tra_ver_upw1_ho(const double *ttf, const double *W) {
   }
 }
 
+/* adv_tra_vert_ppm: src/oce_adv_tra_ver.F90:361-538 (Colella & Woodward 1984), init_zero=.false. */
+static void adv_tra_vert_ppm(const double *ttf, const double *W) {
+  double *flux = C_.adv_flux_ver;
+  const double dt = C_.p.dt;
+  double *tv = calloc((size_t)2 * (NL + 3), sizeof(double)), *tvert = tv + NL + 3;
+  for (int n = 1; n <= C_.m.myDim_nod2D; n++) {
+    int nzmax = NLEVN(n), nzmin = ULEVN(n);
+#define T_(k) A2(ttf, k, n)
+    tv[nzmin] = T_(nzmin);
+    tv[nzmin + 1] = 0.5 * (T_(nzmin) + T_(nzmin + 1));
+    {
+      double sg = copysign(1.0, A2L(W, nzmax - 1, n));
+      tv[nzmax - 1] = -T_(nzmax - 2) * (sg < 0. ? sg : 0.) + T_(nzmax - 1) * (sg > 0. ? sg : 0.);
+    }
+    tv[nzmax] = T_(nzmax - 1);
+    for (int nz = nzmin + 1; nz <= nzmax - 3; nz++) {
+      double dzjm1 = A2(C_.hnode_new, nz - 1, n), dzj = A2(C_.hnode_new, nz, n), dzjp1 = A2(C_.hnode_new, nz + 1, n), dzjp2 = A2(C_.hnode_new, nz + 2, n);
+      double d0 = T_(nz + 1) - T_(nz), dm = T_(nz) - T_(nz - 1), dp = T_(nz + 2) - T_(nz + 1);
+      double deltaj = dzj / (dzjm1 + dzj + dzjp1) * ((2. * dzjm1 + dzj) / (dzjp1 + dzj) * d0 + (dzj + 2. * dzjp1) / (dzjm1 + dzj) * dm);
+      double deltajp1 = dzjp1 / (dzj + dzjp1 + dzjp2) * ((2. * dzj + dzjp1) / (dzjp2 + dzjp1) * dp + (dzjp1 + 2. * dzjp2) / (dzj + dzjp1) * d0);
+      if (d0 * dm > 0.) deltaj = fmin(fmin(fabs(deltaj), 2. * fabs(d0)), 2. * fabs(dm)) * copysign(1.0, deltaj);
+      else deltaj = 0.0;
+      if (dp * d0 > 0.) deltajp1 = fmin(fmin(fabs(deltajp1), 2. * fabs(dp)), 2. * fabs(d0)) * copysign(1.0, deltajp1);
+      else deltajp1 = 0.0;
+      tv[nz + 1] = T_(nz) + dzj / (dzj + dzjp1) * d0 +
+                   1. / (dzjm1 + dzj + dzjp1 + dzjp2) *
+                       ((2. * dzjp1 * dzj) / (dzj + dzjp1) * ((dzjm1 + dzj) / (2. * dzj + dzjp1) - (dzjp2 + dzjp1) / (2. * dzjp1 + dzj)) * d0 -
+                        dzj * (dzjm1 + dzj) / (2. * dzj + dzjp1) * deltajp1 + dzjp1 * (dzjp1 + dzjp2) / (dzj + 2. * dzjp1) * deltaj);
+    }
+    for (int k = 1; k <= nzmax; k++) tvert[k] = 0.;
+    for (int nz = nzmin; nz <= nzmax - 1; nz++) {
+      double w0 = A2L(W, nz, n), w1 = A2L(W, nz + 1, n);
+      if (w0 <= 0. && w1 >= 0.) continue;
+      double aL = tv[nz], aR = tv[nz + 1], t = T_(nz);
+      if ((aR - t) * (t - aL) <= 0.) { aL = t; aR = t; }
+      if ((aR - aL) * (t - 0.5 * (aL + aR)) > (aR - aL) * (aR - aL) / 6.) aL = 3. * t - 2. * aR;
+      if ((aR - aL) * (t - 0.5 * (aR + aL)) < -((aR - aL) * (aR - aL)) / 6.) aR = 3. * t - 2. * aL;
+      double dzj = A2(C_.hnode, nz, n);
+      double aj = 6.0 * (t - 0.5 * (aL + aR));
+      if (w0 > 0.) {
+        double x = fmin(w0 * dt / dzj, 1.);
+        tvert[nz] = (-aL - 0.5 * x * (aR - aL + (1. - 2. / 3. * x) * aj));
+        tvert[nz] = tvert[nz] * AREA(nz, n) * w0;
+      }
+      if (w1 < 0.) {
+        double x = fmin(-w1 * dt / dzj, 1.);
+        tvert[nz + 1] = (-aR + 0.5 * x * (aR - aL - (1. - 2. / 3. * x) * aj));
+        tvert[nz + 1] = tvert[nz + 1] * AREA(nz + 1, n) * w1;
+      }
+    }
+    tvert[nzmin] = -tv[nzmin] * A2L(W, nzmin, n) * AREA(nzmin, n);
+    tvert[nzmax] = 0.0;
+    for (int nz = nzmin; nz <= nzmax; nz++) A2L(flux, nz, n) = tvert[nz] - A2L(flux, nz, n);
+#undef T_
+  }
+  free(tv);
+}
+
 /* adv_tra_ver_qr4c: src/oce_adv_tra_ver.F90:286-357 (init_zero=.false.) */
 static void adv_tra_ver_qr4c(const double *ttf, const double *W, double num_ord) {
   double *flux = C_.adv_flux_ver;
@@ -400,6 +458,7 @@ void orc_adv_tracers_ale(int tr) {
   adv_tra_hor(ttfAB, C_.p.tra_adv_hor == 1 ? 3 : C_.p.tra_adv_hor == 2 ? 2 : 1, C_.p.tra_adv_ph);
   if (C_.p.tra_adv_ver == 1) adv_tra_ver_cdiff(ttfAB, C_.Wvel);
   else if (C_.p.tra_adv_ver == 2) adv_tra_ver_upw1_ho(ttfAB, C_.Wvel);
+  else if (C_.p.tra_adv_ver == 3) adv_tra_vert_ppm(ttfAB, C_.Wvel);
   else adv_tra_ver_qr4c(ttfAB, C_.Wvel, C_.p.tra_adv_pv);
   oce_tra_adv_fct(ttf);
   /* flux2dtracer with use_lo */

@@ -194,6 +194,10 @@ CFGS = {
                         rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                         fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
                         balance_salt_water=".true.", synth_forcing=True, tra_adv_ver="UPW1", w_split=".true.", w_max_cfl="0.0003"),
+    "pi_pp_ppm": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                      rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                      fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                      balance_salt_water=".true.", synth_forcing=True, tra_adv_ver="PPM"),
     # horizontal high-order advection variants under FCT: tra_adv_hor = 'MUSCL', 'UPW1'
     "pi_pp_muscl": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
                         rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,

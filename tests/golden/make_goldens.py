@@ -113,6 +113,7 @@ def main():
     make("pi_pp_visc7", "pi_pp_visc7_reference.npz")    # visc_option = 7 (visc_filt_bidiff)
     make("pi_pp_cdiff", "pi_pp_cdiff_reference.npz")    # tra_adv_ver = 'CDIFF'
     make("pi_pp_upw1v", "pi_pp_upw1v_reference.npz")    # tra_adv_ver = 'UPW1' with w_split
+    make("pi_pp_ppm", "pi_pp_ppm_reference.npz")        # tra_adv_ver = 'PPM'
     make("pi_pp_upw1h", "pi_pp_upw1h_reference.npz")    # tra_adv_hor = 'UPW1', tra_adv_ver = 'CDIFF'
     make("souf", "souf_reference.npz")
     make("souf_linfs", "souf_linfs_reference.npz")      # linear free surface, full cells

@@ -345,6 +345,8 @@ FUZZ = [
     dict(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equation=1, mix_scheme="PP", tra_adv_hor="MUSCL"),
     dict(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equation=1, mix_scheme="KPP", tra_adv_hor="UPW1", tra_adv_ver="CDIFF"),
     dict(dt=900.0, which_ale="linfs", use_partial_cell=True, state_equation=1, mix_scheme="PP", tra_adv_hor="MUSCL", tra_adv_ver="UPW1", w_split=True, w_max_cfl=0.0005),
+    dict(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equation=1, mix_scheme="PP", tra_adv_ver="PPM"),
+    dict(dt=1200.0, which_ale="zstar", use_partial_cell=False, state_equation=1, mix_scheme="KPP", tra_adv_ver="PPM", Fer_GM=True, scaling_Ferreira=True, w_split=True, w_max_cfl=0.0005),
 ]
 
 

@@ -235,9 +235,9 @@ def test_oracle_chain_bitwise_biharmonic_viscosity(built, opt):
 
 
 @pytest.mark.parametrize("ver,cfg,kw", [("CDIFF", "pi_pp_cdiff", {}), ("UPW1", "pi_pp_upw1v", dict(w_split=True, w_max_cfl=0.0003)),
-                                        ("CDIFF", "pi_pp_upw1h", dict(tra_adv_hor="UPW1"))])
+                                        ("CDIFF", "pi_pp_upw1h", dict(tra_adv_hor="UPW1")), ("PPM", "pi_pp_ppm", {})])
 def test_oracle_chain_bitwise_vertical_advection_variants(built, ver, cfg, kw):
-    """tra_adv_ver = 'CDIFF' (adv_tra_ver_cdiff, src/oce_adv_tra_ver.F90:542-590) and 'UPW1' (:231-282, here together with w_split) as
+    """tra_adv_ver = 'CDIFF' (adv_tra_ver_cdiff, src/oce_adv_tra_ver.F90:542-590), 'PPM' (adv_tra_vert_ppm :361-538) and 'UPW1' (:231-282, with w_split) as
     the high-order vertical scheme under FCT, tra_adv_hor = 'UPW1' (src/oce_adv_tra_hor.F90:57-211) as the horizontal one: reference runs
     `pi_pp_cdiff`, `pi_pp_upw1v`, `pi_pp_upw1h`, every routine of 3 steps bit for bit.
     (tra_adv_hor = 'MUSCL' cannot be pinned this way: the reference forms nboundary_lay from the rank's own edges and never exchanges it
