@@ -457,3 +457,22 @@ def test_biharmonic_viscosity_chain_bitwise(built, opt):
             break
     assert not failures, "\n".join(failures[:10])
     gpu.close()
+
+
+@pytest.mark.parametrize("field,value,msg", [("visc_option", 4, "visc_option"), ("visc_option", 8, "visc_option"), ("tra_adv_ver", 4, "tra_adv_ver"),
+                                             ("tra_adv_ver", -1, "tra_adv_ver"), ("tra_adv_hor", 3, "tra_adv_hor"), ("mom_adv", 3, "mom_adv"),
+                                             ("mix_scheme", 3, "mix_scheme")])
+def test_init_refuses_options_it_does_not_implement(built, field, value, msg):
+    """fesom_gpu_init fails with a message naming the option instead of silently running something else (the Fortran layer maps a
+    namelist value it does not know to -1); the reference-side caller keeps its own routine for those runs."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.core import OceanCore
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0)
+    setattr(par, field, value)
+    with pytest.raises(RuntimeError, match=msg):
+        OceanCore(mesh, par)
+    par = make_params(dt=900.0)                      # and the library is usable afterwards
+    gpu = OceanCore(mesh, par)
+    gpu.close()
