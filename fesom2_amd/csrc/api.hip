@@ -452,6 +452,13 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
 #undef F
 #undef FT
   m.sv_info = dev_alloc<int>(4);
+  m.lat_deg = nullptr;
+  if (!par->Kv0_const) {                // geo_coord_nod2D(2,node)/rad with the reference's rad = pi/180, pi = 3.14159265358979 (oce_modules.F90:11-12)
+    const double rad = 3.14159265358979 / 180.0;
+    std::vector<double> lat(N);
+    for (size_t n = 0; n < N; n++) lat[n] = d->geo_coord_nod2D[2 * n + 1] / rad;
+    m.lat_deg = dev_upload(lat);
+  }
   m.nb_lay = nullptr;
   if (par->tra_adv_hor == 1) {          // nboundary_lay: the layer below which a node touches the boundary (oce_muscl_adv.F90:74-104, owned edges)
     std::vector<int> nb(N, (int)nl - 1);

@@ -51,6 +51,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   double *ssh_values;
   // Gent-McWilliams bolus velocities (kernels_gm.hip)
   double *fer_K, *fer_gamma, *fer_Wvel, *fer_c, *fer_UV;   // (nl,N), (2,nl,N), (nl,N), (N), (2,nl-1,E)
+  const double *lat_deg;                                  // (N) geographic latitude in degrees (geo_coord_nod2D(2,:)/rad), Kv0_const = .false. only
   const int *nb_lay;                                      // (N) nboundary_lay (oce_muscl_adv.F90:74-104), tra_adv_hor = MUSCL only
   const double *redi_k0;                                  // (N) K_hor*(mesh_resolution/100km)^2: surface Ki of Redi without GM
   const double *gm_scal_static;                           // (N) mesh-only part of the horizontal GM scaling
@@ -153,6 +154,19 @@ __device__ __forceinline__ int col_id_th() { return __builtin_amdgcn_readfirstla
 static inline size_t thomas_lds_bytes(int nlm1, int nrhs) { return (size_t)(3 + nrhs) * nlm1 * TH_CP * sizeof(double) + 2 * TH_COLS * sizeof(int); }
 static inline int nblocks_th(int ncol) { return (ncol + TH_COLS - 1) / TH_COLS; }
 #define LAUNCH_TH(k, ncol, nrhs, ...) hipLaunchKernelGGL(k, dim3(nblocks_th(ncol)), dim3(TH_BLOCK), thomas_lds_bytes(m.nlm1, nrhs), s, __VA_ARGS__)
+
+// Kv0_background_qiang (src/oce_ale_mixing_pp.F90:91-125): background vertical diffusivity by latitude [deg] and depth [m]
+__device__ __forceinline__ double kv0_background_qiang(double lat, double dep) {
+  const double aux = (0.6 + 1.0598 / 3.1415926 * atan(4.5e-3 * (dep - 2500.0))) * 1.0e-5;
+  double ratio;
+  if (fabs(lat) < 5.0) ratio = 1.0;
+  else ratio = fmin(1.0 + 9.0 * (fabs(lat) - 5.0) / 10.0, 10.0);
+  if (lat > 70.0) {
+    if (dep <= 50.0) ratio = 4.0 + 6.0 * (50.0 - dep) / 50.0;
+    else ratio = 4.0;
+  }
+  return aux * ratio;
+}
 
 template <int NRHS>
 __device__ __forceinline__ void thomas_inblock(double *sh, int nl1, bool valid, int kmin, int kmax, double a, double b, double c, double r1,

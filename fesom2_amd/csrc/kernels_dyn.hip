@@ -284,7 +284,7 @@ __device__ __forceinline__ void pp_node_body(const DM &m, int n) {     // Kv: Ri
   int nzmin = m.ulev_n[n];
   if (nz < nzmin + 1 || nz > m.nlev_n[n] - 1) return;
   double k = pp_raw(m, nz, n);
-  double kv = 0.01 * (k * k * k) + m.p.K_ver;
+  double kv = 0.01 * (k * k * k) + (m.p.Kv0_const ? m.p.K_ver : kv0_background_qiang(m.lat_deg[n], fabs(DA2L(m.zbar_3d_n, nz, n))));
   if (m.p.use_instabmix && DA2L(m.bvfreq, nz, n) < 0.) kv = dmax_(kv, m.p.instabmix_kv);
   if (nzmin <= 1 && m.p.use_windmix && nz <= m.p.windmix_nl + 1) kv = dmax_(kv, m.p.windmix_kv);
   DA2L(m.Kv, nz, n) = kv;

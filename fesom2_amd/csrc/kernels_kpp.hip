@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(BLOCK) k_kpp_col(DM m) {
     double frit = 1.0 - ratio * ratio;
     frit = frit * frit * frit;
     visc = m.p.visc_sh_limit * frit + m.p.A_ver;
-    kv1 = m.p.diff_sh_limit * frit + m.p.K_ver;
+    kv1 = m.p.diff_sh_limit * frit + (m.p.Kv0_const ? m.p.K_ver : kv0_background_qiang(m.lat_deg[n], fabs(DA2L(m.zbar_3d_n, nz, n))));
   }
   {
     double vf = bcast(visc, nzmin), vl = bcast(visc, nzmax - 2), kf = bcast(kv1, nzmin), kl = bcast(kv1, nzmax - 2);

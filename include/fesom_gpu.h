@@ -113,7 +113,7 @@ typedef struct fesom_params {
   double K_GM_rampmax, K_GM_rampmin, K_GM_resscalorder;
   int    scaling_Ferreira, scaling_Rossby /* unsupported */, scaling_resolution, scaling_FESOM14;
   int    Redi;               /* isoneutral (Redi) diffusion: rotated horizontal + explicit/implicit vertical parts (oce_ale_tracer.F90) */
-  /* KPP (mix_scheme=1; namelist.oce: visc_sh_limit, diff_sh_limit, Ricr, concv; Kv0_const=.true., double_diffusion=.false.,
+  /* KPP (mix_scheme=1; namelist.oce: visc_sh_limit, diff_sh_limit, Ricr, concv; double_diffusion=.false.,
      use_sw_pene=.false., use_kpp_nonlclflx=.false. are the only supported settings of those switches) */
   double visc_sh_limit, diff_sh_limit, Ricr, concv;
   int    use_sw_pene;        /* short-wave penetration (namelist.config run_config): sw_3d of the forcing enters the temperature
@@ -122,6 +122,8 @@ typedef struct fesom_params {
                                 0 'QR4C' (default), 1 'CDIFF', 2 'UPW1', 3 'PPM'; tra_adv_lim='FCT' is fixed */
   int    tra_adv_hor;        /* high-order horizontal tracer advection under FCT (tra_adv_hor, oce_adv_tra_driver.F90:140-153):
                                 0 'MFCT' (default), 1 'MUSCL' (nboundary_lay of oce_muscl_adv.F90:74-104 is formed inside the library), 2 'UPW1' */
+  int    Kv0_const;          /* 1 (default): background vertical diffusivity K_ver; 0: latitude/depth dependent Kv0_background_qiang
+                                (oce_ale_mixing_pp.F90:91-125) in the PP and KPP schemes */
 } fesom_params;
 
 /* ---- prognostic state = restart set (io_restart.F90:99-155) + ALE thickness arrays -- */

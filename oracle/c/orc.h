@@ -109,6 +109,7 @@ void orc_kpp_tables(double *wmt, double *wst, double *deltaz, double *deltau);
 void orc_compute_vel_rhs(void);
 void orc_visc_filt_bcksct(void);
 void orc_viscosity_filter(void);
+double orc_kv0_background_qiang(int n, int nz);
 void orc_impl_vert_visc_ale(void);
 void orc_update_stiff_mat_ale(void);
 void orc_compute_ssh_rhs_ale(void);

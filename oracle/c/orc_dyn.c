@@ -465,6 +465,21 @@ static void visc_filt_biharmonic(int opt) {
   }
 }
 
+/* Kv0_background_qiang(Kv0_b, geo_coord_nod2D(2,node)/rad, abs(zbar_3d_n(nz,node))): src/oce_ale_mixing_pp.F90:91-125, callers
+ * :73-76 and oce_ale_mixing_kpp.F90:821-822 (Kv0_const=.false.) */
+double orc_kv0_background_qiang(int n, int nz) {
+  const double rad = 3.14159265358979 / 180.0;
+  double lat = C_.m.geo_coord_nod2D[2 * (n - 1) + 1] / rad, dep = fabs(A2L(C_.zbar_3d_n, nz, n));
+  double aux = (0.6 + 1.0598 / 3.1415926 * atan(4.5e-3 * (dep - 2500.0))) * 1.0e-5, ratio;
+  if (fabs(lat) < 5.0) ratio = 1.0;
+  else ratio = fmin(1.0 + 9.0 * (fabs(lat) - 5.0) / 10.0, 10.0);
+  if (lat > 70.0) {
+    if (dep <= 50.0) ratio = 4.0 + 6.0 * (50.0 - dep) / 50.0;
+    else ratio = 4.0;
+  }
+  return aux * ratio;
+}
+
 /* viscosity_filter(visc_option): src/oce_dyn.F90:196-228 (options 5, 6, 7) */
 void orc_viscosity_filter(void) {
   if (C_.p.visc_option == 5) orc_visc_filt_bcksct();

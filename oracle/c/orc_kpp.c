@@ -117,7 +117,7 @@ static void ri_iwmix(void) {
       double frit = 1.0 - ratio * ratio;
       frit = frit * frit * frit;
       A2L(C_.kpp_viscA, nz, n) = C_.p.visc_sh_limit * frit + C_.p.A_ver;
-      A2L(C_.kpp_Kv1, nz, n) = C_.p.diff_sh_limit * frit + C_.p.K_ver;
+      A2L(C_.kpp_Kv1, nz, n) = C_.p.diff_sh_limit * frit + (C_.p.Kv0_const ? C_.p.K_ver : orc_kv0_background_qiang(n, nz));
       A2L(C_.kpp_Kv2, nz, n) = A2L(C_.kpp_Kv1, nz, n);
     }
     A2L(C_.kpp_viscA, nzmin, n) = A2L(C_.kpp_viscA, nzmin + 1, n);

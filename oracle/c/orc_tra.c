@@ -687,7 +687,7 @@ void orc_mixing_pp(void) {
   for (int n = 1; n <= C_.N; n++)
     for (int nz = ULEVN(n) + 1; nz <= NLEVN(n) - 1; nz++) {
       double k = A2L(C_.Kv, nz, n);
-      A2L(C_.Kv, nz, n) = mix_coeff_PP * (k * k * k) + C_.p.K_ver;
+      A2L(C_.Kv, nz, n) = mix_coeff_PP * (k * k * k) + (C_.p.Kv0_const ? C_.p.K_ver : orc_kv0_background_qiang(n, nz));
     }
 }
 

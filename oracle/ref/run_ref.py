@@ -116,7 +116,7 @@ gamma0_tra=0.0005
 gamma1_tra=0.0125
 gamma2_tra=0.
 diff_sh_limit=5.0e-3
-Kv0_const=.true.
+Kv0_const={Kv0_const}
 double_diffusion=.false.
 K_ver=1.0e-5
 K_hor={k_hor}
@@ -198,6 +198,15 @@ CFGS = {
                       rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                       fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
                       balance_salt_water=".true.", synth_forcing=True, tra_adv_ver="PPM"),
+    # Kv0_const=.false.: latitude/depth dependent background diffusivity (Kv0_background_qiang) in PP and in KPP
+    "pi_pp_kv0": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                      rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                      fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                      balance_salt_water=".true.", synth_forcing=True, Kv0_const=".false."),
+    "pi_kpp_kv0": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                       rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                       fer_gm=".false.", redi=".false.", mix_scheme="KPP", k_hor="3000.", surf_relax_s="1.929e-06",
+                       balance_salt_water=".true.", synth_forcing=True, Kv0_const=".false."),
     # horizontal high-order advection variants under FCT: tra_adv_hor = 'MUSCL', 'UPW1'
     "pi_pp_muscl": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
                         rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
@@ -263,7 +272,7 @@ def prepare(cfg, np_, tag=""):
             partition_io.write_dist(cp, np_)
         meshdir = cp
     open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **dict(dict(use_sw_pene=".false."), **c)))
-    open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0", visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT"), **c)))
+    open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0", visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=".true."), **c)))
     if c["toy_ocean"] == ".false.":
         from fesom2_amd.synthetic import write_ic_files
         write_ic_files(meshdir, rd)

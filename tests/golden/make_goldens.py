@@ -114,6 +114,8 @@ def main():
     make("pi_pp_cdiff", "pi_pp_cdiff_reference.npz")    # tra_adv_ver = 'CDIFF'
     make("pi_pp_upw1v", "pi_pp_upw1v_reference.npz")    # tra_adv_ver = 'UPW1' with w_split
     make("pi_pp_ppm", "pi_pp_ppm_reference.npz")        # tra_adv_ver = 'PPM'
+    make("pi_pp_kv0", "pi_pp_kv0_reference.npz")        # Kv0_const = .false. with PP
+    make("pi_kpp_kv0", "pi_kpp_kv0_reference.npz")      # Kv0_const = .false. with KPP
     make("pi_pp_upw1h", "pi_pp_upw1h_reference.npz")    # tra_adv_hor = 'UPW1', tra_adv_ver = 'CDIFF'
     make("souf", "souf_reference.npz")
     make("souf_linfs", "souf_linfs_reference.npz")      # linear free surface, full cells

@@ -261,3 +261,27 @@ def test_oracle_chain_bitwise_vertical_advection_variants(built, ver, cfg, kw):
         orc.set(f, g["forcing/" + f])
     bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
     assert not bad, "\n".join(bad[:20])
+
+
+@pytest.mark.parametrize("mix,cfg", [("PP", "pi_pp_kv0"), ("KPP", "pi_kpp_kv0")])
+def test_oracle_chain_bitwise_kv0_background(built, mix, cfg):
+    """Kv0_const=.false.: latitude/depth dependent background diffusivity Kv0_background_qiang (src/oce_ale_mixing_pp.F90:91-125) in
+    oce_mixing_PP (:73-76) and in KPP's ri_iwmix (oce_ale_mixing_kpp.F90:821-822); reference runs `pi_pp_kv0` / `pi_kpp_kv0`, every
+    routine of 3 steps bit for bit (atan: the oracle and the reference build use the same libm here)."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.synthetic import analytic_ts
+    from oracle_lib import Oracle
+    from ref_chain import run_reference_chain
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, mix_scheme=mix, Kv0_const=False)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    orc = Oracle(mesh, par)
+    orc.set_state(st)
+    g = gold(cfg)
+    for f in FORCING:
+        orc.set(f, g["forcing/" + f])
+    bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
+    assert not bad, "\n".join(bad[:20])
