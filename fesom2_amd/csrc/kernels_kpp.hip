@@ -5,7 +5,7 @@
 // One wavefront per node column, lane = level.  Everything the reference does with sequential searches over a column
 // (first level whose bulk Richardson number exceeds Ricr, first interface below hbl) is a ballot + find-first over the lanes;
 // per-column scalars (ustar, Bo, hbl, kbl, caseA, the matching coefficients at hbl) are computed redundantly by all lanes.
-// Supported switches: use_sw_pene (sw_3d from the forcing), double_diffusion=.false., Kv0_const=.true., use_kpp_nonlclflx=.false.;
+// Supported switches: use_sw_pene (sw_3d from the forcing), double_diffusion=.false., use_kpp_nonlclflx=.false.; Kv0_const either way;
 // module switches as in the source (smooth_blmc=.true., the others .false.).
 //   k_kpp_col     dVsq, ustar, Bo, ri_iwmix, bldepth, blmix_kpp, enhance          (owned nodes)
 //   k_kpp_smooth  one sweep of smooth_nod3D for the three blmc fields (grid.y)    (owned nodes; halo by exchange)

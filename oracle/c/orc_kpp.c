@@ -10,7 +10,7 @@
  *   blmix_kpp           :958-1145  boundary layer profiles, nonlocal coefficient ghats
  *   enhance             :1152-1191 enhanced diffusivity at the kbl-1 interface
  *   smooth_nod3D        src/gen_support.F90:78-178
- * Supported options: use_sw_pene (sw_3d from the forcing), double_diffusion=.false., Kv0_const=.true., use_kpp_nonlclflx=.false.
+ * Supported options: use_sw_pene (sw_3d from the forcing), double_diffusion=.false., use_kpp_nonlclflx=.false.; Kv0_const either way
  * (the reference's defaults);
  * module switches smooth_blmc=.true., smooth_hbl/smooth_Ri_hor/smooth_Ri_ver/limit_hbl_ekmmob=.false. as in the source.
  */
