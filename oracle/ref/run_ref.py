@@ -251,6 +251,25 @@ def refined_case(levels, npes, base="pi_pp", workdir=None):
     return name, d
 
 
+def channel_case(levels, npes, layers=47, base="souf", workdir=None):
+    """registers configuration `chan_r<levels>_<layers>`: the Soufflet channel of the reference's CI case refined `levels` times
+    (fesom2_amd.channel_mesh: cyclic refinement, `layers` stretched layers, dt = 1200 s / 2**levels) with edge files and a
+    `dist_<npes>` partition in the reference's formats -- the CORE2-class workload (BASELINE config #3) that the REFERENCE runs too."""
+    import tempfile
+    from fesom2_amd import channel_mesh, partition_io
+    d = os.path.join(workdir or tempfile.gettempdir(), f"fesom_chan_r{levels}_{layers}")
+    kw = dict(force_rotation=False, cyclic_length_deg=channel_mesh.CYCLIC_DEG)
+    if not os.path.exists(os.path.join(d, "edgenum.out")):
+        channel_mesh.build(os.path.join(MESHES, "soufflet"), d, levels, layers)
+        partition_io.write_edge_files(d, **kw)
+    for n in sorted({npes, 1}):
+        if n > 1 and not os.path.isdir(os.path.join(d, f"dist_{n}")):
+            partition_io.write_dist(d, n, **kw)
+    name = f"chan_r{levels}_{layers}"
+    CFGS[name] = dict(CFGS[base], mesh=d, step_per_day=int(round(86400.0 / channel_mesh.dt_for(levels))))
+    return name, d
+
+
 def prepare(cfg, np_, tag=""):
     c = CFGS[cfg]
     rd = os.path.join(OUT, f"run_{cfg}_{np_}{tag}")

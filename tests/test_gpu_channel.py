@@ -1,0 +1,144 @@
+"""GPU: the CORE2-class workload (BASELINE config #3 stand-in) = the Soufflet channel of the reference's CI case refined
+uniformly, 47 layers (fesom2_amd/channel_mesh.py, fesom2_amd/workloads.py).
+
+  * refinement level 1 (11 450 nodes, multi-workgroup SSH solve): HIP == oracle bit for bit, routine by routine over 2 steps
+    incl. the toy hooks, and for the prognostic state after 10 further steps through fesom_gpu_run_steps;
+  * level 1 against the REAL reference (oracle/_ref/fesom_oracle.x on 2 MPI ranks; mesh, edge files and partition written in
+    its formats by partition_io) after 10 steps: solver-tolerance agreement;
+  * level 3 = the benchmark size (182 600 nodes, 8.6 M wet node cells): first steps against the extrema the reference prints
+    (write_step_info) -- committed in tests/golden/channel_r3_reference.json by tests/golden/make_channel_golden.py -- and
+    size-independent properties over 40 steps: tracer content conserved, salinity stays 35, no blow-up flag.
+"""
+import json
+import os
+import numpy as np
+import pytest
+
+from parity_chain import full_chain, compare
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def toy_chain():
+    ch = []
+    for routine, arg, fields in full_chain(2):
+        ch.append((routine, arg, fields))
+        if routine == "solve_ssh":
+            ch.append(("relax_zonal_vel", 0, ["UV_rhs"]))
+        if routine == "diff_tracers_ale":
+            ch.append(("relax_zonal_temp", 0, ["tr_arr"]))
+    return ch
+
+
+def start_pair(levels, tmp):
+    from fesom2_amd import workloads
+    from fesom2_amd.core import OceanCore
+    from oracle_lib import Oracle
+    wl = workloads.channel(levels, workdir=str(tmp))
+    mesh = wl.load_mesh()
+    par = wl.params()
+    gpu, orc = OceanCore(mesh, par), Oracle(mesh, par)
+    st, aux, _ = wl.initial_state(mesh)
+    gpu.upload_state(st); orc.set_state(st)
+    for k, v in aux.items():
+        gpu.set(k, v); orc.set(k, v)
+    orc.call("compute_zonal_mean_ini")
+    gpu.call("compute_zonal_mean"); orc.call("compute_zonal_mean")
+    return wl, mesh, gpu, orc
+
+
+def run_chain(gpu, orc, steps):
+    failures = []
+    for step in steps:
+        for routine, arg, fields in toy_chain():
+            gpu.call(routine, arg); orc.call(routine, arg)
+            for f in fields:
+                ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+                if not ok:
+                    failures.append(f"step {step} {routine}({arg}) {msg}")
+        if failures:
+            break
+    return failures
+
+
+def test_channel_r1_chain_and_steps_bitwise(built, tmp_path):
+    wl, mesh, gpu, orc = start_pair(1, tmp_path)
+    assert mesh.nod2D > 4096 and mesh.nl == 48
+    failures = run_chain(gpu, orc, (1, 2))
+    assert not failures, "\n".join(failures[:10])
+    assert gpu.solver_iterations == orc.solver_iterations
+    gpu.run_steps(3, 10)
+    for n in range(10):
+        if (3 + n) % 10 == 0:
+            orc.call("compute_zonal_mean")
+        orc.call("step", 3 + n)
+    for f in ("tr_arr", "UV", "eta_n", "hnode"):
+        ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+        assert ok, msg
+    gpu.close()
+
+
+def test_channel_r1_vs_reference_cpu(built):
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
+    from oracle.ref import run_ref
+    from oracle.ref.compare_oracle import assemble
+    from refdump import read_dump
+    from fesom2_amd import workloads
+    from fesom2_amd.core import OceanCore
+    assert os.path.exists(os.path.join(REPO, "oracle", "_ref", "fesom_oracle.x"))
+    nsteps = 10
+    name, d = run_ref.channel_case(1, 2)
+    rd, rc, lines = run_ref.run(name, 2, nsteps, mode="step", dump=(nsteps,))
+    assert rc == 0, open(os.path.join(rd, "stdout.log")).read()[-2000:]
+    sc = [read_dump(os.path.join(rd, "dumps", f"setup.r{r:05d}.bin")) for r in range(2)]
+    dc = [read_dump(os.path.join(rd, "dumps", f"state{nsteps:04d}.r{r:05d}.bin")) for r in range(2)]
+    wl = workloads.channel(1)
+    mesh = wl.load_mesh()
+    gpu = OceanCore(mesh, wl.params())
+    wl.start(gpu, mesh)
+    gpu.run_steps(1, nsteps)
+    N, E, n1 = mesh.nod2D, mesh.elem2D, mesh.nl - 1
+    mine = {"eta_n": gpu.get("eta_n", N), "tr_arr": gpu.get("tr_arr", 2 * n1 * N).reshape(2, N, n1), "UV": gpu.get("UV", 2 * n1 * E).reshape(E, n1, 2),
+            "hnode": gpu.get("hnode", n1 * N).reshape(N, n1)}
+    gpu.close()
+    worst = {}
+    for f, a in mine.items():
+        b = assemble(dc, sc, f)
+        assert b.shape == a.shape, (f, a.shape, b.shape)
+        worst[f] = float(np.abs(a - b).max())
+    assert 0.0 < worst["eta_n"] < 1e-8 and worst["tr_arr"] < 1e-8 and worst["UV"] < 1e-8 and worst["hnode"] < 1e-8, worst
+
+
+def test_channel_r3_benchmark_size(built, tmp_path):
+    """182 600 nodes: eta extrema of the first steps == what the reference prints on the same mesh (8 MPI ranks, committed
+    golden), properties over 40 steps"""
+    from fesom2_amd import workloads
+    from fesom2_amd.core import OceanCore
+    gold = json.load(open(os.path.join(REPO, "tests", "golden", "channel_r3_reference.json")))
+    wl = workloads.channel(3, workdir=str(tmp_path))
+    mesh = wl.load_mesh()
+    assert mesh.nod2D == gold["nod2D"]
+    gpu = OceanCore(mesh, wl.params())
+    wl.start(gpu, mesh)
+    n1, N = mesh.nl - 1, mesh.nod2D
+    vol = np.array(mesh.areasvol)[:, :n1]
+    T0 = gpu.get("tr_arr", 2 * n1 * N).reshape(2, N, n1)[0]
+    h0 = gpu.get("hnode", n1 * N).reshape(N, n1)
+    c0 = float((T0 * h0 * vol).sum())
+    for n in range(1, 41):
+        gpu.run_steps(n, 1)
+        if str(n) in gold["eta_minmax"]:
+            e = gpu.get("eta_n", N)
+            lo, hi = gold["eta_minmax"][str(n)]
+            assert abs(e.min() - lo) < 1e-7 * max(1.0, abs(lo)) * 10 and abs(e.max() - hi) < 1e-7 * max(1.0, abs(hi)) * 10, (n, e.min(), e.max(), lo, hi)
+    si = gpu.step_info()
+    assert si["blowup"] == 0.0
+    tr = gpu.get("tr_arr", 2 * n1 * N).reshape(2, N, n1)
+    h = gpu.get("hnode", n1 * N).reshape(N, n1)
+    assert np.abs(tr[1] - 35.0).max() < 1e-10                        # constant salinity stays constant (round-off of the FCT update only)
+    c1 = float((tr[0] * h * vol).sum())
+    # heat content changes only through the relaxation to the zonal-mean climatology (tau = 50 d): tiny over 40 steps of 150 s
+    assert abs(c1 - c0) / abs(c0) < 1e-6, (c0, c1)
+    gpu.close()
