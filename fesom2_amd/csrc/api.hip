@@ -15,6 +15,8 @@
 int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int first_step);
 int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg);
 void solver_prepare();
+void tile_prepare_tra();
+void tile_prepare_dyn();
 
 namespace {
 struct Field { void *p; size_t count; int slabs; };   // slabs>1: one slab of `count` values per tracer
@@ -282,6 +284,11 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   m.p = *par;
   m.N = d->myDim_nod2D + d->eDim_nod2D; m.E = d->myDim_elem2D + d->eDim_elem2D; m.D = d->myDim_edge2D + d->eDim_edge2D;
   m.myN = d->myDim_nod2D; m.myE = d->myDim_elem2D; m.myD = d->myDim_edge2D;
+  {   // shape of the kernels that end in a Thomas sweep: tiles on CORE2-class meshes (dev.h:TL_MIN_COLUMNS), FESOM_GPU_TILE=0/1 overrides
+    const char *tl = getenv("FESOM_GPU_TILE");
+    m.use_tile = tl ? atoi(tl) : (m.myN >= TL_MIN_COLUMNS ? 1 : 0);
+    if (m.use_tile < 0 || m.use_tile > 4) m.use_tile = 1;
+  }
   m.nl = d->nl; m.nlm1 = d->nl - 1; m.ntr = par->num_tracers; m.maxk = d->max_nod_in_elem; m.nza = d->ssh_nza; m.edge2D_in = d->edge2D_in;
   const size_t N = m.N, E = m.E, D = m.D, nl = m.nl, n1 = m.nlm1;
   const int EX = m.E + d->eXDim_elem2D;
@@ -540,6 +547,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     }
   }
   solver_prepare();
+  tile_prepare_tra(); tile_prepare_dyn();
   G.first_step = 1;
   G.ready = true;
   HIPCHK(hipDeviceSynchronize());

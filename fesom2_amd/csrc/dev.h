@@ -21,6 +21,7 @@
 
 struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg segment, scalar loads)
   int N, E, EX, D, myN, myE, myD, nl, nlm1, ntr, maxk, nza, edge2D_in, ssh_maxnnz;   // EX = E + extended element halo
+  int use_tile;               // CORE2-class shape of the kernels that end in a Thomas sweep (ThTile<.., TL_COLS>), see TL_MIN_COLUMNS
   // ---- connectivity, 0-based (-1 = none)
   const int *elem_nodes;      // (3,E)
   const int *edges;           // (2,D)
@@ -116,22 +117,39 @@ __device__ __forceinline__ int rdlane(int x, int lane) { return __builtin_amdgcn
 __device__ __forceinline__ double shup(double x) { return __shfl_up(x, 1, 64); }     // value of lane-1
 __device__ __forceinline__ double shdn(double x) { return __shfl_down(x, 1, 64); }   // value of lane+1
 
-// Sequential (reference-order) running sums across the lanes of one wavefront.  All lanes execute
-// the same chain; lane j keeps the partial sum after element j.  O(n) broadcasts, bit-identical to
-// the scalar loop  acc = init; for j=first..last: acc = acc + x[j].
+// Sequential (reference-order) running sums across the lanes of one wavefront, bit-identical to the scalar loop
+//   acc = init; for j = first..last: acc = acc + x[j]      (lane j keeps the partial sum after element j).
+// Ripple form: every lane holds y (start: init); one step is  y[l] = y[l-1] + x[l]  for ALL lanes at once (DPP wavefront shift,
+// lane 0 takes init; x = 0 outside [first, last]).  After k steps the lanes first .. first+k-1 hold their final value and keep
+// it (their left neighbour no longer changes), so last-first+1 steps finish the column: 2 DPP moves + 1 add per step, no
+// broadcast through SGPRs, no per-step selects.  (init + 0.0 == init for every init but -0.0, which no caller passes.)
+__device__ __forceinline__ double dpp_wave_shr1(double y, double fill) {      // lane l <- y[l-1], lane 0 <- fill
+  int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(y), 0x138, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(y), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_wave_shl1(double y, double fill) {      // lane l <- y[l+1], lane 63 <- fill
+  int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(y), 0x130, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(y), 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double seq_sum_up(double x, int first, int last, double init) {
-  double acc = init, mine = init;
-  int l = lane_id();
+  const int l = lane_id();
   first = __builtin_amdgcn_readfirstlane(first); last = __builtin_amdgcn_readfirstlane(last);      // level bounds of the wave's column: uniform
-  for (int j = first; j <= last; ++j) { acc = acc + bcast(x, j); if (l == j) mine = acc; }
-  return mine;
+  const bool in = l >= first && l <= last;
+  const double xi = in ? x : 0.0;
+  double y = init;
+  for (int k = last - first + 1; k > 0; --k) y = dpp_wave_shr1(y, init) + xi;
+  return in ? y : init;
 }
 __device__ __forceinline__ double seq_sum_down(double x, int first, int last, double init) {   // j = first, first-1, ..., last
-  double acc = init, mine = init;
-  int l = lane_id();
+  const int l = lane_id();
   first = __builtin_amdgcn_readfirstlane(first); last = __builtin_amdgcn_readfirstlane(last);
-  for (int j = first; j >= last; --j) { acc = acc + bcast(x, j); if (l == j) mine = acc; }
-  return mine;
+  const bool in = l <= first && l >= last;
+  const double xi = in ? x : 0.0;
+  double y = init;
+  for (int k = first - last + 1; k > 0; --k) y = dpp_wave_shl1(y, init) + xi;
+  return in ? y : init;
 }
 __device__ __forceinline__ double wave_max(double x) {
   for (int s = 32; s >= 1; s >>= 1) x = fmax(x, __shfl_xor(x, s, 64));
@@ -168,77 +186,115 @@ __device__ __forceinline__ double kv0_background_qiang(double lat, double dep) {
   return aux * ratio;
 }
 
+// Tile of COLS columns whose tridiagonal systems (NRHS right-hand sides) are solved by ONE wavefront with lane = column.
+// LDS image: [3 + NRHS arrays: a, b, c, r1 (, r2)][level][COLS + 1 (padding)] doubles, then the level range of every column.
+//   put(ci, ...)  -- by the wave that assembled column ci (lane = level)          } a kernel calls put for all its columns,
+//   sweep()       -- whole block: barrier, wave 0 solves all columns, barrier     } then sweep once, then get
+//   get(ci, ...)  -- solution of column ci back to lane = level
+// Two shapes are instantiated: COLS = 8, one column per wave (pi: latency-bound, the columns' values stay in registers across
+// the sweep) and COLS = 32 / 64 with several columns per wave (CORE2-class meshes: the sweep is amortised over a full tile).
+template <int NRHS, int COLS>
+struct ThTile {
+  double *sh; int nl1, astr; int *rng;
+  static constexpr int CP = COLS + 1;
+  __device__ __forceinline__ ThTile(double *s, int nl1_) : sh(s), nl1(nl1_), astr(nl1_ * CP) { rng = (int *)(sh + (size_t)(3 + NRHS) * astr); }
+  static size_t lds_bytes(int nlm1) { return (size_t)(3 + NRHS) * nlm1 * CP * sizeof(double) + 2 * COLS * sizeof(int); }
+  __device__ __forceinline__ void put(int ci, bool valid, int kmin, int kmax, double a, double b, double c, double r1, double r2) {
+    const int l = threadIdx.x & 63, nz = l + 1;
+    if (l == 0) { rng[2 * ci] = valid ? kmin : 1; rng[2 * ci + 1] = valid ? kmax : 0; }
+    if (nz <= nl1) {
+      double *p = sh + (nz - 1) * CP + ci;
+      p[0] = a; p[astr] = b; p[2 * astr] = c; p[3 * astr] = r1;
+      if (NRHS == 2) p[4 * astr] = r2;
+    }
+  }
+  __device__ __forceinline__ void get(int ci, double &x1, double &x2) const {
+    const int nz = (threadIdx.x & 63) + 1;
+    x1 = 0.0; x2 = 0.0;
+    if (nz <= nl1) {
+      const double *p = sh + (nz - 1) * CP + ci;
+      x1 = p[3 * astr];
+      if (NRHS == 2) x2 = p[4 * astr];
+    }
+  }
+  __device__ __forceinline__ void sweep() {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (w == 0) {
+      // Branch-free and software-pipelined: the first active level uses a = 0 (b - cp*0 = b, r - x*0 = r exactly, i.e. the
+      // reference's c/b, r/b start), inactive levels are discarded by selects, so the independent divide chains (cp, x1,
+      // x2) interleave in straight-line code and  cp_j = c_j / (b_j - cp_{j-1} a_j)  is the only serial part.
+      const int lc = l < COLS ? l : COLS - 1;
+      int kmn = 1, kmxl = 0;
+      if (l < COLS) { kmn = rng[2 * l]; kmxl = rng[2 * l + 1]; }
+      int kmx = kmxl;
+      for (int s = 32; s >= 1; s >>= 1) kmx = max(kmx, __shfl_xor(kmx, s, 64));
+      kmx = __builtin_amdgcn_readfirstlane(kmx);
+      double *p0 = sh + lc;
+      double cpp = 0.0, x1p = 0.0, x2p = 0.0;
+      double ca = p0[0], cb = p0[astr], cc = p0[2 * astr], c1 = p0[3 * astr], c2 = (NRHS == 2) ? p0[4 * astr] : 0.0;
+      double *pj = p0;
+      for (int j = 1; j <= kmx; j++) {
+        double *pn = (j < kmx) ? pj + CP : pj;
+        double na = pn[0], nb = pn[astr], nc = pn[2 * astr], n1 = pn[3 * astr], n2 = (NRHS == 2) ? pn[4 * astr] : 0.0;
+        const bool act = (j >= kmn) && (j <= kmxl);
+        const double am = (j == kmn) ? 0.0 : ca;
+        double mm = cb - cpp * am;
+        double ncp = cc / mm;
+        double nx1 = (c1 - x1p * am) / mm;
+        double nx2 = (NRHS == 2) ? (c2 - x2p * am) / mm : 0.0;
+        if (act) {
+          cpp = ncp; x1p = nx1; x2p = nx2;
+          pj[2 * astr] = ncp; pj[3 * astr] = nx1;
+          if (NRHS == 2) pj[4 * astr] = nx2;
+        }
+        ca = na; cb = nb; cc = nc; c1 = n1; c2 = n2;
+        pj = pn;
+      }
+      double y1 = 0.0, y2 = 0.0;
+      pj = p0 + (kmx > 0 ? kmx - 1 : 0) * CP;
+      double cp = pj[2 * astr], u1 = pj[3 * astr], u2 = (NRHS == 2) ? pj[4 * astr] : 0.0;
+      for (int j = kmx; j >= 1; j--) {
+        double *pn = (j > 1) ? pj - CP : pj;
+        double ncp = pn[2 * astr], nu1 = pn[3 * astr], nu2 = (NRHS == 2) ? pn[4 * astr] : 0.0;
+        if (j >= kmn && j <= kmxl) {
+          if (j == kmxl) { y1 = u1; if (NRHS == 2) y2 = u2; }
+          else {
+            y1 = u1 - cp * y1;
+            if (NRHS == 2) y2 = u2 - cp * y2;
+          }
+          pj[3 * astr] = y1;
+          if (NRHS == 2) pj[4 * astr] = y2;
+        }
+        cp = ncp; u1 = nu1; u2 = nu2;
+        pj = pn;
+      }
+    }
+    __syncthreads();
+  }
+};
+
+// one column per wave, TH_COLS columns per block (the pi shape): must be called by every thread of the block
 template <int NRHS>
 __device__ __forceinline__ void thomas_inblock(double *sh, int nl1, bool valid, int kmin, int kmax, double a, double b, double c, double r1,
                                                double r2, double &x1, double &x2) {
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nz = l + 1;
-  const int astr = nl1 * TH_CP;                              // array stride (doubles); layout [arr][level][column]
-  int *rng = (int *)(sh + (size_t)(3 + NRHS) * astr);
-  if (l == 0) { rng[2 * w] = valid ? kmin : 1; rng[2 * w + 1] = valid ? kmax : 0; }
-  if (nz <= nl1) {
-    double *p = sh + (nz - 1) * TH_CP + w;
-    p[0] = a; p[astr] = b; p[2 * astr] = c; p[3 * astr] = r1;
-    if (NRHS == 2) p[4 * astr] = r2;
-  }
-  __syncthreads();
-  if (w == 0) {
-    // Branch-free and software-pipelined: the first active level uses a = 0 (b - cp*0 = b, r - x*0 = r exactly, i.e. the
-    // reference's c/b, r/b start), inactive levels are discarded by selects, so the independent divide chains (cp, x1,
-    // x2) interleave in straight-line code and  cp_j = c_j / (b_j - cp_{j-1} a_j)  is the only serial part.
-    const int lc = l < TH_COLS ? l : TH_COLS - 1;
-    int kmn = 1, kmxl = 0;
-    if (l < TH_COLS) { kmn = rng[2 * l]; kmxl = rng[2 * l + 1]; }
-    int kmx = kmxl;
-    for (int s = 4; s >= 1; s >>= 1) kmx = max(kmx, __shfl_xor(kmx, s, 64));
-    kmx = __builtin_amdgcn_readfirstlane(kmx);
-    double *p0 = sh + lc;
-    double cpp = 0.0, x1p = 0.0, x2p = 0.0;
-    double ca = p0[0], cb = p0[astr], cc = p0[2 * astr], c1 = p0[3 * astr], c2 = (NRHS == 2) ? p0[4 * astr] : 0.0;
-    double *pj = p0;
-    for (int j = 1; j <= kmx; j++) {
-      double *pn = (j < kmx) ? pj + TH_CP : pj;
-      double na = pn[0], nb = pn[astr], nc = pn[2 * astr], n1 = pn[3 * astr], n2 = (NRHS == 2) ? pn[4 * astr] : 0.0;
-      const bool act = (j >= kmn) && (j <= kmxl);
-      const double am = (j == kmn) ? 0.0 : ca;
-      double mm = cb - cpp * am;
-      double ncp = cc / mm;
-      double nx1 = (c1 - x1p * am) / mm;
-      double nx2 = (NRHS == 2) ? (c2 - x2p * am) / mm : 0.0;
-      if (act) {
-        cpp = ncp; x1p = nx1; x2p = nx2;
-        pj[2 * astr] = ncp; pj[3 * astr] = nx1;
-        if (NRHS == 2) pj[4 * astr] = nx2;
-      }
-      ca = na; cb = nb; cc = nc; c1 = n1; c2 = n2;
-      pj = pn;
-    }
-    double y1 = 0.0, y2 = 0.0;
-    pj = p0 + (kmx > 0 ? kmx - 1 : 0) * TH_CP;
-    double cp = pj[2 * astr], u1 = pj[3 * astr], u2 = (NRHS == 2) ? pj[4 * astr] : 0.0;
-    for (int j = kmx; j >= 1; j--) {
-      double *pn = (j > 1) ? pj - TH_CP : pj;
-      double ncp = pn[2 * astr], nu1 = pn[3 * astr], nu2 = (NRHS == 2) ? pn[4 * astr] : 0.0;
-      if (j >= kmn && j <= kmxl) {
-        if (j == kmxl) { y1 = u1; if (NRHS == 2) y2 = u2; }
-        else {
-          y1 = u1 - cp * y1;
-          if (NRHS == 2) y2 = u2 - cp * y2;
-        }
-        pj[3 * astr] = y1;
-        if (NRHS == 2) pj[4 * astr] = y2;
-      }
-      cp = ncp; u1 = nu1; u2 = nu2;
-      pj = pn;
-    }
-  }
-  __syncthreads();
-  x1 = 0.0; x2 = 0.0;
-  if (nz <= nl1) {
-    const double *p = sh + (nz - 1) * TH_CP + w;
-    x1 = p[3 * astr];
-    if (NRHS == 2) x2 = p[4 * astr];
-  }
+  ThTile<NRHS, TH_COLS> t(sh, nl1);
+  const int w = threadIdx.x >> 6;
+  t.put(w, valid, kmin, kmax, a, b, c, r1, r2);
+  t.sweep();
+  t.get(w, x1, x2);
 }
+
+// CORE2-class meshes: tiles of TL_COLS columns per block of TL_WAVES wavefronts (TL_COLS / TL_WAVES columns per wave)
+// DM::use_tile selects the shape: 1 = 32 columns x 8 waves (default), 2 = 32 x 4, 3 = 64 x 8, 4 = 64 x 4 (FESOM_GPU_TILE=<n>)
+#define TL_COLS 32
+#define TL_WAVES 8
+#define TL_BLOCK (WAVE * TL_WAVES)
+#define TILE_SHAPES(X) X(1, 32, 8) X(2, 32, 4) X(3, 64, 8) X(4, 64, 4)
+static inline int nblocks_tl(int ncol) { return (ncol + TL_COLS - 1) / TL_COLS; }
+// the tile kernels replace the one-column-per-wave kernels when the mesh has at least this many node columns (or when
+// FESOM_GPU_TILE=1 / 0 forces / forbids them; decided once in fesom_gpu_init: DM::use_tile)
+#define TL_MIN_COLUMNS 20000
 
 static inline int nblocks(int ncol) { return (ncol + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK; }
 

@@ -487,91 +487,118 @@ __global__ void __launch_bounds__(BLOCK) k_visc_node(DM m) {
 // impl_vert_visc_ale (src/oce_ale.F90:2348-2517) with the last loop of visc_filt_bcksct (oce_dyn.F90:638-648)
 // fused in front.  Coefficients per level in parallel (this kernel); the Thomas sweep runs one lane per column in
 // k_thomas<2>.  1 N3 + 8 E3 values (+ 5 E3 scratch written, 5 read).
-__global__ void __launch_bounds__(TH_BLOCK) k_impl_visc(DM m, int apply_visc, int do_impl) {
+// Shapes (dev.h:ThTile): <8, 8> one element column per wave (pi), <TL_COLS, TL_WAVES> tiles with several columns per wave.
+template <int COLS, int WAVES>
+__global__ void __launch_bounds__(WAVE * WAVES) k_impl_visc(DM m, int apply_visc, int do_impl) {
   extern __shared__ double th_sh[];
-  int e = col_id_th(), l = lane_id(), nz = l + 1;
-  const bool valid = e < m.myE;                            // no early exit: the block meets at the barriers of the sweep
-  if (!valid) e = m.myE - 1;
-  const int nzmin = m.ulev[e], nzmax = m.nlev[e];
-  const bool wet = valid && (nz >= nzmin && nz <= nzmax - 1);
-  const int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
-  const double dt = m.p.dt;
-  double ur = 0.0, vr = 0.0, u = 0.0, v = 0.0, he = 0.0;
-  if (wet) {
-    ur = DV2(m.UV_rhs, 1, nz, e); vr = DV2(m.UV_rhs, 2, nz, e);
-    u = DV2(m.UV, 1, nz, e); v = DV2(m.UV, 2, nz, e); he = DA2(m.helem, nz, e);
-    if (apply_visc) {
-      double bs = m.p.easy_bs_return;
-      ur = ur + DV2(m.U_b, 1, nz, e) - bs * (DV2(m.U_c, 1, nz, n1) + DV2(m.U_c, 1, nz, n2) + DV2(m.U_c, 1, nz, n3)) / 3.0;
-      vr = vr + DV2(m.U_b, 2, nz, e) - bs * (DV2(m.U_c, 2, nz, n1) + DV2(m.U_c, 2, nz, n2) + DV2(m.U_c, 2, nz, n3)) / 3.0;
+  ThTile<2, COLS> tile(th_sh, m.nlm1);
+  const int w = threadIdx.x >> 6, l = lane_id(), nz = l + 1;
+  const int base = xcd_block() * COLS;
+  constexpr bool SINGLE = (COLS == WAVES);
+  int e = 0; bool wet = false;
+  for (int ci = w; ci < COLS; ci += WAVES) {
+    e = __builtin_amdgcn_readfirstlane(base + ci);
+    const bool valid = e < m.myE;                            // no early exit: the block meets at the barriers of the sweep
+    if (!valid) e = m.myE - 1;
+    const int nzmin = m.ulev[e], nzmax = m.nlev[e];
+    wet = valid && (nz >= nzmin && nz <= nzmax - 1);
+    const int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
+    const double dt = m.p.dt;
+    double ur = 0.0, vr = 0.0, u = 0.0, v = 0.0, he = 0.0;
+    if (wet) {
+      ur = DV2(m.UV_rhs, 1, nz, e); vr = DV2(m.UV_rhs, 2, nz, e);
+      u = DV2(m.UV, 1, nz, e); v = DV2(m.UV, 2, nz, e); he = DA2(m.helem, nz, e);
+      if (apply_visc) {
+        double bs = m.p.easy_bs_return;
+        ur = ur + DV2(m.U_b, 1, nz, e) - bs * (DV2(m.U_c, 1, nz, n1) + DV2(m.U_c, 1, nz, n2) + DV2(m.U_c, 1, nz, n3)) / 3.0;
+        vr = vr + DV2(m.U_b, 2, nz, e) - bs * (DV2(m.U_c, 2, nz, n1) + DV2(m.U_c, 2, nz, n2) + DV2(m.U_c, 2, nz, n3)) / 3.0;
+      }
     }
+    if (!do_impl) {
+      if (wet) { DV2(m.UV_rhs, 1, nz, e) = ur; DV2(m.UV_rhs, 2, nz, e) = vr; }
+      continue;
+    }
+    // zbar_n, Z_n of the element column
+    double zb_top = seq_sum_down(he, nzmax - 2, nzmin - 1, m.zbar_e_bot[e]);   // zbar_n(nz)
+    double zb_bot = shdn(zb_top);
+    if (nz == nzmax - 1) zb_bot = m.zbar_e_bot[e];
+    double Zn = zb_bot + he / 2.0;                                             // Z_n(nz)
+    double Zn_up = shup(Zn), Zn_dn = shdn(Zn);
+    double a = 0.0, b = 1.0, c = 0.0;
+    double wi_top = 0.0, wi_bot = 0.0, av_top = 0.0, av_bot = 0.0;
+    if (wet) {
+      wi_top = (DA2L(m.Wvel_i, nz, n1) + DA2L(m.Wvel_i, nz, n2) + DA2L(m.Wvel_i, nz, n3)) / 3.;
+      wi_bot = (DA2L(m.Wvel_i, nz + 1, n1) + DA2L(m.Wvel_i, nz + 1, n2) + DA2L(m.Wvel_i, nz + 1, n3)) / 3.;
+      av_top = DA2L(m.Av, nz, e); av_bot = DA2L(m.Av, nz + 1, e);
+      double zinv = 1.0 * dt / (zb_top - zb_bot);
+      if (nz > nzmin && nz < nzmax - 1) {
+        a = -av_top / (Zn_up - Zn) * zinv;
+        c = -av_bot / (Zn - Zn_dn) * zinv;
+        b = -a - c + 1.0;
+        a = a + dmin_(0., wi_top) * zinv;
+        b = b + dmax_(0., wi_top) * zinv;
+        b = b - dmin_(0., wi_bot) * zinv;
+        c = c - dmax_(0., wi_bot) * zinv;
+      } else if (nz == nzmax - 1 && nz != nzmin) {
+        a = -av_top / (Zn_up - Zn) * zinv;
+        b = -a + 1.0;
+        c = 0.0;
+        a = a + dmin_(0., wi_top) * zinv;
+        b = b + dmax_(0., wi_top) * zinv;
+      } else if (nz == nzmin) {
+        c = -av_bot / (Zn - Zn_dn) * zinv;
+        a = 0.0;
+        b = -c + 1.0;
+        b = b + wi_top * zinv;
+        b = b - dmin_(0., wi_bot) * zinv;
+        c = c - dmax_(0., wi_bot) * zinv;
+      }
+      if (nz == nzmin) {
+        ur = ur + zinv * m.stress_surf[2 * e] / D_RHO0;
+        vr = vr + zinv * m.stress_surf[2 * e + 1] / D_RHO0;
+      }
+      if (nz == nzmax - 1) {
+        double friction = -m.p.C_d * sqrt(u * u + v * v);
+        ur = ur + zinv * friction * u;
+        vr = vr + zinv * friction * v;
+      }
+    }
+    double u_up = shup(u), v_up = shup(v), u_dn = shdn(u), v_dn = shdn(v);
+    if (wet) {
+      if (nz > nzmin && nz < nzmax - 1) {
+        ur = ur - a * u_up - (b - 1.0) * u - c * u_dn;
+        vr = vr - a * v_up - (b - 1.0) * v - c * v_dn;
+      } else if (nz == nzmin) {
+        ur = ur - (b - 1.0) * u - c * u_dn;
+        vr = vr - (b - 1.0) * v - c * v_dn;
+      } else {
+        ur = ur - a * u_up - (b - 1.0) * u;
+        vr = vr - a * v_up - (b - 1.0) * v;
+      }
+    }
+    tile.put(ci, valid, nzmin, nzmax - 1, a, b, c, ur, vr);
   }
-  if (!do_impl) {
-    if (wet) { DV2(m.UV_rhs, 1, nz, e) = ur; DV2(m.UV_rhs, 2, nz, e) = vr; }
-    return;
+  if (!do_impl) return;
+  tile.sweep();
+  for (int ci = w; ci < COLS; ci += WAVES) {
+    double du, dv;
+    tile.get(ci, du, dv);
+    if (!SINGLE) {
+      e = __builtin_amdgcn_readfirstlane(base + ci);
+      wet = e < m.myE;
+      if (wet) wet = nz >= m.ulev[e] && nz <= m.nlev[e] - 1;
+    }
+    if (wet) { DV2(m.UV_rhs, 1, nz, e) = du; DV2(m.UV_rhs, 2, nz, e) = dv; }     // UV_rhs = (du, dv), oce_ale.F90:2505-2510
   }
-  // zbar_n, Z_n of the element column
-  double zb_top = seq_sum_down(he, nzmax - 2, nzmin - 1, m.zbar_e_bot[e]);   // zbar_n(nz)
-  double zb_bot = shdn(zb_top);
-  if (nz == nzmax - 1) zb_bot = m.zbar_e_bot[e];
-  double Zn = zb_bot + he / 2.0;                                             // Z_n(nz)
-  double Zn_up = shup(Zn), Zn_dn = shdn(Zn);
-  double a = 0.0, b = 1.0, c = 0.0;
-  double wi_top = 0.0, wi_bot = 0.0, av_top = 0.0, av_bot = 0.0;
-  if (wet) {
-    wi_top = (DA2L(m.Wvel_i, nz, n1) + DA2L(m.Wvel_i, nz, n2) + DA2L(m.Wvel_i, nz, n3)) / 3.;
-    wi_bot = (DA2L(m.Wvel_i, nz + 1, n1) + DA2L(m.Wvel_i, nz + 1, n2) + DA2L(m.Wvel_i, nz + 1, n3)) / 3.;
-    av_top = DA2L(m.Av, nz, e); av_bot = DA2L(m.Av, nz + 1, e);
-    double zinv = 1.0 * dt / (zb_top - zb_bot);
-    if (nz > nzmin && nz < nzmax - 1) {
-      a = -av_top / (Zn_up - Zn) * zinv;
-      c = -av_bot / (Zn - Zn_dn) * zinv;
-      b = -a - c + 1.0;
-      a = a + dmin_(0., wi_top) * zinv;
-      b = b + dmax_(0., wi_top) * zinv;
-      b = b - dmin_(0., wi_bot) * zinv;
-      c = c - dmax_(0., wi_bot) * zinv;
-    } else if (nz == nzmax - 1 && nz != nzmin) {
-      a = -av_top / (Zn_up - Zn) * zinv;
-      b = -a + 1.0;
-      c = 0.0;
-      a = a + dmin_(0., wi_top) * zinv;
-      b = b + dmax_(0., wi_top) * zinv;
-    } else if (nz == nzmin) {
-      c = -av_bot / (Zn - Zn_dn) * zinv;
-      a = 0.0;
-      b = -c + 1.0;
-      b = b + wi_top * zinv;
-      b = b - dmin_(0., wi_bot) * zinv;
-      c = c - dmax_(0., wi_bot) * zinv;
-    }
-    if (nz == nzmin) {
-      ur = ur + zinv * m.stress_surf[2 * e] / D_RHO0;
-      vr = vr + zinv * m.stress_surf[2 * e + 1] / D_RHO0;
-    }
-    if (nz == nzmax - 1) {
-      double friction = -m.p.C_d * sqrt(u * u + v * v);
-      ur = ur + zinv * friction * u;
-      vr = vr + zinv * friction * v;
-    }
-  }
-  double u_up = shup(u), v_up = shup(v), u_dn = shdn(u), v_dn = shdn(v);
-  if (wet) {
-    if (nz > nzmin && nz < nzmax - 1) {
-      ur = ur - a * u_up - (b - 1.0) * u - c * u_dn;
-      vr = vr - a * v_up - (b - 1.0) * v - c * v_dn;
-    } else if (nz == nzmin) {
-      ur = ur - (b - 1.0) * u - c * u_dn;
-      vr = vr - (b - 1.0) * v - c * v_dn;
-    } else {
-      ur = ur - a * u_up - (b - 1.0) * u;
-      vr = vr - a * v_up - (b - 1.0) * v;
-    }
-  }
-  double du, dv;
-  thomas_inblock<2>(th_sh, m.nlm1, valid, nzmin, nzmax - 1, a, b, c, ur, vr, du, dv);
-  if (wet) { DV2(m.UV_rhs, 1, nz, e) = du; DV2(m.UV_rhs, 2, nz, e) = dv; }     // UV_rhs = (du, dv), oce_ale.F90:2505-2510
 }
+#define IV_SHAPE(id, C_, W_) case id: hipLaunchKernelGGL((k_impl_visc<C_, W_>), dim3((m.myE + C_ - 1) / C_), dim3(WAVE * W_), (ThTile<2, C_>::lds_bytes(m.nlm1)), s, m, av, di); break;
+static void launch_impl_visc(const DM &m, hipStream_t s, int av, int di) {
+  switch (m.use_tile) {
+    TILE_SHAPES(IV_SHAPE)
+    default: hipLaunchKernelGGL((k_impl_visc<TH_COLS, TH_COLS>), dim3(nblocks_th(m.myE)), dim3(TH_BLOCK), (ThTile<2, TH_COLS>::lds_bytes(m.nlm1)), s, m, av, di);
+  }
+}
+#define LAUNCH_IMPL_VISC(av, di) launch_impl_visc(m, s, av, di)
 
 // ------------------------------------------------------------------------------------------------
 // update_stiff_mat_ale (src/oce_ale.F90:1371-1470) as a gather per CSR entry: the contribution list of every
@@ -837,6 +864,8 @@ __global__ void __launch_bounds__(BLOCK) k_thick(DM m, int ncolN) {
 #define LAUNCH_COL(k, ncol, ...) hipLaunchKernelGGL(k, dim3(nblocks(ncol)), dim3(BLOCK), 0, s, __VA_ARGS__)
 #define LAUNCH_FLAT(k, n, ...) hipLaunchKernelGGL(k, dim3(((n) + 255) / 256), dim3(256), 0, s, __VA_ARGS__)
 
+#define IV_ATTR(id, C_, W_) (void)hipFuncSetAttribute((const void *)k_impl_visc<C_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+void tile_prepare_dyn() { TILE_SHAPES(IV_ATTR) }
 void launch_dynamics_pre(const DM &m, hipStream_t s, int first_step) {
   LAUNCH_COL(k_vel_nodes, m.myN, m);
   LAUNCH_COL(k_pressure_bv, m.N, m);
@@ -851,7 +880,7 @@ void launch_dynamics_pre(const DM &m, hipStream_t s, int first_step) {
   LAUNCH_COL(k_visc_elem, m.E, m);
   if (m.p.visc_option == 5) LAUNCH_COL(k_visc_node, m.myN, m);
   else LAUNCH_COL(k_visc_apply, m.myE, m);
-  LAUNCH_TH(k_impl_visc, m.myE, 2, m, m.p.visc_option == 5, m.p.i_vert_visc);
+  LAUNCH_IMPL_VISC(m.p.visc_option == 5, m.p.i_vert_visc);
 }
 void launch_ssh_rhs(const DM &m, hipStream_t s) {
   if (m.p.which_ale != 0) LAUNCH_FLAT(k_stiff_update, m.nza, m);
@@ -889,7 +918,7 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
     if (!strcmp(name, "k_visc_elem")) { LAUNCH_COL(k_visc_elem, m.E, m); return 0; }
     if (!strcmp(name, "k_visc_node")) { LAUNCH_COL(k_visc_node, m.myN, m); return 0; }
     if (!strcmp(name, "k_visc_apply")) { LAUNCH_COL(k_visc_apply, m.myE, m); return 0; }
-    if (!strcmp(name, "k_impl_visc")) { LAUNCH_TH(k_impl_visc, m.myE, 2, m, m.p.visc_option == 5, m.p.i_vert_visc); return 0; }
+    if (!strcmp(name, "k_impl_visc")) { LAUNCH_IMPL_VISC(m.p.visc_option == 5, m.p.i_vert_visc); return 0; }
     if (!strcmp(name, "k_stiff_update")) { LAUNCH_FLAT(k_stiff_update, m.nza, m); return 0; }
     if (!strcmp(name, "k_edge_transport")) { LAUNCH_COL(k_edge_transport, m.myD, m, 0); return 0; }
     if (!strcmp(name, "k_edge_transport1")) { LAUNCH_COL(k_edge_transport, m.myD, m, 1); return 0; }
@@ -917,9 +946,9 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
   if (!strcmp(name, "visc_filt_bcksct") || !strcmp(name, "viscosity_filter")) {      // viscosity_filter(visc_option): 5, 6 or 7
     LAUNCH_COL(k_visc_elem, m.E, m);
     if (m.p.visc_option != 5) { LAUNCH_COL(k_visc_apply, m.myE, m); return 0; }
-    LAUNCH_COL(k_visc_node, m.myN, m); LAUNCH_TH(k_impl_visc, m.myE, 2, m, 1, 0); return 0;
+    LAUNCH_COL(k_visc_node, m.myN, m); LAUNCH_IMPL_VISC(1, 0); return 0;
   }
-  if (!strcmp(name, "impl_vert_visc_ale")) { LAUNCH_TH(k_impl_visc, m.myE, 2, m, 0, 1); return 0; }
+  if (!strcmp(name, "impl_vert_visc_ale")) { LAUNCH_IMPL_VISC(0, 1); return 0; }
   if (!strcmp(name, "update_stiff_mat_ale")) { LAUNCH_FLAT(k_stiff_update, m.nza, m); return 0; }
   if (!strcmp(name, "compute_ssh_rhs_ale")) { LAUNCH_COL(k_edge_transport, m.myD, m, 0); LAUNCH_FLAT(k_ssh_rhs_node, m.myN, m); return 0; }
   if (!strcmp(name, "update_vel")) {

@@ -505,37 +505,54 @@ __global__ void __launch_bounds__(BLOCK) k_diff_flux(DM m, int tr0) {
 // The kernel is latency-bound, not bandwidth-bound: the edge list of the node is read lane-parallel (lane q = q-th
 // incident edge), broadcast with v_readlane, and all edge values are fetched in one batch before the ordered sums.
 #define TRU_MAXD 10                     // batch of this kernel (4 loads per edge): keeps it at <= 128 VGPRs, 2 blocks per CU
-template <bool REDI>
-__global__ void __launch_bounds__(TH_BLOCK) k_tr_update(DM m, int tr0) {
-  const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
-  extern __shared__ double th_sh[];
-  const TV t = tracer_view(m, tr);
-  int n = col_id_th(), l = lane_id(), nz = l + 1;
-  const bool valid = n < m.myN;                            // no early exit: the block meets at the barriers of the sweep
-  if (n >= m.myN && n < m.N && nz <= m.nlm1)               // halo columns: only tr_arr_old(:,:,tr) = tr_arr(:,:,tr) (whole-array copy, :274)
-    DTR(m.tr_arr_old, nz, n, tr) = DTR(m.tr_arr, nz, n, tr);
-  if (!valid) n = m.myN - 1;
-  const int nzmin = m.ulev_n[n], nzmax = m.nlev_n[n];
-  const double dt = m.p.dt;
-  const bool wet = valid && (nz >= nzmin && nz <= nzmax - 1);
-  const int q0 = m.ne_ptr[n], deg = m.ne_ptr[n + 1] - q0;
-  int ed_l = 0, sg_l = 0, fn_l = 0;
-  unsigned rg_l = 1u;                                       // lo = 1, hi = 0: empty range
-  if (l < deg) {
-    ed_l = m.ne_idx[q0 + l]; sg_l = m.ne_sgn[q0 + l]; rg_l = m.ne_rng[q0 + l];
-    fn_l = (sg_l > 0) ? m.edges[2 * ed_l + 1] : m.edges[2 * ed_l];       // far-end node of the edge
+// Shapes (dev.h:ThTile): <REDI, 1, 8, 8> = one column per wave, one tracer per block row (pi); <REDI, 2, TL_COLS, TL_WAVES> =
+// tiles of TL_COLS columns, several columns per wave, BOTH tracers of a column in the same block (CORE2-class meshes): the
+// tracer-independent part of the column (thicknesses, interface depths, the coefficients a, b, c of the implicit operator, the
+// edge list) is formed once and the sweep solves the two right-hand sides together (3 divides per level instead of 2 x 2).
+struct TruCol {                          // tracer-independent part of one node column (lane = level)
+  int n, nzmin, nzmax, q0, deg, ed_l, sg_l, fn_l;
+  unsigned rg_l;
+  bool valid, wet;
+  double hn, hnn, asv;                                   // tru_head
+  double zb_top, zb_bot, Zn, Zn_up, Zn_dn, ki, s3sq, s1, s2;   // tru_zcol (ki .. s2: Redi only)
+  double a, b, c, ar_dn;                                 // tru_coeffs
+};
+// The parts are called in the order  head, [hor, (zcol once), fin] per tracer, coeffs, rhs per tracer : what the horizontal
+// gathers keep live (two batches of edge values) never overlaps with the interface depths and the coefficients.
+__device__ __forceinline__ void tru_head(const DM &m, int n_in, TruCol &k) {
+  const int l = lane_id(), nz = l + 1;
+  int n = n_in;
+  k.valid = n < m.myN;
+  if (!k.valid) n = m.myN - 1;
+  k.n = n;
+  k.nzmin = m.ulev_n[n]; k.nzmax = m.nlev_n[n];
+  k.wet = k.valid && (nz >= k.nzmin && nz <= k.nzmax - 1);
+  k.q0 = m.ne_ptr[n]; k.deg = m.ne_ptr[n + 1] - k.q0;
+  k.ed_l = 0; k.sg_l = 0; k.fn_l = 0; k.rg_l = 1u;          // lo = 1, hi = 0: empty range
+  if (l < k.deg) {
+    k.ed_l = m.ne_idx[k.q0 + l]; k.sg_l = m.ne_sgn[k.q0 + l]; k.rg_l = m.ne_rng[k.q0 + l];
+    k.fn_l = (k.sg_l > 0) ? m.edges[2 * k.ed_l + 1] : m.edges[2 * k.ed_l];       // far-end node of the edge
   }
+  k.hn = 0.0; k.hnn = 1.0; k.asv = 1.0;
+  if (k.wet) { k.hn = DA2(m.hnode, nz, n); k.hnn = DA2(m.hnode_new, nz, n); k.asv = DA2L(m.areasvol, nz, n); }
+}
+// flux -> tendency (oce_tra_adv_flux2dtracer) and horizontal diffusion of tracer `tr`: T^n and del (lane = level)
+__device__ __forceinline__ void tru_hor(const DM &m, const TruCol &k, int tr, double &T, double &del) {
+  const TV t = tracer_view(m, tr);
+  const int l = lane_id(), nz = l + 1, n = k.n, nzmin = k.nzmin, nzmax = k.nzmax;
+  const double dt = m.p.dt, asv = k.asv, hn = k.hn, hnn = k.hnn;
+  const bool wet = k.wet;
   const int nzc = min(nz, m.nlm1);
   const bool dif = m.p.with_diffusion != 0;
   const double p_own = DA2(t.fct_plus, nzc, n), m_own = DA2(t.fct_minus, nzc, n);
   double fa[TRU_MAXD], fd[TRU_MAXD];
 #pragma unroll
   for (int q = 0; q < TRU_MAXD; q++) {                   // one batch of independent loads
-    int ed = rdlane(ed_l, q), k = rdlane(fn_l, q);
-    const bool first = rdlane(sg_l, q) > 0;                 // this node is edges(1,ed)
+    int ed = rdlane(k.ed_l, q), kk = rdlane(k.fn_l, q);
+    const bool first = rdlane(k.sg_l, q) > 0;               // this node is edges(1,ed)
     // limited antidiffusive flux ae * flux with the factors of oce_adv_tra_fct.F90:318-347 applied on the fly:
     // flux >= 0: min(1, plus(n1), minus(n2)); flux < 0: min(1, minus(n1), plus(n2))
-    double fr = DA2(t.adv_flux_raw, nzc, ed), p_far = DA2(t.fct_plus, nzc, k), m_far = DA2(t.fct_minus, nzc, k);
+    double fr = DA2(t.adv_flux_raw, nzc, ed), p_far = DA2(t.fct_plus, nzc, kk), m_far = DA2(t.fct_minus, nzc, kk);
     double p1 = first ? p_own : p_far, m1 = first ? m_own : m_far, p2 = first ? p_far : p_own, m2 = first ? m_far : m_own;
     double ae = dmin_(dmin_(1.0, (fr >= 0.) ? p1 : m1), (fr >= 0.) ? m2 : p2);
     fa[q] = ae * fr;
@@ -543,79 +560,91 @@ __global__ void __launch_bounds__(TH_BLOCK) k_tr_update(DM m, int tr0) {
   }
   double adv = (nz >= nzmin && nz <= nzmax) ? DA2L(t.adv_flux_ver, nz, n) : 0.0;
   double adv_dn = shdn(adv);
-  double T = 0.0, hn = 0.0, hnn = 1.0, del = 0.0, asv = 1.0;
-  if (wet) {
-    T = DTR(m.tr_arr, nz, n, tr); hn = DA2(m.hnode, nz, n); hnn = DA2(m.hnode_new, nz, n); asv = DA2L(m.areasvol, nz, n);
-  }
+  T = 0.0;
+  if (wet) T = DTR(m.tr_arr, nz, n, tr);
   double dv = 0.0 - T * hn + (wet ? DA2(t.fct_LO, nz, n) : 0.0) * hnn;
   dv = dv + (adv - adv_dn) * dt / asv;
   double dh = 0.0;
 #pragma unroll
   for (int q = 0; q < TRU_MAXD; q++) {
-    unsigned rg = (unsigned)rdlane((int)rg_l, q);
-    int sg = rdlane(sg_l, q);
+    unsigned rg = (unsigned)rdlane((int)k.rg_l, q);
+    int sg = rdlane(k.sg_l, q);
     bool on = nz >= (int)(rg & 0xffu) && nz <= (int)((rg >> 8) & 0xffu);
     double f = fa[q] * dt / asv;
     double nh = (sg > 0) ? dh + f : dh - f;
     dh = on ? nh : dh;
   }
-  for (int q = TRU_MAXD; q < deg; q++) {                    // nodes with more incident edges than the batch (rare)
-    int ed = m.ne_idx[q0 + q];
-    unsigned rg = m.ne_rng[q0 + q];
+  for (int q = TRU_MAXD; q < k.deg; q++) {                  // nodes with more incident edges than the batch (rare)
+    int ed = m.ne_idx[k.q0 + q];
+    unsigned rg = m.ne_rng[k.q0 + q];
     if (nz < (int)(rg & 0xffu) || nz > (int)((rg >> 8) & 0xffu)) continue;
     int n1 = m.edges[2 * ed], n2 = m.edges[2 * ed + 1];
     double fr = DA2(t.adv_flux_raw, nz, ed);
     double ae = dmin_(dmin_(1.0, (fr >= 0.) ? DA2(t.fct_plus, nz, n1) : DA2(t.fct_minus, nz, n1)), (fr >= 0.) ? DA2(t.fct_minus, nz, n2) : DA2(t.fct_plus, nz, n2));
     double f = (ae * fr) * dt / asv;
-    dh = (m.ne_sgn[q0 + q] > 0) ? dh + f : dh - f;
+    dh = (m.ne_sgn[k.q0 + q] > 0) ? dh + f : dh - f;
   }
   del = 0.0 + dh + dv;
   if (dif) {
 #pragma unroll
     for (int q = 0; q < TRU_MAXD; q++) {
-      unsigned rg = (unsigned)rdlane((int)rg_l, q);
-      int sg = rdlane(sg_l, q);
+      unsigned rg = (unsigned)rdlane((int)k.rg_l, q);
+      int sg = rdlane(k.sg_l, q);
       bool on = nz >= (int)(rg & 0xffu) && nz <= (int)((rg >> 8) & 0xffu);
-      double rhs = (sg > 0) ? 0.0 + fd[q] : 0.0 - fd[q];
-      double nd = del + rhs * dt / asv;
+      double r_ = (sg > 0) ? 0.0 + fd[q] : 0.0 - fd[q];
+      double nd = del + r_ * dt / asv;
       del = on ? nd : del;
     }
-    for (int q = TRU_MAXD; q < deg; q++) {
-      int ed = m.ne_idx[q0 + q];
-      unsigned rg = m.ne_rng[q0 + q];
+    for (int q = TRU_MAXD; q < k.deg; q++) {
+      int ed = m.ne_idx[k.q0 + q];
+      unsigned rg = m.ne_rng[k.q0 + q];
       if (nz < (int)(rg & 0xffu) || nz > (int)((rg >> 8) & 0xffu)) continue;
       double c = DA2(t.diff_flux, nz, ed);
-      double rhs = (m.ne_sgn[q0 + q] > 0) ? 0.0 + c : 0.0 - c;
-      del = del + rhs * dt / asv;
+      double r_ = (m.ne_sgn[k.q0 + q] > 0) ? 0.0 + c : 0.0 - c;
+      del = del + r_ * dt / asv;
     }
   }
-  // zbar_n / Z_n of the node column from hnode_new (bottom-up, reference order)
-  double zb_top = seq_sum_down(wet ? hnn : 0.0, nzmax - 2, nzmin - 1, m.zbar_n_bot[n]);
-  double zb_bot = shdn(zb_top);
-  if (nz == nzmax - 1) zb_bot = m.zbar_n_bot[n];
-  double Zn = zb_bot + hnn / 2.0;
-  double Zn_up = shup(Zn), Zn_dn = shdn(Zn);
-  double ki = 0.0, s3sq = 0.0;
+}
+// zbar_n / Z_n of the node column from hnode_new (bottom-up, reference order); Redi: slopes and Ki of the column
+template <bool REDI>
+__device__ __forceinline__ void tru_zcol(const DM &m, TruCol &k) {
+  const int nz = lane_id() + 1, n = k.n;
+  k.zb_top = seq_sum_down(k.wet ? k.hnn : 0.0, k.nzmax - 2, k.nzmin - 1, m.zbar_n_bot[n]);
+  k.zb_bot = shdn(k.zb_top);
+  if (nz == k.nzmax - 1) k.zb_bot = m.zbar_n_bot[n];
+  k.Zn = k.zb_bot + k.hnn / 2.0;
+  k.Zn_up = shup(k.Zn); k.Zn_dn = shdn(k.Zn);
+  k.ki = 0.0; k.s3sq = 0.0; k.s1 = 0.0; k.s2 = 0.0;
+  if (REDI && k.wet) {
+    k.s1 = DV3(m.slope_tapered, 1, nz, n); k.s2 = DV3(m.slope_tapered, 2, nz, n);
+    double s3 = DV3(m.slope_tapered, 3, nz, n);
+    k.s3sq = s3 * s3; k.ki = DA2(m.Ki, nz, n);
+  }
+}
+// Redi's explicit vertical flux, T* update, copies: returns T* in T
+template <bool REDI>
+__device__ __forceinline__ void tru_fin(const DM &m, const TruCol &k, int tr, double &T, double del) {
+  const TV t = tracer_view(m, tr);
+  const int nz = lane_id() + 1, n = k.n, nzmin = k.nzmin, nzmax = k.nzmax;
+  const double dt = m.p.dt, asv = k.asv, hn = k.hn, hnn = k.hnn;
+  const bool wet = k.wet;
   if (REDI) {            // diff_ver_part_redi_expl (:860-927): vertical flux of the isoneutral tensor's off-diagonal part
-    double Tx = 0.0, Ty = 0.0, s1 = 0.0, s2 = 0.0, G = 0.0;
+    double Tx = 0.0, Ty = 0.0, G = 0.0;
     if (wet) {
       const int num = m.nie_num[n];
-      for (int k = 0; k < num; k++) {
-        int el = m.nie[(size_t)m.maxk * n + k];
+      for (int q = 0; q < num; q++) {
+        int el = m.nie[(size_t)m.maxk * n + q];
         if (nz <= m.nlev[el] - 1 && nz >= m.ulev[el]) { double ar = m.elem_area[el]; Tx = Tx + DV2(t.tr_xy, 1, nz, el) * ar; Ty = Ty + DV2(t.tr_xy, 2, nz, el) * ar; }
       }
       Tx = Tx / 3.0 / asv; Ty = Ty / 3.0 / asv;
-      s1 = DV3(m.slope_tapered, 1, nz, n); s2 = DV3(m.slope_tapered, 2, nz, n);
-      double s3 = DV3(m.slope_tapered, 3, nz, n);
-      s3sq = s3 * s3; ki = DA2(m.Ki, nz, n);
-      G = s1 * Tx + s2 * Ty;
+      G = k.s1 * Tx + k.s2 * Ty;
     }
-    double G_up = shup(G), ki_up = shup(ki);
+    double G_up = shup(G), ki_up = shup(k.ki);
     double vd = 0.0;
     if (nz >= nzmin + 1 && nz <= nzmax - 1) {
-      vd = (Zn_up - zb_top) * G_up * ki_up;
-      vd = vd + (zb_top - Zn) * G * ki;
-      vd = vd / (Zn_up - Zn) * DA2L(m.area, nz, n);
+      vd = (k.Zn_up - k.zb_top) * G_up * ki_up;
+      vd = vd + (k.zb_top - k.Zn) * G * k.ki;
+      vd = vd / (k.Zn_up - k.Zn) * DA2L(m.area, nz, n);
     }
     double vd_dn = shdn(vd);
     if (nz == nzmax - 1) vd_dn = 0.0;
@@ -627,71 +656,147 @@ __global__ void __launch_bounds__(TH_BLOCK) k_tr_update(DM m, int tr0) {
     DA2(t.del_ttf, nz, n) = del;
     T = T + del / hnn;
   }
-  if (valid && !wet && nz <= m.nlm1) DTR(m.tr_arr_old, nz, n, tr) = DTR(m.tr_arr, nz, n, tr);   // whole-array copy incl. dry cells
-  if (m.p.with_diffusion && m.p.i_vert_diff) {
-    double a = 0.0, b = 1.0, c = 0.0, rhs = 0.0;
-    double T_up = shup(T), T_dn = shdn(T);
-    const double ki_up = shup(ki), ki_dn = shdn(ki), sq_up = shup(s3sq), sq_dn = shdn(s3sq), zb_bb = shdn(zb_bot);
-    if (wet) {
-      double zinv = 1.0 * dt;
-      double zinv1 = 1.0 / (Zn_up - Zn), zinv2 = 1.0 / (Zn - Zn_dn);
-      double Ty = 0.0, Ty1 = 0.0;              // K33 = slope^2 * Ki of the isoneutral tensor (:528-599), isredi = 1
-      if (REDI) {
-        if (nz > nzmin) Ty = (Zn_up - zb_top) * zinv1 * sq_up * ki_up + (zb_top - Zn) * zinv1 * s3sq * ki;
-        if (nz <= nzmax - 2) Ty1 = (Zn - zb_bot) * zinv2 * s3sq * ki + (zb_bot - Zn_dn) * zinv2 * sq_dn * ki_dn;
-        Ty = Ty * 1.0; Ty1 = Ty1 * 1.0;
-        (void)zb_bb;
-      }
-      double ar = DA2L(m.area, nz, n), ar_dn = DA2L(m.area, nz + 1, n);
-      double kv = DA2L(m.Kv, nz, n), kv_dn = DA2L(m.Kv, nz + 1, n);
-      if (nz == nzmin) {
-        a = 0.0;
-        c = -(kv_dn + Ty1) * zinv2 * zinv * ar_dn / asv;
-        b = -c + hnn;
-        rhs = -(b - hnn) * T - c * T_dn;
-      } else if (nz <= nzmax - 2) {
-        a = -(kv + Ty) * zinv1 * zinv * (ar / asv);
-        c = -(kv_dn + Ty1) * zinv2 * zinv * ar_dn / asv;
-        b = -a - c + hnn;
-        rhs = -a * T_up - (b - hnn) * T - c * T_dn;
-      } else {
-        a = -(kv + Ty) * zinv1 * zinv * (ar / asv);
-        c = 0.0;
-        b = -a + hnn;
-        rhs = -a * T_up - (b - hnn) * T;
-      }
-      if (m.p.use_sw_pene && tr == 0)            // short-wave penetration (oce_ale_tracer.F90:785-791)
-        rhs = rhs + (DA2L(m.sw_3d, nz, n) - DA2L(m.sw_3d, nz + 1, n) * ar_dn / asv) * zinv;
-      if (nz == nzmin) {
-        double nonlin = (m.p.which_ale == 0) ? 0.0 : 1.0, bc;
-        if (tr == 0) bc = -dt * (m.heat_flux[n] / D_VCPW + T * m.water_flux[n] * nonlin);
-        else if (tr == 1) bc = dt * (m.virtual_salt[n] + m.relax_salt[n] - m.real_salt_flux[n] * nonlin);
-        else bc = 0.0;
-        rhs = rhs + bc;
-      }
+  if (k.valid && !wet && nz <= m.nlm1) DTR(m.tr_arr_old, nz, n, tr) = DTR(m.tr_arr, nz, n, tr);   // whole-array copy incl. dry cells
+}
+// coefficients of the implicit vertical diffusion (diff_ver_part_impl_ale :398-856): the same for every tracer
+template <bool REDI>
+__device__ __forceinline__ void tru_coeffs(const DM &m, TruCol &k) {
+  const int nz = lane_id() + 1, n = k.n;
+  k.a = 0.0; k.b = 1.0; k.c = 0.0; k.ar_dn = 0.0;
+  const double ki_up = shup(k.ki), ki_dn = shdn(k.ki), sq_up = shup(k.s3sq), sq_dn = shdn(k.s3sq);
+  if (k.wet) {
+    const double dt = m.p.dt, hnn = k.hnn, asv = k.asv;
+    double zinv = 1.0 * dt;
+    double zinv1 = 1.0 / (k.Zn_up - k.Zn), zinv2 = 1.0 / (k.Zn - k.Zn_dn);
+    double Ty = 0.0, Ty1 = 0.0;              // K33 = slope^2 * Ki of the isoneutral tensor (:528-599), isredi = 1
+    if (REDI) {
+      if (nz > k.nzmin) Ty = (k.Zn_up - k.zb_top) * zinv1 * sq_up * ki_up + (k.zb_top - k.Zn) * zinv1 * k.s3sq * k.ki;
+      if (nz <= k.nzmax - 2) Ty1 = (k.Zn - k.zb_bot) * zinv2 * k.s3sq * k.ki + (k.zb_bot - k.Zn_dn) * zinv2 * sq_dn * ki_dn;
+      Ty = Ty * 1.0; Ty1 = Ty1 * 1.0;
     }
-    double dT, unused;
-    thomas_inblock<1>(th_sh, m.nlm1, valid, nzmin, nzmax - 1, a, b, c, rhs, 0.0, dT, unused);
-    if (wet) {                                 // tr_arr = T* + dT ; salinity clamp (oce_ale_tracer.F90:176-198)
-      T = T + dT;
-      if (tr == 1) { if (T > 45.0) T = 45.0; if (T < 3.0) T = 3.0; }
-      DTR(m.tr_arr, nz, n, tr) = T;
+    double ar = DA2L(m.area, nz, n), ar_dn = DA2L(m.area, nz + 1, n);
+    double kv = DA2L(m.Kv, nz, n), kv_dn = DA2L(m.Kv, nz + 1, n);
+    k.ar_dn = ar_dn;
+    if (nz == k.nzmin) {
+      k.a = 0.0;
+      k.c = -(kv_dn + Ty1) * zinv2 * zinv * ar_dn / asv;
+      k.b = -k.c + hnn;
+    } else if (nz <= k.nzmax - 2) {
+      k.a = -(kv + Ty) * zinv1 * zinv * (ar / asv);
+      k.c = -(kv_dn + Ty1) * zinv2 * zinv * ar_dn / asv;
+      k.b = -k.a - k.c + hnn;
+    } else {
+      k.a = -(kv + Ty) * zinv1 * zinv * (ar / asv);
+      k.c = 0.0;
+      k.b = -k.a + hnn;
     }
-    return;
   }
-  if (wet) {
-    if (tr == 1) { if (T > 45.0) T = 45.0; if (T < 3.0) T = 3.0; }
-    DTR(m.tr_arr, nz, n, tr) = T;
+}
+// right-hand side of the implicit vertical diffusion for T* (surface boundary condition, short-wave penetration)
+__device__ __forceinline__ double tru_rhs(const DM &m, const TruCol &k, int tr, double T) {
+  const int nz = lane_id() + 1, n = k.n, nzmin = k.nzmin, nzmax = k.nzmax;
+  const double dt = m.p.dt, asv = k.asv, hnn = k.hnn;
+  double rhs = 0.0;
+  double T_up = shup(T), T_dn = shdn(T);
+  if (k.wet) {
+    const double a = k.a, b = k.b, c = k.c;
+    double zinv = 1.0 * dt;
+    if (nz == nzmin) rhs = -(b - hnn) * T - c * T_dn;
+    else if (nz <= nzmax - 2) rhs = -a * T_up - (b - hnn) * T - c * T_dn;
+    else rhs = -a * T_up - (b - hnn) * T;
+    if (m.p.use_sw_pene && tr == 0)            // short-wave penetration (oce_ale_tracer.F90:785-791)
+      rhs = rhs + (DA2L(m.sw_3d, nz, n) - DA2L(m.sw_3d, nz + 1, n) * k.ar_dn / asv) * zinv;
+    if (nz == nzmin) {
+      double nonlin = (m.p.which_ale == 0) ? 0.0 : 1.0, bc;
+      if (tr == 0) bc = -dt * (m.heat_flux[n] / D_VCPW + T * m.water_flux[n] * nonlin);
+      else if (tr == 1) bc = dt * (m.virtual_salt[n] + m.relax_salt[n] - m.real_salt_flux[n] * nonlin);
+      else bc = 0.0;
+      rhs = rhs + bc;
+    }
+  }
+  return rhs;
+}
+__device__ __forceinline__ double tru_clamp(double T, int tr) {           // salinity clamp (oce_ale_tracer.F90:176-198)
+  if (tr == 1) { if (T > 45.0) T = 45.0; if (T < 3.0) T = 3.0; }
+  return T;
+}
+template <bool REDI, int NT, int COLS, int WAVES>
+__global__ void __launch_bounds__(WAVE * WAVES, (COLS == WAVES) ? 4 : 2) k_tr_update(DM m, int tr0) {
+  extern __shared__ double th_sh[];
+  ThTile<NT, COLS> tile(th_sh, m.nlm1);
+  const int trA = tr0 + blockIdx.y * NT;                  // first tracer of this block (grid.y = tracer groups of the launch)
+  const int w = threadIdx.x >> 6, nz = lane_id() + 1;
+  const int base = xcd_block() * COLS;
+  const bool impl = m.p.with_diffusion && m.p.i_vert_diff;
+  constexpr bool SINGLE = (COLS == WAVES);                // one column per wave: everything stays in registers across the sweep
+  TruCol k;
+  double Ts[NT] = {}, rhs[NT] = {};
+  for (int ci = w; ci < COLS; ci += WAVES) {
+    const int n = __builtin_amdgcn_readfirstlane(base + ci);
+    if (n >= m.myN && n < m.N && nz <= m.nlm1) {           // halo columns: only tr_arr_old(:,:,tr) = tr_arr(:,:,tr) (whole-array copy, :274)
+#pragma unroll
+      for (int t = 0; t < NT; t++) if (trA + t < m.ntr) DTR(m.tr_arr_old, nz, n, trA + t) = DTR(m.tr_arr, nz, n, trA + t);
+    }
+    tru_head(m, n, k);
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      Ts[t] = 0.0; rhs[t] = 0.0;
+      double del = 0.0;
+      if (trA + t < m.ntr) tru_hor(m, k, trA + t, Ts[t], del);
+      if (t == 0) tru_zcol<REDI>(m, k);
+      if (trA + t < m.ntr) tru_fin<REDI>(m, k, trA + t, Ts[t], del);
+    }
+    if (impl) {
+      tru_coeffs<REDI>(m, k);
+#pragma unroll
+      for (int t = 0; t < NT; t++) if (trA + t < m.ntr) rhs[t] = tru_rhs(m, k, trA + t, Ts[t]);
+    }
+    if (!impl || !SINGLE) {                               // T* to memory: final value without the implicit part, else picked up after the sweep
+#pragma unroll
+      for (int t = 0; t < NT; t++) if (k.wet && trA + t < m.ntr) DTR(m.tr_arr, nz, k.n, trA + t) = impl ? Ts[t] : tru_clamp(Ts[t], trA + t);
+    }
+    if (impl) tile.put(ci, k.valid, k.nzmin, k.nzmax - 1, k.a, k.b, k.c, rhs[0], NT == 2 ? rhs[NT - 1] : 0.0);
+  }
+  if (!impl) return;
+  tile.sweep();
+  for (int ci = w; ci < COLS; ci += WAVES) {
+    double dT[2];
+    tile.get(ci, dT[0], dT[1]);
+    int n = k.n; bool wet = k.wet;
+    if (!SINGLE) {
+      n = __builtin_amdgcn_readfirstlane(base + ci);
+      wet = n < m.myN;
+      if (wet) wet = nz >= m.ulev_n[n] && nz <= m.nlev_n[n] - 1;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+      if (wet && trA + t < m.ntr) {                        // tr_arr = T* + dT ; salinity clamp
+        double T = SINGLE ? Ts[t] : DTR(m.tr_arr, nz, n, trA + t);
+        DTR(m.tr_arr, nz, n, trA + t) = tru_clamp(T + dT[t], trA + t);
+      }
   }
 }
 
 // tr >= 0: that tracer only; tr < 0: all tracers in one launch (grid.y), their chains are independent
 #define LAUNCH_COL(k, ncol, m_, tr_) hipLaunchKernelGGL(k, dim3(nblocks(ncol), (tr_) < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m_, (tr_) < 0 ? 0 : (tr_))
-#define LAUNCH_TRU(m_, tr_) do { if (m.p.Redi) hipLaunchKernelGGL(k_tr_update<true>, dim3(nblocks_th(m.N), (tr_) < 0 ? m.ntr : 1), dim3(TH_BLOCK), thomas_lds_bytes(m.nlm1, 1), s, m_, (tr_) < 0 ? 0 : (tr_)); \
-  else hipLaunchKernelGGL(k_tr_update<false>, dim3(nblocks_th(m.N), (tr_) < 0 ? m.ntr : 1), dim3(TH_BLOCK), thomas_lds_bytes(m.nlm1, 1), s, m_, (tr_) < 0 ? 0 : (tr_)); } while (0)
+// one column per wave, one tracer per block row (pi) -- or tiles with both tracers per block (DM::use_tile; all tracers of the launch)
+#define LAUNCH_TRU1(R, m_, tr_) hipLaunchKernelGGL((k_tr_update<R, 1, TH_COLS, TH_COLS>), dim3(nblocks_th(m.N), (tr_) < 0 ? m.ntr : 1), dim3(TH_BLOCK), (ThTile<1, TH_COLS>::lds_bytes(m.nlm1)), s, m_, (tr_) < 0 ? 0 : (tr_))
+#define TRU_SHAPE(id, C_, W_) case id: hipLaunchKernelGGL((k_tr_update<R_, NT_, C_, W_>), dim3((m.N + C_ - 1) / C_, gy), dim3(WAVE * W_), (ThTile<NT_, C_>::lds_bytes(m.nlm1)), s, m, tr0); break;
+template <bool R_, int NT_> static void launch_tru_tile(const DM &m, hipStream_t s, int gy, int tr0) { switch (m.use_tile) { TILE_SHAPES(TRU_SHAPE) default: break; } }
+#define LAUNCH_TRU(m_, tr_) do { if (m.use_tile && (tr_) < 0) { if (m.p.Redi) launch_tru_tile<true, 2>(m_, s, (m.ntr + 1) / 2, 0); else launch_tru_tile<false, 2>(m_, s, (m.ntr + 1) / 2, 0); } \
+  else if (m.use_tile) { if (m.p.Redi) launch_tru_tile<true, 1>(m_, s, 1, tr_); else launch_tru_tile<false, 1>(m_, s, 1, tr_); }   /* one named tracer (routine-level tests) */ \
+  else if (m.p.Redi) LAUNCH_TRU1(true, m_, tr_); else LAUNCH_TRU1(false, m_, tr_); } while (0)
 #define LAUNCH_WIMPL(m_, tr_) do { if (m.p.w_split) hipLaunchKernelGGL(k_fct_lo_wimpl, dim3(nblocks_th(m.myN), (tr_) < 0 ? m.ntr : 1), dim3(TH_BLOCK), thomas_lds_bytes(m.nlm1, 1), s, m_, (tr_) < 0 ? 0 : (tr_)); } while (0)
 #define LAUNCH_DFX(m_, tr_) do { if (m.p.Redi) LAUNCH_COL(k_diff_flux<true>, m.myD, m_, tr_); else LAUNCH_COL(k_diff_flux<false>, m.myD, m_, tr_); } while (0)
 
+#define TRU_ATTR(id, C_, W_) (void)hipFuncSetAttribute((const void *)k_tr_update<false, 2, C_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, big); \
+  (void)hipFuncSetAttribute((const void *)k_tr_update<true, 2, C_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, big); \
+  (void)hipFuncSetAttribute((const void *)k_tr_update<false, 1, C_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, big); \
+  (void)hipFuncSetAttribute((const void *)k_tr_update<true, 1, C_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+void tile_prepare_tra() {      // tiles of meshes with many levels / 64 columns need more than the default 64 KB of dynamic LDS
+  const int big = 160 * 1024;
+  TILE_SHAPES(TRU_ATTR)
+}
 void launch_tracer(const DM &m, hipStream_t s, int tr) {   // tr 0-based
   LAUNCH_COL(k_tr_ab, m.N, m, tr);
   LAUNCH_COL(k_tr_z, m.N, m, tr);

@@ -166,7 +166,7 @@ def aggregate(A, theta=0.0):
 
 
 class AMG:
-    def __init__(self, As, coarse=64, nu=1, omega=0.7, smoother="jacobi", kcycle=False, over=1.0, maxlev=10):
+    def __init__(self, As, coarse=64, nu=1, omega=0.7, smoother="jacobi", kcycle=False, over=1.0, maxlev=10, sa=0.0, cheb=0):
         self.lv = []
         A = sp.csr_matrix(As)
         while True:
@@ -179,27 +179,51 @@ class AMG:
                 break
             agg, na = aggregate(A)
             P = sp.csr_matrix((np.ones(A.shape[0]), (np.arange(A.shape[0]), agg)), shape=(A.shape[0], na))
+            if sa > 0.0:                      # smoothed aggregation: P = (I - sa * D^-1 A) P_tent
+                P = (P - sa * (sp.diags(1.0 / d) @ A @ P)).tocsr()
             lev["P"] = P
             A = (P.T @ A @ P).tocsr()
         self.nu, self.omega, self.over = nu, omega, over
         last = self.lv[-1]["A"]
         self.coarse_lu = spla.splu(sp.csc_matrix(last))
         self.sizes = [l["A"].shape[0] for l in self.lv]
+        self.nnz = [round(l["A"].nnz / l["A"].shape[0], 1) for l in self.lv]
+        self.cheb = cheb
+        if cheb:
+            for l in self.lv[:-1]:
+                B = sp.diags(l["Dinv"]) @ l["A"]
+                l["lmax"] = abs(spla.eigs(B, k=1, which="LM", return_eigenvectors=False, tol=1e-2)[0]) * 1.05
+
+    def smooth(self, lev, z, r):
+        A, Dinv = lev["A"], lev["Dinv"]
+        if not self.cheb:
+            for _ in range(self.nu):
+                z = z + self.omega * Dinv * (r - A @ z)
+            return z
+        lmax = lev["lmax"]; lmin = lmax / 4.0
+        theta, delta = 0.5 * (lmax + lmin), 0.5 * (lmax - lmin)
+        sigma = theta / delta; rho = 1.0 / sigma
+        res = Dinv * (r - A @ z)
+        dd = res / theta
+        z = z + dd
+        for _ in range(self.cheb - 1):
+            res = Dinv * (r - A @ z)
+            rho_n = 1.0 / (2.0 * sigma - rho)
+            dd = rho_n * rho * dd + 2.0 * rho_n / delta * res
+            z = z + dd
+            rho = rho_n
+        return z
 
     def cycle(self, k, r):
         lev = self.lv[k]
         if k == len(self.lv) - 1:
             return self.coarse_lu.solve(r)
         A, Dinv, P = lev["A"], lev["Dinv"], lev["P"]
-        z = self.omega * Dinv * r
-        for _ in range(self.nu - 1):
-            z = z + self.omega * Dinv * (r - A @ z)
+        z = self.smooth(lev, np.zeros_like(r), r)
         rc = P.T @ (r - A @ z)
         zc = self.cycle(k + 1, rc)
         z = z + self.over * (P @ zc)
-        for _ in range(self.nu):
-            z = z + self.omega * Dinv * (r - A @ z)
-        return z
+        return self.smooth(lev, z, r)
 
     def __call__(self, r):
         return self.cycle(0, r)
@@ -215,13 +239,14 @@ def main():
     precs = {"jacobi": None}
     d0 = A0s.diagonal()
     precs["jacobi"] = lambda r, d=d0: r / d
-    for deg in (2, 3, 4):
-        precs[f"cheb{deg}"] = cheb_prec(A0s, deg)[0]
-    M, nc = mc_sgs_prec(A0s); precs[f"mcSGS({nc} colours)"] = M
-    precs["ilu0-natural"] = ilu_prec(A0s, 1)
-    for nu, om, over in ((1, 0.7, 1.0), (1, 0.7, 1.5), (2, 0.7, 1.5)):
-        amg = AMG(A0s, nu=nu, omega=om, over=over)
-        precs[f"amg nu{nu} om{om} over{over} {amg.sizes}"] = amg
+    if "--amg-only" not in sys.argv:
+        for deg in (2, 3, 4):
+            precs[f"cheb{deg}"] = cheb_prec(A0s, deg)[0]
+        M, nc = mc_sgs_prec(A0s); precs[f"mcSGS({nc} colours)"] = M
+        precs["ilu0-natural"] = ilu_prec(A0s, 1)
+    for kw in (dict(nu=1, over=1.5), dict(nu=1, over=1.0, sa=0.66), dict(nu=1, over=1.0, sa=0.5), dict(nu=2, over=1.0, sa=0.66), dict(cheb=2, over=1.5), dict(cheb=2, sa=0.66), dict(cheb=3, sa=0.66)):
+        amg = AMG(A0s, **kw)
+        precs[f"amg {kw} {amg.sizes} nnz/row {amg.nnz}"] = amg
     print("setup s", round(time.time() - t0, 1))
     for name, M in precs.items():
         res = []
