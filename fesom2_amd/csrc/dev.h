@@ -93,6 +93,26 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
 #define DGS(j, e)          m.gsca[6 * (size_t)(e) + (j) - 1]
 #define DECD(j, d)         m.ecd[4 * (size_t)(d) + (j) - 1]
 
+// The same accessors for a WAVE-UNIFORM horizontal index (the column a wavefront works on, or a neighbour column whose index
+// came out of v_readlane / a scalar load): the column's base address is formed on the scalar unit and every lane adds the SAME
+// 32-bit level offset, so the access is  global_load v, v_off, s[base:base+1]  -- no 64-bit vector address arithmetic per load.
+// NEVER use them with an index that differs between the lanes of a wave.
+template <class T> __device__ __forceinline__ __attribute__((address_space(1))) T *uni_ptr(T *p) {      // (global address space kept explicit)
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (__attribute__((address_space(1))) T *)(((unsigned long long)hi << 32) | lo);
+}
+// (the level offset is formed as a 32-bit BYTE offset: that is the form the address-mode selection folds into saddr + voffset)
+template <class T> __device__ __forceinline__ __attribute__((address_space(1))) T &uni_at(T *colbase, unsigned byte_off) {
+  return *(__attribute__((address_space(1))) T *)((__attribute__((address_space(1))) char *)uni_ptr(colbase) + byte_off);
+}
+#define UA2(a, nz, n)       uni_at((a) + (size_t)(n) * m.nlm1, ((unsigned)(nz) - 1u) * 8u)
+#define UA2L(a, nz, n)      uni_at((a) + (size_t)(n) * m.nl, ((unsigned)(nz) - 1u) * 8u)
+#define UV2(a, c, nz, e)    uni_at((a) + (size_t)(e) * m.nlm1 * 2, (((unsigned)(nz) - 1u) * 2u + ((unsigned)(c) - 1u)) * 8u)
+#define UV3(a, c, nz, e)    uni_at((a) + (size_t)(e) * m.nlm1 * 3, (((unsigned)(nz) - 1u) * 3u + ((unsigned)(c) - 1u)) * 8u)
+#define UV4(a, c, nz, e)    uni_at((a) + (size_t)(e) * m.nlm1 * 4, (((unsigned)(nz) - 1u) * 4u + ((unsigned)(c) - 1u)) * 8u)
+#define UTR(a, nz, n, t)    uni_at((a) + ((size_t)(t) * m.N + (n)) * m.nlm1, ((unsigned)(nz) - 1u) * 8u)
+
 #define D_G 9.81
 #define D_RHO0 1030.0
 #define D_REARTH 6367500.0
@@ -116,6 +136,37 @@ __device__ __forceinline__ double bcast(double x, int src) {
 __device__ __forceinline__ int rdlane(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }   // lane must be wave-uniform
 __device__ __forceinline__ double shup(double x) { return __shfl_up(x, 1, 64); }     // value of lane-1
 __device__ __forceinline__ double shdn(double x) { return __shfl_down(x, 1, 64); }   // value of lane+1
+
+// Many quotients with the SAME denominator (x * dt / areasvol for every edge of a node): the device's IEEE fp64 division is
+// the sequence  ds = div_scale(d), r = rcp(ds) refined by two Newton steps, ns = div_scale(n), q0 = ns*r,
+// rem = fma(-ds, q0, ns), q = div_fmas(rem, r, q0), div_fixup  -- and everything up to r depends on the denominator only.
+// rcp_prepare() forms r once, div_by() finishes a quotient with the remaining three operations: the same instructions on the
+// same values as `n / d`, hence the same bits, as long as div_scale leaves both operands unscaled and div_fixup passes q
+// through: d and n normal with exponents in 2^-255 .. 2^256 (the quotient is then far from the exponent limits too), or
+// n = 0.  A zero numerator gives +0 here where the division gives a zero with the sign of the quotient: use div_by only
+// where the quotient is ADDED to an accumulator that is not -0 (x + (+-0) == x), as all call sites do.
+// div_by() records in `bad` whether a lane left that range; the caller then redoes the column with the plain division
+// (cold path; never observed on ocean data: fluxes are exactly zero or many orders of magnitude inside the range).
+struct RcpD { double d, r; };
+__device__ __forceinline__ RcpD rcp_prepare(double d, bool &bad) {
+  RcpD k;
+  k.d = d;
+  double r0 = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r0, 1.0);
+  double r1 = __builtin_fma(r0, e, r0);
+  e = __builtin_fma(-d, r1, 1.0);
+  k.r = __builtin_fma(r1, e, r1);
+  const unsigned ex = ((unsigned)__double2hiint(d) >> 20) & 0x7ffu;
+  bad = bad || (ex - 0x300u) > 0x1ffu;
+  return k;
+}
+__device__ __forceinline__ double div_by(double n, const RcpD &k, bool &bad) {
+  const unsigned hn = (unsigned)__double2hiint(n) & 0x7fffffffu;
+  bad = bad || (((hn >> 20) - 0x300u) > 0x1ffu && (hn | (unsigned)__double2loint(n)) != 0u);
+  const double q0 = n * k.r;
+  const double rem = __builtin_fma(-k.d, q0, n);
+  return __builtin_fma(rem, k.r, q0);
+}
 
 // Sequential (reference-order) running sums across the lanes of one wavefront, bit-identical to the scalar loop
 //   acc = init; for j = first..last: acc = acc + x[j]      (lane j keeps the partial sum after element j).
@@ -207,6 +258,16 @@ struct ThTile {
       p[0] = a; p[astr] = b; p[2 * astr] = c; p[3 * astr] = r1;
       if (NRHS == 2) p[4 * astr] = r2;
     }
+  }
+  // the same in two parts (tiles with several right-hand sides assembled one after the other)
+  __device__ __forceinline__ void put_abc(int ci, bool valid, int kmin, int kmax, double a, double b, double c) {
+    const int l = threadIdx.x & 63, nz = l + 1;
+    if (l == 0) { rng[2 * ci] = valid ? kmin : 1; rng[2 * ci + 1] = valid ? kmax : 0; }
+    if (nz <= nl1) { double *p = sh + (nz - 1) * CP + ci; p[0] = a; p[astr] = b; p[2 * astr] = c; }
+  }
+  __device__ __forceinline__ void put_rhs(int ci, int which, double r) {
+    const int nz = (threadIdx.x & 63) + 1;
+    if (nz <= nl1) sh[(size_t)(3 + which) * astr + (nz - 1) * CP + ci] = r;
   }
   __device__ __forceinline__ void get(int ci, double &x1, double &x2) const {
     const int nz = (threadIdx.x & 63) + 1;

@@ -505,6 +505,7 @@ __global__ void __launch_bounds__(BLOCK) k_diff_flux(DM m, int tr0) {
 // The kernel is latency-bound, not bandwidth-bound: the edge list of the node is read lane-parallel (lane q = q-th
 // incident edge), broadcast with v_readlane, and all edge values are fetched in one batch before the ordered sums.
 #define TRU_MAXD 10                     // batch of this kernel (4 loads per edge): keeps it at <= 128 VGPRs, 2 blocks per CU
+#define TRU_MAXD_TILE 8                 // tile shapes: two tracers per block, 8 edges per batch (nodes of degree > 8 take the remainder loop)
 // Shapes (dev.h:ThTile): <REDI, 1, 8, 8> = one column per wave, one tracer per block row (pi); <REDI, 2, TL_COLS, TL_WAVES> =
 // tiles of TL_COLS columns, several columns per wave, BOTH tracers of a column in the same block (CORE2-class meshes): the
 // tracer-independent part of the column (thicknesses, interface depths, the coefficients a, b, c of the implicit operator, the
@@ -537,73 +538,81 @@ __device__ __forceinline__ void tru_head(const DM &m, int n_in, TruCol &k) {
   if (k.wet) { k.hn = DA2(m.hnode, nz, n); k.hnn = DA2(m.hnode_new, nz, n); k.asv = DA2L(m.areasvol, nz, n); }
 }
 // flux -> tendency (oce_tra_adv_flux2dtracer) and horizontal diffusion of tracer `tr`: T^n and del (lane = level)
-__device__ __forceinline__ void tru_hor(const DM &m, const TruCol &k, int tr, double &T, double &del) {
+// FAST: the quotients by areasvol(nz,n) share one reciprocal (dev.h: div_by, same bits as '/'); returns true if a lane left the
+// range in which that holds -- the caller then repeats the call with FAST = false (plain divisions)
+template <bool FAST, int MAXD>
+__device__ __forceinline__ bool tru_hor(const DM &m, const TruCol &k, int tr, double &T, double &del) {
   const TV t = tracer_view(m, tr);
   const int l = lane_id(), nz = l + 1, n = k.n, nzmin = k.nzmin, nzmax = k.nzmax;
   const double dt = m.p.dt, asv = k.asv, hn = k.hn, hnn = k.hnn;
   const bool wet = k.wet;
   const int nzc = min(nz, m.nlm1);
   const bool dif = m.p.with_diffusion != 0;
-  const double p_own = DA2(t.fct_plus, nzc, n), m_own = DA2(t.fct_minus, nzc, n);
-  double fa[TRU_MAXD], fd[TRU_MAXD];
+  const double p_own = UA2(t.fct_plus, nzc, n), m_own = UA2(t.fct_minus, nzc, n);
+  double fa[MAXD], fd[MAXD];
 #pragma unroll
-  for (int q = 0; q < TRU_MAXD; q++) {                   // one batch of independent loads
+  for (int q = 0; q < MAXD; q++) {                   // one batch of independent loads
     int ed = rdlane(k.ed_l, q), kk = rdlane(k.fn_l, q);
     const bool first = rdlane(k.sg_l, q) > 0;               // this node is edges(1,ed)
     // limited antidiffusive flux ae * flux with the factors of oce_adv_tra_fct.F90:318-347 applied on the fly:
     // flux >= 0: min(1, plus(n1), minus(n2)); flux < 0: min(1, minus(n1), plus(n2))
-    double fr = DA2(t.adv_flux_raw, nzc, ed), p_far = DA2(t.fct_plus, nzc, kk), m_far = DA2(t.fct_minus, nzc, kk);
+    double fr = UA2(t.adv_flux_raw, nzc, ed), p_far = UA2(t.fct_plus, nzc, kk), m_far = UA2(t.fct_minus, nzc, kk);
     double p1 = first ? p_own : p_far, m1 = first ? m_own : m_far, p2 = first ? p_far : p_own, m2 = first ? m_far : m_own;
     double ae = dmin_(dmin_(1.0, (fr >= 0.) ? p1 : m1), (fr >= 0.) ? m2 : p2);
     fa[q] = ae * fr;
-    fd[q] = dif ? DA2(t.diff_flux, nzc, ed) : 0.0;
+    fd[q] = dif ? UA2(t.diff_flux, nzc, ed) : 0.0;
   }
-  double adv = (nz >= nzmin && nz <= nzmax) ? DA2L(t.adv_flux_ver, nz, n) : 0.0;
+  double adv = (nz >= nzmin && nz <= nzmax) ? UA2L(t.adv_flux_ver, nz, n) : 0.0;
   double adv_dn = shdn(adv);
   T = 0.0;
-  if (wet) T = DTR(m.tr_arr, nz, n, tr);
-  double dv = 0.0 - T * hn + (wet ? DA2(t.fct_LO, nz, n) : 0.0) * hnn;
-  dv = dv + (adv - adv_dn) * dt / asv;
+  if (wet) T = UTR(m.tr_arr, nz, n, tr);
+  bool bad = false;
+  const RcpD rasv = rcp_prepare(asv, bad);                 // ~21 quotients by areasvol(nz,n) follow
+#define QDIV(x) (FAST ? div_by((x), rasv, bad) : (x) / asv)
+  double dv = 0.0 - T * hn + (wet ? UA2(t.fct_LO, nz, n) : 0.0) * hnn;
+  dv = dv + QDIV((adv - adv_dn) * dt);
   double dh = 0.0;
 #pragma unroll
-  for (int q = 0; q < TRU_MAXD; q++) {
+  for (int q = 0; q < MAXD; q++) {
     unsigned rg = (unsigned)rdlane((int)k.rg_l, q);
     int sg = rdlane(k.sg_l, q);
     bool on = nz >= (int)(rg & 0xffu) && nz <= (int)((rg >> 8) & 0xffu);
-    double f = fa[q] * dt / asv;
+    double f = QDIV(fa[q] * dt);
     double nh = (sg > 0) ? dh + f : dh - f;
     dh = on ? nh : dh;
   }
-  for (int q = TRU_MAXD; q < k.deg; q++) {                  // nodes with more incident edges than the batch (rare)
+  for (int q = MAXD; q < k.deg; q++) {                  // nodes with more incident edges than the batch (rare)
     int ed = m.ne_idx[k.q0 + q];
     unsigned rg = m.ne_rng[k.q0 + q];
     if (nz < (int)(rg & 0xffu) || nz > (int)((rg >> 8) & 0xffu)) continue;
     int n1 = m.edges[2 * ed], n2 = m.edges[2 * ed + 1];
-    double fr = DA2(t.adv_flux_raw, nz, ed);
-    double ae = dmin_(dmin_(1.0, (fr >= 0.) ? DA2(t.fct_plus, nz, n1) : DA2(t.fct_minus, nz, n1)), (fr >= 0.) ? DA2(t.fct_minus, nz, n2) : DA2(t.fct_plus, nz, n2));
+    double fr = UA2(t.adv_flux_raw, nz, ed);
+    double ae = dmin_(dmin_(1.0, (fr >= 0.) ? UA2(t.fct_plus, nz, n1) : UA2(t.fct_minus, nz, n1)), (fr >= 0.) ? UA2(t.fct_minus, nz, n2) : UA2(t.fct_plus, nz, n2));
     double f = (ae * fr) * dt / asv;
     dh = (m.ne_sgn[k.q0 + q] > 0) ? dh + f : dh - f;
   }
   del = 0.0 + dh + dv;
   if (dif) {
 #pragma unroll
-    for (int q = 0; q < TRU_MAXD; q++) {
+    for (int q = 0; q < MAXD; q++) {
       unsigned rg = (unsigned)rdlane((int)k.rg_l, q);
       int sg = rdlane(k.sg_l, q);
       bool on = nz >= (int)(rg & 0xffu) && nz <= (int)((rg >> 8) & 0xffu);
       double r_ = (sg > 0) ? 0.0 + fd[q] : 0.0 - fd[q];
-      double nd = del + r_ * dt / asv;
+      double nd = del + QDIV(r_ * dt);
       del = on ? nd : del;
     }
-    for (int q = TRU_MAXD; q < k.deg; q++) {
+    for (int q = MAXD; q < k.deg; q++) {
       int ed = m.ne_idx[k.q0 + q];
       unsigned rg = m.ne_rng[k.q0 + q];
       if (nz < (int)(rg & 0xffu) || nz > (int)((rg >> 8) & 0xffu)) continue;
-      double c = DA2(t.diff_flux, nz, ed);
+      double c = UA2(t.diff_flux, nz, ed);
       double r_ = (m.ne_sgn[k.q0 + q] > 0) ? 0.0 + c : 0.0 - c;
       del = del + r_ * dt / asv;
     }
   }
+#undef QDIV
+  return FAST && __any(bad);
 }
 // zbar_n / Z_n of the node column from hnode_new (bottom-up, reference order); Redi: slopes and Ki of the column
 template <bool REDI>
@@ -721,7 +730,7 @@ __device__ __forceinline__ double tru_clamp(double T, int tr) {           // sal
   return T;
 }
 template <bool REDI, int NT, int COLS, int WAVES>
-__global__ void __launch_bounds__(WAVE * WAVES, (COLS == WAVES) ? 4 : 2) k_tr_update(DM m, int tr0) {
+__global__ void __launch_bounds__(WAVE * WAVES, (WAVES == 8) ? 4 : 2) k_tr_update(DM m, int tr0) {
   extern __shared__ double th_sh[];
   ThTile<NT, COLS> tile(th_sh, m.nlm1);
   const int trA = tr0 + blockIdx.y * NT;                  // first tracer of this block (grid.y = tracer groups of the launch)
@@ -738,24 +747,40 @@ __global__ void __launch_bounds__(WAVE * WAVES, (COLS == WAVES) ? 4 : 2) k_tr_up
       for (int t = 0; t < NT; t++) if (trA + t < m.ntr) DTR(m.tr_arr_old, nz, n, trA + t) = DTR(m.tr_arr, nz, n, trA + t);
     }
     tru_head(m, n, k);
+    if (SINGLE) {
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
-      Ts[t] = 0.0; rhs[t] = 0.0;
-      double del = 0.0;
-      if (trA + t < m.ntr) tru_hor(m, k, trA + t, Ts[t], del);
-      if (t == 0) tru_zcol<REDI>(m, k);
-      if (trA + t < m.ntr) tru_fin<REDI>(m, k, trA + t, Ts[t], del);
-    }
-    if (impl) {
-      tru_coeffs<REDI>(m, k);
+      for (int t = 0; t < NT; t++) {
+        Ts[t] = 0.0; rhs[t] = 0.0;
+        double del = 0.0;
+        if (trA + t < m.ntr) tru_hor<false, TRU_MAXD>(m, k, trA + t, Ts[t], del);      // (latency-bound shape: plain divisions keep it at its register budget)
+        if (t == 0) tru_zcol<REDI>(m, k);
+        if (trA + t < m.ntr) tru_fin<REDI>(m, k, trA + t, Ts[t], del);
+      }
+      if (impl) {
+        tru_coeffs<REDI>(m, k);
 #pragma unroll
-      for (int t = 0; t < NT; t++) if (trA + t < m.ntr) rhs[t] = tru_rhs(m, k, trA + t, Ts[t]);
-    }
-    if (!impl || !SINGLE) {                               // T* to memory: final value without the implicit part, else picked up after the sweep
+        for (int t = 0; t < NT; t++) if (trA + t < m.ntr) rhs[t] = tru_rhs(m, k, trA + t, Ts[t]);
+        tile.put(ci, k.valid, k.nzmin, k.nzmax - 1, k.a, k.b, k.c, rhs[0], NT == 2 ? rhs[NT - 1] : 0.0);
+      } else {
 #pragma unroll
-      for (int t = 0; t < NT; t++) if (k.wet && trA + t < m.ntr) DTR(m.tr_arr, nz, k.n, trA + t) = impl ? Ts[t] : tru_clamp(Ts[t], trA + t);
+        for (int t = 0; t < NT; t++) if (k.wet && trA + t < m.ntr) DTR(m.tr_arr, nz, k.n, trA + t) = tru_clamp(Ts[t], trA + t);
+      }
+    } else {
+      // several columns per wave: the column's coefficients first, then tracer after tracer straight into the tile / memory
+      tru_zcol<REDI>(m, k);
+      if (impl) { tru_coeffs<REDI>(m, k); tile.put_abc(ci, k.valid, k.nzmin, k.nzmax - 1, k.a, k.b, k.c); }
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        double T = 0.0, del = 0.0, r = 0.0;
+        if (trA + t < m.ntr) {
+          if (tru_hor<true, TRU_MAXD_TILE>(m, k, trA + t, T, del)) tru_hor<false, TRU_MAXD_TILE>(m, k, trA + t, T, del);
+          tru_fin<REDI>(m, k, trA + t, T, del);
+          if (k.wet) DTR(m.tr_arr, nz, k.n, trA + t) = impl ? T : tru_clamp(T, trA + t);    // T*: picked up again after the sweep
+          if (impl) r = tru_rhs(m, k, trA + t, T);
+        }
+        if (impl) tile.put_rhs(ci, t, r);
+      }
     }
-    if (impl) tile.put(ci, k.valid, k.nzmin, k.nzmax - 1, k.a, k.b, k.c, rhs[0], NT == 2 ? rhs[NT - 1] : 0.0);
   }
   if (!impl) return;
   tile.sweep();
