@@ -649,6 +649,58 @@ __global__ void __launch_bounds__(BLOCK) k_edge_transport(DM m, int mode) {
   for (int j = u2 - 1; j <= l2 - 1; ++j) c2 = c2 - bcast(t2, j);
   if (l == 0) m.edge_c12[ed] = c1 + c2;
 }
+// The same for CORE2-class meshes (DM::use_tile).  The two vertical sums are sequential in the reference, so in the kernel above
+// all 64 lanes of a wave run the same 2 x (nl-1)-step chain for ONE edge.  Here a wave takes ET_EDGES edges: their per-level
+// terms go through a wave-private LDS image [t1 | t2][level][edge], then lane = edge runs the two chains for all its edges at
+// once (levels outside an element's range hold +0.0: c + 0.0 == c, c - 0.0 == c for the running sums, which are never -0).
+#define ET_EDGES 16
+#define ET_CP (ET_EDGES + 1)
+__global__ void __launch_bounds__(BLOCK) k_edge_transport_tile(DM m, int mode) {
+  extern __shared__ double et_sh[];
+  const int w = threadIdx.x >> 6, l = lane_id(), nz = l + 1, nl1 = m.nlm1;
+  double *img = et_sh + (size_t)w * 2 * nl1 * ET_CP;          // this wave's image
+  const int base = (xcd_block() * COLS_PER_BLOCK + w) * ET_EDGES;
+  const double alpha = m.p.alpha;
+  // the index chain of all ET_EDGES edges in one round (lane k = k-th edge), then four edges' field loads in flight at a time
+  int e1_l = 0, e2_l = -1, u1_l = 1, l1_l = 0, u2_l = 1, l2_l = 0;
+  if (l < ET_EDGES && base + l < m.myD) {
+    e1_l = m.edge_tri[2 * (base + l)]; e2_l = m.edge_tri[2 * (base + l) + 1];
+    u1_l = m.ulev[e1_l]; l1_l = m.nlev[e1_l] - 1;
+    if (e2_l >= 0) { u2_l = m.ulev[e2_l]; l2_l = m.nlev[e2_l] - 1; }
+  }
+#pragma unroll 4
+  for (int k = 0; k < ET_EDGES; k++) {
+    const int ed = __builtin_amdgcn_readfirstlane(base + k);
+    const int e1 = rdlane(e1_l, k), e2 = rdlane(e2_l, k);
+    double t1 = 0.0, t2 = 0.0;
+    if (nz >= rdlane(u1_l, k) && nz <= rdlane(l1_l, k)) {            // (edges beyond myD: empty ranges)
+      double uu = UV2(m.UV, 1, nz, e1), vv = UV2(m.UV, 2, nz, e1), h = UA2(m.helem, nz, e1);
+      if (mode == 0) t1 = alpha * ((vv + UV2(m.UV_rhs, 2, nz, e1)) * DECD(1, ed) - (uu + UV2(m.UV_rhs, 1, nz, e1)) * DECD(2, ed)) * h;
+      else t1 = (vv * DECD(1, ed) - uu * DECD(2, ed)) * h;
+    }
+    if (nz >= rdlane(u2_l, k) && nz <= rdlane(l2_l, k)) {
+      double uu = UV2(m.UV, 1, nz, e2), vv = UV2(m.UV, 2, nz, e2), h = UA2(m.helem, nz, e2);
+      if (mode == 0) t2 = alpha * ((vv + UV2(m.UV_rhs, 2, nz, e2)) * DECD(3, ed) - (uu + UV2(m.UV_rhs, 1, nz, e2)) * DECD(4, ed)) * h;
+      else t2 = (vv * DECD(3, ed) - uu * DECD(4, ed)) * h;
+    }
+    if (nz <= nl1) { img[l * ET_CP + k] = t1; img[(nl1 + l) * ET_CP + k] = t2; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // lane = edge: c1 = sum t1 top-down, c2 = c2 - t2 (reference: c2 = c2 - term), then c1 + c2
+  const int kk = l < ET_EDGES ? l : ET_EDGES - 1;
+  double c1 = 0.0, c2 = 0.0;
+  for (int j = 0; j < nl1; j++) {
+    c1 = c1 + img[j * ET_CP + kk];
+    c2 = c2 - img[(nl1 + j) * ET_CP + kk];
+  }
+  if (l < ET_EDGES && base + l < m.myD) m.edge_c12[base + l] = c1 + c2;
+}
+static void launch_edge_transport(const DM &m, hipStream_t s, int mode) {
+  if (m.use_tile) {
+    const int per_block = COLS_PER_BLOCK * ET_EDGES;
+    hipLaunchKernelGGL(k_edge_transport_tile, dim3((m.myD + per_block - 1) / per_block), dim3(BLOCK), (size_t)COLS_PER_BLOCK * 2 * m.nlm1 * ET_CP * sizeof(double), s, m, mode);
+  } else hipLaunchKernelGGL(k_edge_transport, dim3(nblocks(m.myD)), dim3(BLOCK), 0, s, m, mode);
+}
 __global__ void k_ssh_rhs_node(DM m) {
   int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= m.myN) return;
@@ -865,7 +917,7 @@ __global__ void __launch_bounds__(BLOCK) k_thick(DM m, int ncolN) {
 #define LAUNCH_FLAT(k, n, ...) hipLaunchKernelGGL(k, dim3(((n) + 255) / 256), dim3(256), 0, s, __VA_ARGS__)
 
 #define IV_ATTR(id, C_, W_) (void)hipFuncSetAttribute((const void *)k_impl_visc<C_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-void tile_prepare_dyn() { TILE_SHAPES(IV_ATTR) }
+void tile_prepare_dyn() { TILE_SHAPES(IV_ATTR) (void)hipFuncSetAttribute((const void *)k_edge_transport_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
 void launch_dynamics_pre(const DM &m, hipStream_t s, int first_step) {
   LAUNCH_COL(k_vel_nodes, m.myN, m);
   LAUNCH_COL(k_pressure_bv, m.N, m);
@@ -884,13 +936,13 @@ void launch_dynamics_pre(const DM &m, hipStream_t s, int first_step) {
 }
 void launch_ssh_rhs(const DM &m, hipStream_t s) {
   if (m.p.which_ale != 0) LAUNCH_FLAT(k_stiff_update, m.nza, m);
-  LAUNCH_COL(k_edge_transport, m.myD, m, 0);
+  launch_edge_transport(m, s, 0);
   LAUNCH_FLAT(k_ssh_rhs_node, m.myN, m);
 }
 void launch_dynamics_post(const DM &m, hipStream_t s) {
   int ncol = m.myE > (m.N + BLOCK - 1) / BLOCK * COLS_PER_BLOCK ? m.myE : (m.N + BLOCK - 1) / BLOCK * COLS_PER_BLOCK;
   LAUNCH_COL(k_update_vel, ncol, m);
-  LAUNCH_COL(k_edge_transport, m.myD, m, 1);
+  launch_edge_transport(m, s, 1);
   LAUNCH_FLAT(k_hbar_node, m.myN, m);
   LAUNCH_FLAT(k_dhe, m.myE, m);
   LAUNCH_COL(k_vert_vel, m.myN, m, 0);
@@ -920,8 +972,8 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
     if (!strcmp(name, "k_visc_apply")) { LAUNCH_COL(k_visc_apply, m.myE, m); return 0; }
     if (!strcmp(name, "k_impl_visc")) { LAUNCH_IMPL_VISC(m.p.visc_option == 5, m.p.i_vert_visc); return 0; }
     if (!strcmp(name, "k_stiff_update")) { LAUNCH_FLAT(k_stiff_update, m.nza, m); return 0; }
-    if (!strcmp(name, "k_edge_transport")) { LAUNCH_COL(k_edge_transport, m.myD, m, 0); return 0; }
-    if (!strcmp(name, "k_edge_transport1")) { LAUNCH_COL(k_edge_transport, m.myD, m, 1); return 0; }
+    if (!strcmp(name, "k_edge_transport")) { launch_edge_transport(m, s, 0); return 0; }
+    if (!strcmp(name, "k_edge_transport1")) { launch_edge_transport(m, s, 1); return 0; }
     if (!strcmp(name, "k_ssh_rhs_node")) { LAUNCH_FLAT(k_ssh_rhs_node, m.myN, m); return 0; }
     if (!strcmp(name, "k_update_vel")) { LAUNCH_COL(k_update_vel, ncol_uv, m); return 0; }
     if (!strcmp(name, "k_hbar_node")) { LAUNCH_FLAT(k_hbar_node, m.myN, m); return 0; }
@@ -950,13 +1002,13 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
   }
   if (!strcmp(name, "impl_vert_visc_ale")) { LAUNCH_IMPL_VISC(0, 1); return 0; }
   if (!strcmp(name, "update_stiff_mat_ale")) { LAUNCH_FLAT(k_stiff_update, m.nza, m); return 0; }
-  if (!strcmp(name, "compute_ssh_rhs_ale")) { LAUNCH_COL(k_edge_transport, m.myD, m, 0); LAUNCH_FLAT(k_ssh_rhs_node, m.myN, m); return 0; }
+  if (!strcmp(name, "compute_ssh_rhs_ale")) { launch_edge_transport(m, s, 0); LAUNCH_FLAT(k_ssh_rhs_node, m.myN, m); return 0; }
   if (!strcmp(name, "update_vel")) {
     int ncol = m.myE > (m.N + BLOCK - 1) / BLOCK * COLS_PER_BLOCK ? m.myE : (m.N + BLOCK - 1) / BLOCK * COLS_PER_BLOCK;
     LAUNCH_COL(k_update_vel, ncol, m); return 0;
   }
   if (!strcmp(name, "compute_hbar_ale")) {                                                    // includes the eta_n update
-    LAUNCH_COL(k_edge_transport, m.myD, m, 1); LAUNCH_FLAT(k_hbar_node, m.myN, m); LAUNCH_FLAT(k_dhe, m.myE, m); return 0;
+    launch_edge_transport(m, s, 1); LAUNCH_FLAT(k_hbar_node, m.myN, m); LAUNCH_FLAT(k_dhe, m.myE, m); return 0;
   }
   if (!strcmp(name, "eta_update")) return 0;
   if (!strcmp(name, "vert_vel_ale")) { LAUNCH_COL(k_vert_vel, m.myN, m, 0); return 0; }

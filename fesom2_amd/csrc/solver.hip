@@ -424,12 +424,14 @@ __global__ void __launch_bounds__(DSB) k_ds_finish(DM m) {        // x = D^-1 y
 // ds_scal_alpha, ds_s, ds_spmv2, ds_scal_omega, ds_update, ds_finish
 int launch_named_dsolve(const DM &m, hipStream_t s, const char *name) {
   if (strncmp(name, "ds_", 3)) return -1;
-  const int W = m.ssh_maxnnz <= 10 ? 10 : 16, NP = (m.myN + 63) / 64 * 64, nblk = (m.myN + DSB - 1) / DSB;
+  // ELL width of the phases: 8 / 10 / 16 slabs (the column pattern sv_colsi holds >= that many; narrower kernels skip padding slabs)
+  const int W = m.ssh_maxnnz <= 8 ? 8 : m.ssh_maxnnz <= 10 ? 10 : 16, NP = (m.myN + 63) / 64 * 64, nblk = (m.myN + DSB - 1) / DSB;
   if (m.ssh_maxnnz > 16) return 1;
-#define DSW(k, ...) do { if (W == 10) hipLaunchKernelGGL(k<10>, dim3(nblk), dim3(DSB), 0, s, __VA_ARGS__); else hipLaunchKernelGGL(k<16>, dim3(nblk), dim3(DSB), 0, s, __VA_ARGS__); } while (0)
+#define DSW(k, ...) do { if (W == 8) hipLaunchKernelGGL(k<8>, dim3(nblk), dim3(DSB), 0, s, __VA_ARGS__); else if (W == 10) hipLaunchKernelGGL(k<10>, dim3(nblk), dim3(DSB), 0, s, __VA_ARGS__); else hipLaunchKernelGGL(k<16>, dim3(nblk), dim3(DSB), 0, s, __VA_ARGS__); } while (0)
   if (!strcmp(name, "ds_scale")) { launch_row_scale(m, s); return 0; }
   if (!strcmp(name, "ds_setup")) {
-    if (W == 10) hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, 0, 0);
+    if (W == 8) hipLaunchKernelGGL(k_solver_setup<8>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, 0, 0);
+    else if (W == 10) hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, 0, 0);
     else hipLaunchKernelGGL(k_solver_setup<16>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, 0, 0);
     return 0;
   }
@@ -474,6 +476,27 @@ __device__ __forceinline__ double dm_sum_blocks(const double *part, int nblk, do
   double r = sh[0];
   __syncthreads();
   return r;
+}
+// four sums at once (same order per quantity as dm_sum_blocks, one set of barriers for all four)
+__device__ __forceinline__ void dm_sum_blocks4(const double *part, int nblk, double (*sh)[DSB], double (&out)[4]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    double a = 0.0;
+    for (int b = t; b < nblk; b += DSB) a = a + part[(size_t)q * nblk + b];
+    sh[q][t] = a;
+  }
+  __syncthreads();
+  for (int s2 = DSB / 2; s2 >= 1; s2 >>= 1) {
+    if (t < s2) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) sh[q][t] = sh[q][t] + sh[q][t + s2];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) out[q] = sh[q][0];
+  __syncthreads();
 }
 __global__ void __launch_bounds__(DSB) k_dm_start(DM m, int nblk, double tol2, int maxits) {   // after k_ds_init: state + first p
   __shared__ double sh[DSB];
@@ -530,10 +553,11 @@ __global__ void __launch_bounds__(DSB) k_dm_upd(DM m, int nblk, int slot, double
     if (blockIdx.x == 0 && threadIdx.x < 16) so[threadIdx.x] = st[threadIdx.x];
     return;
   }
-  __shared__ double sh[DSB];
+  __shared__ double sh[4][DSB];
   const double *part2 = m.sv_part + 4 * (size_t)nblk;
-  const double tt = dm_sum_blocks(part2, nblk, sh), ts = dm_sum_blocks(part2 + (size_t)nblk, nblk, sh);
-  const double r0t = dm_sum_blocks(part2 + 2 * (size_t)nblk, nblk, sh), ss = dm_sum_blocks(part2 + 3 * (size_t)nblk, nblk, sh);
+  double tot[4];
+  dm_sum_blocks4(part2, nblk, sh, tot);
+  const double tt = tot[0], ts = tot[1], r0t = tot[2], ss = tot[3];
   const double alpha = m.sv_kry[32];
   const double omega = (tt > 0.0) ? ts / tt : 0.0;
   const double rho = st[4], rho_new = -omega * r0t;
@@ -565,18 +589,22 @@ __global__ void __launch_bounds__(DSB) k_dm_finish(DM m, int slot) {
 
 int launch_solver_multi(const DM &m, hipStream_t s, int fuse_rhs, int scale_done) {
   if (m.ssh_maxnnz > 16) return 1;
-  const int W = m.ssh_maxnnz <= 10 ? 10 : 16, NP = (m.myN + 63) / 64 * 64, nblk = (m.myN + DSB - 1) / DSB;
+  // ELL width of the phases: 8 / 10 / 16 slabs (the column pattern sv_colsi holds >= that many; narrower kernels skip padding slabs)
+  const int W = m.ssh_maxnnz <= 8 ? 8 : m.ssh_maxnnz <= 10 ? 10 : 16, NP = (m.myN + 63) / 64 * 64, nblk = (m.myN + DSB - 1) / DSB;
   const double tol2 = 1e-10 * 1e-10; const int maxits = 2000;
   if (!scale_done) launch_row_scale(m, s);
-  if (W == 10) hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs, 0);
+  if (W == 8) hipLaunchKernelGGL(k_solver_setup<8>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs, 0);
+  else if (W == 10) hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs, 0);
   else hipLaunchKernelGGL(k_solver_setup<16>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs, 0);
   static double *hk = nullptr;                                   // pinned copy of the scalar state
   static int last_its = 24;
   if (!hk && hipHostMalloc((void **)&hk, 16 * sizeof(double)) != hipSuccess) return 1;
-#define DMW(k, ...) do { if (W == 10) hipLaunchKernelGGL(k<10>, dim3(nblk), dim3(DSB), 0, s, __VA_ARGS__); else hipLaunchKernelGGL(k<16>, dim3(nblk), dim3(DSB), 0, s, __VA_ARGS__); } while (0)
+#define DMW(k, ...) do { if (W == 8) hipLaunchKernelGGL(k<8>, dim3(nblk), dim3(DSB), 0, s, __VA_ARGS__); else if (W == 10) hipLaunchKernelGGL(k<10>, dim3(nblk), dim3(DSB), 0, s, __VA_ARGS__); else hipLaunchKernelGGL(k<16>, dim3(nblk), dim3(DSB), 0, s, __VA_ARGS__); } while (0)
   DMW(k_ds_init, m, NP, nblk);
   hipLaunchKernelGGL(k_dm_start, dim3(nblk), dim3(DSB), 0, s, m, nblk, tol2, maxits);
-  int slot = 0, total = 0, chunk = last_its > 6 ? last_its - 2 : 4;
+  // one read-back of the convergence flag per solve as a rule: a few iterations more than the last solve needed (launches after
+  // convergence are no-ops of ~2 us; a second read-back costs a host round trip of 30-50 us)
+  int slot = 0, total = 0, chunk = last_its + 6;
   for (;;) {
     for (int k = 0; k < chunk; k++) {
       DMW(k_dm_spmv1, m, NP, nblk, slot);
@@ -588,7 +616,7 @@ int launch_solver_multi(const DM &m, hipStream_t s, int fuse_rhs, int scale_done
     if (hipMemcpyAsync(hk, m.sv_kry + 16 * slot, 16 * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
     if (hipStreamSynchronize(s) != hipSuccess) return 1;
     if (hk[7] != 0.0 || total >= maxits) break;
-    chunk = 4;
+    chunk = 8;
   }
   last_its = (int)hk[6];
   hipLaunchKernelGGL(k_dm_finish, dim3(nblk), dim3(DSB), 0, s, m, slot);
