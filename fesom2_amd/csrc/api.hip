@@ -180,7 +180,8 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
     if (gm) { launch_named_gm(m, s3, "fer_solve_Gamma"); launch_named_gm(m, s3, "fer_gamma2vel"); launch_named_gm(m, s3, "fer_wvel"); }
     ev_gm = d.ev(); hipEventRecord(ev_gm, s3);
   }
-  K(s3, "k_tr_ab", 0); K(s3, "k_tr_grad_elem", 0); K(s3, "k_updn_grad", 0);
+  const bool fuse_updn = m.use_tile != 0;             // CORE2-class meshes: k_flux_hor evaluates fill_up_dn_grad on the fly (kernels_tra.hip)
+  K(s3, "k_tr_ab", 0); K(s3, "k_tr_grad_elem", 0); if (!fuse_updn) K(s3, "k_updn_grad", 0);
   if (m.p.with_diffusion && !redi) K(s3, "k_diff_flux", 0);        // with Redi it needs tr_z of the new thicknesses: see s1 below
   hipEvent_t ev_prep = d.ev(); hipEventRecord(ev_prep, s3);
   // s0: critical chain
@@ -206,7 +207,7 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   hipStreamWaitEvent(s0, ev_prep, 0);
   hipEvent_t ev_df = nullptr;
   if (redi && m.p.with_diffusion) { hipStreamWaitEvent(s1, ev_prep, 0); K(s1, "k_diff_flux", 0); ev_df = d.ev(); hipEventRecord(ev_df, s1); }
-  K(s0, "k_flux_hor", 0); K(s0, "k_fct_lo_node", 0); K(s0, "k_fct_node", 0);
+  K(s0, fuse_updn ? "k_flux_hor_fused" : "k_flux_hor", 0); K(s0, "k_fct_lo_node", 0); K(s0, "k_fct_node", 0);
   // (k_fct_edge_limit only materialises the limited flux field adv_flux_hor, which no kernel of the step reads -- k_tr_update limits on
   // the fly: it is part of the named routine adv_tracers_ale, not of the running step)
   if (ev_df) hipStreamWaitEvent(s0, ev_df, 0);

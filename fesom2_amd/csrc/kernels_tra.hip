@@ -75,17 +75,13 @@ __device__ __forceinline__ void cluster_grad(const DM &m, const TV &t, int node,
   }
   gx = tx / tvol; gy = ty / tvol;
 }
-__global__ void __launch_bounds__(BLOCK) k_updn_grad(DM m, int tr0) {
-  const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
-  const TV t = tracer_view(m, tr);
-  int ed = col_id(), nz = lane_id() + 1;
-  if (ed >= m.myD) return;
-  if (nz > m.nlm1) return;
+// the four up/down-wind gradient values of edge `ed` at level nz (w1: values (1,3) are defined here, w2: (2,4))
+__device__ __forceinline__ void updn_grad(const DM &m, const TV &t, int ed, int nz, double &g1, double &g2, double &g3, double &g4, bool &w1, bool &w2) {
   int n1 = m.edges[2 * ed], n2 = m.edges[2 * ed + 1];
   int t1 = m.updn[2 * ed], t2 = m.updn[2 * ed + 1];
   int ul1 = m.ulev_n[n1], ul2 = m.ulev_n[n2], nl1 = m.nlev_n[n1] - 1, nl2 = m.nlev_n[n2] - 1;
-  double g1, g2, g3, g4;
-  bool w1 = false, w2 = false;      // write (1,3) / (2,4)
+  w1 = false; w2 = false;      // write (1,3) / (2,4)
+  g1 = g2 = g3 = g4 = 0.0;
   if (t1 >= 0 && t2 >= 0) {
     int nzmin = max(m.ulev_n_max[n1], m.ulev_n_max[n2]), nzmax = min(m.nlev_n_min[n1], m.nlev_n_min[n2]);
     if (nz >= nzmin && nz <= nzmax - 1) {
@@ -100,6 +96,16 @@ __global__ void __launch_bounds__(BLOCK) k_updn_grad(DM m, int tr0) {
     if (nz >= ul1 && nz <= nl1) { cluster_grad(m, t, n1, nz, g1, g3); w1 = true; }
     if (nz >= ul2 && nz <= nl2) { cluster_grad(m, t, n2, nz, g2, g4); w2 = true; }
   }
+}
+__global__ void __launch_bounds__(BLOCK) k_updn_grad(DM m, int tr0) {
+  const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
+  const TV t = tracer_view(m, tr);
+  int ed = col_id(), nz = lane_id() + 1;
+  if (ed >= m.myD) return;
+  if (nz > m.nlm1) return;
+  double g1, g2, g3, g4;
+  bool w1, w2;
+  updn_grad(m, t, ed, nz, g1, g2, g3, g4, w1, w2);
   if (w1) { DV4(t.edge_up_dn_grad, 1, nz, ed) = g1; DV4(t.edge_up_dn_grad, 3, nz, ed) = g3; }
   if (w2) { DV4(t.edge_up_dn_grad, 2, nz, ed) = g2; DV4(t.edge_up_dn_grad, 4, nz, ed) = g4; }
 }
@@ -107,6 +113,10 @@ __global__ void __launch_bounds__(BLOCK) k_updn_grad(DM m, int tr0) {
 // adv_tra_hor_upw1 (src/oce_adv_tra_hor.F90:57-211) + adv_tra_hor_mfct (:485-733) in one edge pass:
 // flux_lo_hor = low-order flux, adv_flux_raw = high-order minus low-order (the init_zero=.false. convention), not yet
 // limited; k_fct_edge_limit turns it into adv_flux_hor.
+// FUSED (CORE2-class meshes, running step): fill_up_dn_grad is evaluated on the fly instead of being written to / read from
+// edge_up_dn_grad (4 values per edge cell and tracer, the largest array of the step); entries the reference leaves untouched
+// (not defined at this level) are still taken from the array, as k_flux_hor<false> would.
+template <bool FUSED>
 __global__ void __launch_bounds__(BLOCK) k_flux_hor(DM m, int tr0) {
   const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   const TV t = tracer_view(m, tr);
@@ -147,13 +157,23 @@ __global__ void __launch_bounds__(BLOCK) k_flux_hor(DM m, int tr0) {
     return;
   }
   double Tmean2 = s2, Tmean1 = s1;
+  double g1, g2, g3, g4;
+  if (FUSED) {
+    bool w1, w2;
+    updn_grad(m, t, ed, nz, g1, g2, g3, g4, w1, w2);
+    if (!w1) { g1 = DV4(t.edge_up_dn_grad, 1, nz, ed); g3 = DV4(t.edge_up_dn_grad, 3, nz, ed); }
+    if (!w2) { g2 = DV4(t.edge_up_dn_grad, 2, nz, ed); g4 = DV4(t.edge_up_dn_grad, 4, nz, ed); }
+  } else {
+    g1 = DV4(t.edge_up_dn_grad, 1, nz, ed); g2 = DV4(t.edge_up_dn_grad, 2, nz, ed);
+    g3 = DV4(t.edge_up_dn_grad, 3, nz, ed); g4 = DV4(t.edge_up_dn_grad, 4, nz, ed);
+  }
   if (hor == 1) {   // MUSCL: the gradient correction is switched off below nboundary_lay of the node (c_lo = 0 or 1)
     const double c1 = (m.nb_lay[n1] - nz >= 0) ? 1.0 : 0.0, c2 = (m.nb_lay[n2] - nz >= 0) ? 1.0 : 0.0;
-    Tmean2 = s2 - (2.0 * (s2 - s1) + ex * a * DV4(t.edge_up_dn_grad, 2, nz, ed) + ey * D_REARTH * DV4(t.edge_up_dn_grad, 4, nz, ed)) / 6.0 * c2;
-    Tmean1 = s1 + (2.0 * (s2 - s1) + ex * a * DV4(t.edge_up_dn_grad, 1, nz, ed) + ey * D_REARTH * DV4(t.edge_up_dn_grad, 3, nz, ed)) / 6.0 * c1;
+    Tmean2 = s2 - (2.0 * (s2 - s1) + ex * a * g2 + ey * D_REARTH * g4) / 6.0 * c2;
+    Tmean1 = s1 + (2.0 * (s2 - s1) + ex * a * g1 + ey * D_REARTH * g3) / 6.0 * c1;
   } else {
-    Tmean2 = s2 - (2.0 * (s2 - s1) + ex * a * DV4(t.edge_up_dn_grad, 2, nz, ed) + ey * D_REARTH * DV4(t.edge_up_dn_grad, 4, nz, ed)) / 6.0;
-    Tmean1 = s1 + (2.0 * (s2 - s1) + ex * a * DV4(t.edge_up_dn_grad, 1, nz, ed) + ey * D_REARTH * DV4(t.edge_up_dn_grad, 3, nz, ed)) / 6.0;
+    Tmean2 = s2 - (2.0 * (s2 - s1) + ex * a * g2 + ey * D_REARTH * g4) / 6.0;
+    Tmean1 = s1 + (2.0 * (s2 - s1) + ex * a * g1 + ey * D_REARTH * g3) / 6.0;
   }
   double cHO = (vflux + av) * Tmean1 + (vflux - av) * Tmean2;
   DA2(t.adv_flux_raw, nz, ed) = -0.5 * (1.0 - num_ord) * cHO - vflux * num_ord * (0.5 * (Tmean1 + Tmean2)) - lo;
@@ -826,8 +846,9 @@ void launch_tracer(const DM &m, hipStream_t s, int tr) {   // tr 0-based
   LAUNCH_COL(k_tr_ab, m.N, m, tr);
   LAUNCH_COL(k_tr_z, m.N, m, tr);
   LAUNCH_COL(k_tr_grad_elem, m.myE, m, tr);
-  LAUNCH_COL(k_updn_grad, m.myD, m, tr);
-  LAUNCH_COL(k_flux_hor, m.myD, m, tr);
+  const bool fuse_updn = m.use_tile && tr < 0;             // as the step DAG does (api.hip)
+  if (!fuse_updn) LAUNCH_COL(k_updn_grad, m.myD, m, tr);
+  if (fuse_updn) LAUNCH_COL(k_flux_hor<true>, m.myD, m, tr); else LAUNCH_COL(k_flux_hor<false>, m.myD, m, tr);
   LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); LAUNCH_WIMPL(m, tr);
   LAUNCH_COL(k_fct_node, m.myN, m, tr);
   LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr);
@@ -842,7 +863,8 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
     if (!strcmp(name, "k_tr_z")) { LAUNCH_COL(k_tr_z, m.N, m, tr); return 0; }
     if (!strcmp(name, "k_tr_grad_elem")) { LAUNCH_COL(k_tr_grad_elem, m.myE, m, tr); return 0; }
     if (!strcmp(name, "k_updn_grad")) { LAUNCH_COL(k_updn_grad, m.myD, m, tr); return 0; }
-    if (!strcmp(name, "k_flux_hor")) { LAUNCH_COL(k_flux_hor, m.myD, m, tr); return 0; }
+    if (!strcmp(name, "k_flux_hor")) { LAUNCH_COL(k_flux_hor<false>, m.myD, m, tr); return 0; }
+    if (!strcmp(name, "k_flux_hor_fused")) { LAUNCH_COL(k_flux_hor<true>, m.myD, m, tr); return 0; }     // fill_up_dn_grad on the fly
     if (!strcmp(name, "k_fct_lo_node")) { LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); LAUNCH_WIMPL(m, tr); return 0; }   // (+ implicit part with w_split)
     if (!strcmp(name, "k_fct_node")) { LAUNCH_COL(k_fct_node, m.myN, m, tr); return 0; }
     if (!strcmp(name, "k_fct_edge_limit")) { LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr); return 0; }
@@ -855,7 +877,7 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
     LAUNCH_COL(k_updn_grad, m.myD, m, tr); return 0;
   }
   if (!strcmp(name, "adv_tracers_ale")) {
-    LAUNCH_COL(k_flux_hor, m.myD, m, tr); LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); LAUNCH_WIMPL(m, tr);
+    LAUNCH_COL(k_flux_hor<false>, m.myD, m, tr); LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); LAUNCH_WIMPL(m, tr);
     LAUNCH_COL(k_fct_node, m.myN, m, tr); LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr); return 0;
   }
   if (!strcmp(name, "diff_tracers_ale")) {                                                    // incl. flux2dtracer + clamp
