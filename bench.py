@@ -55,13 +55,15 @@ KERNEL_VALUES = {
     "k_kpp_elem": (1, 1, 0), "k_gm_coef": (6, 0, 0), "k_fer_gamma": (8, 0, 0), "k_fer_uv": (2, 3, 0), "k_fer_wvel": (2, 3, 0),
     "bolus_add": (3, 6, 0), "bolus_remove": (3, 6, 0),
     "k_toy_relax_vel": (0, 3, 0), "k_toy_relax_temp": (3, 0, 0),
+    "k_flux_hor_fused": (2, 5, 2),          # fill_up_dn_grad on the fly: tr_xy_ab instead of edge_up_dn_grad (CORE2-class meshes)
 }
-PER_TRACER = ("k_tr_ab", "k_tr_z", "k_tr_grad_elem", "k_updn_grad", "k_flux_hor", "k_fct_lo_node", "k_fct_node", "k_tr_update", "k_diff_flux")
+PER_TRACER = ("k_tr_ab", "k_tr_z", "k_tr_grad_elem", "k_updn_grad", "k_flux_hor", "k_flux_hor_fused", "k_fct_lo_node", "k_fct_node", "k_tr_update", "k_diff_flux")
 REDI_EXTRA = {"k_tr_update": (24, 2, 2), "k_diff_flux": (10, 6, 1)}     # slope_tapered (3), Ki, tr_z, tr_xy cluster means on top
 
 
-def step_kernels(p):
-    """kernels of ONE running step (csrc/api.hip:enqueue_step_dag) for the option set `p` (fesom_params), with multiplicity"""
+def step_kernels(p, tile=False):
+    """kernels of ONE running step (csrc/api.hip:enqueue_step_dag) for the option set `p` (fesom_params), with multiplicity;
+    tile: the CORE2-class shapes (>= 20 000 node columns): k_updn_grad is fused into k_flux_hor"""
     ks = ["k_vel_nodes", "k_pressure_bv", "k_pgf", "k_momadv_node", "k_vel_rhs", "k_visc_elem", "k_sigma_slope"]
     if p.visc_option == 5:
         ks.append("k_visc_node")
@@ -74,7 +76,7 @@ def step_kernels(p):
     if p.Fer_GM:
         ks += ["k_fer_gamma", "k_fer_uv", "k_fer_wvel", "bolus_add", "bolus_remove"]
     ks += ["k_impl_visc", "k_edge_transport", "k_update_vel", "k_edge_transport1", "k_vert_vel_hbar", "k_dhe",
-           "k_tr_ab", "k_tr_grad_elem", "k_updn_grad", "k_diff_flux", "k_flux_hor", "k_fct_lo_node", "k_fct_node", "k_tr_update", "k_thick"]
+           "k_tr_ab", "k_tr_grad_elem"] + (["k_flux_hor_fused"] if tile else ["k_updn_grad", "k_flux_hor"]) + ["k_diff_flux", "k_fct_lo_node", "k_fct_node", "k_tr_update", "k_thick"]
     if p.Redi:
         ks.append("k_tr_z")
     if p.toy_soufflet:
@@ -96,17 +98,21 @@ def kernel_table(core, mesh, wl):
         core.call(r)
     times["k_solver"] = core.kernel_time_ms("k_solver_replay", 3 if big else 10) * 1e-3
     its = core.solver_iterations
-    for k in dict.fromkeys(step_kernels(p)):
+    tile = core.tile_shape > 0
+    for k in dict.fromkeys(step_kernels(p, tile)):
         a, b, c = REDI_EXTRA[k] if (p.Redi and k in REDI_EXTRA) else KERNEL_VALUES[k]
         name = {"k_thick": "update_thickness_ale"}.get(k, k)
         # per-tracer kernels: timed as the step launches them, T and S in one launch (grid.y = 2)
         times[k] = core.kernel_time_ms(name + (":all" if k in PER_TRACER else ""), 10 if big else 50) * 1e-3
         kbytes[k] = 8.0 * (a * N3 + b * E3 + c * D3) * (2 if k in PER_TRACER else 1)
     mult = {}
-    for k in step_kernels(p):
+    for k in step_kernels(p, tile):
         mult[k] = mult.get(k, 0) + 1
-    step_bytes = sum(kbytes[k] * n for k, n in mult.items())
-    return dict(times=times, kbytes=kbytes, mult=mult, step_bytes=step_bytes, its=its, wet=(N3, E3, D3))
+    # whole step: the counting rule and table of SURVEY 8(d) for the REFERENCE's routines (77 N3 + 67 E3 dynamics, 77 N3 + 16 E3 +
+    # 16 D3 per tracer), independent of how this build fuses them; the per-kernel figures above are per launch of THIS build
+    step_bytes = 8.0 * ((77 * N3 + 67 * E3) + 2 * (77 * N3 + 16 * E3 + 16 * D3))
+    return dict(times=times, kbytes=kbytes, mult=mult, step_bytes=step_bytes, sum_kernel_bytes=sum(kbytes[k] * n for k, n in mult.items()),
+                its=its, wet=(N3, E3, D3))
 
 
 def pmc_traffic(kernel, workload_key, redi):

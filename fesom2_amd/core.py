@@ -77,6 +77,10 @@ class OceanCore:
         return self.lib.fesom_gpu_last_solver_iterations()
 
     @property
+    def tile_shape(self):
+        return self.lib.fesom_gpu_tile_shape()
+
+    @property
     def solver_residual(self):
         return self.lib.fesom_gpu_last_solver_residual()
 

@@ -859,6 +859,7 @@ int fesom_gpu_last_solver_iterations(void) {
   hipMemcpy(&it, G.m.sv_info, sizeof(int), hipMemcpyDeviceToHost);
   return it;
 }
+int fesom_gpu_tile_shape(void) { return G.ready ? G.m.use_tile : -1; }
 double fesom_gpu_last_solver_residual(void) {
   if (!G.ready) return -1.0;
   double r = -1.0;

@@ -265,6 +265,11 @@ struct ThTile {
     if (l == 0) { rng[2 * ci] = valid ? kmin : 1; rng[2 * ci + 1] = valid ? kmax : 0; }
     if (nz <= nl1) { double *p = sh + (nz - 1) * CP + ci; p[0] = a; p[astr] = b; p[2 * astr] = c; }
   }
+  __device__ __forceinline__ void get_abc(int ci, double &a, double &b, double &c) const {      // what put_abc stored (same wave)
+    const int nz = (threadIdx.x & 63) + 1;
+    a = 0.0; b = 1.0; c = 0.0;
+    if (nz <= nl1) { const double *p = sh + (nz - 1) * CP + ci; a = p[0]; b = p[astr]; c = p[2 * astr]; }
+  }
   __device__ __forceinline__ void put_rhs(int ci, int which, double r) {
     const int nz = (threadIdx.x & 63) + 1;
     if (nz <= nl1) sh[(size_t)(3 + which) * astr + (nz - 1) * CP + ci] = r;

@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(BLOCK) k_diff_flux(DM m, int tr0) {
 // The kernel is latency-bound, not bandwidth-bound: the edge list of the node is read lane-parallel (lane q = q-th
 // incident edge), broadcast with v_readlane, and all edge values are fetched in one batch before the ordered sums.
 #define TRU_MAXD 10                     // batch of this kernel (4 loads per edge): keeps it at <= 128 VGPRs, 2 blocks per CU
-#define TRU_MAXD_TILE 8                 // tile shapes: two tracers per block, 8 edges per batch (nodes of degree > 8 take the remainder loop)
+#define TRU_MAXD_TILE 6                 // tile shapes: two tracers per block, 6 edges per batch (the typical degree; nodes of higher degree take the remainder loop)
 // Shapes (dev.h:ThTile): <REDI, 1, 8, 8> = one column per wave, one tracer per block row (pi); <REDI, 2, TL_COLS, TL_WAVES> =
 // tiles of TL_COLS columns, several columns per wave, BOTH tracers of a column in the same block (CORE2-class meshes): the
 // tracer-independent part of the column (thicknesses, interface depths, the coefficients a, b, c of the implicit operator, the
@@ -569,18 +569,29 @@ __device__ __forceinline__ bool tru_hor(const DM &m, const TruCol &k, int tr, do
   const int nzc = min(nz, m.nlm1);
   const bool dif = m.p.with_diffusion != 0;
   const double p_own = UA2(t.fct_plus, nzc, n), m_own = UA2(t.fct_minus, nzc, n);
+  // Per edge of the batch: the limited antidiffusive flux and the diffusive flux, already masked with the level range of the
+  // edge (+0.0 outside: x + 0.0 == x for the running sums below, which start at +0.0 and therefore never are -0.0) and carrying
+  // the sign of this node's end of the edge (x - f == x + (-f) bit for bit), so that the ordered sums are plain additions.
   double fa[MAXD], fd[MAXD];
 #pragma unroll
-  for (int q = 0; q < MAXD; q++) {                   // one batch of independent loads
+  for (int q = 0; q < MAXD; q++) {                       // one batch of independent loads
     int ed = rdlane(k.ed_l, q), kk = rdlane(k.fn_l, q);
-    const bool first = rdlane(k.sg_l, q) > 0;               // this node is edges(1,ed)
+    const bool first = rdlane(k.sg_l, q) > 0;               // this node is edges(1,ed)  (wave-uniform)
+    const unsigned rg = (unsigned)rdlane((int)k.rg_l, q);
+    const bool on = nz >= (int)(rg & 0xffu) && nz <= (int)((rg >> 8) & 0xffu);
+    const int flip = first ? 0 : (int)0x80000000;
     // limited antidiffusive flux ae * flux with the factors of oce_adv_tra_fct.F90:318-347 applied on the fly:
-    // flux >= 0: min(1, plus(n1), minus(n2)); flux < 0: min(1, minus(n1), plus(n2))
+    // flux >= 0: min(1, plus(n1), minus(n2)); flux < 0: min(1, minus(n1), plus(n2)).  With s = (flux >= 0) == (this node is n1)
+    // the factor of this node is s ? plus : minus, that of the far node s ? minus : plus.
     double fr = UA2(t.adv_flux_raw, nzc, ed), p_far = UA2(t.fct_plus, nzc, kk), m_far = UA2(t.fct_minus, nzc, kk);
-    double p1 = first ? p_own : p_far, m1 = first ? m_own : m_far, p2 = first ? p_far : p_own, m2 = first ? m_far : m_own;
-    double ae = dmin_(dmin_(1.0, (fr >= 0.) ? p1 : m1), (fr >= 0.) ? m2 : p2);
-    fa[q] = ae * fr;
-    fd[q] = dif ? UA2(t.diff_flux, nzc, ed) : 0.0;
+    const bool sel = (fr >= 0.) == first;
+    double ae = dmin_(dmin_(1.0, sel ? p_own : m_own), sel ? m_far : p_far);
+    double f = ae * fr;
+    f = __hiloint2double(__double2hiint(f) ^ flip, __double2loint(f));
+    fa[q] = on ? f : 0.0;
+    double d = dif ? UA2(t.diff_flux, nzc, ed) : 0.0;
+    d = 0.0 + __hiloint2double(__double2hiint(d) ^ flip, __double2loint(d));       // (0.0 + fd) resp. (0.0 - fd) of the reference
+    fd[q] = on ? d : 0.0;
   }
   double adv = (nz >= nzmin && nz <= nzmax) ? UA2L(t.adv_flux_ver, nz, n) : 0.0;
   double adv_dn = shdn(adv);
@@ -593,14 +604,7 @@ __device__ __forceinline__ bool tru_hor(const DM &m, const TruCol &k, int tr, do
   dv = dv + QDIV((adv - adv_dn) * dt);
   double dh = 0.0;
 #pragma unroll
-  for (int q = 0; q < MAXD; q++) {
-    unsigned rg = (unsigned)rdlane((int)k.rg_l, q);
-    int sg = rdlane(k.sg_l, q);
-    bool on = nz >= (int)(rg & 0xffu) && nz <= (int)((rg >> 8) & 0xffu);
-    double f = QDIV(fa[q] * dt);
-    double nh = (sg > 0) ? dh + f : dh - f;
-    dh = on ? nh : dh;
-  }
+  for (int q = 0; q < MAXD; q++) dh = dh + QDIV(fa[q] * dt);
   for (int q = MAXD; q < k.deg; q++) {                  // nodes with more incident edges than the batch (rare)
     int ed = m.ne_idx[k.q0 + q];
     unsigned rg = m.ne_rng[k.q0 + q];
@@ -614,14 +618,7 @@ __device__ __forceinline__ bool tru_hor(const DM &m, const TruCol &k, int tr, do
   del = 0.0 + dh + dv;
   if (dif) {
 #pragma unroll
-    for (int q = 0; q < MAXD; q++) {
-      unsigned rg = (unsigned)rdlane((int)k.rg_l, q);
-      int sg = rdlane(k.sg_l, q);
-      bool on = nz >= (int)(rg & 0xffu) && nz <= (int)((rg >> 8) & 0xffu);
-      double r_ = (sg > 0) ? 0.0 + fd[q] : 0.0 - fd[q];
-      double nd = del + QDIV(r_ * dt);
-      del = on ? nd : del;
-    }
+    for (int q = 0; q < MAXD; q++) del = del + QDIV(fd[q] * dt);
     for (int q = MAXD; q < k.deg; q++) {
       int ed = m.ne_idx[k.q0 + q];
       unsigned rg = m.ne_rng[k.q0 + q];
@@ -796,7 +793,7 @@ __global__ void __launch_bounds__(WAVE * WAVES, (WAVES == 8) ? 4 : 2) k_tr_updat
           if (tru_hor<true, TRU_MAXD_TILE>(m, k, trA + t, T, del)) tru_hor<false, TRU_MAXD_TILE>(m, k, trA + t, T, del);
           tru_fin<REDI>(m, k, trA + t, T, del);
           if (k.wet) DTR(m.tr_arr, nz, k.n, trA + t) = impl ? T : tru_clamp(T, trA + t);    // T*: picked up again after the sweep
-          if (impl) r = tru_rhs(m, k, trA + t, T);
+          if (impl) { tile.get_abc(ci, k.a, k.b, k.c); r = tru_rhs(m, k, trA + t, T); }      // (a, b, c back from the tile: not kept in registers across the gathers)
         }
         if (impl) tile.put_rhs(ci, t, r);
       }

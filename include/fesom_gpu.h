@@ -207,6 +207,9 @@ int  fesom_gpu_step_info(fesom_step_info *out);
  * fesom_gpu_step.  Single partition, no toy hooks. */
 int  fesom_gpu_profile_step(int n, double ms[7]);
 int  fesom_gpu_last_solver_iterations(void);
+/* kernel shape chosen at init: 0 = one column per wave (pi class), > 0 = tiles for CORE2-class meshes (>= 20 000 node columns;
+   FESOM_GPU_TILE overrides).  Informational: results do not depend on it. */
+int  fesom_gpu_tile_shape(void);
 double fesom_gpu_last_solver_residual(void);
 int  fesom_gpu_kernel_time_ms(const char *kernel_group, int nrep, double *ms_per_launch);
 const char *fesom_gpu_last_error(void);
