@@ -286,10 +286,26 @@ def main():
             import datetime
             from fesom2_amd import parallel
             pg = dist.new_group(timeout=datetime.timedelta(seconds=120))
-            pc = parallel.PartitionedCore(wl, group=pg)
+            # transport: the library's built-in RCCL send/recv groups; if its set-up or self test fails on ANY rank, every rank
+            # falls back to the host-callback transport (torch.distributed on the device buffers) and the line says so
+            tr_note = None
+            want = os.environ.get("FESOM_BENCH_TRANSPORT") or ("rccl" if dist.get_backend() == "nccl" else "callback")
+            try:
+                pc = parallel.PartitionedCore(wl, group=pg, transport=want)
+                bad_tr = 0.0
+            except Exception as e:      # noqa: BLE001
+                tr_note, bad_tr, pc = f"built-in transport unavailable ({type(e).__name__}: {e})"[:500], 1.0, None
+            fl = torch.tensor([bad_tr], dtype=torch.float64, device="cuda")
+            dist.all_reduce(fl, op=dist.ReduceOp.MAX, group=pg)
+            if fl.item() > 0:
+                if pc is not None:
+                    pc.close()
+                pc = parallel.PartitionedCore(wl, group=pg, transport="callback")
+                tr_note = tr_note or "built-in transport failed on another rank"
             for n in range(1, warmup + 1):
                 pc.step_native(n)
             pc.sync(); torch.cuda.synchronize(); dist.barrier(group=pg)
+            pc.comm_stats()
             tp = time.perf_counter()
             for n in range(warmup + 1, warmup + steps + 1):
                 pc.step_native(n)
@@ -297,7 +313,9 @@ def main():
             pel = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device="cuda")
             dist.all_reduce(pel, op=dist.ReduceOp.MAX, group=pg)
             psps = float(pel.item()) / steps
+            nex, nar, _ = pc.comm_stats()
             gl, eta_own = pc.owned("eta_n", 1)
+            gl = gl - 1                                       # myList_nod2D is 1-based
             d_eta = float(np.abs(eta_own[:, 0] - ref_state["eta_n"][gl]).max())
             myN = pc.mesh.myDim_nod2D
             trl = pc.core.get("tr_arr", 2 * (pc.mesh.myDim_nod2D + pc.mesh.eDim_nod2D) * n1).reshape(2, -1, n1)[:, :myN]
@@ -305,9 +323,18 @@ def main():
             dmax = torch.tensor([d_eta, d_tr, 0.0 if (np.isfinite(eta_own).all() and np.isfinite(trl).all()) else 1.0], dtype=torch.float64, device="cuda")
             dist.all_reduce(dmax, op=dist.ReduceOp.MAX, group=pg)
             d_eta, d_tr, bad = (float(x) for x in dmax.tolist())
+            its_part = pc.solver_iterations
+            # per-exchange device time (pack kernel .. unpack kernel, HIP events on the library's stream): 5 extra, untimed steps
+            pc.comm_timing(True)
+            for n in range(warmup + steps + 1, warmup + steps + 6):
+                pc.step_native(n)
+            pc.sync()
+            nex5, _, ms5 = pc.comm_stats()
+            pc.comm_timing(False)
             partitioned = {"ms_per_step": round(psps * 1e3, 4), "value": round(86400.0 / (steps_per_year * psps), 2), "unit": "simulated_years/day",
-                           "scaling": "strong", "steps": steps, "warmup": warmup, "solver_iterations": pc.solver_iterations,
-                           "transport": pc.transport_name, "exchanges_per_step": pc.exchanges_per_step, "us_per_exchange": pc.us_per_exchange,
+                           "scaling": "strong", "steps": steps, "warmup": warmup, "solver_iterations": its_part,
+                           "transport": pc.transport_name, "transport_note": tr_note, "exchanges_per_step": round(nex / steps, 1), "allreduces_per_step": round(nar / steps, 1),
+                           "us_per_exchange": round(ms5 * 1e3 / max(nex5, 1), 2),
                            "owned_nodes_per_gpu": int(myN), "check_vs_single_gpu": {"max_abs_d_eta": d_eta, "max_abs_d_tracer": d_tr, "tolerance": 1e-8},
                            "error": None}
             if bad or not (d_eta < 1e-8 and d_tr < 1e-8):

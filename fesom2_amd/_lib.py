@@ -109,6 +109,7 @@ EXPORTS = ("fesom_gpu_init", "fesom_gpu_upload_state", "fesom_gpu_download_state
            "fesom_gpu_last_solver_residual", "fesom_gpu_kernel_time_ms", "fesom_gpu_last_error", "fesom_gpu_step_info", "fesom_gpu_step_partitioned", "fesom_gpu_profile_step",
            "psolver_init", "psolve", "psolver_final",
            "fesom_gpu_halo_info", "fesom_gpu_halo_pack", "fesom_gpu_halo_unpack", "fesom_gpu_copy", "fesom_gpu_sync", "fesom_gpu_set_stream", "fesom_gpu_field_ptr",
+           "fesom_gpu_comm_unique_id", "fesom_gpu_comm_init", "fesom_gpu_comm_finalize", "fesom_gpu_comm_selftest", "fesom_gpu_comm_timing", "fesom_gpu_comm_stats",
            "fesom_mesh_load", "fesom_mesh_get_desc", "fesom_mesh_get_part", "fesom_mesh_get_initial_state",
            "fesom_mesh_free")
 

@@ -11,6 +11,8 @@
 #include <chrono>
 #include <map>
 #include <algorithm>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int first_step);
 int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg);
@@ -44,7 +46,54 @@ struct Ctx {
   int npes = 1, mype = 0;
   struct Halo { std::vector<int> rPE, rptr, sPE, sptr; const int *rlist = nullptr, *slist = nullptr; const int *rptr_d = nullptr, *sptr_d = nullptr; int nrecv = 0, nsend = 0; } halo[3];
   double *hsend = nullptr, *hrecv = nullptr; size_t hcap = 0;
+  // communication statistics of the partitioned step (fesom_gpu_comm_stats)
+  long long n_exch = 0, n_allred = 0;
+  bool comm_timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> comm_ev;
 } G;
+
+// ---- built-in transport: RCCL point-to-point over xGMI, issued by the library on its own stream --------------------------
+// The reference posts MPI_Isend/Irecv per neighbour and waits (src/gen_halo_exchange.F90:129-164, 317-363); here every exchange
+// is ONE RCCL group of ncclSend/ncclRecv (one pair per neighbour of the com list) on the stream that runs the pack and unpack
+// kernels, so the step needs no host callback and no host synchronisation per exchange.  librccl is loaded on first use
+// (dlopen by soname: inside a PyTorch process that is the librccl torch has already loaded; FESOM_GPU_RCCL_LIB overrides, which
+// the tests use to put a shared-memory stand-in between two ranks that share one GPU).
+struct RcclApi {
+  void *h = nullptr;
+  ncclComm_t comm = nullptr;
+  int nranks = 0, rank = -1;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+} R;
+int rccl_load() {
+  if (R.h) return 0;
+  const char *ov = getenv("FESOM_GPU_RCCL_LIB");
+  const char *cand[] = {ov, "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+  for (const char *c : cand) {
+    if (!c || !*c) continue;
+    R.h = dlopen(c, RTLD_NOW | RTLD_LOCAL);
+    if (R.h) break;
+    if (c == ov) { G.err = std::string("comm: cannot load FESOM_GPU_RCCL_LIB=") + ov + ": " + dlerror(); return 1; }
+  }
+  if (!R.h) { G.err = std::string("comm: cannot load librccl: ") + dlerror(); return 1; }
+  bool ok = true;
+#define SYM(f, n) do { *(void **)(&R.f) = dlsym(R.h, n); ok = ok && R.f; } while (0)
+  SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+  SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
+  SYM(AllReduce, "ncclAllReduce"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+  if (!ok) { G.err = "comm: librccl lacks a required symbol"; dlclose(R.h); R.h = nullptr; return 1; }
+  return 0;
+}
+#define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { G.err = std::string(#x) + ": " + R.GetErrorString(r_); fprintf(stderr, "fesom_gpu: %s\n", G.err.c_str()); return 1; } } while (0)
+
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { G.err = std::string(#x) + ": " + hipGetErrorString(e_); fprintf(stderr, "fesom_gpu: %s\n", G.err.c_str()); return 1; } } while (0)
 
@@ -611,26 +660,54 @@ static int call_named(const char *name, int arg);
 // ---- partitioned step driven by the library (phase order = fesom2_amd/parallel.py:run_step, which the tests probe phase by
 // phase; both call the same kernels in the same order, so their results are bit-identical for the same transport)
 namespace {
+// one exchange through the built-in transport: a group of ncclSend / ncclRecv, one pair per neighbour, on the library's stream
+int rccl_exchange(int kind, double *sd, double *rd, int W) {
+  const Ctx::Halo &h = G.halo[kind];
+  NCCLCHK(R.GroupStart());
+  for (size_t p = 0; p < h.sPE.size(); p++) {
+    const size_t first = (size_t)(h.sptr[p] - 1), cnt = (size_t)(h.sptr[p + 1] - h.sptr[p]);
+    if (cnt) NCCLCHK(R.Send(sd + first * W, cnt * W, ncclDouble, h.sPE[p], R.comm, G.stream));
+  }
+  for (size_t p = 0; p < h.rPE.size(); p++) {
+    const size_t first = (size_t)(h.rptr[p] - 1), cnt = (size_t)(h.rptr[p + 1] - h.rptr[p]);
+    if (cnt) NCCLCHK(R.Recv(rd + first * W, cnt * W, ncclDouble, h.rPE[p], R.comm, G.stream));
+  }
+  NCCLCHK(R.GroupEnd());
+  return 0;
+}
 struct PStep {
-  const fesom_transport *t;
+  const fesom_transport *t;                       // nullptr: the built-in RCCL transport (fesom_gpu_comm_init)
   int rc = 0;
   void c(const char *name, int arg = 0) { if (!rc && call_named(name, arg)) { rc = 1; if (G.err.empty()) G.err = std::string("step_partitioned: unknown phase ") + name; } }
   void X(int kind, std::initializer_list<const char *> names) {
     if (rc) return;
     std::vector<const char *> nm(names);        // (no early-out for a rank without neighbours: the transport may be a collective)
     void *sd = nullptr, *rd = nullptr; int W = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (G.comm_timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, G.stream); }
     if (fesom_gpu_halo_pack(kind, (int)nm.size(), nm.data(), &sd, &rd, &W)) { rc = 1; return; }
-    if (t->exchange(t->ctx, kind, sd, rd, W)) { rc = 1; G.err = "step_partitioned: transport exchange failed"; return; }
+    if (t) { if (t->exchange(t->ctx, kind, sd, rd, W)) { rc = 1; G.err = "step_partitioned: transport exchange failed"; return; } }
+    else if (rccl_exchange(kind, (double *)sd, (double *)rd, W)) { rc = 1; return; }
     if (fesom_gpu_halo_unpack(kind, (int)nm.size(), nm.data())) rc = 1;
+    if (e0) { hipEventRecord(e1, G.stream); G.comm_ev.push_back({e0, e1}); }
+    G.n_exch++;
   }
-  void AR(int n) { if (!rc && t->allreduce_sum(t->ctx, G.m.sv_red, n)) { rc = 1; G.err = "step_partitioned: transport allreduce failed"; } }
+  void AR(int n) {
+    if (rc) return;
+    if (t) { if (t->allreduce_sum(t->ctx, G.m.sv_red, n)) { rc = 1; G.err = "step_partitioned: transport allreduce failed"; } }
+    else if (R.AllReduce(G.m.sv_red, G.m.sv_red, (size_t)n, ncclDouble, ncclSum, R.comm, G.stream) != ncclSuccess) { rc = 1; G.err = "step_partitioned: ncclAllReduce failed"; }
+    G.n_allred++;
+  }
 };
 }  // namespace
 
 int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
   NEED_READY();
   if (G.npes < 2) return fesom_gpu_step(n);
-  if (!t || !t->exchange || !t->allreduce_sum) { G.err = "step_partitioned: transport callbacks missing"; return 1; }
+  if (t && (!t->exchange || !t->allreduce_sum)) { G.err = "step_partitioned: transport callbacks missing"; return 1; }
+  if (!t && (!R.comm || R.nranks != G.npes || R.rank != G.mype)) {
+    G.err = "step_partitioned: no transport given and the built-in RCCL transport is not initialised for this partition (fesom_gpu_comm_init)"; return 1;
+  }
   const fesom_params &p = G.m.p;
   PStep S{t};
   (void)n;
@@ -1104,6 +1181,75 @@ int fesom_gpu_set_stream(void *hip_stream) {
   HIPCHK(hipStreamSynchronize(G.stream));
   if (!G.ext_stream) hipStreamDestroy(G.stream);
   G.stream = (hipStream_t)hip_stream; G.ext_stream = true;
+  return 0;
+}
+
+// ---- built-in RCCL transport (see RcclApi above) -------------------------------------------------------------------------
+// Rank 0 obtains the 128-byte RCCL unique id and hands it to the other ranks by whatever the host has (MPI_Bcast in a Fortran
+// host, torch.distributed / a file in Python); then every rank calls fesom_gpu_comm_init.  Independent of fesom_gpu_init.
+int fesom_gpu_comm_unique_id(void *id128) {
+  if (rccl_load()) return 1;
+  ncclUniqueId id;
+  NCCLCHK(R.GetUniqueId(&id));
+  memcpy(id128, &id, sizeof(id));
+  return 0;
+}
+int fesom_gpu_comm_init(const void *id128, int nranks, int rank) {
+  if (rccl_load()) return 1;
+  if (R.comm) { R.CommDestroy(R.comm); R.comm = nullptr; }
+  if (nranks < 1 || rank < 0 || rank >= nranks) { G.err = "comm_init: bad rank / nranks"; return 1; }
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  NCCLCHK(R.CommInitRank(&R.comm, nranks, id, rank));
+  R.nranks = nranks; R.rank = rank;
+  return 0;
+}
+int fesom_gpu_comm_finalize(void) {
+  if (R.comm) { if (G.ready && G.stream) hipStreamSynchronize(G.stream); R.CommDestroy(R.comm); R.comm = nullptr; }
+  R.nranks = 0; R.rank = -1;
+  return 0;
+}
+// Self test of the transport on the library's stream: a ring shift (every rank sends `n` doubles to rank+1 and receives from
+// rank-1 in one group) and an in-place sum; returns 0 if both arrive as expected.  Works with one rank too (send to self).
+int fesom_gpu_comm_selftest(int n) {
+  NEED_READY();
+  if (!R.comm) { G.err = "comm_selftest: fesom_gpu_comm_init has not been called"; return 1; }
+  if (n < 1) n = 1;
+  double *buf = nullptr;
+  HIPCHK(hipMalloc((void **)&buf, sizeof(double) * (2 * (size_t)n + 2)));
+  std::vector<double> h(2 * (size_t)n + 2, 0.0);
+  for (int i = 0; i < n; i++) h[i] = 1000.0 * R.rank + i;
+  h[2 * (size_t)n] = R.rank + 1.0; h[2 * (size_t)n + 1] = 0.5;
+  HIPCHK(hipMemcpyAsync(buf, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, G.stream));
+  const int to = (R.rank + 1) % R.nranks, from = (R.rank + R.nranks - 1) % R.nranks;
+  NCCLCHK(R.GroupStart());
+  NCCLCHK(R.Send(buf, (size_t)n, ncclDouble, to, R.comm, G.stream));
+  NCCLCHK(R.Recv(buf + n, (size_t)n, ncclDouble, from, R.comm, G.stream));
+  NCCLCHK(R.GroupEnd());
+  NCCLCHK(R.AllReduce(buf + 2 * (size_t)n, buf + 2 * (size_t)n, 2, ncclDouble, ncclSum, R.comm, G.stream));
+  HIPCHK(hipMemcpyAsync(h.data(), buf, sizeof(double) * h.size(), hipMemcpyDeviceToHost, G.stream));
+  HIPCHK(hipStreamSynchronize(G.stream));
+  hipFree(buf);
+  for (int i = 0; i < n; i++) if (h[(size_t)n + i] != 1000.0 * from + i) { G.err = "comm_selftest: ring shift delivered wrong data"; return 2; }
+  if (h[2 * (size_t)n] != 0.5 * R.nranks * (R.nranks + 1) || h[2 * (size_t)n + 1] != 0.5 * R.nranks) { G.err = "comm_selftest: all-reduce delivered a wrong sum"; return 3; }
+  return 0;
+}
+// exchanges / all-reduces issued by fesom_gpu_step_partitioned since the last call, and -- if timing was switched on with
+// fesom_gpu_comm_timing(1) -- the device time (ms, HIP events on the library's stream) from the first pack kernel to the last
+// unpack kernel of those exchanges, summed.  Resets the counters.
+int fesom_gpu_comm_timing(int on) { G.comm_timing = on != 0; return 0; }
+int fesom_gpu_comm_stats(long long *exchanges, long long *allreduces, double *exchange_ms) {
+  NEED_READY();
+  double ms = 0.0;
+  if (!G.comm_ev.empty()) {
+    HIPCHK(hipStreamSynchronize(G.stream));
+    for (auto &pr : G.comm_ev) { float t = 0; if (hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) ms += t; hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    G.comm_ev.clear();
+  }
+  if (exchanges) *exchanges = G.n_exch;
+  if (allreduces) *allreduces = G.n_allred;
+  if (exchange_ms) *exchange_ms = ms;
+  G.n_exch = G.n_allred = 0;
   return 0;
 }
 }

@@ -102,6 +102,24 @@ module fesom_gpu_shim
        integer(c_int), value :: n
        type(fesom_transport), intent(in) :: t
      end function
+     integer(c_int) function c_fesom_gpu_step_partitioned_builtin(n, t) bind(C, name='fesom_gpu_step_partitioned')
+       import
+       integer(c_int), value :: n
+       type(c_ptr), value :: t                   ! c_null_ptr: the library's built-in RCCL transport
+     end function
+     integer(c_int) function c_fesom_gpu_comm_unique_id(id128) bind(C, name='fesom_gpu_comm_unique_id')
+       import
+       character(kind=c_char), intent(out) :: id128(128)
+     end function
+     integer(c_int) function c_fesom_gpu_comm_init(id128, nranks, rank) bind(C, name='fesom_gpu_comm_init')
+       import
+       character(kind=c_char), intent(in) :: id128(128)
+       integer(c_int), value :: nranks, rank
+     end function
+     integer(c_int) function c_fesom_gpu_comm_selftest(n) bind(C, name='fesom_gpu_comm_selftest')
+       import
+       integer(c_int), value :: n
+     end function
      integer(c_int) function c_fesom_gpu_copy(dst, src, bytes, dir) bind(C, name='fesom_gpu_copy')
        import
        type(c_ptr), value :: dst, src
@@ -130,6 +148,7 @@ module fesom_gpu_shim
   real(kind=WP), allocatable, target, save :: hsend(:), hrecv(:)      ! host staging of the packed halo messages
   real(kind=WP), target, save :: hred(8)
   logical, save :: is_setup = .false.
+  logical, save :: builtin_transport = .false.   ! FESOM_GPU_TRANSPORT=rccl: halo exchange + solver sums by the library itself (RCCL over xGMI)
 
 contains
 
@@ -293,6 +312,7 @@ contains
     transport%allreduce_sum = c_funloc(mpi_allreduce_sum)
     call check(c_fesom_gpu_init(d, pp, p), 'fesom_gpu_init')
     call status_check
+    if (npes > 1) call setup_builtin_transport
     call state_desc(mesh, st)
     call check(c_fesom_gpu_upload_state(st), 'fesom_gpu_upload_state')
     call status_check
@@ -324,11 +344,33 @@ contains
        rtime_oce_dynssh = rtime_oce_dynssh + pms(3)*1.0e-3_WP; rtime_oce_solvessh = rtime_oce_solvessh + pms(4)*1.0e-3_WP
        rtime_oce_GMRedi = rtime_oce_GMRedi + pms(5)*1.0e-3_WP; rtime_oce_solvetra = rtime_oce_solvetra + pms(6)*1.0e-3_WP
        rtime_oce = rtime_oce + pms(7)*1.0e-3_WP
+    else if (npes > 1 .and. builtin_transport) then   ! phases, halo exchange (RCCL groups) and solver sums all inside the library
+       call check(c_fesom_gpu_step_partitioned_builtin(int(n, c_int), c_null_ptr), 'fesom_gpu_step_partitioned')
     else if (npes > 1) then     ! the library runs the phases and the partitioned SSH solve, this layer moves the halo bytes with MPI
        call check(c_fesom_gpu_step_partitioned(int(n, c_int), transport), 'fesom_gpu_step_partitioned')
     else
        call check(c_fesom_gpu_step(int(n, c_int)), 'fesom_gpu_step')
     end if
+    call status_check
+  end subroutine
+
+  ! Built-in transport of the library (include/fesom_gpu.h): one rank per GPU, RCCL send/recv groups on the library's stream.
+  ! Selected with FESOM_GPU_TRANSPORT=rccl; rank 0 draws RCCL's unique id, MPI_BCAST carries it over MPI_COMM_FESOM, every rank
+  ! joins with its FESOM rank (mype), then a ring shift + global sum through the new communicator checks it end to end.
+  subroutine setup_builtin_transport
+    character(len=32) :: v
+    character(kind=c_char) :: id(128)
+    integer :: ierr, stat
+    call get_environment_variable('FESOM_GPU_TRANSPORT', v, status=stat)
+    builtin_transport = (stat == 0 .and. trim(v) == 'rccl')
+    if (.not. builtin_transport) return
+    id = c_null_char
+    if (mype == 0) call check(c_fesom_gpu_comm_unique_id(id), 'fesom_gpu_comm_unique_id')
+    call status_check
+    call MPI_BCAST(id, 128, MPI_CHARACTER, 0, MPI_COMM_FESOM, ierr)
+    call check(c_fesom_gpu_comm_init(id, int(npes, c_int), int(mype, c_int)), 'fesom_gpu_comm_init')
+    call status_check
+    call check(c_fesom_gpu_comm_selftest(1000_c_int), 'fesom_gpu_comm_selftest')
     call status_check
   end subroutine
 

@@ -191,24 +191,81 @@ class HaloExchanger:
 
 
 class PartitionedCore:
-    """One rank of a partitioned run.  `torch.distributed` must be initialised (rank = partition index)."""
+    """One rank of a partitioned run.  `torch.distributed` must be initialised (rank = partition index).
 
-    def __init__(self, meshdir, params, group=None, **mesh_kw):
+    PartitionedCore(meshdir, params, **mesh_kw)  or  PartitionedCore(workload) -- a fesom2_amd.workloads.Workload, whose
+    initial state (and forcing) is then uploaded as well.
+
+    transport: "rccl"     the library's built-in transport (ncclSend/ncclRecv groups + ncclAllReduce issued by libfesom_gpu.so
+                          on its own stream, include/fesom_gpu.h); default when the process group's backend is nccl;
+               "callback" the host moves the bytes (torch.distributed on the device buffers with nccl, host-staged with gloo);
+                          default with gloo."""
+
+    def __init__(self, meshdir, params=None, group=None, transport=None, **mesh_kw):
         self.group = group
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        self.mesh = Mesh.load(meshdir, npes=self.world, mype=self.rank, **mesh_kw)
+        wl = None
+        if not isinstance(meshdir, str):
+            wl = meshdir
+            self.mesh = wl.load_mesh(npes=self.world, mype=self.rank)
+            params = wl.params()
+        else:
+            self.mesh = Mesh.load(meshdir, npes=self.world, mype=self.rank, **mesh_kw)
         self.par = params
         self.core = OceanCore(self.mesh, params)
         self.halo = HaloExchanger(self.core, group)
         self.first = True
         self.solver_iterations = 0
         self.red_dev = None
+        lib = self.core.lib
+        lib.fesom_gpu_comm_unique_id.argtypes = [C.c_void_p]
+        lib.fesom_gpu_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.fesom_gpu_comm_selftest.argtypes = [C.c_int]
+        lib.fesom_gpu_comm_timing.argtypes = [C.c_int]
+        lib.fesom_gpu_comm_stats.argtypes = [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
+        self.transport = transport or ("rccl" if dist.get_backend() == "nccl" else "callback")
+        if self.transport == "rccl":
+            self._init_builtin_transport()
         if self.halo.device:
-            lib = self.core.lib
             lib.fesom_gpu_field_ptr.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_longlong)]
             ptr, cnt = C.c_void_p(), C.c_longlong()
             assert lib.fesom_gpu_field_ptr(b"sv_red", C.byref(ptr), C.byref(cnt)) == 0
             self.red_dev = self.halo.dev_tensor(ptr.value, int(cnt.value))
+        self._steps = 0
+        if wl is not None:
+            wl.start(self.core, self.mesh)
+
+    def _init_builtin_transport(self):
+        """RCCL communicator of the library: rank 0 draws the unique id, torch.distributed carries the 128 bytes to the others
+        (a Fortran host uses MPI_Bcast), every rank joins with its partition rank; then a self test through the transport."""
+        lib = self.core.lib
+        idbuf = (C.c_char * 128)()
+        if self.rank == 0:
+            self.core._chk(lib.fesom_gpu_comm_unique_id(idbuf), "comm_unique_id")
+        box = [bytes(idbuf.raw)]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0, group=self.group)
+        idbuf.raw = box[0]
+        self.core._chk(lib.fesom_gpu_comm_init(idbuf, self.world, self.rank), "comm_init")
+        self.core._chk(lib.fesom_gpu_comm_selftest(1000), "comm_selftest")
+
+    @property
+    def transport_name(self):
+        if self.transport == "rccl":
+            return "built-in: RCCL ncclSend/ncclRecv groups + ncclAllReduce issued by the library on its stream"
+        return "host callback: torch.distributed " + ("nccl (RCCL) on the device buffers" if self.halo.device else "gloo, host-staged")
+
+    def comm_timing(self, on=True):
+        self.core.lib.fesom_gpu_comm_timing(1 if on else 0)
+
+    def comm_stats(self):
+        """(exchanges, all-reduces, device ms spent in exchanges [if comm_timing was on]) since the last call"""
+        a, b, ms = C.c_longlong(), C.c_longlong(), C.c_double()
+        self.core._chk(self.core.lib.fesom_gpu_comm_stats(C.byref(a), C.byref(b), C.byref(ms)), "comm_stats")
+        return a.value, b.value, ms.value
+
+    def sync(self):
+        self.core.lib.fesom_gpu_sync()
 
     # -- global sums of the partial dot products (in place in the device buffer sv_red)
     def _allreduce(self, n):
@@ -273,7 +330,8 @@ class PartitionedCore:
             self._cb = (_lib.TRANSPORT_EXCHANGE(exchange), _lib.TRANSPORT_ALLREDUCE(allreduce))     # keep the thunks alive
             self._transport = _lib.Transport(None, self._cb[0], self._cb[1])
         self.core.call("first_step", 1 if self.first else 0)
-        self.core._chk(self.core.lib.fesom_gpu_step_partitioned(int(n), C.byref(self._transport)), "step_partitioned")
+        tr = None if (self.transport == "rccl" and self.world > 1) else C.byref(self._transport)
+        self.core._chk(self.core.lib.fesom_gpu_step_partitioned(int(n), tr), "step_partitioned")
         self.first = False
         self.solver_iterations = self.core.lib.fesom_gpu_last_solver_iterations()
 
@@ -285,4 +343,6 @@ class PartitionedCore:
         return self.mesh.myList_nod2D[:n].copy(), a[:n].copy()
 
     def close(self):
+        if self.transport == "rccl":
+            self.core.lib.fesom_gpu_comm_finalize()
         self.core.close()

@@ -183,7 +183,22 @@ typedef struct fesom_transport {
   int (*exchange)(void *ctx, int kind, void *send_dev, void *recv_dev, int values_per_item);
   int (*allreduce_sum)(void *ctx, void *buf_dev, int n);
 } fesom_transport;
-int  fesom_gpu_step_partitioned(int n, const fesom_transport *t);
+int  fesom_gpu_step_partitioned(int n, const fesom_transport *t);   /* t == NULL: the built-in RCCL transport below */
+
+/* ---- built-in transport: RCCL send/recv over xGMI issued by the library itself (replaces exchange_nod / exchange_elem,
+ * src/gen_halo_exchange.F90:58-1035, and the MPI_Allreduce of pARMS' dot products, lib/parms/src/parms_comm.c:205-356).
+ * Every halo exchange is ONE group of ncclSend/ncclRecv (a pair per neighbour of the com list) on the stream that runs the
+ * pack / unpack kernels; the solver's global sums are ncclAllReduce on the same stream: no host callback, no host
+ * synchronisation per exchange.  Set-up: rank 0 calls fesom_gpu_comm_unique_id (128 bytes), the host broadcasts them
+ * (MPI_Bcast on the Fortran side, fesom_gpu_shim.F90), every rank calls fesom_gpu_comm_init(id, npes, mype) with the
+ * partition's rank numbering; then fesom_gpu_step_partitioned(n, NULL).  librccl is loaded on first use (the copy already in
+ * the process, e.g. PyTorch's; FESOM_GPU_RCCL_LIB=<path> overrides). */
+int  fesom_gpu_comm_unique_id(void *id128);
+int  fesom_gpu_comm_init(const void *id128, int nranks, int rank);
+int  fesom_gpu_comm_finalize(void);
+int  fesom_gpu_comm_selftest(int n);            /* ring shift of n doubles + a global sum through the transport; 0 = ok */
+int  fesom_gpu_comm_timing(int on);             /* HIP-event timing of every exchange (pack .. unpack) from now on */
+int  fesom_gpu_comm_stats(long long *exchanges, long long *allreduces, double *exchange_ms);   /* since the last call */
 
 /* Device-side step monitor = write_step_info + check_blowup of the reference (src/write_step_info.F90:14-222, :225-447),
  * evaluated on the device over this rank's OWNED nodes, no per-step host synchronisation needed: call it at the logging

@@ -80,7 +80,8 @@ def main():
         first = False
     g.close()
     # ---- this rank's partition
-    pc = parallel.PartitionedCore(PI, par, dt=900.0)
+    TRANSPORT = os.environ.get("PART_TRANSPORT") or None      # "rccl": the library's built-in transport (real RCCL, or the test double)
+    pc = parallel.PartitionedCore(PI, par, dt=900.0, transport=TRANSPORT)
     lm = pc.mesh
     ln = lm.myList_nod2D - 1
     st = lm.initial_state(2); st.tr_arr[0], st.tr_arr[1] = T[ln], S[ln]; st.tr_arr_old[...] = st.tr_arr
@@ -120,7 +121,7 @@ def main():
                                                            ("UV", 2 * (lm.nl - 1) * (myE + lm.eDim_elem2D)))}
     its_py = pc.solver_iterations
     pc.close()
-    pc = parallel.PartitionedCore(PI, par, dt=900.0)
+    pc = parallel.PartitionedCore(PI, par, dt=900.0, transport=TRANSPORT)
     pc.core.upload_state(st)
     if "kpp" in opts:
         pc.core.set_forcing(**analytic_forcing(lm))
@@ -128,6 +129,8 @@ def main():
         pc.step_native(n)
     report["native_mismatch"] = [f for f, a in fin.items() if not np.array_equal(a.view(np.int64), pc.core.get(f, a.size).view(np.int64))]
     report["native_iters"] = [int(its_py), int(pc.solver_iterations)]
+    report["transport"] = pc.transport_name
+    report["comm_stats"] = list(pc.comm_stats())
     pc.close()
     sys.stdout.write("PARTREPORT " + json.dumps(report) + chr(10)); sys.stdout.flush()
     dist.destroy_process_group()

@@ -125,3 +125,28 @@ def test_fortran_phase_timers_from_the_gpu(built):
     if os.path.isdir(out):
         with open(os.path.join(out, "dropin_phase_timers.txt"), "w") as fh:
             fh.write("pi_default, 10 steps, seconds summed over the steps (reference's rtime_oce* from fesom_gpu_profile_step)\n" + ph[0] + "\n")
+
+
+def test_fortran_dropin_builtin_transport_equals_mpi_transport(built):
+    """2 MPI ranks, FESOM_GPU_TRANSPORT=rccl: the Fortran layer broadcasts the unique id with MPI_BCAST and the library moves halos
+    and solver sums itself (ncclSend/ncclRecv groups + ncclAllReduce on its stream, no callback per exchange).  Two ranks sharing
+    one GPU cannot use RCCL proper, so the shared-memory stand-in of tests/helpers/fake_rccl.cpp is loaded in its place; the
+    state after 10 steps must equal, bit for bit, the run whose halo bytes travel through MPI_Isend/Irecv callbacks."""
+    from oracle.ref import run_ref
+    from refdump import read_dump
+    fake = os.path.join(REPO, "tests", "helpers", "libfake_rccl.so")
+    assert os.path.exists(fake) and os.path.exists(os.path.join(REPO, "oracle", "_ref", "fesom_gpu_dropin.x"))
+    os.environ["FESOM_GPU_DEVICE"] = "0"
+    states = []
+    for builtin in (False, True):
+        if builtin:
+            os.environ.update(FESOM_GPU_TRANSPORT="rccl", FESOM_GPU_RCCL_LIB=fake)
+        try:
+            rd, rc, lines = run_ref.run("pi_default", 2, NSTEPS, mode="gpu", dump=(NSTEPS,), exe_name="fesom_gpu_dropin.x")
+        finally:
+            os.environ.pop("FESOM_GPU_TRANSPORT", None); os.environ.pop("FESOM_GPU_RCCL_LIB", None)
+        assert rc == 0, open(os.path.join(rd, "stdout.log")).read()[-3000:]
+        states.append([{k: np.array(v) for k, v in read_dump(os.path.join(rd, "dumps", f"state{NSTEPS:04d}.r{r:05d}.bin")).items()} for r in range(2)])
+    for r in range(2):
+        for f in ("eta_n", "tr_arr", "UV", "hnode", "Wvel"):
+            assert np.array_equal(states[0][r][f], states[1][r][f]), (r, f)

@@ -12,13 +12,22 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world,backend,opts", [(2, "gloo", ""), (4, "gloo", ""), (1, "nccl", ""), (2, "gloo", "gm,redi"), (2, "gloo", "kpp,gm,redi"), (2, "gloo", "visc6"), (2, "gloo", "visc7")])
+@pytest.mark.parametrize("world,backend,opts", [(2, "gloo", ""), (4, "gloo", ""), (1, "nccl", ""), (2, "gloo", "gm,redi"), (2, "gloo", "kpp,gm,redi"), (2, "gloo", "visc6"), (2, "gloo", "visc7"),
+                                                (2, "gloo", "builtin_transport"), (2, "gloo", "builtin_transport,kpp,gm,redi")])
 def test_partitioned_step_matches_single_partition(built, world, backend, opts):
     """(1, "nccl"): one rank over RCCL = the device-resident transport path (library kernels on torch's stream, all-reduce
     in place on the device buffer) that a multi-GPU node uses; it has no neighbours to exchange with on a one-GPU box."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", FESOM_GPU_DEVICE="0", PART_NSTEPS="4", PART_BACKEND=backend, PART_OPTS=opts)
+    if "builtin_transport" in opts:
+        # the library's own transport (ncclSend/ncclRecv groups + ncclAllReduce issued from libfesom_gpu.so) between two real
+        # processes: RCCL refuses two ranks on one GPU, so a shared-memory stand-in with the same entry points is loaded in its
+        # place (tests/helpers/fake_rccl.cpp; it rejects mismatched byte counts).  The library-driven steps through it must equal
+        # the Python-driven steps over gloo bit for bit.
+        fake = os.path.join(REPO, "tests", "helpers", "libfake_rccl.so")
+        assert os.path.exists(fake), "tests/helpers/libfake_rccl.so is not built (python __graft_entry__.py)"
+        env.update(FESOM_GPU_RCCL_LIB=fake, PART_TRANSPORT="rccl")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-                        "--master-port", str(29620 + world + (10 if backend == "nccl" else 0) + (20 if opts else 0) + (7 if 'kpp' in opts else 0) + (31 if 'visc6' in opts else 0) + (37 if 'visc7' in opts else 0)), os.path.join(REPO, "tests", "helpers", "partitioned_worker.py")],
+                        "--master-port", str(29620 + world + (10 if backend == "nccl" else 0) + (20 if opts else 0) + (7 if 'kpp' in opts else 0) + (31 if 'visc6' in opts else 0) + (37 if 'visc7' in opts else 0) + (41 if 'builtin' in opts else 0)), os.path.join(REPO, "tests", "helpers", "partitioned_worker.py")],
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     reps = [json.loads(x) for x in re.findall(r"PARTREPORT (\{.*\})", r.stdout)]
@@ -34,3 +43,7 @@ def test_partitioned_step_matches_single_partition(built, world, backend, opts):
         if world > 1:        # library-driven step == Python-driven step, bit for bit (one rank: the library takes the single-GPU solver)
             assert rep["native_mismatch"] == [], rep["native_mismatch"]
             assert rep["native_iters"][0] == rep["native_iters"][1], rep["native_iters"]
+        if "builtin_transport" in opts:
+            assert rep["transport"].startswith("built-in") and rep["comm_stats"][0] > 4 * 11, rep
+        if backend == "nccl":          # one rank: real librccl loaded by the library, communicator + self test through it
+            assert rep["transport"].startswith("built-in"), rep
