@@ -6,16 +6,19 @@ SRC    = fesom2_amd/csrc
 OBJ    = fesom2_amd/build
 HFLAGS = --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-result
 HIPSRC = kernels_dyn kernels_tra kernels_toy kernels_gm kernels_kpp kernels_mon solver api
-OBJS   = $(addprefix $(OBJ)/,$(addsuffix .o,$(HIPSRC))) $(OBJ)/mesh_host.o
+OBJS   = $(addprefix $(OBJ)/,$(addsuffix .o,$(HIPSRC))) $(OBJ)/mesh_host.o $(OBJ)/precond_host.o
 
 fesom2_amd/libfesom_gpu.so: $(OBJS)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS) -lpthread
 
 $(OBJ)/%.o: $(SRC)/%.hip $(SRC)/dev.h include/fesom_gpu.h | $(OBJ)
 	$(HIPCC) $(HFLAGS) -x hip -c $< -o $@
 
 $(OBJ)/mesh_host.o: $(SRC)/mesh_host.cpp include/fesom_gpu.h | $(OBJ)
 	$(CXX) -O2 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -c $< -o $@
+
+$(OBJ)/precond_host.o: $(SRC)/precond_host.cpp | $(OBJ)
+	$(CXX) -O3 -pthread -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -c $< -o $@
 
 $(OBJ):
 	mkdir -p $(OBJ)

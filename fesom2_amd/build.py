@@ -10,7 +10,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: no FMA contraction on host or device, results are compared bitwise with the CPU oracle.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result"]
-SOURCES = ["kernels_dyn.hip", "kernels_tra.hip", "kernels_toy.hip", "kernels_gm.hip", "kernels_kpp.hip", "kernels_mon.hip", "solver.hip", "api.hip", "mesh_host.cpp"]
+SOURCES = ["kernels_dyn.hip", "kernels_tra.hip", "kernels_toy.hip", "kernels_gm.hip", "kernels_kpp.hip", "kernels_mon.hip", "solver.hip", "api.hip", "mesh_host.cpp", "precond_host.cpp"]
 
 
 def _stale(target, deps):
@@ -35,7 +35,7 @@ def build(force=False, verbose=True):
             else:
                 # host-only geometry code: g++ keeps sin/cos/asin/atan2 as separate glibc calls, which is what the
                 # reference's Fortran does; clang's sincos folding changes 7 of 6280 coordinates in the last bit
-                cmd = [os.environ.get("CXX", "g++"), "-O2", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-c", src, "-o", obj]
+                cmd = [os.environ.get("CXX", "g++"), "-O3" if s == "precond_host.cpp" else "-O2", "-pthread", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -50,7 +50,7 @@ def build(force=False, verbose=True):
     if failed:
         raise RuntimeError("hipcc failed")
     if force or _stale(OUT, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-lpthread"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

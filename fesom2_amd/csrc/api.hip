@@ -17,6 +17,9 @@
 int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int first_step);
 int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg);
 void solver_prepare();
+extern "C" int fesom_xinv_build(int n, const int *rp, const int *ci, const double *vals, int ld, float *out, int *bandwidth);
+extern "C" void fesom_xinv_sparsify(int n, int ld, const float *M, double tau, int *rowptr, unsigned short *cols, float *vals);
+#define XINV_DROP 1.0e-4      /* entries of the inverse below this fraction of their row's largest are dropped */
 void tile_prepare_tra();
 void tile_prepare_dyn();
 
@@ -113,6 +116,37 @@ const double *dev_upload_d(const double *h, size_t n) {
   double *p = dev_alloc<double>(n);
   if (p && n) hipMemcpy(p, h, n * sizeof(double), hipMemcpyHostToDevice);
   return p;
+}
+// Explicit-inverse preconditioner (csrc/precond_host.cpp): built on the host from the operator the run starts with, uploaded once.
+// The last matrix is kept per process and reused when the same operator comes again (tests and benches re-initialise often).
+struct XinvCache { std::vector<int> rp, ci; std::vector<double> vals; std::vector<int> mp; std::vector<unsigned short> mc; std::vector<float> mv; } XC;
+int xinv_device(int n, const int *rp, const int *ci, const double *vals, DM &m, std::vector<void *> &owner) {
+  const int nza = rp[n];
+  const bool hit = (int)XC.rp.size() == n + 1 && (int)XC.vals.size() == nza && !XC.mp.empty() && !memcmp(XC.rp.data(), rp, sizeof(int) * (n + 1)) &&
+                   !memcmp(XC.ci.data(), ci, sizeof(int) * nza) && !memcmp(XC.vals.data(), vals, sizeof(double) * nza);
+  if (!hit) {
+    const int ld = (n + 255) / 256 * 256;
+    std::vector<float> M((size_t)n * ld, 0.0f);
+    XC.mp.clear();
+    if (fesom_xinv_build(n, rp, ci, vals, ld, M.data(), nullptr)) return 1;
+    XC.mp.assign(n + 1, 0);
+    fesom_xinv_sparsify(n, ld, M.data(), XINV_DROP, XC.mp.data(), nullptr, nullptr);
+    XC.mc.assign(XC.mp[n], 0); XC.mv.assign(XC.mp[n], 0.0f);
+    fesom_xinv_sparsify(n, ld, M.data(), XINV_DROP, XC.mp.data(), XC.mc.data(), XC.mv.data());
+    XC.rp.assign(rp, rp + n + 1); XC.ci.assign(ci, ci + nza); XC.vals.assign(vals, vals + nza);
+  }
+  void *dp = nullptr, *dc = nullptr, *dv = nullptr;
+  if (hipMalloc(&dp, XC.mp.size() * sizeof(int)) != hipSuccess) return 1;
+  owner.push_back(dp);
+  if (hipMalloc(&dc, XC.mc.size() * sizeof(unsigned short) + 8) != hipSuccess) return 1;
+  owner.push_back(dc);
+  if (hipMalloc(&dv, XC.mv.size() * sizeof(float) + 8) != hipSuccess) return 1;
+  owner.push_back(dv);
+  if (hipMemcpy(dp, XC.mp.data(), XC.mp.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(dc, XC.mc.data(), XC.mc.size() * sizeof(unsigned short), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(dv, XC.mv.data(), XC.mv.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return 1;
+  m.sv_mp = (const int *)dp; m.sv_mc = (const unsigned short *)dc; m.sv_minv = (const float *)dv;
+  return 0;
 }
 double *field(const char *name, size_t n, int slabs = 1) {
   double *p = dev_alloc<double>(n * slabs);
@@ -505,6 +539,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   F(sv_ph, N + 64); F(sv_x0, 16 * (N + 64)); F(sv_snap, N);
   F(sv_part, 8 * ((N + 255) / 256 + 1)); F(sv_red, 8); F(sv_kry, 48);
   F(sv_resid, 1); F(sv_h1, N); F(sv_h2, N); F(sv_h3, N); F(sv_scale, N + 64);
+  F(sv_bn, N + 64); F(sv_x, N + 64); F(sv_pd, N + 64); F(sv_sn, N + 64); F(sv_sh, N + 64);
   m.sv_extrap = 1;
 #undef F
 #undef FT
@@ -595,6 +630,14 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
       HIPCHK(hipMemcpy(m.Av, av.data(), sizeof(double) * av.size(), hipMemcpyHostToDevice));
       HIPCHK(hipMemcpy(m.Kv, kv.data(), sizeof(double) * kv.size(), hipMemcpyHostToDevice));
     }
+  }
+  m.sv_minv = nullptr; m.sv_mp = nullptr; m.sv_mc = nullptr; m.sv_xi_its = par->solver_xinv_its;
+  if (par->solver_precond == 1 && G.npes <= 1 && m.myN <= 4096 && m.ssh_maxnnz <= 10 && m.myN >= 64) {
+    // explicit inverse of the row-scaled operator this run starts with (frozen, like the reference's ILU factors)
+    std::vector<int> rp(m.myN + 1), ci(m.nza);
+    for (int i = 0; i <= m.myN; i++) rp[i] = d->ssh_rowptr[i] - d->ssh_rowptr[0];
+    for (int j = 0; j < m.nza; j++) ci[j] = d->ssh_colind_loc[j] - 1;
+    if (xinv_device(m.myN, rp.data(), ci.data(), d->ssh_values, m, G.allocs)) { m.sv_minv = nullptr; G.err = "fesom_gpu_init: the explicit-inverse SSH preconditioner could not be built (singular operator or out of memory)"; return 1; }
   }
   solver_prepare();
   tile_prepare_tra(); tile_prepare_dyn();
@@ -995,29 +1038,59 @@ int fesom_gpu_kernel_time_ms(const char *group_in, int nrep, double *ms_per_laun
 }
 
 // ---- psolver_init / psolve / psolver_final with the reference's signatures (src/psolve.c:16,117,152) -----
+// The reference's functions are void and report through stderr + exit (psolve.c:203 "ERROR: matrix data is static"; pARMS aborts
+// via MPI_Abort): a caller linked against this library cannot see a status either, so every violated precondition or failed HIP
+// call prints one line and terminates the process with a non-zero status instead of returning an unsolved `sol`.
 static struct { bool ok = false; int n = 0, nza = 0; DM m; std::vector<void *> al; } PS;
+[[noreturn]] static void ps_die(const std::string &msg) {
+  fprintf(stderr, "fesom_gpu psolver: %s\n", msg.c_str());
+  fflush(stderr);
+  exit(3);
+}
+#define PSCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) ps_die(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 void psolver_final(void) { for (void *p : PS.al) hipFree(p); PS.al.clear(); PS.ok = false; }
 void psolver_init(int *id, int *stype, int *pctype, int *pcilutype, int *ilulevel, int *fillin, double *droptol, int *maxits,
                   int *restart, double *soltol, int *part, int *rptr, int *cols, double *vals, int *reuse, int *fcomm) {
-  (void)id; (void)stype; (void)pctype; (void)pcilutype; (void)ilulevel; (void)fillin; (void)droptol; (void)maxits; (void)restart;
-  (void)soltol; (void)reuse; (void)fcomm;
+  // solver / preconditioner selectors of pARMS (SOLBICGS_RAS, PCILUK, fill level ...) have one answer here: BiCGstab with this
+  // library's frozen preconditioner; `reuse` (keep the factors of the first matrix) is how the preconditioner is always used
+  (void)id; (void)stype; (void)pctype; (void)pcilutype; (void)ilulevel; (void)fillin; (void)droptol; (void)restart; (void)reuse; (void)fcomm;
   psolver_final();
-  int n = part[1] - part[0];                 // one partition: owned rows = all rows
-  int nza = rptr[n];
+  // one GPU = one partition.  The row partition is part[0..npes]; the rank count is not an argument (psolve.c:31-33 asks MPI), so
+  // what can be checked is that this rank's block starts at row 0 and that every column lies inside it -- a block of a
+  // multi-rank partition has off-block columns or a non-zero offset and is refused (use fesom_gpu_step_partitioned there).
+  if (part[0] != 0) ps_die("psolver_init: part[0] != 0 -- the rows of this rank are a block of a multi-rank partition; this entry point solves single-partition systems only");
+  const int n = part[1] - part[0];
+  if (n < 1) ps_die("psolver_init: no rows");
+  if (rptr[0] != 0) ps_die("psolver_init: rptr[0] must be 0 (0-based CSR, src/oce_ale.F90:2302-2304)");
+  const int nza = rptr[n];
+  int maxnnz = 0;
+  for (int i = 0; i < n; i++) {
+    if (rptr[i + 1] < rptr[i]) ps_die("psolver_init: rptr is not non-decreasing");
+    maxnnz = std::max(maxnnz, rptr[i + 1] - rptr[i]);
+  }
+  if (maxnnz > 16) ps_die("psolver_init: more than 16 entries in a row (the SSH operator of a triangular mesh has <= ~10)");
+  for (int j = 0; j < nza; j++)
+    if (cols[j] < 0 || cols[j] >= n) ps_die("psolver_init: column index outside [0, n) -- rows of a multi-rank partition (global columns) are not supported here");
+  for (int i = 0; i < n; i++)
+    if (rptr[i + 1] == rptr[i] || cols[rptr[i]] != i) ps_die("psolver_init: the first entry of every row must be the diagonal (src/oce_ale.F90:1128-1151)");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) ps_die("no HIP device: the MI355X path has no CPU fallback");
   memset(&PS.m, 0, sizeof(PS.m));
-  auto A = [&](size_t bytes) { void *p = nullptr; hipMalloc(&p, bytes ? bytes : 8); hipMemset(p, 0, bytes ? bytes : 8); PS.al.push_back(p); return p; };
+  auto A = [&](size_t bytes) { void *p = nullptr; PSCHK(hipMalloc(&p, bytes ? bytes : 8)); PSCHK(hipMemset(p, 0, bytes ? bytes : 8)); PS.al.push_back(p); return p; };
   DM &m = PS.m;
   m.myN = m.N = n; m.nza = nza;
+  m.sv_tol = (soltol && *soltol > 0.0) ? *soltol : 0.0;            // absolute tolerance on the row-scaled residual (psolve.c:97, bicgstab_ras.c:78)
+  m.sv_maxits = (maxits && *maxits > 0) ? *maxits : 0;
   int *rp = (int *)A(sizeof(int) * (n + 1)), *ci = (int *)A(sizeof(int) * nza);
-  hipMemcpy(rp, rptr, sizeof(int) * (n + 1), hipMemcpyHostToDevice);
-  hipMemcpy(ci, cols, sizeof(int) * nza, hipMemcpyHostToDevice);
+  PSCHK(hipMemcpy(rp, rptr, sizeof(int) * (n + 1), hipMemcpyHostToDevice));
+  PSCHK(hipMemcpy(ci, cols, sizeof(int) * nza, hipMemcpyHostToDevice));
   m.rowptr = rp; m.colind = ci;
-  m.ssh_maxnnz = 0;
-  for (int i = 0; i < n; i++) m.ssh_maxnnz = std::max(m.ssh_maxnnz, rptr[i + 1] - rptr[i]);
+  m.ssh_maxnnz = maxnnz;
   m.ssh_values = (double *)A(sizeof(double) * nza);
-  hipMemcpy(m.ssh_values, vals, sizeof(double) * nza, hipMemcpyHostToDevice);
+  PSCHK(hipMemcpy(m.ssh_values, vals, sizeof(double) * nza, hipMemcpyHostToDevice));
   m.sv_vals = (double *)A(sizeof(double) * 16 * (n + 64));
-  double **vecs[] = {&m.sv_scale, &m.sv_dinv, &m.sv_b, &m.sv_r, &m.sv_r0, &m.sv_p, &m.sv_v, &m.sv_s, &m.sv_t, &m.sv_ph, &m.d_eta, &m.ssh_rhs};
+  double **vecs[] = {&m.sv_scale, &m.sv_dinv, &m.sv_b, &m.sv_r, &m.sv_r0, &m.sv_p, &m.sv_v, &m.sv_s, &m.sv_t, &m.sv_ph, &m.d_eta, &m.ssh_rhs,
+                     &m.sv_bn, &m.sv_x, &m.sv_pd, &m.sv_sn, &m.sv_sh};
   for (auto v : vecs) *v = (double *)A(sizeof(double) * (n + 64));
   m.sv_x0 = (double *)A(sizeof(double) * 16 * (n + 64));
   m.sv_info = (int *)A(16); m.sv_resid = (double *)A(8);
@@ -1026,34 +1099,41 @@ void psolver_init(int *id, int *stype, int *pctype, int *pcilutype, int *iluleve
     solver_row_order(rptr, n, m.ssh_maxnnz, n <= 4096 && m.ssh_maxnnz <= 10, perm, inv, wid);
     for (auto pv : {std::make_pair(&perm, &m.sv_perm), std::make_pair(&inv, &m.sv_inv), std::make_pair(&wid, &m.sv_wid)}) {
       int *dp = (int *)A(pv.first->size() * sizeof(int));
-      hipMemcpy(dp, pv.first->data(), pv.first->size() * sizeof(int), hipMemcpyHostToDevice);
+      PSCHK(hipMemcpy(dp, pv.first->data(), pv.first->size() * sizeof(int), hipMemcpyHostToDevice));
       *pv.second = dp;
     }
     std::vector<unsigned short> ec = ell_cols(rptr, cols, n, m.ssh_maxnnz, perm, inv);
     m.sv_cols = (unsigned short *)A(ec.size() * sizeof(unsigned short));
-    hipMemcpy(m.sv_cols, ec.data(), ec.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
+    PSCHK(hipMemcpy(m.sv_cols, ec.data(), ec.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
     const int W = m.ssh_maxnnz <= 10 ? 10 : 16, NP = (n + 63) / 64 * 64;      // 32-bit pattern + work space of the multi-workgroup phases
     std::vector<int> c32((size_t)W * NP, 0);
     for (int i = 0; i < NP; i++)
       for (int k = 0; k < W; k++) c32[(size_t)k * NP + i] = (i < n && rptr[i] + k < rptr[i + 1]) ? cols[rptr[i] + k] : (i < n ? i : 0);
     int *c32d = (int *)A(c32.size() * sizeof(int));
-    hipMemcpy(c32d, c32.data(), c32.size() * sizeof(int), hipMemcpyHostToDevice);
+    PSCHK(hipMemcpy(c32d, c32.data(), c32.size() * sizeof(int), hipMemcpyHostToDevice));
     m.sv_colsi = c32d;
     m.sv_part = (double *)A(sizeof(double) * 8 * ((n + 255) / 256 + 1)); m.sv_red = (double *)A(64); m.sv_kry = (double *)A(48 * sizeof(double));
+  }
+  // frozen preconditioner from the matrix of this call (the reference computes its ILU factors from the first matrix, psolve.c:117-150):
+  // the explicit inverse where it fits, FESOM_GPU_PRECOND=jacobi opts out
+  const char *pc = getenv("FESOM_GPU_PRECOND");
+  if (!(pc && !strcmp(pc, "jacobi")) && n <= 4096 && n >= 64 && maxnnz <= 10) {
+    if (xinv_device(n, rptr, cols, vals, m, PS.al)) ps_die("psolver_init: the explicit-inverse preconditioner could not be built (singular matrix or out of device memory)");
   }
   solver_prepare();
   PS.n = n; PS.nza = nza; PS.ok = true;
 }
 void psolve(int *id, double *rhs, double *vals, double *sol, int *newvals) {
   (void)id;
-  if (!PS.ok) { fprintf(stderr, "psolve: psolver_init has not been called\n"); return; }
+  if (!PS.ok) ps_die("psolve: psolver_init has not been called");
   DM &m = PS.m;
-  if (*newvals) hipMemcpy(m.ssh_values, vals, sizeof(double) * PS.nza, hipMemcpyHostToDevice);
-  hipMemcpy(m.ssh_rhs, rhs, sizeof(double) * PS.n, hipMemcpyHostToDevice);
-  hipMemcpy(m.d_eta, sol, sizeof(double) * PS.n, hipMemcpyHostToDevice);
-  launch_solver(m, 0);
-  hipDeviceSynchronize();
-  hipMemcpy(sol, m.d_eta, sizeof(double) * PS.n, hipMemcpyDeviceToHost);
+  if (*newvals) PSCHK(hipMemcpy(m.ssh_values, vals, sizeof(double) * PS.nza, hipMemcpyHostToDevice));
+  PSCHK(hipMemcpy(m.ssh_rhs, rhs, sizeof(double) * PS.n, hipMemcpyHostToDevice));
+  PSCHK(hipMemcpy(m.d_eta, sol, sizeof(double) * PS.n, hipMemcpyHostToDevice));
+  if (launch_solver(m, 0)) ps_die("psolve: no solver kernel for this operator");
+  PSCHK(hipGetLastError());
+  PSCHK(hipDeviceSynchronize());
+  PSCHK(hipMemcpy(sol, m.d_eta, sizeof(double) * PS.n, hipMemcpyDeviceToHost));
 }
 }
 

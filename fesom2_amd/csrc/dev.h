@@ -80,6 +80,12 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   // same ELL width and the padding is skipped.  sv_perm[position] = row, sv_inv[row] = position, sv_wid[position / 64] = width.
   // Identity / full width wherever the natural order is needed (multi-workgroup and partitioned phases).
   const int *sv_perm, *sv_inv, *sv_wid;
+  // explicit-inverse preconditioner of pi-class operators (csrc/precond_host.cpp, solver.hip "xinv"): fp32 inverse of the frozen
+  // row-scaled operator with the entries below 1e-4 of their row's largest dropped, CSR (sv_mp row pointer, sv_mc columns, sv_minv
+  // values); natural-order work vectors of the preconditioned BiCGstab; iterations per solve
+  const float *sv_minv; const int *sv_mp; const unsigned short *sv_mc; int sv_xi_its;
+  double sv_tol; int sv_maxits;   // stop rule: ||scaled residual|| < sv_tol (0: the reference's 1e-10, bicgstab_ras.c:78), iteration cap (0: 2000)
+  double *sv_bn, *sv_x, *sv_pd, *sv_sn, *sv_sh;
   fesom_params p;
 };
 

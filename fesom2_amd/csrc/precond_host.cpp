@@ -1,0 +1,174 @@
+// Host set-up of the SSH preconditioner for pi-class operators: the EXPLICIT INVERSE of the row-scaled operator, frozen at
+// the operator the run starts with -- the role pARMS' ILU factors play in the reference, which are computed in the first
+// psolve call and reused for the whole run (src/psolve.c:117-150, lib/parms/src/parms_ilu_vcsr.c:651-1128).
+// Why an explicit inverse: a 2-D operator with a few thousand rows (pi: 3140) is far too small for the GPU to be busy with
+// sparse triangular solves (sequential) and its dense inverse is only n*n*4 bytes (pi: 42 MB in fp32), which 256 CUs stream
+// in a few microseconds at HBM speed, so applying the preconditioner is ONE full-GPU matrix-vector product and BiCGstab
+// needs 1-2 iterations instead of 20-30 (csrc/solver_xinv.hip).
+//
+// Algorithm (deterministic, no pivoting: the operator is a diagonally dominant M-matrix after row scaling):
+//   1. A_s = diag(1/sum_j|a_ij|) A         (psolve.c:58-65)
+//   2. reverse Cuthill-McKee ordering     (small bandwidth: pi 136)
+//   3. banded LU of P A_s P^T
+//   4. for every unit vector: forward / backward substitution, 16 right-hand sides at a time, threads over the blocks
+//   5. Minv[i][j] (row-major, leading dimension ld, fp32) = (A_s^-1)_ij, un-permuted
+//   6. sparsification: the inverse of this Helmholtz-type operator decays exponentially with distance (pi: 5 % of the entries
+//      exceed 1e-6 of the largest); entries below tau * (largest entry of their row) are dropped (fesom_xinv_sparsify).  With
+//      tau = 1e-4 pi keeps 82 entries per row (1.5 MB instead of 42 MB) and BiCGstab still needs 2 iterations.
+// Every entry is formed by the same sequence of fp64 operations whatever the thread count or the block size, so the
+// CPU checker of the tests (its own restatement of these steps) reproduces the matrix bit for bit.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace {
+// reverse Cuthill-McKee on the symmetrised pattern; ties by index; components in order of their lowest-degree node
+void rcm_order(int n, const int *rp, const int *ci, std::vector<int> &order) {
+  std::vector<std::vector<int>> adj(n);
+  for (int i = 0; i < n; i++)
+    for (int q = rp[i]; q < rp[i + 1]; q++) {
+      const int j = ci[q];
+      if (j == i || j < 0 || j >= n) continue;
+      adj[i].push_back(j); adj[j].push_back(i);
+    }
+  std::vector<int> deg(n);
+  for (int i = 0; i < n; i++) {
+    std::sort(adj[i].begin(), adj[i].end());
+    adj[i].erase(std::unique(adj[i].begin(), adj[i].end()), adj[i].end());
+    deg[i] = (int)adj[i].size();
+  }
+  for (int i = 0; i < n; i++) std::sort(adj[i].begin(), adj[i].end(), [&](int a, int b) { return deg[a] != deg[b] ? deg[a] < deg[b] : a < b; });
+  std::vector<char> seen(n, 0);
+  std::vector<int> level(n), queue;
+  order.clear(); order.reserve(n);
+  auto bfs = [&](int start, std::vector<int> &out) {          // breadth first, neighbours by (degree, index); returns the depth
+    out.clear(); out.push_back(start);
+    level[start] = 0;
+    std::vector<char> vis(n, 0);
+    vis[start] = 1;
+    for (size_t h = 0; h < out.size(); h++)
+      for (int nb : adj[out[h]])
+        if (!vis[nb] && !seen[nb]) { vis[nb] = 1; level[nb] = level[out[h]] + 1; out.push_back(nb); }
+    return level[out.back()];
+  };
+  for (;;) {
+    int start = -1;
+    for (int i = 0; i < n; i++) if (!seen[i] && (start < 0 || deg[i] < deg[start])) start = i;
+    if (start < 0) break;
+    int depth = bfs(start, queue);
+    for (int sweep = 0; sweep < 4; sweep++) {                  // pseudo-peripheral start node
+      int cand = queue.back();
+      for (int k = (int)queue.size() - 1; k >= 0 && level[queue[k]] == depth; k--)
+        if (deg[queue[k]] < deg[cand] || (deg[queue[k]] == deg[cand] && queue[k] < cand)) cand = queue[k];
+      std::vector<int> q2;
+      int d2 = bfs(cand, q2);
+      if (d2 <= depth) break;
+      depth = d2; start = cand; queue.swap(q2);
+    }
+    bfs(start, queue);
+    for (int v : queue) { seen[v] = 1; order.push_back(v); }
+  }
+  std::reverse(order.begin(), order.end());
+}
+}  // namespace
+
+// n rows, 0-based CSR (rp, ci, vals), out: n rows of ld floats (ld >= n; the padding columns are set to 0).
+// Returns 0, or 1 if the factorisation meets a zero pivot.  *bandwidth (optional) receives the half bandwidth after RCM.
+extern "C" int fesom_xinv_build(int n, const int *rp, const int *ci, const double *vals, int ld, float *out, int *bandwidth) {
+  std::vector<int> order, pos(n);
+  rcm_order(n, rp, ci, order);
+  for (int k = 0; k < n; k++) pos[order[k]] = k;
+  int bw = 0;
+  for (int i = 0; i < n; i++)
+    for (int q = rp[i]; q < rp[i + 1]; q++) bw = std::max(bw, std::abs(pos[i] - pos[ci[q]]));
+  if (bandwidth) *bandwidth = bw;
+  const size_t W = 2 * (size_t)bw + 1;
+  std::vector<double> ab((size_t)n * W, 0.0);                   // band storage: ab[i*W + (j - i + bw)]
+  for (int i = 0; i < n; i++) {
+    double tmp = 0.;
+    for (int q = rp[i]; q < rp[i + 1]; q++) tmp += fabs(vals[q]);
+    const double sc = 1. / tmp;
+    for (int q = rp[i]; q < rp[i + 1]; q++) ab[(size_t)pos[i] * W + (size_t)(pos[ci[q]] - pos[i] + bw)] = vals[q] * sc;
+  }
+  for (int k = 0; k < n; k++) {                                 // LU, L below the diagonal (unit), U on and above
+    const double piv = ab[(size_t)k * W + bw];
+    if (piv == 0.0) return 1;
+    const int hi = std::min(n - 1, k + bw);
+    for (int i = k + 1; i <= hi; i++) {
+      double &lik = ab[(size_t)i * W + (size_t)(k - i + bw)];
+      if (lik == 0.0) continue;
+      lik = lik / piv;
+      const double l = lik;
+      double *ri = &ab[(size_t)i * W + (size_t)(bw - i)];        // ri[j] = a(i,j)
+      const double *rk = &ab[(size_t)k * W + (size_t)(bw - k)];
+      for (int j = k + 1; j <= hi; j++) ri[j] = ri[j] - l * rk[j];
+    }
+  }
+  for (int i = 0; i < n; i++) memset(out + (size_t)i * ld, 0, sizeof(float) * (size_t)ld);
+  constexpr int NB = 16;
+  const int nblocks = (n + NB - 1) / NB;
+  unsigned hc = std::thread::hardware_concurrency();
+  int nthreads = (int)std::max(1u, std::min(hc ? hc : 1u, 16u));
+  if (const char *e = getenv("FESOM_GPU_HOST_THREADS")) nthreads = std::max(1, atoi(e));
+  nthreads = std::min(nthreads, nblocks);
+  auto work = [&](int tid) {
+    std::vector<double> y((size_t)n * NB);
+    for (int b = tid; b < nblocks; b += nthreads) {
+      const int c0 = b * NB, nc = std::min(NB, n - c0);
+      std::fill(y.begin(), y.end(), 0.0);
+      for (int r = 0; r < nc; r++) y[(size_t)(c0 + r) * NB + r] = 1.0;
+      for (int i = c0 + 1; i < n; i++) {                        // L y = e : y_i -= l_ij y_j, j ascending
+        double *yi = &y[(size_t)i * NB];
+        const double *ri = &ab[(size_t)i * W + (size_t)(bw - i)];
+        for (int j = std::max(c0, i - bw); j < i; j++) {
+          const double l = ri[j];
+          if (l == 0.0) continue;
+          const double *yj = &y[(size_t)j * NB];
+          for (int r = 0; r < NB; r++) yi[r] = yi[r] - l * yj[r];
+        }
+      }
+      for (int i = n - 1; i >= 0; i--) {                        // U x = y : x_i = (y_i - sum_{j>i, ascending} u_ij x_j) / u_ii
+        double *yi = &y[(size_t)i * NB];
+        const double *ri = &ab[(size_t)i * W + (size_t)(bw - i)];
+        const int hi = std::min(n - 1, i + bw);
+        for (int j = i + 1; j <= hi; j++) {
+          const double u = ri[j];
+          if (u == 0.0) continue;
+          const double *yj = &y[(size_t)j * NB];
+          for (int r = 0; r < NB; r++) yi[r] = yi[r] - u * yj[r];
+        }
+        const double d = ri[i];
+        for (int r = 0; r < NB; r++) yi[r] = yi[r] / d;
+      }
+      for (int i = 0; i < n; i++)
+        for (int r = 0; r < nc; r++) out[(size_t)order[i] * ld + order[c0 + r]] = (float)y[(size_t)i * NB + r];
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
+  work(0);
+  for (auto &t : th) t.join();
+  return 0;
+}
+
+// CSR of the entries with |M_ij| >= tau * max_j |M_ij| (columns ascending).  Call with cols == vals == nullptr to get the
+// row pointer (n + 1 entries) only, then again with arrays of rowptr[n] entries.
+extern "C" void fesom_xinv_sparsify(int n, int ld, const float *M, double tau, int *rowptr, unsigned short *cols, float *vals) {
+  rowptr[0] = 0;
+  for (int i = 0; i < n; i++) {
+    const float *mr = M + (size_t)i * ld;
+    double big = 0.0;
+    for (int j = 0; j < n; j++) big = std::max(big, fabs((double)mr[j]));
+    const double cut = tau * big;
+    int q = rowptr[i];
+    for (int j = 0; j < n; j++)
+      if (fabs((double)mr[j]) >= cut && mr[j] != 0.0f) {
+        if (cols) { cols[q] = (unsigned short)j; vals[q] = mr[j]; }
+        q++;
+      }
+    rowptr[i + 1] = q;
+  }
+}

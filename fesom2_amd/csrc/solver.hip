@@ -94,7 +94,7 @@ __global__ void k_solver_setup(DM m, int NP, int fuse_rhs, int sorted) {      //
   double *Bg = m.sv_vals;
   if (i >= n) {                                            // padding rows keep their position
 #pragma unroll
-    for (int k = 0; k < W; k++) Bg[k * NP + i] = 0.0;
+    for (int k = 0; k < W; k++) { Bg[k * NP + i] = 0.0; if (m.sv_minv) m.sv_x0[k * NP + i] = 0.0; }
     m.sv_s[i] = 0.0;
     return;
   }
@@ -125,15 +125,19 @@ __global__ void k_solver_setup(DM m, int NP, int fuse_rhs, int sorted) {      //
     m.sv_h3[i] = m.sv_h2[i]; m.sv_h2[i] = m.sv_h1[i]; m.sv_h1[i] = xi;
   }
   m.sv_s[q] = x0 * diag;                                  // y0 = D x0
+  const bool xinv = m.sv_minv != nullptr;                 // explicit-inverse path: A_s, b, x0 in natural row order as well
+  if (xinv) { m.sv_bn[i] = rhs * sc; m.sv_x[i] = x0; m.d_eta[i] = x0; }   // (d_eta always holds the best iterate: no finishing launch)
 #pragma unroll
   for (int k = 0; k < W; k++) {
-    double bk = 0.0;
+    double bk = 0.0, ak = 0.0;
     if (j0 + k < j1) {
       int c = ci[j0 + k];
       double dinv_c = 1.0 / m.sv_dinv[c];
-      bk = (m.ssh_values[j0 + k] * sc) * dinv_c;           // B = A_s D^-1
+      ak = m.ssh_values[j0 + k] * sc;                      // A_s
+      bk = ak * dinv_c;                                    // B = A_s D^-1
     }
     Bg[k * NP + q] = bk;
+    if (xinv) m.sv_x0[k * NP + i] = ak;
   }
 }
 
@@ -142,7 +146,13 @@ __global__ void k_solver_setup(DM m, int NP, int fuse_rhs, int sorted) {      //
 // row stride (own-row accesses are immediate-offset, conflict-free); the operator values are the only L2 traffic in
 // the loop (coalesced, scalar base + lane offset).  Same arithmetic and reduction order as solver_body.
 template <int W, int NP4, int WL, int WR>  // NP4: LDS stride of the vectors (>= rows); entries [0,WL) of every row in LDS, [WL,WL+WR) in registers
-__global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2, int NP) {
+__global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2, int NP, const double *cont) {
+  // cont != nullptr: safety net behind the explicit-inverse solve -- cont = its final scalar state (5 ||r||^2, 6 iterations, 7 done):
+  // nothing to do if it converged; else continue from its iterate m.sv_x with the Jacobi preconditioner
+  if (cont && cont[7] != 0.0) {
+    if (threadIdx.x == 0 && m.sv_extrap && m.sv_info[1] < 3) m.sv_info[1] = m.sv_info[1] + 1;
+    return;
+  }
   extern __shared__ double lds[];
   constexpr int R = 4;
   double *bufA = lds, *bufB = lds + 64;
@@ -169,7 +179,7 @@ __global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2
       cpk[k][w2] = (c0 << 3) | (c1 << 19);
     }
     if (i < (unsigned)NP4) {
-      sl[i] = ok[k] ? m.sv_s[i] : 0.0;                     // y0 = D x0 from the set-up kernel
+      sl[i] = ok[k] ? (cont ? m.sv_x[m.sv_perm[i]] * m.sv_dinv[m.sv_perm[i]] : m.sv_s[i]) : 0.0;     // y0 = D x0 from the set-up kernel
 #pragma unroll
       for (int w = 0; w < WL; w++) bl[w * NP4 + i] = ok[k] ? Bg[(size_t)w * (unsigned)NP + i] : 0.0;
       pl[i] = 0.0;
@@ -262,7 +272,11 @@ __global__ void __launch_bounds__(ST) k_solver_reg(DM m, int maxits, double tol2
 #pragma unroll
   for (int k = 0; k < R; k++)
     if (ok[k]) { const unsigned i = t + k * ST; const int row = m.sv_perm[i]; m.d_eta[row] = y[k] * (1.0 / m.sv_dinv[row]); }
-  if (t == 0) { m.sv_info[0] = it; m.sv_resid[0] = sqrt(rr > 0.0 ? rr : 0.0); if (m.sv_extrap && m.sv_info[1] < 3) m.sv_info[1] = m.sv_info[1] + 1; }
+  if (t == 0) {
+    m.sv_info[0] = it + (cont ? (int)cont[6] : 0); m.sv_resid[0] = sqrt(rr > 0.0 ? rr : 0.0);
+    if (cont) m.sv_info[2] = m.sv_info[2] + 1;             // solves the safety net had to finish
+    if (m.sv_extrap && m.sv_info[1] < 3) m.sv_info[1] = m.sv_info[1] + 1;
+  }
 }
 
 void solver_prepare() {
@@ -274,20 +288,23 @@ void solver_prepare() {
   }
 }
 int launch_solver_multi(const DM &m, hipStream_t s, int fuse_rhs, int scale_done);
+int launch_solver_xinv(const DM &m, hipStream_t s, int fuse_rhs, int scale_done);
 // Returns non-zero if the operator is wider than the widest instantiated ELL kernel.
 int launch_solver(const DM &m, hipStream_t s, int fuse_rhs, int scale_done) {
   if (m.ssh_maxnnz > 16) return 1;
+  if (m.sv_minv) return launch_solver_xinv(m, s, fuse_rhs, scale_done);
   // one workgroup holds up to 4096 rows of <= 10 entries in registers/LDS; larger (or wider) operators take the
   // multi-workgroup phases
   if (m.myN > 4 * ST || m.ssh_maxnnz > 10) return launch_solver_multi(m, s, fuse_rhs, scale_done);
   const int W = 10, NP = (m.myN + 63) / 64 * 64;
   if (!scale_done) launch_row_scale(m, s);
   hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs, 1);
-  const double tol2 = 1e-10 * 1e-10;                     // bicgstab_ras.c:78,146,220
+  const double tol2 = m.sv_tol > 0.0 ? m.sv_tol * m.sv_tol : 1e-10 * 1e-10;                     // bicgstab_ras.c:78,146,220
+  const int maxits = m.sv_maxits > 0 ? m.sv_maxits : 2000;
   (void)W;
   // LDS: reduction scratch + p, s + the leading entries of every row; up to 3200 rows (pi: 3140) four of them fit, else two
-  if (m.myN <= 3200) hipLaunchKernelGGL((k_solver_reg<10, 3200, 4, 3>), dim3(1), dim3(ST), (size_t)(128 + (2 + 4) * 3200) * sizeof(double), s, m, 2000, tol2, NP);
-  else hipLaunchKernelGGL((k_solver_reg<10, 4096, 2, 3>), dim3(1), dim3(ST), (size_t)(128 + (2 + 2) * 4096) * sizeof(double), s, m, 2000, tol2, NP);
+  if (m.myN <= 3200) hipLaunchKernelGGL((k_solver_reg<10, 3200, 4, 3>), dim3(1), dim3(ST), (size_t)(128 + (2 + 4) * 3200) * sizeof(double), s, m, maxits, tol2, NP, (const double *)nullptr);
+  else hipLaunchKernelGGL((k_solver_reg<10, 4096, 2, 3>), dim3(1), dim3(ST), (size_t)(128 + (2 + 2) * 4096) * sizeof(double), s, m, maxits, tol2, NP, (const double *)nullptr);
   return 0;
 }
 
@@ -422,7 +439,9 @@ __global__ void __launch_bounds__(DSB) k_ds_finish(DM m) {        // x = D^-1 y
 
 // named phases of the partitioned solve (fesom_gpu_call): ds_scale, ds_setup, ds_init, ds_scal_init, ds_p, ds_spmv1,
 // ds_scal_alpha, ds_s, ds_spmv2, ds_scal_omega, ds_update, ds_finish
+int launch_named_xi(const DM &m, hipStream_t s, const char *name);
 int launch_named_dsolve(const DM &m, hipStream_t s, const char *name) {
+  if (!strncmp(name, "xi_", 3)) return launch_named_xi(m, s, name);
   if (strncmp(name, "ds_", 3)) return -1;
   // ELL width of the phases: 8 / 10 / 16 slabs (the column pattern sv_colsi holds >= that many; narrower kernels skip padding slabs)
   const int W = m.ssh_maxnnz <= 8 ? 8 : m.ssh_maxnnz <= 10 ? 10 : 16, NP = (m.myN + 63) / 64 * 64, nblk = (m.myN + DSB - 1) / DSB;
@@ -435,7 +454,7 @@ int launch_named_dsolve(const DM &m, hipStream_t s, const char *name) {
     else hipLaunchKernelGGL(k_solver_setup<16>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, 0, 0);
     return 0;
   }
-  const double tol2 = 1e-10 * 1e-10; const int maxits = 2000;      // bicgstab_ras.c:78,146,220 / solve_ssh_ale
+  const double tol2 = m.sv_tol > 0.0 ? m.sv_tol * m.sv_tol : 1e-10 * 1e-10; const int maxits = m.sv_maxits > 0 ? m.sv_maxits : 2000;      // bicgstab_ras.c:78,146,220 / solve_ssh_ale
   if (!strcmp(name, "ds_init")) {
     hipMemsetAsync(m.sv_kry, 0, 16 * sizeof(double), s);
     DSW(k_ds_init, m, NP, nblk); hipLaunchKernelGGL(k_ds_reduce, dim3(1), dim3(64), 0, s, m, 1, nblk); return 0;
@@ -591,7 +610,7 @@ int launch_solver_multi(const DM &m, hipStream_t s, int fuse_rhs, int scale_done
   if (m.ssh_maxnnz > 16) return 1;
   // ELL width of the phases: 8 / 10 / 16 slabs (the column pattern sv_colsi holds >= that many; narrower kernels skip padding slabs)
   const int W = m.ssh_maxnnz <= 8 ? 8 : m.ssh_maxnnz <= 10 ? 10 : 16, NP = (m.myN + 63) / 64 * 64, nblk = (m.myN + DSB - 1) / DSB;
-  const double tol2 = 1e-10 * 1e-10; const int maxits = 2000;
+  const double tol2 = m.sv_tol > 0.0 ? m.sv_tol * m.sv_tol : 1e-10 * 1e-10; const int maxits = m.sv_maxits > 0 ? m.sv_maxits : 2000;
   if (!scale_done) launch_row_scale(m, s);
   if (W == 8) hipLaunchKernelGGL(k_solver_setup<8>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs, 0);
   else if (W == 10) hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs, 0);
@@ -621,4 +640,200 @@ int launch_solver_multi(const DM &m, hipStream_t s, int fuse_rhs, int scale_done
   last_its = (int)hk[6];
   hipLaunchKernelGGL(k_dm_finish, dim3(nblk), dim3(DSB), 0, s, m, slot);
   return 0;
+}
+
+
+// =====================================================================================================================
+// pi-class operators (single partition, <= 4096 rows): BiCGstab preconditioned with the EXPLICIT INVERSE of the frozen
+// row-scaled operator (csrc/precond_host.cpp; the reference freezes its ILU(2) factors the same way, psolve.c:117-150).
+// One workgroup is LDS-gather-bound at ~6.6 us per Jacobi iteration and needs 20-30 of them.  The inverse of this Helmholtz-type
+// operator decays exponentially away from the diagonal, so it is kept as a SPARSE fp32 matrix (entries above 1e-4 of their row's
+// largest: 82 per row on pi, 1.5 MB, L2-resident) that all CUs apply in one short launch (k_xi_gemv: wave per row, vector in LDS,
+// fp64 accumulation); BiCGstab converges in 1-2 iterations, and the whole solve is a fixed number of stream-ordered launches
+// with no host read-back:
+//     setup | init | K x { gemv(p^ = M p) , v = A p^ , gemv(s^ = M s) , t = A s^ , update } | finish | safety net
+// Right preconditioning: the residual b - A_s x is the reference's row-scaled residual and the stop rule is unchanged
+// (||r||^2 < 1e-20, bicgstab_ras.c:78,146,220).  Launches after convergence are no-ops; if K iterations do not suffice the
+// Jacobi one-workgroup solver above continues from the current iterate (k_solver_reg, cont), so the result is always converged.
+// Summation orders are fixed (per-thread sequential, DPP wave tree, wave partials in order; block partials as in the
+// multi-workgroup phases) and restated by the CPU checker of the tests.
+// =====================================================================================================================
+#define XI_ROWS 16                       // rows per 256-thread block of the preconditioner kernel (4 per wavefront)
+__device__ __forceinline__ double xi_wave_total(double x) {           // same lane tree as block_reduce: total in lane 63
+  x = dpp_add<0x118, 0xf>(x); x = dpp_add<0x114, 0xf>(x); x = dpp_add<0x112, 0xf>(x); x = dpp_add<0x111, 0xf>(x);
+  x = dpp_add<0x142, 0xa>(x); x = dpp_add<0x143, 0xc>(x);
+  return x;
+}
+// sum of nblk <= 16 block partials in the order of dm_sum_blocks (thread b holds part[b], halving tree: the strides 128..16 only add
+// zeros), evaluated by every thread in registers: no barrier
+__device__ __forceinline__ double xi_sum16(const double *part, int nblk) {
+  double p[16];
+#pragma unroll
+  for (int b = 0; b < 16; b++) p[b] = b < nblk ? part[b] : 0.0;
+#pragma unroll
+  for (int b = 0; b < 8; b++) p[b] = p[b] + p[b + 8];
+#pragma unroll
+  for (int b = 0; b < 4; b++) p[b] = p[b] + p[b + 4];
+  p[0] = p[0] + p[2]; p[1] = p[1] + p[3];
+  return p[0] + p[1];
+}
+template <int W>
+__global__ void __launch_bounds__(DSB) k_xi_init(DM m, int NP, int nblk) {    // r = b - A_s x0 ; r0 = p = r ; partial ||r||^2
+  int i = blockIdx.x * DSB + threadIdx.x;
+  double q[1] = {0.0};
+  if (i < m.myN) {
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < W; k++) a = a + m.sv_x0[(size_t)k * NP + i] * m.sv_x[m.sv_colsi[(size_t)k * NP + i]];
+    double ri = m.sv_bn[i] - a;
+    m.sv_r[i] = ri; m.sv_r0[i] = ri; m.sv_pd[i] = ri;
+    q[0] = ri * ri;
+  }
+  ds_block_partials<1>(q, m.sv_part, nblk);
+}
+// z = M x with the sparsified inverse (CSR: sv_mp, sv_mc, sv_minv).  The vector (<= 4096 doubles) is staged in LDS by every block,
+// a wavefront takes one row at a time: lane l adds the entries l, l+64, ... of the row in that order, the 64 partial sums go through
+// the wave tree.  MODE 0: x = p (first: evaluates ||r0||^2 and the start state);  MODE 1: alpha ; x = s = r - alpha v (block 0 stores s).
+template <int MODE>
+__global__ void __launch_bounds__(256) k_xi_gemv(DM m, int nblk, int slot, int first, double tol2) {
+  __shared__ double xs[4096];
+  const int t = threadIdx.x;
+  const double *st = m.sv_kry + 16 * slot;
+  double alpha = 0.0;
+  if (MODE == 0) {
+    if (first) {
+      const double rr = xi_sum16(m.sv_part, nblk);
+      const bool go = rr >= tol2;
+      if (blockIdx.x == 0 && t == 0) {
+        double *s0 = m.sv_kry;
+        s0[0] = 1.0; s0[1] = 1.0; s0[2] = rr; s0[3] = 1.0; s0[4] = rr; s0[5] = rr; s0[6] = 0.0; s0[7] = go ? 0.0 : 1.0;
+        m.sv_info[0] = 0; m.sv_resid[0] = sqrt(rr > 0.0 ? rr : 0.0);
+      }
+      if (!go) return;
+    } else if (st[7] != 0.0) return;
+  } else {
+    if (st[7] != 0.0) return;
+    alpha = st[4] / xi_sum16(m.sv_part, nblk);
+    if (blockIdx.x == 0 && t == 0) m.sv_kry[32] = alpha;
+  }
+  const int n = m.myN;
+  for (int i = t; i < n; i += 256) {
+    const double val = (MODE == 0) ? m.sv_pd[i] : m.sv_r[i] - alpha * m.sv_v[i];
+    xs[i] = val;
+    if (MODE == 1 && blockIdx.x == 0) m.sv_sn[i] = val;
+  }
+  __syncthreads();
+  const int lane = t & 63, w = t >> 6;
+  double *out = MODE == 0 ? m.sv_ph : m.sv_sh;
+#pragma unroll
+  for (int q = 0; q < XI_ROWS / 4; q++) {
+    const int row = blockIdx.x * XI_ROWS + w * (XI_ROWS / 4) + q;
+    if (row >= n) break;
+    const int beg = m.sv_mp[row], end = m.sv_mp[row + 1];
+    double a = 0.0;
+    for (int e = beg + lane; e < end; e += 64) a = a + (double)m.sv_minv[e] * xs[m.sv_mc[e]];
+    a = xi_wave_total(a);
+    if (lane == 63) out[row] = a;
+  }
+}
+template <int W>
+__global__ void __launch_bounds__(DSB) k_xi_spmv1(DM m, int NP, int nblk, int slot) {          // v = A_s p^ ; r0.v
+  const double *st = m.sv_kry + 16 * slot;
+  if (st[7] != 0.0) return;
+  int i = blockIdx.x * DSB + threadIdx.x;
+  double q[1] = {0.0};
+  if (i < m.myN) {
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < W; k++) a = a + m.sv_x0[(size_t)k * NP + i] * m.sv_ph[m.sv_colsi[(size_t)k * NP + i]];
+    m.sv_v[i] = a; q[0] = m.sv_r0[i] * a;
+  }
+  ds_block_partials<1>(q, m.sv_part, nblk);
+}
+template <int W>
+__global__ void __launch_bounds__(DSB) k_xi_spmv2(DM m, int NP, int nblk, int slot) {          // t = A_s s^ ; t.t, t.s, r0.t, s.s
+  const double *st = m.sv_kry + 16 * slot;
+  if (st[7] != 0.0) return;
+  int i = blockIdx.x * DSB + threadIdx.x;
+  double q[4] = {0.0, 0.0, 0.0, 0.0};
+  if (i < m.myN) {
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < W; k++) a = a + m.sv_x0[(size_t)k * NP + i] * m.sv_sh[m.sv_colsi[(size_t)k * NP + i]];
+    const double si = m.sv_sn[i];
+    m.sv_t[i] = a;
+    q[0] = a * a; q[1] = a * si; q[2] = m.sv_r0[i] * a; q[3] = si * si;
+  }
+  ds_block_partials<4>(q, m.sv_part + 4 * (size_t)nblk, nblk);
+}
+__global__ void __launch_bounds__(DSB) k_xi_upd(DM m, int nblk, int slot, double tol2, int maxits) {   // scalars ; x, r ; next p
+  const double *st = m.sv_kry + 16 * slot;
+  double *so = m.sv_kry + 16 * (1 - slot);
+  if (st[7] != 0.0) {
+    if (blockIdx.x == 0 && threadIdx.x < 16) so[threadIdx.x] = st[threadIdx.x];
+    return;
+  }
+  __shared__ double sh[4][DSB];
+  double tot[4];
+  dm_sum_blocks4(m.sv_part + 4 * (size_t)nblk, nblk, sh, tot);
+  const double tt = tot[0], ts = tot[1], r0t = tot[2], ss = tot[3];
+  const double alpha = m.sv_kry[32];
+  const double omega = (tt > 0.0) ? ts / tt : 0.0;
+  const double rho = st[4], rho_new = -omega * r0t;
+  const double rr = ss - omega * (2.0 * ts - omega * tt);
+  const double it = st[6] + 1.0;
+  const bool more = (rr >= tol2 && it < (double)maxits);
+  const double beta = more ? (rho_new / rho) * (alpha / omega) : 0.0;
+  int i = blockIdx.x * DSB + threadIdx.x;
+  if (i < m.myN) {
+    const double si = m.sv_sn[i];
+    const double ri = si - omega * m.sv_t[i];
+    m.sv_r[i] = ri;
+    const double xn = (m.sv_x[i] + alpha * m.sv_ph[i]) + omega * m.sv_sh[i];
+    m.sv_x[i] = xn;
+    if (more) m.sv_pd[i] = ri + beta * (m.sv_pd[i] - omega * m.sv_v[i]);
+    else m.d_eta[i] = xn;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    so[0] = alpha; so[1] = omega; so[2] = beta; so[3] = rho; so[4] = rho_new; so[5] = rr; so[6] = it; so[7] = more ? 0.0 : 1.0;
+    m.sv_info[0] = (int)it; m.sv_resid[0] = sqrt(rr > 0.0 ? rr : 0.0);
+  }
+}
+int launch_solver_xinv(const DM &m, hipStream_t s, int fuse_rhs, int scale_done) {
+  const int NP = (m.myN + 63) / 64 * 64, nblk = (m.myN + DSB - 1) / DSB;
+  const double tol2 = m.sv_tol > 0.0 ? m.sv_tol * m.sv_tol : 1e-10 * 1e-10; const int maxits = m.sv_maxits > 0 ? m.sv_maxits : 2000;
+  if (!scale_done) launch_row_scale(m, s);
+  hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs, 1);   // Jacobi copies for the safety net + natural-order A_s, b, x0
+  hipLaunchKernelGGL(k_xi_init<10>, dim3(nblk), dim3(DSB), 0, s, m, NP, nblk);
+  const int K = m.sv_xi_its > 0 ? m.sv_xi_its : 2, gblk = (m.myN + XI_ROWS - 1) / XI_ROWS;
+  int slot = 0;
+  for (int k = 0; k < K; k++) {
+    hipLaunchKernelGGL(k_xi_gemv<0>, dim3(gblk), dim3(256), 0, s, m, nblk, slot, k == 0 ? 1 : 0, tol2);
+    hipLaunchKernelGGL(k_xi_spmv1<10>, dim3(nblk), dim3(DSB), 0, s, m, NP, nblk, slot);
+    hipLaunchKernelGGL(k_xi_gemv<1>, dim3(gblk), dim3(256), 0, s, m, nblk, slot, 0, tol2);
+    hipLaunchKernelGGL(k_xi_spmv2<10>, dim3(nblk), dim3(DSB), 0, s, m, NP, nblk, slot);
+    hipLaunchKernelGGL(k_xi_upd, dim3(nblk), dim3(DSB), 0, s, m, nblk, slot, tol2, maxits);
+    slot = 1 - slot;
+  }
+  const double *cont = m.sv_kry + 16 * slot;
+  if (m.myN <= 3200) hipLaunchKernelGGL((k_solver_reg<10, 3200, 4, 3>), dim3(1), dim3(ST), (size_t)(128 + (2 + 4) * 3200) * sizeof(double), s, m, maxits, tol2, NP, cont);
+  else hipLaunchKernelGGL((k_solver_reg<10, 4096, 2, 3>), dim3(1), dim3(ST), (size_t)(128 + (2 + 2) * 4096) * sizeof(double), s, m, maxits, tol2, NP, cont);
+  return 0;
+}
+
+// single phases of the explicit-inverse solve for per-kernel timing (fesom_gpu_kernel_time_ms): they run on whatever the last
+// solve left in the work vectors, with the `done` flag of slot 1 cleared first by "xi_arm"
+__global__ void k_xi_arm(DM m) { if (!threadIdx.x) { m.sv_kry[7] = 0.0; m.sv_kry[23] = 0.0; m.sv_kry[4] = 1.0; m.sv_kry[20] = 1.0; } }
+int launch_named_xi(const DM &m, hipStream_t s, const char *name) {
+  if (!m.sv_minv) return 1;
+  const int NP = (m.myN + 63) / 64 * 64, nblk = (m.myN + DSB - 1) / DSB, gblk = (m.myN + XI_ROWS - 1) / XI_ROWS;
+  const double tol2 = 1e-10 * 1e-10;
+  if (!strcmp(name, "xi_arm")) { hipLaunchKernelGGL(k_xi_arm, dim3(1), dim3(64), 0, s, m); return 0; }
+  if (!strcmp(name, "xi_gemv0")) { hipLaunchKernelGGL(k_xi_gemv<0>, dim3(gblk), dim3(256), 0, s, m, nblk, 1, 0, tol2); return 0; }
+  if (!strcmp(name, "xi_gemv1")) { hipLaunchKernelGGL(k_xi_gemv<1>, dim3(gblk), dim3(256), 0, s, m, nblk, 1, 0, tol2); return 0; }
+  if (!strcmp(name, "xi_spmv1")) { hipLaunchKernelGGL(k_xi_spmv1<10>, dim3(nblk), dim3(DSB), 0, s, m, NP, nblk, 1); return 0; }
+  if (!strcmp(name, "xi_spmv2")) { hipLaunchKernelGGL(k_xi_spmv2<10>, dim3(nblk), dim3(DSB), 0, s, m, NP, nblk, 1); return 0; }
+  if (!strcmp(name, "xi_init")) { hipLaunchKernelGGL(k_xi_init<10>, dim3(nblk), dim3(DSB), 0, s, m, NP, nblk); return 0; }
+  if (!strcmp(name, "xi_setup")) { hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, 0, 1); return 0; }
+  return -1;
 }

@@ -124,6 +124,11 @@ typedef struct fesom_params {
                                 0 'MFCT' (default), 1 'MUSCL' (nboundary_lay of oce_muscl_adv.F90:74-104 is formed inside the library), 2 'UPW1' */
   int    Kv0_const;          /* 1 (default): background vertical diffusivity K_ver; 0: latitude/depth dependent Kv0_background_qiang
                                 (oce_ale_mixing_pp.F90:91-125) in the PP and KPP schemes */
+  int    solver_precond;     /* SSH solver preconditioner, frozen at the operator of the first step like the reference's ILU factors
+                                (psolve.c:117-150): 0 = Jacobi; 1 = explicit inverse of the row-scaled operator (fp32, applied as one
+                                full-GPU matrix-vector product) where it fits: single partition, <= 4096 rows (pi), else Jacobi */
+  int    solver_xinv_its;    /* solver_precond=1: BiCGstab iterations enqueued per solve (no host read-back inside a step); a solve that
+                                has not converged by then is finished by the Jacobi-preconditioned one-workgroup solver.  0 = default (2) */
 } fesom_params;
 
 /* ---- prognostic state = restart set (io_restart.F90:99-155) + ALE thickness arrays -- */

@@ -24,6 +24,7 @@ int orc_init(const fesom_mesh_desc *m, const fesom_params *p) {
   free(C_.toy_bpos); free(C_.toy_owner); free(C_.MLD1_ind);
   free(C_.kpp_wmt); free(C_.kpp_wst); free(C_.kpp_work); free(C_.kpp_vol); free(C_.kpp_kbl);
   memset(&C_, 0, sizeof(C_));
+  { extern void orc_solver_reset(void); orc_solver_reset(); }
   C_.m = *m; C_.p = *p;
   C_.N = m->myDim_nod2D + m->eDim_nod2D; C_.E = m->myDim_elem2D + m->eDim_elem2D; C_.D = m->myDim_edge2D + m->eDim_edge2D;
   C_.nl = m->nl; C_.nlm1 = m->nl - 1; C_.ntr = p->num_tracers;
@@ -138,23 +139,34 @@ static double dot_blocks(const double *x, const double *y, int n) {
   return col[0];
 }
 static double dot_sel(const double *x, const double *y, int n) { return n > 4 * SOLVER_T ? dot_blocks(x, y, n) : dot_fixed(x, y, n); }
+/* explicit-inverse preconditioner of the HIP path for pi-class operators (orc_xinv.c): built once per context from the operator the
+ * run starts with (the mesh's ssh_values, as fesom_gpu_init does), frozen afterwards */
+int orc_xinv_build(int n, const int *rp, const int *ci, const double *vals, int ld, float *out);
+void orc_xinv_sparsify(int n, int ld, const float *M, double tau, int *rowptr, unsigned short *cols, float *vals);
+void orc_xinv_apply(int n, const int *mp, const unsigned short *mc, const float *mv, const double *x, double *z);
+#define XINV_DROP 1.0e-4                      /* csrc/api.hip */
+static float *xinv_M = NULL;                  /* sparsified inverse: CSR values / columns / row pointer */
+static unsigned short *xinv_mc = NULL;
+static int *xinv_mp = NULL;
+static int xinv_n = 0;
+static const void *xinv_key = NULL;
+void orc_solver_reset(void) { free(xinv_M); free(xinv_mc); free(xinv_mp); xinv_M = NULL; xinv_mc = NULL; xinv_mp = NULL; xinv_n = 0; xinv_key = NULL; }
+
 void orc_solve_ssh(void) {
   int n = C_.m.myDim_nod2D;
   const int *rp = C_.m.ssh_rowptr, *ci = C_.m.ssh_colind_loc;
   int off = rp[0];
   int *perm = NULL;
-  {
-    int maxnnz = 0;
-    for (int i = 0; i < n; i++) maxnnz = rp[i + 1] - rp[i] > maxnnz ? rp[i + 1] - rp[i] : maxnnz;
-    if (n <= 4 * SOLVER_T && maxnnz <= 10) {               /* (csrc/api.hip: solver_row_order) */
-      perm = malloc(sizeof(int) * n);
-      int q = 0;
-      for (int w = maxnnz; w >= 0; w--) for (int i = 0; i < n; i++) if (rp[i + 1] - rp[i] == w) perm[q++] = i;
-    }
+  int maxnnz = 0;
+  for (int i = 0; i < n; i++) maxnnz = rp[i + 1] - rp[i] > maxnnz ? rp[i + 1] - rp[i] : maxnnz;
+  if (n <= 4 * SOLVER_T && maxnnz <= 10) {               /* (csrc/api.hip: solver_row_order) */
+    perm = malloc(sizeof(int) * n);
+    int q = 0;
+    for (int w = maxnnz; w >= 0; w--) for (int i = 0; i < n; i++) if (rp[i + 1] - rp[i] == w) perm[q++] = i;
   }
-  solver_perm = perm;
-  double *B = malloc(sizeof(double) * C_.m.ssh_nza), *diag = malloc(sizeof(double) * n * 10);
+  double *B = malloc(sizeof(double) * C_.m.ssh_nza), *As = malloc(sizeof(double) * C_.m.ssh_nza), *diag = malloc(sizeof(double) * n * 14);
   double *dinv = diag + n, *b = dinv + n, *r = b + n, *r0 = r + n, *pv = r0 + n, *v = pv + n, *s = v + n, *t = s + n, *y = t + n;
+  double *ph = y + n, *sh = ph + n, *xx = sh + n;
   double *x = C_.d_eta;
   /* initial guess: previous solution (reference) or quadratic / cubic extrapolation of the last solutions */
   for (int i = 0; i < n; i++) {
@@ -170,43 +182,103 @@ void orc_solve_ssh(void) {
     double tmp = 0.;
     for (int j = rp[i] - off; j < rp[i + 1] - off; j++) tmp += fabs(C_.ssh_values[j]);
     double sc = 1. / tmp;
-    for (int j = rp[i] - off; j < rp[i + 1] - off; j++) B[j] = C_.ssh_values[j] * sc;
+    for (int j = rp[i] - off; j < rp[i + 1] - off; j++) { As[j] = C_.ssh_values[j] * sc; B[j] = As[j]; }
     b[i] = C_.ssh_rhs[i] * sc;
     diag[i] = B[rp[i] - off];                   /* first entry of a row is the diagonal (oce_ale.F90:1128-1151) */
     dinv[i] = 1.0 / diag[i];
-    y[i] = x[i] * diag[i];
   }
   for (int i = 0; i < n; i++)
     for (int j = rp[i] - off; j < rp[i + 1] - off; j++) B[j] = B[j] * dinv[ci[j] - 1];
-#define SPMV(out, in) for (int i = 0; i < n; i++) { double a = 0.0; for (int j = rp[i] - off; j < rp[i + 1] - off; j++) a = a + B[j] * (in)[ci[j] - 1]; (out)[i] = a; }
+#define SPMV_(M_, out, in) for (int i = 0; i < n; i++) { double a = 0.0; for (int j = rp[i] - off; j < rp[i + 1] - off; j++) a = a + (M_)[j] * (in)[ci[j] - 1]; (out)[i] = a; }
+#define SPMV(out, in) SPMV_(B, out, in)
   const double tol2 = 1e-10 * 1e-10;
   const int maxits = 2000;
-  SPMV(r, y);
-  for (int i = 0; i < n; i++) { r[i] = b[i] - r[i]; r0[i] = r[i]; pv[i] = 0.0; v[i] = 0.0; }
-  double rho = 1.0, alpha = 1.0, omega = 1.0;
-  double rr = dot_sel(r, r, n);
-  double rho_new = rr;
-  int it = 0;
-  /* BiCGstab with two reduction points per iteration: rho and ||r||^2 come from recurrences
-   * (r0.s = 0 by construction  =>  r0.r = -omega r0.t ;  r = s - omega t  =>  r.r = s.s - omega(2 t.s - omega t.t)) */
-  while (rr >= tol2 && it < maxits) {
-    double beta = (rho_new / rho) * (alpha / omega);
-    for (int i = 0; i < n; i++) pv[i] = r[i] + beta * (pv[i] - omega * v[i]);
-    SPMV(v, pv);
-    alpha = rho_new / dot_sel(r0, v, n);
-    for (int i = 0; i < n; i++) s[i] = r[i] - alpha * v[i];
-    SPMV(t, s);
-    double tt = dot_sel(t, t, n), ts = dot_sel(t, s, n), r0t = dot_sel(r0, t, n), ss = dot_sel(s, s, n);
-    omega = (tt > 0.0) ? ts / tt : 0.0;
-    for (int i = 0; i < n; i++) { y[i] = (y[i] + alpha * pv[i]) + omega * s[i]; r[i] = s[i] - omega * t[i]; }
-    rho = rho_new;
-    rho_new = -omega * r0t;
-    rr = ss - omega * (2.0 * ts - omega * tt);
-    it++;
+  double rho = 1.0, alpha = 1.0, omega = 1.0, rr, rho_new;
+  int it = 0, it0 = 0, converged = 0;
+  const int use_xinv = C_.p.solver_precond == 1 && perm != NULL && n >= 64;
+  if (use_xinv) {
+    /* ---- BiCGstab on A_s, right-preconditioned with the frozen explicit inverse (csrc/solver.hip: launch_solver_xinv): the
+     * multi-block summation order (dot_blocks), K iterations at most, then the Jacobi one-workgroup solver takes over */
+    if (!xinv_M || xinv_n != n || xinv_key != (const void *)C_.m.ssh_values) {
+      orc_solver_reset();
+      const int ld = (n + 255) / 256 * 256;
+      float *dense = malloc(sizeof(float) * (size_t)n * ld);
+      int *rp0 = malloc(sizeof(int) * (n + 1)), *ci0 = malloc(sizeof(int) * C_.m.ssh_nza);
+      for (int i = 0; i <= n; i++) rp0[i] = rp[i] - off;
+      for (int j = 0; j < C_.m.ssh_nza; j++) ci0[j] = ci[j] - 1;
+      if (orc_xinv_build(n, rp0, ci0, C_.m.ssh_values, ld, dense)) { fprintf(stderr, "orc: singular SSH operator\n"); abort(); }
+      free(rp0); free(ci0);
+      xinv_mp = malloc(sizeof(int) * (n + 1));
+      orc_xinv_sparsify(n, ld, dense, XINV_DROP, xinv_mp, NULL, NULL);
+      xinv_mc = malloc(sizeof(unsigned short) * (size_t)(xinv_mp[n] + 1)); xinv_M = malloc(sizeof(float) * (size_t)(xinv_mp[n] + 1));
+      orc_xinv_sparsify(n, ld, dense, XINV_DROP, xinv_mp, xinv_mc, xinv_M);
+      free(dense);
+      xinv_n = n; xinv_key = (const void *)C_.m.ssh_values;
+    }
+    const int K = C_.p.solver_xinv_its > 0 ? C_.p.solver_xinv_its : 2;
+    for (int i = 0; i < n; i++) xx[i] = x[i];
+    SPMV_(As, r, xx);
+    for (int i = 0; i < n; i++) { r[i] = b[i] - r[i]; r0[i] = r[i]; pv[i] = r[i]; }
+    rr = dot_blocks(r, r, n);
+    rho_new = rr;
+    while (rr >= tol2 && it < maxits && it < K) {
+      orc_xinv_apply(n, xinv_mp, xinv_mc, xinv_M, pv, ph);
+      SPMV_(As, v, ph);
+      alpha = rho_new / dot_blocks(r0, v, n);
+      for (int i = 0; i < n; i++) s[i] = r[i] - alpha * v[i];
+      orc_xinv_apply(n, xinv_mp, xinv_mc, xinv_M, s, sh);
+      SPMV_(As, t, sh);
+      double tt = dot_blocks(t, t, n), ts = dot_blocks(t, s, n), r0t = dot_blocks(r0, t, n), ss = dot_blocks(s, s, n);
+      omega = (tt > 0.0) ? ts / tt : 0.0;
+      rho = rho_new;
+      rho_new = -omega * r0t;
+      rr = ss - omega * (2.0 * ts - omega * tt);
+      it++;
+      const int more = (rr >= tol2 && it < maxits);
+      const double beta = more ? (rho_new / rho) * (alpha / omega) : 0.0;
+      for (int i = 0; i < n; i++) {
+        r[i] = s[i] - omega * t[i];
+        xx[i] = (xx[i] + alpha * ph[i]) + omega * sh[i];
+        if (more) pv[i] = r[i] + beta * (pv[i] - omega * v[i]);
+      }
+    }
+    converged = !(rr >= tol2 && it < maxits);
+    for (int i = 0; i < n; i++) x[i] = xx[i];
+    it0 = it;
   }
-  for (int i = 0; i < n; i++) x[i] = y[i] * (1.0 / diag[i]);
+  if (!converged) {
+    /* ---- Jacobi, applied as the column scaling B = A_s D^-1, y = D x: the one-workgroup / multi-workgroup HIP solve; after the
+     * explicit-inverse iterations it continues from their iterate */
+    solver_perm = perm;
+    for (int i = 0; i < n; i++) y[i] = x[i] * diag[i];
+    SPMV(r, y);
+    for (int i = 0; i < n; i++) { r[i] = b[i] - r[i]; r0[i] = r[i]; pv[i] = 0.0; v[i] = 0.0; }
+    rho = 1.0; alpha = 1.0; omega = 1.0;
+    rr = dot_sel(r, r, n);
+    rho_new = rr;
+    it = 0;
+    /* BiCGstab with two reduction points per iteration: rho and ||r||^2 come from recurrences
+     * (r0.s = 0 by construction  =>  r0.r = -omega r0.t ;  r = s - omega t  =>  r.r = s.s - omega(2 t.s - omega t.t)) */
+    while (rr >= tol2 && it < maxits) {
+      double beta = (rho_new / rho) * (alpha / omega);
+      for (int i = 0; i < n; i++) pv[i] = r[i] + beta * (pv[i] - omega * v[i]);
+      SPMV(v, pv);
+      alpha = rho_new / dot_sel(r0, v, n);
+      for (int i = 0; i < n; i++) s[i] = r[i] - alpha * v[i];
+      SPMV(t, s);
+      double tt = dot_sel(t, t, n), ts = dot_sel(t, s, n), r0t = dot_sel(r0, t, n), ss = dot_sel(s, s, n);
+      omega = (tt > 0.0) ? ts / tt : 0.0;
+      for (int i = 0; i < n; i++) { y[i] = (y[i] + alpha * pv[i]) + omega * s[i]; r[i] = s[i] - omega * t[i]; }
+      rho = rho_new;
+      rho_new = -omega * r0t;
+      rr = ss - omega * (2.0 * ts - omega * tt);
+      it++;
+    }
+    for (int i = 0; i < n; i++) x[i] = y[i] * (1.0 / diag[i]);
+    it += it0;
+  }
   C_.solver_iters = it; C_.solver_resid = sqrt(rr > 0.0 ? rr : 0.0);
-  free(B); free(diag); free(perm); solver_perm = NULL;
+  free(B); free(As); free(diag); free(perm); solver_perm = NULL;
 }
 
 /* oce_timestep_ale sequence for the supported options: src/oce_ale.F90:2556-2767 (+ fvom_main.F90:216) */
