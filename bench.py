@@ -115,6 +115,16 @@ def kernel_table(core, mesh, wl):
                 its=its, wet=(N3, E3, D3))
 
 
+def solver_launches(core):
+    """kernel launches of one SSH solve as the running step issues it (csrc/solver.hip)"""
+    n, K = core.mesh.myDim_nod2D, (core.params.solver_xinv_its or 2)
+    if core.params.solver_precond == 1 and n <= 4096:
+        return 2 + 5 * K + 1            # set-up, initial residual, K x (M p, A p^, M s, A s^, update), safety net
+    if n <= 4096:
+        return 2                        # set-up + one-workgroup Krylov loop
+    return 3 + 3 * (core.solver_iterations + 6)
+
+
 def pmc_traffic(kernel, workload_key, redi):
     """HBM-side bytes per launch from the committed PMC summary of THIS workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
     separate passes, gfx950 correction; tools/pmc_summary.py).  (bytes, source) or (None, reason)."""
@@ -385,7 +395,11 @@ def main():
                                    "frac": round(kt["step_bytes"] / sps / 1e9 / HBM_PEAK_GBS, 4),
                                    "sum_kernel_us": round(sum(share.values()) * 1e6, 1),
                                    "solver_us": round(times["k_solver"] * 1e6, 1), "solver_iterations": kt["its"]},
-                    "top5_us": {k: round(v * 1e6, 2) for k, v in sorted(share.items(), key=lambda kv: -kv[1])[:5]}}
+                    "top5_us": {k: round(v * 1e6, 2) for k, v in sorted(share.items(), key=lambda kv: -kv[1])[:5]},
+                    "kernels": {k: {"us": round(times[k] * 1e6, 2), "launches_per_step": mult.get(k, 1),
+                                    "GBs": (round(kbytes[k] / times[k] / 1e9, 1) if k in kbytes and times[k] > 0 else None)}
+                                for k in sorted(times, key=lambda k: -share[k])},
+                    "launches_per_step": int(sum(mult.values())) + solver_launches(core)}
         rows = mesh.myDim_nod2D
         nnz = int(mesh.ssh_nza)
         # one BiCGstab iteration = 2 operator applications (+ preconditioner) over the 2-D operator: nnz values + indices, ~10 vector passes

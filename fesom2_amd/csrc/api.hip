@@ -17,7 +17,7 @@
 int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int first_step);
 int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg);
 void solver_prepare();
-extern "C" int fesom_xinv_build(int n, const int *rp, const int *ci, const double *vals, int ld, float *out, int *bandwidth);
+extern "C" int fesom_xinv_build(int n, const int *rp, const int *ci, const double *vals, const double *scale, int ld, float *out, int *bandwidth);
 extern "C" void fesom_xinv_sparsify(int n, int ld, const float *M, double tau, int *rowptr, unsigned short *cols, float *vals);
 #define XINV_DROP 1.0e-4      /* entries of the inverse below this fraction of their row's largest are dropped */
 void tile_prepare_tra();
@@ -48,7 +48,10 @@ struct Ctx {
   // partition + halo exchange (npes > 1)
   int npes = 1, mype = 0;
   struct Halo { std::vector<int> rPE, rptr, sPE, sptr; const int *rlist = nullptr, *slist = nullptr; const int *rptr_d = nullptr, *sptr_d = nullptr; int nrecv = 0, nsend = 0; } halo[3];
-  double *hsend = nullptr, *hrecv = nullptr; size_t hcap = 0;
+  double *hsend = nullptr, *hrecv = nullptr; size_t hcap = 0;        // channel 0: exchanges on the step's stream
+  double *hsend1 = nullptr, *hrecv1 = nullptr; size_t hcap1 = 0;     // channel 1: the exchange in flight on the communication stream
+  hipStream_t cstream = nullptr; hipEvent_t ev_prod = nullptr, ev_done = nullptr;
+  long long n_async = 0;
   // communication statistics of the partitioned step (fesom_gpu_comm_stats)
   long long n_exch = 0, n_allred = 0;
   bool comm_timing = false;
@@ -120,20 +123,21 @@ const double *dev_upload_d(const double *h, size_t n) {
 // Explicit-inverse preconditioner (csrc/precond_host.cpp): built on the host from the operator the run starts with, uploaded once.
 // The last matrix is kept per process and reused when the same operator comes again (tests and benches re-initialise often).
 struct XinvCache { std::vector<int> rp, ci; std::vector<double> vals; std::vector<int> mp; std::vector<unsigned short> mc; std::vector<float> mv; } XC;
-int xinv_device(int n, const int *rp, const int *ci, const double *vals, DM &m, std::vector<void *> &owner) {
+int xinv_device(int n, const int *rp, const int *ci, const double *vals, const double *scale, DM &m, std::vector<void *> &owner) {
   const int nza = rp[n];
-  const bool hit = (int)XC.rp.size() == n + 1 && (int)XC.vals.size() == nza && !XC.mp.empty() && !memcmp(XC.rp.data(), rp, sizeof(int) * (n + 1)) &&
+  const bool hit = !scale && (int)XC.rp.size() == n + 1 && (int)XC.vals.size() == nza && !XC.mp.empty() && !memcmp(XC.rp.data(), rp, sizeof(int) * (n + 1)) &&
                    !memcmp(XC.ci.data(), ci, sizeof(int) * nza) && !memcmp(XC.vals.data(), vals, sizeof(double) * nza);
   if (!hit) {
     const int ld = (n + 255) / 256 * 256;
     std::vector<float> M((size_t)n * ld, 0.0f);
     XC.mp.clear();
-    if (fesom_xinv_build(n, rp, ci, vals, ld, M.data(), nullptr)) return 1;
+    if (fesom_xinv_build(n, rp, ci, vals, scale, ld, M.data(), nullptr)) return 1;
     XC.mp.assign(n + 1, 0);
     fesom_xinv_sparsify(n, ld, M.data(), XINV_DROP, XC.mp.data(), nullptr, nullptr);
     XC.mc.assign(XC.mp[n], 0); XC.mv.assign(XC.mp[n], 0.0f);
     fesom_xinv_sparsify(n, ld, M.data(), XINV_DROP, XC.mp.data(), XC.mc.data(), XC.mv.data());
     XC.rp.assign(rp, rp + n + 1); XC.ci.assign(ci, ci + nza); XC.vals.assign(vals, vals + nza);
+    if (scale) XC.rp.clear();                              // (a partition's block: not cached)
   }
   void *dp = nullptr, *dc = nullptr, *dv = nullptr;
   if (hipMalloc(&dp, XC.mp.size() * sizeof(int)) != hipSuccess) return 1;
@@ -579,7 +583,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     m.MLD1_ind = dev_alloc<int>(N);
   }
   G.npes = part ? part->npes : 1; G.mype = part ? part->mype : 0;
-  G.hsend = G.hrecv = nullptr; G.hcap = 0;
+  G.hsend = G.hrecv = nullptr; G.hcap = 0; G.hsend1 = G.hrecv1 = nullptr; G.hcap1 = 0;
   if (part && part->npes > 1) {
     const fesom_com_desc *cs[3] = {&part->com_nod2D, &part->com_elem2D, &part->com_elem2D_full};
     for (int k = 0; k < 3; k++) {
@@ -637,7 +641,24 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     std::vector<int> rp(m.myN + 1), ci(m.nza);
     for (int i = 0; i <= m.myN; i++) rp[i] = d->ssh_rowptr[i] - d->ssh_rowptr[0];
     for (int j = 0; j < m.nza; j++) ci[j] = d->ssh_colind_loc[j] - 1;
-    if (xinv_device(m.myN, rp.data(), ci.data(), d->ssh_values, m, G.allocs)) { m.sv_minv = nullptr; G.err = "fesom_gpu_init: the explicit-inverse SSH preconditioner could not be built (singular operator or out of memory)"; return 1; }
+    if (xinv_device(m.myN, rp.data(), ci.data(), d->ssh_values, nullptr, m, G.allocs)) { m.sv_minv = nullptr; G.err = "fesom_gpu_init: the explicit-inverse SSH preconditioner could not be built (singular operator or out of memory)"; return 1; }
+  }
+  if (par->solver_precond == 1 && G.npes > 1 && m.myN <= 4096 && m.ssh_maxnnz <= 16 && m.myN >= 64) {
+    // partitioned run: every rank inverts the owned-owned block of its rows (block Jacobi with exact blocks; the reference's RAS applies
+    // its ILU factors per rank the same way, bicgstab_ras.c), row scales from the whole rows as in the solver
+    std::vector<int> rp(m.myN + 1, 0), ci; std::vector<double> va, sc(m.myN);
+    const int off = d->ssh_rowptr[0];
+    for (int i = 0; i < m.myN; i++) {
+      double tmp = 0.;
+      for (int q = d->ssh_rowptr[i] - off; q < d->ssh_rowptr[i + 1] - off; q++) {
+        tmp += fabs(d->ssh_values[q]);
+        const int c = d->ssh_colind_loc[q] - 1;
+        if (c < m.myN) { ci.push_back(c); va.push_back(d->ssh_values[q]); }
+      }
+      sc[i] = 1. / tmp;
+      rp[i + 1] = (int)ci.size();
+    }
+    if (xinv_device(m.myN, rp.data(), ci.data(), va.data(), sc.data(), m, G.allocs)) { m.sv_minv = nullptr; G.err = "fesom_gpu_init: the block-inverse SSH preconditioner of this partition could not be built"; return 1; }
   }
   solver_prepare();
   tile_prepare_tra(); tile_prepare_dyn();
@@ -700,20 +721,22 @@ int fesom_gpu_set_forcing(const fesom_forcing_desc *f) {
 }
 
 static int call_named(const char *name, int arg);
+static int halo_pack_on(int kind, int nfields, const char *const *names, void **send_dev, void **recv_dev, int *values_per_item, int ch);
+static int halo_unpack_on(int kind, int nfields, const char *const *names, int ch);
 // ---- partitioned step driven by the library (phase order = fesom2_amd/parallel.py:run_step, which the tests probe phase by
 // phase; both call the same kernels in the same order, so their results are bit-identical for the same transport)
 namespace {
 // one exchange through the built-in transport: a group of ncclSend / ncclRecv, one pair per neighbour, on the library's stream
-int rccl_exchange(int kind, double *sd, double *rd, int W) {
+int rccl_exchange(int kind, double *sd, double *rd, int W, hipStream_t stream) {
   const Ctx::Halo &h = G.halo[kind];
   NCCLCHK(R.GroupStart());
   for (size_t p = 0; p < h.sPE.size(); p++) {
     const size_t first = (size_t)(h.sptr[p] - 1), cnt = (size_t)(h.sptr[p + 1] - h.sptr[p]);
-    if (cnt) NCCLCHK(R.Send(sd + first * W, cnt * W, ncclDouble, h.sPE[p], R.comm, G.stream));
+    if (cnt) NCCLCHK(R.Send(sd + first * W, cnt * W, ncclDouble, h.sPE[p], R.comm, stream));
   }
   for (size_t p = 0; p < h.rPE.size(); p++) {
     const size_t first = (size_t)(h.rptr[p] - 1), cnt = (size_t)(h.rptr[p + 1] - h.rptr[p]);
-    if (cnt) NCCLCHK(R.Recv(rd + first * W, cnt * W, ncclDouble, h.rPE[p], R.comm, G.stream));
+    if (cnt) NCCLCHK(R.Recv(rd + first * W, cnt * W, ncclDouble, h.rPE[p], R.comm, stream));
   }
   NCCLCHK(R.GroupEnd());
   return 0;
@@ -722,21 +745,43 @@ struct PStep {
   const fesom_transport *t;                       // nullptr: the built-in RCCL transport (fesom_gpu_comm_init)
   int rc = 0;
   void c(const char *name, int arg = 0) { if (!rc && call_named(name, arg)) { rc = 1; if (G.err.empty()) G.err = std::string("step_partitioned: unknown phase ") + name; } }
+  // Asynchronous exchange (built-in transport only): pack, the RCCL group and unpack run on the communication stream behind an event
+  // of the step's stream, the step's stream carries on with kernels that do not read the halo and waits in Wt() -- the overlap the
+  // reference has at one place, init_tracers_AB (src/oce_tracer_mod.F90:68-81).  One exchange in flight; any other communication
+  // waits for it first, so the operations of the communicator stay in program order on every rank.
+  bool pending = false;
+  void Wt() { if (pending) { hipStreamWaitEvent(G.stream, G.ev_done, 0); pending = false; } }
+  void XA(int kind, std::initializer_list<const char *> names) {
+    if (rc) return;
+    if (t || !G.cstream) { X(kind, names); return; }
+    Wt();
+    std::vector<const char *> nm(names);
+    void *sd = nullptr, *rd = nullptr; int W = 0;
+    hipEventRecord(G.ev_prod, G.stream); hipStreamWaitEvent(G.cstream, G.ev_prod, 0);
+    if (halo_pack_on(kind, (int)nm.size(), nm.data(), &sd, &rd, &W, 1)) { rc = 1; return; }
+    if (rccl_exchange(kind, (double *)sd, (double *)rd, W, G.cstream)) { rc = 1; return; }
+    if (halo_unpack_on(kind, (int)nm.size(), nm.data(), 1)) { rc = 1; return; }
+    hipEventRecord(G.ev_done, G.cstream);
+    pending = true;
+    G.n_exch++; G.n_async++;
+  }
   void X(int kind, std::initializer_list<const char *> names) {
     if (rc) return;
+    Wt();
     std::vector<const char *> nm(names);        // (no early-out for a rank without neighbours: the transport may be a collective)
     void *sd = nullptr, *rd = nullptr; int W = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (G.comm_timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, G.stream); }
     if (fesom_gpu_halo_pack(kind, (int)nm.size(), nm.data(), &sd, &rd, &W)) { rc = 1; return; }
     if (t) { if (t->exchange(t->ctx, kind, sd, rd, W)) { rc = 1; G.err = "step_partitioned: transport exchange failed"; return; } }
-    else if (rccl_exchange(kind, (double *)sd, (double *)rd, W)) { rc = 1; return; }
+    else if (rccl_exchange(kind, (double *)sd, (double *)rd, W, G.stream)) { rc = 1; return; }
     if (fesom_gpu_halo_unpack(kind, (int)nm.size(), nm.data())) rc = 1;
     if (e0) { hipEventRecord(e1, G.stream); G.comm_ev.push_back({e0, e1}); }
     G.n_exch++;
   }
   void AR(int n) {
     if (rc) return;
+    Wt();
     if (t) { if (t->allreduce_sum(t->ctx, G.m.sv_red, n)) { rc = 1; G.err = "step_partitioned: transport allreduce failed"; } }
     else if (R.AllReduce(G.m.sv_red, G.m.sv_red, (size_t)n, ncclDouble, ncclSum, R.comm, G.stream) != ncclSuccess) { rc = 1; G.err = "step_partitioned: ncclAllReduce failed"; }
     G.n_allred++;
@@ -754,7 +799,7 @@ int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
   const fesom_params &p = G.m.p;
   PStep S{t};
   (void)n;
-  S.c("k_vel_nodes"); S.X(0, {"Unode"});
+  S.c("k_vel_nodes"); S.XA(0, {"Unode"});          // read by k_momadv_node only: in flight under pressure / PGF / slopes / mixing
   S.c("k_pressure_bv"); S.c("k_pgf"); S.c("k_sigma_slope");
   if (p.Redi) S.X(0, {"slope_tapered"});
   if (p.mix_scheme == 2) S.c("k_pp");
@@ -766,6 +811,7 @@ int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
     S.c("k_kpp_final"); S.X(0, {"kpp_viscA", "Kv"});
     S.c("k_kpp_elem");
   }
+  S.Wt();
   S.c("k_momadv_node"); S.X(0, {"Unode_rhs"});
   S.c("k_vel_rhs");
   S.c("k_visc_elem"); S.X(1, {"U_b"});
@@ -774,7 +820,24 @@ int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
   S.c("k_impl_visc");
   if (p.which_ale != 0) S.c("k_stiff_update");
   S.c("k_edge_transport"); S.c("k_ssh_rhs_node");
-  {   // partitioned SSH solve: recurrences of the single-GPU kernel, Krylov scalars + convergence flag on the device
+  if (G.m.sv_minv) {   // partitioned SSH solve, BiCGstab preconditioned with the inverse of each rank's own block (solver.hip "dsx_")
+    S.c("ds_scale"); S.X(0, {"sv_dinv"});
+    S.c("ds_setup"); S.X(0, {"sv_x"});
+    S.c("dsx_init"); S.AR(1); S.c("ds_scal_init");
+    const int poll = 2;
+    double kry[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    while (!S.rc) {
+      for (int k = 0; k < poll; k++) {
+        S.c("dsx_prec0"); S.X(0, {"sv_ph"}); S.c("dsx_spmv1"); S.AR(1); S.c("ds_scal_alpha");
+        S.c("dsx_prec1"); S.X(0, {"sv_sh"}); S.c("dsx_spmv2"); S.AR(4); S.c("ds_scal_omega"); S.c("dsx_update");
+      }
+      HIPCHK(hipMemcpyAsync(kry, G.m.sv_kry, sizeof(kry), hipMemcpyDeviceToHost, G.stream));
+      HIPCHK(hipStreamSynchronize(G.stream));
+      if (kry[7] != 0.0 || kry[6] >= 2000) break;
+    }
+    G.part_iters = (int)kry[6];
+    S.c("dsx_finish");
+  } else {   // partitioned SSH solve: recurrences of the single-GPU kernel, Krylov scalars + convergence flag on the device
     S.c("ds_scale"); S.X(0, {"sv_dinv"});
     S.c("ds_setup"); S.X(0, {"sv_s"});
     S.c("ds_init"); S.AR(1); S.c("ds_scal_init"); S.c("ds_p");
@@ -806,9 +869,10 @@ int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
   S.X(0, {"Wvel", "Wvel_e", "Wvel_i", "hnode_new", "hbar", "hbar_old", "eta_n", "ssh_rhs_old"});
   S.c("k_dhe");
   if (p.Fer_GM) S.c("bolus_add");
-  S.c("k_tr_ab", 0); S.c("k_tr_grad_elem", 0); S.X(2, {"tr_xy_ab"});
-  S.c("k_updn_grad", 0);
+  S.c("k_tr_ab", 0); S.c("k_tr_grad_elem", 0); S.XA(2, {"tr_xy_ab"});       // the reference's own overlap (oce_tracer_mod.F90:68-81)
   S.c("k_tr_z", 0);
+  S.Wt();
+  S.c("k_updn_grad", 0);
   if (p.Redi) S.X(0, {"tr_z"});
   if (p.with_diffusion) S.c("k_diff_flux", 0);
   S.c("k_flux_hor", 0); S.c("k_fct_lo_node", 0); S.X(0, {"fct_LO"});
@@ -816,6 +880,7 @@ int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
   S.c("k_fct_edge_limit", 0); S.c("k_tr_update", 0); S.X(0, {"tr_arr"});
   if (p.Fer_GM) S.c("bolus_remove");
   S.c("k_thick_node"); S.c("k_thick_elem");
+  S.Wt();
   G.first_step = 0;
   HIPCHK(hipGetLastError());
   return S.rc;
@@ -980,6 +1045,7 @@ int fesom_gpu_last_solver_iterations(void) {
   return it;
 }
 int fesom_gpu_tile_shape(void) { return G.ready ? G.m.use_tile : -1; }
+int fesom_gpu_solver_kind(void) { return !G.ready ? -1 : (G.m.sv_minv ? 1 : 0); }
 double fesom_gpu_last_solver_residual(void) {
   if (!G.ready) return -1.0;
   double r = -1.0;
@@ -1118,7 +1184,7 @@ void psolver_init(int *id, int *stype, int *pctype, int *pcilutype, int *iluleve
   // the explicit inverse where it fits, FESOM_GPU_PRECOND=jacobi opts out
   const char *pc = getenv("FESOM_GPU_PRECOND");
   if (!(pc && !strcmp(pc, "jacobi")) && n <= 4096 && n >= 64 && maxnnz <= 10) {
-    if (xinv_device(n, rptr, cols, vals, m, PS.al)) ps_die("psolver_init: the explicit-inverse preconditioner could not be built (singular matrix or out of device memory)");
+    if (xinv_device(n, rptr, cols, vals, nullptr, m, PS.al)) ps_die("psolver_init: the explicit-inverse preconditioner could not be built (singular matrix or out of device memory)");
   }
   solver_prepare();
   PS.n = n; PS.nza = nza; PS.ok = true;
@@ -1183,15 +1249,58 @@ int halo_subfields(int kind, int nf, const char *const *names, std::vector<Sub> 
   }
   return 0;
 }
-int halo_reserve(size_t doubles) {
-  if (doubles <= G.hcap) return 0;
+int halo_reserve(size_t doubles, int ch) {
+  size_t &capr = ch ? G.hcap1 : G.hcap;
+  if (doubles <= capr) return 0;
   size_t cap = doubles * 2;
-  G.hsend = dev_alloc<double>(cap); G.hrecv = dev_alloc<double>(cap);      // (old buffers are released at finalize)
-  if (!G.hsend || !G.hrecv) { G.err = "halo: buffer allocation failed"; return 1; }
-  G.hcap = cap;
+  double *a = dev_alloc<double>(cap), *b2 = dev_alloc<double>(cap);      // (old buffers are released at finalize)
+  if (!a || !b2) { G.err = "halo: buffer allocation failed"; return 1; }
+  if (ch) { G.hsend1 = a; G.hrecv1 = b2; } else { G.hsend = a; G.hrecv = b2; }
+  capr = cap;
   return 0;
 }
 }  // namespace
+
+// channel 0: the step's stream and buffers; channel 1: the communication stream (asynchronous exchange of the built-in transport)
+static int halo_pack_on(int kind, int nfields, const char *const *names, void **send_dev, void **recv_dev, int *values_per_item, int ch) {
+  NEED_READY();
+  if (G.npes < 2) { G.err = "halo: single partition"; return 1; }
+  if (kind < 0 || kind > 2) { G.err = "halo: bad kind"; return 1; }
+  const Ctx::Halo &h = G.halo[kind];
+  std::vector<Sub> subs; int Wtot = 0;
+  if (halo_subfields(kind, nfields, names, subs, Wtot)) return 1;
+  if (halo_reserve((size_t)std::max(h.nsend, h.nrecv) * Wtot, ch)) return 1;
+  hipStream_t st = ch ? G.cstream : G.stream;
+  double *sbuf = ch ? G.hsend1 : G.hsend;
+  int off = 0;
+  for (auto &sb : subs) {
+    long long tot = (long long)h.nsend * sb.W;
+    if (tot > 0) hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, sb.p, sb.W, h.slist, h.sptr_d, (int)h.sPE.size(), h.nsend, Wtot, off, sbuf);
+    off += sb.W;
+  }
+  // stream-ordered: fesom_gpu_copy / fesom_gpu_sync wait for the pack kernels; a transport on the same stream
+  // (fesom_gpu_set_stream) needs no host wait at all
+  HIPCHK(hipGetLastError());
+  *send_dev = sbuf; *recv_dev = ch ? G.hrecv1 : G.hrecv; *values_per_item = Wtot;
+  return 0;
+}
+static int halo_unpack_on(int kind, int nfields, const char *const *names, int ch) {
+  NEED_READY();
+  if (kind < 0 || kind > 2) { G.err = "halo: bad kind"; return 1; }
+  const Ctx::Halo &h = G.halo[kind];
+  std::vector<Sub> subs; int Wtot = 0;
+  if (halo_subfields(kind, nfields, names, subs, Wtot)) return 1;
+  hipStream_t st = ch ? G.cstream : G.stream;
+  const double *rbuf = ch ? G.hrecv1 : G.hrecv;
+  int off = 0;
+  for (auto &sb : subs) {
+    long long tot = (long long)h.nrecv * sb.W;
+    if (tot > 0) hipLaunchKernelGGL(k_halo_unpack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, sb.p, sb.W, h.rlist, h.rptr_d, (int)h.rPE.size(), h.nrecv, Wtot, off, rbuf);
+    off += sb.W;
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 
 extern "C" {
 int fesom_gpu_halo_info(int kind, int *npes, int *mype, int *nr, int *rPE, int *rcnt, int *ns, int *sPE, int *scnt) {
@@ -1206,38 +1315,9 @@ int fesom_gpu_halo_info(int kind, int *npes, int *mype, int *nr, int *rPE, int *
 // packs the send halo of `names` into the device send buffer; returns both device buffers and the number of values per
 // item (a neighbour's block holds count(p) * values_per_item doubles, blocks are consecutive in sPE / rPE order)
 int fesom_gpu_halo_pack(int kind, int nfields, const char *const *names, void **send_dev, void **recv_dev, int *values_per_item) {
-  NEED_READY();
-  if (G.npes < 2) { G.err = "halo: single partition"; return 1; }
-  const Ctx::Halo &h = G.halo[kind];
-  std::vector<Sub> subs; int Wtot = 0;
-  if (halo_subfields(kind, nfields, names, subs, Wtot)) return 1;
-  if (halo_reserve((size_t)std::max(h.nsend, h.nrecv) * Wtot)) return 1;
-  int off = 0;
-  for (auto &sb : subs) {
-    long long tot = (long long)h.nsend * sb.W;
-    if (tot > 0) hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, G.stream, sb.p, sb.W, h.slist, h.sptr_d, (int)h.sPE.size(), h.nsend, Wtot, off, G.hsend);
-    off += sb.W;
-  }
-  // stream-ordered: fesom_gpu_copy / fesom_gpu_sync wait for the pack kernels; a transport on the same stream
-  // (fesom_gpu_set_stream) needs no host wait at all
-  HIPCHK(hipGetLastError());
-  *send_dev = G.hsend; *recv_dev = G.hrecv; *values_per_item = Wtot;
-  return 0;
+  return halo_pack_on(kind, nfields, names, send_dev, recv_dev, values_per_item, 0);
 }
-int fesom_gpu_halo_unpack(int kind, int nfields, const char *const *names) {
-  NEED_READY();
-  const Ctx::Halo &h = G.halo[kind];
-  std::vector<Sub> subs; int Wtot = 0;
-  if (halo_subfields(kind, nfields, names, subs, Wtot)) return 1;
-  int off = 0;
-  for (auto &sb : subs) {
-    long long tot = (long long)h.nrecv * sb.W;
-    if (tot > 0) hipLaunchKernelGGL(k_halo_unpack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, G.stream, sb.p, sb.W, h.rlist, h.rptr_d, (int)h.rPE.size(), h.nrecv, Wtot, off, G.hrecv);
-    off += sb.W;
-  }
-  HIPCHK(hipGetLastError());
-  return 0;
-}
+int fesom_gpu_halo_unpack(int kind, int nfields, const char *const *names) { return halo_unpack_on(kind, nfields, names, 0); }
 // plain copies for hosts that stage through host memory (dir 0: device -> host, 1: host -> device); synchronous
 int fesom_gpu_copy(void *dst, const void *src, long long bytes, int dir) {
   NEED_READY();
@@ -1282,10 +1362,15 @@ int fesom_gpu_comm_init(const void *id128, int nranks, int rank) {
   memcpy(&id, id128, sizeof(id));
   NCCLCHK(R.CommInitRank(&R.comm, nranks, id, rank));
   R.nranks = nranks; R.rank = rank;
+  if (!G.cstream && !getenv("FESOM_GPU_NO_OVERLAP")) {     // communication stream of the asynchronous exchanges
+    if (hipStreamCreateWithFlags(&G.cstream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&G.ev_prod, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&G.ev_done, hipEventDisableTiming) != hipSuccess) { G.cstream = nullptr; G.err = "comm_init: cannot create the communication stream"; return 1; }
+  }
   return 0;
 }
 int fesom_gpu_comm_finalize(void) {
-  if (R.comm) { if (G.ready && G.stream) hipStreamSynchronize(G.stream); R.CommDestroy(R.comm); R.comm = nullptr; }
+  if (R.comm) { if (G.ready && G.stream) hipStreamSynchronize(G.stream); if (G.cstream) hipStreamSynchronize(G.cstream); R.CommDestroy(R.comm); R.comm = nullptr; }
+  if (G.cstream) { hipStreamDestroy(G.cstream); hipEventDestroy(G.ev_prod); hipEventDestroy(G.ev_done); G.cstream = nullptr; }
   R.nranks = 0; R.rank = -1;
   return 0;
 }

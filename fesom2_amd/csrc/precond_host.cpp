@@ -76,8 +76,10 @@ void rcm_order(int n, const int *rp, const int *ci, std::vector<int> &order) {
 }  // namespace
 
 // n rows, 0-based CSR (rp, ci, vals), out: n rows of ld floats (ld >= n; the padding columns are set to 0).
+// `scale` (optional): the row scales to use instead of 1/sum|a_ij| over the given entries -- a rank of a partitioned run inverts the
+// owned-owned block of its rows but scales them like the solver does, with the sums over the WHOLE rows (halo columns included).
 // Returns 0, or 1 if the factorisation meets a zero pivot.  *bandwidth (optional) receives the half bandwidth after RCM.
-extern "C" int fesom_xinv_build(int n, const int *rp, const int *ci, const double *vals, int ld, float *out, int *bandwidth) {
+extern "C" int fesom_xinv_build(int n, const int *rp, const int *ci, const double *vals, const double *scale, int ld, float *out, int *bandwidth) {
   std::vector<int> order, pos(n);
   rcm_order(n, rp, ci, order);
   for (int k = 0; k < n; k++) pos[order[k]] = k;
@@ -90,7 +92,7 @@ extern "C" int fesom_xinv_build(int n, const int *rp, const int *ci, const doubl
   for (int i = 0; i < n; i++) {
     double tmp = 0.;
     for (int q = rp[i]; q < rp[i + 1]; q++) tmp += fabs(vals[q]);
-    const double sc = 1. / tmp;
+    const double sc = scale ? scale[i] : 1. / tmp;
     for (int q = rp[i]; q < rp[i + 1]; q++) ab[(size_t)pos[i] * W + (size_t)(pos[ci[q]] - pos[i] + bw)] = vals[q] * sc;
   }
   for (int k = 0; k < n; k++) {                                 // LU, L below the diagonal (unit), U on and above

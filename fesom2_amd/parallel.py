@@ -281,6 +281,20 @@ class PartitionedCore:
         scalars and the convergence flag on the device; the host only polls the flag every `poll` iterations (phases after
         convergence are no-ops on the device, so the result does not depend on `poll`)."""
         c, X, AR = self.core.call, self.halo.exchange, self._allreduce
+        if self.core.lib.fesom_gpu_solver_kind() == 1:      # block-inverse preconditioner (csrc/solver.hip "dsx_"): same exchanges per iteration
+            c("ds_scale"); X(NOD, ["sv_dinv"])
+            c("ds_setup"); X(NOD, ["sv_x"])
+            c("dsx_init"); AR(1); c("ds_scal_init")
+            while True:
+                for _ in range(2):
+                    c("dsx_prec0"); X(NOD, ["sv_ph"]); c("dsx_spmv1"); AR(1); c("ds_scal_alpha")
+                    c("dsx_prec1"); X(NOD, ["sv_sh"]); c("dsx_spmv2"); AR(4); c("ds_scal_omega"); c("dsx_update")
+                kry = self.core.get("sv_kry", 48)
+                if kry[7] != 0.0 or kry[6] >= MAXITS:
+                    break
+            c("dsx_finish")
+            self.solver_iterations = int(kry[6])
+            return
         c("ds_scale"); X(NOD, ["sv_dinv"])
         c("ds_setup"); X(NOD, ["sv_s"])
         c("ds_init"); AR(1); c("ds_scal_init"); c("ds_p")

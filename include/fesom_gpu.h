@@ -230,6 +230,8 @@ int  fesom_gpu_last_solver_iterations(void);
 /* kernel shape chosen at init: 0 = one column per wave (pi class), > 0 = tiles for CORE2-class meshes (>= 20 000 node columns;
    FESOM_GPU_TILE overrides).  Informational: results do not depend on it. */
 int  fesom_gpu_tile_shape(void);
+/* SSH preconditioner in use: 0 = Jacobi, 1 = explicit (block) inverse -- see fesom_params.solver_precond */
+int  fesom_gpu_solver_kind(void);
 double fesom_gpu_last_solver_residual(void);
 int  fesom_gpu_kernel_time_ms(const char *kernel_group, int nrep, double *ms_per_launch);
 const char *fesom_gpu_last_error(void);
