@@ -802,7 +802,7 @@ int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
   S.c("k_vel_nodes"); S.XA(0, {"Unode"});          // read by k_momadv_node only: in flight under pressure / PGF / slopes / mixing
   S.c("k_pressure_bv"); S.c("k_pgf"); S.c("k_sigma_slope");
   if (p.Redi) S.X(0, {"slope_tapered"});
-  if (p.mix_scheme == 2) S.c("k_pp");
+  if (p.mix_scheme == 2) { S.Wt(); S.c("k_pp"); }      // (the shear of oce_mixing_PP is read at the three nodes of every owned element)
   if (p.mix_scheme == 1) {
     S.c("k_kpp_col"); S.X(0, {"kpp_blmc"});
     S.c("k_kpp_smooth1"); S.X(0, {"kpp_sA"});
@@ -1255,6 +1255,9 @@ int halo_reserve(size_t doubles, int ch) {
   size_t cap = doubles * 2;
   double *a = dev_alloc<double>(cap), *b2 = dev_alloc<double>(cap);      // (old buffers are released at finalize)
   if (!a || !b2) { G.err = "halo: buffer allocation failed"; return 1; }
+  // dev_alloc clears the new buffers on the NULL stream, which the non-blocking communication stream does not wait for: make sure the
+  // clearing is over before a pack kernel writes into them (buffers grow a few times in the first step only)
+  if (hipDeviceSynchronize() != hipSuccess) { G.err = "halo: device synchronisation failed"; return 1; }
   if (ch) { G.hsend1 = a; G.hrecv1 = b2; } else { G.hsend = a; G.hrecv = b2; }
   capr = cap;
   return 0;
