@@ -136,9 +136,16 @@ def pmc_traffic(kernel, workload_key, redi):
         if js.get("workload") != workload_key:
             continue
         kern = js["kernels"]
-        for key in (kernel, kernel + ("<true>" if redi else "<false>")):
-            if key in kern:
-                return kern[key]["traffic_bytes_max"], os.path.relpath(fn, REPO)
+        # kernel names as rocprofv3 prints them: templated kernels keep their arguments (first one of k_tr_update / k_diff_flux = Redi,
+        # k_flux_hor<true> = the fused CORE2-class shape)
+        want = {"k_flux_hor_fused": ("k_flux_hor", "true"), "k_flux_hor": ("k_flux_hor", "false")}.get(kernel, (kernel, "true" if redi else "false"))
+        for key, v in kern.items():
+            base, _, targs = key.partition("<")
+            if base != want[0]:
+                continue
+            if targs and targs.rstrip(">").split(",")[0].strip() in ("true", "false") and targs.rstrip(">").split(",")[0].strip() != want[1]:
+                continue
+            return v["traffic_bytes_max"], os.path.relpath(fn, REPO)
     return None, f"no committed PMC summary for workload '{workload_key}'"
 
 

@@ -73,8 +73,15 @@ GPULIB=$REPO/fesom2_amd
 if [ -f "$GPULIB/libfesom_gpu.so" ]; then
   echo "FC fesom_gpu_shim"
   $FC $FFLAGS -c $GPULIB/fortran/fesom_gpu_shim.F90 -o fesom_gpu_shim.o 2> fesom_gpu_shim.log || { grep -v warning fesom_gpu_shim.log | head -40; exit 1; }
-  $FC $FFLAGS -DWITH_GPU_SHIM -c $HERE/driver.F90 -o driver_gpu.o 2> driver_gpu.log || { grep -v warning driver_gpu.log | head -40; exit 1; }
-  GOBJS=$(echo $OBJS | sed 's/ driver.o/ fesom_gpu_shim.o driver_gpu.o/')
+  # the reference's oce_ale.F90 once more with its time step renamed by the preprocessor (no source edit), so that the NAME
+  # oce_timestep_ale -- what fvom_main.F90:250 calls -- resolves to the repo's drop-in (fesom_gpu_oce_timestep_ale.F90);
+  # module files of this variant go to their own directory
+  mkdir -p gpumod
+  GFLAGS="-cpp -DPARMS -fdefault-real-8 -O2 -I$MPI_INC -I$REF/src -I$REF/lib/parms/include -module-dir $OUT/obj/gpumod -I$OUT/obj"
+  $FC $GFLAGS -Doce_timestep_ale=oce_timestep_ale_cpu -c $S/oce_ale.F90 -o oce_ale_cpuname.o 2> oce_ale_cpuname.log || { grep -v warning oce_ale_cpuname.log | head -40; exit 1; }
+  $FC $FFLAGS -c $GPULIB/fortran/fesom_gpu_oce_timestep_ale.F90 -o fesom_gpu_oce_timestep_ale.o 2> fesom_gpu_oce_timestep_ale.log || { grep -v warning fesom_gpu_oce_timestep_ale.log | head -40; exit 1; }
+  $FC $GFLAGS -DWITH_GPU_SHIM -I$OUT/obj/gpumod -c $HERE/driver.F90 -o driver_gpu.o 2> driver_gpu.log || { grep -v warning driver_gpu.log | head -40; exit 1; }
+  GOBJS=$(echo $OBJS | sed 's/ driver.o/ fesom_gpu_shim.o fesom_gpu_oce_timestep_ale.o driver_gpu.o/; s/ oce_ale.o/ oce_ale_cpuname.o/')
   $FC -O2 -o "$OUT/fesom_gpu_dropin.x" $GOBJS psolve.o "$OUT/libparms.a" -L$MPI_LIB -lmpifort -lmpi -L$GPULIB -lfesom_gpu \
     -Wl,-rpath,$MPI_LIB -Wl,-rpath,/root/repo/fesom2_amd -Wl,-rpath,$GPULIB
   echo "built $OUT/fesom_gpu_dropin.x"

@@ -208,9 +208,11 @@ program oracle_driver
         end if
 #ifdef WITH_GPU_SHIM
      else if (trim(mode)=='gpu') then
-        ! the drop-in: the repo's Fortran host layer in place of compute_vel_nodes + oce_timestep_ale (fvom_main.F90:216,250)
+        ! the drop-in under the reference's own name: in this executable oce_ale.F90 is compiled with -Doce_timestep_ale=oce_timestep_ale_cpu
+        ! and  oce_timestep_ale  is fesom2_amd/fortran/fesom_gpu_oce_timestep_ale.F90 -- the two calls below are fvom_main.F90:216,250 verbatim
         fesom_gpu_profile = gpu_profile
-        call oce_timestep_ale_gpu(n, mesh)
+        call compute_vel_nodes(mesh)
+        call oce_timestep_ale(n, mesh)
         if (any(dump_steps==n)) then
            call fesom_gpu_fetch_state(mesh)
            write(tag,'(A,I4.4)') 'state', n
