@@ -103,21 +103,22 @@ int rccl_load() {
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { G.err = std::string(#x) + ": " + hipGetErrorString(e_); fprintf(stderr, "fesom_gpu: %s\n", G.err.c_str()); return 1; } } while (0)
 
+bool g_alloc_failed = false;                       // any device allocation / upload of fesom_gpu_init that failed (checked at its end)
 template <class T> T *dev_alloc(size_t n) {
   void *p = nullptr;
-  if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+  if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) { g_alloc_failed = true; return nullptr; }
   hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T));
   G.allocs.push_back(p);
   return (T *)p;
 }
 template <class T> const T *dev_upload(const std::vector<T> &h) {
   T *p = dev_alloc<T>(h.size());
-  if (p && !h.empty()) hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+  if (p && !h.empty() && hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) g_alloc_failed = true;
   return p;
 }
 const double *dev_upload_d(const double *h, size_t n) {
   double *p = dev_alloc<double>(n);
-  if (p && n) hipMemcpy(p, h, n * sizeof(double), hipMemcpyHostToDevice);
+  if (p && n && hipMemcpy(p, h, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) g_alloc_failed = true;
   return p;
 }
 // Explicit-inverse preconditioner (csrc/precond_host.cpp): built on the host from the operator the run starts with, uploaded once.
@@ -338,6 +339,7 @@ int fesom_gpu_finalize(void) {
 int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const fesom_params *par) {
   if (G.ready) fesom_gpu_finalize();
   G.err.clear();
+  g_alloc_failed = false;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { G.err = "no HIP device: the MI355X path has no CPU fallback"; fprintf(stderr, "fesom_gpu: %s\n", G.err.c_str()); return 2; }
   if (part && part->npes > 1 && par->toy_soufflet) { G.err = "fesom_gpu_init: the Soufflet toy hooks (global zonal means) are single-partition only"; return 3; }
@@ -355,7 +357,10 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     const char *dv = getenv("FESOM_GPU_DEVICE");
     if (!dv) dv = getenv("LOCAL_RANK");
     int dev = dv ? atoi(dv) : 0;
-    if (dev < 0 || dev >= ndev) dev = 0;
+    if (dev < 0 || dev >= ndev) {     // a mis-set multi-rank launch must not pile every rank on device 0 and still report numbers
+      G.err = std::string("fesom_gpu_init: device index ") + std::to_string(dev) + " (FESOM_GPU_DEVICE / LOCAL_RANK) but only " + std::to_string(ndev) + " HIP device(s) are visible";
+      fprintf(stderr, "fesom_gpu: %s\n", G.err.c_str()); return 2;
+    }
     HIPCHK(hipSetDevice(dev));
   }
   HIPCHK(hipStreamCreate(&G.stream));
@@ -367,6 +372,15 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   // and the HIP runtime bundled with PyTorch 2.10 (ROCm 7.0) recurses without bound in hipStreamEndCapture for this multi-stream
   // capture (the ROCm 7.2 runtime of /opt/rocm is fine), so it stays opt-in for hosts that link the system runtime.
   G.use_graph = getenv("FESOM_GPU_GRAPH") != nullptr;
+  if (G.use_graph) {
+    // the HIP runtime bundled with PyTorch wheels (ROCm 7.0) recurses without bound in hipStreamEndCapture for this multi-stream
+    // capture: refuse graph mode there instead of crashing; the system runtime of /opt/rocm (7.2) is fine
+    Dl_info di;
+    if (dladdr((void *)hipStreamEndCapture, &di) && di.dli_fname && strstr(di.dli_fname, "/torch/")) {
+      fprintf(stderr, "fesom_gpu: FESOM_GPU_GRAPH ignored: libamdhip64 comes from a PyTorch wheel (%s), whose stream capture of a multi-stream step is broken; eager stream DAG used\n", di.dli_fname);
+      G.use_graph = false;
+    }
+  }
   DM &m = G.m;
   memset(&m, 0, sizeof(m));
   m.p = *par;
@@ -625,6 +639,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     m.toy_e_a = dev_upload(ea); m.toy_n_a = dev_upload(na); m.toy_znum = dev_upload(znum);
   }
   for (auto &kv : G.fields) if (!kv.second.p) { G.err = "device allocation failed"; return 1; }
+  if (g_alloc_failed) { G.err = "fesom_gpu_init: a device allocation or upload of the mesh / halo lists failed (out of device memory?)"; fprintf(stderr, "fesom_gpu: %s\n", G.err.c_str()); return 1; }
   HIPCHK(hipMemcpy(m.ssh_values, d->ssh_values, sizeof(double) * m.nza, hipMemcpyHostToDevice));
   {   // Ki = K_hor*(mesh_resolution/100000)**2 (oce_setup_step.F90:328-331); Av/Kv constant when no mixing scheme is selected
     std::vector<double> ki(n1 * N), av(nl * E, par->A_ver), kv(nl * N, par->K_ver);
@@ -1015,7 +1030,10 @@ int fesom_gpu_run_steps(int n_first, int nsteps) {
   for (int k = 0; k < nsteps; k++) {
     int which = G.first_step ? 1 : 0;
     const int n = n_first + k;
-    if (G.use_graph && !G.m.p.toy_soufflet) {          // (the toy hooks depend on the step number: no fixed graph)
+    // graph replay only where the step is a fixed launch sequence: the toy hooks depend on the step number, the multi-workgroup SSH
+    // solve reads its convergence flag back (a host synchronisation is illegal inside a capture)
+    const bool solver_syncs = !G.m.sv_minv && (G.m.myN > 4096 || G.m.ssh_maxnnz > 10);
+    if (G.use_graph && !G.m.p.toy_soufflet && !solver_syncs) {
       if (!G.graph[which] && build_graph(which)) return 1;
       HIPCHK(hipGraphLaunch(G.graph[which], G.stream));
     } else if (!G.serial) {

@@ -118,7 +118,7 @@ class HaloExchanger:
         self.info = []
         for kind in range(3):
             npes, mype, nr, ns = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-            rPE, rc, sPE, sc = ((C.c_int * 64)() for _ in range(4))
+            rPE, rc, sPE, sc = ((C.c_int * 4096)() for _ in range(4))       # (one entry per neighbour rank at most)
             rcode = lib.fesom_gpu_halo_info(kind, C.byref(npes), C.byref(mype), C.byref(nr), rPE, rc, C.byref(ns), sPE, sc)
             assert rcode == 0, lib.fesom_gpu_last_error().decode()
             self.info.append(dict(rPE=list(rPE[: nr.value]), rcnt=list(rc[: nr.value]), sPE=list(sPE[: ns.value]), scnt=list(sc[: ns.value])))

@@ -132,3 +132,74 @@ def test_level_area_and_volume_checks_match_reference_printout(built):
     assert np.allclose(vn, ve, rtol=1e-13)
     tn, te = mesh.total_volume(mesh.initial_state(2))
     assert abs(tn - te) < 1e-3 * tn and tn > 1e17        # (node and element columns differ in their partial bottom cells)
+
+
+def test_explicit_inverse_host_builder_equals_oracle_bitwise():
+    """The SSH preconditioner of pi-class operators is built on the host (csrc/precond_host.cpp: row scaling, reverse Cuthill-McKee,
+    banded LU, substitution, fp32 rounding, drop rule); the oracle restates it in C (oracle/c/orc_xinv.c).  On the pi operator both
+    give the same matrix bit for bit (dense and sparsified), and it is an inverse: max |I - A_s M| < 1e-6 (fp32), 82 entries per row."""
+    import sys
+    from fesom2_amd import _lib
+    from fesom2_amd.mesh import Mesh
+    import oracle_lib
+    lib = _lib.load()
+    oracle_lib.build()
+    orc = C.CDLL(oracle_lib.ORC_LIB)
+    mesh = Mesh.load(os.path.join(REPO, "tests", "golden", "meshes", "pi"), dt=900.0)
+    n = mesh.myDim_nod2D
+    rp = (np.array(mesh.ssh_rowptr[:n + 1]) - mesh.ssh_rowptr[0]).astype(np.int32)
+    ci = (np.array(mesh.ssh_colind_loc) - 1).astype(np.int32)
+    vals = np.ctypeslib.as_array(mesh.desc_p.contents.ssh_values, shape=(int(mesh.ssh_nza),)).copy()
+    ld = (n + 255) // 256 * 256
+    A, B = np.zeros((n, ld), dtype=np.float32), np.zeros((n, ld), dtype=np.float32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert lib.fesom_xinv_build(n, vp(rp), vp(ci), vp(vals), None, ld, vp(A), None) == 0
+    assert orc.orc_xinv_build(n, vp(rp), vp(ci), vp(vals), ld, vp(B)) == 0
+    assert np.array_equal(A.view(np.int32), B.view(np.int32))
+    sc = 1.0 / np.add.reduceat(np.abs(vals), rp[:-1])
+    As = np.zeros((n, n))
+    for i in range(n):
+        As[i, ci[rp[i]:rp[i + 1]]] = vals[rp[i]:rp[i + 1]] * sc[i]
+    assert np.abs(np.eye(n) - As @ A[:, :n].astype(np.float64)).max() < 1e-6
+    out = []
+    for fn in (lib.fesom_xinv_sparsify, orc.orc_xinv_sparsify):
+        fn.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        mp = np.zeros(n + 1, dtype=np.int32)
+        fn(n, ld, vp(A), 1e-4, vp(mp), None, None)
+        mc, mv = np.zeros(mp[n], dtype=np.uint16), np.zeros(mp[n], dtype=np.float32)
+        fn(n, ld, vp(A), 1e-4, vp(mp), vp(mc), vp(mv))
+        out.append((mp, mc, mv))
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+    assert 60 < out[0][0][n] / n < 110
+
+
+def test_psolver_init_refuses_a_block_of_a_multi_rank_partition(tmp_path):
+    """psolver_init / psolve keep the reference's void signatures (src/psolve.c:16,152), so a violated precondition cannot be
+    returned: the library prints one line and exits with status 3 -- a block of a multi-rank partition (row offset, or global
+    column indices) and a non-zero rptr[0] are refused before any device work."""
+    import sys
+    import textwrap
+    script = tmp_path / "p.py"
+    script.write_text(textwrap.dedent(f"""
+        import ctypes as C, sys
+        import numpy as np
+        sys.path.insert(0, {REPO!r})
+        from fesom2_amd import _lib
+        lib = _lib.load()
+        case = sys.argv[1]
+        n = 4
+        rptr = np.array([0, 2, 4, 6, 8], dtype=np.int32); cols = np.array([0, 1, 1, 2, 2, 3, 3, 0], dtype=np.int32)
+        vals = np.array([2., -1.] * 4); part = np.array([0, n], dtype=np.int32)
+        if case == "offset": part = np.array([4, 8], dtype=np.int32)
+        if case == "global_cols": cols[1] = 7
+        if case == "rptr0": rptr = rptr + 1
+        one = C.c_int(1); z = C.c_int(0); tol = C.c_double(1e-10); mi = C.c_int(2000); dt = C.c_double(1e-8)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        lib.psolver_init(C.byref(one), C.byref(one), C.byref(one), C.byref(one), C.byref(one), C.byref(one), C.byref(dt), C.byref(mi),
+                         C.byref(one), C.byref(tol), p(part), p(rptr), p(cols), p(vals), C.byref(z), C.byref(z))
+        print("returned")
+    """))
+    for case, text in (("offset", "part[0] != 0"), ("global_cols", "column index outside"), ("rptr0", "rptr[0] must be 0")):
+        r = subprocess.run([sys.executable, str(script), case], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 3 and text in r.stderr and "returned" not in r.stdout, (case, r.returncode, r.stderr[-400:])
