@@ -299,6 +299,22 @@ def main():
         ref_state = {"eta_n": core.get("eta_n", mesh.nod2D), "tr_arr": core.get("tr_arr", 2 * mesh.nod2D * n1).reshape(2, mesh.nod2D, n1)}
         core.close(); core = None
         pc = None
+        # A point-to-point operation that never completes (a wedged link, a rank that died) would hang this process for ever: RCCL send /
+        # recv has no timeout of its own.  A watchdog ends the run with a diagnosable line instead: the replicas' figures, value = null.
+        import threading
+        limit = float(os.environ.get("FESOM_BENCH_PARTITIONED_TIMEOUT", "420"))
+
+        def _give_up():
+            if rank == 0:
+                print(json.dumps({"metric": "SYPD (simulated years/day) on pi mesh, 47 z-levels", "value": None, "unit": "simulated_years/day", "n_gpus": world,
+                                  "steps": steps, "warmup": warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                                  "dtype": "f64", "data": "synthetic", "config": {"workload": wl.text, "parallelism": f"one simulation partitioned over {world} GPUs -- TIMED OUT"},
+                                  "partitioned": {"error": f"the partitioned leg did not finish within {limit:.0f} s (communication hang?)"},
+                                  "replicas": {"value": round(sypd_one * world, 2), "unit": "simulated_years/day", "ms_per_step": round(sps * 1e3, 5), "scaling": "weak"}}), flush=True)
+            os._exit(3)
+        watchdog = threading.Timer(limit, _give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             import datetime
             from fesom2_amd import parallel
@@ -359,6 +375,7 @@ def main():
         except Exception as e:          # noqa: BLE001 -- recorded, never replaced by another metric
             partitioned = {"error": f"{type(e).__name__}: {e}"[:2000]}
         finally:
+            watchdog.cancel()
             if pc is not None:
                 try:
                     pc.close()

@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(BLOCK) k_vel_rhs(DM m, int first_step) {
 // ------------------------------------------------------------------------------------------------
 // visc_filt_bcksct (src/oce_dyn.F90:563-649): (1) element gather over its <=3 internal edges,
 // (2) node average, (3) apply (fused into k_impl_visc).  4 N3 + 12 E3 values.
-// visc_option 6 / 7 (visc_filt_bilapl :658-726, visc_filt_bidiff :734-801): the same gather is the first stage of the
+// visc_option 4 / 6 / 7 (visc_filt_biharm(1) :275-372, visc_filt_bilapl :658-726, visc_filt_bidiff :734-801): the same gather is the first stage of the
 // biharmonic operator (the result lives in U_b, the reference's U_c/V_c), the second stage is k_visc_apply.
 __global__ void __launch_bounds__(BLOCK) k_visc_elem(DM m) {
   int e = col_id(), nz = lane_id() + 1;
@@ -429,6 +429,12 @@ __global__ void __launch_bounds__(BLOCK) k_visc_elem(DM m) {
     double len = sqrt(m.elem_area[e]);
     double u1 = ub * ub + vb * vb;
     double vi = dmax_(g0, dmax_(g1 * sqrt(u1), g2 * u1)) * len * dt;
+    ub = -ub * vi; vb = -vb * vi;
+  }
+  if (opt == 4 && nz >= m.ulev[e] && nz <= m.nlev[e] - 1) {    // visc_filt_biharm(1) :314-331: "an analog to the third-order upwind", vi = gamma1 |u| l
+    double len = sqrt(m.elem_area[e]);
+    double uu = DV2(m.UV, 1, nz, e), vv = DV2(m.UV, 2, nz, e);
+    double vi = dmax_(g0, g1 * sqrt(uu * uu + vv * vv)) * len * dt;
     ub = -ub * vi; vb = -vb * vi;
   }
   DV2(m.U_b, 1, nz, e) = ub;

@@ -439,6 +439,15 @@ static void visc_filt_biharmonic(int opt) {
         V2(Uc, 2, nz, e) = -V2(Uc, 2, nz, e) * vi;
       }
     }
+  if (opt == 4)                                  /* visc_filt_biharm(option = 1), src/oce_dyn.F90:314-331 */
+    for (int e = 1; e <= C_.m.myDim_elem2D; e++) {
+      double len = sqrt(C_.m.elem_area[e - 1]);
+      for (int nz = ULEV(e); nz <= NLEV(e) - 1; nz++) {
+        double vi = dmax(g0, g1 * sqrt(V2(C_.UV, 1, nz, e) * V2(C_.UV, 1, nz, e) + V2(C_.UV, 2, nz, e) * V2(C_.UV, 2, nz, e))) * len * dt;
+        V2(Uc, 1, nz, e) = -V2(Uc, 1, nz, e) * vi;
+        V2(Uc, 2, nz, e) = -V2(Uc, 2, nz, e) * vi;
+      }
+    }
   /* (exchange_elem(U_c), exchange_elem(V_c): single partition) */
   for (int ed = 1; ed <= C_.D; ed++) {
     if (C_.m.myList_edge2D[ed - 1] > C_.m.edge2D_in) continue;
@@ -480,7 +489,7 @@ double orc_kv0_background_qiang(int n, int nz) {
   return aux * ratio;
 }
 
-/* viscosity_filter(visc_option): src/oce_dyn.F90:196-228 (options 5, 6, 7) */
+/* viscosity_filter(visc_option): src/oce_dyn.F90:196-228 (options 4, 5, 6, 7) */
 void orc_viscosity_filter(void) {
   if (C_.p.visc_option == 5) orc_visc_filt_bcksct();
   else visc_filt_biharmonic(C_.p.visc_option);

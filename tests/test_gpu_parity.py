@@ -425,9 +425,9 @@ def test_profile_step_is_the_same_step(built, case):
     gpu.close()
 
 
-@pytest.mark.parametrize("opt", [6, 7])
+@pytest.mark.parametrize("opt", [4, 6, 7])
 def test_biharmonic_viscosity_chain_bitwise(built, opt):
-    """visc_option 6 / 7 (visc_filt_bilapl, visc_filt_bidiff; oracle pinned on the reference runs pi_pp_visc6 / pi_pp_visc7): HIP == oracle
+    """visc_option 4 / 6 / 7 (visc_filt_biharm(1), visc_filt_bilapl, visc_filt_bidiff; oracle pinned on the reference runs pi_pp_visc4 / 6 / 7): HIP == oracle
     bit for bit after every routine of 3 steps under surface forcing."""
     from fesom2_amd.mesh import Mesh
     from fesom2_amd.config import make_params
@@ -459,7 +459,7 @@ def test_biharmonic_viscosity_chain_bitwise(built, opt):
     gpu.close()
 
 
-@pytest.mark.parametrize("field,value,msg", [("visc_option", 4, "visc_option"), ("visc_option", 8, "visc_option"), ("tra_adv_ver", 4, "tra_adv_ver"),
+@pytest.mark.parametrize("field,value,msg", [("visc_option", 3, "visc_option"), ("visc_option", 8, "visc_option"), ("tra_adv_ver", 4, "tra_adv_ver"),
                                              ("tra_adv_ver", -1, "tra_adv_ver"), ("tra_adv_hor", 3, "tra_adv_hor"), ("mom_adv", 3, "mom_adv"),
                                              ("mix_scheme", 3, "mix_scheme")])
 def test_init_refuses_options_it_does_not_implement(built, field, value, msg):

@@ -208,10 +208,10 @@ def test_oracle_chain_bitwise_w_split(built):
     assert np.count_nonzero(wi) > 1000                     # the split is really active
 
 
-@pytest.mark.parametrize("opt", [6, 7])
+@pytest.mark.parametrize("opt", [4, 6, 7])
 def test_oracle_chain_bitwise_biharmonic_viscosity(built, opt):
-    """visc_option = 6 (visc_filt_bilapl, src/oce_dyn.F90:658-726) and 7 (visc_filt_bidiff, :734-801) instead of the easy backscatter:
-    reference runs `pi_pp_visc6` / `pi_pp_visc7` (PP mixing, surface forcing), every routine of 3 steps bit for bit."""
+    """visc_option = 4 (visc_filt_biharm(1), src/oce_dyn.F90:275-372), 6 (visc_filt_bilapl, :658-726) and 7 (visc_filt_bidiff, :734-801) instead
+    of the easy backscatter: reference runs `pi_pp_visc4` / `pi_pp_visc6` / `pi_pp_visc7` (PP mixing, surface forcing), every routine of 3 steps bit for bit."""
     from fesom2_amd.mesh import Mesh
     from fesom2_amd.config import make_params
     from fesom2_amd.synthetic import analytic_ts
