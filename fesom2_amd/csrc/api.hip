@@ -52,6 +52,7 @@ struct Ctx {
   double *hsend1 = nullptr, *hrecv1 = nullptr; size_t hcap1 = 0;     // channel 1: the exchange in flight on the communication stream
   hipStream_t cstream = nullptr; hipEvent_t ev_prod = nullptr, ev_done = nullptr;
   long long n_async = 0;
+  bool toy_znum_global = false;                       // partitioned Soufflet channel: the per-bin element counts have been summed over the ranks
   // communication statistics of the partitioned step (fesom_gpu_comm_stats)
   long long n_exch = 0, n_allred = 0;
   bool comm_timing = false;
@@ -342,7 +343,6 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   g_alloc_failed = false;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { G.err = "no HIP device: the MI355X path has no CPU fallback"; fprintf(stderr, "fesom_gpu: %s\n", G.err.c_str()); return 2; }
-  if (part && part->npes > 1 && par->toy_soufflet) { G.err = "fesom_gpu_init: the Soufflet toy hooks (global zonal means) are single-partition only"; return 3; }
   if (d->nl > 64) { G.err = "fesom_gpu_init: nl > 64 levels not supported by the one-wave-per-column kernels"; return 3; }
   if (par->which_ale != 0 && par->which_ale != 2) { G.err = "fesom_gpu_init: which_ale must be linfs(0) or zstar(2)"; return 3; }
   if (par->mom_adv != 2 || par->visc_option < 4 || par->visc_option > 7) { G.err = "fesom_gpu_init: only mom_adv=2, visc_option=4,5,6,7 are implemented"; return 3; }
@@ -597,7 +597,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     m.MLD1_ind = dev_alloc<int>(N);
   }
   G.npes = part ? part->npes : 1; G.mype = part ? part->mype : 0;
-  G.hsend = G.hrecv = nullptr; G.hcap = 0; G.hsend1 = G.hrecv1 = nullptr; G.hcap1 = 0;
+  G.hsend = G.hrecv = nullptr; G.hcap = 0; G.hsend1 = G.hrecv1 = nullptr; G.hcap1 = 0; G.toy_znum_global = false;
   if (part && part->npes > 1) {
     const fesom_com_desc *cs[3] = {&part->com_nod2D, &part->com_elem2D, &part->com_elem2D_full};
     for (int k = 0; k < 3; k++) {
@@ -794,12 +794,21 @@ struct PStep {
     if (e0) { hipEventRecord(e1, G.stream); G.comm_ev.push_back({e0, e1}); }
     G.n_exch++;
   }
-  void AR(int n) {
+  void ARp(double *buf, int n) {                  // global sum over the ranks of n doubles at a device address, in place
     if (rc) return;
     Wt();
-    if (t) { if (t->allreduce_sum(t->ctx, G.m.sv_red, n)) { rc = 1; G.err = "step_partitioned: transport allreduce failed"; } }
-    else if (R.AllReduce(G.m.sv_red, G.m.sv_red, (size_t)n, ncclDouble, ncclSum, R.comm, G.stream) != ncclSuccess) { rc = 1; G.err = "step_partitioned: ncclAllReduce failed"; }
+    if (t) { if (t->allreduce_sum(t->ctx, buf, n)) { rc = 1; G.err = "step_partitioned: transport allreduce failed"; } }
+    else if (R.AllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, R.comm, G.stream) != ncclSuccess) { rc = 1; G.err = "step_partitioned: ncclAllReduce failed"; }
     G.n_allred++;
+  }
+  void AR(int n) { ARp(G.m.sv_red, n); }
+  // compute_zonal_mean of the Soufflet channel on a partition (src/toy_channel_soufflet.F90:157-217): local sums, the two global sums
+  // of the reference (plus, once, the one of compute_zonal_mean_ini :141-150 for the element counts), division
+  void zonal() {
+    c("toy_zonal_sum");
+    if (!G.toy_znum_global) { ARp((double *)G.m.toy_znum, 100); G.toy_znum_global = !rc; }
+    ARp(G.m.toy_zvel, 100 * G.m.nlm1); ARp(G.m.toy_ztem, 100 * G.m.nlm1);
+    c("toy_zonal_div");
   }
 };
 }  // namespace
@@ -813,7 +822,8 @@ int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
   }
   const fesom_params &p = G.m.p;
   PStep S{t};
-  (void)n;
+  const bool toy = p.toy_soufflet != 0;
+  if (toy && n % 10 == 0) S.zonal();                  // before_oce_step (oce_setup_step.F90:625-630)
   S.c("k_vel_nodes"); S.XA(0, {"Unode"});          // read by k_momadv_node only: in flight under pressure / PGF / slopes / mixing
   S.c("k_pressure_bv"); S.c("k_pgf"); S.c("k_sigma_slope");
   if (p.Redi) S.X(0, {"slope_tapered"});
@@ -871,6 +881,7 @@ int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
     S.c("ds_finish");
   }
   S.X(0, {"d_eta"});
+  if (toy) S.c("relax_zonal_vel");                    // oce_ale.F90:2696
   if (p.Redi && !p.Fer_GM) { S.c("init_Redi_GM"); S.X(0, {"Ki"}); }
   if (p.Fer_GM) {
     S.c("init_Redi_GM");
@@ -892,11 +903,27 @@ int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
   if (p.with_diffusion) S.c("k_diff_flux", 0);
   S.c("k_flux_hor", 0); S.c("k_fct_lo_node", 0); S.X(0, {"fct_LO"});
   S.c("k_fct_node", 0); S.X(0, {"fct_plus", "fct_minus"});
-  S.c("k_fct_edge_limit", 0); S.c("k_tr_update", 0); S.X(0, {"tr_arr"});
+  S.c("k_fct_edge_limit", 0); S.c("k_tr_update", 0);
+  if (toy) for (int tr = 0; tr < G.m.ntr; tr++) S.c("relax_zonal_temp");     // once per tracer of the loop, always on tracer 1 (oce_ale_tracer.F90:150)
+  S.X(0, {"tr_arr"});
   if (p.Fer_GM) S.c("bolus_remove");
   S.c("k_thick_node"); S.c("k_thick_elem");
   S.Wt();
   G.first_step = 0;
+  HIPCHK(hipGetLastError());
+  return S.rc;
+}
+
+// zonal means of a partitioned Soufflet channel outside a step (the set-up calls compute_zonal_mean once before the first step,
+// toy_channel_soufflet.F90:343); t == NULL: the built-in transport
+int fesom_gpu_toy_zonal_mean(const fesom_transport *t) {
+  NEED_READY();
+  if (!G.m.p.toy_soufflet) { G.err = "toy_zonal_mean: not a Soufflet channel run"; return 1; }
+  if (G.npes < 2) return call_named("compute_zonal_mean", 0);
+  if (t && !t->allreduce_sum) { G.err = "toy_zonal_mean: transport callbacks missing"; return 1; }
+  if (!t && (!R.comm || R.nranks != G.npes)) { G.err = "toy_zonal_mean: the built-in transport is not initialised"; return 1; }
+  PStep S{t};
+  S.zonal();
   HIPCHK(hipGetLastError());
   return S.rc;
 }

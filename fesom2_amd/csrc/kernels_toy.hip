@@ -26,6 +26,30 @@ __global__ void __launch_bounds__(BLOCK) k_toy_zonal_mean(DM m) {
   m.toy_ztem[(size_t)b * m.nlm1 + nz - 1] = zt / (cnt + 0.001);
 }
 
+// Partitioned runs: the rank-local sums (every element once: where its first node is owned, :167) first, then the host's / the
+// library's all-reduce over the ranks (the two MPI_AllREDUCE of :182-203), then the division by the global count.
+__global__ void __launch_bounds__(BLOCK) k_toy_zonal_sum(DM m) {
+  int b = col_id(), nz = lane_id() + 1;
+  if (b >= 100 || nz > m.nlm1) return;
+  double zt = 0.0, zv = 0.0;
+  for (int q = m.toy_bptr[b]; q < m.toy_bptr[b + 1]; q++) {
+    int e = m.toy_bidx[q];
+    if (nz > m.nlev[e] - 1) continue;
+    int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
+    zt = zt + ((DTR(m.tr_arr, nz, n1, 0) + DTR(m.tr_arr, nz, n2, 0)) + DTR(m.tr_arr, nz, n3, 0)) / 3.0;
+    zv = zv + DV2(m.UV, 1, nz, e);
+  }
+  m.toy_zvel[(size_t)b * m.nlm1 + nz - 1] = zv;
+  m.toy_ztem[(size_t)b * m.nlm1 + nz - 1] = zt;
+}
+__global__ void __launch_bounds__(BLOCK) k_toy_zonal_div(DM m) {
+  int b = col_id(), nz = lane_id() + 1;
+  if (b >= 100 || nz > m.nlm1) return;
+  double cnt = m.toy_znum[b];
+  m.toy_zvel[(size_t)b * m.nlm1 + nz - 1] = m.toy_zvel[(size_t)b * m.nlm1 + nz - 1] / (cnt + 0.001);
+  m.toy_ztem[(size_t)b * m.nlm1 + nz - 1] = m.toy_ztem[(size_t)b * m.nlm1 + nz - 1] / (cnt + 0.001);
+}
+
 // relax_zonal_vel (:46-79)
 __global__ void __launch_bounds__(BLOCK) k_toy_relax_vel(DM m) {
   int e = col_id(), nz = lane_id() + 1;
@@ -52,6 +76,8 @@ __global__ void __launch_bounds__(BLOCK) k_toy_relax_temp(DM m) {
 int launch_named_toy(const DM &m, hipStream_t s, const char *name) {
   if (!m.p.toy_soufflet) return -1;
   if (!strcmp(name, "compute_zonal_mean") || !strcmp(name, "k_toy_zonal_mean")) { LAUNCH_COL(k_toy_zonal_mean, 100, m); return 0; }
+  if (!strcmp(name, "toy_zonal_sum")) { LAUNCH_COL(k_toy_zonal_sum, 100, m); return 0; }
+  if (!strcmp(name, "toy_zonal_div")) { LAUNCH_COL(k_toy_zonal_div, 100, m); return 0; }
   if (!strcmp(name, "relax_zonal_vel") || !strcmp(name, "k_toy_relax_vel")) { LAUNCH_COL(k_toy_relax_vel, m.myE, m); return 0; }
   if (!strcmp(name, "relax_zonal_temp") || !strcmp(name, "k_toy_relax_temp")) { LAUNCH_COL(k_toy_relax_temp, m.N, m); return 0; }
   return -1;

@@ -427,12 +427,15 @@ contains
   integer(c_int) function mpi_allreduce_sum(ctx, buf_dev, n) bind(C)
     type(c_ptr), value :: ctx, buf_dev
     integer(c_int), value :: n
-    real(kind=WP) :: loc(8)
+    real(kind=WP), allocatable, target, save :: loc(:), glo(:)      ! (<= 4 values in the solver, 100*(nl-1) in the Soufflet zonal means)
     integer :: ierr
-    mpi_allreduce_sum = c_fesom_gpu_copy(c_loc(hred), buf_dev, int(n, c_long_long)*8_c_long_long, 0_c_int)
-    loc(1:n) = hred(1:n)
-    call MPI_ALLREDUCE(loc, hred, n, MPI_DOUBLE_PRECISION, MPI_SUM, MPI_COMM_FESOM, ierr)
-    if (c_fesom_gpu_copy(buf_dev, c_loc(hred), int(n, c_long_long)*8_c_long_long, 1_c_int) /= 0) mpi_allreduce_sum = 1
+    if (.not. allocated(loc)) allocate(loc(max(n, 8)), glo(max(n, 8)))
+    if (size(loc) < n) then
+       deallocate(loc, glo); allocate(loc(n), glo(n))
+    end if
+    mpi_allreduce_sum = c_fesom_gpu_copy(c_loc(loc), buf_dev, int(n, c_long_long)*8_c_long_long, 0_c_int)
+    call MPI_ALLREDUCE(loc, glo, n, MPI_DOUBLE_PRECISION, MPI_SUM, MPI_COMM_FESOM, ierr)
+    if (c_fesom_gpu_copy(buf_dev, c_loc(glo), int(n, c_long_long)*8_c_long_long, 1_c_int) /= 0) mpi_allreduce_sum = 1
   end function
 
   subroutine fesom_gpu_fetch_state(mesh)

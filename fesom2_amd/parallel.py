@@ -34,12 +34,15 @@ NOD, ELEM, ELEM_FULL = 0, 1, 2
 MAXITS = 2000
 
 
-def run_step(core, par, X, solve, first, probe=None):
+def run_step(core, par, X, solve, first, probe=None, n=1, zonal=None):
     """One step, phase by phase (kernel names of libfesom_gpu.so).  X(kind, fields) = halo exchange, solve() = SSH solve;
-    `probe(label)` (optional) is called after the phases whose results the tests compare across partitions."""
+    `probe(label)` (optional) is called after the phases whose results the tests compare across partitions; n = step number and
+    zonal() = the partitioned compute_zonal_mean, both only used by the Soufflet channel hooks."""
     c, p = core.call, par
     P = probe if probe is not None else (lambda label: None)
     c("first_step", 1 if first else 0)
+    if p.toy_soufflet and n % 10 == 0:                # before_oce_step (oce_setup_step.F90:625-630)
+        zonal() if zonal is not None else c("compute_zonal_mean")
     c("k_vel_nodes"); X(NOD, ["Unode"]); P("vel_nodes")
     c("k_pressure_bv"); c("k_pgf"); c("k_sigma_slope"); P("pressure")
     if p.Redi:
@@ -65,6 +68,8 @@ def run_step(core, par, X, solve, first, probe=None):
         c("k_stiff_update")
     c("k_edge_transport"); c("k_ssh_rhs_node"); P("ssh_rhs")
     solve(); X(NOD, ["d_eta"]); P("solve")
+    if p.toy_soufflet:
+        c("relax_zonal_vel")                          # oce_ale.F90:2696
     if p.Redi and not p.Fer_GM:
         c("init_Redi_GM"); X(NOD, ["Ki"])
     if p.Fer_GM:                                      # bolus velocities (oce_fer_gm.F90), before vert_vel_ale moves hnode_new
@@ -87,7 +92,11 @@ def run_step(core, par, X, solve, first, probe=None):
         c("k_diff_flux", 0)
     c("k_flux_hor", 0); c("k_fct_lo_node", 0); X(NOD, ["fct_LO"])
     c("k_fct_node", 0); X(NOD, ["fct_plus", "fct_minus"])
-    c("k_fct_edge_limit", 0); c("k_tr_update", 0); X(NOD, ["tr_arr"]); P("tracers")
+    c("k_fct_edge_limit", 0); c("k_tr_update", 0)
+    if p.toy_soufflet:
+        for _ in range(p.num_tracers):                # once per tracer of the loop, always on tracer 1 (oce_ale_tracer.F90:150)
+            c("relax_zonal_temp")
+    X(NOD, ["tr_arr"]); P("tracers")
     if p.Fer_GM:
         c("bolus_remove")
     c("k_thick_node"); c("k_thick_elem"); P("thickness")
@@ -232,8 +241,12 @@ class PartitionedCore:
             assert lib.fesom_gpu_field_ptr(b"sv_red", C.byref(ptr), C.byref(cnt)) == 0
             self.red_dev = self.halo.dev_tensor(ptr.value, int(cnt.value))
         self._steps = 0
+        self.core.lib.fesom_gpu_toy_zonal_mean.argtypes = [C.c_void_p]
         if wl is not None:
             wl.start(self.core, self.mesh)
+            if params.toy_soufflet and self.world > 1:
+                self.halo.exchange(ELEM, ["UV"])      # call exchange_elem(UV) of initial_state_soufflet (toy_channel_soufflet.F90:327)
+                self.zonal_mean()                     # (wl.start formed rank-local means: redo them over all ranks)
 
     def _init_builtin_transport(self):
         """RCCL communicator of the library: rank 0 draws the unique id, torch.distributed carries the 128 bytes to the others
@@ -309,13 +322,27 @@ class PartitionedCore:
         self.solver_iterations = int(kry[6])
 
     def step(self, n=1, probe=None):
-        run_step(self.core, self.par, self.halo.exchange, self.solve_ssh, self.first, probe)
+        run_step(self.core, self.par, self.halo.exchange, self.solve_ssh, self.first, probe, n=n, zonal=self.zonal_mean)
         self.first = False
+
+    def zonal_mean(self):
+        """compute_zonal_mean of the Soufflet channel over all ranks (rank-local sums on the device, global sums through the
+        transport, division): fesom_gpu_toy_zonal_mean"""
+        tr = None if (self.transport == "rccl" and self.world > 1) else C.byref(self._get_transport())
+        self.core._chk(self.core.lib.fesom_gpu_toy_zonal_mean(tr), "toy_zonal_mean")
 
     def step_native(self, n=1):
         """The same step driven by the library (fesom_gpu_step_partitioned, include/fesom_gpu.h): the phase loop and the solver
         loop run in C++, this host only supplies the two transport callbacks -- what a Fortran/MPI host does as well
         (fesom2_amd/fortran/fesom_gpu_shim.F90)."""
+        self._get_transport()
+        self.core.call("first_step", 1 if self.first else 0)
+        tr = None if (self.transport == "rccl" and self.world > 1) else C.byref(self._transport)
+        self.core._chk(self.core.lib.fesom_gpu_step_partitioned(int(n), tr), "step_partitioned")
+        self.first = False
+        self.solver_iterations = self.core.lib.fesom_gpu_last_solver_iterations()
+
+    def _get_transport(self):
         if not hasattr(self, "_transport"):
             halo, lib, grp = self.halo, self.core.lib, self.group
 
@@ -330,7 +357,7 @@ class PartitionedCore:
             def allreduce(ctx, buf, n):
                 try:
                     if halo.device:
-                        dist.all_reduce(halo.dev_tensor(buf, 8)[:n], group=grp)
+                        dist.all_reduce(halo.dev_tensor(buf, n), group=grp)
                     else:
                         h = np.empty(n)
                         halo._chk(lib.fesom_gpu_copy(h.ctypes.data, C.c_void_p(buf), n * 8, 0), "copy d2h")
@@ -343,11 +370,7 @@ class PartitionedCore:
 
             self._cb = (_lib.TRANSPORT_EXCHANGE(exchange), _lib.TRANSPORT_ALLREDUCE(allreduce))     # keep the thunks alive
             self._transport = _lib.Transport(None, self._cb[0], self._cb[1])
-        self.core.call("first_step", 1 if self.first else 0)
-        tr = None if (self.transport == "rccl" and self.world > 1) else C.byref(self._transport)
-        self.core._chk(self.core.lib.fesom_gpu_step_partitioned(int(n), tr), "step_partitioned")
-        self.first = False
-        self.solver_iterations = self.core.lib.fesom_gpu_last_solver_iterations()
+        return self._transport
 
     def owned(self, name, width):
         """(global ids, values) of the owned part of a node field with `width` values per node"""

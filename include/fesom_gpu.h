@@ -189,6 +189,9 @@ typedef struct fesom_transport {
   int (*allreduce_sum)(void *ctx, void *buf_dev, int n);
 } fesom_transport;
 int  fesom_gpu_step_partitioned(int n, const fesom_transport *t);   /* t == NULL: the built-in RCCL transport below */
+/* Soufflet channel on a partition: compute_zonal_mean (src/toy_channel_soufflet.F90:157-217: rank-local sums, global sums, division)
+ * outside a step -- the set-up calls it once before the first step; inside fesom_gpu_step_partitioned it runs every 10th step. */
+int  fesom_gpu_toy_zonal_mean(const fesom_transport *t);
 
 /* ---- built-in transport: RCCL send/recv over xGMI issued by the library itself (replaces exchange_nod / exchange_elem,
  * src/gen_halo_exchange.F90:58-1035, and the MPI_Allreduce of pARMS' dot products, lib/parms/src/parms_comm.c:205-356).

@@ -22,7 +22,7 @@ constexpr size_t CAP = 6u << 20;
 struct Mailbox { std::atomic<uint64_t> written, consumed; uint64_t bytes; char data[CAP]; };
 struct Shm {
   std::atomic<int> count; std::atomic<int> sense;
-  double red[MAXR][64];
+  double red[MAXR][8192];
   Mailbox mb[MAXR][MAXR];
 };
 struct Comm { Shm *s; int n, rank; int local_sense; char name[64]; };
@@ -114,11 +114,11 @@ ncclResult_t ncclRecv(void *buf, size_t count, ncclDataType_t t, int peer, ncclC
 }
 ncclResult_t ncclAllReduce(const void *sb, void *rb, size_t count, ncclDataType_t t, ncclRedOp_t op, ncclComm_t comm, hipStream_t st) {
   Comm *c = (Comm *)comm;
-  if (t != ncclDouble || op != ncclSum || count > 64) return ncclInvalidArgument;
+  if (t != ncclDouble || op != ncclSum || count > 8192) return ncclInvalidArgument;
   if (hipStreamSynchronize(st) != hipSuccess) return ncclUnhandledCudaError;
   if (hipMemcpy(c->s->red[c->rank], sb, count * 8, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
   if (!barrier(c)) return ncclSystemError;
-  double out[64];
+  static thread_local double out[8192];
   for (size_t i = 0; i < count; i++) { double a = 0.0; for (int r = 0; r < c->n; r++) a += c->s->red[r][i]; out[i] = a; }
   if (!barrier(c)) return ncclSystemError;
   if (hipMemcpy(rb, out, count * 8, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;

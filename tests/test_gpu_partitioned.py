@@ -47,3 +47,26 @@ def test_partitioned_step_matches_single_partition(built, world, backend, opts):
             assert rep["transport"].startswith("built-in") and rep["comm_stats"][0] > 4 * 11, rep
         if backend == "nccl":          # one rank: real librccl loaded by the library, communicator + self test through it
             assert rep["transport"].startswith("built-in"), rep
+
+
+@pytest.mark.parametrize("transport", ["callback", "builtin"])
+def test_partitioned_channel(built, tmp_path, transport):
+    """The CORE2-class workload's mesh family partitioned (BASELINE config #4 in kind): the Soufflet channel refined once (11 450 nodes,
+    47 layers, multi-workgroup solve on one rank, Jacobi phases on a partition), 2 ranks sharing the GPU, 12 steps so that the global
+    zonal means of the toy hooks (every 10th step: rank-local sums, all-reduce over the ranks, division) are on the path.  Owned values
+    agree with the single-partition run of the same steps to the solver tolerance."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", FESOM_GPU_DEVICE="0", CHAN_LEVELS="1", CHAN_NSTEPS="12", CHAN_WORKDIR=str(tmp_path))
+    if transport == "builtin":
+        fake = os.path.join(REPO, "tests", "helpers", "libfake_rccl.so")
+        assert os.path.exists(fake)
+        env.update(FESOM_GPU_RCCL_LIB=fake, PART_TRANSPORT="rccl")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29790 + (1 if transport == "builtin" else 0)), os.path.join(REPO, "tests", "helpers", "partitioned_channel_worker.py")],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    reps = [json.loads(x) for x in re.findall(r"CHANREPORT (\{.*\})", r.stdout)]
+    assert len(reps) == 2
+    for rep in reps:
+        assert rep["d_eta"] < 1e-8 and rep["d_T"] < 1e-8 and rep["d_UV"] < 1e-8, rep
+        assert rep["eta_range"][1] - rep["eta_range"][0] > 1e-3, rep          # the jet really evolves
+        assert rep["owned"] > 4096
