@@ -1091,6 +1091,14 @@ int fesom_gpu_last_solver_iterations(void) {
 }
 int fesom_gpu_tile_shape(void) { return G.ready ? G.m.use_tile : -1; }
 int fesom_gpu_solver_kind(void) { return !G.ready ? -1 : (G.m.sv_minv ? 1 : 0); }
+// solves of this run that the explicit-inverse iterations did not finish (the Jacobi safety net took over); synchronises
+int fesom_gpu_solver_safety_net_count(void) {
+  if (!G.ready) return -1;
+  int v[4] = {0, 0, 0, 0};
+  hipStreamSynchronize(G.stream);
+  hipMemcpy(v, G.m.sv_info, sizeof(v), hipMemcpyDeviceToHost);
+  return v[2];
+}
 double fesom_gpu_last_solver_residual(void) {
   if (!G.ready) return -1.0;
   double r = -1.0;

@@ -235,6 +235,7 @@ int  fesom_gpu_last_solver_iterations(void);
 int  fesom_gpu_tile_shape(void);
 /* SSH preconditioner in use: 0 = Jacobi, 1 = explicit (block) inverse -- see fesom_params.solver_precond */
 int  fesom_gpu_solver_kind(void);
+int  fesom_gpu_solver_safety_net_count(void);   /* solver_precond=1: solves the Jacobi safety net had to finish since fesom_gpu_init */
 double fesom_gpu_last_solver_residual(void);
 int  fesom_gpu_kernel_time_ms(const char *kernel_group, int nrep, double *ms_per_launch);
 const char *fesom_gpu_last_error(void);

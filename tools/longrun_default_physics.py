@@ -16,6 +16,6 @@ t0 = time.time(); n = 1
 for chunk in range(10):
     core.run_steps(n, 3504); n += 3504
     si = core.step_info()
-    print(f"day {n*900/86400:7.1f} its {core.solver_iterations} eta {si['min_eta']:.2f} {si['max_eta']:.2f} T {si['min_temp']:.2f} {si['max_temp']:.2f} S {si['min_salt']:.2f} {si['max_salt']:.2f} umax {max(abs(si['min_uvel']), si['max_uvel']):.2f} cfl_z {si['max_cfl_z']:.3f} blowup {si['blowup']}", flush=True)
+    print(f"day {n*900/86400:7.1f} its {core.solver_iterations} (safety net so far: {core.lib.fesom_gpu_solver_safety_net_count()}) eta {si['min_eta']:.2f} {si['max_eta']:.2f} T {si['min_temp']:.2f} {si['max_temp']:.2f} S {si['min_salt']:.2f} {si['max_salt']:.2f} umax {max(abs(si['min_uvel']), si['max_uvel']):.2f} cfl_z {si['max_cfl_z']:.3f} blowup {si['blowup']}", flush=True)
     if si["blowup"]: break
 print("wall s", round(time.time() - t0, 1), "for", n - 1, "steps =", round((n - 1) * 900 / 86400 / 365, 2), "years")
