@@ -5,7 +5,7 @@ CXX   ?= g++
 SRC    = fesom2_amd/csrc
 OBJ    = fesom2_amd/build
 HFLAGS = --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-result
-HIPSRC = kernels_dyn kernels_tra kernels_toy kernels_gm kernels_kpp kernels_mon solver api
+HIPSRC = kernels_dyn kernels_tra kernels_toy kernels_gm kernels_kpp kernels_mon kernels_ice solver api
 OBJS   = $(addprefix $(OBJ)/,$(addsuffix .o,$(HIPSRC))) $(OBJ)/mesh_host.o $(OBJ)/precond_host.o
 
 fesom2_amd/libfesom_gpu.so: $(OBJS)

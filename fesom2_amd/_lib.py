@@ -59,7 +59,7 @@ class Params(C.Structure):
                    ("scaling_resolution", C.c_int), ("scaling_FESOM14", C.c_int), ("Redi", C.c_int),
                    ("visc_sh_limit", C.c_double), ("diff_sh_limit", C.c_double), ("Ricr", C.c_double), ("concv", C.c_double),
                    ("use_sw_pene", C.c_int), ("tra_adv_ver", C.c_int), ("tra_adv_hor", C.c_int), ("Kv0_const", C.c_int),
-                   ("solver_precond", C.c_int), ("solver_xinv_its", C.c_int)])
+                   ("solver_precond", C.c_int), ("tra_adv_lim", C.c_int), ("solver_xinv_its", C.c_int)])
 
 
 STATE_FIELDS = ("tr_arr", "tr_arr_old", "UV", "UV_rhsAB", "eta_n", "d_eta", "ssh_rhs", "ssh_rhs_old", "hbar",
@@ -104,6 +104,20 @@ class MeshOpts(C.Structure):
 
 
 # every symbol include/fesom_gpu.h declares
+class IceParams(C.Structure):
+    """fesom_ice_params (include/fesom_gpu.h)"""
+    _fields_ = [(n, C.c_double) for n in ("ice_dt", "ellipse", "alpha_evp", "beta_evp", "Pstar", "c_pressure", "delta_min", "cd_oce_ice", "max_ice_loading")] + \
+               [("evp_rheol_steps", C.c_int), ("use_floatice", C.c_int)]
+
+
+ICE_FIELDS = ("u_ice", "v_ice", "a_ice", "m_ice", "m_snow", "elevation", "u_w", "v_w", "stress_atmice_x", "stress_atmice_y", "sigma11", "sigma12", "sigma22")
+
+
+class IceState(C.Structure):
+    """fesom_ice_state (include/fesom_gpu.h)"""
+    _fields_ = [(n, PD) for n in ICE_FIELDS]
+
+
 EXPORTS = ("fesom_gpu_init", "fesom_gpu_upload_state", "fesom_gpu_download_state", "fesom_gpu_set_forcing",
            "fesom_gpu_step", "fesom_gpu_run_steps", "fesom_gpu_finalize", "fesom_gpu_get_field",
            "fesom_gpu_set_field", "fesom_gpu_call", "fesom_gpu_last_solver_iterations", "fesom_gpu_tile_shape", "fesom_gpu_solver_kind", "fesom_gpu_solver_safety_net_count",
@@ -111,6 +125,7 @@ EXPORTS = ("fesom_gpu_init", "fesom_gpu_upload_state", "fesom_gpu_download_state
            "psolver_init", "psolve", "psolver_final",
            "fesom_gpu_halo_info", "fesom_gpu_halo_pack", "fesom_gpu_halo_unpack", "fesom_gpu_copy", "fesom_gpu_sync", "fesom_gpu_set_stream", "fesom_gpu_field_ptr",
            "fesom_gpu_comm_unique_id", "fesom_gpu_comm_init", "fesom_gpu_comm_finalize", "fesom_gpu_comm_selftest", "fesom_gpu_comm_timing", "fesom_gpu_comm_stats",
+           "fesom_gpu_ice_init", "fesom_gpu_ice_upload", "fesom_gpu_ice_evp", "fesom_gpu_ice_download", "fesom_gpu_ice_time_ms", "fesom_gpu_ice_finalize", "fesom_gpu_ice_last_error",
            "fesom_mesh_load", "fesom_mesh_get_desc", "fesom_mesh_get_part", "fesom_mesh_get_initial_state",
            "fesom_mesh_free")
 

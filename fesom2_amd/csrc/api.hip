@@ -350,6 +350,8 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   if (par->tra_adv_ver < 0 || par->tra_adv_ver > 3 || par->tra_adv_hor < 0 || par->tra_adv_hor > 2) {
     G.err = "fesom_gpu_init: tra_adv_ver must be QR4C (0), CDIFF (1), UPW1 (2) or PPM (3), tra_adv_hor MFCT (0), MUSCL (1) or UPW1 (2), tra_adv_lim='FCT'"; return 3;
   }
+  if (par->tra_adv_lim < 0 || par->tra_adv_lim > 1) { G.err = "fesom_gpu_init: tra_adv_lim must be 'FCT' (0) or 'NON' (1)"; return 3; }
+  if (par->tra_adv_lim == 1 && par->w_split) { G.err = "fesom_gpu_init: tra_adv_lim='NON' together with w_split (implicit vertical advection inside the diffusion solve) is not implemented"; return 3; }
   if (par->mix_scheme < 0 || par->mix_scheme > 2) { G.err = "fesom_gpu_init: mix_scheme must be 0 (constant), 1 (KPP) or 2 (PP); the cvmix schemes are not implemented"; return 3; }
   for (int e = 0; e < d->myDim_elem2D + d->eDim_elem2D; e++)
     if (d->ulevels[e] != 1) { G.err = "fesom_gpu_init: cavities (ulevels>1) are not supported"; return 3; }
@@ -901,8 +903,8 @@ int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
   S.c("k_updn_grad", 0);
   if (p.Redi) S.X(0, {"tr_z"});
   if (p.with_diffusion) S.c("k_diff_flux", 0);
-  S.c("k_flux_hor", 0); S.c("k_fct_lo_node", 0); S.X(0, {"fct_LO"});
-  S.c("k_fct_node", 0); S.X(0, {"fct_plus", "fct_minus"});
+  S.c("k_flux_hor", 0); S.c("k_fct_lo_node", 0);
+  if (!p.tra_adv_lim) { S.X(0, {"fct_LO"}); S.c("k_fct_node", 0); S.X(0, {"fct_plus", "fct_minus"}); }     // (no low-order solution, no limiter with tra_adv_lim='NON')
   S.c("k_fct_edge_limit", 0); S.c("k_tr_update", 0);
   if (toy) for (int tr = 0; tr < G.m.ntr; tr++) S.c("relax_zonal_temp");     // once per tracer of the loop, always on tracer 1 (oce_ale_tracer.F90:150)
   S.X(0, {"tr_arr"});

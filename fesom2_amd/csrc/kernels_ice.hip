@@ -1,0 +1,332 @@
+// Sea-ice mEVP rheology on gfx950: EVPdynamics_m of the reference (src/ice_maEVP.F90:273-602; whichEVP = 1, Bouillon et al. 2013 /
+// Kimmritz et al. 2015), the subcycled momentum solve of the sea-ice model: evp_rheol_steps (120) subcycles per ice step, each one
+//   element loop : strain rates from the nodal velocities, viscous-plastic stresses (implicit relaxation with alpha_evp),
+//                  stress divergence scattered to the three nodes
+//   node loop    : + sea-surface slope, ocean drag and Coriolis implicitly, relaxation with beta_evp -> new velocities
+//   boundary     : zero velocity on the coast; halo exchange.
+// MI355X shape: ONE launch per subcycle, thread per node.  The element loop's scatter-add becomes a gather over the node's elements in
+// increasing element index (= the order in which the reference's element loop adds to the node), and every node thread evaluates the
+// stress update of its elements itself -- each element is updated by up to three threads with identical arithmetic (old stresses and
+// old velocities are read from ping-pong buffers, so nobody sees a half-updated state), one designated thread stores the new stress.
+// No atomics, deterministic, bit-identical to the CPU checker of the tests and to the reference's own routine
+// (tests/test_ice.py).  The 120 launches of a call are captured once into a hipGraph and replayed (2-D problem: launch-bound).
+// exp() of the pressure factor is evaluated on the HOST when the ice state is uploaded (glibc, as in the reference's build), the
+// only libm call of the routine whose device version could differ in the last bit.
+#include "dev.h"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define ICE_G 9.81
+#define ICE_DENSITY_0 1030.0
+#define ICE_RHOICE 910.0
+#define ICE_RHOSNO 290.0
+#define ICE_INV_RHOWAT (1. / 1025.)        // i_therm_param (src/ice_modules.F90)
+
+namespace {
+struct IceDM {
+  int N, myN, myE, maxk;
+  const int *en;             // (3, myE) 0-based
+  const int *nie, *nie_num;  // (maxk, N) 0-based elements of a node in increasing index, -1 padded
+  const double *gsca, *elem_area, *metric, *area1, *cori_n;
+  const unsigned char *bnd;  // coastal nodes
+  double *u_ice, *v_ice, *a_ice, *m_ice, *m_snow, *elev, *u_w, *v_w, *tax, *tay;
+  double *sig[2];            // [parity] -> 3 * myE (sigma11 | sigma12 | sigma22)
+  double *ua[2], *va[2];
+  double *rhs_a, *rhs_m, *invt, *mass, *pfac, *efac;
+  unsigned char *ice_nod, *ice_el;
+  fesom_ice_params p;
+};
+struct IceCtx {
+  bool ready = false;
+  IceDM m;
+  std::vector<void *> allocs;
+  hipStream_t stream = nullptr;
+  hipGraphExec_t graph = nullptr;
+  int cur = 0;               // parity of the buffers that hold the current stresses
+  std::vector<int> h_en; std::vector<double> h_efac;
+  std::string err;
+} I;
+
+#define ICECHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { I.err = std::string(#x) + ": " + hipGetErrorString(e_); fprintf(stderr, "fesom_gpu_ice: %s\n", I.err.c_str()); return 1; } } while (0)
+
+template <class T> T *ialloc(size_t n) {
+  void *p = nullptr;
+  if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
+  hipMemset(p, 0, (n ? n : 1) * sizeof(T));
+  I.allocs.push_back(p);
+  return (T *)p;
+}
+template <class T> const T *iupload(const std::vector<T> &h) {
+  T *p = ialloc<T>(h.size());
+  if (p && !h.empty()) hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+  return p;
+}
+
+// ssh2rhs inlined (:340-392), thickness / mass (:394-419), start of the solver variables (:323-324)
+__global__ void k_ice_prep_node(IceDM m) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.N) return;
+  m.ua[0][i] = m.u_ice[i]; m.va[0][i] = m.v_ice[i];
+  if (i >= m.myN) return;
+  const double val3 = 1.0 / 3.0;
+  double ra = 0.0, rm = 0.0;
+  for (int k = 0; k < m.nie_num[i]; k++) {
+    const int el = m.nie[(size_t)m.maxk * i + k];
+    const int *en = m.en + 3 * el;
+    const double *gs = m.gsca + 6 * (size_t)el;
+    double e3[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      e3[q] = m.elev[en[q]];
+      if (m.p.use_floatice) {
+        double pi = (ICE_RHOICE * m.m_ice[en[q]] + ICE_RHOSNO * m.m_snow[en[q]]) * ICE_INV_RHOWAT;
+        pi = pi < m.p.max_ice_loading ? pi : m.p.max_ice_loading;
+        e3[q] = e3[q] + pi;
+      }
+    }
+    double bb = ICE_G * val3 * m.elem_area[el];
+    const double aa = bb * ((gs[0] * e3[0] + gs[1] * e3[1]) + gs[2] * e3[2]);
+    bb = bb * ((gs[3] * e3[0] + gs[4] * e3[1]) + gs[5] * e3[2]);
+    ra = ra - aa; rm = rm - bb;
+  }
+  double invt = 0.0, mass = 0.0;
+  unsigned char on = 0;
+  if (m.a_ice[i] >= 0.01) {
+    double it = (ICE_RHOICE * m.m_ice[i] + ICE_RHOSNO * m.m_snow[i]) / m.a_ice[i];
+    invt = 1.0 / (it > 9.0 ? it : 9.0);
+    const double ms = (m.m_ice[i] * ICE_RHOICE + m.m_snow[i] * ICE_RHOSNO);
+    mass = ms / ((1.0 + ms * ms) * m.area1[i]);
+    ra = ra / m.area1[i]; rm = rm / m.area1[i];
+    on = 1;
+  }
+  m.rhs_a[i] = ra; m.rhs_m[i] = rm; m.invt[i] = invt; m.mass[i] = mass; m.ice_nod[i] = on;
+}
+// pressure factor (:421-438); exp(-c_pressure (1 - asum)) comes from the host (efac)
+__global__ void k_ice_prep_elem(IceDM m) {
+  const int el = blockIdx.x * blockDim.x + threadIdx.x;
+  if (el >= m.myE) return;
+  const int *en = m.en + 3 * el;
+  const double val3 = 1.0 / 3.0, det2 = 1.0 / (1.0 + m.p.alpha_evp);
+  const double msum = ((m.m_ice[en[0]] + m.m_ice[en[1]]) + m.m_ice[en[2]]) * val3;
+  double pf = 0.0;
+  unsigned char on = 0;
+  if (msum > 0.01) { on = 1; pf = det2 * m.p.Pstar * msum * m.efac[el]; }
+  m.pfac[el] = pf; m.ice_el[el] = on;
+}
+// one subcycle (:452-590): stresses of the node's elements from the buffers of parity `par`, new stresses / velocities to parity 1 - par
+__global__ void __launch_bounds__(128) k_ice_sub(IceDM m, int par) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.N) return;
+  const double *uo = m.ua[par], *vo = m.va[par];
+  double *un = m.ua[1 - par], *vn = m.va[1 - par];
+  if (i >= m.myN) { un[i] = uo[i]; vn[i] = vo[i]; return; }       // (halo values arrive by exchange in a partitioned run)
+  const double *so = m.sig[par];
+  double *sn = m.sig[1 - par];
+  const size_t E = (size_t)m.myE;
+  const double val3 = 1.0 / 3.0, vale = 1.0 / (m.p.ellipse * m.p.ellipse);
+  const double det2 = 1.0 / (1.0 + m.p.alpha_evp), det1 = m.p.alpha_evp * det2, rdt = m.p.ice_dt;
+  double urhs = 0.0, vrhs = 0.0;
+  for (int k = 0; k < m.nie_num[i]; k++) {
+    const int el = m.nie[(size_t)m.maxk * i + k];
+    const int n1 = m.en[3 * el], n2 = m.en[3 * el + 1], n3 = m.en[3 * el + 2];
+    const bool writer = (n1 < m.myN) ? (n1 == i) : ((n2 < m.myN) ? (n2 == i) : (n3 == i));   // the element's first owned node stores
+    double s11 = so[el], s12 = so[E + el], s22 = so[2 * E + el];
+    if (m.ice_el[el]) {
+      const double *dx = m.gsca + 6 * (size_t)el, *dy = dx + 3;
+      const double meancos = val3 * m.metric[el];
+      const double u1 = uo[n1], u2 = uo[n2], u3 = uo[n3], v1 = vo[n1], v2 = vo[n2], v3 = vo[n3];
+      const double eps11 = ((dx[0] * u1 + dx[1] * u2) + dx[2] * u3) - ((v1 + v2) + v3) * meancos;
+      const double eps22 = (dy[0] * v1 + dy[1] * v2) + dy[2] * v3;
+      const double eps12 = 0.5 * ((((dy[0] * u1 + dx[0] * v1) + (dy[1] * u2 + dx[1] * v2)) + (dy[2] * u3 + dx[2] * v3)) + ((u1 + u2) + u3) * meancos);
+      const double eps1 = eps11 + eps22, eps2 = eps11 - eps22;
+      const double delta = sqrt(eps1 * eps1 + vale * (eps2 * eps2 + 4.0 * (eps12 * eps12)));
+      const double pressure = m.pfac[el] / (delta + m.p.delta_min);
+      s12 = det1 * s12 + pressure * eps12 * vale;
+      s11 = det1 * s11 + 0.5 * pressure * (eps1 - delta + eps2 * vale);
+      s22 = det1 * s22 + 0.5 * pressure * (eps1 - delta - eps2 * vale);
+      const int pos = (n1 == i) ? 0 : ((n2 == i) ? 1 : 2);
+      const double ar = m.elem_area[el];
+      urhs = urhs - ar * (s11 * dx[pos] + s12 * (dy[pos] + meancos));
+      vrhs = vrhs - ar * (s12 * dx[pos] + s22 * dy[pos] - s11 * meancos);
+    }
+    if (writer) { sn[el] = s11; sn[E + el] = s12; sn[2 * E + el] = s22; }
+  }
+  double ua = uo[i], va = vo[i];
+  if (m.ice_nod[i]) {
+    urhs = urhs * m.mass[i] + m.rhs_a[i];
+    vrhs = vrhs * m.mass[i] + m.rhs_m[i];
+    const double uw = m.u_w[i], vw = m.v_w[i], invt = m.invt[i];
+    const double du = ua - uw, dv = va - vw;
+    const double umod = sqrt(du * du + dv * dv);
+    const double drag = rdt * m.p.cd_oce_ice * umod * ICE_DENSITY_0 * invt;
+    const double rhsu = m.u_ice[i] + drag * uw + rdt * (invt * m.tax[i] + urhs) + m.p.beta_evp * ua;
+    const double rhsv = m.v_ice[i] + drag * vw + rdt * (invt * m.tay[i] + vrhs) + m.p.beta_evp * va;
+    const double bd = 1.0 + m.p.beta_evp + drag, rc = rdt * m.cori_n[i];
+    const double det = (m.bnd[i] ? 0.0 : 1.0) / (bd * bd + rc * rc);
+    ua = det * (bd * rhsu + rc * rhsv);
+    va = det * (bd * rhsv - rc * rhsu);
+  }
+  if (m.bnd[i]) { ua = 0.0; va = 0.0; }
+  un[i] = ua; vn[i] = va;
+}
+__global__ void k_ice_finish(IceDM m, int par) {             // u_ice = u_ice_aux (:599-600)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.N) return;
+  m.u_ice[i] = m.ua[par][i]; m.v_ice[i] = m.va[par][i];
+}
+
+// one EVPdynamics_m call; the stresses start in parity I.cur; returns the parity they end in
+int enqueue_call(hipStream_t s, int par) {
+  const IceDM &m = I.m;
+  hipLaunchKernelGGL(k_ice_prep_node, dim3((m.N + 255) / 256), dim3(256), 0, s, m);
+  hipLaunchKernelGGL(k_ice_prep_elem, dim3((m.myE + 255) / 256), dim3(256), 0, s, m);
+  // the solver variables start in ua[0]; the stresses in sig[par]: make both parities agree by starting the velocities there as well
+  if (par == 1) {
+    hipMemcpyAsync(m.ua[1], m.ua[0], sizeof(double) * m.N, hipMemcpyDeviceToDevice, s);
+    hipMemcpyAsync(m.va[1], m.va[0], sizeof(double) * m.N, hipMemcpyDeviceToDevice, s);
+  }
+  for (int k = 0; k < m.p.evp_rheol_steps; k++) { hipLaunchKernelGGL(k_ice_sub, dim3((m.N + 127) / 128), dim3(128), 0, s, m, par); par = 1 - par; }
+  hipLaunchKernelGGL(k_ice_finish, dim3((m.N + 255) / 256), dim3(256), 0, s, m, par);
+  return par;
+}
+}  // namespace
+
+extern "C" {
+int fesom_gpu_ice_finalize(void) {
+  if (I.stream) hipStreamSynchronize(I.stream);
+  if (I.graph) { hipGraphExecDestroy(I.graph); I.graph = nullptr; }
+  for (void *p : I.allocs) hipFree(p);
+  I.allocs.clear();
+  if (I.stream) { hipStreamDestroy(I.stream); I.stream = nullptr; }
+  I.ready = false;
+  return 0;
+}
+const char *fesom_gpu_ice_last_error(void) { return I.err.c_str(); }
+
+int fesom_gpu_ice_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const fesom_ice_params *par) {
+  if (I.ready) fesom_gpu_ice_finalize();
+  I.err.clear();
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { I.err = "no HIP device: the MI355X path has no CPU fallback"; fprintf(stderr, "fesom_gpu_ice: %s\n", I.err.c_str()); return 2; }
+  if (part && part->npes > 1) { I.err = "fesom_gpu_ice_init: single partition only in this round"; return 3; }
+  if (par->evp_rheol_steps < 1) { I.err = "fesom_gpu_ice_init: evp_rheol_steps < 1"; return 3; }
+  for (int e = 0; e < d->myDim_elem2D; e++) if (d->ulevels[e] != 1) { I.err = "fesom_gpu_ice_init: cavities (ulevels > 1) are not supported"; return 3; }
+  ICECHK(hipStreamCreate(&I.stream));
+  IceDM &m = I.m;
+  memset(&m, 0, sizeof(m));
+  m.p = *par;
+  m.myN = d->myDim_nod2D; m.N = d->myDim_nod2D + d->eDim_nod2D; m.myE = d->myDim_elem2D; m.maxk = d->max_nod_in_elem;
+  const size_t N = m.N, E = m.myE;
+  I.h_en.resize(3 * E);
+  for (size_t q = 0; q < 3 * E; q++) I.h_en[q] = d->elem2D_nodes[q] - 1;
+  m.en = iupload(I.h_en);
+  {   // elements of a node, restricted to the owned elements (0-based, increasing)
+    std::vector<int> nie((size_t)m.maxk * N, -1), num(N, 0);
+    for (size_t n = 0; n < N; n++)
+      for (int k = 0; k < d->nod_in_elem2D_num[n]; k++) {
+        const int el = d->nod_in_elem2D[(size_t)m.maxk * n + k] - 1;
+        if (el >= 0 && el < m.myE) nie[(size_t)m.maxk * n + num[n]++] = el;
+      }
+    m.nie = iupload(nie); m.nie_num = iupload(num);
+  }
+  m.gsca = iupload(std::vector<double>(d->gradient_sca, d->gradient_sca + 6 * E));
+  m.elem_area = iupload(std::vector<double>(d->elem_area, d->elem_area + E));
+  m.metric = iupload(std::vector<double>(d->metric_factor, d->metric_factor + E));
+  m.cori_n = iupload(std::vector<double>(d->coriolis_node, d->coriolis_node + N));
+  {
+    std::vector<double> a1(N);
+    for (size_t n = 0; n < N; n++) a1[n] = d->area[n * (size_t)d->nl];
+    m.area1 = iupload(a1);
+    std::vector<unsigned char> bnd(N, 0);
+    for (int ed = 0; ed < d->myDim_edge2D; ed++)
+      if (d->myList_edge2D[ed] > d->edge2D_in) { bnd[d->edges[2 * ed] - 1] = 1; bnd[d->edges[2 * ed + 1] - 1] = 1; }
+    m.bnd = iupload(bnd);
+  }
+  double **nf[] = {&m.u_ice, &m.v_ice, &m.a_ice, &m.m_ice, &m.m_snow, &m.elev, &m.u_w, &m.v_w, &m.tax, &m.tay, &m.ua[0], &m.ua[1], &m.va[0], &m.va[1],
+                   &m.rhs_a, &m.rhs_m, &m.invt, &m.mass};
+  for (auto f : nf) *f = ialloc<double>(N);
+  m.sig[0] = ialloc<double>(3 * E); m.sig[1] = ialloc<double>(3 * E); m.pfac = ialloc<double>(E); m.efac = ialloc<double>(E);
+  m.ice_nod = ialloc<unsigned char>(N); m.ice_el = ialloc<unsigned char>(E);
+  for (void *p : I.allocs) if (!p) { I.err = "fesom_gpu_ice_init: device allocation failed"; return 1; }
+  I.h_efac.assign(E, 0.0);
+  I.cur = 0;
+  ICECHK(hipDeviceSynchronize());
+  I.ready = true;
+  return 0;
+}
+
+#define ICE_READY() if (!I.ready) { I.err = "fesom_gpu_ice: not initialised"; return 1; }
+int fesom_gpu_ice_upload(const fesom_ice_state *st) {
+  ICE_READY();
+  const IceDM &m = I.m;
+  ICECHK(hipStreamSynchronize(I.stream));
+  struct { const double *h; double *d; } nodef[] = {{st->u_ice, m.u_ice}, {st->v_ice, m.v_ice}, {st->a_ice, m.a_ice}, {st->m_ice, m.m_ice}, {st->m_snow, m.m_snow},
+      {st->elevation, m.elev}, {st->u_w, m.u_w}, {st->v_w, m.v_w}, {st->stress_atmice_x, m.tax}, {st->stress_atmice_y, m.tay}};
+  for (auto &f : nodef) if (f.h) ICECHK(hipMemcpy(f.d, f.h, sizeof(double) * m.N, hipMemcpyHostToDevice));
+  const size_t E = m.myE;
+  double *sg = m.sig[I.cur];
+  if (st->sigma11) ICECHK(hipMemcpy(sg, st->sigma11, sizeof(double) * E, hipMemcpyHostToDevice));
+  if (st->sigma12) ICECHK(hipMemcpy(sg + E, st->sigma12, sizeof(double) * E, hipMemcpyHostToDevice));
+  if (st->sigma22) ICECHK(hipMemcpy(sg + 2 * E, st->sigma22, sizeof(double) * E, hipMemcpyHostToDevice));
+  if (st->a_ice) {      // exp of the pressure factor on the host (glibc exp, the reference's)
+    const double val3 = 1.0 / 3.0;
+    for (size_t el = 0; el < E; el++) {
+      const int *en = &I.h_en[3 * el];
+      const double asum = ((st->a_ice[en[0]] + st->a_ice[en[1]]) + st->a_ice[en[2]]) * val3;
+      I.h_efac[el] = exp(-m.p.c_pressure * (1.0 - asum));
+    }
+    ICECHK(hipMemcpy(m.efac, I.h_efac.data(), sizeof(double) * E, hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+int fesom_gpu_ice_evp(int ncalls) {
+  ICE_READY();
+  for (int c = 0; c < ncalls; c++) {
+    if (I.m.p.evp_rheol_steps % 2 == 0 && I.cur == 0) {      // the usual case: an even number of subcycles returns to parity 0 -> one fixed graph
+      if (!I.graph) {
+        hipGraph_t g;
+        ICECHK(hipStreamBeginCapture(I.stream, hipStreamCaptureModeGlobal));
+        enqueue_call(I.stream, 0);
+        ICECHK(hipStreamEndCapture(I.stream, &g));
+        ICECHK(hipGraphInstantiate(&I.graph, g, nullptr, nullptr, 0));
+        hipGraphDestroy(g);
+      }
+      ICECHK(hipGraphLaunch(I.graph, I.stream));
+    } else I.cur = enqueue_call(I.stream, I.cur);
+  }
+  ICECHK(hipGetLastError());
+  return 0;
+}
+int fesom_gpu_ice_download(const fesom_ice_state *st) {
+  ICE_READY();
+  const IceDM &m = I.m;
+  ICECHK(hipStreamSynchronize(I.stream));
+  if (st->u_ice) ICECHK(hipMemcpy(st->u_ice, m.u_ice, sizeof(double) * m.N, hipMemcpyDeviceToHost));
+  if (st->v_ice) ICECHK(hipMemcpy(st->v_ice, m.v_ice, sizeof(double) * m.N, hipMemcpyDeviceToHost));
+  const size_t E = m.myE;
+  const double *sg = m.sig[I.cur];
+  if (st->sigma11) ICECHK(hipMemcpy(st->sigma11, sg, sizeof(double) * E, hipMemcpyDeviceToHost));
+  if (st->sigma12) ICECHK(hipMemcpy(st->sigma12, sg + E, sizeof(double) * E, hipMemcpyDeviceToHost));
+  if (st->sigma22) ICECHK(hipMemcpy(st->sigma22, sg + 2 * E, sizeof(double) * E, hipMemcpyDeviceToHost));
+  return 0;
+}
+int fesom_gpu_ice_time_ms(int ncalls, double *ms_per_call) {
+  ICE_READY();
+  hipEvent_t e0, e1;
+  ICECHK(hipEventCreate(&e0)); ICECHK(hipEventCreate(&e1));
+  if (fesom_gpu_ice_evp(1)) return 1;                          // warm-up (builds the graph)
+  ICECHK(hipStreamSynchronize(I.stream));
+  ICECHK(hipEventRecord(e0, I.stream));
+  if (fesom_gpu_ice_evp(ncalls)) return 1;
+  ICECHK(hipEventRecord(e1, I.stream));
+  ICECHK(hipEventSynchronize(e1));
+  float ms = 0;
+  ICECHK(hipEventElapsedTime(&ms, e0, e1));
+  *ms_per_call = ms / (ncalls > 0 ? ncalls : 1);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  return 0;
+}
+}

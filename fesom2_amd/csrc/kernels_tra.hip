@@ -146,7 +146,8 @@ __global__ void __launch_bounds__(BLOCK) k_flux_hor(DM m, int tr0) {
   else vflux = (DV2(m.UV, 2, nz, e2) * dX2 - DV2(m.UV, 1, nz, e2) * dY2) * DA2(m.helem, nz, e2);
   double av = fabs(vflux);
   double t1 = DTR(m.tr_arr, nz, n1, tr), t2 = DTR(m.tr_arr, nz, n2, tr);
-  double lo = -0.5 * (t1 * (vflux + av) + t2 * (vflux - av)) - 0.0;
+  // tra_adv_lim = 'NON' (oce_adv_tra_driver.F90:137-153): no low-order flux, the high-order flux is formed with init_zero=.true. (flux - 0.0)
+  double lo = m.p.tra_adv_lim ? 0.0 : -0.5 * (t1 * (vflux + av) + t2 * (vflux - av)) - 0.0;
   DA2(t.flux_lo_hor, nz, ed) = lo;
   double s1 = DTR(m.tr_arr_old, nz, n1, tr), s2 = DTR(m.tr_arr_old, nz, n2, tr);
   double num_ord = m.p.tra_adv_ph;
@@ -193,6 +194,10 @@ __global__ void __launch_bounds__(BLOCK) k_fct_lo_node(DM m, int tr0) {
   // the full w (oce_adv_tra_driver.F90:111,124-131); without it the two are the same array values
   double fv = 0.0, adf = 0.0;
   const bool split = m.p.w_split != 0;
+  // tra_adv_lim = 'NON' (oce_adv_tra_driver.F90:155-177): the high-order vertical flux alone, with the explicit velocity (pwvel => we) and
+  // init_zero=.true. (flux - 0.0); no low-order solution
+  const bool non = m.p.tra_adv_lim != 0;
+  const double *Who = non ? m.Wvel_e : m.Wvel;
   const int ver = m.p.tra_adv_ver;                          // 0 QR4C, 1 CDIFF (adv_tra_ver_cdiff :542-590), 2 UPW1 (:231-282), 3 PPM (:361-538)
   double ppm = 0.0;
   if (ver == 3) {
@@ -202,7 +207,7 @@ __global__ void __launch_bounds__(BLOCK) k_fct_lo_node(DM m, int tr0) {
     const double T0 = lay ? DTR(m.tr_arr_old, nz, n, tr) : 0.0, h0 = lay ? DA2(m.hnode_new, nz, n) : 1.0;
     const double Tm1 = shup(T0), Tp1 = shdn(T0), Tp2 = shdn(Tp1);
     const double hm1 = shup(h0), hp1 = shdn(h0), hp2 = shdn(hp1);
-    const double Wk = (nz >= nzmin && nz <= nzmax) ? DA2L(m.Wvel, nz, n) : 0.0, Wk1 = shdn(Wk);
+    const double Wk = (nz >= nzmin && nz <= nzmax) ? DA2L(Who, nz, n) : 0.0, Wk1 = shdn(Wk);
     const double d0 = Tp1 - T0, dm = T0 - Tm1, dp = Tp2 - Tp1;
     double deltaj = h0 / (hm1 + h0 + hp1) * ((2. * hm1 + h0) / (hp1 + h0) * d0 + (h0 + 2. * hp1) / (hm1 + h0) * dm);
     double deltajp1 = hp1 / (h0 + hp1 + hp2) * ((2. * h0 + hp1) / (hp2 + hp1) * dp + (hp1 + 2. * hp2) / (h0 + hp1) * d0);
@@ -248,17 +253,18 @@ __global__ void __launch_bounds__(BLOCK) k_fct_lo_node(DM m, int tr0) {
     double ar = DA2L(m.area, nz, n);
     if (nz == nzmin) {
       fv = -DA2L(m.Wvel_e, nz, n) * DTR(m.tr_arr, nz, n, tr) * ar - 0.0;
-      const double fvw = split ? -DA2L(m.Wvel, nz, n) * DTR(m.tr_arr, nz, n, tr) * ar - 0.0 : fv;
-      adf = -DTR(m.tr_arr_old, nz, n, tr) * DA2L(m.Wvel, nz, n) * ar - fvw;
+      const double fvw = non ? 0.0 : (split ? -DA2L(m.Wvel, nz, n) * DTR(m.tr_arr, nz, n, tr) * ar - 0.0 : fv);
+      adf = -DTR(m.tr_arr_old, nz, n, tr) * DA2L(Who, nz, n) * ar - fvw;
       if (ver == 3) adf = ppm - fvw;
     } else if (nz == nzmax) {
       fv = 0.0 - 0.0;
-      adf = 0.0 - fv;
+      adf = 0.0 - (non ? 0.0 : fv);
     } else {
       double we = DA2L(m.Wvel_e, nz, n);
       fv = -0.5 * (DTR(m.tr_arr, nz, n, tr) * (we + fabs(we)) + DTR(m.tr_arr, nz - 1, n, tr) * (we - fabs(we))) * ar - 0.0;
       double w = DA2L(m.Wvel, nz, n);
-      const double fvw = split ? -0.5 * (DTR(m.tr_arr, nz, n, tr) * (w + fabs(w)) + DTR(m.tr_arr, nz - 1, n, tr) * (w - fabs(w))) * ar - 0.0 : fv;
+      const double fvw = non ? 0.0 : (split ? -0.5 * (DTR(m.tr_arr, nz, n, tr) * (w + fabs(w)) + DTR(m.tr_arr, nz - 1, n, tr) * (w - fabs(w))) * ar - 0.0 : fv);
+      w = DA2L(Who, nz, n);
       double s0 = DTR(m.tr_arr_old, nz, n, tr), sm1 = DTR(m.tr_arr_old, nz - 1, n, tr);
       if (ver == 3) {
         adf = ppm - fvw;
@@ -303,7 +309,7 @@ __global__ void __launch_bounds__(BLOCK) k_fct_lo_node(DM m, int tr0) {
     double f = DA2(t.flux_lo_hor, nz, m.ne_idx[q0 + q]);
     lo = (m.ne_sgn[q0 + q] > 0) ? lo + f : lo - f;
   }
-  if (nz >= nzmin && nz <= nzmax - 1) {
+  if (!non && nz >= nzmin && nz <= nzmax - 1) {
     double ttf = DTR(m.tr_arr, nz, n, tr);
     lo = (ttf * DA2(m.hnode, nz, n) + (lo + (fv - fv_dn)) * dt / DA2L(m.areasvol, nz, n)) / DA2(m.hnode_new, nz, n);
     DA2(t.fct_LO, nz, n) = lo;            // the nodal bounds max/min(LO, ttf) (oce_adv_tra_fct.F90:94-101) are formed by their consumer
@@ -470,7 +476,8 @@ __global__ void __launch_bounds__(BLOCK) k_fct_edge_limit(DM m, int tr0) {
   if (e2 >= 0) { nl12 = max(nl12, m.nlev[e2] - 1); nu12 = min(nu12, m.ulev[e2]); }
   if (nz < nu12 || nz > nl12) return;
   double ae = 1.0, flux = DA2(t.adv_flux_raw, nz, ed);
-  if (flux >= 0.) { ae = dmin_(ae, DA2(t.fct_plus, nz, n1)); ae = dmin_(ae, DA2(t.fct_minus, nz, n2)); }
+  if (m.p.tra_adv_lim) ae = 1.0;                           // 'NON': the high-order flux itself
+  else if (flux >= 0.) { ae = dmin_(ae, DA2(t.fct_plus, nz, n1)); ae = dmin_(ae, DA2(t.fct_minus, nz, n2)); }
   else { ae = dmin_(ae, DA2(t.fct_minus, nz, n1)); ae = dmin_(ae, DA2(t.fct_plus, nz, n2)); }
   DA2(t.adv_flux_hor, nz, ed) = ae * flux;
 }
@@ -560,7 +567,7 @@ __device__ __forceinline__ void tru_head(const DM &m, int n_in, TruCol &k) {
 // flux -> tendency (oce_tra_adv_flux2dtracer) and horizontal diffusion of tracer `tr`: T^n and del (lane = level)
 // FAST: the quotients by areasvol(nz,n) share one reciprocal (dev.h: div_by, same bits as '/'); returns true if a lane left the
 // range in which that holds -- the caller then repeats the call with FAST = false (plain divisions)
-template <bool FAST, int MAXD>
+template <bool FAST, int MAXD, bool NON = false>        // NON: tra_adv_lim = 'NON' (no limiter, no low-order solution); a compile-time path so that the default costs nothing
 __device__ __forceinline__ bool tru_hor(const DM &m, const TruCol &k, int tr, double &T, double &del) {
   const TV t = tracer_view(m, tr);
   const int l = lane_id(), nz = l + 1, n = k.n, nzmin = k.nzmin, nzmax = k.nzmax;
@@ -568,7 +575,8 @@ __device__ __forceinline__ bool tru_hor(const DM &m, const TruCol &k, int tr, do
   const bool wet = k.wet;
   const int nzc = min(nz, m.nlm1);
   const bool dif = m.p.with_diffusion != 0;
-  const double p_own = UA2(t.fct_plus, nzc, n), m_own = UA2(t.fct_minus, nzc, n);
+  constexpr bool non = NON;                                // 'NON': no limiter (factor 1), no low-order solution in the vertical update
+  const double p_own = non ? 1.0 : UA2(t.fct_plus, nzc, n), m_own = non ? 1.0 : UA2(t.fct_minus, nzc, n);
   // Per edge of the batch: the limited antidiffusive flux and the diffusive flux, already masked with the level range of the
   // edge (+0.0 outside: x + 0.0 == x for the running sums below, which start at +0.0 and therefore never are -0.0) and carrying
   // the sign of this node's end of the edge (x - f == x + (-f) bit for bit), so that the ordered sums are plain additions.
@@ -583,9 +591,9 @@ __device__ __forceinline__ bool tru_hor(const DM &m, const TruCol &k, int tr, do
     // limited antidiffusive flux ae * flux with the factors of oce_adv_tra_fct.F90:318-347 applied on the fly:
     // flux >= 0: min(1, plus(n1), minus(n2)); flux < 0: min(1, minus(n1), plus(n2)).  With s = (flux >= 0) == (this node is n1)
     // the factor of this node is s ? plus : minus, that of the far node s ? minus : plus.
-    double fr = UA2(t.adv_flux_raw, nzc, ed), p_far = UA2(t.fct_plus, nzc, kk), m_far = UA2(t.fct_minus, nzc, kk);
+    double fr = UA2(t.adv_flux_raw, nzc, ed), p_far = non ? 1.0 : UA2(t.fct_plus, nzc, kk), m_far = non ? 1.0 : UA2(t.fct_minus, nzc, kk);
     const bool sel = (fr >= 0.) == first;
-    double ae = dmin_(dmin_(1.0, sel ? p_own : m_own), sel ? m_far : p_far);
+    double ae = non ? 1.0 : dmin_(dmin_(1.0, sel ? p_own : m_own), sel ? m_far : p_far);
     double f = ae * fr;
     f = __hiloint2double(__double2hiint(f) ^ flip, __double2loint(f));
     fa[q] = on ? f : 0.0;
@@ -600,7 +608,7 @@ __device__ __forceinline__ bool tru_hor(const DM &m, const TruCol &k, int tr, do
   bool bad = false;
   const RcpD rasv = rcp_prepare(asv, bad);                 // ~21 quotients by areasvol(nz,n) follow
 #define QDIV(x) (FAST ? div_by((x), rasv, bad) : (x) / asv)
-  double dv = 0.0 - T * hn + (wet ? UA2(t.fct_LO, nz, n) : 0.0) * hnn;
+  double dv = non ? 0.0 : 0.0 - T * hn + (wet ? UA2(t.fct_LO, nz, n) : 0.0) * hnn;      // flux2dtracer use_lo (oce_adv_tra_driver.F90:222-233)
   dv = dv + QDIV((adv - adv_dn) * dt);
   double dh = 0.0;
 #pragma unroll
@@ -611,7 +619,7 @@ __device__ __forceinline__ bool tru_hor(const DM &m, const TruCol &k, int tr, do
     if (nz < (int)(rg & 0xffu) || nz > (int)((rg >> 8) & 0xffu)) continue;
     int n1 = m.edges[2 * ed], n2 = m.edges[2 * ed + 1];
     double fr = UA2(t.adv_flux_raw, nz, ed);
-    double ae = dmin_(dmin_(1.0, (fr >= 0.) ? UA2(t.fct_plus, nz, n1) : UA2(t.fct_minus, nz, n1)), (fr >= 0.) ? UA2(t.fct_minus, nz, n2) : UA2(t.fct_plus, nz, n2));
+    double ae = non ? 1.0 : dmin_(dmin_(1.0, (fr >= 0.) ? UA2(t.fct_plus, nz, n1) : UA2(t.fct_minus, nz, n1)), (fr >= 0.) ? UA2(t.fct_minus, nz, n2) : UA2(t.fct_plus, nz, n2));
     double f = (ae * fr) * dt / asv;
     dh = (m.ne_sgn[k.q0 + q] > 0) ? dh + f : dh - f;
   }
@@ -769,7 +777,9 @@ __global__ void __launch_bounds__(WAVE * WAVES, (WAVES == 8) ? 4 : 2) k_tr_updat
       for (int t = 0; t < NT; t++) {
         Ts[t] = 0.0; rhs[t] = 0.0;
         double del = 0.0;
-        if (trA + t < m.ntr) tru_hor<false, TRU_MAXD>(m, k, trA + t, Ts[t], del);      // (latency-bound shape: plain divisions keep it at its register budget)
+        if (trA + t < m.ntr) {                                                          // (latency-bound shape: plain divisions keep it at its register budget)
+          if (m.p.tra_adv_lim) tru_hor<false, TRU_MAXD, true>(m, k, trA + t, Ts[t], del); else tru_hor<false, TRU_MAXD>(m, k, trA + t, Ts[t], del);
+        }
         if (t == 0) tru_zcol<REDI>(m, k);
         if (trA + t < m.ntr) tru_fin<REDI>(m, k, trA + t, Ts[t], del);
       }
@@ -790,7 +800,8 @@ __global__ void __launch_bounds__(WAVE * WAVES, (WAVES == 8) ? 4 : 2) k_tr_updat
       for (int t = 0; t < NT; t++) {
         double T = 0.0, del = 0.0, r = 0.0;
         if (trA + t < m.ntr) {
-          if (tru_hor<true, TRU_MAXD_TILE>(m, k, trA + t, T, del)) tru_hor<false, TRU_MAXD_TILE>(m, k, trA + t, T, del);
+          if (m.p.tra_adv_lim) tru_hor<false, TRU_MAXD_TILE, true>(m, k, trA + t, T, del);
+          else if (tru_hor<true, TRU_MAXD_TILE>(m, k, trA + t, T, del)) tru_hor<false, TRU_MAXD_TILE>(m, k, trA + t, T, del);
           tru_fin<REDI>(m, k, trA + t, T, del);
           if (k.wet) DTR(m.tr_arr, nz, k.n, trA + t) = impl ? T : tru_clamp(T, trA + t);    // T*: picked up again after the sweep
           if (impl) { tile.get_abc(ci, k.a, k.b, k.c); r = tru_rhs(m, k, trA + t, T); }      // (a, b, c back from the tile: not kept in registers across the gathers)
@@ -847,7 +858,7 @@ void launch_tracer(const DM &m, hipStream_t s, int tr) {   // tr 0-based
   if (!fuse_updn) LAUNCH_COL(k_updn_grad, m.myD, m, tr);
   if (fuse_updn) LAUNCH_COL(k_flux_hor<true>, m.myD, m, tr); else LAUNCH_COL(k_flux_hor<false>, m.myD, m, tr);
   LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); LAUNCH_WIMPL(m, tr);
-  LAUNCH_COL(k_fct_node, m.myN, m, tr);
+  if (!m.p.tra_adv_lim) LAUNCH_COL(k_fct_node, m.myN, m, tr);
   LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr);
   if (m.p.with_diffusion) LAUNCH_DFX(m, tr);
   LAUNCH_TRU(m, tr);
@@ -863,7 +874,7 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
     if (!strcmp(name, "k_flux_hor")) { LAUNCH_COL(k_flux_hor<false>, m.myD, m, tr); return 0; }
     if (!strcmp(name, "k_flux_hor_fused")) { LAUNCH_COL(k_flux_hor<true>, m.myD, m, tr); return 0; }     // fill_up_dn_grad on the fly
     if (!strcmp(name, "k_fct_lo_node")) { LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); LAUNCH_WIMPL(m, tr); return 0; }   // (+ implicit part with w_split)
-    if (!strcmp(name, "k_fct_node")) { LAUNCH_COL(k_fct_node, m.myN, m, tr); return 0; }
+    if (!strcmp(name, "k_fct_node")) { if (!m.p.tra_adv_lim) LAUNCH_COL(k_fct_node, m.myN, m, tr); return 0; }      // (no limiter with tra_adv_lim='NON')
     if (!strcmp(name, "k_fct_edge_limit")) { LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr); return 0; }
     if (!strcmp(name, "k_diff_flux")) { LAUNCH_DFX(m, tr); return 0; }
     if (!strcmp(name, "k_tr_update")) { LAUNCH_TRU(m, tr); return 0; }
@@ -875,7 +886,9 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
   }
   if (!strcmp(name, "adv_tracers_ale")) {
     LAUNCH_COL(k_flux_hor<false>, m.myD, m, tr); LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); LAUNCH_WIMPL(m, tr);
-    LAUNCH_COL(k_fct_node, m.myN, m, tr); LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr); return 0;
+    if (!m.p.tra_adv_lim) LAUNCH_COL(k_fct_node, m.myN, m, tr);
+    LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr);
+    return 0;
   }
   if (!strcmp(name, "diff_tracers_ale")) {                                                    // incl. flux2dtracer + clamp
     if (m.p.with_diffusion) LAUNCH_DFX(m, tr);

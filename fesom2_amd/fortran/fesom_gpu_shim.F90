@@ -60,7 +60,7 @@ module fesom_gpu_shim
      real(c_double) :: K_GM_rampmax, K_GM_rampmin, K_GM_resscalorder
      integer(c_int) :: scaling_Ferreira, scaling_Rossby, scaling_resolution, scaling_FESOM14, Redi
      real(c_double) :: visc_sh_limit, diff_sh_limit, Ricr, concv
-     integer(c_int) :: use_sw_pene, tra_adv_ver, tra_adv_hor, Kv0_const, solver_precond, solver_xinv_its
+     integer(c_int) :: use_sw_pene, tra_adv_ver, tra_adv_hor, Kv0_const, solver_precond, tra_adv_lim, solver_xinv_its
   end type
   type, bind(C) :: fesom_state_desc
      type(c_ptr) :: tr_arr, tr_arr_old, UV, UV_rhsAB, eta_n, d_eta, ssh_rhs, ssh_rhs_old, hbar, hbar_old, dhe, hnode, hnode_new, &
@@ -304,7 +304,11 @@ contains
     case ('UPW1'); p%tra_adv_hor = 2
     case default; p%tra_adv_hor = -1
     end select
-    if (trim(tra_adv_lim) /= 'FCT') p%tra_adv_ver = -1
+    select case (trim(tra_adv_lim))
+    case ('FCT'); p%tra_adv_lim = 0
+    case ('NON'); p%tra_adv_lim = 1
+    case default; p%tra_adv_lim = -1
+    end select
     p%Kv0_const = l2i(Kv0_const)
     p%solver_precond = 1; p%solver_xinv_its = 0     ! explicit-inverse preconditioner where it fits (pi), library default iterations
 

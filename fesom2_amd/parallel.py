@@ -90,8 +90,9 @@ def run_step(core, par, X, solve, first, probe=None, n=1, zonal=None):
         X(NOD, ["tr_z"])
     if p.with_diffusion:
         c("k_diff_flux", 0)
-    c("k_flux_hor", 0); c("k_fct_lo_node", 0); X(NOD, ["fct_LO"])
-    c("k_fct_node", 0); X(NOD, ["fct_plus", "fct_minus"])
+    c("k_flux_hor", 0); c("k_fct_lo_node", 0)
+    if not p.tra_adv_lim:                             # (no low-order solution, no limiter with tra_adv_lim='NON')
+        X(NOD, ["fct_LO"]); c("k_fct_node", 0); X(NOD, ["fct_plus", "fct_minus"])
     c("k_fct_edge_limit", 0); c("k_tr_update", 0)
     if p.toy_soufflet:
         for _ in range(p.num_tracers):                # once per tracer of the loop, always on tracer 1 (oce_ale_tracer.F90:150)

@@ -127,6 +127,9 @@ typedef struct fesom_params {
   int    solver_precond;     /* SSH solver preconditioner, frozen at the operator of the first step like the reference's ILU factors
                                 (psolve.c:117-150): 0 = Jacobi; 1 = explicit inverse of the row-scaled operator (fp32, applied as one
                                 full-GPU matrix-vector product) where it fits: single partition, <= 4096 rows (pi), else Jacobi */
+  int    tra_adv_lim;        /* limiter of the tracer advection (namelist.oce tra_adv_lim, oce_adv_tra_driver.F90:79-197): 0 'FCT' (default: low-order
+                                solution + limited anti-diffusive fluxes), 1 'NON' (the high-order fluxes applied as they are, vertical part with the
+                                explicit velocity; not together with w_split) */
   int    solver_xinv_its;    /* solver_precond=1: BiCGstab iterations enqueued per solve (no host read-back inside a step); a solve that
                                 has not converged by then is finished by the Jacobi-preconditioned one-workgroup solver.  0 = default (2) */
 } fesom_params;
@@ -254,6 +257,32 @@ int  fesom_gpu_copy(void *dst, const void *src, long long bytes, int dir);   /* 
 int  fesom_gpu_sync(void);
 int  fesom_gpu_field_ptr(const char *name, void **dev, long long *count);   /* device address of a named field */
 int  fesom_gpu_set_stream(void *hip_stream);   /* run the library's kernels on the host's stream (stream-ordered transport) */
+
+/* ---- sea-ice mEVP rheology: EVPdynamics_m (src/ice_maEVP.F90:273-602), the subcycled momentum solve of the sea-ice model
+ * (whichEVP = 1; Bouillon et al. 2013 / Kimmritz et al. 2015).  One call = evp_rheol_steps subcycles (default 120) of: strain rates
+ * and viscous-plastic stresses on elements, stress divergence gathered to nodes, implicit Coriolis / ocean-drag velocity update,
+ * coastal boundary condition.  Independent of the ocean core's context (may coexist with it); single partition in this round.
+ * Arrays keep the reference's extents: node fields myDim_nod2D + eDim_nod2D, stresses myDim_elem2D.  Not built: cavities
+ * (ulevels > 1), icepack, the other two EVP variants (whichEVP = 0, 2). */
+typedef struct fesom_ice_params {
+  double ice_dt;             /* ice_ave_steps * dt */
+  double ellipse, alpha_evp, beta_evp, Pstar, c_pressure, delta_min, cd_oce_ice;   /* namelist.ice &ice_dyn (src/ice_modules.F90:7-27) */
+  double max_ice_loading;    /* namelist.config &ale_def */
+  int    evp_rheol_steps;
+  int    use_floatice;       /* use_floatice .and. which_ALE /= 'linfs' (ice_maEVP.F90:159): ice + snow load in the sea-surface slope term */
+} fesom_ice_params;
+typedef struct fesom_ice_state {
+  double *u_ice, *v_ice;                                            /* in / out */
+  double *a_ice, *m_ice, *m_snow, *elevation, *u_w, *v_w, *stress_atmice_x, *stress_atmice_y;   /* in */
+  double *sigma11, *sigma12, *sigma22;                              /* in / out: the stresses are state across calls */
+} fesom_ice_state;
+int  fesom_gpu_ice_init(const fesom_mesh_desc *mesh, const fesom_part_desc *part, const fesom_ice_params *par);
+int  fesom_gpu_ice_upload(const fesom_ice_state *st);     /* every non-NULL field host -> device */
+int  fesom_gpu_ice_evp(int ncalls);                       /* ncalls x EVPdynamics_m on the device-resident state; asynchronous */
+int  fesom_gpu_ice_download(const fesom_ice_state *st);   /* u_ice, v_ice, sigma11/12/22 device -> host (synchronises) */
+int  fesom_gpu_ice_time_ms(int ncalls, double *ms_per_call);   /* device time of a call (HIP events), state left as after the calls */
+int  fesom_gpu_ice_finalize(void);
+const char *fesom_gpu_ice_last_error(void);
 
 /* SSH solver with the reference's own C signatures (src/psolve.c:16,117,152;
  * Fortran interface blocks src/oce_ale.F90:2272-2291).  All by reference,

@@ -435,6 +435,9 @@ void orc_adv_tracers_ale(int tr) {
   double *dh = C_.del_ttf_advhoriz, *dv = C_.del_ttf_advvert, *LO = C_.fct_LO;
   memset(dh, 0, sizeof(double) * cnt);
   memset(dv, 0, sizeof(double) * cnt);
+  const int fct = C_.p.tra_adv_lim == 0;           /* tra_adv_lim = 'FCT' | 'NON' (oce_adv_tra_driver.F90:79,137,155,189) */
+  const double *Who = fct ? C_.Wvel : C_.Wvel_e;   /* pwvel => w with FCT, => we without (:155-159) */
+  if (fct) {
   adv_tra_hor(ttf, 0, 0.0);
   memset(LO, 0, sizeof(double) * cnt);
   for (int ed = 1; ed <= C_.m.myDim_edge2D; ed++) {
@@ -455,16 +458,22 @@ void orc_adv_tracers_ale(int tr) {
     adv_tra_vert_impl(LO, C_.Wvel_i);
     adv_tra_ver_upw1(ttf, C_.Wvel);        /* low-order part of the anti-diffusive vertical fluxes: on the full w */
   }
+  } else {                                 /* do_zero_flux = .true.: the high-order routines zero their flux arrays first */
+    memset(C_.adv_flux_hor, 0, sizeof(double) * (size_t)NLM1 * C_.m.myDim_edge2D);
+    memset(C_.adv_flux_ver, 0, sizeof(double) * (size_t)NL * C_.m.myDim_nod2D);
+  }
   adv_tra_hor(ttfAB, C_.p.tra_adv_hor == 1 ? 3 : C_.p.tra_adv_hor == 2 ? 2 : 1, C_.p.tra_adv_ph);
-  if (C_.p.tra_adv_ver == 1) adv_tra_ver_cdiff(ttfAB, C_.Wvel);
-  else if (C_.p.tra_adv_ver == 2) adv_tra_ver_upw1_ho(ttfAB, C_.Wvel);
-  else if (C_.p.tra_adv_ver == 3) adv_tra_vert_ppm(ttfAB, C_.Wvel);
-  else adv_tra_ver_qr4c(ttfAB, C_.Wvel, C_.p.tra_adv_pv);
-  oce_tra_adv_fct(ttf);
-  /* flux2dtracer with use_lo */
-  for (int n = 1; n <= C_.m.myDim_nod2D; n++)
-    for (int nz = ULEVN(n); nz <= NLEVN(n) - 1; nz++)
-      A2(dv, nz, n) = A2(dv, nz, n) - A2(ttf, nz, n) * A2(C_.hnode, nz, n) + A2(LO, nz, n) * A2(C_.hnode_new, nz, n);
+  if (C_.p.tra_adv_ver == 1) adv_tra_ver_cdiff(ttfAB, Who);
+  else if (C_.p.tra_adv_ver == 2) adv_tra_ver_upw1_ho(ttfAB, Who);
+  else if (C_.p.tra_adv_ver == 3) adv_tra_vert_ppm(ttfAB, Who);
+  else adv_tra_ver_qr4c(ttfAB, Who, C_.p.tra_adv_pv);
+  if (fct) {
+    oce_tra_adv_fct(ttf);
+    /* flux2dtracer with use_lo */
+    for (int n = 1; n <= C_.m.myDim_nod2D; n++)
+      for (int nz = ULEVN(n); nz <= NLEVN(n) - 1; nz++)
+        A2(dv, nz, n) = A2(dv, nz, n) - A2(ttf, nz, n) * A2(C_.hnode, nz, n) + A2(LO, nz, n) * A2(C_.hnode_new, nz, n);
+  }
   for (int n = 1; n <= C_.m.myDim_nod2D; n++)
     for (int nz = ULEVN(n); nz <= NLEVN(n) - 1; nz++)
       A2(dv, nz, n) = A2(dv, nz, n) + (A2L(C_.adv_flux_ver, nz, n) - A2L(C_.adv_flux_ver, nz + 1, n)) * dt / AREASVOL(nz, n);

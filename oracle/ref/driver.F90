@@ -83,6 +83,7 @@ program oracle_driver
   use g_forcing_param
   use g_forcing_arrays
   use i_ARRAYS
+  use i_PARAM
   use g_ic3d
   use g_clock, only: timenew, daynew, yearnew
   use diagnostics, only: diag_list
@@ -141,6 +142,7 @@ program oracle_driver
   close (20)
   r_restart=.false.
   mstep=0
+  if (trim(mode)=='ice') whichEVP=1       ! mesh_setup allocates bc_index_nod2D only for the modified EVP solvers (oce_mesh.F90:2404-2413)
 
   call mesh_setup(mesh)
   call check_mesh_consistency(mesh)
@@ -183,6 +185,16 @@ program oracle_driver
   end if
 
   if (dump_mesh) call dump_setup()
+
+  if (trim(mode)=='ice') then
+     ! ---- sea-ice mEVP rheology (src/ice_maEVP.F90:273-602) alone: the ice arrays of i_ARRAYS are allocated here as ice_array_setup
+     ! (src/ice_setup_step.F90) does and filled with analytic fields (the harness's own choice: ice-free and ice-covered regions,
+     ! concentrations below and above the 0.01 threshold, thick and thin ice, wind, ocean currents, sea-surface slope); then
+     ! nsteps calls of the reference's EVPdynamics_m (evp_rheol_steps = 120 subcycles each) with a dump after every call
+     call ice_harness()
+     call MPI_FINALIZE(ierr)
+     stop
+  end if
 
   if (do_mean) then
      allocate(mT(mesh%nl-1,myDim_nod2D), mS(mesh%nl-1,myDim_nod2D))
@@ -304,6 +316,68 @@ contains
     call dump_state()
     call dump_close()
   end subroutine dump_setup
+
+  subroutine ice_harness()
+    interface
+       subroutine EVPdynamics_m(mesh)
+         use mod_mesh
+         type(t_mesh), intent(in), target :: mesh
+       end subroutine
+    end interface
+    integer :: n2, e2, i, it
+    real(kind=WP) :: lon, lat, t0i, t1i
+    n2=myDim_nod2D+eDim_nod2D; e2=myDim_elem2D+eDim_elem2D
+    allocate(u_ice(n2), v_ice(n2), m_ice(n2), a_ice(n2), m_snow(n2), u_ice_aux(n2), v_ice_aux(n2))
+    allocate(rhs_a(n2), rhs_m(n2), u_rhs_ice(n2), v_rhs_ice(n2), u_w(n2), v_w(n2), elevation(n2))
+    allocate(stress_atmice_x(n2), stress_atmice_y(n2))
+    allocate(sigma11(e2), sigma12(e2), sigma22(e2), eps11(e2), eps12(e2), eps22(e2))
+    ice_dt=real(ice_ave_steps,WP)*dt
+    sigma11=0.0_WP; sigma12=0.0_WP; sigma22=0.0_WP; eps11=0.0_WP; eps12=0.0_WP; eps22=0.0_WP
+    rhs_a=0.0_WP; rhs_m=0.0_WP; u_rhs_ice=0.0_WP; v_rhs_ice=0.0_WP; u_ice_aux=0.0_WP; v_ice_aux=0.0_WP
+    do i=1, n2
+       lon=mesh%geo_coord_nod2D(1,i); lat=mesh%geo_coord_nod2D(2,i)
+       a_ice(i)=min(1.0_WP, max(0.0_WP, 0.55_WP+0.6_WP*sin(2.0_WP*lat)+0.25_WP*cos(3.0_WP*lon)))
+       if (a_ice(i) < 0.02_WP .and. cos(5.0_WP*lon) > 0.0_WP) a_ice(i)=0.005_WP        ! below the 0.01 threshold but not zero
+       m_ice(i)=a_ice(i)*(1.2_WP+0.9_WP*cos(2.0_WP*lon+1.0_WP))
+       m_snow(i)=0.15_WP*a_ice(i)*(1.0_WP+sin(lon))
+       u_ice(i)=0.08_WP*sin(lon)*cos(lat); v_ice(i)=0.05_WP*cos(2.0_WP*lon)
+       u_w(i)=0.12_WP*cos(lon+0.5_WP); v_w(i)=0.07_WP*sin(2.0_WP*lat)
+       elevation(i)=0.3_WP*sin(2.0_WP*lon)*cos(lat)
+       stress_atmice_x(i)=0.12_WP*cos(3.0_WP*lat); stress_atmice_y(i)=0.05_WP*sin(2.0_WP*lon+0.3_WP)
+    end do
+    ! velocities vanish on the coast, as the model keeps them (ice_maEVP.F90:568-573)
+    do i=1, n2
+       u_ice(i)=u_ice(i)*real(mesh%bc_index_nod2D(i),WP); v_ice(i)=v_ice(i)*real(mesh%bc_index_nod2D(i),WP)
+    end do
+    call dump_open(trim(dump_dir), 'ice_in', mype)
+    call dump('bc_index_nod2D', mesh%bc_index_nod2D)
+    call dump('metric_factor', mesh%metric_factor)
+    call dump('coriolis_node', coriolis_node)
+    call dump_ice()
+    call dump_close()
+    call MPI_BARRIER(MPI_COMM_FESOM, ierr)
+    t0i=MPI_Wtime()
+    do it=1, nsteps
+       call EVPdynamics_m(mesh)
+       if (any(dump_steps==it)) then
+          write(tag,'(A,I4.4)') 'ice_out', it
+          call dump_open(trim(dump_dir), trim(tag), mype)
+          call dump_ice()
+          call dump_close()
+       end if
+    end do
+    call MPI_BARRIER(MPI_COMM_FESOM, ierr)
+    t1i=MPI_Wtime()
+    if (mype==0) write(*,'(A,I6,A,ES14.6,A,I4)') 'ORACLE_TIMING_ICE calls=', nsteps, ' s_per_call=', (t1i-t0i)/real(max(nsteps,1),WP), ' subcycles=', evp_rheol_steps
+  end subroutine ice_harness
+
+  subroutine dump_ice()
+    call dump('u_ice', u_ice); call dump('v_ice', v_ice); call dump('a_ice', a_ice); call dump('m_ice', m_ice); call dump('m_snow', m_snow)
+    call dump('u_w', u_w); call dump('v_w', v_w); call dump('elevation', elevation)
+    call dump('stress_atmice_x', stress_atmice_x); call dump('stress_atmice_y', stress_atmice_y)
+    call dump('sigma11', sigma11); call dump('sigma12', sigma12); call dump('sigma22', sigma22)
+    call dump('ice_params', (/ ice_dt, ellipse, alpha_evp, beta_evp, Pstar, c_pressure, delta_min, cd_oce_ice, real(evp_rheol_steps,WP), max_ice_loading /))
+  end subroutine dump_ice
 
   ! prognostic + ALE state (= restart set, io_restart.F90:99-155, plus thickness arrays)
   subroutine dump_state()

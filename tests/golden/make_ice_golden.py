@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Golden vectors for the sea-ice mEVP rheology: the REFERENCE's own EVPdynamics_m (src/ice_maEVP.F90:273-602, compiled into
+oracle/_ref/fesom_oracle.x) run by the harness driver (mode 'ice': analytic ice state, see oracle/ref/driver.F90:ice_harness) on the
+pi mesh with ONE MPI rank -- the reference's metric_factor quirk (oce_mesh.F90:2183) makes the result depend on the partition --
+two calls of 120 subcycles.  Inputs and outputs are stored in full (3140 nodes, 5839 elements).  Needs /root/reference (build):
+python tests/golden/make_ice_golden.py"""
+import os, sys
+import numpy as np
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, REPO); sys.path.insert(0, HERE)
+from oracle.ref import run_ref
+from refdump import read_dump
+
+rd, rc, lines = run_ref.run("pi_pp", 1, 2, mode="ice", dump=(1, 2))
+assert rc == 0, open(os.path.join(rd, "stdout.log")).read()[-2000:]
+out = {}
+a = read_dump(os.path.join(rd, "dumps", "ice_in.r00000.bin"))
+for k, v in a.items():
+    out["in/" + k] = np.array(v)
+for n in (1, 2):
+    b = read_dump(os.path.join(rd, "dumps", f"ice_out{n:04d}.r00000.bin"))
+    for k in ("u_ice", "v_ice", "sigma11", "sigma12", "sigma22"):
+        out[f"out{n}/{k}"] = np.array(b[k])
+np.savez_compressed(os.path.join(HERE, "ice_evp_reference.npz"), **out)
+print("wrote ice_evp_reference.npz:", {k: v.shape for k, v in out.items() if k.startswith("in/")}, lines)

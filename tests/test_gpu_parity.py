@@ -425,6 +425,47 @@ def test_profile_step_is_the_same_step(built, case):
     gpu.close()
 
 
+def test_no_limiter_chain_bitwise(built):
+    """tra_adv_lim = 'NON' (oracle pinned on the reference run pi_pp_non): HIP == oracle bit for bit after every routine of 3 steps under
+    surface forcing, and for the state after 8 further steps through fesom_gpu_run_steps."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.core import OceanCore
+    from fesom2_amd.synthetic import analytic_ts, analytic_forcing
+    from oracle_lib import Oracle
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, tra_adv_lim="NON")
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    gpu, orc = OceanCore(mesh, par), Oracle(mesh, par)
+    gpu.upload_state(st); orc.set_state(st)
+    forcing = analytic_forcing(mesh)
+    gpu.set_forcing(**forcing)
+    for k, v in forcing.items():
+        orc.set(k, v)
+    failures = []
+    for step in range(1, 4):
+        for routine, arg, fields in full_chain(2):
+            gpu.call(routine, arg); orc.call(routine, arg)
+            for f in fields:
+                if f in ("fct_LO", "fct_plus", "fct_minus"):        # not formed without the limiter
+                    continue
+                ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+                if not ok:
+                    failures.append(f"step {step} {routine}({arg}) {msg}")
+        if failures:
+            break
+    assert not failures, "\n".join(failures[:10])
+    gpu.run_steps(4, 8)
+    for n in range(4, 12):
+        orc.call("step", n)
+    for f in ("tr_arr", "UV", "eta_n", "hnode"):
+        ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+        assert ok, msg
+    gpu.close()
+
+
 @pytest.mark.parametrize("opt", [4, 6, 7])
 def test_biharmonic_viscosity_chain_bitwise(built, opt):
     """visc_option 4 / 6 / 7 (visc_filt_biharm(1), visc_filt_bilapl, visc_filt_bidiff; oracle pinned on the reference runs pi_pp_visc4 / 6 / 7): HIP == oracle

@@ -1,0 +1,97 @@
+"""Sea-ice mEVP rheology (row f-4 of SURVEY 8: src/ice_maEVP.F90:273-602, EVPdynamics_m).
+CPU: the oracle's restatement (oracle/c/orc_ice.c) against the REFERENCE's own routine -- golden vectors from a 1-rank run of
+oracle/_ref on the pi mesh with an analytic ice state (tests/golden/make_ice_golden.py): bit for bit after one and after two calls
+of 120 subcycles.  GPU: the HIP kernels through the C ABI against the oracle and against the golden vectors, bit for bit."""
+import ctypes as C
+import os
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PI = os.path.join(REPO, "tests", "golden", "meshes", "pi")
+STATE = ("u_ice", "v_ice", "a_ice", "m_ice", "m_snow", "elevation", "u_w", "v_w", "stress_atmice_x", "stress_atmice_y", "sigma11", "sigma12", "sigma22")
+OUT = ("u_ice", "v_ice", "sigma11", "sigma12", "sigma22")
+
+
+def gold():
+    return np.load(os.path.join(REPO, "tests", "golden", "ice_evp_reference.npz"))
+
+
+def setup(g, **kw):
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd import ice
+    mesh = Mesh.load(PI, dt=900.0)
+    pv = g["in/ice_params"]
+    par = ice.ice_params(ice_dt=pv[0], ellipse=pv[1], alpha_evp=pv[2], beta_evp=pv[3], Pstar=pv[4], c_pressure=pv[5], delta_min=pv[6], cd_oce_ice=pv[7],
+                         evp_rheol_steps=int(pv[8]), max_ice_loading=pv[9], **kw)
+    fields = ice.IceFields(**{k: g["in/" + k] for k in STATE})
+    return mesh, par, fields
+
+
+def bits(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64).ravel(); b = np.ascontiguousarray(b, dtype=np.float64).ravel()
+    return bool(((a.view(np.int64) == b.view(np.int64)) | ((a == 0) & (b == 0))).all())
+
+
+def oracle_evp(mesh, par, fields):
+    import oracle_lib
+    oracle_lib.build()
+    orc = C.CDLL(oracle_lib.ORC_LIB)
+    assert orc.orc_ice_evp(mesh.desc_p, C.byref(par), C.byref(fields.desc)) == 0
+
+
+def test_host_mesh_layer_supplies_the_ice_metrics(built):
+    """metric_factor (with the reference's quirk: every entry = tan(latitude of the last element)/r_earth, oce_mesh.F90:2183) and
+    coriolis_node of the host mesh layer equal the reference's arrays bit for bit; the coastal nodes formed from the boundary edges
+    are the nodes with bc_index_nod2D = 0 (oce_mesh.F90:2404-2413)"""
+    from fesom2_amd.mesh import Mesh
+    g = gold()
+    mesh = Mesh.load(PI, dt=900.0)
+    d = mesh.desc_p.contents
+    E, N = mesh.myDim_elem2D, mesh.myDim_nod2D
+    assert bits(np.ctypeslib.as_array(d.metric_factor, shape=(E,)), g["in/metric_factor"][:E])
+    assert bits(np.ctypeslib.as_array(d.coriolis_node, shape=(N,)), g["in/coriolis_node"])
+    edges = np.ctypeslib.as_array(d.edges, shape=(mesh.myDim_edge2D, 2)); lst = np.ctypeslib.as_array(d.myList_edge2D, shape=(mesh.myDim_edge2D,))
+    bc = np.ones(N); bc[edges[lst > d.edge2D_in].ravel() - 1] = 0
+    assert np.array_equal(bc, g["in/bc_index_nod2D"])
+
+
+def test_oracle_evp_equals_reference_bitwise(built):
+    g = gold()
+    mesh, par, fields = setup(g)
+    assert (fields["a_ice"] >= 0.01).sum() > 2000 and (fields["a_ice"] < 0.01).sum() > 100        # ice-covered and ice-free regions
+    for n in (1, 2):
+        oracle_evp(mesh, par, fields)
+        for k in OUT:
+            assert bits(fields[k], g[f"out{n}/{k}"]), (n, k, float(np.abs(fields[k] - g[f"out{n}/{k}"]).max()))
+    assert np.abs(fields["u_ice"] - g["in/u_ice"]).max() > 1e-3 and np.abs(fields["sigma11"]).max() > 1e3
+
+
+def test_oracle_evp_floating_ice_variant_runs(built):
+    """use_floatice (ice + snow load in the sea-surface slope term, ice_maEVP.F90:159-185): no reference run pins it (parity unpinned);
+    it changes the answer and stays finite"""
+    g = gold()
+    mesh, par, fields = setup(g, use_floatice=True)
+    oracle_evp(mesh, par, fields)
+    assert np.isfinite(fields["u_ice"]).all() and not bits(fields["u_ice"], g["out1/u_ice"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("floatice", [False, True])
+def test_gpu_evp_equals_oracle_and_reference_bitwise(built, floatice):
+    from fesom2_amd import ice
+    g = gold()
+    mesh, par, fo = setup(g, use_floatice=floatice)
+    _, _, fg = setup(g, use_floatice=floatice)
+    core = ice.IceCore(mesh, par)
+    core.upload(fg)
+    for n in (1, 2):
+        core.evp(1); core.download(fg)
+        oracle_evp(mesh, par, fo)
+        for k in OUT:
+            assert bits(fg[k], fo[k]), (n, k, float(np.abs(fg[k] - fo[k]).max()))
+            if not floatice:
+                assert bits(fg[k], g[f"out{n}/{k}"]), (n, k)
+    ms = core.time_ms(3)
+    assert 0.0 < ms < 50.0
+    core.close()

@@ -208,6 +208,30 @@ def test_oracle_chain_bitwise_w_split(built):
     assert np.count_nonzero(wi) > 1000                     # the split is really active
 
 
+def test_oracle_chain_bitwise_no_limiter(built):
+    """tra_adv_lim = 'NON' (src/oce_adv_tra_driver.F90:137-197: high-order fluxes with init_zero=.true., vertical part with the explicit
+    velocity, flux2dtracer without the low-order solution): reference run `pi_pp_non`, every routine of 3 steps bit for bit."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.synthetic import analytic_ts
+    from oracle_lib import Oracle
+    from ref_chain import run_reference_chain
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, tra_adv_lim="NON")
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    orc = Oracle(mesh, par)
+    orc.set_state(st)
+    g = gold("pi_pp_non")
+    for f in FORCING:
+        orc.set(f, g["forcing/" + f])
+    bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
+    assert not bad, "\n".join(bad[:20])
+    gf = gold("pi_pp_wsplit")                                # an FCT run: the limiter arrays are formed there, not here
+    assert not np.array_equal(g["s2/tr1.adv.fct_plus"], gf["s2/tr1.adv.fct_plus"])
+
+
 @pytest.mark.parametrize("opt", [4, 6, 7])
 def test_oracle_chain_bitwise_biharmonic_viscosity(built, opt):
     """visc_option = 4 (visc_filt_biharm(1), src/oce_dyn.F90:275-372), 6 (visc_filt_bilapl, :658-726) and 7 (visc_filt_bidiff, :734-801) instead
