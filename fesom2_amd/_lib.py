@@ -125,7 +125,7 @@ EXPORTS = ("fesom_gpu_init", "fesom_gpu_upload_state", "fesom_gpu_download_state
            "psolver_init", "psolve", "psolver_final",
            "fesom_gpu_halo_info", "fesom_gpu_halo_pack", "fesom_gpu_halo_unpack", "fesom_gpu_copy", "fesom_gpu_sync", "fesom_gpu_set_stream", "fesom_gpu_field_ptr",
            "fesom_gpu_comm_unique_id", "fesom_gpu_comm_init", "fesom_gpu_comm_finalize", "fesom_gpu_comm_selftest", "fesom_gpu_comm_timing", "fesom_gpu_comm_stats",
-           "fesom_gpu_ice_init", "fesom_gpu_ice_upload", "fesom_gpu_ice_evp", "fesom_gpu_ice_download", "fesom_gpu_ice_time_ms", "fesom_gpu_ice_finalize", "fesom_gpu_ice_last_error",
+           "fesom_gpu_ice_init", "fesom_gpu_ice_upload", "fesom_gpu_ice_evp", "fesom_gpu_ice_evp_partitioned", "fesom_gpu_ice_download", "fesom_gpu_ice_time_ms", "fesom_gpu_ice_finalize", "fesom_gpu_ice_last_error",
            "fesom_mesh_load", "fesom_mesh_get_desc", "fesom_mesh_get_part", "fesom_mesh_get_initial_state",
            "fesom_mesh_free")
 

@@ -319,6 +319,21 @@ int build_graph(int which) {
 }
 }  // namespace
 
+int fesom_internal_rccl_exchange(int ns, const int *sPE, const int *sptr, int nr, const int *rPE, const int *rptr, double *sd, double *rd, int W, hipStream_t s) {
+  if (!R.comm) { G.err = "built-in transport not initialised (fesom_gpu_comm_init)"; return 1; }
+  NCCLCHK(R.GroupStart());
+  for (int p = 0; p < ns; p++) {
+    const size_t first = (size_t)(sptr[p] - 1), cnt = (size_t)(sptr[p + 1] - sptr[p]);
+    if (cnt) NCCLCHK(R.Send(sd + first * W, cnt * W, ncclDouble, sPE[p], R.comm, s));
+  }
+  for (int p = 0; p < nr; p++) {
+    const size_t first = (size_t)(rptr[p] - 1), cnt = (size_t)(rptr[p + 1] - rptr[p]);
+    if (cnt) NCCLCHK(R.Recv(rd + first * W, cnt * W, ncclDouble, rPE[p], R.comm, s));
+  }
+  NCCLCHK(R.GroupEnd());
+  return 0;
+}
+
 extern "C" {
 
 const char *fesom_gpu_last_error(void) { return G.err.c_str(); }

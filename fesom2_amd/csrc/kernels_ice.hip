@@ -49,6 +49,12 @@ struct IceCtx {
   int cur = 0;               // parity of the buffers that hold the current stresses
   std::vector<int> h_en; std::vector<double> h_efac;
   std::string err;
+  // partition (npes > 1): com_nod2D lists of the rank, packed-message buffers
+  int npes = 1;
+  std::vector<int> sPE, sptr, rPE, rptr;
+  const int *slist = nullptr, *rlist = nullptr;     // device, 0-based
+  int nsend = 0, nrecv = 0;
+  double *hsend = nullptr, *hrecv = nullptr;
 } I;
 
 #define ICECHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { I.err = std::string(#x) + ": " + hipGetErrorString(e_); fprintf(stderr, "fesom_gpu_ice: %s\n", I.err.c_str()); return 1; } } while (0)
@@ -255,6 +261,28 @@ __global__ void k_ice_finish(IceDM m, int par) {             // u_ice = u_ice_au
   m.u_ice[i] = m.ua[par][i]; m.v_ice[i] = m.va[par][i];
 }
 
+// halo of (u_ice_aux, v_ice_aux) after a subcycle (exchange_nod_begin / _end, ice_maEVP.F90:588-596): per neighbour the u items then the v items
+__global__ void k_ice_pack(const double *__restrict__ u, const double *__restrict__ v, const int *__restrict__ list, const int *__restrict__ ptr, int npe, int nitems,
+                           double *__restrict__ buf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nitems) return;
+  int p = 0;
+  while (p + 1 < npe && i >= ptr[p + 1] - 1) p++;
+  const int first = ptr[p] - 1, cnt = ptr[p + 1] - ptr[p];
+  buf[(size_t)first * 2 + (i - first)] = u[list[i]];
+  buf[(size_t)first * 2 + cnt + (i - first)] = v[list[i]];
+}
+__global__ void k_ice_unpack(double *__restrict__ u, double *__restrict__ v, const int *__restrict__ list, const int *__restrict__ ptr, int npe, int nitems,
+                             const double *__restrict__ buf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nitems) return;
+  int p = 0;
+  while (p + 1 < npe && i >= ptr[p + 1] - 1) p++;
+  const int first = ptr[p] - 1, cnt = ptr[p + 1] - ptr[p];
+  u[list[i]] = buf[(size_t)first * 2 + (i - first)];
+  v[list[i]] = buf[(size_t)first * 2 + cnt + (i - first)];
+}
+
 // one EVPdynamics_m call; the stresses start in parity I.cur; returns the parity they end in
 int enqueue_call(hipStream_t s, int par) {
   const IceDM &m = I.m;
@@ -293,7 +321,7 @@ int fesom_gpu_ice_init(const fesom_mesh_desc *d, const fesom_part_desc *part, co
   I.err.clear();
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { I.err = "no HIP device: the MI355X path has no CPU fallback"; fprintf(stderr, "fesom_gpu_ice: %s\n", I.err.c_str()); return 2; }
-  if (part && part->npes > 1) { I.err = "fesom_gpu_ice_init: single partition only in this round"; return 3; }
+  I.npes = part ? part->npes : 1;
   if (par->evp_rheol_steps < 1) { I.err = "fesom_gpu_ice_init: evp_rheol_steps < 1"; return 3; }
   for (int e = 0; e < d->myDim_elem2D; e++) if (d->ulevels[e] != 1) { I.err = "fesom_gpu_ice_init: cavities (ulevels > 1) are not supported"; return 3; }
   ICECHK(hipStreamCreate(&I.stream));
@@ -335,6 +363,17 @@ int fesom_gpu_ice_init(const fesom_mesh_desc *d, const fesom_part_desc *part, co
   for (void *p : I.allocs) if (!p) { I.err = "fesom_gpu_ice_init: device allocation failed"; return 1; }
   I.h_efac.assign(E, 0.0);
   I.cur = 0;
+  if (I.npes > 1) {     // com_nod2D of this rank (gen_modules_partitioning.F90:17-29)
+    const fesom_com_desc &c = part->com_nod2D;
+    I.rPE.assign(c.rPE, c.rPE + c.rPEnum); I.rptr.assign(c.rptr, c.rptr + c.rPEnum + 1);
+    I.sPE.assign(c.sPE, c.sPE + c.sPEnum); I.sptr.assign(c.sptr, c.sptr + c.sPEnum + 1);
+    I.nrecv = I.rptr.back() - 1; I.nsend = I.sptr.back() - 1;
+    std::vector<int> rl(I.nrecv), sl(I.nsend);
+    for (int q = 0; q < I.nrecv; q++) rl[q] = c.rlist[q] - 1;
+    for (int q = 0; q < I.nsend; q++) sl[q] = c.slist[q] - 1;
+    I.rlist = iupload(rl); I.slist = iupload(sl);
+    I.hsend = ialloc<double>(2 * (size_t)I.nsend); I.hrecv = ialloc<double>(2 * (size_t)I.nrecv);
+  }
   ICECHK(hipDeviceSynchronize());
   I.ready = true;
   return 0;
@@ -378,6 +417,44 @@ int fesom_gpu_ice_evp(int ncalls) {
       }
       ICECHK(hipGraphLaunch(I.graph, I.stream));
     } else I.cur = enqueue_call(I.stream, I.cur);
+  }
+  ICECHK(hipGetLastError());
+  return 0;
+}
+// Partitioned run (one rank per GPU): the same call with the halo of (u_ice_aux, v_ice_aux) exchanged after every subcycle, as the
+// reference does (ice_maEVP.F90:588-596).  t == NULL: the library's built-in RCCL transport (fesom_gpu_comm_init); else the host's
+// callbacks (exchange is called with kind 0 = com_nod2D and two values per item).
+int fesom_gpu_ice_evp_partitioned(int ncalls, const fesom_transport *t) {
+  ICE_READY();
+  if (I.npes < 2) return fesom_gpu_ice_evp(ncalls);
+  if (t && !t->exchange) { I.err = "ice_evp_partitioned: transport callback missing"; return 1; }
+  const IceDM &m = I.m;
+  static const int *sptr_d = nullptr, *rptr_d = nullptr;
+  static const void *owner = nullptr;
+  if (owner != (const void *)I.slist) { sptr_d = iupload(I.sptr); rptr_d = iupload(I.rptr); owner = (const void *)I.slist; }
+  hipStream_t s = I.stream;
+  for (int c = 0; c < ncalls; c++) {
+    int par = I.cur;
+    hipLaunchKernelGGL(k_ice_prep_node, dim3((m.N + 255) / 256), dim3(256), 0, s, m);
+    hipLaunchKernelGGL(k_ice_prep_elem, dim3((m.myE + 255) / 256), dim3(256), 0, s, m);
+    if (par == 1) {
+      ICECHK(hipMemcpyAsync(m.ua[1], m.ua[0], sizeof(double) * m.N, hipMemcpyDeviceToDevice, s));
+      ICECHK(hipMemcpyAsync(m.va[1], m.va[0], sizeof(double) * m.N, hipMemcpyDeviceToDevice, s));
+    }
+    for (int k = 0; k < m.p.evp_rheol_steps; k++) {
+      hipLaunchKernelGGL(k_ice_sub8, dim3((unsigned)(((size_t)m.N * 8 + 255) / 256)), dim3(256), 0, s, m, par);
+      par = 1 - par;
+      if (I.nsend > 0) hipLaunchKernelGGL(k_ice_pack, dim3((I.nsend + 255) / 256), dim3(256), 0, s, m.ua[par], m.va[par], I.slist, sptr_d, (int)I.sPE.size(), I.nsend, I.hsend);
+      if (t) {
+        ICECHK(hipStreamSynchronize(s));                      // (a host transport reads the packed buffer)
+        if (t->exchange(t->ctx, 0, I.hsend, I.hrecv, 2)) { I.err = "ice_evp_partitioned: transport exchange failed"; return 1; }
+      } else if (fesom_internal_rccl_exchange((int)I.sPE.size(), I.sPE.data(), I.sptr.data(), (int)I.rPE.size(), I.rPE.data(), I.rptr.data(), I.hsend, I.hrecv, 2, s)) {
+        I.err = "ice_evp_partitioned: built-in transport failed (fesom_gpu_comm_init?)"; return 1;
+      }
+      if (I.nrecv > 0) hipLaunchKernelGGL(k_ice_unpack, dim3((I.nrecv + 255) / 256), dim3(256), 0, s, m.ua[par], m.va[par], I.rlist, rptr_d, (int)I.rPE.size(), I.nrecv, I.hrecv);
+    }
+    hipLaunchKernelGGL(k_ice_finish, dim3((m.N + 255) / 256), dim3(256), 0, s, m, par);
+    I.cur = par;
   }
   ICECHK(hipGetLastError());
   return 0;

@@ -41,7 +41,7 @@ struct Mesh {
   ivec elem_nodes, edges, edge_tri, elem_edges, elem_nb, nie, nie_num;
   ivec nlev, ulev, nlev_n, ulev_n, nlev_n_min, ulev_n_max;
   dvec elem_area, area, area_inv, areasvol, areasvol_inv, resol;
-  dvec grad_sca, grad_vec, edge_dxdy, edge_cross, elem_cos, metric, cori, cori_n;
+  dvec grad_sca, grad_vec, edge_dxdy, edge_cross, elem_cos, metric, cori, cori_n, cen_y;
   ivec rowptr, colind, colind_loc; dvec values;
   ivec updn;
   dvec zbar_n_bot, zbar_n_srf, bot_n_th, zbar_e_bot, zbar_e_srf, bot_e_th;
@@ -369,6 +369,7 @@ void auxiliary(Mesh &m) {
   // reference quirk (oce_mesh.F90:2183): the whole metric_factor array is assigned in every iteration,
   // so every entry ends up tan(center_y(last element))/r_earth
   { double v = tan(cy[m.E2 - 1]) / R_EARTH; std::fill(m.metric.begin(), m.metric.end(), v); }
+  m.cen_y = cy;
   m.edge_dxdy.resize(2 * m.D2); m.edge_cross.resize(4 * m.D2);
   for (int d = 1; d <= m.D2; d++) {
     int n1 = ED(1, d), n2 = ED(2, d);
@@ -798,7 +799,12 @@ void make_local(Mesh &m, int np, int me) {
   d.mesh_resolution = KD(gather(m.resol, 1, m.list_n, Nl));
   d.gradient_sca = KD(gather(m.grad_sca, 6, m.list_e, m.myE)); d.gradient_vec = KD(gather(m.grad_vec, 6, m.list_e, m.myE));
   d.edge_dxdy = KD(gather(m.edge_dxdy, 2, m.list_d, Dl)); d.edge_cross_dxdy = KD(gather(m.edge_cross, 4, m.list_d, Dl));
-  d.elem_cos = KD(gather(m.elem_cos, 1, m.list_e, EX)); d.metric_factor = KD(gather(m.metric, 1, m.list_e, EX));
+  d.elem_cos = KD(gather(m.elem_cos, 1, m.list_e, EX));
+  {   // the quirk of oce_mesh.F90:2183 on a partition: every rank ends up with tan(latitude of ITS last owned element)/r_earth in all its
+      // owned entries (halo entries take their owner's value in the reference; nothing on the hot path reads them: the rank's own value here)
+    dvec mf(EX, tan(m.cen_y[m.list_e[m.myE - 1] - 1]) / R_EARTH);
+    d.metric_factor = KD(mf);
+  }
   d.coriolis = KD(gather(m.cori, 1, m.list_e, m.myE)); d.coriolis_node = KD(gather(m.cori_n, 1, m.list_n, Nl));
   d.edge_up_dn_tri = KI(tr(gather(m.updn, 2, m.list_d, m.myD), ge));
   d.zbar_n_bot = KD(gather(m.zbar_n_bot, 1, m.list_n, Nl)); d.zbar_n_srf = KD(gather(m.zbar_n_srf, 1, m.list_n, Nl));

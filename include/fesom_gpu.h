@@ -261,7 +261,7 @@ int  fesom_gpu_set_stream(void *hip_stream);   /* run the library's kernels on t
 /* ---- sea-ice mEVP rheology: EVPdynamics_m (src/ice_maEVP.F90:273-602), the subcycled momentum solve of the sea-ice model
  * (whichEVP = 1; Bouillon et al. 2013 / Kimmritz et al. 2015).  One call = evp_rheol_steps subcycles (default 120) of: strain rates
  * and viscous-plastic stresses on elements, stress divergence gathered to nodes, implicit Coriolis / ocean-drag velocity update,
- * coastal boundary condition.  Independent of the ocean core's context (may coexist with it); single partition in this round.
+ * coastal boundary condition.  Independent of the ocean core's context (may coexist with it); partitions: fesom_gpu_ice_evp_partitioned.
  * Arrays keep the reference's extents: node fields myDim_nod2D + eDim_nod2D, stresses myDim_elem2D.  Not built: cavities
  * (ulevels > 1), icepack, the other two EVP variants (whichEVP = 0, 2). */
 typedef struct fesom_ice_params {
@@ -279,6 +279,7 @@ typedef struct fesom_ice_state {
 int  fesom_gpu_ice_init(const fesom_mesh_desc *mesh, const fesom_part_desc *part, const fesom_ice_params *par);
 int  fesom_gpu_ice_upload(const fesom_ice_state *st);     /* every non-NULL field host -> device */
 int  fesom_gpu_ice_evp(int ncalls);                       /* ncalls x EVPdynamics_m on the device-resident state; asynchronous */
+int  fesom_gpu_ice_evp_partitioned(int ncalls, const fesom_transport *t);   /* npes > 1: halo of (u_ice_aux, v_ice_aux) after every subcycle (ice_maEVP.F90:588-596); t == NULL: built-in RCCL transport */
 int  fesom_gpu_ice_download(const fesom_ice_state *st);   /* u_ice, v_ice, sigma11/12/22 device -> host (synchronises) */
 int  fesom_gpu_ice_time_ms(int ncalls, double *ms_per_call);   /* device time of a call (HIP events), state left as after the calls */
 int  fesom_gpu_ice_finalize(void);

@@ -22,5 +22,15 @@ for n in (1, 2):
     b = read_dump(os.path.join(rd, "dumps", f"ice_out{n:04d}.r00000.bin"))
     for k in ("u_ice", "v_ice", "sigma11", "sigma12", "sigma22"):
         out[f"out{n}/{k}"] = np.array(b[k])
+# the same on TWO ranks (dist_2): rank-local inputs and outputs of one call -- the pin of the partitioned GPU path (halo exchange of
+# u_ice_aux / v_ice_aux after every subcycle); the reference's result differs from the 1-rank one through the metric_factor quirk
+rd2, rc2, lines2 = run_ref.run("pi_pp", 2, 1, mode="ice", dump=(1,))
+assert rc2 == 0
+for r in range(2):
+    a = read_dump(os.path.join(rd2, "dumps", f"ice_in.r{r:05d}.bin")); b = read_dump(os.path.join(rd2, "dumps", f"ice_out0001.r{r:05d}.bin"))
+    for k in ("u_ice", "v_ice", "a_ice", "m_ice", "m_snow", "elevation", "u_w", "v_w", "stress_atmice_x", "stress_atmice_y", "sigma11", "sigma12", "sigma22", "metric_factor"):
+        out[f"r2/{r}/in/{k}"] = np.array(a[k])
+    for k in ("u_ice", "v_ice", "sigma11", "sigma12", "sigma22"):
+        out[f"r2/{r}/out1/{k}"] = np.array(b[k])
 np.savez_compressed(os.path.join(HERE, "ice_evp_reference.npz"), **out)
 print("wrote ice_evp_reference.npz:", {k: v.shape for k, v in out.items() if k.startswith("in/")}, lines)

@@ -95,3 +95,27 @@ def test_gpu_evp_equals_oracle_and_reference_bitwise(built, floatice):
     ms = core.time_ms(3)
     assert 0.0 < ms < 50.0
     core.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["callback", "builtin"])
+def test_gpu_partitioned_evp_equals_reference(built, transport):
+    """2 ranks (the reference's dist_2 partition of pi, sharing the GPU): halo of (u_ice_aux, v_ice_aux) after every subcycle through the
+    host-callback transport (gloo) or the library's built-in transport (shared-memory stand-in for librccl); every rank's u_ice, v_ice
+    (owned + halo) and stresses equal the rank-local outputs of the reference's own 2-rank run bit for bit -- including the
+    reference's partition-dependent metric_factor (oce_mesh.F90:2183)."""
+    import json, re, subprocess, sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", FESOM_GPU_DEVICE="0")
+    if transport == "builtin":
+        fake = os.path.join(REPO, "tests", "helpers", "libfake_rccl.so")
+        assert os.path.exists(fake)
+        env.update(FESOM_GPU_RCCL_LIB=fake, PART_TRANSPORT="rccl")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29830 + (1 if transport == "builtin" else 0)), os.path.join(REPO, "tests", "helpers", "partitioned_ice_worker.py")],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    reps = [json.loads(x) for x in re.findall(r"ICEREPORT (\{.*\})", r.stdout)]
+    assert len(reps) == 2
+    for rep in reps:
+        assert rep["bad"] == [], rep
+        assert rep["changed"] > 1e-3
