@@ -53,6 +53,7 @@ struct IceCtx {
   int npes = 1;
   std::vector<int> sPE, sptr, rPE, rptr;
   const int *slist = nullptr, *rlist = nullptr;     // device, 0-based
+  const int *sptr_d = nullptr, *rptr_d = nullptr;   // device copies of the 1-based block pointers
   int nsend = 0, nrecv = 0;
   double *hsend = nullptr, *hrecv = nullptr;
 } I;
@@ -372,6 +373,7 @@ int fesom_gpu_ice_init(const fesom_mesh_desc *d, const fesom_part_desc *part, co
     for (int q = 0; q < I.nrecv; q++) rl[q] = c.rlist[q] - 1;
     for (int q = 0; q < I.nsend; q++) sl[q] = c.slist[q] - 1;
     I.rlist = iupload(rl); I.slist = iupload(sl);
+    I.sptr_d = iupload(I.sptr); I.rptr_d = iupload(I.rptr);
     I.hsend = ialloc<double>(2 * (size_t)I.nsend); I.hrecv = ialloc<double>(2 * (size_t)I.nrecv);
   }
   ICECHK(hipDeviceSynchronize());
@@ -429,9 +431,7 @@ int fesom_gpu_ice_evp_partitioned(int ncalls, const fesom_transport *t) {
   if (I.npes < 2) return fesom_gpu_ice_evp(ncalls);
   if (t && !t->exchange) { I.err = "ice_evp_partitioned: transport callback missing"; return 1; }
   const IceDM &m = I.m;
-  static const int *sptr_d = nullptr, *rptr_d = nullptr;
-  static const void *owner = nullptr;
-  if (owner != (const void *)I.slist) { sptr_d = iupload(I.sptr); rptr_d = iupload(I.rptr); owner = (const void *)I.slist; }
+  const int *sptr_d = I.sptr_d, *rptr_d = I.rptr_d;
   hipStream_t s = I.stream;
   for (int c = 0; c < ncalls; c++) {
     int par = I.cur;
