@@ -61,6 +61,7 @@ module fesom_gpu_shim
      integer(c_int) :: scaling_Ferreira, scaling_Rossby, scaling_resolution, scaling_FESOM14, Redi
      real(c_double) :: visc_sh_limit, diff_sh_limit, Ricr, concv
      integer(c_int) :: use_sw_pene, tra_adv_ver, tra_adv_hor, Kv0_const, solver_precond, tra_adv_lim, solver_xinv_its
+     real(c_double) :: Leith_c, Div_c
   end type
   type, bind(C) :: fesom_state_desc
      type(c_ptr) :: tr_arr, tr_arr_old, UV, UV_rhsAB, eta_n, d_eta, ssh_rhs, ssh_rhs_old, hbar, hbar_old, dhe, hnode, hnode_new, &
@@ -310,6 +311,7 @@ contains
     case default; p%tra_adv_lim = -1
     end select
     p%Kv0_const = l2i(Kv0_const)
+    p%Leith_c = Leith_c; p%Div_c = Div_c
     p%solver_precond = 1; p%solver_xinv_its = 0     ! explicit-inverse preconditioner where it fits (pi), library default iterations
 
     transport%ctx = c_null_ptr

@@ -90,7 +90,8 @@ typedef struct fesom_params {
   int    state_equation;     /* 1 Jackett-McDougall, 0 linear */
   int    num_tracers;
   int    mom_adv;            /* 2 (scalar control volumes) */
-  int    visc_option;        /* 5 (easy backscatter, visc_filt_bcksct), 6 (visc_filt_bilapl), 7 (visc_filt_bidiff); oce_dyn.F90:196-228 */
+  int    visc_option;        /* 5 (easy backscatter, visc_filt_bcksct; default), 1 (Leith + visc_filt_harmon), 2 (Leith + visc_filt_hbhmix), 3 (Leith + visc_filt_biharm(2)),
+                                4 (visc_filt_biharm(1)), 6 (visc_filt_bilapl), 7 (visc_filt_bidiff); oce_dyn.F90:196-228 */
   int    i_vert_visc, i_vert_diff, w_split;
   int    mix_scheme;         /* 1 = KPP (oce_ale_mixing_kpp.F90) ; 2 = PP ; 0 = constant A_ver/K_ver (no mixing scheme) */
   int    use_instabmix, use_windmix, windmix_nl;
@@ -132,6 +133,8 @@ typedef struct fesom_params {
                                 explicit velocity; not together with w_split) */
   int    solver_xinv_its;    /* solver_precond=1: BiCGstab iterations enqueued per solve (no host read-back inside a step); a solve that
                                 has not converged by then is finished by the Jacobi-preconditioned one-workgroup solver.  0 = default (2) */
+  double Leith_c, Div_c;     /* visc_option 1-3: weights of the Leith and the modified (divergence) Leith viscosity (namelist.oce &oce_dyn; h_viscosity_leith,
+                                src/oce_dyn.F90:461-561) */
 } fesom_params;
 
 /* ---- prognostic state = restart set (io_restart.F90:99-155) + ALE thickness arrays -- */

@@ -34,6 +34,7 @@ typedef struct {
   double *pgf_x, *pgf_y, *helem;                 /* (nl-1,E) */
   double *Av;                                    /* (nl,E) */
   double *dhe, *stress_surf;                     /* (E), (2,E) */
+  double *Visc, *vorticity, *leith_aux;          /* Leith viscosity (nl-1,E), relative vorticity (nl-1,N), smoothing work array (nl-1,N) */
   /* edge */
   double *adv_flux_hor;                          /* (nl-1,D) */
   double *edge_up_dn_grad;                       /* (4,nl-1,D) */

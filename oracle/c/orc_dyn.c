@@ -489,9 +489,137 @@ double orc_kv0_background_qiang(int n, int nz) {
   return aux * ratio;
 }
 
-/* viscosity_filter(visc_option): src/oce_dyn.F90:196-228 (options 4, 5, 6, 7) */
+/* relative_vorticity: src/oce_vel_rhs_vinv.F90:14-102 (circulation around the scalar control volumes / areasvol) */
+static void relative_vorticity(void) {
+  double *vo = C_.vorticity;
+  for (int n = 1; n <= C_.m.myDim_nod2D; n++) for (int nz = 1; nz <= NLM1; nz++) A2(vo, nz, n) = 0.0;
+  for (int ed = 1; ed <= C_.m.myDim_edge2D; ed++) {
+    int n1 = EDG(1, ed), n2 = EDG(2, ed), e1 = ETRI(1, ed), e2 = ETRI(2, ed);
+    int nl1 = NLEV(e1) - 1, ul1 = ULEV(e1), nl2 = 0, ul2 = 0;
+    double dX1 = ECD(1, ed), dY1 = ECD(2, ed), dX2 = 0, dY2 = 0;
+    if (e2 > 0) { dX2 = ECD(3, ed); dY2 = ECD(4, ed); nl2 = NLEV(e2) - 1; ul2 = ULEV(e2); }
+    int nl12 = nl1 < nl2 ? nl1 : nl2, ul12 = ul1 > ul2 ? ul1 : ul2;
+#define VADD(c1) { A2(vo, nz, n1) = A2(vo, nz, n1) + (c1); A2(vo, nz, n2) = A2(vo, nz, n2) - (c1); }
+    for (int nz = ul1; nz <= ul12 - 1; nz++) VADD(dX1 * V2(C_.UV, 1, nz, e1) + dY1 * V2(C_.UV, 2, nz, e1));
+    if (ul2 > 0) for (int nz = ul2; nz <= ul12 - 1; nz++) VADD(-dX2 * V2(C_.UV, 1, nz, e2) - dY2 * V2(C_.UV, 2, nz, e2));
+    for (int nz = ul12; nz <= nl12; nz++) VADD(dX1 * V2(C_.UV, 1, nz, e1) + dY1 * V2(C_.UV, 2, nz, e1) - dX2 * V2(C_.UV, 1, nz, e2) - dY2 * V2(C_.UV, 2, nz, e2));
+    for (int nz = nl12 + 1; nz <= nl1; nz++) VADD(dX1 * V2(C_.UV, 1, nz, e1) + dY1 * V2(C_.UV, 2, nz, e1));
+    for (int nz = nl12 + 1; nz <= nl2; nz++) VADD(-dX2 * V2(C_.UV, 1, nz, e2) - dY2 * V2(C_.UV, 2, nz, e2));
+#undef VADD
+  }
+  for (int n = 1; n <= C_.m.myDim_nod2D; n++)
+    for (int nz = ULEVN(n); nz <= NLEVN(n) - 1; nz++) A2(vo, nz, n) = A2(vo, nz, n) / AREASVOL(nz, n);
+  /* (exchange_nod(vorticity): single partition) */
+}
+
+/* h_viscosity_leith: src/oce_dyn.F90:461-561 (Leith + modified Leith coefficient, two rounds of node / element averaging) */
+static void h_viscosity_leith(void) {
+  const int nl = NL;
+  double *Visc = C_.Visc, *aux = C_.leith_aux, *zbar_n = calloc((size_t)nl + 2, sizeof(double));
+  const double dt = C_.p.dt, g1 = C_.p.gamma1, Div_c = C_.p.Div_c, Leith_c = C_.p.Leith_c;
+  relative_vorticity();                                   /* mom_adv < 4 */
+  memset(Visc, 0, sizeof(double) * (size_t)NLM1 * C_.E);
+  for (int e = 1; e <= C_.m.myDim_elem2D; e++) {
+    int nl1 = NLEV(e) - 1, ul1 = ULEV(e), en[3] = {EN(1, e), EN(2, e), EN(3, e)};
+    for (int k = 0; k <= nl + 1; k++) zbar_n[k] = 0.0;
+    zbar_n[nl1 + 1] = C_.m.zbar_e_bot[e - 1];
+    for (int nz = nl1; nz >= ul1 + 1; nz--) zbar_n[nz] = zbar_n[nz + 1] + A2(C_.helem, nz, e);
+    zbar_n[ul1] = zbar_n[ul1 + 1] + A2(C_.helem, ul1, e);
+    const double ar = C_.m.elem_area[e - 1];
+    for (int nz = ul1; nz <= nl1; nz++) {
+      double dz = zbar_n[nz] - zbar_n[nz + 1], d3[3], v3[3];
+      for (int j = 0; j < 3; j++) { d3[j] = (A2L(C_.Wvel, nz, en[j]) - A2L(C_.Wvel, nz + 1, en[j])) / dz; v3[j] = A2(C_.vorticity, nz, en[j]); }
+      double xe = (GS(1, e) * d3[0] + GS(2, e) * d3[1]) + GS(3, e) * d3[2], ye = (GS(4, e) * d3[0] + GS(5, e) * d3[1]) + GS(6, e) * d3[2];
+      double lx = (GS(1, e) * v3[0] + GS(2, e) * v3[1]) + GS(3, e) * v3[2], ly = (GS(4, e) * v3[0] + GS(5, e) * v3[1]) + GS(6, e) * v3[2];
+      A2(Visc, nz, e) = dmin(g1 * ar * sqrt((Div_c * (xe * xe + ye * ye) + Leith_c * (lx * lx + ly * ly)) * ar), ar / dt);
+    }
+  }
+  memset(aux, 0, sizeof(double) * (size_t)NLM1 * C_.N);
+  for (int nt = 1; nt <= 2; nt++) {
+    for (int n = 1; n <= C_.m.myDim_nod2D; n++)
+      for (int nz = ULEVN(n); nz <= NLEVN(n) - 1; nz++) {
+        double dz = 0.0, vi = 0.0;
+        for (int k = 1; k <= C_.m.nod_in_elem2D_num[n - 1]; k++) {
+          int el = NIE(k, n);
+          dz = dz + C_.m.elem_area[el - 1];
+          vi = vi + A2(Visc, nz, el) * C_.m.elem_area[el - 1];
+        }
+        A2(aux, nz, n) = vi / dz;
+      }
+    /* (exchange_nod(aux): single partition) */
+    for (int e = 1; e <= C_.m.myDim_elem2D; e++) {
+      int nl1 = NLEV(e) - 1, ul1 = ULEV(e), n1 = EN(1, e), n2 = EN(2, e), n3 = EN(3, e);
+      for (int nz = 1; nz <= NLM1; nz++) A2(Visc, nz, e) = (nz >= ul1 && nz <= nl1) ? ((A2(aux, nz, n1) + A2(aux, nz, n2)) + A2(aux, nz, n3)) / 3.0 : 0.0;
+    }
+  }
+  /* (exchange_elem(Visc): single partition) */
+  free(zbar_n);
+}
+
+/* visc_filt_harmon (option 1, :236-273) and the harmonic Leith part of visc_filt_hbhmix (option 2, :376-458), which also leaves the
+ * first stage of its biharmonic background in U_c; visc_filt_biharm(2) (option 3, :275-372) is the two-stage filter of option 4 with
+ * the Leith coefficient */
+static void visc_filt_leith(int opt) {
+  double *Uc = C_.U_b, *Visc = C_.Visc;
+  const double dt = C_.p.dt, g0 = C_.p.gamma0;
+  memset(Uc, 0, sizeof(double) * 2 * NLM1 * C_.E);
+  if (opt == 1 || opt == 2)
+    for (int ed = 1; ed <= C_.D; ed++) {
+      if (C_.m.myList_edge2D[ed - 1] > C_.m.edge2D_in) continue;
+      int e1 = ETRI(1, ed), e2 = ETRI(2, ed);
+      double a1 = C_.m.elem_area[e1 - 1], a2 = C_.m.elem_area[e2 - 1], len = sqrt(a1 + a2);
+      int nzmax = NLEV(e1) < NLEV(e2) ? NLEV(e1) : NLEV(e2), nzmin = ULEV(e1) > ULEV(e2) ? ULEV(e1) : ULEV(e2);
+      for (int nz = nzmin; nz <= nzmax - 1; nz++) {
+        double u1 = V2(C_.UV, 1, nz, e1) - V2(C_.UV, 1, nz, e2), v1 = V2(C_.UV, 2, nz, e1) - V2(C_.UV, 2, nz, e2), vi;
+        if (opt == 1) { vi = 0.5 * (A2(Visc, nz, e1) + A2(Visc, nz, e2)); vi = dmax(vi, g0 * len) * dt; }
+        else {
+          vi = dt * 0.5 * (A2(Visc, nz, e1) + A2(Visc, nz, e2));
+          V2(Uc, 1, nz, e1) = V2(Uc, 1, nz, e1) - u1; V2(Uc, 1, nz, e2) = V2(Uc, 1, nz, e2) + u1;
+          V2(Uc, 2, nz, e1) = V2(Uc, 2, nz, e1) - v1; V2(Uc, 2, nz, e2) = V2(Uc, 2, nz, e2) + v1;
+        }
+        u1 = u1 * vi; v1 = v1 * vi;
+        V2(C_.UV_rhs, 1, nz, e1) = V2(C_.UV_rhs, 1, nz, e1) - u1 / a1; V2(C_.UV_rhs, 1, nz, e2) = V2(C_.UV_rhs, 1, nz, e2) + u1 / a2;
+        V2(C_.UV_rhs, 2, nz, e1) = V2(C_.UV_rhs, 2, nz, e1) - v1 / a1; V2(C_.UV_rhs, 2, nz, e2) = V2(C_.UV_rhs, 2, nz, e2) + v1 / a2;
+      }
+    }
+  if (opt == 1) return;
+  if (opt == 3)                                           /* first stage of visc_filt_biharm */
+    for (int ed = 1; ed <= C_.D; ed++) {
+      if (C_.m.myList_edge2D[ed - 1] > C_.m.edge2D_in) continue;
+      int e1 = ETRI(1, ed), e2 = ETRI(2, ed);
+      int nzmax = NLEV(e1) < NLEV(e2) ? NLEV(e1) : NLEV(e2), nzmin = ULEV(e1) > ULEV(e2) ? ULEV(e1) : ULEV(e2);
+      for (int nz = nzmin; nz <= nzmax - 1; nz++) {
+        double u1 = V2(C_.UV, 1, nz, e1) - V2(C_.UV, 1, nz, e2), v1 = V2(C_.UV, 2, nz, e1) - V2(C_.UV, 2, nz, e2);
+        V2(Uc, 1, nz, e1) = V2(Uc, 1, nz, e1) - u1; V2(Uc, 1, nz, e2) = V2(Uc, 1, nz, e2) + u1;
+        V2(Uc, 2, nz, e1) = V2(Uc, 2, nz, e1) - v1; V2(Uc, 2, nz, e2) = V2(Uc, 2, nz, e2) + v1;
+      }
+    }
+  for (int e = 1; e <= C_.m.myDim_elem2D; e++) {
+    double len = sqrt(C_.m.elem_area[e - 1]);
+    for (int nz = ULEV(e); nz <= NLEV(e) - 1; nz++) {
+      double vi = (opt == 2) ? dt * g0 * len : dmax(A2(Visc, nz, e), g0 * len) * dt;
+      V2(Uc, 1, nz, e) = -V2(Uc, 1, nz, e) * vi;
+      V2(Uc, 2, nz, e) = -V2(Uc, 2, nz, e) * vi;
+    }
+  }
+  /* (exchange_elem(U_c), exchange_elem(V_c): single partition) */
+  for (int ed = 1; ed <= C_.D; ed++) {
+    if (C_.m.myList_edge2D[ed - 1] > C_.m.edge2D_in) continue;
+    int e1 = ETRI(1, ed), e2 = ETRI(2, ed);
+    double a1 = C_.m.elem_area[e1 - 1], a2 = C_.m.elem_area[e2 - 1];
+    int nzmax = NLEV(e1) < NLEV(e2) ? NLEV(e1) : NLEV(e2), nzmin = ULEV(e1) > ULEV(e2) ? ULEV(e1) : ULEV(e2);
+    for (int nz = nzmin; nz <= nzmax - 1; nz++) {
+      double u1 = V2(Uc, 1, nz, e1) - V2(Uc, 1, nz, e2), v1 = V2(Uc, 2, nz, e1) - V2(Uc, 2, nz, e2);
+      V2(C_.UV_rhs, 1, nz, e1) = V2(C_.UV_rhs, 1, nz, e1) - u1 / a1; V2(C_.UV_rhs, 1, nz, e2) = V2(C_.UV_rhs, 1, nz, e2) + u1 / a2;
+      V2(C_.UV_rhs, 2, nz, e1) = V2(C_.UV_rhs, 2, nz, e1) - v1 / a1; V2(C_.UV_rhs, 2, nz, e2) = V2(C_.UV_rhs, 2, nz, e2) + v1 / a2;
+    }
+  }
+}
+
+/* viscosity_filter(visc_option): src/oce_dyn.F90:196-228 (options 1-7) */
 void orc_viscosity_filter(void) {
   if (C_.p.visc_option == 5) orc_visc_filt_bcksct();
+  else if (C_.p.visc_option <= 3) { h_viscosity_leith(); visc_filt_leith(C_.p.visc_option); }
   else visc_filt_biharmonic(C_.p.visc_option);
 }
 

@@ -482,6 +482,9 @@ contains
     call mark('viscosity_filter')
     call viscosity_filter(visc_option, mesh)
     call dump('viscosity_filter.UV_rhs', UV_rhs)
+    if (visc_option<=3) then
+       call dump('viscosity_filter.Visc', Visc); call dump('viscosity_filter.vorticity', vorticity)
+    end if
     call mark('impl_vert_visc_ale')
     if (i_vert_visc) call impl_vert_visc_ale(mesh)
     call dump('impl_vert_visc_ale.UV_rhs', UV_rhs)

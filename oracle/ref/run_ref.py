@@ -186,6 +186,19 @@ CFGS = {
                       rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                       fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
                       balance_salt_water=".true.", synth_forcing=True, tra_adv_lim="NON"),
+    # visc_option = 1, 2, 3: Leith viscosity (h_viscosity_leith) with the harmonic / harmonic + biharmonic background / biharmonic filter
+    "pi_pp_visc1": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                        fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                        balance_salt_water=".true.", synth_forcing=True, visc_option=1),
+    "pi_pp_visc2": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                        fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                        balance_salt_water=".true.", synth_forcing=True, visc_option=2),
+    "pi_pp_visc3": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                        fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                        balance_salt_water=".true.", synth_forcing=True, visc_option=3),
     # visc_option = 4: visc_filt_biharm(1), the biharmonic "third-order-upwind-like" filter (src/oce_dyn.F90:275-372)
     "pi_pp_visc4": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
                         rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,

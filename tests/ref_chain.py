@@ -49,6 +49,8 @@ def run_reference_chain(orc, mesh, g, steps=(1, 2, 3), toy=False, skip=(), after
         orc.call("mo_convect"); chk(step, "Av", "mixing.Av"); chk(step, "Kv", "mixing.Kv")
         orc.call("compute_vel_rhs"); chk(step, "UV_rhs", "compute_vel_rhs.UV_rhs", "e2"); chk(step, "UV_rhsAB", "compute_vel_rhs.UV_rhsAB", "e2")
         orc.call("viscosity_filter"); chk(step, "UV_rhs", "viscosity_filter.UV_rhs", "e2")
+        if orc.params.visc_option <= 3:                     # h_viscosity_leith (src/oce_dyn.F90:461-561)
+            chk(step, "vorticity", "viscosity_filter.vorticity", "n"); chk(step, "Visc", "viscosity_filter.Visc", "e")
         orc.call("impl_vert_visc_ale"); chk(step, "UV_rhs", "impl_vert_visc_ale.UV_rhs", "e2")
         if orc.params.which_ale != 0:
             orc.call("update_stiff_mat_ale")
