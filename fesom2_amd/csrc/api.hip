@@ -257,7 +257,9 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   launch_row_scale(m, s1);
   hipEvent_t ev_op = d.ev(); hipEventRecord(ev_op, s1);
   // s3: viscosity stencil, then everything nobody waits for soon (sigma/slope, tracer preparation)
-  K(s3, "k_visc_elem"); if (m.p.visc_option == 5) K(s3, "k_visc_node");
+  if (m.p.visc_option <= 3) K(s3, "h_viscosity_leith");      // UV, Wvel, helem of the incoming state only
+  if (m.p.visc_option != 1) K(s3, "k_visc_elem");
+  if (m.p.visc_option == 5) K(s3, "k_visc_node");
   hipEvent_t ev_visc = d.ev(); hipEventRecord(ev_visc, s3);
   hipStreamWaitEvent(s3, ev_pb, 0);
   K(s3, "k_sigma_slope");
@@ -360,7 +362,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { G.err = "no HIP device: the MI355X path has no CPU fallback"; fprintf(stderr, "fesom_gpu: %s\n", G.err.c_str()); return 2; }
   if (d->nl > 64) { G.err = "fesom_gpu_init: nl > 64 levels not supported by the one-wave-per-column kernels"; return 3; }
   if (par->which_ale != 0 && par->which_ale != 2) { G.err = "fesom_gpu_init: which_ale must be linfs(0) or zstar(2)"; return 3; }
-  if (par->mom_adv != 2 || par->visc_option < 4 || par->visc_option > 7) { G.err = "fesom_gpu_init: only mom_adv=2, visc_option=4,5,6,7 are implemented"; return 3; }
+  if (par->mom_adv != 2 || par->visc_option < 1 || par->visc_option > 7) { G.err = "fesom_gpu_init: only mom_adv=2, visc_option=1..7 are implemented"; return 3; }
   if (par->Fer_GM && par->scaling_Rossby) { G.err = "fesom_gpu_init: scaling_Rossby=.true. (GM cut-off by the Rossby radius) is not implemented"; return 3; }
   if (par->tra_adv_ver < 0 || par->tra_adv_ver > 3 || par->tra_adv_hor < 0 || par->tra_adv_hor > 2) {
     G.err = "fesom_gpu_init: tra_adv_ver must be QR4C (0), CDIFF (1), UPW1 (2) or PPM (3), tra_adv_hor MFCT (0), MUSCL (1) or UPW1 (2), tra_adv_lim='FCT'"; return 3;
@@ -527,6 +529,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   F(pgf_x, n1 * E); F(pgf_y, n1 * E); F(helem, n1 * E); F(Av, nl * E); F(dhe, E);
   FT(adv_flux_hor, n1 * D); FT(adv_flux_raw, n1 * D); FT(flux_lo_hor, n1 * D); FT(diff_flux, n1 * D); FT(edge_up_dn_grad, 4 * n1 * D); F(edge_c12, D);
   F(ssh_values, m.nza);
+  if (par->visc_option <= 3) { F(Visc, n1 * E); F(vorticity, n1 * N); F(leith_aux, n1 * N); }
   if (par->Fer_GM) { F(fer_K, nl * N); F(fer_gamma, 2 * nl * N); F(fer_Wvel, nl * N); F(fer_c, N); F(fer_UV, 2 * n1 * E); }
   {   // surface forcing: ONE device block (one host->device copy per fesom_gpu_set_forcing), fields are views into it
     G.frc_count = 2 * E + 7 * N + (par->use_sw_pene ? nl * N : 0);
@@ -856,7 +859,12 @@ int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
   S.Wt();
   S.c("k_momadv_node"); S.X(0, {"Unode_rhs"});
   S.c("k_vel_rhs");
-  S.c("k_visc_elem"); S.X(1, {"U_b"});
+  if (p.visc_option <= 3) {    // h_viscosity_leith with its exchange_nod(vorticity), 2 x exchange_nod(aux), exchange_elem(Visc)
+    S.c("k_leith_vort"); S.X(0, {"vorticity"}); S.c("k_leith_elem");
+    for (int nt = 0; nt < 2; nt++) { S.c("k_leith_node"); S.X(0, {"leith_aux"}); S.c("k_leith_avg"); }
+    S.X(1, {"Visc"});
+  }
+  if (p.visc_option != 1) { S.c("k_visc_elem"); S.X(1, {"U_b"}); }
   if (p.visc_option == 5) { S.c("k_visc_node"); S.X(0, {"U_c"}); }
   else S.c("k_visc_apply");
   S.c("k_impl_visc");

@@ -47,6 +47,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   double *eta_n, *d_eta, *ssh_rhs, *ssh_rhs_old, *hbar, *hbar_old, *MLD1, *MLD2;
   double *heat_flux, *water_flux, *virtual_salt, *relax_salt, *real_salt_flux;
   double *UV, *UV_rhs, *UV_rhsAB, *tr_xy, *tr_xy_ab, *U_b;
+  double *Visc, *vorticity, *leith_aux;    // visc_option 1-3: Leith coefficient (nl-1, E), relative vorticity and smoothing work array (nl-1, N)
   double *pgf_x, *pgf_y, *helem, *Av, *dhe, *stress_surf;
   double *adv_flux_hor, *adv_flux_raw, *flux_lo_hor, *edge_up_dn_grad, *edge_c12, *diff_flux;
   double *ssh_values;

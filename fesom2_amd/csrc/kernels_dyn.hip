@@ -388,6 +388,81 @@ __global__ void __launch_bounds__(BLOCK) k_vel_rhs(DM m, int first_step) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// visc_option 1 / 2 / 3: the Leith coefficient of h_viscosity_leith (src/oce_dyn.F90:461-561).
+// relative_vorticity (src/oce_vel_rhs_vinv.F90:14-102): circulation around the scalar control volume, gathered over the node's
+// incident owned edges in the reference's edge order, / areasvol.  Owned nodes; halo nodes arrive by exchange.
+__global__ void __launch_bounds__(BLOCK) k_leith_vort(DM m) {
+  int n = col_id(), nz = lane_id() + 1;
+  if (n >= m.myN || nz > m.nlm1) return;
+  double vo = 0.0;
+  for (int q = m.ne_ptr[n]; q < m.ne_ptr[n + 1]; q++) {
+    int ed = m.ne_idx[q], sg = m.ne_sgn[q];
+    int el1 = m.edge_tri[2 * ed], el2 = m.edge_tri[2 * ed + 1];
+    bool in1 = nz >= m.ulev[el1] && nz <= m.nlev[el1] - 1, in2 = false;
+    if (el2 >= 0) in2 = nz >= m.ulev[el2] && nz <= m.nlev[el2] - 1;
+    if (!in1 && !in2) continue;
+    double c1;
+    if (in1 && in2) c1 = DECD(1, ed) * DV2(m.UV, 1, nz, el1) + DECD(2, ed) * DV2(m.UV, 2, nz, el1) - DECD(3, ed) * DV2(m.UV, 1, nz, el2) - DECD(4, ed) * DV2(m.UV, 2, nz, el2);
+    else if (in1)   c1 = DECD(1, ed) * DV2(m.UV, 1, nz, el1) + DECD(2, ed) * DV2(m.UV, 2, nz, el1);
+    else            c1 = -DECD(3, ed) * DV2(m.UV, 1, nz, el2) - DECD(4, ed) * DV2(m.UV, 2, nz, el2);
+    vo = sg > 0 ? vo + c1 : vo - c1;
+  }
+  if (nz >= m.ulev_n[n] && nz <= m.nlev_n[n] - 1) vo = vo / DA2L(m.areasvol, nz, n);
+  DA2(m.vorticity, nz, n) = vo;
+}
+// Leith + modified Leith coefficient on the owned elements (:483-523); halo elements hold 0 through the smoothing rounds, as in
+// the reference (Visc = 0 at :482, exchange_elem only after the rounds :558)
+__global__ void __launch_bounds__(BLOCK) k_leith_elem(DM m) {
+  int e = col_id(), l = lane_id(), nz = l + 1;
+  if (e >= m.E) return;
+  double vi = 0.0;
+  if (e < m.myE) {
+    const int nl1 = m.nlev[e] - 1, ul1 = m.ulev[e];
+    const bool wet = nz >= ul1 && nz <= nl1;
+    double he = wet ? DA2(m.helem, nz, e) : 0.0;
+    double zt = seq_sum_down(he, nl1 - 1, ul1 - 1, m.zbar_e_bot[e]);          // zbar_n(nz), summed from the bottom up
+    double zb = shdn(zt);
+    if (nz == nl1) zb = m.zbar_e_bot[e];
+    if (wet) {
+      const double dz = zt - zb, ar = m.elem_area[e];
+      const int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
+      double d1 = (DA2L(m.Wvel, nz, n1) - DA2L(m.Wvel, nz + 1, n1)) / dz, d2 = (DA2L(m.Wvel, nz, n2) - DA2L(m.Wvel, nz + 1, n2)) / dz,
+             d3 = (DA2L(m.Wvel, nz, n3) - DA2L(m.Wvel, nz + 1, n3)) / dz;
+      double v1 = DA2(m.vorticity, nz, n1), v2 = DA2(m.vorticity, nz, n2), v3 = DA2(m.vorticity, nz, n3);
+      double xe = (DGS(1, e) * d1 + DGS(2, e) * d2) + DGS(3, e) * d3, ye = (DGS(4, e) * d1 + DGS(5, e) * d2) + DGS(6, e) * d3;
+      double lx = (DGS(1, e) * v1 + DGS(2, e) * v2) + DGS(3, e) * v3, ly = (DGS(4, e) * v1 + DGS(5, e) * v2) + DGS(6, e) * v3;
+      vi = dmin_(m.p.gamma1 * ar * sqrt((m.p.Div_c * (xe * xe + ye * ye) + m.p.Leith_c * (lx * lx + ly * ly)) * ar), ar / m.p.dt);
+    }
+  }
+  if (nz <= m.nlm1) DA2(m.Visc, nz, e) = vi;
+}
+// the two smoothing rounds (:527-557): area-weighted node average over the element cluster, then the mean of the three nodes
+__global__ void __launch_bounds__(BLOCK) k_leith_node(DM m) {
+  int n = col_id(), nz = lane_id() + 1;
+  if (n >= m.myN) return;
+  if (nz < m.ulev_n[n] || nz > m.nlev_n[n] - 1) return;
+  double dz = 0.0, vi = 0.0;
+  const int num = m.nie_num[n];
+  for (int k = 0; k < num; k++) {
+    int el = m.nie[(size_t)m.maxk * n + k];
+    double ar = m.elem_area[el];
+    dz = dz + ar;
+    vi = vi + DA2(m.Visc, nz, el) * ar;
+  }
+  DA2(m.leith_aux, nz, n) = vi / dz;
+}
+__global__ void __launch_bounds__(BLOCK) k_leith_avg(DM m) {
+  int e = col_id(), nz = lane_id() + 1;
+  if (e >= m.myE || nz > m.nlm1) return;
+  double vi = 0.0;
+  if (nz >= m.ulev[e] && nz <= m.nlev[e] - 1) {
+    const int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
+    vi = ((DA2(m.leith_aux, nz, n1) + DA2(m.leith_aux, nz, n2)) + DA2(m.leith_aux, nz, n3)) / 3.0;
+  }
+  DA2(m.Visc, nz, e) = vi;
+}
+
+// ------------------------------------------------------------------------------------------------
 // visc_filt_bcksct (src/oce_dyn.F90:563-649): (1) element gather over its <=3 internal edges,
 // (2) node average, (3) apply (fused into k_impl_visc).  4 N3 + 12 E3 values.
 // visc_option 4 / 6 / 7 (visc_filt_biharm(1) :275-372, visc_filt_bilapl :658-726, visc_filt_bidiff :734-801): the same gather is the first stage of the
@@ -431,6 +506,11 @@ __global__ void __launch_bounds__(BLOCK) k_visc_elem(DM m) {
     double vi = dmax_(g0, dmax_(g1 * sqrt(u1), g2 * u1)) * len * dt;
     ub = -ub * vi; vb = -vb * vi;
   }
+  if ((opt == 2 || opt == 3) && nz >= m.ulev[e] && nz <= m.nlev[e] - 1) {    // visc_filt_hbhmix :427-436 (background), visc_filt_biharm(2) :332-343 (Leith)
+    double len = sqrt(m.elem_area[e]);
+    double vi = (opt == 2) ? dt * g0 * len : dmax_(DA2(m.Visc, nz, e), g0 * len) * dt;
+    ub = -ub * vi; vb = -vb * vi;
+  }
   if (opt == 4 && nz >= m.ulev[e] && nz <= m.nlev[e] - 1) {    // visc_filt_biharm(1) :314-331: "an analog to the third-order upwind", vi = gamma1 |u| l
     double len = sqrt(m.elem_area[e]);
     double uu = DV2(m.UV, 1, nz, e), vv = DV2(m.UV, 2, nz, e);
@@ -449,7 +529,25 @@ __global__ void __launch_bounds__(BLOCK) k_visc_apply(DM m) {
   const double dt = m.p.dt, g0 = m.p.gamma0, g1 = m.p.gamma1, g2 = m.p.gamma2;
   const int opt = m.p.visc_option;
   double ur = DV2(m.UV_rhs, 1, nz, e), vr = DV2(m.UV_rhs, 2, nz, e);
-  for (int q = 0; q < 3; q++) {
+  if (opt == 1 || opt == 2)           // harmonic Leith viscosity: visc_filt_harmon :236-273, first edge loop of visc_filt_hbhmix :398-425
+    for (int q = 0; q < 3; q++) {
+      int side = m.ee_side[3 * e + q];
+      if (side == 0) continue;
+      int ed = m.ee_idx[3 * e + q];
+      int e1 = m.edge_tri[2 * ed], e2 = m.edge_tri[2 * ed + 1];
+      int nzmax = min(m.nlev[e1], m.nlev[e2]), nzmin = max(m.ulev[e1], m.ulev[e2]);
+      if (nz < nzmin || nz > nzmax - 1) continue;
+      double a1 = m.elem_area[e1], a2 = m.elem_area[e2];
+      double u1 = DV2(m.UV, 1, nz, e1) - DV2(m.UV, 1, nz, e2);
+      double v1 = DV2(m.UV, 2, nz, e1) - DV2(m.UV, 2, nz, e2);
+      double vi;
+      if (opt == 1) { vi = 0.5 * (DA2(m.Visc, nz, e1) + DA2(m.Visc, nz, e2)); vi = dmax_(vi, g0 * sqrt(a1 + a2)) * dt; }
+      else vi = dt * 0.5 * (DA2(m.Visc, nz, e1) + DA2(m.Visc, nz, e2));
+      u1 = u1 * vi; v1 = v1 * vi;
+      if (side == 1) { ur = ur - u1 / a1; vr = vr - v1 / a1; }
+      else           { ur = ur + u1 / a2; vr = vr + v1 / a2; }
+    }
+  for (int q = 0; q < 3 && opt != 1; q++) {
     int side = m.ee_side[3 * e + q];
     if (side == 0) continue;
     int ed = m.ee_idx[3 * e + q];
@@ -924,6 +1022,11 @@ __global__ void __launch_bounds__(BLOCK) k_thick(DM m, int ncolN) {
 
 #define IV_ATTR(id, C_, W_) (void)hipFuncSetAttribute((const void *)k_impl_visc<C_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 void tile_prepare_dyn() { TILE_SHAPES(IV_ATTR) (void)hipFuncSetAttribute((const void *)k_edge_transport_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+// h_viscosity_leith on one partition: vorticity, coefficient, two smoothing rounds
+void launch_leith(const DM &m, hipStream_t s) {
+  LAUNCH_COL(k_leith_vort, m.myN, m); LAUNCH_COL(k_leith_elem, m.E, m);
+  for (int nt = 0; nt < 2; nt++) { LAUNCH_COL(k_leith_node, m.myN, m); LAUNCH_COL(k_leith_avg, m.myE, m); }
+}
 void launch_dynamics_pre(const DM &m, hipStream_t s, int first_step) {
   LAUNCH_COL(k_vel_nodes, m.myN, m);
   LAUNCH_COL(k_pressure_bv, m.N, m);
@@ -935,7 +1038,8 @@ void launch_dynamics_pre(const DM &m, hipStream_t s, int first_step) {
   if (m.p.mix_scheme == 1) launch_named_kpp(m, s, "mixing_kpp");
   LAUNCH_COL(k_momadv_node, m.myN, m);
   LAUNCH_COL(k_vel_rhs, m.myE, m, first_step);
-  LAUNCH_COL(k_visc_elem, m.E, m);
+  if (m.p.visc_option <= 3) launch_leith(m, s);
+  if (m.p.visc_option != 1) LAUNCH_COL(k_visc_elem, m.E, m);
   if (m.p.visc_option == 5) LAUNCH_COL(k_visc_node, m.myN, m);
   else LAUNCH_COL(k_visc_apply, m.myE, m);
   LAUNCH_IMPL_VISC(m.p.visc_option == 5, m.p.i_vert_visc);
@@ -974,6 +1078,11 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
     if (!strcmp(name, "k_momadv_node")) { LAUNCH_COL(k_momadv_node, m.myN, m); return 0; }
     if (!strcmp(name, "k_vel_rhs")) { LAUNCH_COL(k_vel_rhs, m.myE, m, first_step); return 0; }
     if (!strcmp(name, "k_visc_elem")) { LAUNCH_COL(k_visc_elem, m.E, m); return 0; }
+    if (!strcmp(name, "k_leith_vort")) { LAUNCH_COL(k_leith_vort, m.myN, m); return 0; }
+    if (!strcmp(name, "k_leith_elem")) { LAUNCH_COL(k_leith_elem, m.E, m); return 0; }
+    if (!strcmp(name, "k_leith_node")) { LAUNCH_COL(k_leith_node, m.myN, m); return 0; }
+    if (!strcmp(name, "k_leith_avg")) { LAUNCH_COL(k_leith_avg, m.myE, m); return 0; }
+    if (!strcmp(name, "h_viscosity_leith")) { launch_leith(m, s); return 0; }
     if (!strcmp(name, "k_visc_node")) { LAUNCH_COL(k_visc_node, m.myN, m); return 0; }
     if (!strcmp(name, "k_visc_apply")) { LAUNCH_COL(k_visc_apply, m.myE, m); return 0; }
     if (!strcmp(name, "k_impl_visc")) { LAUNCH_IMPL_VISC(m.p.visc_option == 5, m.p.i_vert_visc); return 0; }
@@ -1001,8 +1110,9 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
   }
   if (!strcmp(name, "mo_convect")) return 0;                                                  // fused into mixing_pp
   if (!strcmp(name, "compute_vel_rhs")) { LAUNCH_COL(k_momadv_node, m.myN, m); LAUNCH_COL(k_vel_rhs, m.myE, m, first_step); return 0; }
-  if (!strcmp(name, "visc_filt_bcksct") || !strcmp(name, "viscosity_filter")) {      // viscosity_filter(visc_option): 5, 6 or 7
-    LAUNCH_COL(k_visc_elem, m.E, m);
+  if (!strcmp(name, "visc_filt_bcksct") || !strcmp(name, "viscosity_filter")) {      // viscosity_filter(visc_option): 1 .. 7
+    if (m.p.visc_option <= 3) launch_leith(m, s);
+    if (m.p.visc_option != 1) LAUNCH_COL(k_visc_elem, m.E, m);
     if (m.p.visc_option != 5) { LAUNCH_COL(k_visc_apply, m.myE, m); return 0; }
     LAUNCH_COL(k_visc_node, m.myN, m); LAUNCH_IMPL_VISC(1, 0); return 0;
   }

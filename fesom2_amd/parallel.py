@@ -58,7 +58,13 @@ def run_step(core, par, X, solve, first, probe=None, n=1, zonal=None):
         c("k_kpp_elem"); P("mixing")
     c("k_momadv_node"); X(NOD, ["Unode_rhs"])
     c("k_vel_rhs"); P("vel_rhs")
-    c("k_visc_elem"); X(ELEM, ["U_b"])
+    if p.visc_option <= 3:
+        c("k_leith_vort"); X(NOD, ["vorticity"]); c("k_leith_elem")
+        for _ in range(2):
+            c("k_leith_node"); X(NOD, ["leith_aux"]); c("k_leith_avg")
+        X(ELEM, ["Visc"])
+    if p.visc_option != 1:
+        c("k_visc_elem"); X(ELEM, ["U_b"])
     if p.visc_option == 5:
         c("k_visc_node"); X(NOD, ["U_c"])
     else:

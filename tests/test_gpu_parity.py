@@ -466,10 +466,11 @@ def test_no_limiter_chain_bitwise(built):
     gpu.close()
 
 
-@pytest.mark.parametrize("opt", [4, 6, 7])
+@pytest.mark.parametrize("opt", [1, 2, 3, 4, 6, 7])
 def test_biharmonic_viscosity_chain_bitwise(built, opt):
-    """visc_option 4 / 6 / 7 (visc_filt_biharm(1), visc_filt_bilapl, visc_filt_bidiff; oracle pinned on the reference runs pi_pp_visc4 / 6 / 7): HIP == oracle
-    bit for bit after every routine of 3 steps under surface forcing."""
+    """visc_option 1 / 2 / 3 (h_viscosity_leith + visc_filt_harmon / visc_filt_hbhmix / visc_filt_biharm(2); the Leith coefficient and the relative
+    vorticity are compared as well) and 4 / 6 / 7 (visc_filt_biharm(1), visc_filt_bilapl, visc_filt_bidiff); oracle pinned on the reference runs
+    pi_pp_visc1 .. 7: HIP == oracle bit for bit after every routine of 3 steps under surface forcing."""
     from fesom2_amd.mesh import Mesh
     from fesom2_amd.config import make_params
     from fesom2_amd.core import OceanCore
@@ -490,7 +491,7 @@ def test_biharmonic_viscosity_chain_bitwise(built, opt):
     for step in range(1, 4):
         for routine, arg, fields in full_chain(2):
             gpu.call(routine, arg); orc.call(routine, arg)
-            for f in fields:
+            for f in list(fields) + (["Visc", "vorticity"] if routine == "viscosity_filter" and opt <= 3 else []):
                 ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
                 if not ok:
                     failures.append(f"step {step} {routine}({arg}) {msg}")
