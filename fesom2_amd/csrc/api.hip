@@ -363,6 +363,9 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   if (d->nl > 64) { G.err = "fesom_gpu_init: nl > 64 levels not supported by the one-wave-per-column kernels"; return 3; }
   if (par->which_ale != 0 && par->which_ale != 2) { G.err = "fesom_gpu_init: which_ale must be linfs(0) or zstar(2)"; return 3; }
   if (par->mom_adv != 2 || par->visc_option < 1 || par->visc_option > 7) { G.err = "fesom_gpu_init: only mom_adv=2, visc_option=1..7 are implemented"; return 3; }
+  if (par->which_pgf != 0 && !(par->which_ale == 0 && !par->use_partial_cell)) {
+    G.err = "fesom_gpu_init: which_pgf must be 'shchepetkin' (0); the nemo / cubicspline / easypgf / sergey pressure gradient schemes are not implemented"; return 3;
+  }
   if (par->Fer_GM && par->scaling_Rossby) { G.err = "fesom_gpu_init: scaling_Rossby=.true. (GM cut-off by the Rossby radius) is not implemented"; return 3; }
   if (par->tra_adv_ver < 0 || par->tra_adv_ver > 3 || par->tra_adv_hor < 0 || par->tra_adv_hor > 2) {
     G.err = "fesom_gpu_init: tra_adv_ver must be QR4C (0), CDIFF (1), UPW1 (2) or PPM (3), tra_adv_hor MFCT (0), MUSCL (1) or UPW1 (2), tra_adv_lim='FCT'"; return 3;

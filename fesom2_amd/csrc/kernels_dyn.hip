@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(BLOCK) k_pressure_bv(DM m) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// pressure_force_4_zxxxx_shchepetkin (src/oce_ale_pressure_bv.F90:1878-2104) / _linfs_fullcell (:432-466).
+// pressure_force_4_zxxxx_shchepetkin (src/oce_ale_pressure_bv.F90:1878-2104) / _linfs_fullcell (:432-466) / _linfs_shchepetkin (:647-891).
 // Per element column: density-Jacobian terms per level in parallel, the two vertical integrals as
 // reference-order running sums.  Reads 3 node columns x (rho, Z) -> HBM-bound gather, 2 N3 + 3 E3 values.
 __global__ void __launch_bounds__(BLOCK) k_pgf(DM m) {
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(BLOCK) k_pgf(DM m) {
   const int nle = m.nlev[e] - 1, ule = m.ulev[e];
   const bool wet = (nlz >= ule && nlz <= nle);
   const int n0 = m.elem_nodes[3 * e], n1 = m.elem_nodes[3 * e + 1], n2 = m.elem_nodes[3 * e + 2];
-  if (m.p.which_ale == 0) {
+  if (m.p.which_ale == 0 && !m.p.use_partial_cell) {
     if (wet) {
       DA2(m.pgf_x, nlz, e) = DGS(1, e) * DA2L(m.hpressure, nlz, n0) / D_RHO0 + DGS(2, e) * DA2L(m.hpressure, nlz, n1) / D_RHO0 +
                              DGS(3, e) * DA2L(m.hpressure, nlz, n2) / D_RHO0;
@@ -189,10 +189,12 @@ __global__ void __launch_bounds__(BLOCK) k_pgf(DM m) {
     double s3 = (drho_dz[0] + drho_dz[1] + drho_dz[2]) / 3.0;
     double drho_dx = DGS(1, e) * rho_c[0] + DGS(2, e) * rho_c[1] + DGS(3, e) * rho_c[2];
     double dz_dx = DGS(1, e) * z_c[0] + DGS(2, e) * z_c[1] + DGS(3, e) * z_c[2];
-    auxx = (drho_dx - s3 * dz_dx) * he * D_G / D_RHO0;
+    // pressure_force_4_linfs_shchepetkin (:647-891, linfs with partial cells): the Jacobian correction only in the bottom layer
+    const bool flat = m.p.which_ale == 0 && nlz != nle;
+    auxx = flat ? drho_dx * he * D_G / D_RHO0 : (drho_dx - s3 * dz_dx) * he * D_G / D_RHO0;
     double drho_dy = DGS(4, e) * rho_c[0] + DGS(5, e) * rho_c[1] + DGS(6, e) * rho_c[2];
     double dz_dy = DGS(4, e) * z_c[0] + DGS(5, e) * z_c[1] + DGS(6, e) * z_c[2];
-    auxy = (drho_dy - s3 * dz_dy) * he * D_G / D_RHO0;
+    auxy = flat ? drho_dy * he * D_G / D_RHO0 : (drho_dy - s3 * dz_dy) * he * D_G / D_RHO0;
   }
   // int_dp_dx after level nlz: first level assigns aux, later levels add (reference order)
   double ax0 = bcast(auxx, ule - 1), ay0 = bcast(auxy, ule - 1);

@@ -62,6 +62,7 @@ module fesom_gpu_shim
      real(c_double) :: visc_sh_limit, diff_sh_limit, Ricr, concv
      integer(c_int) :: use_sw_pene, tra_adv_ver, tra_adv_hor, Kv0_const, solver_precond, tra_adv_lim, solver_xinv_its
      real(c_double) :: Leith_c, Div_c
+     integer(c_int) :: which_pgf
   end type
   type, bind(C) :: fesom_state_desc
      type(c_ptr) :: tr_arr, tr_arr_old, UV, UV_rhsAB, eta_n, d_eta, ssh_rhs, ssh_rhs_old, hbar, hbar_old, dhe, hnode, hnode_new, &
@@ -312,6 +313,10 @@ contains
     end select
     p%Kv0_const = l2i(Kv0_const)
     p%Leith_c = Leith_c; p%Div_c = Div_c
+    select case (trim(which_pgf))
+    case ('shchepetkin'); p%which_pgf = 0
+    case default; p%which_pgf = -1
+    end select
     p%solver_precond = 1; p%solver_xinv_its = 0     ! explicit-inverse preconditioner where it fits (pi), library default iterations
 
     transport%ctx = c_null_ptr

@@ -135,6 +135,10 @@ typedef struct fesom_params {
                                 has not converged by then is finished by the Jacobi-preconditioned one-workgroup solver.  0 = default (2) */
   double Leith_c, Div_c;     /* visc_option 1-3: weights of the Leith and the modified (divergence) Leith viscosity (namelist.oce &oce_dyn; h_viscosity_leith,
                                 src/oce_dyn.F90:461-561) */
+  int    which_pgf;          /* namelist.oce which_pgf: 0 'shchepetkin' (default, oce_modules.F90:172): pressure_force_4_zxxxx_shchepetkin for zstar,
+                                pressure_force_4_linfs_shchepetkin for linfs with partial cells; linfs with full cells always takes
+                                pressure_force_4_linfs_fullcell (oce_ale_pressure_bv.F90:385-386).  Any other scheme (nemo, cubicspline, easypgf,
+                                sergey): pass -1, fesom_gpu_init refuses it */
 } fesom_params;
 
 /* ---- prognostic state = restart set (io_restart.F90:99-155) + ALE thickness arrays -- */

@@ -111,10 +111,13 @@ void orc_pressure_bv(void) {
 }
 
 /* pressure_force_4_zxxxx_shchepetkin: src/oce_ale_pressure_bv.F90:1878-2104 ;
- * pressure_force_4_linfs_fullcell: :432-466 */
+ * pressure_force_4_linfs_fullcell: :432-466 ;
+ * pressure_force_4_linfs_shchepetkin (linfs with partial cells): :647-891 -- the same integral, the density-Jacobian correction only
+ * in the bottom layer (the levels above are flat: "in case linfs: dz_dx == 0.0", :799) */
 static void pgf_linfs_fullcell(void);
 void orc_pressure_force(void) {
-  if (C_.p.which_ale == 0) { pgf_linfs_fullcell(); return; }
+  if (C_.p.which_ale == 0 && !C_.p.use_partial_cell) { pgf_linfs_fullcell(); return; }
+  const int lin = C_.p.which_ale == 0;
   int nl = NL;
   double *zbar_n = calloc(nl + 2, sizeof(double)), *Z_n = calloc(nl + 2, sizeof(double));
   for (int e = 1; e <= C_.m.myDim_elem2D; e++) {
@@ -150,13 +153,13 @@ void orc_pressure_force(void) {
       double drho_dx = GS(1, e) * A2(C_.density_m_rho0, nlz, en[0]) + GS(2, e) * A2(C_.density_m_rho0, nlz, en[1]) +
                        GS(3, e) * A2(C_.density_m_rho0, nlz, en[2]);
       double dz_dx = GS(1, e) * A2(C_.Z_3d_n, nlz, en[0]) + GS(2, e) * A2(C_.Z_3d_n, nlz, en[1]) + GS(3, e) * A2(C_.Z_3d_n, nlz, en[2]);
-      double aux = (drho_dx - s3 * dz_dx) * A2(C_.helem, nlz, e) * G_ACC / DENSITY_0;
+      double aux = (lin && nlz != nle) ? drho_dx * A2(C_.helem, nlz, e) * G_ACC / DENSITY_0 : (drho_dx - s3 * dz_dx) * A2(C_.helem, nlz, e) * G_ACC / DENSITY_0;
       A2(C_.pgf_x, nlz, e) = (nlz == ule) ? aux * 0.5 : int_dp_dx[0] + aux * 0.5;
       int_dp_dx[0] = (nlz == ule) ? aux : int_dp_dx[0] + aux;
       double drho_dy = GS(4, e) * A2(C_.density_m_rho0, nlz, en[0]) + GS(5, e) * A2(C_.density_m_rho0, nlz, en[1]) +
                        GS(6, e) * A2(C_.density_m_rho0, nlz, en[2]);
       double dz_dy = GS(4, e) * A2(C_.Z_3d_n, nlz, en[0]) + GS(5, e) * A2(C_.Z_3d_n, nlz, en[1]) + GS(6, e) * A2(C_.Z_3d_n, nlz, en[2]);
-      aux = (drho_dy - s3 * dz_dy) * A2(C_.helem, nlz, e) * G_ACC / DENSITY_0;
+      aux = (lin && nlz != nle) ? drho_dy * A2(C_.helem, nlz, e) * G_ACC / DENSITY_0 : (drho_dy - s3 * dz_dy) * A2(C_.helem, nlz, e) * G_ACC / DENSITY_0;
       A2(C_.pgf_y, nlz, e) = (nlz == ule) ? aux * 0.5 : int_dp_dx[1] + aux * 0.5;
       int_dp_dx[1] = (nlz == ule) ? aux : int_dp_dx[1] + aux;
     }

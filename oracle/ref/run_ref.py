@@ -200,6 +200,11 @@ CFGS = {
                         fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
                         balance_salt_water=".true.", synth_forcing=True, visc_option=3),
     # visc_option = 4: visc_filt_biharm(1), the biharmonic "third-order-upwind-like" filter (src/oce_dyn.F90:275-372)
+    # linfs with partial cells: pressure_force_4_linfs_shchepetkin (src/oce_ale_pressure_bv.F90:647-891)
+    "pi_pp_linfs_pc": dict(mesh="pi", step_per_day=96, which_ale="linfs", use_partial_cell=".true.", cyclic_length=360,
+                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                        fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                        balance_salt_water=".true.", synth_forcing=True),
     "pi_pp_visc4": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
                         rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                         fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",

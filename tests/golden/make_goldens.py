@@ -110,6 +110,7 @@ def main():
     make("pi_pp_wsplit", "pi_pp_wsplit_reference.npz")  # PP + w_split with surface forcing
     make("pi_default_sw", "pi_default_sw_reference.npz")  # default physics + short-wave penetration
     make("pi_pp_non", "pi_pp_non_reference.npz")        # tra_adv_lim = 'NON'
+    make("pi_pp_linfs_pc", "pi_pp_linfs_pc_reference.npz")  # which_ALE = 'linfs' with partial cells (pressure_force_4_linfs_shchepetkin)
     make("pi_pp_visc4", "pi_pp_visc4_reference.npz")    # visc_option = 4 (visc_filt_biharm(1))
     make("pi_pp_visc6", "pi_pp_visc6_reference.npz")    # visc_option = 6 (visc_filt_bilapl)
     make("pi_pp_visc7", "pi_pp_visc7_reference.npz")    # visc_option = 7 (visc_filt_bidiff)

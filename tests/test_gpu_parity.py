@@ -501,7 +501,7 @@ def test_biharmonic_viscosity_chain_bitwise(built, opt):
     gpu.close()
 
 
-@pytest.mark.parametrize("field,value,msg", [("visc_option", 3, "visc_option"), ("visc_option", 8, "visc_option"), ("tra_adv_ver", 4, "tra_adv_ver"),
+@pytest.mark.parametrize("field,value,msg", [("visc_option", 0, "visc_option"), ("visc_option", 8, "visc_option"), ("which_pgf", -1, "which_pgf"), ("tra_adv_ver", 4, "tra_adv_ver"),
                                              ("tra_adv_ver", -1, "tra_adv_ver"), ("tra_adv_hor", 3, "tra_adv_hor"), ("mom_adv", 3, "mom_adv"),
                                              ("mix_scheme", 3, "mix_scheme")])
 def test_init_refuses_options_it_does_not_implement(built, field, value, msg):

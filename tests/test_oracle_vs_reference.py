@@ -232,6 +232,31 @@ def test_oracle_chain_bitwise_no_limiter(built):
     assert not np.array_equal(g["s2/tr1.adv.fct_plus"], gf["s2/tr1.adv.fct_plus"])
 
 
+def test_oracle_chain_bitwise_linfs_partial_cells(built):
+    """which_ALE = 'linfs' with use_partial_cell = .true. on pi: pressure_force_4_linfs_shchepetkin (src/oce_ale_pressure_bv.F90:647-891), the linfs branches
+    of compute_hbar_ale / vert_vel_ale / the SSH right-hand side on a mesh with partial bottom cells: reference run `pi_pp_linfs_pc`, every routine of
+    3 steps bit for bit."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.synthetic import analytic_ts
+    from oracle_lib import Oracle
+    from ref_chain import run_reference_chain
+    mesh = Mesh.load(PI, dt=900.0, which_ale="linfs", use_partial_cell=True)
+    par = make_params(dt=900.0, which_ale="linfs", use_partial_cell=True)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    orc = Oracle(mesh, par)
+    orc.set_state(st)
+    g = gold("pi_pp_linfs_pc")
+    for f in FORCING:
+        orc.set(f, g["forcing/" + f])
+    bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
+    assert not bad, "\n".join(bad[:20])
+    gz = gold("pi_pp_wsplit")                                # the zstar run: a different pressure gradient
+    assert not np.array_equal(g["s2/pressure_force.pgf_x"], gz["s2/pressure_force.pgf_x"])
+
+
 @pytest.mark.parametrize("opt", [1, 2, 3, 4, 6, 7])
 def test_oracle_chain_bitwise_biharmonic_viscosity(built, opt):
     """visc_option = 1 / 2 / 3 (h_viscosity_leith :461-561 over relative_vorticity src/oce_vel_rhs_vinv.F90:14-102, then visc_filt_harmon :236-273,
