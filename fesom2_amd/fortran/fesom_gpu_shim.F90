@@ -190,6 +190,16 @@ contains
     pe_status = 1
   end subroutine
 
+  ! a switch of the namelists that changes oce_timestep_ale and that the library does not implement: say so and stop the run through
+  ! status_check (the reference's own routine stays the one to call for such a run, INTEGRATION.md)
+  subroutine refuse(cond, what)
+    logical, intent(in) :: cond
+    character(*), intent(in) :: what
+    if (.not. cond) return
+    if (mype == 0) write(*,*) 'fesom_gpu: not implemented on the GPU path: ', what
+    pe_status = 1
+  end subroutine
+
   subroutine fill_com(c, f)
     type(com_struct), intent(in) :: c
     type(fesom_com_desc), intent(out) :: f
@@ -269,6 +279,17 @@ contains
        call check_plan(com_nod2D, 'nod2D'); call check_plan(com_elem2D, 'elem2D'); call check_plan(com_elem2D_full, 'elem2D_full')
        call status_check
     end if
+
+    call refuse(use_cavity .or. use_cavity_partial_cell, 'use_cavity / use_cavity_partial_cell (ice-shelf cavities)')
+    call refuse(use_floatice, 'use_floatice (ice and snow load in the sea-surface slope, oce_ale_vel_rhs.F90:41)')
+    call refuse(use_global_tides, 'use_global_tides (tidal potential in compute_vel_rhs, oce_ale_vel_rhs.F90:92)')
+    call refuse(SPP, 'SPP (salt plume parameterization, oce_ale_tracer.F90:120)')
+    call refuse(smooth_bh_tra, 'smooth_bh_tra (biharmonic tracer diffusion, oce_ale_tracer.F90:322)')
+    call refuse(use_kpp_nonlclflx, 'use_kpp_nonlclflx (KPP non-local fluxes, oce_ale_tracer.F90:688)')
+    call refuse(double_diffusion .and. mix_scheme_nmb == 1, 'double_diffusion (oce_ale_mixing_kpp.F90:356)')
+    call refuse(clim_relax > 1.0e-8_WP .and. .not. toy_ocean, 'clim_relax > 0 (relax_to_clim, oce_tracer_mod.F90:99)')
+    call refuse(use_momix, 'use_momix (Monin-Obukhov mixing of mo_convect, oce_mo_conv.F90:22)')
+    call status_check
 
     p%dt = dt
     select case (trim(which_ALE))

@@ -139,6 +139,9 @@ typedef struct fesom_params {
                                 pressure_force_4_linfs_shchepetkin for linfs with partial cells; linfs with full cells always takes
                                 pressure_force_4_linfs_fullcell (oce_ale_pressure_bv.F90:385-386).  Any other scheme (nemo, cubicspline, easypgf,
                                 sergey): pass -1, fesom_gpu_init refuses it */
+  int    use_momix;          /* Monin-Obukhov mixing of Timmermann & Beckmann 2004 inside mo_convect (oce_mo_conv.F90:22-55, :95; on in the shipped
+                                config/namelist.oce:48; the reference allocates its arrays only with use_ice): needs u_ice, v_ice, a_ice with the forcing */
+  double momix_lat, momix_kv;/* applied south of momix_lat [degrees] (-50), diffusivity / viscosity added within the mixing length (0.01) */
 } fesom_params;
 
 /* ---- prognostic state = restart set (io_restart.F90:99-155) + ALE thickness arrays -- */
@@ -163,6 +166,7 @@ typedef struct fesom_forcing_desc {
   const double *heat_flux, *water_flux, *virtual_salt, *relax_salt, *real_salt_flux; /* (N) */
   const double *stress_atmoce_x, *stress_atmoce_y;   /* (N) wind stress at nodes (KPP friction velocity, oce_ale_mixing_kpp.F90:341) */
   const double *sw_3d;           /* (nl,N) penetrating short-wave flux / vcpw [K m/s], positive down (gen_modules_forcing.F90:76); use_sw_pene only */
+  const double *u_ice, *v_ice, *a_ice;   /* (N) ice velocity and concentration of i_ARRAYS: the turbulent-kinetic-energy source of mo_length (oce_mo_conv.F90:36-39); use_momix only */
 } fesom_forcing_desc;
 
 /* Lifecycle.  fesom_gpu_init uploads the mesh and allocates every device mirror;

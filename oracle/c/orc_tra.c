@@ -700,8 +700,52 @@ void orc_mixing_pp(void) {
     }
 }
 
-/* mo_convect with use_momix=.false.: src/oce_mo_conv.F90:4-103 */
+/* pmlktmo (Monin-Obukhov length, src/oce_mo_conv.F90:148-182) and mo_length (:107-145).  The reference is built with
+ * -fdefault-real-8 (src/CMakeLists.txt:73): its unsuffixed literals (cosgam, qhw = 1/7.0, betas, betat) are doubles. */
+static double mo_pmlktmo(double qfm, double qtm, double qw) {
+  const double qhw = 1 / 7.0, betas = 0.0008, betat = 0.00004;
+  double qrho = betas * qfm - betat * qtm, ttmp = 60.0;
+  if (qrho > 0.) ttmp = 0.0;
+  else
+    for (int iter = 1; iter <= 5; iter++) {
+      double a1 = exp(-ttmp * qhw);
+      double f0 = 2.0 * qw * a1 + 9.81 * qrho * ttmp;
+      double f1 = -(2.0 * qw * a1 * qhw) + 9.81 * qrho;
+      ttmp = ttmp - f0 / f1;
+      ttmp = dmax(ttmp, 10.0);
+    }
+  return dmax(ttmp, 10.0);
+}
+static void mo_length(double water_flux, double heat_flux, double sx, double sy, double ui, double vi, double ai, double dt, double *mixlength) {
+  const double cosgam = 0.913632;
+  double qfm = water_flux * 34.0, qtm = -2.38e-7 * heat_flux;
+  double tau = sqrt(sx * sx + sy * sy), ustar = sqrt(tau / 1030.0), uabs = sqrt(ui * ui + vi * vi);
+  double qw = 1.25 * (ustar * ustar * ustar) * (1.0 - ai) + 0.005 * (uabs * uabs * uabs) * cosgam * ai;
+  double obuk = mo_pmlktmo(qfm, qtm, qw);
+  double rtc = dt / (10.0 * 86400.0);
+  if (obuk < *mixlength) { double ret = (obuk - *mixlength) * rtc; *mixlength = *mixlength + ret; }
+  else *mixlength = obuk;
+}
+
+/* mo_convect: src/oce_mo_conv.F90:4-103 (use_momix: Timmermann & Beckmann 2004 south of momix_lat; instabmix; windmix) */
 void orc_mo_convect(void) {
+  const double rad = 3.14159265358979 / 180.0;        /* oce_modules.F90:11-12 */
+  double *mo = NULL;
+  if (C_.p.use_momix) {
+    mo = calloc((size_t)NL * C_.N, sizeof(double));
+    for (int n = 1; n <= C_.N; n++) {
+      int nzmax = NLEVN(n), nzmin = ULEVN(n);
+      if (C_.m.geo_coord_nod2D[2 * (n - 1) + 1] > C_.p.momix_lat * rad) continue;
+      if (nzmin > 1) continue;
+      mo_length(C_.water_flux[n - 1], C_.heat_flux[n - 1], C_.stress_atmoce_x[n - 1], C_.stress_atmoce_y[n - 1], C_.u_ice[n - 1], C_.v_ice[n - 1],
+                C_.a_ice[n - 1], C_.p.dt, &C_.mixlength[n - 1]);
+      for (int nz = nzmin + 1; nz <= nzmax - 1; nz++)
+        if (fabs(A2L(C_.zbar_3d_n, nz, n)) <= C_.mixlength[n - 1]) {
+          A2L(mo, nz, n) = C_.p.momix_kv;
+          A2L(C_.Kv, nz, n) = A2L(C_.Kv, nz, n) + A2L(mo, nz, n);
+        }
+    }
+  }
   for (int n = 1; n <= C_.N; n++) {
     int nzmin = ULEVN(n);
     for (int nz = nzmin + 1; nz <= NLEVN(n) - 1; nz++) {
@@ -716,7 +760,10 @@ void orc_mo_convect(void) {
       if (C_.p.use_instabmix && (A2L(C_.bvfreq, nz, n1) < 0. || A2L(C_.bvfreq, nz, n2) < 0. || A2L(C_.bvfreq, nz, n3) < 0.))
         A2L(C_.Av, nz, e) = dmax(A2L(C_.Av, nz, e), C_.p.instabmix_kv);
       if (nzmin > 1) continue;
+      if (C_.p.use_momix && ((C_.m.geo_coord_nod2D[2 * (n1 - 1) + 1] + C_.m.geo_coord_nod2D[2 * (n2 - 1) + 1]) + C_.m.geo_coord_nod2D[2 * (n3 - 1) + 1]) / 3.0 <= C_.p.momix_lat * rad)
+        A2L(C_.Av, nz, e) = A2L(C_.Av, nz, e) + ((A2L(mo, nz, n1) + A2L(mo, nz, n2)) + A2L(mo, nz, n3)) / 3.0;
       if (C_.p.use_windmix && nz <= C_.p.windmix_nl + 1) A2L(C_.Av, nz, e) = dmax(A2L(C_.Av, nz, e), C_.p.windmix_kv);
     }
   }
+  free(mo);
 }

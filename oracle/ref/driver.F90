@@ -184,6 +184,20 @@ program oracle_driver
      end do
   end if
 
+  if (use_momix .and. trim(mode)/='ice') then
+     ! Monin-Obukhov mixing inside mo_convect (src/oce_mo_conv.F90:22-55): the reference allocates mo / mixlength only together with the
+     ! ice model (oce_setup_step.F90:218-219), whose arrays u_ice, v_ice, a_ice it reads; the harness has no ice model: it allocates them
+     ! here and fills the ice state with analytic fields (ice-free, partly and fully covered regions; its own choice), constant in time
+     if (.not. allocated(mo)) allocate(mo(mesh%nl, myDim_nod2D+eDim_nod2D), mixlength(myDim_nod2D+eDim_nod2D))
+     mo=0.0_WP; mixlength=0.0_WP
+     if (.not. allocated(u_ice)) allocate(u_ice(myDim_nod2D+eDim_nod2D), v_ice(myDim_nod2D+eDim_nod2D), a_ice(myDim_nod2D+eDim_nod2D))
+     do i=1, myDim_nod2D+eDim_nod2D
+        flon=mesh%geo_coord_nod2D(1,i); flat=mesh%geo_coord_nod2D(2,i)
+        a_ice(i)=min(1.0_WP, max(0.0_WP, -0.9_WP-1.6_WP*sin(flat)+0.25_WP*cos(3.0_WP*flon)))
+        u_ice(i)=0.08_WP*sin(flon)*cos(flat); v_ice(i)=0.05_WP*cos(2.0_WP*flon)
+     end do
+  end if
+
   if (dump_mesh) call dump_setup()
 
   if (trim(mode)=='ice') then
@@ -313,6 +327,9 @@ contains
     call dump('forcing.heat_flux', heat_flux); call dump('forcing.water_flux', water_flux)
     call dump('forcing.stress_surf', stress_surf)
     if (use_sw_pene .and. allocated(sw_3d)) call dump('forcing.sw_3d', sw_3d)
+    if (use_momix .and. allocated(a_ice)) then
+       call dump('forcing.u_ice', u_ice); call dump('forcing.v_ice', v_ice); call dump('forcing.a_ice', a_ice)
+    end if
     call dump_state()
     call dump_close()
   end subroutine dump_setup
@@ -471,6 +488,7 @@ contains
        call mo_convect(mesh)
     end if
     call dump('mixing.Av', Av); call dump('mixing.Kv', Kv)
+    if (use_momix) call dump('mixing.mixlength', mixlength)
     if (mom_adv/=3) then
        call mark('compute_vel_rhs')
        call compute_vel_rhs(mesh)

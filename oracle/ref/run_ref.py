@@ -103,7 +103,7 @@ Ricr=0.3
 concv=1.6
 /
 &oce_tra
-use_momix=.false.
+use_momix={use_momix}
 momix_lat=-50.0
 momix_kv=0.01
 use_instabmix=.true.
@@ -165,6 +165,11 @@ CFGS = {
                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                        fer_gm=".true.", redi=".true.", mix_scheme="KPP", k_hor="3000.", surf_relax_s="1.929e-06",
                        balance_salt_water=".true.", synth_forcing=True),
+    # the physics of the shipped config/namelist.oce in full: KPP + GM + Redi + use_momix (analytic ice state for mo_length)
+    "pi_default_momix": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                       rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                       fer_gm=".true.", redi=".true.", mix_scheme="KPP", k_hor="3000.", surf_relax_s="1.929e-06",
+                       balance_salt_water=".true.", synth_forcing=True, use_momix=".true."),
     # PP + w_split: vertical velocity split into an explicit and an implicit part where CFL_z > w_max_cfl (threshold lowered so that
     # the split is active on pi from the first steps)
     "pi_pp_wsplit": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
@@ -200,6 +205,11 @@ CFGS = {
                         fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
                         balance_salt_water=".true.", synth_forcing=True, visc_option=3),
     # visc_option = 4: visc_filt_biharm(1), the biharmonic "third-order-upwind-like" filter (src/oce_dyn.F90:275-372)
+    # use_momix = .true. (the shipped config/namelist.oce:48): Monin-Obukhov mixing of mo_convect south of 50 S, with an analytic ice state
+    "pi_pp_momix": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                        fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                        balance_salt_water=".true.", synth_forcing=True, use_momix=".true."),
     # linfs with partial cells: pressure_force_4_linfs_shchepetkin (src/oce_ale_pressure_bv.F90:647-891)
     "pi_pp_linfs_pc": dict(mesh="pi", step_per_day=96, which_ale="linfs", use_partial_cell=".true.", cyclic_length=360,
                         rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
@@ -319,7 +329,7 @@ def prepare(cfg, np_, tag=""):
             partition_io.write_dist(cp, np_)
         meshdir = cp
     open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **dict(dict(use_sw_pene=".false."), **c)))
-    open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0", visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=".true.", tra_adv_lim="FCT"), **c)))
+    open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0", visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=".true.", tra_adv_lim="FCT", use_momix=".false."), **c)))
     if c["toy_ocean"] == ".false.":
         from fesom2_amd.synthetic import write_ic_files
         write_ic_files(meshdir, rd)

@@ -47,6 +47,8 @@ def run_reference_chain(orc, mesh, g, steps=(1, 2, 3), toy=False, skip=(), after
         else:
             orc.call("mixing_pp"); chk(step, "Av", "oce_mixing_PP.Av"); chk(step, "Kv", "oce_mixing_PP.Kv")
         orc.call("mo_convect"); chk(step, "Av", "mixing.Av"); chk(step, "Kv", "mixing.Kv")
+        if orc.params.use_momix:
+            chk(step, "mixlength", "mixing.mixlength")
         orc.call("compute_vel_rhs"); chk(step, "UV_rhs", "compute_vel_rhs.UV_rhs", "e2"); chk(step, "UV_rhsAB", "compute_vel_rhs.UV_rhsAB", "e2")
         orc.call("viscosity_filter"); chk(step, "UV_rhs", "viscosity_filter.UV_rhs", "e2")
         if orc.params.visc_option <= 3:                     # h_viscosity_leith (src/oce_dyn.F90:461-561)

@@ -232,6 +232,32 @@ def test_oracle_chain_bitwise_no_limiter(built):
     assert not np.array_equal(g["s2/tr1.adv.fct_plus"], gf["s2/tr1.adv.fct_plus"])
 
 
+@pytest.mark.parametrize("cfg,kw", [("pi_pp_momix", dict(mix_scheme="PP")), ("pi_default_momix", dict(mix_scheme="KPP", Fer_GM=True, Redi=True))])
+def test_oracle_chain_bitwise_monin_obukhov_mixing(built, cfg, kw):
+    """use_momix = .true. (shipped config/namelist.oce:48): mo_length / pmlktmo (src/oce_mo_conv.F90:107-182) and the momix branches of mo_convect
+    (:22-55, :95) south of 50 S, with the harness's analytic ice state: reference runs `pi_pp_momix` and `pi_default_momix` (= the shipped physics in
+    full: KPP + GM + Redi + momix), every routine of 3 steps bit for bit incl. the mixing length carried from step to step."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.synthetic import analytic_ts
+    from oracle_lib import Oracle
+    from ref_chain import run_reference_chain
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, use_momix=True, **kw)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    orc = Oracle(mesh, par)
+    orc.set_state(st)
+    g = gold(cfg)
+    for f in FORCING + ("u_ice", "v_ice", "a_ice"):
+        orc.set(f, g["forcing/" + f])
+    bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
+    assert not bad, "\n".join(bad[:20])
+    g0 = gold("pi_pp_wsplit" if cfg == "pi_pp_momix" else "pi_default")
+    assert not np.array_equal(g["s2/mixing.Kv"], g0["s2/mixing.Kv"]) and not np.array_equal(g["s2/mixing.Av"], g0["s2/mixing.Av"])
+
+
 def test_oracle_chain_bitwise_linfs_partial_cells(built):
     """which_ALE = 'linfs' with use_partial_cell = .true. on pi: pressure_force_4_linfs_shchepetkin (src/oce_ale_pressure_bv.F90:647-891), the linfs branches
     of compute_hbar_ale / vert_vel_ale / the SSH right-hand side on a mesh with partial bottom cells: reference run `pi_pp_linfs_pc`, every routine of
