@@ -278,6 +278,7 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   // s0: critical chain
   K(s0, "k_vel_nodes");
   hipStreamWaitEvent(s0, ev_pb, 0);
+  if (m.p.use_momix && m.p.mix_scheme == 2) K(s0, "k_momix");    // mixing length of mo_convect (forcing + ice state only); "mixing_kpp" launches it itself
   if (m.p.mix_scheme == 2) K(s0, "k_pp");          // element (Av) and node (Kv) part in one launch
   if (m.p.mix_scheme == 1) K(s0, "mixing_kpp");       // k_kpp_col, 3 smoothing sweeps, k_kpp_final, k_kpp_elem
   hipStreamWaitEvent(s0, ev_rhs, 0); hipStreamWaitEvent(s0, ev_visc, 0);
@@ -533,9 +534,20 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   FT(adv_flux_hor, n1 * D); FT(adv_flux_raw, n1 * D); FT(flux_lo_hor, n1 * D); FT(diff_flux, n1 * D); FT(edge_up_dn_grad, 4 * n1 * D); F(edge_c12, D);
   F(ssh_values, m.nza);
   if (par->visc_option <= 3) { F(Visc, n1 * E); F(vorticity, n1 * N); F(leith_aux, n1 * N); }
+  if (par->use_momix) {       // where mo_convect applies the Monin-Obukhov mixing (oce_mo_conv.F90:28-31, :95); rad = pi/180 with the reference's pi (oce_modules.F90:11-12)
+    F(mixlength, N);
+    const double rad = 3.14159265358979 / 180.0, lim = par->momix_lat * rad;
+    std::vector<int> fn(N), fe(E, 0);
+    for (size_t n = 0; n < N; n++) fn[n] = !(d->geo_coord_nod2D[2 * n + 1] > lim) && d->ulevels_nod2D[n] <= 1;
+    for (int e = 0; e < m.myE; e++) {
+      const int n1 = d->elem2D_nodes[3 * e] - 1, n2 = d->elem2D_nodes[3 * e + 1] - 1, n3 = d->elem2D_nodes[3 * e + 2] - 1;
+      fe[e] = ((d->geo_coord_nod2D[2 * n1 + 1] + d->geo_coord_nod2D[2 * n2 + 1]) + d->geo_coord_nod2D[2 * n3 + 1]) / 3.0 <= lim && d->ulevels[e] <= 1;
+    }
+    m.momix_node = dev_upload(fn); m.momix_elem = dev_upload(fe);
+  }
   if (par->Fer_GM) { F(fer_K, nl * N); F(fer_gamma, 2 * nl * N); F(fer_Wvel, nl * N); F(fer_c, N); F(fer_UV, 2 * n1 * E); }
   {   // surface forcing: ONE device block (one host->device copy per fesom_gpu_set_forcing), fields are views into it
-    G.frc_count = 2 * E + 7 * N + (par->use_sw_pene ? nl * N : 0);
+    G.frc_count = 2 * E + 7 * N + (par->use_sw_pene ? nl * N : 0) + (par->use_momix ? 3 * N : 0);
     G.frc_dev = dev_alloc<double>(G.frc_count);
     double *q = G.frc_dev;
     auto view = [&](const char *name, size_t cnt) { double *r = q; G.fields[name] = Field{r, cnt, 1}; q += cnt; return r; };
@@ -543,6 +555,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     m.virtual_salt = view("virtual_salt", N); m.relax_salt = view("relax_salt", N); m.real_salt_flux = view("real_salt_flux", N);
     m.stress_atmoce_x = view("stress_atmoce_x", N); m.stress_atmoce_y = view("stress_atmoce_y", N);
     m.sw_3d = par->use_sw_pene ? view("sw_3d", nl * N) : nullptr;
+    if (par->use_momix) { m.u_ice = view("u_ice", N); m.v_ice = view("v_ice", N); m.a_ice = view("a_ice", N); }
   }
   if (par->mix_scheme == 1) {
     F(dbsfc, nl * N);
@@ -753,6 +766,7 @@ int fesom_gpu_set_forcing(const fesom_forcing_desc *f) {
   put(f->stress_surf, myE2, E2); put(f->heat_flux, N, N); put(f->water_flux, N, N); put(f->virtual_salt, N, N);
   put(f->relax_salt, N, N); put(f->real_salt_flux, N, N); put(f->stress_atmoce_x, N, N); put(f->stress_atmoce_y, N, N);
   if (G.m.sw_3d) put(f->sw_3d, (size_t)G.m.nl * N, (size_t)G.m.nl * N);
+  if (G.m.p.use_momix) { put(f->u_ice, N, N); put(f->v_ice, N, N); put(f->a_ice, N, N); }
   HIPCHK(hipMemcpyAsync(G.frc_dev, G.frc_pin[b], G.frc_count * sizeof(double), hipMemcpyHostToDevice, G.stream));
   HIPCHK(hipEventRecord(G.frc_ev[b], G.stream));
   return 0;
@@ -850,6 +864,7 @@ int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
   S.c("k_vel_nodes"); S.XA(0, {"Unode"});          // read by k_momadv_node only: in flight under pressure / PGF / slopes / mixing
   S.c("k_pressure_bv"); S.c("k_pgf"); S.c("k_sigma_slope");
   if (p.Redi) S.X(0, {"slope_tapered"});
+  if (p.use_momix) S.c("k_momix");
   if (p.mix_scheme == 2) { S.Wt(); S.c("k_pp"); }      // (the shear of oce_mixing_PP is read at the three nodes of every owned element)
   if (p.mix_scheme == 1) {
     S.c("k_kpp_col"); S.X(0, {"kpp_blmc"});

@@ -47,6 +47,9 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   double *eta_n, *d_eta, *ssh_rhs, *ssh_rhs_old, *hbar, *hbar_old, *MLD1, *MLD2;
   double *heat_flux, *water_flux, *virtual_salt, *relax_salt, *real_salt_flux;
   double *UV, *UV_rhs, *UV_rhsAB, *tr_xy, *tr_xy_ab, *U_b;
+  const double *u_ice, *v_ice, *a_ice;     // use_momix: ice state with the forcing (N)
+  double *mixlength;                       // Monin-Obukhov mixing length (N), kept from step to step
+  const int *momix_node, *momix_elem;      // 1 where mo_convect applies the Monin-Obukhov mixing (latitude / no cavity), per node and per owned element
   double *Visc, *vorticity, *leith_aux;    // visc_option 1-3: Leith coefficient (nl-1, E), relative vorticity and smoothing work array (nl-1, N)
   double *pgf_x, *pgf_y, *helem, *Av, *dhe, *stress_surf;
   double *adv_flux_hor, *adv_flux_raw, *flux_lo_hor, *edge_up_dn_grad, *edge_c12, *diff_flux;
@@ -144,6 +147,11 @@ __device__ __forceinline__ int rdlane(int x, int lane) { return __builtin_amdgcn
 __device__ __forceinline__ double shup(double x) { return __shfl_up(x, 1, 64); }     // value of lane-1
 __device__ __forceinline__ double shdn(double x) { return __shfl_down(x, 1, 64); }   // value of lane+1
 
+// mo(nz, node) of mo_convect (src/oce_mo_conv.F90:44-52): momix_kv inside the mixing length of a node the scheme applies to, else 0
+__device__ __forceinline__ double momix_mo(const DM &m, int nz, int n) {
+  if (!m.momix_node[n] || nz < m.ulev_n[n] + 1 || nz > m.nlev_n[n] - 1) return 0.0;
+  return fabs(DA2L(m.zbar_3d_n, nz, n)) <= m.mixlength[n] ? m.p.momix_kv : 0.0;
+}
 // Many quotients with the SAME denominator (x * dt / areasvol for every edge of a node): the device's IEEE fp64 division is
 // the sequence  ds = div_scale(d), r = rcp(ds) refined by two Newton steps, ns = div_scale(n), q0 = ns*r,
 // rem = fma(-ds, q0, ns), q = div_fmas(rem, r, q0), div_fixup  -- and everything up to r depends on the denominator only.
@@ -373,6 +381,7 @@ static inline int nblocks(int ncol) { return (ncol + COLS_PER_BLOCK - 1) / COLS_
 
 // launchers implemented in the kernel translation units
 void launch_dynamics_pre(const DM &m, hipStream_t s, int first_step);
+void launch_momix(const DM &m, hipStream_t s);      // mo_length of mo_convect (use_momix): before the fused mixing kernels
 void launch_ssh_rhs(const DM &m, hipStream_t s);
 int  launch_solver(const DM &m, hipStream_t s, int fuse_rhs = 0, int scale_done = 0);
 void launch_row_scale(const DM &m, hipStream_t s);

@@ -265,6 +265,35 @@ __device__ __forceinline__ double pp_raw(const DM &m, int nz, int n) {
   shear = shear * dz_inv * dz_inv;
   return shear / (shear + 5. * dmax_(DA2L(m.bvfreq, nz, n), 0.0) + 1.0e-14);
 }
+// Monin-Obukhov mixing of mo_convect (src/oce_mo_conv.F90:22-55): mo_length / pmlktmo (:107-182) for every node south of momix_lat,
+// one thread per node (owned + halo, as in the reference); the mixing length is state.  (The reference's unsuffixed literals are doubles:
+// it is built with -fdefault-real-8.)  exp is the device's: the one place where the last bit may differ from the host's libm.
+__global__ void k_momix(DM m) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= m.N || !m.momix_node[n]) return;
+  const double cosgam = 0.913632, qhw = 1 / 7.0, betas = 0.0008, betat = 0.00004;
+  const double qfm = m.water_flux[n] * 34.0, qtm = -2.38e-7 * m.heat_flux[n];
+  const double sx = m.stress_atmoce_x[n], sy = m.stress_atmoce_y[n], ui = m.u_ice[n], vi = m.v_ice[n], ai = m.a_ice[n];
+  const double tau = sqrt(sx * sx + sy * sy), ustar = sqrt(tau / 1030.0), uabs = sqrt(ui * ui + vi * vi);
+  const double qw = 1.25 * (ustar * ustar * ustar) * (1.0 - ai) + 0.005 * (uabs * uabs * uabs) * cosgam * ai;
+  const double qrho = betas * qfm - betat * qtm;
+  double ttmp = 60.0;
+  if (qrho > 0.) ttmp = 0.0;
+  else
+    for (int iter = 1; iter <= 5; iter++) {
+      double a1 = exp(-ttmp * qhw);
+      double f0 = 2.0 * qw * a1 + 9.81 * qrho * ttmp;
+      double f1 = -(2.0 * qw * a1 * qhw) + 9.81 * qrho;
+      ttmp = ttmp - f0 / f1;
+      ttmp = dmax_(ttmp, 10.0);
+    }
+  const double obuk = dmax_(ttmp, 10.0), rtc = m.p.dt / (10.0 * 86400.0);
+  double ml = m.mixlength[n];
+  if (obuk < ml) { double ret = (obuk - ml) * rtc; ml = ml + ret; }
+  else ml = obuk;
+  m.mixlength[n] = ml;
+}
+
 // Av incl. mo_convect element part.  The factor of the three nodes is evaluated here again instead of read from Kv, which makes the
 // element and the node part independent of each other: both run in ONE launch (k_pp).
 __device__ __forceinline__ void pp_elem_body(const DM &m, int e) {
@@ -277,6 +306,7 @@ __device__ __forceinline__ void pp_elem_body(const DM &m, int e) {
   double av = 0.01 * (k1 * k1 + k2 * k2 + k3 * k3) / 3.0 + m.p.A_ver;
   if (m.p.use_instabmix && (DA2L(m.bvfreq, nz, n1) < 0. || DA2L(m.bvfreq, nz, n2) < 0. || DA2L(m.bvfreq, nz, n3) < 0.))
     av = dmax_(av, m.p.instabmix_kv);
+  if (m.p.use_momix && m.momix_elem[e]) av = av + ((momix_mo(m, nz, n1) + momix_mo(m, nz, n2)) + momix_mo(m, nz, n3)) / 3.0;
   if (nzmin <= 1 && m.p.use_windmix && nz <= m.p.windmix_nl + 1) av = dmax_(av, m.p.windmix_kv);
   DA2L(m.Av, nz, e) = av;
 }
@@ -287,6 +317,7 @@ __device__ __forceinline__ void pp_node_body(const DM &m, int n) {     // Kv: Ri
   if (nz < nzmin + 1 || nz > m.nlev_n[n] - 1) return;
   double k = pp_raw(m, nz, n);
   double kv = 0.01 * (k * k * k) + (m.p.Kv0_const ? m.p.K_ver : kv0_background_qiang(m.lat_deg[n], fabs(DA2L(m.zbar_3d_n, nz, n))));
+  if (m.p.use_momix) kv = kv + momix_mo(m, nz, n);
   if (m.p.use_instabmix && DA2L(m.bvfreq, nz, n) < 0.) kv = dmax_(kv, m.p.instabmix_kv);
   if (nzmin <= 1 && m.p.use_windmix && nz <= m.p.windmix_nl + 1) kv = dmax_(kv, m.p.windmix_kv);
   DA2L(m.Kv, nz, n) = kv;
@@ -1024,6 +1055,7 @@ __global__ void __launch_bounds__(BLOCK) k_thick(DM m, int ncolN) {
 
 #define IV_ATTR(id, C_, W_) (void)hipFuncSetAttribute((const void *)k_impl_visc<C_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 void tile_prepare_dyn() { TILE_SHAPES(IV_ATTR) (void)hipFuncSetAttribute((const void *)k_edge_transport_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+void launch_momix(const DM &m, hipStream_t s) { if (m.p.use_momix) LAUNCH_FLAT(k_momix, m.N, m); }
 // h_viscosity_leith on one partition: vorticity, coefficient, two smoothing rounds
 void launch_leith(const DM &m, hipStream_t s) {
   LAUNCH_COL(k_leith_vort, m.myN, m); LAUNCH_COL(k_leith_elem, m.E, m);
@@ -1035,9 +1067,10 @@ void launch_dynamics_pre(const DM &m, hipStream_t s, int first_step) {
   LAUNCH_COL(k_pgf, m.myE, m);
   LAUNCH_COL(k_sigma_slope, m.myN, m);
   if (m.p.mix_scheme == 2) {
+    launch_momix(m, s);
     hipLaunchKernelGGL(k_pp, dim3(nblocks(m.myE) + nblocks(m.N)), dim3(BLOCK), 0, s, m, nblocks(m.myE) * COLS_PER_BLOCK);
   }
-  if (m.p.mix_scheme == 1) launch_named_kpp(m, s, "mixing_kpp");
+  if (m.p.mix_scheme == 1) launch_named_kpp(m, s, "mixing_kpp");      // (launches k_momix itself)
   LAUNCH_COL(k_momadv_node, m.myN, m);
   LAUNCH_COL(k_vel_rhs, m.myE, m, first_step);
   if (m.p.visc_option <= 3) launch_leith(m, s);
@@ -1079,6 +1112,7 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
     if (!strcmp(name, "k_pp_node_final")) { LAUNCH_COL(k_pp_node_final, m.N, m); return 0; }
     if (!strcmp(name, "k_momadv_node")) { LAUNCH_COL(k_momadv_node, m.myN, m); return 0; }
     if (!strcmp(name, "k_vel_rhs")) { LAUNCH_COL(k_vel_rhs, m.myE, m, first_step); return 0; }
+    if (!strcmp(name, "k_momix")) { if (m.p.use_momix) LAUNCH_FLAT(k_momix, m.N, m); return 0; }
     if (!strcmp(name, "k_visc_elem")) { LAUNCH_COL(k_visc_elem, m.E, m); return 0; }
     if (!strcmp(name, "k_leith_vort")) { LAUNCH_COL(k_leith_vort, m.myN, m); return 0; }
     if (!strcmp(name, "k_leith_elem")) { LAUNCH_COL(k_leith_elem, m.E, m); return 0; }
@@ -1108,6 +1142,7 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
   if (!strcmp(name, "compute_sigma_xy")) { LAUNCH_COL(k_sigma_slope, m.myN, m); return 0; } // includes neutral slope
   if (!strcmp(name, "compute_neutral_slope")) return 0;
   if (!strcmp(name, "mixing_pp")) {
+    if (m.p.use_momix) LAUNCH_FLAT(k_momix, m.N, m);                                        // mo_length of mo_convect, which is fused into k_pp
     hipLaunchKernelGGL(k_pp, dim3(nblocks(m.myE) + nblocks(m.N)), dim3(BLOCK), 0, s, m, nblocks(m.myE) * COLS_PER_BLOCK); return 0;
   }
   if (!strcmp(name, "mo_convect")) return 0;                                                  // fused into mixing_pp

@@ -317,6 +317,7 @@ __global__ void __launch_bounds__(BLOCK) k_kpp_final(DM m) {
   }
   double kv = kv1;
   if (nz >= nzmin + 1 && nz <= nzmax - 1) {
+    if (m.p.use_momix) kv = kv + momix_mo(m, nz, n);
     if (m.p.use_instabmix && DA2L(m.bvfreq, nz, n) < 0.) kv = dmax_(kv, m.p.instabmix_kv);
     if (nzmin <= 1 && m.p.use_windmix && nz <= m.p.windmix_nl + 1) kv = dmax_(kv, m.p.windmix_kv);
   }
@@ -336,6 +337,7 @@ __global__ void __launch_bounds__(BLOCK) k_kpp_elem(DM m) {
   if (nz >= nzmin + 1 && nz <= nzmax - 1) {
     if (m.p.use_instabmix && (DA2L(m.bvfreq, nz, n1) < 0. || DA2L(m.bvfreq, nz, n2) < 0. || DA2L(m.bvfreq, nz, n3) < 0.))
       av = dmax_(av, m.p.instabmix_kv);
+    if (m.p.use_momix && m.momix_elem[e]) av = av + ((momix_mo(m, nz, n1) + momix_mo(m, nz, n2)) + momix_mo(m, nz, n3)) / 3.0;
     if (nzmin <= 1 && m.p.use_windmix && nz <= m.p.windmix_nl + 1) av = dmax_(av, m.p.windmix_kv);
   }
   DA2L(m.Av, nz, e) = av;
@@ -354,6 +356,7 @@ int launch_named_kpp(const DM &m, hipStream_t s, const char *name) {
   if (!strcmp(name, "k_kpp_final")) { LAUNCH_COL(k_kpp_final, m.myN, m); return 0; }
   if (!strcmp(name, "k_kpp_elem")) { LAUNCH_COL(k_kpp_elem, m.myE, m); return 0; }
   if (!strcmp(name, "mixing_kpp")) {                        // oce_mixing_KPP + Kv = Kv_double(:,:,1) + mo_convect
+    launch_momix(m, s);
     LAUNCH_COL(k_kpp_col, m.myN, m);
     smooth(m, s, m.kpp_blmc, m.kpp_sA); smooth(m, s, m.kpp_sA, m.kpp_sB); smooth(m, s, m.kpp_sB, m.kpp_blmc);
     LAUNCH_COL(k_kpp_final, m.myN, m); LAUNCH_COL(k_kpp_elem, m.myE, m);

@@ -20,6 +20,7 @@ module fesom_gpu_shim
   use g_PARSUP
   use g_config
   use g_forcing_arrays, only: real_salt_flux, sw_3d
+  use i_ARRAYS, only: u_ice, v_ice, a_ice
   implicit none
   private
   public :: fesom_gpu_setup, oce_timestep_ale_gpu, fesom_gpu_fetch_state, fesom_gpu_push_state, fesom_gpu_shutdown, fesom_gpu_profile
@@ -62,7 +63,8 @@ module fesom_gpu_shim
      real(c_double) :: visc_sh_limit, diff_sh_limit, Ricr, concv
      integer(c_int) :: use_sw_pene, tra_adv_ver, tra_adv_hor, Kv0_const, solver_precond, tra_adv_lim, solver_xinv_its
      real(c_double) :: Leith_c, Div_c
-     integer(c_int) :: which_pgf
+     integer(c_int) :: which_pgf, use_momix
+     real(c_double) :: momix_lat, momix_kv
   end type
   type, bind(C) :: fesom_state_desc
      type(c_ptr) :: tr_arr, tr_arr_old, UV, UV_rhsAB, eta_n, d_eta, ssh_rhs, ssh_rhs_old, hbar, hbar_old, dhe, hnode, hnode_new, &
@@ -73,7 +75,7 @@ module fesom_gpu_shim
      type(c_funptr) :: exchange, allreduce_sum
   end type
   type, bind(C) :: fesom_forcing_desc
-     type(c_ptr) :: stress_surf, heat_flux, water_flux, virtual_salt, relax_salt, real_salt_flux, stress_atmoce_x, stress_atmoce_y, sw_3d
+     type(c_ptr) :: stress_surf, heat_flux, water_flux, virtual_salt, relax_salt, real_salt_flux, stress_atmoce_x, stress_atmoce_y, sw_3d, u_ice, v_ice, a_ice
   end type
 
   interface
@@ -90,6 +92,18 @@ module fesom_gpu_shim
      integer(c_int) function c_fesom_gpu_download_state(st) bind(C, name='fesom_gpu_download_state')
        import
        type(fesom_state_desc), intent(in) :: st
+     end function
+     integer(c_int) function c_fesom_gpu_get_field(name, out, count) bind(C, name='fesom_gpu_get_field')
+       import
+       character(kind=c_char), intent(in) :: name(*)
+       type(c_ptr), value :: out
+       integer(c_long_long), value :: count
+     end function
+     integer(c_int) function c_fesom_gpu_set_field(name, src, count) bind(C, name='fesom_gpu_set_field')
+       import
+       character(kind=c_char), intent(in) :: name(*)
+       type(c_ptr), value :: src
+       integer(c_long_long), value :: count
      end function
      integer(c_int) function c_fesom_gpu_set_forcing(f) bind(C, name='fesom_gpu_set_forcing')
        import
@@ -288,7 +302,7 @@ contains
     call refuse(use_kpp_nonlclflx, 'use_kpp_nonlclflx (KPP non-local fluxes, oce_ale_tracer.F90:688)')
     call refuse(double_diffusion .and. mix_scheme_nmb == 1, 'double_diffusion (oce_ale_mixing_kpp.F90:356)')
     call refuse(clim_relax > 1.0e-8_WP .and. .not. toy_ocean, 'clim_relax > 0 (relax_to_clim, oce_tracer_mod.F90:99)')
-    call refuse(use_momix, 'use_momix (Monin-Obukhov mixing of mo_convect, oce_mo_conv.F90:22)')
+    call refuse(use_momix .and. .not. allocated(mixlength), 'use_momix without the ice arrays (the reference allocates mo / mixlength only with use_ice, oce_setup_step.F90:218)')
     call status_check
 
     p%dt = dt
@@ -338,6 +352,7 @@ contains
     case ('shchepetkin'); p%which_pgf = 0
     case default; p%which_pgf = -1
     end select
+    p%use_momix = l2i(use_momix); p%momix_lat = momix_lat; p%momix_kv = momix_kv
     p%solver_precond = 1; p%solver_xinv_its = 0     ! explicit-inverse preconditioner where it fits (pi), library default iterations
 
     transport%ctx = c_null_ptr
@@ -348,6 +363,7 @@ contains
     if (npes > 1) call setup_builtin_transport
     call state_desc(mesh, st)
     call check(c_fesom_gpu_upload_state(st), 'fesom_gpu_upload_state')
+    if (use_momix .and. allocated(mixlength)) call check(c_fesom_gpu_set_field('mixlength'//c_null_char, ar(mixlength), int(size(mixlength), c_long_long)), 'fesom_gpu_set_field(mixlength)')
     call status_check
     is_setup = .true.
   end subroutine
@@ -370,6 +386,10 @@ contains
     end if
     f%sw_3d = c_null_ptr
     if (use_sw_pene .and. allocated(sw_3d)) f%sw_3d = ar(sw_3d)
+    f%u_ice = c_null_ptr; f%v_ice = c_null_ptr; f%a_ice = c_null_ptr
+    if (use_momix .and. allocated(a_ice)) then
+       f%u_ice = ar(u_ice); f%v_ice = ar(v_ice); f%a_ice = ar(a_ice)
+    end if
     call check(c_fesom_gpu_set_forcing(f), 'fesom_gpu_set_forcing')
     if (fesom_gpu_profile .and. npes == 1) then
        call check(c_fesom_gpu_profile_step(int(n, c_int), pms), 'fesom_gpu_profile_step')
@@ -475,6 +495,7 @@ contains
     type(fesom_state_desc) :: st
     call state_desc(mesh, st)
     call check(c_fesom_gpu_download_state(st), 'fesom_gpu_download_state')
+    if (use_momix .and. allocated(mixlength)) call check(c_fesom_gpu_get_field('mixlength'//c_null_char, ar(mixlength), int(size(mixlength), c_long_long)), 'fesom_gpu_get_field(mixlength)')
     call status_check
   end subroutine
 
@@ -483,6 +504,7 @@ contains
     type(fesom_state_desc) :: st
     call state_desc(mesh, st)
     call check(c_fesom_gpu_upload_state(st), 'fesom_gpu_upload_state')
+    if (use_momix .and. allocated(mixlength)) call check(c_fesom_gpu_set_field('mixlength'//c_null_char, ar(mixlength), int(size(mixlength), c_long_long)), 'fesom_gpu_set_field(mixlength)')
     call status_check
   end subroutine
 

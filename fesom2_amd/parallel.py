@@ -47,6 +47,8 @@ def run_step(core, par, X, solve, first, probe=None, n=1, zonal=None):
     c("k_pressure_bv"); c("k_pgf"); c("k_sigma_slope"); P("pressure")
     if p.Redi:
         X(NOD, ["slope_tapered"])
+    if p.use_momix:
+        c("k_momix")
     if p.mix_scheme == 2:
         c("k_pp"); P("mixing")
     if p.mix_scheme == 1:                             # KPP: smoothing of blmc needs the neighbours' values after every sweep

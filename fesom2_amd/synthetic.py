@@ -74,6 +74,15 @@ def analytic_forcing(mesh):
     return {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in f.items()}
 
 
+def analytic_ice(mesh):
+    """Analytic ice state for mo_length of mo_convect (use_momix): ice-free, partly and fully covered regions, ice drift.  Same formulas as the
+    reference harness (oracle/ref/driver.F90)."""
+    lon, lat = mesh.geo_coord_nod2D[:, 0], mesh.geo_coord_nod2D[:, 1]
+    f = {"a_ice": np.minimum(1.0, np.maximum(0.0, -0.9 - 1.6 * np.sin(lat) + 0.25 * np.cos(3.0 * lon))),
+         "u_ice": 0.08 * np.sin(lon) * np.cos(lat), "v_ice": 0.05 * np.cos(2.0 * lon)}
+    return {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in f.items()}
+
+
 def analytic_sw_3d(mesh, heat_flux):
     """Penetrating short-wave flux / vcpw [K m/s] (nl, N) for use_sw_pene: half of the positive part of `heat_flux`, decaying
     over ~15 m; +,-,*,/ only, the same operations as the reference harness (bit-identical values)."""

@@ -36,7 +36,7 @@ def tracer_chain(tr):
 TAIL = [("salinity_clamp", 0, ["tr_arr"]), ("update_thickness_ale", 0, ["hnode", "helem", "zbar_3d_n", "Z_3d_n"])]
 
 # fields whose values go through a libm call that differs between glibc and the device library
-ULP_FIELDS = {"slope_tapered": 1e-12}
+ULP_FIELDS = {"slope_tapered": 1e-12, "mixlength": 1e-13}    # mixlength: exp of the device vs glibc inside the Newton iteration of pmlktmo
 
 
 GM_BEFORE_W = [("init_Redi_GM", 0, ["fer_K", "fer_c"]), ("fer_solve_Gamma", 0, ["fer_gamma"]), ("fer_gamma2vel", 0, ["fer_UV"])]

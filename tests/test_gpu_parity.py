@@ -501,6 +501,51 @@ def test_biharmonic_viscosity_chain_bitwise(built, opt):
     gpu.close()
 
 
+@pytest.mark.parametrize("kw", [dict(mix_scheme="PP"), dict(mix_scheme="KPP", Fer_GM=True, Redi=True)])
+def test_monin_obukhov_mixing_chain(built, kw):
+    """use_momix = .true. (the shipped config/namelist.oce; oracle pinned on the reference runs pi_pp_momix / pi_default_momix): k_momix (mo_length, pmlktmo)
+    + the momix terms of the fused mixing kernels.  HIP == oracle bit for bit after every routine of 3 steps; the mixing length itself to 1e-13 relative
+    (its Newton iteration calls exp: the device's libm against glibc), Kv / Av are compared bitwise (they only see it through |zbar| <= mixlength)."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.core import OceanCore
+    from fesom2_amd.synthetic import analytic_ts, analytic_forcing, analytic_ice
+    from oracle_lib import Oracle
+    kpp = kw["mix_scheme"] == "KPP"
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, use_momix=True, **kw)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    gpu, orc = OceanCore(mesh, par), Oracle(mesh, par)
+    gpu.upload_state(st); orc.set_state(st)
+    forcing = dict(analytic_forcing(mesh), **analytic_ice(mesh))
+    gpu.set_forcing(**forcing)
+    for k, v in forcing.items():
+        orc.set(k, v)
+    failures, deep = [], 0
+    for step in range(1, 4):
+        for routine, arg, fields in full_chain(2, gm=kpp, redi=kpp, kpp=kpp):
+            gpu.call(routine, arg); orc.call(routine, arg)
+            if routine == "compute_neutral_slope" and kpp:          # tanh: device libm vs glibc (see test_redi_chain_bitwise_and_steps)
+                gpu.set("slope_tapered", orc.get("slope_tapered"))
+            if routine == "mo_convect":                             # exp inside pmlktmo: compared to 1e-13 below, then the same bits on both sides
+                ok, msg = compare("mixlength", gpu.get("mixlength", orc.count("mixlength")), orc.get("mixlength"))
+                if not ok:
+                    failures.append(f"step {step} {routine}({arg}) {msg}")
+                gpu.set("mixlength", orc.get("mixlength"))
+            for f in fields:
+                ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+                if not ok:
+                    failures.append(f"step {step} {routine}({arg}) {msg}")
+        if failures:
+            break
+    assert not failures, "\n".join(failures[:10])
+    ml = gpu.get("mixlength", orc.count("mixlength"))
+    assert (ml >= 10.0).sum() > 500 and (ml == 0.0).sum() > 1000          # applied south of 50 S only
+    gpu.close()
+
+
 @pytest.mark.parametrize("field,value,msg", [("visc_option", 0, "visc_option"), ("visc_option", 8, "visc_option"), ("which_pgf", -1, "which_pgf"), ("tra_adv_ver", 4, "tra_adv_ver"),
                                              ("tra_adv_ver", -1, "tra_adv_ver"), ("tra_adv_hor", 3, "tra_adv_hor"), ("mom_adv", 3, "mom_adv"),
                                              ("mix_scheme", 3, "mix_scheme")])
