@@ -52,7 +52,7 @@ KERNEL_VALUES = {
     "k_thick": (5, 1, 0), "k_dhe": (0, 0, 0),
     # KPP (kernels_kpp.hip), GM / Redi (kernels_gm.hip)
     "k_kpp_col": (15, 0, 0), "k_kpp_smooth1": (6, 0, 0), "k_kpp_smooth2": (6, 0, 0), "k_kpp_smooth3": (6, 0, 0), "k_kpp_final": (10, 0, 0),
-    "k_kpp_elem": (1, 1, 0), "k_gm_coef": (6, 0, 0), "k_fer_gamma": (8, 0, 0), "k_fer_uv": (2, 3, 0), "k_fer_wvel": (2, 3, 0),
+    "k_kpp_elem": (1, 1, 0), "k_kpp_final_elem": (11, 1, 0), "k_gm_coef": (6, 0, 0), "k_fer_gamma": (8, 0, 0), "k_fer_uv": (2, 3, 0), "k_fer_wvel": (2, 3, 0),
     "bolus_add": (3, 6, 0), "bolus_remove": (3, 6, 0),
     "k_toy_relax_vel": (0, 3, 0), "k_toy_relax_temp": (3, 0, 0),
     "k_flux_hor_fused": (2, 5, 2),          # fill_up_dn_grad on the fly: tr_xy_ab instead of edge_up_dn_grad (CORE2-class meshes)
@@ -70,7 +70,7 @@ def step_kernels(p, tile=False):
     if p.mix_scheme == 2:
         ks.append("k_pp")
     if p.mix_scheme == 1:
-        ks += ["k_kpp_col", "k_kpp_smooth1", "k_kpp_smooth2", "k_kpp_smooth3", "k_kpp_final", "k_kpp_elem"]
+        ks += ["k_kpp_col", "k_kpp_smooth1", "k_kpp_smooth2", "k_kpp_smooth3", "k_kpp_final_elem"]     # (one partition: node + element part in one launch)
     if p.Fer_GM or p.Redi:
         ks.append("k_gm_coef")
     if p.Fer_GM:

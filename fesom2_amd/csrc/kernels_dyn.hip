@@ -144,8 +144,49 @@ __global__ void __launch_bounds__(BLOCK) k_pressure_bv(DM m) {
   }
 }
 
+// pressure_force_4_zxxxx_cubicspline (src/oce_ale_pressure_bv.F90:1697-1866): density of one node interpolated to the depth Zn with the
+// monotonised cubic spline of the four levels around it (surface / bottom / bulk cases :1757-1803)
+__device__ __forceinline__ double pgf_cubic_rho(const DM &m, int node, double Zn) {
+  const int nln = m.nlev_n[node] - 1, uln = m.ulev_n[node];
+  int nlc = nln - 1;
+  for (int dd = uln; dd <= nln; dd++)
+    if (DA2(m.Z_3d_n, dd, node) <= Zn) { nlc = dd - 1; if (dd == 1) nlc = 1; break; }
+  int i0 = nlc - 1, i3 = nlc + 2;
+  const bool surf = nlc == uln, bot = !surf && nlc == nln - 1;
+  if (surf) i0 = uln;
+  if (bot) i3 = nlc + 1;
+  const double z0 = DA2(m.Z_3d_n, i0, node), z1 = DA2(m.Z_3d_n, nlc, node), z2 = DA2(m.Z_3d_n, nlc + 1, node), z3 = DA2(m.Z_3d_n, i3, node);
+  const double d0 = DA2(m.density_m_rho0, i0, node), d1 = DA2(m.density_m_rho0, nlc, node), d2 = DA2(m.density_m_rho0, nlc + 1, node),
+               d3 = DA2(m.density_m_rho0, i3, node);
+  const double s_H = z2 - z1, aux1 = (d2 - d1) / s_H;
+  double s_dup, s_dlo, aux2;
+  if (surf) {
+    aux2 = (d3 - d2) / (z3 - z2);
+    s_dlo = 0.0;
+    if (aux1 * aux2 > 0.) s_dlo = 2.0 * aux1 * aux2 / (aux1 + aux2);
+    s_dup = 1.5 * aux1 - 0.5 * s_dlo;
+  } else if (bot) {
+    aux2 = (d1 - d0) / (z1 - z0);
+    s_dup = 0.0;
+    if (aux1 * aux2 > 0.) s_dup = 2.0 * aux1 * aux2 / (aux1 + aux2);
+    s_dlo = 1.5 * aux1 - 0.5 * s_dup;
+  } else {
+    aux2 = (d1 - d0) / (z1 - z0);
+    s_dup = 0.0;
+    if (aux1 * aux2 > 0.) s_dup = 2.0 * aux1 * aux2 / (aux1 + aux2);
+    aux2 = (d3 - d2) / (z3 - z2);
+    s_dlo = 0.0;
+    if (aux1 * aux2 > 0.) s_dlo = 2.0 * aux1 * aux2 / (aux1 + aux2);
+  }
+  const double c = -(2.0 * s_dup + s_dlo) / s_H + 3.0 * (d2 - d1) / (s_H * s_H);
+  const double d = (s_dup + s_dlo) / (s_H * s_H) - 2.0 * (d2 - d1) / ((s_H * s_H) * s_H);
+  const double dz = Zn - z1;
+  return d1 + s_dup * dz + c * (dz * dz) + d * ((dz * dz) * dz);
+}
+
 // ------------------------------------------------------------------------------------------------
-// pressure_force_4_zxxxx_shchepetkin (src/oce_ale_pressure_bv.F90:1878-2104) / _linfs_fullcell (:432-466) / _linfs_shchepetkin (:647-891).
+// pressure_force_4_zxxxx_shchepetkin (src/oce_ale_pressure_bv.F90:1878-2104) / _zxxxx_cubicspline (:1697-1866) / _linfs_fullcell (:432-466) /
+// _linfs_shchepetkin (:647-891).
 // Per element column: density-Jacobian terms per level in parallel, the two vertical integrals as
 // reference-order running sums.  Reads 3 node columns x (rho, Z) -> HBM-bound gather, 2 N3 + 3 E3 values.
 __global__ void __launch_bounds__(BLOCK) k_pgf(DM m) {
@@ -170,7 +211,11 @@ __global__ void __launch_bounds__(BLOCK) k_pgf(DM m) {
   if (nlz == nle) zb_bot = m.zbar_e_bot[e];
   double Zn = zb_bot + he * 0.5;                                         // Z_n(nlz)
   double auxx = 0.0, auxy = 0.0;
-  if (wet) {
+  if (wet && m.p.which_pgf == 1) {                         // 'cubicspline'
+    const double r0 = pgf_cubic_rho(m, n0, Zn), r1 = pgf_cubic_rho(m, n1, Zn), r2 = pgf_cubic_rho(m, n2, Zn);
+    const double gx = (DGS(1, e) * r0 + DGS(2, e) * r1) + DGS(3, e) * r2, gy = (DGS(4, e) * r0 + DGS(5, e) * r1) + DGS(6, e) * r2;
+    auxx = D_G * he * gx / D_RHO0; auxy = D_G * he * gy / D_RHO0;
+  } else if (wet) {
     const int en[3] = {n0, n1, n2};
     double drho_dz[3], rho_c[3], z_c[3];
 #pragma unroll

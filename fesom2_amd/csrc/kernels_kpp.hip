@@ -300,8 +300,8 @@ __global__ void __launch_bounds__(BLOCK) k_kpp_smooth(DM m, const double *src, d
 }
 
 // :377-392 + Kv = Kv_double(:,:,1) + mo_convect node part (oce_mo_conv.F90:47-57)
-__global__ void __launch_bounds__(BLOCK) k_kpp_final(DM m) {
-  const int n = col_id(), l = lane_id(), nz = l + 1;
+__device__ __forceinline__ void kpp_final_body(const DM &m, int n) {
+  const int l = lane_id(), nz = l + 1;
   if (n >= m.myN) return;
   const int nzmin = m.ulev_n[n], nzmax = m.nlev_n[n];
   if (nz < nzmin || nz > nzmax) return;
@@ -325,14 +325,23 @@ __global__ void __launch_bounds__(BLOCK) k_kpp_final(DM m) {
 }
 
 // :400-416 + mo_convect element part (oce_mo_conv.F90:62-77)
-__global__ void __launch_bounds__(BLOCK) k_kpp_elem(DM m) {
-  const int e = col_id(), nz = lane_id() + 1;
+// viscosity of node n at interface k as k_kpp_final leaves it.  FUSED: the node part of the same launch may or may not have stored it yet; the
+// maximum with blmc applied to either value gives the same number (max(max(a, b), b) = max(a, b)), 8-byte loads are not torn.
+template <bool FUSED>
+__device__ __forceinline__ double kpp_visc_final(const DM &m, int k, int n) {
+  double v = DA2L(m.kpp_viscA, k, n);
+  if (FUSED && k >= m.ulev_n[n] + 1 && k <= m.nlev_n[n] - 1 && k < m.kpp_kbl[n]) v = dmax_(v, m.kpp_blmc[(size_t)n * m.nl + k - 1]);
+  return v;
+}
+template <bool FUSED>
+__device__ __forceinline__ void kpp_elem_body(const DM &m, int e) {
+  const int nz = lane_id() + 1;
   if (e >= m.myE) return;
   const int nzmin = m.ulev[e], nzmax = m.nlev[e];
   if (nz < nzmin || nz > nzmax) return;
   const int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
   const int k = nz < nzmax ? nz : nzmax - 1;                               // viscAE(nlevels) = viscAE(nlevels-1)
-  double av = (DA2L(m.kpp_viscA, k, n1) + DA2L(m.kpp_viscA, k, n2) + DA2L(m.kpp_viscA, k, n3)) / 3.0;
+  double av = (kpp_visc_final<FUSED>(m, k, n1) + kpp_visc_final<FUSED>(m, k, n2) + kpp_visc_final<FUSED>(m, k, n3)) / 3.0;
   if (nz == nzmin && av < 3.0e-3) av = 3.0e-3;                            // minmix on the first interface only
   if (nz >= nzmin + 1 && nz <= nzmax - 1) {
     if (m.p.use_instabmix && (DA2L(m.bvfreq, nz, n1) < 0. || DA2L(m.bvfreq, nz, n2) < 0. || DA2L(m.bvfreq, nz, n3) < 0.))
@@ -341,6 +350,13 @@ __global__ void __launch_bounds__(BLOCK) k_kpp_elem(DM m) {
     if (nzmin <= 1 && m.p.use_windmix && nz <= m.p.windmix_nl + 1) av = dmax_(av, m.p.windmix_kv);
   }
   DA2L(m.Av, nz, e) = av;
+}
+__global__ void __launch_bounds__(BLOCK) k_kpp_final(DM m) { kpp_final_body(m, col_id()); }
+__global__ void __launch_bounds__(BLOCK) k_kpp_elem(DM m) { kpp_elem_body<false>(m, col_id()); }
+// single partition: both in ONE launch (first ncolE column slots are element columns), one dependent launch less on the critical chain
+__global__ void __launch_bounds__(BLOCK) k_kpp_final_elem(DM m, int ncolE) {
+  const int c = col_id();
+  if (c < ncolE) kpp_elem_body<true>(m, c); else kpp_final_body(m, c - ncolE);
 }
 
 #define LAUNCH_COL(k, ncol, ...) hipLaunchKernelGGL(k, dim3(nblocks(ncol)), dim3(BLOCK), 0, s, __VA_ARGS__)
@@ -355,11 +371,13 @@ int launch_named_kpp(const DM &m, hipStream_t s, const char *name) {
   if (!strcmp(name, "k_kpp_smooth3")) { smooth(m, s, m.kpp_sB, m.kpp_blmc); return 0; }
   if (!strcmp(name, "k_kpp_final")) { LAUNCH_COL(k_kpp_final, m.myN, m); return 0; }
   if (!strcmp(name, "k_kpp_elem")) { LAUNCH_COL(k_kpp_elem, m.myE, m); return 0; }
+  if (!strcmp(name, "k_kpp_final_elem")) { hipLaunchKernelGGL(k_kpp_final_elem, dim3(nblocks(m.myE) + nblocks(m.myN)), dim3(BLOCK), 0, s, m, nblocks(m.myE) * COLS_PER_BLOCK); return 0; }
   if (!strcmp(name, "mixing_kpp")) {                        // oce_mixing_KPP + Kv = Kv_double(:,:,1) + mo_convect
     launch_momix(m, s);
     LAUNCH_COL(k_kpp_col, m.myN, m);
     smooth(m, s, m.kpp_blmc, m.kpp_sA); smooth(m, s, m.kpp_sA, m.kpp_sB); smooth(m, s, m.kpp_sB, m.kpp_blmc);
-    LAUNCH_COL(k_kpp_final, m.myN, m); LAUNCH_COL(k_kpp_elem, m.myE, m);
+    if (m.N == m.myN) hipLaunchKernelGGL(k_kpp_final_elem, dim3(nblocks(m.myE) + nblocks(m.myN)), dim3(BLOCK), 0, s, m, nblocks(m.myE) * COLS_PER_BLOCK);
+    else { LAUNCH_COL(k_kpp_final, m.myN, m); LAUNCH_COL(k_kpp_elem, m.myE, m); }
     return 0;
   }
   if (!strcmp(name, "mo_convect")) return 0;                // fused into k_kpp_final / k_kpp_elem

@@ -350,6 +350,7 @@ contains
     p%Leith_c = Leith_c; p%Div_c = Div_c
     select case (trim(which_pgf))
     case ('shchepetkin'); p%which_pgf = 0
+    case ('cubicspline'); p%which_pgf = 1
     case default; p%which_pgf = -1
     end select
     p%use_momix = l2i(use_momix); p%momix_lat = momix_lat; p%momix_kv = momix_kv

@@ -115,8 +115,74 @@ void orc_pressure_bv(void) {
  * pressure_force_4_linfs_shchepetkin (linfs with partial cells): :647-891 -- the same integral, the density-Jacobian correction only
  * in the bottom layer (the levels above are flat: "in case linfs: dz_dx == 0.0", :799) */
 static void pgf_linfs_fullcell(void);
+/* pressure_force_4_zxxxx_cubicspline: src/oce_ale_pressure_bv.F90:1697-1866 (which_pgf = 'cubicspline': the density of the three nodes is
+ * interpolated to the mid-depth of the element layer with a monotonised cubic spline, "like in FESOM1.4") */
+static void pgf_zxxxx_cubicspline(void) {
+  int nl = NL;
+  double *zbar_n = calloc(nl + 2, sizeof(double)), *Z_n = calloc(nl + 2, sizeof(double));
+  for (int e = 1; e <= C_.m.myDim_elem2D; e++) {
+    int nle = NLEV(e) - 1, ule = ULEV(e);
+    int en[3] = {EN(1, e), EN(2, e), EN(3, e)};
+    for (int k = 0; k <= nl; k++) { zbar_n[k] = 0.0; Z_n[k] = 0.0; }
+    zbar_n[nle + 1] = C_.m.zbar_e_bot[e - 1];
+    Z_n[nle] = zbar_n[nle + 1] + A2(C_.helem, nle, e) / 2.0;
+    for (int nlz = nle; nlz >= ule + 1; nlz--) {
+      zbar_n[nlz] = zbar_n[nlz + 1] + A2(C_.helem, nlz, e);
+      Z_n[nlz - 1] = zbar_n[nlz] + A2(C_.helem, nlz - 1, e) / 2.0;
+    }
+    zbar_n[ule] = zbar_n[ule + 1] + A2(C_.helem, ule, e);
+    double p_grad[2] = {0.0, 0.0};
+    for (int nlz = ule; nlz <= nle; nlz++) {
+      double rho_n[3];
+      for (int ni = 0; ni < 3; ni++) {
+        int node = en[ni], nln = NLEVN(node) - 1, uln = ULEVN(node);
+        int nlc = nln - 1;
+        for (int dd = uln; dd <= nln; dd++)
+          if (A2(C_.Z_3d_n, dd, node) <= Z_n[nlz]) { nlc = dd - 1; if (dd == 1) nlc = 1; break; }
+        int si[4] = {nlc - 1, nlc, nlc + 1, nlc + 2};
+        double s_z[4], s_d[4], s_H, aux1, aux2, s_dup, s_dlo;
+        if (nlc == uln) si[0] = uln;
+        else if (nlc == nln - 1) si[3] = nlc + 1;
+        for (int k = 0; k < 4; k++) { s_z[k] = A2(C_.Z_3d_n, si[k], node); s_d[k] = A2(C_.density_m_rho0, si[k], node); }
+        s_H = s_z[2] - s_z[1];
+        aux1 = (s_d[2] - s_d[1]) / s_H;
+        if (nlc == uln) {                      /* surface case */
+          aux2 = (s_d[3] - s_d[2]) / (s_z[3] - s_z[2]);
+          s_dlo = 0.0;
+          if (aux1 * aux2 > 0.) s_dlo = 2.0 * aux1 * aux2 / (aux1 + aux2);
+          s_dup = 1.5 * aux1 - 0.5 * s_dlo;
+        } else if (nlc == nln - 1) {           /* bottom case */
+          aux2 = (s_d[1] - s_d[0]) / (s_z[1] - s_z[0]);
+          s_dup = 0.0;
+          if (aux1 * aux2 > 0.) s_dup = 2.0 * aux1 * aux2 / (aux1 + aux2);
+          s_dlo = 1.5 * aux1 - 0.5 * s_dup;
+        } else {
+          aux2 = (s_d[1] - s_d[0]) / (s_z[1] - s_z[0]);
+          s_dup = 0.0;
+          if (aux1 * aux2 > 0.) s_dup = 2.0 * aux1 * aux2 / (aux1 + aux2);
+          aux2 = (s_d[3] - s_d[2]) / (s_z[3] - s_z[2]);
+          s_dlo = 0.0;
+          if (aux1 * aux2 > 0.) s_dlo = 2.0 * aux1 * aux2 / (aux1 + aux2);
+        }
+        double a = s_d[1], b = s_dup;
+        double c = -(2.0 * s_dup + s_dlo) / s_H + 3.0 * (s_d[2] - s_d[1]) / (s_H * s_H);
+        double d = (s_dup + s_dlo) / (s_H * s_H) - 2.0 * (s_d[2] - s_d[1]) / ((s_H * s_H) * s_H);
+        double dz = Z_n[nlz] - s_z[1];
+        rho_n[ni] = a + b * dz + c * (dz * dz) + d * ((dz * dz) * dz);
+      }
+      double gx = (GS(1, e) * rho_n[0] + GS(2, e) * rho_n[1]) + GS(3, e) * rho_n[2], gy = (GS(4, e) * rho_n[0] + GS(5, e) * rho_n[1]) + GS(6, e) * rho_n[2];
+      double ax = G_ACC * A2(C_.helem, nlz, e) * gx / DENSITY_0, ay = G_ACC * A2(C_.helem, nlz, e) * gy / DENSITY_0;
+      A2(C_.pgf_x, nlz, e) = p_grad[0] + ax * 0.5;
+      A2(C_.pgf_y, nlz, e) = p_grad[1] + ay * 0.5;
+      p_grad[0] = p_grad[0] + ax; p_grad[1] = p_grad[1] + ay;
+    }
+  }
+  free(zbar_n); free(Z_n);
+}
+
 void orc_pressure_force(void) {
   if (C_.p.which_ale == 0 && !C_.p.use_partial_cell) { pgf_linfs_fullcell(); return; }
+  if (C_.p.which_ale != 0 && C_.p.which_pgf == 1) { pgf_zxxxx_cubicspline(); return; }
   const int lin = C_.p.which_ale == 0;
   int nl = NL;
   double *zbar_n = calloc(nl + 2, sizeof(double)), *Z_n = calloc(nl + 2, sizeof(double));
