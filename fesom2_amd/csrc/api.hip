@@ -231,7 +231,9 @@ struct Dag {
   void dep(hipStream_t to, hipStream_t from) { hipEvent_t e = ev(); hipEventRecord(e, from); hipStreamWaitEvent(to, e, 0); }
   ~Dag() { for (auto e : evs) hipEventDestroy(e); }
 };
+static int g_exp_skip_side = -1, g_exp_step = 0;     // timing experiment (FESOM_GPU_EXP_SKIP_SIDE=<step>): from that step on only the critical chain is launched
 int K(hipStream_t s, const char *k, int arg = 0, int fs = 0) {
+  if (g_exp_skip_side >= 0 && g_exp_step >= g_exp_skip_side && s != G.stream) return 0;
   int rc = launch_named_dyn(G.m, s, k, arg, fs);
   if (rc < 0) rc = launch_named_tra(G.m, s, k, arg);
   if (rc < 0) rc = launch_named_kpp(G.m, s, k);
@@ -242,6 +244,7 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   // carry what only has to be READY by then.  All tracers go through the same launches (grid.y = tracer).
   const DM &m = G.m;
   hipStream_t s1 = G.side[0], s2 = G.side[1], s3 = G.side[2];
+  { static bool once = false; if (!once) { once = true; const char *e = getenv("FESOM_GPU_EXP_SKIP_SIDE"); if (e) g_exp_skip_side = atoi(e); } g_exp_step++; }
   const bool toy = m.p.toy_soufflet != 0;
   if (toy && n % 10 == 0) launch_named_toy(m, s0, "compute_zonal_mean");   // before_oce_step (oce_setup_step.F90:625-630)
   d.dep(s1, s0); d.dep(s2, s0); d.dep(s3, s0);
