@@ -114,3 +114,181 @@ int orc_ice_evp(const fesom_mesh_desc *m, const fesom_ice_params *p, fesom_ice_s
   free(ua); free(va); free(rhs_a); free(rhs_m); free(urhs); free(vrhs); free(invt); free(mass); free(pfac); free(ice_nod); free(ice_el); free(bnd);
   return 0;
 }
+
+/* ---- FCT advection of m_ice, a_ice, m_snow: ice_TG_rhs_div, ice_fct_solve (ice_solve_high_order, ice_solve_low_order, ice_fem_fct x 3),
+ * ice_update_for_div (src/ice_fct.F90) and cut_off (src/ice_thermo_oce.F90:2-63) = the "Advection part" of ice_timestep
+ * (src/ice_setup_step.F90:213-232; no __oifs, no cavities).  One partition.  Pinned bitwise on a run of the reference's own routines
+ * (tests/golden/ice_adv_reference.npz).  dbg: NULL or 20 arrays of N doubles that receive, in this order, u_ice, v_ice, rhs_m, rhs_a,
+ * rhs_ms, rhs_mdiv, rhs_adiv, rhs_msdiv, m_icel, a_icel, m_snowl, dm_ice, da_ice, dm_snow (after ice_fct_solve), m_ice, a_ice, m_snow
+ * (after ice_fct_solve) and (after ice_update_for_div). */
+static double *mass_matrix_fill(const fesom_mesh_desc *m) {           /* ice_mass_matrix_fill (:634-709) */
+  const int myN = m->myDim_nod2D, N = myN + m->eDim_nod2D;
+  const int r0 = m->ssh_rowptr[0];
+  double *mm = calloc((size_t)(m->ssh_rowptr[myN] - r0), sizeof(double));
+  int *col_pos = calloc(N, sizeof(int));
+  for (int el = 0; el < m->myDim_elem2D; el++) {
+    const int *en = m->elem2D_nodes + 3 * el;
+    for (int n = 0; n < 3; n++) {
+      const int row = en[n];
+      if (row > myN) continue;
+      const int off = m->ssh_rowptr[row - 1] - r0, cn = m->ssh_rowptr[row] - m->ssh_rowptr[row - 1];
+      for (int q = 0; q < cn; q++) col_pos[m->ssh_colind_loc[off + q] - 1] = q;
+      for (int q = 0; q < 3; q++) {
+        if (m->ulevels[el] > 1) continue;
+        const int ipos = off + col_pos[en[q] - 1];
+        mm[ipos] = mm[ipos] + m->elem_area[el] / 12.0;
+        if (q == n) mm[ipos] = mm[ipos] + m->elem_area[el] / 12.0;
+      }
+    }
+  }
+  free(col_pos);
+  return mm;
+}
+static double mm_row(const fesom_mesh_desc *m, const double *mm, const double *x, int row) {     /* sum(mass_matrix(clo:clo2) * x(nn_pos(1:cn, row))) */
+  const int r0 = m->ssh_rowptr[0], a = m->ssh_rowptr[row] - r0, b = m->ssh_rowptr[row + 1] - r0;
+  double s = 0.0;
+  for (int q = a; q < b; q++) s = s + mm[q] * x[m->ssh_colind_loc[q] - 1];
+  return s;
+}
+/* the three-sweep mass-matrix solve shared by ice_solve_high_order (:239-317) and ice_update_for_div (:804-892) */
+static void mm_solve3(const fesom_mesh_desc *m, const double *mm, const double *rhs[3], double *d[3], double *l[3]) {
+  const int myN = m->myDim_nod2D, nl = m->nl;
+  for (int row = 0; row < myN; row++) {
+    if (m->ulevels_nod2D[row] > 1) continue;
+    for (int t = 0; t < 3; t++) d[t][row] = rhs[t][row] / m->area[(size_t)row * nl];
+  }
+  /* (exchange_nod: single partition) */
+  for (int n = 1; n <= 2; n++) {
+    for (int row = 0; row < myN; row++) {
+      if (m->ulevels_nod2D[row] > 1) continue;
+      for (int t = 0; t < 3; t++) {
+        double rhs_new = rhs[t][row] - mm_row(m, mm, d[t], row);
+        l[t][row] = d[t][row] + rhs_new / m->area[(size_t)row * nl];
+      }
+    }
+    for (int row = 0; row < myN; row++) {
+      if (m->ulevels_nod2D[row] > 1) continue;
+      for (int t = 0; t < 3; t++) d[t][row] = l[t][row];
+    }
+  }
+}
+int orc_ice_adv(const fesom_mesh_desc *m, double ice_dt, double gamma, fesom_ice_state *s, double **dbg) {
+  const int myN = m->myDim_nod2D, N = myN + m->eDim_nod2D, myE = m->myDim_elem2D, nl = m->nl;
+  double *mm = mass_matrix_fill(m);
+  double *buf = calloc((size_t)17 * N + 3 * (size_t)myE, sizeof(double));
+  double *rhs[3] = {buf, buf + N, buf + 2 * N}, *rdiv[3] = {buf + 3 * N, buf + 4 * N, buf + 5 * N};
+  double *lo[3] = {buf + 6 * N, buf + 7 * N, buf + 8 * N}, *d[3] = {buf + 9 * N, buf + 10 * N, buf + 11 * N};
+  double *tmax = buf + 12 * N, *tmin = buf + 13 * N, *pplus = buf + 14 * N, *pminus = buf + 15 * N, *flx = buf + 17 * N;
+  double *tr[3] = {s->m_ice, s->a_ice, s->m_snow};
+  const double *u = s->u_ice, *v = s->v_ice;
+#define DBG(i, a) if (dbg && dbg[i]) memcpy(dbg[i], a, sizeof(double) * N)
+  DBG(0, u); DBG(1, v);
+  /* ice_TG_rhs_div (:713-800) */
+  for (int el = 0; el < myE; el++) {
+    const int *en = m->elem2D_nodes + 3 * el;
+    if (m->ulevels[el] > 1) continue;
+    const double *dx = m->gradient_sca + 6 * (size_t)el, *dy = dx + 3, vol = m->elem_area[el];
+    const double u3[3] = {u[en[0] - 1], u[en[1] - 1], u[en[2] - 1]}, v3[3] = {v[en[0] - 1], v[en[1] - 1], v[en[2] - 1]};
+    const double um = (u3[0] + u3[1]) + u3[2], vm = (v3[0] + v3[1]) + v3[2];
+    const double c1 = (um * um + ((u3[0] * u3[0] + u3[1] * u3[1]) + u3[2] * u3[2])) / 12.0;
+    const double c2 = (vm * vm + ((v3[0] * v3[0] + v3[1] * v3[1]) + v3[2] * v3[2])) / 12.0;
+    const double c3 = (um * vm + ((v3[0] * u3[0] + v3[1] * u3[1]) + v3[2] * u3[2])) / 12.0;
+    const double c4 = ((dx[0] * u3[0] + dy[0] * v3[0]) + (dx[1] * u3[1] + dy[1] * v3[1])) + (dx[2] * u3[2] + dy[2] * v3[2]);
+    for (int n = 0; n < 3; n++) {
+      const int row = en[n] - 1;
+      double ent[3], ent2[3];
+      for (int q = 0; q < 3; q++) {
+        ent[q] = vol * ice_dt * ((1.0 - 0.5 * ice_dt * c4) * (dx[n] * (um + u3[q]) + dy[n] * (vm + v3[q])) / 12.0 -
+                                 0.5 * ice_dt * (c1 * dx[n] * dx[q] + c2 * dy[n] * dy[q] + c3 * (dx[n] * dy[q] + dx[q] * dy[n])));
+        ent2[q] = 0.5 * ice_dt * (dx[n] * (um + u3[q]) + dy[n] * (vm + v3[q]) - dx[q] * (um + u3[n]) - dy[q] * (vm + v3[n]));
+      }
+      for (int t = 0; t < 3; t++) {
+        const double a3[3] = {tr[t][en[0] - 1], tr[t][en[1] - 1], tr[t][en[2] - 1]};
+        const double cx = vol * ice_dt * c4 * ((((a3[0] + a3[1]) + a3[2]) + a3[n]) + ((ent2[0] * a3[0] + ent2[1] * a3[1]) + ent2[2] * a3[2])) / 12.0;
+        if (row < myN) {      /* (halo rows of the reference's arrays receive partial sums that nothing reads) */
+          rhs[t][row] = (rhs[t][row] + ((ent[0] * a3[0] + ent[1] * a3[1]) + ent[2] * a3[2])) + cx;
+          rdiv[t][row] = rdiv[t][row] - cx;
+        }
+      }
+    }
+  }
+  DBG(2, rhs[0]); DBG(3, rhs[1]); DBG(4, rhs[2]); DBG(5, rdiv[0]); DBG(6, rdiv[1]); DBG(7, rdiv[2]);
+  /* ice_fct_solve (:151-169): high order, low order, FCT per tracer */
+  { const double *r3[3] = {rhs[0], rhs[1], rhs[2]}; mm_solve3(m, mm, r3, d, lo); }
+  for (int row = 0; row < myN; row++) {                                   /* ice_solve_low_order (:173-235) */
+    if (m->ulevels_nod2D[row] > 1) continue;
+    for (int t = 0; t < 3; t++)
+      lo[t][row] = (rhs[t][row] + gamma * mm_row(m, mm, tr[t], row)) / m->area[(size_t)row * nl] + (1.0 - gamma) * tr[t][row];
+  }
+  for (int t = 0; t < 3; t++) {                                           /* ice_fem_fct(t) (:321-630) */
+    for (int el = 0; el < myE; el++) {
+      const int *en = m->elem2D_nodes + 3 * el;
+      if (m->ulevels[el] > 1) continue;
+      const double vol = m->elem_area[el];
+      double w[3];
+      for (int k = 0; k < 3; k++) w[k] = gamma * tr[t][en[k] - 1] + d[t][en[k] - 1];
+      for (int q = 0; q < 3; q++) {
+        double sm = 0.0;                                                  /* sum(icoef(:,q) * w): icoef = 1, -2 on the diagonal */
+        for (int k = 0; k < 3; k++) sm = sm + (k == q ? -2.0 : 1.0) * w[k];
+        flx[3 * (size_t)el + q] = -sm * (vol / m->area[(size_t)(en[q] - 1) * nl]) / 12.0;
+      }
+    }
+    for (int row = 0; row < myN; row++) {
+      tmax[row] = 0.0; tmin[row] = 0.0;
+      if (m->ulevels_nod2D[row] > 1) continue;
+      const int r0 = m->ssh_rowptr[0], a = m->ssh_rowptr[row] - r0, b = m->ssh_rowptr[row + 1] - r0;
+      double mx = lo[t][m->ssh_colind_loc[a] - 1], mn = mx;
+      for (int q = a + 1; q < b; q++) { double x = lo[t][m->ssh_colind_loc[q] - 1]; if (x > mx) mx = x; if (x < mn) mn = x; }
+      tmax[row] = mx - lo[t][row]; tmin[row] = mn - lo[t][row];
+    }
+    for (int i = 0; i < N; i++) { pplus[i] = 0.0; pminus[i] = 0.0; }
+    for (int el = 0; el < myE; el++) {
+      const int *en = m->elem2D_nodes + 3 * el;
+      if (m->ulevels[el] > 1) continue;
+      for (int q = 0; q < 3; q++) {
+        const double f = flx[3 * (size_t)el + q];
+        if (f > 0) pplus[en[q] - 1] = pplus[en[q] - 1] + f; else pminus[en[q] - 1] = pminus[en[q] - 1] + f;
+      }
+    }
+    for (int n = 0; n < myN; n++) {
+      if (m->ulevels_nod2D[n] > 1) continue;
+      double f = pplus[n];
+      pplus[n] = fabs(f) > 0 ? fmin(1.0, tmax[n] / f) : 0.0;
+      f = pminus[n];
+      pminus[n] = fabs(f) > 0 ? fmin(1.0, tmin[n] / f) : 0.0;
+    }
+    /* (exchange_nod(icepminus, icepplus): single partition) */
+    for (int el = 0; el < myE; el++) {
+      const int *en = m->elem2D_nodes + 3 * el;
+      if (m->ulevels[el] > 1) continue;
+      double ae = 1.0;
+      for (int q = 0; q < 3; q++) {
+        const double f = flx[3 * (size_t)el + q];
+        if (f >= 0.) ae = fmin(ae, pplus[en[q] - 1]);
+        if (f < 0.) ae = fmin(ae, pminus[en[q] - 1]);
+      }
+      for (int q = 0; q < 3; q++) flx[3 * (size_t)el + q] = ae * flx[3 * (size_t)el + q];
+    }
+    for (int n = 0; n < myN; n++) { if (m->ulevels_nod2D[n] > 1) continue; tr[t][n] = lo[t][n]; }
+    for (int el = 0; el < myE; el++) {
+      const int *en = m->elem2D_nodes + 3 * el;
+      if (m->ulevels[el] > 1) continue;
+      for (int q = 0; q < 3; q++) if (en[q] <= myN) tr[t][en[q] - 1] = tr[t][en[q] - 1] + flx[3 * (size_t)el + q];
+    }
+    /* (exchange_nod(m_ice, a_ice, m_snow): single partition) */
+  }
+  DBG(8, lo[0]); DBG(9, lo[1]); DBG(10, lo[2]); DBG(11, d[0]); DBG(12, d[1]); DBG(13, d[2]); DBG(14, tr[0]); DBG(15, tr[1]); DBG(16, tr[2]);
+  /* ice_update_for_div (:804-892) */
+  { const double *r3[3] = {rdiv[0], rdiv[1], rdiv[2]}; mm_solve3(m, mm, r3, d, lo); }
+  for (int t = 0; t < 3; t++) for (int i = 0; i < N; i++) tr[t][i] = tr[t][i] + d[t][i];
+  DBG(17, tr[0]); DBG(18, tr[1]); DBG(19, tr[2]);
+  /* cut_off (src/ice_thermo_oce.F90:2-63) */
+  for (int i = 0; i < N; i++) {
+    if (s->a_ice[i] > 1.0) s->a_ice[i] = 1.0;
+    if (s->a_ice[i] < 0.1e-8) s->a_ice[i] = 0.0;
+    if (s->m_ice[i] < 0.1e-8) s->m_ice[i] = 0.0;
+  }
+#undef DBG
+  free(mm); free(buf);
+  return 0;
+}

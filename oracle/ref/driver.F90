@@ -101,13 +101,13 @@ program oracle_driver
   character(len=16) :: mode
   character(len=256) :: dump_dir
   integer :: dump_steps(64), ndump
-  logical :: dump_mesh, do_mean, debug, synth_forcing, step_info, gpu_profile
+  logical :: dump_mesh, do_mean, debug, synth_forcing, step_info, gpu_profile, ice_adv
   real(kind=WP) :: flon, flat
   integer :: fel(3)
   real(kind=WP) :: t0, t1, tloop
   character(len=64) :: tag
   namelist /clockinit/ timenew, daynew, yearnew
-  namelist /oracle/ nsteps, mode, dump_dir, dump_steps, dump_mesh, do_mean, debug, synth_forcing, step_info, gpu_profile
+  namelist /oracle/ nsteps, mode, dump_dir, dump_steps, dump_mesh, do_mean, debug, synth_forcing, step_info, gpu_profile, ice_adv
   ! running sums for the fcheck-style known answer (setups/test_souf/setup.yml:82-88)
   real(kind=WP), allocatable :: mT(:,:), mS(:,:), mU(:,:), mV(:,:)
 
@@ -136,7 +136,7 @@ program oracle_driver
   read (20,NML=oce_tra)
   read (20,NML=oce_init3d)
   close (20)
-  nsteps=1; mode='step'; dump_dir='dumps'; dump_steps=-1; dump_mesh=.false.; do_mean=.false.; debug=.false.; synth_forcing=.false.; step_info=.false.; gpu_profile=.false.
+  nsteps=1; mode='step'; dump_dir='dumps'; dump_steps=-1; dump_mesh=.false.; do_mean=.false.; debug=.false.; synth_forcing=.false.; step_info=.false.; gpu_profile=.false.; ice_adv=.false.
   open (20,file='namelist.oracle')
   read (20,NML=oracle)
   close (20)
@@ -340,6 +340,26 @@ contains
          use mod_mesh
          type(t_mesh), intent(in), target :: mesh
        end subroutine
+       subroutine ice_fct_init(mesh)
+         use mod_mesh
+         type(t_mesh), intent(in), target :: mesh
+       end subroutine
+       subroutine ice_TG_rhs_div(mesh)
+         use mod_mesh
+         type(t_mesh), intent(in), target :: mesh
+       end subroutine
+       subroutine ice_fct_solve(mesh)
+         use mod_mesh
+         type(t_mesh), intent(in), target :: mesh
+       end subroutine
+       subroutine ice_update_for_div(mesh)
+         use mod_mesh
+         type(t_mesh), intent(in), target :: mesh
+       end subroutine
+       subroutine cut_off(mesh)
+         use mod_mesh
+         type(t_mesh), intent(in), target :: mesh
+       end subroutine
     end interface
     integer :: n2, e2, i, it
     real(kind=WP) :: lon, lat, t0i, t1i
@@ -347,6 +367,11 @@ contains
     allocate(u_ice(n2), v_ice(n2), m_ice(n2), a_ice(n2), m_snow(n2), u_ice_aux(n2), v_ice_aux(n2))
     allocate(rhs_a(n2), rhs_m(n2), u_rhs_ice(n2), v_rhs_ice(n2), u_w(n2), v_w(n2), elevation(n2))
     allocate(stress_atmice_x(n2), stress_atmice_y(n2))
+    if (ice_adv) then          ! FCT advection of m_ice, a_ice, m_snow after every EVP call (the "Advection part" of ice_timestep, src/ice_setup_step.F90:213-232)
+       allocate(rhs_ms(n2), rhs_mdiv(n2), rhs_adiv(n2), rhs_msdiv(n2))
+       rhs_ms=0.0_WP; rhs_mdiv=0.0_WP; rhs_adiv=0.0_WP; rhs_msdiv=0.0_WP
+       call ice_fct_init(mesh)
+    end if
     allocate(sigma11(e2), sigma12(e2), sigma22(e2), eps11(e2), eps12(e2), eps22(e2))
     ice_dt=real(ice_ave_steps,WP)*dt
     sigma11=0.0_WP; sigma12=0.0_WP; sigma22=0.0_WP; eps11=0.0_WP; eps12=0.0_WP; eps22=0.0_WP
@@ -368,6 +393,9 @@ contains
     end do
     call dump_open(trim(dump_dir), 'ice_in', mype)
     call dump('bc_index_nod2D', mesh%bc_index_nod2D)
+    if (ice_adv) then
+       call dump('mass_matrix', mass_matrix); call dump('ice_gamma_fct', (/ ice_gamma_fct /))
+    end if
     call dump('metric_factor', mesh%metric_factor)
     call dump('coriolis_node', coriolis_node)
     call dump_ice()
@@ -376,6 +404,30 @@ contains
     t0i=MPI_Wtime()
     do it=1, nsteps
        call EVPdynamics_m(mesh)
+       if (ice_adv) then
+          if (any(dump_steps==it)) then
+             write(tag,'(A,I4.4)') 'ice_adv', it
+             call dump_open(trim(dump_dir), trim(tag), mype)
+             call dump('evp.u_ice', u_ice); call dump('evp.v_ice', v_ice)
+          end if
+          call ice_TG_rhs_div(mesh)
+          if (any(dump_steps==it)) then
+             call dump('tg.rhs_m', rhs_m); call dump('tg.rhs_a', rhs_a); call dump('tg.rhs_ms', rhs_ms)
+             call dump('tg.rhs_mdiv', rhs_mdiv); call dump('tg.rhs_adiv', rhs_adiv); call dump('tg.rhs_msdiv', rhs_msdiv)
+          end if
+          call ice_fct_solve(mesh)
+          if (any(dump_steps==it)) then
+             call dump('fct.m_icel', m_icel); call dump('fct.a_icel', a_icel); call dump('fct.m_snowl', m_snowl)
+             call dump('fct.dm_ice', dm_ice); call dump('fct.da_ice', da_ice); call dump('fct.dm_snow', dm_snow)
+             call dump('fct.m_ice', m_ice); call dump('fct.a_ice', a_ice); call dump('fct.m_snow', m_snow)
+          end if
+          call ice_update_for_div(mesh)
+          if (any(dump_steps==it)) then
+             call dump('div.m_ice', m_ice); call dump('div.a_ice', a_ice); call dump('div.m_snow', m_snow)
+          end if
+          call cut_off(mesh)
+          if (any(dump_steps==it)) call dump_close()
+       end if
        if (any(dump_steps==it)) then
           write(tag,'(A,I4.4)') 'ice_out', it
           call dump_open(trim(dump_dir), trim(tag), mype)

@@ -119,3 +119,44 @@ def test_gpu_partitioned_evp_equals_reference(built, transport):
     for rep in reps:
         assert rep["bad"] == [], rep
         assert rep["changed"] > 1e-3
+
+
+# ---- FCT advection of m_ice, a_ice, m_snow (src/ice_fct.F90: ice_TG_rhs_div, ice_fct_solve, ice_update_for_div; cut_off) --------------------
+ADV = ("evp.u_ice", "evp.v_ice", "tg.rhs_m", "tg.rhs_a", "tg.rhs_ms", "tg.rhs_mdiv", "tg.rhs_adiv", "tg.rhs_msdiv", "fct.m_icel", "fct.a_icel", "fct.m_snowl",
+       "fct.dm_ice", "fct.da_ice", "fct.dm_snow", "fct.m_ice", "fct.a_ice", "fct.m_snow", "div.m_ice", "div.a_ice", "div.m_snow")
+
+
+def gold_adv():
+    return np.load(os.path.join(REPO, "tests", "golden", "ice_adv_reference.npz"))
+
+
+def oracle_adv(mesh, par, fields, gamma, want_dbg=False):
+    import oracle_lib
+    oracle_lib.build()
+    orc = C.CDLL(oracle_lib.ORC_LIB)
+    N = mesh.myDim_nod2D + mesh.eDim_nod2D
+    dbg = [np.zeros(N) for _ in ADV]
+    arr = (C.POINTER(C.c_double) * len(ADV))(*[a.ctypes.data_as(C.POINTER(C.c_double)) for a in dbg])
+    orc.orc_ice_adv.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    assert orc.orc_ice_adv(C.cast(mesh.desc_p, C.c_void_p), C.c_double(par.ice_dt), C.c_double(gamma), C.cast(C.byref(fields.desc), C.c_void_p),
+                           C.cast(arr, C.c_void_p) if want_dbg else None) == 0
+    return dict(zip(ADV, dbg))
+
+
+def test_host_mass_matrix_and_oracle_advection_equal_reference_bitwise(built):
+    """Three ice steps (EVPdynamics_m, then the FCT advection) of the oracle against the reference's own routines on pi, one rank
+    (tests/golden/make_ice_adv_golden.py): the Taylor-Galerkin right-hand sides, the high- and low-order solutions, the limited update, the
+    divergence correction and the state after cut_off, every array bit for bit in each of the three steps."""
+    g = gold_adv()
+    mesh, par, fields = setup(g)
+    gamma = float(g["in/ice_gamma_fct"][0])
+    myN = mesh.myDim_nod2D
+    for n in (1, 2, 3):
+        oracle_evp(mesh, par, fields)
+        dbg = oracle_adv(mesh, par, fields, gamma, want_dbg=True)
+        for k in ADV:
+            assert bits(dbg[k][:myN], g[f"adv{n}/{k}"][:myN]), (n, k, float(np.abs(dbg[k][:myN] - g[f"adv{n}/{k}"][:myN]).max()))
+        for k in ("u_ice", "v_ice", "a_ice", "m_ice", "m_snow", "sigma11", "sigma12", "sigma22"):
+            assert bits(fields[k], g[f"out{n}/{k}"]), (n, k, float(np.abs(fields[k] - g[f"out{n}/{k}"]).max()))
+    assert np.abs(fields["m_ice"] - g["in/m_ice"]).max() > 0.05                  # the ice has moved
+    assert fields["a_ice"].max() <= 1.0 and fields["m_ice"].min() >= 0.0        # cut_off
