@@ -107,7 +107,7 @@ class MeshOpts(C.Structure):
 class IceParams(C.Structure):
     """fesom_ice_params (include/fesom_gpu.h)"""
     _fields_ = [(n, C.c_double) for n in ("ice_dt", "ellipse", "alpha_evp", "beta_evp", "Pstar", "c_pressure", "delta_min", "cd_oce_ice", "max_ice_loading")] + \
-               [("evp_rheol_steps", C.c_int), ("use_floatice", C.c_int)]
+               [("evp_rheol_steps", C.c_int), ("use_floatice", C.c_int), ("ice_gamma_fct", C.c_double)]
 
 
 ICE_FIELDS = ("u_ice", "v_ice", "a_ice", "m_ice", "m_snow", "elevation", "u_w", "v_w", "stress_atmice_x", "stress_atmice_y", "sigma11", "sigma12", "sigma22")
@@ -125,7 +125,7 @@ EXPORTS = ("fesom_gpu_init", "fesom_gpu_upload_state", "fesom_gpu_download_state
            "psolver_init", "psolve", "psolver_final",
            "fesom_gpu_halo_info", "fesom_gpu_halo_pack", "fesom_gpu_halo_unpack", "fesom_gpu_copy", "fesom_gpu_sync", "fesom_gpu_set_stream", "fesom_gpu_field_ptr",
            "fesom_gpu_comm_unique_id", "fesom_gpu_comm_init", "fesom_gpu_comm_finalize", "fesom_gpu_comm_selftest", "fesom_gpu_comm_timing", "fesom_gpu_comm_stats",
-           "fesom_gpu_ice_init", "fesom_gpu_ice_upload", "fesom_gpu_ice_evp", "fesom_gpu_ice_evp_partitioned", "fesom_gpu_ice_download", "fesom_gpu_ice_time_ms", "fesom_gpu_ice_finalize", "fesom_gpu_ice_last_error",
+           "fesom_gpu_ice_init", "fesom_gpu_ice_upload", "fesom_gpu_ice_evp", "fesom_gpu_ice_evp_partitioned", "fesom_gpu_ice_advect", "fesom_gpu_ice_advect_partitioned", "fesom_gpu_ice_download", "fesom_gpu_ice_time_ms", "fesom_gpu_ice_finalize", "fesom_gpu_ice_last_error",
            "fesom_mesh_load", "fesom_mesh_get_desc", "fesom_mesh_get_part", "fesom_mesh_get_initial_state",
            "fesom_mesh_free")
 

@@ -38,6 +38,12 @@ struct IceDM {
   double *ua[2], *va[2];
   double *rhs_a, *rhs_m, *invt, *mass, *pfac, *efac;
   unsigned char *ice_nod, *ice_el;
+  // FCT advection (src/ice_fct.F90): CSR pattern of the owned rows (= nn_pos / ssh_stiff, 0-based), consistent mass matrix, work arrays of 3 tracers
+  const int *rp, *ci;
+  const double *mm;
+  double *tr3;               // m_ice | a_ice | m_snow (3 N), the state arrays above are views into it
+  double *rhs, *rdiv, *lo, *dA, *dB, *pp;      // 3 N each; pp: icepplus (3 N) | icepminus (3 N)
+  double *flx;               // (3 tracers, myE, 3)
   fesom_ice_params p;
 };
 struct IceCtx {
@@ -56,6 +62,7 @@ struct IceCtx {
   const int *sptr_d = nullptr, *rptr_d = nullptr;   // device copies of the 1-based block pointers
   int nsend = 0, nrecv = 0;
   double *hsend = nullptr, *hrecv = nullptr;
+  std::vector<double> h_aice;                       // staging of a_ice for the host-side exp of the pressure factor
 } I;
 
 #define ICECHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { I.err = std::string(#x) + ": " + hipGetErrorString(e_); fprintf(stderr, "fesom_gpu_ice: %s\n", I.err.c_str()); return 1; } } while (0)
@@ -284,6 +291,188 @@ __global__ void k_ice_unpack(double *__restrict__ u, double *__restrict__ v, con
   v[list[i]] = buf[(size_t)first * 2 + cnt + (i - first)];
 }
 
+
+// ====================================================================================================================
+// FCT advection of m_ice, a_ice, m_snow: ice_TG_rhs_div, ice_fct_solve (ice_solve_high_order, ice_solve_low_order, ice_fem_fct x 3),
+// ice_update_for_div (src/ice_fct.F90) and cut_off (src/ice_thermo_oce.F90:2-63) = the "Advection part" of ice_timestep
+// (src/ice_setup_step.F90:213-232).  Thread per node / per element, the three tracers side by side (they do not depend on each other);
+// the element loops' scatter-adds are gathers over the node's elements in increasing element index, each node thread forms the
+// element terms it needs itself (same arithmetic in up to three threads); the mass-matrix sweeps ping-pong between two buffers.
+// 8 launches per step on one partition.
+// ====================================================================================================================
+__device__ __forceinline__ double ice_mm_row(const IceDM &m, const double *x, int row) {       // sum(mass_matrix(clo:clo2) * x(nn_pos(1:cn, row)))
+  double s = 0.0;
+  for (int q = m.rp[row]; q < m.rp[row + 1]; q++) s = s + m.mm[q] * x[m.ci[q]];
+  return s;
+}
+// ice_TG_rhs_div (:713-800) + the starts of ice_solve_high_order (:255-264) and ice_solve_low_order (:189-212)
+__global__ void k_ice_adv_tg(IceDM m, double gamma) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.myN) return;
+  const double dt = m.p.ice_dt;
+  const size_t N = m.N;
+  double rhs[3] = {0.0, 0.0, 0.0}, rdv[3] = {0.0, 0.0, 0.0};
+  for (int k = 0; k < m.nie_num[i]; k++) {
+    const int el = m.nie[(size_t)m.maxk * i + k];
+    const int *en = m.en + 3 * el;
+    const double *dx = m.gsca + 6 * (size_t)el, *dy = dx + 3, vol = m.elem_area[el];
+    const int n = (en[0] == i) ? 0 : ((en[1] == i) ? 1 : 2);
+    const double u3[3] = {m.u_ice[en[0]], m.u_ice[en[1]], m.u_ice[en[2]]}, v3[3] = {m.v_ice[en[0]], m.v_ice[en[1]], m.v_ice[en[2]]};
+    const double um = (u3[0] + u3[1]) + u3[2], vm = (v3[0] + v3[1]) + v3[2];
+    const double c1 = (um * um + ((u3[0] * u3[0] + u3[1] * u3[1]) + u3[2] * u3[2])) / 12.0;
+    const double c2 = (vm * vm + ((v3[0] * v3[0] + v3[1] * v3[1]) + v3[2] * v3[2])) / 12.0;
+    const double c3 = (um * vm + ((v3[0] * u3[0] + v3[1] * u3[1]) + v3[2] * u3[2])) / 12.0;
+    const double c4 = ((dx[0] * u3[0] + dy[0] * v3[0]) + (dx[1] * u3[1] + dy[1] * v3[1])) + (dx[2] * u3[2] + dy[2] * v3[2]);
+    double ent[3], ent2[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      ent[q] = vol * dt * ((1.0 - 0.5 * dt * c4) * (dx[n] * (um + u3[q]) + dy[n] * (vm + v3[q])) / 12.0 -
+                           0.5 * dt * (c1 * dx[n] * dx[q] + c2 * dy[n] * dy[q] + c3 * (dx[n] * dy[q] + dx[q] * dy[n])));
+      ent2[q] = 0.5 * dt * (dx[n] * (um + u3[q]) + dy[n] * (vm + v3[q]) - dx[q] * (um + u3[n]) - dy[q] * (vm + v3[n]));
+    }
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const double *tr = m.tr3 + t * N;
+      const double a3[3] = {tr[en[0]], tr[en[1]], tr[en[2]]};
+      const double cx = vol * dt * c4 * ((((a3[0] + a3[1]) + a3[2]) + a3[n]) + ((ent2[0] * a3[0] + ent2[1] * a3[1]) + ent2[2] * a3[2])) / 12.0;
+      rhs[t] = (rhs[t] + ((ent[0] * a3[0] + ent[1] * a3[1]) + ent[2] * a3[2])) + cx;
+      rdv[t] = rdv[t] - cx;
+    }
+  }
+  const double ar = m.area1[i];
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    const double *tr = m.tr3 + t * N;
+    m.rhs[t * N + i] = rhs[t]; m.rdiv[t * N + i] = rdv[t];
+    m.dA[t * N + i] = rhs[t] / ar;
+    m.lo[t * N + i] = (rhs[t] + gamma * ice_mm_row(m, tr, i)) / ar + (1.0 - gamma) * tr[i];
+  }
+}
+// one sweep of the mass-matrix iteration (:273-308, :840-878): dst = src + (R - M src) / area.  FIN: the last sweep of ice_update_for_div on one
+// partition, followed by m_ice = m_ice + dm_ice (:880-882) and cut_off
+template <bool FIN>
+__global__ void k_ice_adv_sweep(IceDM m, const double *__restrict__ R, const double *__restrict__ src, double *__restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.myN) return;
+  const size_t N = m.N;
+  double v[3];
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    const double rn = R[t * N + i] - ice_mm_row(m, src + t * N, i);
+    v[t] = src[t * N + i] + rn / m.area1[i];
+    dst[t * N + i] = v[t];
+  }
+  if (FIN) {
+    double mi = m.tr3[i] + v[0], ai = m.tr3[N + i] + v[1];
+    m.tr3[2 * N + i] = m.tr3[2 * N + i] + v[2];
+    if (ai > 1.0) ai = 1.0;
+    if (ai < 0.1e-8) ai = 0.0;
+    if (mi < 0.1e-8) mi = 0.0;
+    m.tr3[i] = mi; m.tr3[N + i] = ai;
+  }
+}
+// partitions: m_ice = m_ice + dm_ice on owned AND halo nodes (the increments come in by exchange), then cut_off
+__global__ void k_ice_adv_add_cut(IceDM m, const double *__restrict__ d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.N) return;
+  const size_t N = m.N;
+  double mi = m.tr3[i] + d[i], ai = m.tr3[N + i] + d[N + i];
+  m.tr3[2 * N + i] = m.tr3[2 * N + i] + d[2 * N + i];
+  if (ai > 1.0) ai = 1.0;
+  if (ai < 0.1e-8) ai = 0.0;
+  if (mi < 0.1e-8) mi = 0.0;
+  m.tr3[i] = mi; m.tr3[N + i] = ai;
+}
+// antidiffusive element fluxes of ice_fem_fct (:345-380)
+__global__ void k_ice_adv_flux(IceDM m, double gamma, const double *__restrict__ d) {
+  const int el = blockIdx.x * blockDim.x + threadIdx.x;
+  if (el >= m.myE) return;
+  const int *en = m.en + 3 * el;
+  const size_t N = m.N;
+  const double vol = m.elem_area[el];
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    const double *tr = m.tr3 + t * N;
+    double w[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) w[k] = gamma * tr[en[k]] + d[t * N + en[k]];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      double sm = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) sm = sm + (k == q ? -2.0 : 1.0) * w[k];
+      m.flx[((size_t)t * m.myE + el) * 3 + q] = -sm * (vol / m.area1[en[q]]) / 12.0;
+    }
+  }
+}
+// admissible increments and the sums of the positive / negative fluxes into a node -> limiting factors (:381-467)
+__global__ void k_ice_adv_lim(IceDM m) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.myN) return;
+  const size_t N = m.N;
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    const double *lo = m.lo + t * N;
+    double mx = lo[m.ci[m.rp[i]]], mn = mx;
+    for (int q = m.rp[i] + 1; q < m.rp[i + 1]; q++) { const double x = lo[m.ci[q]]; if (x > mx) mx = x; if (x < mn) mn = x; }
+    const double tmax = mx - lo[i], tmin = mn - lo[i];
+    double pp = 0.0, pm = 0.0;
+    for (int k = 0; k < m.nie_num[i]; k++) {
+      const int el = m.nie[(size_t)m.maxk * i + k];
+      const int *en = m.en + 3 * el;
+      const int n = (en[0] == i) ? 0 : ((en[1] == i) ? 1 : 2);
+      const double f = m.flx[((size_t)t * m.myE + el) * 3 + n];
+      if (f > 0) pp = pp + f; else pm = pm + f;
+    }
+    m.pp[t * N + i] = fabs(pp) > 0 ? fmin(1.0, tmax / pp) : 0.0;
+    m.pp[(3 + t) * N + i] = fabs(pm) > 0 ? fmin(1.0, tmin / pm) : 0.0;
+  }
+}
+// limited fluxes added to the low-order solution (:468-600) + the start of ice_update_for_div (:820-828)
+__global__ void k_ice_adv_upd(IceDM m, double *__restrict__ d0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.myN) return;
+  const size_t N = m.N;
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    double v = m.lo[t * N + i];
+    for (int k = 0; k < m.nie_num[i]; k++) {
+      const int el = m.nie[(size_t)m.maxk * i + k];
+      const int *en = m.en + 3 * el;
+      const double *f3 = m.flx + ((size_t)t * m.myE + el) * 3;
+      double ae = 1.0;
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        if (f3[q] >= 0.) ae = fmin(ae, m.pp[t * N + en[q]]);
+        if (f3[q] < 0.) ae = fmin(ae, m.pp[(3 + t) * N + en[q]]);
+      }
+      const int n = (en[0] == i) ? 0 : ((en[1] == i) ? 1 : 2);
+      v = v + ae * f3[n];
+    }
+    m.tr3[t * N + i] = v;
+    d0[t * N + i] = m.rdiv[t * N + i] / m.area1[i];
+  }
+}
+// halo messages of W node fields that lie N apart (base + f N): per neighbour the items of field 0, then of field 1, ...
+__global__ void k_ice_packw(const double *__restrict__ base, size_t N, int W, const int *__restrict__ list, const int *__restrict__ ptr, int npe, int nitems,
+                            double *__restrict__ buf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nitems) return;
+  int p = 0;
+  while (p + 1 < npe && i >= ptr[p + 1] - 1) p++;
+  const int first = ptr[p] - 1, cnt = ptr[p + 1] - ptr[p];
+  for (int f = 0; f < W; f++) buf[(size_t)first * W + (size_t)f * cnt + (i - first)] = base[f * N + list[i]];
+}
+__global__ void k_ice_unpackw(double *__restrict__ base, size_t N, int W, const int *__restrict__ list, const int *__restrict__ ptr, int npe, int nitems,
+                              const double *__restrict__ buf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nitems) return;
+  int p = 0;
+  while (p + 1 < npe && i >= ptr[p + 1] - 1) p++;
+  const int first = ptr[p] - 1, cnt = ptr[p + 1] - ptr[p];
+  for (int f = 0; f < W; f++) base[f * N + list[i]] = buf[(size_t)first * W + (size_t)f * cnt + (i - first)];
+}
+
 // one EVPdynamics_m call; the stresses start in parity I.cur; returns the parity they end in
 int enqueue_call(hipStream_t s, int par) {
   const IceDM &m = I.m;
@@ -356,9 +545,36 @@ int fesom_gpu_ice_init(const fesom_mesh_desc *d, const fesom_part_desc *part, co
       if (d->myList_edge2D[ed] > d->edge2D_in) { bnd[d->edges[2 * ed] - 1] = 1; bnd[d->edges[2 * ed + 1] - 1] = 1; }
     m.bnd = iupload(bnd);
   }
-  double **nf[] = {&m.u_ice, &m.v_ice, &m.a_ice, &m.m_ice, &m.m_snow, &m.elev, &m.u_w, &m.v_w, &m.tax, &m.tay, &m.ua[0], &m.ua[1], &m.va[0], &m.va[1],
+  double **nf[] = {&m.u_ice, &m.v_ice, &m.elev, &m.u_w, &m.v_w, &m.tax, &m.tay, &m.ua[0], &m.ua[1], &m.va[0], &m.va[1],
                    &m.rhs_a, &m.rhs_m, &m.invt, &m.mass};
   for (auto f : nf) *f = ialloc<double>(N);
+  m.tr3 = ialloc<double>(3 * N);                      // the advected fields side by side
+  if (m.tr3) { m.m_ice = m.tr3; m.a_ice = m.tr3 + N; m.m_snow = m.tr3 + 2 * N; }
+  {   // FCT advection: pattern of the owned rows (nn_pos = ssh_stiff%colind_loc: the node itself first, then its neighbours in edge order) and the
+      // consistent mass matrix assembled as ice_mass_matrix_fill does (src/ice_fct.F90:634-709: element loop, area/12 per pair, twice on the diagonal)
+    const int r0 = d->ssh_rowptr[0], nnz = d->ssh_rowptr[m.myN] - r0;
+    std::vector<int> rp(m.myN + 1), ci(nnz), col_pos(N, 0);
+    for (int i = 0; i <= m.myN; i++) rp[i] = d->ssh_rowptr[i] - r0;
+    for (int q = 0; q < nnz; q++) ci[q] = d->ssh_colind_loc[q] - 1;
+    std::vector<double> mm(nnz, 0.0);
+    for (size_t el = 0; el < E; el++) {
+      const int *en = &I.h_en[3 * el];
+      for (int n = 0; n < 3; n++) {
+        const int row = en[n];
+        if (row >= m.myN) continue;
+        for (int q = rp[row]; q < rp[row + 1]; q++) col_pos[ci[q]] = q;
+        for (int q = 0; q < 3; q++) {
+          const int ipos = col_pos[en[q]];
+          mm[ipos] = mm[ipos] + d->elem_area[el] / 12.0;
+          if (q == n) mm[ipos] = mm[ipos] + d->elem_area[el] / 12.0;
+        }
+      }
+    }
+    m.rp = iupload(rp); m.ci = iupload(ci); m.mm = iupload(mm);
+    double **wf[] = {&m.rhs, &m.rdiv, &m.lo, &m.dA, &m.dB};
+    for (auto f : wf) *f = ialloc<double>(3 * N);
+    m.pp = ialloc<double>(6 * N); m.flx = ialloc<double>(9 * E);
+  }
   m.sig[0] = ialloc<double>(3 * E); m.sig[1] = ialloc<double>(3 * E); m.pfac = ialloc<double>(E); m.efac = ialloc<double>(E);
   m.ice_nod = ialloc<unsigned char>(N); m.ice_el = ialloc<unsigned char>(E);
   for (void *p : I.allocs) if (!p) { I.err = "fesom_gpu_ice_init: device allocation failed"; return 1; }
@@ -374,7 +590,7 @@ int fesom_gpu_ice_init(const fesom_mesh_desc *d, const fesom_part_desc *part, co
     for (int q = 0; q < I.nsend; q++) sl[q] = c.slist[q] - 1;
     I.rlist = iupload(rl); I.slist = iupload(sl);
     I.sptr_d = iupload(I.sptr); I.rptr_d = iupload(I.rptr);
-    I.hsend = ialloc<double>(2 * (size_t)I.nsend); I.hrecv = ialloc<double>(2 * (size_t)I.nrecv);
+    I.hsend = ialloc<double>(6 * (size_t)I.nsend); I.hrecv = ialloc<double>(6 * (size_t)I.nrecv);     // up to 6 fields per exchange (the FCT limiting factors)
   }
   ICECHK(hipDeviceSynchronize());
   I.ready = true;
@@ -459,12 +675,100 @@ int fesom_gpu_ice_evp_partitioned(int ncalls, const fesom_transport *t) {
   ICECHK(hipGetLastError());
   return 0;
 }
+
+// exp of the pressure factor for the CURRENT a_ice (it changes with every advection step): evaluated on the host with glibc's exp like at upload,
+// the one libm call of the ice dynamics whose device version could differ in the last bit -> one small device-host-device round trip per ice step
+static int ice_refresh_efac() {
+  const IceDM &m = I.m;
+  ICECHK(hipStreamSynchronize(I.stream));
+  I.h_aice.resize(m.N);
+  ICECHK(hipMemcpy(I.h_aice.data(), m.a_ice, sizeof(double) * m.N, hipMemcpyDeviceToHost));
+  const double val3 = 1.0 / 3.0;
+  for (size_t el = 0; el < (size_t)m.myE; el++) {
+    const int *en = &I.h_en[3 * el];
+    const double asum = ((I.h_aice[en[0]] + I.h_aice[en[1]]) + I.h_aice[en[2]]) * val3;
+    I.h_efac[el] = exp(-m.p.c_pressure * (1.0 - asum));
+  }
+  ICECHK(hipMemcpy(m.efac, I.h_efac.data(), sizeof(double) * m.myE, hipMemcpyHostToDevice));
+  return 0;
+}
+static int ice_exchange(double *base, int W, const fesom_transport *t) {          // halo of W node fields N apart
+  const IceDM &m = I.m;
+  hipStream_t s = I.stream;
+  if (I.nsend > 0) hipLaunchKernelGGL(k_ice_packw, dim3((I.nsend + 255) / 256), dim3(256), 0, s, base, (size_t)m.N, W, I.slist, I.sptr_d, (int)I.sPE.size(), I.nsend, I.hsend);
+  if (t) {
+    ICECHK(hipStreamSynchronize(s));
+    if (t->exchange(t->ctx, 0, I.hsend, I.hrecv, W)) { I.err = "ice_advect_partitioned: transport exchange failed"; return 1; }
+  } else if (fesom_internal_rccl_exchange((int)I.sPE.size(), I.sPE.data(), I.sptr.data(), (int)I.rPE.size(), I.rPE.data(), I.rptr.data(), I.hsend, I.hrecv, W, s)) {
+    I.err = "ice_advect_partitioned: built-in transport failed (fesom_gpu_comm_init?)"; return 1;
+  }
+  if (I.nrecv > 0) hipLaunchKernelGGL(k_ice_unpackw, dim3((I.nrecv + 255) / 256), dim3(256), 0, s, base, (size_t)m.N, W, I.rlist, I.rptr_d, (int)I.rPE.size(), I.nrecv, I.hrecv);
+  return 0;
+}
+// ncalls x the advection part of ice_timestep (ice_TG_rhs_div, ice_fct_solve, ice_update_for_div, cut_off) on the device-resident state with the
+// current ice velocities; the pressure factor of the next EVP call follows the new concentration
+int fesom_gpu_ice_advect(int ncalls) {
+  ICE_READY();
+  if (I.npes > 1) { I.err = "fesom_gpu_ice_advect: partitioned context, call fesom_gpu_ice_advect_partitioned"; return 1; }
+  const IceDM &m = I.m;
+  hipStream_t s = I.stream;
+  const dim3 gn((m.myN + 127) / 128), ge((m.myE + 127) / 128), b(128);
+  const double gamma = m.p.ice_gamma_fct;
+  for (int c = 0; c < ncalls; c++) {
+    hipLaunchKernelGGL(k_ice_adv_tg, gn, b, 0, s, m, gamma);
+    hipLaunchKernelGGL(k_ice_adv_sweep<false>, gn, b, 0, s, m, (const double *)m.rhs, (const double *)m.dA, m.dB);
+    hipLaunchKernelGGL(k_ice_adv_sweep<false>, gn, b, 0, s, m, (const double *)m.rhs, (const double *)m.dB, m.dA);
+    hipLaunchKernelGGL(k_ice_adv_flux, ge, b, 0, s, m, gamma, (const double *)m.dA);
+    hipLaunchKernelGGL(k_ice_adv_lim, gn, b, 0, s, m);
+    hipLaunchKernelGGL(k_ice_adv_upd, gn, b, 0, s, m, m.dB);
+    hipLaunchKernelGGL(k_ice_adv_sweep<false>, gn, b, 0, s, m, (const double *)m.rdiv, (const double *)m.dB, m.dA);
+    hipLaunchKernelGGL(k_ice_adv_sweep<true>, gn, b, 0, s, m, (const double *)m.rdiv, (const double *)m.dA, m.dB);
+    if (ice_refresh_efac()) return 1;
+  }
+  ICECHK(hipGetLastError());
+  return 0;
+}
+// partitions: the exchanges of the reference (exchange_nod of the high-order increments at the start and after each sweep, of the low-order
+// solution, of the limiting factors, of the advected fields, of the divergence increments), three tracers per message
+int fesom_gpu_ice_advect_partitioned(int ncalls, const fesom_transport *t) {
+  ICE_READY();
+  if (I.npes < 2) return fesom_gpu_ice_advect(ncalls);
+  if (t && !t->exchange) { I.err = "ice_advect_partitioned: transport callback missing"; return 1; }
+  const IceDM &m = I.m;
+  hipStream_t s = I.stream;
+  const dim3 gn((m.myN + 127) / 128), ga((m.N + 127) / 128), ge((m.myE + 127) / 128), b(128);
+  const double gamma = m.p.ice_gamma_fct;
+  for (int c = 0; c < ncalls; c++) {
+    hipLaunchKernelGGL(k_ice_adv_tg, gn, b, 0, s, m, gamma);
+    if (ice_exchange(m.dA, 3, t) || ice_exchange(m.lo, 3, t)) return 1;
+    hipLaunchKernelGGL(k_ice_adv_sweep<false>, gn, b, 0, s, m, (const double *)m.rhs, (const double *)m.dA, m.dB);
+    if (ice_exchange(m.dB, 3, t)) return 1;
+    hipLaunchKernelGGL(k_ice_adv_sweep<false>, gn, b, 0, s, m, (const double *)m.rhs, (const double *)m.dB, m.dA);
+    if (ice_exchange(m.dA, 3, t)) return 1;
+    hipLaunchKernelGGL(k_ice_adv_flux, ge, b, 0, s, m, gamma, (const double *)m.dA);
+    hipLaunchKernelGGL(k_ice_adv_lim, gn, b, 0, s, m);
+    if (ice_exchange(m.pp, 6, t)) return 1;
+    hipLaunchKernelGGL(k_ice_adv_upd, gn, b, 0, s, m, m.dB);
+    if (ice_exchange(m.tr3, 3, t) || ice_exchange(m.dB, 3, t)) return 1;
+    hipLaunchKernelGGL(k_ice_adv_sweep<false>, gn, b, 0, s, m, (const double *)m.rdiv, (const double *)m.dB, m.dA);
+    if (ice_exchange(m.dA, 3, t)) return 1;
+    hipLaunchKernelGGL(k_ice_adv_sweep<false>, gn, b, 0, s, m, (const double *)m.rdiv, (const double *)m.dA, m.dB);
+    if (ice_exchange(m.dB, 3, t)) return 1;
+    hipLaunchKernelGGL(k_ice_adv_add_cut, ga, b, 0, s, m, (const double *)m.dB);
+    if (ice_refresh_efac()) return 1;
+  }
+  ICECHK(hipGetLastError());
+  return 0;
+}
 int fesom_gpu_ice_download(const fesom_ice_state *st) {
   ICE_READY();
   const IceDM &m = I.m;
   ICECHK(hipStreamSynchronize(I.stream));
   if (st->u_ice) ICECHK(hipMemcpy(st->u_ice, m.u_ice, sizeof(double) * m.N, hipMemcpyDeviceToHost));
   if (st->v_ice) ICECHK(hipMemcpy(st->v_ice, m.v_ice, sizeof(double) * m.N, hipMemcpyDeviceToHost));
+  if (st->a_ice) ICECHK(hipMemcpy(st->a_ice, m.a_ice, sizeof(double) * m.N, hipMemcpyDeviceToHost));      // (advected: fesom_gpu_ice_advect)
+  if (st->m_ice) ICECHK(hipMemcpy(st->m_ice, m.m_ice, sizeof(double) * m.N, hipMemcpyDeviceToHost));
+  if (st->m_snow) ICECHK(hipMemcpy(st->m_snow, m.m_snow, sizeof(double) * m.N, hipMemcpyDeviceToHost));
   const size_t E = m.myE;
   const double *sg = m.sig[I.cur];
   if (st->sigma11) ICECHK(hipMemcpy(st->sigma11, sg, sizeof(double) * E, hipMemcpyDeviceToHost));

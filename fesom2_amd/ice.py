@@ -1,17 +1,19 @@
-"""Host-side handle on the sea-ice mEVP rheology of libfesom_gpu.so (fesom_gpu_ice_*, include/fesom_gpu.h): the subcycled
-momentum solve EVPdynamics_m of the reference (src/ice_maEVP.F90:273-602).  No CPU fallback."""
+"""Host-side handle on the sea-ice dynamics of libfesom_gpu.so (fesom_gpu_ice_*, include/fesom_gpu.h): the subcycled
+momentum solve EVPdynamics_m of the reference (src/ice_maEVP.F90:273-602) and the FCT advection of the ice fields (src/ice_fct.F90).
+No CPU fallback."""
 import ctypes as C
 import numpy as np
 from . import _lib
 
 
 def ice_params(ice_dt=900.0, ellipse=2.0, alpha_evp=250.0, beta_evp=250.0, Pstar=30000.0, c_pressure=20.0, delta_min=1.0e-11, cd_oce_ice=5.5e-3,
-               max_ice_loading=5.0, evp_rheol_steps=120, use_floatice=False):
+               max_ice_loading=5.0, evp_rheol_steps=120, use_floatice=False, ice_gamma_fct=0.25):
     """defaults = src/ice_modules.F90:7-27 (i_PARAM) and gen_modules_config.F90:67"""
     p = _lib.IceParams()
     p.ice_dt, p.ellipse, p.alpha_evp, p.beta_evp, p.Pstar, p.c_pressure = ice_dt, ellipse, alpha_evp, beta_evp, Pstar, c_pressure
     p.delta_min, p.cd_oce_ice, p.max_ice_loading = delta_min, cd_oce_ice, max_ice_loading
     p.evp_rheol_steps, p.use_floatice = int(evp_rheol_steps), int(use_floatice)
+    p.ice_gamma_fct = ice_gamma_fct
     return p
 
 
@@ -49,6 +51,16 @@ class IceCore:
 
     def evp(self, ncalls=1):
         self._chk(self.lib.fesom_gpu_ice_evp(int(ncalls)), "ice_evp")
+
+    def advect(self, ncalls=1):
+        """FCT advection of m_ice, a_ice, m_snow with the current ice velocities (src/ice_fct.F90 + cut_off)"""
+        self.lib.fesom_gpu_ice_advect.argtypes = [C.c_int]
+        self._chk(self.lib.fesom_gpu_ice_advect(int(ncalls)), "ice_advect")
+
+    def step(self, nsteps=1):
+        """the dynamics of ice_timestep: EVPdynamics_m, then the advection part (src/ice_setup_step.F90:195-232)"""
+        for _ in range(int(nsteps)):
+            self.evp(1); self.advect(1)
 
     def download(self, fields):
         self._chk(self.lib.fesom_gpu_ice_download(C.byref(fields.desc)), "ice_download")

@@ -281,17 +281,24 @@ typedef struct fesom_ice_params {
   double max_ice_loading;    /* namelist.config &ale_def */
   int    evp_rheol_steps;
   int    use_floatice;       /* use_floatice .and. which_ALE /= 'linfs' (ice_maEVP.F90:159): ice + snow load in the sea-surface slope term */
+  double ice_gamma_fct;      /* smoothing parameter of the FCT advection (namelist.ice &ice_dyn, src/ice_modules.F90:27: 0.25) */
 } fesom_ice_params;
 typedef struct fesom_ice_state {
   double *u_ice, *v_ice;                                            /* in / out */
-  double *a_ice, *m_ice, *m_snow, *elevation, *u_w, *v_w, *stress_atmice_x, *stress_atmice_y;   /* in */
+  double *a_ice, *m_ice, *m_snow;                                   /* in; in / out of the advection */
+  double *elevation, *u_w, *v_w, *stress_atmice_x, *stress_atmice_y;   /* in */
   double *sigma11, *sigma12, *sigma22;                              /* in / out: the stresses are state across calls */
 } fesom_ice_state;
 int  fesom_gpu_ice_init(const fesom_mesh_desc *mesh, const fesom_part_desc *part, const fesom_ice_params *par);
 int  fesom_gpu_ice_upload(const fesom_ice_state *st);     /* every non-NULL field host -> device */
 int  fesom_gpu_ice_evp(int ncalls);                       /* ncalls x EVPdynamics_m on the device-resident state; asynchronous */
 int  fesom_gpu_ice_evp_partitioned(int ncalls, const fesom_transport *t);   /* npes > 1: halo of (u_ice_aux, v_ice_aux) after every subcycle (ice_maEVP.F90:588-596); t == NULL: built-in RCCL transport */
-int  fesom_gpu_ice_download(const fesom_ice_state *st);   /* u_ice, v_ice, sigma11/12/22 device -> host (synchronises) */
+/* FCT advection of m_ice, a_ice, m_snow with the current ice velocities = the "Advection part" of ice_timestep (src/ice_setup_step.F90:213-232):
+ * ice_TG_rhs_div, ice_fct_solve (ice_solve_high_order, ice_solve_low_order, ice_fem_fct x 3), ice_update_for_div (src/ice_fct.F90), cut_off
+ * (src/ice_thermo_oce.F90:2-63).  One ice step of the dynamics = fesom_gpu_ice_evp(1) + fesom_gpu_ice_advect(1). */
+int  fesom_gpu_ice_advect(int ncalls);
+int  fesom_gpu_ice_advect_partitioned(int ncalls, const fesom_transport *t);   /* npes > 1: the reference's exchange_nod calls, three tracers per message */
+int  fesom_gpu_ice_download(const fesom_ice_state *st);   /* u_ice, v_ice, a_ice, m_ice, m_snow, sigma11/12/22 device -> host (synchronises) */
 int  fesom_gpu_ice_time_ms(int ncalls, double *ms_per_call);   /* device time of a call (HIP events), state left as after the calls */
 int  fesom_gpu_ice_finalize(void);
 const char *fesom_gpu_ice_last_error(void);

@@ -22,7 +22,8 @@ def bits(a, b):
 def main():
     dist.init_process_group("gloo")
     rank = dist.get_rank()
-    g = np.load(os.path.join(REPO, "tests", "golden", "ice_evp_reference.npz"))
+    adv = os.environ.get("ICE_ADV") == "1"                    # + the FCT advection after the EVP call (tests/golden/ice_adv_reference.npz)
+    g = np.load(os.path.join(REPO, "tests", "golden", "ice_adv_reference.npz" if adv else "ice_evp_reference.npz"))
     transport = os.environ.get("PART_TRANSPORT") or None
     pc = parallel.PartitionedCore(PI, make_params(dt=900.0), dt=900.0, transport=transport)     # the partition's transport (ocean context = same com lists)
     mesh = pc.mesh
@@ -36,14 +37,17 @@ def main():
     core.lib.fesom_gpu_ice_evp_partitioned.argtypes = [C.c_int, C.c_void_p]
     tr = None if (pc.transport == "rccl") else C.byref(pc._get_transport())
     core._chk(core.lib.fesom_gpu_ice_evp_partitioned(1, tr), "ice_evp_partitioned")
+    if adv:
+        core.lib.fesom_gpu_ice_advect_partitioned.argtypes = [C.c_int, C.c_void_p]
+        core._chk(core.lib.fesom_gpu_ice_advect_partitioned(1, tr), "ice_advect_partitioned")
     core.download(fields)
     rep = {"rank": rank, "transport": pc.transport_name, "bad": []}
-    for k in ("u_ice", "v_ice", "sigma11", "sigma12", "sigma22"):
+    for k in (("u_ice", "v_ice", "a_ice", "m_ice", "m_snow") if adv else ("u_ice", "v_ice", "sigma11", "sigma12", "sigma22")):
         ref = g[f"r2/{rank}/out1/{k}"]
         ref = ref[:myE] if k.startswith("sigma") else ref[:N]
         if not bits(fields[k], ref):
             rep["bad"].append(f"{k}: max |d| {float(np.abs(fields[k] - ref).max()):.3e}")
-    rep["changed"] = float(np.abs(fields["u_ice"] - g[f"r2/{rank}/in/u_ice"]).max())
+    rep["changed"] = float(np.abs(fields["m_ice"] - g[f"r2/{rank}/in/m_ice"]).max()) * 1e2 if adv else float(np.abs(fields["u_ice"] - g[f"r2/{rank}/in/u_ice"]).max())
     core.close(); pc.close()
     sys.stdout.write("ICEREPORT " + json.dumps(rep) + chr(10)); sys.stdout.flush()
     dist.destroy_process_group()

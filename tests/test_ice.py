@@ -98,20 +98,24 @@ def test_gpu_evp_equals_oracle_and_reference_bitwise(built, floatice):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("transport", ["callback", "builtin"])
-def test_gpu_partitioned_evp_equals_reference(built, transport):
+@pytest.mark.parametrize("transport,adv", [("callback", False), ("builtin", False), ("callback", True), ("builtin", True)])
+def test_gpu_partitioned_evp_equals_reference(built, transport, adv):
     """2 ranks (the reference's dist_2 partition of pi, sharing the GPU): halo of (u_ice_aux, v_ice_aux) after every subcycle through the
     host-callback transport (gloo) or the library's built-in transport (shared-memory stand-in for librccl); every rank's u_ice, v_ice
     (owned + halo) and stresses equal the rank-local outputs of the reference's own 2-rank run bit for bit -- including the
-    reference's partition-dependent metric_factor (oce_mesh.F90:2183)."""
+    reference's partition-dependent metric_factor (oce_mesh.F90:2183).  adv: + the FCT advection of m_ice, a_ice, m_snow after the EVP call
+    (fesom_gpu_ice_advect_partitioned: the reference's exchange_nod calls, three tracers per message) against the 2-rank run of the reference's
+    own ice_fct routines (tests/golden/ice_adv_reference.npz), owned + halo nodes bit for bit."""
     import json, re, subprocess, sys
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", FESOM_GPU_DEVICE="0")
     if transport == "builtin":
         fake = os.path.join(REPO, "tests", "helpers", "libfake_rccl.so")
         assert os.path.exists(fake)
         env.update(FESOM_GPU_RCCL_LIB=fake, PART_TRANSPORT="rccl")
+    if adv:
+        env["ICE_ADV"] = "1"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(29830 + (1 if transport == "builtin" else 0)), os.path.join(REPO, "tests", "helpers", "partitioned_ice_worker.py")],
+                        "--master-port", str(29830 + (1 if transport == "builtin" else 0) + (2 if adv else 0)), os.path.join(REPO, "tests", "helpers", "partitioned_ice_worker.py")],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     reps = [json.loads(x) for x in re.findall(r"ICEREPORT (\{.*\})", r.stdout)]
@@ -160,3 +164,22 @@ def test_host_mass_matrix_and_oracle_advection_equal_reference_bitwise(built):
             assert bits(fields[k], g[f"out{n}/{k}"]), (n, k, float(np.abs(fields[k] - g[f"out{n}/{k}"]).max()))
     assert np.abs(fields["m_ice"] - g["in/m_ice"]).max() > 0.05                  # the ice has moved
     assert fields["a_ice"].max() <= 1.0 and fields["m_ice"].min() >= 0.0        # cut_off
+
+
+@pytest.mark.gpu
+def test_gpu_ice_step_equals_oracle_and_reference_bitwise(built):
+    """Three ice steps on the GPU (fesom_gpu_ice_evp + fesom_gpu_ice_advect on the device-resident state; the pressure factor follows the advected
+    concentration) against the oracle and against the reference's own run: u_ice, v_ice, stresses, m_ice, a_ice, m_snow bit for bit after every step."""
+    from fesom2_amd import ice
+    g = gold_adv()
+    mesh, par, fo = setup(g, ice_gamma_fct=float(g["in/ice_gamma_fct"][0]))
+    _, _, fg = setup(g)
+    core = ice.IceCore(mesh, par)
+    core.upload(fg)
+    for n in (1, 2, 3):
+        core.step(1); core.download(fg)
+        oracle_evp(mesh, par, fo); oracle_adv(mesh, par, fo, par.ice_gamma_fct)
+        for k in ("u_ice", "v_ice", "a_ice", "m_ice", "m_snow", "sigma11", "sigma12", "sigma22"):
+            assert bits(fg[k], fo[k]), (n, k, float(np.abs(fg[k] - fo[k]).max()))
+            assert bits(fg[k], g[f"out{n}/{k}"]), (n, k, float(np.abs(fg[k] - g[f"out{n}/{k}"]).max()))
+    core.close()
