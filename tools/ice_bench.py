@@ -33,12 +33,19 @@ def gpu(mesh, dt):
     ms = core.time_ms(10)
     core.download(st)
     assert np.isfinite(st["u_ice"]).all()
+    # whole ice steps (EVP + FCT advection incl. the host-side exp of the pressure factor): wall time over 10 steps, state finite afterwards
+    core.step(2); core.download(st)
+    t0 = time.perf_counter()
+    core.step(10); core.download(st)
+    step_ms = (time.perf_counter() - t0) * 1e3 / 10
+    assert np.isfinite(st["m_ice"]).all() and st["a_ice"].max() <= 1.0
     core.close()
     E = mesh.myDim_elem2D; N = mesh.myDim_nod2D
     # algorithmic traffic of one subcycle: stresses read + written (6 E), gradients + metric + area (8 E), velocities read + written (4 N), node data (10 N)
     by = 8.0 * (14 * E + 14 * N)
     return {"nodes": int(N), "elements": int(E), "ms_per_call": round(ms, 4), "us_per_subcycle": round(ms * 1e3 / 120, 3), "subcycles": 120,
-            "algorithmic_GBs": round(by * 120 / (ms * 1e-3) / 1e9, 1), "umax": float(np.abs(st["u_ice"]).max())}
+            "algorithmic_GBs": round(by * 120 / (ms * 1e-3) / 1e9, 1), "umax": float(np.abs(st["u_ice"]).max()),
+            "ms_per_ice_step_evp_plus_advection_wall": round(step_ms, 4), "ms_advection_wall": round(step_ms - ms, 4)}
 
 
 def main():
@@ -49,7 +56,7 @@ def main():
     out["channel_r3"] = gpu(wl.load_mesh(), wl.dt)
     try:
         from oracle.ref import run_ref
-        tried = {}
+        tried, tried_adv = {}, {}
         for ranks in (1, 8, 16):
             if ranks > (os.cpu_count() or 1):
                 continue
@@ -57,9 +64,15 @@ def main():
             tl = [l for l in lines if l.startswith("ORACLE_TIMING_ICE")]
             if rc == 0 and tl:
                 tried[ranks] = round(float(tl[0].split("s_per_call=")[1].split()[0]) * 1e3, 3)
+            rd, rc, lines = run_ref.run("pi_pp", ranks, 20, mode="ice", dump=(), ice_adv=True)
+            tl = [l for l in lines if l.startswith("ORACLE_TIMING_ICE")]
+            if rc == 0 and tl:
+                tried_adv[ranks] = round(float(tl[0].split("s_per_call=")[1].split()[0]) * 1e3, 3)
         best = min(tried, key=tried.get)
         out["cpu_reference_pi"] = {"ms_per_call_by_ranks": tried, "best_ranks": best, "ms_per_call": tried[best], "host_cores": os.cpu_count(),
-                                   "gpu_over_cpu": round(tried[best] / out["pi"]["ms_per_call"], 1)}
+                                   "gpu_over_cpu": round(tried[best] / out["pi"]["ms_per_call"], 1),
+                                   "ms_per_ice_step_evp_plus_advection_by_ranks": tried_adv,
+                                   "gpu_over_cpu_ice_step": round(min(tried_adv.values()) / out["pi"]["ms_per_ice_step_evp_plus_advection_wall"], 1) if tried_adv else None}
     except Exception as e:      # noqa: BLE001
         out["cpu_reference_pi"] = {"error": str(e)[:300]}
     print(json.dumps(out, indent=1))
