@@ -378,23 +378,43 @@ __global__ void __launch_bounds__(BLOCK) k_pp(DM m, int ncolE) {
 // ------------------------------------------------------------------------------------------------
 // momentum_adv_scalar, node part (src/oce_ale_vel_rhs.F90:154-331): vertical advection from the element
 // cluster + horizontal flux-form advection gathered over the incident edges (reference edge order).
+// The index chains (element cluster; incident edges with their triangles, level ranges and cross-edge coefficients) are read lane-parallel
+// (lane k = k-th element / edge) and broadcast with v_readlane; the field loads of MA_B elements / edges are issued as one batch before the ordered
+// sums -- no chain of dependent loads per element or edge (same arithmetic and order as the plain loops).
 __global__ void __launch_bounds__(BLOCK) k_momadv_node(DM m) {
   int n = col_id(), l = lane_id(), nz = l + 1;
   if (n >= m.myN) return;
   const int nl1 = m.nlev_n[n] - 1, ul1 = m.ulev_n[n];
+  const int nzc = nz <= m.nlm1 ? nz : m.nlm1, nzm = nzc > 1 ? nzc - 1 : 1;
+  constexpr int MA_B = 6;
   double wu = 0.0, wv = 0.0;                 // wu(nz), nz = 1..nl1+1
-  int num = m.nie_num[n];
-  for (int k = 0; k < num; k++) {
-    int el = m.nie[(size_t)m.maxk * n + k];
-    int nle = m.nlev[el] - 1, ule = m.ulev[el];
-    double ar = m.elem_area[el];
-    if (ule == 1 && nz == ule) {
-      wu = wu + DV2(m.UV, 1, ule, el) * ar;
-      wv = wv + DV2(m.UV, 2, ule, el) * ar;
+  {
+    const int num = m.nie_num[n];
+    int el_l = 0, r_l = 1;                   // range packed ule | nle << 8 ; (1, 0) = empty
+    double ar_l = 0.0;
+    if (l < num) {
+      el_l = m.nie[(size_t)m.maxk * n + l];
+      r_l = m.ulev[el_l] | ((m.nlev[el_l] - 1) << 8);
+      ar_l = m.elem_area[el_l];
     }
-    if (nz >= ule + 1 && nz <= nle) {
-      wu = wu + 0.5 * (DV2(m.UV, 1, nz, el) + DV2(m.UV, 1, nz - 1, el)) * ar;
-      wv = wv + 0.5 * (DV2(m.UV, 2, nz, el) + DV2(m.UV, 2, nz - 1, el)) * ar;
+    for (int k0 = 0; k0 < num; k0 += MA_B) {
+      double u0[MA_B], v0[MA_B], um[MA_B], vm[MA_B];
+#pragma unroll
+      for (int k = 0; k < MA_B; k++) {
+        const int el = rdlane(el_l, (k0 + k < num) ? k0 + k : 0);
+        u0[k] = DV2(m.UV, 1, nzc, el); v0[k] = DV2(m.UV, 2, nzc, el);
+        um[k] = DV2(m.UV, 1, nzm, el); vm[k] = DV2(m.UV, 2, nzm, el);
+      }
+#pragma unroll
+      for (int k = 0; k < MA_B; k++) {
+        const int kk = k0 + k;
+        if (kk < num) {
+          const int r = rdlane(r_l, kk), ule = r & 0xff, nle = r >> 8;
+          const double ar = bcast(ar_l, kk);
+          if (ule == 1 && nz == ule) { wu = wu + u0[k] * ar; wv = wv + v0[k] * ar; }
+          if (nz >= ule + 1 && nz <= nle) { wu = wu + 0.5 * (u0[k] + um[k]) * ar; wv = wv + 0.5 * (v0[k] + vm[k]) * ar; }
+        }
+      }
     }
   }
   const bool wet = (nz >= ul1 && nz <= nl1);
@@ -407,32 +427,56 @@ __global__ void __launch_bounds__(BLOCK) k_momadv_node(DM m) {
     ur = -(wu - wu_dn) / h3;
     vr = -(wv - wv_dn) / h3;
   }
-  if (nz <= m.nlm1) {
-    for (int q = m.ne_ptr[n]; q < m.ne_ptr[n + 1]; q++) {
-      int ed = m.ne_idx[q], sg = m.ne_sgn[q];
-      int el1 = m.edge_tri[2 * ed], el2 = m.edge_tri[2 * ed + 1];
-      int l1 = m.nlev[el1] - 1, u1 = m.ulev[el1];
-      double un1 = 0.0, un2 = 0.0, a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0;
-      bool act;
-      a1 = DV2(m.UV, 1, nz, el1); b1 = DV2(m.UV, 2, nz, el1);
-      if (nz >= u1 && nz <= l1) un1 = b1 * DECD(1, ed) - a1 * DECD(2, ed);
-      if (el2 >= 0) {
-        int l2 = m.nlev[el2] - 1, u2 = m.ulev[el2];
-        a2 = DV2(m.UV, 1, nz, el2); b2 = DV2(m.UV, 2, nz, el2);
-        if (nz >= u2 && nz <= l2) un2 = -b2 * DECD(3, ed) + a2 * DECD(4, ed);
-        act = (nz >= (u1 < u2 ? u1 : u2) && nz <= (l1 > l2 ? l1 : l2));
-        if (act) {
-          if (sg > 0) { ur = ur + un1 * a1 + un2 * a2; vr = vr + un1 * b1 + un2 * b2; }
-          else        { ur = ur - un1 * a1 - un2 * a2; vr = vr - un1 * b1 - un2 * b2; }
-        }
-      } else {
-        act = (nz >= u1 && nz <= l1);
-        if (act) {
-          if (sg > 0) { ur = ur + un1 * a1; vr = vr + un1 * b1; }
-          else        { ur = ur - un1 * a1; vr = vr - un1 * b1; }
+  {
+    const int q0 = m.ne_ptr[n], deg = m.ne_ptr[n + 1] - q0;
+    int sg_l = 0, e1_l = 0, e2_l = 0, r1_l = 1, r2_l = 1, has2_l = 0;
+    double x1_l = 0.0, x2_l = 0.0, x3_l = 0.0, x4_l = 0.0;
+    if (l < deg) {
+      const int ed = m.ne_idx[q0 + l];
+      sg_l = m.ne_sgn[q0 + l];
+      e1_l = m.edge_tri[2 * ed];
+      const int e2 = m.edge_tri[2 * ed + 1];
+      r1_l = m.ulev[e1_l] | ((m.nlev[e1_l] - 1) << 8);
+      has2_l = e2 >= 0;
+      e2_l = e2 >= 0 ? e2 : e1_l;
+      r2_l = e2 >= 0 ? (m.ulev[e2] | ((m.nlev[e2] - 1) << 8)) : 1;
+      x1_l = DECD(1, ed); x2_l = DECD(2, ed); x3_l = DECD(3, ed); x4_l = DECD(4, ed);
+    }
+    for (int k0 = 0; k0 < deg; k0 += MA_B) {
+      double A1[MA_B], B1[MA_B], A2[MA_B], B2[MA_B];
+#pragma unroll
+      for (int k = 0; k < MA_B; k++) {
+        const int kk = (k0 + k < deg) ? k0 + k : 0;
+        const int e1 = rdlane(e1_l, kk), e2 = rdlane(e2_l, kk);
+        A1[k] = DV2(m.UV, 1, nzc, e1); B1[k] = DV2(m.UV, 2, nzc, e1);
+        A2[k] = DV2(m.UV, 1, nzc, e2); B2[k] = DV2(m.UV, 2, nzc, e2);
+      }
+#pragma unroll
+      for (int k = 0; k < MA_B; k++) {
+        const int kk = k0 + k;
+        if (kk < deg) {
+          const int r1 = rdlane(r1_l, kk), r2 = rdlane(r2_l, kk), u1 = r1 & 0xff, l1 = r1 >> 8;
+          const bool pos = rdlane(sg_l, kk) > 0, has2 = rdlane(has2_l, kk) != 0;
+          const double a1 = A1[k], b1 = B1[k], a2 = A2[k], b2 = B2[k];
+          double un1 = 0.0, un2 = 0.0;
+          if (nz >= u1 && nz <= l1) un1 = b1 * bcast(x1_l, kk) - a1 * bcast(x2_l, kk);
+          if (has2) {
+            const int u2 = r2 & 0xff, l2 = r2 >> 8;
+            if (nz >= u2 && nz <= l2) un2 = -b2 * bcast(x3_l, kk) + a2 * bcast(x4_l, kk);
+            const bool act = (nz >= (u1 < u2 ? u1 : u2) && nz <= (l1 > l2 ? l1 : l2));
+            if (act) {
+              if (pos) { ur = ur + un1 * a1 + un2 * a2; vr = vr + un1 * b1 + un2 * b2; }
+              else     { ur = ur - un1 * a1 - un2 * a2; vr = vr - un1 * b1 - un2 * b2; }
+            }
+          } else if (nz >= u1 && nz <= l1) {
+            if (pos) { ur = ur + un1 * a1; vr = vr + un1 * b1; }
+            else     { ur = ur - un1 * a1; vr = vr - un1 * b1; }
+          }
         }
       }
     }
+  }
+  if (nz <= m.nlm1) {
     if (wet) { double ai = DA2L(m.areasvol_inv, nz, n); ur = ur * ai; vr = vr * ai; }
     DV2(m.Unode_rhs, 1, nz, n) = ur;
     DV2(m.Unode_rhs, 2, nz, n) = vr;
