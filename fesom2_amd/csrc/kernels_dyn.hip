@@ -252,6 +252,121 @@ __global__ void __launch_bounds__(BLOCK) k_pgf(DM m) {
   }
 }
 
+// The same (Shchepetkin variants) for CORE2-class meshes (DM::use_tile).  The three vertical sums of an element column are sequential in the
+// reference; in k_pgf all 64 lanes of a wave step through them for ONE element (2 DPP moves + 1 add per level and sum: what that kernel's time is
+// made of).  Here a wave takes PG_ELEMS elements: per-level terms go through a wave-private LDS image [level][element], lane = element runs the
+// chains of all its elements at once, the results go back through the image (in place).
+#define PG_ELEMS 16
+#define PG_CP (PG_ELEMS + 1)
+__global__ void __launch_bounds__(BLOCK) k_pgf_tile(DM m) {
+  extern __shared__ double pg_sh[];
+  const int w = threadIdx.x >> 6, l = lane_id(), nlz = l + 1, nl1 = m.nlm1;
+  double *imA = pg_sh + (size_t)w * 2 * nl1 * PG_CP, *imB = imA + (size_t)nl1 * PG_CP;
+  const int base = (xcd_block() * COLS_PER_BLOCK + w) * PG_ELEMS;
+  // the index chain of all PG_ELEMS elements in one round (lane k = k-th element)
+  int nle_l = 0, ule_l = 1, n0_l = 0, n1_l = 0, n2_l = 0, lv0_l = 0, lv1_l = 0, lv2_l = 0;      // lv: ulev_n | (nlev_n - 1) << 8 of the three nodes
+  double bot_l = 0.0;
+  if (l < PG_ELEMS && base + l < m.myE) {
+    const int e = base + l;
+    nle_l = m.nlev[e] - 1; ule_l = m.ulev[e]; bot_l = m.zbar_e_bot[e];
+    n0_l = m.elem_nodes[3 * e]; n1_l = m.elem_nodes[3 * e + 1]; n2_l = m.elem_nodes[3 * e + 2];
+    lv0_l = m.ulev_n[n0_l] | ((m.nlev_n[n0_l] - 1) << 8); lv1_l = m.ulev_n[n1_l] | ((m.nlev_n[n1_l] - 1) << 8); lv2_l = m.ulev_n[n2_l] | ((m.nlev_n[n2_l] - 1) << 8);
+  }
+  // A: layer thicknesses into the image
+#pragma unroll 4
+  for (int k = 0; k < PG_ELEMS; k++) {
+    const int e = __builtin_amdgcn_readfirstlane(base + k);
+    double he = 0.0;
+    if (nlz >= rdlane(ule_l, k) && nlz <= rdlane(nle_l, k)) he = UA2(m.helem, nlz, e);      // (elements beyond myE: empty range)
+    if (nlz <= nl1) imA[l * PG_CP + k] = he;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // B: lane = element: zbar_n(nlz) = zbar_e_bot + sum_{k = nle .. nlz} helem(k), bottom-up (seq_sum_down of k_pgf)
+  {
+    const int kk = l < PG_ELEMS ? l : PG_ELEMS - 1;
+    double y = bot_l;
+    for (int j = nl1 - 1; j >= 0; j--) {
+      const bool in = (j <= nle_l - 1 && j >= ule_l - 1);
+      const double x = imA[j * PG_CP + kk];
+      y = in ? y + x : y;
+      if (l < PG_ELEMS) imA[j * PG_CP + kk] = in ? y : bot_l;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // C: lane = level: density-Jacobian terms of every element of the wave
+#pragma unroll 2
+  for (int k = 0; k < PG_ELEMS; k++) {
+    const int e = __builtin_amdgcn_readfirstlane(base + k);
+    const int nle = rdlane(nle_l, k), ule = rdlane(ule_l, k);
+    const bool wet = (nlz >= ule && nlz <= nle);
+    double auxx = 0.0, auxy = 0.0;
+    const int lc = l < nl1 ? l : nl1 - 1, ln = l + 1 < nl1 ? l + 1 : nl1 - 1;
+    const double zb_top = imA[lc * PG_CP + k];
+    double zb_bot = imA[ln * PG_CP + k];
+    (void)zb_top;
+    if (wet) {
+      const double bot = bcast(bot_l, k);
+      if (nlz == nle) zb_bot = bot;
+      const double he = UA2(m.helem, nlz, e);
+      const double Zn = zb_bot + he * 0.5;
+      const int en[3] = {rdlane(n0_l, k), rdlane(n1_l, k), rdlane(n2_l, k)};
+      const int lv[3] = {rdlane(lv0_l, k), rdlane(lv1_l, k), rdlane(lv2_l, k)};
+      double drho_dz[3], rho_c[3], z_c[3];
+#pragma unroll
+      for (int ni = 0; ni < 3; ni++) {
+        const int n = en[ni];
+        int k0;
+        if (nlz == ule && (nlz - (lv[ni] & 0xff)) == 0) k0 = nlz + 1;
+        else if (nlz == nle && nlz != ule && ((lv[ni] >> 8) - nlz) == 0) k0 = nlz - 1;
+        else k0 = nlz;
+        double zm = UA2(m.Z_3d_n, k0 - 1, n), zc = UA2(m.Z_3d_n, k0, n), zp = UA2(m.Z_3d_n, k0 + 1, n);      // (node index wave-uniform: scalar column base)
+        double rm = UA2(m.density_m_rho0, k0 - 1, n), rc = UA2(m.density_m_rho0, k0, n), rp = UA2(m.density_m_rho0, k0 + 1, n);
+        double dx10 = zc - zm, dx21 = zp - zc, dx20 = zp - zm, df10 = rc - rm, df21 = rp - rc;
+        drho_dz[ni] = df10 / dx10 + (dx10 * df21 - dx21 * df10) / (dx20 * dx21 * dx10) * ((Zn - zc) + (Zn - zm));
+        rho_c[ni] = (k0 == nlz) ? rc : UA2(m.density_m_rho0, nlz, n);
+        z_c[ni] = (k0 == nlz) ? zc : UA2(m.Z_3d_n, nlz, n);
+      }
+      double s3 = (drho_dz[0] + drho_dz[1] + drho_dz[2]) / 3.0;
+      double drho_dx = DGS(1, e) * rho_c[0] + DGS(2, e) * rho_c[1] + DGS(3, e) * rho_c[2];
+      double dz_dx = DGS(1, e) * z_c[0] + DGS(2, e) * z_c[1] + DGS(3, e) * z_c[2];
+      const bool flat = m.p.which_ale == 0 && nlz != nle;
+      auxx = flat ? drho_dx * he * D_G / D_RHO0 : (drho_dx - s3 * dz_dx) * he * D_G / D_RHO0;
+      double drho_dy = DGS(4, e) * rho_c[0] + DGS(5, e) * rho_c[1] + DGS(6, e) * rho_c[2];
+      double dz_dy = DGS(4, e) * z_c[0] + DGS(5, e) * z_c[1] + DGS(6, e) * z_c[2];
+      auxy = flat ? drho_dy * he * D_G / D_RHO0 : (drho_dy - s3 * dz_dy) * he * D_G / D_RHO0;
+    }
+    if (nlz <= nl1) { imA[l * PG_CP + k] = auxx; imB[l * PG_CP + k] = auxy; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // D: lane = element: int_dp_dx top-down; the first level assigns aux, later levels add (reference order); pgf = sum before the level + aux / 2
+  {
+    const int kk = l < PG_ELEMS ? l : PG_ELEMS - 1;
+    double sx = 0.0, sy = 0.0;
+    for (int j = 0; j < nl1; j++) {
+      const int lev = j + 1;
+      const double ax = imA[j * PG_CP + kk], ay = imB[j * PG_CP + kk];
+      const bool first = lev == ule_l, in = (lev >= ule_l && lev <= nle_l);
+      const double ox = first ? ax * 0.5 : sx + ax * 0.5, oy = first ? ay * 0.5 : sy + ay * 0.5;
+      if (in) { sx = first ? ax : sx + ax; sy = first ? ay : sy + ay; }
+      if (l < PG_ELEMS) { imA[j * PG_CP + kk] = ox; imB[j * PG_CP + kk] = oy; }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // E: results out
+#pragma unroll 4
+  for (int k = 0; k < PG_ELEMS; k++) {
+    const int e = __builtin_amdgcn_readfirstlane(base + k);
+    if (nlz >= rdlane(ule_l, k) && nlz <= rdlane(nle_l, k)) { UA2(m.pgf_x, nlz, e) = imA[l * PG_CP + k]; UA2(m.pgf_y, nlz, e) = imB[l * PG_CP + k]; }
+  }
+}
+static void launch_pgf(const DM &m, hipStream_t s) {
+  const bool shch = m.p.which_pgf == 0 && !(m.p.which_ale == 0 && !m.p.use_partial_cell);
+  if (m.use_tile && shch) {
+    const int per_block = COLS_PER_BLOCK * PG_ELEMS;
+    hipLaunchKernelGGL(k_pgf_tile, dim3((m.myE + per_block - 1) / per_block), dim3(BLOCK), (size_t)COLS_PER_BLOCK * 2 * m.nlm1 * PG_CP * sizeof(double), s, m);
+  } else hipLaunchKernelGGL(k_pgf, dim3(nblocks(m.myE)), dim3(BLOCK), 0, s, m);
+}
+
 // ------------------------------------------------------------------------------------------------
 // compute_sigma_xy (:2826-2900) fused with compute_neutral_slope (:2905-2946): node gathers T,S at the
 // 3 nodes of each surrounding element.  20 N3 values.
@@ -1143,7 +1258,8 @@ __global__ void __launch_bounds__(BLOCK) k_thick(DM m, int ncolN) {
 #define LAUNCH_FLAT(k, n, ...) hipLaunchKernelGGL(k, dim3(((n) + 255) / 256), dim3(256), 0, s, __VA_ARGS__)
 
 #define IV_ATTR(id, C_, W_) (void)hipFuncSetAttribute((const void *)k_impl_visc<C_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-void tile_prepare_dyn() { TILE_SHAPES(IV_ATTR) (void)hipFuncSetAttribute((const void *)k_edge_transport_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+void tile_prepare_dyn() { TILE_SHAPES(IV_ATTR) (void)hipFuncSetAttribute((const void *)k_edge_transport_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void *)k_pgf_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
 void launch_momix(const DM &m, hipStream_t s) { if (m.p.use_momix) LAUNCH_FLAT(k_momix, m.N, m); }
 // h_viscosity_leith on one partition: vorticity, coefficient, two smoothing rounds
 void launch_leith(const DM &m, hipStream_t s) {
@@ -1153,7 +1269,7 @@ void launch_leith(const DM &m, hipStream_t s) {
 void launch_dynamics_pre(const DM &m, hipStream_t s, int first_step) {
   LAUNCH_COL(k_vel_nodes, m.myN, m);
   LAUNCH_COL(k_pressure_bv, m.N, m);
-  LAUNCH_COL(k_pgf, m.myE, m);
+  launch_pgf(m, s);
   LAUNCH_COL(k_sigma_slope, m.myN, m);
   if (m.p.mix_scheme == 2) {
     launch_momix(m, s);
@@ -1194,7 +1310,7 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
     int ncol_uv = m.myE > (m.N + BLOCK - 1) / BLOCK * COLS_PER_BLOCK ? m.myE : (m.N + BLOCK - 1) / BLOCK * COLS_PER_BLOCK;
     if (!strcmp(name, "k_vel_nodes")) { LAUNCH_COL(k_vel_nodes, m.myN, m); return 0; }
     if (!strcmp(name, "k_pressure_bv")) { LAUNCH_COL(k_pressure_bv, m.N, m); return 0; }
-    if (!strcmp(name, "k_pgf")) { LAUNCH_COL(k_pgf, m.myE, m); return 0; }
+    if (!strcmp(name, "k_pgf")) { launch_pgf(m, s); return 0; }
     if (!strcmp(name, "k_sigma_slope")) { LAUNCH_COL(k_sigma_slope, m.myN, m); return 0; }
     if (!strcmp(name, "k_pp")) { hipLaunchKernelGGL(k_pp, dim3(nblocks(m.myE) + nblocks(m.N)), dim3(BLOCK), 0, s, m, nblocks(m.myE) * COLS_PER_BLOCK); return 0; }
     if (!strcmp(name, "k_pp_elem")) { LAUNCH_COL(k_pp_elem, m.myE, m); return 0; }
@@ -1227,7 +1343,7 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
   if (!strcmp(name, "compute_vel_nodes")) { LAUNCH_COL(k_vel_nodes, m.myN, m); return 0; }
   if (!strcmp(name, "pressure_bv")) { LAUNCH_COL(k_pressure_bv, m.N, m); return 0; }       // includes sw_alpha_beta
   if (!strcmp(name, "sw_alpha_beta")) return 0;
-  if (!strcmp(name, "pressure_force")) { LAUNCH_COL(k_pgf, m.myE, m); return 0; }
+  if (!strcmp(name, "pressure_force")) { launch_pgf(m, s); return 0; }
   if (!strcmp(name, "compute_sigma_xy")) { LAUNCH_COL(k_sigma_slope, m.myN, m); return 0; } // includes neutral slope
   if (!strcmp(name, "compute_neutral_slope")) return 0;
   if (!strcmp(name, "mixing_pp")) {
