@@ -11,14 +11,14 @@ def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equati
                 K_GM_resscalorder=1.0, scaling_Ferreira=False, scaling_resolution=True, scaling_FESOM14=False, Redi=False,
                 visc_sh_limit=5.0e-3, diff_sh_limit=5.0e-3, Ricr=0.3, concv=1.6,
                 gamma0=0.003, gamma1=0.1, gamma2=0.285, easy_bs_return=1.5, C_d=0.0025, w_max_cfl=1.0, use_sw_pene=False, visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=True,
-                solver_precond=1, solver_xinv_its=0, tra_adv_lim="FCT", Leith_c=0.05, Div_c=0.5, which_pgf="shchepetkin", use_momix=False, momix_lat=-50.0, momix_kv=0.01):
+                solver_precond=1, solver_xinv_its=0, tra_adv_lim="FCT", Leith_c=0.05, Div_c=0.5, which_pgf="shchepetkin", use_momix=False, momix_lat=-50.0, momix_kv=0.01, mom_adv=2):
     p = _lib.Params()
     p.dt = dt
     p.which_ale = WHICH_ALE[which_ale]
     p.use_partial_cell = int(use_partial_cell)
     p.state_equation = state_equation
     p.num_tracers = num_tracers
-    p.mom_adv = 2
+    p.mom_adv = int(mom_adv)         # 2 scalar control volumes (default), 3 vector invariant (linfs only)
     p.visc_option = int(visc_option)
     p.i_vert_visc = 1
     p.i_vert_diff = 1

@@ -35,6 +35,7 @@ typedef struct {
   double *pgf_x, *pgf_y, *helem;                 /* (nl-1,E) */
   double *Av;                                    /* (nl,E) */
   double *dhe, *stress_surf;                     /* (E), (2,E) */
+  double *KE_node;                               /* mom_adv = 3: kinetic energy at nodes (nl-1,N) */
   double *Visc, *vorticity, *leith_aux;          /* Leith viscosity (nl-1,E), relative vorticity (nl-1,N), smoothing work array (nl-1,N) */
   /* edge */
   double *adv_flux_hor;                          /* (nl-1,D) */

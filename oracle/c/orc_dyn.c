@@ -389,7 +389,62 @@ static void momentum_adv_scalar(void) {
 }
 
 /* compute_vel_rhs: src/oce_ale_vel_rhs.F90:13-148 (no ice loading, no air pressure, no tides) */
+static void relative_vorticity(void);
+/* compute_vel_rhs_vinv (mom_adv = 3, vector-invariant form): src/oce_vel_rhs_vinv.F90:104-322.  The reference's vertical term is multiplied by
+ * w = 0 (:122, the lines that would set w are commented out), i.e. uvert = 0 and UV_rhsAB - uvert * area = UV_rhsAB: left out.  hpressure exists
+ * only with the linear free surface (pressure_bv, oce_ale_pressure_bv.F90:262): the scheme is meaningful for which_ALE = 'linfs' only. */
+static void compute_vel_rhs_vinv(void) {
+  const double eps = C_.p.epsilon, d0inv = 1. / DENSITY_0;
+  double *KE = C_.KE_node;
+  memset(KE, 0, sizeof(double) * (size_t)NLM1 * C_.N);
+  for (int e = 1; e <= C_.m.myDim_elem2D; e++)
+    for (int j = 1; j <= 3; j++)
+      for (int nz = ULEV(e); nz <= NLEV(e) - 1; nz++)
+        A2(KE, nz, EN(j, e)) = A2(KE, nz, EN(j, e)) + (V2(C_.UV, 1, nz, e) * V2(C_.UV, 1, nz, e) + V2(C_.UV, 2, nz, e) * V2(C_.UV, 2, nz, e)) * C_.m.elem_area[e - 1];
+  for (int n = 1; n <= C_.m.myDim_nod2D; n++)
+    for (int nz = ULEVN(n); nz <= NLEVN(n) - 1; nz++) A2(KE, nz, n) = A2(KE, nz, n) / (6. * AREASVOL(nz, n));
+  for (int ed = 1; ed <= C_.m.myDim_edge2D; ed++)            /* zero at lateral walls */
+    if (C_.m.myList_edge2D[ed - 1] > C_.m.edge2D_in)
+      for (int k = 1; k <= 2; k++) for (int nz = 1; nz <= NLM1; nz++) A2(KE, nz, EDG(k, ed)) = 0.0;
+  /* (exchange_nod(KE_node): single partition) */
+  for (int e = 1; e <= C_.m.myDim_elem2D; e++)
+    for (int nz = ULEV(e); nz <= NLEV(e) - 1; nz++) {
+      V2(C_.UV_rhs, 1, nz, e) = -(0.5 + eps) * V2(C_.UV_rhsAB, 1, nz, e);
+      V2(C_.UV_rhs, 2, nz, e) = -(0.5 + eps) * V2(C_.UV_rhsAB, 2, nz, e);
+    }
+  relative_vorticity();
+  for (int e = 1; e <= C_.m.myDim_elem2D; e++) {
+    const int en[3] = {EN(1, e), EN(2, e), EN(3, e)};
+    double eta[3], ff[3];
+    for (int k = 0; k < 3; k++) { eta[k] = G_ACC * C_.eta_n[en[k] - 1]; ff[k] = C_.m.coriolis_node[en[k] - 1]; }
+    const double gg = C_.m.elem_area[e - 1];
+    for (int nz = ULEV(e); nz <= NLEV(e) - 1; nz++) {
+      double pre[3];
+      for (int k = 0; k < 3; k++) pre[k] = -(eta[k] + A2L(C_.hpressure, nz, en[k]) * d0inv);
+      double Fx = (GS(1, e) * pre[0] + GS(2, e) * pre[1]) + GS(3, e) * pre[2], Fy = (GS(4, e) * pre[0] + GS(5, e) * pre[1]) + GS(6, e) * pre[2];
+      V2(C_.UV_rhs, 1, nz, e) = V2(C_.UV_rhs, 1, nz, e) + Fx * gg;
+      V2(C_.UV_rhs, 2, nz, e) = V2(C_.UV_rhs, 2, nz, e) + Fy * gg;
+      for (int k = 0; k < 3; k++) pre[k] = -A2(KE, nz, en[k]);
+      Fx = (GS(1, e) * pre[0] + GS(2, e) * pre[1]) + GS(3, e) * pre[2]; Fy = (GS(4, e) * pre[0] + GS(5, e) * pre[1]) + GS(6, e) * pre[2];
+      const double sfv = ((ff[0] + A2(C_.vorticity, nz, en[0])) + (ff[1] + A2(C_.vorticity, nz, en[1]))) + (ff[2] + A2(C_.vorticity, nz, en[2]));
+      const double da = V2(C_.UV, 2, nz, e) * sfv / 3.0, db = -V2(C_.UV, 1, nz, e) * sfv / 3.0;
+      V2(C_.UV_rhsAB, 1, nz, e) = (da + Fx) * gg;
+      V2(C_.UV_rhsAB, 2, nz, e) = (db + Fy) * gg;
+    }
+  }
+  double g2 = 1.5 + eps;
+  if (!C_.first_step_done) { g2 = 1.0; C_.first_step_done = 1; }
+  for (int e = 1; e <= C_.m.myDim_elem2D; e++) {
+    const double ai = C_.p.dt / C_.m.elem_area[e - 1];
+    for (int nz = ULEV(e); nz <= NLEV(e) - 1; nz++) {
+      V2(C_.UV_rhs, 1, nz, e) = (V2(C_.UV_rhs, 1, nz, e) + V2(C_.UV_rhsAB, 1, nz, e) * g2) * ai;
+      V2(C_.UV_rhs, 2, nz, e) = (V2(C_.UV_rhs, 2, nz, e) + V2(C_.UV_rhsAB, 2, nz, e) * g2) * ai;
+    }
+  }
+}
+
 void orc_compute_vel_rhs(void) {
+  if (C_.p.mom_adv == 3) { compute_vel_rhs_vinv(); return; }
   double eps = C_.p.epsilon;
   for (int e = 1; e <= C_.m.myDim_elem2D; e++) {
     int nzmax = NLEV(e), nzmin = ULEV(e);

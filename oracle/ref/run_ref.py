@@ -80,7 +80,7 @@ which_pgf='{which_pgf}'
 easy_bs_return=1.5
 A_ver=1.e-4
 scale_area=5.8e9
-mom_adv=2
+mom_adv={mom_adv}
 free_slip=.false.
 i_vert_visc=.true.
 w_split={w_split}
@@ -211,6 +211,11 @@ CFGS = {
                         rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                         fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
                         balance_salt_water=".true.", synth_forcing=True, use_momix=".true."),
+    # mom_adv = 3: compute_vel_rhs_vinv (src/oce_vel_rhs_vinv.F90:104-322), linear free surface with full cells (hpressure exists only there)
+    "pi_pp_linfs_vinv": dict(mesh="pi", step_per_day=96, which_ale="linfs", use_partial_cell=".false.", cyclic_length=360,
+                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                        fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                        balance_salt_water=".true.", synth_forcing=True, mom_adv=3),
     # which_pgf = 'cubicspline': pressure_force_4_zxxxx_cubicspline (src/oce_ale_pressure_bv.F90:1697-1866)
     "pi_pp_cubicspline": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
                         rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
@@ -335,7 +340,7 @@ def prepare(cfg, np_, tag=""):
             partition_io.write_dist(cp, np_)
         meshdir = cp
     open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **dict(dict(use_sw_pene=".false."), **c)))
-    open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0", visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=".true.", tra_adv_lim="FCT", use_momix=".false.", which_pgf="shchepetkin"), **c)))
+    open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0", visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=".true.", tra_adv_lim="FCT", use_momix=".false.", which_pgf="shchepetkin", mom_adv=2), **c)))
     if c["toy_ocean"] == ".false.":
         from fesom2_amd.synthetic import write_ic_files
         write_ic_files(meshdir, rd)

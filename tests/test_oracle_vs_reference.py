@@ -258,6 +258,29 @@ def test_oracle_chain_bitwise_monin_obukhov_mixing(built, cfg, kw):
     assert not np.array_equal(g["s2/mixing.Kv"], g0["s2/mixing.Kv"]) and not np.array_equal(g["s2/mixing.Av"], g0["s2/mixing.Av"])
 
 
+def test_oracle_chain_bitwise_vector_invariant_momentum(built):
+    """mom_adv = 3 (compute_vel_rhs_vinv, src/oce_vel_rhs_vinv.F90:104-322: kinetic energy at nodes, relative vorticity, gradient of the Bernoulli function) with
+    the linear free surface and full cells, the only set-up in which the reference forms hpressure: reference run `pi_pp_linfs_vinv`, every routine of 3 steps
+    bit for bit."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.synthetic import analytic_ts
+    from oracle_lib import Oracle
+    from ref_chain import run_reference_chain
+    mesh = Mesh.load(PI, dt=900.0, which_ale="linfs", use_partial_cell=False)
+    par = make_params(dt=900.0, which_ale="linfs", use_partial_cell=False, mom_adv=3)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    orc = Oracle(mesh, par)
+    orc.set_state(st)
+    g = gold("pi_pp_linfs_vinv")
+    for f in FORCING:
+        orc.set(f, g["forcing/" + f])
+    bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
+    assert not bad, "\n".join(bad[:20])
+
+
 def test_oracle_chain_bitwise_cubicspline_pgf(built):
     """which_pgf = 'cubicspline' (pressure_force_4_zxxxx_cubicspline, src/oce_ale_pressure_bv.F90:1697-1866): reference run `pi_pp_cubicspline`, every
     routine of 3 steps bit for bit."""
