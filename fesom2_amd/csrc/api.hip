@@ -231,12 +231,14 @@ struct Dag {
   void dep(hipStream_t to, hipStream_t from) { hipEvent_t e = ev(); hipEventRecord(e, from); hipStreamWaitEvent(to, e, 0); }
   ~Dag() { for (auto e : evs) hipEventDestroy(e); }
 };
+static std::string g_bad_launch;
 static int g_exp_skip_side = -1, g_exp_step = 0;     // timing experiment (FESOM_GPU_EXP_SKIP_SIDE=<step>): from that step on only the critical chain is launched
 int K(hipStream_t s, const char *k, int arg = 0, int fs = 0) {
   if (g_exp_skip_side >= 0 && g_exp_step >= g_exp_skip_side && s != G.stream) return 0;
   int rc = launch_named_dyn(G.m, s, k, arg, fs);
   if (rc < 0) rc = launch_named_tra(G.m, s, k, arg);
   if (rc < 0) rc = launch_named_kpp(G.m, s, k);
+  if (rc != 0 && g_bad_launch.empty()) g_bad_launch = k;          // a phase of the step that no launcher knows: the step must not pass for done
   return rc;
 }
 void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
@@ -252,9 +254,12 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   K(s1, "k_pressure_bv");
   hipEvent_t ev_pb = d.ev(); hipEventRecord(ev_pb, s1);
   K(s1, "k_pgf");
-  K(s2, "k_momadv_node");
-  d.dep(s1, s2);
-  K(s1, "k_vel_rhs", 0, first_step);
+  if (m.p.mom_adv == 3) K(s1, "k_vel_rhs_step", 0, first_step);      // k_vinv_ke, k_leith_vort, k_vinv_elem
+  else {
+    K(s2, "k_momadv_node");
+    d.dep(s1, s2);
+    K(s1, "k_vel_rhs", 0, first_step);
+  }
   hipEvent_t ev_rhs = d.ev(); hipEventRecord(ev_rhs, s1);
   if (m.p.which_ale != 0) K(s1, "k_stiff_update");
   launch_row_scale(m, s1);
@@ -366,7 +371,8 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { G.err = "no HIP device: the MI355X path has no CPU fallback"; fprintf(stderr, "fesom_gpu: %s\n", G.err.c_str()); return 2; }
   if (d->nl > 64) { G.err = "fesom_gpu_init: nl > 64 levels not supported by the one-wave-per-column kernels"; return 3; }
   if (par->which_ale != 0 && par->which_ale != 2) { G.err = "fesom_gpu_init: which_ale must be linfs(0) or zstar(2)"; return 3; }
-  if (par->mom_adv != 2 || par->visc_option < 1 || par->visc_option > 7) { G.err = "fesom_gpu_init: only mom_adv=2, visc_option=1..7 are implemented"; return 3; }
+  if ((par->mom_adv != 2 && par->mom_adv != 3) || par->visc_option < 1 || par->visc_option > 7) { G.err = "fesom_gpu_init: only mom_adv=2 or 3, visc_option=1..7 are implemented"; return 3; }
+  if (par->mom_adv == 3 && par->which_ale != 0) { G.err = "fesom_gpu_init: mom_adv=3 (vector-invariant momentum) needs which_ALE='linfs': it reads hpressure, which the reference forms only there (oce_ale_pressure_bv.F90:262)"; return 3; }
   if (par->which_pgf != 0 && !(par->which_pgf == 1 && par->which_ale == 2) && !(par->which_ale == 0 && !par->use_partial_cell)) {
     G.err = "fesom_gpu_init: which_pgf must be 'shchepetkin' (0) or, with zstar, 'cubicspline' (1); the nemo / easypgf / sergey pressure gradient schemes and cubicspline with linfs are not implemented"; return 3;
   }
@@ -536,7 +542,15 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   F(pgf_x, n1 * E); F(pgf_y, n1 * E); F(helem, n1 * E); F(Av, nl * E); F(dhe, E);
   FT(adv_flux_hor, n1 * D); FT(adv_flux_raw, n1 * D); FT(flux_lo_hor, n1 * D); FT(diff_flux, n1 * D); FT(edge_up_dn_grad, 4 * n1 * D); F(edge_c12, D);
   F(ssh_values, m.nza);
-  if (par->visc_option <= 3) { F(Visc, n1 * E); F(vorticity, n1 * N); F(leith_aux, n1 * N); }
+  if (par->visc_option <= 3) { F(Visc, n1 * E); F(leith_aux, n1 * N); }
+  if (par->visc_option <= 3 || par->mom_adv == 3) F(vorticity, n1 * N);
+  if (par->mom_adv == 3) {
+    F(KE_node, n1 * N);
+    std::vector<unsigned char> wall(N, 0);
+    for (int e = 0; e < m.myD; e++) if (d->myList_edge2D[e] > d->edge2D_in) { wall[ed[2 * e]] = 1; wall[ed[2 * e + 1]] = 1; }
+    m.wall_node = dev_upload(wall);
+    if (!m.coriolis_node) m.coriolis_node = dev_upload_d(d->coriolis_node, N);
+  }
   if (par->use_momix) {       // where mo_convect applies the Monin-Obukhov mixing (oce_mo_conv.F90:28-31, :95); rad = pi/180 with the reference's pi (oce_modules.F90:11-12)
     F(mixlength, N);
     const double rad = 3.14159265358979 / 180.0, lim = par->momix_lat * rad;
@@ -878,8 +892,8 @@ int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
     S.c("k_kpp_elem");
   }
   S.Wt();
-  S.c("k_momadv_node"); S.X(0, {"Unode_rhs"});
-  S.c("k_vel_rhs");
+  if (p.mom_adv == 3) { S.c("k_vinv_ke"); S.X(0, {"KE_node"}); S.c("k_leith_vort"); S.X(0, {"vorticity"}); S.c("k_vinv_elem"); }
+  else { S.c("k_momadv_node"); S.X(0, {"Unode_rhs"}); S.c("k_vel_rhs"); }
   if (p.visc_option <= 3) {    // h_viscosity_leith with its exchange_nod(vorticity), 2 x exchange_nod(aux), exchange_elem(Visc)
     S.c("k_leith_vort"); S.X(0, {"vorticity"}); S.c("k_leith_elem");
     for (int nt = 0; nt < 2; nt++) { S.c("k_leith_node"); S.X(0, {"leith_aux"}); S.c("k_leith_avg"); }
@@ -1116,6 +1130,7 @@ int fesom_gpu_run_steps(int n_first, int nsteps) {
     } else enqueue_step(G.stream, which, n);
     G.first_step = 0;
   }
+  if (!g_bad_launch.empty()) { G.err = "fesom_gpu_run_steps: the step names a kernel no launcher knows: " + g_bad_launch; fprintf(stderr, "fesom_gpu: %s\n", G.err.c_str()); return 1; }
   if (timing) {
     double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     fprintf(stderr, "[fesom_gpu] host enqueue: %d steps in %.1f us (%.1f us/step)\n", nsteps, us, us / (nsteps ? nsteps : 1));

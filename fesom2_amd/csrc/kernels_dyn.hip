@@ -598,6 +598,46 @@ __global__ void __launch_bounds__(BLOCK) k_momadv_node(DM m) {
   }
 }
 
+// mom_adv = 3, compute_vel_rhs_vinv (src/oce_vel_rhs_vinv.F90:104-322; linear free surface only: hpressure): kinetic energy at nodes (:128-166),
+// then (after relative_vorticity = k_leith_vort) the element part: old AB term, gradient of g eta + p/rho0, (f + zeta) k x u, gradient of the
+// kinetic energy, AB2 update.  The reference's vertical term is multiplied by w = 0 (:122): nothing to add.
+__global__ void __launch_bounds__(BLOCK) k_vinv_ke(DM m) {
+  const int n = col_id(), nz = lane_id() + 1;
+  if (n >= m.myN || nz > m.nlm1) return;
+  double ke = 0.0;
+  const int num = m.nie_num[n];
+  for (int k = 0; k < num; k++) {
+    const int el = m.nie[(size_t)m.maxk * n + k];
+    if (nz < m.ulev[el] || nz > m.nlev[el] - 1) continue;
+    const double u = DV2(m.UV, 1, nz, el), v = DV2(m.UV, 2, nz, el);
+    ke = ke + (u * u + v * v) * m.elem_area[el];
+  }
+  if (nz >= m.ulev_n[n] && nz <= m.nlev_n[n] - 1) ke = ke / (6. * DA2L(m.areasvol, nz, n));
+  if (m.wall_node[n]) ke = 0.0;
+  DA2(m.KE_node, nz, n) = ke;
+}
+__global__ void __launch_bounds__(BLOCK) k_vinv_elem(DM m, int first_step) {
+  const int e = col_id(), nz = lane_id() + 1;
+  if (e >= m.myE) return;
+  if (nz < m.ulev[e] || nz > m.nlev[e] - 1) return;
+  const int n0 = m.elem_nodes[3 * e], n1 = m.elem_nodes[3 * e + 1], n2 = m.elem_nodes[3 * e + 2];
+  const double eps = m.p.epsilon, d0inv = 1. / D_RHO0, gg = m.elem_area[e];
+  double r1 = -(0.5 + eps) * DV2(m.UV_rhsAB, 1, nz, e), r2 = -(0.5 + eps) * DV2(m.UV_rhsAB, 2, nz, e);
+  double p0 = -(D_G * m.eta_n[n0] + DA2L(m.hpressure, nz, n0) * d0inv), p1 = -(D_G * m.eta_n[n1] + DA2L(m.hpressure, nz, n1) * d0inv),
+         p2 = -(D_G * m.eta_n[n2] + DA2L(m.hpressure, nz, n2) * d0inv);
+  double Fx = (DGS(1, e) * p0 + DGS(2, e) * p1) + DGS(3, e) * p2, Fy = (DGS(4, e) * p0 + DGS(5, e) * p1) + DGS(6, e) * p2;
+  r1 = r1 + Fx * gg; r2 = r2 + Fy * gg;
+  p0 = -DA2(m.KE_node, nz, n0); p1 = -DA2(m.KE_node, nz, n1); p2 = -DA2(m.KE_node, nz, n2);
+  Fx = (DGS(1, e) * p0 + DGS(2, e) * p1) + DGS(3, e) * p2; Fy = (DGS(4, e) * p0 + DGS(5, e) * p1) + DGS(6, e) * p2;
+  const double sfv = ((m.coriolis_node[n0] + DA2(m.vorticity, nz, n0)) + (m.coriolis_node[n1] + DA2(m.vorticity, nz, n1))) + (m.coriolis_node[n2] + DA2(m.vorticity, nz, n2));
+  const double da = DV2(m.UV, 2, nz, e) * sfv / 3.0, db = -DV2(m.UV, 1, nz, e) * sfv / 3.0;
+  const double ab1 = (da + Fx) * gg, ab2 = (db + Fy) * gg;
+  DV2(m.UV_rhsAB, 1, nz, e) = ab1; DV2(m.UV_rhsAB, 2, nz, e) = ab2;
+  const double g2 = first_step ? 1.0 : (1.5 + eps), ai = m.p.dt / gg;
+  DV2(m.UV_rhs, 1, nz, e) = (r1 + ab1 * g2) * ai;
+  DV2(m.UV_rhs, 2, nz, e) = (r2 + ab2 * g2) * ai;
+}
+
 // compute_vel_rhs (src/oce_ale_vel_rhs.F90:13-148) incl. the element part of momentum_adv_scalar (:333-343):
 // one streaming pass per element column.  16 E3 values.
 __global__ void __launch_bounds__(BLOCK) k_vel_rhs(DM m, int first_step) {
@@ -1260,6 +1300,11 @@ __global__ void __launch_bounds__(BLOCK) k_thick(DM m, int ncolN) {
 #define IV_ATTR(id, C_, W_) (void)hipFuncSetAttribute((const void *)k_impl_visc<C_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 void tile_prepare_dyn() { TILE_SHAPES(IV_ATTR) (void)hipFuncSetAttribute((const void *)k_edge_transport_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void *)k_pgf_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+// compute_vel_rhs (mom_adv = 2) / compute_vel_rhs_vinv (mom_adv = 3) on one partition
+static void launch_vel_rhs(const DM &m, hipStream_t s, int first_step) {
+  if (m.p.mom_adv == 3) { LAUNCH_COL(k_vinv_ke, m.myN, m); LAUNCH_COL(k_leith_vort, m.myN, m); LAUNCH_COL(k_vinv_elem, m.myE, m, first_step); }
+  else { LAUNCH_COL(k_momadv_node, m.myN, m); LAUNCH_COL(k_vel_rhs, m.myE, m, first_step); }
+}
 void launch_momix(const DM &m, hipStream_t s) { if (m.p.use_momix) LAUNCH_FLAT(k_momix, m.N, m); }
 // h_viscosity_leith on one partition: vorticity, coefficient, two smoothing rounds
 void launch_leith(const DM &m, hipStream_t s) {
@@ -1276,8 +1321,7 @@ void launch_dynamics_pre(const DM &m, hipStream_t s, int first_step) {
     hipLaunchKernelGGL(k_pp, dim3(nblocks(m.myE) + nblocks(m.N)), dim3(BLOCK), 0, s, m, nblocks(m.myE) * COLS_PER_BLOCK);
   }
   if (m.p.mix_scheme == 1) launch_named_kpp(m, s, "mixing_kpp");      // (launches k_momix itself)
-  LAUNCH_COL(k_momadv_node, m.myN, m);
-  LAUNCH_COL(k_vel_rhs, m.myE, m, first_step);
+  launch_vel_rhs(m, s, first_step);
   if (m.p.visc_option <= 3) launch_leith(m, s);
   if (m.p.visc_option != 1) LAUNCH_COL(k_visc_elem, m.E, m);
   if (m.p.visc_option == 5) LAUNCH_COL(k_visc_node, m.myN, m);
@@ -1317,6 +1361,9 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
     if (!strcmp(name, "k_pp_node_final")) { LAUNCH_COL(k_pp_node_final, m.N, m); return 0; }
     if (!strcmp(name, "k_momadv_node")) { LAUNCH_COL(k_momadv_node, m.myN, m); return 0; }
     if (!strcmp(name, "k_vel_rhs")) { LAUNCH_COL(k_vel_rhs, m.myE, m, first_step); return 0; }
+    if (!strcmp(name, "k_vinv_ke")) { LAUNCH_COL(k_vinv_ke, m.myN, m); return 0; }
+    if (!strcmp(name, "k_vinv_elem")) { LAUNCH_COL(k_vinv_elem, m.myE, m, first_step); return 0; }
+    if (!strcmp(name, "k_vel_rhs_step")) { launch_vel_rhs(m, s, first_step); return 0; }
     if (!strcmp(name, "k_momix")) { if (m.p.use_momix) LAUNCH_FLAT(k_momix, m.N, m); return 0; }
     if (!strcmp(name, "k_visc_elem")) { LAUNCH_COL(k_visc_elem, m.E, m); return 0; }
     if (!strcmp(name, "k_leith_vort")) { LAUNCH_COL(k_leith_vort, m.myN, m); return 0; }
@@ -1351,7 +1398,7 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
     hipLaunchKernelGGL(k_pp, dim3(nblocks(m.myE) + nblocks(m.N)), dim3(BLOCK), 0, s, m, nblocks(m.myE) * COLS_PER_BLOCK); return 0;
   }
   if (!strcmp(name, "mo_convect")) return 0;                                                  // fused into mixing_pp
-  if (!strcmp(name, "compute_vel_rhs")) { LAUNCH_COL(k_momadv_node, m.myN, m); LAUNCH_COL(k_vel_rhs, m.myE, m, first_step); return 0; }
+  if (!strcmp(name, "compute_vel_rhs")) { launch_vel_rhs(m, s, first_step); return 0; }
   if (!strcmp(name, "visc_filt_bcksct") || !strcmp(name, "viscosity_filter")) {      // viscosity_filter(visc_option): 1 .. 7
     if (m.p.visc_option <= 3) launch_leith(m, s);
     if (m.p.visc_option != 1) LAUNCH_COL(k_visc_elem, m.E, m);

@@ -58,8 +58,11 @@ def run_step(core, par, X, solve, first, probe=None, n=1, zonal=None):
         c("k_kpp_smooth3")
         c("k_kpp_final"); X(NOD, ["kpp_viscA", "Kv"])
         c("k_kpp_elem"); P("mixing")
-    c("k_momadv_node"); X(NOD, ["Unode_rhs"])
-    c("k_vel_rhs"); P("vel_rhs")
+    if p.mom_adv == 3:
+        c("k_vinv_ke"); X(NOD, ["KE_node"]); c("k_leith_vort"); X(NOD, ["vorticity"]); c("k_vinv_elem"); P("vel_rhs")
+    else:
+        c("k_momadv_node"); X(NOD, ["Unode_rhs"])
+        c("k_vel_rhs"); P("vel_rhs")
     if p.visc_option <= 3:
         c("k_leith_vort"); X(NOD, ["vorticity"]); c("k_leith_elem")
         for _ in range(2):
