@@ -146,13 +146,14 @@ __global__ void __launch_bounds__(BLOCK) k_pressure_bv(DM m) {
 
 // pressure_force_4_zxxxx_cubicspline (src/oce_ale_pressure_bv.F90:1697-1866): density of one node interpolated to the depth Zn with the
 // monotonised cubic spline of the four levels around it (surface / bottom / bulk cases :1757-1803)
+template <bool LINFS_BOTTOM>          // pressure_force_4_linfs_cubicspline (:1365-1413) always takes the bottom-case stencil
 __device__ __forceinline__ double pgf_cubic_rho(const DM &m, int node, double Zn) {
   const int nln = m.nlev_n[node] - 1, uln = m.ulev_n[node];
   int nlc = nln - 1;
   for (int dd = uln; dd <= nln; dd++)
     if (DA2(m.Z_3d_n, dd, node) <= Zn) { nlc = dd - 1; if (dd == 1) nlc = 1; break; }
   int i0 = nlc - 1, i3 = nlc + 2;
-  const bool surf = nlc == uln, bot = !surf && nlc == nln - 1;
+  const bool surf = !LINFS_BOTTOM && nlc == uln, bot = LINFS_BOTTOM || (!surf && nlc == nln - 1);
   if (surf) i0 = uln;
   if (bot) i3 = nlc + 1;
   const double z0 = DA2(m.Z_3d_n, i0, node), z1 = DA2(m.Z_3d_n, nlc, node), z2 = DA2(m.Z_3d_n, nlc + 1, node), z3 = DA2(m.Z_3d_n, i3, node);
@@ -211,8 +212,14 @@ __global__ void __launch_bounds__(BLOCK) k_pgf(DM m) {
   if (nlz == nle) zb_bot = m.zbar_e_bot[e];
   double Zn = zb_bot + he * 0.5;                                         // Z_n(nlz)
   double auxx = 0.0, auxy = 0.0;
-  if (wet && m.p.which_pgf == 1) {                         // 'cubicspline'
-    const double r0 = pgf_cubic_rho(m, n0, Zn), r1 = pgf_cubic_rho(m, n1, Zn), r2 = pgf_cubic_rho(m, n2, Zn);
+  if (wet && m.p.which_pgf == 1 && m.p.which_ale == 0) {   // 'cubicspline', linfs with partial cells (:1252-1444): flat layers, spline in the bottom layer
+    double r0, r1, r2;
+    if (nlz == nle && nle > ule) { r0 = pgf_cubic_rho<true>(m, n0, Zn); r1 = pgf_cubic_rho<true>(m, n1, Zn); r2 = pgf_cubic_rho<true>(m, n2, Zn); }
+    else { r0 = DA2(m.density_m_rho0, nlz, n0); r1 = DA2(m.density_m_rho0, nlz, n1); r2 = DA2(m.density_m_rho0, nlz, n2); }
+    const double gx = (DGS(1, e) * r0 + DGS(2, e) * r1) + DGS(3, e) * r2, gy = (DGS(4, e) * r0 + DGS(5, e) * r1) + DGS(6, e) * r2;
+    auxx = gx * he * D_G / D_RHO0; auxy = gy * he * D_G / D_RHO0;
+  } else if (wet && m.p.which_pgf == 1) {                  // 'cubicspline', zstar (:1697-1866)
+    const double r0 = pgf_cubic_rho<false>(m, n0, Zn), r1 = pgf_cubic_rho<false>(m, n1, Zn), r2 = pgf_cubic_rho<false>(m, n2, Zn);
     const double gx = (DGS(1, e) * r0 + DGS(2, e) * r1) + DGS(3, e) * r2, gy = (DGS(4, e) * r0 + DGS(5, e) * r1) + DGS(6, e) * r2;
     auxx = D_G * he * gx / D_RHO0; auxy = D_G * he * gy / D_RHO0;
   } else if (wet) {

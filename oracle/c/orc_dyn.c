@@ -180,9 +180,57 @@ static void pgf_zxxxx_cubicspline(void) {
   free(zbar_n); free(Z_n);
 }
 
+/* pressure_force_4_linfs_cubicspline: src/oce_ale_pressure_bv.F90:1252-1444 (linfs with partial cells, which_pgf = 'cubicspline': flat layers, the
+ * densities of the bottom layer interpolated to the element's mid-depth with the bottom-case spline) */
+static void pgf_linfs_cubicspline(void) {
+  int nl = NL;
+  double *zbar_n = calloc(nl + 2, sizeof(double)), *Z_n = calloc(nl + 2, sizeof(double));
+  for (int e = 1; e <= C_.m.myDim_elem2D; e++) {
+    int nle = NLEV(e) - 1, ule = ULEV(e);
+    int en[3] = {EN(1, e), EN(2, e), EN(3, e)};
+    for (int k = 0; k <= nl; k++) { zbar_n[k] = 0.0; Z_n[k] = 0.0; }
+    zbar_n[nle + 1] = C_.m.zbar_e_bot[e - 1];
+    Z_n[nle] = zbar_n[nle + 1] + A2(C_.helem, nle, e) / 2.0;
+    for (int nlz = nle; nlz >= 2; nlz--) {
+      zbar_n[nlz] = zbar_n[nlz + 1] + A2(C_.helem, nlz, e);
+      Z_n[nlz - 1] = zbar_n[nlz] + A2(C_.helem, nlz - 1, e) / 2.0;
+    }
+    zbar_n[1] = zbar_n[2] + A2(C_.helem, 1, e);
+    double ip[2] = {0.0, 0.0};
+    for (int nlz = ule; nlz <= nle; nlz++) {
+      double r3[3];
+      if (nlz < nle || nle == ule) for (int ni = 0; ni < 3; ni++) r3[ni] = A2(C_.density_m_rho0, nlz, en[ni]);
+      if (nlz == nle && nle > ule)
+        for (int ni = 0; ni < 3; ni++) {
+          int node = en[ni], nln = NLEVN(node) - 1, uln = ULEVN(node);
+          int nlc = nln - 1;
+          for (int dd = uln; dd <= nln; dd++)
+            if (A2(C_.Z_3d_n, dd, node) <= Z_n[nlz]) { nlc = dd - 1; if (dd == 1) nlc = 1; break; }
+          const int si[4] = {nlc - 1, nlc, nlc + 1, nlc + 1};
+          double s_z[4], s_d[4];
+          for (int k = 0; k < 4; k++) { s_z[k] = A2(C_.Z_3d_n, si[k], node); s_d[k] = A2(C_.density_m_rho0, si[k], node); }
+          double s_H = s_z[2] - s_z[1], aux1 = (s_d[2] - s_d[1]) / s_H, aux2 = (s_d[1] - s_d[0]) / (s_z[1] - s_z[0]);
+          double s_dup = 0.0;
+          if (aux1 * aux2 > 0.) s_dup = 2.0 * aux1 * aux2 / (aux1 + aux2);
+          double s_dlo = 1.5 * aux1 - 0.5 * s_dup;
+          double c = -(2.0 * s_dup + s_dlo) / s_H + 3.0 * (s_d[2] - s_d[1]) / (s_H * s_H);
+          double d = (s_dup + s_dlo) / (s_H * s_H) - 2.0 * (s_d[2] - s_d[1]) / ((s_H * s_H) * s_H);
+          double dz = Z_n[nlz] - s_z[1];
+          r3[ni] = s_d[1] + s_dup * dz + c * (dz * dz) + d * ((dz * dz) * dz);
+        }
+      double gx = (GS(1, e) * r3[0] + GS(2, e) * r3[1]) + GS(3, e) * r3[2], gy = (GS(4, e) * r3[0] + GS(5, e) * r3[1]) + GS(6, e) * r3[2];
+      double ax = gx * A2(C_.helem, nlz, e) * G_ACC / DENSITY_0, ay = gy * A2(C_.helem, nlz, e) * G_ACC / DENSITY_0;
+      A2(C_.pgf_x, nlz, e) = ip[0] + ax * 0.5; ip[0] = ip[0] + ax;
+      A2(C_.pgf_y, nlz, e) = ip[1] + ay * 0.5; ip[1] = ip[1] + ay;
+    }
+  }
+  free(zbar_n); free(Z_n);
+}
+
 void orc_pressure_force(void) {
   if (C_.p.which_ale == 0 && !C_.p.use_partial_cell) { pgf_linfs_fullcell(); return; }
   if (C_.p.which_ale != 0 && C_.p.which_pgf == 1) { pgf_zxxxx_cubicspline(); return; }
+  if (C_.p.which_ale == 0 && C_.p.which_pgf == 1) { pgf_linfs_cubicspline(); return; }
   const int lin = C_.p.which_ale == 0;
   int nl = NL;
   double *zbar_n = calloc(nl + 2, sizeof(double)), *Z_n = calloc(nl + 2, sizeof(double));

@@ -540,16 +540,17 @@ def test_vector_invariant_momentum_chain_bitwise(built):
     gpu.close()
 
 
-def test_cubicspline_pgf_chain_bitwise(built):
-    """which_pgf = 'cubicspline' (pressure_force_4_zxxxx_cubicspline; oracle pinned on the reference run pi_pp_cubicspline): HIP == oracle bit for bit
-    after every routine of 3 steps under surface forcing."""
+@pytest.mark.parametrize("kw", [dict(), dict(which_ale="linfs", use_partial_cell=True)])
+def test_cubicspline_pgf_chain_bitwise(built, kw):
+    """which_pgf = 'cubicspline' (pressure_force_4_zxxxx_cubicspline with zstar, pressure_force_4_linfs_cubicspline with linfs + partial cells; oracle pinned on
+    the reference runs pi_pp_cubicspline / pi_pp_linfs_cubic): HIP == oracle bit for bit after every routine of 3 steps under surface forcing."""
     from fesom2_amd.mesh import Mesh
     from fesom2_amd.config import make_params
     from fesom2_amd.core import OceanCore
     from fesom2_amd.synthetic import analytic_ts, analytic_forcing
     from oracle_lib import Oracle
-    mesh = Mesh.load(PI, dt=900.0)
-    par = make_params(dt=900.0, which_pgf="cubicspline")
+    mesh = Mesh.load(PI, dt=900.0, **kw)
+    par = make_params(dt=900.0, which_pgf="cubicspline", **kw)
     st = mesh.initial_state(2)
     st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
     st.tr_arr_old[...] = st.tr_arr

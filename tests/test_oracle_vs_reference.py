@@ -281,27 +281,28 @@ def test_oracle_chain_bitwise_vector_invariant_momentum(built):
     assert not bad, "\n".join(bad[:20])
 
 
-def test_oracle_chain_bitwise_cubicspline_pgf(built):
-    """which_pgf = 'cubicspline' (pressure_force_4_zxxxx_cubicspline, src/oce_ale_pressure_bv.F90:1697-1866): reference run `pi_pp_cubicspline`, every
-    routine of 3 steps bit for bit."""
+@pytest.mark.parametrize("cfg,kw", [("pi_pp_cubicspline", dict()), ("pi_pp_linfs_cubic", dict(which_ale="linfs", use_partial_cell=True))])
+def test_oracle_chain_bitwise_cubicspline_pgf(built, cfg, kw):
+    """which_pgf = 'cubicspline': pressure_force_4_zxxxx_cubicspline (src/oce_ale_pressure_bv.F90:1697-1866, zstar) and pressure_force_4_linfs_cubicspline
+    (:1252-1444, linfs with partial cells): reference runs `pi_pp_cubicspline`, `pi_pp_linfs_cubic`, every routine of 3 steps bit for bit."""
     from fesom2_amd.mesh import Mesh
     from fesom2_amd.config import make_params
     from fesom2_amd.synthetic import analytic_ts
     from oracle_lib import Oracle
     from ref_chain import run_reference_chain
-    mesh = Mesh.load(PI, dt=900.0)
-    par = make_params(dt=900.0, which_pgf="cubicspline")
+    mesh = Mesh.load(PI, dt=900.0, **kw)
+    par = make_params(dt=900.0, which_pgf="cubicspline", **kw)
     st = mesh.initial_state(2)
     st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
     st.tr_arr_old[...] = st.tr_arr
     orc = Oracle(mesh, par)
     orc.set_state(st)
-    g = gold("pi_pp_cubicspline")
+    g = gold(cfg)
     for f in FORCING:
         orc.set(f, g["forcing/" + f])
     bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
     assert not bad, "\n".join(bad[:20])
-    gz = gold("pi_pp_wsplit")                                # the shchepetkin run
+    gz = gold("pi_pp_wsplit" if not kw else "pi_pp_linfs_pc")      # the shchepetkin runs
     assert not np.array_equal(g["s2/pressure_force.pgf_x"], gz["s2/pressure_force.pgf_x"])
 
 
