@@ -738,6 +738,19 @@ __device__ __forceinline__ double tru_rhs(const DM &m, const TruCol &k, int tr, 
     if (nz == nzmin) rhs = -(b - hnn) * T - c * T_dn;
     else if (nz <= nzmax - 2) rhs = -a * T_up - (b - hnn) * T - c * T_dn;
     else rhs = -a * T_up - (b - hnn) * T;
+    if (m.p.use_kpp_nonlclflx && m.p.mix_scheme == 1 && tr < 2) {      // KPP non-local transport of heat / salt (oce_ale_tracer.F90:688-724)
+      const double *bl = m.kpp_blmc + (size_t)(tr + 1) * m.nl * m.N + (size_t)n * m.nl;           // blmc(:, n, 2) for heat, (:, n, 3) for salt
+      const double g0 = dmin_(DA2(m.kpp_ghats, nz, n) * bl[nz - 1], 1.0) * (DA2L(m.area, nz, n) / asv);
+      const int nzp = nz + 1 <= m.nlm1 ? nz + 1 : m.nlm1;
+      const double g1 = dmin_(DA2(m.kpp_ghats, nzp, n) * bl[nzp - 1], 1.0) * (k.ar_dn / asv);
+      const double X = (nz == nzmin) ? -g1 : ((nz <= nzmax - 2) ? g0 - g1 : g0);
+      if (tr == 0) rhs = rhs + X * m.heat_flux[n] / D_VCPW * dt;
+      else {
+        const double s1 = bcast(T, 0);                 // tr_arr(1, n, 2) at this point of the reference = T* of the first level
+        const double rsss = m.p.ref_sss_local ? s1 : m.p.ref_sss;
+        rhs = rhs - X * rsss * m.water_flux[n] * dt;
+      }
+    }
     if (m.p.use_sw_pene && tr == 0)            // short-wave penetration (oce_ale_tracer.F90:785-791)
       rhs = rhs + (DA2L(m.sw_3d, nz, n) - DA2L(m.sw_3d, nz + 1, n) * k.ar_dn / asv) * zinv;
     if (nz == nzmin) {

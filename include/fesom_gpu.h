@@ -142,6 +142,9 @@ typedef struct fesom_params {
   int    use_momix;          /* Monin-Obukhov mixing of Timmermann & Beckmann 2004 inside mo_convect (oce_mo_conv.F90:22-55, :95; on in the shipped
                                 config/namelist.oce:48; the reference allocates its arrays only with use_ice): needs u_ice, v_ice, a_ice with the forcing */
   double momix_lat, momix_kv;/* applied south of momix_lat [degrees] (-50), diffusivity / viscosity added within the mixing length (0.01) */
+  int    use_kpp_nonlclflx;  /* KPP (mix_scheme = 1): non-local transport of heat and salt in the implicit vertical diffusion (oce_ale_tracer.F90:688-781) */
+  int    ref_sss_local;      /* its reference salinity: the local surface salinity tr_arr(1,n,2) (namelist.oce: .true.) or ref_sss */
+  double ref_sss;
 } fesom_params;
 
 /* ---- prognostic state = restart set (io_restart.F90:99-155) + ALE thickness arrays -- */

@@ -634,6 +634,20 @@ static void diff_ver_part_impl_ale(int tr) {
     nz = nzmax - 1;
     dz = A2(C_.hnode_new, nz, n);
     trv[nz] = -a[nz] * TR(nz - 1, n, tr) - (b[nz] - dz) * TR(nz, n, tr);
+    if (C_.p.use_kpp_nonlclflx && C_.p.mix_scheme == 1 && (tr == 1 || tr == 2)) {      /* KPP non-local transport, oce_ale_tracer.F90:688-724 */
+      const double *bl = C_.kpp_blmc[tr];                /* blmc(:,:,2) for heat, (:,:,3) for salt */
+      const double rsss = C_.p.ref_sss_local ? TR(1, n, 2) : C_.p.ref_sss;
+#define GH(z) (dmin(A2(C_.kpp_ghats, z, n) * A2L(bl, z, n), 1.0) * (AREA(z, n) / AREASVOL(nz, n)))
+      for (nz = nzmin; nz <= nzmax - 1; nz++) {
+        double X;
+        if (nz == nzmin) X = -GH(nz + 1);
+        else if (nz <= nzmax - 2) X = GH(nz) - GH(nz + 1);
+        else X = GH(nz);
+        if (tr == 1) trv[nz] = trv[nz] + X * C_.heat_flux[n - 1] / VCPW * dt;
+        else trv[nz] = trv[nz] - X * rsss * C_.water_flux[n - 1] * dt;
+      }
+#undef GH
+    }
     if (C_.p.use_sw_pene && tr == 1)                   /* short-wave penetration, oce_ale_tracer.F90:785-791 */
       for (nz = nzmin; nz <= nzmax - 1; nz++)
         trv[nz] = trv[nz] + (A2L(C_.sw_3d, nz, n) - A2L(C_.sw_3d, nz + 1, n) * AREA(nz + 1, n) / AREASVOL(nz, n)) * (1.0 * dt);

@@ -116,6 +116,7 @@ smooth_bh_tra=.false.
 gamma0_tra=0.0005
 gamma1_tra=0.0125
 gamma2_tra=0.
+use_kpp_nonlclflx={use_kpp_nonlclflx}
 diff_sh_limit=5.0e-3
 Kv0_const={Kv0_const}
 double_diffusion=.false.
@@ -171,6 +172,15 @@ CFGS = {
                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                        fer_gm=".true.", redi=".true.", mix_scheme="KPP", k_hor="3000.", surf_relax_s="1.929e-06",
                        balance_salt_water=".true.", synth_forcing=True, use_momix=".true."),
+    # KPP with its non-local transport terms (use_kpp_nonlclflx = .true., oce_ale_tracer.F90:688-724)
+    "pi_kpp_nonlcl": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                       rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                       fer_gm=".false.", redi=".false.", mix_scheme="KPP", k_hor="3000.", surf_relax_s="1.929e-06",
+                       balance_salt_water=".true.", synth_forcing=True, use_kpp_nonlclflx=".true."),
+    "pi_kpp_nonlcl_linfs": dict(mesh="pi", step_per_day=96, which_ale="linfs", use_partial_cell=".false.", cyclic_length=360,
+                       rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                       fer_gm=".false.", redi=".false.", mix_scheme="KPP", k_hor="3000.", surf_relax_s="1.929e-06",
+                       balance_salt_water=".true.", synth_forcing=True, use_kpp_nonlclflx=".true."),
     # PP + w_split: vertical velocity split into an explicit and an implicit part where CFL_z > w_max_cfl (threshold lowered so that
     # the split is active on pi from the first steps)
     "pi_pp_wsplit": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
@@ -345,7 +355,7 @@ def prepare(cfg, np_, tag=""):
             partition_io.write_dist(cp, np_)
         meshdir = cp
     open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **dict(dict(use_sw_pene=".false."), **c)))
-    open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0", visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=".true.", tra_adv_lim="FCT", use_momix=".false.", which_pgf="shchepetkin", mom_adv=2), **c)))
+    open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0", visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=".true.", tra_adv_lim="FCT", use_momix=".false.", which_pgf="shchepetkin", mom_adv=2, use_kpp_nonlclflx=".false."), **c)))
     if c["toy_ocean"] == ".false.":
         from fesom2_amd.synthetic import write_ic_files
         write_ic_files(meshdir, rd)

@@ -189,18 +189,20 @@ def test_redi_chain_bitwise_and_steps(built, gm):
     gpu.close()
 
 
-@pytest.mark.parametrize("full,sw", [(False, False), (True, False), (True, True), (False, True)])
-def test_kpp_chain_and_steps(built, full, sw):
+@pytest.mark.parametrize("full,sw,nonlcl", [(False, False, ""), (True, False, ""), (True, True, ""), (False, True, ""), (False, False, "zstar"), (False, True, "linfs")])
+def test_kpp_chain_and_steps(built, full, sw, nonlcl):
     """KPP vertical mixing under surface forcing (full = with GM + Redi, the reference's default physics): routine chain over
     3 steps, HIP == oracle bitwise (with Redi the oracle's tapered slopes are handed over, see the Redi test), then 10 whole
-    steps through the step graph: bitwise without Redi, 1e-9 relative with it."""
+    steps through the step graph: bitwise without Redi, 1e-9 relative with it.  nonlcl: + use_kpp_nonlclflx (non-local transport of heat and,
+    with linfs where the reference keeps ref_sss, of salt; oracle pinned on the reference runs pi_kpp_nonlcl / pi_kpp_nonlcl_linfs)."""
     from fesom2_amd.mesh import Mesh
     from fesom2_amd.config import make_params
     from fesom2_amd.core import OceanCore
     from fesom2_amd.synthetic import analytic_ts
     from oracle_lib import Oracle
-    mesh = Mesh.load(PI, dt=900.0)
-    par = make_params(dt=900.0, mix_scheme="KPP", Fer_GM=full, Redi=full, scaling_Ferreira=full, use_sw_pene=sw)   # sw: short-wave penetration
+    akw = dict(which_ale="linfs", use_partial_cell=False) if nonlcl == "linfs" else {}
+    mesh = Mesh.load(PI, dt=900.0, **akw)
+    par = make_params(dt=900.0, mix_scheme="KPP", Fer_GM=full, Redi=full, scaling_Ferreira=full, use_sw_pene=sw, use_kpp_nonlclflx=bool(nonlcl), **akw)   # sw: short-wave penetration
     st = mesh.initial_state(2)
     st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
     st.tr_arr_old[...] = st.tr_arr
