@@ -100,6 +100,28 @@ __global__ void __launch_bounds__(BLOCK) k_kpp_col(DM m) {
     if (nz == nzmax) { visc = vl; kv1 = kl; }
   }
   double kv2 = kv1;
+  if (m.p.double_diffusion) {        // ddmix (:857-934): salt fingering / diffusive convection on the interior interfaces; exp is the device's
+    double a1 = kv1, a2 = kv2;
+    if (inner) {
+      const double alphaDT = DA2(m.sw_alpha, nz - 1, n) * DTR(m.tr_arr, nz - 1, n, 0), betaDS = DA2(m.sw_beta, nz - 1, n) * DTR(m.tr_arr, nz - 1, n, 1);
+      if (alphaDT > betaDS && betaDS > 0.0) {
+        const double Rrho = dmin_(alphaDT / betaDS, 1.9);
+        double diffdd = 1.0 - ((Rrho - 1.0) / (1.9 - 1.0));
+        diffdd = 1.e-4 * diffdd * diffdd * diffdd;
+        a1 = a1 + 0.7 * diffdd; a2 = a2 + diffdd;
+      } else if (alphaDT < 0.0 && alphaDT > betaDS) {
+        const double Rrho = alphaDT / betaDS;
+        const double diffdd = 1.5e-6 * 0.909 * exp(4.6 * exp(-0.54 * (1.0 / Rrho - 1.0)));
+        double prandtl = 0.15 * Rrho;
+        if (Rrho > 0.5) prandtl = (1.85 - 0.85 / Rrho) * Rrho;
+        a1 = a1 + diffdd; a2 = a2 + prandtl * diffdd;
+      }
+    }
+    kv1 = a1; kv2 = a2;
+    const double f1 = bcast(kv1, nzmin), l1 = bcast(kv1, nzmax - 2), f2 = bcast(kv2, nzmin), l2 = bcast(kv2, nzmax - 2);
+    if (nz == nzmin) { kv1 = f1; kv2 = f2; }
+    if (nz == nzmax) { kv1 = l1; kv2 = l2; }
+  }
   // ---- bldepth (:446-650).  Without short-wave penetration bfsfc = Bo throughout; with it (use_sw_pene) the buoyancy forcing
   // at level nz includes the short-wave flux absorbed above it, so bfsfc / stable depend on the lane inside the search.
   const bool sw = m.p.use_sw_pene != 0;

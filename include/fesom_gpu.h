@@ -145,6 +145,7 @@ typedef struct fesom_params {
   int    use_kpp_nonlclflx;  /* KPP (mix_scheme = 1): non-local transport of heat and salt in the implicit vertical diffusion (oce_ale_tracer.F90:688-781) */
   int    ref_sss_local;      /* its reference salinity: the local surface salinity tr_arr(1,n,2) (namelist.oce: .true.) or ref_sss */
   double ref_sss;
+  int    double_diffusion;   /* KPP: salt fingering / diffusive convection added to the interior diffusivities (ddmix, oce_ale_mixing_kpp.F90:857-934) */
 } fesom_params;
 
 /* ---- prognostic state = restart set (io_restart.F90:99-155) + ALE thickness arrays -- */

@@ -129,6 +129,33 @@ static void ri_iwmix(void) {
   }
 }
 
+/* ddmix :857-934 (double_diffusion): salt fingering / diffusive convection added to the interior diffusivities of heat (Kv1) and salt (Kv2) */
+static void ddmix(void) {
+  const double Rrho0 = 1.9, dsfmax = 1.e-4, viscosity_molecular = 1.5e-6;
+  for (int n = 1; n <= C_.m.myDim_nod2D; n++) {
+    int nzmin = ULEVN(n), nzmax = NLEVN(n);
+    for (int nz = nzmin + 1; nz <= nzmax - 1; nz++) {
+      double alphaDT = A2(C_.sw_alpha, nz - 1, n) * TR(nz - 1, n, 1), betaDS = A2(C_.sw_beta, nz - 1, n) * TR(nz - 1, n, 2);
+      if (alphaDT > betaDS && betaDS > 0.0) {
+        double Rrho = dmin(alphaDT / betaDS, Rrho0);
+        double diffdd = 1.0 - ((Rrho - 1.0) / (Rrho0 - 1.0));
+        diffdd = dsfmax * diffdd * diffdd * diffdd;
+        A2L(C_.kpp_Kv1, nz, n) = A2L(C_.kpp_Kv1, nz, n) + 0.7 * diffdd;
+        A2L(C_.kpp_Kv2, nz, n) = A2L(C_.kpp_Kv2, nz, n) + diffdd;
+      } else if (alphaDT < 0.0 && alphaDT > betaDS) {
+        double Rrho = alphaDT / betaDS;
+        double diffdd = viscosity_molecular * 0.909 * exp(4.6 * exp(-0.54 * (1.0 / Rrho - 1.0)));
+        double prandtl = 0.15 * Rrho;
+        if (Rrho > 0.5) prandtl = (1.85 - 0.85 / Rrho) * Rrho;
+        A2L(C_.kpp_Kv1, nz, n) = A2L(C_.kpp_Kv1, nz, n) + diffdd;
+        A2L(C_.kpp_Kv2, nz, n) = A2L(C_.kpp_Kv2, nz, n) + prandtl * diffdd;
+      }
+    }
+    A2L(C_.kpp_Kv1, nzmin, n) = A2L(C_.kpp_Kv1, nzmin + 1, n); A2L(C_.kpp_Kv2, nzmin, n) = A2L(C_.kpp_Kv2, nzmin + 1, n);
+    A2L(C_.kpp_Kv1, nzmax, n) = A2L(C_.kpp_Kv1, nzmax - 1, n); A2L(C_.kpp_Kv2, nzmax, n) = A2L(C_.kpp_Kv2, nzmax - 1, n);
+  }
+}
+
 /* bldepth :446-650 (use_sw_pene=.false.) */
 static void bldepth(void) {
   const double cekman = 0.7, cmonob = 1.0, Ricr = C_.p.Ricr;
@@ -339,6 +366,7 @@ void orc_mixing_kpp(void) {
                                 A2(C_.sw_beta, nzmin, n) * C_.water_flux[n - 1] * TR(nzmin, n, 2));
   }
   ri_iwmix();
+  if (C_.p.double_diffusion) ddmix();
   bldepth();
   blmix_kpp();
   enhance();

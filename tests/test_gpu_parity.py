@@ -189,12 +189,13 @@ def test_redi_chain_bitwise_and_steps(built, gm):
     gpu.close()
 
 
-@pytest.mark.parametrize("full,sw,nonlcl", [(False, False, ""), (True, False, ""), (True, True, ""), (False, True, ""), (False, False, "zstar"), (False, True, "linfs")])
+@pytest.mark.parametrize("full,sw,nonlcl", [(False, False, ""), (True, False, ""), (True, True, ""), (False, True, ""), (False, False, "zstar"), (False, True, "linfs"), (False, False, "dd")])
 def test_kpp_chain_and_steps(built, full, sw, nonlcl):
     """KPP vertical mixing under surface forcing (full = with GM + Redi, the reference's default physics): routine chain over
     3 steps, HIP == oracle bitwise (with Redi the oracle's tapered slopes are handed over, see the Redi test), then 10 whole
     steps through the step graph: bitwise without Redi, 1e-9 relative with it.  nonlcl: + use_kpp_nonlclflx (non-local transport of heat and,
-    with linfs where the reference keeps ref_sss, of salt; oracle pinned on the reference runs pi_kpp_nonlcl / pi_kpp_nonlcl_linfs)."""
+    with linfs where the reference keeps ref_sss, of salt; oracle pinned on the reference runs pi_kpp_nonlcl / pi_kpp_nonlcl_linfs); "dd": double_diffusion
+    (ddmix; oracle pinned on pi_kpp_dd)."""
     from fesom2_amd.mesh import Mesh
     from fesom2_amd.config import make_params
     from fesom2_amd.core import OceanCore
@@ -202,9 +203,14 @@ def test_kpp_chain_and_steps(built, full, sw, nonlcl):
     from oracle_lib import Oracle
     akw = dict(which_ale="linfs", use_partial_cell=False) if nonlcl == "linfs" else {}
     mesh = Mesh.load(PI, dt=900.0, **akw)
-    par = make_params(dt=900.0, mix_scheme="KPP", Fer_GM=full, Redi=full, scaling_Ferreira=full, use_sw_pene=sw, use_kpp_nonlclflx=bool(nonlcl), **akw)   # sw: short-wave penetration
+    par = make_params(dt=900.0, mix_scheme="KPP", Fer_GM=full, Redi=full, scaling_Ferreira=full, use_sw_pene=sw, use_kpp_nonlclflx=nonlcl in ("zstar", "linfs"), double_diffusion=(nonlcl == "dd"), **akw)   # sw: short-wave penetration
     st = mesh.initial_state(2)
     st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    if nonlcl == "dd":
+        # ddmix compares alpha*T with beta*S (the tracer values themselves, oce_ale_mixing_kpp.F90:880-883): with oceanic salinities neither branch is ever
+        # taken -- the reference run pi_kpp_dd is bit-identical to pi_kpp, which is all that pins the oracle.  A brackish state (S ~ 5) takes the salt-fingering
+        # branch (the diffusive-convection branch needs beta*S < alpha*T < 0 and cannot be reached): HIP == oracle there, parity with the reference unpinned.
+        st.tr_arr[1] *= 0.15
     st.tr_arr_old[...] = st.tr_arr
     gpu, orc = OceanCore(mesh, par), Oracle(mesh, par)
     gpu.upload_state(st); orc.set_state(st)
@@ -228,6 +234,9 @@ def test_kpp_chain_and_steps(built, full, sw, nonlcl):
         if failures:
             break
     assert not failures, "\n".join(failures[:10])
+    if nonlcl == "dd":
+        k1, k2 = orc.get("kpp_Kv1"), orc.get("kpp_Kv2")
+        assert (k2 > k1).sum() > 1000                        # the salt-fingering branch is taken (Kv2 - Kv1 = 0.3 diffdd)
     gpu.run_steps(4, 10)
     for n in range(10):
         orc.call("step", 4 + n)

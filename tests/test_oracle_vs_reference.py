@@ -83,7 +83,7 @@ def test_oracle_chain_bitwise_gm(built, redi):
 FORCING = ("stress_atmoce_x", "stress_atmoce_y", "heat_flux", "water_flux", "stress_surf")
 
 
-@pytest.mark.parametrize("cfg", ["pi_kpp", "pi_default", "pi_default_sw", "pi_kpp_nonlcl", "pi_kpp_nonlcl_linfs"])
+@pytest.mark.parametrize("cfg", ["pi_kpp", "pi_default", "pi_default_sw", "pi_kpp_nonlcl", "pi_kpp_nonlcl_linfs", "pi_kpp_dd"])
 def test_oracle_chain_bitwise_kpp_forced(built, cfg):
     """KPP vertical mixing (src/oce_ale_mixing_kpp.F90: ri_iwmix, bldepth, wscale tables, blmix_kpp, enhance, smoothing of blmc)
     under the harness's analytic wind stress / heat / fresh-water forcing, which also pins the surface boundary terms of
@@ -94,13 +94,14 @@ def test_oracle_chain_bitwise_kpp_forced(built, cfg):
     from fesom2_amd.synthetic import analytic_ts
     from oracle_lib import Oracle
     from ref_chain import run_reference_chain
-    full = cfg not in ("pi_kpp", "pi_kpp_nonlcl", "pi_kpp_nonlcl_linfs")
+    full = cfg not in ("pi_kpp", "pi_kpp_nonlcl", "pi_kpp_nonlcl_linfs", "pi_kpp_dd")
+    dd = cfg == "pi_kpp_dd"                     # + double diffusion (ddmix, oce_ale_mixing_kpp.F90:857-934)
     nonlcl = cfg.startswith("pi_kpp_nonlcl")    # + the non-local transport of heat and salt (use_kpp_nonlclflx, oce_ale_tracer.F90:688-724); with zstar the
     # reference's ocean_setup zeroes ref_sss (oce_setup_step.F90:42-47) and only the heat term acts, with linfs (+ full cells) both do
     akw = dict(which_ale="linfs", use_partial_cell=False) if cfg.endswith("linfs") else {}
     sw = cfg == "pi_default_sw"                 # + short-wave penetration (use_sw_pene=.true., the default of namelist.config)
     mesh = Mesh.load(PI, dt=900.0, **akw)
-    par = make_params(dt=900.0, mix_scheme="KPP", Fer_GM=full, Redi=full, use_sw_pene=sw, use_kpp_nonlclflx=nonlcl, **akw)
+    par = make_params(dt=900.0, mix_scheme="KPP", Fer_GM=full, Redi=full, use_sw_pene=sw, use_kpp_nonlclflx=nonlcl, double_diffusion=dd, **akw)
     st = mesh.initial_state(2)
     st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
     st.tr_arr_old[...] = st.tr_arr
