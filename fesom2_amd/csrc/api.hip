@@ -312,6 +312,7 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   // the fly: it is part of the named routine adv_tracers_ale, not of the running step)
   if (ev_df) hipStreamWaitEvent(s0, ev_df, 0);
   K(s0, "k_tr_update", 0);                         // incl. the Thomas sweep
+  if (m.p.smooth_bh_tra) { K(s0, "k_bh1", 0); K(s0, "k_bh2", 0); }      // diff_part_bh at the end of diff_tracers_ale
   if (toy) for (int tr = 0; tr < m.ntr; tr++) launch_named_toy(m, s0, "relax_zonal_temp");   // once per tracer
   if (gm) launch_named_gm(m, s0, "bolus_remove");                          // :165-169
   d.dep(s0, s1); d.dep(s0, s2); d.dep(s0, s3);
@@ -543,6 +544,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   FT(adv_flux_hor, n1 * D); FT(adv_flux_raw, n1 * D); FT(flux_lo_hor, n1 * D); FT(diff_flux, n1 * D); FT(edge_up_dn_grad, 4 * n1 * D); F(edge_c12, D);
   F(ssh_values, m.nza);
   if (par->visc_option <= 3) { F(Visc, n1 * E); F(leith_aux, n1 * N); }
+  if (par->smooth_bh_tra) FT(bh_tmp, n1 * N);
   if (par->visc_option <= 3 || par->mom_adv == 3) F(vorticity, n1 * N);
   if (par->mom_adv == 3) {
     F(KE_node, n1 * N);
@@ -964,6 +966,7 @@ int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
   S.c("k_flux_hor", 0); S.c("k_fct_lo_node", 0);
   if (!p.tra_adv_lim) { S.X(0, {"fct_LO"}); S.c("k_fct_node", 0); S.X(0, {"fct_plus", "fct_minus"}); }     // (no low-order solution, no limiter with tra_adv_lim='NON')
   S.c("k_fct_edge_limit", 0); S.c("k_tr_update", 0);
+  if (p.smooth_bh_tra) { S.c("k_bh1", 0); S.X(0, {"bh_tmp"}); S.c("k_bh2", 0); }     // (the tracer halo still holds the values of the previous exchange, as in the reference)
   if (toy) for (int tr = 0; tr < G.m.ntr; tr++) S.c("relax_zonal_temp");     // once per tracer of the loop, always on tracer 1 (oce_ale_tracer.F90:150)
   S.X(0, {"tr_arr"});
   if (p.Fer_GM) S.c("bolus_remove");

@@ -50,6 +50,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   const double *u_ice, *v_ice, *a_ice;     // use_momix: ice state with the forcing (N)
   double *mixlength;                       // Monin-Obukhov mixing length (N), kept from step to step
   const int *momix_node, *momix_elem;      // 1 where mo_convect applies the Monin-Obukhov mixing (latitude / no cavity), per node and per owned element
+  double *bh_tmp;                          // smooth_bh_tra: first stage of the biharmonic tracer filter (nl-1, N) per tracer
   double *KE_node;                         // mom_adv = 3: kinetic energy at nodes (nl-1, N)
   const unsigned char *wall_node;          // mom_adv = 3: 1 for both nodes of the owned boundary edges (KE_node = 0 at lateral walls)
   double *Visc, *vorticity, *leith_aux;    // visc_option 1-3: Leith coefficient (nl-1, E), relative vorticity and smoothing work array (nl-1, N)

@@ -767,6 +767,48 @@ __device__ __forceinline__ double tru_clamp(double T, int tr) {           // sal
   if (tr == 1) { if (T > 45.0) T = 45.0; if (T < 3.0) T = 3.0; }
   return T;
 }
+// diff_part_bh (smooth_bh_tra, oce_ale_tracer.F90:1081-1150): biharmonic diffusion of the tracer as a filter at the end of diff_tracers_ale, with the
+// flow-dependent coefficient of the momentum filters.  Two node gathers over the incident internal edges in edge order (= the reference's scatter order);
+// the salinity clamp, which the reference applies after the tracer loop, moves from k_tr_update to the second stage.  grid.y = tracer.
+__device__ __forceinline__ bool bh_edge(const DM &m, int ed, int nz, double &vi) {
+  if (m.edge_glob[ed] > m.edge2D_in) return false;
+  const int e1 = m.edge_tri[2 * ed], e2 = m.edge_tri[2 * ed + 1], n1 = m.edges[2 * ed], n2 = m.edges[2 * ed + 1];
+  const int ul1 = min(m.ulev_n_max[n1], m.ulev_n_max[n2]), nl1 = max(m.nlev_n_min[n1], m.nlev_n_min[n2]) - 1;
+  if (nz < ul1 || nz > nl1) return false;
+  const double len = sqrt(m.elem_area[e1] + m.elem_area[e2]);
+  const double u1 = DV2(m.UV, 1, nz, e1) - DV2(m.UV, 1, nz, e2), v1 = DV2(m.UV, 2, nz, e1) - DV2(m.UV, 2, nz, e2);
+  vi = u1 * u1 + v1 * v1;
+  vi = sqrt(dmax_(m.p.gamma0, dmax_(m.p.gamma1 * sqrt(vi), m.p.gamma2 * vi)) * len);
+  return true;
+}
+__global__ void __launch_bounds__(BLOCK) k_bh1(DM m, int tr0) {
+  const int tr = tr0 + blockIdx.y, n = col_id(), nz = lane_id() + 1;
+  if (n >= m.myN || nz > m.nlm1) return;
+  double tmp = 0.0;
+  for (int q = m.ne_ptr[n]; q < m.ne_ptr[n + 1]; q++) {
+    const int ed = m.ne_idx[q];
+    double vi;
+    if (!bh_edge(m, ed, nz, vi)) continue;
+    const double tt = (DTR(m.tr_arr, nz, m.edges[2 * ed], tr) - DTR(m.tr_arr, nz, m.edges[2 * ed + 1], tr)) * vi;
+    tmp = m.ne_sgn[q] > 0 ? tmp - tt : tmp + tt;
+  }
+  DTR(m.bh_tmp, nz, n, tr) = tmp;
+}
+__global__ void __launch_bounds__(BLOCK) k_bh2(DM m, int tr0) {
+  const int tr = tr0 + blockIdx.y, n = col_id(), nz = lane_id() + 1;
+  if (n >= m.myN || nz > m.nlm1) return;
+  double T = DTR(m.tr_arr, nz, n, tr);
+  const double ar = DA2L(m.area, nz, n);
+  for (int q = m.ne_ptr[n]; q < m.ne_ptr[n + 1]; q++) {
+    const int ed = m.ne_idx[q];
+    double vi;
+    if (!bh_edge(m, ed, nz, vi)) continue;
+    const double tt = -(DTR(m.bh_tmp, nz, m.edges[2 * ed], tr) - DTR(m.bh_tmp, nz, m.edges[2 * ed + 1], tr)) * vi * m.p.dt;
+    T = m.ne_sgn[q] > 0 ? T - tt / ar : T + tt / ar;
+  }
+  if (nz >= m.ulev_n[n] && nz <= m.nlev_n[n] - 1) T = tru_clamp(T, tr);
+  DTR(m.tr_arr, nz, n, tr) = T;
+}
 template <bool REDI, int NT, int COLS, int WAVES>
 __global__ void __launch_bounds__(WAVE * WAVES, (WAVES == 8) ? 4 : 2) k_tr_update(DM m, int tr0) {
   extern __shared__ double th_sh[];
@@ -803,7 +845,7 @@ __global__ void __launch_bounds__(WAVE * WAVES, (WAVES == 8) ? 4 : 2) k_tr_updat
         tile.put(ci, k.valid, k.nzmin, k.nzmax - 1, k.a, k.b, k.c, rhs[0], NT == 2 ? rhs[NT - 1] : 0.0);
       } else {
 #pragma unroll
-        for (int t = 0; t < NT; t++) if (k.wet && trA + t < m.ntr) DTR(m.tr_arr, nz, k.n, trA + t) = tru_clamp(Ts[t], trA + t);
+        for (int t = 0; t < NT; t++) if (k.wet && trA + t < m.ntr) DTR(m.tr_arr, nz, k.n, trA + t) = m.p.smooth_bh_tra ? Ts[t] : tru_clamp(Ts[t], trA + t);
       }
     } else {
       // several columns per wave: the column's coefficients first, then tracer after tracer straight into the tile / memory
@@ -816,7 +858,7 @@ __global__ void __launch_bounds__(WAVE * WAVES, (WAVES == 8) ? 4 : 2) k_tr_updat
           if (m.p.tra_adv_lim) tru_hor<false, TRU_MAXD_TILE, true>(m, k, trA + t, T, del);
           else if (tru_hor<true, TRU_MAXD_TILE>(m, k, trA + t, T, del)) tru_hor<false, TRU_MAXD_TILE>(m, k, trA + t, T, del);
           tru_fin<REDI>(m, k, trA + t, T, del);
-          if (k.wet) DTR(m.tr_arr, nz, k.n, trA + t) = impl ? T : tru_clamp(T, trA + t);    // T*: picked up again after the sweep
+          if (k.wet) DTR(m.tr_arr, nz, k.n, trA + t) = (impl || m.p.smooth_bh_tra) ? T : tru_clamp(T, trA + t);    // T*: picked up again after the sweep
           if (impl) { tile.get_abc(ci, k.a, k.b, k.c); r = tru_rhs(m, k, trA + t, T); }      // (a, b, c back from the tile: not kept in registers across the gathers)
         }
         if (impl) tile.put_rhs(ci, t, r);
@@ -838,7 +880,7 @@ __global__ void __launch_bounds__(WAVE * WAVES, (WAVES == 8) ? 4 : 2) k_tr_updat
     for (int t = 0; t < NT; t++)
       if (wet && trA + t < m.ntr) {                        // tr_arr = T* + dT ; salinity clamp
         double T = SINGLE ? Ts[t] : DTR(m.tr_arr, nz, n, trA + t);
-        DTR(m.tr_arr, nz, n, trA + t) = tru_clamp(T + dT[t], trA + t);
+        DTR(m.tr_arr, nz, n, trA + t) = m.p.smooth_bh_tra ? T + dT[t] : tru_clamp(T + dT[t], trA + t);
       }
   }
 }
@@ -875,6 +917,10 @@ void launch_tracer(const DM &m, hipStream_t s, int tr) {   // tr 0-based
   LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr);
   if (m.p.with_diffusion) LAUNCH_DFX(m, tr);
   LAUNCH_TRU(m, tr);
+  if (m.p.smooth_bh_tra) {
+    hipLaunchKernelGGL(k_bh1, dim3(nblocks(m.myN), tr < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m, tr < 0 ? 0 : tr);
+    hipLaunchKernelGGL(k_bh2, dim3(nblocks(m.myN), tr < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m, tr < 0 ? 0 : tr);
+  }
 }
 
 int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
@@ -891,6 +937,8 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
     if (!strcmp(name, "k_fct_edge_limit")) { LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr); return 0; }
     if (!strcmp(name, "k_diff_flux")) { LAUNCH_DFX(m, tr); return 0; }
     if (!strcmp(name, "k_tr_update")) { LAUNCH_TRU(m, tr); return 0; }
+    if (!strcmp(name, "k_bh1")) { hipLaunchKernelGGL(k_bh1, dim3(nblocks(m.myN), tr < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m, tr < 0 ? 0 : tr); return 0; }
+    if (!strcmp(name, "k_bh2")) { hipLaunchKernelGGL(k_bh2, dim3(nblocks(m.myN), tr < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m, tr < 0 ? 0 : tr); return 0; }
     return -1;
   }
   if (!strcmp(name, "init_tracers_AB")) {
@@ -906,6 +954,10 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
   if (!strcmp(name, "diff_tracers_ale")) {                                                    // incl. flux2dtracer + clamp
     if (m.p.with_diffusion) LAUNCH_DFX(m, tr);
     LAUNCH_TRU(m, tr);
+    if (m.p.smooth_bh_tra) {
+      hipLaunchKernelGGL(k_bh1, dim3(nblocks(m.myN), tr < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m, tr < 0 ? 0 : tr);
+      hipLaunchKernelGGL(k_bh2, dim3(nblocks(m.myN), tr < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m, tr < 0 ? 0 : tr);
+    }
     return 0;
   }
   if (!strcmp(name, "salinity_clamp")) return 0;

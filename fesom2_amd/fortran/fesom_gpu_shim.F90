@@ -67,7 +67,7 @@ module fesom_gpu_shim
      real(c_double) :: momix_lat, momix_kv
      integer(c_int) :: use_kpp_nonlclflx, ref_sss_local
      real(c_double) :: ref_sss
-     integer(c_int) :: double_diffusion
+     integer(c_int) :: smooth_bh_tra, double_diffusion
   end type
   type, bind(C) :: fesom_state_desc
      type(c_ptr) :: tr_arr, tr_arr_old, UV, UV_rhsAB, eta_n, d_eta, ssh_rhs, ssh_rhs_old, hbar, hbar_old, dhe, hnode, hnode_new, &
@@ -301,7 +301,6 @@ contains
     call refuse(use_floatice, 'use_floatice (ice and snow load in the sea-surface slope, oce_ale_vel_rhs.F90:41)')
     call refuse(use_global_tides, 'use_global_tides (tidal potential in compute_vel_rhs, oce_ale_vel_rhs.F90:92)')
     call refuse(SPP, 'SPP (salt plume parameterization, oce_ale_tracer.F90:120)')
-    call refuse(smooth_bh_tra, 'smooth_bh_tra (biharmonic tracer diffusion, oce_ale_tracer.F90:322)')
     call refuse(use_kpp_nonlclflx .and. mix_scheme_nmb /= 1, 'use_kpp_nonlclflx with a mixing scheme other than KPP (oce_ale_tracer.F90:725)')
     call refuse(clim_relax > 1.0e-8_WP .and. .not. toy_ocean, 'clim_relax > 0 (relax_to_clim, oce_tracer_mod.F90:99)')
     call refuse(use_momix .and. .not. allocated(mixlength), 'use_momix without the ice arrays (the reference allocates mo / mixlength only with use_ice, oce_setup_step.F90:218)')
@@ -357,7 +356,7 @@ contains
     end select
     p%use_momix = l2i(use_momix); p%momix_lat = momix_lat; p%momix_kv = momix_kv
     p%use_kpp_nonlclflx = l2i(use_kpp_nonlclflx); p%ref_sss_local = l2i(ref_sss_local); p%ref_sss = ref_sss
-    p%double_diffusion = l2i(double_diffusion)
+    p%double_diffusion = l2i(double_diffusion); p%smooth_bh_tra = l2i(smooth_bh_tra)
     p%solver_precond = 1; p%solver_xinv_its = 0     ! explicit-inverse preconditioner where it fits (pi), library default iterations
 
     transport%ctx = c_null_ptr

@@ -105,6 +105,8 @@ def run_step(core, par, X, solve, first, probe=None, n=1, zonal=None):
     if not p.tra_adv_lim:                             # (no low-order solution, no limiter with tra_adv_lim='NON')
         X(NOD, ["fct_LO"]); c("k_fct_node", 0); X(NOD, ["fct_plus", "fct_minus"])
     c("k_fct_edge_limit", 0); c("k_tr_update", 0)
+    if p.smooth_bh_tra:
+        c("k_bh1", 0); X(NOD, ["bh_tmp"]); c("k_bh2", 0)
     if p.toy_soufflet:
         for _ in range(p.num_tracers):                # once per tracer of the loop, always on tracer 1 (oce_ale_tracer.F90:150)
             c("relax_zonal_temp")

@@ -145,6 +145,8 @@ typedef struct fesom_params {
   int    use_kpp_nonlclflx;  /* KPP (mix_scheme = 1): non-local transport of heat and salt in the implicit vertical diffusion (oce_ale_tracer.F90:688-781) */
   int    ref_sss_local;      /* its reference salinity: the local surface salinity tr_arr(1,n,2) (namelist.oce: .true.) or ref_sss */
   double ref_sss;
+  int    smooth_bh_tra;      /* biharmonic diffusion of the tracers applied as a filter at the end of diff_tracers_ale (diff_part_bh, oce_ale_tracer.F90:1081-1150;
+                                it uses the momentum coefficients gamma0 / gamma1 / gamma2) */
   int    double_diffusion;   /* KPP: salt fingering / diffusive convection added to the interior diffusivities (ddmix, oce_ale_mixing_kpp.F90:857-934) */
 } fesom_params;
 

@@ -666,6 +666,36 @@ static void diff_ver_part_impl_ale(int tr) {
   free(buf);
 }
 
+/* diff_part_bh (smooth_bh_tra): src/oce_ale_tracer.F90:1081-1150, biharmonic diffusion of the tracer as a filter with the flow-dependent
+ * coefficient of the momentum filters (gamma0, gamma1, gamma2) */
+static void diff_part_bh(int tr) {
+  double *tmp = calloc((size_t)NLM1 * C_.N, sizeof(double));
+  const double g0 = C_.p.gamma0, g1 = C_.p.gamma1, g2 = C_.p.gamma2, dt = C_.p.dt;
+  for (int stage = 0; stage < 2; stage++) {
+    for (int ed = 1; ed <= C_.D; ed++) {
+      if (C_.m.myList_edge2D[ed - 1] > C_.m.edge2D_in) continue;
+      int e1 = ETRI(1, ed), e2 = ETRI(2, ed), n1 = EDG(1, ed), n2 = EDG(2, ed);
+      double len = sqrt(C_.m.elem_area[e1 - 1] + C_.m.elem_area[e2 - 1]);
+      int ul1 = C_.m.ulevels_nod2D_max[n1 - 1] < C_.m.ulevels_nod2D_max[n2 - 1] ? C_.m.ulevels_nod2D_max[n1 - 1] : C_.m.ulevels_nod2D_max[n2 - 1];
+      int nl1 = (C_.m.nlevels_nod2D_min[n1 - 1] > C_.m.nlevels_nod2D_min[n2 - 1] ? C_.m.nlevels_nod2D_min[n1 - 1] : C_.m.nlevels_nod2D_min[n2 - 1]) - 1;
+      for (int nz = ul1; nz <= nl1; nz++) {
+        double u1 = V2(C_.UV, 1, nz, e1) - V2(C_.UV, 1, nz, e2), v1 = V2(C_.UV, 2, nz, e1) - V2(C_.UV, 2, nz, e2);
+        double vi = u1 * u1 + v1 * v1;
+        vi = sqrt(dmax(g0, dmax(g1 * sqrt(vi), g2 * vi)) * len);
+        if (stage == 0) {
+          double tt = (TR(nz, n1, tr) - TR(nz, n2, tr)) * vi;
+          A2(tmp, nz, n1) = A2(tmp, nz, n1) - tt; A2(tmp, nz, n2) = A2(tmp, nz, n2) + tt;
+        } else {
+          double tt = -(A2(tmp, nz, n1) - A2(tmp, nz, n2)) * vi * dt;
+          TR(nz, n1, tr) = TR(nz, n1, tr) - tt / AREA(nz, n1); TR(nz, n2, tr) = TR(nz, n2, tr) + tt / AREA(nz, n2);
+        }
+      }
+    }
+    /* (exchange_nod(temporary_ttf): single partition) */
+  }
+  free(tmp);
+}
+
 /* diff_tracers_ale: src/oce_ale_tracer.F90:253-325 */
 void orc_diff_tracers_ale(int tr) {
   size_t cnt = (size_t)NLM1 * C_.N;
@@ -678,6 +708,7 @@ void orc_diff_tracers_ale(int tr) {
       TR(nz, n, tr) = TR(nz, n, tr) + A2(C_.del_ttf, nz, n) / A2(C_.hnode_new, nz, n);
     }
   if (C_.p.with_diffusion && C_.p.i_vert_diff) diff_ver_part_impl_ale(tr);
+  if (C_.p.smooth_bh_tra) diff_part_bh(tr);
 }
 
 /* solve_tracers_ale tail: salinity clamp, src/oce_ale_tracer.F90:176-198 */

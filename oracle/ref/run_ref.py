@@ -112,7 +112,7 @@ instabmix_kv=0.1
 use_windmix=.false.
 windmix_kv=1.e-3
 windmix_nl=2
-smooth_bh_tra=.false.
+smooth_bh_tra={smooth_bh_tra}
 gamma0_tra=0.0005
 gamma1_tra=0.0125
 gamma2_tra=0.
@@ -177,6 +177,11 @@ CFGS = {
                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                        fer_gm=".false.", redi=".false.", mix_scheme="KPP", k_hor="3000.", surf_relax_s="1.929e-06",
                        balance_salt_water=".true.", synth_forcing=True, use_kpp_nonlclflx=".true."),
+    # smooth_bh_tra = .true.: biharmonic tracer diffusion as a filter (diff_part_bh, oce_ale_tracer.F90:1081-1150)
+    "pi_pp_bhtra": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                       rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                       fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                       balance_salt_water=".true.", synth_forcing=True, smooth_bh_tra=".true."),
     # KPP with double diffusion (ddmix, oce_ale_mixing_kpp.F90:857-934)
     "pi_kpp_dd": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
@@ -360,7 +365,7 @@ def prepare(cfg, np_, tag=""):
             partition_io.write_dist(cp, np_)
         meshdir = cp
     open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **dict(dict(use_sw_pene=".false."), **c)))
-    open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0", visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=".true.", tra_adv_lim="FCT", use_momix=".false.", which_pgf="shchepetkin", mom_adv=2, use_kpp_nonlclflx=".false.", double_diffusion=".false."), **c)))
+    open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0", visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=".true.", tra_adv_lim="FCT", use_momix=".false.", which_pgf="shchepetkin", mom_adv=2, use_kpp_nonlclflx=".false.", double_diffusion=".false.", smooth_bh_tra=".false."), **c)))
     if c["toy_ocean"] == ".false.":
         from fesom2_amd.synthetic import write_ic_files
         write_ic_files(meshdir, rd)

@@ -113,6 +113,7 @@ def main():
     make("pi_pp_wsplit", "pi_pp_wsplit_reference.npz")  # PP + w_split with surface forcing
     make("pi_default_sw", "pi_default_sw_reference.npz")  # default physics + short-wave penetration
     make("pi_pp_non", "pi_pp_non_reference.npz")        # tra_adv_lim = 'NON'
+    make("pi_pp_bhtra", "pi_pp_bhtra_reference.npz")    # smooth_bh_tra
     make("pi_kpp_dd", "pi_kpp_dd_reference.npz")        # KPP + double_diffusion
     make("pi_kpp_nonlcl", "pi_kpp_nonlcl_reference.npz")  # KPP + use_kpp_nonlclflx (zstar: ocean_setup zeroes ref_sss, heat term only)
     make("pi_kpp_nonlcl_linfs", "pi_kpp_nonlcl_linfs_reference.npz")  # the same with linfs + full cells: heat and salt terms

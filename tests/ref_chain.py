@@ -6,9 +6,10 @@ import numpy as np
 from golden_util import check_digest, wet_masks
 
 
-def run_reference_chain(orc, mesh, g, steps=(1, 2, 3), toy=False, skip=(), after_step=None):
+def run_reference_chain(orc, mesh, g, steps=(1, 2, 3), toy=False, skip=(), after_step=None, node_keep=None):
     """returns the list of mismatches (empty = bit-identical on every sampled value).  `skip` = set of (step, key)
-    entries that are known to differ (documented where used)."""
+    entries that are known to differ (documented where used).  `node_keep` (bool per global node): tracer fields are compared at these nodes only
+    (options whose result the reference makes depend on the partition: the goldens come from a 2-rank run)."""
     W = wet_masks(mesh)
     nlm1 = mesh.nl - 1
     bad = []
@@ -19,7 +20,12 @@ def run_reference_chain(orc, mesh, g, steps=(1, 2, 3), toy=False, skip=(), after
         a = orc.get(field)
         if sub is not None:
             a = a.reshape(2, -1, nlm1)[sub]
-        ok, msg = check_digest(a, g[f"s{step}/{key}"], None if mask is None else W[mask])
+        mk = None if mask is None else W[mask]
+        if node_keep is not None and field in ("tr_arr", "del_ttf") and a.size % node_keep.size == 0:
+            keep = np.broadcast_to(node_keep[:, None], (node_keep.size, a.size // node_keep.size // (2 if (field == "tr_arr" and sub is None) else 1)))
+            keep = np.tile(keep.reshape(-1), 2) if (field == "tr_arr" and sub is None) else keep.reshape(-1)
+            mk = keep.reshape(np.shape(mk)) & mk if mk is not None else keep
+        ok, msg = check_digest(a, g[f"s{step}/{key}"], mk)
         if not ok:
             bad.append(f"step {step} {key}: {msg}")
 

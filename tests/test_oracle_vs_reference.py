@@ -310,6 +310,47 @@ def test_oracle_chain_bitwise_cubicspline_pgf(built, cfg, kw):
     assert not np.array_equal(g["s2/pressure_force.pgf_x"], gz["s2/pressure_force.pgf_x"])
 
 
+def test_oracle_chain_bitwise_biharmonic_tracer_filter(built):
+    """smooth_bh_tra = .true. (diff_part_bh, src/oce_ale_tracer.F90:1081-1150, at the end of diff_tracers_ale): reference run `pi_pp_bhtra`, every routine of 3
+    routine of step 1 bit for bit.  The reference applies the filter with the halo values of the PREVIOUS exchange (the tracer is exchanged only after
+    diff_tracers_ale, :1104-1118 read ttf at halo nodes), so in its 2-rank run -- where the goldens come from; a 1-rank run of the harness does not exist --
+    the nodes within two rings of the partition boundary differ from a one-partition result (measured: 3e-10 in 6 of 262 samples).  They are left out of the
+    tracer comparisons here, and only step 1 is compared (afterwards the difference spreads); the partition-faithful behaviour itself is pinned by the 2-rank
+    drop-in run of the library against the reference's 2-rank run (tests/test_gpu_dropin.py[pi_pp_bhtra-2])."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.synthetic import analytic_ts
+    from oracle_lib import Oracle
+    from ref_chain import run_reference_chain
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, smooth_bh_tra=True)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    orc = Oracle(mesh, par)
+    orc.set_state(st)
+    g = gold("pi_pp_bhtra")
+    for f in FORCING:
+        orc.set(f, g["forcing/" + f])
+    # owner rank of every node in the reference's dist_2 partition, nodes within two rings of the other rank's nodes
+    N = mesh.nod2D
+    tok = np.array(open(os.path.join(PI, "dist_2", "rpart.out")).read().split(), dtype=np.int64)      # npes, owned counts, PE-contiguous index of every node
+    assert tok[0] == 2 and tok.size == 3 + N
+    rank = (tok[3:] > tok[1]).astype(np.int32)
+    ed = np.asarray(mesh.edges).reshape(-1, 2) - 1
+    near = np.zeros(N, dtype=bool)
+    cut = rank[ed[:, 0]] != rank[ed[:, 1]]
+    near[ed[cut].ravel()] = True
+    for _ in range(2):
+        grow = near[ed[:, 0]] | near[ed[:, 1]]
+        near[ed[grow].ravel()] = True
+    assert 100 < near.sum() < N // 2
+    bad = run_reference_chain(orc, mesh, g, steps=(1,), node_keep=~near)
+    assert not bad, "\n".join(bad[:20])
+    gz = gold("pi_pp_wsplit")
+    assert not np.array_equal(g["s1/tr1.end.tr_arr"], gz["s1/tr1.end.tr_arr"])
+
+
 def test_oracle_chain_bitwise_linfs_partial_cells(built):
     """which_ALE = 'linfs' with use_partial_cell = .true. on pi: pressure_force_4_linfs_shchepetkin (src/oce_ale_pressure_bv.F90:647-891), the linfs branches
     of compute_hbar_ale / vert_vel_ale / the SSH right-hand side on a mesh with partial bottom cells: reference run `pi_pp_linfs_pc`, every routine of
