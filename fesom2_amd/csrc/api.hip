@@ -566,7 +566,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   }
   if (par->Fer_GM) { F(fer_K, nl * N); F(fer_gamma, 2 * nl * N); F(fer_Wvel, nl * N); F(fer_c, N); F(fer_UV, 2 * n1 * E); }
   {   // surface forcing: ONE device block (one host->device copy per fesom_gpu_set_forcing), fields are views into it
-    G.frc_count = 2 * E + 7 * N + (par->use_sw_pene ? nl * N : 0) + (par->use_momix ? 3 * N : 0);
+    G.frc_count = 2 * E + 7 * N + (par->use_sw_pene ? nl * N : 0) + (par->use_momix ? 3 * N : 0) + (par->use_floatice ? 2 * N : 0) + (par->l_mslp ? N : 0) + (par->use_global_tides ? N : 0);
     G.frc_dev = dev_alloc<double>(G.frc_count);
     double *q = G.frc_dev;
     auto view = [&](const char *name, size_t cnt) { double *r = q; G.fields[name] = Field{r, cnt, 1}; q += cnt; return r; };
@@ -575,6 +575,9 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     m.stress_atmoce_x = view("stress_atmoce_x", N); m.stress_atmoce_y = view("stress_atmoce_y", N);
     m.sw_3d = par->use_sw_pene ? view("sw_3d", nl * N) : nullptr;
     if (par->use_momix) { m.u_ice = view("u_ice", N); m.v_ice = view("v_ice", N); m.a_ice = view("a_ice", N); }
+    if (par->use_floatice) { m.m_ice = view("m_ice", N); m.m_snow = view("m_snow", N); }
+    if (par->l_mslp) m.press_air = view("press_air", N);
+    if (par->use_global_tides) m.ssh_gp = view("ssh_gp", N);
   }
   if (par->mix_scheme == 1) {
     F(dbsfc, nl * N);
@@ -786,6 +789,9 @@ int fesom_gpu_set_forcing(const fesom_forcing_desc *f) {
   put(f->relax_salt, N, N); put(f->real_salt_flux, N, N); put(f->stress_atmoce_x, N, N); put(f->stress_atmoce_y, N, N);
   if (G.m.sw_3d) put(f->sw_3d, (size_t)G.m.nl * N, (size_t)G.m.nl * N);
   if (G.m.p.use_momix) { put(f->u_ice, N, N); put(f->v_ice, N, N); put(f->a_ice, N, N); }
+  if (G.m.p.use_floatice) { put(f->m_ice, N, N); put(f->m_snow, N, N); }
+  if (G.m.p.l_mslp) put(f->press_air, N, N);
+  if (G.m.p.use_global_tides) put(f->ssh_gp, N, N);
   HIPCHK(hipMemcpyAsync(G.frc_dev, G.frc_pin[b], G.frc_count * sizeof(double), hipMemcpyHostToDevice, G.stream));
   HIPCHK(hipEventRecord(G.frc_ev[b], G.stream));
   return 0;

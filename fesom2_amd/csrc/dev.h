@@ -47,6 +47,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   double *eta_n, *d_eta, *ssh_rhs, *ssh_rhs_old, *hbar, *hbar_old, *MLD1, *MLD2;
   double *heat_flux, *water_flux, *virtual_salt, *relax_salt, *real_salt_flux;
   double *UV, *UV_rhs, *UV_rhsAB, *tr_xy, *tr_xy_ab, *U_b;
+  const double *m_ice, *m_snow, *press_air, *ssh_gp;      // use_floatice / l_mslp / use_global_tides: potentials of the surface pressure gradient (N), with the forcing
   const double *u_ice, *v_ice, *a_ice;     // use_momix: ice state with the forcing (N)
   double *mixlength;                       // Monin-Obukhov mixing length (N), kept from step to step
   const int *momix_node, *momix_elem;      // 1 where mo_convect applies the Monin-Obukhov mixing (latitude / no cavity), per node and per owned element
@@ -150,6 +151,15 @@ __device__ __forceinline__ int rdlane(int x, int lane) { return __builtin_amdgcn
 __device__ __forceinline__ double shup(double x) { return __shfl_up(x, 1, 64); }     // value of lane-1
 __device__ __forceinline__ double shdn(double x) { return __shfl_down(x, 1, 64); }   // value of lane+1
 
+// -(p_eta + p_ice + p_air) [- ssh_gp] at a node: the surface potentials of compute_vel_rhs (src/oce_ale_vel_rhs.F90:52-76)
+__device__ __forceinline__ double surf_pre(const DM &m, int n) {
+  double p_ice = 0.0, p_air = 0.0;
+  if (m.p.use_floatice) { p_ice = (m.m_ice[n] * 910. + m.m_snow[n] * 290.) * (1. / 1025.); p_ice = 9.81 * (p_ice < m.p.max_ice_loading ? p_ice : m.p.max_ice_loading); }
+  if (m.p.l_mslp) p_air = m.press_air[n] / 1000;
+  double pre = -(9.81 * m.eta_n[n] + p_ice + p_air);
+  if (m.p.use_global_tides) pre = pre - m.ssh_gp[n];
+  return pre;
+}
 // mo(nz, node) of mo_convect (src/oce_mo_conv.F90:44-52): momix_kv inside the mixing length of a node the scheme applies to, else 0
 __device__ __forceinline__ double momix_mo(const DM &m, int nz, int n) {
   if (!m.momix_node[n] || nz < m.ulev_n[n] + 1 || nz > m.nlev_n[n] - 1) return 0.0;

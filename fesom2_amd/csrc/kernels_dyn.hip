@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(BLOCK) k_vel_rhs(DM m, int first_step) {
   int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
   double ar = m.elem_area[e];
   double r1 = -(0.5 + eps) * DV2(m.UV_rhsAB, 1, nz, e), r2 = -(0.5 + eps) * DV2(m.UV_rhsAB, 2, nz, e);
-  double p0 = -(D_G * m.eta_n[n1] + 0.0 + 0.0), p1 = -(D_G * m.eta_n[n2] + 0.0 + 0.0), p2 = -(D_G * m.eta_n[n3] + 0.0 + 0.0);
+  double p0 = surf_pre(m, n1), p1 = surf_pre(m, n2), p2 = surf_pre(m, n3);
   double ff = m.coriolis[e] * ar;
   double Fx = DGS(1, e) * p0 + DGS(2, e) * p1 + DGS(3, e) * p2;
   double Fy = DGS(4, e) * p0 + DGS(5, e) * p1 + DGS(6, e) * p2;

@@ -20,7 +20,9 @@ module fesom_gpu_shim
   use g_PARSUP
   use g_config
   use g_forcing_arrays, only: real_salt_flux, sw_3d
-  use i_ARRAYS, only: u_ice, v_ice, a_ice
+  use i_ARRAYS, only: u_ice, v_ice, a_ice, m_ice, m_snow
+  use g_forcing_arrays, only: press_air
+  use g_sbf, only: l_mslp
   implicit none
   private
   public :: fesom_gpu_setup, oce_timestep_ale_gpu, fesom_gpu_fetch_state, fesom_gpu_push_state, fesom_gpu_shutdown, fesom_gpu_profile
@@ -68,6 +70,8 @@ module fesom_gpu_shim
      integer(c_int) :: use_kpp_nonlclflx, ref_sss_local
      real(c_double) :: ref_sss
      integer(c_int) :: smooth_bh_tra, double_diffusion
+     integer(c_int) :: use_floatice, l_mslp, use_global_tides
+     real(c_double) :: max_ice_loading
   end type
   type, bind(C) :: fesom_state_desc
      type(c_ptr) :: tr_arr, tr_arr_old, UV, UV_rhsAB, eta_n, d_eta, ssh_rhs, ssh_rhs_old, hbar, hbar_old, dhe, hnode, hnode_new, &
@@ -78,7 +82,7 @@ module fesom_gpu_shim
      type(c_funptr) :: exchange, allreduce_sum
   end type
   type, bind(C) :: fesom_forcing_desc
-     type(c_ptr) :: stress_surf, heat_flux, water_flux, virtual_salt, relax_salt, real_salt_flux, stress_atmoce_x, stress_atmoce_y, sw_3d, u_ice, v_ice, a_ice
+     type(c_ptr) :: stress_surf, heat_flux, water_flux, virtual_salt, relax_salt, real_salt_flux, stress_atmoce_x, stress_atmoce_y, sw_3d, m_ice, m_snow, press_air, ssh_gp, u_ice, v_ice, a_ice
   end type
 
   interface
@@ -298,8 +302,6 @@ contains
     end if
 
     call refuse(use_cavity .or. use_cavity_partial_cell, 'use_cavity / use_cavity_partial_cell (ice-shelf cavities)')
-    call refuse(use_floatice, 'use_floatice (ice and snow load in the sea-surface slope, oce_ale_vel_rhs.F90:41)')
-    call refuse(use_global_tides, 'use_global_tides (tidal potential in compute_vel_rhs, oce_ale_vel_rhs.F90:92)')
     call refuse(SPP, 'SPP (salt plume parameterization, oce_ale_tracer.F90:120)')
     call refuse(use_kpp_nonlclflx .and. mix_scheme_nmb /= 1, 'use_kpp_nonlclflx with a mixing scheme other than KPP (oce_ale_tracer.F90:725)')
     call refuse(clim_relax > 1.0e-8_WP .and. .not. toy_ocean, 'clim_relax > 0 (relax_to_clim, oce_tracer_mod.F90:99)')
@@ -357,6 +359,8 @@ contains
     p%use_momix = l2i(use_momix); p%momix_lat = momix_lat; p%momix_kv = momix_kv
     p%use_kpp_nonlclflx = l2i(use_kpp_nonlclflx); p%ref_sss_local = l2i(ref_sss_local); p%ref_sss = ref_sss
     p%double_diffusion = l2i(double_diffusion); p%smooth_bh_tra = l2i(smooth_bh_tra)
+    p%use_floatice = l2i(use_floatice .and. .not. trim(which_ALE)=='linfs'); p%l_mslp = l2i(l_mslp); p%use_global_tides = l2i(use_global_tides)
+    p%max_ice_loading = max_ice_loading
     p%solver_precond = 1; p%solver_xinv_its = 0     ! explicit-inverse preconditioner where it fits (pi), library default iterations
 
     transport%ctx = c_null_ptr
@@ -390,6 +394,12 @@ contains
     end if
     f%sw_3d = c_null_ptr
     if (use_sw_pene .and. allocated(sw_3d)) f%sw_3d = ar(sw_3d)
+    f%m_ice = c_null_ptr; f%m_snow = c_null_ptr; f%press_air = c_null_ptr; f%ssh_gp = c_null_ptr
+    if (use_floatice .and. allocated(m_ice)) then
+       f%m_ice = ar(m_ice); f%m_snow = ar(m_snow)
+    end if
+    if (l_mslp .and. allocated(press_air)) f%press_air = ar(press_air)
+    if (use_global_tides .and. allocated(ssh_gp)) f%ssh_gp = ar(ssh_gp)
     f%u_ice = c_null_ptr; f%v_ice = c_null_ptr; f%a_ice = c_null_ptr
     if (use_momix .and. allocated(a_ice)) then
        f%u_ice = ar(u_ice); f%v_ice = ar(v_ice); f%a_ice = ar(a_ice)

@@ -83,6 +83,15 @@ def analytic_ice(mesh):
     return {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in f.items()}
 
 
+def analytic_surface_potentials(mesh):
+    """Analytic ice / snow thickness, air pressure and tidal potential for the surface pressure gradient of compute_vel_rhs (use_floatice, l_mslp,
+    use_global_tides).  Same formulas as the reference harness (oracle/ref/driver.F90)."""
+    lon, lat = mesh.geo_coord_nod2D[:, 0], mesh.geo_coord_nod2D[:, 1]
+    mi = np.maximum(0.0, 12.0 * (np.sin(lat) * np.sin(lat) - 0.55)) * (1.0 + 0.5 * np.cos(2.0 * lon))
+    f = {"m_ice": mi, "m_snow": 0.2 * mi, "press_air": 101325.0 + 1500.0 * np.sin(2.0 * lon + 0.5) * np.cos(lat), "ssh_gp": 2.5 * np.sin(2.0 * lon) * np.cos(lat) * np.cos(lat)}
+    return {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in f.items()}
+
+
 def analytic_sw_3d(mesh, heat_flux):
     """Penetrating short-wave flux / vcpw [K m/s] (nl, N) for use_sw_pene: half of the positive part of `heat_flux`, decaying
     over ~15 m; +,-,*,/ only, the same operations as the reference harness (bit-identical values)."""

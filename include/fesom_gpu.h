@@ -148,6 +148,11 @@ typedef struct fesom_params {
   int    smooth_bh_tra;      /* biharmonic diffusion of the tracers applied as a filter at the end of diff_tracers_ale (diff_part_bh, oce_ale_tracer.F90:1081-1150;
                                 it uses the momentum coefficients gamma0 / gamma1 / gamma2) */
   int    double_diffusion;   /* KPP: salt fingering / diffusive convection added to the interior diffusivities (ddmix, oce_ale_mixing_kpp.F90:857-934) */
+  /* potentials beside g*eta_n in the surface pressure gradient of compute_vel_rhs (oce_ale_vel_rhs.F90:52-76); the nodal arrays come with the forcing */
+  int    use_floatice;       /* ice + snow load g*min((m_ice*rhoice + m_snow*rhosno)/rhowat, max_ice_loading); the reference applies it unless which_ALE = 'linfs' */
+  int    l_mslp;             /* atmospheric pressure press_air / 1000 */
+  int    use_global_tides;   /* tidal potential ssh_gp (gen_modules_gpot.F90) */
+  double max_ice_loading;    /* namelist.config &ale_def (5.0) */
 } fesom_params;
 
 /* ---- prognostic state = restart set (io_restart.F90:99-155) + ALE thickness arrays -- */
@@ -172,6 +177,9 @@ typedef struct fesom_forcing_desc {
   const double *heat_flux, *water_flux, *virtual_salt, *relax_salt, *real_salt_flux; /* (N) */
   const double *stress_atmoce_x, *stress_atmoce_y;   /* (N) wind stress at nodes (KPP friction velocity, oce_ale_mixing_kpp.F90:341) */
   const double *sw_3d;           /* (nl,N) penetrating short-wave flux / vcpw [K m/s], positive down (gen_modules_forcing.F90:76); use_sw_pene only */
+  const double *m_ice, *m_snow;  /* (N) ice and snow thickness of i_ARRAYS; use_floatice only */
+  const double *press_air;       /* (N) g_forcing_arrays; l_mslp only */
+  const double *ssh_gp;          /* (N) o_ARRAYS; use_global_tides only */
   const double *u_ice, *v_ice, *a_ice;   /* (N) ice velocity and concentration of i_ARRAYS: the turbulent-kinetic-energy source of mo_length (oce_mo_conv.F90:36-39); use_momix only */
 } fesom_forcing_desc;
 

@@ -29,6 +29,7 @@ typedef struct {
   /* node 2D */
   double *eta_n, *d_eta, *ssh_rhs, *ssh_rhs_old, *hbar, *hbar_old, *MLD1, *MLD2;
   double *heat_flux, *water_flux, *virtual_salt, *relax_salt, *real_salt_flux;
+  double *m_ice, *m_snow, *press_air, *ssh_gp;   /* use_floatice / l_mslp / use_global_tides: surface potentials of compute_vel_rhs (N) */
   double *u_ice, *v_ice, *a_ice, *mixlength;     /* use_momix: ice state (input) and the Monin-Obukhov mixing length (N), kept from step to step */
   /* elem */
   double *UV, *UV_rhs, *UV_rhsAB, *tr_xy, *U_b, *fct_ebnd;  /* (2,nl-1,E) */

@@ -41,7 +41,7 @@ int orc_init(const fesom_mesh_desc *m, const fesom_params *p) {
   R(U_c, 2 * n1 * N);
   R(eta_n, N); R(d_eta, N); R(ssh_rhs, N); R(ssh_rhs_old, N); R(hbar, N); R(hbar_old, N); R(MLD1, N); R(MLD2, N);
   R(heat_flux, N); R(water_flux, N); R(virtual_salt, N); R(relax_salt, N); R(real_salt_flux, N);
-  R(u_ice, N); R(v_ice, N); R(a_ice, N); R(mixlength, N);
+  R(u_ice, N); R(v_ice, N); R(a_ice, N); R(mixlength, N); R(m_ice, N); R(m_snow, N); R(press_air, N); R(ssh_gp, N);
   R(UV, 2 * n1 * E); R(UV_rhs, 2 * n1 * E); R(UV_rhsAB, 2 * n1 * E); R(tr_xy, 2 * n1 * E); R(U_b, 2 * n1 * E); R(fct_ebnd, 2 * n1 * E);
   R(pgf_x, n1 * E); R(pgf_y, n1 * E); R(helem, n1 * E); R(Av, nl * E); R(dhe, E); R(stress_surf, 2 * E);
   R(Visc, n1 * E); R(vorticity, n1 * N); R(leith_aux, n1 * N); R(KE_node, n1 * N);

@@ -501,9 +501,13 @@ void orc_compute_vel_rhs(void) {
       V2(C_.UV_rhs, 2, nz, e) = -(0.5 + eps) * V2(C_.UV_rhsAB, 2, nz, e);
     }
     double pre[3];
-    for (int k = 0; k < 3; k++) {
-      double p_eta = G_ACC * C_.eta_n[EN(k + 1, e) - 1];
-      pre[k] = -(p_eta + 0.0 + 0.0);
+    for (int k = 0; k < 3; k++) {                       /* surface potentials, src/oce_ale_vel_rhs.F90:52-76 */
+      const int n = EN(k + 1, e) - 1;
+      double p_eta = G_ACC * C_.eta_n[n], p_ice = 0.0, p_air = 0.0;
+      if (C_.p.use_floatice) { p_ice = (C_.m_ice[n] * 910. + C_.m_snow[n] * 290.) * (1. / 1025.); p_ice = G_ACC * dmin(p_ice, C_.p.max_ice_loading); }
+      if (C_.p.l_mslp) p_air = C_.press_air[n] / 1000;
+      pre[k] = -(p_eta + p_ice + p_air);
+      if (C_.p.use_global_tides) pre[k] = pre[k] - C_.ssh_gp[n];
     }
     double ff = C_.m.coriolis[e - 1] * C_.m.elem_area[e - 1];
     double Fx = GS(1, e) * pre[0] + GS(2, e) * pre[1] + GS(3, e) * pre[2];

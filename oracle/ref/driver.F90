@@ -82,6 +82,7 @@ program oracle_driver
   use g_comm_auto
   use g_forcing_param
   use g_forcing_arrays
+  use g_sbf, only: l_mslp
   use i_ARRAYS
   use i_PARAM
   use g_ic3d
@@ -101,13 +102,13 @@ program oracle_driver
   character(len=16) :: mode
   character(len=256) :: dump_dir
   integer :: dump_steps(64), ndump
-  logical :: dump_mesh, do_mean, debug, synth_forcing, step_info, gpu_profile, ice_adv
+  logical :: dump_mesh, do_mean, debug, synth_forcing, step_info, gpu_profile, ice_adv, mslp, tides
   real(kind=WP) :: flon, flat
   integer :: fel(3)
   real(kind=WP) :: t0, t1, tloop
   character(len=64) :: tag
   namelist /clockinit/ timenew, daynew, yearnew
-  namelist /oracle/ nsteps, mode, dump_dir, dump_steps, dump_mesh, do_mean, debug, synth_forcing, step_info, gpu_profile, ice_adv
+  namelist /oracle/ nsteps, mode, dump_dir, dump_steps, dump_mesh, do_mean, debug, synth_forcing, step_info, gpu_profile, ice_adv, mslp, tides
   ! running sums for the fcheck-style known answer (setups/test_souf/setup.yml:82-88)
   real(kind=WP), allocatable :: mT(:,:), mS(:,:), mU(:,:), mV(:,:)
 
@@ -136,12 +137,13 @@ program oracle_driver
   read (20,NML=oce_tra)
   read (20,NML=oce_init3d)
   close (20)
-  nsteps=1; mode='step'; dump_dir='dumps'; dump_steps=-1; dump_mesh=.false.; do_mean=.false.; debug=.false.; synth_forcing=.false.; step_info=.false.; gpu_profile=.false.; ice_adv=.false.
+  nsteps=1; mode='step'; dump_dir='dumps'; dump_steps=-1; dump_mesh=.false.; do_mean=.false.; debug=.false.; synth_forcing=.false.; step_info=.false.; gpu_profile=.false.; ice_adv=.false.; mslp=.false.; tides=.false.
   open (20,file='namelist.oracle')
   read (20,NML=oracle)
   close (20)
   r_restart=.false.
   mstep=0
+  if (tides) use_global_tides=.true.      ! (a module variable of o_PARAM that no namelist of the reference holds; array_setup allocates ssh_gp with it)
   if (trim(mode)=='ice') whichEVP=1       ! mesh_setup allocates bc_index_nod2D only for the modified EVP solvers (oce_mesh.F90:2404-2413)
 
   call mesh_setup(mesh)
@@ -195,6 +197,25 @@ program oracle_driver
         flon=mesh%geo_coord_nod2D(1,i); flat=mesh%geo_coord_nod2D(2,i)
         a_ice(i)=min(1.0_WP, max(0.0_WP, -0.9_WP-1.6_WP*sin(flat)+0.25_WP*cos(3.0_WP*flon)))
         u_ice(i)=0.08_WP*sin(flon)*cos(flat); v_ice(i)=0.05_WP*cos(2.0_WP*flon)
+     end do
+  end if
+
+  if (trim(mode)/='ice' .and. (use_floatice .or. use_global_tides .or. mslp)) then
+     ! the potentials beside g*eta in the surface pressure gradient of compute_vel_rhs (src/oce_ale_vel_rhs.F90:52-76): the harness has no ice model, no
+     ! atmospheric forcing reader and no tidal module; it fills their arrays with analytic fields (its own choice), constant in time
+     if (use_floatice .and. .not. allocated(m_ice)) allocate(m_ice(myDim_nod2D+eDim_nod2D), m_snow(myDim_nod2D+eDim_nod2D))
+     if (mslp) then
+        l_mslp=.true.
+        if (.not. allocated(press_air)) allocate(press_air(myDim_nod2D+eDim_nod2D))
+     end if
+     do i=1, myDim_nod2D+eDim_nod2D
+        flon=mesh%geo_coord_nod2D(1,i); flat=mesh%geo_coord_nod2D(2,i)
+        if (use_floatice) then
+           m_ice(i)=max(0.0_WP, 12.0_WP*(sin(flat)*sin(flat)-0.55_WP))*(1.0_WP+0.5_WP*cos(2.0_WP*flon))     ! up to ~8 m: the max_ice_loading limit acts
+           m_snow(i)=0.2_WP*m_ice(i)
+        end if
+        if (mslp) press_air(i)=101325.0_WP+1500.0_WP*sin(2.0_WP*flon+0.5_WP)*cos(flat)
+        if (use_global_tides) ssh_gp(i)=2.5_WP*sin(2.0_WP*flon)*cos(flat)*cos(flat)
      end do
   end if
 
@@ -327,6 +348,11 @@ contains
     call dump('forcing.heat_flux', heat_flux); call dump('forcing.water_flux', water_flux)
     call dump('forcing.stress_surf', stress_surf)
     if (use_sw_pene .and. allocated(sw_3d)) call dump('forcing.sw_3d', sw_3d)
+    if (use_floatice .and. allocated(m_ice)) then
+       call dump('forcing.m_ice', m_ice); call dump('forcing.m_snow', m_snow)
+    end if
+    if (l_mslp .and. allocated(press_air)) call dump('forcing.press_air', press_air)
+    if (use_global_tides .and. allocated(ssh_gp)) call dump('forcing.ssh_gp', ssh_gp)
     if (use_momix .and. allocated(a_ice)) then
        call dump('forcing.u_ice', u_ice); call dump('forcing.v_ice', v_ice); call dump('forcing.a_ice', a_ice)
     end if

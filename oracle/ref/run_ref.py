@@ -59,7 +59,7 @@ include_fleapyear=.false.
 use_ice=.false.
 use_cavity=.false.
 use_cavity_partial_cell=.false.
-use_floatice=.false.
+use_floatice={use_floatice}
 use_sw_pene={use_sw_pene}
 toy_ocean={toy_ocean}
 which_toy='soufflet'
@@ -177,6 +177,11 @@ CFGS = {
                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                        fer_gm=".false.", redi=".false.", mix_scheme="KPP", k_hor="3000.", surf_relax_s="1.929e-06",
                        balance_salt_water=".true.", synth_forcing=True, use_kpp_nonlclflx=".true."),
+    # the surface potentials of compute_vel_rhs beside g*eta (oce_ale_vel_rhs.F90:52-76): floating ice load, atmospheric pressure, tidal potential (analytic fields)
+    "pi_pp_surfpot": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                       rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                       fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                       balance_salt_water=".true.", synth_forcing=True, use_floatice=".true.", tides=True, mslp=True),     # (use_global_tides is in no namelist of the reference: the harness sets the module variable)
     # smooth_bh_tra = .true.: biharmonic tracer diffusion as a filter (diff_part_bh, oce_ale_tracer.F90:1081-1150)
     "pi_pp_bhtra": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
@@ -364,7 +369,7 @@ def prepare(cfg, np_, tag=""):
                 os.chmod(root, 0o755)
             partition_io.write_dist(cp, np_)
         meshdir = cp
-    open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **dict(dict(use_sw_pene=".false."), **c)))
+    open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **dict(dict(use_sw_pene=".false.", use_floatice=".false."), **c)))
     open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0", visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=".true.", tra_adv_lim="FCT", use_momix=".false.", which_pgf="shchepetkin", mom_adv=2, use_kpp_nonlclflx=".false.", double_diffusion=".false.", smooth_bh_tra=".false."), **c)))
     if c["toy_ocean"] == ".false.":
         from fesom2_amd.synthetic import write_ic_files
@@ -379,7 +384,7 @@ def run(cfg, np_, nsteps, mode="step", dump=(), mean=False, dump_mesh=True, quie
     open(os.path.join(rd, "namelist.oracle"), "w").write(
         f"&oracle\nnsteps={nsteps}\nmode='{mode}'\ndump_dir='dumps'\ndump_steps={ds}\n"
         f"dump_mesh={'.true.' if dump_mesh else '.false.'}\ndo_mean={'.true.' if mean else '.false.'}\n"
-        f"synth_forcing={'.true.' if forcing else '.false.'}\nstep_info={'.true.' if step_info else '.false.'}\ngpu_profile={'.true.' if gpu_profile else '.false.'}\nice_adv={'.true.' if ice_adv else '.false.'}\n/\n")
+        f"synth_forcing={'.true.' if forcing else '.false.'}\nstep_info={'.true.' if step_info else '.false.'}\ngpu_profile={'.true.' if gpu_profile else '.false.'}\nice_adv={'.true.' if ice_adv else '.false.'}\nmslp={'.true.' if CFGS[cfg].get('mslp') else '.false.'}\ntides={'.true.' if CFGS[cfg].get('tides') else '.false.'}\n/\n")
     exe = os.path.join(OUT, exe_name)
     cmd = ["/opt/conda/bin/mpiexec", "-n", str(np_), exe]
     def big_stack():        # the reference keeps (nl, nodes) work arrays on the stack: larger meshes overflow the default 8 MB

@@ -512,6 +512,45 @@ def test_biharmonic_viscosity_chain_bitwise(built, opt):
     gpu.close()
 
 
+def test_surface_potentials_chain_bitwise(built):
+    """use_floatice + l_mslp + use_global_tides in the surface pressure gradient (surf_pre in k_vel_rhs; oracle pinned on the reference run pi_pp_surfpot):
+    HIP == oracle bit for bit after every routine of 3 steps and after 6 further whole steps."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.core import OceanCore
+    from fesom2_amd.synthetic import analytic_ts, analytic_forcing, analytic_surface_potentials
+    from oracle_lib import Oracle
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, use_floatice=True, l_mslp=True, use_global_tides=True)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    gpu, orc = OceanCore(mesh, par), Oracle(mesh, par)
+    gpu.upload_state(st); orc.set_state(st)
+    forcing = dict(analytic_forcing(mesh), **analytic_surface_potentials(mesh))
+    gpu.set_forcing(**forcing)
+    for k, v in forcing.items():
+        orc.set(k, v)
+    failures = []
+    for step in range(1, 4):
+        for routine, arg, fields in full_chain(2):
+            gpu.call(routine, arg); orc.call(routine, arg)
+            for f in fields:
+                ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+                if not ok:
+                    failures.append(f"step {step} {routine}({arg}) {msg}")
+        if failures:
+            break
+    assert not failures, "\n".join(failures[:10])
+    gpu.run_steps(4, 6)
+    for n in range(6):
+        orc.call("step", 4 + n)
+    for f in ("tr_arr", "UV", "eta_n", "hnode", "hbar", "Wvel"):
+        ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+        assert ok, msg
+    gpu.close()
+
+
 def test_biharmonic_tracer_filter_chain_bitwise(built):
     """smooth_bh_tra (diff_part_bh: k_bh1, k_bh2 after k_tr_update, the salinity clamp moved behind them as in the reference); oracle pinned on the reference run
     pi_pp_bhtra: HIP == oracle bit for bit after every routine of 3 steps and after 6 further whole steps."""

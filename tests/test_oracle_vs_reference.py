@@ -310,6 +310,31 @@ def test_oracle_chain_bitwise_cubicspline_pgf(built, cfg, kw):
     assert not np.array_equal(g["s2/pressure_force.pgf_x"], gz["s2/pressure_force.pgf_x"])
 
 
+def test_oracle_chain_bitwise_surface_potentials(built):
+    """use_floatice (ice + snow load, limited by max_ice_loading), l_mslp (atmospheric pressure) and use_global_tides (tidal potential) in the surface pressure
+    gradient of compute_vel_rhs (src/oce_ale_vel_rhs.F90:52-76), with the harness's analytic fields: reference run `pi_pp_surfpot`, every routine of 3 steps bit for bit."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.synthetic import analytic_ts
+    from oracle_lib import Oracle
+    from ref_chain import run_reference_chain
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, use_floatice=True, l_mslp=True, use_global_tides=True)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    orc = Oracle(mesh, par)
+    orc.set_state(st)
+    g = gold("pi_pp_surfpot")
+    for f in FORCING + ("m_ice", "m_snow", "press_air", "ssh_gp"):
+        orc.set(f, g["forcing/" + f])
+    assert (g["forcing/m_ice"] * 910. + g["forcing/m_snow"] * 290.).max() / 1025. > 5.0        # the max_ice_loading limit acts somewhere
+    bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
+    assert not bad, "\n".join(bad[:20])
+    gz = gold("pi_pp_wsplit")
+    assert not np.array_equal(g["s1/compute_vel_rhs.UV_rhs"], gz["s1/compute_vel_rhs.UV_rhs"])
+
+
 def test_oracle_chain_bitwise_biharmonic_tracer_filter(built):
     """smooth_bh_tra = .true. (diff_part_bh, src/oce_ale_tracer.F90:1081-1150, at the end of diff_tracers_ale): reference run `pi_pp_bhtra`, every routine of 3
     routine of step 1 bit for bit.  The reference applies the filter with the halo values of the PREVIOUS exchange (the tracer is exchanged only after
