@@ -275,7 +275,7 @@ const char *fesom_gpu_last_error(void);
  * per neighbour: block of neighbour p = count(p) * values_per_item doubles, blocks consecutive in sPE (send) / rPE (recv)
  * order.  With npes > 1 the step is driven phase by phase through fesom_gpu_call (kernel names "k_*", partitioned SSH solve
  * "ds_*"); the sequence with its exchange points is fesom2_amd/parallel.py. */
-int  fesom_gpu_halo_info(int kind, int *npes, int *mype, int *nr, int *rPE, int *rcnt, int *ns, int *sPE, int *scnt);
+int  fesom_gpu_halo_info(int kind, int *npes, int *mype, int *nr, int *rPE, int *rcnt, int *ns, int *sPE, int *scnt);   /* rPE/rcnt/sPE/scnt: room for npes entries each */
 int  fesom_gpu_halo_pack(int kind, int nfields, const char *const *names, void **send_dev, void **recv_dev, int *values_per_item);
 int  fesom_gpu_halo_unpack(int kind, int nfields, const char *const *names);
 int  fesom_gpu_copy(void *dst, const void *src, long long bytes, int dir);   /* 0: device->host, 1: host->device */
