@@ -214,6 +214,7 @@ void enqueue_step(hipStream_t s, int first_step, int n) {
   launch_tracer(m, s, -1);                   // solve_tracers_ale, all tracers per launch
   if (gm) launch_named_gm(m, s, "bolus_remove");                            // :165-169
   if (toy) for (int tr = 0; tr < m.ntr; tr++) launch_named_toy(m, s, "relax_zonal_temp");   // once per tracer, oce_ale_tracer.F90:150
+  else if (m.p.clim_relax > 1.0e-8) launch_named_tra(m, s, "relax_to_clim", 0);
   launch_thickness(m, s);                    // update_thickness_ale
 }
 
@@ -314,6 +315,7 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   K(s0, "k_tr_update", 0);                         // incl. the Thomas sweep
   if (m.p.smooth_bh_tra) { K(s0, "k_bh1", 0); K(s0, "k_bh2", 0); }      // diff_part_bh at the end of diff_tracers_ale
   if (toy) for (int tr = 0; tr < m.ntr; tr++) launch_named_toy(m, s0, "relax_zonal_temp");   // once per tracer
+  else if (m.p.clim_relax > 1.0e-8) launch_named_tra(m, s0, "relax_to_clim", 0);
   if (gm) launch_named_gm(m, s0, "bolus_remove");                          // :165-169
   d.dep(s0, s1); d.dep(s0, s2); d.dep(s0, s3);
   launch_thickness(m, s0);
@@ -611,6 +613,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     m.kpp_wmt = dev_upload(wmt); m.kpp_wst = dev_upload(wst);
   }
   if (par->toy_soufflet) { F(Tclim, n1 * N); F(Uclim, n1 * E); F(toy_zvel, n1 * 100); F(toy_ztem, n1 * 100); }
+  else if (par->clim_relax > 1.0e-8) { F(Tclim, n1 * N); F(Sclim, n1 * N); F(relax2clim, N); }
   F(sv_vals, 16 * (N + 64)); F(sv_dinv, N + 64); F(sv_b, N + 64); F(sv_r, N + 64); F(sv_r0, N + 64); F(sv_p, N + 64); F(sv_v, N + 64); F(sv_s, N + 64); F(sv_t, N + 64);
   F(sv_ph, N + 64); F(sv_x0, 16 * (N + 64)); F(sv_snap, N);
   F(sv_part, 8 * ((N + 255) / 256 + 1)); F(sv_red, 8); F(sv_kry, 48);
@@ -974,6 +977,7 @@ int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
   S.c("k_fct_edge_limit", 0); S.c("k_tr_update", 0);
   if (p.smooth_bh_tra) { S.c("k_bh1", 0); S.X(0, {"bh_tmp"}); S.c("k_bh2", 0); }     // (the tracer halo still holds the values of the previous exchange, as in the reference)
   if (toy) for (int tr = 0; tr < G.m.ntr; tr++) S.c("relax_zonal_temp");     // once per tracer of the loop, always on tracer 1 (oce_ale_tracer.F90:150)
+  else if (p.clim_relax > 1.0e-8) S.c("relax_to_clim", 0);
   S.X(0, {"tr_arr"});
   if (p.Fer_GM) S.c("bolus_remove");
   S.c("k_thick_node"); S.c("k_thick_elem");

@@ -74,6 +74,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   double kpp_deltaz, kpp_deltau, kpp_Vtc, kpp_cg;
   // Soufflet toy channel (kernels_toy.hip): relaxation targets, zonal means per (level, latitude bin), static bin tables
   double *Tclim, *Uclim, *toy_zvel, *toy_ztem;
+  double *Sclim, *relax2clim;              // clim_relax > 0: salinity climatology (nl-1, N) and the relaxation rate (N); Tclim above
   const double *toy_znum, *toy_e_a, *toy_n_a;
   const int *toy_bptr, *toy_bidx, *toy_e_nn, *toy_n_nn;
   // solver workspace

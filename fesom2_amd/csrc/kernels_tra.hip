@@ -763,6 +763,8 @@ __device__ __forceinline__ double tru_rhs(const DM &m, const TruCol &k, int tr, 
   }
   return rhs;
 }
+// the reference clamps the salinity after the tracer loop (oce_ale_tracer.F90:176-198): when a filter or a relaxation follows the implicit solve, the clamp moves behind it
+__device__ __forceinline__ bool defer_clamp(const DM &m) { return m.p.smooth_bh_tra || (m.p.clim_relax > 1.0e-8 && !m.p.toy_soufflet); }
 __device__ __forceinline__ double tru_clamp(double T, int tr) {           // salinity clamp (oce_ale_tracer.F90:176-198)
   if (tr == 1) { if (T > 45.0) T = 45.0; if (T < 3.0) T = 3.0; }
   return T;
@@ -780,6 +782,16 @@ __device__ __forceinline__ bool bh_edge(const DM &m, int ed, int nz, double &vi)
   vi = u1 * u1 + v1 * v1;
   vi = sqrt(dmax_(m.p.gamma0, dmax_(m.p.gamma1 * sqrt(vi), m.p.gamma2 * vi)) * len);
   return true;
+}
+// relax_to_clim (clim_relax > 0, src/oce_tracer_mod.F90:86-121) after diff_tracers_ale: T and S of the owned nodes towards the climatology at the nodal rate
+// relax2clim; the salinity clamp follows it as in the reference.  grid.y = tracer (0, 1).
+__global__ void __launch_bounds__(BLOCK) k_relax_clim(DM m, int tr0) {
+  const int tr = tr0 + blockIdx.y, n = col_id(), nz = lane_id() + 1;
+  if (n >= m.myN || nz < m.ulev_n[n] || nz > m.nlev_n[n] - 1) return;
+  const double *cl = tr == 0 ? m.Tclim : m.Sclim;
+  double T = DTR(m.tr_arr, nz, n, tr);
+  T = T + m.relax2clim[n] * m.p.dt * (DA2(cl, nz, n) - T);
+  DTR(m.tr_arr, nz, n, tr) = tru_clamp(T, tr);
 }
 __global__ void __launch_bounds__(BLOCK) k_bh1(DM m, int tr0) {
   const int tr = tr0 + blockIdx.y, n = col_id(), nz = lane_id() + 1;
@@ -806,7 +818,7 @@ __global__ void __launch_bounds__(BLOCK) k_bh2(DM m, int tr0) {
     const double tt = -(DTR(m.bh_tmp, nz, m.edges[2 * ed], tr) - DTR(m.bh_tmp, nz, m.edges[2 * ed + 1], tr)) * vi * m.p.dt;
     T = m.ne_sgn[q] > 0 ? T - tt / ar : T + tt / ar;
   }
-  if (nz >= m.ulev_n[n] && nz <= m.nlev_n[n] - 1) T = tru_clamp(T, tr);
+  if (nz >= m.ulev_n[n] && nz <= m.nlev_n[n] - 1 && !(m.p.clim_relax > 1.0e-8 && !m.p.toy_soufflet)) T = tru_clamp(T, tr);     // (with relax_to_clim the clamp follows that)
   DTR(m.tr_arr, nz, n, tr) = T;
 }
 template <bool REDI, int NT, int COLS, int WAVES>
@@ -845,7 +857,7 @@ __global__ void __launch_bounds__(WAVE * WAVES, (WAVES == 8) ? 4 : 2) k_tr_updat
         tile.put(ci, k.valid, k.nzmin, k.nzmax - 1, k.a, k.b, k.c, rhs[0], NT == 2 ? rhs[NT - 1] : 0.0);
       } else {
 #pragma unroll
-        for (int t = 0; t < NT; t++) if (k.wet && trA + t < m.ntr) DTR(m.tr_arr, nz, k.n, trA + t) = m.p.smooth_bh_tra ? Ts[t] : tru_clamp(Ts[t], trA + t);
+        for (int t = 0; t < NT; t++) if (k.wet && trA + t < m.ntr) DTR(m.tr_arr, nz, k.n, trA + t) = defer_clamp(m) ? Ts[t] : tru_clamp(Ts[t], trA + t);
       }
     } else {
       // several columns per wave: the column's coefficients first, then tracer after tracer straight into the tile / memory
@@ -858,7 +870,7 @@ __global__ void __launch_bounds__(WAVE * WAVES, (WAVES == 8) ? 4 : 2) k_tr_updat
           if (m.p.tra_adv_lim) tru_hor<false, TRU_MAXD_TILE, true>(m, k, trA + t, T, del);
           else if (tru_hor<true, TRU_MAXD_TILE>(m, k, trA + t, T, del)) tru_hor<false, TRU_MAXD_TILE>(m, k, trA + t, T, del);
           tru_fin<REDI>(m, k, trA + t, T, del);
-          if (k.wet) DTR(m.tr_arr, nz, k.n, trA + t) = (impl || m.p.smooth_bh_tra) ? T : tru_clamp(T, trA + t);    // T*: picked up again after the sweep
+          if (k.wet) DTR(m.tr_arr, nz, k.n, trA + t) = (impl || defer_clamp(m)) ? T : tru_clamp(T, trA + t);    // T*: picked up again after the sweep
           if (impl) { tile.get_abc(ci, k.a, k.b, k.c); r = tru_rhs(m, k, trA + t, T); }      // (a, b, c back from the tile: not kept in registers across the gathers)
         }
         if (impl) tile.put_rhs(ci, t, r);
@@ -880,7 +892,7 @@ __global__ void __launch_bounds__(WAVE * WAVES, (WAVES == 8) ? 4 : 2) k_tr_updat
     for (int t = 0; t < NT; t++)
       if (wet && trA + t < m.ntr) {                        // tr_arr = T* + dT ; salinity clamp
         double T = SINGLE ? Ts[t] : DTR(m.tr_arr, nz, n, trA + t);
-        DTR(m.tr_arr, nz, n, trA + t) = m.p.smooth_bh_tra ? T + dT[t] : tru_clamp(T + dT[t], trA + t);
+        DTR(m.tr_arr, nz, n, trA + t) = defer_clamp(m) ? T + dT[t] : tru_clamp(T + dT[t], trA + t);
       }
   }
 }
@@ -958,6 +970,11 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
       hipLaunchKernelGGL(k_bh1, dim3(nblocks(m.myN), tr < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m, tr < 0 ? 0 : tr);
       hipLaunchKernelGGL(k_bh2, dim3(nblocks(m.myN), tr < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m, tr < 0 ? 0 : tr);
     }
+    return 0;
+  }
+  if (!strcmp(name, "relax_to_clim")) {
+    if (m.p.clim_relax > 1.0e-8 && !m.p.toy_soufflet && tr < 2)           // tr < 0: T and S in one launch
+      hipLaunchKernelGGL(k_relax_clim, dim3(nblocks(m.myN), tr < 0 ? (m.ntr < 2 ? m.ntr : 2) : 1), dim3(BLOCK), 0, s, m, tr < 0 ? 0 : tr);
     return 0;
   }
   if (!strcmp(name, "salinity_clamp")) return 0;

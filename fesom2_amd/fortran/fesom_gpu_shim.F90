@@ -71,7 +71,7 @@ module fesom_gpu_shim
      real(c_double) :: ref_sss
      integer(c_int) :: smooth_bh_tra, double_diffusion
      integer(c_int) :: use_floatice, l_mslp, use_global_tides
-     real(c_double) :: max_ice_loading
+     real(c_double) :: max_ice_loading, clim_relax
   end type
   type, bind(C) :: fesom_state_desc
      type(c_ptr) :: tr_arr, tr_arr_old, UV, UV_rhsAB, eta_n, d_eta, ssh_rhs, ssh_rhs_old, hbar, hbar_old, dhe, hnode, hnode_new, &
@@ -304,7 +304,6 @@ contains
     call refuse(use_cavity .or. use_cavity_partial_cell, 'use_cavity / use_cavity_partial_cell (ice-shelf cavities)')
     call refuse(SPP, 'SPP (salt plume parameterization, oce_ale_tracer.F90:120)')
     call refuse(use_kpp_nonlclflx .and. mix_scheme_nmb /= 1, 'use_kpp_nonlclflx with a mixing scheme other than KPP (oce_ale_tracer.F90:725)')
-    call refuse(clim_relax > 1.0e-8_WP .and. .not. toy_ocean, 'clim_relax > 0 (relax_to_clim, oce_tracer_mod.F90:99)')
     call refuse(use_momix .and. .not. allocated(mixlength), 'use_momix without the ice arrays (the reference allocates mo / mixlength only with use_ice, oce_setup_step.F90:218)')
     call status_check
 
@@ -360,7 +359,7 @@ contains
     p%use_kpp_nonlclflx = l2i(use_kpp_nonlclflx); p%ref_sss_local = l2i(ref_sss_local); p%ref_sss = ref_sss
     p%double_diffusion = l2i(double_diffusion); p%smooth_bh_tra = l2i(smooth_bh_tra)
     p%use_floatice = l2i(use_floatice .and. .not. trim(which_ALE)=='linfs'); p%l_mslp = l2i(l_mslp); p%use_global_tides = l2i(use_global_tides)
-    p%max_ice_loading = max_ice_loading
+    p%max_ice_loading = max_ice_loading; p%clim_relax = clim_relax
     p%solver_precond = 1; p%solver_xinv_its = 0     ! explicit-inverse preconditioner where it fits (pi), library default iterations
 
     transport%ctx = c_null_ptr
@@ -372,6 +371,11 @@ contains
     call state_desc(mesh, st)
     call check(c_fesom_gpu_upload_state(st), 'fesom_gpu_upload_state')
     if (use_momix .and. allocated(mixlength)) call check(c_fesom_gpu_set_field('mixlength'//c_null_char, ar(mixlength), int(size(mixlength), c_long_long)), 'fesom_gpu_set_field(mixlength)')
+    if (clim_relax > 1.0e-8_WP .and. .not. toy_ocean) then        ! relax_to_clim: the static climatology and the nodal rate
+       call check(c_fesom_gpu_set_field('Tclim'//c_null_char, ar(Tclim), int(size(Tclim), c_long_long)), 'fesom_gpu_set_field(Tclim)')
+       call check(c_fesom_gpu_set_field('Sclim'//c_null_char, ar(Sclim), int(size(Sclim), c_long_long)), 'fesom_gpu_set_field(Sclim)')
+       call check(c_fesom_gpu_set_field('relax2clim'//c_null_char, ar(relax2clim), int(size(relax2clim), c_long_long)), 'fesom_gpu_set_field(relax2clim)')
+    end if
     call status_check
     is_setup = .true.
   end subroutine

@@ -110,6 +110,8 @@ def run_step(core, par, X, solve, first, probe=None, n=1, zonal=None):
     if p.toy_soufflet:
         for _ in range(p.num_tracers):                # once per tracer of the loop, always on tracer 1 (oce_ale_tracer.F90:150)
             c("relax_zonal_temp")
+    elif p.clim_relax > 1.0e-8:
+        c("relax_to_clim", 0)
     X(NOD, ["tr_arr"]); P("tracers")
     if p.Fer_GM:
         c("bolus_remove")

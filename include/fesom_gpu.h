@@ -153,6 +153,8 @@ typedef struct fesom_params {
   int    l_mslp;             /* atmospheric pressure press_air / 1000 */
   int    use_global_tides;   /* tidal potential ssh_gp (gen_modules_gpot.F90) */
   double max_ice_loading;    /* namelist.config &ale_def (5.0) */
+  double clim_relax;         /* > 1e-8: relax_to_clim after diff_tracers_ale (oce_tracer_mod.F90:86-121): T, S += relax2clim(n) * dt * (clim - tracer); the static
+                                arrays Tclim, Sclim (nl-1,N) and relax2clim (N) are handed over once with fesom_gpu_set_field */
 } fesom_params;
 
 /* ---- prognostic state = restart set (io_restart.F90:99-155) + ALE thickness arrays -- */

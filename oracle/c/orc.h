@@ -22,6 +22,7 @@ typedef struct {
   double *tr_arr, *tr_arr_old, *density_m_rho0, *density_ref, *hnode, *hnode_new, *Z_3d_n, *sw_alpha, *sw_beta;
   double *del_ttf, *del_ttf_advhoriz, *del_ttf_advvert, *fct_LO, *fct_ttf_max, *fct_ttf_min, *fct_plus, *fct_minus;
   double *Ki, *Tclim, *Sclim;
+  double *relax2clim;                            /* clim_relax > 0: nodal relaxation rate (N) */
   /* node (nl) */
   double *bvfreq, *hpressure, *zbar_3d_n, *Wvel, *Wvel_e, *Wvel_i, *CFL_z, *Kv, *tr_z, *adv_flux_ver, *dbsfc;
   /* node vectors */
@@ -137,6 +138,7 @@ void orc_compute_zonal_mean_ini(void);
 void orc_compute_zonal_mean(void);
 void orc_relax_zonal_vel(void);
 void orc_relax_zonal_temp(void);
+void orc_relax_to_clim(int tr);
 void orc_toy_set_partition(const int *owner, int nranks);
 void orc_step(int n);
 #endif

@@ -34,7 +34,7 @@ int orc_init(const fesom_mesh_desc *m, const fesom_params *p) {
   R(density_m_rho0, n1 * N); R(density_ref, n1 * N); R(hnode, n1 * N); R(hnode_new, n1 * N); R(Z_3d_n, n1 * N);
   R(sw_alpha, n1 * N); R(sw_beta, n1 * N); R(del_ttf, n1 * N); R(del_ttf_advhoriz, n1 * N); R(del_ttf_advvert, n1 * N);
   R(fct_LO, n1 * N); R(fct_ttf_max, n1 * N); R(fct_ttf_min, n1 * N); R(fct_plus, n1 * N); R(fct_minus, n1 * N);
-  R(Ki, n1 * N); R(Tclim, n1 * N); R(Sclim, n1 * N);
+  R(Ki, n1 * N); R(Tclim, n1 * N); R(Sclim, n1 * N); R(relax2clim, N);
   R(bvfreq, nl * N); R(hpressure, nl * N); R(zbar_3d_n, nl * N); R(Wvel, nl * N); R(Wvel_e, nl * N); R(Wvel_i, nl * N);
   R(CFL_z, nl * N); R(Kv, nl * N); R(tr_z, nl * N); R(adv_flux_ver, nl * N); R(dbsfc, nl * N);
   R(Unode, 2 * n1 * N); R(Unode_rhs, 2 * n1 * N); R(sigma_xy, 2 * n1 * N); R(neutral_slope, 3 * n1 * N); R(slope_tapered, 3 * n1 * N);
@@ -313,6 +313,7 @@ void orc_step(int n) {
     orc_adv_tracers_ale(tr);
     orc_diff_tracers_ale(tr);
     if (C_.p.toy_soufflet) orc_relax_zonal_temp();                       /* oce_ale_tracer.F90:150-151, once per tracer */
+    else orc_relax_to_clim(tr);
   }
   if (C_.p.Fer_GM) orc_bolus_remove();                                  /* oce_ale_tracer.F90:165-169 */
   orc_salinity_clamp();
@@ -328,7 +329,7 @@ int orc_call(const char *name, int arg) {
   CALL0(compute_hbar_ale) CALL0(eta_update) CALL0(vert_vel_ale) CALL1(init_tracers_AB) CALL1(adv_tracers_ale)
   CALL1(diff_tracers_ale) CALL0(salinity_clamp) CALL0(update_thickness_ale) CALL1(step)
   CALL0(init_Redi_GM) CALL0(fer_solve_Gamma) CALL0(fer_gamma2vel) CALL0(fer_wvel) CALL0(bolus_add) CALL0(bolus_remove)
-  CALL0(compute_zonal_mean_ini) CALL0(compute_zonal_mean) CALL0(relax_zonal_vel) CALL0(relax_zonal_temp)
+  CALL0(compute_zonal_mean_ini) CALL0(compute_zonal_mean) CALL0(relax_zonal_vel) CALL0(relax_zonal_temp) CALL1(relax_to_clim)
   fprintf(stderr, "orc_call: unknown routine %s\n", name);
   return 1;
 }

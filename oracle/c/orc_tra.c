@@ -711,6 +711,15 @@ void orc_diff_tracers_ale(int tr) {
   if (C_.p.smooth_bh_tra) diff_part_bh(tr);
 }
 
+/* relax_to_clim: src/oce_tracer_mod.F90:86-121 (clim_relax > 0; T towards Tclim, S towards Sclim at the nodal rate relax2clim) */
+void orc_relax_to_clim(int tr) {
+  if (!(C_.p.clim_relax > 1.0e-8) || tr > 2) return;
+  const double *cl = tr == 1 ? C_.Tclim : C_.Sclim;
+  for (int n = 1; n <= C_.m.myDim_nod2D; n++)
+    for (int nz = ULEVN(n); nz <= NLEVN(n) - 1; nz++)
+      TR(nz, n, tr) = TR(nz, n, tr) + C_.relax2clim[n - 1] * C_.p.dt * (A2(cl, nz, n) - TR(nz, n, tr));
+}
+
 /* solve_tracers_ale tail: salinity clamp, src/oce_ale_tracer.F90:176-198 */
 void orc_salinity_clamp(void) {
   for (int n = 1; n <= C_.N; n++)

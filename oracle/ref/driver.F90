@@ -219,6 +219,15 @@ program oracle_driver
      end do
   end if
 
+  if (clim_relax>1.0e-8_WP .and. .not. toy_ocean) then
+     ! relax_to_clim (src/oce_tracer_mod.F90:86-121): the reference fills relax2clim in its regional initial-state routines (oce_ice_init_state.F90), which the
+     ! harness does not call; an analytic rate instead (its own choice): clim_relax near the poles, zero in the tropics
+     do i=1, myDim_nod2D+eDim_nod2D
+        flat=mesh%geo_coord_nod2D(2,i)
+        relax2clim(i)=clim_relax*max(0.0_WP, 2.0_WP*sin(flat)*sin(flat)-0.5_WP)
+     end do
+  end if
+
   if (dump_mesh) call dump_setup()
 
   if (trim(mode)=='ice') then
@@ -348,6 +357,7 @@ contains
     call dump('forcing.heat_flux', heat_flux); call dump('forcing.water_flux', water_flux)
     call dump('forcing.stress_surf', stress_surf)
     if (use_sw_pene .and. allocated(sw_3d)) call dump('forcing.sw_3d', sw_3d)
+    if (clim_relax>1.0e-8_WP .and. .not. toy_ocean) call dump('forcing.relax2clim', relax2clim)
     if (use_floatice .and. allocated(m_ice)) then
        call dump('forcing.m_ice', m_ice); call dump('forcing.m_snow', m_snow)
     end if

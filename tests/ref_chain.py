@@ -105,6 +105,8 @@ def run_reference_chain(orc, mesh, g, steps=(1, 2, 3), toy=False, skip=(), after
             chk(step, "del_ttf", p + "diff.del_ttf", "n")
             if toy:
                 orc.call("relax_zonal_temp")             # after every tracer of the loop, always on tracer 1
+            elif orc.params.clim_relax > 1.0e-8:
+                orc.call("relax_to_clim", tr)
             chk(step, "tr_arr", p + "end.tr_arr", "n", sub=tr - 1)
         if gm:
             orc.call("bolus_remove")

@@ -512,6 +512,53 @@ def test_biharmonic_viscosity_chain_bitwise(built, opt):
     gpu.close()
 
 
+def test_relax_to_clim_chain_bitwise(built):
+    """clim_relax > 0 (k_relax_clim after the tracer update, the salinity clamp behind it; oracle pinned on the reference run pi_pp_climrelax): HIP == oracle bit
+    for bit after every routine of 3 steps and after 6 further whole steps."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.core import OceanCore
+    from fesom2_amd.synthetic import analytic_ts, analytic_forcing
+    from oracle_lib import Oracle
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, clim_relax=1.1574e-6)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    gpu, orc = OceanCore(mesh, par), Oracle(mesh, par)
+    gpu.upload_state(st); orc.set_state(st)
+    forcing = analytic_forcing(mesh)
+    gpu.set_forcing(**forcing)
+    for k, v in forcing.items():
+        orc.set(k, v)
+    lat = mesh.geo_coord_nod2D[:, 1]
+    clim = {"Tclim": st.tr_arr[0] + 0.5, "Sclim": st.tr_arr[1] - 0.2, "relax2clim": 1.1574e-6 * np.maximum(0.0, 2.0 * np.sin(lat) ** 2 - 0.5)}
+    for k, v in clim.items():
+        gpu.set(k, v); orc.set(k, v)
+    failures = []
+    for step in range(1, 4):
+        for routine, arg, fields in full_chain(2):
+            gpu.call(routine, arg); orc.call(routine, arg)
+            if routine == "diff_tracers_ale":
+                gpu.call("relax_to_clim", arg); orc.call("relax_to_clim", arg)
+            for f in fields:
+                ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+                if not ok:
+                    failures.append(f"step {step} {routine}({arg}) {msg}")
+        if failures:
+            break
+    assert not failures, "\n".join(failures[:10])
+    gpu.run_steps(4, 6)
+    for n in range(6):
+        orc.call("step", 4 + n)
+    for f in ("tr_arr", "UV", "eta_n", "hnode", "hbar", "Wvel"):
+        ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+        assert ok, msg
+    T0 = st.tr_arr[0]
+    assert np.abs(gpu.get("tr_arr", orc.count("tr_arr")).reshape(2, -1, mesh.nl - 1)[0] - T0).max() > 1e-3
+    gpu.close()
+
+
 def test_surface_potentials_chain_bitwise(built):
     """use_floatice + l_mslp + use_global_tides in the surface pressure gradient (surf_pre in k_vel_rhs; oracle pinned on the reference run pi_pp_surfpot):
     HIP == oracle bit for bit after every routine of 3 steps and after 6 further whole steps."""

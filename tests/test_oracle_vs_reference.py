@@ -310,6 +310,31 @@ def test_oracle_chain_bitwise_cubicspline_pgf(built, cfg, kw):
     assert not np.array_equal(g["s2/pressure_force.pgf_x"], gz["s2/pressure_force.pgf_x"])
 
 
+def test_oracle_chain_bitwise_relax_to_clim(built):
+    """clim_relax > 0 (relax_to_clim, src/oce_tracer_mod.F90:86-121; Tclim / Sclim = the initial T / S as ocean_setup sets them, oce_setup_step.F90:480-481; the
+    harness's analytic nodal rate relax2clim): reference run `pi_pp_climrelax`, every routine of 3 steps bit for bit."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.synthetic import analytic_ts
+    from oracle_lib import Oracle
+    from ref_chain import run_reference_chain
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, clim_relax=1.1574e-6)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    orc = Oracle(mesh, par)
+    orc.set_state(st)
+    g = gold("pi_pp_climrelax")
+    for f in FORCING + ("relax2clim",):
+        orc.set(f, g["forcing/" + f])
+    orc.set("Tclim", st.tr_arr[0]); orc.set("Sclim", st.tr_arr[1])
+    bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
+    assert not bad, "\n".join(bad[:20])
+    gz = gold("pi_pp_wsplit")
+    assert not np.array_equal(g["s3/tr1.end.tr_arr"], gz["s3/tr1.end.tr_arr"])
+
+
 def test_oracle_chain_bitwise_surface_potentials(built):
     """use_floatice (ice + snow load, limited by max_ice_loading), l_mslp (atmospheric pressure) and use_global_tides (tidal potential) in the surface pressure
     gradient of compute_vel_rhs (src/oce_ale_vel_rhs.F90:52-76), with the harness's analytic fields: reference run `pi_pp_surfpot`, every routine of 3 steps bit for bit."""
