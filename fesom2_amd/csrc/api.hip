@@ -229,7 +229,7 @@ struct Dag {
     if (next == evs.size()) { hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming); evs.push_back(e); }
     return evs[next++];
   }
-  void dep(hipStream_t to, hipStream_t from) { hipEvent_t e = ev(); hipEventRecord(e, from); hipStreamWaitEvent(to, e, 0); }
+  void dep(hipStream_t to, hipStream_t from) { if (to == from) return; hipEvent_t e = ev(); hipEventRecord(e, from); hipStreamWaitEvent(to, e, 0); }     // (same stream: already ordered)
   ~Dag() { for (auto e : evs) hipEventDestroy(e); }
 };
 static std::string g_bad_launch;
@@ -246,7 +246,8 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   // The critical chain stays on s0 (momentum -> SSH solve -> W -> tracer advection/diffusion -> thickness); side streams
   // carry what only has to be READY by then.  All tracers go through the same launches (grid.y = tracer).
   const DM &m = G.m;
-  hipStream_t s1 = G.side[0], s2 = G.side[1], s3 = G.side[2];
+  static const int nside = getenv("FESOM_GPU_SIDE_STREAMS") ? atoi(getenv("FESOM_GPU_SIDE_STREAMS")) : 3;     // timing experiment: 1 or 2 = fewer side streams
+  hipStream_t s1 = G.side[0], s2 = nside >= 2 ? G.side[1] : G.side[0], s3 = nside >= 3 ? G.side[2] : G.side[0];
   { static bool once = false; if (!once) { once = true; const char *e = getenv("FESOM_GPU_EXP_SKIP_SIDE"); if (e) g_exp_skip_side = atoi(e); } g_exp_step++; }
   const bool toy = m.p.toy_soufflet != 0;
   if (toy && n % 10 == 0) launch_named_toy(m, s0, "compute_zonal_mean");   // before_oce_step (oce_setup_step.F90:625-630)
@@ -270,7 +271,7 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   if (m.p.visc_option != 1) K(s3, "k_visc_elem");
   if (m.p.visc_option == 5) K(s3, "k_visc_node");
   hipEvent_t ev_visc = d.ev(); hipEventRecord(ev_visc, s3);
-  hipStreamWaitEvent(s3, ev_pb, 0);
+  if (s3 != s1) hipStreamWaitEvent(s3, ev_pb, 0);
   K(s3, "k_sigma_slope");
   const bool gm = m.p.Fer_GM != 0;
   hipEvent_t ev_gm = nullptr;
@@ -290,11 +291,12 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   if (m.p.use_momix && m.p.mix_scheme == 2) K(s0, "k_momix");    // mixing length of mo_convect (forcing + ice state only); "mixing_kpp" launches it itself
   if (m.p.mix_scheme == 2) K(s0, "k_pp");          // element (Av) and node (Kv) part in one launch
   if (m.p.mix_scheme == 1) K(s0, "mixing_kpp");       // k_kpp_col, 3 smoothing sweeps, k_kpp_final, k_kpp_elem
-  hipStreamWaitEvent(s0, ev_rhs, 0); hipStreamWaitEvent(s0, ev_visc, 0);
+  if (s3 != s1) hipStreamWaitEvent(s0, ev_rhs, 0);      // (one side stream: ev_visc is recorded behind ev_rhs and ev_op on it)
+  hipStreamWaitEvent(s0, ev_visc, 0);
   if (m.p.visc_option != 5) K(s0, "k_visc_apply");  // second stage of the biharmonic filters (visc_option 6, 7): in place on UV_rhs
   K(s0, "k_impl_visc");                            // incl. the Thomas sweep
   K(s0, "k_edge_transport");
-  hipStreamWaitEvent(s0, ev_op, 0);
+  if (s3 != s1) hipStreamWaitEvent(s0, ev_op, 0);
   launch_solver(m, s0, 1, 1);                      // set-up gathers ssh_rhs (k_ssh_rhs_node fused); row scales from s1
   if (toy) launch_named_toy(m, s0, "relax_zonal_vel");                     // oce_ale.F90:2696
   K(s0, "k_update_vel"); K(s0, "k_edge_transport1");
