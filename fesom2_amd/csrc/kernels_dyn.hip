@@ -205,6 +205,43 @@ __global__ void __launch_bounds__(BLOCK) k_pgf(DM m) {
     }
     return;
   }
+  if (m.p.which_ale == 0 && m.p.which_pgf == 2) {         // 'nemo' (pressure_force_4_linfs_nemo :479-635): hydrostatic pressure above the bottom layer; in the bottom
+    if (!wet) return;                                     // layer T, S interpolated to the shallowest bottom mid-depth of the three nodes, density there, thinnest layer
+    if (nlz < nle) {
+      DA2(m.pgf_x, nlz, e) = (DGS(1, e) * DA2L(m.hpressure, nlz, n0) / D_RHO0 + DGS(2, e) * DA2L(m.hpressure, nlz, n1) / D_RHO0) + DGS(3, e) * DA2L(m.hpressure, nlz, n2) / D_RHO0;
+      DA2(m.pgf_y, nlz, e) = (DGS(4, e) * DA2L(m.hpressure, nlz, n0) / D_RHO0 + DGS(5, e) * DA2L(m.hpressure, nlz, n1) / D_RHO0) + DGS(6, e) * DA2L(m.hpressure, nlz, n2) / D_RHO0;
+      return;
+    }
+    const int en[3] = {n0, n1, n2};
+    const double Zn = m.zbar_e_bot[e] + DA2(m.helem, nle, e) / 2.0, seq = (double)m.p.state_equation;
+    double zmax = DA2(m.Z_3d_n, nle, n0), dh = DA2(m.hnode, nle, n0);
+    for (int k = 1; k < 3; k++) { zmax = dmax_(zmax, DA2(m.Z_3d_n, nle, en[k])); dh = dmin_(dh, DA2(m.hnode, nle, en[k])); }
+    double hpb[3];
+    for (int ni = 0; ni < 3; ni++) {
+      const int n = en[ni], nln = m.nlev_n[n] - 1, uln = m.ulev_n[n];
+      int pos = 0; double best = 0.0;                     // minloc of the positive differences (first minimum)
+      for (int k = uln; k <= nln; k++) {
+        const double dd = DA2(m.Z_3d_n, k, n) - zmax;
+        if (dd > 0.0 && (pos == 0 || dd < best)) { pos = k - uln + 1; best = dd; }
+      }
+      int nlc = pos + 1;
+      if (nlc > nln) nlc = nln;
+      const double dZn = DA2(m.Z_3d_n, nlc, n) - DA2(m.Z_3d_n, nlc - 1, n), dZn_i = zmax - DA2(m.Z_3d_n, nlc - 1, n);
+      double dval = DTR(m.tr_arr, nlc, n, 0) - DTR(m.tr_arr, nlc - 1, n, 0);
+      const double ti = DTR(m.tr_arr, nlc - 1, n, 0) + (dval / dZn * dZn_i);
+      dval = DTR(m.tr_arr, nlc, n, 1) - DTR(m.tr_arr, nlc - 1, n, 1);
+      const double si = DTR(m.tr_arr, nlc - 1, n, 1) + (dval / dZn * dZn_i);
+      double b0, bpz, bpz2, rp;
+      eos(m.p, ti, si, b0, bpz, bpz2, rp);
+      double dens = b0 + Zn * (bpz + Zn * bpz2);
+      dens = dens * rp / (dens + 0.1 * Zn * seq) - D_RHO0;          // density_ref == density_0 (use_density_ref=.false.)
+      const int nlce = nlc < nle ? nlc : nle;
+      hpb[ni] = DA2L(m.hpressure, nlce - 1, n) + 0.5 * D_G * (DA2(m.density_m_rho0, nlce - 1, n) * DA2(m.hnode, nlce - 1, n) + dens * dh);
+    }
+    DA2(m.pgf_x, nle, e) = ((DGS(1, e) * hpb[0] + DGS(2, e) * hpb[1]) + DGS(3, e) * hpb[2]) / D_RHO0;
+    DA2(m.pgf_y, nle, e) = ((DGS(4, e) * hpb[0] + DGS(5, e) * hpb[1]) + DGS(6, e) * hpb[2]) / D_RHO0;
+    return;
+  }
   double he = wet ? DA2(m.helem, nlz, e) : 0.0;
   // zbar_n(nlz) = zbar_e_bot + sum_{k=nle..nlz} helem(k)  (bottom-up, reference order); lane l <-> level l+1
   double zb_top = seq_sum_down(he, nle - 1, ule - 1, m.zbar_e_bot[e]);   // zbar_n(nlz)
@@ -367,7 +404,7 @@ __global__ void __launch_bounds__(BLOCK) k_pgf_tile(DM m) {
   }
 }
 static void launch_pgf(const DM &m, hipStream_t s) {
-  const bool shch = m.p.which_pgf == 0 && !(m.p.which_ale == 0 && !m.p.use_partial_cell);
+  const bool shch = m.p.which_pgf == 0 && !(m.p.which_ale == 0 && !m.p.use_partial_cell);      // (cubicspline / nemo: k_pgf)
   if (m.use_tile && shch) {
     const int per_block = COLS_PER_BLOCK * PG_ELEMS;
     hipLaunchKernelGGL(k_pgf_tile, dim3((m.myE + per_block - 1) / per_block), dim3(BLOCK), (size_t)COLS_PER_BLOCK * 2 * m.nlm1 * PG_CP * sizeof(double), s, m);

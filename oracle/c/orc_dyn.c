@@ -227,10 +227,53 @@ static void pgf_linfs_cubicspline(void) {
   free(zbar_n); free(Z_n);
 }
 
+/* pressure_force_4_linfs_nemo: src/oce_ale_pressure_bv.F90:479-635 (linfs with partial cells, which_pgf = 'nemo': hydrostatic pressure on the levels above
+ * the bottom; in the bottom layer T and S of every node are interpolated to the shallowest of the three bottom mid-depths, the density is formed there and the
+ * pressure is integrated over the thinnest bottom layer) */
+static void pgf_linfs_nemo(void) {
+  const double seq = (double)C_.p.state_equation;
+  for (int e = 1; e <= C_.m.myDim_elem2D; e++) {
+    const int nle = NLEV(e) - 1, ule = ULEV(e);
+    const int en[3] = {EN(1, e), EN(2, e), EN(3, e)};
+    for (int nlz = ule; nlz <= nle - 1; nlz++) {
+      A2(C_.pgf_x, nlz, e) = (GS(1, e) * A2L(C_.hpressure, nlz, en[0]) / DENSITY_0 + GS(2, e) * A2L(C_.hpressure, nlz, en[1]) / DENSITY_0) + GS(3, e) * A2L(C_.hpressure, nlz, en[2]) / DENSITY_0;
+      A2(C_.pgf_y, nlz, e) = (GS(4, e) * A2L(C_.hpressure, nlz, en[0]) / DENSITY_0 + GS(5, e) * A2L(C_.hpressure, nlz, en[1]) / DENSITY_0) + GS(6, e) * A2L(C_.hpressure, nlz, en[2]) / DENSITY_0;
+    }
+    const double Zn = C_.m.zbar_e_bot[e - 1] + A2(C_.helem, nle, e) / 2.0;                 /* Z_n(nle) */
+    double zmax = A2(C_.Z_3d_n, nle, en[0]), dh = A2(C_.hnode, nle, en[0]);
+    for (int k = 1; k < 3; k++) { zmax = dmax(zmax, A2(C_.Z_3d_n, nle, en[k])); dh = dmin(dh, A2(C_.hnode, nle, en[k])); }
+    double hpb[3];
+    for (int ni = 0; ni < 3; ni++) {
+      const int n = en[ni], nln = NLEVN(n) - 1, uln = ULEVN(n);
+      int pos = 0; double best = 0.0;                               /* minloc of the positive differences, first minimum */
+      for (int k = uln; k <= nln; k++) {
+        const double dd = A2(C_.Z_3d_n, k, n) - zmax;
+        if (dd > 0.0 && (pos == 0 || dd < best)) { pos = k - uln + 1; best = dd; }
+      }
+      int nlc = pos + 1;
+      if (nlc > nln) nlc = nln;
+      const double dZn = A2(C_.Z_3d_n, nlc, n) - A2(C_.Z_3d_n, nlc - 1, n), dZn_i = zmax - A2(C_.Z_3d_n, nlc - 1, n);
+      double dval = TR(nlc, n, 1) - TR(nlc - 1, n, 1);
+      const double ti = TR(nlc - 1, n, 1) + (dval / dZn * dZn_i);
+      dval = TR(nlc, n, 2) - TR(nlc - 1, n, 2);
+      const double si = TR(nlc - 1, n, 2) + (dval / dZn * dZn_i);
+      double b0, bpz, bpz2, rp;
+      eos(ti, si, &b0, &bpz, &bpz2, &rp);
+      double dens = b0 + Zn * (bpz + Zn * bpz2);
+      dens = dens * rp / (dens + 0.1 * Zn * seq) - A2(C_.density_ref, nle, n);
+      const int nlce = nlc < nle ? nlc : nle;
+      hpb[ni] = A2L(C_.hpressure, nlce - 1, n) + 0.5 * G_ACC * (A2(C_.density_m_rho0, nlce - 1, n) * A2(C_.hnode, nlce - 1, n) + dens * dh);
+    }
+    A2(C_.pgf_x, nle, e) = ((GS(1, e) * hpb[0] + GS(2, e) * hpb[1]) + GS(3, e) * hpb[2]) / DENSITY_0;
+    A2(C_.pgf_y, nle, e) = ((GS(4, e) * hpb[0] + GS(5, e) * hpb[1]) + GS(6, e) * hpb[2]) / DENSITY_0;
+  }
+}
+
 void orc_pressure_force(void) {
   if (C_.p.which_ale == 0 && !C_.p.use_partial_cell) { pgf_linfs_fullcell(); return; }
   if (C_.p.which_ale != 0 && C_.p.which_pgf == 1) { pgf_zxxxx_cubicspline(); return; }
   if (C_.p.which_ale == 0 && C_.p.which_pgf == 1) { pgf_linfs_cubicspline(); return; }
+  if (C_.p.which_ale == 0 && C_.p.which_pgf == 2) { pgf_linfs_nemo(); return; }
   const int lin = C_.p.which_ale == 0;
   int nl = NL;
   double *zbar_n = calloc(nl + 2, sizeof(double)), *Z_n = calloc(nl + 2, sizeof(double));

@@ -676,7 +676,7 @@ def test_vector_invariant_momentum_chain_bitwise(built):
     gpu.close()
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(which_ale="linfs", use_partial_cell=True)])
+@pytest.mark.parametrize("kw", [dict(), dict(which_ale="linfs", use_partial_cell=True), dict(which_ale="linfs", use_partial_cell=True, which_pgf="nemo")])
 def test_cubicspline_pgf_chain_bitwise(built, kw):
     """which_pgf = 'cubicspline' (pressure_force_4_zxxxx_cubicspline with zstar, pressure_force_4_linfs_cubicspline with linfs + partial cells; oracle pinned on
     the reference runs pi_pp_cubicspline / pi_pp_linfs_cubic): HIP == oracle bit for bit after every routine of 3 steps under surface forcing."""
@@ -685,8 +685,8 @@ def test_cubicspline_pgf_chain_bitwise(built, kw):
     from fesom2_amd.core import OceanCore
     from fesom2_amd.synthetic import analytic_ts, analytic_forcing
     from oracle_lib import Oracle
-    mesh = Mesh.load(PI, dt=900.0, **kw)
-    par = make_params(dt=900.0, which_pgf="cubicspline", **kw)
+    mesh = Mesh.load(PI, dt=900.0, **{k: v for k, v in kw.items() if k != "which_pgf"})
+    par = make_params(dt=900.0, **dict(dict(which_pgf="cubicspline"), **kw))             # (the third case: 'nemo', pinned on pi_pp_linfs_nemo)
     st = mesh.initial_state(2)
     st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
     st.tr_arr_old[...] = st.tr_arr

@@ -285,7 +285,8 @@ def test_oracle_chain_bitwise_vector_invariant_momentum(built):
     assert not bad, "\n".join(bad[:20])
 
 
-@pytest.mark.parametrize("cfg,kw", [("pi_pp_cubicspline", dict()), ("pi_pp_linfs_cubic", dict(which_ale="linfs", use_partial_cell=True))])
+@pytest.mark.parametrize("cfg,kw", [("pi_pp_cubicspline", dict()), ("pi_pp_linfs_cubic", dict(which_ale="linfs", use_partial_cell=True)),
+                                    ("pi_pp_linfs_nemo", dict(which_ale="linfs", use_partial_cell=True, which_pgf="nemo"))])
 def test_oracle_chain_bitwise_cubicspline_pgf(built, cfg, kw):
     """which_pgf = 'cubicspline': pressure_force_4_zxxxx_cubicspline (src/oce_ale_pressure_bv.F90:1697-1866, zstar) and pressure_force_4_linfs_cubicspline
     (:1252-1444, linfs with partial cells): reference runs `pi_pp_cubicspline`, `pi_pp_linfs_cubic`, every routine of 3 steps bit for bit."""
@@ -294,8 +295,8 @@ def test_oracle_chain_bitwise_cubicspline_pgf(built, cfg, kw):
     from fesom2_amd.synthetic import analytic_ts
     from oracle_lib import Oracle
     from ref_chain import run_reference_chain
-    mesh = Mesh.load(PI, dt=900.0, **kw)
-    par = make_params(dt=900.0, which_pgf="cubicspline", **kw)
+    mesh = Mesh.load(PI, dt=900.0, **{k: v for k, v in kw.items() if k != "which_pgf"})
+    par = make_params(dt=900.0, **dict(dict(which_pgf="cubicspline"), **kw))         # (pi_pp_linfs_nemo: pressure_force_4_linfs_nemo, :479-635)
     st = mesh.initial_state(2)
     st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
     st.tr_arr_old[...] = st.tr_arr
