@@ -50,7 +50,7 @@ def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equati
     p.solver_precond, p.solver_xinv_its = int(solver_precond), int(solver_xinv_its)
     p.tra_adv_lim = {"FCT": 0, "NON": 1}[tra_adv_lim]
     p.Leith_c, p.Div_c = Leith_c, Div_c              # config/namelist.oce:8-9
-    p.which_pgf = {"shchepetkin": 0, "cubicspline": 1, "nemo": 2}.get(which_pgf, -1)  # oce_modules.F90:172
+    p.which_pgf = {"shchepetkin": 0, "cubicspline": 1, "nemo": 2, "easypgf": 3}.get(which_pgf, -1)  # oce_modules.F90:172
     p.use_momix, p.momix_lat, p.momix_kv = int(use_momix), momix_lat, momix_kv   # config/namelist.oce:48-50
     # ocean_setup (src/oce_setup_step.F90:42-47): unless which_ALE = 'linfs' the reference sets ref_sss_local = .false., ref_sss = 0 ("this will force the
     # virtual salinity flux to be zero"), whatever the namelist says -- the salt part of the KPP non-local transport vanishes with it

@@ -259,6 +259,31 @@ __global__ void __launch_bounds__(BLOCK) k_pgf(DM m) {
     const double r0 = pgf_cubic_rho<false>(m, n0, Zn), r1 = pgf_cubic_rho<false>(m, n1, Zn), r2 = pgf_cubic_rho<false>(m, n2, Zn);
     const double gx = (DGS(1, e) * r0 + DGS(2, e) * r1) + DGS(3, e) * r2, gy = (DGS(4, e) * r0 + DGS(5, e) * r1) + DGS(6, e) * r2;
     auxx = D_G * he * gx / D_RHO0; auxy = D_G * he * gy / D_RHO0;
+  } else if (wet && m.p.which_pgf == 3) {                  // 'easypgf', zstar (:2116-2546): T, S interpolated to Z_n with the Newton polynomial of three levels, density there
+    const int en[3] = {n0, n1, n2};
+    const double seq = (double)m.p.state_equation;
+    double r3[3];
+#pragma unroll
+    for (int ni = 0; ni < 3; ni++) {
+      int n = en[ni], k0;
+      if (nlz == ule && (nlz - m.ulev_n[n]) == 0) k0 = nlz + 1;
+      else if (nlz == nle && nlz != ule && (m.nlev_n[n] - 1 - nlz) == 0) k0 = nlz - 1;
+      else k0 = nlz;
+      const double zm = DA2(m.Z_3d_n, k0 - 1, n), zc = DA2(m.Z_3d_n, k0, n), zp = DA2(m.Z_3d_n, k0 + 1, n);
+      const double dx10 = zc - zm, dx21 = zp - zc, dx20 = zp - zm;
+      double ts[2];
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const double x0 = DTR(m.tr_arr, k0 - 1, n, t), d10 = DTR(m.tr_arr, k0, n, t) - x0, d21 = DTR(m.tr_arr, k0 + 1, n, t) - DTR(m.tr_arr, k0, n, t);
+        ts[t] = x0 + d10 / dx10 * (Zn - zm) + (dx10 * d21 - dx21 * d10) / (dx20 * dx21 * dx10) * (Zn - zc) * (Zn - zm);
+      }
+      double b0, bpz, bpz2, rp;
+      eos(m.p, ts[0], ts[1], b0, bpz, bpz2, rp);
+      const double rho = b0 + Zn * (bpz + Zn * bpz2);
+      r3[ni] = rho * rp / (rho + 0.1 * Zn * seq) - D_RHO0;
+    }
+    const double gx = (DGS(1, e) * r3[0] + DGS(2, e) * r3[1]) + DGS(3, e) * r3[2], gy = (DGS(4, e) * r3[0] + DGS(5, e) * r3[1]) + DGS(6, e) * r3[2];
+    auxx = gx * he * D_G / D_RHO0; auxy = gy * he * D_G / D_RHO0;
   } else if (wet) {
     const int en[3] = {n0, n1, n2};
     double drho_dz[3], rho_c[3], z_c[3];

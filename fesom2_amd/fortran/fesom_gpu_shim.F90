@@ -354,6 +354,7 @@ contains
     case ('shchepetkin'); p%which_pgf = 0
     case ('cubicspline'); p%which_pgf = 1
     case ('nemo'); p%which_pgf = 2
+    case ('easypgf'); p%which_pgf = 3
     case default; p%which_pgf = -1
     end select
     p%use_momix = l2i(use_momix); p%momix_lat = momix_lat; p%momix_kv = momix_kv

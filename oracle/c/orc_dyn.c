@@ -269,9 +269,56 @@ static void pgf_linfs_nemo(void) {
   }
 }
 
+/* pressure_force_4_zxxxx_easypgf: src/oce_ale_pressure_bv.F90:2116-2546 (which_pgf = 'easypgf': T and S of the three nodes interpolated to the mid-depth of the
+ * element layer with the second-order Newton polynomial of three levels, the density formed there; the three blocks of the source -- surface, bulk, bottom -- differ
+ * only in the centre level k0 of the stencil) */
+static void pgf_zxxxx_easypgf(void) {
+  int nl = NL;
+  const double seq = (double)C_.p.state_equation;
+  double *zbar_n = calloc(nl + 2, sizeof(double)), *Z_n = calloc(nl + 2, sizeof(double));
+  for (int e = 1; e <= C_.m.myDim_elem2D; e++) {
+    int nle = NLEV(e) - 1, ule = ULEV(e);
+    int en[3] = {EN(1, e), EN(2, e), EN(3, e)};
+    for (int k = 0; k <= nl; k++) { zbar_n[k] = 0.0; Z_n[k] = 0.0; }
+    zbar_n[nle + 1] = C_.m.zbar_e_bot[e - 1];
+    Z_n[nle] = zbar_n[nle + 1] + A2(C_.helem, nle, e) * 0.5;
+    for (int nlz = nle; nlz >= ule + 1; nlz--) {
+      zbar_n[nlz] = zbar_n[nlz + 1] + A2(C_.helem, nlz, e);
+      Z_n[nlz - 1] = zbar_n[nlz] + A2(C_.helem, nlz - 1, e) * 0.5;
+    }
+    double ip[2] = {0.0, 0.0};
+    for (int nlz = ule; nlz <= nle; nlz++) {
+      double r3[3];
+      for (int ni = 0; ni < 3; ni++) {
+        int n = en[ni], k0;
+        if (nlz == ule && (nlz - ULEVN(n)) == 0) k0 = nlz + 1;
+        else if (nlz == nle && nlz != ule && (NLEVN(n) - 1 - nlz) == 0) k0 = nlz - 1;
+        else k0 = nlz;
+        const double zm = A2(C_.Z_3d_n, k0 - 1, n), zc = A2(C_.Z_3d_n, k0, n), zp = A2(C_.Z_3d_n, k0 + 1, n);
+        const double dx10 = zc - zm, dx21 = zp - zc, dx20 = zp - zm, Zn = Z_n[nlz];
+        double ts[2];
+        for (int t = 1; t <= 2; t++) {
+          const double x0 = TR(k0 - 1, n, t), d10 = TR(k0, n, t) - TR(k0 - 1, n, t), d21 = TR(k0 + 1, n, t) - TR(k0, n, t);
+          ts[t - 1] = x0 + d10 / dx10 * (Zn - zm) + (dx10 * d21 - dx21 * d10) / (dx20 * dx21 * dx10) * (Zn - zc) * (Zn - zm);
+        }
+        double b0, bpz, bpz2, rp;
+        eos(ts[0], ts[1], &b0, &bpz, &bpz2, &rp);
+        double rho = b0 + Zn * (bpz + Zn * bpz2);
+        r3[ni] = rho * rp / (rho + 0.1 * Zn * seq) - DENSITY_0;
+      }
+      double gx = (GS(1, e) * r3[0] + GS(2, e) * r3[1]) + GS(3, e) * r3[2], gy = (GS(4, e) * r3[0] + GS(5, e) * r3[1]) + GS(6, e) * r3[2];
+      double ax = gx * A2(C_.helem, nlz, e) * G_ACC / DENSITY_0, ay = gy * A2(C_.helem, nlz, e) * G_ACC / DENSITY_0;
+      A2(C_.pgf_x, nlz, e) = (nlz == ule) ? ax * 0.5 : ip[0] + ax * 0.5; ip[0] = (nlz == ule) ? ax : ip[0] + ax;
+      A2(C_.pgf_y, nlz, e) = (nlz == ule) ? ay * 0.5 : ip[1] + ay * 0.5; ip[1] = (nlz == ule) ? ay : ip[1] + ay;
+    }
+  }
+  free(zbar_n); free(Z_n);
+}
+
 void orc_pressure_force(void) {
   if (C_.p.which_ale == 0 && !C_.p.use_partial_cell) { pgf_linfs_fullcell(); return; }
   if (C_.p.which_ale != 0 && C_.p.which_pgf == 1) { pgf_zxxxx_cubicspline(); return; }
+  if (C_.p.which_ale != 0 && C_.p.which_pgf == 3) { pgf_zxxxx_easypgf(); return; }
   if (C_.p.which_ale == 0 && C_.p.which_pgf == 1) { pgf_linfs_cubicspline(); return; }
   if (C_.p.which_ale == 0 && C_.p.which_pgf == 2) { pgf_linfs_nemo(); return; }
   const int lin = C_.p.which_ale == 0;
