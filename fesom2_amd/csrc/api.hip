@@ -378,8 +378,8 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   if (par->which_ale != 0 && par->which_ale != 2) { G.err = "fesom_gpu_init: which_ale must be linfs(0) or zstar(2)"; return 3; }
   if ((par->mom_adv != 2 && par->mom_adv != 3) || par->visc_option < 1 || par->visc_option > 7) { G.err = "fesom_gpu_init: only mom_adv=2 or 3, visc_option=1..7 are implemented"; return 3; }
   if (par->mom_adv == 3 && par->which_ale != 0) { G.err = "fesom_gpu_init: mom_adv=3 (vector-invariant momentum) needs which_ALE='linfs': it reads hpressure, which the reference forms only there (oce_ale_pressure_bv.F90:262)"; return 3; }
-  if (par->which_pgf != 0 && par->which_pgf != 1 && !(par->which_pgf == 2 && par->which_ale == 0) && !(par->which_pgf == 3 && par->which_ale == 2) && !(par->which_ale == 0 && !par->use_partial_cell)) {
-    G.err = "fesom_gpu_init: which_pgf must be 'shchepetkin' (0), 'cubicspline' (1), with linfs 'nemo' (2) or with zstar 'easypgf' (3); easypgf with linfs and the cavity scheme 'sergey' are not implemented"; return 3;
+  if (par->which_pgf != 0 && par->which_pgf != 1 && !(par->which_pgf == 2 && par->which_ale == 0) && !(par->which_pgf == 3) && !(par->which_ale == 0 && !par->use_partial_cell)) {
+    G.err = "fesom_gpu_init: which_pgf must be 'shchepetkin' (0), 'cubicspline' (1), with linfs 'nemo' (2) or 'easypgf' (3); the cavity scheme 'sergey' is not implemented"; return 3;
   }
   if (par->Fer_GM && par->scaling_Rossby) { G.err = "fesom_gpu_init: scaling_Rossby=.true. (GM cut-off by the Rossby radius) is not implemented"; return 3; }
   if (par->tra_adv_ver < 0 || par->tra_adv_ver > 3 || par->tra_adv_hor < 0 || par->tra_adv_hor > 2) {

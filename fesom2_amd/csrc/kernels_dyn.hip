@@ -259,13 +259,14 @@ __global__ void __launch_bounds__(BLOCK) k_pgf(DM m) {
     const double r0 = pgf_cubic_rho<false>(m, n0, Zn), r1 = pgf_cubic_rho<false>(m, n1, Zn), r2 = pgf_cubic_rho<false>(m, n2, Zn);
     const double gx = (DGS(1, e) * r0 + DGS(2, e) * r1) + DGS(3, e) * r2, gy = (DGS(4, e) * r0 + DGS(5, e) * r1) + DGS(6, e) * r2;
     auxx = D_G * he * gx / D_RHO0; auxy = D_G * he * gy / D_RHO0;
-  } else if (wet && m.p.which_pgf == 3) {                  // 'easypgf', zstar (:2116-2546): T, S interpolated to Z_n with the Newton polynomial of three levels, density there
+  } else if (wet && m.p.which_pgf == 3) {                  // 'easypgf', zstar (:2116-2546) and linfs with partial cells (:898-1245): T, S interpolated to Z_n with the Newton polynomial of three levels, density there
     const int en[3] = {n0, n1, n2};
     const double seq = (double)m.p.state_equation;
     double r3[3];
 #pragma unroll
     for (int ni = 0; ni < 3; ni++) {
       int n = en[ni], k0;
+      if (m.p.which_ale == 0 && nlz != nle) { r3[ni] = DA2(m.density_m_rho0, nlz, n); continue; }      // pressure_force_4_linfs_easypgf (:898-1245): flat above the bottom layer
       if (nlz == ule && (nlz - m.ulev_n[n]) == 0) k0 = nlz + 1;
       else if (nlz == nle && nlz != ule && (m.nlev_n[n] - 1 - nlz) == 0) k0 = nlz - 1;
       else k0 = nlz;

@@ -139,7 +139,7 @@ typedef struct fesom_params {
                                 pressure_force_4_linfs_shchepetkin for linfs with partial cells; linfs with full cells always takes
                                 pressure_force_4_linfs_fullcell (oce_ale_pressure_bv.F90:385-386); 1 'cubicspline': pressure_force_4_zxxxx_cubicspline (zstar),
                                 pressure_force_4_linfs_cubicspline (linfs with partial cells); 2 'nemo': pressure_force_4_linfs_nemo (linfs with partial cells only);
-                                3 'easypgf': pressure_force_4_zxxxx_easypgf (zstar only).  Anything else (easypgf with linfs, sergey): pass -1, fesom_gpu_init refuses it */
+                                3 'easypgf': pressure_force_4_zxxxx_easypgf (zstar), pressure_force_4_linfs_easypgf (linfs with partial cells).  Anything else (sergey): pass -1, fesom_gpu_init refuses it */
   int    use_momix;          /* Monin-Obukhov mixing of Timmermann & Beckmann 2004 inside mo_convect (oce_mo_conv.F90:22-55, :95; on in the shipped
                                 config/namelist.oce:48; the reference allocates its arrays only with use_ice): needs u_ice, v_ice, a_ice with the forcing */
   double momix_lat, momix_kv;/* applied south of momix_lat [degrees] (-50), diffusivity / viscosity added within the mixing length (0.01) */

@@ -272,7 +272,8 @@ static void pgf_linfs_nemo(void) {
 /* pressure_force_4_zxxxx_easypgf: src/oce_ale_pressure_bv.F90:2116-2546 (which_pgf = 'easypgf': T and S of the three nodes interpolated to the mid-depth of the
  * element layer with the second-order Newton polynomial of three levels, the density formed there; the three blocks of the source -- surface, bulk, bottom -- differ
  * only in the centre level k0 of the stencil) */
-static void pgf_zxxxx_easypgf(void) {
+static void pgf_zxxxx_easypgf(void) {         /* also pressure_force_4_linfs_easypgf (:898-1245, linfs with partial cells): the interpolation only in the bottom layer */
+  const int lin = C_.p.which_ale == 0;
   int nl = NL;
   const double seq = (double)C_.p.state_equation;
   double *zbar_n = calloc(nl + 2, sizeof(double)), *Z_n = calloc(nl + 2, sizeof(double));
@@ -291,6 +292,7 @@ static void pgf_zxxxx_easypgf(void) {
       double r3[3];
       for (int ni = 0; ni < 3; ni++) {
         int n = en[ni], k0;
+        if (lin && nlz != nle) { r3[ni] = A2(C_.density_m_rho0, nlz, n); continue; }
         if (nlz == ule && (nlz - ULEVN(n)) == 0) k0 = nlz + 1;
         else if (nlz == nle && nlz != ule && (NLEVN(n) - 1 - nlz) == 0) k0 = nlz - 1;
         else k0 = nlz;
@@ -318,7 +320,7 @@ static void pgf_zxxxx_easypgf(void) {
 void orc_pressure_force(void) {
   if (C_.p.which_ale == 0 && !C_.p.use_partial_cell) { pgf_linfs_fullcell(); return; }
   if (C_.p.which_ale != 0 && C_.p.which_pgf == 1) { pgf_zxxxx_cubicspline(); return; }
-  if (C_.p.which_ale != 0 && C_.p.which_pgf == 3) { pgf_zxxxx_easypgf(); return; }
+  if (C_.p.which_pgf == 3) { pgf_zxxxx_easypgf(); return; }        /* zstar, and linfs with partial cells (full cells returned above) */
   if (C_.p.which_ale == 0 && C_.p.which_pgf == 1) { pgf_linfs_cubicspline(); return; }
   if (C_.p.which_ale == 0 && C_.p.which_pgf == 2) { pgf_linfs_nemo(); return; }
   const int lin = C_.p.which_ale == 0;

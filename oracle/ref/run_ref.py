@@ -261,6 +261,10 @@ CFGS = {
                         rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                         fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
                         balance_salt_water=".true.", synth_forcing=True, which_pgf="easypgf"),
+    "pi_pp_linfs_easypgf": dict(mesh="pi", step_per_day=96, which_ale="linfs", use_partial_cell=".true.", cyclic_length=360,
+                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                        fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                        balance_salt_water=".true.", synth_forcing=True, which_pgf="easypgf"),
     # which_pgf = 'cubicspline': pressure_force_4_zxxxx_cubicspline (src/oce_ale_pressure_bv.F90:1697-1866)
     "pi_pp_cubicspline": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
                         rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,

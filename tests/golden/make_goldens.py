@@ -124,6 +124,7 @@ def main():
     make("pi_pp_linfs_vinv", "pi_pp_linfs_vinv_reference.npz")  # mom_adv = 3 (vector-invariant momentum), linfs with full cells
     make("pi_pp_linfs_cubic", "pi_pp_linfs_cubic_reference.npz")  # linfs + partial cells + which_pgf = 'cubicspline'
     make("pi_pp_linfs_nemo", "pi_pp_linfs_nemo_reference.npz")  # linfs + partial cells + which_pgf = 'nemo'
+    make("pi_pp_linfs_easypgf", "pi_pp_linfs_easypgf_reference.npz")  # linfs + partial cells + which_pgf = 'easypgf'
     make("pi_pp_easypgf", "pi_pp_easypgf_reference.npz")  # which_pgf = 'easypgf' (zstar)
     make("pi_pp_cubicspline", "pi_pp_cubicspline_reference.npz")  # which_pgf = 'cubicspline'
     make("pi_pp_linfs_pc", "pi_pp_linfs_pc_reference.npz")  # which_ALE = 'linfs' with partial cells (pressure_force_4_linfs_shchepetkin)

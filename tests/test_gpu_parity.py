@@ -676,7 +676,7 @@ def test_vector_invariant_momentum_chain_bitwise(built):
     gpu.close()
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(which_ale="linfs", use_partial_cell=True), dict(which_ale="linfs", use_partial_cell=True, which_pgf="nemo"), dict(which_pgf="easypgf")])
+@pytest.mark.parametrize("kw", [dict(), dict(which_ale="linfs", use_partial_cell=True), dict(which_ale="linfs", use_partial_cell=True, which_pgf="nemo"), dict(which_pgf="easypgf"), dict(which_ale="linfs", use_partial_cell=True, which_pgf="easypgf")])
 def test_cubicspline_pgf_chain_bitwise(built, kw):
     """which_pgf = 'cubicspline' (pressure_force_4_zxxxx_cubicspline with zstar, pressure_force_4_linfs_cubicspline with linfs + partial cells; oracle pinned on
     the reference runs pi_pp_cubicspline / pi_pp_linfs_cubic): HIP == oracle bit for bit after every routine of 3 steps under surface forcing."""

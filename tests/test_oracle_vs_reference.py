@@ -286,7 +286,8 @@ def test_oracle_chain_bitwise_vector_invariant_momentum(built):
 
 
 @pytest.mark.parametrize("cfg,kw", [("pi_pp_cubicspline", dict()), ("pi_pp_linfs_cubic", dict(which_ale="linfs", use_partial_cell=True)),
-                                    ("pi_pp_linfs_nemo", dict(which_ale="linfs", use_partial_cell=True, which_pgf="nemo")), ("pi_pp_easypgf", dict(which_pgf="easypgf"))])
+                                    ("pi_pp_linfs_nemo", dict(which_ale="linfs", use_partial_cell=True, which_pgf="nemo")), ("pi_pp_easypgf", dict(which_pgf="easypgf")),
+                                    ("pi_pp_linfs_easypgf", dict(which_ale="linfs", use_partial_cell=True, which_pgf="easypgf"))])
 def test_oracle_chain_bitwise_cubicspline_pgf(built, cfg, kw):
     """which_pgf = 'cubicspline': pressure_force_4_zxxxx_cubicspline (src/oce_ale_pressure_bv.F90:1697-1866, zstar) and pressure_force_4_linfs_cubicspline
     (:1252-1444, linfs with partial cells): reference runs `pi_pp_cubicspline`, `pi_pp_linfs_cubic`, every routine of 3 steps bit for bit."""
