@@ -210,6 +210,7 @@ void enqueue_step(hipStream_t s, int first_step, int n) {
   if (gm || m.p.Redi) launch_named_gm(m, s, "init_Redi_GM");               // before vert_vel_ale touches hnode_new (oce_ale.F90:2729-2739)
   if (gm) { launch_named_gm(m, s, "fer_solve_Gamma"); launch_named_gm(m, s, "fer_gamma2vel"); launch_named_gm(m, s, "fer_wvel"); }
   launch_dynamics_post(m, s);                // update_vel, compute_hbar_ale, eta_n, vert_vel_ale
+  if (m.p.SPP) launch_named_tra(m, s, "k_spp", 0);                          // solve_tracers_ale :120-121
   if (gm) launch_named_gm(m, s, "bolus_add");                               // solve_tracers_ale :127-131
   launch_tracer(m, s, -1);                   // solve_tracers_ale, all tracers per launch
   if (gm) launch_named_gm(m, s, "bolus_remove");                            // :165-169
@@ -327,7 +328,7 @@ int build_graph(int which) {
   hipGraph_t g;
   Dag d;                                            // events must outlive the capture
   HIPCHK(hipStreamBeginCapture(G.stream, hipStreamCaptureModeGlobal));
-  if (G.serial) enqueue_step(G.stream, which, 1); else enqueue_step_dag(G.stream, which, d, 1);
+  if (G.serial || G.m.p.SPP) enqueue_step(G.stream, which, 1); else enqueue_step_dag(G.stream, which, d, 1);     // (SPP: see fesom_gpu_run_steps)
   HIPCHK(hipStreamEndCapture(G.stream, &g));
   HIPCHK(hipGraphInstantiate(&G.graph[which], g, nullptr, nullptr, 0));
   hipGraphDestroy(g);
@@ -549,6 +550,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   F(ssh_values, m.nza);
   if (par->visc_option <= 3) { F(Visc, n1 * E); F(leith_aux, n1 * N); }
   if (par->smooth_bh_tra) FT(bh_tmp, n1 * N);
+  if (par->SPP) { std::vector<double> gl(N); for (size_t n = 0; n < N; n++) gl[n] = d->geo_coord_nod2D[2 * n + 1]; m.geo_lat = dev_upload(gl); }
   if (par->visc_option <= 3 || par->mom_adv == 3) F(vorticity, n1 * N);
   if (par->mom_adv == 3) {
     F(KE_node, n1 * N);
@@ -570,7 +572,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   }
   if (par->Fer_GM) { F(fer_K, nl * N); F(fer_gamma, 2 * nl * N); F(fer_Wvel, nl * N); F(fer_c, N); F(fer_UV, 2 * n1 * E); }
   {   // surface forcing: ONE device block (one host->device copy per fesom_gpu_set_forcing), fields are views into it
-    G.frc_count = 2 * E + 7 * N + (par->use_sw_pene ? nl * N : 0) + (par->use_momix ? 3 * N : 0) + (par->use_floatice ? 2 * N : 0) + (par->l_mslp ? N : 0) + (par->use_global_tides ? N : 0);
+    G.frc_count = 2 * E + 7 * N + (par->use_sw_pene ? nl * N : 0) + (par->use_momix ? 3 * N : 0) + (par->use_floatice ? 2 * N : 0) + (par->l_mslp ? N : 0) + (par->use_global_tides ? N : 0) + (par->SPP ? 2 * N : 0);
     G.frc_dev = dev_alloc<double>(G.frc_count);
     double *q = G.frc_dev;
     auto view = [&](const char *name, size_t cnt) { double *r = q; G.fields[name] = Field{r, cnt, 1}; q += cnt; return r; };
@@ -582,6 +584,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     if (par->use_floatice) { m.m_ice = view("m_ice", N); m.m_snow = view("m_snow", N); }
     if (par->l_mslp) m.press_air = view("press_air", N);
     if (par->use_global_tides) m.ssh_gp = view("ssh_gp", N);
+    if (par->SPP) { m.thdgr = view("thdgr", N); m.S_oc = view("S_oc_array", N); }
   }
   if (par->mix_scheme == 1) {
     F(dbsfc, nl * N);
@@ -797,6 +800,7 @@ int fesom_gpu_set_forcing(const fesom_forcing_desc *f) {
   if (G.m.p.use_floatice) { put(f->m_ice, N, N); put(f->m_snow, N, N); }
   if (G.m.p.l_mslp) put(f->press_air, N, N);
   if (G.m.p.use_global_tides) put(f->ssh_gp, N, N);
+  if (G.m.p.SPP) { put(f->thdgr, N, N); put(f->S_oc_array, N, N); }
   HIPCHK(hipMemcpyAsync(G.frc_dev, G.frc_pin[b], G.frc_count * sizeof(double), hipMemcpyHostToDevice, G.stream));
   HIPCHK(hipEventRecord(G.frc_ev[b], G.stream));
   return 0;
@@ -968,6 +972,7 @@ int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
   S.X(0, {"Wvel", "Wvel_e", "Wvel_i", "hnode_new", "hbar", "hbar_old", "eta_n", "ssh_rhs_old"});
   S.c("k_dhe");
   if (p.Fer_GM) S.c("bolus_add");
+  if (p.SPP) S.c("k_spp", 0);                      // solve_tracers_ale :120-121 (owned and halo nodes, as the reference)
   S.c("k_tr_ab", 0); S.c("k_tr_grad_elem", 0); S.XA(2, {"tr_xy_ab"});       // the reference's own overlap (oce_tracer_mod.F90:68-81)
   S.c("k_tr_z", 0);
   S.Wt();
@@ -1138,8 +1143,8 @@ int fesom_gpu_run_steps(int n_first, int nsteps) {
     if (G.use_graph && !G.m.p.toy_soufflet && !solver_syncs) {
       if (!G.graph[which] && build_graph(which)) return 1;
       HIPCHK(hipGraphLaunch(G.graph[which], G.stream));
-    } else if (!G.serial) {
-      static Dag dag;                                   // pooled events
+    } else if (!G.serial && !G.m.p.SPP) {               // (SPP changes the salinity at the head of solve_tracers_ale: the tracer preparation cannot be hoisted
+      static Dag dag;                                   //  to the start of the step as the DAG does -> the serial order)  pooled events
       dag.reset();
       enqueue_step_dag(G.stream, which, dag, n);
     } else enqueue_step(G.stream, which, n);

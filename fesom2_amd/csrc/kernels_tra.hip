@@ -783,6 +783,39 @@ __device__ __forceinline__ bool bh_edge(const DM &m, int ed, int nz, double &vi)
   vi = sqrt(dmax_(m.p.gamma0, dmax_(m.p.gamma1 * sqrt(vi), m.p.gamma2 * vi)) * len);
   return true;
 }
+// Salt plume parameterization (SPP): cal_rejected_salt + app_rejected_salt (src/oce_spp.F90) at the head of solve_tracers_ale.  One thread per node (owned and
+// halo, as the reference): the salt rejected by growing ice leaves the surface layer and is spread over the mixed layer (northern hemisphere, levels above
+// the first one with drho/dz >= 0.01 kg/m^4 or below 50 m) with weights area * h * (Z_1 - Z_k)^5 (the integer power as flang's runtime forms it: x * (x^2)^2).
+__global__ void k_spp(DM m) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= m.N) return;
+  const int nzmin = m.ulev_n[n], nzmax = m.nlev_n[n];
+  if (nzmin > 1) return;
+  const double th = m.thdgr[n];
+  if (!(th > 0.0)) return;
+  const double rej = (m.S_oc[n] - m.p.Sice) * th * (910. / 1025. * m.p.dt) * DA2L(m.area, 1, n);
+  if (rej <= 0.0) return;
+  if (DTR(m.tr_arr, nzmin, n, 1) < 10.0) return;
+  if (!(m.geo_lat[n] > 0.0)) return;
+  int kml = 1;
+  double spar[64], ssum = 0.0;
+  spar[nzmin] = 0.0;
+  for (int k = nzmin; k <= nzmax && k + 1 <= m.nlm1 && k + 1 < 64; k++) {          // (the search ends at 50 m depth: far above the bottom)
+    const double drhodz = DA2L(m.bvfreq, k, n) * D_RHO0 / D_G;
+    if (drhodz >= 0.01 || DA2(m.Z_3d_n, k, n) < -50.0) break;
+    kml = kml + 1;
+    const double x = DA2(m.Z_3d_n, 1, n) - DA2(m.Z_3d_n, k + 1, n), x2 = x * x;
+    spar[k + 1] = DA2L(m.area, k + 1, n) * DA2(m.hnode, k + 1, n) * (x * (x2 * x2));
+  }
+  if (kml > nzmin) {
+    DTR(m.tr_arr, nzmin, n, 1) = DTR(m.tr_arr, nzmin, n, 1) - rej / DA2L(m.areasvol, 1, n) / DA2(m.hnode, 1, n);
+    for (int k = nzmin + 1; k <= kml; k++) ssum = ssum + spar[k];
+    for (int k = nzmin + 1; k <= kml; k++) {
+      const double w = spar[k] / ssum;
+      DTR(m.tr_arr, k, n, 1) = DTR(m.tr_arr, k, n, 1) + rej * w / DA2L(m.areasvol, k, n) / DA2(m.hnode, k, n);
+    }
+  }
+}
 // relax_to_clim (clim_relax > 0, src/oce_tracer_mod.F90:86-121) after diff_tracers_ale: T and S of the owned nodes towards the climatology at the nodal rate
 // relax2clim; the salinity clamp follows it as in the reference.  grid.y = tracer (0, 1).
 __global__ void __launch_bounds__(BLOCK) k_relax_clim(DM m, int tr0) {
@@ -949,6 +982,7 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
     if (!strcmp(name, "k_fct_edge_limit")) { LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr); return 0; }
     if (!strcmp(name, "k_diff_flux")) { LAUNCH_DFX(m, tr); return 0; }
     if (!strcmp(name, "k_tr_update")) { LAUNCH_TRU(m, tr); return 0; }
+    if (!strcmp(name, "k_spp")) { if (m.p.SPP) hipLaunchKernelGGL(k_spp, dim3((m.N + 127) / 128), dim3(128), 0, s, m); return 0; }
     if (!strcmp(name, "k_bh1")) { hipLaunchKernelGGL(k_bh1, dim3(nblocks(m.myN), tr < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m, tr < 0 ? 0 : tr); return 0; }
     if (!strcmp(name, "k_bh2")) { hipLaunchKernelGGL(k_bh2, dim3(nblocks(m.myN), tr < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m, tr < 0 ? 0 : tr); return 0; }
     return -1;
@@ -977,6 +1011,7 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
       hipLaunchKernelGGL(k_relax_clim, dim3(nblocks(m.myN), tr < 0 ? (m.ntr < 2 ? m.ntr : 2) : 1), dim3(BLOCK), 0, s, m, tr < 0 ? 0 : tr);
     return 0;
   }
+  if (!strcmp(name, "spp")) { if (m.p.SPP) hipLaunchKernelGGL(k_spp, dim3((m.N + 127) / 128), dim3(128), 0, s, m); return 0; }
   if (!strcmp(name, "salinity_clamp")) return 0;
   return -1;
 }

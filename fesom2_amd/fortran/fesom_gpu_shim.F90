@@ -20,8 +20,9 @@ module fesom_gpu_shim
   use g_PARSUP
   use g_config
   use g_forcing_arrays, only: real_salt_flux, sw_3d
-  use i_ARRAYS, only: u_ice, v_ice, a_ice, m_ice, m_snow
-  use g_forcing_arrays, only: press_air
+  use i_ARRAYS, only: u_ice, v_ice, a_ice, m_ice, m_snow, S_oc_array
+  use g_forcing_arrays, only: press_air, thdgr
+  use i_therm_param, only: Sice
   use g_sbf, only: l_mslp
   implicit none
   private
@@ -71,7 +72,9 @@ module fesom_gpu_shim
      real(c_double) :: ref_sss
      integer(c_int) :: smooth_bh_tra, double_diffusion
      integer(c_int) :: use_floatice, l_mslp, use_global_tides
-     real(c_double) :: max_ice_loading, clim_relax
+     real(c_double) :: max_ice_loading
+     integer(c_int) :: SPP
+     real(c_double) :: Sice, clim_relax
   end type
   type, bind(C) :: fesom_state_desc
      type(c_ptr) :: tr_arr, tr_arr_old, UV, UV_rhsAB, eta_n, d_eta, ssh_rhs, ssh_rhs_old, hbar, hbar_old, dhe, hnode, hnode_new, &
@@ -82,7 +85,7 @@ module fesom_gpu_shim
      type(c_funptr) :: exchange, allreduce_sum
   end type
   type, bind(C) :: fesom_forcing_desc
-     type(c_ptr) :: stress_surf, heat_flux, water_flux, virtual_salt, relax_salt, real_salt_flux, stress_atmoce_x, stress_atmoce_y, sw_3d, m_ice, m_snow, press_air, ssh_gp, u_ice, v_ice, a_ice
+     type(c_ptr) :: stress_surf, heat_flux, water_flux, virtual_salt, relax_salt, real_salt_flux, stress_atmoce_x, stress_atmoce_y, sw_3d, m_ice, m_snow, press_air, ssh_gp, thdgr, S_oc_array, u_ice, v_ice, a_ice
   end type
 
   interface
@@ -302,8 +305,8 @@ contains
     end if
 
     call refuse(use_cavity .or. use_cavity_partial_cell, 'use_cavity / use_cavity_partial_cell (ice-shelf cavities)')
-    call refuse(SPP, 'SPP (salt plume parameterization, oce_ale_tracer.F90:120)')
     call refuse(use_kpp_nonlclflx .and. mix_scheme_nmb /= 1, 'use_kpp_nonlclflx with a mixing scheme other than KPP (oce_ale_tracer.F90:725)')
+    call refuse(SPP .and. .not. (allocated(thdgr) .and. allocated(S_oc_array)), 'SPP without the sea-ice arrays thdgr / S_oc_array (gen_forcing_init.F90:134, ice_setup_step.F90:127)')
     call refuse(use_momix .and. .not. allocated(mixlength), 'use_momix without the ice arrays (the reference allocates mo / mixlength only with use_ice, oce_setup_step.F90:218)')
     call status_check
 
@@ -362,6 +365,7 @@ contains
     p%double_diffusion = l2i(double_diffusion); p%smooth_bh_tra = l2i(smooth_bh_tra)
     p%use_floatice = l2i(use_floatice .and. .not. trim(which_ALE)=='linfs'); p%l_mslp = l2i(l_mslp); p%use_global_tides = l2i(use_global_tides)
     p%max_ice_loading = max_ice_loading; p%clim_relax = clim_relax
+    p%SPP = l2i(SPP); p%Sice = Sice
     p%solver_precond = 1; p%solver_xinv_its = 0     ! explicit-inverse preconditioner where it fits (pi), library default iterations
 
     transport%ctx = c_null_ptr
@@ -406,6 +410,10 @@ contains
     end if
     if (l_mslp .and. allocated(press_air)) f%press_air = ar(press_air)
     if (use_global_tides .and. allocated(ssh_gp)) f%ssh_gp = ar(ssh_gp)
+    f%thdgr = c_null_ptr; f%S_oc_array = c_null_ptr
+    if (SPP .and. allocated(thdgr) .and. allocated(S_oc_array)) then
+       f%thdgr = ar(thdgr); f%S_oc_array = ar(S_oc_array)
+    end if
     f%u_ice = c_null_ptr; f%v_ice = c_null_ptr; f%a_ice = c_null_ptr
     if (use_momix .and. allocated(a_ice)) then
        f%u_ice = ar(u_ice); f%v_ice = ar(v_ice); f%a_ice = ar(a_ice)

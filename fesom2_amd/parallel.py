@@ -94,6 +94,8 @@ def run_step(core, par, X, solve, first, probe=None, n=1, zonal=None):
     c("k_dhe"); P("vert_vel")
     if p.Fer_GM:
         c("bolus_add")
+    if p.SPP:
+        c("k_spp", 0)
     c("k_tr_ab", 0); c("k_tr_grad_elem", 0); X(ELEM_FULL, ["tr_xy_ab"])
     c("k_updn_grad", 0)
     c("k_tr_z", 0)

@@ -154,6 +154,9 @@ typedef struct fesom_params {
   int    l_mslp;             /* atmospheric pressure press_air / 1000 */
   int    use_global_tides;   /* tidal potential ssh_gp (gen_modules_gpot.F90) */
   double max_ice_loading;    /* namelist.config &ale_def (5.0) */
+  int    SPP;                /* salt plume parameterization at the head of solve_tracers_ale (cal_rejected_salt / app_rejected_salt, src/oce_spp.F90): the salt rejected by
+                                growing ice (thdgr > 0, from S_oc_array and Sice) is taken from the surface layer and spread over the mixed layer (northern hemisphere) */
+  double Sice;               /* ice salinity (i_therm_param, 4.0) */
   double clim_relax;         /* > 1e-8: relax_to_clim after diff_tracers_ale (oce_tracer_mod.F90:86-121): T, S += relax2clim(n) * dt * (clim - tracer); the static
                                 arrays Tclim, Sclim (nl-1,N) and relax2clim (N) are handed over once with fesom_gpu_set_field */
 } fesom_params;
@@ -183,6 +186,7 @@ typedef struct fesom_forcing_desc {
   const double *m_ice, *m_snow;  /* (N) ice and snow thickness of i_ARRAYS; use_floatice only */
   const double *press_air;       /* (N) g_forcing_arrays; l_mslp only */
   const double *ssh_gp;          /* (N) o_ARRAYS; use_global_tides only */
+  const double *thdgr, *S_oc_array;   /* (N) ice growth rate (g_forcing_arrays) and the ocean salinity seen by the ice (i_ARRAYS); SPP only */
   const double *u_ice, *v_ice, *a_ice;   /* (N) ice velocity and concentration of i_ARRAYS: the turbulent-kinetic-energy source of mo_length (oce_mo_conv.F90:36-39); use_momix only */
 } fesom_forcing_desc;
 

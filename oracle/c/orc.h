@@ -30,6 +30,7 @@ typedef struct {
   /* node 2D */
   double *eta_n, *d_eta, *ssh_rhs, *ssh_rhs_old, *hbar, *hbar_old, *MLD1, *MLD2;
   double *heat_flux, *water_flux, *virtual_salt, *relax_salt, *real_salt_flux;
+  double *thdgr, *S_oc_array;                    /* SPP: ice growth rate, ocean salinity seen by the ice (N) */
   double *m_ice, *m_snow, *press_air, *ssh_gp;   /* use_floatice / l_mslp / use_global_tides: surface potentials of compute_vel_rhs (N) */
   double *u_ice, *v_ice, *a_ice, *mixlength;     /* use_momix: ice state (input) and the Monin-Obukhov mixing length (N), kept from step to step */
   /* elem */
@@ -139,6 +140,7 @@ void orc_compute_zonal_mean(void);
 void orc_relax_zonal_vel(void);
 void orc_relax_zonal_temp(void);
 void orc_relax_to_clim(int tr);
+void orc_spp(void);
 void orc_toy_set_partition(const int *owner, int nranks);
 void orc_step(int n);
 #endif

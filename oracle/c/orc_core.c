@@ -41,7 +41,7 @@ int orc_init(const fesom_mesh_desc *m, const fesom_params *p) {
   R(U_c, 2 * n1 * N);
   R(eta_n, N); R(d_eta, N); R(ssh_rhs, N); R(ssh_rhs_old, N); R(hbar, N); R(hbar_old, N); R(MLD1, N); R(MLD2, N);
   R(heat_flux, N); R(water_flux, N); R(virtual_salt, N); R(relax_salt, N); R(real_salt_flux, N);
-  R(u_ice, N); R(v_ice, N); R(a_ice, N); R(mixlength, N); R(m_ice, N); R(m_snow, N); R(press_air, N); R(ssh_gp, N);
+  R(u_ice, N); R(v_ice, N); R(a_ice, N); R(mixlength, N); R(m_ice, N); R(m_snow, N); R(press_air, N); R(ssh_gp, N); R(thdgr, N); R(S_oc_array, N);
   R(UV, 2 * n1 * E); R(UV_rhs, 2 * n1 * E); R(UV_rhsAB, 2 * n1 * E); R(tr_xy, 2 * n1 * E); R(U_b, 2 * n1 * E); R(fct_ebnd, 2 * n1 * E);
   R(pgf_x, n1 * E); R(pgf_y, n1 * E); R(helem, n1 * E); R(Av, nl * E); R(dhe, E); R(stress_surf, 2 * E);
   R(Visc, n1 * E); R(vorticity, n1 * N); R(leith_aux, n1 * N); R(KE_node, n1 * N);
@@ -307,6 +307,7 @@ void orc_step(int n) {
   if (C_.p.Fer_GM || C_.p.Redi) orc_init_Redi_GM();                                        /* oce_ale.F90:2729-2739 */
   if (C_.p.Fer_GM) { orc_fer_solve_Gamma(); orc_fer_gamma2vel(); }
   orc_vert_vel_ale();
+  if (C_.p.SPP) orc_spp();                                                                  /* solve_tracers_ale :120-121 */
   if (C_.p.Fer_GM) { orc_fer_wvel(); orc_bolus_add(); }                                   /* oce_ale.F90:1720-1811, oce_ale_tracer.F90:127-131 */
   for (int tr = 1; tr <= C_.ntr; tr++) {
     orc_init_tracers_AB(tr);
@@ -329,7 +330,7 @@ int orc_call(const char *name, int arg) {
   CALL0(compute_hbar_ale) CALL0(eta_update) CALL0(vert_vel_ale) CALL1(init_tracers_AB) CALL1(adv_tracers_ale)
   CALL1(diff_tracers_ale) CALL0(salinity_clamp) CALL0(update_thickness_ale) CALL1(step)
   CALL0(init_Redi_GM) CALL0(fer_solve_Gamma) CALL0(fer_gamma2vel) CALL0(fer_wvel) CALL0(bolus_add) CALL0(bolus_remove)
-  CALL0(compute_zonal_mean_ini) CALL0(compute_zonal_mean) CALL0(relax_zonal_vel) CALL0(relax_zonal_temp) CALL1(relax_to_clim)
+  CALL0(compute_zonal_mean_ini) CALL0(compute_zonal_mean) CALL0(relax_zonal_vel) CALL0(relax_zonal_temp) CALL1(relax_to_clim) CALL0(spp)
   fprintf(stderr, "orc_call: unknown routine %s\n", name);
   return 1;
 }

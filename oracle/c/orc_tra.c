@@ -711,6 +711,37 @@ void orc_diff_tracers_ale(int tr) {
   if (C_.p.smooth_bh_tra) diff_part_bh(tr);
 }
 
+/* cal_rejected_salt + app_rejected_salt (SPP): src/oce_spp.F90.  spar(k)**n_distr with the integer variable n_distr = 5 is what the compiler's runtime makes of
+ * it (__powidf2: repeated squaring, x * (x^2)^2). */
+void orc_spp(void) {
+  const double aux = 910. / 1025. * C_.p.dt;
+  double spar[128];
+  for (int n = 1; n <= C_.N; n++) {
+    const int nzmin = ULEVN(n), nzmax = NLEVN(n);
+    double rej = 0.0;
+    if (C_.thdgr[n - 1] > 0.0 && nzmin == 1) rej = (C_.S_oc_array[n - 1] - C_.p.Sice) * C_.thdgr[n - 1] * aux * AREA(1, n);
+    if (nzmin > 1) continue;
+    if (rej <= 0.0) continue;
+    if (TR(nzmin, n, 2) < 10.0) continue;
+    if (!(C_.m.geo_coord_nod2D[2 * (n - 1) + 1] > 0.0)) continue;
+    int kml = 1;
+    spar[nzmin] = 0.0;
+    for (int k = nzmin; k <= nzmax; k++) {
+      const double drhodz = A2L(C_.bvfreq, k, n) * DENSITY_0 / G_ACC;
+      if (drhodz >= 0.01 || A2(C_.Z_3d_n, k, n) < -50.0) break;
+      kml = kml + 1;
+      const double x = A2(C_.Z_3d_n, 1, n) - A2(C_.Z_3d_n, k + 1, n), x2 = x * x;
+      spar[k + 1] = AREA(k + 1, n) * A2(C_.hnode, k + 1, n) * (x * (x2 * x2));
+    }
+    if (kml > nzmin) {
+      TR(nzmin, n, 2) = TR(nzmin, n, 2) - rej / AREASVOL(1, n) / A2(C_.hnode, 1, n);
+      double ssum = 0.0;
+      for (int k = nzmin + 1; k <= kml; k++) ssum = ssum + spar[k];
+      for (int k = nzmin + 1; k <= kml; k++) TR(k, n, 2) = TR(k, n, 2) + rej * (spar[k] / ssum) / AREASVOL(k, n) / A2(C_.hnode, k, n);
+    }
+  }
+}
+
 /* relax_to_clim: src/oce_tracer_mod.F90:86-121 (clim_relax > 0; T towards Tclim, S towards Sclim at the nodal rate relax2clim) */
 void orc_relax_to_clim(int tr) {
   if (!(C_.p.clim_relax > 1.0e-8) || tr > 2) return;

@@ -219,6 +219,19 @@ program oracle_driver
      end do
   end if
 
+  if (SPP) then
+     ! salt plume parameterization (src/oce_spp.F90): the ice growth rate thdgr and the salinity S_oc_array the ice model saw come from the sea-ice thermodynamics,
+     ! which the harness does not run; analytic fields instead (its own choice): growth at high latitudes of BOTH hemispheres (the routine acts in the northern one
+     ! only), melt (thdgr<0) elsewhere
+     if (.not. allocated(thdgr)) allocate(thdgr(myDim_nod2D+eDim_nod2D))
+     if (.not. allocated(S_oc_array)) allocate(S_oc_array(myDim_nod2D+eDim_nod2D))
+     do i=1, myDim_nod2D+eDim_nod2D
+        flon=mesh%geo_coord_nod2D(1,i); flat=mesh%geo_coord_nod2D(2,i)
+        thdgr(i)=3.0e-7_WP*(abs(sin(flat))-0.7_WP)*(1.0_WP+0.3_WP*cos(2.0_WP*flon))
+        S_oc_array(i)=33.0_WP+1.5_WP*cos(flon)
+     end do
+  end if
+
   if (clim_relax>1.0e-8_WP .and. .not. toy_ocean) then
      ! relax_to_clim (src/oce_tracer_mod.F90:86-121): the reference fills relax2clim in its regional initial-state routines (oce_ice_init_state.F90), which the
      ! harness does not call; an analytic rate instead (its own choice): clim_relax near the poles, zero in the tropics
@@ -362,6 +375,9 @@ contains
        call dump('forcing.m_ice', m_ice); call dump('forcing.m_snow', m_snow)
     end if
     if (l_mslp .and. allocated(press_air)) call dump('forcing.press_air', press_air)
+    if (SPP) then
+       call dump('forcing.thdgr', thdgr); call dump('forcing.S_oc_array', S_oc_array)
+    end if
     if (use_global_tides .and. allocated(ssh_gp)) call dump('forcing.ssh_gp', ssh_gp)
     if (use_momix .and. allocated(a_ice)) then
        call dump('forcing.u_ice', u_ice); call dump('forcing.v_ice', v_ice); call dump('forcing.a_ice', a_ice)
@@ -635,6 +651,12 @@ contains
     if (Fer_GM) call dump('gm.fer_Wvel', fer_Wvel)
 
     ! ---- solve_tracers_ale replayed (src/oce_ale_tracer.F90:101-199) ----
+    if (SPP) then
+       call mark('spp')
+       call cal_rejected_salt(mesh)
+       call app_rejected_salt(mesh)
+       call dump('spp.salt', tr_arr(:,:,2))
+    end if
     if (Fer_GM) then
        UV    =UV    +fer_UV
        Wvel_e=Wvel_e+fer_Wvel

@@ -74,7 +74,7 @@ def make(cfg, outname):
         # the harness's analytic surface forcing, in full (global numbering): the tests hand it to the oracle / HIP path
         for k in ("stress_atmoce_x", "stress_atmoce_y", "heat_flux", "water_flux", "stress_surf"):
             out["forcing/" + k] = assemble(setups, setups, "forcing." + k).astype(np.float64)
-        for k in ("u_ice", "v_ice", "a_ice", "m_ice", "m_snow", "press_air", "ssh_gp", "relax2clim"):    # use_momix / surface potentials: the harness's analytic fields
+        for k in ("u_ice", "v_ice", "a_ice", "m_ice", "m_snow", "press_air", "ssh_gp", "relax2clim", "thdgr", "S_oc_array"):    # use_momix / surface potentials: the harness's analytic fields
             if "forcing." + k in setups[0]:
                 out["forcing/" + k] = assemble(setups, setups, "forcing." + k).astype(np.float64)
         if "forcing.sw_3d" in setups[0]:                   # (nl, N): only a digest; fesom2_amd.synthetic.analytic_sw_3d reproduces the bits
@@ -114,6 +114,7 @@ def main():
     make("pi_default_sw", "pi_default_sw_reference.npz")  # default physics + short-wave penetration
     make("pi_pp_non", "pi_pp_non_reference.npz")        # tra_adv_lim = 'NON'
     make("pi_pp_climrelax", "pi_pp_climrelax_reference.npz")  # clim_relax > 0
+    make("pi_pp_linfs_spp", "pi_pp_linfs_spp_reference.npz")  # SPP (salt plume parameterization)
     make("pi_pp_surfpot", "pi_pp_surfpot_reference.npz")  # use_floatice + l_mslp + use_global_tides
     make("pi_pp_bhtra", "pi_pp_bhtra_reference.npz")    # smooth_bh_tra
     make("pi_kpp_dd", "pi_kpp_dd_reference.npz")        # KPP + double_diffusion

@@ -72,7 +72,7 @@ def full_chain(ntr=2, gm=False, redi=False, kpp=False):
 def bits_equal(a, b):
     a = np.ascontiguousarray(a, dtype=np.float64).ravel()
     b = np.ascontiguousarray(b, dtype=np.float64).ravel()
-    return (a.view(np.int64) == b.view(np.int64)) | ((a == 0) & (b == 0))
+    return (a.view(np.int64) == b.view(np.int64)) | ((a == 0) & (b == 0)) | (np.isnan(a) & np.isnan(b))     # (NaN: sign/payload of 0/0 are the machine's)
 
 
 def compare(name, a, b):

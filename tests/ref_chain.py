@@ -91,6 +91,8 @@ def run_reference_chain(orc, mesh, g, steps=(1, 2, 3), toy=False, skip=(), after
         if gm:
             orc.call("fer_wvel"); chk(step, "fer_Wvel", "gm.fer_Wvel", "nl")
             orc.call("bolus_add")                           # solve_tracers_ale: UV, Wvel(_e) += bolus velocities around the tracer loop
+        if orc.params.SPP:                                  # solve_tracers_ale :120-121 (src/oce_spp.F90)
+            orc.call("spp"); chk(step, "tr_arr", "spp.salt", "n", sub=1)
         for tr in (1, 2):
             p = f"tr{tr}."
             orc.call("init_tracers_AB", tr)

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 NSTEPS = 10
 
 
-@pytest.mark.parametrize("cfg,ranks", [("pi_default", 1), ("pi_pp", 1), ("pi_default", 2), ("pi_default_sw", 2), ("pi_default", 4), ("pi_pp_momix", 1), ("pi_default_momix", 2), ("pi_pp_climrelax", 2), ("pi_pp_surfpot", 2), ("pi_pp_bhtra", 2), ("pi_kpp_dd", 2), ("pi_kpp_nonlcl", 2), ("pi_kpp_nonlcl_linfs", 2), ("pi_pp_linfs_vinv", 2), ("pi_pp_cubicspline", 2), ("pi_pp_linfs_cubic", 2), ("pi_pp_linfs_nemo", 2), ("pi_pp_easypgf", 2), ("pi_pp_linfs_easypgf", 2), ("pi_pp_linfs_pc", 2), ("pi_pp_visc1", 2), ("pi_pp_visc2", 2), ("pi_pp_visc3", 2), ("pi_pp_visc4", 2), ("pi_pp_non", 2), ("pi_pp_visc6", 1), ("pi_pp_visc7", 2), ("pi_pp_cdiff", 1), ("pi_pp_upw1v", 2), ("pi_pp_muscl", 2), ("pi_pp_upw1h", 1), ("pi_pp_ppm", 2), ("pi_kpp_kv0", 2)])
+@pytest.mark.parametrize("cfg,ranks", [("pi_default", 1), ("pi_pp", 1), ("pi_default", 2), ("pi_default_sw", 2), ("pi_default", 4), ("pi_pp_momix", 1), ("pi_default_momix", 2), ("pi_pp_climrelax", 2), ("pi_pp_linfs_spp", 2), ("pi_pp_surfpot", 2), ("pi_pp_bhtra", 2), ("pi_kpp_dd", 2), ("pi_kpp_nonlcl", 2), ("pi_kpp_nonlcl_linfs", 2), ("pi_pp_linfs_vinv", 2), ("pi_pp_cubicspline", 2), ("pi_pp_linfs_cubic", 2), ("pi_pp_linfs_nemo", 2), ("pi_pp_easypgf", 2), ("pi_pp_linfs_easypgf", 2), ("pi_pp_linfs_pc", 2), ("pi_pp_visc1", 2), ("pi_pp_visc2", 2), ("pi_pp_visc3", 2), ("pi_pp_visc4", 2), ("pi_pp_non", 2), ("pi_pp_visc6", 1), ("pi_pp_visc7", 2), ("pi_pp_cdiff", 1), ("pi_pp_upw1v", 2), ("pi_pp_muscl", 2), ("pi_pp_upw1h", 1), ("pi_pp_ppm", 2), ("pi_kpp_kv0", 2)])
 def test_fortran_dropin_matches_reference_cpu_step(built, cfg, ranks):
     """ranks = 2: two MPI ranks of the reference's own partition (dist_2) share the box's GPU; the Fortran layer hands the
     reference's com_struct lists to the library and moves the packed halo messages with MPI_Isend/Irecv (host-staged), the
@@ -45,9 +45,14 @@ def test_fortran_dropin_matches_reference_cpu_step(built, cfg, ranks):
     sc = [read_dump(os.path.join(rd_c, "dumps", f"setup.r{r:05d}.bin")) for r in range(2)]
     dc = [read_dump(os.path.join(rd_c, "dumps", f"state{NSTEPS:04d}.r{r:05d}.bin")) for r in range(2)]
     worst = {}
+    spp = run_ref.CFGS[cfg].get("SPP") == ".true."
     for f in ("eta_n", "tr_arr", "UV", "hnode", "hbar", "Wvel"):
         a, b = assemble(dg, sg, f), assemble(dc, sc, f)
         assert a is not None and b is not None and a.shape == b.shape, f
+        if spp and f == "tr_arr":                              # SPP: the reference leaves 0/0 below the bottom of shallow columns; both runs hold it in the same cells
+            both = np.isnan(a) & np.isnan(b)
+            assert 0 < both.sum() < 200
+            a[both] = 0.0; b[both] = 0.0
         assert np.isfinite(a).all(), f
         worst[f] = float(np.abs(a - b).max())
         assert np.abs(b).max() > 0
@@ -57,6 +62,8 @@ def test_fortran_dropin_matches_reference_cpu_step(built, cfg, ranks):
     vol_g = assemble(dg, sg, "hnode") * assemble(sg, sg, "areasvol")[:, :-1]
     vol_c = assemble(dc, sc, "hnode") * assemble(sc, sc, "areasvol")[:, :-1]
     tg, tc = assemble(dg, sg, "tr_arr"), assemble(dc, sc, "tr_arr")
+    if spp:
+        tg, tc = np.nan_to_num(tg), np.nan_to_num(tc)        # (below the bottom, where hnode = 0)
     for k, name in ((0, "heat"), (1, "salt")):
         cg_, cc_ = float((tg[k] * vol_g).sum()), float((tc[k] * vol_c).sum())
         cons[name] = abs(cg_ - cc_) / abs(cc_)

@@ -512,6 +512,60 @@ def test_biharmonic_viscosity_chain_bitwise(built, opt):
     gpu.close()
 
 
+def test_spp_chain_bitwise(built):
+    """SPP = .true. (k_spp: cal_rejected_salt + app_rejected_salt at the head of solve_tracers_ale, linfs; oracle pinned on the reference run pi_pp_linfs_spp):
+    HIP == oracle bit for bit after every routine of 3 steps and after 6 further whole steps.  (The reference leaves 0/0 in the salinity below the bottom of
+    columns shallower than the plume depth; the comparison takes NaN == NaN there and is bitwise everywhere else.)"""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.core import OceanCore
+    from fesom2_amd.synthetic import analytic_ts, analytic_forcing
+    from oracle_lib import Oracle
+    mesh = Mesh.load(PI, dt=900.0, which_ale="linfs", use_partial_cell=False)
+    par = make_params(dt=900.0, which_ale="linfs", use_partial_cell=False, SPP=True)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    gpu, orc = OceanCore(mesh, par), Oracle(mesh, par)
+    gpu.upload_state(st); orc.set_state(st)
+    forcing = analytic_forcing(mesh)
+    lon, lat = mesh.geo_coord_nod2D[:, 0], mesh.geo_coord_nod2D[:, 1]
+    forcing["thdgr"] = 3.0e-7 * (np.abs(np.sin(lat)) - 0.7) * (1.0 + 0.3 * np.cos(2.0 * lon))
+    forcing["S_oc_array"] = 33.0 + 1.5 * np.cos(lon)
+    gpu.set_forcing(**forcing)
+    for k, v in forcing.items():
+        orc.set(k, v)
+    chain = full_chain(2)
+    i0 = [r for r, _, _ in chain].index("init_tracers_AB")
+    chain = chain[:i0] + [("spp", 0, ["tr_arr"])] + chain[i0:]
+    failures = []
+    for step in range(1, 4):
+        for routine, arg, fields in chain:
+            if routine == "spp":
+                S0 = orc.get("tr_arr").copy()
+            gpu.call(routine, arg); orc.call(routine, arg)
+            for f in fields:
+                ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+                if not ok:
+                    failures.append(f"step {step} {routine}({arg}) {msg}")
+            if routine == "spp":
+                d = np.nan_to_num(orc.get("tr_arr") - S0).reshape(2, -1, mesh.nl - 1)
+                assert d[0].max() == 0.0 and d[0].min() == 0.0 and d[1].min() < -1e-5 and d[1].max() > 1e-6      # salt leaves the surface cell for the plume
+                assert not (d[1][lat <= 0.0] != 0.0).any()                                                            # northern hemisphere only
+        if failures:
+            break
+    assert not failures, "\n".join(failures[:10])
+    gpu.run_steps(4, 6)
+    for n in range(6):
+        orc.call("step", 4 + n)
+    for f in ("tr_arr", "UV", "eta_n", "hnode", "hbar", "Wvel"):
+        ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+        assert ok, msg
+    wet = (np.arange(mesh.nl - 1)[None, :] < (mesh.nlevels_nod2D[:, None] - 1))
+    assert np.isfinite(gpu.get("tr_arr", orc.count("tr_arr")).reshape(2, -1, mesh.nl - 1)[:, wet]).all()       # the 0/0 stays below the bottom
+    gpu.close()
+
+
 def test_relax_to_clim_chain_bitwise(built):
     """clim_relax > 0 (k_relax_clim after the tracer update, the salinity clamp behind it; oracle pinned on the reference run pi_pp_climrelax): HIP == oracle bit
     for bit after every routine of 3 steps and after 6 further whole steps."""

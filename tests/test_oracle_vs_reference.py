@@ -337,6 +337,31 @@ def test_oracle_chain_bitwise_relax_to_clim(built):
     assert not np.array_equal(g["s3/tr1.end.tr_arr"], gz["s3/tr1.end.tr_arr"])
 
 
+def test_oracle_chain_bitwise_spp(built):
+    """SPP = .true. (salt plume parameterization, cal_rejected_salt + app_rejected_salt, src/oce_spp.F90, at the head of solve_tracers_ale; linfs as the routine's
+    header asks; the harness's analytic ice growth rate thdgr and S_oc_array): reference run `pi_pp_linfs_spp`, every routine of 3 steps bit for bit."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.synthetic import analytic_ts
+    from oracle_lib import Oracle
+    from ref_chain import run_reference_chain
+    mesh = Mesh.load(PI, dt=900.0, which_ale="linfs", use_partial_cell=False)
+    par = make_params(dt=900.0, which_ale="linfs", use_partial_cell=False, SPP=True)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    orc = Oracle(mesh, par)
+    orc.set_state(st)
+    g = gold("pi_pp_linfs_spp")
+    for f in FORCING + ("thdgr", "S_oc_array"):
+        orc.set(f, g["forcing/" + f])
+    bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
+    assert not bad, "\n".join(bad[:20])
+    gz = gold("pi_pp_linfs_vinv")                                   # (a run without SPP from the same initial salinity)
+    assert not np.array_equal(g["s1/tr2.init_AB.tr_arr_old"], gz["s1/tr2.init_AB.tr_arr_old"])      # the plumes moved salt before the tracer loop
+    assert (g["forcing/thdgr"] > 0).any() and (g["forcing/thdgr"] < 0).any()
+
+
 def test_oracle_chain_bitwise_surface_potentials(built):
     """use_floatice (ice + snow load, limited by max_ice_loading), l_mslp (atmospheric pressure) and use_global_tides (tidal potential) in the surface pressure
     gradient of compute_vel_rhs (src/oce_ale_vel_rhs.F90:52-76), with the harness's analytic fields: reference run `pi_pp_surfpot`, every routine of 3 steps bit for bit."""
