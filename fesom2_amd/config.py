@@ -11,7 +11,7 @@ def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equati
                 K_GM_resscalorder=1.0, scaling_Ferreira=False, scaling_resolution=True, scaling_FESOM14=False, Redi=False,
                 visc_sh_limit=5.0e-3, diff_sh_limit=5.0e-3, Ricr=0.3, concv=1.6,
                 gamma0=0.003, gamma1=0.1, gamma2=0.285, easy_bs_return=1.5, C_d=0.0025, w_max_cfl=1.0, use_sw_pene=False, visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=True,
-                solver_precond=1, solver_xinv_its=0, tra_adv_lim="FCT", Leith_c=0.05, Div_c=0.5, which_pgf="shchepetkin", use_momix=False, momix_lat=-50.0, momix_kv=0.01, mom_adv=2, use_kpp_nonlclflx=False, ref_sss_local=True, ref_sss=34.0, double_diffusion=False, smooth_bh_tra=False, use_floatice=False, l_mslp=False, use_global_tides=False, max_ice_loading=5.0, clim_relax=0.0, SPP=False, Sice=4.0):
+                solver_precond=1, solver_xinv_its=0, tra_adv_lim="FCT", Leith_c=0.05, Div_c=0.5, which_pgf="shchepetkin", use_momix=False, momix_lat=-50.0, momix_kv=0.01, mom_adv=2, use_kpp_nonlclflx=False, ref_sss_local=True, ref_sss=34.0, double_diffusion=False, smooth_bh_tra=False, use_floatice=False, l_mslp=False, use_global_tides=False, max_ice_loading=5.0, clim_relax=0.0, SPP=False, Sice=4.0, min_hnode=0.5, lzstar_lev=4):
     p = _lib.Params()
     p.dt = dt
     p.which_ale = WHICH_ALE[which_ale]
@@ -58,6 +58,7 @@ def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equati
     p.smooth_bh_tra = int(smooth_bh_tra)               # config/namelist.oce:57
     p.use_floatice, p.l_mslp, p.use_global_tides, p.max_ice_loading = int(use_floatice and which_ale != "linfs"), int(l_mslp), int(use_global_tides), max_ice_loading
     p.clim_relax = clim_relax                          # config/namelist.oce:70
+    p.min_hnode, p.lzstar_lev = min_hnode, lzstar_lev  # gen_modules_config.F90:60,64 (zlevel)
     p.SPP, p.Sice = int(SPP), Sice                     # config/namelist.oce:26, src/ice_modules.F90:132
     linfs = (which_ale == "linfs")
     p.use_kpp_nonlclflx, p.ref_sss_local, p.ref_sss = int(use_kpp_nonlclflx), int(ref_sss_local and linfs), (ref_sss if linfs else 0.0)   # config/namelist.oce:71-72, :83

@@ -55,6 +55,10 @@ class OceanCore:
         """Enqueue nsteps steps back to back (no host synchronisation)."""
         self._chk(self.lib.fesom_gpu_run_steps(int(n_first), int(nsteps)), "run_steps")
 
+    def sync(self):
+        """wait for the enqueued steps; deferred device-side errors (zlevel: the missing local-zstar fallback) are reported here"""
+        self._chk(self.lib.fesom_gpu_sync(), "sync")
+
     def step_info(self):
         """device-side step monitor (write_step_info + check_blowup of the reference) over the owned nodes; returns a dict"""
         si = _lib.StepInfo()

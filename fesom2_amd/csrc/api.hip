@@ -376,7 +376,8 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { G.err = "no HIP device: the MI355X path has no CPU fallback"; fprintf(stderr, "fesom_gpu: %s\n", G.err.c_str()); return 2; }
   if (d->nl > 64) { G.err = "fesom_gpu_init: nl > 64 levels not supported by the one-wave-per-column kernels"; return 3; }
-  if (par->which_ale != 0 && par->which_ale != 2) { G.err = "fesom_gpu_init: which_ale must be linfs(0) or zstar(2)"; return 3; }
+  if (par->which_ale < 0 || par->which_ale > 2) { G.err = "fesom_gpu_init: which_ale must be linfs (0), zlevel (1) or zstar (2)"; return 3; }
+  if (par->which_ale == 1 && (par->lzstar_lev < 1 || par->lzstar_lev > 32 || par->lzstar_lev + 1 > d->nl - 1)) { G.err = "fesom_gpu_init: which_ALE='zlevel' needs 1 <= lzstar_lev <= 32 and lzstar_lev + 1 layers"; return 3; }
   if ((par->mom_adv != 2 && par->mom_adv != 3) || par->visc_option < 1 || par->visc_option > 7) { G.err = "fesom_gpu_init: only mom_adv=2 or 3, visc_option=1..7 are implemented"; return 3; }
   if (par->mom_adv == 3 && par->which_ale != 0) { G.err = "fesom_gpu_init: mom_adv=3 (vector-invariant momentum) needs which_ALE='linfs': it reads hpressure, which the reference forms only there (oce_ale_pressure_bv.F90:262)"; return 3; }
   if (par->which_pgf != 0 && par->which_pgf != 1 && !(par->which_pgf == 2 && par->which_ale == 0) && !(par->which_pgf == 3) && !(par->which_ale == 0 && !par->use_partial_cell)) {
@@ -550,6 +551,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   F(ssh_values, m.nza);
   if (par->visc_option <= 3) { F(Visc, n1 * E); F(leith_aux, n1 * N); }
   if (par->smooth_bh_tra) FT(bh_tmp, n1 * N);
+  m.ale_flag = dev_alloc<int>(1); HIPCHK(hipMemset(m.ale_flag, 0, sizeof(int)));
   if (par->SPP) { std::vector<double> gl(N); for (size_t n = 0; n < N; n++) gl[n] = d->geo_coord_nod2D[2 * n + 1]; m.geo_lat = dev_upload(gl); }
   if (par->visc_option <= 3 || par->mom_adv == 3) F(vorticity, n1 * N);
   if (par->mom_adv == 3) {
@@ -751,6 +753,15 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
 
 #define NEED_READY() if (!G.ready) { G.err = "fesom_gpu: not initialised"; return 1; }
 
+// zlevel: a column whose surface layer would fall below min_hnode needs the reference's local-zstar fallback (oce_ale.F90:1859-1942), which is not built (the
+// reference itself stops in update_thickness_ale's non-conformable PACK there under flang): reported at the next synchronising call
+static int check_ale_flag() {
+  if (G.m.p.which_ale != 1) return 0;
+  int f = 0;
+  HIPCHK(hipMemcpy(&f, G.m.ale_flag, sizeof(int), hipMemcpyDeviceToHost));
+  if (f) { G.err = "which_ALE='zlevel': the surface layer of a column fell below min_hnode of its resting thickness; the local-zstar fallback of vert_vel_ale is not implemented"; return 1; }
+  return 0;
+}
 static int copy_state(const fesom_state_desc *st, bool up) {
   NEED_READY();
   struct { const char *n; double *h; } tab[] = {
@@ -759,6 +770,7 @@ static int copy_state(const fesom_state_desc *st, bool up) {
       {"dhe", st->dhe}, {"hnode", st->hnode}, {"hnode_new", st->hnode_new}, {"helem", st->helem}, {"zbar_3d_n", st->zbar_3d_n},
       {"Z_3d_n", st->Z_3d_n}, {"Wvel", st->Wvel}, {"Wvel_e", st->Wvel_e}, {"Wvel_i", st->Wvel_i}, {"ssh_values", st->ssh_values}};
   HIPCHK(hipStreamSynchronize(G.stream));
+  if (!up && check_ale_flag()) return 1;
   for (auto &t : tab) {
     if (!t.h) continue;
     Field &f = G.fields[t.n];
@@ -1069,7 +1081,7 @@ int fesom_gpu_step_info(fesom_step_info *out) {
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, G.mon_out, sizeof(fesom_step_info), hipMemcpyDeviceToHost, G.stream));
   HIPCHK(hipStreamSynchronize(G.stream));
-  return 0;
+  return check_ale_flag();
 }
 
 int fesom_gpu_get_field(const char *name, double *out, long long count) {
@@ -1470,7 +1482,7 @@ int fesom_gpu_field_ptr(const char *name, void **dev, long long *count) {
   *dev = it->second.p; *count = (long long)it->second.count;
   return 0;
 }
-int fesom_gpu_sync(void) { NEED_READY(); HIPCHK(hipStreamSynchronize(G.stream)); return 0; }
+int fesom_gpu_sync(void) { NEED_READY(); HIPCHK(hipStreamSynchronize(G.stream)); return check_ale_flag(); }
 // run every kernel of the library on the host's stream (e.g. torch.cuda.current_stream().cuda_stream), so that the host's
 // stream-ordered transport (RCCL) and the library's pack / unpack / compute kernels need no host synchronisation
 int fesom_gpu_set_stream(void *hip_stream) {

@@ -1301,6 +1301,34 @@ __global__ void __launch_bounds__(BLOCK) k_vert_vel(DM m, int fuse_hbar) {
     }
     if (nz == nzmin) W = W - m.water_flux[n];
   }
+  if (m.p.which_ale == 1) {                    // zlevel (oce_ale.F90:1830-2023): the ssh change goes into the surface layer
+    if (nzmin == 1) {
+      const double dh = hb_new - hb_old;
+      const int lz = m.p.lzstar_lev, k = nz - nzmin + 1;
+      const bool inl = k >= 1 && k <= lz && nz <= m.nlm1;
+      const double h_old = inl ? DA2(m.hnode, nz, n) : 0.0, zd = inl ? (m.zbar[nz - 1] - m.zbar[nz]) : 0.0;
+      const unsigned long long ne = __ballot(inl && h_old != zd);                      // layers off their resting thickness
+      if (dh < 0.0 && bcast(h_old, nzmin - 1) + dh <= bcast(zd, nzmin - 1) * m.p.min_hnode) *m.ale_flag = 1;     // the local-zstar fallback (:1859-1942) is not built
+      if (dh > 0.0 && (ne & ~(1ull << (nzmin - 1))) != 0ull) {           // return to zlevel (:1950-2003): refill the sub-surface layers first
+        const int nzr = (63 - __clzll((long long)ne)) - (nzmin - 1) + 1, nlm = m.nlev_n_min[n] - 2;
+        const int top = nzr < nlm ? nzr : nlm;
+        const double md = k == 1 ? 1000.0 : zd - h_old;
+        double rest = dh, integ = 0.0;
+        for (int kk = top; kk >= 1; kk--) {
+          const double d = dmin_(rest, bcast(md, nzmin - 1 + kk - 1));
+          rest = rest - d;
+          rest = dmax_(0.0, rest);
+          integ = integ + d;
+          if (k == kk) { W = W - integ / dt; hn_new = h_old + d; DA2(m.hnode_new, nz, n) = hn_new; }
+        }
+      } else if (nz == nzmin) {
+        W = W - dh / dt;
+        hn_new = h_old + dh;
+        DA2(m.hnode_new, nz, n) = hn_new;
+      }
+    }
+    if (nz == nzmin) W = W - m.water_flux[n];
+  }
   // CFL_z(nz) = |W(nz-1 .. )| pieces: c2 of the layer above + c1 of this layer
   double W_dn = shdn(W);                       // W(nz+1) ; W(nzmax+1) = 0
   if (nz == nzmax) W_dn = 0.0;
@@ -1326,11 +1354,21 @@ __global__ void __launch_bounds__(BLOCK) k_vert_vel(DM m, int fuse_hbar) {
   }
 }
 
-// update_thickness_ale (src/oce_ale.F90:800-993, zstar branch)
+// update_thickness_ale (src/oce_ale.F90:800-993, zlevel and zstar branches)
 __device__ __forceinline__ void thick_node_body(const DM &m, int n) {
   int l = lane_id(), nz = l + 1;
   if (n >= m.N) return;
   int nzmin = m.ulev_n[n], nzmax = m.nlev_n_min[n] - 2;
+  if (m.p.which_ale == 1) {                   // zlevel (oce_ale.F90:883-943): the surface layer, or the layers the return to zlevel changed
+    nzmin = m.ulev_n_max[n];
+    if (nzmin > 1) return;
+    const int lz = m.p.lzstar_lev, k = nz - nzmin + 1;
+    const bool inl = k >= 1 && k <= lz && nz <= m.nlm1;
+    const unsigned long long ch = __ballot(inl && (DA2(m.hnode_new, inl ? nz : 1, n) - DA2(m.hnode, inl ? nz : 1, n) != 0.0));
+    int top = nzmin;
+    if ((ch & ~(1ull << (nzmin - 1))) != 0ull) { top = 63 - __clzll((long long)ch) + 1; top = top < nzmax ? top : nzmax; }     // (nzmax = nlevels_nod2D_min - 2)
+    nzmax = top;
+  }
   if (nzmin > 1) return;
   bool in = (nz >= nzmin && nz <= nzmax);
   double hn = in ? DA2(m.hnode_new, nz, n) : 0.0;
@@ -1349,6 +1387,7 @@ __device__ __forceinline__ void thick_elem_body(const DM &m, int e) {
   if (e >= m.myE) return;
   int nzmin = m.ulev[e], nzmax = m.nlev[e] - 1;
   if (nzmin > 1) return;
+  if (m.p.which_ale == 1) nzmax = nzmin + 1;  // zlevel (oce_ale.F90:881-884): the surface layer only
   if (nz < nzmin || nz > nzmax - 1) return;
   int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
   // hnode after the update = hnode_new on every level the update touches, and the two are equal elsewhere: reading hnode_new
@@ -1412,7 +1451,7 @@ void launch_dynamics_post(const DM &m, hipStream_t s) {
   LAUNCH_COL(k_vert_vel, m.myN, m, 0);
 }
 void launch_thickness(const DM &m, hipStream_t s) {
-  if (m.p.which_ale != 2) return;
+  if (m.p.which_ale == 0) return;
   const int ncolN = nblocks(m.N) * COLS_PER_BLOCK;
   hipLaunchKernelGGL(k_thick, dim3(nblocks(m.N) + nblocks(m.myE)), dim3(BLOCK), 0, s, m, ncolN);
 }
@@ -1453,8 +1492,8 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
     if (!strcmp(name, "k_dhe")) { LAUNCH_FLAT(k_dhe, m.myE, m); return 0; }
     if (!strcmp(name, "k_vert_vel")) { LAUNCH_COL(k_vert_vel, m.myN, m, 0); return 0; }
     if (!strcmp(name, "k_vert_vel_hbar")) { LAUNCH_COL(k_vert_vel, m.myN, m, 1); return 0; }
-    if (!strcmp(name, "k_thick_node")) { LAUNCH_COL(k_thick_node, m.N, m); return 0; }
-    if (!strcmp(name, "k_thick_elem")) { LAUNCH_COL(k_thick_elem, m.myE, m); return 0; }
+    if (!strcmp(name, "k_thick_node")) { if (m.p.which_ale != 0) LAUNCH_COL(k_thick_node, m.N, m); return 0; }          // (linfs: update_thickness_ale does nothing)
+    if (!strcmp(name, "k_thick_elem")) { if (m.p.which_ale != 0) LAUNCH_COL(k_thick_elem, m.myE, m); return 0; }
     return -1;
   }
   if (!strcmp(name, "compute_vel_nodes")) { LAUNCH_COL(k_vel_nodes, m.myN, m); return 0; }

@@ -490,6 +490,9 @@ void ale_init(Mesh &m) {
     int nzmin = m.ulev_n[n - 1], nzmax = m.nlev_n[n - 1] - 1;
     if (m.o.which_ale == 0) {
       for (int nz = nzmin; nz <= nzmax - 1; nz++) h[nz] = (zb[nz] - zb[nz + 1]);
+    } else if (m.o.which_ale == 1) {   // zlevel (oce_ale.F90:630-660): the whole ssh variation in the top layer
+      h[nzmin] = (nzmin == 1 ? m.hbar[n - 1] : 0.0) + (zb[nzmin] - zb[nzmin + 1]);
+      for (int nz = nzmin + 1; nz <= nzmax - 1; nz++) h[nz] = (zb[nz] - zb[nz + 1]);
     } else {   // zstar
       if (nzmin == 1) {
         int nmin = m.nlev_n_min[n - 1];
@@ -507,6 +510,10 @@ void ale_init(Mesh &m) {
     int n1 = EN(1, e), n2 = EN(2, e), n3 = EN(3, e);
     if (m.o.which_ale == 0) {
       he[nzmin] = (m.zbar_e_srf[e - 1] - m.zbar[nzmin]);
+      for (int nz = nzmin + 1; nz <= nzmax - 1; nz++) he[nz] = (m.zbar[nz - 1] - m.zbar[nz]);
+    } else if (m.o.which_ale == 1) {   // zlevel (oce_ale.F90:663-690)
+      m.dhe[e - 1] = (m.hbar[n1 - 1] + m.hbar[n2 - 1] + m.hbar[n3 - 1]) / 3.0;
+      he[nzmin] = (nzmin == 1 ? m.dhe[e - 1] : 0.0) + (m.zbar_e_srf[e - 1] - m.zbar[nzmin]);
       for (int nz = nzmin + 1; nz <= nzmax - 1; nz++) he[nz] = (m.zbar[nz - 1] - m.zbar[nz]);
     } else {
       m.dhe[e - 1] = (m.hbar[n1 - 1] + m.hbar[n2 - 1] + m.hbar[n3 - 1]) / 3.0;
@@ -885,7 +892,7 @@ extern "C" {
 
 void *fesom_mesh_load(const char *meshdir, const fesom_mesh_opts *opts) {
   if (opts->npes < 1 || opts->mype < 0 || opts->mype >= opts->npes) { fprintf(stderr, "fesom_mesh_load: bad npes/mype\n"); return nullptr; }
-  if (opts->which_ale != 0 && opts->which_ale != 2) { fprintf(stderr, "fesom_mesh_load: which_ale must be 0 (linfs) or 2 (zstar)\n"); return nullptr; }
+  if (opts->which_ale < 0 || opts->which_ale > 2) { fprintf(stderr, "fesom_mesh_load: which_ale must be 0 (linfs), 1 (zlevel) or 2 (zstar)\n"); return nullptr; }
   Mesh *mp = new Mesh();
   Mesh &m = *mp;
   m.o = *opts;

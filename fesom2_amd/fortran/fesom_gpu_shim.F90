@@ -75,6 +75,8 @@ module fesom_gpu_shim
      real(c_double) :: max_ice_loading
      integer(c_int) :: SPP
      real(c_double) :: Sice, clim_relax
+     integer(c_int) :: lzstar_lev
+     real(c_double) :: min_hnode
   end type
   type, bind(C) :: fesom_state_desc
      type(c_ptr) :: tr_arr, tr_arr_old, UV, UV_rhsAB, eta_n, d_eta, ssh_rhs, ssh_rhs_old, hbar, hbar_old, dhe, hnode, hnode_new, &
@@ -366,6 +368,7 @@ contains
     p%use_floatice = l2i(use_floatice .and. .not. trim(which_ALE)=='linfs'); p%l_mslp = l2i(l_mslp); p%use_global_tides = l2i(use_global_tides)
     p%max_ice_loading = max_ice_loading; p%clim_relax = clim_relax
     p%SPP = l2i(SPP); p%Sice = Sice
+    p%lzstar_lev = lzstar_lev; p%min_hnode = min_hnode
     p%solver_precond = 1; p%solver_xinv_its = 0     ! explicit-inverse preconditioner where it fits (pi), library default iterations
 
     transport%ctx = c_null_ptr

@@ -85,7 +85,7 @@ typedef struct fesom_part_desc {
  *      src/oce_modules.F90:7-190, src/gen_modules_config.F90:8-127) ------------------- */
 typedef struct fesom_params {
   double dt;                 /* 86400/step_per_day (gen_model_setup.F90:44) */
-  int    which_ale;          /* 0 linfs, 1 zlevel (unsupported), 2 zstar */
+  int    which_ale;          /* 0 linfs, 1 zlevel, 2 zstar */
   int    use_partial_cell;
   int    state_equation;     /* 1 Jackett-McDougall, 0 linear */
   int    num_tracers;
@@ -159,6 +159,9 @@ typedef struct fesom_params {
   double Sice;               /* ice salinity (i_therm_param, 4.0) */
   double clim_relax;         /* > 1e-8: relax_to_clim after diff_tracers_ale (oce_tracer_mod.F90:86-121): T, S += relax2clim(n) * dt * (clim - tracer); the static
                                 arrays Tclim, Sclim (nl-1,N) and relax2clim (N) are handed over once with fesom_gpu_set_field */
+  int    lzstar_lev;         /* which_ALE='zlevel' (namelist.config &ale_def, 4): number of surface layers the reference's local-zstar fallback works on */
+  double min_hnode;          /* which_ALE='zlevel' (&ale_def, 0.5): smallest allowed fraction of the surface layer's resting thickness; a step that would go below it
+                                needs the local-zstar fallback of vert_vel_ale (oce_ale.F90:1859-1942), which is not built: the library reports an error */
 } fesom_params;
 
 /* ---- prognostic state = restart set (io_restart.F90:99-155) + ALE thickness arrays -- */

@@ -141,6 +141,8 @@ void orc_relax_zonal_vel(void);
 void orc_relax_zonal_temp(void);
 void orc_relax_to_clim(int tr);
 void orc_spp(void);
+extern int orc_ale_flag;                        /* zlevel: a step needed the local-zstar fallback (not restated) */
+int orc_get_ale_flag(void);
 void orc_toy_set_partition(const int *owner, int nranks);
 void orc_step(int n);
 #endif

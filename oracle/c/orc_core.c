@@ -18,7 +18,10 @@ static void reg(const char *name, double **p, size_t cnt) {
   F_[nF_].name = name; F_[nF_].p = p; F_[nF_].cnt = cnt; nF_++;
 }
 
+int orc_ale_flag = 0;
+int orc_get_ale_flag(void) { return orc_ale_flag; }
 int orc_init(const fesom_mesh_desc *m, const fesom_params *p) {
+  orc_ale_flag = 0;
   for (int i = 0; i < nF_; i++) free(*F_[i].p);
   nF_ = 0;
   free(C_.toy_bpos); free(C_.toy_owner); free(C_.MLD1_ind);

@@ -1119,6 +1119,47 @@ void orc_vert_vel_ale(void) {
       A2L(C_.Wvel, nzmin, n) = A2L(C_.Wvel, nzmin, n) - C_.water_flux[n - 1];
     }
   }
+  if (C_.p.which_ale == 1) {            /* zlevel (oce_ale.F90:1830-2023) */
+    const int lz = C_.p.lzstar_lev;
+    const double *zbar = C_.m.zbar;     /* zbar(k) = zbar[k-1] */
+    for (int n = 1; n <= C_.m.myDim_nod2D; n++) {
+      int nzmin = ULEVN(n), nzmax = C_.m.nlevels_nod2D_min[n - 1] - 1;
+      if (nzmin == 1) {
+        const double dhbar_total = C_.hbar[n - 1] - C_.hbar_old[n - 1];
+        int changed = 0;                /* any(hnode(nzmin+1:nzmin+lz-1,n) /= zbar(nzmin+1:nzmin+lz-1)-zbar(nzmin+2:nzmin+lz)) */
+        for (int k = 2; k <= lz; k++) if (A2(C_.hnode, nzmin + k - 1, n) != (zbar[nzmin + k - 2] - zbar[nzmin + k - 1])) changed = 1;
+        if (dhbar_total < 0.0 && A2(C_.hnode, nzmin, n) + dhbar_total <= (zbar[nzmin - 1] - zbar[nzmin]) * C_.p.min_hnode) {
+          /* the reference goes to its local-zstar fallback here (:1859-1942) and its update_thickness_ale then stops in a non-conformable PACK (:871-873, run-time error
+           * under the compiler the reference is built with in this repository): not restated, reported */
+          orc_ale_flag = 1;
+          A2L(C_.Wvel, nzmin, n) = A2L(C_.Wvel, nzmin, n) - dhbar_total / dt;
+          A2(C_.hnode_new, nzmin, n) = A2(C_.hnode, nzmin, n) + dhbar_total;
+        } else if (dhbar_total > 0.0 && changed) {         /* return to zlevel (:1950-2003): refill the sub-surface layers first */
+          double max_d[64];
+          int nz = 0;
+          for (int k = 1; k <= lz; k++) {
+            max_d[k] = (zbar[nzmin + k - 2] - zbar[nzmin + k - 1]) - A2(C_.hnode, nzmin + k - 1, n);
+            if (A2(C_.hnode, nzmin + k - 1, n) != (zbar[nzmin + k - 2] - zbar[nzmin + k - 1])) nz = k;
+          }
+          max_d[1] = 1000.0;
+          nzmax = nz < nzmax - 1 ? nz : nzmax - 1;
+          double rest = dhbar_total, integ = 0.0;
+          for (nz = nzmax; nz >= 1; nz--) {
+            const double d = dmin(rest, max_d[nz]);
+            rest = rest - d;
+            rest = dmax(0.0, rest);
+            integ = integ + d;
+            A2L(C_.Wvel, nzmin + nz - 1, n) = A2L(C_.Wvel, nzmin + nz - 1, n) - integ / dt;
+            A2(C_.hnode_new, nzmin + nz - 1, n) = A2(C_.hnode, nzmin + nz - 1, n) + d;
+          }
+        } else {
+          A2L(C_.Wvel, nzmin, n) = A2L(C_.Wvel, nzmin, n) - dhbar_total / dt;
+          A2(C_.hnode_new, nzmin, n) = A2(C_.hnode, nzmin, n) + dhbar_total;
+        }
+      }
+      A2L(C_.Wvel, nzmin, n) = A2L(C_.Wvel, nzmin, n) - C_.water_flux[n - 1];
+    }
+  }
   for (int n = 1; n <= C_.N; n++) A2L(C_.CFL_z, 1, n) = 0.0;
   for (int n = 1; n <= C_.N; n++)
     for (int nz = ULEVN(n); nz <= NLEVN(n) - 1; nz++) {
@@ -1140,8 +1181,33 @@ void orc_vert_vel_ale(void) {
     }
 }
 
-/* update_thickness_ale: src/oce_ale.F90:800-993 (zstar branch; linfs: nothing) */
+/* update_thickness_ale: src/oce_ale.F90:800-993 (zlevel and zstar branches; linfs: nothing) */
 void orc_update_thickness_ale(void) {
+  if (C_.p.which_ale == 1) {            /* zlevel (:817-943).  The element part's local-zstar case (:865-880) is the PACK the reference stops in: see vert_vel_ale */
+    const int lz = C_.p.lzstar_lev;
+    for (int e = 1; e <= C_.m.myDim_elem2D; e++) {
+      int nzmin = ULEV(e);
+      if (nzmin > 1) continue;
+      int n1 = EN(1, e), n2 = EN(2, e), n3 = EN(3, e);
+      A2(C_.helem, nzmin, e) = (A2(C_.hnode_new, nzmin, n1) + A2(C_.hnode_new, nzmin, n2) + A2(C_.hnode_new, nzmin, n3)) / 3.0;
+    }
+    for (int n = 1; n <= C_.N; n++) {
+      int nzmin = C_.m.ulevels_nod2D_max[n - 1], nzmax = C_.m.nlevels_nod2D_min[n - 1] - 1;
+      if (nzmin > 1) continue;
+      int local = 0, top = nzmin;
+      for (int k = 2; k <= lz; k++) if (A2(C_.hnode_new, nzmin + k - 1, n) - A2(C_.hnode, nzmin + k - 1, n) != 0.0) local = 1;
+      if (local) {                      /* hnode of the layers the fallback / the return to zlevel changed */
+        for (int k = 1; k <= lz; k++) if (A2(C_.hnode_new, nzmin + k - 1, n) - A2(C_.hnode, nzmin + k - 1, n) != 0.0) top = nzmin + k - 1;
+        top = top < nzmax - 1 ? top : nzmax - 1;
+      }
+      for (int nz = top; nz >= nzmin; nz--) {
+        A2(C_.hnode, nz, n) = A2(C_.hnode_new, nz, n);
+        A2L(C_.zbar_3d_n, nz, n) = A2L(C_.zbar_3d_n, nz + 1, n) + A2(C_.hnode_new, nz, n);
+        A2(C_.Z_3d_n, nz, n) = A2L(C_.zbar_3d_n, nz + 1, n) + A2(C_.hnode_new, nz, n) / 2.0;
+      }
+    }
+    return;
+  }
   if (C_.p.which_ale != 2) return;
   for (int n = 1; n <= C_.N; n++) {
     int nzmin = ULEVN(n), nzmax = C_.m.nlevels_nod2D_min[n - 1] - 2;

@@ -41,6 +41,7 @@ logfile_outfreq=100000
 &ale_def
 which_ALE='{which_ale}'
 use_partial_cell={use_partial_cell}
+min_hnode={min_hnode}
 /
 &geometry
 cartesian=.false.
@@ -182,6 +183,12 @@ CFGS = {
                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                        fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
                        balance_salt_water=".true.", synth_forcing=True, use_floatice=".true.", tides=True, mslp=True),     # (use_global_tides is in no namelist of the reference: the harness sets the module variable)
+    # which_ALE = 'zlevel': the ssh change in the surface layer only (oce_ale.F90:630-690, 817-943, 1830-2023); pi has 4-layer columns, whose partial bottom cell
+    # sends every rising step through the "return to zlevel" branch
+    "pi_pp_zlevel": dict(mesh="pi", step_per_day=96, which_ale="zlevel", use_partial_cell=".true.", cyclic_length=360,
+                       rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                       fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                       balance_salt_water=".true.", synth_forcing=True),
     # SPP = .true.: salt plume parameterization at the head of solve_tracers_ale (src/oce_spp.F90), linfs as its header asks; analytic thdgr / S_oc_array
     "pi_pp_linfs_spp": dict(mesh="pi", step_per_day=96, which_ale="linfs", use_partial_cell=".false.", cyclic_length=360,
                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
@@ -393,7 +400,7 @@ def prepare(cfg, np_, tag=""):
                 os.chmod(root, 0o755)
             partition_io.write_dist(cp, np_)
         meshdir = cp
-    open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **dict(dict(use_sw_pene=".false.", use_floatice=".false."), **c)))
+    open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **dict(dict(use_sw_pene=".false.", use_floatice=".false.", min_hnode="0.5"), **c)))
     open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0", visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=".true.", tra_adv_lim="FCT", use_momix=".false.", which_pgf="shchepetkin", mom_adv=2, use_kpp_nonlclflx=".false.", double_diffusion=".false.", smooth_bh_tra=".false.", clim_relax="0.0", SPP=".false."), **c)))
     if c["toy_ocean"] == ".false.":
         from fesom2_amd.synthetic import write_ic_files

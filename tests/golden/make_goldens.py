@@ -115,6 +115,7 @@ def main():
     make("pi_pp_non", "pi_pp_non_reference.npz")        # tra_adv_lim = 'NON'
     make("pi_pp_climrelax", "pi_pp_climrelax_reference.npz")  # clim_relax > 0
     make("pi_pp_linfs_spp", "pi_pp_linfs_spp_reference.npz")  # SPP (salt plume parameterization)
+    make("pi_pp_zlevel", "pi_pp_zlevel_reference.npz")        # which_ALE = 'zlevel'
     make("pi_pp_surfpot", "pi_pp_surfpot_reference.npz")  # use_floatice + l_mslp + use_global_tides
     make("pi_pp_bhtra", "pi_pp_bhtra_reference.npz")    # smooth_bh_tra
     make("pi_kpp_dd", "pi_kpp_dd_reference.npz")        # KPP + double_diffusion

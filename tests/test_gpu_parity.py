@@ -512,6 +512,88 @@ def test_biharmonic_viscosity_chain_bitwise(built, opt):
     gpu.close()
 
 
+def test_zlevel_chain_bitwise(built):
+    """which_ALE = 'zlevel' (k_vert_vel / k_thick zlevel branches; oracle pinned on the reference run pi_pp_zlevel): HIP == oracle bit for bit after every routine of
+    3 steps and after 6 further whole steps; then from a state whose sub-surface layers 2 and 3 are thinner than at rest (what the reference's local-zstar fallback
+    leaves behind), so that the "return to zlevel" branch refills them over several layers: again bit for bit."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.core import OceanCore
+    from fesom2_amd.synthetic import analytic_ts, analytic_forcing
+    from oracle_lib import Oracle
+    mesh = Mesh.load(PI, dt=900.0, which_ale="zlevel")
+    par = make_params(dt=900.0, which_ale="zlevel")
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    gpu, orc = OceanCore(mesh, par), Oracle(mesh, par)
+    gpu.upload_state(st); orc.set_state(st)
+    forcing = analytic_forcing(mesh)
+    gpu.set_forcing(**forcing)
+    for k, v in forcing.items():
+        orc.set(k, v)
+    failures = []
+    for step in range(1, 4):
+        for routine, arg, fields in full_chain(2):
+            gpu.call(routine, arg); orc.call(routine, arg)
+            for f in fields:
+                ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+                if not ok:
+                    failures.append(f"step {step} {routine}({arg}) {msg}")
+        if failures:
+            break
+    assert not failures, "\n".join(failures[:10])
+    gpu.run_steps(4, 6)
+    for n in range(6):
+        orc.call("step", 4 + n)
+    for f in ("tr_arr", "UV", "eta_n", "hnode", "hnode_new", "helem", "zbar_3d_n", "Z_3d_n", "hbar", "Wvel"):
+        ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+        assert ok, msg
+    gpu.sync()                                                      # (no column needed the local-zstar fallback)
+    h0 = st.hnode.reshape(-1, mesh.nl - 1)
+    assert np.abs(orc.get("hnode").reshape(-1, mesh.nl - 1)[:, 1:] - h0[:, 1:]).max() == 0.0 and np.abs(orc.get("hnode").reshape(-1, mesh.nl - 1)[:, 0] - h0[:, 0]).max() > 1e-4
+    # thinner sub-surface layers: the rising columns refill layer 3, then 2, then the surface layer
+    hn = orc.get("hnode").reshape(-1, mesh.nl - 1).copy()
+    deep = mesh.nlevels_nod2D_min > 8
+    hn[deep, 1] -= 2.0e-4; hn[deep, 2] -= 1.0e-4
+    for f in ("hnode", "hnode_new"):
+        gpu.set(f, hn.ravel()); orc.set(f, hn.ravel())
+    for step in range(10, 13):
+        for routine, arg, fields in full_chain(2):
+            gpu.call(routine, arg); orc.call(routine, arg)
+            for f in list(fields) + (["hnode_new"] if routine == "vert_vel_ale" else []):
+                ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+                if not ok:
+                    failures.append(f"refill step {step} {routine}({arg}) {msg}")
+        if failures:
+            break
+    assert not failures, "\n".join(failures[:10])
+    hn2 = orc.get("hnode").reshape(-1, mesh.nl - 1)
+    assert (hn2[deep, 2] > hn[deep, 2]).any() and (hn2[deep, 1] > hn[deep, 1]).any()       # layers 3 and 2 were refilled somewhere
+    gpu.close()
+
+
+def test_zlevel_reports_the_missing_local_zstar_fallback(built):
+    """zlevel with min_hnode just below 1: the first falling step of any column asks for the reference's local-zstar fallback (oce_ale.F90:1859-1942), which is not
+    built (the reference's own update_thickness_ale stops in a non-conformable PACK there under the compiler it is built with here): the library says so at the next
+    synchronising call instead of stepping on silently."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.core import OceanCore
+    from fesom2_amd.synthetic import analytic_ts, analytic_forcing
+    mesh = Mesh.load(PI, dt=900.0, which_ale="zlevel")
+    gpu = OceanCore(mesh, make_params(dt=900.0, which_ale="zlevel", min_hnode=0.999999))
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    gpu.upload_state(st)
+    gpu.set_forcing(**analytic_forcing(mesh))
+    gpu.run_steps(1, 3)
+    with pytest.raises(RuntimeError, match="local-zstar"):
+        gpu.sync()
+    gpu.close()
+
+
 def test_spp_chain_bitwise(built):
     """SPP = .true. (k_spp: cal_rejected_salt + app_rejected_salt at the head of solve_tracers_ale, linfs; oracle pinned on the reference run pi_pp_linfs_spp):
     HIP == oracle bit for bit after every routine of 3 steps and after 6 further whole steps.  (The reference leaves 0/0 in the salinity below the bottom of

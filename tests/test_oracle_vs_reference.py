@@ -337,6 +337,32 @@ def test_oracle_chain_bitwise_relax_to_clim(built):
     assert not np.array_equal(g["s3/tr1.end.tr_arr"], gz["s3/tr1.end.tr_arr"])
 
 
+def test_oracle_chain_bitwise_zlevel(built):
+    """which_ALE = 'zlevel' (init_thickness_ale :630-690, vert_vel_ale :1830-2023 incl. the "return to zlevel" branch that pi's 4-layer columns take on every rising
+    step, update_thickness_ale :817-943): reference run `pi_pp_zlevel`, every routine of 3 steps bit for bit."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.synthetic import analytic_ts
+    from oracle_lib import Oracle
+    from ref_chain import run_reference_chain
+    mesh = Mesh.load(PI, dt=900.0, which_ale="zlevel")
+    par = make_params(dt=900.0, which_ale="zlevel")
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    orc = Oracle(mesh, par)
+    orc.set_state(st)
+    g = gold("pi_pp_zlevel")
+    for f in FORCING:
+        orc.set(f, g["forcing/" + f])
+    bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
+    assert not bad, "\n".join(bad[:20])
+    gz = gold("pi_pp_wsplit")                                       # (the same set-up with zstar)
+    assert not np.array_equal(g["s2/update_thickness_ale.hnode"], gz["s2/update_thickness_ale.hnode"])
+    assert orc.lib.orc_get_ale_flag() == 0
+    assert (mesh.nlevels_nod2D == 5).any()                          # columns whose partial bottom cell lies within the lzstar_lev surface layers
+
+
 def test_oracle_chain_bitwise_spp(built):
     """SPP = .true. (salt plume parameterization, cal_rejected_salt + app_rejected_salt, src/oce_spp.F90, at the head of solve_tracers_ale; linfs as the routine's
     header asks; the harness's analytic ice growth rate thdgr and S_oc_array): reference run `pi_pp_linfs_spp`, every routine of 3 steps bit for bit."""
