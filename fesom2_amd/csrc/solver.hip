@@ -477,7 +477,7 @@ int launch_named_dsolve(const DM &m, hipStream_t s, const char *name) {
 }
 
 // Single GPU, operator too large for one workgroup (> 4096 rows): the same recurrences and the same summation order as the
-// phases above, 3 launches per iteration instead of 9 -- there is no host all-reduce between the phases here, so every block
+// phases above, 2 launches per iteration (k_dm_upd_spmv1, k_dm_spmv2) instead of 9 -- there is no host all-reduce between the phases here, so every block
 // sums the block partials itself (in block order) and evaluates the Krylov scalars redundantly.  The scalar state ping-pongs
 // between two slots of sv_kry (a block must not read what block 0 of the same launch is about to write); the convergence
 // flag is read back between chunks of iterations (launches after convergence are no-ops).
@@ -551,17 +551,24 @@ __global__ void __launch_bounds__(DSB) k_dm_spmv2(DM m, int NP, int nblk, int sl
   int i = blockIdx.x * DSB + threadIdx.x;
   double q[4] = {0.0, 0.0, 0.0, 0.0};
   if (!done) {
+    // the row's operands do not depend on alpha: their loads are issued before the block sum (whose barriers the compiler will not move loads across)
+    double av[W], rj[W], vj[W], r_i = 0.0, v_i = 0.0, r0_i = 0.0;
+    if (i < m.myN) {
+#pragma unroll
+      for (int k = 0; k < W; k++) {
+        const int j = m.sv_colsi[(size_t)k * NP + i];
+        av[k] = m.sv_vals[(size_t)k * NP + i]; rj[k] = m.sv_r[j]; vj[k] = m.sv_v[j];
+      }
+      r_i = m.sv_r[i]; v_i = m.sv_v[i]; r0_i = m.sv_r0[i];
+    }
     const double alpha = st[4] / dm_sum_blocks(m.sv_part, nblk, sh);
     if (i < m.myN) {
       double a = 0.0;
 #pragma unroll
-      for (int k = 0; k < W; k++) {
-        int j = m.sv_colsi[(size_t)k * NP + i];
-        a = a + m.sv_vals[(size_t)k * NP + i] * (m.sv_r[j] - alpha * m.sv_v[j]);
-      }
-      double si = m.sv_r[i] - alpha * m.sv_v[i];
+      for (int k = 0; k < W; k++) a = a + av[k] * (rj[k] - alpha * vj[k]);
+      double si = r_i - alpha * v_i;
       m.sv_s[i] = si; m.sv_t[i] = a;
-      q[0] = a * a; q[1] = a * si; q[2] = m.sv_r0[i] * a; q[3] = si * si;
+      q[0] = a * a; q[1] = a * si; q[2] = r0_i * a; q[3] = si * si;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) m.sv_kry[32] = alpha;
   }
@@ -598,6 +605,63 @@ __global__ void __launch_bounds__(DSB) k_dm_upd(DM m, int nblk, int slot, double
     so[0] = alpha; so[1] = omega; so[2] = beta; so[3] = rho; so[4] = rho_new; so[5] = rr; so[6] = it; so[7] = more ? 0.0 : 1.0;
   }
 }
+// k_dm_upd of iteration k and k_dm_spmv1 of iteration k+1 in ONE launch: the new p^ at the neighbour columns is evaluated on the fly from s, t, the old p^ and
+// the old v (the same expressions, hence the same bits, as the stored p^_i), so the product does not have to wait for a launch boundary behind the update.
+// p^ and v are double-buffered (other workgroups still read the old ones): 2 launches per iteration instead of 3.
+template <int W>
+__global__ void __launch_bounds__(DSB) k_dm_upd_spmv1(DM m, int NP, int nblk, int slot, double tol2, int maxits, const double *ph_old, const double *v_old,
+                                                      double *ph_new, double *v_new) {
+  const double *st = m.sv_kry + 16 * slot;
+  double *so = m.sv_kry + 16 * (1 - slot);
+  if (st[7] != 0.0) {
+    if (blockIdx.x == 0 && threadIdx.x < 16) so[threadIdx.x] = st[threadIdx.x];
+    return;
+  }
+  __shared__ double sh[4][DSB];
+  const double *part2 = m.sv_part + 4 * (size_t)nblk;
+  const int i = blockIdx.x * DSB + threadIdx.x;
+  // operands first (independent of the Krylov scalars), then the block sums
+  double av[W], sj[W], tj[W], pj[W], vj[W], s_i = 0.0, t_i = 0.0, p_i = 0.0, v_i = 0.0, y_i = 0.0, r0_i = 0.0;
+  if (i < m.myN) {
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      const int j = m.sv_colsi[(size_t)k * NP + i];
+      av[k] = m.sv_vals[(size_t)k * NP + i]; sj[k] = m.sv_s[j]; tj[k] = m.sv_t[j]; pj[k] = ph_old[j]; vj[k] = v_old[j];
+    }
+    s_i = m.sv_s[i]; t_i = m.sv_t[i]; p_i = ph_old[i]; v_i = v_old[i]; y_i = m.sv_p[i]; r0_i = m.sv_r0[i];
+  }
+  double tot[4];
+  dm_sum_blocks4(part2, nblk, sh, tot);
+  const double tt = tot[0], ts = tot[1], r0t = tot[2], ss = tot[3];
+  const double alpha = m.sv_kry[32];
+  const double omega = (tt > 0.0) ? ts / tt : 0.0;
+  const double rho = st[4], rho_new = -omega * r0t;
+  const double rr = ss - omega * (2.0 * ts - omega * tt);
+  const double it = st[6] + 1.0;
+  const bool more = (rr >= tol2 && it < (double)maxits);
+  const double beta = more ? (rho_new / rho) * (alpha / omega) : 0.0;
+  double q[1] = {0.0};
+  if (i < m.myN) {
+    const double si = s_i, pi = p_i;
+    const double ri = si - omega * t_i;
+    m.sv_r[i] = ri;
+    m.sv_p[i] = (y_i + alpha * pi) + omega * si;
+    if (more) {
+      ph_new[i] = ri + beta * (pi - omega * v_i);
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < W; k++) {
+        const double rj = sj[k] - omega * tj[k];
+        a = a + av[k] * (rj + beta * (pj[k] - omega * vj[k]));
+      }
+      v_new[i] = a; q[0] = r0_i * a;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    so[0] = alpha; so[1] = omega; so[2] = beta; so[3] = rho; so[4] = rho_new; so[5] = rr; so[6] = it; so[7] = more ? 0.0 : 1.0;
+  }
+  if (more) ds_block_partials<1>(q, m.sv_part, nblk);             // (`more` is the same in every workgroup)
+}
 __global__ void __launch_bounds__(DSB) k_dm_finish(DM m, int slot) {
   const double *st = m.sv_kry + 16 * slot;
   int i = blockIdx.x * DSB + threadIdx.x;
@@ -626,11 +690,29 @@ int launch_solver_multi(const DM &m, hipStream_t s, int fuse_rhs, int scale_done
   // one read-back of the convergence flag per solve as a rule: a few iterations more than the last solve needed (launches after
   // convergence are no-ops of ~2 us; a second read-back costs a host round trip of 30-50 us)
   int slot = 0, total = 0, chunk = last_its + 6;
+  const char *e3 = getenv("FESOM_GPU_SOLVER_3LAUNCH");           // the three-launch iteration (same bits; kept for the comparison test)
+  const bool three = e3 && atoi(e3) != 0;
+  DM mm[2] = {m, m};                                              // the two (p^, v) buffer pairs
+  mm[1].sv_ph = m.sv_ph2; mm[1].sv_v = m.sv_v2; mm[1].sv_ph2 = m.sv_ph; mm[1].sv_v2 = m.sv_v;
+  int cur = 0;
   for (;;) {
-    for (int k = 0; k < chunk; k++) {
-      DMW(k_dm_spmv1, m, NP, nblk, slot);
-      DMW(k_dm_spmv2, m, NP, nblk, slot);
-      hipLaunchKernelGGL(k_dm_upd, dim3(nblk), dim3(DSB), 0, s, m, nblk, slot, tol2, maxits);
+    if (three) {
+      for (int k = 0; k < chunk; k++) {
+        DMW(k_dm_spmv1, m, NP, nblk, slot);
+        DMW(k_dm_spmv2, m, NP, nblk, slot);
+        hipLaunchKernelGGL(k_dm_upd, dim3(nblk), dim3(DSB), 0, s, m, nblk, slot, tol2, maxits);
+        slot = 1 - slot;
+      }
+    } else {
+      // spmv1 spmv2 { upd+spmv1 spmv2 } x (chunk-1) upd
+      DMW(k_dm_spmv1, mm[cur], NP, nblk, slot);
+      DMW(k_dm_spmv2, mm[cur], NP, nblk, slot);
+      for (int k = 1; k < chunk; k++) {
+        DMW(k_dm_upd_spmv1, mm[cur], NP, nblk, slot, tol2, maxits, (const double *)mm[cur].sv_ph, (const double *)mm[cur].sv_v, mm[1 - cur].sv_ph, mm[1 - cur].sv_v);
+        cur = 1 - cur; slot = 1 - slot;
+        DMW(k_dm_spmv2, mm[cur], NP, nblk, slot);
+      }
+      hipLaunchKernelGGL(k_dm_upd, dim3(nblk), dim3(DSB), 0, s, mm[cur], nblk, slot, tol2, maxits);
       slot = 1 - slot;
     }
     total += chunk;

@@ -76,6 +76,20 @@ def test_channel_r1_chain_and_steps_bitwise(built, tmp_path):
     for f in ("tr_arr", "UV", "eta_n", "hnode"):
         ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
         assert ok, msg
+    # the two-launch iteration of the multi-workgroup solve (update + next product in one kernel, neighbour values on the fly) against the three-launch one
+    gpu.call("solver_snapshot")
+    res = {}
+    for mode in ("0", "1"):
+        os.environ["FESOM_GPU_SOLVER_3LAUNCH"] = mode
+        try:
+            gpu.call("k_solver_replay")
+            res[mode] = (gpu.get("d_eta", orc.count("d_eta")).copy(), gpu.solver_iterations)
+        finally:
+            os.environ.pop("FESOM_GPU_SOLVER_3LAUNCH", None)
+    # (the two replays start from different extrapolated first guesses -- the solver keeps a history of its solutions -- so they agree to the solver tolerance only;
+    #  the bitwise statement is the comparison with the oracle above, which ran the two-launch iteration)
+    assert res["0"][1] > 10 and res["1"][1] > 10
+    assert np.abs(res["0"][0] - res["1"][0]).max() < 1e-8
     gpu.close()
 
 
