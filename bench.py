@@ -117,7 +117,7 @@ def kernel_table(core, mesh, wl):
 
 def solver_launches(core):
     """kernel launches of one SSH solve as the running step issues it (csrc/solver.hip)"""
-    n, K = core.mesh.myDim_nod2D, (core.params.solver_xinv_its or 2)
+    n, K = core.mesh.myDim_nod2D, (core.params.solver_xinv_its or 1)
     if core.params.solver_precond == 1 and n <= 4096:
         return 2 + 5 * K + 1            # set-up, initial residual, K x (M p, A p^, M s, A s^, update), safety net
     if n <= 4096:

@@ -125,6 +125,7 @@ const double *dev_upload_d(const double *h, size_t n) {
 // Explicit-inverse preconditioner (csrc/precond_host.cpp): built on the host from the operator the run starts with, uploaded once.
 // The last matrix is kept per process and reused when the same operator comes again (tests and benches re-initialise often).
 struct XinvCache { std::vector<int> rp, ci; std::vector<double> vals; std::vector<int> mp; std::vector<unsigned short> mc; std::vector<float> mv; } XC;
+static double xinv_drop() { const char *e = getenv("FESOM_GPU_XINV_DROP"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : XINV_DROP; }     // (experiments: tools/xinv_sweep.py)
 int xinv_device(int n, const int *rp, const int *ci, const double *vals, const double *scale, DM &m, std::vector<void *> &owner) {
   const int nza = rp[n];
   const bool hit = !scale && (int)XC.rp.size() == n + 1 && (int)XC.vals.size() == nza && !XC.mp.empty() && !memcmp(XC.rp.data(), rp, sizeof(int) * (n + 1)) &&
@@ -135,9 +136,9 @@ int xinv_device(int n, const int *rp, const int *ci, const double *vals, const d
     XC.mp.clear();
     if (fesom_xinv_build(n, rp, ci, vals, scale, ld, M.data(), nullptr)) return 1;
     XC.mp.assign(n + 1, 0);
-    fesom_xinv_sparsify(n, ld, M.data(), XINV_DROP, XC.mp.data(), nullptr, nullptr);
+    fesom_xinv_sparsify(n, ld, M.data(), xinv_drop(), XC.mp.data(), nullptr, nullptr);
     XC.mc.assign(XC.mp[n], 0); XC.mv.assign(XC.mp[n], 0.0f);
-    fesom_xinv_sparsify(n, ld, M.data(), XINV_DROP, XC.mp.data(), XC.mc.data(), XC.mv.data());
+    fesom_xinv_sparsify(n, ld, M.data(), xinv_drop(), XC.mp.data(), XC.mc.data(), XC.mv.data());
     XC.rp.assign(rp, rp + n + 1); XC.ci.assign(ci, ci + nza); XC.vals.assign(vals, vals + nza);
     if (scale) XC.rp.clear();                              // (a partition's block: not cached)
   }

@@ -889,7 +889,7 @@ int launch_solver_xinv(const DM &m, hipStream_t s, int fuse_rhs, int scale_done)
   if (!scale_done) launch_row_scale(m, s);
   hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, fuse_rhs, 1);   // Jacobi copies for the safety net + natural-order A_s, b, x0
   hipLaunchKernelGGL(k_xi_init<10>, dim3(nblk), dim3(DSB), 0, s, m, NP, nblk);
-  const int K = m.sv_xi_its > 0 ? m.sv_xi_its : 2, gblk = (m.myN + XI_ROWS - 1) / XI_ROWS;
+  const int K = m.sv_xi_its > 0 ? m.sv_xi_its : 1, gblk = (m.myN + XI_ROWS - 1) / XI_ROWS;
   int slot = 0;
   for (int k = 0; k < K; k++) {
     hipLaunchKernelGGL(k_xi_gemv<0>, dim3(gblk), dim3(256), 0, s, m, nblk, slot, k == 0 ? 1 : 0, tol2);

@@ -132,7 +132,9 @@ typedef struct fesom_params {
                                 solution + limited anti-diffusive fluxes), 1 'NON' (the high-order fluxes applied as they are, vertical part with the
                                 explicit velocity; not together with w_split) */
   int    solver_xinv_its;    /* solver_precond=1: BiCGstab iterations enqueued per solve (no host read-back inside a step); a solve that
-                                has not converged by then is finished by the Jacobi-preconditioned one-workgroup solver.  0 = default (2) */
+                                has not converged by then is finished by the Jacobi-preconditioned one-workgroup solver.  0 = default (1: after the spin-up the
+                                extrapolated first guess makes one iteration enough; where a second is needed the continuation costs one 6.6 us
+                                Jacobi iteration instead of five launches) */
   double Leith_c, Div_c;     /* visc_option 1-3: weights of the Leith and the modified (divergence) Leith viscosity (namelist.oce &oce_dyn; h_viscosity_leith,
                                 src/oce_dyn.F90:461-561) */
   int    which_pgf;          /* namelist.oce which_pgf: 0 'shchepetkin' (default, oce_modules.F90:172): pressure_force_4_zxxxx_shchepetkin for zstar,

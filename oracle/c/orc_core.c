@@ -220,7 +220,7 @@ void orc_solve_ssh(void) {
       free(dense);
       xinv_n = n; xinv_key = (const void *)C_.m.ssh_values;
     }
-    const int K = C_.p.solver_xinv_its > 0 ? C_.p.solver_xinv_its : 2;
+    const int K = C_.p.solver_xinv_its > 0 ? C_.p.solver_xinv_its : 1;
     for (int i = 0; i < n; i++) xx[i] = x[i];
     SPMV_(As, r, xx);
     for (int i = 0; i < n; i++) { r[i] = b[i] - r[i]; r0[i] = r[i]; pv[i] = r[i]; }
