@@ -430,6 +430,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     const char *tl = getenv("FESOM_GPU_TILE");
     m.use_tile = tl ? atoi(tl) : (m.myN >= TL_MIN_COLUMNS ? 1 : 0);
     if (m.use_tile < 0 || m.use_tile > 4) m.use_tile = 1;
+    { const char *e2 = getenv("FESOM_GPU_TRU_NT2"); m.tru_nt2 = e2 ? atoi(e2) : 1; }     // both tracers of a column in one wave (pi: 55 against 59 us; 0 = one tracer per wave)
   }
   m.nl = d->nl; m.nlm1 = d->nl - 1; m.ntr = par->num_tracers; m.maxk = d->max_nod_in_elem; m.nza = d->ssh_nza; m.edge2D_in = d->edge2D_in;
   const size_t N = m.N, E = m.E, D = m.D, nl = m.nl, n1 = m.nlm1;

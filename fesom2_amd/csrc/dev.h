@@ -47,6 +47,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   double *eta_n, *d_eta, *ssh_rhs, *ssh_rhs_old, *hbar, *hbar_old, *MLD1, *MLD2;
   double *heat_flux, *water_flux, *virtual_salt, *relax_salt, *real_salt_flux;
   double *UV, *UV_rhs, *UV_rhsAB, *tr_xy, *tr_xy_ab, *U_b;
+  int tru_nt2;                                            // one-column-per-wave k_tr_update with both tracers per wave (pi)
   int *ale_flag;                                          // zlevel: set when a column needs the local-zstar fallback (not built)
   const double *geo_lat;                                  // SPP: geographic latitude [rad] (N)
   const double *thdgr, *S_oc;                             // SPP: ice growth rate and ocean salinity seen by the ice (N), with the forcing

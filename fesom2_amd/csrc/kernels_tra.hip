@@ -664,12 +664,34 @@ __device__ __forceinline__ void tru_fin(const DM &m, const TruCol &k, int tr, do
   const bool wet = k.wet;
   if (REDI) {            // diff_ver_part_redi_expl (:860-927): vertical flux of the isoneutral tensor's off-diagonal part
     double Tx = 0.0, Ty = 0.0, G = 0.0;
-    if (wet) {
-      const int num = m.nie_num[n];
-      for (int q = 0; q < num; q++) {
-        int el = m.nie[(size_t)m.maxk * n + q];
-        if (nz <= m.nlev[el] - 1 && nz >= m.ulev[el]) { double ar = m.elem_area[el]; Tx = Tx + DV2(t.tr_xy, 1, nz, el) * ar; Ty = Ty + DV2(t.tr_xy, 2, nz, el) * ar; }
+    {
+      // the elements around the node: their index chain (element, level range, area) once per lane, the gradients in batches of independent loads;
+      // the sums stay in the reference's element order
+      const int l = lane_id(), num = m.nie_num[n], nzc = nz <= m.nlm1 ? nz : m.nlm1;
+      int el_l = 0, rg_l = 1;                          // range packed lo | hi << 8 ; (1, 0) = empty
+      double ar_l = 0.0;
+      if (l < num) { el_l = m.nie[(size_t)m.maxk * n + l]; rg_l = m.ulev[el_l] | ((m.nlev[el_l] - 1) << 8); ar_l = m.elem_area[el_l]; }
+      constexpr int RB = 6;
+      for (int q0 = 0; q0 < num; q0 += RB) {
+        double tx[RB], ty[RB];
+#pragma unroll
+        for (int j = 0; j < RB; j++) {
+          const int el = rdlane(el_l, q0 + j < num ? q0 + j : 0);
+          tx[j] = DV2(t.tr_xy, 1, nzc, el); ty[j] = DV2(t.tr_xy, 2, nzc, el);
+        }
+#pragma unroll
+        for (int j = 0; j < RB; j++) {
+          if (q0 + j < num) {
+            const int rg = rdlane(rg_l, q0 + j);
+            const double ar = bcast(ar_l, q0 + j);
+            const bool on = wet && nz >= (rg & 0xff) && nz <= (rg >> 8);
+            const double ax = Tx + tx[j] * ar, ay = Ty + ty[j] * ar;
+            Tx = on ? ax : Tx; Ty = on ? ay : Ty;
+          }
+        }
       }
+    }
+    if (wet) {
       Tx = Tx / 3.0 / asv; Ty = Ty / 3.0 / asv;
       G = k.s1 * Tx + k.s2 * Ty;
     }
@@ -934,10 +956,12 @@ __global__ void __launch_bounds__(WAVE * WAVES, (WAVES == 8) ? 4 : 2) k_tr_updat
 #define LAUNCH_COL(k, ncol, m_, tr_) hipLaunchKernelGGL(k, dim3(nblocks(ncol), (tr_) < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m_, (tr_) < 0 ? 0 : (tr_))
 // one column per wave, one tracer per block row (pi) -- or tiles with both tracers per block (DM::use_tile; all tracers of the launch)
 #define LAUNCH_TRU1(R, m_, tr_) hipLaunchKernelGGL((k_tr_update<R, 1, TH_COLS, TH_COLS>), dim3(nblocks_th(m.N), (tr_) < 0 ? m.ntr : 1), dim3(TH_BLOCK), (ThTile<1, TH_COLS>::lds_bytes(m.nlm1)), s, m_, (tr_) < 0 ? 0 : (tr_))
+#define LAUNCH_TRU2(R, m_) hipLaunchKernelGGL((k_tr_update<R, 2, TH_COLS, TH_COLS>), dim3(nblocks_th(m.N), (m.ntr + 1) / 2), dim3(TH_BLOCK), (ThTile<2, TH_COLS>::lds_bytes(m.nlm1)), s, m_, 0)
 #define TRU_SHAPE(id, C_, W_) case id: hipLaunchKernelGGL((k_tr_update<R_, NT_, C_, W_>), dim3((m.N + C_ - 1) / C_, gy), dim3(WAVE * W_), (ThTile<NT_, C_>::lds_bytes(m.nlm1)), s, m, tr0); break;
 template <bool R_, int NT_> static void launch_tru_tile(const DM &m, hipStream_t s, int gy, int tr0) { switch (m.use_tile) { TILE_SHAPES(TRU_SHAPE) default: break; } }
 #define LAUNCH_TRU(m_, tr_) do { if (m.use_tile && (tr_) < 0) { if (m.p.Redi) launch_tru_tile<true, 2>(m_, s, (m.ntr + 1) / 2, 0); else launch_tru_tile<false, 2>(m_, s, (m.ntr + 1) / 2, 0); } \
   else if (m.use_tile) { if (m.p.Redi) launch_tru_tile<true, 1>(m_, s, 1, tr_); else launch_tru_tile<false, 1>(m_, s, 1, tr_); }   /* one named tracer (routine-level tests) */ \
+  else if (m.tru_nt2 && (tr_) < 0) { if (m.p.Redi) LAUNCH_TRU2(true, m_); else LAUNCH_TRU2(false, m_); }   /* both tracers of a column in one wave */ \
   else if (m.p.Redi) LAUNCH_TRU1(true, m_, tr_); else LAUNCH_TRU1(false, m_, tr_); } while (0)
 #define LAUNCH_WIMPL(m_, tr_) do { if (m.p.w_split) hipLaunchKernelGGL(k_fct_lo_wimpl, dim3(nblocks_th(m.myN), (tr_) < 0 ? m.ntr : 1), dim3(TH_BLOCK), thomas_lds_bytes(m.nlm1, 1), s, m_, (tr_) < 0 ? 0 : (tr_)); } while (0)
 #define LAUNCH_DFX(m_, tr_) do { if (m.p.Redi) LAUNCH_COL(k_diff_flux<true>, m.myD, m_, tr_); else LAUNCH_COL(k_diff_flux<false>, m.myD, m_, tr_); } while (0)
