@@ -625,6 +625,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   else if (par->clim_relax > 1.0e-8) { F(Tclim, n1 * N); F(Sclim, n1 * N); F(relax2clim, N); }
   F(sv_vals, 16 * (N + 64)); F(sv_dinv, N + 64); F(sv_b, N + 64); F(sv_r, N + 64); F(sv_r0, N + 64); F(sv_p, N + 64); F(sv_v, N + 64); F(sv_s, N + 64); F(sv_t, N + 64);
   F(sv_ph, N + 64); F(sv_x0, 16 * (N + 64)); F(sv_snap, N); F(sv_ph2, N + 64); F(sv_v2, N + 64);
+  if (!part || part->npes <= 1) F(sv_rdinv, N + 64);                 // 1 / D of every row, formed with the row scales off the critical chain (one partition: no halo of it is needed)
   F(sv_part, 8 * ((N + 255) / 256 + 1)); F(sv_red, 8); F(sv_kry, 48);
   F(sv_resid, 1); F(sv_h1, N); F(sv_h2, N); F(sv_h3, N); F(sv_scale, N + 64);
   F(sv_bn, N + 64); F(sv_x, N + 64); F(sv_pd, N + 64); F(sv_sn, N + 64); F(sv_sh, N + 64);

@@ -82,7 +82,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   const double *toy_znum, *toy_e_a, *toy_n_a;
   const int *toy_bptr, *toy_bidx, *toy_e_nn, *toy_n_nn;
   // solver workspace
-  double *sv_vals, *sv_dinv, *sv_b, *sv_r, *sv_r0, *sv_p, *sv_v, *sv_s, *sv_t, *sv_ph, *sv_x0, *sv_snap, *sv_ph2, *sv_v2;
+  double *sv_vals, *sv_dinv, *sv_b, *sv_r, *sv_r0, *sv_p, *sv_v, *sv_s, *sv_t, *sv_ph, *sv_x0, *sv_snap, *sv_ph2, *sv_v2, *sv_rdinv;
   int *sv_info; double *sv_resid;   // sv_info[0] iterations of the last solve, [1] number of stored previous solutions
   double *sv_scale;
   double *sv_part, *sv_red, *sv_kry;    // partitioned solve: block partial sums, reduced sums, Krylov scalars + flags (solver.hip)

@@ -81,7 +81,9 @@ __global__ void k_row_scale(DM m) {
   for (int j = j0; j < j1; j++) tmp += fabs(m.ssh_values[j]);
   double sc = 1. / tmp;
   m.sv_scale[i] = sc;
-  m.sv_dinv[i] = m.ssh_values[j0] * sc;                  // D (first entry of a row is the diagonal, oce_ale.F90:1128-1151)
+  const double dg = m.ssh_values[j0] * sc;
+  m.sv_dinv[i] = dg;                                     // D (first entry of a row is the diagonal, oce_ale.F90:1128-1151)
+  if (m.sv_rdinv) m.sv_rdinv[i] = 1.0 / dg;              // (k_solver_setup, on the critical chain, then has no divisions left)
 }
 void launch_row_scale(const DM &m, hipStream_t s) { hipLaunchKernelGGL(k_row_scale, dim3((m.myN + 255) / 256), dim3(256), 0, s, m); }
 
@@ -104,9 +106,16 @@ __global__ void k_solver_setup(DM m, int NP, int fuse_rhs, int sorted) {      //
   double rhs;
   if (fuse_rhs) {          // node part of compute_ssh_rhs_ale (oce_ale.F90:1548-1570) fused in: gather of the edge transports
     double sacc = 0.0;
-    for (int q = m.ne_ptr[i]; q < m.ne_ptr[i + 1]; q++) {
-      double c = m.edge_c12[m.ne_idx[q]];
-      sacc = (m.ne_sgn[q] > 0) ? sacc + c : sacc - c;
+    {                                                     // batches of independent loads, the sum in the edge order of the list
+      const int q0 = m.ne_ptr[i], deg = m.ne_ptr[i + 1] - q0;
+      constexpr int EB = 8;
+      for (int b0 = 0; b0 < deg; b0 += EB) {
+        double c[EB]; int sg[EB];
+#pragma unroll
+        for (int k = 0; k < EB; k++) { const int qq = q0 + (b0 + k < deg ? b0 + k : 0); c[k] = m.edge_c12[m.ne_idx[qq]]; sg[k] = m.ne_sgn[qq]; }
+#pragma unroll
+        for (int k = 0; k < EB; k++) if (b0 + k < deg) sacc = (sg[k] > 0) ? sacc + c[k] : sacc - c[k];
+      }
     }
     const double al = m.p.alpha;
     if (m.p.which_ale != 0) sacc = sacc - al * m.water_flux[i] * m.areasvol[(size_t)i * m.nl + m.ulev_n[i] - 1] + (1.0 - al) * m.ssh_rhs_old[i];
@@ -132,7 +141,7 @@ __global__ void k_solver_setup(DM m, int NP, int fuse_rhs, int sorted) {      //
     double bk = 0.0, ak = 0.0;
     if (j0 + k < j1) {
       int c = ci[j0 + k];
-      double dinv_c = 1.0 / m.sv_dinv[c];
+      double dinv_c = m.sv_rdinv ? m.sv_rdinv[c] : 1.0 / m.sv_dinv[c];
       ak = m.ssh_values[j0 + k] * sc;                      // A_s
       bk = ak * dinv_c;                                    // B = A_s D^-1
     }
