@@ -5,19 +5,19 @@ CXX   ?= g++
 SRC    = fesom2_amd/csrc
 OBJ    = fesom2_amd/build
 HFLAGS = --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-result
-HIPSRC = kernels_dyn kernels_tra kernels_toy kernels_gm kernels_kpp kernels_mon kernels_ice solver api
+HIPSRC = kernels_dyn kernels_tra kernels_toy kernels_gm kernels_kpp kernels_mon kernels_ice solver solver_ras api
 OBJS   = $(addprefix $(OBJ)/,$(addsuffix .o,$(HIPSRC))) $(OBJ)/mesh_host.o $(OBJ)/precond_host.o
 
 fesom2_amd/libfesom_gpu.so: $(OBJS)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS) -lpthread
 
-$(OBJ)/%.o: $(SRC)/%.hip $(SRC)/dev.h include/fesom_gpu.h | $(OBJ)
+$(OBJ)/%.o: $(SRC)/%.hip $(SRC)/dev.h $(SRC)/solver_dev.h $(SRC)/ras_host.h include/fesom_gpu.h | $(OBJ)
 	$(HIPCC) $(HFLAGS) -x hip -c $< -o $@
 
 $(OBJ)/mesh_host.o: $(SRC)/mesh_host.cpp include/fesom_gpu.h | $(OBJ)
 	$(CXX) -O2 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -c $< -o $@
 
-$(OBJ)/precond_host.o: $(SRC)/precond_host.cpp | $(OBJ)
+$(OBJ)/precond_host.o: $(SRC)/precond_host.cpp $(SRC)/ras_host.h | $(OBJ)
 	$(CXX) -O3 -pthread -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -c $< -o $@
 
 $(OBJ):

@@ -10,7 +10,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: no FMA contraction on host or device, results are compared bitwise with the CPU oracle.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result"]
-SOURCES = ["kernels_dyn.hip", "kernels_tra.hip", "kernels_toy.hip", "kernels_gm.hip", "kernels_kpp.hip", "kernels_mon.hip", "kernels_ice.hip", "solver.hip", "api.hip", "mesh_host.cpp", "precond_host.cpp"]
+SOURCES = ["kernels_dyn.hip", "kernels_tra.hip", "kernels_toy.hip", "kernels_gm.hip", "kernels_kpp.hip", "kernels_mon.hip", "kernels_ice.hip", "solver.hip", "solver_ras.hip", "api.hip", "mesh_host.cpp", "precond_host.cpp"]
 
 
 def _stale(target, deps):
@@ -23,7 +23,7 @@ def _stale(target, deps):
 def build(force=False, verbose=True):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [os.path.join(SRC, "dev.h"), os.path.join(HERE, "..", "include", "fesom_gpu.h")]
+    hdrs = [os.path.join(SRC, h) for h in ("dev.h", "solver_dev.h", "ras_host.h")] + [os.path.join(HERE, "..", "include", "fesom_gpu.h")]
     objs, procs = [], []
     for s in SOURCES:
         src = os.path.join(SRC, s)

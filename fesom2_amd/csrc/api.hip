@@ -20,6 +20,8 @@ void solver_prepare();
 extern "C" int fesom_xinv_build(int n, const int *rp, const int *ci, const double *vals, const double *scale, int ld, float *out, int *bandwidth);
 extern "C" void fesom_xinv_sparsify(int n, int ld, const float *M, double tau, int *rowptr, unsigned short *cols, float *vals);
 #define XINV_DROP 1.0e-4      /* entries of the inverse below this fraction of their row's largest are dropped */
+#include "ras_host.h"
+int launch_named_ras(const DM &m, hipStream_t s, const char *name);
 void tile_prepare_tra();
 void tile_prepare_dyn();
 
@@ -153,6 +155,46 @@ int xinv_device(int n, const int *rp, const int *ci, const double *vals, const d
       hipMemcpy(dc, XC.mc.data(), XC.mc.size() * sizeof(unsigned short), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(dv, XC.mv.data(), XC.mv.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return 1;
   m.sv_mp = (const int *)dp; m.sv_mc = (const unsigned short *)dc; m.sv_minv = (const float *)dv;
+  return 0;
+}
+// RAS-Chebyshev preconditioner (csrc/ras_host.h): plan built on the host from the operator the run starts with (frozen, like the
+// reference's ILU factors), uploaded once.  `ld` = length of the solver vectors' owned part rounded up to 64 (ELL leading dimension).
+static int env_int(const char *n, int dflt) { const char *e = getenv(n); return e && *e ? atoi(e) : dflt; }
+int ras_device(int n, int ncols, const int *rp, const int *ci, const double *vals, int maxnnz, DM &m, std::vector<void *> &owner) {
+  RasPlan pl;
+  const char *ek = getenv("FESOM_GPU_RAS_KAPPA");
+  if (fesom_ras_build(n, rp, ci, vals, nullptr, env_int("FESOM_GPU_RAS_PATCH", RAS_PATCH_MAX), env_int("FESOM_GPU_RAS_OVL", RAS_OVERLAP), env_int("FESOM_GPU_RAS_DEG", RAS_DEG),
+                      ek && atof(ek) > 1.0 ? atof(ek) : RAS_KAPPA, pl)) return 1;
+  auto up = [&](const void *h, size_t bytes) -> void * {
+    void *d = nullptr;
+    if (hipMalloc(&d, bytes ? bytes : 8) != hipSuccess) return nullptr;
+    owner.push_back(d);
+    if (bytes && hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return d;
+  };
+  std::vector<double> cheb(128, 0.0);
+  cheb[0] = pl.inv_theta;
+  for (int k = 1; k < pl.deg; k++) { cheb[1 + k] = pl.c1[k]; cheb[64 + k] = pl.c2[k]; }
+  const int W = maxnnz <= 8 ? 8 : maxnnz <= 10 ? 10 : 16, NP = (n + 63) / 64 * 64;
+  std::vector<int> colsq((size_t)W * NP, 0);                  // ELL pattern of the products with A_s, as positions (halo columns keep their index)
+  for (int q = 0; q < NP; q++)
+    for (int k = 0; k < W; k++) {
+      int c = q < n ? q : 0;
+      if (q < n) { const int i = pl.perm[q]; if (rp[i] + k < rp[i + 1]) { const int cc = ci[rp[i] + k]; c = cc < n ? pl.inv[cc] : cc; } }
+      colsq[(size_t)k * NP + q] = c;
+    }
+  (void)ncols;
+  m.rs_pinfo = (const int *)up(pl.pinfo.data(), pl.pinfo.size() * sizeof(int));
+  m.rs_extq = (const int *)up(pl.extq.data(), pl.extq.size() * sizeof(int));
+  m.rs_perm = (const int *)up(pl.perm.data(), pl.perm.size() * sizeof(int));
+  m.rs_inv = (const int *)up(pl.inv.data(), pl.inv.size() * sizeof(int));
+  m.rs_colsq = (const int *)up(colsq.data(), colsq.size() * sizeof(int));
+  m.rs_lv = (const float *)up(pl.lv.data(), pl.lv.size() * sizeof(float));
+  m.rs_lc = (const unsigned short *)up(pl.lc.data(), pl.lc.size() * sizeof(unsigned short));
+  m.rs_dsc = (const double *)up(pl.dsc.data(), pl.dsc.size() * sizeof(double));
+  m.rs_cheb = (const double *)up(cheb.data(), cheb.size() * sizeof(double));
+  if (!m.rs_pinfo || !m.rs_extq || !m.rs_perm || !m.rs_inv || !m.rs_colsq || !m.rs_lv || !m.rs_lc || !m.rs_dsc || !m.rs_cheb) { m.rs_pinfo = nullptr; return 1; }
+  m.rs_P = pl.P; m.rs_NS = pl.NS; m.rs_rpt = pl.rpt; m.rs_woff = pl.woff; m.rs_deg = pl.deg;
   return 0;
 }
 double *field(const char *name, size_t n, int slabs = 1) {
@@ -746,6 +788,13 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     }
     if (xinv_device(m.myN, rp.data(), ci.data(), va.data(), sc.data(), m, G.allocs)) { m.sv_minv = nullptr; G.err = "fesom_gpu_init: the block-inverse SSH preconditioner of this partition could not be built"; return 1; }
   }
+  if (par->solver_precond == 1 && !m.sv_minv && m.ssh_maxnnz <= 16 && G.npes <= 1) {
+    // operators beyond the explicit inverse: RAS-Chebyshev (solver_ras.hip), frozen at the operator this run starts with
+    std::vector<int> rp(m.myN + 1), ci(m.nza);
+    for (int i = 0; i <= m.myN; i++) rp[i] = d->ssh_rowptr[i] - d->ssh_rowptr[0];
+    for (int j = 0; j < m.nza; j++) ci[j] = d->ssh_colind_loc[j] - 1;
+    if (ras_device(m.myN, m.N, rp.data(), ci.data(), d->ssh_values, m.ssh_maxnnz, m, G.allocs)) m.rs_pinfo = nullptr;      // (does not qualify: Jacobi)
+  }
   solver_prepare();
   tile_prepare_tra(); tile_prepare_dyn();
   G.first_step = 1;
@@ -1134,6 +1183,8 @@ static int call_named(const char *name, int arg) {
   if (rc == 0) return 0;
   rc = launch_named_dsolve(m, G.stream, name);
   if (rc == 0) return 0;
+  rc = launch_named_ras(m, G.stream, name);
+  if (rc == 0) return 0;
   G.err = std::string("fesom_gpu_call: unknown routine ") + name;
   return 1;
 }
@@ -1186,7 +1237,7 @@ int fesom_gpu_last_solver_iterations(void) {
   return it;
 }
 int fesom_gpu_tile_shape(void) { return G.ready ? G.m.use_tile : -1; }
-int fesom_gpu_solver_kind(void) { return !G.ready ? -1 : (G.m.sv_minv ? 1 : 0); }
+int fesom_gpu_solver_kind(void) { return !G.ready ? -1 : (G.m.sv_minv ? 1 : G.m.rs_pinfo ? 2 : 0); }
 // solves of this run that the explicit-inverse iterations did not finish (the Jacobi safety net took over); synchronises
 int fesom_gpu_solver_safety_net_count(void) {
   if (!G.ready) return -1;
@@ -1334,6 +1385,9 @@ void psolver_init(int *id, int *stype, int *pctype, int *pcilutype, int *iluleve
   const char *pc = getenv("FESOM_GPU_PRECOND");
   if (!(pc && !strcmp(pc, "jacobi")) && n <= 4096 && n >= 64 && maxnnz <= 10) {
     if (xinv_device(n, rptr, cols, vals, nullptr, m, PS.al)) ps_die("psolver_init: the explicit-inverse preconditioner could not be built (singular matrix or out of device memory)");
+  } else if (!(pc && !strcmp(pc, "jacobi")) && n > 4096) {
+    m.rs_inv = nullptr;
+    if (ras_device(n, n, rptr, cols, vals, maxnnz, m, PS.al)) m.rs_pinfo = nullptr;               // (does not qualify: Jacobi)
   }
   solver_prepare();
   PS.n = n; PS.nza = nza; PS.ok = true;

@@ -99,6 +99,12 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   const float *sv_minv; const int *sv_mp; const unsigned short *sv_mc; int sv_xi_its;
   double sv_tol; int sv_maxits;   // stop rule: ||scaled residual|| < sv_tol (0: the reference's 1e-10, bicgstab_ras.c:78), iteration cap (0: 2000)
   double *sv_bn, *sv_x, *sv_pd, *sv_sn, *sv_sh;
+  // RAS-Chebyshev preconditioner of operators beyond the explicit inverse (csrc/ras_host.h, solver_ras.hip): patches of the row graph,
+  // one workgroup each; all solver vectors then live in the patch order (rs_perm[position] = row, rs_inv[row] = position; halo rows of a
+  // partition keep their place behind the owned ones).  rs_colsq = ELL column pattern [k][NP] as positions.
+  const int *rs_pinfo, *rs_extq, *rs_perm, *rs_inv, *rs_colsq;
+  const float *rs_lv; const unsigned short *rs_lc; const double *rs_dsc, *rs_cheb;   // rs_cheb: [0] 1/theta, [1+k] c1_k, [64+k] c2_k
+  int rs_P, rs_NS, rs_rpt, rs_woff, rs_deg;
   fesom_params p;
 };
 

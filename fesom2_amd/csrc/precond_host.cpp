@@ -174,3 +174,198 @@ extern "C" void fesom_xinv_sparsify(int n, int ld, const float *M, double tau, i
     rowptr[i + 1] = q;
   }
 }
+
+// =====================================================================================================================
+// RAS-Chebyshev preconditioner for operators that are too large for the explicit inverse (CORE2-class meshes, partitions):
+// plan construction.  See ras_host.h for the reference counterpart.  Everything here is integer / graph work plus a few
+// fp64 divisions per entry, formed in a fixed order, so that the CPU checker of the tests (its own restatement of the same
+// rules, oracle/c/orc_ras.c) reproduces the plan bit for bit.
+//   patches : recursive bisection of the row graph into L = ceil(n / patch_max) leaves.  One bisection of a set S: breadth-first
+//             order from the smallest row of S, again from the row that order ends with (a far end of the set), rows the search
+//             does not reach are appended by further searches from the smallest unvisited row; the first |S| * (L/2) / L rows of
+//             the second order form the left part.  Neighbours are visited in CSR order.
+//   order   : patches in the order the bisection emits them, rows of a patch by increasing index (= layout of all solver vectors)
+//   overlap : `overlap` rings of neighbouring rows (each ring sorted by index), as long as the patch stays within 2048 rows
+//   patch operator: a_ij / a_ii of the frozen operator for the columns inside the patch (Dirichlet condition outside), fp32
+// =====================================================================================================================
+#include "ras_host.h"
+namespace {
+struct RasGraph {
+  int n; const int *rp, *ci;
+  std::vector<int> mark;            // visit stamps of the searches
+  std::vector<int> inset;           // id of the set a row currently belongs to
+  int stamp = 0, setid = 0;
+  void bfs(int start, int sid, std::vector<int> &out) {
+    mark[start] = stamp; out.push_back(start);
+    for (size_t h = out.size() - 1; h < out.size(); h++) {
+      const int u = out[h];
+      for (int q = rp[u]; q < rp[u + 1]; q++) {
+        const int v = ci[q];
+        if (v < 0 || v >= n || v == u || inset[v] != sid || mark[v] == stamp) continue;
+        mark[v] = stamp; out.push_back(v);
+      }
+    }
+  }
+  void order(const std::vector<int> &S, int first, int sid, std::vector<int> &out) {    // S sorted by index
+    stamp++; out.clear(); out.reserve(S.size());
+    bfs(first, sid, out);
+    if (out.size() < S.size())
+      for (int u : S) if (mark[u] != stamp) bfs(u, sid, out);
+  }
+  void bisect(std::vector<int> &S, int L, std::vector<std::vector<int>> &patches) {
+    if (L <= 1) { patches.push_back(S); return; }
+    const int sid = ++setid;
+    for (int u : S) inset[u] = sid;
+    std::vector<int> o1, o2;
+    order(S, S[0], sid, o1);
+    order(S, o1.back(), sid, o2);
+    const int nl = L / 2;
+    const size_t cut = (size_t)((long long)S.size() * nl / L);
+    std::vector<int> a(o2.begin(), o2.begin() + cut), b(o2.begin() + cut, o2.end());
+    std::vector<int>().swap(o1); std::vector<int>().swap(o2); std::vector<int>().swap(S);
+    std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
+    bisect(a, nl, patches); bisect(b, L - nl, patches);
+  }
+};
+}  // namespace
+
+int fesom_ras_build(int n, const int *rp, const int *ci, const double *vals, const double *scale, int patch_max, int overlap, int deg, double kappa, RasPlan &out) {
+  if (n < 1 || patch_max < 1 || deg < 1 || deg > RAS_MAX_DEG || overlap < 0 || !(kappa > 1.0)) return 1;
+  std::vector<int> dpos(n);
+  for (int i = 0; i < n; i++) {                                  // position of the diagonal (first entry as a rule, oce_ale.F90:1128-1151)
+    int d = -1;
+    for (int q = rp[i]; q < rp[i + 1]; q++) if (ci[q] == i) { d = q; break; }
+    if (d < 0 || vals[d] == 0.0) return 1;
+    dpos[i] = d;
+  }
+  RasGraph g{n, rp, ci, std::vector<int>(n, 0), std::vector<int>(n, 0)};
+  std::vector<std::vector<int>> patches;
+  {
+    std::vector<int> all(n);
+    for (int i = 0; i < n; i++) all[i] = i;
+    g.bisect(all, (n + patch_max - 1) / patch_max, patches);
+  }
+  const int P = (int)patches.size(), cap = RAS_THREADS * RAS_MAX_RPT;
+  out = RasPlan();
+  out.n = n; out.P = P; out.deg = deg; out.ovl = overlap; out.kappa = kappa;
+  out.perm.resize(n); out.inv.resize(n); out.pinfo.assign(4 * (size_t)P, 0);
+  {
+    int q = 0;
+    for (int p = 0; p < P; p++) {
+      if ((int)patches[p].size() > cap) return 1;
+      out.pinfo[4 * p] = q; out.pinfo[4 * p + 1] = (int)patches[p].size();
+      for (int r : patches[p]) { out.perm[q] = r; out.inv[r] = q; q++; }
+    }
+  }
+  // overlap rings
+  std::vector<std::vector<int>> ext(P);
+  std::vector<int> member(n, -1);
+  int ne_max = 0;
+  for (int p = 0; p < P; p++) {
+    std::vector<int> &e = ext[p];
+    e = patches[p];
+    for (int r : e) member[r] = p;
+    size_t ring0 = 0;
+    for (int k = 0; k < overlap; k++) {
+      std::vector<int> cand;
+      for (size_t h = ring0; h < e.size(); h++)
+        for (int q = rp[e[h]]; q < rp[e[h] + 1]; q++) {
+          const int v = ci[q];
+          if (v >= 0 && v < n && member[v] != p) cand.push_back(v);
+        }
+      std::sort(cand.begin(), cand.end());
+      cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+      if (cand.empty() || e.size() + cand.size() > (size_t)cap) break;
+      ring0 = e.size();
+      for (int v : cand) { member[v] = p; e.push_back(v); }
+    }
+    for (int r : e) member[r] = -1;
+    ne_max = std::max(ne_max, (int)e.size());
+    out.pinfo[4 * p + 3] = (int)e.size();
+  }
+  out.rpt = std::max(2, (ne_max + RAS_THREADS - 1) / RAS_THREADS);
+  out.NS = RAS_THREADS * out.rpt;
+  // patch operators
+  int maxoff = 0;
+  std::vector<int> lidx(n, -1);
+  for (int pass = 0; pass < 2; pass++) {
+    if (pass == 1) {
+      out.woff = maxoff <= 6 ? 6 : maxoff <= 9 ? 9 : 15;
+      if (maxoff > 15) return 1;
+      out.lv.assign((size_t)P * out.woff * out.NS, 0.0f);
+      out.lc.assign((size_t)P * out.woff * out.NS, 0);
+      out.dsc.assign((size_t)P * out.NS, 0.0);
+    }
+    int off = 0;
+    for (int p = 0; p < P; p++) {
+      const std::vector<int> &e = ext[p];
+      for (size_t s = 0; s < e.size(); s++) lidx[e[s]] = (int)s;
+      if (pass == 1) {
+        out.pinfo[4 * p + 2] = off;
+        for (int r : e) out.extq.push_back(out.inv[r]);
+        for (int k = 0; k < out.woff; k++)
+          for (int s = 0; s < out.NS; s++) out.lc[((size_t)p * out.woff + k) * out.NS + s] = (unsigned short)s;
+      }
+      for (size_t s = 0; s < e.size(); s++) {
+        const int i = e[s];
+        const double aii = vals[dpos[i]];
+        int k = 0;
+        for (int q = rp[i]; q < rp[i + 1]; q++) {
+          const int c = ci[q];
+          if (q == dpos[i] || c < 0 || c >= n || lidx[c] < 0) continue;
+          if (pass == 1) {
+            out.lv[((size_t)p * out.woff + k) * out.NS + s] = (float)(vals[q] / aii);
+            out.lc[((size_t)p * out.woff + k) * out.NS + s] = (unsigned short)lidx[c];
+          }
+          k++;
+        }
+        maxoff = std::max(maxoff, k);
+        if (pass == 1) {
+          double sc;
+          if (scale) sc = scale[i];
+          else { double tmp = 0.; for (int q = rp[i]; q < rp[i + 1]; q++) tmp += fabs(vals[q]); sc = 1. / tmp; }
+          const double dg = aii * sc;
+          out.dsc[(size_t)p * out.NS + s] = 1.0 / dg;
+        }
+      }
+      for (int r : e) lidx[r] = -1;
+      off += (int)e.size();
+    }
+  }
+  // Chebyshev coefficients: Gershgorin bound of the Jacobi-scaled operator, interval [lmax / kappa, lmax]
+  double lmax = 0.0;
+  for (int i = 0; i < n; i++) {
+    const double aii = vals[dpos[i]];
+    double s = 0.0;
+    for (int q = rp[i]; q < rp[i + 1]; q++) if (ci[q] >= 0 && ci[q] < n) s += fabs(vals[q] / aii);
+    lmax = std::max(lmax, s);
+  }
+  out.lmax = lmax;
+  const double lmin = lmax / kappa, theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+  out.inv_theta = 1.0 / theta;
+  out.c1.assign(deg + 1, 0.0); out.c2.assign(deg + 1, 0.0);
+  double rho = 1.0 / sigma;
+  for (int k = 1; k < deg; k++) {
+    const double rn = 1.0 / (2.0 * sigma - rho);
+    out.c1[k] = rn * rho; out.c2[k] = 2.0 * rn / delta;
+    rho = rn;
+  }
+  return 0;
+}
+
+// Plan of the defaults as plain arrays (tests: the plan equals the CPU checker's, entry for entry).  dims = P, NS, rpt, woff, deg, rows in extq;
+// with perm == NULL only dims is filled.  cheb: [0] 1/theta, [1+k] c1_k, [64+k] c2_k, [127] lmax.
+extern "C" int fesom_ras_plan_export(int n, const int *rp, const int *ci, const double *vals, int *dims, int *perm, int *pinfo, int *extq, float *lv,
+                                     unsigned short *lc, double *dsc, double *cheb) {
+  RasPlan pl;
+  if (fesom_ras_build(n, rp, ci, vals, nullptr, RAS_PATCH_MAX, RAS_OVERLAP, RAS_DEG, RAS_KAPPA, pl)) return 1;
+  dims[0] = pl.P; dims[1] = pl.NS; dims[2] = pl.rpt; dims[3] = pl.woff; dims[4] = pl.deg; dims[5] = (int)pl.extq.size();
+  if (!perm) return 0;
+  memcpy(perm, pl.perm.data(), sizeof(int) * n); memcpy(pinfo, pl.pinfo.data(), sizeof(int) * pl.pinfo.size());
+  memcpy(extq, pl.extq.data(), sizeof(int) * pl.extq.size()); memcpy(lv, pl.lv.data(), sizeof(float) * pl.lv.size());
+  memcpy(lc, pl.lc.data(), sizeof(unsigned short) * pl.lc.size()); memcpy(dsc, pl.dsc.data(), sizeof(double) * pl.dsc.size());
+  for (int k = 0; k < 128; k++) cheb[k] = 0.0;
+  cheb[0] = pl.inv_theta; cheb[127] = pl.lmax;
+  for (int k = 1; k < pl.deg; k++) { cheb[1 + k] = pl.c1[k]; cheb[64 + k] = pl.c2[k]; }
+  return 0;
+}

@@ -15,6 +15,7 @@
 // ~5k rows), own-row vectors are coalesced L2 traffic.  Dot products use a FIXED reduction order (1024 strided
 // partial sums, halving tree) that the CPU oracle reproduces: oracle and HIP agree bitwise.
 #include "dev.h"
+#include "solver_dev.h"
 #include <string.h>
 
 #define ST 1024
@@ -298,10 +299,12 @@ void solver_prepare() {
 }
 int launch_solver_multi(const DM &m, hipStream_t s, int fuse_rhs, int scale_done);
 int launch_solver_xinv(const DM &m, hipStream_t s, int fuse_rhs, int scale_done);
+int launch_solver_ras(const DM &m, hipStream_t s, int fuse_rhs, int scale_done);
 // Returns non-zero if the operator is wider than the widest instantiated ELL kernel.
 int launch_solver(const DM &m, hipStream_t s, int fuse_rhs, int scale_done) {
   if (m.ssh_maxnnz > 16) return 1;
   if (m.sv_minv) return launch_solver_xinv(m, s, fuse_rhs, scale_done);
+  if (m.rs_pinfo) return launch_solver_ras(m, s, fuse_rhs, scale_done);     // operators beyond the explicit inverse (solver_ras.hip)
   // one workgroup holds up to 4096 rows of <= 10 entries in registers/LDS; larger (or wider) operators take the
   // multi-workgroup phases
   if (m.myN > 4 * ST || m.ssh_maxnnz > 10) return launch_solver_multi(m, s, fuse_rhs, scale_done);
@@ -324,26 +327,6 @@ int launch_solver(const DM &m, hipStream_t s, int fuse_rhs, int scale_done) {
 // Reference: the row partition of psolve (src/psolve.c:16-115, part[]) and the halo exchange + MPI_Allreduce inside
 // pARMS' bicgstab_ras (lib/parms/src/bicgstab_ras.c:49-259).  Partial sums: per block, then over blocks in block order.
 // =====================================================================================================================
-#define DSB 256
-template <int NQ>
-__device__ __forceinline__ void ds_block_partials(double (&v)[NQ], double *part, int nblk) {
-  __shared__ double sh[NQ][DSB];
-  const int t = threadIdx.x;
-#pragma unroll
-  for (int q = 0; q < NQ; q++) sh[q][t] = v[q];
-  __syncthreads();
-  for (int s = DSB / 2; s >= 1; s >>= 1) {
-    if (t < s) {
-#pragma unroll
-      for (int q = 0; q < NQ; q++) sh[q][t] = sh[q][t] + sh[q][t + s];
-    }
-    __syncthreads();
-  }
-  if (t == 0) {
-#pragma unroll
-    for (int q = 0; q < NQ; q++) part[(size_t)q * nblk + blockIdx.x] = sh[q][0];
-  }
-}
 __global__ void k_ds_reduce(DM m, int nq, int nblk) {
   int q = threadIdx.x;
   if (q >= nq) return;
@@ -493,41 +476,6 @@ int launch_named_dsolve(const DM &m, hipStream_t s, const char *name) {
 //   state slot (16 doubles): 0 alpha, 1 omega, 2 beta, 3 rho, 4 rho_new, 5 ||r||^2, 6 iterations, 7 done
 // sum of the nblk block partials, evaluated by every block in the same fixed order: thread t adds part[t], part[t+256], ...
 // in that order, then the halving tree over the 256 threads (strides 128..1).  Must be called by the whole block.
-__device__ __forceinline__ double dm_sum_blocks(const double *part, int nblk, double *sh /* DSB doubles */) {
-  const int t = threadIdx.x;
-  double a = 0.0;
-  for (int b = t; b < nblk; b += DSB) a = a + part[b];
-  sh[t] = a;
-  __syncthreads();
-  for (int s2 = DSB / 2; s2 >= 1; s2 >>= 1) {
-    if (t < s2) sh[t] = sh[t] + sh[t + s2];
-    __syncthreads();
-  }
-  double r = sh[0];
-  __syncthreads();
-  return r;
-}
-// four sums at once (same order per quantity as dm_sum_blocks, one set of barriers for all four)
-__device__ __forceinline__ void dm_sum_blocks4(const double *part, int nblk, double (*sh)[DSB], double (&out)[4]) {
-  const int t = threadIdx.x;
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    double a = 0.0;
-    for (int b = t; b < nblk; b += DSB) a = a + part[(size_t)q * nblk + b];
-    sh[q][t] = a;
-  }
-  __syncthreads();
-  for (int s2 = DSB / 2; s2 >= 1; s2 >>= 1) {
-    if (t < s2) {
-#pragma unroll
-      for (int q = 0; q < 4; q++) sh[q][t] = sh[q][t] + sh[q][t + s2];
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int q = 0; q < 4; q++) out[q] = sh[q][0];
-  __syncthreads();
-}
 __global__ void __launch_bounds__(DSB) k_dm_start(DM m, int nblk, double tol2, int maxits) {   // after k_ds_init: state + first p
   __shared__ double sh[DSB];
   const double rr = dm_sum_blocks(m.sv_part, nblk, sh);

@@ -155,7 +155,16 @@ static unsigned short *xinv_mc = NULL;
 static int *xinv_mp = NULL;
 static int xinv_n = 0;
 static const void *xinv_key = NULL;
-void orc_solver_reset(void) { free(xinv_M); free(xinv_mc); free(xinv_mp); xinv_M = NULL; xinv_mc = NULL; xinv_mp = NULL; xinv_n = 0; xinv_key = NULL; }
+/* RAS-Chebyshev preconditioner of the HIP path for operators beyond the explicit inverse (orc_ras.c), frozen the same way */
+#include "orc_ras.h"
+static orc_ras_plan ras_plan;
+static const void *ras_key = NULL;
+static int ras_n = 0;
+void orc_solver_reset(void) {
+  free(xinv_M); free(xinv_mc); free(xinv_mp); xinv_M = NULL; xinv_mc = NULL; xinv_mp = NULL; xinv_n = 0; xinv_key = NULL;
+  if (ras_key) orc_ras_free(&ras_plan);
+  ras_key = NULL; ras_n = 0;
+}
 
 void orc_solve_ssh(void) {
   int n = C_.m.myDim_nod2D;
@@ -250,6 +259,53 @@ void orc_solve_ssh(void) {
     converged = !(rr >= tol2 && it < maxits);
     for (int i = 0; i < n; i++) x[i] = xx[i];
     it0 = it;
+  }
+  int use_ras = C_.p.solver_precond == 1 && !use_xinv && maxnnz <= 16;
+  if (use_ras && (ras_key != (const void *)C_.m.ssh_values || ras_n != n)) {
+    orc_solver_reset();
+    int *rp0 = malloc(sizeof(int) * (n + 1)), *ci0 = malloc(sizeof(int) * C_.m.ssh_nza);
+    for (int i = 0; i <= n; i++) rp0[i] = rp[i] - off;
+    for (int j = 0; j < C_.m.ssh_nza; j++) ci0[j] = ci[j] - 1;
+    if (orc_ras_build(n, rp0, ci0, C_.m.ssh_values, ORC_RAS_PATCH_MAX, ORC_RAS_OVERLAP, ORC_RAS_DEG, ORC_RAS_KAPPA, &ras_plan)) use_ras = 0;      /* (does not qualify: Jacobi) */
+    else { ras_key = (const void *)C_.m.ssh_values; ras_n = n; }
+    free(rp0); free(ci0);
+  }
+  if (use_ras) {
+    /* ---- BiCGstab on A_s, right-preconditioned with the frozen RAS-Chebyshev operator (csrc/solver_ras.hip: launch_solver_ras).  All
+     * vectors in the patch order of the plan (perm[position] = row), block partial sums over positions (dot_blocks) */
+    const int *perm_q = ras_plan.perm, *inv_q = ras_plan.inv;
+    double *bq = malloc(sizeof(double) * n);
+#define SPMVQ(out, in) for (int q = 0; q < n; q++) { const int i = perm_q[q]; double a = 0.0; for (int j = rp[i] - off; j < rp[i + 1] - off; j++) a = a + As[j] * (in)[inv_q[ci[j] - 1]]; (out)[q] = a; }
+    for (int q = 0; q < n; q++) { xx[q] = x[perm_q[q]]; bq[q] = b[perm_q[q]]; }
+    SPMVQ(r, xx);
+    for (int q = 0; q < n; q++) { r[q] = bq[q] - r[q]; r0[q] = r[q]; pv[q] = r[q]; }
+    rr = dot_blocks(r, r, n);
+    rho_new = rr;
+    while (rr >= tol2 && it < maxits) {
+      orc_ras_apply(&ras_plan, pv, ph);
+      SPMVQ(v, ph);
+      alpha = rho_new / dot_blocks(r0, v, n);
+      for (int q = 0; q < n; q++) s[q] = r[q] - alpha * v[q];
+      orc_ras_apply(&ras_plan, s, sh);
+      SPMVQ(t, sh);
+      double tt = dot_blocks(t, t, n), ts = dot_blocks(t, s, n), r0t = dot_blocks(r0, t, n), ss = dot_blocks(s, s, n);
+      omega = (tt > 0.0) ? ts / tt : 0.0;
+      rho = rho_new;
+      rho_new = -omega * r0t;
+      rr = ss - omega * (2.0 * ts - omega * tt);
+      it++;
+      const int more = (rr >= tol2 && it < maxits);
+      const double beta = more ? (rho_new / rho) * (alpha / omega) : 0.0;
+      for (int q = 0; q < n; q++) {
+        r[q] = s[q] - omega * t[q];
+        xx[q] = (xx[q] + alpha * ph[q]) + omega * sh[q];
+        if (more) pv[q] = r[q] + beta * (pv[q] - omega * v[q]);
+      }
+    }
+#undef SPMVQ
+    for (int q = 0; q < n; q++) x[perm_q[q]] = xx[q];
+    free(bq);
+    converged = 1;
   }
   if (!converged) {
     /* ---- Jacobi, applied as the column scaling B = A_s D^-1, y = D x: the one-workgroup / multi-workgroup HIP solve; after the

@@ -31,13 +31,13 @@ def toy_chain():
     return ch
 
 
-def start_pair(levels, tmp):
+def start_pair(levels, tmp, **param_kw):
     from fesom2_amd import workloads
     from fesom2_amd.core import OceanCore
     from oracle_lib import Oracle
     wl = workloads.channel(levels, workdir=str(tmp))
     mesh = wl.load_mesh()
-    par = wl.params()
+    par = wl.params(**param_kw)
     gpu, orc = OceanCore(mesh, par), Oracle(mesh, par)
     st, aux, _ = wl.initial_state(mesh)
     gpu.upload_state(st); orc.set_state(st)
@@ -62,12 +62,16 @@ def run_chain(gpu, orc, steps):
     return failures
 
 
-def test_channel_r1_chain_and_steps_bitwise(built, tmp_path):
-    wl, mesh, gpu, orc = start_pair(1, tmp_path)
+@pytest.mark.parametrize("precond", [1, 0])
+def test_channel_r1_chain_and_steps_bitwise(built, tmp_path, precond):
+    """precond 1: BiCGstab with the RAS-Chebyshev preconditioner (solver_ras.hip, the default beyond 4096 rows); 0: Jacobi, multi-workgroup phases"""
+    wl, mesh, gpu, orc = start_pair(1, tmp_path, solver_precond=precond)
     assert mesh.nod2D > 4096 and mesh.nl == 48
+    assert gpu.lib.fesom_gpu_solver_kind() == (2 if precond else 0)
     failures = run_chain(gpu, orc, (1, 2))
     assert not failures, "\n".join(failures[:10])
     assert gpu.solver_iterations == orc.solver_iterations
+    assert gpu.solver_iterations <= 25 if precond else gpu.solver_iterations > 50
     gpu.run_steps(3, 10)
     for n in range(10):
         if (3 + n) % 10 == 0:
@@ -76,6 +80,9 @@ def test_channel_r1_chain_and_steps_bitwise(built, tmp_path):
     for f in ("tr_arr", "UV", "eta_n", "hnode"):
         ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
         assert ok, msg
+    if precond:
+        gpu.close()
+        return
     # the two-launch iteration of the multi-workgroup solve (update + next product in one kernel, neighbour values on the fly) against the three-launch one
     gpu.call("solver_snapshot")
     res = {}
