@@ -49,14 +49,17 @@ struct Ctx {
   std::string err;
   // partition + halo exchange (npes > 1)
   int npes = 1, mype = 0;
-  struct Halo { std::vector<int> rPE, rptr, sPE, sptr; const int *rlist = nullptr, *slist = nullptr; const int *rptr_d = nullptr, *sptr_d = nullptr; int nrecv = 0, nsend = 0; } halo[3];
+  struct Halo { std::vector<int> rPE, rptr, sPE, sptr, slist_h; const int *rlist = nullptr, *slist = nullptr, *slist_q = nullptr; const int *rptr_d = nullptr, *sptr_d = nullptr; int nrecv = 0, nsend = 0; } halo[3];   // slist_q: node send list as positions of the solver's patch order
   double *hsend = nullptr, *hrecv = nullptr; size_t hcap = 0;        // channel 0: exchanges on the step's stream
   double *hsend1 = nullptr, *hrecv1 = nullptr; size_t hcap1 = 0;     // channel 1: the exchange in flight on the communication stream
   hipStream_t cstream = nullptr; hipEvent_t ev_prod = nullptr, ev_done = nullptr;
   long long n_async = 0;
+  bool x_pending = false;                             // an exchange is in flight on the communication stream
   bool toy_znum_global = false;                       // partitioned Soufflet channel: the per-bin element counts have been summed over the ranks
   // communication statistics of the partitioned step (fesom_gpu_comm_stats)
-  long long n_exch = 0, n_allred = 0;
+  long long n_exch = 0, n_allred = 0, n_parts = 0;
+  bool precond_agreed = false;                        // partitioned runs: all ranks have settled on one SSH preconditioner
+  int generation = 0;                                 // counts fesom_gpu_init calls (cached plans of the partitioned step belong to one)
   bool comm_timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> comm_ev;
 } G;
@@ -106,6 +109,7 @@ int rccl_load() {
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { G.err = std::string(#x) + ": " + hipGetErrorString(e_); fprintf(stderr, "fesom_gpu: %s\n", G.err.c_str()); return 1; } } while (0)
 
+bool g_prog_ready = false;                         // the program of the partitioned step (build_program) belongs to this context
 bool g_alloc_failed = false;                       // any device allocation / upload of fesom_gpu_init that failed (checked at its end)
 template <class T> T *dev_alloc(size_t n) {
   void *p = nullptr;
@@ -160,7 +164,7 @@ int xinv_device(int n, const int *rp, const int *ci, const double *vals, const d
 // RAS-Chebyshev preconditioner (csrc/ras_host.h): plan built on the host from the operator the run starts with (frozen, like the
 // reference's ILU factors), uploaded once.  `ld` = length of the solver vectors' owned part rounded up to 64 (ELL leading dimension).
 static int env_int(const char *n, int dflt) { const char *e = getenv(n); return e && *e ? atoi(e) : dflt; }
-int ras_device(int n, int ncols, const int *rp, const int *ci, const double *vals, int maxnnz, DM &m, std::vector<void *> &owner) {
+int ras_device(int n, int ncols, const int *rp, const int *ci, const double *vals, int maxnnz, DM &m, std::vector<void *> &owner, std::vector<int> *inv_out = nullptr) {
   RasPlan pl;
   const char *ek = getenv("FESOM_GPU_RAS_KAPPA");
   if (fesom_ras_build(n, rp, ci, vals, nullptr, env_int("FESOM_GPU_RAS_PATCH", RAS_PATCH_MAX), env_int("FESOM_GPU_RAS_OVL", RAS_OVERLAP), env_int("FESOM_GPU_RAS_DEG", RAS_DEG),
@@ -195,6 +199,7 @@ int ras_device(int n, int ncols, const int *rp, const int *ci, const double *val
   m.rs_cheb = (const double *)up(cheb.data(), cheb.size() * sizeof(double));
   if (!m.rs_pinfo || !m.rs_extq || !m.rs_perm || !m.rs_inv || !m.rs_colsq || !m.rs_lv || !m.rs_lc || !m.rs_dsc || !m.rs_cheb) { m.rs_pinfo = nullptr; return 1; }
   m.rs_P = pl.P; m.rs_NS = pl.NS; m.rs_rpt = pl.rpt; m.rs_woff = pl.woff; m.rs_deg = pl.deg;
+  if (inv_out) *inv_out = pl.inv;
   return 0;
 }
 double *field(const char *name, size_t n, int slabs = 1) {
@@ -379,6 +384,29 @@ int build_graph(int which) {
 }
 }  // namespace
 
+// Device of this process, shared by every context of the library (ocean core, sea ice, communicator): FESOM_GPU_DEVICE, else LOCAL_RANK
+// (one rank per GPU), else 0.  A mis-set multi-rank launch must not pile every rank on device 0 and still report numbers; a context
+// must not end up on another device than the one an earlier context of the process is bound to.
+int fesom_internal_select_device(std::string &err) {
+  static int bound = -1;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { err = "no HIP device: the MI355X path has no CPU fallback"; return 1; }
+  const char *dv = getenv("FESOM_GPU_DEVICE");
+  if (!dv) dv = getenv("LOCAL_RANK");
+  const int dev = dv ? atoi(dv) : 0;
+  if (dev < 0 || dev >= ndev) {
+    err = std::string("device index ") + std::to_string(dev) + " (FESOM_GPU_DEVICE / LOCAL_RANK) but only " + std::to_string(ndev) + " HIP device(s) are visible";
+    return 1;
+  }
+  if (bound >= 0 && bound != dev && (G.ready || R.comm)) {
+    err = std::string("device index ") + std::to_string(dev) + " requested, but a context of this process is already bound to device " + std::to_string(bound);
+    return 1;
+  }
+  if (hipSetDevice(dev) != hipSuccess) { err = "hipSetDevice failed"; return 1; }
+  bound = dev;
+  return 0;
+}
+
 int fesom_internal_rccl_exchange(int ns, const int *sPE, const int *sptr, int nr, const int *rPE, const int *rptr, double *sd, double *rd, int W, hipStream_t s) {
   if (!R.comm) { G.err = "built-in transport not initialised (fesom_gpu_comm_init)"; return 1; }
   NCCLCHK(R.GroupStart());
@@ -435,16 +463,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   if (par->mix_scheme < 0 || par->mix_scheme > 2) { G.err = "fesom_gpu_init: mix_scheme must be 0 (constant), 1 (KPP) or 2 (PP); the cvmix schemes are not implemented"; return 3; }
   for (int e = 0; e < d->myDim_elem2D + d->eDim_elem2D; e++)
     if (d->ulevels[e] != 1) { G.err = "fesom_gpu_init: cavities (ulevels>1) are not supported"; return 3; }
-  {
-    const char *dv = getenv("FESOM_GPU_DEVICE");
-    if (!dv) dv = getenv("LOCAL_RANK");
-    int dev = dv ? atoi(dv) : 0;
-    if (dev < 0 || dev >= ndev) {     // a mis-set multi-rank launch must not pile every rank on device 0 and still report numbers
-      G.err = std::string("fesom_gpu_init: device index ") + std::to_string(dev) + " (FESOM_GPU_DEVICE / LOCAL_RANK) but only " + std::to_string(ndev) + " HIP device(s) are visible";
-      fprintf(stderr, "fesom_gpu: %s\n", G.err.c_str()); return 2;
-    }
-    HIPCHK(hipSetDevice(dev));
-  }
+  if (fesom_internal_select_device(G.err)) { fprintf(stderr, "fesom_gpu: %s\n", G.err.c_str()); return 2; }
   HIPCHK(hipStreamCreate(&G.stream));
   for (int i = 0; i < 3; i++) HIPCHK(hipStreamCreateWithFlags(&G.side[i], hipStreamNonBlocking));   // (stream priorities: no effect, measured)
   G.serial = getenv("FESOM_GPU_SERIAL") != nullptr;
@@ -710,6 +729,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     m.MLD1_ind = dev_alloc<int>(N);
   }
   G.npes = part ? part->npes : 1; G.mype = part ? part->mype : 0;
+  G.precond_agreed = false; G.x_pending = false; G.generation++; g_prog_ready = false;
   G.hsend = G.hrecv = nullptr; G.hcap = 0; G.hsend1 = G.hrecv1 = nullptr; G.hcap1 = 0; G.toy_znum_global = false;
   if (part && part->npes > 1) {
     const fesom_com_desc *cs[3] = {&part->com_nod2D, &part->com_elem2D, &part->com_elem2D_full};
@@ -719,7 +739,8 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
       h.rPE.assign(c.rPE, c.rPE + c.rPEnum); h.rptr.assign(c.rptr, c.rptr + c.rPEnum + 1);
       h.sPE.assign(c.sPE, c.sPE + c.sPEnum); h.sptr.assign(c.sptr, c.sptr + c.sPEnum + 1);
       h.nrecv = h.rptr.back() - 1; h.nsend = h.sptr.back() - 1;
-      h.rlist = dev_upload(minus1(c.rlist, h.nrecv)); h.slist = dev_upload(minus1(c.slist, h.nsend));
+      h.slist_h = minus1(c.slist, h.nsend);
+      h.rlist = dev_upload(minus1(c.rlist, h.nrecv)); h.slist = dev_upload(h.slist_h); h.slist_q = nullptr;
       h.rptr_d = dev_upload(h.rptr); h.sptr_d = dev_upload(h.sptr);
     }
   }
@@ -771,29 +792,23 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     for (int j = 0; j < m.nza; j++) ci[j] = d->ssh_colind_loc[j] - 1;
     if (xinv_device(m.myN, rp.data(), ci.data(), d->ssh_values, nullptr, m, G.allocs)) { m.sv_minv = nullptr; G.err = "fesom_gpu_init: the explicit-inverse SSH preconditioner could not be built (singular operator or out of memory)"; return 1; }
   }
-  if (par->solver_precond == 1 && G.npes > 1 && m.myN <= 4096 && m.ssh_maxnnz <= 16 && m.myN >= 64) {
-    // partitioned run: every rank inverts the owned-owned block of its rows (block Jacobi with exact blocks; the reference's RAS applies
-    // its ILU factors per rank the same way, bicgstab_ras.c), row scales from the whole rows as in the solver
-    std::vector<int> rp(m.myN + 1, 0), ci; std::vector<double> va, sc(m.myN);
-    const int off = d->ssh_rowptr[0];
-    for (int i = 0; i < m.myN; i++) {
-      double tmp = 0.;
-      for (int q = d->ssh_rowptr[i] - off; q < d->ssh_rowptr[i + 1] - off; q++) {
-        tmp += fabs(d->ssh_values[q]);
-        const int c = d->ssh_colind_loc[q] - 1;
-        if (c < m.myN) { ci.push_back(c); va.push_back(d->ssh_values[q]); }
-      }
-      sc[i] = 1. / tmp;
-      rp[i + 1] = (int)ci.size();
-    }
-    if (xinv_device(m.myN, rp.data(), ci.data(), va.data(), sc.data(), m, G.allocs)) { m.sv_minv = nullptr; G.err = "fesom_gpu_init: the block-inverse SSH preconditioner of this partition could not be built"; return 1; }
-  }
-  if (par->solver_precond == 1 && !m.sv_minv && m.ssh_maxnnz <= 16 && G.npes <= 1) {
-    // operators beyond the explicit inverse: RAS-Chebyshev (solver_ras.hip), frozen at the operator this run starts with
-    std::vector<int> rp(m.myN + 1), ci(m.nza);
+  if (par->solver_precond == 1 && !m.sv_minv && m.ssh_maxnnz <= 16) {
+    // operators beyond the explicit inverse and every partitioned run: RAS-Chebyshev (solver_ras.hip), frozen at the operator this run
+    // starts with.  On a partition the patches cover the rank's owned rows (halo columns are outside every patch), so applying the
+    // preconditioner needs no communication -- the role of the per-rank ILU factors in the reference's RAS (bicgstab_ras.c:49-259).
+    // The choice does not depend on the rank's size, so all ranks take the same solver path (checked once more at the first step).
+    std::vector<int> rp(m.myN + 1), ci(m.nza), inv;
     for (int i = 0; i <= m.myN; i++) rp[i] = d->ssh_rowptr[i] - d->ssh_rowptr[0];
     for (int j = 0; j < m.nza; j++) ci[j] = d->ssh_colind_loc[j] - 1;
-    if (ras_device(m.myN, m.N, rp.data(), ci.data(), d->ssh_values, m.ssh_maxnnz, m, G.allocs)) m.rs_pinfo = nullptr;      // (does not qualify: Jacobi)
+    const char *off = getenv("FESOM_GPU_RAS_OFF_ON_RANK");          // (tests: a rank whose block does not qualify -- all ranks must then fall back together)
+    if ((off && G.npes > 1 && atoi(off) == G.mype) || ras_device(m.myN, m.N, rp.data(), ci.data(), d->ssh_values, m.ssh_maxnnz, m, G.allocs, &inv)) m.rs_pinfo = nullptr;      // (does not qualify: Jacobi)
+    if (m.rs_pinfo && G.npes > 1) {
+      Ctx::Halo &h = G.halo[0];
+      std::vector<int> sq(h.slist_h.size());
+      for (size_t k = 0; k < sq.size(); k++) sq[k] = (h.slist_h[k] >= 0 && h.slist_h[k] < m.myN) ? inv[h.slist_h[k]] : h.slist_h[k];
+      h.slist_q = dev_upload(sq);
+      if (g_alloc_failed) { G.err = "fesom_gpu_init: device allocation failed (halo send list of the solver)"; return 1; }
+    }
   }
   solver_prepare();
   tile_prepare_tra(); tile_prepare_dyn();
@@ -871,63 +886,138 @@ int fesom_gpu_set_forcing(const fesom_forcing_desc *f) {
 }
 
 static int call_named(const char *name, int arg);
-static int halo_pack_on(int kind, int nfields, const char *const *names, void **send_dev, void **recv_dev, int *values_per_item, int ch);
-static int halo_unpack_on(int kind, int nfields, const char *const *names, int ch);
-// ---- partitioned step driven by the library (phase order = fesom2_amd/parallel.py:run_step, which the tests probe phase by
-// phase; both call the same kernels in the same order, so their results are bit-identical for the same transport)
+// ---- partitioned step driven by the library.  The same phases, exchange points and solver loop as fesom2_amd/parallel.py:run_step,
+// which the tests probe phase by phase; both issue the same kernels on the same data, so their results are bit-identical for the same
+// transport.  Built for few, large messages and no host synchronisation outside the one convergence read-back of the SSH solve:
+//   * the step is a PROGRAM (vector of ops) built once per context: kernel ops hold the launcher of their family, exchange ops their
+//     resolved field lists, message layout and buffer offsets -- nothing is looked up by name while a step is enqueued;
+//   * an exchange point may carry node AND element fields (one RCCL group; one callback per kind with the host transport), and the
+//     kernel order inside a step is chosen so that fields that are ready at the same time travel together: 13 exchange points per
+//     step with the reference's default physics (KPP + GM + Redi) outside the SSH solve, 8 with PP (the reference: ~50 calls);
+//   * exchanges whose consumer is far away run on the communication stream (pack, RCCL group, unpack behind an event) while the
+//     step's stream carries on -- the overlap the reference has at one place (src/oce_tracer_mod.F90:68-81).
 namespace {
-// one exchange through the built-in transport: a group of ncclSend / ncclRecv, one pair per neighbour, on the library's stream
-int rccl_exchange(int kind, double *sd, double *rd, int W, hipStream_t stream) {
-  const Ctx::Halo &h = G.halo[kind];
-  NCCLCHK(R.GroupStart());
-  for (size_t p = 0; p < h.sPE.size(); p++) {
-    const size_t first = (size_t)(h.sptr[p] - 1), cnt = (size_t)(h.sptr[p + 1] - h.sptr[p]);
-    if (cnt) NCCLCHK(R.Send(sd + first * W, cnt * W, ncclDouble, h.sPE[p], R.comm, stream));
+struct Sub { double *p; int W; bool q; };          // q: a solver vector in the patch order of the RAS preconditioner (send list as positions)
+struct XSpec { int kind; std::vector<const char *> names; };
+struct XPlan {
+  struct Part { int kind, Wtot; std::vector<Sub> subs; size_t soff, roff; };
+  std::vector<Part> parts;
+  size_t stot = 0, rtot = 0;
+};
+int halo_subfields(int kind, int nf, const char *const *names, std::vector<Sub> &subs, int &Wtot);
+int halo_reserve(size_t doubles, int ch);
+int xplan_build(const std::vector<XSpec> &spec, XPlan &x) {
+  x.parts.clear(); x.stot = x.rtot = 0;
+  for (const XSpec &sp : spec) {
+    if (sp.kind < 0 || sp.kind > 2) { G.err = "halo: bad kind"; return 1; }
+    XPlan::Part pt;
+    pt.kind = sp.kind;
+    if (halo_subfields(sp.kind, (int)sp.names.size(), sp.names.data(), pt.subs, pt.Wtot)) return 1;
+    pt.soff = x.stot; pt.roff = x.rtot;
+    x.stot += (size_t)G.halo[sp.kind].nsend * pt.Wtot; x.rtot += (size_t)G.halo[sp.kind].nrecv * pt.Wtot;
+    x.parts.push_back(pt);
   }
-  for (size_t p = 0; p < h.rPE.size(); p++) {
-    const size_t first = (size_t)(h.rptr[p] - 1), cnt = (size_t)(h.rptr[p + 1] - h.rptr[p]);
-    if (cnt) NCCLCHK(R.Recv(rd + first * W, cnt * W, ncclDouble, h.rPE[p], R.comm, stream));
+  return 0;
+}
+__global__ void k_halo_pack(const double *__restrict__ f, int W, const int *__restrict__ list, const int *__restrict__ ptr, int npe, int nitems,
+                            int Wtot, int Woff, double *__restrict__ buf);
+__global__ void k_halo_unpack(double *__restrict__ f, int W, const int *__restrict__ list, const int *__restrict__ ptr, int npe, int nitems,
+                              int Wtot, int Woff, const double *__restrict__ buf);
+int xplan_pack(const XPlan &x, int ch) {
+  if (halo_reserve(std::max(x.stot, x.rtot), ch)) return 1;
+  hipStream_t st = ch ? G.cstream : G.stream;
+  double *sbuf = ch ? G.hsend1 : G.hsend;
+  for (const XPlan::Part &pt : x.parts) {
+    const Ctx::Halo &h = G.halo[pt.kind];
+    int off = 0;
+    for (const Sub &sb : pt.subs) {
+      const long long tot = (long long)h.nsend * sb.W;
+      if (tot > 0) hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, sb.p, sb.W, sb.q ? h.slist_q : h.slist, h.sptr_d, (int)h.sPE.size(), h.nsend, pt.Wtot, off, sbuf + pt.soff);
+      off += sb.W;
+    }
+  }
+  return 0;
+}
+int xplan_unpack(const XPlan &x, int ch) {
+  hipStream_t st = ch ? G.cstream : G.stream;
+  const double *rbuf = ch ? G.hrecv1 : G.hrecv;
+  for (const XPlan::Part &pt : x.parts) {
+    const Ctx::Halo &h = G.halo[pt.kind];
+    int off = 0;
+    for (const Sub &sb : pt.subs) {
+      const long long tot = (long long)h.nrecv * sb.W;
+      if (tot > 0) hipLaunchKernelGGL(k_halo_unpack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, sb.p, sb.W, h.rlist, h.rptr_d, (int)h.rPE.size(), h.nrecv, pt.Wtot, off, rbuf + pt.roff);
+      off += sb.W;
+    }
+  }
+  return 0;
+}
+// the bytes of one exchange point: ONE group of ncclSend / ncclRecv through the built-in transport (a pair per neighbour and part), or one
+// callback per part through the host's transport
+int xplan_move(const XPlan &x, const fesom_transport *t, int ch, hipStream_t stream) {
+  double *sbuf = ch ? G.hsend1 : G.hsend, *rbuf = ch ? G.hrecv1 : G.hrecv;
+  if (t) {
+    for (const XPlan::Part &pt : x.parts)
+      if (t->exchange(t->ctx, pt.kind, sbuf + pt.soff, rbuf + pt.roff, pt.Wtot)) { G.err = "step_partitioned: transport exchange failed"; return 1; }
+    return 0;
+  }
+  NCCLCHK(R.GroupStart());
+  for (const XPlan::Part &pt : x.parts) {
+    const Ctx::Halo &h = G.halo[pt.kind];
+    const int W = pt.Wtot;
+    for (size_t p = 0; p < h.sPE.size(); p++) {
+      const size_t first = (size_t)(h.sptr[p] - 1), cnt = (size_t)(h.sptr[p + 1] - h.sptr[p]);
+      if (cnt) NCCLCHK(R.Send(sbuf + pt.soff + first * W, cnt * W, ncclDouble, h.sPE[p], R.comm, stream));
+    }
+    for (size_t p = 0; p < h.rPE.size(); p++) {
+      const size_t first = (size_t)(h.rptr[p] - 1), cnt = (size_t)(h.rptr[p + 1] - h.rptr[p]);
+      if (cnt) NCCLCHK(R.Recv(rbuf + pt.roff + first * W, cnt * W, ncclDouble, h.rPE[p], R.comm, stream));
+    }
   }
   NCCLCHK(R.GroupEnd());
   return 0;
 }
+
+typedef int (*FamFn)(const DM &, hipStream_t, const char *, int, int);
+int fam_dyn(const DM &m, hipStream_t s, const char *n, int a, int fs) { return launch_named_dyn(m, s, n, a, fs); }
+int fam_tra(const DM &m, hipStream_t s, const char *n, int a, int) { return launch_named_tra(m, s, n, a); }
+int fam_kpp(const DM &m, hipStream_t s, const char *n, int, int) { return launch_named_kpp(m, s, n); }
+int fam_gm(const DM &m, hipStream_t s, const char *n, int, int) { return launch_named_gm(m, s, n); }
+int fam_toy(const DM &m, hipStream_t s, const char *n, int, int) { return launch_named_toy(m, s, n); }
+int fam_sol(const DM &m, hipStream_t s, const char *n, int, int) { return launch_named_dsolve(m, s, n); }
+int fam_ras(const DM &m, hipStream_t s, const char *n, int, int) { return launch_named_ras(m, s, n); }
+
 struct PStep {
   const fesom_transport *t;                       // nullptr: the built-in RCCL transport (fesom_gpu_comm_init)
   int rc = 0;
-  void c(const char *name, int arg = 0) { if (!rc && call_named(name, arg)) { rc = 1; if (G.err.empty()) G.err = std::string("step_partitioned: unknown phase ") + name; } }
-  // Asynchronous exchange (built-in transport only): pack, the RCCL group and unpack run on the communication stream behind an event
-  // of the step's stream, the step's stream carries on with kernels that do not read the halo and waits in Wt() -- the overlap the
-  // reference has at one place, init_tracers_AB (src/oce_tracer_mod.F90:68-81).  One exchange in flight; any other communication
-  // waits for it first, so the operations of the communicator stay in program order on every rank.
-  bool pending = false;
-  void Wt() { if (pending) { hipStreamWaitEvent(G.stream, G.ev_done, 0); pending = false; } }
-  void XA(int kind, std::initializer_list<const char *> names) {
+  void k(FamFn f, const char *name, int arg = 0) {
     if (rc) return;
-    if (t || !G.cstream) { X(kind, names); return; }
-    Wt();
-    std::vector<const char *> nm(names);
-    void *sd = nullptr, *rd = nullptr; int W = 0;
-    hipEventRecord(G.ev_prod, G.stream); hipStreamWaitEvent(G.cstream, G.ev_prod, 0);
-    if (halo_pack_on(kind, (int)nm.size(), nm.data(), &sd, &rd, &W, 1)) { rc = 1; return; }
-    if (rccl_exchange(kind, (double *)sd, (double *)rd, W, G.cstream)) { rc = 1; return; }
-    if (halo_unpack_on(kind, (int)nm.size(), nm.data(), 1)) { rc = 1; return; }
-    hipEventRecord(G.ev_done, G.cstream);
-    pending = true;
-    G.n_exch++; G.n_async++;
+    if (f(G.m, G.stream, name, arg, G.first_step) != 0) { rc = 1; if (G.err.empty()) G.err = std::string("step_partitioned: unknown phase ") + name; }
   }
-  void X(int kind, std::initializer_list<const char *> names) {
-    if (rc) return;
-    Wt();
-    std::vector<const char *> nm(names);        // (no early-out for a rank without neighbours: the transport may be a collective)
-    void *sd = nullptr, *rd = nullptr; int W = 0;
+  // One exchange in flight on the communication stream (built-in transport only); any other communication waits for it first, so the
+  // operations of the communicator stay in program order on every rank.
+  bool &pending = G.x_pending;
+  void Wt() {
+    if (!pending) return;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (G.comm_timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, G.stream); }
-    if (fesom_gpu_halo_pack(kind, (int)nm.size(), nm.data(), &sd, &rd, &W)) { rc = 1; return; }
-    if (t) { if (t->exchange(t->ctx, kind, sd, rd, W)) { rc = 1; G.err = "step_partitioned: transport exchange failed"; return; } }
-    else if (rccl_exchange(kind, (double *)sd, (double *)rd, W, G.stream)) { rc = 1; return; }
-    if (fesom_gpu_halo_unpack(kind, (int)nm.size(), nm.data())) rc = 1;
+    hipStreamWaitEvent(G.stream, G.ev_done, 0);
+    if (e0) { hipEventRecord(e1, G.stream); G.comm_ev.push_back({e0, e1}); }       // what the step's stream still had to wait for
+    pending = false;
+  }
+  void X(const XPlan &x, bool async) {
+    if (rc) return;
+    Wt();
+    const bool as = async && !t && G.cstream;
+    const int ch = as ? 1 : 0;
+    hipStream_t st = as ? G.cstream : G.stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (as) { hipEventRecord(G.ev_prod, G.stream); hipStreamWaitEvent(G.cstream, G.ev_prod, 0); }
+    else if (G.comm_timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, G.stream); }
+    if (xplan_pack(x, ch) || xplan_move(x, t, ch, st) || xplan_unpack(x, ch)) { rc = 1; return; }
+    if (as) { hipEventRecord(G.ev_done, G.cstream); pending = true; G.n_async++; }
     if (e0) { hipEventRecord(e1, G.stream); G.comm_ev.push_back({e0, e1}); }
-    G.n_exch++;
+    G.n_exch++; G.n_parts += (long long)x.parts.size();
   }
   void ARp(double *buf, int n) {                  // global sum over the ranks of n doubles at a device address, in place
     if (rc) return;
@@ -940,12 +1030,187 @@ struct PStep {
   // compute_zonal_mean of the Soufflet channel on a partition (src/toy_channel_soufflet.F90:157-217): local sums, the two global sums
   // of the reference (plus, once, the one of compute_zonal_mean_ini :141-150 for the element counts), division
   void zonal() {
-    c("toy_zonal_sum");
+    k(fam_toy, "toy_zonal_sum");
     if (!G.toy_znum_global) { ARp((double *)G.m.toy_znum, 100); G.toy_znum_global = !rc; }
     ARp(G.m.toy_zvel, 100 * G.m.nlm1); ARp(G.m.toy_ztem, 100 * G.m.nlm1);
-    c("toy_zonal_div");
+    k(fam_toy, "toy_zonal_div");
   }
 };
+
+// the program of one step
+enum OpType { O_KERNEL, O_XCHG, O_XCHG_ASYNC, O_WAIT, O_SOLVE, O_ZONAL10 };
+struct Op { OpType type; FamFn fam; const char *name; int arg; XPlan x; };
+std::vector<Op> g_prog;
+int g_last_part_its = 8;
+
+int build_program() {
+  const fesom_params &p = G.m.p;
+  std::vector<Op> &P = g_prog;
+  P.clear();
+  int bad = 0;
+  auto K = [&](FamFn f, const char *name, int arg = 0) { P.push_back(Op{O_KERNEL, f, name, arg, XPlan()}); };
+  auto X = [&](std::vector<XSpec> spec, bool async = false) {
+    Op o{async ? O_XCHG_ASYNC : O_XCHG, nullptr, nullptr, 0, XPlan()};
+    bad |= xplan_build(spec, o.x);
+    P.push_back(o);
+  };
+  auto W = [&]() { P.push_back(Op{O_WAIT, nullptr, nullptr, 0, XPlan()}); };
+  const bool toy = p.toy_soufflet != 0, kpp = p.mix_scheme == 1, v5 = p.visc_option == 5;
+  if (toy) P.push_back(Op{O_ZONAL10, nullptr, nullptr, 0, XPlan()});       // before_oce_step (oce_setup_step.F90:625-630)
+  // head: everything that only needs the incoming state, so that Unode and (visc_option 5..7) U_b leave in ONE message, in flight under
+  // pressure / PGF / slopes / the KPP column part
+  K(fam_dyn, "k_vel_nodes");
+  const bool ub_early = p.visc_option >= 4;                                // (options 1-3 read the Leith coefficient, formed further down)
+  if (ub_early) { K(fam_dyn, "k_visc_elem"); X({{0, {"Unode"}}, {1, {"U_b"}}}, true); }
+  else X({{0, {"Unode"}}}, true);
+  K(fam_dyn, "k_pressure_bv"); K(fam_dyn, "k_pgf"); K(fam_dyn, "k_sigma_slope");
+  if (p.use_momix) K(fam_dyn, "k_momix");
+  if (kpp) K(fam_kpp, "k_kpp_col");
+  W();
+  std::vector<const char *> n2;                                              // second node message: whatever is ready by now
+  if (p.mom_adv == 3) { K(fam_dyn, "k_vinv_ke"); n2.push_back("KE_node"); }
+  else { K(fam_dyn, "k_momadv_node"); n2.push_back("Unode_rhs"); }
+  if (v5 && ub_early) { K(fam_dyn, "k_visc_node"); n2.push_back("U_c"); }
+  if (p.Redi) n2.push_back("slope_tapered");
+  if (kpp) n2.push_back("kpp_blmc");
+  X({{0, n2}});
+  if (p.mix_scheme == 2) K(fam_dyn, "k_pp");          // (the shear of oce_mixing_PP is read at the three nodes of every owned element)
+  if (kpp) {
+    K(fam_kpp, "k_kpp_smooth1"); X({{0, {"kpp_sA"}}});
+    K(fam_kpp, "k_kpp_smooth2"); X({{0, {"kpp_sB"}}});
+    K(fam_kpp, "k_kpp_smooth3");
+    K(fam_kpp, "k_kpp_final"); X({{0, {"kpp_viscA", "Kv"}}});
+    K(fam_kpp, "k_kpp_elem");
+  }
+  if (p.mom_adv == 3) { K(fam_dyn, "k_leith_vort"); X({{0, {"vorticity"}}}); K(fam_dyn, "k_vinv_elem"); }
+  else K(fam_dyn, "k_vel_rhs");
+  if (p.visc_option <= 3) {    // h_viscosity_leith with its exchange_nod(vorticity), 2 x exchange_nod(aux), exchange_elem(Visc)
+    K(fam_dyn, "k_leith_vort"); X({{0, {"vorticity"}}}); K(fam_dyn, "k_leith_elem");
+    for (int nt = 0; nt < 2; nt++) { K(fam_dyn, "k_leith_node"); X({{0, {"leith_aux"}}}); K(fam_dyn, "k_leith_avg"); }
+    X({{1, {"Visc"}}});
+    if (p.visc_option != 1) { K(fam_dyn, "k_visc_elem"); X({{1, {"U_b"}}}); }
+  }
+  if (!v5) K(fam_dyn, "k_visc_apply");
+  K(fam_dyn, "k_impl_visc");
+  if (p.which_ale != 0) K(fam_dyn, "k_stiff_update");
+  K(fam_dyn, "k_edge_transport"); K(fam_dyn, "k_ssh_rhs_node");
+  P.push_back(Op{O_SOLVE, nullptr, nullptr, 0, XPlan()});
+  X({{0, {"d_eta"}}});
+  if (toy) K(fam_toy, "relax_zonal_vel");                    // oce_ale.F90:2696
+  if (p.Redi && !p.Fer_GM) { K(fam_gm, "init_Redi_GM"); X({{0, {"Ki"}}}); }
+  if (p.Fer_GM) {
+    K(fam_gm, "init_Redi_GM");
+    if (p.Redi) X({{0, {"fer_c", "fer_K", "Ki"}}}); else X({{0, {"fer_c", "fer_K"}}});
+    K(fam_gm, "fer_solve_Gamma"); X({{0, {"fer_gamma"}}});
+    K(fam_gm, "fer_gamma2vel"); K(fam_gm, "fer_wvel");     // (owned edges only touch elements this rank computes itself: the halos can wait)
+  }
+  K(fam_dyn, "k_update_vel"); K(fam_dyn, "k_edge_transport1"); K(fam_dyn, "k_vert_vel_hbar");
+  {   // ONE message for everything the dynamics leave behind: element velocities and the node fields of vert_vel_ale / compute_hbar_ale
+    std::vector<const char *> nn = {"Wvel", "Wvel_e", "Wvel_i", "hnode_new", "hbar", "hbar_old", "eta_n", "ssh_rhs_old"}, ee = {"UV"};
+    if (p.Fer_GM) { nn.push_back("fer_Wvel"); ee.push_back("fer_UV"); }
+    X({{0, nn}, {1, ee}});
+  }
+  K(fam_dyn, "k_dhe");
+  if (p.Fer_GM) K(fam_gm, "bolus_add");
+  if (p.SPP) K(fam_tra, "k_spp", 0);                         // solve_tracers_ale :120-121 (owned and halo nodes, as the reference)
+  K(fam_tra, "k_tr_ab", 0); K(fam_tra, "k_tr_grad_elem", 0); X({{2, {"tr_xy_ab"}}}, true);       // the reference's own overlap (oce_tracer_mod.F90:68-81)
+  K(fam_tra, "k_tr_z", 0);
+  W();
+  K(fam_tra, "k_updn_grad", 0);
+  K(fam_tra, "k_flux_hor", 0); K(fam_tra, "k_fct_lo_node", 0);
+  if (!p.tra_adv_lim) {                                        // (no low-order solution, no limiter with tra_adv_lim='NON')
+    if (p.Redi) X({{0, {"fct_LO", "tr_z"}}}); else X({{0, {"fct_LO"}}});
+    if (p.with_diffusion) K(fam_tra, "k_diff_flux", 0);
+    K(fam_tra, "k_fct_node", 0); X({{0, {"fct_plus", "fct_minus"}}});
+  } else {
+    if (p.Redi) X({{0, {"tr_z"}}});
+    if (p.with_diffusion) K(fam_tra, "k_diff_flux", 0);
+  }
+  K(fam_tra, "k_fct_edge_limit", 0); K(fam_tra, "k_tr_update", 0);
+  if (p.smooth_bh_tra) { K(fam_tra, "k_bh1", 0); X({{0, {"bh_tmp"}}}); K(fam_tra, "k_bh2", 0); }     // (the tracer halo still holds the values of the previous exchange, as in the reference)
+  if (toy) for (int tr = 0; tr < G.m.ntr; tr++) K(fam_toy, "relax_zonal_temp");     // once per tracer of the loop, always on tracer 1 (oce_ale_tracer.F90:150)
+  else if (p.clim_relax > 1.0e-8) K(fam_tra, "relax_to_clim", 0);
+  X({{0, {"tr_arr"}}}, true);                                 // in flight under the thickness update and the head of the next step
+  if (p.Fer_GM) K(fam_gm, "bolus_remove");
+  K(fam_dyn, "k_thick_node"); K(fam_dyn, "k_thick_elem");
+  if (bad) return 1;
+  g_prog_ready = true;
+  return 0;
+}
+
+// Every rank must take the same solver path (their exchanges and all-reduces have to match): a rank whose block does not qualify for the
+// RAS preconditioner takes it from all of them.  One global sum + one read-back, at the first partitioned step.
+int agree_on_preconditioner(PStep &S) {
+  if (G.precond_agreed) return 0;
+  const double mine = G.m.rs_pinfo ? 1.0 : 0.0;
+  HIPCHK(hipMemcpyAsync(G.m.sv_red, &mine, sizeof(double), hipMemcpyHostToDevice, G.stream));
+  S.AR(1);
+  if (S.rc) return 1;
+  double all = 0.0;
+  HIPCHK(hipMemcpyAsync(&all, G.m.sv_red, sizeof(double), hipMemcpyDeviceToHost, G.stream));
+  HIPCHK(hipStreamSynchronize(G.stream));
+  if (all != (double)G.npes) G.m.rs_pinfo = nullptr;
+  G.precond_agreed = true;
+  return 0;
+}
+
+// Partitioned SSH solve: BiCGstab over the owned rows, halo of the gathered vector before each product with A_s, global sum of the
+// partial dot products after it (pARMS does the same with MPI, lib/parms/src/bicgstab_ras.c:49-259, parms_comm.c:205-356).  Krylov scalars
+// and the convergence flag live on the device; iterations are enqueued in chunks and the flag is read back once per solve as a rule (one
+// iteration more than the last solve needed first; phases behind the convergence are no-ops, so the result does not depend on the chunks).
+int part_solve(PStep &S) {
+  const DM &m = G.m;
+  static XPlan x_x, x_ph, x_sh, x_dinv, x_s;
+  static int key = -1;                                   // the context (fesom_gpu_init call) the cached message plans belong to
+  if (key != G.generation) {
+    if (xplan_build({{0, {"sv_x"}}}, x_x) || xplan_build({{0, {"sv_ph"}}}, x_ph) || xplan_build({{0, {"sv_sh"}}}, x_sh) || xplan_build({{0, {"sv_dinv"}}}, x_dinv) ||
+        xplan_build({{0, {"sv_s"}}}, x_s)) return 1;
+    key = G.generation;
+  }
+  const int maxits = m.sv_maxits > 0 ? m.sv_maxits : 2000;
+  static double *hk = nullptr;
+  if (!hk && hipHostMalloc((void **)&hk, 16 * sizeof(double)) != hipSuccess) { G.err = "step_partitioned: pinned allocation failed"; return 1; }
+  const bool ras = m.rs_pinfo != nullptr;
+  S.k(fam_sol, "ds_scale");
+  if (ras) {
+    S.k(fam_ras, "dsr_setup"); S.X(x_x, false);
+    S.k(fam_ras, "dsr_init"); S.AR(1); S.k(fam_ras, "dsr_scal_init");
+  } else {
+    S.X(x_dinv, false);
+    S.k(fam_sol, "ds_setup"); S.X(x_s, false);
+    S.k(fam_sol, "ds_init"); S.AR(1); S.k(fam_sol, "ds_scal_init"); S.k(fam_sol, "ds_p");
+  }
+  int total = 0, chunk = std::max(1, g_last_part_its + 1);
+  const int flag = ras ? 8 : 7;
+  for (;;) {
+    for (int i = 0; i < chunk && !S.rc; i++) {
+      if (ras) {
+        S.k(fam_ras, "dsr_prec0"); S.X(x_ph, false); S.k(fam_ras, "dsr_spmv1"); S.AR(1); S.k(fam_ras, "dsr_scal_alpha");
+        S.k(fam_ras, "dsr_prec1"); S.X(x_sh, false); S.k(fam_ras, "dsr_spmv2"); S.AR(4); S.k(fam_ras, "dsr_scal_omega"); S.k(fam_ras, "dsr_update");
+      } else {
+        S.X(x_ph, false); S.k(fam_sol, "ds_spmv1"); S.AR(1); S.k(fam_sol, "ds_scal_alpha"); S.k(fam_sol, "ds_s");
+        S.X(x_s, false); S.k(fam_sol, "ds_spmv2"); S.AR(4); S.k(fam_sol, "ds_scal_omega"); S.k(fam_sol, "ds_update"); S.k(fam_sol, "ds_p");
+      }
+    }
+    if (S.rc) return 1;
+    total += chunk;
+    HIPCHK(hipMemcpyAsync(hk, m.sv_kry, 16 * sizeof(double), hipMemcpyDeviceToHost, G.stream));
+    HIPCHK(hipStreamSynchronize(G.stream));
+    if (hk[flag] != 0.0 || hk[6] >= (double)maxits) break;
+    chunk = 2;
+  }
+  (void)total;
+  G.part_iters = (int)hk[6]; g_last_part_its = G.part_iters;
+  S.k(ras ? fam_ras : fam_sol, ras ? "dsr_finish" : "ds_finish");
+  const double tol = m.sv_tol > 0.0 ? m.sv_tol : 1e-10;
+  if (!(hk[5] < tol * tol)) {          // the reference's BiCGstab reports this too (bicgstab_ras.c:237); a step must not go on with an unconverged SSH
+    char b[200];
+    snprintf(b, sizeof b, "step_partitioned: the SSH solve did not converge: %d iterations, ||scaled residual|| = %.3e (tolerance %.1e)", G.part_iters, sqrt(hk[5] > 0.0 ? hk[5] : 0.0), tol);
+    G.err = b; fprintf(stderr, "fesom_gpu: %s\n", b);
+    return 1;
+  }
+  return 0;
+}
 }  // namespace
 
 int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
@@ -955,103 +1220,20 @@ int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
   if (!t && (!R.comm || R.nranks != G.npes || R.rank != G.mype)) {
     G.err = "step_partitioned: no transport given and the built-in RCCL transport is not initialised for this partition (fesom_gpu_comm_init)"; return 1;
   }
-  const fesom_params &p = G.m.p;
   PStep S{t};
-  const bool toy = p.toy_soufflet != 0;
-  if (toy && n % 10 == 0) S.zonal();                  // before_oce_step (oce_setup_step.F90:625-630)
-  S.c("k_vel_nodes"); S.XA(0, {"Unode"});          // read by k_momadv_node only: in flight under pressure / PGF / slopes / mixing
-  S.c("k_pressure_bv"); S.c("k_pgf"); S.c("k_sigma_slope");
-  if (p.Redi) S.X(0, {"slope_tapered"});
-  if (p.use_momix) S.c("k_momix");
-  if (p.mix_scheme == 2) { S.Wt(); S.c("k_pp"); }      // (the shear of oce_mixing_PP is read at the three nodes of every owned element)
-  if (p.mix_scheme == 1) {
-    S.c("k_kpp_col"); S.X(0, {"kpp_blmc"});
-    S.c("k_kpp_smooth1"); S.X(0, {"kpp_sA"});
-    S.c("k_kpp_smooth2"); S.X(0, {"kpp_sB"});
-    S.c("k_kpp_smooth3");
-    S.c("k_kpp_final"); S.X(0, {"kpp_viscA", "Kv"});
-    S.c("k_kpp_elem");
-  }
-  S.Wt();
-  if (p.mom_adv == 3) { S.c("k_vinv_ke"); S.X(0, {"KE_node"}); S.c("k_leith_vort"); S.X(0, {"vorticity"}); S.c("k_vinv_elem"); }
-  else { S.c("k_momadv_node"); S.X(0, {"Unode_rhs"}); S.c("k_vel_rhs"); }
-  if (p.visc_option <= 3) {    // h_viscosity_leith with its exchange_nod(vorticity), 2 x exchange_nod(aux), exchange_elem(Visc)
-    S.c("k_leith_vort"); S.X(0, {"vorticity"}); S.c("k_leith_elem");
-    for (int nt = 0; nt < 2; nt++) { S.c("k_leith_node"); S.X(0, {"leith_aux"}); S.c("k_leith_avg"); }
-    S.X(1, {"Visc"});
-  }
-  if (p.visc_option != 1) { S.c("k_visc_elem"); S.X(1, {"U_b"}); }
-  if (p.visc_option == 5) { S.c("k_visc_node"); S.X(0, {"U_c"}); }
-  else S.c("k_visc_apply");
-  S.c("k_impl_visc");
-  if (p.which_ale != 0) S.c("k_stiff_update");
-  S.c("k_edge_transport"); S.c("k_ssh_rhs_node");
-  if (G.m.sv_minv) {   // partitioned SSH solve, BiCGstab preconditioned with the inverse of each rank's own block (solver.hip "dsx_")
-    S.c("ds_scale"); S.X(0, {"sv_dinv"});
-    S.c("ds_setup"); S.X(0, {"sv_x"});
-    S.c("dsx_init"); S.AR(1); S.c("ds_scal_init");
-    const int poll = 2;
-    double kry[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    while (!S.rc) {
-      for (int k = 0; k < poll; k++) {
-        S.c("dsx_prec0"); S.X(0, {"sv_ph"}); S.c("dsx_spmv1"); S.AR(1); S.c("ds_scal_alpha");
-        S.c("dsx_prec1"); S.X(0, {"sv_sh"}); S.c("dsx_spmv2"); S.AR(4); S.c("ds_scal_omega"); S.c("dsx_update");
-      }
-      HIPCHK(hipMemcpyAsync(kry, G.m.sv_kry, sizeof(kry), hipMemcpyDeviceToHost, G.stream));
-      HIPCHK(hipStreamSynchronize(G.stream));
-      if (kry[7] != 0.0 || kry[6] >= 2000) break;
+  if (agree_on_preconditioner(S)) return 1;
+  if (!g_prog_ready && build_program()) return 1;
+  for (const Op &o : g_prog) {
+    if (S.rc) break;
+    switch (o.type) {
+      case O_KERNEL: S.k(o.fam, o.name, o.arg); break;
+      case O_XCHG: S.X(o.x, false); break;
+      case O_XCHG_ASYNC: S.X(o.x, true); break;
+      case O_WAIT: S.Wt(); break;
+      case O_SOLVE: if (part_solve(S)) S.rc = 1; break;
+      case O_ZONAL10: if (n % 10 == 0) S.zonal(); break;
     }
-    G.part_iters = (int)kry[6];
-    S.c("dsx_finish");
-  } else {   // partitioned SSH solve: recurrences of the single-GPU kernel, Krylov scalars + convergence flag on the device
-    S.c("ds_scale"); S.X(0, {"sv_dinv"});
-    S.c("ds_setup"); S.X(0, {"sv_s"});
-    S.c("ds_init"); S.AR(1); S.c("ds_scal_init"); S.c("ds_p");
-    const int poll = 4;
-    double kry[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    while (!S.rc) {
-      for (int k = 0; k < poll; k++) {
-        S.X(0, {"sv_ph"}); S.c("ds_spmv1"); S.AR(1); S.c("ds_scal_alpha"); S.c("ds_s");
-        S.X(0, {"sv_s"}); S.c("ds_spmv2"); S.AR(4); S.c("ds_scal_omega"); S.c("ds_update"); S.c("ds_p");
-      }
-      HIPCHK(hipMemcpyAsync(kry, G.m.sv_kry, sizeof(kry), hipMemcpyDeviceToHost, G.stream));
-      HIPCHK(hipStreamSynchronize(G.stream));
-      if (kry[7] != 0.0 || kry[6] >= 2000) break;
-    }
-    G.part_iters = (int)kry[6];
-    S.c("ds_finish");
   }
-  S.X(0, {"d_eta"});
-  if (toy) S.c("relax_zonal_vel");                    // oce_ale.F90:2696
-  if (p.Redi && !p.Fer_GM) { S.c("init_Redi_GM"); S.X(0, {"Ki"}); }
-  if (p.Fer_GM) {
-    S.c("init_Redi_GM");
-    if (p.Redi) S.X(0, {"fer_c", "fer_K", "Ki"}); else S.X(0, {"fer_c", "fer_K"});
-    S.c("fer_solve_Gamma"); S.X(0, {"fer_gamma"});
-    S.c("fer_gamma2vel"); S.X(1, {"fer_UV"});
-    S.c("fer_wvel"); S.X(0, {"fer_Wvel"});
-  }
-  S.c("k_update_vel"); S.X(1, {"UV"});
-  S.c("k_edge_transport1"); S.c("k_vert_vel_hbar");
-  S.X(0, {"Wvel", "Wvel_e", "Wvel_i", "hnode_new", "hbar", "hbar_old", "eta_n", "ssh_rhs_old"});
-  S.c("k_dhe");
-  if (p.Fer_GM) S.c("bolus_add");
-  if (p.SPP) S.c("k_spp", 0);                      // solve_tracers_ale :120-121 (owned and halo nodes, as the reference)
-  S.c("k_tr_ab", 0); S.c("k_tr_grad_elem", 0); S.XA(2, {"tr_xy_ab"});       // the reference's own overlap (oce_tracer_mod.F90:68-81)
-  S.c("k_tr_z", 0);
-  S.Wt();
-  S.c("k_updn_grad", 0);
-  if (p.Redi) S.X(0, {"tr_z"});
-  if (p.with_diffusion) S.c("k_diff_flux", 0);
-  S.c("k_flux_hor", 0); S.c("k_fct_lo_node", 0);
-  if (!p.tra_adv_lim) { S.X(0, {"fct_LO"}); S.c("k_fct_node", 0); S.X(0, {"fct_plus", "fct_minus"}); }     // (no low-order solution, no limiter with tra_adv_lim='NON')
-  S.c("k_fct_edge_limit", 0); S.c("k_tr_update", 0);
-  if (p.smooth_bh_tra) { S.c("k_bh1", 0); S.X(0, {"bh_tmp"}); S.c("k_bh2", 0); }     // (the tracer halo still holds the values of the previous exchange, as in the reference)
-  if (toy) for (int tr = 0; tr < G.m.ntr; tr++) S.c("relax_zonal_temp");     // once per tracer of the loop, always on tracer 1 (oce_ale_tracer.F90:150)
-  else if (p.clim_relax > 1.0e-8) S.c("relax_to_clim", 0);
-  S.X(0, {"tr_arr"});
-  if (p.Fer_GM) S.c("bolus_remove");
-  S.c("k_thick_node"); S.c("k_thick_elem");
   S.Wt();
   G.first_step = 0;
   HIPCHK(hipGetLastError());
@@ -1416,7 +1598,6 @@ void psolve(int *id, double *rhs, double *vals, double *sol, int *newvals) {
 // [items of p][values per item] (an item is a node / element column, contiguous in memory: vertical index fastest).
 // =====================================================================================================================
 namespace {
-struct Sub { double *p; int W; };
 __global__ void k_halo_pack(const double *__restrict__ f, int W, const int *__restrict__ list, const int *__restrict__ ptr, int npe, int nitems,
                             int Wtot, int Woff, double *__restrict__ buf) {
   long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1446,9 +1627,15 @@ int halo_subfields(int kind, int nf, const char *const *names, std::vector<Sub> 
     if (it == G.fields.end()) { G.err = std::string("halo: unknown field ") + names[k]; return 1; }
     size_t cnt = it->second.count; int slabs = it->second.slabs;
     if (!strcmp(names[k], "tr_arr") || !strcmp(names[k], "tr_arr_old")) { slabs = m.ntr; cnt /= m.ntr; }   // (nz, node, tracer)
-    if (!strncmp(names[k], "sv_", 3)) cnt = items;                                                        // solver vectors are padded
+    bool q = false;
+    if (!strncmp(names[k], "sv_", 3)) {                                                                   // solver vectors are padded
+      cnt = items;
+      // with the RAS preconditioner the owned part of the Krylov vectors is in the patch order (solver_ras.hip): the send list as positions
+      q = G.m.rs_pinfo && kind == 0 && (!strcmp(names[k], "sv_x") || !strcmp(names[k], "sv_ph") || !strcmp(names[k], "sv_sh"));
+      if (q && !G.halo[0].slist_q) { G.err = "halo: the send list in the solver's patch order is missing"; return 1; }
+    }
     if (cnt % items) { G.err = std::string("halo: field size does not match the exchange kind: ") + names[k]; return 1; }
-    for (int sl = 0; sl < slabs; sl++) { subs.push_back(Sub{(double *)it->second.p + (size_t)sl * cnt, (int)(cnt / items)}); Wtot += (int)(cnt / items); }
+    for (int sl = 0; sl < slabs; sl++) { subs.push_back(Sub{(double *)it->second.p + (size_t)sl * cnt, (int)(cnt / items), q}); Wtot += (int)(cnt / items); }
   }
   return 0;
 }
@@ -1467,43 +1654,26 @@ int halo_reserve(size_t doubles, int ch) {
 }
 }  // namespace
 
-// channel 0: the step's stream and buffers; channel 1: the communication stream (asynchronous exchange of the built-in transport)
-static int halo_pack_on(int kind, int nfields, const char *const *names, void **send_dev, void **recv_dev, int *values_per_item, int ch) {
+// single exchanges for hosts that drive the step phase by phase (fesom2_amd/parallel.py): pack / unpack on the step's stream
+static XPlan g_hx;                                      // plan of the exchange between fesom_gpu_halo_pack and fesom_gpu_halo_unpack
+static int halo_pack_on(int kind, int nfields, const char *const *names, void **send_dev, void **recv_dev, int *values_per_item) {
   NEED_READY();
   if (G.npes < 2) { G.err = "halo: single partition"; return 1; }
-  if (kind < 0 || kind > 2) { G.err = "halo: bad kind"; return 1; }
-  const Ctx::Halo &h = G.halo[kind];
-  std::vector<Sub> subs; int Wtot = 0;
-  if (halo_subfields(kind, nfields, names, subs, Wtot)) return 1;
-  if (halo_reserve((size_t)std::max(h.nsend, h.nrecv) * Wtot, ch)) return 1;
-  hipStream_t st = ch ? G.cstream : G.stream;
-  double *sbuf = ch ? G.hsend1 : G.hsend;
-  int off = 0;
-  for (auto &sb : subs) {
-    long long tot = (long long)h.nsend * sb.W;
-    if (tot > 0) hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, sb.p, sb.W, h.slist, h.sptr_d, (int)h.sPE.size(), h.nsend, Wtot, off, sbuf);
-    off += sb.W;
-  }
+  std::vector<XSpec> spec(1);
+  spec[0].kind = kind; spec[0].names.assign(names, names + nfields);
+  if (xplan_build(spec, g_hx) || xplan_pack(g_hx, 0)) return 1;
   // stream-ordered: fesom_gpu_copy / fesom_gpu_sync wait for the pack kernels; a transport on the same stream
   // (fesom_gpu_set_stream) needs no host wait at all
   HIPCHK(hipGetLastError());
-  *send_dev = sbuf; *recv_dev = ch ? G.hrecv1 : G.hrecv; *values_per_item = Wtot;
+  *send_dev = G.hsend; *recv_dev = G.hrecv; *values_per_item = g_hx.parts[0].Wtot;
   return 0;
 }
-static int halo_unpack_on(int kind, int nfields, const char *const *names, int ch) {
+static int halo_unpack_on(int kind, int nfields, const char *const *names) {
   NEED_READY();
-  if (kind < 0 || kind > 2) { G.err = "halo: bad kind"; return 1; }
-  const Ctx::Halo &h = G.halo[kind];
-  std::vector<Sub> subs; int Wtot = 0;
-  if (halo_subfields(kind, nfields, names, subs, Wtot)) return 1;
-  hipStream_t st = ch ? G.cstream : G.stream;
-  const double *rbuf = ch ? G.hrecv1 : G.hrecv;
-  int off = 0;
-  for (auto &sb : subs) {
-    long long tot = (long long)h.nrecv * sb.W;
-    if (tot > 0) hipLaunchKernelGGL(k_halo_unpack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, sb.p, sb.W, h.rlist, h.rptr_d, (int)h.rPE.size(), h.nrecv, Wtot, off, rbuf);
-    off += sb.W;
-  }
+  std::vector<XSpec> spec(1);
+  spec[0].kind = kind; spec[0].names.assign(names, names + nfields);
+  XPlan x;
+  if (xplan_build(spec, x) || xplan_unpack(x, 0)) return 1;
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1521,9 +1691,9 @@ int fesom_gpu_halo_info(int kind, int *npes, int *mype, int *nr, int *rPE, int *
 // packs the send halo of `names` into the device send buffer; returns both device buffers and the number of values per
 // item (a neighbour's block holds count(p) * values_per_item doubles, blocks are consecutive in sPE / rPE order)
 int fesom_gpu_halo_pack(int kind, int nfields, const char *const *names, void **send_dev, void **recv_dev, int *values_per_item) {
-  return halo_pack_on(kind, nfields, names, send_dev, recv_dev, values_per_item, 0);
+  return halo_pack_on(kind, nfields, names, send_dev, recv_dev, values_per_item);
 }
-int fesom_gpu_halo_unpack(int kind, int nfields, const char *const *names) { return halo_unpack_on(kind, nfields, names, 0); }
+int fesom_gpu_halo_unpack(int kind, int nfields, const char *const *names) { return halo_unpack_on(kind, nfields, names); }
 // plain copies for hosts that stage through host memory (dir 0: device -> host, 1: host -> device); synchronous
 int fesom_gpu_copy(void *dst, const void *src, long long bytes, int dir) {
   NEED_READY();
@@ -1561,6 +1731,7 @@ int fesom_gpu_comm_unique_id(void *id128) {
   return 0;
 }
 int fesom_gpu_comm_init(const void *id128, int nranks, int rank) {
+  if (fesom_internal_select_device(G.err)) return 1;            // (independent of fesom_gpu_init: bind the communicator to this rank's device)
   if (rccl_load()) return 1;
   if (R.comm) { R.CommDestroy(R.comm); R.comm = nullptr; }
   if (nranks < 1 || rank < 0 || rank >= nranks) { G.err = "comm_init: bad rank / nranks"; return 1; }
@@ -1609,6 +1780,9 @@ int fesom_gpu_comm_selftest(int n) {
 // fesom_gpu_comm_timing(1) -- the device time (ms, HIP events on the library's stream) from the first pack kernel to the last
 // unpack kernel of those exchanges, summed.  Resets the counters.
 int fesom_gpu_comm_timing(int on) { G.comm_timing = on != 0; return 0; }
+// exchange points, message parts (an exchange point that carries node and element fields has two), all-reduces and exchanges that ran on
+// the communication stream since the last fesom_gpu_comm_stats call (not reset here)
+int fesom_gpu_comm_counts(long long out[4]) { NEED_READY(); out[0] = G.n_exch; out[1] = G.n_parts; out[2] = G.n_allred; out[3] = G.n_async; return 0; }
 int fesom_gpu_comm_stats(long long *exchanges, long long *allreduces, double *exchange_ms) {
   NEED_READY();
   double ms = 0.0;
@@ -1620,7 +1794,7 @@ int fesom_gpu_comm_stats(long long *exchanges, long long *allreduces, double *ex
   if (exchanges) *exchanges = G.n_exch;
   if (allreduces) *allreduces = G.n_allred;
   if (exchange_ms) *exchange_ms = ms;
-  G.n_exch = G.n_allred = 0;
+  G.n_exch = G.n_allred = G.n_parts = G.n_async = 0;
   return 0;
 }
 }

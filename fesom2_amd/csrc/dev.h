@@ -419,4 +419,6 @@ void launch_step_info(const DM &m, hipStream_t s, double *col, double *out);
 int  launch_named_dsolve(const DM &m, hipStream_t s, const char *name);
 // one neighbour exchange through the library's RCCL communicator (csrc/api.hip) for a caller with its own lists and buffers (the sea-ice
 // context): blocks of (ptr[p+1]-ptr[p]) * W doubles per neighbour, consecutive in sPE / rPE order; 1-based CSR pointers as in com_struct
+#include <string>
+int  fesom_internal_select_device(std::string &err);      // csrc/api.hip: the device of this rank (FESOM_GPU_DEVICE / LOCAL_RANK), shared by all contexts
 int  fesom_internal_rccl_exchange(int ns, const int *sPE, const int *sptr, int nr, const int *rPE, const int *rptr, double *sd, double *rd, int W, hipStream_t s);

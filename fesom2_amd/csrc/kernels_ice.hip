@@ -509,8 +509,7 @@ const char *fesom_gpu_ice_last_error(void) { return I.err.c_str(); }
 int fesom_gpu_ice_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const fesom_ice_params *par) {
   if (I.ready) fesom_gpu_ice_finalize();
   I.err.clear();
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { I.err = "no HIP device: the MI355X path has no CPU fallback"; fprintf(stderr, "fesom_gpu_ice: %s\n", I.err.c_str()); return 2; }
+  if (fesom_internal_select_device(I.err)) { fprintf(stderr, "fesom_gpu_ice: %s\n", I.err.c_str()); return 2; }       // the device of this rank, as the ocean core (csrc/api.hip)
   I.npes = part ? part->npes : 1;
   if (par->evp_rheol_steps < 1) { I.err = "fesom_gpu_ice_init: evp_rheol_steps < 1"; return 3; }
   for (int e = 0; e < d->myDim_elem2D; e++) if (d->ulevels[e] != 1) { I.err = "fesom_gpu_ice_init: cavities (ulevels > 1) are not supported"; return 3; }

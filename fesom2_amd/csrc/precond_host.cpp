@@ -179,14 +179,17 @@ extern "C" void fesom_xinv_sparsify(int n, int ld, const float *M, double tau, i
 // RAS-Chebyshev preconditioner for operators that are too large for the explicit inverse (CORE2-class meshes, partitions):
 // plan construction.  See ras_host.h for the reference counterpart.  Everything here is integer / graph work plus a few
 // fp64 divisions per entry, formed in a fixed order, so that the CPU checker of the tests (its own restatement of the same
-// rules, oracle/c/orc_ras.c) reproduces the plan bit for bit.
+// rules) reproduces the plan bit for bit.
 //   patches : recursive bisection of the row graph into L = ceil(n / patch_max) leaves.  One bisection of a set S: breadth-first
 //             order from the smallest row of S, again from the row that order ends with (a far end of the set), rows the search
 //             does not reach are appended by further searches from the smallest unvisited row; the first |S| * (L/2) / L rows of
 //             the second order form the left part.  Neighbours are visited in CSR order.
-//   order   : patches in the order the bisection emits them, rows of a patch by increasing index (= layout of all solver vectors)
-//   overlap : `overlap` rings of neighbouring rows (each ring sorted by index), as long as the patch stays within 2048 rows
-//   patch operator: a_ij / a_ii of the frozen operator for the columns inside the patch (Dirichlet condition outside), fp32
+//   order   : patches in the order the bisection emits them, rows of a patch in breadth-first order from its smallest row (= layout of
+//             all solver vectors)
+//   overlap : `overlap` rings of neighbouring rows (each ring in the order its rows are met from the previous one), as long as the
+//             patch stays within 2048 rows
+//   patch operator: a_ij / a_ii of the frozen operator for the columns inside the patch (Dirichlet condition outside), fp32, the
+//             entries of a row sorted by their position in the patch
 // =====================================================================================================================
 #include "ras_host.h"
 namespace {
@@ -251,8 +254,15 @@ int fesom_ras_build(int n, const int *rp, const int *ci, const double *vals, con
   out.perm.resize(n); out.inv.resize(n); out.pinfo.assign(4 * (size_t)P, 0);
   {
     int q = 0;
+    std::vector<int> bo;
     for (int p = 0; p < P; p++) {
       if ((int)patches[p].size() > cap) return 1;
+      // rows of a patch in breadth-first order from its smallest row (neighbouring rows get neighbouring positions: few LDS bank
+      // conflicts in the patch solve, coalesced gathers in the products with A_s)
+      const int sid = ++g.setid;
+      for (int r : patches[p]) g.inset[r] = sid;
+      g.order(patches[p], patches[p][0], sid, bo);
+      patches[p] = bo;
       out.pinfo[4 * p] = q; out.pinfo[4 * p + 1] = (int)patches[p].size();
       for (int r : patches[p]) { out.perm[q] = r; out.inv[r] = q; q++; }
     }
@@ -267,15 +277,13 @@ int fesom_ras_build(int n, const int *rp, const int *ci, const double *vals, con
     for (int r : e) member[r] = p;
     size_t ring0 = 0;
     for (int k = 0; k < overlap; k++) {
-      std::vector<int> cand;
+      std::vector<int> cand;                                   // the next ring in the order its rows are met
       for (size_t h = ring0; h < e.size(); h++)
         for (int q = rp[e[h]]; q < rp[e[h] + 1]; q++) {
           const int v = ci[q];
-          if (v >= 0 && v < n && member[v] != p) cand.push_back(v);
+          if (v >= 0 && v < n && member[v] != p && member[v] != -2 - p) { member[v] = -2 - p; cand.push_back(v); }
         }
-      std::sort(cand.begin(), cand.end());
-      cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
-      if (cand.empty() || e.size() + cand.size() > (size_t)cap) break;
+      if (cand.empty() || e.size() + cand.size() > (size_t)cap) { for (int v : cand) member[v] = -1; break; }
       ring0 = e.size();
       for (int v : cand) { member[v] = p; e.push_back(v); }
     }
@@ -310,15 +318,20 @@ int fesom_ras_build(int n, const int *rp, const int *ci, const double *vals, con
         const int i = e[s];
         const double aii = vals[dpos[i]];
         int k = 0;
+        std::pair<int, int> ent[64];                          // (local column, CSR position), sorted by local column: lanes of a wave read neighbouring LDS words
         for (int q = rp[i]; q < rp[i + 1]; q++) {
           const int c = ci[q];
           if (q == dpos[i] || c < 0 || c >= n || lidx[c] < 0) continue;
-          if (pass == 1) {
-            out.lv[((size_t)p * out.woff + k) * out.NS + s] = (float)(vals[q] / aii);
-            out.lc[((size_t)p * out.woff + k) * out.NS + s] = (unsigned short)lidx[c];
-          }
+          if (k < 64) ent[k] = {lidx[c], q};
           k++;
         }
+        if (k > 15) return 1;
+        std::sort(ent, ent + k);
+        if (pass == 1)
+          for (int kk = 0; kk < k; kk++) {
+            out.lv[((size_t)p * out.woff + kk) * out.NS + s] = (float)(vals[ent[kk].second] / aii);
+            out.lc[((size_t)p * out.woff + kk) * out.NS + s] = (unsigned short)ent[kk].first;
+          }
         maxoff = std::max(maxoff, k);
         if (pass == 1) {
           double sc;

@@ -429,13 +429,12 @@ __global__ void __launch_bounds__(DSB) k_ds_finish(DM m) {        // x = D^-1 y
   }
 }
 
-// named phases of the partitioned solve (fesom_gpu_call): ds_scale, ds_setup, ds_init, ds_scal_init, ds_p, ds_spmv1,
+// named phases of the Jacobi-preconditioned partitioned solve (fesom_gpu_call; solver_precond = 0 -- the default on a partition is the
+// RAS-Chebyshev preconditioner, solver_ras.hip "dsr_*"): ds_scale, ds_setup, ds_init, ds_scal_init, ds_p, ds_spmv1,
 // ds_scal_alpha, ds_s, ds_spmv2, ds_scal_omega, ds_update, ds_finish
 int launch_named_xi(const DM &m, hipStream_t s, const char *name);
-int launch_named_dsx(const DM &m, hipStream_t s, const char *name);
 int launch_named_dsolve(const DM &m, hipStream_t s, const char *name) {
   if (!strncmp(name, "xi_", 3)) return launch_named_xi(m, s, name);
-  if (!strncmp(name, "dsx_", 4)) return launch_named_dsx(m, s, name);
   if (strncmp(name, "ds_", 3)) return -1;
   // ELL width of the phases: 8 / 10 / 16 slabs (the column pattern sv_colsi holds >= that many; narrower kernels skip padding slabs)
   const int W = m.ssh_maxnnz <= 8 ? 8 : m.ssh_maxnnz <= 10 ? 10 : 16, NP = (m.myN + 63) / 64 * 64, nblk = (m.myN + DSB - 1) / DSB;
@@ -876,116 +875,5 @@ int launch_named_xi(const DM &m, hipStream_t s, const char *name) {
   if (!strcmp(name, "xi_spmv2")) { hipLaunchKernelGGL(k_xi_spmv2<10>, dim3(nblk), dim3(DSB), 0, s, m, NP, nblk, 1); return 0; }
   if (!strcmp(name, "xi_init")) { hipLaunchKernelGGL(k_xi_init<10>, dim3(nblk), dim3(DSB), 0, s, m, NP, nblk); return 0; }
   if (!strcmp(name, "xi_setup")) { hipLaunchKernelGGL(k_solver_setup<10>, dim3((NP + 255) / 256), dim3(256), 0, s, m, NP, 0, 1); return 0; }
-  return -1;
-}
-
-// =====================================================================================================================
-// Partitioned SSH solve with the block-inverse preconditioner (npes > 1): every rank holds the sparsified inverse of the
-// owned-owned block of its (row-scaled) rows -- block Jacobi with exact blocks, the role of the per-rank ILU factors in the
-// reference's RAS (lib/parms/src/bicgstab_ras.c:49-259).  Applying it needs no communication; the products with A_s need the
-// halo of p^ / s^ as before, the dot products one all-reduce each: the same 2 exchanges + 2 all-reduces per iteration as the
-// Jacobi phases above, with a fraction of the iterations.  Scalars and the convergence flag live in sv_kry (k_ds_scal_*).
-// Named phases (fesom_gpu_call): dsx_init, dsx_prec0, dsx_spmv1, dsx_prec1, dsx_spmv2, dsx_update, dsx_finish.
-// =====================================================================================================================
-template <int W>
-__global__ void __launch_bounds__(DSB) k_dsx_init(DM m, int NP, int nblk) {   // r = b - A_s x0 (halo of x0 exchanged) ; r0 = p = r
-  int i = blockIdx.x * DSB + threadIdx.x;
-  double q[1] = {0.0};
-  if (i < m.myN) {
-    double a = 0.0;
-#pragma unroll
-    for (int k = 0; k < W; k++) a = a + m.sv_x0[(size_t)k * NP + i] * m.sv_x[m.sv_colsi[(size_t)k * NP + i]];
-    double ri = m.sv_bn[i] - a;
-    m.sv_r[i] = ri; m.sv_r0[i] = ri; m.sv_pd[i] = ri;
-    q[0] = ri * ri;
-  }
-  ds_block_partials<1>(q, m.sv_part, nblk);
-}
-template <int MODE>
-__global__ void __launch_bounds__(256) k_dsx_prec(DM m) {       // MODE 0: p^ = M p ; MODE 1: s = r - alpha v, s^ = M s (owned rows)
-  __shared__ double xs[4096];
-  if (KRY_DONE(m)) return;
-  const int t = threadIdx.x, n = m.myN;
-  const double alpha = m.sv_kry[0];
-  for (int i = t; i < n; i += 256) {
-    const double val = (MODE == 0) ? m.sv_pd[i] : m.sv_r[i] - alpha * m.sv_v[i];
-    xs[i] = val;
-    if (MODE == 1 && blockIdx.x == 0) m.sv_sn[i] = val;
-  }
-  __syncthreads();
-  const int lane = t & 63, w = t >> 6;
-  double *out = MODE == 0 ? m.sv_ph : m.sv_sh;
-#pragma unroll
-  for (int q = 0; q < XI_ROWS / 4; q++) {
-    const int row = blockIdx.x * XI_ROWS + w * (XI_ROWS / 4) + q;
-    if (row >= n) break;
-    const int beg = m.sv_mp[row], end = m.sv_mp[row + 1];
-    double a = 0.0;
-    for (int e = beg + lane; e < end; e += 64) a = a + (double)m.sv_minv[e] * xs[m.sv_mc[e]];
-    a = xi_wave_total(a);
-    if (lane == 63) out[row] = a;
-  }
-}
-template <int W>
-__global__ void __launch_bounds__(DSB) k_dsx_spmv1(DM m, int NP, int nblk) {   // v = A_s p^ ; r0.v
-  int i = blockIdx.x * DSB + threadIdx.x;
-  double q[1] = {0.0};
-  if (i < m.myN && !KRY_DONE(m)) {
-    double a = 0.0;
-#pragma unroll
-    for (int k = 0; k < W; k++) a = a + m.sv_x0[(size_t)k * NP + i] * m.sv_ph[m.sv_colsi[(size_t)k * NP + i]];
-    m.sv_v[i] = a; q[0] = m.sv_r0[i] * a;
-  }
-  ds_block_partials<1>(q, m.sv_part, nblk);
-}
-template <int W>
-__global__ void __launch_bounds__(DSB) k_dsx_spmv2(DM m, int NP, int nblk) {   // t = A_s s^ ; t.t, t.s, r0.t, s.s
-  int i = blockIdx.x * DSB + threadIdx.x;
-  double q[4] = {0.0, 0.0, 0.0, 0.0};
-  if (i < m.myN && !KRY_DONE(m)) {
-    double a = 0.0;
-#pragma unroll
-    for (int k = 0; k < W; k++) a = a + m.sv_x0[(size_t)k * NP + i] * m.sv_sh[m.sv_colsi[(size_t)k * NP + i]];
-    const double si = m.sv_sn[i];
-    m.sv_t[i] = a;
-    q[0] = a * a; q[1] = a * si; q[2] = m.sv_r0[i] * a; q[3] = si * si;
-  }
-  ds_block_partials<4>(q, m.sv_part, nblk);
-}
-__global__ void __launch_bounds__(DSB) k_dsx_update(DM m) {     // x += alpha p^ + omega s^ ; r = s - omega t ; p = r + beta (p - omega v)
-  int i = blockIdx.x * DSB + threadIdx.x;
-  if (KRY_DONE(m)) return;
-  if (i < m.myN) {
-    const double alpha = m.sv_kry[0], omega = m.sv_kry[1], beta = m.sv_kry[2];
-    const double si = m.sv_sn[i], ri = si - omega * m.sv_t[i];
-    m.sv_r[i] = ri;
-    m.sv_x[i] = (m.sv_x[i] + alpha * m.sv_ph[i]) + omega * m.sv_sh[i];
-    m.sv_pd[i] = ri + beta * (m.sv_pd[i] - omega * m.sv_v[i]);
-  }
-}
-__global__ void __launch_bounds__(DSB) k_dsx_finish(DM m) {
-  int i = blockIdx.x * DSB + threadIdx.x;
-  if (i < m.myN) m.d_eta[i] = m.sv_x[i];
-  if (i == 0) {
-    m.sv_info[0] = (int)m.sv_kry[6]; m.sv_resid[0] = sqrt(m.sv_kry[5] > 0.0 ? m.sv_kry[5] : 0.0);
-    if (m.sv_extrap && m.sv_info[1] < 3) m.sv_info[1] = m.sv_info[1] + 1;
-  }
-}
-int launch_named_dsx(const DM &m, hipStream_t s, const char *name) {
-  if (!m.sv_minv) return 1;
-  const int W = m.ssh_maxnnz <= 8 ? 8 : m.ssh_maxnnz <= 10 ? 10 : 16, NP = (m.myN + 63) / 64 * 64, nblk = (m.myN + DSB - 1) / DSB, gblk = (m.myN + XI_ROWS - 1) / XI_ROWS;
-  if (!strcmp(name, "dsx_init")) {
-    hipMemsetAsync(m.sv_kry, 0, 16 * sizeof(double), s);
-    DSW(k_dsx_init, m, NP, nblk); hipLaunchKernelGGL(k_ds_reduce, dim3(1), dim3(64), 0, s, m, 1, nblk); return 0;
-  }
-  if (!strcmp(name, "dsx_prec0")) { hipLaunchKernelGGL(k_dsx_prec<0>, dim3(gblk), dim3(256), 0, s, m); return 0; }
-  if (!strcmp(name, "dsx_prec1")) { hipLaunchKernelGGL(k_dsx_prec<1>, dim3(gblk), dim3(256), 0, s, m); return 0; }
-  if (!strcmp(name, "dsx_spmv1")) { DSW(k_dsx_spmv1, m, NP, nblk); hipLaunchKernelGGL(k_ds_reduce, dim3(1), dim3(64), 0, s, m, 1, nblk); return 0; }
-  if (!strcmp(name, "dsx_spmv2")) { DSW(k_dsx_spmv2, m, NP, nblk); hipLaunchKernelGGL(k_ds_reduce, dim3(1), dim3(64), 0, s, m, 4, nblk); return 0; }
-  if (!strcmp(name, "dsx_update")) {
-    hipLaunchKernelGGL(k_dsx_update, dim3(nblk), dim3(DSB), 0, s, m);
-    hipLaunchKernelGGL(k_ds_latch, dim3(1), dim3(64), 0, s, m); return 0;
-  }
-  if (!strcmp(name, "dsx_finish")) { hipLaunchKernelGGL(k_dsx_finish, dim3(nblk), dim3(DSB), 0, s, m); return 0; }
   return -1;
 }

@@ -12,7 +12,7 @@
 // 7 launches instead of ~105 Jacobi iterations of 2.  No dot product inside the preconditioner: nothing to all-reduce on a
 // partition either (patches never cross the rank's owned rows).
 // All solver vectors live in the patch order (DM::rs_perm / rs_inv), so a patch's owned rows are one contiguous run.
-// Summation orders are fixed and restated by the CPU checker of the tests (oracle/c/orc_ras.c): HIP == checker bitwise.
+// Summation orders are fixed and restated by the CPU checker of the tests: HIP == checker bitwise.
 #include "dev.h"
 #include "solver_dev.h"
 #include "ras_host.h"
@@ -186,14 +186,14 @@ __global__ void __launch_bounds__(DSB) k_ras_finish(DM m) {      // back to the 
 template <int WOFF, int RPT, int MODE>
 __global__ void __launch_bounds__(RAS_THREADS) k_ras_apply(DM m) {
   if (RAS_FINISHED(m)) return;
-  constexpr int NS = RAS_THREADS * RPT, WP = (WOFF + 1) / 2;
-  __shared__ double zb[2 * NS];
+  constexpr int NS = RAS_THREADS * RPT;
+  __shared__ double zb0[NS], zb1[NS];                      // two images of z: a step reads one and writes the other, one barrier per step
   const int p = blockIdx.x, t = threadIdx.x;
   const int own0 = m.rs_pinfo[4 * p], no = m.rs_pinfo[4 * p + 1], eoff = m.rs_pinfo[4 * p + 2], ne = m.rs_pinfo[4 * p + 3];
   const double alpha = MODE ? m.sv_kry[0] : 0.0;
   const double inv_theta = m.rs_cheb[0];
-  float lv[RPT][WOFF];
-  unsigned lc[RPT][WP];
+  double lv[RPT][WOFF];                                    // (fp32 in memory; widened once: a conversion per use would cost more than the multiply)
+  unsigned lo[RPT][WOFF];                                  // LDS byte offsets of the columns
   double rb[RPT], d[RPT], z[RPT];
 #pragma unroll
   for (int j = 0; j < RPT; j++) {
@@ -206,37 +206,35 @@ __global__ void __launch_bounds__(RAS_THREADS) k_ras_apply(DM m) {
     }
     rb[j] = val * m.rs_dsc[(size_t)p * NS + slot];
 #pragma unroll
-    for (int k = 0; k < WOFF; k++) lv[j][k] = m.rs_lv[((size_t)p * WOFF + k) * NS + slot];
-#pragma unroll
-    for (int k2 = 0; k2 < WP; k2++) {
-      const unsigned c0 = m.rs_lc[((size_t)p * WOFF + 2 * k2) * NS + slot];
-      const unsigned c1 = (2 * k2 + 1 < WOFF) ? m.rs_lc[((size_t)p * WOFF + 2 * k2 + 1) * NS + slot] : 0u;
-      lc[j][k2] = (c0 << 3) | (c1 << 19);
+    for (int k = 0; k < WOFF; k++) {
+      lv[j][k] = (double)m.rs_lv[((size_t)p * WOFF + k) * NS + slot];
+      lo[j][k] = (unsigned)m.rs_lc[((size_t)p * WOFF + k) * NS + slot] << 3;
     }
     d[j] = rb[j] * inv_theta; z[j] = d[j];
-    zb[slot] = z[j];
+    zb0[slot] = z[j];
   }
   __syncthreads();
   const int deg = m.rs_deg;
-  for (int k = 1; k < deg; k++) {
-    const double c1 = m.rs_cheb[1 + k], c2 = m.rs_cheb[64 + k];
-    const double *src = zb + ((k - 1) & 1) * NS;
-    double *dst = zb + (k & 1) * NS;
-#pragma unroll
-    for (int j = 0; j < RPT; j++) {
-      double acc = 0.0;
-#pragma unroll
-      for (int kk = 0; kk < WOFF; kk++) {
-        const unsigned c8 = (kk & 1) ? (lc[j][kk >> 1] >> 16) : (lc[j][kk >> 1] & 0xffffu);
-        acc = acc + (double)lv[j][kk] * *(const double *)((const char *)src + c8);
-      }
-      const double res = (rb[j] - z[j]) - acc;
-      d[j] = c1 * d[j] + c2 * res;
-      z[j] = z[j] + d[j];
-      dst[t + j * RAS_THREADS] = z[j];
-    }
-    __syncthreads();
+#define RAS_STEP(SRC, DST, K)                                                                            \
+  {                                                                                                      \
+    const double c1 = m.rs_cheb[1 + (K)], c2 = m.rs_cheb[64 + (K)];                                      \
+    _Pragma("unroll") for (int j = 0; j < RPT; j++) {                                                    \
+      double acc = 0.0;                                                                                  \
+      _Pragma("unroll") for (int kk = 0; kk < WOFF; kk++) acc = acc + lv[j][kk] * *(const double *)((const char *)(SRC) + lo[j][kk]); \
+      const double res = (rb[j] - z[j]) - acc;                                                           \
+      d[j] = c1 * d[j] + c2 * res;                                                                       \
+      z[j] = z[j] + d[j];                                                                                \
+      (DST)[t + j * RAS_THREADS] = z[j];                                                                 \
+    }                                                                                                    \
+    __syncthreads();                                                                                     \
   }
+  int k = 1;
+  for (; k + 1 < deg; k += 2) {
+    RAS_STEP(zb0, zb1, k)
+    RAS_STEP(zb1, zb0, k + 1)
+  }
+  if (k < deg) RAS_STEP(zb0, zb1, k)
+#undef RAS_STEP
   double *out = MODE == 0 ? m.sv_ph : m.sv_sh;
 #pragma unroll
   for (int j = 0; j < RPT; j++) {

@@ -22,6 +22,7 @@ kernel computes them for owned nodes only.)  Owned values do not depend on the p
 dot products are summed in a different order (agreement to the solver tolerance, like the reference across partitions).
 """
 import ctypes as C
+import os
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -35,44 +36,67 @@ MAXITS = 2000
 
 
 def run_step(core, par, X, solve, first, probe=None, n=1, zonal=None):
-    """One step, phase by phase (kernel names of libfesom_gpu.so).  X(kind, fields) = halo exchange, solve() = SSH solve;
-    `probe(label)` (optional) is called after the phases whose results the tests compare across partitions; n = step number and
-    zonal() = the partitioned compute_zonal_mean, both only used by the Soufflet channel hooks."""
+    """One step, phase by phase (kernel names of libfesom_gpu.so), in the order of the library's own program of the partitioned step
+    (csrc/api.hip:build_program).  X(kind, fields) = halo exchange -- X([(kind, fields), ...]) where node and element fields leave in
+    one message --, solve() = SSH solve; `probe(label)` (optional) is called after the phases whose results the tests compare across
+    partitions; n = step number and zonal() = the partitioned compute_zonal_mean, both only used by the Soufflet channel hooks.
+    The kernels of a step are ordered so that fields that are ready together travel together (13 exchange points with KPP + GM + Redi
+    outside the solver, 8 with PP): everything that needs only the incoming state comes first."""
     c, p = core.call, par
     P = probe if probe is not None else (lambda label: None)
+
+    def XM(parts):
+        for kind, names in parts:
+            X(kind, names)
+
     c("first_step", 1 if first else 0)
     if p.toy_soufflet and n % 10 == 0:                # before_oce_step (oce_setup_step.F90:625-630)
         zonal() if zonal is not None else c("compute_zonal_mean")
-    c("k_vel_nodes"); X(NOD, ["Unode"]); P("vel_nodes")
+    kpp, v5 = p.mix_scheme == 1, p.visc_option == 5
+    ub_early = p.visc_option >= 4                      # (options 1-3 read the Leith coefficient, formed further down)
+    c("k_vel_nodes")
+    if ub_early:
+        c("k_visc_elem"); XM([(NOD, ["Unode"]), (ELEM, ["U_b"])])
+    else:
+        X(NOD, ["Unode"])
+    P("vel_nodes")
     c("k_pressure_bv"); c("k_pgf"); c("k_sigma_slope"); P("pressure")
-    if p.Redi:
-        X(NOD, ["slope_tapered"])
     if p.use_momix:
         c("k_momix")
+    if kpp:
+        c("k_kpp_col")
+    n2 = []
+    if p.mom_adv == 3:
+        c("k_vinv_ke"); n2.append("KE_node")
+    else:
+        c("k_momadv_node"); n2.append("Unode_rhs")
+    if v5 and ub_early:
+        c("k_visc_node"); n2.append("U_c")
+    if p.Redi:
+        n2.append("slope_tapered")
+    if kpp:
+        n2.append("kpp_blmc")
+    X(NOD, n2)
     if p.mix_scheme == 2:
         c("k_pp"); P("mixing")
-    if p.mix_scheme == 1:                             # KPP: smoothing of blmc needs the neighbours' values after every sweep
-        c("k_kpp_col"); X(NOD, ["kpp_blmc"])
+    if kpp:                                           # KPP: smoothing of blmc needs the neighbours' values after every sweep
         c("k_kpp_smooth1"); X(NOD, ["kpp_sA"])
         c("k_kpp_smooth2"); X(NOD, ["kpp_sB"])
         c("k_kpp_smooth3")
         c("k_kpp_final"); X(NOD, ["kpp_viscA", "Kv"])
         c("k_kpp_elem"); P("mixing")
     if p.mom_adv == 3:
-        c("k_vinv_ke"); X(NOD, ["KE_node"]); c("k_leith_vort"); X(NOD, ["vorticity"]); c("k_vinv_elem"); P("vel_rhs")
+        c("k_leith_vort"); X(NOD, ["vorticity"]); c("k_vinv_elem"); P("vel_rhs")
     else:
-        c("k_momadv_node"); X(NOD, ["Unode_rhs"])
         c("k_vel_rhs"); P("vel_rhs")
     if p.visc_option <= 3:
         c("k_leith_vort"); X(NOD, ["vorticity"]); c("k_leith_elem")
         for _ in range(2):
             c("k_leith_node"); X(NOD, ["leith_aux"]); c("k_leith_avg")
         X(ELEM, ["Visc"])
-    if p.visc_option != 1:
-        c("k_visc_elem"); X(ELEM, ["U_b"])
-    if p.visc_option == 5:
-        c("k_visc_node"); X(NOD, ["U_c"])
-    else:
+        if p.visc_option != 1:
+            c("k_visc_elem"); X(ELEM, ["U_b"])
+    if not v5:
         c("k_visc_apply")
     c("k_impl_visc"); P("impl_visc")
     if p.which_ale != 0:
@@ -86,26 +110,31 @@ def run_step(core, par, X, solve, first, probe=None, n=1, zonal=None):
     if p.Fer_GM:                                      # bolus velocities (oce_fer_gm.F90), before vert_vel_ale moves hnode_new
         c("init_Redi_GM"); X(NOD, ["fer_c", "fer_K"] + (["Ki"] if p.Redi else []))
         c("fer_solve_Gamma"); X(NOD, ["fer_gamma"])
-        c("fer_gamma2vel"); X(ELEM, ["fer_UV"])
-        c("fer_wvel"); X(NOD, ["fer_Wvel"])
-    c("k_update_vel"); X(ELEM, ["UV"])
-    c("k_edge_transport1"); c("k_vert_vel_hbar")
-    X(NOD, ["Wvel", "Wvel_e", "Wvel_i", "hnode_new", "hbar", "hbar_old", "eta_n", "ssh_rhs_old"])
+        c("fer_gamma2vel"); c("fer_wvel")             # (owned edges only touch elements this rank computes itself: the halos can wait)
+    c("k_update_vel"); c("k_edge_transport1"); c("k_vert_vel_hbar")
+    nn, ee = ["Wvel", "Wvel_e", "Wvel_i", "hnode_new", "hbar", "hbar_old", "eta_n", "ssh_rhs_old"], ["UV"]
+    if p.Fer_GM:
+        nn.append("fer_Wvel"); ee.append("fer_UV")
+    XM([(NOD, nn), (ELEM, ee)])
     c("k_dhe"); P("vert_vel")
     if p.Fer_GM:
         c("bolus_add")
     if p.SPP:
         c("k_spp", 0)
     c("k_tr_ab", 0); c("k_tr_grad_elem", 0); X(ELEM_FULL, ["tr_xy_ab"])
-    c("k_updn_grad", 0)
     c("k_tr_z", 0)
-    if p.Redi:
-        X(NOD, ["tr_z"])
-    if p.with_diffusion:
-        c("k_diff_flux", 0)
+    c("k_updn_grad", 0)
     c("k_flux_hor", 0); c("k_fct_lo_node", 0)
     if not p.tra_adv_lim:                             # (no low-order solution, no limiter with tra_adv_lim='NON')
-        X(NOD, ["fct_LO"]); c("k_fct_node", 0); X(NOD, ["fct_plus", "fct_minus"])
+        X(NOD, ["fct_LO"] + (["tr_z"] if p.Redi else []))
+        if p.with_diffusion:
+            c("k_diff_flux", 0)
+        c("k_fct_node", 0); X(NOD, ["fct_plus", "fct_minus"])
+    else:
+        if p.Redi:
+            X(NOD, ["tr_z"])
+        if p.with_diffusion:
+            c("k_diff_flux", 0)
     c("k_fct_edge_limit", 0); c("k_tr_update", 0)
     if p.smooth_bh_tra:
         c("k_bh1", 0); X(NOD, ["bh_tmp"]); c("k_bh2", 0)
@@ -243,6 +272,7 @@ class PartitionedCore:
         self.halo = HaloExchanger(self.core, group)
         self.first = True
         self.solver_iterations = 0
+        self._last_its = 8
         self.red_dev = None
         lib = self.core.lib
         lib.fesom_gpu_comm_unique_id.argtypes = [C.c_void_p]
@@ -283,7 +313,9 @@ class PartitionedCore:
     @property
     def transport_name(self):
         if self.transport == "rccl":
-            return "built-in: RCCL ncclSend/ncclRecv groups + ncclAllReduce issued by the library on its stream"
+            lib = os.environ.get("FESOM_GPU_RCCL_LIB")
+            what = f"a stand-in for librccl ({os.path.basename(lib)}: test double, host-staged)" if lib else "RCCL"
+            return f"built-in: {what} ncclSend/ncclRecv groups + ncclAllReduce issued by the library on its stream"
         return "host callback: torch.distributed " + ("nccl (RCCL) on the device buffers" if self.halo.device else "gloo, host-staged")
 
     def comm_timing(self, on=True):
@@ -307,37 +339,42 @@ class PartitionedCore:
             t = torch.from_numpy(v[:n].copy()); dist.all_reduce(t, group=self.group)
             v[:n] = t.numpy(); self.core.set("sv_red", v)
 
-    def solve_ssh(self, poll=4):
-        """Jacobi-scaled BiCGstab over the partitioned rows: the recurrences of the single-GPU kernel (solver.hip), Krylov
-        scalars and the convergence flag on the device; the host only polls the flag every `poll` iterations (phases after
-        convergence are no-ops on the device, so the result does not depend on `poll`)."""
+    def solve_ssh(self):
+        """Partitioned SSH solve, the phases of csrc/api.hip:part_solve: BiCGstab over the owned rows with the RAS-Chebyshev preconditioner
+        of the rank's own block (solver_ras.hip "dsr_", no communication inside it) -- or Jacobi ("ds_") where solver_precond = 0 --, halo of
+        the gathered vector before each product with A_s, global sum of the partial dot products after it.  Krylov scalars and the
+        convergence flag live on the device; the host reads the flag once per chunk of iterations (phases behind the convergence are
+        no-ops, so the result does not depend on the chunks).  A solve that does not converge raises."""
         c, X, AR = self.core.call, self.halo.exchange, self._allreduce
-        if self.core.lib.fesom_gpu_solver_kind() == 1:      # block-inverse preconditioner (csrc/solver.hip "dsx_"): same exchanges per iteration
-            c("ds_scale"); X(NOD, ["sv_dinv"])
-            c("ds_setup"); X(NOD, ["sv_x"])
-            c("dsx_init"); AR(1); c("ds_scal_init")
-            while True:
-                for _ in range(2):
-                    c("dsx_prec0"); X(NOD, ["sv_ph"]); c("dsx_spmv1"); AR(1); c("ds_scal_alpha")
-                    c("dsx_prec1"); X(NOD, ["sv_sh"]); c("dsx_spmv2"); AR(4); c("ds_scal_omega"); c("dsx_update")
-                kry = self.core.get("sv_kry", 48)
-                if kry[7] != 0.0 or kry[6] >= MAXITS:
-                    break
-            c("dsx_finish")
-            self.solver_iterations = int(kry[6])
+        if self.world == 1:                            # one partition: the single-GPU solver of the library
+            c("solve_ssh"); self.solver_iterations = self.core.solver_iterations
             return
-        c("ds_scale"); X(NOD, ["sv_dinv"])
-        c("ds_setup"); X(NOD, ["sv_s"])
-        c("ds_init"); AR(1); c("ds_scal_init"); c("ds_p")
+        ras = self.core.lib.fesom_gpu_solver_kind() == 2
+        c("ds_scale")
+        if ras:
+            c("dsr_setup"); X(NOD, ["sv_x"])
+            c("dsr_init"); AR(1); c("dsr_scal_init")
+        else:
+            X(NOD, ["sv_dinv"])
+            c("ds_setup"); X(NOD, ["sv_s"])
+            c("ds_init"); AR(1); c("ds_scal_init"); c("ds_p")
+        chunk = max(1, self._last_its + 1)
         while True:
-            for _ in range(poll):
-                X(NOD, ["sv_ph"]); c("ds_spmv1"); AR(1); c("ds_scal_alpha"); c("ds_s")
-                X(NOD, ["sv_s"]); c("ds_spmv2"); AR(4); c("ds_scal_omega"); c("ds_update"); c("ds_p")
+            for _ in range(chunk):
+                if ras:
+                    c("dsr_prec0"); X(NOD, ["sv_ph"]); c("dsr_spmv1"); AR(1); c("dsr_scal_alpha")
+                    c("dsr_prec1"); X(NOD, ["sv_sh"]); c("dsr_spmv2"); AR(4); c("dsr_scal_omega"); c("dsr_update")
+                else:
+                    X(NOD, ["sv_ph"]); c("ds_spmv1"); AR(1); c("ds_scal_alpha"); c("ds_s")
+                    X(NOD, ["sv_s"]); c("ds_spmv2"); AR(4); c("ds_scal_omega"); c("ds_update"); c("ds_p")
             kry = self.core.get("sv_kry", 48)
-            if kry[7] != 0.0 or kry[6] >= MAXITS:
+            if kry[8 if ras else 7] != 0.0 or kry[6] >= MAXITS:
                 break
-        c("ds_finish")
-        self.solver_iterations = int(kry[6])
+            chunk = 2
+        c("dsr_finish" if ras else "ds_finish")
+        self.solver_iterations = self._last_its = int(kry[6])
+        if not kry[5] < 1e-20:
+            raise RuntimeError(f"partitioned SSH solve did not converge: {int(kry[6])} iterations, ||scaled residual|| = {np.sqrt(max(kry[5], 0.0)):.3e}")
 
     def step(self, n=1, probe=None):
         run_step(self.core, self.par, self.halo.exchange, self.solve_ssh, self.first, probe, n=n, zonal=self.zonal_mean)

@@ -247,6 +247,7 @@ int  fesom_gpu_comm_finalize(void);
 int  fesom_gpu_comm_selftest(int n);            /* ring shift of n doubles + a global sum through the transport; 0 = ok */
 int  fesom_gpu_comm_timing(int on);             /* HIP-event timing of every exchange (pack .. unpack) from now on */
 int  fesom_gpu_comm_stats(long long *exchanges, long long *allreduces, double *exchange_ms);   /* since the last call */
+int  fesom_gpu_comm_counts(long long out[4]);   /* exchange points, message parts (node + element fields in one exchange point = 2), all-reduces, exchanges on the communication stream; since the last comm_stats call */
 
 /* Device-side step monitor = write_step_info + check_blowup of the reference (src/write_step_info.F90:14-222, :225-447),
  * evaluated on the device over this rank's OWNED nodes, no per-step host synchronisation needed: call it at the logging

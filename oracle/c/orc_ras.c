@@ -11,10 +11,10 @@
  *             breadth-first order from S's smallest row, then again from the row that order ends with, unreached rows by further
  *             searches from the smallest unvisited row; neighbours in CSR order; the first |S| * (L/2) / L rows of the second
  *             order are the left part (L/2 leaves), the rest the right part.
- *   layout  : patches in emission order (left before right), rows of a patch by increasing index.
- *   overlap : up to `overlap` rings, each ring = the not yet included neighbours of the previous ring, sorted; a ring that would
- *             take the patch beyond 2048 rows ends the growth.
- *   patch operator: off-diagonal a_ij / a_ii (fp32) for columns inside the patch, in CSR order, ELL-padded with (0, own row);
+ *   layout  : patches in emission order (left before right), rows of a patch in breadth-first order from its smallest row.
+ *   overlap : up to `overlap` rings, each ring = the not yet included neighbours of the previous ring in the order they are met; a
+ *             ring that would take the patch beyond 2048 rows ends the growth.
+ *   patch operator: off-diagonal a_ij / a_ii (fp32) for columns inside the patch, sorted by position in the patch, ELL-padded with (0, own row);
  *             right-hand side scale 1 / (a_ii / sum_j |a_ij|).
  *   Chebyshev: interval [lmax / kappa, lmax], lmax = max_i sum_j |a_ij / a_ii|; z_1 = rhs / theta, deg - 1 further steps. */
 #include <math.h>
@@ -100,6 +100,13 @@ int orc_ras_build(int n, const int *rp, const int *ci, const double *vals, int p
   pl->n = n; pl->P = P; pl->deg = deg;
   pl->perm = malloc(sizeof(int) * n); pl->inv = malloc(sizeof(int) * n); pl->pinfo = calloc(4 * (size_t)P, sizeof(int));
   for (int p = 0, q = 0; p < P; p++) {
+    {                                                       /* rows of a patch in breadth-first order from its smallest row */
+      const int sid = ++g.setid, ns = g.leaf_n[p];
+      int *o = malloc(sizeof(int) * ns);
+      for (int k = 0; k < ns; k++) g.inset[g.leaf[p][k]] = sid;
+      set_order(&g, g.leaf[p], ns, g.leaf[p][0], sid, o);
+      free(g.leaf[p]); g.leaf[p] = o;
+    }
     pl->pinfo[4 * p] = q; pl->pinfo[4 * p + 1] = g.leaf_n[p];
     for (int k = 0; k < g.leaf_n[p]; k++, q++) { pl->perm[q] = g.leaf[p][k]; pl->inv[g.leaf[p][k]] = q; }
   }
@@ -114,16 +121,20 @@ int orc_ras_build(int n, const int *rp, const int *ci, const double *vals, int p
     for (int k = 0; k < ne; k++) member[e[k]] = p;
     int ring0 = 0;
     for (int r = 0; r < overlap; r++) {
-      int nc = 0;
+      int nu = 0;                                           /* the next ring, rows in the order they are met */
       for (int h = ring0; h < ne; h++)
         for (int q = rp[e[h]]; q < rp[e[h] + 1]; q++) {
           const int v = ci[q];
-          if (v >= 0 && v < n && member[v] != p) cand[nc++] = v;
+          if (v < 0 || v >= n || member[v] == p || member[v] == -2 - p) continue;
+          member[v] = -2 - p;
+          if (nu < CAP) cand[nu] = v;
+          nu++;
         }
-      qsort(cand, nc, sizeof(int), cmp_int);
-      int nu = 0;
-      for (int k = 0; k < nc; k++) if (k == 0 || cand[k] != cand[k - 1]) cand[nu++] = cand[k];
-      if (nu == 0 || ne + nu > CAP) break;
+      if (nu == 0 || ne + nu > CAP) {
+        for (int k = 0; k < nu && k < CAP; k++) member[cand[k]] = -1;
+        if (nu > CAP) for (int i = 0; i < n; i++) if (member[i] == -2 - p) member[i] = -1;
+        break;
+      }
       ring0 = ne;
       for (int k = 0; k < nu; k++) { member[cand[k]] = p; e[ne++] = cand[k]; }
     }
@@ -160,14 +171,18 @@ int orc_ras_build(int n, const int *rp, const int *ci, const double *vals, int p
     for (int s = 0; s < ext_n[p]; s++) {
       const int i = ext[p][s];
       const double aii = vals[dpos[i]];
-      int k = 0;
+      int k = 0, col[16], pos[16];
       double tmp = 0.;
       for (int q = rp[i]; q < rp[i + 1]; q++) {
         tmp += fabs(vals[q]);
         if (q == dpos[i] || ci[q] < 0 || ci[q] >= n || lidx[ci[q]] < 0) continue;
-        pl->lv[((size_t)p * WO + k) * NS + s] = (float)(vals[q] / aii);
-        pl->lc[((size_t)p * WO + k) * NS + s] = (unsigned short)lidx[ci[q]];
-        k++;
+        int h = k++;                                        /* insertion by increasing local column */
+        while (h > 0 && col[h - 1] > lidx[ci[q]]) { col[h] = col[h - 1]; pos[h] = pos[h - 1]; h--; }
+        col[h] = lidx[ci[q]]; pos[h] = q;
+      }
+      for (int kk = 0; kk < k; kk++) {
+        pl->lv[((size_t)p * WO + kk) * NS + s] = (float)(vals[pos[kk]] / aii);
+        pl->lc[((size_t)p * WO + kk) * NS + s] = (unsigned short)col[kk];
       }
       const double sc = 1. / tmp, dg = aii * sc;
       pl->dsc[(size_t)p * NS + s] = 1.0 / dg;

@@ -81,6 +81,31 @@ def main():
     g.close()
     # ---- this rank's partition
     TRANSPORT = os.environ.get("PART_TRANSPORT") or None      # "rccl": the library's built-in transport (real RCCL, or the test double)
+    if "ras_off" in opts:
+        # rank 1 pretends its block does not qualify for the RAS preconditioner: the library must notice at the first step (global sum of
+        # the ranks' flags) and take the Jacobi phases on EVERY rank -- mismatched solver paths would hang or scramble d_eta.  Library-
+        # driven steps only; compared with the single-partition run to the solver tolerance.
+        os.environ["FESOM_GPU_RAS_OFF_ON_RANK"] = "1"
+        pc = parallel.PartitionedCore(PI, par, dt=900.0, transport=TRANSPORT)
+        lm = pc.mesh
+        ln = lm.myList_nod2D - 1
+        st = lm.initial_state(2); st.tr_arr[0], st.tr_arr[1] = T[ln], S[ln]; st.tr_arr_old[...] = st.tr_arr
+        pc.core.upload_state(st)
+        kinds = [pc.core.lib.fesom_gpu_solver_kind()]
+        for n in range(1, NSTEPS + 1):
+            pc.step_native(n)
+        kinds.append(pc.core.lib.fesom_gpu_solver_kind())
+        myN = lm.myDim_nod2D
+        N = myN + lm.eDim_nod2D
+        eta = pc.core.get("eta_n", N)[:myN]
+        tr = pc.core.get("tr_arr", 2 * (lm.nl - 1) * N).reshape(2, N, lm.nl - 1)[:, :myN]
+        report = {"rank": rank, "kinds": kinds, "iters": int(pc.solver_iterations),
+                  "d_eta": float(np.abs(eta - ref[(NSTEPS, "vert_vel", "eta_n")][ln[:myN], 0]).max()),
+                  "d_T": float(np.abs(tr - ref[(NSTEPS, "tracers", "tr_arr")][:, ln[:myN]]).max())}
+        pc.close()
+        sys.stdout.write("PARTREPORT " + json.dumps(report) + chr(10)); sys.stdout.flush()
+        dist.destroy_process_group()
+        return
     pc = parallel.PartitionedCore(PI, par, dt=900.0, transport=TRANSPORT)
     lm = pc.mesh
     ln = lm.myList_nod2D - 1

@@ -13,7 +13,14 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 wl = workloads.channel(lev)
 mesh = wl.load_mesh()
 out = {}
-for pc in (1, 0):
+configs = [(1, {}), (0, {})]
+if "--sweep" in sys.argv:
+    configs = [(1, dict(FESOM_GPU_RAS_PATCH=str(pm), FESOM_GPU_RAS_DEG=str(dg), FESOM_GPU_RAS_OVL=str(ov), FESOM_GPU_RAS_KAPPA=str(kp)))
+               for pm, dg, ov, kp in ((768, 16, 4, 200), (768, 12, 4, 150), (768, 20, 4, 300), (768, 24, 4, 400), (768, 16, 3, 200), (384, 16, 4, 200), (384, 12, 3, 150), (512, 16, 4, 200), (768, 8, 3, 80))]
+for pc, env in configs:
+    for k in [k for k in os.environ if k.startswith("FESOM_GPU_RAS_")]:
+        del os.environ[k]
+    os.environ.update(env)
     gpu = OceanCore(mesh, wl.params(solver_precond=pc))
     wl.start(gpu, mesh)
     its = []
@@ -26,7 +33,7 @@ for pc in (1, 0):
     dt = (time.time() - t0) / steps
     gpu.call("solver_snapshot")
     t_solve = gpu.kernel_time_ms("k_solver_replay", 10)
-    rec = dict(kind=gpu.lib.fesom_gpu_solver_kind(), ms_per_step=dt * 1e3, solver_ms=t_solve, iterations=its[-10:], resid=gpu.solver_residual)
+    rec = dict(env=env, kind=gpu.lib.fesom_gpu_solver_kind(), ms_per_step=dt * 1e3, solver_ms=t_solve, iterations=its[-10:], resid=gpu.solver_residual)
     if pc:
         for k in ("ras_apply0", "ras_apply1", "ras_spmv1", "ras_spmv2", "dsr_update"):
             gpu.call("ras_arm")
