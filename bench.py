@@ -27,6 +27,7 @@ Besides the contract fields the JSON line carries
                  that fit os.cpu_count(); or the scalar C restatement (kind "port") if the reference binary cannot run here.
 """
 import argparse
+import ctypes as C
 import glob
 import json
 import os
@@ -41,10 +42,12 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured-achievable
 
 # algorithmic traffic per launch in 8-byte values per wet cell (N3 node cells, E3 prism cells, D3 edge cells):
-# every distinct 3-D array once per read and once per write, gathers once per gathered value (SURVEY 8d rule)
+# every distinct 3-D array once per read and once per write, gathers of a node array by elements / edges once per NODE value
+# (SURVEY 8d rule; k_pp: Z_3d_n, Unode (2), bvfreq read, Kv written = 5 N3, Av written = 1 E3).  audit_byte_table() flags every
+# kernel whose figure comes out above the HBM peak or above the PMC traffic of the committed summary.
 KERNEL_VALUES = {
     "k_vel_nodes": (2, 2, 0), "k_pressure_bv": (8, 0, 0), "k_pgf": (2, 3, 0), "k_sigma_slope": (13, 0, 0),
-    "k_pp": (5, 22, 0), "k_momadv_node": (5, 2, 0),
+    "k_pp": (5, 1, 0), "k_momadv_node": (5, 2, 0),
     "k_vel_rhs": (2, 10, 0), "k_visc_elem": (0, 4, 0), "k_visc_node": (2, 2, 0), "k_impl_visc": (3, 13, 0),
     "k_edge_transport": (0, 5, 0), "k_edge_transport1": (0, 3, 0), "k_update_vel": (0, 6, 0), "k_vert_vel_hbar": (8, 3, 0),
     "k_tr_ab": (3, 0, 0), "k_tr_z": (3, 0, 0), "k_tr_grad_elem": (2, 4, 0), "k_updn_grad": (0, 2, 4), "k_flux_hor": (2, 3, 6),
@@ -122,7 +125,9 @@ def solver_launches(core):
         return 2 + 5 * K + 1            # set-up, initial residual, K x (M p, A p^, M s, A s^, update), safety net
     if n <= 4096:
         return 2                        # set-up + one-workgroup Krylov loop
-    return 3 + 3 * (core.solver_iterations + 6)
+    if core.lib.fesom_gpu_solver_kind() == 2:
+        return 4 + 7 * (core.solver_iterations + 2)     # RAS-Chebyshev (solver_ras.hip): set-up, residual, sum, 7 per iteration, finish
+    return 3 + 2 * (core.solver_iterations + 6)
 
 
 def pmc_traffic(kernel, workload_key, redi):
@@ -147,6 +152,89 @@ def pmc_traffic(kernel, workload_key, redi):
                 continue
             return v["traffic_bytes_max"], os.path.relpath(fn, REPO)
     return None, f"no committed PMC summary for workload '{workload_key}'"
+
+
+def audit_byte_table(times, kbytes, workload_key, redi):
+    """the per-kernel byte table against what cannot be: a rate above the HBM peak, or algorithmic bytes above the HBM traffic the
+    PMC counters saw for that kernel (committed summary of the same workload)"""
+    over = {k: round(kbytes[k] / times[k] / 1e9, 1) for k in kbytes if times.get(k, 0) > 0 and kbytes[k] / times[k] / 1e9 > HBM_PEAK_GBS}
+    above_pmc = {}
+    for k in kbytes:
+        tr, _ = pmc_traffic(k, workload_key, redi)
+        if tr and kbytes[k] > 1.02 * tr:
+            above_pmc[k] = {"algorithmic": kbytes[k], "pmc": tr}
+    return {"over_hbm_peak": over, "algorithmic_above_pmc": above_pmc, "ok": not over and not above_pmc}
+
+
+def roofline_object(core, mesh, wl, sps):
+    """roofline record of one workload from the per-kernel table (HIP events on the library's stream)"""
+    kt = kernel_table(core, mesh, wl)
+    times, kbytes, mult = kt["times"], kt["kbytes"], kt["mult"]
+    N3, E3, D3 = kt["wet"]
+    share = {k: times[k] * mult.get(k, 1) for k in times}
+    dom = max((k for k in share if k != "k_solver"), key=lambda k: share[k])
+    dom_all = max(share, key=lambda k: share[k])
+    achieved = kbytes[dom] / times[dom] / 1e9
+    wkey = wl.name + (f"_r{wl.levels}" if wl.levels else "") + (f"_{wl.physics}" if wl.physics else "")
+    redi = bool(core.params.Redi)
+    traffic, tsrc = pmc_traffic(dom, wkey, redi)
+    ntr = core.params.num_tracers
+    f1_bytes = 8.0 * ntr * (40 * N3 + 10 * E3 + 10 * D3)          # SURVEY 8(d): mixing, diffusion, GM/Redi on top of the core path, per step and tracer
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
+                "kernel_us": round(times[dom] * 1e6, 2), "algorithmic_bytes_per_launch": kbytes[dom],
+                "dominant_by_time": {"kernel": dom_all, "us": round(share[dom_all] * 1e6, 1),
+                                     "note": "k_solver = the whole SSH solve (all BiCGstab iterations); a 2-D problem, see 'solver'"},
+                "whole_step": {"algorithmic_GB_per_step": round(kt["step_bytes"] / 1e9, 4),
+                               "achieved_GBs": round(kt["step_bytes"] / sps / 1e9, 1),
+                               "frac": round(kt["step_bytes"] / sps / 1e9 / HBM_PEAK_GBS, 4),
+                               "with_f1_physics_GB_per_step": round((kt["step_bytes"] + f1_bytes) / 1e9, 4),
+                               "with_f1_physics_frac": round((kt["step_bytes"] + f1_bytes) / sps / 1e9 / HBM_PEAK_GBS, 4),
+                               "sum_kernel_us": round(sum(share.values()) * 1e6, 1),
+                               "solver_us": round(times["k_solver"] * 1e6, 1), "solver_iterations": kt["its"]},
+                "top5_us": {k: round(v * 1e6, 2) for k, v in sorted(share.items(), key=lambda kv: -kv[1])[:5]},
+                "kernels": {k: {"us": round(times[k] * 1e6, 2), "launches_per_step": mult.get(k, 1),
+                                "GBs": (round(kbytes[k] / times[k] / 1e9, 1) if k in kbytes and times[k] > 0 else None)}
+                            for k in sorted(times, key=lambda k: -share[k])},
+                "launches_per_step": int(sum(mult.values())) + solver_launches(core),
+                "byte_table_audit": audit_byte_table(times, kbytes, wkey, redi)}
+    rows = mesh.myDim_nod2D
+    nnz = int(mesh.ssh_nza)
+    # one BiCGstab iteration = 2 operator applications (+ preconditioner) over the 2-D operator: nnz values + indices, ~10 vector passes
+    sol_bytes = kt["its"] * (2 * (nnz * 12.0) + 10 * rows * 8.0)
+    kind = core.lib.fesom_gpu_solver_kind()
+    roofline["solver"] = {"us": round(times["k_solver"] * 1e6, 1), "iterations": kt["its"], "rows": rows, "nnz": nnz,
+                          "preconditioner": {0: "Jacobi", 1: "explicit sparsified inverse", 2: "RAS-Chebyshev (patches of the row graph, one workgroup each)"}.get(kind, str(kind)),
+                          "algorithmic_bytes": sol_bytes, "achieved_GBs": round(sol_bytes / times["k_solver"] / 1e9, 1),
+                          "bound": "latency (one workgroup, LDS/register-resident operator)" if rows <= 4096 else "launch/latency (7 launches per iteration, patch solves out of LDS)"}
+    return roofline, kt
+
+
+def large_mesh_record(steps=60, warmup=10, levels=3):
+    """BASELINE config #3 stand-in inside the default line: the Soufflet channel refined `levels` times (182 600 nodes at 3), the kernel
+    shapes of CORE2-class meshes, the RAS-Chebyshev SSH solve.  GPU figures only (its reference CPU timing: bench.py --workload channel)."""
+    from fesom2_amd.core import OceanCore
+    wl = workloads.channel(levels)
+    mesh = wl.load_mesh()
+    core = OceanCore(mesh, wl.params())
+    try:
+        wl.start(core, mesh)
+        core.run_steps(1, warmup); core.lib.fesom_gpu_sync()
+        t0 = time.perf_counter()
+        core.run_steps(1 + warmup, steps); core.lib.fesom_gpu_sync()
+        sps = (time.perf_counter() - t0) / steps
+        eta = core.get("eta_n", mesh.myDim_nod2D)
+        assert np.isfinite(eta).all(), "model state blew up (large mesh)"
+        roofline, kt = roofline_object(core, mesh, wl, sps)
+        spy = 365 * 86400.0 / wl.dt
+        N3, E3, D3 = kt["wet"]
+        return {"workload": f"{wl.text} ({mesh.nod2D} nodes, {mesh.elem2D} elements, {mesh.nl - 1} layers)", "steps": steps, "warmup": warmup,
+                "ms_per_step": round(sps * 1e3, 4), "value": round(86400.0 / (spy * sps), 3), "unit": "simulated_years/day", "steps_per_day": int(round(86400.0 / wl.dt)),
+                "wet_cells": {"N3": N3, "E3": E3, "D3": D3},
+                "roofline": {k: roofline[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel_us", "whole_step", "top5_us", "solver", "launches_per_step", "byte_table_audit")},
+                "kernels_GBs": {k: v["GBs"] for k, v in roofline["kernels"].items() if v["GBs"] is not None}}
+    finally:
+        core.close()
 
 
 def cpu_baseline(wl, nsteps_ref=None):
@@ -223,10 +311,14 @@ def main():
     ap.add_argument("--workload", choices=("pi", "channel"), default="pi")
     ap.add_argument("--levels", type=int, default=3, help="channel workload: uniform refinement levels of the Soufflet channel (3 = 184 000 nodes)")
     ap.add_argument("--refine", type=int, default=0, help="pi workload, supplementary: pi refined uniformly L times")
+    ap.add_argument("--no-large-mesh", action="store_true", help="skip the CORE2-class record (channel refined 3x, ~60 steps) of the default N = 1 line")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}: start N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} "
+                         f"--master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...` (one rank per GPU); a single process measures one GPU only")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
@@ -362,12 +454,16 @@ def main():
             for n in range(warmup + steps + 1, warmup + steps + 6):
                 pc.step_native(n)
             pc.sync()
+            cnt5 = (C.c_longlong * 4)()
+            pc.core.lib.fesom_gpu_comm_counts(cnt5)
             nex5, _, ms5 = pc.comm_stats()
             pc.comm_timing(False)
             partitioned = {"ms_per_step": round(psps * 1e3, 4), "value": round(86400.0 / (steps_per_year * psps), 2), "unit": "simulated_years/day",
                            "scaling": "strong", "steps": steps, "warmup": warmup, "solver_iterations": its_part,
                            "transport": pc.transport_name, "transport_note": tr_note, "exchanges_per_step": round(nex / steps, 1), "allreduces_per_step": round(nar / steps, 1),
+                           "exchange_points_per_step": round(cnt5[0] / 5.0, 1), "message_parts_per_step": round(cnt5[1] / 5.0, 1), "async_exchanges_per_step": round(cnt5[3] / 5.0, 1),
                            "us_per_exchange": round(ms5 * 1e3 / max(nex5, 1), 2),
+                           "comm_fraction_of_step_stream": round(ms5 / 5.0 / (psps * 1e3), 3),      # pack..unpack of the synchronous exchanges + what the stream waited for the asynchronous ones
                            "owned_nodes_per_gpu": int(myN), "check_vs_single_gpu": {"max_abs_d_eta": d_eta, "max_abs_d_tracer": d_tr, "tolerance": 1e-8},
                            "error": None}
             if bad or not (d_eta < 1e-8 and d_tr < 1e-8):
@@ -400,37 +496,8 @@ def main():
         eta = core.get("eta_n", mesh.myDim_nod2D)
         T = core.get("tr_arr", 2 * mesh.myDim_nod2D * n1)
         assert np.isfinite(eta).all() and np.isfinite(T).all(), "model state blew up"
-        kt = kernel_table(core, mesh, wl)
-        times, kbytes, mult = kt["times"], kt["kbytes"], kt["mult"]
+        roofline, kt = roofline_object(core, mesh, wl, sps)
         N3, E3, D3 = kt["wet"]
-        share = {k: times[k] * mult.get(k, 1) for k in times}
-        dom = max((k for k in share if k != "k_solver"), key=lambda k: share[k])
-        dom_all = max(share, key=lambda k: share[k])
-        achieved = kbytes[dom] / times[dom] / 1e9
-        wkey = wl.name + (f"_r{wl.levels}" if wl.levels else "") + (f"_{wl.physics}" if wl.physics else "")
-        traffic, tsrc = pmc_traffic(dom, wkey, bool(core.params.Redi))
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
-                    "kernel_us": round(times[dom] * 1e6, 2), "algorithmic_bytes_per_launch": kbytes[dom],
-                    "dominant_by_time": {"kernel": dom_all, "us": round(share[dom_all] * 1e6, 1),
-                                         "note": "k_solver = the whole SSH solve (all BiCGstab iterations); a 2-D problem, see 'solver'"},
-                    "whole_step": {"algorithmic_GB_per_step": round(kt["step_bytes"] / 1e9, 4),
-                                   "achieved_GBs": round(kt["step_bytes"] / sps / 1e9, 1),
-                                   "frac": round(kt["step_bytes"] / sps / 1e9 / HBM_PEAK_GBS, 4),
-                                   "sum_kernel_us": round(sum(share.values()) * 1e6, 1),
-                                   "solver_us": round(times["k_solver"] * 1e6, 1), "solver_iterations": kt["its"]},
-                    "top5_us": {k: round(v * 1e6, 2) for k, v in sorted(share.items(), key=lambda kv: -kv[1])[:5]},
-                    "kernels": {k: {"us": round(times[k] * 1e6, 2), "launches_per_step": mult.get(k, 1),
-                                    "GBs": (round(kbytes[k] / times[k] / 1e9, 1) if k in kbytes and times[k] > 0 else None)}
-                                for k in sorted(times, key=lambda k: -share[k])},
-                    "launches_per_step": int(sum(mult.values())) + solver_launches(core)}
-        rows = mesh.myDim_nod2D
-        nnz = int(mesh.ssh_nza)
-        # one BiCGstab iteration = 2 operator applications (+ preconditioner) over the 2-D operator: nnz values + indices, ~10 vector passes
-        sol_bytes = kt["its"] * (2 * (nnz * 12.0) + 10 * rows * 8.0)
-        roofline["solver"] = {"us": round(times["k_solver"] * 1e6, 1), "iterations": kt["its"], "rows": rows, "nnz": nnz,
-                              "algorithmic_bytes": sol_bytes, "achieved_GBs": round(sol_bytes / times["k_solver"] / 1e9, 1),
-                              "bound": "latency (one workgroup, LDS/register-resident operator)" if rows <= 4096 else "launch/latency (multi-workgroup phases)"}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(wl)
@@ -451,7 +518,7 @@ def main():
                      "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(owl, 200)}
         part_ok = world > 1 and partitioned is not None and not partitioned.get("error")
         if world == 1:
-            value, ms, scaling = round(sypd_one, 2), round(sps * 1e3, 5), "weak"
+            value, ms, scaling = round(sypd_one, 2), round(sps * 1e3, 5), None
             par_text = "single GPU"
         elif part_ok:
             value, ms, scaling = partitioned["value"], partitioned["ms_per_step"], "strong"
@@ -475,6 +542,12 @@ def main():
                                "note": f"aggregate of {world} independent simulations, one per GPU (no communication)"}
         if other is not None:
             out["other_physics"] = other
+        if world == 1 and wl.name == "pi" and wl.levels == 0 and not args.no_large_mesh:
+            core.close(); core = None
+            try:
+                out["large_mesh"] = large_mesh_record()
+            except Exception as e:      # noqa: BLE001 -- recorded, the headline stands on its own
+                out["large_mesh"] = {"error": f"{type(e).__name__}: {e}"[:1000]}
         print(json.dumps(out), flush=True)
     if core is not None:
         core.close()

@@ -900,14 +900,19 @@ namespace {
 struct Sub { double *p; int W; bool q; };          // q: a solver vector in the patch order of the RAS preconditioner (send list as positions)
 struct XSpec { int kind; std::vector<const char *> names; };
 struct XPlan {
-  struct Part { int kind, Wtot; std::vector<Sub> subs; size_t soff, roff; };
+  // two layouts of the packed buffers: kind-major (a contiguous region per part, neighbour blocks inside: what the host transport's
+  // exchange(kind, ...) callback expects) and neighbour-major (ONE message per neighbour, the parts' blocks one after the other inside
+  // it: what the built-in transport sends -- one ncclSend / ncclRecv pair per neighbour and exchange point)
+  struct Part { int kind, Wtot; std::vector<Sub> subs; size_t soff, roff; const long long *sbase_d = nullptr, *rbase_d = nullptr; };
+  struct Msg { int peer; size_t soff, scnt, roff, rcnt; };
   std::vector<Part> parts;
+  std::vector<Msg> msgs;
   size_t stot = 0, rtot = 0;
 };
 int halo_subfields(int kind, int nf, const char *const *names, std::vector<Sub> &subs, int &Wtot);
 int halo_reserve(size_t doubles, int ch);
 int xplan_build(const std::vector<XSpec> &spec, XPlan &x) {
-  x.parts.clear(); x.stot = x.rtot = 0;
+  x.parts.clear(); x.msgs.clear(); x.stot = x.rtot = 0;
   for (const XSpec &sp : spec) {
     if (sp.kind < 0 || sp.kind > 2) { G.err = "halo: bad kind"; return 1; }
     XPlan::Part pt;
@@ -917,43 +922,70 @@ int xplan_build(const std::vector<XSpec> &spec, XPlan &x) {
     x.stot += (size_t)G.halo[sp.kind].nsend * pt.Wtot; x.rtot += (size_t)G.halo[sp.kind].nrecv * pt.Wtot;
     x.parts.push_back(pt);
   }
+  // neighbour-major layout
+  std::vector<int> peers;
+  for (const XPlan::Part &pt : x.parts) { const Ctx::Halo &h = G.halo[pt.kind]; peers.insert(peers.end(), h.sPE.begin(), h.sPE.end()); peers.insert(peers.end(), h.rPE.begin(), h.rPE.end()); }
+  std::sort(peers.begin(), peers.end()); peers.erase(std::unique(peers.begin(), peers.end()), peers.end());
+  std::vector<std::vector<long long>> sb(x.parts.size()), rb(x.parts.size());
+  for (size_t k = 0; k < x.parts.size(); k++) { sb[k].assign(G.halo[x.parts[k].kind].sPE.size(), 0); rb[k].assign(G.halo[x.parts[k].kind].rPE.size(), 0); }
+  size_t so = 0, ro = 0;
+  for (int pe : peers) {
+    XPlan::Msg mg{pe, so, 0, ro, 0};
+    for (size_t k = 0; k < x.parts.size(); k++) {
+      const Ctx::Halo &h = G.halo[x.parts[k].kind];
+      for (size_t p = 0; p < h.sPE.size(); p++) if (h.sPE[p] == pe) { sb[k][p] = (long long)so; so += (size_t)(h.sptr[p + 1] - h.sptr[p]) * x.parts[k].Wtot; }
+      for (size_t p = 0; p < h.rPE.size(); p++) if (h.rPE[p] == pe) { rb[k][p] = (long long)ro; ro += (size_t)(h.rptr[p + 1] - h.rptr[p]) * x.parts[k].Wtot; }
+    }
+    mg.scnt = so - mg.soff; mg.rcnt = ro - mg.roff;
+    x.msgs.push_back(mg);
+  }
+  if (x.parts.size() > 1)
+    for (size_t k = 0; k < x.parts.size(); k++) {
+      x.parts[k].sbase_d = dev_upload(sb[k]); x.parts[k].rbase_d = dev_upload(rb[k]);
+      if (g_alloc_failed) { G.err = "halo: device allocation failed (message layout)"; return 1; }
+    }
   return 0;
 }
 __global__ void k_halo_pack(const double *__restrict__ f, int W, const int *__restrict__ list, const int *__restrict__ ptr, int npe, int nitems,
-                            int Wtot, int Woff, double *__restrict__ buf);
+                            int Wtot, int Woff, double *__restrict__ buf, const long long *__restrict__ pbase);
 __global__ void k_halo_unpack(double *__restrict__ f, int W, const int *__restrict__ list, const int *__restrict__ ptr, int npe, int nitems,
-                              int Wtot, int Woff, const double *__restrict__ buf);
-int xplan_pack(const XPlan &x, int ch) {
+                              int Wtot, int Woff, const double *__restrict__ buf, const long long *__restrict__ pbase);
+// merged: the neighbour-major layout (built-in transport)
+int xplan_pack(const XPlan &x, int ch, bool merged) {
   if (halo_reserve(std::max(x.stot, x.rtot), ch)) return 1;
   hipStream_t st = ch ? G.cstream : G.stream;
   double *sbuf = ch ? G.hsend1 : G.hsend;
   for (const XPlan::Part &pt : x.parts) {
     const Ctx::Halo &h = G.halo[pt.kind];
+    const long long *pb = merged ? pt.sbase_d : nullptr;
     int off = 0;
     for (const Sub &sb : pt.subs) {
       const long long tot = (long long)h.nsend * sb.W;
-      if (tot > 0) hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, sb.p, sb.W, sb.q ? h.slist_q : h.slist, h.sptr_d, (int)h.sPE.size(), h.nsend, pt.Wtot, off, sbuf + pt.soff);
+      if (tot > 0) hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, sb.p, sb.W, sb.q ? h.slist_q : h.slist, h.sptr_d, (int)h.sPE.size(), h.nsend, pt.Wtot, off,
+                                      pb ? sbuf : sbuf + pt.soff, pb);
       off += sb.W;
     }
   }
   return 0;
 }
-int xplan_unpack(const XPlan &x, int ch) {
+int xplan_unpack(const XPlan &x, int ch, bool merged) {
   hipStream_t st = ch ? G.cstream : G.stream;
   const double *rbuf = ch ? G.hrecv1 : G.hrecv;
   for (const XPlan::Part &pt : x.parts) {
     const Ctx::Halo &h = G.halo[pt.kind];
+    const long long *pb = merged ? pt.rbase_d : nullptr;
     int off = 0;
     for (const Sub &sb : pt.subs) {
       const long long tot = (long long)h.nrecv * sb.W;
-      if (tot > 0) hipLaunchKernelGGL(k_halo_unpack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, sb.p, sb.W, h.rlist, h.rptr_d, (int)h.rPE.size(), h.nrecv, pt.Wtot, off, rbuf + pt.roff);
+      if (tot > 0) hipLaunchKernelGGL(k_halo_unpack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, sb.p, sb.W, h.rlist, h.rptr_d, (int)h.rPE.size(), h.nrecv, pt.Wtot, off,
+                                      pb ? rbuf : rbuf + pt.roff, pb);
       off += sb.W;
     }
   }
   return 0;
 }
-// the bytes of one exchange point: ONE group of ncclSend / ncclRecv through the built-in transport (a pair per neighbour and part), or one
-// callback per part through the host's transport
+// the bytes of one exchange point: ONE group of ncclSend / ncclRecv through the built-in transport, one pair per neighbour (reference:
+// one MPI_Isend / MPI_Irecv per neighbour and FIELD, src/gen_halo_exchange.F90:129-164), or one callback per part through the host's transport
 int xplan_move(const XPlan &x, const fesom_transport *t, int ch, hipStream_t stream) {
   double *sbuf = ch ? G.hsend1 : G.hsend, *rbuf = ch ? G.hrecv1 : G.hrecv;
   if (t) {
@@ -962,18 +994,8 @@ int xplan_move(const XPlan &x, const fesom_transport *t, int ch, hipStream_t str
     return 0;
   }
   NCCLCHK(R.GroupStart());
-  for (const XPlan::Part &pt : x.parts) {
-    const Ctx::Halo &h = G.halo[pt.kind];
-    const int W = pt.Wtot;
-    for (size_t p = 0; p < h.sPE.size(); p++) {
-      const size_t first = (size_t)(h.sptr[p] - 1), cnt = (size_t)(h.sptr[p + 1] - h.sptr[p]);
-      if (cnt) NCCLCHK(R.Send(sbuf + pt.soff + first * W, cnt * W, ncclDouble, h.sPE[p], R.comm, stream));
-    }
-    for (size_t p = 0; p < h.rPE.size(); p++) {
-      const size_t first = (size_t)(h.rptr[p] - 1), cnt = (size_t)(h.rptr[p + 1] - h.rptr[p]);
-      if (cnt) NCCLCHK(R.Recv(rbuf + pt.roff + first * W, cnt * W, ncclDouble, h.rPE[p], R.comm, stream));
-    }
-  }
+  for (const XPlan::Msg &mg : x.msgs) if (mg.scnt) NCCLCHK(R.Send(sbuf + mg.soff, mg.scnt, ncclDouble, mg.peer, R.comm, stream));
+  for (const XPlan::Msg &mg : x.msgs) if (mg.rcnt) NCCLCHK(R.Recv(rbuf + mg.roff, mg.rcnt, ncclDouble, mg.peer, R.comm, stream));
   NCCLCHK(R.GroupEnd());
   return 0;
 }
@@ -1014,7 +1036,7 @@ struct PStep {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (as) { hipEventRecord(G.ev_prod, G.stream); hipStreamWaitEvent(G.cstream, G.ev_prod, 0); }
     else if (G.comm_timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, G.stream); }
-    if (xplan_pack(x, ch) || xplan_move(x, t, ch, st) || xplan_unpack(x, ch)) { rc = 1; return; }
+    if (xplan_pack(x, ch, !t) || xplan_move(x, t, ch, st) || xplan_unpack(x, ch, !t)) { rc = 1; return; }
     if (as) { hipEventRecord(G.ev_done, G.cstream); pending = true; G.n_async++; }
     if (e0) { hipEventRecord(e1, G.stream); G.comm_ev.push_back({e0, e1}); }
     G.n_exch++; G.n_parts += (long long)x.parts.size();
@@ -1599,24 +1621,26 @@ void psolve(int *id, double *rhs, double *vals, double *sol, int *newvals) {
 // =====================================================================================================================
 namespace {
 __global__ void k_halo_pack(const double *__restrict__ f, int W, const int *__restrict__ list, const int *__restrict__ ptr, int npe, int nitems,
-                            int Wtot, int Woff, double *__restrict__ buf) {
+                            int Wtot, int Woff, double *__restrict__ buf, const long long *__restrict__ pbase) {
   long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (long long)nitems * W) return;
   int i = (int)(g / W), w = (int)(g % W);
   int p = 0;
   while (p + 1 < npe && i >= ptr[p + 1] - 1) p++;
   int first = ptr[p] - 1, cnt = ptr[p + 1] - ptr[p];
-  buf[(size_t)first * Wtot + (size_t)cnt * Woff + (size_t)(i - first) * W + w] = f[(size_t)list[i] * W + w];
+  const size_t base = pbase ? (size_t)pbase[p] : (size_t)first * Wtot;       // start of neighbour p's block of this part
+  buf[base + (size_t)cnt * Woff + (size_t)(i - first) * W + w] = f[(size_t)list[i] * W + w];
 }
 __global__ void k_halo_unpack(double *__restrict__ f, int W, const int *__restrict__ list, const int *__restrict__ ptr, int npe, int nitems,
-                              int Wtot, int Woff, const double *__restrict__ buf) {
+                              int Wtot, int Woff, const double *__restrict__ buf, const long long *__restrict__ pbase) {
   long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (long long)nitems * W) return;
   int i = (int)(g / W), w = (int)(g % W);
   int p = 0;
   while (p + 1 < npe && i >= ptr[p + 1] - 1) p++;
   int first = ptr[p] - 1, cnt = ptr[p + 1] - ptr[p];
-  f[(size_t)list[i] * W + w] = buf[(size_t)first * Wtot + (size_t)cnt * Woff + (size_t)(i - first) * W + w];
+  const size_t base = pbase ? (size_t)pbase[p] : (size_t)first * Wtot;
+  f[(size_t)list[i] * W + w] = buf[base + (size_t)cnt * Woff + (size_t)(i - first) * W + w];
 }
 int halo_subfields(int kind, int nf, const char *const *names, std::vector<Sub> &subs, int &Wtot) {
   const DM &m = G.m;
@@ -1661,7 +1685,7 @@ static int halo_pack_on(int kind, int nfields, const char *const *names, void **
   if (G.npes < 2) { G.err = "halo: single partition"; return 1; }
   std::vector<XSpec> spec(1);
   spec[0].kind = kind; spec[0].names.assign(names, names + nfields);
-  if (xplan_build(spec, g_hx) || xplan_pack(g_hx, 0)) return 1;
+  if (xplan_build(spec, g_hx) || xplan_pack(g_hx, 0, false)) return 1;
   // stream-ordered: fesom_gpu_copy / fesom_gpu_sync wait for the pack kernels; a transport on the same stream
   // (fesom_gpu_set_stream) needs no host wait at all
   HIPCHK(hipGetLastError());
@@ -1673,7 +1697,7 @@ static int halo_unpack_on(int kind, int nfields, const char *const *names) {
   std::vector<XSpec> spec(1);
   spec[0].kind = kind; spec[0].names.assign(names, names + nfields);
   XPlan x;
-  if (xplan_build(spec, x) || xplan_unpack(x, 0)) return 1;
+  if (xplan_build(spec, x) || xplan_unpack(x, 0, false)) return 1;
   HIPCHK(hipGetLastError());
   return 0;
 }

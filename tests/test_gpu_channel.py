@@ -129,7 +129,9 @@ def test_channel_r1_vs_reference_cpu(built):
         b = assemble(dc, sc, f)
         assert b.shape == a.shape, (f, a.shape, b.shape)
         worst[f] = float(np.abs(a - b).max())
-    assert 0.0 < worst["eta_n"] < 1e-8 and worst["tr_arr"] < 1e-8 and worst["UV"] < 1e-8 and worst["hnode"] < 1e-8, worst
+    # both solvers stop at ||scaled residual|| < 1e-10 (bicgstab_ras.c:78): their solutions differ by that times the conditioning of the row-scaled
+    # operator (a few hundred on this mesh: the Jacobi iteration count says so), and eta_n accumulates d_eta over the steps
+    assert 0.0 < worst["eta_n"] < 5e-8 and worst["tr_arr"] < 2e-9 and worst["UV"] < 2e-9 and worst["hnode"] < 5e-9, worst
 
 
 def test_channel_r3_benchmark_size(built, tmp_path):

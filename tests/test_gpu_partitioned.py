@@ -81,6 +81,8 @@ def test_partitioned_channel(built, tmp_path, transport):
     reps = [json.loads(x) for x in re.findall(r"CHANREPORT (\{.*\})", r.stdout)]
     assert len(reps) == 2
     for rep in reps:
-        assert rep["d_eta"] < 1e-8 and rep["d_T"] < 1e-8 and rep["d_UV"] < 1e-8, rep
+        # (both runs stop their SSH solves at ||scaled residual|| < 1e-10 with different preconditioners -- the patches of a partition are not those of
+        # the whole mesh: solver tolerance x conditioning of the operator, accumulated in eta_n over 12 steps)
+        assert rep["d_eta"] < 5e-8 and rep["d_T"] < 2e-9 and rep["d_UV"] < 2e-9, rep
         assert rep["eta_range"][1] - rep["eta_range"][0] > 1e-3, rep          # the jet really evolves
         assert rep["owned"] > 4096
