@@ -11,8 +11,10 @@ Workloads (fesom2_amd/workloads.py):
   pi (default, BASELINE config #2) : the reference's pi mesh, 3140 nodes, 47 layers, dt = 900 s (step_per_day = 96,
       setups/pi/setup.yml:12).  --physics default = the reference's pi configuration (KPP + GM + Redi, config/namelist.oce)
       under analytic surface forcing -- the headline; "pp" (PP mixing only) is reported under "other_physics".
-  channel (BASELINE config #3 stand-in, the reference ships no CORE2 mesh): the Soufflet channel of the reference's CI case
-      refined --levels times (3 -> 184 000 nodes), 47 layers, dt = 1200 s / 2**levels.
+  basin (BASELINE config #3 in kind, the reference ships no CORE2 mesh): the channel geometry refined --levels times (3 -> 182 600
+      nodes) with an analytic bathymetry (ragged bottom levels, partial cells) and the reference's default physics (JM EOS, KPP + GM +
+      Redi, analytic forcing), 47 layers, dt = 1200 s / 2**levels.  The default N = 1 line carries it as "large_mesh".
+  channel: the Soufflet channel of the reference's CI case refined (flat bottom, linear EOS, PP mixing, toy hooks): "large_mesh_channel".
 
 N > 1 (one process per GPU under torch.distributed.run): `value` = SYPD of ONE simulation partitioned over the N GPUs
 (reference node partition, halo exchange + partitioned SSH solve; "scaling": "strong"), checked against the single-GPU run of
@@ -210,11 +212,13 @@ def roofline_object(core, mesh, wl, sps):
     return roofline, kt
 
 
-def large_mesh_record(steps=60, warmup=10, levels=3):
-    """BASELINE config #3 stand-in inside the default line: the Soufflet channel refined `levels` times (182 600 nodes at 3), the kernel
-    shapes of CORE2-class meshes, the RAS-Chebyshev SSH solve.  GPU figures only (its reference CPU timing: bench.py --workload channel)."""
+def large_mesh_record(which="basin", steps=60, warmup=10, levels=3):
+    """BASELINE config #3 in kind inside the default line: the channel geometry refined `levels` times (182 600 nodes at 3), the kernel shapes of
+    CORE2-class meshes, the RAS-Chebyshev SSH solve.  which = "basin": analytic bathymetry, the reference's default physics (JM EOS, KPP + GM +
+    Redi, analytic forcing); "channel": the reference's CI case test_souf refined (flat bottom, linear EOS, PP, toy hooks).  GPU figures only
+    (the reference's CPU timing on the same mesh: bench.py --workload basin | channel)."""
     from fesom2_amd.core import OceanCore
-    wl = workloads.channel(levels)
+    wl = workloads.basin(levels) if which == "basin" else workloads.channel(levels)
     mesh = wl.load_mesh()
     core = OceanCore(mesh, wl.params())
     try:
@@ -250,8 +254,8 @@ def cpu_baseline(wl, nsteps_ref=None):
         cand = [r for r in (8, 16, 32) if r <= ncpu] or [2]
         tried, best = {}, None
         for ranks in cand:
-            if wl.name == "channel":
-                cfg, _ = run_ref.channel_case(wl.levels, ranks, wl.layers)
+            if wl.name in ("channel", "basin"):
+                cfg, _ = (run_ref.channel_case if wl.name == "channel" else run_ref.basin_case)(wl.levels, ranks, wl.layers)
                 n = nsteps_ref or max(10, 400 // 4 ** wl.levels)
             else:
                 cfg = workloads.PHYSICS[wl.physics]["ref_cfg"]
@@ -308,7 +312,7 @@ def main():
     ap.add_argument("--no-other", action="store_true", help="skip the short run of the other physics set")
     ap.add_argument("--physics", choices=sorted(workloads.PHYSICS), default="default",
                     help="pi workload: options of the timed step (default = the reference's pi configuration KPP + GM + Redi; the other set is reported in 'other_physics' at N=1)")
-    ap.add_argument("--workload", choices=("pi", "channel"), default="pi")
+    ap.add_argument("--workload", choices=("pi", "channel", "basin"), default="pi")
     ap.add_argument("--levels", type=int, default=3, help="channel workload: uniform refinement levels of the Soufflet channel (3 = 184 000 nodes)")
     ap.add_argument("--refine", type=int, default=0, help="pi workload, supplementary: pi refined uniformly L times")
     ap.add_argument("--no-large-mesh", action="store_true", help="skip the CORE2-class record (channel refined 3x, ~60 steps) of the default N = 1 line")
@@ -342,15 +346,16 @@ def main():
         dist.barrier()
     from fesom2_amd.core import OceanCore
 
-    big = args.workload == "channel" and args.levels >= 2
+    big = args.workload in ("channel", "basin") and args.levels >= 2
     steps = args.steps if args.steps is not None else (100 if big else 2000)
     warmup = args.warmup if args.warmup is not None else (20 if big else 200)
-    if args.workload == "channel":
+    if args.workload in ("channel", "basin"):
+        mk = workloads.channel if args.workload == "channel" else workloads.basin
         if rank == 0:
-            wl = workloads.channel(args.levels)
+            wl = mk(args.levels)
         if world > 1:
             dist.barrier()
-        wl = workloads.channel(args.levels)
+        wl = mk(args.levels)
     else:
         wl = workloads.pi(args.physics, args.refine)
     steps_per_year = 365 * 86400.0 / wl.dt
@@ -529,7 +534,7 @@ def main():
         else:
             value, ms, scaling = None, None, "strong"
             par_text = f"one simulation partitioned over {world} GPUs -- FAILED, see 'partitioned.error'"
-        out = {"metric": "SYPD (simulated years/day) on pi mesh, 47 z-levels" if wl.name == "pi" else "SYPD (simulated years/day), CORE2-class channel, 47 z-levels",
+        out = {"metric": "SYPD (simulated years/day) on pi mesh, 47 z-levels" if wl.name == "pi" else f"SYPD (simulated years/day), CORE2-class {wl.name}, 47 z-levels",
                "value": value, "unit": "simulated_years/day", "n_gpus": world, "steps": steps, "warmup": warmup,
                "ms_per_step": ms, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"{wl.text} ({mesh.nod2D} nodes, {mesh.elem2D} elements, {n1} layers)",
@@ -545,9 +550,13 @@ def main():
         if world == 1 and wl.name == "pi" and wl.levels == 0 and not args.no_large_mesh:
             core.close(); core = None
             try:
-                out["large_mesh"] = large_mesh_record()
+                out["large_mesh"] = large_mesh_record("basin")
             except Exception as e:      # noqa: BLE001 -- recorded, the headline stands on its own
                 out["large_mesh"] = {"error": f"{type(e).__name__}: {e}"[:1000]}
+            try:
+                out["large_mesh_channel"] = large_mesh_record("channel", steps=40)
+            except Exception as e:      # noqa: BLE001
+                out["large_mesh_channel"] = {"error": f"{type(e).__name__}: {e}"[:1000]}
         print(json.dumps(out), flush=True)
     if core is not None:
         core.close()

@@ -58,6 +58,9 @@ struct Ctx {
   bool toy_znum_global = false;                       // partitioned Soufflet channel: the per-bin element counts have been summed over the ranks
   // communication statistics of the partitioned step (fesom_gpu_comm_stats)
   long long n_exch = 0, n_allred = 0, n_parts = 0;
+  // interior / boundary split of the node-column kernels behind an exchange (partitioned runs): owned nodes whose edge neighbours are all owned,
+  // owned nodes with a halo neighbour, and the latter plus the halo nodes themselves
+  struct ColList { const int *d = nullptr; int n = 0; } sub_int, sub_cb, sub_cbh;
   bool precond_agreed = false;                        // partitioned runs: all ranks have settled on one SSH preconditioner
   int generation = 0;                                 // counts fesom_gpu_init calls (cached plans of the partitioned step belong to one)
   bool comm_timing = false;
@@ -612,6 +615,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   F(pgf_x, n1 * E); F(pgf_y, n1 * E); F(helem, n1 * E); F(Av, nl * E); F(dhe, E);
   FT(adv_flux_hor, n1 * D); FT(adv_flux_raw, n1 * D); FT(flux_lo_hor, n1 * D); FT(diff_flux, n1 * D); FT(edge_up_dn_grad, 4 * n1 * D); F(edge_c12, D);
   F(ssh_values, m.nza);
+  if (par->which_pgf == 0 && !(par->which_ale == 0 && !par->use_partial_cell)) { F(pgf_A, n1 * N); F(pgf_B, n1 * N); }      // shchepetkin variants
   if (par->visc_option <= 3) { F(Visc, n1 * E); F(leith_aux, n1 * N); }
   if (par->smooth_bh_tra) FT(bh_tmp, n1 * N);
   m.ale_flag = dev_alloc<int>(1); HIPCHK(hipMemset(m.ale_flag, 0, sizeof(int)));
@@ -743,6 +747,22 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
       h.rlist = dev_upload(minus1(c.rlist, h.nrecv)); h.slist = dev_upload(h.slist_h); h.slist_q = nullptr;
       h.rptr_d = dev_upload(h.rptr); h.sptr_d = dev_upload(h.sptr);
     }
+  }
+  G.sub_int = G.sub_cb = G.sub_cbh = Ctx::ColList();
+  if (part && part->npes > 1) {
+    std::vector<char> bnd(m.myN, 0);
+    for (int e = 0; e < m.myD; e++) {
+      const int a = ed[2 * e], b = ed[2 * e + 1];
+      if (a < m.myN && b >= m.myN) bnd[a] = 1;
+      if (b < m.myN && a >= m.myN) bnd[b] = 1;
+    }
+    std::vector<int> li, lb;
+    for (int n = 0; n < m.myN; n++) (bnd[n] ? lb : li).push_back(n);
+    std::vector<int> lbh(lb);
+    for (int n = m.myN; n < m.N; n++) lbh.push_back(n);
+    G.sub_int.d = dev_upload(li); G.sub_int.n = (int)li.size();
+    G.sub_cb.d = dev_upload(lb); G.sub_cb.n = (int)lb.size();
+    G.sub_cbh.d = dev_upload(lbh); G.sub_cbh.n = (int)lbh.size();
   }
   if (par->toy_soufflet) {
     // static tables of the Soufflet hooks: compute_zonal_mean_ini (toy_channel_soufflet.F90:104-155) and the interpolation
@@ -1012,8 +1032,16 @@ int fam_ras(const DM &m, hipStream_t s, const char *n, int, int) { return launch
 struct PStep {
   const fesom_transport *t;                       // nullptr: the built-in RCCL transport (fesom_gpu_comm_init)
   int rc = 0;
-  void k(FamFn f, const char *name, int arg = 0) {
+  void k(FamFn f, const char *name, int arg = 0, int sub = 0) {
     if (rc) return;
+    if (sub) {                                     // the same kernel over a list of columns (DM::sub_list)
+      const Ctx::ColList &cl = sub == 1 ? G.sub_int : sub == 2 ? G.sub_cb : G.sub_cbh;
+      if (cl.n == 0) return;
+      DM ms = G.m;
+      ms.sub_list = cl.d; ms.sub_n = cl.n;
+      if (f(ms, G.stream, name, arg, G.first_step) != 0) { rc = 1; if (G.err.empty()) G.err = std::string("step_partitioned: unknown phase ") + name; }
+      return;
+    }
     if (f(G.m, G.stream, name, arg, G.first_step) != 0) { rc = 1; if (G.err.empty()) G.err = std::string("step_partitioned: unknown phase ") + name; }
   }
   // One exchange in flight on the communication stream (built-in transport only); any other communication waits for it first, so the
@@ -1061,7 +1089,7 @@ struct PStep {
 
 // the program of one step
 enum OpType { O_KERNEL, O_XCHG, O_XCHG_ASYNC, O_WAIT, O_SOLVE, O_ZONAL10 };
-struct Op { OpType type; FamFn fam; const char *name; int arg; XPlan x; };
+struct Op { OpType type; FamFn fam; const char *name; int arg; XPlan x; int sub = 0; };      // sub: 0 all columns, 1 interior nodes, 2 nodes with a halo neighbour, 3 those + the halo nodes
 std::vector<Op> g_prog;
 int g_last_part_its = 8;
 
@@ -1140,15 +1168,27 @@ int build_program() {
   W();
   K(fam_tra, "k_updn_grad", 0);
   K(fam_tra, "k_flux_hor", 0); K(fam_tra, "k_fct_lo_node", 0);
+  auto KS = [&](FamFn f, const char *name, int sub) { Op o{O_KERNEL, f, name, 0, XPlan()}; o.sub = sub; P.push_back(o); };
   if (!p.tra_adv_lim) {                                        // (no low-order solution, no limiter with tra_adv_lim='NON')
-    if (p.Redi) X({{0, {"fct_LO", "tr_z"}}}); else X({{0, {"fct_LO"}}});
-    if (p.with_diffusion) K(fam_tra, "k_diff_flux", 0);
-    K(fam_tra, "k_fct_node", 0); X({{0, {"fct_plus", "fct_minus"}}});
+    // INTERIOR / BOUNDARY SPLIT (the reference's mechanism: src/gen_halo_exchange.F90:129-164 posts, :317-363 waits; its one use: src/oce_tracer_mod.F90:68-81):
+    // the low-order solution travels on the communication stream while the limiter works on the nodes whose neighbours are all owned; the
+    // nodes next to the halo follow once it has arrived.  The same for the limiting factors and the tracer update.
+    if (p.with_diffusion && !p.Redi) K(fam_tra, "k_diff_flux", 0);
+    if (p.Redi) X({{0, {"fct_LO", "tr_z"}}}, true); else X({{0, {"fct_LO"}}}, true);
+    KS(fam_tra, "k_fct_node", 1);
+    W();
+    if (p.with_diffusion && p.Redi) K(fam_tra, "k_diff_flux", 0);     // (with Redi it reads the halo of tr_z)
+    KS(fam_tra, "k_fct_node", 2);
+    X({{0, {"fct_plus", "fct_minus"}}}, true);
+    KS(fam_tra, "k_tr_update", 1);
+    W();
+    K(fam_tra, "k_fct_edge_limit", 0);                          // (reads the factors at both nodes of every owned edge, halo nodes included)
+    KS(fam_tra, "k_tr_update", 3);
   } else {
     if (p.Redi) X({{0, {"tr_z"}}});
     if (p.with_diffusion) K(fam_tra, "k_diff_flux", 0);
+    K(fam_tra, "k_fct_edge_limit", 0); K(fam_tra, "k_tr_update", 0);
   }
-  K(fam_tra, "k_fct_edge_limit", 0); K(fam_tra, "k_tr_update", 0);
   if (p.smooth_bh_tra) { K(fam_tra, "k_bh1", 0); X({{0, {"bh_tmp"}}}); K(fam_tra, "k_bh2", 0); }     // (the tracer halo still holds the values of the previous exchange, as in the reference)
   if (toy) for (int tr = 0; tr < G.m.ntr; tr++) K(fam_toy, "relax_zonal_temp");     // once per tracer of the loop, always on tracer 1 (oce_ale_tracer.F90:150)
   else if (p.clim_relax > 1.0e-8) K(fam_tra, "relax_to_clim", 0);
@@ -1248,7 +1288,7 @@ int fesom_gpu_step_partitioned(int n, const fesom_transport *t) {
   for (const Op &o : g_prog) {
     if (S.rc) break;
     switch (o.type) {
-      case O_KERNEL: S.k(o.fam, o.name, o.arg); break;
+      case O_KERNEL: S.k(o.fam, o.name, o.arg, o.sub); break;
       case O_XCHG: S.X(o.x, false); break;
       case O_XCHG_ASYNC: S.X(o.x, true); break;
       case O_WAIT: S.Wt(); break;

@@ -60,6 +60,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   const unsigned char *wall_node;          // mom_adv = 3: 1 for both nodes of the owned boundary edges (KE_node = 0 at lateral walls)
   double *Visc, *vorticity, *leith_aux;    // visc_option 1-3: Leith coefficient (nl-1, E), relative vorticity and smoothing work array (nl-1, N)
   double *pgf_x, *pgf_y, *helem, *Av, *dhe, *stress_surf;
+  double *pgf_A, *pgf_B;                   // shchepetkin PGF: the two quotients of the density-Jacobian's vertical derivative that depend on the NODE column only (k_pressure_bv forms them once per node and level; every element around the node reads them)
   double *adv_flux_hor, *adv_flux_raw, *flux_lo_hor, *edge_up_dn_grad, *edge_c12, *diff_flux;
   double *ssh_values;
   // Gent-McWilliams bolus velocities (kernels_gm.hip)
@@ -105,6 +106,9 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   const int *rs_pinfo, *rs_extq, *rs_perm, *rs_inv, *rs_colsq;
   const float *rs_lv; const unsigned short *rs_lc; const double *rs_dsc, *rs_cheb;   // rs_cheb: [0] 1/theta, [1+k] c1_k, [64+k] c2_k
   int rs_P, rs_NS, rs_rpt, rs_woff, rs_deg;
+  // sub-launch of a column kernel over a LIST of columns (partitioned runs: interior columns while a halo exchange is in flight, then the
+  // columns whose stencil reaches into the halo): column slot i works on sub_list[i], i < sub_n.  nullptr = all columns.
+  const int *sub_list; int sub_n;
   fesom_params p;
 };
 
@@ -152,7 +156,9 @@ __device__ __forceinline__ int xcd_block() {
   const unsigned b = blockIdx.x, nb = gridDim.x, q = nb >> 3, r = nb & 7u, x = b & 7u, j = b >> 3;
   return (int)(x * q + (x < r ? x : r) + j);
 }
-__device__ __forceinline__ int col_id() { return __builtin_amdgcn_readfirstlane(xcd_block() * COLS_PER_BLOCK + (threadIdx.x >> 6)); }
+// column slot -> column: the identity, or an entry of the launch's column list (DM::sub_list; slots past its end give a column no kernel owns)
+__device__ __forceinline__ int sub_col(const DM &m, int slot) { return m.sub_list ? (slot < m.sub_n ? m.sub_list[slot] : 0x7fffffff) : slot; }
+__device__ __forceinline__ int col_id(const DM &m) { return __builtin_amdgcn_readfirstlane(sub_col(m, xcd_block() * COLS_PER_BLOCK + (threadIdx.x >> 6))); }
 // broadcast of lane `src`; src must be wave-uniform (it always is a level index of the wave's column): v_readlane, no LDS
 __device__ __forceinline__ double bcast(double x, int src) {
   int lo = __builtin_amdgcn_readlane(__double2loint(x), src), hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
@@ -258,7 +264,7 @@ __device__ __forceinline__ double dmax_(double a, double b) { return a > b ? a :
 #define TH_COLS 8
 #define TH_CP (TH_COLS + 1)
 #define TH_BLOCK (WAVE * TH_COLS)
-__device__ __forceinline__ int col_id_th() { return __builtin_amdgcn_readfirstlane(xcd_block() * TH_COLS + (threadIdx.x >> 6)); }
+__device__ __forceinline__ int col_id_th(const DM &m) { return __builtin_amdgcn_readfirstlane(sub_col(m, xcd_block() * TH_COLS + (threadIdx.x >> 6))); }
 static inline size_t thomas_lds_bytes(int nlm1, int nrhs) { return (size_t)(3 + nrhs) * nlm1 * TH_CP * sizeof(double) + 2 * TH_COLS * sizeof(int); }
 static inline int nblocks_th(int ncol) { return (ncol + TH_COLS - 1) / TH_COLS; }
 #define LAUNCH_TH(k, ncol, nrhs, ...) hipLaunchKernelGGL(k, dim3(nblocks_th(ncol)), dim3(TH_BLOCK), thomas_lds_bytes(m.nlm1, nrhs), s, __VA_ARGS__)
@@ -402,6 +408,7 @@ static inline int nblocks_tl(int ncol) { return (ncol + TL_COLS - 1) / TL_COLS; 
 #define TL_MIN_COLUMNS 20000
 
 static inline int nblocks(int ncol) { return (ncol + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK; }
+#define SUBN(m_, n_) ((m_).sub_list ? (m_).sub_n : (n_))       /* column slots of a launch: all n_ columns, or the launch's column list */
 
 // launchers implemented in the kernel translation units
 void launch_dynamics_pre(const DM &m, hipStream_t s, int first_step);

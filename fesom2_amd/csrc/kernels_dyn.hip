@@ -8,7 +8,7 @@
 // compute_vel_nodes (src/oce_dyn.F90:133-169): node <- area-weighted mean of surrounding elements.
 // HBM-bound gather; algorithmic traffic 2 N3 + 2 E3 values.
 __global__ void __launch_bounds__(BLOCK) k_vel_nodes(DM m) {
-  int n = col_id(), nz = lane_id() + 1;
+  int n = col_id(m), nz = lane_id() + 1;
   if (n >= m.myN) return;
   if (nz < m.ulev_n[n] || nz > m.nlev_n[n] - 1) return;
   double tvol = 0.0, tx = 0.0, ty = 0.0;
@@ -58,7 +58,7 @@ __device__ __forceinline__ void eos(const fesom_params &p, double t, double s, d
 // pointwise in (T,S,Z) per node column.  Vertical neighbours come from wave shuffles; MLD searches are
 // ballots.  ~150 flops/cell, 7+5 values/cell -> HBM-bound.
 __global__ void __launch_bounds__(BLOCK) k_pressure_bv(DM m) {
-  int n = col_id(), l = lane_id(), nz = l + 1;
+  int n = col_id(m), l = lane_id(), nz = l + 1;
   if (n >= m.N) return;
   const int nzmin = m.ulev_n[n], nzmax = m.nlev_n[n];
   const bool wet = (nz >= nzmin && nz <= nzmax - 1);
@@ -80,6 +80,20 @@ __global__ void __launch_bounds__(BLOCK) k_pressure_bv(DM m) {
     double zk = (nz > nzmin + 1) ? z : z2;                      // Z_3d_n(max(nz,nzmin+1))
     dbq = dbsfc1 / fabs(zmin - zk);
     if (m.dbsfc) { DA2L(m.dbsfc, nz, n) = dbsfc1; if (nz == nzmax - 1) DA2L(m.dbsfc, nzmax, n) = dbsfc1; }   // KPP: buoyancy difference to the surface
+  }
+  if (m.pgf_A) {
+    // pressure_force_4_zxxxx_shchepetkin (src/oce_ale_pressure_bv.F90:1878-2104): drho/dz at a node of an element is
+    //   df10/dx10 + (dx10*df21 - dx21*df10)/(dx20*dx21*dx10) * ((Z_n - zc) + (Z_n - zm))
+    // around a level k0 of the NODE column; the two quotients do not depend on the element.  They are formed here, once per node and level, with the
+    // operands and operations of the reference (the same bits as when every element forms them again: six fp64 divisions per element and level saved)
+    const double zm = shup(z), zp = shdn(z), rm = shup(rho), rp = shdn(rho);
+    double qa = 0.0, qb = 0.0;
+    if (wet && nz - 1 >= nzmin && nz + 1 <= nzmax - 1) {
+      const double dx10 = z - zm, dx21 = zp - z, dx20 = zp - zm, df10 = rho - rm, df21 = rp - rho;
+      qa = df10 / dx10;
+      qb = (dx10 * df21 - dx21 * df10) / (dx20 * dx21 * dx10);
+    }
+    if (nz <= m.nlm1) { DA2(m.pgf_A, nz, n) = qa; DA2(m.pgf_B, nz, n) = qb; }
   }
   double db_max = wave_max(wet ? dmax_(dbq, 0.0) : 0.0);
   // linfs: hydrostatic pressure (sequential running sum, reference order)
@@ -191,7 +205,7 @@ __device__ __forceinline__ double pgf_cubic_rho(const DM &m, int node, double Zn
 // Per element column: density-Jacobian terms per level in parallel, the two vertical integrals as
 // reference-order running sums.  Reads 3 node columns x (rho, Z) -> HBM-bound gather, 2 N3 + 3 E3 values.
 __global__ void __launch_bounds__(BLOCK) k_pgf(DM m) {
-  int e = col_id(), l = lane_id(), nlz = l + 1;
+  int e = col_id(m), l = lane_id(), nlz = l + 1;
   if (e >= m.myE) return;
   const int nle = m.nlev[e] - 1, ule = m.ulev[e];
   const bool wet = (nlz >= ule && nlz <= nle);
@@ -294,11 +308,9 @@ __global__ void __launch_bounds__(BLOCK) k_pgf(DM m) {
       if (nlz == ule && (nlz - m.ulev_n[n]) == 0) k0 = nlz + 1;
       else if (nlz == nle && nlz != ule && (m.nlev_n[n] - 1 - nlz) == 0) k0 = nlz - 1;
       else k0 = nlz;
-      double zm = DA2(m.Z_3d_n, k0 - 1, n), zc = DA2(m.Z_3d_n, k0, n), zp = DA2(m.Z_3d_n, k0 + 1, n);
-      double rm = DA2(m.density_m_rho0, k0 - 1, n), rc = DA2(m.density_m_rho0, k0, n), rp = DA2(m.density_m_rho0, k0 + 1, n);
-      double dx10 = zc - zm, dx21 = zp - zc, dx20 = zp - zm, df10 = rc - rm, df21 = rp - rc;
-      drho_dz[ni] = df10 / dx10 + (dx10 * df21 - dx21 * df10) / (dx20 * dx21 * dx10) * ((Zn - zc) + (Zn - zm));
-      rho_c[ni] = (k0 == nlz) ? rc : DA2(m.density_m_rho0, nlz, n);
+      const double zm = DA2(m.Z_3d_n, k0 - 1, n), zc = DA2(m.Z_3d_n, k0, n);
+      drho_dz[ni] = DA2(m.pgf_A, k0, n) + DA2(m.pgf_B, k0, n) * ((Zn - zc) + (Zn - zm));      // (the quotients: k_pressure_bv)
+      rho_c[ni] = DA2(m.density_m_rho0, nlz, n);
       z_c[ni] = (k0 == nlz) ? zc : DA2(m.Z_3d_n, nlz, n);
     }
     double s3 = (drho_dz[0] + drho_dz[1] + drho_dz[2]) / 3.0;
@@ -389,11 +401,9 @@ __global__ void __launch_bounds__(BLOCK) k_pgf_tile(DM m) {
         if (nlz == ule && (nlz - (lv[ni] & 0xff)) == 0) k0 = nlz + 1;
         else if (nlz == nle && nlz != ule && ((lv[ni] >> 8) - nlz) == 0) k0 = nlz - 1;
         else k0 = nlz;
-        double zm = UA2(m.Z_3d_n, k0 - 1, n), zc = UA2(m.Z_3d_n, k0, n), zp = UA2(m.Z_3d_n, k0 + 1, n);      // (node index wave-uniform: scalar column base)
-        double rm = UA2(m.density_m_rho0, k0 - 1, n), rc = UA2(m.density_m_rho0, k0, n), rp = UA2(m.density_m_rho0, k0 + 1, n);
-        double dx10 = zc - zm, dx21 = zp - zc, dx20 = zp - zm, df10 = rc - rm, df21 = rp - rc;
-        drho_dz[ni] = df10 / dx10 + (dx10 * df21 - dx21 * df10) / (dx20 * dx21 * dx10) * ((Zn - zc) + (Zn - zm));
-        rho_c[ni] = (k0 == nlz) ? rc : UA2(m.density_m_rho0, nlz, n);
+        const double zm = UA2(m.Z_3d_n, k0 - 1, n), zc = UA2(m.Z_3d_n, k0, n);      // (node index wave-uniform: scalar column base)
+        drho_dz[ni] = UA2(m.pgf_A, k0, n) + UA2(m.pgf_B, k0, n) * ((Zn - zc) + (Zn - zm));      // (the node column's two quotients: k_pressure_bv)
+        rho_c[ni] = UA2(m.density_m_rho0, nlz, n);
         z_c[ni] = (k0 == nlz) ? zc : UA2(m.Z_3d_n, nlz, n);
       }
       double s3 = (drho_dz[0] + drho_dz[1] + drho_dz[2]) / 3.0;
@@ -441,7 +451,7 @@ static void launch_pgf(const DM &m, hipStream_t s) {
 // compute_sigma_xy (:2826-2900) fused with compute_neutral_slope (:2905-2946): node gathers T,S at the
 // 3 nodes of each surrounding element.  20 N3 values.
 __global__ void __launch_bounds__(BLOCK) k_sigma_slope(DM m) {
-  int n = col_id(), l = lane_id(), nz = l + 1;
+  int n = col_id(m), l = lane_id(), nz = l + 1;
   if (n >= m.myN) return;
   const int nln = m.nlev_n[n] - 1, uln = m.ulev_n[n];
   const bool wet = (nz >= uln && nz <= nln);
@@ -552,11 +562,11 @@ __device__ __forceinline__ void pp_node_body(const DM &m, int n) {     // Kv: Ri
   if (nzmin <= 1 && m.p.use_windmix && nz <= m.p.windmix_nl + 1) kv = dmax_(kv, m.p.windmix_kv);
   DA2L(m.Kv, nz, n) = kv;
 }
-__global__ void __launch_bounds__(BLOCK) k_pp_elem(DM m) { pp_elem_body(m, col_id()); }
-__global__ void __launch_bounds__(BLOCK) k_pp_node_final(DM m) { pp_node_body(m, col_id()); }
+__global__ void __launch_bounds__(BLOCK) k_pp_elem(DM m) { pp_elem_body(m, col_id(m)); }
+__global__ void __launch_bounds__(BLOCK) k_pp_node_final(DM m) { pp_node_body(m, col_id(m)); }
 // oce_mixing_PP + mo_convect in one launch: the first ncolE column slots are element columns, the rest node columns
 __global__ void __launch_bounds__(BLOCK) k_pp(DM m, int ncolE) {
-  const int c = col_id();
+  const int c = col_id(m);
   if (c < ncolE) pp_elem_body(m, c); else pp_node_body(m, c - ncolE);
 }
 
@@ -567,7 +577,7 @@ __global__ void __launch_bounds__(BLOCK) k_pp(DM m, int ncolE) {
 // (lane k = k-th element / edge) and broadcast with v_readlane; the field loads of MA_B elements / edges are issued as one batch before the ordered
 // sums -- no chain of dependent loads per element or edge (same arithmetic and order as the plain loops).
 __global__ void __launch_bounds__(BLOCK) k_momadv_node(DM m) {
-  int n = col_id(), l = lane_id(), nz = l + 1;
+  int n = col_id(m), l = lane_id(), nz = l + 1;
   if (n >= m.myN) return;
   const int nl1 = m.nlev_n[n] - 1, ul1 = m.ulev_n[n];
   const int nzc = nz <= m.nlm1 ? nz : m.nlm1, nzm = nzc > 1 ? nzc - 1 : 1;
@@ -672,7 +682,7 @@ __global__ void __launch_bounds__(BLOCK) k_momadv_node(DM m) {
 // then (after relative_vorticity = k_leith_vort) the element part: old AB term, gradient of g eta + p/rho0, (f + zeta) k x u, gradient of the
 // kinetic energy, AB2 update.  The reference's vertical term is multiplied by w = 0 (:122): nothing to add.
 __global__ void __launch_bounds__(BLOCK) k_vinv_ke(DM m) {
-  const int n = col_id(), nz = lane_id() + 1;
+  const int n = col_id(m), nz = lane_id() + 1;
   if (n >= m.myN || nz > m.nlm1) return;
   double ke = 0.0;
   const int num = m.nie_num[n];
@@ -687,7 +697,7 @@ __global__ void __launch_bounds__(BLOCK) k_vinv_ke(DM m) {
   DA2(m.KE_node, nz, n) = ke;
 }
 __global__ void __launch_bounds__(BLOCK) k_vinv_elem(DM m, int first_step) {
-  const int e = col_id(), nz = lane_id() + 1;
+  const int e = col_id(m), nz = lane_id() + 1;
   if (e >= m.myE) return;
   if (nz < m.ulev[e] || nz > m.nlev[e] - 1) return;
   const int n0 = m.elem_nodes[3 * e], n1 = m.elem_nodes[3 * e + 1], n2 = m.elem_nodes[3 * e + 2];
@@ -711,7 +721,7 @@ __global__ void __launch_bounds__(BLOCK) k_vinv_elem(DM m, int first_step) {
 // compute_vel_rhs (src/oce_ale_vel_rhs.F90:13-148) incl. the element part of momentum_adv_scalar (:333-343):
 // one streaming pass per element column.  16 E3 values.
 __global__ void __launch_bounds__(BLOCK) k_vel_rhs(DM m, int first_step) {
-  int e = col_id(), nz = lane_id() + 1;
+  int e = col_id(m), nz = lane_id() + 1;
   if (e >= m.myE) return;
   if (nz < m.ulev[e] || nz > m.nlev[e] - 1) return;
   const double eps = m.p.epsilon, dt = m.p.dt;
@@ -739,7 +749,7 @@ __global__ void __launch_bounds__(BLOCK) k_vel_rhs(DM m, int first_step) {
 // relative_vorticity (src/oce_vel_rhs_vinv.F90:14-102): circulation around the scalar control volume, gathered over the node's
 // incident owned edges in the reference's edge order, / areasvol.  Owned nodes; halo nodes arrive by exchange.
 __global__ void __launch_bounds__(BLOCK) k_leith_vort(DM m) {
-  int n = col_id(), nz = lane_id() + 1;
+  int n = col_id(m), nz = lane_id() + 1;
   if (n >= m.myN || nz > m.nlm1) return;
   double vo = 0.0;
   for (int q = m.ne_ptr[n]; q < m.ne_ptr[n + 1]; q++) {
@@ -760,7 +770,7 @@ __global__ void __launch_bounds__(BLOCK) k_leith_vort(DM m) {
 // Leith + modified Leith coefficient on the owned elements (:483-523); halo elements hold 0 through the smoothing rounds, as in
 // the reference (Visc = 0 at :482, exchange_elem only after the rounds :558)
 __global__ void __launch_bounds__(BLOCK) k_leith_elem(DM m) {
-  int e = col_id(), l = lane_id(), nz = l + 1;
+  int e = col_id(m), l = lane_id(), nz = l + 1;
   if (e >= m.E) return;
   double vi = 0.0;
   if (e < m.myE) {
@@ -785,7 +795,7 @@ __global__ void __launch_bounds__(BLOCK) k_leith_elem(DM m) {
 }
 // the two smoothing rounds (:527-557): area-weighted node average over the element cluster, then the mean of the three nodes
 __global__ void __launch_bounds__(BLOCK) k_leith_node(DM m) {
-  int n = col_id(), nz = lane_id() + 1;
+  int n = col_id(m), nz = lane_id() + 1;
   if (n >= m.myN) return;
   if (nz < m.ulev_n[n] || nz > m.nlev_n[n] - 1) return;
   double dz = 0.0, vi = 0.0;
@@ -799,7 +809,7 @@ __global__ void __launch_bounds__(BLOCK) k_leith_node(DM m) {
   DA2(m.leith_aux, nz, n) = vi / dz;
 }
 __global__ void __launch_bounds__(BLOCK) k_leith_avg(DM m) {
-  int e = col_id(), nz = lane_id() + 1;
+  int e = col_id(m), nz = lane_id() + 1;
   if (e >= m.myE || nz > m.nlm1) return;
   double vi = 0.0;
   if (nz >= m.ulev[e] && nz <= m.nlev[e] - 1) {
@@ -815,7 +825,7 @@ __global__ void __launch_bounds__(BLOCK) k_leith_avg(DM m) {
 // visc_option 4 / 6 / 7 (visc_filt_biharm(1) :275-372, visc_filt_bilapl :658-726, visc_filt_bidiff :734-801): the same gather is the first stage of the
 // biharmonic operator (the result lives in U_b, the reference's U_c/V_c), the second stage is k_visc_apply.
 __global__ void __launch_bounds__(BLOCK) k_visc_elem(DM m) {
-  int e = col_id(), nz = lane_id() + 1;
+  int e = col_id(m), nz = lane_id() + 1;
   if (e >= m.E) return;
   if (nz > m.nlm1) return;
   double ub = 0.0, vb = 0.0;
@@ -870,7 +880,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_elem(DM m) {
 // second stage of visc_option 6 / 7 (:709-724, :781-799): UV_rhs += differences of the first-stage field over the internal
 // edges of the element, in the reference's edge order
 __global__ void __launch_bounds__(BLOCK) k_visc_apply(DM m) {
-  int e = col_id(), nz = lane_id() + 1;
+  int e = col_id(m), nz = lane_id() + 1;
   if (e >= m.myE) return;
   if (nz > m.nlm1) return;
   const double dt = m.p.dt, g0 = m.p.gamma0, g1 = m.p.gamma1, g2 = m.p.gamma2;
@@ -919,7 +929,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_apply(DM m) {
   DV2(m.UV_rhs, 2, nz, e) = vr;
 }
 __global__ void __launch_bounds__(BLOCK) k_visc_node(DM m) {
-  int n = col_id(), nz = lane_id() + 1;
+  int n = col_id(m), nz = lane_id() + 1;
   if (n >= m.myN) return;
   if (nz < m.ulev_n[n] || nz > m.nlev_n[n] - 1) return;
   double vi = 0.0, u1 = 0.0, v1 = 0.0;
@@ -1072,7 +1082,7 @@ __global__ void k_stiff_update(DM m) {
 // compute_ssh_rhs_ale (:1478-1572) and compute_hbar_ale (:1585-1676): per-edge vertical integrals
 // (reference-order running sums), then a node gather.  mode 0: with UV_rhs and alpha; mode 1: UV only.
 __global__ void __launch_bounds__(BLOCK) k_edge_transport(DM m, int mode) {
-  int ed = col_id(), l = lane_id(), nz = l + 1;
+  int ed = col_id(m), l = lane_id(), nz = l + 1;
   if (ed >= m.myD) return;
   int e1 = m.edge_tri[2 * ed], e2 = m.edge_tri[2 * ed + 1];
   const double alpha = m.p.alpha;
@@ -1195,7 +1205,7 @@ __global__ void k_dhe(DM m) {
 
 // update_vel (src/oce_dyn.F90:101-131); the 2-D eta_n += d_eta rides along on extra threads.
 __global__ void __launch_bounds__(BLOCK) k_update_vel(DM m) {
-  int e = col_id(), nz = lane_id() + 1;
+  int e = col_id(m), nz = lane_id() + 1;
   int gid = blockIdx.x * BLOCK + threadIdx.x;
   if (gid < m.N) m.eta_n[gid] = m.eta_n[gid] + m.d_eta[gid];
   if (e >= m.myE) return;
@@ -1213,7 +1223,7 @@ __global__ void __launch_bounds__(BLOCK) k_update_vel(DM m) {
 // edges, bottom-up running sum, /area, zstar distribution of d(hbar), CFL_z, explicit/implicit split.
 // 20 N3 + 3 E3 values.
 __global__ void __launch_bounds__(BLOCK) k_vert_vel(DM m, int fuse_hbar) {
-  int n = col_id(), l = lane_id(), nz = l + 1;
+  int n = col_id(m), l = lane_id(), nz = l + 1;
   if (n >= m.myN) return;
   const int nzmin = m.ulev_n[n], nzmax = m.nlev_n[n] - 1;
   const double dt = m.p.dt;
@@ -1394,11 +1404,11 @@ __device__ __forceinline__ void thick_elem_body(const DM &m, int e) {
   // makes the element part independent of the node part, so both run in ONE launch (k_thick)
   DA2(m.helem, nz, e) = (DA2(m.hnode_new, nz, n1) + DA2(m.hnode_new, nz, n2) + DA2(m.hnode_new, nz, n3)) / 3.0;
 }
-__global__ void __launch_bounds__(BLOCK) k_thick_node(DM m) { thick_node_body(m, col_id()); }
-__global__ void __launch_bounds__(BLOCK) k_thick_elem(DM m) { thick_elem_body(m, col_id()); }
+__global__ void __launch_bounds__(BLOCK) k_thick_node(DM m) { thick_node_body(m, col_id(m)); }
+__global__ void __launch_bounds__(BLOCK) k_thick_elem(DM m) { thick_elem_body(m, col_id(m)); }
 // update_thickness_ale in one launch: the first ncolN column slots are node columns, the rest element columns
 __global__ void __launch_bounds__(BLOCK) k_thick(DM m, int ncolN) {
-  const int c = col_id();
+  const int c = col_id(m);
   if (c < ncolN) thick_node_body(m, c); else thick_elem_body(m, c - ncolN);
 }
 

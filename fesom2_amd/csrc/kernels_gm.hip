@@ -9,7 +9,7 @@
 // init_Redi_GM (:159-340), GM part.  The horizontal factor that only depends on the mesh (resolution scaling with a real
 // exponent -> libm pow, resolution ramp) is prepared on the host at fesom_gpu_init (gm_scal_static).
 __global__ void __launch_bounds__(BLOCK) k_gm_coef(DM m) {
-  int n = col_id(), l = lane_id(), nz = l + 1;
+  int n = col_id(m), l = lane_id(), nz = l + 1;
   if (n >= m.myN) return;
   const int nzmax1 = m.nlev_n_min[n], nzmin1 = m.ulev_n_max[n];
   const double c_min = 0.5, pi = 3.14159265358979;
@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(BLOCK) k_gm_coef(DM m) {
 // fer_solve_Gamma (:8-120): tridiagonal problem per node column with two right-hand sides; the sweep runs in the block
 __global__ void __launch_bounds__(TH_BLOCK) k_fer_gamma(DM m) {
   extern __shared__ double th_sh[];
-  int n = col_id_th(), l = lane_id(), nz = l + 1;
+  int n = col_id_th(m), l = lane_id(), nz = l + 1;
   const bool valid = n < m.myN;
   if (!valid) n = m.myN - 1;
   int nzmax = m.nlev_n[n], nzmin = m.ulev_n[n];
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(TH_BLOCK) k_fer_gamma(DM m) {
 
 // fer_gamma2vel (:125-154)
 __global__ void __launch_bounds__(BLOCK) k_fer_uv(DM m) {
-  int el = col_id(), nz = lane_id() + 1;
+  int el = col_id(m), nz = lane_id() + 1;
   if (el >= m.myE) return;
   if (nz < m.ulev[el] || nz > m.nlev[el] - 1) return;
   const double onethird = 1. / 3.;
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(BLOCK) k_fer_uv(DM m) {
 // fer_Wvel of vert_vel_ale: divergence of the bolus transports gathered over the node's edges in edge order, summed
 // bottom-up, divided by the area
 __global__ void __launch_bounds__(BLOCK) k_fer_wvel(DM m) {
-  int n = col_id(), l = lane_id(), nz = l + 1;
+  int n = col_id(m), l = lane_id(), nz = l + 1;
   if (n >= m.myN) return;
   const int nzmin = m.ulev_n[n], nzmax = m.nlev_n[n] - 1;
   double w = 0.0;

@@ -53,7 +53,7 @@ __device__ __forceinline__ void kpp_wscale(const DM &m, double zehat, double us,
 }
 
 __global__ void __launch_bounds__(BLOCK) k_kpp_col(DM m) {
-  const int n = col_id(), l = lane_id(), nz = l + 1;
+  const int n = col_id(m), l = lane_id(), nz = l + 1;
   if (n >= m.myN) return;
   const int nzmin = m.ulev_n[n], nzmax = m.nlev_n[n];
   const bool lay = (nz >= nzmin && nz <= nzmax - 1);                 // layers
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(BLOCK) k_kpp_col(DM m) {
 // different buffers (the reference gathers into work_array before it overwrites arr); levels outside uln..nln keep the
 // value 0 they have in blmc.  The patch areas are summed again in every sweep, in the same order (same value as `vol`).
 __global__ void __launch_bounds__(BLOCK) k_kpp_smooth(DM m, const double *src, double *dst) {
-  const int n = col_id(), l = lane_id(), nz = l + 1;
+  const int n = col_id(m), l = lane_id(), nz = l + 1;
   if (n >= m.myN) return;
   const size_t off = (size_t)blockIdx.y * m.nl * m.N;
   const double *a = src + off;
@@ -373,11 +373,11 @@ __device__ __forceinline__ void kpp_elem_body(const DM &m, int e) {
   }
   DA2L(m.Av, nz, e) = av;
 }
-__global__ void __launch_bounds__(BLOCK) k_kpp_final(DM m) { kpp_final_body(m, col_id()); }
-__global__ void __launch_bounds__(BLOCK) k_kpp_elem(DM m) { kpp_elem_body<false>(m, col_id()); }
+__global__ void __launch_bounds__(BLOCK) k_kpp_final(DM m) { kpp_final_body(m, col_id(m)); }
+__global__ void __launch_bounds__(BLOCK) k_kpp_elem(DM m) { kpp_elem_body<false>(m, col_id(m)); }
 // single partition: both in ONE launch (first ncolE column slots are element columns), one dependent launch less on the critical chain
 __global__ void __launch_bounds__(BLOCK) k_kpp_final_elem(DM m, int ncolE) {
-  const int c = col_id();
+  const int c = col_id(m);
   if (c < ncolE) kpp_elem_body<true>(m, c); else kpp_final_body(m, c - ncolE);
 }
 

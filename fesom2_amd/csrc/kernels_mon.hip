@@ -15,7 +15,7 @@ __device__ __forceinline__ double wmax(double x) { for (int s = 32; s >= 1; s >>
 __device__ __forceinline__ double wsum(double x) { for (int s = 32; s >= 1; s >>= 1) x = x + __shfl_xor(x, s, 64); return x; }
 
 __global__ void __launch_bounds__(BLOCK) k_mon_col(DM m, double *col) {
-  const int n = col_id(), l = lane_id(), nz = l + 1;
+  const int n = col_id(m), l = lane_id(), nz = l + 1;
   if (n >= m.myN) return;
   const double BIG = 1.0e300;
   double tmin = BIG, tmax = -BIG, smin = BIG, smax = -BIG, cfl = -BIG, kv = -BIG, px = -BIG, py = -BIG, av = -BIG, blow = 0.0;

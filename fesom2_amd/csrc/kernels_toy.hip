@@ -11,7 +11,7 @@
 // compute_zonal_mean (:157-217): one wavefront per latitude bin, lane = level; the elements of the bin are summed in
 // element order (the reference's loop order on one partition), then divided by (count + 0.001).
 __global__ void __launch_bounds__(BLOCK) k_toy_zonal_mean(DM m) {
-  int b = col_id(), nz = lane_id() + 1;
+  int b = col_id(m), nz = lane_id() + 1;
   if (b >= 100 || nz > m.nlm1) return;
   double zt = 0.0, zv = 0.0;
   for (int q = m.toy_bptr[b]; q < m.toy_bptr[b + 1]; q++) {
@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(BLOCK) k_toy_zonal_mean(DM m) {
 // Partitioned runs: the rank-local sums (every element once: where its first node is owned, :167) first, then the host's / the
 // library's all-reduce over the ranks (the two MPI_AllREDUCE of :182-203), then the division by the global count.
 __global__ void __launch_bounds__(BLOCK) k_toy_zonal_sum(DM m) {
-  int b = col_id(), nz = lane_id() + 1;
+  int b = col_id(m), nz = lane_id() + 1;
   if (b >= 100 || nz > m.nlm1) return;
   double zt = 0.0, zv = 0.0;
   for (int q = m.toy_bptr[b]; q < m.toy_bptr[b + 1]; q++) {
@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(BLOCK) k_toy_zonal_sum(DM m) {
   m.toy_ztem[(size_t)b * m.nlm1 + nz - 1] = zt;
 }
 __global__ void __launch_bounds__(BLOCK) k_toy_zonal_div(DM m) {
-  int b = col_id(), nz = lane_id() + 1;
+  int b = col_id(m), nz = lane_id() + 1;
   if (b >= 100 || nz > m.nlm1) return;
   double cnt = m.toy_znum[b];
   m.toy_zvel[(size_t)b * m.nlm1 + nz - 1] = m.toy_zvel[(size_t)b * m.nlm1 + nz - 1] / (cnt + 0.001);
@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(BLOCK) k_toy_zonal_div(DM m) {
 
 // relax_zonal_vel (:46-79)
 __global__ void __launch_bounds__(BLOCK) k_toy_relax_vel(DM m) {
-  int e = col_id(), nz = lane_id() + 1;
+  int e = col_id(m), nz = lane_id() + 1;
   if (e >= m.myE || nz > m.nlev[e] - 1) return;
   const double tau_inv = 1.0 / 50.0 / 24.0 / 3600.0;
   int nn = m.toy_e_nn[2 * e], nn1 = m.toy_e_nn[2 * e + 1];
@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(BLOCK) k_toy_relax_vel(DM m) {
 
 // relax_zonal_temp (:81-103), owned + halo nodes
 __global__ void __launch_bounds__(BLOCK) k_toy_relax_temp(DM m) {
-  int n = col_id(), nz = lane_id() + 1;
+  int n = col_id(m), nz = lane_id() + 1;
   if (n >= m.N || nz > m.nlev_n[n] - 1) return;
   const double tau_inv = 1.0 / 50.0 / 24.0 / 3600.0;
   int nn = m.toy_n_nn[2 * n], nn1 = m.toy_n_nn[2 * n + 1];

@@ -26,7 +26,7 @@ __device__ __forceinline__ TV tracer_view(const DM &m, int tr) {
 // the SSH solve) while tr_z needs hnode_new of this step's vert_vel_ale.
 __global__ void __launch_bounds__(BLOCK) k_tr_ab(DM m, int tr0) {
   const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
-  int n = col_id(), nz = lane_id() + 1;
+  int n = col_id(m), nz = lane_id() + 1;
   if (n >= m.N || nz > m.nlm1) return;
   const double eps = m.p.epsilon;
   double cur = DTR(m.tr_arr, nz, n, tr);
@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(BLOCK) k_tr_ab(DM m, int tr0) {
 __global__ void __launch_bounds__(BLOCK) k_tr_z(DM m, int tr0) {
   const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   const TV t = tracer_view(m, tr);
-  int n = col_id(), nz = lane_id() + 1;
+  int n = col_id(m), nz = lane_id() + 1;
   if (n >= m.N) return;
   int nzmax = m.nlev_n[n], nzmin = m.ulev_n[n];
   if (nz >= nzmin + 1 && nz <= nzmax - 1) {
@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(BLOCK) k_tr_z(DM m, int tr0) {
 __global__ void __launch_bounds__(BLOCK) k_tr_grad_elem(DM m, int tr0) {
   const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   const TV t = tracer_view(m, tr);
-  int e = col_id(), nz = lane_id() + 1;
+  int e = col_id(m), nz = lane_id() + 1;
   if (e >= m.myE) return;
   if (nz < m.ulev[e] || nz > m.nlev[e] - 1) return;
   int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
@@ -100,7 +100,7 @@ __device__ __forceinline__ void updn_grad(const DM &m, const TV &t, int ed, int 
 __global__ void __launch_bounds__(BLOCK) k_updn_grad(DM m, int tr0) {
   const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   const TV t = tracer_view(m, tr);
-  int ed = col_id(), nz = lane_id() + 1;
+  int ed = col_id(m), nz = lane_id() + 1;
   if (ed >= m.myD) return;
   if (nz > m.nlm1) return;
   double g1, g2, g3, g4;
@@ -120,7 +120,7 @@ template <bool FUSED>
 __global__ void __launch_bounds__(BLOCK) k_flux_hor(DM m, int tr0) {
   const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   const TV t = tracer_view(m, tr);
-  int ed = col_id(), nz = lane_id() + 1;
+  int ed = col_id(m), nz = lane_id() + 1;
   if (ed >= m.myD) return;
   if (nz > m.nlm1) return;
   int n1 = m.edges[2 * ed], n2 = m.edges[2 * ed + 1], e1 = m.edge_tri[2 * ed], e2 = m.edge_tri[2 * ed + 1];
@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(BLOCK) k_flux_hor(DM m, int tr0) {
 __global__ void __launch_bounds__(BLOCK) k_fct_lo_node(DM m, int tr0) {
   const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   const TV t = tracer_view(m, tr);
-  int n = col_id(), l = lane_id(), nz = l + 1;
+  int n = col_id(m), l = lane_id(), nz = l + 1;
   if (n >= m.myN) return;
   const int nzmin = m.ulev_n[n], nzmax = m.nlev_n[n];
   const double dt = m.p.dt, num_ord = m.p.tra_adv_pv;
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(TH_BLOCK) k_fct_lo_wimpl(DM m, int tr0) {
   extern __shared__ double th_sh[];
   const int tr = tr0 + blockIdx.y;
   const TV t = tracer_view(m, tr);
-  int n = col_id_th(), l = lane_id(), nz = l + 1;
+  int n = col_id_th(m), l = lane_id(), nz = l + 1;
   const bool valid = n < m.myN;
   if (!valid) n = m.myN - 1;
   const int nzmin = m.ulev_n[n], nzmax = m.nlev_n[n];
@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(TH_BLOCK) k_fct_lo_wimpl(DM m, int tr0) {
 __global__ void __launch_bounds__(BLOCK) k_fct_node(DM m, int tr0) {
   const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   const TV t = tracer_view(m, tr);
-  int n = col_id(), l = lane_id(), nz = l + 1;
+  int n = col_id(m), l = lane_id(), nz = l + 1;
   if (n >= m.myN) return;
   const int nu1 = m.ulev_n[n], nl1 = m.nlev_n[n];
   const double dt = m.p.dt, flux_eps = 1e-16;
@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(BLOCK) k_fct_node(DM m, int tr0) {
 __global__ void __launch_bounds__(BLOCK) k_fct_edge_limit(DM m, int tr0) {
   const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   const TV t = tracer_view(m, tr);
-  int ed = col_id(), nz = lane_id() + 1;
+  int ed = col_id(m), nz = lane_id() + 1;
   if (ed >= m.myD) return;
   int n1 = m.edges[2 * ed], n2 = m.edges[2 * ed + 1], e1 = m.edge_tri[2 * ed], e2 = m.edge_tri[2 * ed + 1];
   int nl12 = m.nlev[e1] - 1, nu12 = m.ulev[e1];
@@ -490,7 +490,7 @@ template <bool REDI>
 __global__ void __launch_bounds__(BLOCK) k_diff_flux(DM m, int tr0) {
   const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
   const TV t = tracer_view(m, tr);
-  int ed = col_id(), nz = lane_id() + 1;
+  int ed = col_id(m), nz = lane_id() + 1;
   if (ed >= m.myD || nz > m.nlm1) return;
   int n1 = m.edges[2 * ed], n2 = m.edges[2 * ed + 1], e1 = m.edge_tri[2 * ed], e2 = m.edge_tri[2 * ed + 1];
   int nl1 = m.nlev[e1] - 1, ul1 = m.ulev[e1], nl2 = 0, ul2 = 0;
@@ -841,7 +841,7 @@ __global__ void k_spp(DM m) {
 // relax_to_clim (clim_relax > 0, src/oce_tracer_mod.F90:86-121) after diff_tracers_ale: T and S of the owned nodes towards the climatology at the nodal rate
 // relax2clim; the salinity clamp follows it as in the reference.  grid.y = tracer (0, 1).
 __global__ void __launch_bounds__(BLOCK) k_relax_clim(DM m, int tr0) {
-  const int tr = tr0 + blockIdx.y, n = col_id(), nz = lane_id() + 1;
+  const int tr = tr0 + blockIdx.y, n = col_id(m), nz = lane_id() + 1;
   if (n >= m.myN || nz < m.ulev_n[n] || nz > m.nlev_n[n] - 1) return;
   const double *cl = tr == 0 ? m.Tclim : m.Sclim;
   double T = DTR(m.tr_arr, nz, n, tr);
@@ -849,7 +849,7 @@ __global__ void __launch_bounds__(BLOCK) k_relax_clim(DM m, int tr0) {
   DTR(m.tr_arr, nz, n, tr) = tru_clamp(T, tr);
 }
 __global__ void __launch_bounds__(BLOCK) k_bh1(DM m, int tr0) {
-  const int tr = tr0 + blockIdx.y, n = col_id(), nz = lane_id() + 1;
+  const int tr = tr0 + blockIdx.y, n = col_id(m), nz = lane_id() + 1;
   if (n >= m.myN || nz > m.nlm1) return;
   double tmp = 0.0;
   for (int q = m.ne_ptr[n]; q < m.ne_ptr[n + 1]; q++) {
@@ -862,7 +862,7 @@ __global__ void __launch_bounds__(BLOCK) k_bh1(DM m, int tr0) {
   DTR(m.bh_tmp, nz, n, tr) = tmp;
 }
 __global__ void __launch_bounds__(BLOCK) k_bh2(DM m, int tr0) {
-  const int tr = tr0 + blockIdx.y, n = col_id(), nz = lane_id() + 1;
+  const int tr = tr0 + blockIdx.y, n = col_id(m), nz = lane_id() + 1;
   if (n >= m.myN || nz > m.nlm1) return;
   double T = DTR(m.tr_arr, nz, n, tr);
   const double ar = DA2L(m.area, nz, n);
@@ -888,7 +888,7 @@ __global__ void __launch_bounds__(WAVE * WAVES, (WAVES == 8) ? 4 : 2) k_tr_updat
   TruCol k;
   double Ts[NT] = {}, rhs[NT] = {};
   for (int ci = w; ci < COLS; ci += WAVES) {
-    const int n = __builtin_amdgcn_readfirstlane(base + ci);
+    const int n = __builtin_amdgcn_readfirstlane(sub_col(m, base + ci));
     if (n >= m.myN && n < m.N && nz <= m.nlm1) {           // halo columns: only tr_arr_old(:,:,tr) = tr_arr(:,:,tr) (whole-array copy, :274)
 #pragma unroll
       for (int t = 0; t < NT; t++) if (trA + t < m.ntr) DTR(m.tr_arr_old, nz, n, trA + t) = DTR(m.tr_arr, nz, n, trA + t);
@@ -939,7 +939,7 @@ __global__ void __launch_bounds__(WAVE * WAVES, (WAVES == 8) ? 4 : 2) k_tr_updat
     tile.get(ci, dT[0], dT[1]);
     int n = k.n; bool wet = k.wet;
     if (!SINGLE) {
-      n = __builtin_amdgcn_readfirstlane(base + ci);
+      n = __builtin_amdgcn_readfirstlane(sub_col(m, base + ci));
       wet = n < m.myN;
       if (wet) wet = nz >= m.ulev_n[n] && nz <= m.nlev_n[n] - 1;
     }
@@ -953,11 +953,11 @@ __global__ void __launch_bounds__(WAVE * WAVES, (WAVES == 8) ? 4 : 2) k_tr_updat
 }
 
 // tr >= 0: that tracer only; tr < 0: all tracers in one launch (grid.y), their chains are independent
-#define LAUNCH_COL(k, ncol, m_, tr_) hipLaunchKernelGGL(k, dim3(nblocks(ncol), (tr_) < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m_, (tr_) < 0 ? 0 : (tr_))
+#define LAUNCH_COL(k, ncol, m_, tr_) hipLaunchKernelGGL(k, dim3(nblocks(SUBN(m_, ncol)), (tr_) < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m_, (tr_) < 0 ? 0 : (tr_))
 // one column per wave, one tracer per block row (pi) -- or tiles with both tracers per block (DM::use_tile; all tracers of the launch)
-#define LAUNCH_TRU1(R, m_, tr_) hipLaunchKernelGGL((k_tr_update<R, 1, TH_COLS, TH_COLS>), dim3(nblocks_th(m.N), (tr_) < 0 ? m.ntr : 1), dim3(TH_BLOCK), (ThTile<1, TH_COLS>::lds_bytes(m.nlm1)), s, m_, (tr_) < 0 ? 0 : (tr_))
-#define LAUNCH_TRU2(R, m_) hipLaunchKernelGGL((k_tr_update<R, 2, TH_COLS, TH_COLS>), dim3(nblocks_th(m.N), (m.ntr + 1) / 2), dim3(TH_BLOCK), (ThTile<2, TH_COLS>::lds_bytes(m.nlm1)), s, m_, 0)
-#define TRU_SHAPE(id, C_, W_) case id: hipLaunchKernelGGL((k_tr_update<R_, NT_, C_, W_>), dim3((m.N + C_ - 1) / C_, gy), dim3(WAVE * W_), (ThTile<NT_, C_>::lds_bytes(m.nlm1)), s, m, tr0); break;
+#define LAUNCH_TRU1(R, m_, tr_) hipLaunchKernelGGL((k_tr_update<R, 1, TH_COLS, TH_COLS>), dim3(nblocks_th(SUBN(m_, m.N)), (tr_) < 0 ? m.ntr : 1), dim3(TH_BLOCK), (ThTile<1, TH_COLS>::lds_bytes(m.nlm1)), s, m_, (tr_) < 0 ? 0 : (tr_))
+#define LAUNCH_TRU2(R, m_) hipLaunchKernelGGL((k_tr_update<R, 2, TH_COLS, TH_COLS>), dim3(nblocks_th(SUBN(m_, m.N)), (m.ntr + 1) / 2), dim3(TH_BLOCK), (ThTile<2, TH_COLS>::lds_bytes(m.nlm1)), s, m_, 0)
+#define TRU_SHAPE(id, C_, W_) case id: hipLaunchKernelGGL((k_tr_update<R_, NT_, C_, W_>), dim3((SUBN(m, m.N) + C_ - 1) / C_, gy), dim3(WAVE * W_), (ThTile<NT_, C_>::lds_bytes(m.nlm1)), s, m, tr0); break;
 template <bool R_, int NT_> static void launch_tru_tile(const DM &m, hipStream_t s, int gy, int tr0) { switch (m.use_tile) { TILE_SHAPES(TRU_SHAPE) default: break; } }
 #define LAUNCH_TRU(m_, tr_) do { if (m.use_tile && (tr_) < 0) { if (m.p.Redi) launch_tru_tile<true, 2>(m_, s, (m.ntr + 1) / 2, 0); else launch_tru_tile<false, 2>(m_, s, (m.ntr + 1) / 2, 0); } \
   else if (m.use_tile) { if (m.p.Redi) launch_tru_tile<true, 1>(m_, s, 1, tr_); else launch_tru_tile<false, 1>(m_, s, 1, tr_); }   /* one named tracer (routine-level tests) */ \

@@ -81,6 +81,27 @@ def pi(physics="default", refine=0):
                     physics=physics, levels=refine)
 
 
+def basin(levels=3, layers=47, workdir=None):
+    """BASELINE config #3 in kind with the reference's DEFAULT physics: the channel geometry refined `levels` times (3 -> 182 600 nodes) with an
+    analytic bathymetry (continental slopes, a ridge, seamounts: ragged bottom levels, partial cells; levels by the reference partitioner's
+    rule), Jackett-McDougall EOS, KPP + GM + Redi, analytic T/S and surface forcing as on pi -- setups/core2/setup.yml:7-12 keeps
+    config/namelist.oce as it is.  No toy hooks.  The reference runs it too (oracle/ref/run_ref.py:basin_case)."""
+    d = os.path.join(workdir or tempfile.gettempdir(), f"fesom_basin_r{levels}_{layers}")
+    if not os.path.exists(os.path.join(d, "nlvls.out")):
+        tmp = d + f".tmp{os.getpid()}"
+        channel_mesh.build_basin(os.path.join(MESHES, "soufflet"), tmp, levels, layers)
+        try:
+            os.rename(tmp, d)
+        except OSError:                 # another rank got there first
+            import shutil
+            shutil.rmtree(tmp, ignore_errors=True)
+    dt = channel_mesh.dt_for(levels)
+    return Workload("basin", d, channel_mesh.basin_mesh_kw(levels), channel_mesh.basin_param_kw(levels), dt,
+                    f"channel basin (Soufflet channel geometry refined {levels}x, analytic bathymetry with slopes / ridge / seamounts, partial cells), {layers} layers, T/S tracers, "
+                    f"zstar ALE, JM EOS, KPP + GM + Redi (namelist.oce defaults), MFCT/QR4C/FCT advection, analytic wind/heat/fresh-water forcing, dt = {dt:g} s",
+                    physics="default", levels=levels, layers=layers)
+
+
 def channel(levels=3, layers=47, workdir=None):
     d = os.path.join(workdir or tempfile.gettempdir(), f"fesom_chan_r{levels}_{layers}")
     if not os.path.exists(os.path.join(d, "nlvls.out")):

@@ -149,6 +149,13 @@ program oracle_driver
   call mesh_setup(mesh)
   call check_mesh_consistency(mesh)
   call ocean_setup(mesh)
+  ! toy_ocean with a toy the reference does not know: nothing of a toy is hooked in (every hook asks for which_toy == 'soufflet'), only the
+  ! rotation sanity check of read_mesh is skipped (src/oce_mesh.F90:359,380) -- that is how a synthetic unrotated basin gets through it.
+  ! ocean_setup then leaves the tracers untouched (src/oce_setup_step.F90:143-154): the reference's own initial-state routine is called here.
+  if (toy_ocean .and. trim(which_toy) /= 'soufflet') then
+     call oce_initial_state(mesh)
+     tr_arr_old=tr_arr
+  end if
   ! ice loading and atmospheric pressure arrays are read by compute_vel_rhs (ice_modules / forcing arrays)
   if (.not. allocated(press_air)) then
      allocate(press_air(myDim_nod2D+eDim_nod2D)); press_air=0.0_WP

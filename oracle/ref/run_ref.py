@@ -63,7 +63,7 @@ use_cavity_partial_cell=.false.
 use_floatice={use_floatice}
 use_sw_pene={use_sw_pene}
 toy_ocean={toy_ocean}
-which_toy='soufflet'
+which_toy='{which_toy}'
 flag_warn_cflz=.false.
 /
 """
@@ -380,6 +380,27 @@ def channel_case(levels, npes, layers=47, base="souf", workdir=None):
     return name, d
 
 
+def basin_case(levels, npes, layers=47, workdir=None):
+    """registers configuration `basin_r<levels>_<layers>`: the channel geometry with the analytic bathymetry of fesom2_amd.channel_mesh
+    (build_basin) and the reference's default physics (pi_default: KPP + GM + Redi, JM EOS, analytic forcing), edge files and `dist_<npes>` in
+    the reference's formats -- the default-physics CORE2-class workload that the REFERENCE runs too."""
+    import tempfile
+    from fesom2_amd import channel_mesh, partition_io
+    d = os.path.join(workdir or tempfile.gettempdir(), f"fesom_basin_r{levels}_{layers}")
+    kw = dict(force_rotation=False, cyclic_length_deg=channel_mesh.CYCLIC_DEG)
+    if not os.path.exists(os.path.join(d, "nlvls.out")):
+        channel_mesh.build_basin(os.path.join(MESHES, "soufflet"), d, levels, layers)
+    if not os.path.exists(os.path.join(d, "edgenum.out")):
+        partition_io.write_edge_files(d, **kw)
+    for n in sorted({npes, 1}):
+        if n > 1 and not os.path.isdir(os.path.join(d, f"dist_{n}")):
+            partition_io.write_dist(d, n, **kw)
+    name = f"basin_r{levels}_{layers}"
+    CFGS[name] = dict(CFGS["pi_default"], mesh=d, step_per_day=int(round(86400.0 / channel_mesh.dt_for(levels))), cyclic_length=4.5,
+                      rotated_grid=".false.", force_rotation=".false.", toy_ocean=".true.", which_toy="basin")     # (toy_ocean only skips read_mesh's rotation check: see driver.F90)
+    return name, d
+
+
 def prepare(cfg, np_, tag=""):
     c = CFGS[cfg]
     rd = os.path.join(OUT, f"run_{cfg}_{np_}{tag}")
@@ -400,9 +421,9 @@ def prepare(cfg, np_, tag=""):
                 os.chmod(root, 0o755)
             partition_io.write_dist(cp, np_)
         meshdir = cp
-    open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **dict(dict(use_sw_pene=".false.", use_floatice=".false.", min_hnode="0.5"), **c)))
+    open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **dict(dict(use_sw_pene=".false.", use_floatice=".false.", min_hnode="0.5", which_toy="soufflet"), **c)))
     open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0", visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=".true.", tra_adv_lim="FCT", use_momix=".false.", which_pgf="shchepetkin", mom_adv=2, use_kpp_nonlclflx=".false.", double_diffusion=".false.", smooth_bh_tra=".false.", clim_relax="0.0", SPP=".false."), **c)))
-    if c["toy_ocean"] == ".false.":
+    if c["toy_ocean"] == ".false." or c.get("which_toy", "soufflet") != "soufflet":
         from fesom2_amd.synthetic import write_ic_files
         write_ic_files(meshdir, rd)
     return rd
