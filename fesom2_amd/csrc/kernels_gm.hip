@@ -51,37 +51,61 @@ __global__ void __launch_bounds__(BLOCK) k_gm_coef(DM m) {
   }
 }
 
-// fer_solve_Gamma (:8-120): tridiagonal problem per node column with two right-hand sides; the sweep runs in the block
-__global__ void __launch_bounds__(TH_BLOCK) k_fer_gamma(DM m) {
+// fer_solve_Gamma (:8-120): tridiagonal problem per node column with two right-hand sides; the sweep runs in the block.
+// Shapes (dev.h:ThTile): <8, 8> one column per wave (pi: latency-bound); <TL_COLS, TL_WAVES> tiles with several columns per wave on CORE2-class
+// meshes (DM::use_tile): ONE wavefront sweeps 32 / 64 columns with lane = column instead of 8, the dependent divide chain is amortised.
+template <int COLS, int WAVES>
+__global__ void __launch_bounds__(WAVE * WAVES) k_fer_gamma(DM m) {
   extern __shared__ double th_sh[];
-  int n = col_id_th(m), l = lane_id(), nz = l + 1;
-  const bool valid = n < m.myN;
-  if (!valid) n = m.myN - 1;
-  int nzmax = m.nlev_n[n], nzmin = m.ulev_n[n];
-  // zbar_n, Z_n of the column from hnode_new (bottom-up, reference order); lane nz-1 <-> level nz
-  double hn = (nz >= nzmin && nz <= nzmax - 1) ? DA2(m.hnode_new, nz, n) : 0.0;
-  double zb = seq_sum_down(hn, nzmax - 2, nzmin - 1, m.zbar_n_bot[n]);   // zbar_n(nz), nz = nzmin..nzmax-1
-  if (nz == nzmax) zb = m.zbar_n_bot[n];
-  double zb_dn = shdn(zb);                                               // zbar_n(nz+1)
-  double Zn = zb_dn + hn / 2.0;                                          // Z_n(nz), nz <= nzmax-1
-  double Zn_up = shup(Zn);
-  nzmax = m.nlev_n_min[n]; nzmin = m.ulev_n_max[n];
-  double a = 0.0, b = 1.0, c = 0.0, t1 = 0.0, t2 = 0.0;
-  double zinv_own = 1.0 / (zb - zb_dn);                                  // 1/(zbar_n(nz)-zbar_n(nz+1))
-  double zinv_up = shup(zinv_own);
-  if (valid && nz >= nzmin + 1 && nz <= nzmax - 1) {
-    double zinv = 1.0 / (Zn_up - Zn);
-    const double fc = m.fer_c[n];
-    a = fc * zinv_up * zinv;
-    c = fc * zinv_own * zinv;
-    b = -a - c - dmax_(DA2L(m.bvfreq, nz, n), 1.e-8);
-    const double r = D_G / D_RHO0, fk = DA2L(m.fer_K, nz, n);
-    t1 = r * 0.5 * (DV2(m.sigma_xy, 1, nz - 1, n) + DV2(m.sigma_xy, 1, nz, n)) * fk;
-    t2 = r * 0.5 * (DV2(m.sigma_xy, 2, nz - 1, n) + DV2(m.sigma_xy, 2, nz, n)) * fk;
+  ThTile<2, COLS> tile(th_sh, m.nl);
+  const int w = threadIdx.x >> 6, l = lane_id(), nz = l + 1;
+  const int base = xcd_block() * COLS;
+  for (int ci = w; ci < COLS; ci += WAVES) {
+    int n = __builtin_amdgcn_readfirstlane(sub_col(m, base + ci));
+    const bool valid = n < m.myN;
+    if (!valid) n = m.myN - 1;
+    int nzmax = m.nlev_n[n], nzmin = m.ulev_n[n];
+    // zbar_n, Z_n of the column from hnode_new (bottom-up, reference order); lane nz-1 <-> level nz
+    double hn = (nz >= nzmin && nz <= nzmax - 1) ? DA2(m.hnode_new, nz, n) : 0.0;
+    double zb = seq_sum_down(hn, nzmax - 2, nzmin - 1, m.zbar_n_bot[n]);   // zbar_n(nz), nz = nzmin..nzmax-1
+    if (nz == nzmax) zb = m.zbar_n_bot[n];
+    double zb_dn = shdn(zb);                                               // zbar_n(nz+1)
+    double Zn = zb_dn + hn / 2.0;                                          // Z_n(nz), nz <= nzmax-1
+    double Zn_up = shup(Zn);
+    nzmax = m.nlev_n_min[n]; nzmin = m.ulev_n_max[n];
+    double a = 0.0, b = 1.0, c = 0.0, t1 = 0.0, t2 = 0.0;
+    double zinv_own = 1.0 / (zb - zb_dn);                                  // 1/(zbar_n(nz)-zbar_n(nz+1))
+    double zinv_up = shup(zinv_own);
+    if (valid && nz >= nzmin + 1 && nz <= nzmax - 1) {
+      double zinv = 1.0 / (Zn_up - Zn);
+      const double fc = m.fer_c[n];
+      a = fc * zinv_up * zinv;
+      c = fc * zinv_own * zinv;
+      b = -a - c - dmax_(DA2L(m.bvfreq, nz, n), 1.e-8);
+      const double r = D_G / D_RHO0, fk = DA2L(m.fer_K, nz, n);
+      t1 = r * 0.5 * (DV2(m.sigma_xy, 1, nz - 1, n) + DV2(m.sigma_xy, 1, nz, n)) * fk;
+      t2 = r * 0.5 * (DV2(m.sigma_xy, 2, nz - 1, n) + DV2(m.sigma_xy, 2, nz, n)) * fk;
+    }
+    tile.put(ci, valid, nzmin, nzmax, a, b, c, t1, t2);
   }
-  double g1, g2;
-  thomas_inblock<2>(th_sh, m.nl, valid, nzmin, nzmax, a, b, c, t1, t2, g1, g2);
-  if (valid && nz >= nzmin && nz <= nzmax) { DG3(m.fer_gamma, 1, nz, n) = g1; DG3(m.fer_gamma, 2, nz, n) = g2; }
+  tile.sweep();
+  for (int ci = w; ci < COLS; ci += WAVES) {
+    const int n = __builtin_amdgcn_readfirstlane(sub_col(m, base + ci));
+    if (n >= m.myN) continue;
+    double g1, g2;
+    tile.get(ci, g1, g2);
+    if (nz >= m.ulev_n_max[n] && nz <= m.nlev_n_min[n]) { DG3(m.fer_gamma, 1, nz, n) = g1; DG3(m.fer_gamma, 2, nz, n) = g2; }
+  }
+}
+#define FG_SHAPE(id, C_, W_) case id: hipLaunchKernelGGL((k_fer_gamma<C_, W_>), dim3((SUBN(m, m.myN) + C_ - 1) / C_), dim3(WAVE * W_), (ThTile<2, C_>::lds_bytes(m.nl)), s, m); break;
+#define FG_ATTR(id, C_, W_) (void)hipFuncSetAttribute((const void *)k_fer_gamma<C_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+static void launch_fer_gamma(const DM &m, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) { attr = true; TILE_SHAPES(FG_ATTR) }
+  switch (m.use_tile) {
+    TILE_SHAPES(FG_SHAPE)
+    default: hipLaunchKernelGGL((k_fer_gamma<TH_COLS, TH_COLS>), dim3(nblocks_th(SUBN(m, m.myN))), dim3(TH_BLOCK), (ThTile<2, TH_COLS>::lds_bytes(m.nl)), s, m); break;
+  }
 }
 
 // fer_gamma2vel (:125-154)
@@ -141,7 +165,7 @@ int launch_named_gm(const DM &m, hipStream_t s, const char *name) {
   if (!m.p.Fer_GM && strcmp(name, "init_Redi_GM") && strcmp(name, "k_gm_coef")) return -1;
   if (!strcmp(name, "init_Redi_GM") || !strcmp(name, "k_gm_coef")) { LAUNCH_COL(k_gm_coef, m.myN, m); return 0; }
   if (!strcmp(name, "fer_solve_Gamma") || !strcmp(name, "k_fer_gamma")) {
-    hipLaunchKernelGGL(k_fer_gamma, dim3(nblocks_th(m.myN)), dim3(TH_BLOCK), thomas_lds_bytes(m.nl, 2), s, m); return 0;
+    launch_fer_gamma(m, s); return 0;
   }
   if (!strcmp(name, "fer_gamma2vel") || !strcmp(name, "k_fer_uv")) { LAUNCH_COL(k_fer_uv, m.myE, m); return 0; }
   if (!strcmp(name, "fer_wvel") || !strcmp(name, "k_fer_wvel")) { LAUNCH_COL(k_fer_wvel, m.myN, m); return 0; }

@@ -8,7 +8,7 @@
 // Supported switches: use_sw_pene (sw_3d from the forcing), double_diffusion=.false., use_kpp_nonlclflx=.false.; Kv0_const either way;
 // module switches as in the source (smooth_blmc=.true., the others .false.).
 //   k_kpp_col     dVsq, ustar, Bo, ri_iwmix, bldepth, blmix_kpp, enhance          (owned nodes)
-//   k_kpp_smooth  one sweep of smooth_nod3D for the three blmc fields (grid.y)    (owned nodes; halo by exchange)
+//   k_kpp_smooth  one sweep of smooth_nod3D for the three blmc fields               (owned nodes; halo by exchange)
 //   k_kpp_final   max(interior, blmc) inside the boundary layer, ghats, Kv + mo_convect node part
 //   k_kpp_elem    node -> element average of the viscosity (+ minmix) + mo_convect element part
 #include "dev.h"
@@ -272,18 +272,18 @@ __global__ void __launch_bounds__(BLOCK) k_kpp_col(DM m) {
   }
 }
 
-// one sweep of smooth_nod3D (gen_support.F90:95-140 / :145-173) for blmc(:,:,1..3): grid.y = field.  src and dst are
+// one sweep of smooth_nod3D (gen_support.F90:95-140 / :145-173) for blmc(:,:,1..3), the three fields of a node in one wave.  src and dst are
 // different buffers (the reference gathers into work_array before it overwrites arr); levels outside uln..nln keep the
 // value 0 they have in blmc.  The patch areas are summed again in every sweep, in the same order (same value as `vol`).
 __global__ void __launch_bounds__(BLOCK) k_kpp_smooth(DM m, const double *src, double *dst) {
   const int n = col_id(m), l = lane_id(), nz = l + 1;
   if (n >= m.myN) return;
-  const size_t off = (size_t)blockIdx.y * m.nl * m.N;
-  const double *a = src + off;
+  const size_t nlN = (size_t)m.nl * m.N;
   const int uln = m.ulev_n[n], nln = m.nlev_n[n] < m.nl ? m.nlev_n[n] : m.nl;
   const int num = m.nie_num[n];
-  // element cluster of the node, lane-parallel (lane k = k-th element): ids, level range, area, the 3 nodes; then ONE batch of
-  // loads for all elements and the sums in the reference's element order (pi is latency-bound: no dependent load chains)
+  // element cluster of the node, lane-parallel (lane k = k-th element): ids, level range, area, the 3 nodes -- read ONCE for the three fields
+  // (a wave per node and field repeated this chain three times); then batches of loads for KB elements x 3 fields and the sums in the
+  // reference's element order, field by field (no dependent load chains)
   int el_l = 0, n1_l = 0, n2_l = 0, n3_l = 0, lo_l = 1, hi_l = 0;
   double ar_l = 0.0;
   if (l < num) {
@@ -295,14 +295,19 @@ __global__ void __launch_bounds__(BLOCK) k_kpp_smooth(DM m, const double *src, d
     ar_l = m.elem_area[el_l];
   }
   const int nzc = nz <= m.nl ? nz : m.nl;
-  constexpr int KB = 8;                                   // elements per batch (pi: at most 8 around a node; more: second batch)
-  double work = 0.0, vol = 0.0;
+  constexpr int KB = 4;                                   // elements per batch
+  double work[3] = {0.0, 0.0, 0.0}, vol = 0.0;
   for (int k0 = 0; k0 < num; k0 += KB) {
-    double v1[KB], v2[KB], v3[KB];
+    double v1[3][KB], v2[3][KB], v3[3][KB];
 #pragma unroll
     for (int k = 0; k < KB; k++) {
       const int kk = (k0 + k < num) ? k0 + k : 0;
-      v1[k] = DA2L(a, nzc, rdlane(n1_l, kk)); v2[k] = DA2L(a, nzc, rdlane(n2_l, kk)); v3[k] = DA2L(a, nzc, rdlane(n3_l, kk));
+      const int a1 = rdlane(n1_l, kk), a2 = rdlane(n2_l, kk), a3 = rdlane(n3_l, kk);
+#pragma unroll
+      for (int f = 0; f < 3; f++) {
+        const double *a = src + (size_t)f * nlN;
+        v1[f][k] = DA2L(a, nzc, a1); v2[f][k] = DA2L(a, nzc, a2); v3[f][k] = DA2L(a, nzc, a3);
+      }
     }
 #pragma unroll
     for (int k = 0; k < KB; k++) {
@@ -310,15 +315,21 @@ __global__ void __launch_bounds__(BLOCK) k_kpp_smooth(DM m, const double *src, d
       if (kk < num) {
         const double ar = bcast(ar_l, kk);
         const bool on = nz >= rdlane(lo_l, kk) && nz <= rdlane(hi_l, kk);
-        const double nv = vol + ar, nw = work + ar * (v1[k] + v2[k] + v3[k]);
-        vol = on ? nv : vol; work = on ? nw : work;
+        const double nv = vol + ar;
+        vol = on ? nv : vol;
+#pragma unroll
+        for (int f = 0; f < 3; f++) {
+          const double nw = work[f] + ar * (v1[f][k] + v2[f][k] + v3[f][k]);
+          work[f] = on ? nw : work[f];
+        }
       }
     }
   }
   if (nz > m.nl) return;
-  double out = 0.0;
-  if (nz >= uln && nz <= nln) { vol = 1. / (3. * vol); out = work * vol; }
-  dst[off + (size_t)n * m.nl + l] = out;
+  const bool in = nz >= uln && nz <= nln;
+  if (in) vol = 1. / (3. * vol);
+#pragma unroll
+  for (int f = 0; f < 3; f++) dst[(size_t)f * nlN + (size_t)n * m.nl + l] = in ? work[f] * vol : 0.0;
 }
 
 // :377-392 + Kv = Kv_double(:,:,1) + mo_convect node part (oce_mo_conv.F90:47-57)
@@ -383,7 +394,7 @@ __global__ void __launch_bounds__(BLOCK) k_kpp_final_elem(DM m, int ncolE) {
 
 #define LAUNCH_COL(k, ncol, ...) hipLaunchKernelGGL(k, dim3(nblocks(ncol)), dim3(BLOCK), 0, s, __VA_ARGS__)
 static void smooth(const DM &m, hipStream_t s, const double *src, double *dst) {
-  hipLaunchKernelGGL(k_kpp_smooth, dim3(nblocks(m.myN), 3), dim3(BLOCK), 0, s, m, src, dst);
+  hipLaunchKernelGGL(k_kpp_smooth, dim3(nblocks(m.myN)), dim3(BLOCK), 0, s, m, src, dst);      // the three blmc fields in one wave per node
 }
 int launch_named_kpp(const DM &m, hipStream_t s, const char *name) {
   if (m.p.mix_scheme != 1) return -1;

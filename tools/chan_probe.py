@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Probe a workload on the GPU: ms/step, solver iterations, device-side step monitor, per-kernel HIP-event times.
-usage: chan_probe.py [--workload channel|pi] [--levels L] [--steps K] [--warmup W] [--kernels] [--monitor-every M]"""
+usage: chan_probe.py [--workload channel|basin|pi] [--levels L] [--steps K] [--warmup W] [--kernels] [--monitor-every M]"""
 import argparse, json, os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -19,7 +19,7 @@ ap.add_argument("--kernels", action="store_true")
 ap.add_argument("--monitor-every", type=int, default=0)
 a = ap.parse_args()
 t0 = time.time()
-wl = workloads.channel(a.levels, a.layers) if a.workload == "channel" else workloads.pi(a.physics, a.levels)
+wl = workloads.channel(a.levels, a.layers) if a.workload == "channel" else workloads.basin(a.levels, a.layers) if a.workload == "basin" else workloads.pi(a.physics, a.levels)
 mesh = wl.load_mesh()
 N3, E3, D3 = mesh.wet_counts()
 print("mesh", mesh.nod2D, mesh.elem2D, mesh.edge2D, "nl", mesh.nl, "wet", N3, E3, D3, "setup s", round(time.time() - t0, 1), flush=True)
