@@ -61,7 +61,9 @@ class Params(C.Structure):
                    ("use_sw_pene", C.c_int), ("tra_adv_ver", C.c_int), ("tra_adv_hor", C.c_int), ("Kv0_const", C.c_int),
                    ("solver_precond", C.c_int), ("tra_adv_lim", C.c_int), ("solver_xinv_its", C.c_int), ("Leith_c", C.c_double), ("Div_c", C.c_double), ("which_pgf", C.c_int), ("use_momix", C.c_int), ("momix_lat", C.c_double), ("momix_kv", C.c_double),
                    ("use_kpp_nonlclflx", C.c_int), ("ref_sss_local", C.c_int), ("ref_sss", C.c_double), ("smooth_bh_tra", C.c_int), ("double_diffusion", C.c_int),
-                   ("use_floatice", C.c_int), ("l_mslp", C.c_int), ("use_global_tides", C.c_int), ("max_ice_loading", C.c_double), ("SPP", C.c_int), ("Sice", C.c_double), ("clim_relax", C.c_double), ("lzstar_lev", C.c_int), ("min_hnode", C.c_double)])
+                   ("use_floatice", C.c_int), ("l_mslp", C.c_int), ("use_global_tides", C.c_int), ("max_ice_loading", C.c_double), ("SPP", C.c_int), ("Sice", C.c_double), ("clim_relax", C.c_double), ("lzstar_lev", C.c_int), ("min_hnode", C.c_double),
+                   ("c_back", C.c_double), ("K_back", C.c_double), ("uke_scaling_factor", C.c_double), ("rosb_dis", C.c_double), ("scale_area", C.c_double),
+                   ("uke_scaling", C.c_int), ("smooth_back", C.c_int), ("smooth_dis", C.c_int), ("smooth_back_tend", C.c_int)])
 
 
 STATE_FIELDS = ("tr_arr", "tr_arr_old", "UV", "UV_rhsAB", "eta_n", "d_eta", "ssh_rhs", "ssh_rhs_old", "hbar",

@@ -453,7 +453,8 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   if (par->which_ale < 0 || par->which_ale > 2) { G.err = "fesom_gpu_init: which_ale must be linfs (0), zlevel (1) or zstar (2)"; return 3; }
   if (par->which_ale == 1 && (par->lzstar_lev < 1 || par->lzstar_lev > 32 || par->lzstar_lev + 1 > d->nl - 1)) { G.err = "fesom_gpu_init: which_ALE='zlevel' needs 1 <= lzstar_lev <= 32 and lzstar_lev + 1 layers"; return 3; }
   if ((par->mom_adv != 2 && par->mom_adv != 3) || par->visc_option < 1 || par->visc_option > 7) { G.err = "fesom_gpu_init: only mom_adv=2 or 3, visc_option=1..7 are implemented"; return 3; }
-  if (par->mom_adv == 3 && par->which_ale != 0) { G.err = "fesom_gpu_init: mom_adv=3 (vector-invariant momentum) needs which_ALE='linfs': it reads hpressure, which the reference forms only there (oce_ale_pressure_bv.F90:262)"; return 3; }
+  // (mom_adv = 3 reads hpressure, which the reference forms with which_ALE='linfs' only, oce_ale_pressure_bv.F90:262; with zstar / zlevel the array keeps
+  //  the zeros of array_setup, oce_setup_step.F90:384, and compute_vel_rhs_vinv runs without a baroclinic pressure term -- kept as it is: run pi_pp_vinv)
   if (par->which_pgf != 0 && par->which_pgf != 1 && !(par->which_pgf == 2 && par->which_ale == 0) && !(par->which_pgf == 3) && !(par->which_ale == 0 && !par->use_partial_cell)) {
     G.err = "fesom_gpu_init: which_pgf must be 'shchepetkin' (0), 'cubicspline' (1), with linfs 'nemo' (2) or 'easypgf' (3); the cavity scheme 'sergey' is not implemented"; return 3;
   }

@@ -77,6 +77,8 @@ module fesom_gpu_shim
      real(c_double) :: Sice, clim_relax
      integer(c_int) :: lzstar_lev
      real(c_double) :: min_hnode
+     real(c_double) :: c_back, K_back, uke_scaling_factor, rosb_dis, scale_area
+     integer(c_int) :: uke_scaling, smooth_back, smooth_dis, smooth_back_tend
   end type
   type, bind(C) :: fesom_state_desc
      type(c_ptr) :: tr_arr, tr_arr_old, UV, UV_rhsAB, eta_n, d_eta, ssh_rhs, ssh_rhs_old, hbar, hbar_old, dhe, hnode, hnode_new, &
@@ -369,6 +371,8 @@ contains
     p%max_ice_loading = max_ice_loading; p%clim_relax = clim_relax
     p%SPP = l2i(SPP); p%Sice = Sice
     p%lzstar_lev = lzstar_lev; p%min_hnode = min_hnode
+    p%c_back = c_back; p%K_back = K_back; p%uke_scaling_factor = uke_scaling_factor; p%rosb_dis = rosb_dis; p%scale_area = scale_area
+    p%uke_scaling = l2i(uke_scaling); p%smooth_back = smooth_back; p%smooth_dis = smooth_dis; p%smooth_back_tend = smooth_back_tend
     p%solver_precond = 1; p%solver_xinv_its = 0     ! explicit-inverse preconditioner where it fits (pi), library default iterations
 
     transport%ctx = c_null_ptr

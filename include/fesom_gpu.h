@@ -91,7 +91,7 @@ typedef struct fesom_params {
   int    num_tracers;
   int    mom_adv;            /* 2 (scalar control volumes) */
   int    visc_option;        /* 5 (easy backscatter, visc_filt_bcksct; default), 1 (Leith + visc_filt_harmon), 2 (Leith + visc_filt_hbhmix), 3 (Leith + visc_filt_biharm(2)),
-                                4 (visc_filt_biharm(1)), 6 (visc_filt_bilapl), 7 (visc_filt_bidiff); oce_dyn.F90:196-228 */
+                                4 (visc_filt_biharm(1)), 6 (visc_filt_bilapl), 7 (visc_filt_bidiff), 8 (backscatter_coef + visc_filt_dbcksc + uke_update); oce_dyn.F90:196-228 */
   int    i_vert_visc, i_vert_diff, w_split;
   int    mix_scheme;         /* 1 = KPP (oce_ale_mixing_kpp.F90) ; 2 = PP ; 0 = constant A_ver/K_ver (no mixing scheme) */
   int    use_instabmix, use_windmix, windmix_nl;
@@ -164,6 +164,12 @@ typedef struct fesom_params {
   int    lzstar_lev;         /* which_ALE='zlevel' (namelist.config &ale_def, 4): number of surface layers the reference's local-zstar fallback works on */
   double min_hnode;          /* which_ALE='zlevel' (&ale_def, 0.5): smallest allowed fraction of the surface layer's resting thickness; a step that would go below it
                                 needs the local-zstar fallback of vert_vel_ale (oce_ale.F90:1859-1942), which is not built: the library reports an error */
+  /* visc_option = 8: kinematic backscatter with a sub-grid energy budget (Juricke et al.; backscatter_coef + visc_filt_dbcksc + uke_update,
+     src/oce_dyn.F90:806-1152; namelist.oce &oce_dyn, defaults src/oce_modules.F90:34-41).  The unresolved kinetic energy `uke` is prognostic
+     device state (fesom_gpu_get/set_field "uke", "uke_rhs", "uke_rhs_old").  Single partition; which_toy = 'soufflet' as in the shipped
+     namelist.config (the hard-coded regional mask of uke_update, :1107-1121, is not built). */
+  double c_back, K_back, uke_scaling_factor, rosb_dis, scale_area;
+  int    uke_scaling, smooth_back, smooth_dis, smooth_back_tend;
 } fesom_params;
 
 /* ---- prognostic state = restart set (io_restart.F90:99-155) + ALE thickness arrays -- */

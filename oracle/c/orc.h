@@ -40,6 +40,8 @@ typedef struct {
   double *dhe, *stress_surf;                     /* (E), (2,E) */
   double *KE_node;                               /* mom_adv = 3: kinetic energy at nodes (nl-1,N) */
   double *Visc, *vorticity, *leith_aux;          /* Leith viscosity (nl-1,E), relative vorticity (nl-1,N), smoothing work array (nl-1,N) */
+  double *uke, *v_back, *uke_rhs, *uke_rhs_old, *uke_dif, *uke_dis, *uke_back;   /* visc_option = 8: sub-grid energy budget (nl-1,E) */
+  double *UV_dis_tend, *UV_back_tend;            /* (2,nl-1,E) */
   /* edge */
   double *adv_flux_hor;                          /* (nl-1,D) */
   double *edge_up_dn_grad;                       /* (4,nl-1,D) */

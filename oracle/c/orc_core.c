@@ -48,6 +48,8 @@ int orc_init(const fesom_mesh_desc *m, const fesom_params *p) {
   R(UV, 2 * n1 * E); R(UV_rhs, 2 * n1 * E); R(UV_rhsAB, 2 * n1 * E); R(tr_xy, 2 * n1 * E); R(U_b, 2 * n1 * E); R(fct_ebnd, 2 * n1 * E);
   R(pgf_x, n1 * E); R(pgf_y, n1 * E); R(helem, n1 * E); R(Av, nl * E); R(dhe, E); R(stress_surf, 2 * E);
   R(Visc, n1 * E); R(vorticity, n1 * N); R(leith_aux, n1 * N); R(KE_node, n1 * N);
+  R(uke, n1 * E); R(v_back, n1 * E); R(uke_rhs, n1 * E); R(uke_rhs_old, n1 * E); R(uke_dif, n1 * E); R(uke_dis, n1 * E); R(uke_back, n1 * E);
+  R(UV_dis_tend, 2 * n1 * E); R(UV_back_tend, 2 * n1 * E);
   R(adv_flux_hor, n1 * D); R(edge_up_dn_grad, 4 * n1 * D);
   R(fer_K, nl * N); R(fer_gamma, 2 * nl * N); R(fer_Wvel, nl * N); R(fer_c, N); R(fer_scal, N); R(gm_scal_static, N); R(fer_UV, 2 * n1 * E);
   R(stress_atmoce_x, N); R(stress_atmoce_y, N); R(sw_3d, nl * N); R(kpp_sw_node, N);

@@ -884,8 +884,164 @@ static void visc_filt_leith(int opt) {
   }
 }
 
-/* viscosity_filter(visc_option): src/oce_dyn.F90:196-228 (options 1-7) */
+/* ---- visc_option = 8: backscatter_coef (src/oce_dyn.F90:967-996), visc_filt_dbcksc (:806-964), uke_update (:999-1152).  Single partition: the
+ * exchange_* calls of the reference are no-ops.  which_toy = 'soufflet' as in the shipped namelist.config: the branch without the hard-coded
+ * regional mask (:1122-1125). */
+/* smooth_elem2D (src/gen_support.F90:183-212) applied to one level of an element field with `nc` interleaved components: N rounds of
+ * element -> node (area-weighted mean over the whole cluster, dry cells included) -> element (mean of the three nodes) */
+static void smooth_elem_level(double *arr, int nc, int comp, int nz, int nrounds, double *work) {
+  for (int q = 0; q < nrounds; q++) {
+    for (int n = 1; n <= C_.m.myDim_nod2D; n++) {
+      double vol = 0., w = 0.;
+      for (int j = 1; j <= C_.m.nod_in_elem2D_num[n - 1]; j++) {
+        int e = NIE(j, n);
+        w = w + arr[((size_t)(e - 1) * NLM1 + (nz - 1)) * nc + comp] * C_.m.elem_area[e - 1];
+        vol = vol + C_.m.elem_area[e - 1];
+      }
+      work[n - 1] = w / vol;
+    }
+    for (int e = 1; e <= C_.m.myDim_elem2D; e++)
+      arr[((size_t)(e - 1) * NLM1 + (nz - 1)) * nc + comp] = ((work[EN(1, e) - 1] + work[EN(2, e) - 1]) + work[EN(3, e) - 1]) / 3.0;
+  }
+}
+static void backscatter_coef(void) {
+  double dt = C_.p.dt;
+  memset(C_.v_back, 0, sizeof(double) * NLM1 * C_.E);
+  for (int e = 1; e <= C_.m.myDim_elem2D; e++) {
+    double ar = C_.m.elem_area[e - 1];
+    for (int nz = 1; nz <= NLEV(e) - 1; nz++)
+      A2(C_.v_back, nz, e) = dmin(-C_.p.c_back * sqrt(ar) * sqrt(dmax(2.0 * A2(C_.uke, nz, e), 0.0)), 0.2 * ar / dt);
+  }
+}
+static void uke_update(double *work) {
+  const double c_min = 0.5, f_min = 1.e-6, r_max = 200000., pi = 3.14159265358979;
+  int E = C_.m.myDim_elem2D, N = C_.m.myDim_nod2D;
+  memset(C_.uke_back, 0, sizeof(double) * NLM1 * C_.E); memset(C_.uke_dis, 0, sizeof(double) * NLM1 * C_.E);
+  for (int e = 1; e <= E; e++)
+    for (int nz = 1; nz <= NLEV(e) - 1; nz++) {
+      A2(C_.uke_dis, nz, e) = (V2(C_.UV, 1, nz, e) * V2(C_.UV_dis_tend, 1, nz, e) + V2(C_.UV, 2, nz, e) * V2(C_.UV_dis_tend, 2, nz, e));
+      A2(C_.uke_back, nz, e) = (V2(C_.UV, 1, nz, e) * V2(C_.UV_back_tend, 1, nz, e) + V2(C_.UV, 2, nz, e) * V2(C_.UV_back_tend, 2, nz, e));
+    }
+  for (int nz = 1; nz <= NLM1; nz++) smooth_elem_level(C_.uke_back, 1, 0, nz, C_.p.smooth_back, work);
+  /* U_work, V_work: area-weighted node means of UV over the whole cluster; V_work = U_work / vol (the reference's line :1066, kept) */
+  double *Uw = calloc((size_t)2 * NLM1 * C_.N, sizeof(double)), *Vw = Uw + (size_t)NLM1 * C_.N;
+  double *rosb = calloc((size_t)NLM1 * C_.E, sizeof(double));
+  for (int nz = 1; nz <= NLM1; nz++)
+    for (int n = 1; n <= N; n++) {
+      double vol = 0., u = 0., v = 0.;
+      for (int j = 1; j <= C_.m.nod_in_elem2D_num[n - 1]; j++) {
+        int e = NIE(j, n);
+        u = u + V2(C_.UV, 1, nz, e) * C_.m.elem_area[e - 1];
+        v = v + V2(C_.UV, 2, nz, e) * C_.m.elem_area[e - 1];
+        vol = vol + C_.m.elem_area[e - 1];
+      }
+      (void)v;
+      u = u / vol;
+      A2(Uw, nz, n) = u; A2(Vw, nz, n) = u / vol;
+    }
+  for (int e = 1; e <= E; e++) {
+    int en[3] = {EN(1, e), EN(2, e), EN(3, e)};
+    for (int nz = 1; nz <= NLEV(e) - 1; nz++) {
+      double gu = (GS(1, e) * A2(Uw, nz, en[0]) + GS(2, e) * A2(Uw, nz, en[1])) + GS(3, e) * A2(Uw, nz, en[2]);
+      double hv = (GS(4, e) * A2(Vw, nz, en[0]) + GS(5, e) * A2(Vw, nz, en[1])) + GS(6, e) * A2(Vw, nz, en[2]);
+      double hu = (GS(4, e) * A2(Uw, nz, en[0]) + GS(5, e) * A2(Uw, nz, en[1])) + GS(6, e) * A2(Uw, nz, en[2]);
+      double gv = (GS(1, e) * A2(Vw, nz, en[0]) + GS(2, e) * A2(Vw, nz, en[1])) + GS(3, e) * A2(Vw, nz, en[2]);
+      A2(rosb, nz, e) = sqrt((gu - hv) * (gu - hv) + (hu + gv) * (hu + gv));
+    }
+  }
+  for (int e = 1; e <= E; e++) {
+    double scaling = 1.0;
+    int en[3] = {EN(1, e), EN(2, e), EN(3, e)};
+    if (C_.p.uke_scaling) {
+      double reso = sqrt(C_.m.elem_area[e - 1] * 4.0 / sqrt(3.0)), rb = 0.0;
+      for (int kk = 0; kk < 3; kk++) {
+        int n = en[kk];
+        double c1 = 0.0;
+        int nzmax = C_.m.nlevels_nod2D_min[n - 1];            /* minval(nlevels(nod_in_elem2D(1:num, n))) */
+        for (int nz = 1; nz <= nzmax - 1; nz++)
+          c1 = c1 + A2(C_.hnode_new, nz, n) * (sqrt(dmax(A2L(C_.bvfreq, nz, n), 0.0)) + sqrt(dmax(A2L(C_.bvfreq, nz + 1, n), 0.0))) / 2.;
+        c1 = dmax(c_min, c1 / pi);
+        rb = rb + dmin(c1 / dmax(fabs(C_.m.coriolis_node[n - 1]), f_min), r_max);
+      }
+      rb = rb / 3.0;
+      scaling = 1.0 / (1.0 + (C_.p.uke_scaling_factor * reso / rb));
+    }
+    for (int nz = 1; nz <= NLEV(e) - 1; nz++) {
+      double fsum = (C_.m.coriolis_node[en[0] - 1] + C_.m.coriolis_node[en[1] - 1]) + C_.m.coriolis_node[en[2] - 1];
+      A2(rosb, nz, e) = A2(rosb, nz, e) / dmax(fabs(fsum), f_min);
+      A2(C_.uke_dis, nz, e) = scaling * 1.0 / (1.0 + A2(rosb, nz, e) / C_.p.rosb_dis) * A2(C_.uke_dis, nz, e);
+    }
+  }
+  free(Uw); free(rosb);
+  for (int nz = 1; nz <= NLM1; nz++) smooth_elem_level(C_.uke_dis, 1, 0, nz, C_.p.smooth_dis, work);
+  for (int e = 1; e <= E; e++)
+    for (int nz = 1; nz <= NLEV(e) - 1; nz++) {
+      A2(C_.uke_rhs_old, nz, e) = A2(C_.uke_rhs, nz, e);
+      A2(C_.uke_rhs, nz, e) = -A2(C_.uke_dis, nz, e) - A2(C_.uke_back, nz, e) + A2(C_.uke_dif, nz, e);
+      A2(C_.uke, nz, e) = A2(C_.uke, nz, e) + 1.5 * A2(C_.uke_rhs, nz, e) - 0.5 * A2(C_.uke_rhs_old, nz, e);
+    }
+}
+static void visc_filt_dbcksc(void) {
+  double dt = C_.p.dt;
+  size_t n2 = (size_t)2 * NLM1 * C_.E;
+  double *Uc = C_.U_b, *back = calloc(n2, sizeof(double)), *dis = calloc(n2, sizeof(double)), *uked = C_.uke_dif;
+  double *work = calloc(C_.N, sizeof(double));
+  memset(Uc, 0, sizeof(double) * n2); memset(uked, 0, sizeof(double) * NLM1 * C_.E);
+  for (int ed = 1; ed <= C_.D; ed++) {
+    if (C_.m.myList_edge2D[ed - 1] > C_.m.edge2D_in) continue;
+    int e1 = ETRI(1, ed), e2 = ETRI(2, ed);
+    int nzmax = NLEV(e1) < NLEV(e2) ? NLEV(e1) : NLEV(e2);
+    for (int nz = 1; nz <= nzmax - 1; nz++) {
+      double u1 = V2(C_.UV, 1, nz, e1) - V2(C_.UV, 1, nz, e2), v1 = V2(C_.UV, 2, nz, e1) - V2(C_.UV, 2, nz, e2);
+      V2(Uc, 1, nz, e1) = V2(Uc, 1, nz, e1) - u1; V2(Uc, 1, nz, e2) = V2(Uc, 1, nz, e2) + u1;
+      V2(Uc, 2, nz, e1) = V2(Uc, 2, nz, e1) - v1; V2(Uc, 2, nz, e2) = V2(Uc, 2, nz, e2) + v1;
+    }
+  }
+  for (int e = 1; e <= C_.m.myDim_elem2D; e++) {
+    double len = sqrt(C_.m.elem_area[e - 1]);
+    len = dt * len / 30.0;
+    for (int nz = 1; nz <= NLEV(e) - 1; nz++) {
+      double vi = dmax(0.2, sqrt(V2(C_.UV, 1, nz, e) * V2(C_.UV, 1, nz, e) + V2(C_.UV, 2, nz, e) * V2(C_.UV, 2, nz, e))) * len;
+      V2(Uc, 1, nz, e) = -V2(Uc, 1, nz, e) * vi;
+      V2(Uc, 2, nz, e) = -V2(Uc, 2, nz, e) * vi;
+    }
+  }
+  for (int ed = 1; ed <= C_.D; ed++) {
+    if (C_.m.myList_edge2D[ed - 1] > C_.m.edge2D_in) continue;
+    int e1 = ETRI(1, ed), e2 = ETRI(2, ed);
+    double a1 = C_.m.elem_area[e1 - 1], a2 = C_.m.elem_area[e2 - 1];
+    double le1 = EDXY(1, ed) * (C_.m.elem_cos[e1 - 1] + C_.m.elem_cos[e2 - 1]) * 0.25, le2 = EDXY(2, ed);
+    double len = sqrt(le1 * le1 + le2 * le2) * R_EARTH;
+    le1 = ECD(1, ed) - ECD(3, ed); le2 = ECD(2, ed) - ECD(4, ed);
+    double crosslen = sqrt(le1 * le1 + le2 * le2);
+    int nzmax = NLEV(e1) < NLEV(e2) ? NLEV(e1) : NLEV(e2);
+    for (int nz = 1; nz <= nzmax - 1; nz++) {
+      double vi = dt * len * (A2(C_.v_back, nz, e1) + A2(C_.v_back, nz, e2)) / crosslen;
+      double u1 = (V2(C_.UV, 1, nz, e1) - V2(C_.UV, 1, nz, e2)) * vi, v1 = (V2(C_.UV, 2, nz, e1) - V2(C_.UV, 2, nz, e2)) * vi;
+      vi = dt * len * (C_.p.K_back * sqrt(a1 / C_.p.scale_area) + C_.p.K_back * sqrt(a2 / C_.p.scale_area)) / crosslen;
+      double uke1 = (A2(C_.uke, nz, e1) - A2(C_.uke, nz, e2)) * vi;
+      V2(back, 1, nz, e1) = V2(back, 1, nz, e1) - u1 / a1; V2(back, 1, nz, e2) = V2(back, 1, nz, e2) + u1 / a2;
+      V2(back, 2, nz, e1) = V2(back, 2, nz, e1) - v1 / a1; V2(back, 2, nz, e2) = V2(back, 2, nz, e2) + v1 / a2;
+      A2(uked, nz, e1) = A2(uked, nz, e1) - uke1 / a1; A2(uked, nz, e2) = A2(uked, nz, e2) + uke1 / a2;
+      u1 = V2(Uc, 1, nz, e1) - V2(Uc, 1, nz, e2); v1 = V2(Uc, 2, nz, e1) - V2(Uc, 2, nz, e2);
+      V2(dis, 1, nz, e1) = V2(dis, 1, nz, e1) - u1 / a1; V2(dis, 1, nz, e2) = V2(dis, 1, nz, e2) + u1 / a2;
+      V2(dis, 2, nz, e1) = V2(dis, 2, nz, e1) - v1 / a1; V2(dis, 2, nz, e2) = V2(dis, 2, nz, e2) + v1 / a2;
+    }
+  }
+  for (int nz = 1; nz <= NLM1; nz++) { smooth_elem_level(back, 2, 0, nz, C_.p.smooth_back_tend, work); smooth_elem_level(back, 2, 1, nz, C_.p.smooth_back_tend, work); }
+  for (int e = 1; e <= C_.m.myDim_elem2D; e++)
+    for (int nz = 1; nz <= NLEV(e) - 1; nz++) {
+      V2(C_.UV_rhs, 1, nz, e) = V2(C_.UV_rhs, 1, nz, e) + V2(dis, 1, nz, e) + V2(back, 1, nz, e);
+      V2(C_.UV_rhs, 2, nz, e) = V2(C_.UV_rhs, 2, nz, e) + V2(dis, 2, nz, e) + V2(back, 2, nz, e);
+    }
+  memcpy(C_.UV_dis_tend, dis, sizeof(double) * n2); memcpy(C_.UV_back_tend, back, sizeof(double) * n2);
+  uke_update(work);
+  free(back); free(dis); free(work);
+}
+
+/* viscosity_filter(visc_option): src/oce_dyn.F90:196-228 (options 1-8) */
 void orc_viscosity_filter(void) {
+  if (C_.p.visc_option == 8) { backscatter_coef(); visc_filt_dbcksc(); return; }
   if (C_.p.visc_option == 5) orc_visc_filt_bcksct();
   else if (C_.p.visc_option <= 3) { h_viscosity_leith(); visc_filt_leith(C_.p.visc_option); }
   else visc_filt_biharmonic(C_.p.visc_option);

@@ -611,6 +611,11 @@ contains
     call mark('viscosity_filter')
     call viscosity_filter(visc_option, mesh)
     call dump('viscosity_filter.UV_rhs', UV_rhs)
+    if (visc_option==8) then
+       call dump('viscosity_filter.uke', uke); call dump('viscosity_filter.v_back', v_back); call dump('viscosity_filter.uke_rhs', uke_rhs)
+       call dump('viscosity_filter.uke_dis', uke_dis); call dump('viscosity_filter.uke_back', uke_back); call dump('viscosity_filter.uke_dif', uke_dif)
+       call dump('viscosity_filter.UV_back_tend', UV_back_tend); call dump('viscosity_filter.UV_dis_tend', UV_dis_tend)
+    end if
     if (visc_option<=3) then
        call dump('viscosity_filter.Visc', Visc); call dump('viscosity_filter.vorticity', vorticity)
     end if
@@ -624,7 +629,11 @@ contains
     call compute_ssh_rhs_ale(mesh)
     call dump('compute_ssh_rhs_ale.ssh_rhs', ssh_rhs)
     call mark('solve_ssh_ale')
-    call solve_ssh_ale(mesh)
+    if (npes > 1) then
+       call solve_ssh_ale(mesh)
+    else          ! pARMS' RAS solver cannot run on one rank: a single-domain replay keeps d_eta = 0 (every other routine is the reference's, on one partition)
+       d_eta=0.0_WP
+    end if
     call dump('solve_ssh_ale.d_eta', d_eta)
     if ((toy_ocean) .AND. (TRIM(which_toy)=="soufflet")) then
        call mark('relax_zonal_vel')

@@ -258,6 +258,11 @@ CFGS = {
                         rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                         fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
                         balance_salt_water=".true.", synth_forcing=True, mom_adv=3),
+    # mom_adv = 3 with zstar: the reference leaves hpressure at the zeros of array_setup there (no baroclinic pressure term in compute_vel_rhs_vinv)
+    "pi_pp_vinv": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                        fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                        balance_salt_water=".true.", synth_forcing=True, mom_adv=3),
     # linfs with partial cells and which_pgf = 'cubicspline': pressure_force_4_linfs_cubicspline (src/oce_ale_pressure_bv.F90:1252-1444)
     "pi_pp_linfs_cubic": dict(mesh="pi", step_per_day=96, which_ale="linfs", use_partial_cell=".true.", cyclic_length=360,
                         rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
@@ -291,6 +296,11 @@ CFGS = {
                         rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                         fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
                         balance_salt_water=".true.", synth_forcing=True, visc_option=4),
+    # visc_option = 8: backscatter_coef + visc_filt_dbcksc + uke_update (src/oce_dyn.F90:806-1152), prognostic unresolved kinetic energy
+    "pi_pp_visc8": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                        fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                        balance_salt_water=".true.", synth_forcing=True, visc_option=8),
     "pi_pp_visc7": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
                         rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                         fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",

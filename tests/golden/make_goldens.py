@@ -34,7 +34,8 @@ def digest(a):
     return np.concatenate([stats, a[::stride]])
 
 
-def make(cfg, outname):
+def make(cfg, outname, NP=NP):
+    """NP = 1: a single-domain replay (no partition-dependent summation orders); the harness keeps d_eta = 0 there, pARMS cannot run on one rank"""
     rd, rc, lines = run_ref.run(cfg, NP, NSTEPS, mode="replay", dump=tuple(range(1, NSTEPS + 1)))
     assert rc == 0
     setups = [read_dump(os.path.join(rd, "dumps", f"setup.r{r:05d}.bin")) for r in range(NP)]
@@ -101,9 +102,10 @@ def make(cfg, outname):
 
 
 def main():
-    if len(sys.argv) > 1:                                 # only the named configurations
+    if len(sys.argv) > 1:                                 # only the named configurations (cfg or cfg:NP)
         for cfg in sys.argv[1:]:
-            make(cfg, cfg + "_reference.npz")
+            name, _, np_ = cfg.partition(":")
+            make(name, name + "_reference.npz", NP=int(np_) if np_ else NP)
         return
     make("pi_default", "pi_default_reference.npz")      # KPP + GM + Redi (the reference's default physics) with surface forcing
     make("pi_kpp", "pi_kpp_reference.npz")              # KPP alone with surface forcing
@@ -124,6 +126,7 @@ def main():
     make("pi_pp_momix", "pi_pp_momix_reference.npz")    # use_momix = .true.
     make("pi_default_momix", "pi_default_momix_reference.npz")  # the shipped namelist.oce physics: KPP + GM + Redi + use_momix
     make("pi_pp_linfs_vinv", "pi_pp_linfs_vinv_reference.npz")  # mom_adv = 3 (vector-invariant momentum), linfs with full cells
+    make("pi_pp_vinv", "pi_pp_vinv_reference.npz")              # mom_adv = 3 with zstar (hpressure stays zero in the reference)
     make("pi_pp_linfs_cubic", "pi_pp_linfs_cubic_reference.npz")  # linfs + partial cells + which_pgf = 'cubicspline'
     make("pi_pp_linfs_nemo", "pi_pp_linfs_nemo_reference.npz")  # linfs + partial cells + which_pgf = 'nemo'
     make("pi_pp_linfs_easypgf", "pi_pp_linfs_easypgf_reference.npz")  # linfs + partial cells + which_pgf = 'easypgf'
@@ -133,6 +136,7 @@ def main():
     make("pi_pp_visc4", "pi_pp_visc4_reference.npz")    # visc_option = 4 (visc_filt_biharm(1))
     make("pi_pp_visc6", "pi_pp_visc6_reference.npz")    # visc_option = 6 (visc_filt_bilapl)
     make("pi_pp_visc7", "pi_pp_visc7_reference.npz")    # visc_option = 7 (visc_filt_bidiff)
+    make("pi_pp_visc8", "pi_pp_visc8_reference.npz", NP=1)    # visc_option = 8 (backscatter_coef + visc_filt_dbcksc + uke_update): single-domain replay
     make("pi_pp_cdiff", "pi_pp_cdiff_reference.npz")    # tra_adv_ver = 'CDIFF'
     make("pi_pp_upw1v", "pi_pp_upw1v_reference.npz")    # tra_adv_ver = 'UPW1' with w_split
     make("pi_pp_ppm", "pi_pp_ppm_reference.npz")        # tra_adv_ver = 'PPM'

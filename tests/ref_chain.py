@@ -6,7 +6,7 @@ import numpy as np
 from golden_util import check_digest, wet_masks
 
 
-def run_reference_chain(orc, mesh, g, steps=(1, 2, 3), toy=False, skip=(), after_step=None, node_keep=None):
+def run_reference_chain(orc, mesh, g, steps=(1, 2, 3), toy=False, skip=(), after_step=None, node_keep=None, solver_skipped=False):
     """returns the list of mismatches (empty = bit-identical on every sampled value).  `skip` = set of (step, key)
     entries that are known to differ (documented where used).  `node_keep` (bool per global node): tracer fields are compared at these nodes only
     (options whose result the reference makes depend on the partition: the goldens come from a 2-rank run)."""
@@ -57,6 +57,8 @@ def run_reference_chain(orc, mesh, g, steps=(1, 2, 3), toy=False, skip=(), after
             chk(step, "mixlength", "mixing.mixlength")
         orc.call("compute_vel_rhs"); chk(step, "UV_rhs", "compute_vel_rhs.UV_rhs", "e2"); chk(step, "UV_rhsAB", "compute_vel_rhs.UV_rhsAB", "e2")
         orc.call("viscosity_filter"); chk(step, "UV_rhs", "viscosity_filter.UV_rhs", "e2")
+        if orc.params.visc_option == 8:                     # backscatter_coef, uke_update (src/oce_dyn.F90:967-1152)
+            chk(step, "v_back", "viscosity_filter.v_back", "e"); chk(step, "uke", "viscosity_filter.uke", "e"); chk(step, "uke_rhs", "viscosity_filter.uke_rhs", "e")
         if orc.params.visc_option <= 3:                     # h_viscosity_leith (src/oce_dyn.F90:461-561)
             chk(step, "vorticity", "viscosity_filter.vorticity", "n"); chk(step, "Visc", "viscosity_filter.Visc", "e")
         orc.call("impl_vert_visc_ale"); chk(step, "UV_rhs", "impl_vert_visc_ale.UV_rhs", "e2")
@@ -68,7 +70,8 @@ def run_reference_chain(orc, mesh, g, steps=(1, 2, 3), toy=False, skip=(), after
         mine = orc.get("d_eta")
         assert orc.solver_residual < 1e-10
         # tolerance: both solves stop at ||scaled residual|| < 1e-10; scaled operator is O(1) -> |dx| ~ 1e-9
-        assert np.abs(mine - ref).max() < 5e-9, np.abs(mine - ref).max()
+        # (solver_skipped: a single-domain replay of the reference, whose pARMS solver cannot run on one rank -- the harness kept d_eta = 0)
+        assert solver_skipped or np.abs(mine - ref).max() < 5e-9, np.abs(mine - ref).max()
         orc.set("d_eta", ref)
         if toy:
             orc.call("relax_zonal_vel"); chk(step, "UV_rhs", "relax_zonal_vel.UV_rhs", "e2")

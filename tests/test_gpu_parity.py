@@ -773,16 +773,18 @@ def test_biharmonic_tracer_filter_chain_bitwise(built):
     gpu.close()
 
 
-def test_vector_invariant_momentum_chain_bitwise(built):
+@pytest.mark.parametrize("akw", [dict(which_ale="linfs", use_partial_cell=False), dict()])
+def test_vector_invariant_momentum_chain_bitwise(built, akw):
     """mom_adv = 3 (compute_vel_rhs_vinv: k_vinv_ke, k_leith_vort, k_vinv_elem) with the linear free surface and full cells; oracle pinned on the reference
-    run pi_pp_linfs_vinv: HIP == oracle bit for bit after every routine of 3 steps and after 6 further whole steps."""
+    run pi_pp_linfs_vinv: HIP == oracle bit for bit after every routine of 3 steps and after 6 further whole steps.  The same with zstar (pi_pp_vinv:
+    hpressure stays zero there in the reference)."""
     from fesom2_amd.mesh import Mesh
     from fesom2_amd.config import make_params
     from fesom2_amd.core import OceanCore
     from fesom2_amd.synthetic import analytic_ts, analytic_forcing
     from oracle_lib import Oracle
-    mesh = Mesh.load(PI, dt=900.0, which_ale="linfs", use_partial_cell=False)
-    par = make_params(dt=900.0, which_ale="linfs", use_partial_cell=False, mom_adv=3)
+    mesh = Mesh.load(PI, dt=900.0, **akw)
+    par = make_params(dt=900.0, mom_adv=3, **akw)
     st = mesh.initial_state(2)
     st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
     st.tr_arr_old[...] = st.tr_arr

@@ -262,23 +262,25 @@ def test_oracle_chain_bitwise_monin_obukhov_mixing(built, cfg, kw):
     assert not np.array_equal(g["s2/mixing.Kv"], g0["s2/mixing.Kv"]) and not np.array_equal(g["s2/mixing.Av"], g0["s2/mixing.Av"])
 
 
-def test_oracle_chain_bitwise_vector_invariant_momentum(built):
+@pytest.mark.parametrize("cfg,akw", [("pi_pp_linfs_vinv", dict(which_ale="linfs", use_partial_cell=False)), ("pi_pp_vinv", dict())])
+def test_oracle_chain_bitwise_vector_invariant_momentum(built, cfg, akw):
     """mom_adv = 3 (compute_vel_rhs_vinv, src/oce_vel_rhs_vinv.F90:104-322: kinetic energy at nodes, relative vorticity, gradient of the Bernoulli function) with
     the linear free surface and full cells, the only set-up in which the reference forms hpressure: reference run `pi_pp_linfs_vinv`, every routine of 3 steps
-    bit for bit."""
+    bit for bit.  `pi_pp_vinv`: the same with zstar and partial cells, where the reference leaves hpressure at the zeros of array_setup
+    (oce_setup_step.F90:384): compute_vel_rhs_vinv then runs without a baroclinic pressure term -- kept as the reference has it."""
     from fesom2_amd.mesh import Mesh
     from fesom2_amd.config import make_params
     from fesom2_amd.synthetic import analytic_ts
     from oracle_lib import Oracle
     from ref_chain import run_reference_chain
-    mesh = Mesh.load(PI, dt=900.0, which_ale="linfs", use_partial_cell=False)
-    par = make_params(dt=900.0, which_ale="linfs", use_partial_cell=False, mom_adv=3)
+    mesh = Mesh.load(PI, dt=900.0, **akw)
+    par = make_params(dt=900.0, mom_adv=3, **akw)
     st = mesh.initial_state(2)
     st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
     st.tr_arr_old[...] = st.tr_arr
     orc = Oracle(mesh, par)
     orc.set_state(st)
-    g = gold("pi_pp_linfs_vinv")
+    g = gold(cfg)
     for f in FORCING:
         orc.set(f, g["forcing/" + f])
     bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
@@ -479,11 +481,13 @@ def test_oracle_chain_bitwise_linfs_partial_cells(built):
     assert not np.array_equal(g["s2/pressure_force.pgf_x"], gz["s2/pressure_force.pgf_x"])
 
 
-@pytest.mark.parametrize("opt", [1, 2, 3, 4, 6, 7])
+@pytest.mark.parametrize("opt", [1, 2, 3, 4, 6, 7, 8])
 def test_oracle_chain_bitwise_biharmonic_viscosity(built, opt):
     """visc_option = 1 / 2 / 3 (h_viscosity_leith :461-561 over relative_vorticity src/oce_vel_rhs_vinv.F90:14-102, then visc_filt_harmon :236-273,
     visc_filt_hbhmix :376-458, visc_filt_biharm(2) :275-372; the Leith coefficient and the vorticity are compared too), 4 (visc_filt_biharm(1), src/oce_dyn.F90:275-372), 6 (visc_filt_bilapl, :658-726) and 7 (visc_filt_bidiff, :734-801) instead
-    of the easy backscatter: reference runs `pi_pp_visc4` / `pi_pp_visc6` / `pi_pp_visc7` (PP mixing, surface forcing), every routine of 3 steps bit for bit."""
+    of the easy backscatter: reference runs `pi_pp_visc4` / `pi_pp_visc6` / `pi_pp_visc7` (PP mixing, surface forcing), every routine of 3 steps bit for bit.
+    8: backscatter_coef + visc_filt_dbcksc + uke_update (:806-1152) with the prognostic unresolved kinetic energy uke: run `pi_pp_visc8`; v_back, uke and
+    uke_rhs are compared too (the result does not depend on the partition: smooth_elem only reads elements of owned nodes, which every rank forms itself)."""
     from fesom2_amd.mesh import Mesh
     from fesom2_amd.config import make_params
     from fesom2_amd.synthetic import analytic_ts
@@ -499,7 +503,9 @@ def test_oracle_chain_bitwise_biharmonic_viscosity(built, opt):
     g = gold(f"pi_pp_visc{opt}")
     for f in FORCING:
         orc.set(f, g["forcing/" + f])
-    bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
+    # (option 8 is pinned on a SINGLE-DOMAIN replay of the reference: on two ranks its edge loops add the halo edges of an element after the owned ones,
+    #  which moves 0.05 % of UV_dis by one ulp against the single-domain order; the harness keeps d_eta = 0 on one rank, pARMS cannot run there)
+    bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3), solver_skipped=(opt == 8))
     assert not bad, "\n".join(bad[:20])
     # the filter really differs from the default one: UV_rhs after viscosity_filter is not the backscatter result
     g5 = gold("pi_pp_wsplit")
