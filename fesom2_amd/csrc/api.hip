@@ -320,7 +320,7 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   hipEvent_t ev_op = d.ev(); hipEventRecord(ev_op, s1);
   // s3: viscosity stencil, then everything nobody waits for soon (sigma/slope, tracer preparation)
   if (m.p.visc_option <= 3) K(s3, "h_viscosity_leith");      // UV, Wvel, helem of the incoming state only
-  if (m.p.visc_option != 1) K(s3, "k_visc_elem");
+  if (m.p.visc_option != 1 && m.p.visc_option != 8) K(s3, "k_visc_elem");
   if (m.p.visc_option == 5) K(s3, "k_visc_node");
   hipEvent_t ev_visc = d.ev(); hipEventRecord(ev_visc, s3);
   if (s3 != s1) hipStreamWaitEvent(s3, ev_pb, 0);
@@ -345,7 +345,8 @@ void enqueue_step_dag(hipStream_t s0, int first_step, Dag &d, int n) {
   if (m.p.mix_scheme == 1) K(s0, "mixing_kpp");       // k_kpp_col, 3 smoothing sweeps, k_kpp_final, k_kpp_elem
   if (s3 != s1) hipStreamWaitEvent(s0, ev_rhs, 0);      // (one side stream: ev_visc is recorded behind ev_rhs and ev_op on it)
   hipStreamWaitEvent(s0, ev_visc, 0);
-  if (m.p.visc_option != 5) K(s0, "k_visc_apply");  // second stage of the biharmonic filters (visc_option 6, 7): in place on UV_rhs
+  if (m.p.visc_option == 8) K(s0, "viscosity_filter");   // backscatter_coef + visc_filt_dbcksc + uke_update: needs the complete UV_rhs, bvfreq
+  else if (m.p.visc_option != 5) K(s0, "k_visc_apply");  // second stage of the biharmonic filters (visc_option 6, 7): in place on UV_rhs
   K(s0, "k_impl_visc");                            // incl. the Thomas sweep
   K(s0, "k_edge_transport");
   if (s3 != s1) hipStreamWaitEvent(s0, ev_op, 0);
@@ -452,7 +453,8 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   if (d->nl > 64) { G.err = "fesom_gpu_init: nl > 64 levels not supported by the one-wave-per-column kernels"; return 3; }
   if (par->which_ale < 0 || par->which_ale > 2) { G.err = "fesom_gpu_init: which_ale must be linfs (0), zlevel (1) or zstar (2)"; return 3; }
   if (par->which_ale == 1 && (par->lzstar_lev < 1 || par->lzstar_lev > 32 || par->lzstar_lev + 1 > d->nl - 1)) { G.err = "fesom_gpu_init: which_ALE='zlevel' needs 1 <= lzstar_lev <= 32 and lzstar_lev + 1 layers"; return 3; }
-  if ((par->mom_adv != 2 && par->mom_adv != 3) || par->visc_option < 1 || par->visc_option > 7) { G.err = "fesom_gpu_init: only mom_adv=2 or 3, visc_option=1..7 are implemented"; return 3; }
+  if ((par->mom_adv != 2 && par->mom_adv != 3) || par->visc_option < 1 || par->visc_option > 8) { G.err = "fesom_gpu_init: only mom_adv=2 or 3, visc_option=1..8 are implemented"; return 3; }
+  if (par->visc_option == 8 && part && part->npes > 1) { G.err = "fesom_gpu_init: visc_option=8 (backscatter with the uke budget) is built for one partition"; return 3; }
   // (mom_adv = 3 reads hpressure, which the reference forms with which_ALE='linfs' only, oce_ale_pressure_bv.F90:262; with zstar / zlevel the array keeps
   //  the zeros of array_setup, oce_setup_step.F90:384, and compute_vel_rhs_vinv runs without a baroclinic pressure term -- kept as it is: run pi_pp_vinv)
   if (par->which_pgf != 0 && par->which_pgf != 1 && !(par->which_pgf == 2 && par->which_ale == 0) && !(par->which_pgf == 3) && !(par->which_ale == 0 && !par->use_partial_cell)) {
@@ -618,6 +620,11 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   F(ssh_values, m.nza);
   if (par->which_pgf == 0 && !(par->which_ale == 0 && !par->use_partial_cell)) { F(pgf_A, n1 * N); F(pgf_B, n1 * N); }      // shchepetkin variants
   if (par->visc_option <= 3) { F(Visc, n1 * E); F(leith_aux, n1 * N); }
+  if (par->visc_option == 8) {
+    F(uke, n1 * E); F(v_back, n1 * E); F(uke_rhs, n1 * E); F(uke_rhs_old, n1 * E); F(uke_dif, n1 * E); F(uke_dis, n1 * E); F(uke_back, n1 * E);
+    F(UV_dis_tend, 2 * n1 * E); F(UV_back_tend, 2 * n1 * E); F(v8_work, 2 * n1 * N); F(v8_rb, N);
+    if (!m.coriolis_node) m.coriolis_node = dev_upload_d(d->coriolis_node, N);
+  }
   if (par->smooth_bh_tra) FT(bh_tmp, n1 * N);
   m.ale_flag = dev_alloc<int>(1); HIPCHK(hipMemset(m.ale_flag, 0, sizeof(int)));
   if (par->SPP) { std::vector<double> gl(N); for (size_t n = 0; n < N; n++) gl[n] = d->geo_coord_nod2D[2 * n + 1]; m.geo_lat = dev_upload(gl); }

@@ -58,6 +58,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   double *bh_tmp;                          // smooth_bh_tra: first stage of the biharmonic tracer filter (nl-1, N) per tracer
   double *KE_node;                         // mom_adv = 3: kinetic energy at nodes (nl-1, N)
   const unsigned char *wall_node;          // mom_adv = 3: 1 for both nodes of the owned boundary edges (KE_node = 0 at lateral walls)
+  double *uke, *v_back, *uke_rhs, *uke_rhs_old, *uke_dif, *uke_dis, *uke_back, *UV_dis_tend, *UV_back_tend, *v8_work, *v8_rb;   // visc_option 8: sub-grid energy budget (nl-1, E), tendencies (2, nl-1, E), smoothing work array (2, nl-1, N), Rossby radius (N)
   double *Visc, *vorticity, *leith_aux;    // visc_option 1-3: Leith coefficient (nl-1, E), relative vorticity and smoothing work array (nl-1, N)
   double *pgf_x, *pgf_y, *helem, *Av, *dhe, *stress_surf;
   double *pgf_A, *pgf_B;                   // shchepetkin PGF: the two quotients of the density-Jacobian's vertical derivative that depend on the NODE column only (k_pressure_bv forms them once per node and level; every element around the node reads them)

@@ -945,6 +945,177 @@ __global__ void __launch_bounds__(BLOCK) k_visc_node(DM m) {
   DV2(m.U_c, 2, nz, n) = v1 / vi;
 }
 
+// ------------------------------------------------------------------------------------------------
+// visc_option = 8: backscatter_coef (src/oce_dyn.F90:967-996), visc_filt_dbcksc (:806-964), uke_update (:999-1152) -- kinematic backscatter with
+// the prognostic sub-grid energy `uke`.  Single partition, which_toy = 'soufflet' (the branch without the regional mask, :1122-1125).  The
+// reference's edge loops become gathers over the <=3 internal edges of an element in edge order (ee_idx), as in k_visc_elem.
+// (1) v_back and the first stage U_c (kept in U_b)
+__global__ void __launch_bounds__(BLOCK) k_v8_first(DM m) {
+  int e = col_id(m), nz = lane_id() + 1;
+  if (e >= m.myE) return;
+  if (nz > m.nlm1) return;
+  const double dt = m.p.dt, ar = m.elem_area[e];
+  const bool wet = nz <= m.nlev[e] - 1;
+  DA2(m.v_back, nz, e) = wet ? dmin_(-m.p.c_back * sqrt(ar) * sqrt(dmax_(2.0 * DA2(m.uke, nz, e), 0.0)), 0.2 * ar / dt) : 0.0;
+  double ub = 0.0, vb = 0.0;
+  for (int q = 0; q < 3; q++) {
+    int side = m.ee_side[3 * e + q];
+    if (side == 0) continue;
+    int ed = m.ee_idx[3 * e + q];
+    int e1 = m.edge_tri[2 * ed], e2 = m.edge_tri[2 * ed + 1];
+    if (nz > min(m.nlev[e1], m.nlev[e2]) - 1) continue;
+    double u1 = DV2(m.UV, 1, nz, e1) - DV2(m.UV, 1, nz, e2);
+    double v1 = DV2(m.UV, 2, nz, e1) - DV2(m.UV, 2, nz, e2);
+    if (side == 1) { ub = ub - u1; vb = vb - v1; }
+    else           { ub = ub + u1; vb = vb + v1; }
+  }
+  if (wet) {      // :861-870
+    double len = sqrt(ar);
+    len = dt * len / 30.0;
+    double uu = DV2(m.UV, 1, nz, e), vv = DV2(m.UV, 2, nz, e);
+    double vi = dmax_(0.2, sqrt(uu * uu + vv * vv)) * len;
+    ub = -ub * vi; vb = -vb * vi;
+  }
+  DV2(m.U_b, 1, nz, e) = ub;
+  DV2(m.U_b, 2, nz, e) = vb;
+}
+// (2) the tendencies of the second edge loop (:875-917): backscatter (UV_back_tend), dissipation (UV_dis_tend), diffusion of uke (uke_dif)
+__global__ void __launch_bounds__(BLOCK) k_v8_tend(DM m) {
+  int e = col_id(m), nz = lane_id() + 1;
+  if (e >= m.myE) return;
+  if (nz > m.nlm1) return;
+  const double dt = m.p.dt;
+  double bu = 0.0, bv = 0.0, du = 0.0, dv = 0.0, kd = 0.0;
+  for (int q = 0; q < 3; q++) {
+    int side = m.ee_side[3 * e + q];
+    if (side == 0) continue;
+    int ed = m.ee_idx[3 * e + q];
+    int e1 = m.edge_tri[2 * ed], e2 = m.edge_tri[2 * ed + 1];
+    if (nz > min(m.nlev[e1], m.nlev[e2]) - 1) continue;
+    double a1 = m.elem_area[e1], a2 = m.elem_area[e2];
+    double le1 = m.edxy[2 * ed] * (m.elem_cos[e1] + m.elem_cos[e2]) * 0.25, le2 = m.edxy[2 * ed + 1];
+    double len = sqrt(le1 * le1 + le2 * le2) * D_REARTH;
+    le1 = m.ecd[4 * ed] - m.ecd[4 * ed + 2]; le2 = m.ecd[4 * ed + 1] - m.ecd[4 * ed + 3];
+    double crosslen = sqrt(le1 * le1 + le2 * le2);
+    double vi = dt * len * (DA2(m.v_back, nz, e1) + DA2(m.v_back, nz, e2)) / crosslen;
+    double u1 = (DV2(m.UV, 1, nz, e1) - DV2(m.UV, 1, nz, e2)) * vi, v1 = (DV2(m.UV, 2, nz, e1) - DV2(m.UV, 2, nz, e2)) * vi;
+    vi = dt * len * (m.p.K_back * sqrt(a1 / m.p.scale_area) + m.p.K_back * sqrt(a2 / m.p.scale_area)) / crosslen;
+    double uke1 = (DA2(m.uke, nz, e1) - DA2(m.uke, nz, e2)) * vi;
+    double uc = DV2(m.U_b, 1, nz, e1) - DV2(m.U_b, 1, nz, e2), vc = DV2(m.U_b, 2, nz, e1) - DV2(m.U_b, 2, nz, e2);
+    if (side == 1) { bu = bu - u1 / a1; bv = bv - v1 / a1; kd = kd - uke1 / a1; du = du - uc / a1; dv = dv - vc / a1; }
+    else           { bu = bu + u1 / a2; bv = bv + v1 / a2; kd = kd + uke1 / a2; du = du + uc / a2; dv = dv + vc / a2; }
+  }
+  DV2(m.UV_back_tend, 1, nz, e) = bu; DV2(m.UV_back_tend, 2, nz, e) = bv;
+  DV2(m.UV_dis_tend, 1, nz, e) = du; DV2(m.UV_dis_tend, 2, nz, e) = dv;
+  DA2(m.uke_dif, nz, e) = kd;
+}
+// smooth_elem2D (src/gen_support.F90:183-212), one round = element -> node (area-weighted mean over the whole cluster, dry cells included)
+// -> element (mean of the three nodes); every level of the array, nc interleaved components
+__global__ void __launch_bounds__(BLOCK) k_v8_smooth_node(DM m, const double *arr, int nc, double *work) {
+  int n = col_id(m), nz = lane_id() + 1;
+  if (n >= m.myN) return;
+  if (nz > m.nlm1) return;
+  double vol = 0.0, w0 = 0.0, w1 = 0.0;
+  int num = m.nie_num[n];
+  for (int k = 0; k < num; k++) {
+    int e = m.nie[(size_t)m.maxk * n + k];
+    double ar = m.elem_area[e];
+    size_t i = ((size_t)e * m.nlm1 + (nz - 1)) * nc;
+    w0 = w0 + arr[i] * ar;
+    if (nc == 2) w1 = w1 + arr[i + 1] * ar;
+    vol = vol + ar;
+  }
+  size_t o = ((size_t)n * m.nlm1 + (nz - 1)) * nc;
+  work[o] = w0 / vol;
+  if (nc == 2) work[o + 1] = w1 / vol;
+}
+__global__ void __launch_bounds__(BLOCK) k_v8_smooth_elem(DM m, double *arr, int nc, const double *work) {
+  int e = col_id(m), nz = lane_id() + 1;
+  if (e >= m.myE) return;
+  if (nz > m.nlm1) return;
+  const int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
+  for (int c = 0; c < nc; c++) {
+    double a = work[((size_t)n1 * m.nlm1 + (nz - 1)) * nc + c], b = work[((size_t)n2 * m.nlm1 + (nz - 1)) * nc + c], d = work[((size_t)n3 * m.nlm1 + (nz - 1)) * nc + c];
+    arr[((size_t)e * m.nlm1 + (nz - 1)) * nc + c] = ((a + b) + d) / 3.0;
+  }
+}
+// (3) :945-952 UV_rhs += dissipation + smoothed backscatter; uke_update :1031-1043: the work of both tendencies
+__global__ void __launch_bounds__(BLOCK) k_v8_apply(DM m) {
+  int e = col_id(m), nz = lane_id() + 1;
+  if (e >= m.myE) return;
+  if (nz > m.nlm1) return;
+  double kdis = 0.0, kback = 0.0;
+  if (nz <= m.nlev[e] - 1) {
+    double du = DV2(m.UV_dis_tend, 1, nz, e), dv = DV2(m.UV_dis_tend, 2, nz, e), bu = DV2(m.UV_back_tend, 1, nz, e), bv = DV2(m.UV_back_tend, 2, nz, e);
+    double u = DV2(m.UV, 1, nz, e), v = DV2(m.UV, 2, nz, e);
+    DV2(m.UV_rhs, 1, nz, e) = DV2(m.UV_rhs, 1, nz, e) + du + bu;
+    DV2(m.UV_rhs, 2, nz, e) = DV2(m.UV_rhs, 2, nz, e) + dv + bv;
+    kdis = (u * du + v * dv);
+    kback = (u * bu + v * bv);
+  }
+  DA2(m.uke_dis, nz, e) = kdis; DA2(m.uke_back, nz, e) = kback;
+}
+// uke_update :1053-1070: U_work = area-weighted node mean of u over the whole cluster, V_work = U_work / vol as the reference has it (:1066); kept in U_c.
+// One extra lane forms the baroclinic Rossby radius of the node column (:1090-1101) when uke_scaling is on.
+__global__ void __launch_bounds__(BLOCK) k_v8_unode(DM m) {
+  int n = col_id(m), nz = lane_id() + 1;
+  if (n >= m.myN) return;
+  if (m.p.uke_scaling && nz == WAVE) {
+    const double c_min = 0.5, f_min = 1.e-6, r_max = 200000., pi = 3.14159265358979;
+    double c1 = 0.0;
+    int nzmax = m.nlev_n_min[n];
+    for (int k = 1; k <= nzmax - 1; k++)
+      c1 = c1 + DA2(m.hnode_new, k, n) * (sqrt(dmax_(DA2L(m.bvfreq, k, n), 0.0)) + sqrt(dmax_(DA2L(m.bvfreq, k + 1, n), 0.0))) / 2.;
+    c1 = dmax_(c_min, c1 / pi);
+    m.v8_rb[n] = dmin_(c1 / dmax_(fabs(m.coriolis_node[n]), f_min), r_max);
+  }
+  if (nz > m.nlm1) return;
+  double vol = 0.0, u = 0.0;
+  int num = m.nie_num[n];
+  for (int k = 0; k < num; k++) {
+    int e = m.nie[(size_t)m.maxk * n + k];
+    double ar = m.elem_area[e];
+    u = u + DV2(m.UV, 1, nz, e) * ar;
+    vol = vol + ar;
+  }
+  u = u / vol;
+  DV2(m.U_c, 1, nz, n) = u; DV2(m.U_c, 2, nz, n) = u / vol;
+}
+// :1072-1132 Rossby number of the node-mean flow, resolution scaling, damping of the dissipated energy
+__global__ void __launch_bounds__(BLOCK) k_v8_rosb(DM m) {
+  int e = col_id(m), nz = lane_id() + 1;
+  if (e >= m.myE) return;
+  if (nz > m.nlev[e] - 1) return;
+  const double f_min = 1.e-6;
+  const int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
+  const double *gs = m.gsca + 6 * (size_t)e;
+  double u1 = DV2(m.U_c, 1, nz, n1), u2 = DV2(m.U_c, 1, nz, n2), u3 = DV2(m.U_c, 1, nz, n3);
+  double v1 = DV2(m.U_c, 2, nz, n1), v2 = DV2(m.U_c, 2, nz, n2), v3 = DV2(m.U_c, 2, nz, n3);
+  double gu = (gs[0] * u1 + gs[1] * u2) + gs[2] * u3, hv = (gs[3] * v1 + gs[4] * v2) + gs[5] * v3;
+  double hu = (gs[3] * u1 + gs[4] * u2) + gs[5] * u3, gv = (gs[0] * v1 + gs[1] * v2) + gs[2] * v3;
+  double rosb = sqrt((gu - hv) * (gu - hv) + (hu + gv) * (hu + gv));
+  double scaling = 1.0;
+  if (m.p.uke_scaling) {
+    double reso = sqrt(m.elem_area[e] * 4.0 / sqrt(3.0));
+    double rb = ((m.v8_rb[n1] + m.v8_rb[n2]) + m.v8_rb[n3]) / 3.0;
+    scaling = 1.0 / (1.0 + (m.p.uke_scaling_factor * reso / rb));
+  }
+  double fsum = (m.coriolis_node[n1] + m.coriolis_node[n2]) + m.coriolis_node[n3];
+  rosb = rosb / dmax_(fabs(fsum), f_min);
+  DA2(m.uke_dis, nz, e) = scaling * 1.0 / (1.0 + rosb / m.p.rosb_dis) * DA2(m.uke_dis, nz, e);
+}
+// :1139-1149 second-order Adams-Bashforth step of uke
+__global__ void __launch_bounds__(BLOCK) k_v8_uke(DM m) {
+  int e = col_id(m), nz = lane_id() + 1;
+  if (e >= m.myE) return;
+  if (nz > m.nlev[e] - 1) return;
+  double old = DA2(m.uke_rhs, nz, e);
+  double rhs = -DA2(m.uke_dis, nz, e) - DA2(m.uke_back, nz, e) + DA2(m.uke_dif, nz, e);
+  DA2(m.uke_rhs_old, nz, e) = old;
+  DA2(m.uke_rhs, nz, e) = rhs;
+  DA2(m.uke, nz, e) = DA2(m.uke, nz, e) + 1.5 * rhs - 0.5 * old;
+}
+
 // impl_vert_visc_ale (src/oce_ale.F90:2348-2517) with the last loop of visc_filt_bcksct (oce_dyn.F90:638-648)
 // fused in front.  Coefficients per level in parallel (this kernel); the Thomas sweep runs one lane per column in
 // k_thomas<2>.  1 N3 + 8 E3 values (+ 5 E3 scratch written, 5 read).
@@ -1060,6 +1231,25 @@ static void launch_impl_visc(const DM &m, hipStream_t s, int av, int di) {
   }
 }
 #define LAUNCH_IMPL_VISC(av, di) launch_impl_visc(m, s, av, di)
+
+// viscosity_filter for visc_option = 8 (:196-228 -> backscatter_coef, visc_filt_dbcksc, uke_update), 10 + 2 x (smoothing rounds) launches
+static void launch_visc8(const DM &m, hipStream_t s) {
+  auto smooth = [&](double *arr, int nc, int rounds) {
+    for (int q = 0; q < rounds; q++) {
+      hipLaunchKernelGGL(k_v8_smooth_node, dim3(nblocks(m.myN)), dim3(BLOCK), 0, s, m, arr, nc, m.v8_work);
+      hipLaunchKernelGGL(k_v8_smooth_elem, dim3(nblocks(m.myE)), dim3(BLOCK), 0, s, m, arr, nc, m.v8_work);
+    }
+  };
+  hipLaunchKernelGGL(k_v8_first, dim3(nblocks(m.myE)), dim3(BLOCK), 0, s, m);
+  hipLaunchKernelGGL(k_v8_tend, dim3(nblocks(m.myE)), dim3(BLOCK), 0, s, m);
+  smooth(m.UV_back_tend, 2, m.p.smooth_back_tend);
+  hipLaunchKernelGGL(k_v8_apply, dim3(nblocks(m.myE)), dim3(BLOCK), 0, s, m);
+  smooth(m.uke_back, 1, m.p.smooth_back);
+  hipLaunchKernelGGL(k_v8_unode, dim3(nblocks(m.myN)), dim3(BLOCK), 0, s, m);
+  hipLaunchKernelGGL(k_v8_rosb, dim3(nblocks(m.myE)), dim3(BLOCK), 0, s, m);
+  smooth(m.uke_dis, 1, m.p.smooth_dis);
+  hipLaunchKernelGGL(k_v8_uke, dim3(nblocks(m.myE)), dim3(BLOCK), 0, s, m);
+}
 
 // ------------------------------------------------------------------------------------------------
 // update_stiff_mat_ale (src/oce_ale.F90:1371-1470) as a gather per CSR entry: the contribution list of every
@@ -1441,10 +1631,13 @@ void launch_dynamics_pre(const DM &m, hipStream_t s, int first_step) {
   }
   if (m.p.mix_scheme == 1) launch_named_kpp(m, s, "mixing_kpp");      // (launches k_momix itself)
   launch_vel_rhs(m, s, first_step);
-  if (m.p.visc_option <= 3) launch_leith(m, s);
-  if (m.p.visc_option != 1) LAUNCH_COL(k_visc_elem, m.E, m);
-  if (m.p.visc_option == 5) LAUNCH_COL(k_visc_node, m.myN, m);
-  else LAUNCH_COL(k_visc_apply, m.myE, m);
+  if (m.p.visc_option == 8) launch_visc8(m, s);
+  else {
+    if (m.p.visc_option <= 3) launch_leith(m, s);
+    if (m.p.visc_option != 1) LAUNCH_COL(k_visc_elem, m.E, m);
+    if (m.p.visc_option == 5) LAUNCH_COL(k_visc_node, m.myN, m);
+    else LAUNCH_COL(k_visc_apply, m.myE, m);
+  }
   LAUNCH_IMPL_VISC(m.p.visc_option == 5, m.p.i_vert_visc);
 }
 void launch_ssh_rhs(const DM &m, hipStream_t s) {
@@ -1468,6 +1661,7 @@ void launch_thickness(const DM &m, hipStream_t s) {
 
 int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int first_step) {
   (void)arg;
+  if (!strcmp(name, "h_viscosity_leith")) { launch_leith(m, s); return 0; }
   // single kernels (bench.py times each one for the roofline object)
   if (!strncmp(name, "k_", 2)) {
     int ncol_uv = m.myE > (m.N + BLOCK - 1) / BLOCK * COLS_PER_BLOCK ? m.myE : (m.N + BLOCK - 1) / BLOCK * COLS_PER_BLOCK;
@@ -1489,7 +1683,6 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
     if (!strcmp(name, "k_leith_elem")) { LAUNCH_COL(k_leith_elem, m.E, m); return 0; }
     if (!strcmp(name, "k_leith_node")) { LAUNCH_COL(k_leith_node, m.myN, m); return 0; }
     if (!strcmp(name, "k_leith_avg")) { LAUNCH_COL(k_leith_avg, m.myE, m); return 0; }
-    if (!strcmp(name, "h_viscosity_leith")) { launch_leith(m, s); return 0; }
     if (!strcmp(name, "k_visc_node")) { LAUNCH_COL(k_visc_node, m.myN, m); return 0; }
     if (!strcmp(name, "k_visc_apply")) { LAUNCH_COL(k_visc_apply, m.myE, m); return 0; }
     if (!strcmp(name, "k_impl_visc")) { LAUNCH_IMPL_VISC(m.p.visc_option == 5, m.p.i_vert_visc); return 0; }
@@ -1518,7 +1711,8 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
   }
   if (!strcmp(name, "mo_convect")) return 0;                                                  // fused into mixing_pp
   if (!strcmp(name, "compute_vel_rhs")) { launch_vel_rhs(m, s, first_step); return 0; }
-  if (!strcmp(name, "visc_filt_bcksct") || !strcmp(name, "viscosity_filter")) {      // viscosity_filter(visc_option): 1 .. 7
+  if (!strcmp(name, "visc_filt_bcksct") || !strcmp(name, "viscosity_filter")) {      // viscosity_filter(visc_option): 1 .. 8
+    if (m.p.visc_option == 8) { launch_visc8(m, s); return 0; }
     if (m.p.visc_option <= 3) launch_leith(m, s);
     if (m.p.visc_option != 1) LAUNCH_COL(k_visc_elem, m.E, m);
     if (m.p.visc_option != 5) { LAUNCH_COL(k_visc_apply, m.myE, m); return 0; }

@@ -322,6 +322,7 @@ contains
     end select
     p%use_partial_cell = l2i(use_partial_cell); p%state_equation = state_equation; p%num_tracers = num_tracers
     p%mom_adv = mom_adv; p%visc_option = visc_option; p%i_vert_visc = l2i(i_vert_visc); p%i_vert_diff = l2i(i_vert_diff)
+    if (visc_option == 8 .and. trim(which_toy) /= 'soufflet') p%visc_option = -1    ! uke_update's regional mask (oce_dyn.F90:1107-1121) is not built: the library refuses, the caller keeps the CPU step
     p%w_split = l2i(w_split)
     p%mix_scheme = mix_scheme_nmb                  ! 1 KPP, 2 PP (oce_setup_step.F90:69-82); others are rejected by the library
     p%use_instabmix = l2i(use_instabmix); p%use_windmix = l2i(use_windmix); p%windmix_nl = windmix_nl

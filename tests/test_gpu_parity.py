@@ -477,11 +477,12 @@ def test_no_limiter_chain_bitwise(built):
     gpu.close()
 
 
-@pytest.mark.parametrize("opt", [1, 2, 3, 4, 6, 7])
+@pytest.mark.parametrize("opt", [1, 2, 3, 4, 6, 7, 8])
 def test_biharmonic_viscosity_chain_bitwise(built, opt):
     """visc_option 1 / 2 / 3 (h_viscosity_leith + visc_filt_harmon / visc_filt_hbhmix / visc_filt_biharm(2); the Leith coefficient and the relative
-    vorticity are compared as well) and 4 / 6 / 7 (visc_filt_biharm(1), visc_filt_bilapl, visc_filt_bidiff); oracle pinned on the reference runs
-    pi_pp_visc1 .. 7: HIP == oracle bit for bit after every routine of 3 steps under surface forcing."""
+    vorticity are compared as well), 4 / 6 / 7 (visc_filt_biharm(1), visc_filt_bilapl, visc_filt_bidiff) and 8 (backscatter_coef + visc_filt_dbcksc +
+    uke_update; the sub-grid energy budget is compared as well); oracle pinned on the reference runs pi_pp_visc1 .. 8: HIP == oracle bit for bit
+    after every routine of 3 steps under surface forcing."""
     from fesom2_amd.mesh import Mesh
     from fesom2_amd.config import make_params
     from fesom2_amd.core import OceanCore
@@ -502,13 +503,22 @@ def test_biharmonic_viscosity_chain_bitwise(built, opt):
     for step in range(1, 4):
         for routine, arg, fields in full_chain(2):
             gpu.call(routine, arg); orc.call(routine, arg)
-            for f in list(fields) + (["Visc", "vorticity"] if routine == "viscosity_filter" and opt <= 3 else []):
+            extra = []
+            if routine == "viscosity_filter":
+                extra = ["Visc", "vorticity"] if opt <= 3 else ["v_back", "UV_dis_tend", "UV_back_tend", "uke_dif", "uke_dis", "uke_back", "uke_rhs", "uke_rhs_old", "uke"] if opt == 8 else []
+            for f in list(fields) + extra:
                 ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
                 if not ok:
                     failures.append(f"step {step} {routine}({arg}) {msg}")
         if failures:
             break
     assert not failures, "\n".join(failures[:10])
+    gpu.run_steps(4, 4)                                  # the whole-step launch order (stream DAG) as well
+    for n in range(4, 8):
+        orc.call("step", n)
+    for f in ("UV", "eta_n", "tr_arr") + (("uke", "uke_rhs") if opt == 8 else ()):
+        ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+        assert ok, msg
     gpu.close()
 
 
@@ -893,8 +903,8 @@ def test_monin_obukhov_mixing_chain(built, kw):
     gpu.close()
 
 
-@pytest.mark.parametrize("field,value,msg", [("visc_option", 0, "visc_option"), ("visc_option", 8, "visc_option"), ("which_pgf", -1, "which_pgf"), ("tra_adv_ver", 4, "tra_adv_ver"),
-                                             ("tra_adv_ver", -1, "tra_adv_ver"), ("tra_adv_hor", 3, "tra_adv_hor"), ("mom_adv", 3, "mom_adv"),
+@pytest.mark.parametrize("field,value,msg", [("visc_option", 0, "visc_option"), ("visc_option", 9, "visc_option"), ("which_pgf", -1, "which_pgf"), ("tra_adv_ver", 4, "tra_adv_ver"),
+                                             ("tra_adv_ver", -1, "tra_adv_ver"), ("tra_adv_hor", 3, "tra_adv_hor"), ("mom_adv", 1, "mom_adv"),
                                              ("mix_scheme", 3, "mix_scheme")])
 def test_init_refuses_options_it_does_not_implement(built, field, value, msg):
     """fesom_gpu_init fails with a message naming the option instead of silently running something else (the Fortran layer maps a
