@@ -513,8 +513,8 @@ def test_biharmonic_viscosity_chain_bitwise(built, opt):
         if failures:
             break
     assert not failures, "\n".join(failures[:10])
-    gpu.run_steps(4, 4)                                  # the whole-step launch order (stream DAG) as well
-    for n in range(4, 8):
+    gpu.run_steps(4, 8)                                  # the whole-step launch order (stream DAG) as well
+    for n in range(4, 12):
         orc.call("step", n)
     for f in ("UV", "eta_n", "tr_arr") + (("uke", "uke_rhs") if opt == 8 else ()):
         ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
