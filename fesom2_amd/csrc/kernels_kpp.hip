@@ -332,6 +332,63 @@ __global__ void __launch_bounds__(BLOCK) k_kpp_smooth(DM m, const double *src, d
   for (int f = 0; f < 3; f++) dst[(size_t)f * nlN + (size_t)n * m.nl + l] = in ? work[f] * vol : 0.0;
 }
 
+// The same sweep with the distinct nodes of the cluster staged ONCE per wave (DM::kpp_nb: 7 columns x 3 fields on a regular mesh instead of the 18 x 3
+// gathers of the element loop): all loads issued together, then field by field through a wave-private LDS image from which every element takes
+// its 3 nodes (DM::kpp_pos).  Same sums in the same order.  MAXU = upper bound of the distinct nodes (DM::kpp_maxu).
+template <int MAXU>
+__global__ void __launch_bounds__(BLOCK) k_kpp_smooth_u(DM m, const double *src, double *dst) {
+  __shared__ double img[COLS_PER_BLOCK][MAXU][WAVE];
+  const int n = col_id(m), l = lane_id(), nz = l + 1, w = threadIdx.x >> 6;
+  if (n >= m.myN) return;
+  const size_t nlN = (size_t)m.nl * m.N;
+  const int uln = m.ulev_n[n], nln = m.nlev_n[n] < m.nl ? m.nlev_n[n] : m.nl;
+  const int num = m.nie_num[n], nu = m.kpp_nbn[n];
+  int nb_l = 0, pos_l = 0, lo_l = 1, hi_l = 0;
+  double ar_l = 0.0;
+  if (l < nu) nb_l = m.kpp_nb[(size_t)m.kpp_maxu * n + l];
+  if (l < num) {
+    const int el = m.nie[(size_t)m.maxk * n + l];
+    pos_l = m.kpp_pos[(size_t)m.maxk * n + l];
+    lo_l = uln > m.ulev[el] ? uln : m.ulev[el];
+    const int nle = m.nlev[el] < m.nl ? m.nlev[el] : m.nl;
+    hi_l = nln < nle ? nln : nle;
+    ar_l = m.elem_area[el];
+  }
+  const int nzc = nz <= m.nl ? nz : m.nl;
+  double v[3][MAXU];
+#pragma unroll
+  for (int q = 0; q < MAXU; q++) {
+    const int a = rdlane(nb_l, q < nu ? q : 0);
+#pragma unroll
+    for (int f = 0; f < 3; f++) v[f][q] = DA2L(src + (size_t)f * nlN, nzc, a);
+  }
+  double work[3] = {0.0, 0.0, 0.0}, vol = 0.0;
+#pragma unroll
+  for (int f = 0; f < 3; f++) {
+#pragma unroll
+    for (int q = 0; q < MAXU; q++) img[w][q][l] = v[f][q];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double wk = 0.0, vl = 0.0;
+    for (int k = 0; k < num; k++) {
+      const int pk = rdlane(pos_l, k);
+      const double ar = bcast(ar_l, k);
+      const bool on = nz >= rdlane(lo_l, k) && nz <= rdlane(hi_l, k);
+      const double nw = wk + ar * (img[w][pk & 0xff][l] + img[w][(pk >> 8) & 0xff][l] + img[w][(pk >> 16) & 0xff][l]);
+      const double nv = vl + ar;
+      wk = on ? nw : wk; vl = on ? nv : vl;
+    }
+    work[f] = wk; vol = vl;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (nz > m.nl) return;
+  const bool in = nz >= uln && nz <= nln;
+  if (in) vol = 1. / (3. * vol);
+#pragma unroll
+  for (int f = 0; f < 3; f++) dst[(size_t)f * nlN + (size_t)n * m.nl + l] = in ? work[f] * vol : 0.0;
+}
+
 // :377-392 + Kv = Kv_double(:,:,1) + mo_convect node part (oce_mo_conv.F90:47-57)
 __device__ __forceinline__ void kpp_final_body(const DM &m, int n) {
   const int l = lane_id(), nz = l + 1;
@@ -394,7 +451,11 @@ __global__ void __launch_bounds__(BLOCK) k_kpp_final_elem(DM m, int ncolE) {
 
 #define LAUNCH_COL(k, ncol, ...) hipLaunchKernelGGL(k, dim3(nblocks(ncol)), dim3(BLOCK), 0, s, __VA_ARGS__)
 static void smooth(const DM &m, hipStream_t s, const double *src, double *dst) {
-  hipLaunchKernelGGL(k_kpp_smooth, dim3(nblocks(m.myN)), dim3(BLOCK), 0, s, m, src, dst);      // the three blmc fields in one wave per node
+  static const int env = getenv("FESOM_GPU_EXP_KPPU") ? atoi(getenv("FESOM_GPU_EXP_KPPU")) : -1;
+  const bool staged = (env >= 0 ? env != 0 : m.use_tile != 0) && m.kpp_maxu <= 12;
+  if (staged && m.kpp_maxu <= 8) hipLaunchKernelGGL((k_kpp_smooth_u<8>), dim3(nblocks(m.myN)), dim3(BLOCK), 0, s, m, src, dst);
+  else if (staged) hipLaunchKernelGGL((k_kpp_smooth_u<12>), dim3(nblocks(m.myN)), dim3(BLOCK), 0, s, m, src, dst);
+  else hipLaunchKernelGGL(k_kpp_smooth, dim3(nblocks(m.myN)), dim3(BLOCK), 0, s, m, src, dst);      // the three blmc fields in one wave per node
 }
 int launch_named_kpp(const DM &m, hipStream_t s, const char *name) {
   if (m.p.mix_scheme != 1) return -1;

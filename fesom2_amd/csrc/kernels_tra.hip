@@ -60,6 +60,64 @@ __global__ void __launch_bounds__(BLOCK) k_tr_grad_elem(DM m, int tr0) {
   DV2(t.tr_xy, 1, nz, e) = DGS(1, e) * c1 + DGS(2, e) * c2 + DGS(3, e) * c3;
   DV2(t.tr_xy, 2, nz, e) = DGS(4, e) * c1 + DGS(5, e) * c2 + DGS(6, e) * c3;
 }
+// The same for CORE2-class meshes: EPW elements and NT tracers per wave.  The index chain (element -> its 3 nodes, level range) is fetched lane-parallel
+// ONCE for the wave's elements, then all 6 * NT * EPW column loads are issued before the first use: the kernel is bound by the number of loads in
+// flight, not by bandwidth (a column is only 376 B).  Same expressions per cell as k_tr_grad_elem.
+template <int EPW, int NT>
+__global__ void __launch_bounds__(BLOCK) k_tr_grad_elem_b(DM m, int tr0) {
+  const int slot0 = (xcd_block() * COLS_PER_BLOCK + (threadIdx.x >> 6)) * EPW;
+  const int l = lane_id(), nz = l + 1, trb = tr0 + blockIdx.y * NT;
+  int e_l = 0x7fffffff, lo_l = 1, hi_l = 0, nd_l = 0;
+  if (l < EPW) {
+    e_l = sub_col(m, slot0 + l);
+    if (e_l < m.myE) { lo_l = m.ulev[e_l]; hi_l = m.nlev[e_l] - 1; }
+  }
+  {
+    const int eq = __shfl(e_l, l / 3, 64);
+    if (l < 3 * EPW && eq < m.myE) nd_l = m.elem_nodes[3 * eq + l % 3];
+  }
+  double a[EPW][NT][3], c[EPW][NT][3];
+  const int nzc = nz <= m.nlm1 ? nz : m.nlm1;
+#pragma unroll
+  for (int i = 0; i < EPW; i++) {
+    const int n1 = rdlane(nd_l, 3 * i), n2 = rdlane(nd_l, 3 * i + 1), n3 = rdlane(nd_l, 3 * i + 2);
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      const int tr = trb + t < m.ntr ? trb + t : m.ntr - 1;
+      a[i][t][0] = DTR(m.tr_arr_old, nzc, n1, tr); a[i][t][1] = DTR(m.tr_arr_old, nzc, n2, tr); a[i][t][2] = DTR(m.tr_arr_old, nzc, n3, tr);
+      c[i][t][0] = DTR(m.tr_arr, nzc, n1, tr); c[i][t][1] = DTR(m.tr_arr, nzc, n2, tr); c[i][t][2] = DTR(m.tr_arr, nzc, n3, tr);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < EPW; i++) {
+    const int e = rdlane(e_l, i);
+    if (e >= m.myE) continue;
+    if (nz < rdlane(lo_l, i) || nz > rdlane(hi_l, i)) continue;
+    const double g1 = DGS(1, e), g2 = DGS(2, e), g3 = DGS(3, e), g4 = DGS(4, e), g5 = DGS(5, e), g6 = DGS(6, e);
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      if (trb + t >= m.ntr) continue;
+      const TV tv = tracer_view(m, trb + t);
+      DV2(tv.tr_xy_ab, 1, nz, e) = g1 * a[i][t][0] + g2 * a[i][t][1] + g3 * a[i][t][2];
+      DV2(tv.tr_xy_ab, 2, nz, e) = g4 * a[i][t][0] + g5 * a[i][t][1] + g6 * a[i][t][2];
+      DV2(tv.tr_xy, 1, nz, e) = g1 * c[i][t][0] + g2 * c[i][t][1] + g3 * c[i][t][2];
+      DV2(tv.tr_xy, 2, nz, e) = g4 * c[i][t][0] + g5 * c[i][t][1] + g6 * c[i][t][2];
+    }
+  }
+}
+static void launch_tr_grad_elem(const DM &m, hipStream_t s, int tr) {
+  static const int env = getenv("FESOM_GPU_EXP_GRAD") ? atoi(getenv("FESOM_GPU_EXP_GRAD")) : -1;
+  const int epw = env >= 0 ? env : (m.use_tile ? 2 : 0);
+  const int ne = SUBN(m, m.myE);
+  if (epw == 0 || tr >= 0) { hipLaunchKernelGGL(k_tr_grad_elem, dim3(nblocks(ne), tr < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m, tr < 0 ? 0 : tr); return; }
+  const int gy = (m.ntr + 1) / 2;
+  switch (epw) {
+    case 1: hipLaunchKernelGGL((k_tr_grad_elem_b<1, 2>), dim3(nblocks(ne), gy), dim3(BLOCK), 0, s, m, 0); break;
+    case 2: hipLaunchKernelGGL((k_tr_grad_elem_b<2, 2>), dim3(nblocks((ne + 1) / 2), gy), dim3(BLOCK), 0, s, m, 0); break;
+    case 3: hipLaunchKernelGGL((k_tr_grad_elem_b<3, 2>), dim3(nblocks((ne + 2) / 3), gy), dim3(BLOCK), 0, s, m, 0); break;
+    default: hipLaunchKernelGGL((k_tr_grad_elem_b<4, 2>), dim3(nblocks((ne + 3) / 4), gy), dim3(BLOCK), 0, s, m, 0); break;
+  }
+}
 
 // fill_up_dn_grad (src/oce_muscl_adv.F90:285-447)
 __device__ __forceinline__ void cluster_grad(const DM &m, const TV &t, int node, int nz, double &gx, double &gy) {
@@ -76,26 +134,41 @@ __device__ __forceinline__ void cluster_grad(const DM &m, const TV &t, int node,
   gx = tx / tvol; gy = ty / tvol;
 }
 // the four up/down-wind gradient values of edge `ed` at level nz (w1: values (1,3) are defined here, w2: (2,4))
-__device__ __forceinline__ void updn_grad(const DM &m, const TV &t, int ed, int nz, double &g1, double &g2, double &g3, double &g4, bool &w1, bool &w2) {
-  int n1 = m.edges[2 * ed], n2 = m.edges[2 * ed + 1];
-  int t1 = m.updn[2 * ed], t2 = m.updn[2 * ed + 1];
-  int ul1 = m.ulev_n[n1], ul2 = m.ulev_n[n2], nl1 = m.nlev_n[n1] - 1, nl2 = m.nlev_n[n2] - 1;
-  w1 = false; w2 = false;      // write (1,3) / (2,4)
-  g1 = g2 = g3 = g4 = 0.0;
-  if (t1 >= 0 && t2 >= 0) {
-    int nzmin = max(m.ulev_n_max[n1], m.ulev_n_max[n2]), nzmax = min(m.nlev_n_min[n1], m.nlev_n_min[n2]);
-    if (nz >= nzmin && nz <= nzmax - 1) {
-      g1 = DV2(t.tr_xy_ab, 1, nz, t1); g2 = DV2(t.tr_xy_ab, 1, nz, t2);
-      g3 = DV2(t.tr_xy_ab, 2, nz, t1); g4 = DV2(t.tr_xy_ab, 2, nz, t2);
-      w1 = w2 = true;
-    } else {
-      if ((nz >= ul1 && nz <= nzmin - 1) || (nz >= nzmax && nz <= nl1)) { cluster_grad(m, t, n1, nz, g1, g3); w1 = true; }
-      if ((nz >= ul2 && nz <= nzmin - 1) || (nz >= nzmax && nz <= nl2)) { cluster_grad(m, t, n2, nz, g2, g4); w2 = true; }
+struct UpdnIdx { int n1, n2, t1, t2; bool both, c1, c2; };      // what does not depend on the tracer: the two upwind triangles, per level: both values from them / cluster mean at node 1 / 2
+__device__ __forceinline__ UpdnIdx updn_index(const DM &m, int ed, int nz) {
+  UpdnIdx x;
+  x.n1 = m.edges[2 * ed]; x.n2 = m.edges[2 * ed + 1];
+  x.t1 = m.updn[2 * ed]; x.t2 = m.updn[2 * ed + 1];
+  int ul1 = m.ulev_n[x.n1], ul2 = m.ulev_n[x.n2], nl1 = m.nlev_n[x.n1] - 1, nl2 = m.nlev_n[x.n2] - 1;
+  x.both = x.c1 = x.c2 = false;
+  if (x.t1 >= 0 && x.t2 >= 0) {
+    int nzmin = max(m.ulev_n_max[x.n1], m.ulev_n_max[x.n2]), nzmax = min(m.nlev_n_min[x.n1], m.nlev_n_min[x.n2]);
+    if (nz >= nzmin && nz <= nzmax - 1) x.both = true;
+    else {
+      x.c1 = (nz >= ul1 && nz <= nzmin - 1) || (nz >= nzmax && nz <= nl1);
+      x.c2 = (nz >= ul2 && nz <= nzmin - 1) || (nz >= nzmax && nz <= nl2);
     }
   } else {
-    if (nz >= ul1 && nz <= nl1) { cluster_grad(m, t, n1, nz, g1, g3); w1 = true; }
-    if (nz >= ul2 && nz <= nl2) { cluster_grad(m, t, n2, nz, g2, g4); w2 = true; }
+    x.c1 = nz >= ul1 && nz <= nl1;
+    x.c2 = nz >= ul2 && nz <= nl2;
   }
+  return x;
+}
+__device__ __forceinline__ void updn_values(const DM &m, const TV &t, const UpdnIdx &x, int nz, double &g1, double &g2, double &g3, double &g4, bool &w1, bool &w2) {
+  w1 = false; w2 = false;      // write (1,3) / (2,4)
+  g1 = g2 = g3 = g4 = 0.0;
+  if (x.both) {
+    g1 = DV2(t.tr_xy_ab, 1, nz, x.t1); g2 = DV2(t.tr_xy_ab, 1, nz, x.t2);
+    g3 = DV2(t.tr_xy_ab, 2, nz, x.t1); g4 = DV2(t.tr_xy_ab, 2, nz, x.t2);
+    w1 = w2 = true;
+  } else {
+    if (x.c1) { cluster_grad(m, t, x.n1, nz, g1, g3); w1 = true; }
+    if (x.c2) { cluster_grad(m, t, x.n2, nz, g2, g4); w2 = true; }
+  }
+}
+__device__ __forceinline__ void updn_grad(const DM &m, const TV &t, int ed, int nz, double &g1, double &g2, double &g3, double &g4, bool &w1, bool &w2) {
+  const UpdnIdx x = updn_index(m, ed, nz);
+  updn_values(m, t, x, nz, g1, g2, g3, g4, w1, w2);
 }
 __global__ void __launch_bounds__(BLOCK) k_updn_grad(DM m, int tr0) {
   const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
@@ -179,11 +252,101 @@ __global__ void __launch_bounds__(BLOCK) k_flux_hor(DM m, int tr0) {
   double cHO = (vflux + av) * Tmean1 + (vflux - av) * Tmean2;
   DA2(t.adv_flux_raw, nz, ed) = -0.5 * (1.0 - num_ord) * cHO - vflux * num_ord * (0.5 * (Tmean1 + Tmean2)) - lo;
 }
+// CORE2-class meshes: NT tracers of an edge column in one wave.  Everything that does not depend on the tracer (edge -> triangles / nodes, level ranges,
+// the volume flux from UV and helem, the up/down-wind index decisions) is formed once, the loads of all tracers are issued together: these kernels
+// are bound by the number of loads a wave has in flight, not by bandwidth.  Same expressions per cell as k_flux_hor<FUSED>.
+template <bool FUSED, int NT>
+__global__ void __launch_bounds__(BLOCK) k_flux_hor_nt(DM m, int tr0) {
+  const int trb = tr0 + blockIdx.y * NT;
+  int ed = col_id(m), nz = lane_id() + 1;
+  if (ed >= m.myD) return;
+  if (nz > m.nlm1) return;
+  int n1 = m.edges[2 * ed], n2 = m.edges[2 * ed + 1], e1 = m.edge_tri[2 * ed], e2 = m.edge_tri[2 * ed + 1];
+  int nl1 = m.nlev[e1] - 1, nu1 = m.ulev[e1], nl2 = 0, nu2 = 0;
+  double dX1 = DECD(1, ed), dY1 = DECD(2, ed), dX2 = 0, dY2 = 0;
+  double a = D_REARTH * m.elem_cos[e1];
+  if (e2 >= 0) {
+    dX2 = DECD(3, ed); dY2 = DECD(4, ed);
+    nl2 = m.nlev[e2] - 1; nu2 = m.ulev[e2];
+    a = 0.5 * (a + D_REARTH * m.elem_cos[e2]);
+  }
+  int nl12 = min(nl1, nl2), nu12 = max(nu1, nu2);
+  bool use1 = false, use2 = false;
+  if (nz >= nu12 && nz <= nl12) { use1 = true; use2 = true; }
+  else if ((nz >= nu1 && nz <= nu12 - 1) || (nz >= nl12 + 1 && nz <= nl1)) { use1 = true; use2 = false; }
+  else if (nu2 > 0 && ((nz >= nu2 && nz <= nu12 - 1) || (nz >= nl12 + 1 && nz <= nl2))) { use1 = false; use2 = true; }
+  const bool dead = !use1 && !use2;
+  const int hor = m.p.tra_adv_hor;                          // 0 MFCT, 1 MUSCL, 2 UPW1 as the high-order scheme
+  UpdnIdx ux;
+  if (FUSED && !dead && hor != 2) ux = updn_index(m, ed, nz);
+  // loads of all tracers
+  double t1[NT], t2[NT], s1[NT], s2[NT], g1[NT], g2[NT], g3[NT], g4[NT];
+#pragma unroll
+  for (int q = 0; q < NT; q++) {
+    const int tr = trb + q < m.ntr ? trb + q : m.ntr - 1;
+    const TV t = tracer_view(m, tr);
+    t1[q] = t2[q] = s1[q] = s2[q] = g1[q] = g2[q] = g3[q] = g4[q] = 0.0;
+    if (dead) continue;
+    t1[q] = DTR(m.tr_arr, nz, n1, tr); t2[q] = DTR(m.tr_arr, nz, n2, tr);
+    s1[q] = DTR(m.tr_arr_old, nz, n1, tr); s2[q] = DTR(m.tr_arr_old, nz, n2, tr);
+    if (hor == 2) continue;
+    if (FUSED) {
+      bool w1, w2;
+      updn_values(m, t, ux, nz, g1[q], g2[q], g3[q], g4[q], w1, w2);
+      if (!w1) { g1[q] = DV4(t.edge_up_dn_grad, 1, nz, ed); g3[q] = DV4(t.edge_up_dn_grad, 3, nz, ed); }
+      if (!w2) { g2[q] = DV4(t.edge_up_dn_grad, 2, nz, ed); g4[q] = DV4(t.edge_up_dn_grad, 4, nz, ed); }
+    } else {
+      g1[q] = DV4(t.edge_up_dn_grad, 1, nz, ed); g2[q] = DV4(t.edge_up_dn_grad, 2, nz, ed);
+      g3[q] = DV4(t.edge_up_dn_grad, 3, nz, ed); g4[q] = DV4(t.edge_up_dn_grad, 4, nz, ed);
+    }
+  }
+  double vflux = 0.0;
+  if (use1 && use2)
+    vflux = (-DV2(m.UV, 2, nz, e1) * dX1 + DV2(m.UV, 1, nz, e1) * dY1) * DA2(m.helem, nz, e1) +
+            (DV2(m.UV, 2, nz, e2) * dX2 - DV2(m.UV, 1, nz, e2) * dY2) * DA2(m.helem, nz, e2);
+  else if (use1) vflux = (-DV2(m.UV, 2, nz, e1) * dX1 + DV2(m.UV, 1, nz, e1) * dY1) * DA2(m.helem, nz, e1);
+  else if (use2) vflux = (DV2(m.UV, 2, nz, e2) * dX2 - DV2(m.UV, 1, nz, e2) * dY2) * DA2(m.helem, nz, e2);
+  const double av = fabs(vflux);
+  const double num_ord = m.p.tra_adv_ph;
+  const double ex = m.edxy[2 * ed], ey = m.edxy[2 * ed + 1];
+#pragma unroll
+  for (int q = 0; q < NT; q++) {
+    if (trb + q >= m.ntr) continue;
+    const TV t = tracer_view(m, trb + q);
+    if (dead) { DA2(t.flux_lo_hor, nz, ed) = 0.0; DA2(t.adv_flux_raw, nz, ed) = 0.0; continue; }
+    // tra_adv_lim = 'NON' (oce_adv_tra_driver.F90:137-153): no low-order flux, the high-order flux is formed with init_zero=.true. (flux - 0.0)
+    double lo = m.p.tra_adv_lim ? 0.0 : -0.5 * (t1[q] * (vflux + av) + t2[q] * (vflux - av)) - 0.0;
+    DA2(t.flux_lo_hor, nz, ed) = lo;
+    if (hor == 2) {
+      DA2(t.adv_flux_raw, nz, ed) = -0.5 * (s1[q] * (vflux + av) + s2[q] * (vflux - av)) - lo;
+      continue;
+    }
+    double Tmean2, Tmean1;
+    if (hor == 1) {   // MUSCL: the gradient correction is switched off below nboundary_lay of the node (c_lo = 0 or 1)
+      const double c1 = (m.nb_lay[n1] - nz >= 0) ? 1.0 : 0.0, c2 = (m.nb_lay[n2] - nz >= 0) ? 1.0 : 0.0;
+      Tmean2 = s2[q] - (2.0 * (s2[q] - s1[q]) + ex * a * g2[q] + ey * D_REARTH * g4[q]) / 6.0 * c2;
+      Tmean1 = s1[q] + (2.0 * (s2[q] - s1[q]) + ex * a * g1[q] + ey * D_REARTH * g3[q]) / 6.0 * c1;
+    } else {
+      Tmean2 = s2[q] - (2.0 * (s2[q] - s1[q]) + ex * a * g2[q] + ey * D_REARTH * g4[q]) / 6.0;
+      Tmean1 = s1[q] + (2.0 * (s2[q] - s1[q]) + ex * a * g1[q] + ey * D_REARTH * g3[q]) / 6.0;
+    }
+    double cHO = (vflux + av) * Tmean1 + (vflux - av) * Tmean2;
+    DA2(t.adv_flux_raw, nz, ed) = -0.5 * (1.0 - num_ord) * cHO - vflux * num_ord * (0.5 * (Tmean1 + Tmean2)) - lo;
+  }
+}
+// all tracers of a launch (tr < 0) on CORE2-class meshes: two per wave; a single tracer or pi: one tracer per wave, grid.y = tracers
+template <bool FUSED>
+static void launch_flux_hor(const DM &m, hipStream_t s, int tr) {
+  static const int env = getenv("FESOM_GPU_EXP_NT") ? atoi(getenv("FESOM_GPU_EXP_NT")) : -1;
+  const bool nt2 = tr < 0 && m.ntr > 1 && (env >= 0 ? (env & 1) != 0 : m.use_tile != 0);
+  const int nb = nblocks(SUBN(m, m.myD));
+  if (nt2) hipLaunchKernelGGL((k_flux_hor_nt<FUSED, 2>), dim3(nb, (m.ntr + 1) / 2), dim3(BLOCK), 0, s, m, 0);
+  else hipLaunchKernelGGL((k_flux_hor<FUSED>), dim3(nb, tr < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m, tr < 0 ? 0 : tr);
+}
 
 // low-order solution (src/oce_adv_tra_driver.F90:97-133) with adv_tra_ver_upw1 (src/oce_adv_tra_ver.F90:231-282)
 // and adv_tra_ver_qr4c (:286-357) evaluated in registers; also the nodal bounds of oce_tra_adv_fct (:94-101).
-__global__ void __launch_bounds__(BLOCK) k_fct_lo_node(DM m, int tr0) {
-  const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
+__device__ __forceinline__ void k_fct_lo_node_col(const DM &m, const int tr) {
   const TV t = tracer_view(m, tr);
   int n = col_id(m), l = lane_id(), nz = l + 1;
   if (n >= m.myN) return;
@@ -315,6 +478,13 @@ __global__ void __launch_bounds__(BLOCK) k_fct_lo_node(DM m, int tr0) {
     DA2(t.fct_LO, nz, n) = lo;            // the nodal bounds max/min(LO, ttf) (oce_adv_tra_fct.F90:94-101) are formed by their consumer
   }
 }
+__global__ void __launch_bounds__(BLOCK) k_fct_lo_node(DM m, int tr0) { k_fct_lo_node_col(m, tr0 + blockIdx.y); }      // grid.y = tracers of this launch
+template <int NT>
+__global__ void __launch_bounds__(BLOCK) k_fct_lo_node_nt(DM m, int tr0) {      // CORE2-class meshes: NT tracers of a column in one wave (shared index chain, half the waves)
+#pragma unroll
+  for (int q = 0; q < NT; q++)
+    if (tr0 + (int)blockIdx.y * NT + q < m.ntr) k_fct_lo_node_col(m, tr0 + (int)blockIdx.y * NT + q);
+}
 
 // adv_tra_vert_impl (src/oce_adv_tra_ver.F90:83-227), w_split only: implicit vertical advection by Wvel_i applied to the low-order
 // solution (oce_adv_tra_driver.F90:124-126); tridiagonal problem per node column through the in-block Thomas sweep.
@@ -369,8 +539,7 @@ __global__ void __launch_bounds__(TH_BLOCK) k_fct_lo_wimpl(DM m, int tr0) {
 // max over the node itself and the far-end nodes of its incident edges that are wet at this level (an edge is wet
 // where one of its triangles is): no element array, one launch less on the critical chain, the edge list is shared
 // with the flux sums, and fct_ttf_max/min can take their final value (bound - LO) without a race.
-__global__ void __launch_bounds__(BLOCK) k_fct_node(DM m, int tr0) {
-  const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
+__device__ __forceinline__ void k_fct_node_col(const DM &m, const int tr) {
   const TV t = tracer_view(m, tr);
   int n = col_id(m), l = lane_id(), nz = l + 1;
   if (n >= m.myN) return;
@@ -463,11 +632,17 @@ __global__ void __launch_bounds__(BLOCK) k_fct_node(DM m, int tr0) {
     DA2L(t.adv_flux_ver, nz, n) = ae * adv;
   }
 }
+__global__ void __launch_bounds__(BLOCK) k_fct_node(DM m, int tr0) { k_fct_node_col(m, tr0 + blockIdx.y); }      // grid.y = tracers of this launch
+template <int NT>
+__global__ void __launch_bounds__(BLOCK) k_fct_node_nt(DM m, int tr0) {      // CORE2-class meshes: NT tracers of a column in one wave (shared index chain, half the waves)
+#pragma unroll
+  for (int q = 0; q < NT; q++)
+    if (tr0 + (int)blockIdx.y * NT + q < m.ntr) k_fct_node_col(m, tr0 + (int)blockIdx.y * NT + q);
+}
 
 // limiting of the horizontal antidiffusive flux (src/oce_adv_tra_fct.F90:318-347): adv_flux_hor = ae * adv_flux_raw.
 // Off the critical chain: k_tr_update applies the same factors on the fly; this kernel only materialises the field.
-__global__ void __launch_bounds__(BLOCK) k_fct_edge_limit(DM m, int tr0) {
-  const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
+__device__ __forceinline__ void k_fct_edge_limit_col(const DM &m, const int tr) {
   const TV t = tracer_view(m, tr);
   int ed = col_id(m), nz = lane_id() + 1;
   if (ed >= m.myD) return;
@@ -481,14 +656,20 @@ __global__ void __launch_bounds__(BLOCK) k_fct_edge_limit(DM m, int tr0) {
   else { ae = dmin_(ae, DA2(t.fct_minus, nz, n1)); ae = dmin_(ae, DA2(t.fct_plus, nz, n2)); }
   DA2(t.adv_flux_hor, nz, ed) = ae * flux;
 }
+__global__ void __launch_bounds__(BLOCK) k_fct_edge_limit(DM m, int tr0) { k_fct_edge_limit_col(m, tr0 + blockIdx.y); }      // grid.y = tracers of this launch
+template <int NT>
+__global__ void __launch_bounds__(BLOCK) k_fct_edge_limit_nt(DM m, int tr0) {      // CORE2-class meshes: NT tracers of a column in one wave (shared index chain, half the waves)
+#pragma unroll
+  for (int q = 0; q < NT; q++)
+    if (tr0 + (int)blockIdx.y * NT + q < m.ntr) k_fct_edge_limit_col(m, tr0 + (int)blockIdx.y * NT + q);
+}
 
 // Horizontal diffusive flux through every edge (diff_part_hor_redi src/oce_ale_tracer.F90:929-1077, Redi off): the value
 // the reference adds to / subtracts from the two end nodes.  It only needs T^n gradients, Ki and helem of the current
 // step, so it is computed edge-parallel during tracer preparation (hidden under the SSH solve) and k_tr_update just
 // gathers it in reference order.
 template <bool REDI>
-__global__ void __launch_bounds__(BLOCK) k_diff_flux(DM m, int tr0) {
-  const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
+__device__ __forceinline__ void k_diff_flux_col(const DM &m, const int tr) {
   const TV t = tracer_view(m, tr);
   int ed = col_id(m), nz = lane_id() + 1;
   if (ed >= m.myD || nz > m.nlm1) return;
@@ -524,6 +705,14 @@ __global__ void __launch_bounds__(BLOCK) k_diff_flux(DM m, int tr0) {
     c = (dX2 * Fy - dY2 * Fx) * dz;
   }
   DA2(t.diff_flux, nz, ed) = c;
+}
+template <bool REDI>
+__global__ void __launch_bounds__(BLOCK) k_diff_flux(DM m, int tr0) { k_diff_flux_col<REDI>(m, tr0 + blockIdx.y); }      // grid.y = tracers of this launch
+template <bool REDI, int NT>
+__global__ void __launch_bounds__(BLOCK) k_diff_flux_nt(DM m, int tr0) {      // CORE2-class meshes: NT tracers of a column in one wave (shared index chain, half the waves)
+#pragma unroll
+  for (int q = 0; q < NT; q++)
+    if (tr0 + (int)blockIdx.y * NT + q < m.ntr) k_diff_flux_col<REDI>(m, tr0 + (int)blockIdx.y * NT + q);
 }
 
 // oce_tra_adv_flux2dtracer (src/oce_adv_tra_driver.F90:201-269) + adv_tracers_ale tail (src/oce_ale_tracer.F90:241)
@@ -964,7 +1153,16 @@ template <bool R_, int NT_> static void launch_tru_tile(const DM &m, hipStream_t
   else if (m.tru_nt2 && (tr_) < 0) { if (m.p.Redi) LAUNCH_TRU2(true, m_); else LAUNCH_TRU2(false, m_); }   /* both tracers of a column in one wave */ \
   else if (m.p.Redi) LAUNCH_TRU1(true, m_, tr_); else LAUNCH_TRU1(false, m_, tr_); } while (0)
 #define LAUNCH_WIMPL(m_, tr_) do { if (m.p.w_split) hipLaunchKernelGGL(k_fct_lo_wimpl, dim3(nblocks_th(m.myN), (tr_) < 0 ? m.ntr : 1), dim3(TH_BLOCK), thomas_lds_bytes(m.nlm1, 1), s, m_, (tr_) < 0 ? 0 : (tr_)); } while (0)
-#define LAUNCH_DFX(m_, tr_) do { if (m.p.Redi) LAUNCH_COL(k_diff_flux<true>, m.myD, m_, tr_); else LAUNCH_COL(k_diff_flux<false>, m.myD, m_, tr_); } while (0)
+// all tracers of a launch (tr_ < 0) on CORE2-class meshes: two tracers per wave (k##_nt<2>); FESOM_GPU_EXP_NT = bit mask of the kernels that do (experiments)
+static inline bool nt2_on(const DM &m, int tr, int bit) {
+  static const int env = getenv("FESOM_GPU_EXP_NT") ? atoi(getenv("FESOM_GPU_EXP_NT")) : -1;
+  return tr < 0 && m.ntr > 1 && (env >= 0 ? ((env >> bit) & 1) != 0 : m.use_tile != 0);
+}
+#define LAUNCH_COL_NT(bit, k, ncol, m_, tr_) do { if (nt2_on(m, tr_, bit)) hipLaunchKernelGGL((k##_nt<2>), dim3(nblocks(SUBN(m_, ncol)), (m.ntr + 1) / 2), dim3(BLOCK), 0, s, m_, 0); \
+                                                   else LAUNCH_COL(k, ncol, m_, tr_); } while (0)
+#define LAUNCH_DFX(m_, tr_) do { if (nt2_on(m, tr_, 4)) { if (m.p.Redi) hipLaunchKernelGGL((k_diff_flux_nt<true, 2>), dim3(nblocks(SUBN(m_, m.myD)), (m.ntr + 1) / 2), dim3(BLOCK), 0, s, m_, 0); \
+                                                           else hipLaunchKernelGGL((k_diff_flux_nt<false, 2>), dim3(nblocks(SUBN(m_, m.myD)), (m.ntr + 1) / 2), dim3(BLOCK), 0, s, m_, 0); } \
+                                  else if (m.p.Redi) LAUNCH_COL(k_diff_flux<true>, m.myD, m_, tr_); else LAUNCH_COL(k_diff_flux<false>, m.myD, m_, tr_); } while (0)
 
 #define TRU_ATTR(id, C_, W_) (void)hipFuncSetAttribute((const void *)k_tr_update<false, 2, C_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, big); \
   (void)hipFuncSetAttribute((const void *)k_tr_update<true, 2, C_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, big); \
@@ -977,13 +1175,13 @@ void tile_prepare_tra() {      // tiles of meshes with many levels / 64 columns 
 void launch_tracer(const DM &m, hipStream_t s, int tr) {   // tr 0-based
   LAUNCH_COL(k_tr_ab, m.N, m, tr);
   LAUNCH_COL(k_tr_z, m.N, m, tr);
-  LAUNCH_COL(k_tr_grad_elem, m.myE, m, tr);
+  launch_tr_grad_elem(m, s, tr);
   const bool fuse_updn = m.use_tile && tr < 0;             // as the step DAG does (api.hip)
   if (!fuse_updn) LAUNCH_COL(k_updn_grad, m.myD, m, tr);
-  if (fuse_updn) LAUNCH_COL(k_flux_hor<true>, m.myD, m, tr); else LAUNCH_COL(k_flux_hor<false>, m.myD, m, tr);
-  LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); LAUNCH_WIMPL(m, tr);
-  if (!m.p.tra_adv_lim) LAUNCH_COL(k_fct_node, m.myN, m, tr);
-  LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr);
+  if (fuse_updn) launch_flux_hor<true>(m, s, tr); else launch_flux_hor<false>(m, s, tr);
+  LAUNCH_COL_NT(1, k_fct_lo_node, m.myN, m, tr); LAUNCH_WIMPL(m, tr);
+  if (!m.p.tra_adv_lim) LAUNCH_COL_NT(2, k_fct_node, m.myN, m, tr);
+  LAUNCH_COL_NT(3, k_fct_edge_limit, m.myD, m, tr);
   if (m.p.with_diffusion) LAUNCH_DFX(m, tr);
   LAUNCH_TRU(m, tr);
   if (m.p.smooth_bh_tra) {
@@ -997,13 +1195,13 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
   if (!strncmp(name, "k_", 2)) {
     if (!strcmp(name, "k_tr_ab")) { LAUNCH_COL(k_tr_ab, m.N, m, tr); return 0; }
     if (!strcmp(name, "k_tr_z")) { LAUNCH_COL(k_tr_z, m.N, m, tr); return 0; }
-    if (!strcmp(name, "k_tr_grad_elem")) { LAUNCH_COL(k_tr_grad_elem, m.myE, m, tr); return 0; }
+    if (!strcmp(name, "k_tr_grad_elem")) { launch_tr_grad_elem(m, s, tr); return 0; }
     if (!strcmp(name, "k_updn_grad")) { LAUNCH_COL(k_updn_grad, m.myD, m, tr); return 0; }
-    if (!strcmp(name, "k_flux_hor")) { LAUNCH_COL(k_flux_hor<false>, m.myD, m, tr); return 0; }
-    if (!strcmp(name, "k_flux_hor_fused")) { LAUNCH_COL(k_flux_hor<true>, m.myD, m, tr); return 0; }     // fill_up_dn_grad on the fly
-    if (!strcmp(name, "k_fct_lo_node")) { LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); LAUNCH_WIMPL(m, tr); return 0; }   // (+ implicit part with w_split)
-    if (!strcmp(name, "k_fct_node")) { if (!m.p.tra_adv_lim) LAUNCH_COL(k_fct_node, m.myN, m, tr); return 0; }      // (no limiter with tra_adv_lim='NON')
-    if (!strcmp(name, "k_fct_edge_limit")) { LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr); return 0; }
+    if (!strcmp(name, "k_flux_hor")) { launch_flux_hor<false>(m, s, tr); return 0; }
+    if (!strcmp(name, "k_flux_hor_fused")) { launch_flux_hor<true>(m, s, tr); return 0; }     // fill_up_dn_grad on the fly
+    if (!strcmp(name, "k_fct_lo_node")) { LAUNCH_COL_NT(1, k_fct_lo_node, m.myN, m, tr); LAUNCH_WIMPL(m, tr); return 0; }   // (+ implicit part with w_split)
+    if (!strcmp(name, "k_fct_node")) { if (!m.p.tra_adv_lim) LAUNCH_COL_NT(2, k_fct_node, m.myN, m, tr); return 0; }      // (no limiter with tra_adv_lim='NON')
+    if (!strcmp(name, "k_fct_edge_limit")) { LAUNCH_COL_NT(3, k_fct_edge_limit, m.myD, m, tr); return 0; }
     if (!strcmp(name, "k_diff_flux")) { LAUNCH_DFX(m, tr); return 0; }
     if (!strcmp(name, "k_tr_update")) { LAUNCH_TRU(m, tr); return 0; }
     if (!strcmp(name, "k_spp")) { if (m.p.SPP) hipLaunchKernelGGL(k_spp, dim3((m.N + 127) / 128), dim3(128), 0, s, m); return 0; }
@@ -1012,13 +1210,13 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
     return -1;
   }
   if (!strcmp(name, "init_tracers_AB")) {
-    LAUNCH_COL(k_tr_ab, m.N, m, tr); LAUNCH_COL(k_tr_z, m.N, m, tr); LAUNCH_COL(k_tr_grad_elem, m.myE, m, tr);
+    LAUNCH_COL(k_tr_ab, m.N, m, tr); LAUNCH_COL(k_tr_z, m.N, m, tr); launch_tr_grad_elem(m, s, tr);
     LAUNCH_COL(k_updn_grad, m.myD, m, tr); return 0;
   }
   if (!strcmp(name, "adv_tracers_ale")) {
-    LAUNCH_COL(k_flux_hor<false>, m.myD, m, tr); LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); LAUNCH_WIMPL(m, tr);
-    if (!m.p.tra_adv_lim) LAUNCH_COL(k_fct_node, m.myN, m, tr);
-    LAUNCH_COL(k_fct_edge_limit, m.myD, m, tr);
+    launch_flux_hor<false>(m, s, tr); LAUNCH_COL_NT(1, k_fct_lo_node, m.myN, m, tr); LAUNCH_WIMPL(m, tr);
+    if (!m.p.tra_adv_lim) LAUNCH_COL_NT(2, k_fct_node, m.myN, m, tr);
+    LAUNCH_COL_NT(3, k_fct_edge_limit, m.myD, m, tr);
     return 0;
   }
   if (!strcmp(name, "diff_tracers_ale")) {                                                    // incl. flux2dtracer + clamp
