@@ -837,7 +837,8 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
       HIPCHK(hipMemcpy(m.Kv, kv.data(), sizeof(double) * kv.size(), hipMemcpyHostToDevice));
     }
   }
-  m.sv_minv = nullptr; m.sv_mp = nullptr; m.sv_mc = nullptr; m.sv_xi_its = par->solver_xinv_its;
+  m.sv_minv = nullptr; m.sv_mp = nullptr; m.sv_mc = nullptr; m.sv_xi_its = par->solver_xinv_its; m.sv_solves = 0;
+  if (G.use_graph && m.sv_xi_its == 0) m.sv_xi_its = 1;          // (a captured step replays a fixed launch sequence)
   if (par->solver_precond == 1 && G.npes <= 1 && m.myN <= 4096 && m.ssh_maxnnz <= 10 && m.myN >= 64) {
     // explicit inverse of the row-scaled operator this run starts with (frozen, like the reference's ILU factors)
     std::vector<int> rp(m.myN + 1), ci(m.nza);
@@ -1442,7 +1443,10 @@ static int call_named(const char *name, int arg) {
   }
   if (!strcmp(name, "k_solver_replay")) {
     if (hipMemcpyAsync(m.d_eta, m.sv_snap, sizeof(double) * m.N, hipMemcpyDeviceToDevice, G.stream) != hipSuccess) return 1;
-    return launch_solver(m, G.stream);
+    const int solves = m.sv_solves;                // a replay for timing is not a solve of the run (the default iteration schedule counts them)
+    const int rc = launch_solver(m, G.stream);
+    G.m.sv_solves = solves;
+    return rc;
   }
   int fs = G.first_step;
   if (!strcmp(name, "init_tracers_AB") || !strcmp(name, "adv_tracers_ale") || !strcmp(name, "diff_tracers_ale") || !strncmp(name, "k_t", 3) ||

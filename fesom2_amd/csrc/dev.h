@@ -100,6 +100,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   // row-scaled operator with the entries below 1e-4 of their row's largest dropped, CSR (sv_mp row pointer, sv_mc columns, sv_minv
   // values); natural-order work vectors of the preconditioned BiCGstab; iterations per solve
   const float *sv_minv; const int *sv_mp; const unsigned short *sv_mc; int sv_xi_its;
+  int sv_solves;       // host-side: SSH solves launched since init (the default iteration schedule of the explicit-inverse solve depends on it, solver.hip)
   double sv_tol; int sv_maxits;   // stop rule: ||scaled residual|| < sv_tol (0: the reference's 1e-10, bicgstab_ras.c:78), iteration cap (0: 2000)
   double *sv_bn, *sv_x, *sv_pd, *sv_sn, *sv_sh;
   // RAS-Chebyshev preconditioner of operators beyond the explicit inverse (csrc/ras_host.h, solver_ras.hip): patches of the row graph,

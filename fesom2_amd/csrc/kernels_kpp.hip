@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(BLOCK) k_kpp_final_elem(DM m, int ncolE) {
 #define LAUNCH_COL(k, ncol, ...) hipLaunchKernelGGL(k, dim3(nblocks(ncol)), dim3(BLOCK), 0, s, __VA_ARGS__)
 static void smooth(const DM &m, hipStream_t s, const double *src, double *dst) {
   static const int env = getenv("FESOM_GPU_EXP_KPPU") ? atoi(getenv("FESOM_GPU_EXP_KPPU")) : -1;
-  const bool staged = (env >= 0 ? env != 0 : m.use_tile != 0) && m.kpp_maxu <= 12;
+  const bool staged = (env >= 0 ? env != 0 : true) && m.kpp_maxu <= 12;      // (430 -> 228 us per sweep on the basin, 10.7 -> 10.0 us on pi)
   if (staged && m.kpp_maxu <= 8) hipLaunchKernelGGL((k_kpp_smooth_u<8>), dim3(nblocks(m.myN)), dim3(BLOCK), 0, s, m, src, dst);
   else if (staged) hipLaunchKernelGGL((k_kpp_smooth_u<12>), dim3(nblocks(m.myN)), dim3(BLOCK), 0, s, m, src, dst);
   else hipLaunchKernelGGL(k_kpp_smooth, dim3(nblocks(m.myN)), dim3(BLOCK), 0, s, m, src, dst);      // the three blmc fields in one wave per node

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(BLOCK) k_tr_grad_elem(DM m, int tr0) {
   DV2(t.tr_xy, 1, nz, e) = DGS(1, e) * c1 + DGS(2, e) * c2 + DGS(3, e) * c3;
   DV2(t.tr_xy, 2, nz, e) = DGS(4, e) * c1 + DGS(5, e) * c2 + DGS(6, e) * c3;
 }
-// The same for CORE2-class meshes: EPW elements and NT tracers per wave.  The index chain (element -> its 3 nodes, level range) is fetched lane-parallel
+// The same with EPW elements and NT tracers per wave.  The index chain (element -> its 3 nodes, level range) is fetched lane-parallel
 // ONCE for the wave's elements, then all 6 * NT * EPW column loads are issued before the first use: the kernel is bound by the number of loads in
 // flight, not by bandwidth (a column is only 376 B).  Same expressions per cell as k_tr_grad_elem.
 template <int EPW, int NT>
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(BLOCK) k_tr_grad_elem_b(DM m, int tr0) {
 }
 static void launch_tr_grad_elem(const DM &m, hipStream_t s, int tr) {
   static const int env = getenv("FESOM_GPU_EXP_GRAD") ? atoi(getenv("FESOM_GPU_EXP_GRAD")) : -1;
-  const int epw = env >= 0 ? env : (m.use_tile ? 2 : 0);
+  const int epw = env >= 0 ? env : 1;       // one element, both tracers per wave: 590 -> 374 us on the channel, 8.7 -> 6.4 us on pi; more elements per wave do not gain
   const int ne = SUBN(m, m.myE);
   if (epw == 0 || tr >= 0) { hipLaunchKernelGGL(k_tr_grad_elem, dim3(nblocks(ne), tr < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m, tr < 0 ? 0 : tr); return; }
   const int gy = (m.ntr + 1) / 2;
@@ -334,11 +334,11 @@ __global__ void __launch_bounds__(BLOCK) k_flux_hor_nt(DM m, int tr0) {
     DA2(t.adv_flux_raw, nz, ed) = -0.5 * (1.0 - num_ord) * cHO - vflux * num_ord * (0.5 * (Tmean1 + Tmean2)) - lo;
   }
 }
-// all tracers of a launch (tr < 0) on CORE2-class meshes: two per wave; a single tracer or pi: one tracer per wave, grid.y = tracers
+// all tracers of a launch (tr < 0): two per wave; a single tracer: one tracer per wave
 template <bool FUSED>
 static void launch_flux_hor(const DM &m, hipStream_t s, int tr) {
   static const int env = getenv("FESOM_GPU_EXP_NT") ? atoi(getenv("FESOM_GPU_EXP_NT")) : -1;
-  const bool nt2 = tr < 0 && m.ntr > 1 && (env >= 0 ? (env & 1) != 0 : m.use_tile != 0);
+  const bool nt2 = tr < 0 && m.ntr > 1 && (env >= 0 ? (env & 1) != 0 : true);
   const int nb = nblocks(SUBN(m, m.myD));
   if (nt2) hipLaunchKernelGGL((k_flux_hor_nt<FUSED, 2>), dim3(nb, (m.ntr + 1) / 2), dim3(BLOCK), 0, s, m, 0);
   else hipLaunchKernelGGL((k_flux_hor<FUSED>), dim3(nb, tr < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m, tr < 0 ? 0 : tr);
@@ -1153,10 +1153,13 @@ template <bool R_, int NT_> static void launch_tru_tile(const DM &m, hipStream_t
   else if (m.tru_nt2 && (tr_) < 0) { if (m.p.Redi) LAUNCH_TRU2(true, m_); else LAUNCH_TRU2(false, m_); }   /* both tracers of a column in one wave */ \
   else if (m.p.Redi) LAUNCH_TRU1(true, m_, tr_); else LAUNCH_TRU1(false, m_, tr_); } while (0)
 #define LAUNCH_WIMPL(m_, tr_) do { if (m.p.w_split) hipLaunchKernelGGL(k_fct_lo_wimpl, dim3(nblocks_th(m.myN), (tr_) < 0 ? m.ntr : 1), dim3(TH_BLOCK), thomas_lds_bytes(m.nlm1, 1), s, m_, (tr_) < 0 ? 0 : (tr_)); } while (0)
-// all tracers of a launch (tr_ < 0) on CORE2-class meshes: two tracers per wave (k##_nt<2>); FESOM_GPU_EXP_NT = bit mask of the kernels that do (experiments)
+// all tracers of a launch (tr_ < 0): two tracers per wave (k##_nt<2>) where that pays -- measured on MI355X (profiles/r03_*): k_flux_hor 14.2 -> 11.9 us on pi,
+// 1033 -> 863 us on the channel; k_diff_flux 505 -> 411 us on the channel, unchanged on pi; k_fct_lo_node / k_fct_node do not gain (their waves are bound by
+// VALU issue, not by the index chain) and keep one tracer per wave.  FESOM_GPU_EXP_NT = bit mask that overrides the choice (experiments).
 static inline bool nt2_on(const DM &m, int tr, int bit) {
   static const int env = getenv("FESOM_GPU_EXP_NT") ? atoi(getenv("FESOM_GPU_EXP_NT")) : -1;
-  return tr < 0 && m.ntr > 1 && (env >= 0 ? ((env >> bit) & 1) != 0 : m.use_tile != 0);
+  const bool dflt = bit == 4 ? m.use_tile != 0 : true;      // (bit 4 = k_diff_flux)
+  return tr < 0 && m.ntr > 1 && (env >= 0 ? ((env >> bit) & 1) != 0 : dflt);
 }
 #define LAUNCH_COL_NT(bit, k, ncol, m_, tr_) do { if (nt2_on(m, tr_, bit)) hipLaunchKernelGGL((k##_nt<2>), dim3(nblocks(SUBN(m_, ncol)), (m.ntr + 1) / 2), dim3(BLOCK), 0, s, m_, 0); \
                                                    else LAUNCH_COL(k, ncol, m_, tr_); } while (0)
@@ -1179,8 +1182,8 @@ void launch_tracer(const DM &m, hipStream_t s, int tr) {   // tr 0-based
   const bool fuse_updn = m.use_tile && tr < 0;             // as the step DAG does (api.hip)
   if (!fuse_updn) LAUNCH_COL(k_updn_grad, m.myD, m, tr);
   if (fuse_updn) launch_flux_hor<true>(m, s, tr); else launch_flux_hor<false>(m, s, tr);
-  LAUNCH_COL_NT(1, k_fct_lo_node, m.myN, m, tr); LAUNCH_WIMPL(m, tr);
-  if (!m.p.tra_adv_lim) LAUNCH_COL_NT(2, k_fct_node, m.myN, m, tr);
+  LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); LAUNCH_WIMPL(m, tr);
+  if (!m.p.tra_adv_lim) LAUNCH_COL(k_fct_node, m.myN, m, tr);
   LAUNCH_COL_NT(3, k_fct_edge_limit, m.myD, m, tr);
   if (m.p.with_diffusion) LAUNCH_DFX(m, tr);
   LAUNCH_TRU(m, tr);
@@ -1199,8 +1202,8 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
     if (!strcmp(name, "k_updn_grad")) { LAUNCH_COL(k_updn_grad, m.myD, m, tr); return 0; }
     if (!strcmp(name, "k_flux_hor")) { launch_flux_hor<false>(m, s, tr); return 0; }
     if (!strcmp(name, "k_flux_hor_fused")) { launch_flux_hor<true>(m, s, tr); return 0; }     // fill_up_dn_grad on the fly
-    if (!strcmp(name, "k_fct_lo_node")) { LAUNCH_COL_NT(1, k_fct_lo_node, m.myN, m, tr); LAUNCH_WIMPL(m, tr); return 0; }   // (+ implicit part with w_split)
-    if (!strcmp(name, "k_fct_node")) { if (!m.p.tra_adv_lim) LAUNCH_COL_NT(2, k_fct_node, m.myN, m, tr); return 0; }      // (no limiter with tra_adv_lim='NON')
+    if (!strcmp(name, "k_fct_lo_node")) { LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); LAUNCH_WIMPL(m, tr); return 0; }   // (+ implicit part with w_split)
+    if (!strcmp(name, "k_fct_node")) { if (!m.p.tra_adv_lim) LAUNCH_COL(k_fct_node, m.myN, m, tr); return 0; }      // (no limiter with tra_adv_lim='NON')
     if (!strcmp(name, "k_fct_edge_limit")) { LAUNCH_COL_NT(3, k_fct_edge_limit, m.myD, m, tr); return 0; }
     if (!strcmp(name, "k_diff_flux")) { LAUNCH_DFX(m, tr); return 0; }
     if (!strcmp(name, "k_tr_update")) { LAUNCH_TRU(m, tr); return 0; }
@@ -1214,8 +1217,8 @@ int launch_named_tra(const DM &m, hipStream_t s, const char *name, int arg) {
     LAUNCH_COL(k_updn_grad, m.myD, m, tr); return 0;
   }
   if (!strcmp(name, "adv_tracers_ale")) {
-    launch_flux_hor<false>(m, s, tr); LAUNCH_COL_NT(1, k_fct_lo_node, m.myN, m, tr); LAUNCH_WIMPL(m, tr);
-    if (!m.p.tra_adv_lim) LAUNCH_COL_NT(2, k_fct_node, m.myN, m, tr);
+    launch_flux_hor<false>(m, s, tr); LAUNCH_COL(k_fct_lo_node, m.myN, m, tr); LAUNCH_WIMPL(m, tr);
+    if (!m.p.tra_adv_lim) LAUNCH_COL(k_fct_node, m.myN, m, tr);
     LAUNCH_COL_NT(3, k_fct_edge_limit, m.myD, m, tr);
     return 0;
   }

@@ -155,7 +155,7 @@ void orc_xinv_apply(int n, const int *mp, const unsigned short *mc, const float 
 static float *xinv_M = NULL;                  /* sparsified inverse: CSR values / columns / row pointer */
 static unsigned short *xinv_mc = NULL;
 static int *xinv_mp = NULL;
-static int xinv_n = 0;
+static int xinv_n = 0, xinv_solves = 0;
 static const void *xinv_key = NULL;
 /* RAS-Chebyshev preconditioner of the HIP path for operators beyond the explicit inverse (orc_ras.c), frozen the same way */
 #include "orc_ras.h"
@@ -163,7 +163,7 @@ static orc_ras_plan ras_plan;
 static const void *ras_key = NULL;
 static int ras_n = 0;
 void orc_solver_reset(void) {
-  free(xinv_M); free(xinv_mc); free(xinv_mp); xinv_M = NULL; xinv_mc = NULL; xinv_mp = NULL; xinv_n = 0; xinv_key = NULL;
+  free(xinv_M); free(xinv_mc); free(xinv_mp); xinv_M = NULL; xinv_mc = NULL; xinv_mp = NULL; xinv_n = 0; xinv_key = NULL; xinv_solves = 0;
   if (ras_key) orc_ras_free(&ras_plan);
   ras_key = NULL; ras_n = 0;
 }
@@ -231,7 +231,9 @@ void orc_solve_ssh(void) {
       free(dense);
       xinv_n = n; xinv_key = (const void *)C_.m.ssh_values;
     }
-    const int K = C_.p.solver_xinv_its > 0 ? C_.p.solver_xinv_its : 1;
+    /* default schedule (csrc/solver.hip:launch_solver_xinv): two iterations for the first 300 solves after the set-up, one afterwards */
+    const int K = C_.p.solver_xinv_its > 0 ? C_.p.solver_xinv_its : (xinv_solves < 300 ? 2 : 1);
+    xinv_solves++;
     for (int i = 0; i < n; i++) xx[i] = x[i];
     SPMV_(As, r, xx);
     for (int i = 0; i < n; i++) { r[i] = b[i] - r[i]; r0[i] = r[i]; pv[i] = r[i]; }

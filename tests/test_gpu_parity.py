@@ -81,6 +81,40 @@ def test_whole_steps_and_conservation(setup):
     assert np.isfinite(eta).all() and np.abs(eta).max() < 5.0
 
 
+def test_solver_iteration_schedule_across_the_spinup_bitwise(built):
+    """The default schedule of the explicit-inverse solve (solver_xinv_its = 0): two enqueued iterations for the first 300 solves after init, one
+    afterwards (csrc/solver.hip:launch_solver_xinv; the oracle counts the same way).  310 whole steps from rest: HIP == oracle bit for bit on both
+    sides of the switch; a fixed K = 1 run is a different (equally converged) iterate sequence."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.core import OceanCore
+    from fesom2_amd.synthetic import analytic_ts
+    from oracle_lib import Oracle
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    gpu, orc = OceanCore(mesh, par), Oracle(mesh, par)
+    gpu.upload_state(st); orc.set_state(st)
+    for lo, hi in ((1, 299), (299, 311)):            # up to step 298, then across the switch
+        gpu.run_steps(lo, hi - lo)
+        for n in range(lo, hi):
+            orc.call("step", n)
+        for f in ("eta_n", "d_eta", "UV", "tr_arr", "hnode"):
+            ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+            assert ok, (hi, msg)
+    eta = gpu.get("eta_n", orc.count("eta_n"))
+    gpu.close()
+    par1 = make_params(dt=900.0, solver_xinv_its=1)
+    g1 = OceanCore(mesh, par1)
+    g1.upload_state(st)
+    g1.run_steps(1, 310)
+    e1 = g1.get("eta_n", orc.count("eta_n"))
+    g1.close()
+    assert 0.0 < np.abs(e1 - eta).max() < 1e-8
+
+
 def test_psolve_abi(setup):
     """psolver_init/psolve with the reference's C signatures (src/psolve.c:16,152): residual of the
     row-scaled system below the reference's tolerance 1e-10."""
