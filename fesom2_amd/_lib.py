@@ -126,7 +126,7 @@ EXPORTS = ("fesom_gpu_init", "fesom_gpu_upload_state", "fesom_gpu_download_state
            "fesom_gpu_step", "fesom_gpu_run_steps", "fesom_gpu_finalize", "fesom_gpu_get_field",
            "fesom_gpu_set_field", "fesom_gpu_call", "fesom_gpu_last_solver_iterations", "fesom_gpu_tile_shape", "fesom_gpu_solver_kind", "fesom_gpu_comm_counts", "fesom_gpu_solver_safety_net_count",
            "fesom_gpu_last_solver_residual", "fesom_gpu_kernel_time_ms", "fesom_gpu_last_error", "fesom_gpu_step_info", "fesom_gpu_step_partitioned", "fesom_gpu_toy_zonal_mean", "fesom_gpu_profile_step",
-           "psolver_init", "psolve", "psolver_final",
+           "psolver_init", "psolve", "psolver_final", "fesom_gpu_psolver_init", "fesom_gpu_psolve", "fesom_gpu_psolver_final", "fesom_gpu_psolver_init_dist", "fesom_gpu_psolve_dist", "fesom_gpu_psolver_iterations",
            "fesom_gpu_halo_info", "fesom_gpu_halo_pack", "fesom_gpu_halo_unpack", "fesom_gpu_copy", "fesom_gpu_sync", "fesom_gpu_set_stream", "fesom_gpu_field_ptr",
            "fesom_gpu_comm_unique_id", "fesom_gpu_comm_init", "fesom_gpu_comm_finalize", "fesom_gpu_comm_selftest", "fesom_gpu_comm_timing", "fesom_gpu_comm_stats",
            "fesom_gpu_ice_init", "fesom_gpu_ice_upload", "fesom_gpu_ice_evp", "fesom_gpu_ice_evp_partitioned", "fesom_gpu_ice_advect", "fesom_gpu_ice_advect_partitioned", "fesom_gpu_ice_download", "fesom_gpu_ice_time_ms", "fesom_gpu_ice_finalize", "fesom_gpu_ice_last_error",

@@ -61,6 +61,7 @@ struct Ctx {
   // interior / boundary split of the node-column kernels behind an exchange (partitioned runs): owned nodes whose edge neighbours are all owned,
   // owned nodes with a halo neighbour, and the latter plus the halo nodes themselves
   struct ColList { const int *d = nullptr; int n = 0; } sub_int, sub_cb, sub_cbh;
+  bool solver_only = false;                           // the context holds the distributed SSH solver alone (fesom_gpu_psolver_init_dist): no ocean step
   bool precond_agreed = false;                        // partitioned runs: all ranks have settled on one SSH preconditioner
   int generation = 0;                                 // counts fesom_gpu_init calls (cached plans of the partitioned step belong to one)
   bool comm_timing = false;
@@ -440,7 +441,7 @@ int fesom_gpu_finalize(void) {
   if (G.stream && !G.ext_stream) hipStreamDestroy(G.stream);
   G.stream = nullptr; G.ext_stream = false;
   for (int i = 0; i < 3; i++) if (G.side[i]) { hipStreamDestroy(G.side[i]); G.side[i] = nullptr; }
-  G.ready = false;
+  G.ready = false; G.solver_only = false;
   return 0;
 }
 
@@ -872,7 +873,9 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   return 0;
 }
 
-#define NEED_READY() if (!G.ready) { G.err = "fesom_gpu: not initialised"; return 1; }
+#define NEED_CTX() if (!G.ready) { G.err = "fesom_gpu: not initialised"; return 1; }
+// (a context that holds the distributed SSH solver alone, fesom_gpu_psolver_init_dist, has no ocean state: only the halo / copy / communicator calls work on it)
+#define NEED_READY() do { NEED_CTX(); if (G.solver_only) { G.err = "fesom_gpu: the context holds the distributed SSH solver only (fesom_gpu_psolver_init_dist); call fesom_gpu_init for the ocean step"; return 1; } } while (0)
 
 // zlevel: a column whose surface layer would fall below min_hnode needs the reference's local-zstar fallback (oce_ale.F90:1859-1942), which is not built (the
 // reference itself stops in update_thickness_ale's non-conformable PACK there under flang): reported at the next synchronising call
@@ -1415,7 +1418,7 @@ int fesom_gpu_step_info(fesom_step_info *out) {
 }
 
 int fesom_gpu_get_field(const char *name, double *out, long long count) {
-  NEED_READY();
+  NEED_CTX();
   auto it = G.fields.find(name);
   if (it == G.fields.end() || (size_t)count != it->second.count) { G.err = std::string("get_field: bad name/count ") + name; return 1; }
   HIPCHK(hipDeviceSynchronize());
@@ -1424,7 +1427,7 @@ int fesom_gpu_get_field(const char *name, double *out, long long count) {
   return 0;
 }
 int fesom_gpu_set_field(const char *name, const double *in, long long count) {
-  NEED_READY();
+  NEED_CTX();
   auto it = G.fields.find(name);
   if (it == G.fields.end() || (size_t)count != it->second.count) { G.err = std::string("set_field: bad name/count ") + name; return 1; }
   HIPCHK(hipDeviceSynchronize());
@@ -1595,13 +1598,14 @@ static struct { bool ok = false; int n = 0, nza = 0; DM m; std::vector<void *> a
   exit(3);
 }
 #define PSCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) ps_die(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
-void psolver_final(void) { for (void *p : PS.al) hipFree(p); PS.al.clear(); PS.ok = false; }
-void psolver_init(int *id, int *stype, int *pctype, int *pcilutype, int *ilulevel, int *fillin, double *droptol, int *maxits,
-                  int *restart, double *soltol, int *part, int *rptr, int *cols, double *vals, int *reuse, int *fcomm) {
+// (bodies as internal functions: the exported names below may be interposed by a host adapter that defines psolver_init / psolve itself and forwards)
+static void ps_final_impl(void) { for (void *p : PS.al) hipFree(p); PS.al.clear(); PS.ok = false; }
+static void ps_init_impl(int *id, int *stype, int *pctype, int *pcilutype, int *ilulevel, int *fillin, double *droptol, int *maxits,
+                         int *restart, double *soltol, int *part, int *rptr, int *cols, double *vals, int *reuse, int *fcomm) {
   // solver / preconditioner selectors of pARMS (SOLBICGS_RAS, PCILUK, fill level ...) have one answer here: BiCGstab with this
   // library's frozen preconditioner; `reuse` (keep the factors of the first matrix) is how the preconditioner is always used
   (void)id; (void)stype; (void)pctype; (void)pcilutype; (void)ilulevel; (void)fillin; (void)droptol; (void)restart; (void)reuse; (void)fcomm;
-  psolver_final();
+  ps_final_impl();
   // one GPU = one partition.  The row partition is part[0..npes]; the rank count is not an argument (psolve.c:31-33 asks MPI), so
   // what can be checked is that this rank's block starts at row 0 and that every column lies inside it -- a block of a
   // multi-rank partition has off-block columns or a non-zero offset and is refused (use fesom_gpu_step_partitioned there).
@@ -1673,7 +1677,139 @@ void psolver_init(int *id, int *stype, int *pctype, int *pcilutype, int *iluleve
   solver_prepare();
   PS.n = n; PS.nza = nza; PS.ok = true;
 }
-void psolve(int *id, double *rhs, double *vals, double *sol, int *newvals) {
+// ---- distributed variant: the rows of a multi-rank partition (what psolver_init receives from solve_ssh_ale with npes > 1: `part` = prefix of
+// the owned-row counts, `cols` = global contiguous numbering, src/oce_ale.F90:1298-1344, src/psolve.c:16-115).  The library holds no MPI: the
+// host adapter (fesom2_amd/fortran/fesom_gpu_psolve_mpi.c, compiled by the integrator with the application's mpi.h) works out the halo of the
+// row block with MPI, hands it over here together with a transport (MPI callbacks, or NULL = the built-in RCCL transport after
+// fesom_gpu_comm_init) and forwards psolve.  The solve is the partitioned BiCGstab of fesom_gpu_step_partitioned (part_solve: RAS-Chebyshev
+// preconditioner on the owned block, halo of the gathered vector before each product, global sums of the partial dot products), in a context
+// that holds the solver alone.
+//   rglob[0 .. nrecv)  global rows of the halo in receive order (grouped by rPE, counts rcnt), sloc[0 .. nsend) owned rows (0-based, local)
+//   to send, grouped by sPE with counts scnt.
+static struct { bool ok = false; int n = 0, nza = 0; const fesom_transport *t = nullptr; fesom_transport tcopy; } PSD;
+int fesom_gpu_psolver_init_dist(int npes, int mype, const int *part, const int *rptr, const int *cols, const double *vals, int maxits, double soltol,
+                                int nr, const int *rPE, const int *rcnt, const int *rglob, int ns, const int *sPE, const int *scnt, const int *sloc,
+                                const fesom_transport *t) {
+  if (G.ready) fesom_gpu_finalize();
+  ps_final_impl();
+  PSD.ok = false;
+  G.err.clear(); g_alloc_failed = false;
+  if (npes < 2 || mype < 0 || mype >= npes) { G.err = "psolver_init_dist: needs npes >= 2 and 0 <= mype < npes (one partition: psolver_init)"; return 1; }
+  if (t && (!t->exchange || !t->allreduce_sum)) { G.err = "psolver_init_dist: transport callbacks missing"; return 1; }
+  const int n = part[mype + 1] - part[mype], g0 = part[mype];
+  if (n < 1 || rptr[0] != 0) { G.err = "psolver_init_dist: no rows, or rptr[0] != 0"; return 1; }
+  const int nza = rptr[n];
+  int nrecv = 0, nsend = 0;
+  for (int p = 0; p < nr; p++) nrecv += rcnt[p];
+  for (int p = 0; p < ns; p++) nsend += scnt[p];
+  std::map<int, int> hpos;                           // global row of a halo entry -> local column
+  for (int k = 0; k < nrecv; k++) hpos[rglob[k]] = n + k;
+  std::vector<int> rp(rptr, rptr + n + 1), ci(nza);
+  int maxnnz = 0;
+  for (int i = 0; i < n; i++) {
+    if (rp[i + 1] <= rp[i]) { G.err = "psolver_init_dist: empty row or rptr not increasing"; return 1; }
+    maxnnz = std::max(maxnnz, rp[i + 1] - rp[i]);
+    for (int j = rp[i]; j < rp[i + 1]; j++) {
+      const int g = cols[j];
+      if (g >= g0 && g < g0 + n) ci[j] = g - g0;
+      else {
+        auto it = hpos.find(g);
+        if (it == hpos.end()) { G.err = "psolver_init_dist: a column of the row block is neither owned nor in the halo list"; return 1; }
+        ci[j] = it->second;
+      }
+    }
+    if (ci[rp[i]] != i) { G.err = "psolver_init_dist: the first entry of every row must be the diagonal (src/oce_ale.F90:1128-1151)"; return 1; }
+  }
+  if (maxnnz > 16) { G.err = "psolver_init_dist: more than 16 entries in a row"; return 1; }
+  for (int k = 0; k < nsend; k++) if (sloc[k] < 0 || sloc[k] >= n) { G.err = "psolver_init_dist: send list entry outside the owned rows"; return 1; }
+  if (fesom_internal_select_device(G.err)) { fprintf(stderr, "fesom_gpu: %s\n", G.err.c_str()); return 2; }
+  HIPCHK(hipStreamCreate(&G.stream));
+  G.serial = true; G.use_graph = false;
+  DM &m = G.m;
+  memset(&m, 0, sizeof(m));
+  m.myN = n; m.N = n + nrecv; m.nza = nza; m.ssh_maxnnz = maxnnz; m.nl = 2; m.nlm1 = 1; m.ntr = 1;
+  m.p.solver_precond = 1;
+  const size_t N = m.N;
+  m.sv_tol = soltol > 0.0 ? soltol : 0.0; m.sv_maxits = maxits > 0 ? maxits : 0;
+  m.rowptr = dev_upload(rp); m.colind = dev_upload(ci);
+  {
+    std::vector<int> perm, inv, wid;
+    solver_row_order(rp.data(), n, maxnnz, false, perm, inv, wid);
+    m.sv_cols = (unsigned short *)dev_upload(ell_cols(rp.data(), ci.data(), n, maxnnz, perm, inv));
+    m.sv_perm = dev_upload(perm); m.sv_inv = dev_upload(inv); m.sv_wid = dev_upload(wid);
+    const int W = maxnnz <= 10 ? 10 : 16, NP = (n + 63) / 64 * 64;
+    std::vector<int> c32((size_t)W * NP, 0);
+    for (int i = 0; i < NP; i++)
+      for (int k = 0; k < W; k++) c32[(size_t)k * NP + i] = (i < n && rp[i] + k < rp[i + 1]) ? ci[rp[i] + k] : (i < n ? i : 0);
+    m.sv_colsi = dev_upload(c32);
+  }
+#define F(f, c) m.f = field(#f, c)
+  F(ssh_values, nza); F(d_eta, N); F(ssh_rhs, N);
+  F(sv_vals, 16 * (N + 64)); F(sv_dinv, N + 64); F(sv_b, N + 64); F(sv_r, N + 64); F(sv_r0, N + 64); F(sv_p, N + 64); F(sv_v, N + 64); F(sv_s, N + 64); F(sv_t, N + 64);
+  F(sv_ph, N + 64); F(sv_x0, 16 * (N + 64)); F(sv_snap, N); F(sv_ph2, N + 64); F(sv_v2, N + 64);
+  F(sv_part, 8 * ((N + 255) / 256 + 1)); F(sv_red, 8); F(sv_kry, 48);
+  F(sv_resid, 1); F(sv_h1, N); F(sv_h2, N); F(sv_h3, N); F(sv_scale, N + 64);
+  F(sv_bn, N + 64); F(sv_x, N + 64); F(sv_pd, N + 64); F(sv_sn, N + 64); F(sv_sh, N + 64);
+#undef F
+  m.sv_extrap = 0;                                   // warm start from the caller's `sol`, as the reference (psolve.c:155-221)
+  m.sv_info = dev_alloc<int>(4);
+  HIPCHK(hipMemcpy(m.ssh_values, vals, sizeof(double) * nza, hipMemcpyHostToDevice));
+  G.npes = npes; G.mype = mype;
+  G.precond_agreed = false; G.x_pending = false; G.generation++; g_prog_ready = false;
+  G.hsend = G.hrecv = nullptr; G.hcap = 0; G.hsend1 = G.hrecv1 = nullptr; G.hcap1 = 0;
+  for (int k = 0; k < 3; k++) G.halo[k] = Ctx::Halo();
+  {
+    Ctx::Halo &h = G.halo[0];
+    h.rPE.assign(rPE, rPE + nr); h.sPE.assign(sPE, sPE + ns);
+    h.rptr.assign(nr + 1, 1); h.sptr.assign(ns + 1, 1);                       // 1-based prefixes, as the reference's com_struct
+    for (int p = 0; p < nr; p++) h.rptr[p + 1] = h.rptr[p] + rcnt[p];
+    for (int p = 0; p < ns; p++) h.sptr[p + 1] = h.sptr[p] + scnt[p];
+    h.nrecv = nrecv; h.nsend = nsend;
+    h.slist_h.assign(sloc, sloc + nsend);
+    std::vector<int> rl(nrecv);
+    for (int k = 0; k < nrecv; k++) rl[k] = n + k;
+    h.rlist = dev_upload(rl); h.slist = dev_upload(h.slist_h); h.slist_q = nullptr;
+    h.rptr_d = dev_upload(h.rptr); h.sptr_d = dev_upload(h.sptr);
+  }
+  G.sub_int = G.sub_cb = G.sub_cbh = Ctx::ColList();
+  {
+    std::vector<int> inv;
+    const char *pc = getenv("FESOM_GPU_PRECOND");
+    if ((pc && !strcmp(pc, "jacobi")) || ras_device(n, m.N, rp.data(), ci.data(), vals, maxnnz, m, G.allocs, &inv)) m.rs_pinfo = nullptr;      // (does not qualify: Jacobi; the ranks agree at the first solve)
+    if (m.rs_pinfo) {
+      Ctx::Halo &h = G.halo[0];
+      std::vector<int> sq(h.slist_h.size());
+      for (size_t k = 0; k < sq.size(); k++) sq[k] = inv[h.slist_h[k]];
+      h.slist_q = dev_upload(sq);
+    }
+  }
+  for (auto &kv : G.fields) if (!kv.second.p) { G.err = "psolver_init_dist: device allocation failed"; return 1; }
+  if (g_alloc_failed) { G.err = "psolver_init_dist: a device allocation or upload failed"; return 1; }
+  solver_prepare();
+  if (t) { PSD.tcopy = *t; PSD.t = &PSD.tcopy; } else PSD.t = nullptr;
+  PSD.n = n; PSD.nza = nza; PSD.ok = true;
+  G.first_step = 0; G.solver_only = true; G.ready = true;
+  HIPCHK(hipDeviceSynchronize());
+  return 0;
+}
+int fesom_gpu_psolve_dist(const double *rhs, const double *vals, double *sol, int newvals) {
+  if (!PSD.ok || !G.ready || !G.solver_only) { G.err = "psolve_dist: fesom_gpu_psolver_init_dist has not been called"; return 1; }
+  DM &m = G.m;
+  if (!PSD.t && (!R.comm || R.nranks != G.npes || R.rank != G.mype)) { G.err = "psolve_dist: no transport given and the built-in RCCL transport is not initialised for this partition (fesom_gpu_comm_init)"; return 1; }
+  if (newvals) HIPCHK(hipMemcpyAsync(m.ssh_values, vals, sizeof(double) * PSD.nza, hipMemcpyHostToDevice, G.stream));
+  HIPCHK(hipMemcpyAsync(m.ssh_rhs, rhs, sizeof(double) * PSD.n, hipMemcpyHostToDevice, G.stream));
+  HIPCHK(hipMemcpyAsync(m.d_eta, sol, sizeof(double) * PSD.n, hipMemcpyHostToDevice, G.stream));
+  PStep S{PSD.t};
+  if (agree_on_preconditioner(S)) return 1;
+  if (part_solve(S) || S.rc) return 1;
+  S.Wt();
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(G.stream));
+  HIPCHK(hipMemcpy(sol, m.d_eta, sizeof(double) * PSD.n, hipMemcpyDeviceToHost));
+  return 0;
+}
+int fesom_gpu_psolver_iterations(void) { return (PSD.ok && G.ready && G.solver_only) ? G.part_iters : -1; }
+static void ps_solve_impl(int *id, double *rhs, double *vals, double *sol, int *newvals) {
   (void)id;
   if (!PS.ok) ps_die("psolve: psolver_init has not been called");
   DM &m = PS.m;
@@ -1685,6 +1821,19 @@ void psolve(int *id, double *rhs, double *vals, double *sol, int *newvals) {
   PSCHK(hipDeviceSynchronize());
   PSCHK(hipMemcpy(sol, m.d_eta, sizeof(double) * PS.n, hipMemcpyDeviceToHost));
 }
+void psolver_init(int *id, int *stype, int *pctype, int *pcilutype, int *ilulevel, int *fillin, double *droptol, int *maxits,
+                  int *restart, double *soltol, int *part, int *rptr, int *cols, double *vals, int *reuse, int *fcomm) {
+  ps_init_impl(id, stype, pctype, pcilutype, ilulevel, fillin, droptol, maxits, restart, soltol, part, rptr, cols, vals, reuse, fcomm);
+}
+void psolve(int *id, double *rhs, double *vals, double *sol, int *newvals) { ps_solve_impl(id, rhs, vals, sol, newvals); }
+void psolver_final(void) { ps_final_impl(); }
+// the same three under library-prefixed names: what a host adapter that defines psolver_init / psolve / psolver_final itself forwards to on one rank
+void fesom_gpu_psolver_init(int *id, int *stype, int *pctype, int *pcilutype, int *ilulevel, int *fillin, double *droptol, int *maxits,
+                            int *restart, double *soltol, int *part, int *rptr, int *cols, double *vals, int *reuse, int *fcomm) {
+  ps_init_impl(id, stype, pctype, pcilutype, ilulevel, fillin, droptol, maxits, restart, soltol, part, rptr, cols, vals, reuse, fcomm);
+}
+void fesom_gpu_psolve(int *id, double *rhs, double *vals, double *sol, int *newvals) { ps_solve_impl(id, rhs, vals, sol, newvals); }
+void fesom_gpu_psolver_final(void) { ps_final_impl(); if (PSD.ok) { PSD.ok = false; if (G.ready && G.solver_only) fesom_gpu_finalize(); } }
 }
 
 // =====================================================================================================================
@@ -1758,7 +1907,7 @@ int halo_reserve(size_t doubles, int ch) {
 // single exchanges for hosts that drive the step phase by phase (fesom2_amd/parallel.py): pack / unpack on the step's stream
 static XPlan g_hx;                                      // plan of the exchange between fesom_gpu_halo_pack and fesom_gpu_halo_unpack
 static int halo_pack_on(int kind, int nfields, const char *const *names, void **send_dev, void **recv_dev, int *values_per_item) {
-  NEED_READY();
+  NEED_CTX();
   if (G.npes < 2) { G.err = "halo: single partition"; return 1; }
   std::vector<XSpec> spec(1);
   spec[0].kind = kind; spec[0].names.assign(names, names + nfields);
@@ -1770,7 +1919,7 @@ static int halo_pack_on(int kind, int nfields, const char *const *names, void **
   return 0;
 }
 static int halo_unpack_on(int kind, int nfields, const char *const *names) {
-  NEED_READY();
+  NEED_CTX();
   std::vector<XSpec> spec(1);
   spec[0].kind = kind; spec[0].names.assign(names, names + nfields);
   XPlan x;
@@ -1781,7 +1930,7 @@ static int halo_unpack_on(int kind, int nfields, const char *const *names) {
 
 extern "C" {
 int fesom_gpu_halo_info(int kind, int *npes, int *mype, int *nr, int *rPE, int *rcnt, int *ns, int *sPE, int *scnt) {
-  NEED_READY();
+  NEED_CTX();
   if (kind < 0 || kind > 2) { G.err = "halo: bad kind"; return 1; }
   const Ctx::Halo &h = G.halo[kind];
   *npes = G.npes; *mype = G.mype; *nr = (int)h.rPE.size(); *ns = (int)h.sPE.size();
@@ -1797,24 +1946,24 @@ int fesom_gpu_halo_pack(int kind, int nfields, const char *const *names, void **
 int fesom_gpu_halo_unpack(int kind, int nfields, const char *const *names) { return halo_unpack_on(kind, nfields, names); }
 // plain copies for hosts that stage through host memory (dir 0: device -> host, 1: host -> device); synchronous
 int fesom_gpu_copy(void *dst, const void *src, long long bytes, int dir) {
-  NEED_READY();
+  NEED_CTX();
   HIPCHK(hipStreamSynchronize(G.stream));
   HIPCHK(hipMemcpy(dst, src, (size_t)bytes, dir == 0 ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice));
   return 0;
 }
 // device address of a named field (for a host transport that works on device memory, e.g. an all-reduce of sv_red)
 int fesom_gpu_field_ptr(const char *name, void **dev, long long *count) {
-  NEED_READY();
+  NEED_CTX();
   auto it = G.fields.find(name);
   if (it == G.fields.end()) { G.err = std::string("field_ptr: unknown field ") + name; return 1; }
   *dev = it->second.p; *count = (long long)it->second.count;
   return 0;
 }
-int fesom_gpu_sync(void) { NEED_READY(); HIPCHK(hipStreamSynchronize(G.stream)); return check_ale_flag(); }
+int fesom_gpu_sync(void) { NEED_CTX(); HIPCHK(hipStreamSynchronize(G.stream)); return check_ale_flag(); }
 // run every kernel of the library on the host's stream (e.g. torch.cuda.current_stream().cuda_stream), so that the host's
 // stream-ordered transport (RCCL) and the library's pack / unpack / compute kernels need no host synchronisation
 int fesom_gpu_set_stream(void *hip_stream) {
-  NEED_READY();
+  NEED_CTX();
   HIPCHK(hipStreamSynchronize(G.stream));
   if (!G.ext_stream) hipStreamDestroy(G.stream);
   G.stream = (hipStream_t)hip_stream; G.ext_stream = true;
@@ -1855,7 +2004,7 @@ int fesom_gpu_comm_finalize(void) {
 // Self test of the transport on the library's stream: a ring shift (every rank sends `n` doubles to rank+1 and receives from
 // rank-1 in one group) and an in-place sum; returns 0 if both arrive as expected.  Works with one rank too (send to self).
 int fesom_gpu_comm_selftest(int n) {
-  NEED_READY();
+  NEED_CTX();
   if (!R.comm) { G.err = "comm_selftest: fesom_gpu_comm_init has not been called"; return 1; }
   if (n < 1) n = 1;
   double *buf = nullptr;
@@ -1883,9 +2032,9 @@ int fesom_gpu_comm_selftest(int n) {
 int fesom_gpu_comm_timing(int on) { G.comm_timing = on != 0; return 0; }
 // exchange points, message parts (an exchange point that carries node and element fields has two), all-reduces and exchanges that ran on
 // the communication stream since the last fesom_gpu_comm_stats call (not reset here)
-int fesom_gpu_comm_counts(long long out[4]) { NEED_READY(); out[0] = G.n_exch; out[1] = G.n_parts; out[2] = G.n_allred; out[3] = G.n_async; return 0; }
+int fesom_gpu_comm_counts(long long out[4]) { NEED_CTX(); out[0] = G.n_exch; out[1] = G.n_parts; out[2] = G.n_allred; out[3] = G.n_async; return 0; }
 int fesom_gpu_comm_stats(long long *exchanges, long long *allreduces, double *exchange_ms) {
-  NEED_READY();
+  NEED_CTX();
   double ms = 0.0;
   if (!G.comm_ev.empty()) {
     HIPCHK(hipStreamSynchronize(G.stream));

@@ -344,6 +344,27 @@ void psolver_init(int *id, int *stype, int *pctype, int *pcilutype, int *iluleve
                   int *part, int *rptr, int *cols, double *vals, int *reuse, int *fcomm);
 void psolve(int *id, double *rhs, double *vals, double *sol, int *newvals);
 void psolver_final(void);
+/* The same three under library-prefixed names (what a host adapter that defines psolver_init / psolve / psolver_final itself forwards to on one rank). */
+void fesom_gpu_psolver_init(int *id, int *stype, int *pctype, int *pcilutype, int *ilulevel, int *fillin,
+                            double *droptol, int *maxits, int *restart, double *soltol,
+                            int *part, int *rptr, int *cols, double *vals, int *reuse, int *fcomm);
+void fesom_gpu_psolve(int *id, double *rhs, double *vals, double *sol, int *newvals);
+void fesom_gpu_psolver_final(void);
+/* Distributed SSH solve = psolver_init / psolve of the reference with npes > 1 (src/psolve.c:16-221: the rows of this rank's block, `part` the
+ * prefix of the owned-row counts, `cols` in the global contiguous numbering of src/oce_ale.F90:1298-1344; pARMS BiCGstab + RAS/ILU,
+ * lib/parms/src/bicgstab_ras.c:49-259).  The library holds no MPI: the host adapter fesom2_amd/fortran/fesom_gpu_psolve_mpi.c (compiled with
+ * the application's mpi.h; it defines psolver_init / psolve / psolver_final with the reference's signatures) works out the halo of the row
+ * block with MPI and hands it over: rglob[0 .. sum(rcnt)) = global rows of the halo columns in receive order (grouped by rPE), sloc[0 ..
+ * sum(scnt)) = owned rows (0-based, local) to send, grouped by sPE.  t = the transport callbacks (the exchange moves kind-0 messages of the
+ * halo just described; fesom_gpu_halo_info(0, ...) returns it), or NULL = the built-in RCCL transport after fesom_gpu_comm_init.  The
+ * context then holds the solver alone (fesom_gpu_init replaces it).  Solve: BiCGstab over the owned rows, right-preconditioned with the
+ * frozen RAS-Chebyshev operator of the rank's block, stop at ||scaled residual|| < soltol (1e-10 if <= 0) as the reference; a solve that does
+ * not converge within maxits is an error.  Both return 0 on success, the message is in fesom_gpu_last_error(). */
+int  fesom_gpu_psolver_init_dist(int npes, int mype, const int *part, const int *rptr, const int *cols, const double *vals, int maxits, double soltol,
+                                 int nr, const int *rPE, const int *rcnt, const int *rglob, int ns, const int *sPE, const int *scnt, const int *sloc,
+                                 const fesom_transport *t);
+int  fesom_gpu_psolve_dist(const double *rhs, const double *vals, double *sol, int newvals);
+int  fesom_gpu_psolver_iterations(void);          /* BiCGstab iterations of the last distributed solve (-1: none) */
 
 /* ---- host mesh layer (setup, untimed): restates mesh_setup + ocean_setup geometry
  *      (src/oce_mesh.F90:108-143, src/oce_ale.F90:82-795,1088-1354, src/oce_muscl_adv.F90:124-281)

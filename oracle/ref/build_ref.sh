@@ -16,7 +16,7 @@ if [ ! -d "$REF/src" ]; then
   echo "build_ref.sh: $REF not present (GPU box?) - keeping prebuilt oracle/_ref as is"; exit 0
 fi
 if [ -x "$OUT/fesom_oracle.x" ] && [ "$OUT/fesom_oracle.x" -nt "$HERE/driver.F90" ] && [ "$OUT/fesom_oracle.x" -nt "$HERE/stubs.F90" ] && [ -x "$OUT/fesom_gpu_dropin.x" ] && [ -x "$OUT/fesom_psolve_gpu.x" ] && \
-   [ "$OUT/fesom_gpu_dropin.x" -nt "$HERE/../../fesom2_amd/fortran/fesom_gpu_shim.F90" ] && [ "$OUT/fesom_gpu_dropin.x" -nt "$HERE/driver.F90" ] && [ -z "$FORCE" ]; then
+   [ "$OUT/fesom_gpu_dropin.x" -nt "$HERE/../../fesom2_amd/fortran/fesom_gpu_shim.F90" ] && [ "$OUT/fesom_gpu_dropin.x" -nt "$HERE/driver.F90" ] && [ "$OUT/fesom_psolve_gpu.x" -nt "$HERE/../../fesom2_amd/fortran/fesom_gpu_psolve_mpi.c" ] && [ -z "$FORCE" ]; then
   echo "build_ref.sh: up to date"; exit 0
 fi
 FFLAGS="-cpp -DPARMS -fdefault-real-8 -O2 -I$MPI_INC -I$REF/src -I$REF/lib/parms/include -module-dir $OUT/obj -I$OUT/obj"
@@ -87,7 +87,9 @@ if [ -f "$GPULIB/libfesom_gpu.so" ]; then
   echo "built $OUT/fesom_gpu_dropin.x"
   # ---- the reference's CPU time step with ONLY the SSH solve replaced: same objects, no psolve.c / pARMS, the three psolve
   #      entry points (src/psolve.c:16,117,152) resolved by libfesom_gpu.so
-  $FC -O2 -o "$OUT/fesom_psolve_gpu.x" $OBJS -L$MPI_LIB -lmpifort -lmpi -L$GPULIB -lfesom_gpu \
+  #      + the MPI host adapter of the solver (fesom2_amd/fortran/fesom_gpu_psolve_mpi.c): psolver_init / psolve for any number of ranks
+  gcc -O2 -Wall -fPIC -I$MPI_INC -I$REPO/include -c $GPULIB/fortran/fesom_gpu_psolve_mpi.c -o fesom_gpu_psolve_mpi.o
+  $FC -O2 -o "$OUT/fesom_psolve_gpu.x" $OBJS fesom_gpu_psolve_mpi.o -L$MPI_LIB -lmpifort -lmpi -L$GPULIB -lfesom_gpu \
     -Wl,-rpath,$MPI_LIB -Wl,-rpath,/root/repo/fesom2_amd -Wl,-rpath,$GPULIB
   echo "built $OUT/fesom_psolve_gpu.x"
 fi

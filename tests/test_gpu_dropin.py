@@ -79,22 +79,26 @@ def test_fortran_dropin_matches_reference_cpu_step(built, cfg, ranks):
     assert worst["eta_n"] > 0.0, "GPU and CPU runs are bit-identical: the two runs did not use different code paths"
 
 
-def test_psolve_only_dropin(built):
-    """the reference's own CPU time step (1 MPI rank) with ONLY the SSH solve replaced -- the executable
+@pytest.mark.parametrize("ranks", [1, 2, 4])
+def test_psolve_only_dropin(built, ranks):
+    """the reference's own CPU time step with ONLY the SSH solve replaced -- the executable
     is the reference's objects without psolve.c / pARMS, `psolver_init / psolve / psolver_final` (src/psolve.c:16,117,152)
-    resolve to libfesom_gpu.so -- against the unmodified reference (2 ranks, pARMS RAS+ILU).  Everything but the solver is the
-    same Fortran code, so the difference is the solver tolerance propagated through 10 steps."""
+    come from the MPI host adapter fesom2_amd/fortran/fesom_gpu_psolve_mpi.c + libfesom_gpu.so -- against the unmodified reference
+    (2 ranks, pARMS RAS+ILU).  ranks = 1: the single-partition solver; ranks = 2, 4: the reference's own row blocks (part, global columns)
+    go to the distributed solver (fesom_gpu_psolver_init_dist: halo worked out by the adapter with MPI, BiCGstab + RAS-Chebyshev per rank,
+    MPI_Isend/Irecv + MPI_Allreduce callbacks; the ranks share the box's GPU).  Everything but the solver is the same Fortran code, so
+    the difference is the solver tolerance propagated through 10 steps."""
     from oracle.ref import run_ref
     from oracle.ref.compare_oracle import assemble
     from refdump import read_dump
     assert os.path.exists(os.path.join(REPO, "oracle", "_ref", "fesom_psolve_gpu.x"))
     os.environ["FESOM_GPU_DEVICE"] = "0"
-    rd_g, rc_g, lines_g = run_ref.run("pi_default", 1, NSTEPS, mode="step", dump=(NSTEPS,), exe_name="fesom_psolve_gpu.x")
+    rd_g, rc_g, lines_g = run_ref.run("pi_default", ranks, NSTEPS, mode="step", dump=(NSTEPS,), exe_name="fesom_psolve_gpu.x")
     assert rc_g == 0, open(os.path.join(rd_g, "stdout.log")).read()[-3000:]
     rd_c, rc_c, lines_c = run_ref.run("pi_default", 2, NSTEPS, mode="step", dump=(NSTEPS,))
     assert rc_c == 0
-    sg = [read_dump(os.path.join(rd_g, "dumps", "setup.r00000.bin"))]
-    dg = [read_dump(os.path.join(rd_g, "dumps", f"state{NSTEPS:04d}.r00000.bin"))]
+    sg = [read_dump(os.path.join(rd_g, "dumps", f"setup.r{r:05d}.bin")) for r in range(ranks)]
+    dg = [read_dump(os.path.join(rd_g, "dumps", f"state{NSTEPS:04d}.r{r:05d}.bin")) for r in range(ranks)]
     sc = [read_dump(os.path.join(rd_c, "dumps", f"setup.r{r:05d}.bin")) for r in range(2)]
     dc = [read_dump(os.path.join(rd_c, "dumps", f"state{NSTEPS:04d}.r{r:05d}.bin")) for r in range(2)]
     worst = {f: float(np.abs(assemble(dg, sg, f) - assemble(dc, sc, f)).max()) for f in ("eta_n", "d_eta", "tr_arr", "UV", "hnode")}
@@ -102,7 +106,7 @@ def test_psolve_only_dropin(built):
     out = os.path.join(REPO, "gpurun_out")
     if os.path.isdir(out):
         import json
-        json.dump({"max_abs_diff": worst, "timing_gpu_solver": [l for l in lines_g if "TIMING" in l]}, open(os.path.join(out, "dropin_psolve_only.json"), "w"), indent=1)
+        json.dump({"max_abs_diff": worst, "timing_gpu_solver": [l for l in lines_g if "TIMING" in l]}, open(os.path.join(out, f"dropin_psolve_only_{ranks}rank.json"), "w"), indent=1)
 
 
 def test_fortran_phase_timers_from_the_gpu(built):
