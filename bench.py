@@ -241,6 +241,72 @@ def large_mesh_record(which="basin", steps=60, warmup=10, levels=3):
         core.close()
 
 
+def large_mesh_partitioned(torch, dist, pg, rank, world, transport, steps=20, warmup=5, levels=3):
+    """N > 1, supplementary record: the CORE2-class basin (182 600 nodes, default physics) as ONE simulation partitioned over the N GPUs (coordinate
+    bisection of the host mesh layer), strong scaling against the same steps on one GPU (rank 0 runs them afterwards; the extrema of eta must agree).
+    pi has 3140 surface nodes -- 390 per GPU at N = 8 -- so its partitioned run is bound by the exchanges; this is the size the partitioned path is for."""
+    from fesom2_amd import parallel
+    from fesom2_amd.core import OceanCore
+    if rank == 0:
+        workloads.basin(levels)                       # (builds the mesh files once)
+    dist.barrier(group=pg)
+    wl = workloads.basin(levels)
+    pc = parallel.PartitionedCore(wl, group=pg, transport=transport)
+    try:
+        for n in range(1, warmup + 1):
+            pc.step_native(n)
+        pc.sync(); torch.cuda.synchronize(); dist.barrier(group=pg)
+        pc.comm_stats()
+        tp = time.perf_counter()
+        for n in range(warmup + 1, warmup + steps + 1):
+            pc.step_native(n)
+        pc.sync(); torch.cuda.synchronize(); dist.barrier(group=pg)
+        pel = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device="cuda")
+        dist.all_reduce(pel, op=dist.ReduceOp.MAX, group=pg)
+        psps = float(pel.item()) / steps
+        nex, nar, _ = pc.comm_stats()
+        _, eta_own = pc.owned("eta_n", 1)
+        ext = torch.tensor([-float(eta_own.min()), float(eta_own.max()), 0.0 if np.isfinite(eta_own).all() else 1.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(ext, op=dist.ReduceOp.MAX, group=pg)
+        emin, emax, bad = -float(ext[0]), float(ext[1]), float(ext[2])
+        cnt = (C.c_longlong * 4)()
+        pc.comm_timing(True)
+        for n in range(warmup + steps + 1, warmup + steps + 4):
+            pc.step_native(n)
+        pc.sync()
+        pc.core.lib.fesom_gpu_comm_counts(cnt)
+        nex3, _, ms3 = pc.comm_stats()
+        pc.comm_timing(False)
+        rec = {"workload": wl.text, "ms_per_step": round(psps * 1e3, 4), "value": round(86400.0 / (365 * 86400.0 / wl.dt * psps), 3), "unit": "simulated_years/day",
+               "scaling": "strong", "steps": steps, "warmup": warmup, "solver_iterations": pc.solver_iterations, "transport": pc.transport_name,
+               "owned_nodes_per_gpu": int(pc.mesh.myDim_nod2D), "halo_nodes": int(pc.mesh.eDim_nod2D),
+               "exchanges_per_step": round(nex / steps, 1), "allreduces_per_step": round(nar / steps, 1), "exchange_points_per_step": round(cnt[0] / 3.0, 1),
+               "async_exchanges_per_step": round(cnt[3] / 3.0, 1), "us_per_exchange": round(ms3 * 1e3 / max(nex3, 1), 2),
+               "comm_fraction_of_step_stream": round(ms3 / 3.0 / (psps * 1e3), 3), "eta_min_max": [emin, emax], "error": None}
+    finally:
+        pc.close()
+    dist.barrier(group=pg)
+    if rank == 0:                                     # the same steps on one GPU: time and eta extrema
+        mesh = wl.load_mesh()
+        core = OceanCore(mesh, wl.params())
+        try:
+            wl.start(core, mesh)
+            core.run_steps(1, warmup); core.lib.fesom_gpu_sync()
+            t0 = time.perf_counter()
+            core.run_steps(1 + warmup, steps); core.lib.fesom_gpu_sync()
+            s1 = (time.perf_counter() - t0) / steps
+            eta = core.get("eta_n", mesh.myDim_nod2D)
+        finally:
+            core.close()
+        rec["single_gpu_ms_per_step"] = round(s1 * 1e3, 4)
+        rec["speedup_vs_single_gpu"] = round(s1 / psps, 3)
+        rec["check_vs_single_gpu"] = {"eta_min_max_single": [float(eta.min()), float(eta.max())], "tolerance": 1e-7}
+        if bad or abs(eta.min() - emin) > 1e-7 or abs(eta.max() - emax) > 1e-7:
+            rec["error"] = f"eta extrema differ from the single-GPU run: {emin} {emax} against {float(eta.min())} {float(eta.max())}"
+    dist.barrier(group=pg)
+    return rec
+
+
 def cpu_baseline(wl, nsteps_ref=None):
     """Reference Fortran/MPI hot path (oracle/_ref/fesom_oracle.x, built from the reference's own sources) on the host cores:
     same mesh, options, initial state and forcing; best of 8 / 16 / 32 MPI ranks that fit the node (bounded sample)."""
@@ -318,6 +384,7 @@ def main():
     ap.add_argument("--no-large-mesh", action="store_true", help="skip the CORE2-class record (channel refined 3x, ~60 steps) of the default N = 1 line")
     args = ap.parse_args()
 
+    t_start = time.perf_counter()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
@@ -390,7 +457,7 @@ def main():
 
     # ---- N > 1: ONE simulation partitioned over the N GPUs; its owned state is checked against the replica that just ran the
     # same W + K steps from the same initial state (partition- and solver-level differences only: 1e-8, as in the partitioned tests)
-    partitioned, failed = None, False
+    partitioned, failed, large_part = None, False, None
     if world > 1 and os.environ.get("FESOM_BENCH_PARTITIONED", "1") != "0":
         n1 = mesh.nl - 1
         ref_state = {"eta_n": core.get("eta_n", mesh.nod2D), "tr_arr": core.get("tr_arr", 2 * mesh.nod2D * n1).reshape(2, mesh.nod2D, n1)}
@@ -465,7 +532,7 @@ def main():
             pc.comm_timing(False)
             partitioned = {"ms_per_step": round(psps * 1e3, 4), "value": round(86400.0 / (steps_per_year * psps), 2), "unit": "simulated_years/day",
                            "scaling": "strong", "steps": steps, "warmup": warmup, "solver_iterations": its_part,
-                           "transport": pc.transport_name, "transport_note": tr_note, "exchanges_per_step": round(nex / steps, 1), "allreduces_per_step": round(nar / steps, 1),
+                           "transport": pc.transport_name, "transport_key": pc.transport, "transport_note": tr_note, "exchanges_per_step": round(nex / steps, 1), "allreduces_per_step": round(nar / steps, 1),
                            "exchange_points_per_step": round(cnt5[0] / 5.0, 1), "message_parts_per_step": round(cnt5[1] / 5.0, 1), "async_exchanges_per_step": round(cnt5[3] / 5.0, 1),
                            "us_per_exchange": round(ms5 * 1e3 / max(nex5, 1), 2),
                            "comm_fraction_of_step_stream": round(ms5 / 5.0 / (psps * 1e3), 3),      # pack..unpack of the synchronous exchanges + what the stream waited for the asynchronous ones
@@ -491,6 +558,25 @@ def main():
             failed = True
         if failed and not partitioned.get("error"):
             partitioned["error"] = "another rank failed in the partitioned leg"
+        # supplementary: the CORE2-class basin partitioned over the same GPUs (default pi line only; bounded by its own watchdog -- the headline stands alone)
+        if not failed and wl.name == "pi" and wl.levels == 0 and not args.no_large_mesh and time.perf_counter() - t_start < 240.0:
+            lm_limit = float(os.environ.get("FESOM_BENCH_LARGE_MESH_TIMEOUT", "420"))
+
+            def _lm_give_up():      # a hang in the supplementary record must not cost the headline: print the line without it and leave
+                if rank == 0:
+                    print(json.dumps({"metric": "SYPD (simulated years/day) on pi mesh, 47 z-levels", "value": partitioned.get("value"), "unit": "simulated_years/day", "n_gpus": world,
+                                      "steps": steps, "warmup": warmup, "ms_per_step": partitioned.get("ms_per_step"), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                                      "dtype": "f64", "data": "synthetic", "config": {"workload": wl.text, "parallelism": f"one simulation partitioned over {world} GPUs"},
+                                      "partitioned": partitioned, "large_mesh_partitioned": {"error": f"did not finish within {lm_limit:.0f} s"},
+                                      "replicas": {"value": round(sypd_one * world, 2), "unit": "simulated_years/day", "ms_per_step": round(sps * 1e3, 5), "scaling": "weak"}}), flush=True)
+                os._exit(0)
+            wd2 = threading.Timer(lm_limit, _lm_give_up); wd2.daemon = True; wd2.start()
+            try:
+                large_part = large_mesh_partitioned(torch, dist, pg, rank, world, partitioned.get("transport_key", want))
+            except Exception as e:      # noqa: BLE001
+                large_part = {"error": f"{type(e).__name__}: {e}"[:1000]}
+            finally:
+                wd2.cancel()
         if rank == 0:
             core = new_core(wl)
             core.run_steps(1, 60)
@@ -543,6 +629,8 @@ def main():
                "roofline": roofline, "cpu_baseline": cpu}
         if world > 1:
             out["partitioned"] = partitioned
+            if large_part is not None:
+                out["large_mesh_partitioned"] = large_part
             out["replicas"] = {"value": round(sypd_one * world, 2), "unit": "simulated_years/day", "ms_per_step": round(sps * 1e3, 5), "scaling": "weak",
                                "note": f"aggregate of {world} independent simulations, one per GPU (no communication)"}
         if other is not None:
