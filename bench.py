@@ -148,7 +148,10 @@ def pmc_traffic(kernel, workload_key, redi):
         want = {"k_flux_hor_fused": ("k_flux_hor", "true"), "k_flux_hor": ("k_flux_hor", "false")}.get(kernel, (kernel, "true" if redi else "false"))
         for key, v in kern.items():
             base, _, targs = key.partition("<")
-            if base != want[0]:
+            # (round 3: the shapes with two tracers per wave / staged gathers carry a suffix: k_flux_hor_nt<FUSED, 2>, k_diff_flux_nt<REDI, 2>,
+            #  k_tr_grad_elem_b<1, 2>, k_kpp_smooth_u<8>)
+            alias = {"k_kpp_smooth1": "k_kpp_smooth", "k_kpp_smooth2": "k_kpp_smooth", "k_kpp_smooth3": "k_kpp_smooth"}.get(want[0], want[0])
+            if base not in (alias, alias + "_nt", alias + "_b", alias + "_u"):
                 continue
             if targs and targs.rstrip(">").split(",")[0].strip() in ("true", "false") and targs.rstrip(">").split(",")[0].strip() != want[1]:
                 continue
