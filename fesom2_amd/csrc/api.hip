@@ -664,32 +664,32 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     if (par->use_global_tides) m.ssh_gp = view("ssh_gp", N);
     if (par->SPP) { m.thdgr = view("thdgr", N); m.S_oc = view("S_oc_array", N); }
   }
-  if (par->mix_scheme == 1) {
-    {   // smooth_nod3D gathers the 3 nodes of every element of a node's cluster: the DISTINCT nodes of the cluster (7 on a regular mesh against 18 gathers)
-        // are staged once per wave (k_kpp_smooth_u); list of distinct nodes in order of first appearance + where each element's nodes sit in it
-      int maxu = 1;
-      std::vector<std::vector<int>> U(m.myN);
-      std::vector<int> pos((size_t)m.maxk * m.myN, 0), cnt(m.myN, 0);
-      for (int n = 0; n < m.myN; n++) {
-        std::vector<int> &u = U[n];
-        for (int k = 0; k < d->nod_in_elem2D_num[n]; k++) {
-          const int el = d->nod_in_elem2D[(size_t)m.maxk * n + k] - 1;
-          int pk = 0;
-          for (int j = 0; j < 3; j++) {
-            const int nd = en[3 * (size_t)el + j];
-            size_t q = std::find(u.begin(), u.end(), nd) - u.begin();
-            if (q == u.size()) u.push_back(nd);
-            pk |= (int)q << (8 * j);
-          }
-          pos[(size_t)m.maxk * n + k] = pk;
+  {   // kernels that gather the 3 nodes of every element of a node's cluster (smooth_nod3D of KPP, compute_sigma_xy): the DISTINCT nodes of the cluster (7 on a regular mesh against 18 gathers)
+      // are staged once per wave (k_kpp_smooth_u); list of distinct nodes in order of first appearance + where each element's nodes sit in it
+    int maxu = 1;
+    std::vector<std::vector<int>> U(m.myN);
+    std::vector<int> pos((size_t)m.maxk * m.myN, 0), cnt(m.myN, 0);
+    for (int n = 0; n < m.myN; n++) {
+      std::vector<int> &u = U[n];
+      for (int k = 0; k < d->nod_in_elem2D_num[n]; k++) {
+        const int el = d->nod_in_elem2D[(size_t)m.maxk * n + k] - 1;
+        int pk = 0;
+        for (int j = 0; j < 3; j++) {
+          const int nd = en[3 * (size_t)el + j];
+          size_t q = std::find(u.begin(), u.end(), nd) - u.begin();
+          if (q == u.size()) u.push_back(nd);
+          pk |= (int)q << (8 * j);
         }
-        cnt[n] = (int)u.size();
-        maxu = std::max(maxu, cnt[n]);
+        pos[(size_t)m.maxk * n + k] = pk;
       }
-      std::vector<int> nb((size_t)maxu * m.myN, 0);
-      for (int n = 0; n < m.myN; n++) for (size_t q = 0; q < U[n].size(); q++) nb[(size_t)maxu * n + q] = U[n][q];
-      m.kpp_nb = dev_upload(nb); m.kpp_nbn = dev_upload(cnt); m.kpp_pos = dev_upload(pos); m.kpp_maxu = maxu;
+      cnt[n] = (int)u.size();
+      maxu = std::max(maxu, cnt[n]);
     }
+    std::vector<int> nb((size_t)maxu * m.myN, 0);
+    for (int n = 0; n < m.myN; n++) for (size_t q = 0; q < U[n].size(); q++) nb[(size_t)maxu * n + q] = U[n][q];
+    m.cl_nb = dev_upload(nb); m.cl_nbn = dev_upload(cnt); m.cl_pos = dev_upload(pos); m.cl_maxu = maxu;
+  }
+  if (par->mix_scheme == 1) {
     F(dbsfc, nl * N);
     F(kpp_viscA, nl * N); F(kpp_Kv1, nl * N); F(kpp_Kv2, nl * N); F(kpp_ghats, n1 * N); F(kpp_hbl, N); F(kpp_caseA, N); F(kpp_dkm1, 3 * N);
     m.kpp_blmc = field("kpp_blmc", nl * N, 3); m.kpp_sA = field("kpp_sA", nl * N, 3); m.kpp_sB = field("kpp_sB", nl * N, 3);

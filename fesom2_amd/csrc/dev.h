@@ -27,7 +27,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   const int *edges;           // (2,D)
   const int *edge_tri;        // (2,D)
   const int *nie, *nie_num;   // (maxk,N), (N)
-  const int *kpp_nb, *kpp_nbn, *kpp_pos; int kpp_maxu;   // KPP smoothing: distinct nodes of a node's element cluster (kpp_maxu, myN), their number (myN), per cluster element the positions of its 3 nodes in that list, packed (maxk, myN)
+  const int *cl_nb, *cl_nbn, *cl_pos; int cl_maxu;   // distinct nodes of a node's element cluster (cl_maxu, myN), their number (myN), per cluster element the positions of its 3 nodes in that list, packed (maxk, myN): k_kpp_smooth_u
   const int *nlev, *ulev;     // (E)   1-based level counts as in the reference
   const int *nlev_n, *ulev_n, *nlev_n_min, *ulev_n_max;   // (N)
   const int *edge_glob;       // (D) global edge id (1-based) for the internal/boundary test

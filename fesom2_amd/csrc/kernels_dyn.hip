@@ -1604,6 +1604,9 @@ __global__ void __launch_bounds__(BLOCK) k_thick(DM m, int ncolN) {
 
 // ------------------------------------------------------------------------------------------------
 #define LAUNCH_COL(k, ncol, ...) hipLaunchKernelGGL(k, dim3(nblocks(ncol)), dim3(BLOCK), 0, s, __VA_ARGS__)
+// (measured, round 3: staging the distinct nodes of the cluster in LDS as k_kpp_smooth_u does changes nothing here, 399 -> 407 us on the basin: the kernel is
+//  bound by its arithmetic -- tanh, sqrt, the divisions of the slope -- not by its 36 column gathers)
+static void launch_sigma_slope(const DM &m, hipStream_t s) { LAUNCH_COL(k_sigma_slope, m.myN, m); }
 #define LAUNCH_FLAT(k, n, ...) hipLaunchKernelGGL(k, dim3(((n) + 255) / 256), dim3(256), 0, s, __VA_ARGS__)
 
 #define IV_ATTR(id, C_, W_) (void)hipFuncSetAttribute((const void *)k_impl_visc<C_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1624,7 +1627,7 @@ void launch_dynamics_pre(const DM &m, hipStream_t s, int first_step) {
   LAUNCH_COL(k_vel_nodes, m.myN, m);
   LAUNCH_COL(k_pressure_bv, m.N, m);
   launch_pgf(m, s);
-  LAUNCH_COL(k_sigma_slope, m.myN, m);
+  launch_sigma_slope(m, s);
   if (m.p.mix_scheme == 2) {
     launch_momix(m, s);
     hipLaunchKernelGGL(k_pp, dim3(nblocks(m.myE) + nblocks(m.N)), dim3(BLOCK), 0, s, m, nblocks(m.myE) * COLS_PER_BLOCK);
@@ -1668,7 +1671,7 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
     if (!strcmp(name, "k_vel_nodes")) { LAUNCH_COL(k_vel_nodes, m.myN, m); return 0; }
     if (!strcmp(name, "k_pressure_bv")) { LAUNCH_COL(k_pressure_bv, m.N, m); return 0; }
     if (!strcmp(name, "k_pgf")) { launch_pgf(m, s); return 0; }
-    if (!strcmp(name, "k_sigma_slope")) { LAUNCH_COL(k_sigma_slope, m.myN, m); return 0; }
+    if (!strcmp(name, "k_sigma_slope")) { launch_sigma_slope(m, s); return 0; }
     if (!strcmp(name, "k_pp")) { hipLaunchKernelGGL(k_pp, dim3(nblocks(m.myE) + nblocks(m.N)), dim3(BLOCK), 0, s, m, nblocks(m.myE) * COLS_PER_BLOCK); return 0; }
     if (!strcmp(name, "k_pp_elem")) { LAUNCH_COL(k_pp_elem, m.myE, m); return 0; }
     if (!strcmp(name, "k_pp_node_final")) { LAUNCH_COL(k_pp_node_final, m.N, m); return 0; }
@@ -1703,7 +1706,7 @@ int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int 
   if (!strcmp(name, "pressure_bv")) { LAUNCH_COL(k_pressure_bv, m.N, m); return 0; }       // includes sw_alpha_beta
   if (!strcmp(name, "sw_alpha_beta")) return 0;
   if (!strcmp(name, "pressure_force")) { launch_pgf(m, s); return 0; }
-  if (!strcmp(name, "compute_sigma_xy")) { LAUNCH_COL(k_sigma_slope, m.myN, m); return 0; } // includes neutral slope
+  if (!strcmp(name, "compute_sigma_xy")) { launch_sigma_slope(m, s); return 0; } // includes neutral slope
   if (!strcmp(name, "compute_neutral_slope")) return 0;
   if (!strcmp(name, "mixing_pp")) {
     if (m.p.use_momix) LAUNCH_FLAT(k_momix, m.N, m);                                        // mo_length of mo_convect, which is fused into k_pp

@@ -332,9 +332,9 @@ __global__ void __launch_bounds__(BLOCK) k_kpp_smooth(DM m, const double *src, d
   for (int f = 0; f < 3; f++) dst[(size_t)f * nlN + (size_t)n * m.nl + l] = in ? work[f] * vol : 0.0;
 }
 
-// The same sweep with the distinct nodes of the cluster staged ONCE per wave (DM::kpp_nb: 7 columns x 3 fields on a regular mesh instead of the 18 x 3
+// The same sweep with the distinct nodes of the cluster staged ONCE per wave (DM::cl_nb: 7 columns x 3 fields on a regular mesh instead of the 18 x 3
 // gathers of the element loop): all loads issued together, then field by field through a wave-private LDS image from which every element takes
-// its 3 nodes (DM::kpp_pos).  Same sums in the same order.  MAXU = upper bound of the distinct nodes (DM::kpp_maxu).
+// its 3 nodes (DM::cl_pos).  Same sums in the same order.  MAXU = upper bound of the distinct nodes (DM::cl_maxu).
 template <int MAXU>
 __global__ void __launch_bounds__(BLOCK) k_kpp_smooth_u(DM m, const double *src, double *dst) {
   __shared__ double img[COLS_PER_BLOCK][MAXU][WAVE];
@@ -342,13 +342,13 @@ __global__ void __launch_bounds__(BLOCK) k_kpp_smooth_u(DM m, const double *src,
   if (n >= m.myN) return;
   const size_t nlN = (size_t)m.nl * m.N;
   const int uln = m.ulev_n[n], nln = m.nlev_n[n] < m.nl ? m.nlev_n[n] : m.nl;
-  const int num = m.nie_num[n], nu = m.kpp_nbn[n];
+  const int num = m.nie_num[n], nu = m.cl_nbn[n];
   int nb_l = 0, pos_l = 0, lo_l = 1, hi_l = 0;
   double ar_l = 0.0;
-  if (l < nu) nb_l = m.kpp_nb[(size_t)m.kpp_maxu * n + l];
+  if (l < nu) nb_l = m.cl_nb[(size_t)m.cl_maxu * n + l];
   if (l < num) {
     const int el = m.nie[(size_t)m.maxk * n + l];
-    pos_l = m.kpp_pos[(size_t)m.maxk * n + l];
+    pos_l = m.cl_pos[(size_t)m.maxk * n + l];
     lo_l = uln > m.ulev[el] ? uln : m.ulev[el];
     const int nle = m.nlev[el] < m.nl ? m.nlev[el] : m.nl;
     hi_l = nln < nle ? nln : nle;
@@ -452,8 +452,8 @@ __global__ void __launch_bounds__(BLOCK) k_kpp_final_elem(DM m, int ncolE) {
 #define LAUNCH_COL(k, ncol, ...) hipLaunchKernelGGL(k, dim3(nblocks(ncol)), dim3(BLOCK), 0, s, __VA_ARGS__)
 static void smooth(const DM &m, hipStream_t s, const double *src, double *dst) {
   static const int env = getenv("FESOM_GPU_EXP_KPPU") ? atoi(getenv("FESOM_GPU_EXP_KPPU")) : -1;
-  const bool staged = (env >= 0 ? env != 0 : true) && m.kpp_maxu <= 12;      // (430 -> 228 us per sweep on the basin, 10.7 -> 10.0 us on pi)
-  if (staged && m.kpp_maxu <= 8) hipLaunchKernelGGL((k_kpp_smooth_u<8>), dim3(nblocks(m.myN)), dim3(BLOCK), 0, s, m, src, dst);
+  const bool staged = (env >= 0 ? env != 0 : true) && m.cl_maxu <= 12;      // (430 -> 228 us per sweep on the basin, 10.7 -> 10.0 us on pi)
+  if (staged && m.cl_maxu <= 8) hipLaunchKernelGGL((k_kpp_smooth_u<8>), dim3(nblocks(m.myN)), dim3(BLOCK), 0, s, m, src, dst);
   else if (staged) hipLaunchKernelGGL((k_kpp_smooth_u<12>), dim3(nblocks(m.myN)), dim3(BLOCK), 0, s, m, src, dst);
   else hipLaunchKernelGGL(k_kpp_smooth, dim3(nblocks(m.myN)), dim3(BLOCK), 0, s, m, src, dst);      // the three blmc fields in one wave per node
 }

@@ -1,5 +1,6 @@
 """CPU: the N>1 contract of bench.py (one process per rank, barrier-bracketed timed region, MAX over ranks, aggregate
-value) exercised with world_size=2 on the gloo backend.  The data path has no collective in this round (replicas)."""
+value) exercised with world_size=2 on the gloo backend, and the halo-exchange plan of the partitioned step (send / receive lists of the two ranks
+match item for item).  The partitioned data path itself (halo messages + the solver's global sums) needs the GPU: tests/test_gpu_partitioned.py."""
 import os
 import subprocess
 import sys
