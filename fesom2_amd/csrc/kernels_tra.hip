@@ -1084,16 +1084,20 @@ __global__ void __launch_bounds__(WAVE * WAVES, (WAVES == 8) ? 4 : 2) k_tr_updat
     }
     tru_head(m, n, k);
     if (SINGLE) {
+      // the horizontal gathers of all tracers first, then the interface depths / slopes of the column, then the tracers' T*: what the gathers keep
+      // live (a batch of edge values) never overlaps with the nine column values of tru_zcol (register budget of the two-tracer shape)
+      double del[NT];
 #pragma unroll
       for (int t = 0; t < NT; t++) {
-        Ts[t] = 0.0; rhs[t] = 0.0;
-        double del = 0.0;
+        Ts[t] = 0.0; rhs[t] = 0.0; del[t] = 0.0;
         if (trA + t < m.ntr) {                                                          // (latency-bound shape: plain divisions keep it at its register budget)
-          if (m.p.tra_adv_lim) tru_hor<false, TRU_MAXD, true>(m, k, trA + t, Ts[t], del); else tru_hor<false, TRU_MAXD>(m, k, trA + t, Ts[t], del);
+          if (m.p.tra_adv_lim) tru_hor<false, TRU_MAXD, true>(m, k, trA + t, Ts[t], del[t]); else tru_hor<false, TRU_MAXD>(m, k, trA + t, Ts[t], del[t]);
         }
-        if (t == 0) tru_zcol<REDI>(m, k);
-        if (trA + t < m.ntr) tru_fin<REDI>(m, k, trA + t, Ts[t], del);
       }
+      tru_zcol<REDI>(m, k);
+#pragma unroll
+      for (int t = 0; t < NT; t++)
+        if (trA + t < m.ntr) tru_fin<REDI>(m, k, trA + t, Ts[t], del[t]);
       if (impl) {
         tru_coeffs<REDI>(m, k);
 #pragma unroll
@@ -1104,18 +1108,26 @@ __global__ void __launch_bounds__(WAVE * WAVES, (WAVES == 8) ? 4 : 2) k_tr_updat
         for (int t = 0; t < NT; t++) if (k.wet && trA + t < m.ntr) DTR(m.tr_arr, nz, k.n, trA + t) = defer_clamp(m) ? Ts[t] : tru_clamp(Ts[t], trA + t);
       }
     } else {
-      // several columns per wave: the column's coefficients first, then tracer after tracer straight into the tile / memory
+      // several columns per wave: the horizontal gathers of all tracers first (their batches of edge values are the widest live set), then the column's
+      // interface depths and coefficients, then tracer after tracer straight into the tile / memory
+      double Tt[NT], dl[NT];
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        Tt[t] = 0.0; dl[t] = 0.0;
+        if (trA + t < m.ntr) {
+          if (m.p.tra_adv_lim) tru_hor<false, TRU_MAXD_TILE, true>(m, k, trA + t, Tt[t], dl[t]);
+          else if (tru_hor<true, TRU_MAXD_TILE>(m, k, trA + t, Tt[t], dl[t])) tru_hor<false, TRU_MAXD_TILE>(m, k, trA + t, Tt[t], dl[t]);
+        }
+      }
       tru_zcol<REDI>(m, k);
       if (impl) { tru_coeffs<REDI>(m, k); tile.put_abc(ci, k.valid, k.nzmin, k.nzmax - 1, k.a, k.b, k.c); }
 #pragma unroll
       for (int t = 0; t < NT; t++) {
-        double T = 0.0, del = 0.0, r = 0.0;
+        double T = Tt[t], r = 0.0;
         if (trA + t < m.ntr) {
-          if (m.p.tra_adv_lim) tru_hor<false, TRU_MAXD_TILE, true>(m, k, trA + t, T, del);
-          else if (tru_hor<true, TRU_MAXD_TILE>(m, k, trA + t, T, del)) tru_hor<false, TRU_MAXD_TILE>(m, k, trA + t, T, del);
-          tru_fin<REDI>(m, k, trA + t, T, del);
+          tru_fin<REDI>(m, k, trA + t, T, dl[t]);
           if (k.wet) DTR(m.tr_arr, nz, k.n, trA + t) = (impl || defer_clamp(m)) ? T : tru_clamp(T, trA + t);    // T*: picked up again after the sweep
-          if (impl) { tile.get_abc(ci, k.a, k.b, k.c); r = tru_rhs(m, k, trA + t, T); }      // (a, b, c back from the tile: not kept in registers across the gathers)
+          if (impl) r = tru_rhs(m, k, trA + t, T);
         }
         if (impl) tile.put_rhs(ci, t, r);
       }
