@@ -457,10 +457,11 @@ __device__ __forceinline__ void k_fct_lo_node_col(const DM &m, const int tr) {
   const int nzc = min(nz, m.nlm1);
   double fl[GATHER_MAXD];
 #pragma unroll
-  for (int q = 0; q < GATHER_MAXD; q++) fl[q] = DA2(t.flux_lo_hor, nzc, rdlane(ed_l, q));
+  for (int q = 0; q < GATHER_MAXD; q++) fl[q] = q < deg ? DA2(t.flux_lo_hor, nzc, rdlane(ed_l, q)) : 0.0;      // (q < deg: wave-uniform, a scalar branch)
   double lo = 0.0;
 #pragma unroll
   for (int q = 0; q < GATHER_MAXD; q++) {
+    if (q >= deg) continue;
     unsigned rg = (unsigned)rdlane((int)rg_l, q);
     bool on = nz >= (int)(rg & 0xffu) && nz <= (int)((rg >> 8) & 0xffu);
     double nlo = (rdlane(sg_l, q) > 0) ? lo + fl[q] : lo - fl[q];
@@ -560,17 +561,21 @@ __device__ __forceinline__ void k_fct_node_col(const DM &m, const int tr) {
   double bx[GATHER_MAXD], bn[GATHER_MAXD], fh[GATHER_MAXD];
 #pragma unroll
   for (int q = 0; q < GATHER_MAXD; q++) {
-    int k = rdlane(fn_l, q);
-    double lk = DA2(LOp, nzc, k), tk = DA2(Tp, nzc, k);
-    bx[q] = dmax_(lk, tk); bn[q] = dmin_(lk, tk);
-    fh[q] = DA2(t.adv_flux_raw, nzc, rdlane(ed_l, q));
+    bx[q] = bn[q] = fh[q] = 0.0;
+    if (q < deg) {                                          // (wave-uniform: slots beyond the node's degree cost a scalar branch, no loads, no arithmetic)
+      int k = rdlane(fn_l, q);
+      double lk = DA2(LOp, nzc, k), tk = DA2(Tp, nzc, k);
+      bx[q] = dmax_(lk, tk); bn[q] = dmin_(lk, tk);
+      fh[q] = DA2(t.adv_flux_raw, nzc, rdlane(ed_l, q));
+    }
   }
   double lo_own = DA2(LOp, nzc, n), t_own = DA2(Tp, nzc, n);
   double tvmax = wet ? dmax_(lo_own, t_own) : -1e3, tvmin = wet ? dmin_(lo_own, t_own) : 1e3;   // dry: the reference's -1e3 / 1e3
 #pragma unroll
   for (int q = 0; q < GATHER_MAXD; q++) {
+    if (q >= deg) continue;
     unsigned rg = (unsigned)rdlane((int)rg_l, q);
-    bool on = nz >= (int)(rg & 0xffu) && nz <= (int)((rg >> 8) & 0xffu);     // q >= deg: empty range
+    bool on = nz >= (int)(rg & 0xffu) && nz <= (int)((rg >> 8) & 0xffu);
     tvmax = on ? dmax_(tvmax, bx[q]) : tvmax;
     tvmin = on ? dmin_(tvmin, bn[q]) : tvmin;
   }
@@ -589,6 +594,7 @@ __device__ __forceinline__ void k_fct_node_col(const DM &m, const int tr) {
   double minus = 0.0 + (dmin_(0.0, adv) + dmin_(0.0, -adv_dn));
 #pragma unroll
   for (int q = 0; q < GATHER_MAXD; q++) {
+    if (q >= deg) continue;
     unsigned rg = (unsigned)rdlane((int)rg_l, q);
     bool on = nz >= (int)(rg & 0xffu) && nz <= (int)((rg >> 8) & 0xffu);
     double f = (rdlane(sg_l, q) < 0) ? -fh[q] : fh[q];
@@ -765,6 +771,7 @@ __device__ __forceinline__ bool tru_hor(const DM &m, const TruCol &k, int tr, do
   const int nzc = min(nz, m.nlm1);
   const bool dif = m.p.with_diffusion != 0;
   constexpr bool non = NON;                                // 'NON': no limiter (factor 1), no low-order solution in the vertical update
+  constexpr bool GUARD = MAXD > 6;
   const double p_own = non ? 1.0 : UA2(t.fct_plus, nzc, n), m_own = non ? 1.0 : UA2(t.fct_minus, nzc, n);
   // Per edge of the batch: the limited antidiffusive flux and the diffusive flux, already masked with the level range of the
   // edge (+0.0 outside: x + 0.0 == x for the running sums below, which start at +0.0 and therefore never are -0.0) and carrying
@@ -772,6 +779,10 @@ __device__ __forceinline__ bool tru_hor(const DM &m, const TruCol &k, int tr, do
   double fa[MAXD], fd[MAXD];
 #pragma unroll
   for (int q = 0; q < MAXD; q++) {                       // one batch of independent loads
+    fa[q] = 0.0; fd[q] = 0.0;
+    // wave-uniform: slots beyond the node's degree cost a scalar branch instead of four loads.  Only where the batch is wider than the typical degree
+    // (pi: 10 slots, 51 -> 46 us); with the 6 slots of the tile shapes the branches break up the batch of loads and cost more than they save (1093 -> 1281 us)
+    if (GUARD && q >= k.deg) continue;
     int ed = rdlane(k.ed_l, q), kk = rdlane(k.fn_l, q);
     const bool first = rdlane(k.sg_l, q) > 0;               // this node is edges(1,ed)  (wave-uniform)
     const unsigned rg = (unsigned)rdlane((int)k.rg_l, q);
@@ -801,7 +812,7 @@ __device__ __forceinline__ bool tru_hor(const DM &m, const TruCol &k, int tr, do
   dv = dv + QDIV((adv - adv_dn) * dt);
   double dh = 0.0;
 #pragma unroll
-  for (int q = 0; q < MAXD; q++) dh = dh + QDIV(fa[q] * dt);
+  for (int q = 0; q < MAXD; q++) if (!GUARD || q < k.deg) dh = dh + QDIV(fa[q] * dt);          // (a skipped slot would add + 0.0: the same bits)
   for (int q = MAXD; q < k.deg; q++) {                  // nodes with more incident edges than the batch (rare)
     int ed = m.ne_idx[k.q0 + q];
     unsigned rg = m.ne_rng[k.q0 + q];
@@ -815,7 +826,7 @@ __device__ __forceinline__ bool tru_hor(const DM &m, const TruCol &k, int tr, do
   del = 0.0 + dh + dv;
   if (dif) {
 #pragma unroll
-    for (int q = 0; q < MAXD; q++) del = del + QDIV(fd[q] * dt);
+    for (int q = 0; q < MAXD; q++) if (!GUARD || q < k.deg) del = del + QDIV(fd[q] * dt);
     for (int q = MAXD; q < k.deg; q++) {
       int ed = m.ne_idx[k.q0 + q];
       unsigned rg = m.ne_rng[k.q0 + q];
