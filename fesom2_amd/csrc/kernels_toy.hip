@@ -10,38 +10,49 @@
 
 // compute_zonal_mean (:157-217): one wavefront per latitude bin, lane = level; the elements of the bin are summed in
 // element order (the reference's loop order on one partition), then divided by (count + 0.001).
-__global__ void __launch_bounds__(BLOCK) k_toy_zonal_mean(DM m) {
-  int b = col_id(m), nz = lane_id() + 1;
-  if (b >= 100 || nz > m.nlm1) return;
+// The bin's elements come in batches of ZB: their index chains (element, bottom level, the three nodes) are read lane-parallel, the 4 * ZB column
+// loads of a batch are issued together, the sums stay in element order (a bin of the 182 600-node channel holds 3648 elements: 2.7 ms per call with one
+// dependent load chain per element, a quarter of that batched).
+template <bool DIVIDE>
+__device__ __forceinline__ void toy_zonal_bin(const DM &m) {
+  const int b = col_id(m), l = lane_id(), nz = l + 1;
+  if (b >= 100) return;
+  const int nzc = nz <= m.nlm1 ? nz : m.nlm1;
   double zt = 0.0, zv = 0.0;
-  for (int q = m.toy_bptr[b]; q < m.toy_bptr[b + 1]; q++) {
-    int e = m.toy_bidx[q];
-    if (nz > m.nlev[e] - 1) continue;
-    int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
-    zt = zt + ((DTR(m.tr_arr, nz, n1, 0) + DTR(m.tr_arr, nz, n2, 0)) + DTR(m.tr_arr, nz, n3, 0)) / 3.0;
-    zv = zv + DV2(m.UV, 1, nz, e);
+  constexpr int ZB = 8;
+  const int q0 = m.toy_bptr[b], q1 = m.toy_bptr[b + 1];
+  for (int qb = q0; qb < q1; qb += ZB) {
+    int e_l = 0, hi_l = 0, n1_l = 0, n2_l = 0, n3_l = 0;
+    if (l < ZB && qb + l < q1) {
+      e_l = m.toy_bidx[qb + l]; hi_l = m.nlev[e_l] - 1;
+      n1_l = m.elem_nodes[3 * e_l]; n2_l = m.elem_nodes[3 * e_l + 1]; n3_l = m.elem_nodes[3 * e_l + 2];
+    }
+    double t1[ZB], t2[ZB], t3[ZB], u[ZB];
+#pragma unroll
+    for (int k = 0; k < ZB; k++) {
+      t1[k] = DTR(m.tr_arr, nzc, rdlane(n1_l, k), 0); t2[k] = DTR(m.tr_arr, nzc, rdlane(n2_l, k), 0); t3[k] = DTR(m.tr_arr, nzc, rdlane(n3_l, k), 0);
+      u[k] = DV2(m.UV, 1, nzc, rdlane(e_l, k));
+    }
+#pragma unroll
+    for (int k = 0; k < ZB; k++) {
+      const bool on = qb + k < q1 && nz <= rdlane(hi_l, k);
+      const double nt = zt + ((t1[k] + t2[k]) + t3[k]) / 3.0, nv = zv + u[k];
+      zt = on ? nt : zt; zv = on ? nv : zv;
+    }
   }
-  double cnt = m.toy_znum[b];
-  m.toy_zvel[(size_t)b * m.nlm1 + nz - 1] = zv / (cnt + 0.001);
-  m.toy_ztem[(size_t)b * m.nlm1 + nz - 1] = zt / (cnt + 0.001);
-}
-
-// Partitioned runs: the rank-local sums (every element once: where its first node is owned, :167) first, then the host's / the
-// library's all-reduce over the ranks (the two MPI_AllREDUCE of :182-203), then the division by the global count.
-__global__ void __launch_bounds__(BLOCK) k_toy_zonal_sum(DM m) {
-  int b = col_id(m), nz = lane_id() + 1;
-  if (b >= 100 || nz > m.nlm1) return;
-  double zt = 0.0, zv = 0.0;
-  for (int q = m.toy_bptr[b]; q < m.toy_bptr[b + 1]; q++) {
-    int e = m.toy_bidx[q];
-    if (nz > m.nlev[e] - 1) continue;
-    int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
-    zt = zt + ((DTR(m.tr_arr, nz, n1, 0) + DTR(m.tr_arr, nz, n2, 0)) + DTR(m.tr_arr, nz, n3, 0)) / 3.0;
-    zv = zv + DV2(m.UV, 1, nz, e);
+  if (nz > m.nlm1) return;
+  if (DIVIDE) {
+    const double cnt = m.toy_znum[b];
+    zv = zv / (cnt + 0.001); zt = zt / (cnt + 0.001);
   }
   m.toy_zvel[(size_t)b * m.nlm1 + nz - 1] = zv;
   m.toy_ztem[(size_t)b * m.nlm1 + nz - 1] = zt;
 }
+__global__ void __launch_bounds__(BLOCK) k_toy_zonal_mean(DM m) { toy_zonal_bin<true>(m); }
+
+// Partitioned runs: the rank-local sums (every element once: where its first node is owned, :167) first, then the host's / the
+// library's all-reduce over the ranks (the two MPI_AllREDUCE of :182-203), then the division by the global count.
+__global__ void __launch_bounds__(BLOCK) k_toy_zonal_sum(DM m) { toy_zonal_bin<false>(m); }
 __global__ void __launch_bounds__(BLOCK) k_toy_zonal_div(DM m) {
   int b = col_id(m), nz = lane_id() + 1;
   if (b >= 100 || nz > m.nlm1) return;
