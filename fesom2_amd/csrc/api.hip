@@ -618,6 +618,23 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   F(UV, 2 * n1 * E); F(UV_rhs, 2 * n1 * E); F(UV_rhsAB, 2 * n1 * E); FT(tr_xy, 2 * n1 * EX); FT(tr_xy_ab, 2 * n1 * EX); F(U_b, 2 * n1 * E);
   F(pgf_x, n1 * E); F(pgf_y, n1 * E); F(helem, n1 * E); F(Av, nl * E); F(dhe, E);
   FT(adv_flux_hor, n1 * D); FT(adv_flux_raw, n1 * D); FT(flux_lo_hor, n1 * D); FT(diff_flux, n1 * D); FT(edge_up_dn_grad, 4 * n1 * D); F(edge_c12, D);
+  m.cl_grad = nullptr; m.cl_need = nullptr;
+  if (m.use_tile && !getenv("FESOM_GPU_NO_CLUSTER_GRAD")) {
+    // k_flux_hor<FUSED> forms fill_up_dn_grad on the fly; where the two upwind triangles of an edge do not cover a node's column (ragged bottom, boundary
+    // edges) it needs the cluster mean of the gradient at that node -- per NODE in k_cluster_grad instead of once per incident edge
+    std::vector<unsigned char> need(N, 0);
+    const int *ud = d->edge_up_dn_tri;
+    for (int e = 0; e < m.myD; e++) {
+      const int a = ed[2 * e], b = ed[2 * e + 1];
+      if (ud[2 * e] > 0 && ud[2 * e + 1] > 0) {
+        const int nzmin = std::max(d->ulevels_nod2D_max[a], d->ulevels_nod2D_max[b]), nzmax = std::min(d->nlevels_nod2D_min[a], d->nlevels_nod2D_min[b]);
+        if (nzmin > d->ulevels_nod2D[a] || nzmax - 1 < d->nlevels_nod2D[a] - 1) need[a] = 1;
+        if (nzmin > d->ulevels_nod2D[b] || nzmax - 1 < d->nlevels_nod2D[b] - 1) need[b] = 1;
+      } else { need[a] = 1; need[b] = 1; }
+    }
+    m.cl_need = dev_upload(need);
+    FT(cl_grad, 2 * n1 * N);
+  }
   F(ssh_values, m.nza);
   if (par->which_pgf == 0 && !(par->which_ale == 0 && !par->use_partial_cell)) { F(pgf_A, n1 * N); F(pgf_B, n1 * N); }      // shchepetkin variants
   if (par->visc_option <= 3) { F(Visc, n1 * E); F(leith_aux, n1 * N); }

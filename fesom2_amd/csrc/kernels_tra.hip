@@ -154,21 +154,65 @@ __device__ __forceinline__ UpdnIdx updn_index(const DM &m, int ed, int nz) {
   }
   return x;
 }
-__device__ __forceinline__ void updn_values(const DM &m, const TV &t, const UpdnIdx &x, int nz, double &g1, double &g2, double &g3, double &g4, bool &w1, bool &w2) {
+// PRE: the cluster means come from the node field of k_cluster_grad (CORE2-class meshes with a ragged bottom: every edge of a node would evaluate the
+// same mean again, 6 elements x 2 components per node and tracer) instead of being formed on the fly; the same values either way
+template <bool PRE = false>
+__device__ __forceinline__ void updn_values(const DM &m, const TV &t, int tr, const UpdnIdx &x, int nz, double &g1, double &g2, double &g3, double &g4, bool &w1, bool &w2) {
   w1 = false; w2 = false;      // write (1,3) / (2,4)
   g1 = g2 = g3 = g4 = 0.0;
   if (x.both) {
     g1 = DV2(t.tr_xy_ab, 1, nz, x.t1); g2 = DV2(t.tr_xy_ab, 1, nz, x.t2);
     g3 = DV2(t.tr_xy_ab, 2, nz, x.t1); g4 = DV2(t.tr_xy_ab, 2, nz, x.t2);
     w1 = w2 = true;
+  } else if (PRE) {
+    const double *cg = m.cl_grad + (size_t)tr * 2 * m.nlm1 * m.N;
+    if (x.c1) { g1 = DV2(cg, 1, nz, x.n1); g3 = DV2(cg, 2, nz, x.n1); w1 = true; }
+    if (x.c2) { g2 = DV2(cg, 1, nz, x.n2); g4 = DV2(cg, 2, nz, x.n2); w2 = true; }
   } else {
     if (x.c1) { cluster_grad(m, t, x.n1, nz, g1, g3); w1 = true; }
     if (x.c2) { cluster_grad(m, t, x.n2, nz, g2, g4); w2 = true; }
   }
 }
+// fill_up_dn_grad's cluster mean of the horizontal tracer gradient (src/oce_muscl_adv.F90:285-447: area-weighted mean over the elements of the node that
+// reach the level) as a node field, for the nodes some edge needs it for (DM::cl_need: where the two upwind triangles do not cover the node's column).
+// Lane-parallel element list, one batch of loads, the sums in element order: the same additions as cluster_grad().
+__global__ void __launch_bounds__(BLOCK) k_cluster_grad(DM m, int tr0) {
+  const int tr = tr0 + blockIdx.y;
+  const TV t = tracer_view(m, tr);
+  const int n = col_id(m), l = lane_id(), nz = l + 1;
+  if (n >= m.N) return;
+  if (!m.cl_need[n]) return;
+  const int num = m.nie_num[n], nzc = nz <= m.nlm1 ? nz : m.nlm1;
+  int el_l = 0, rg_l = 1;                          // level range of an element packed lo | hi << 8; (1, 0) = empty
+  double ar_l = 0.0;
+  if (l < num) { el_l = m.nie[(size_t)m.maxk * n + l]; rg_l = m.ulev[el_l] | ((m.nlev[el_l] - 1) << 8); ar_l = m.elem_area[el_l]; }
+  double tvol = 0.0, tx = 0.0, ty = 0.0;
+  constexpr int CB = 6;
+  for (int q0 = 0; q0 < num; q0 += CB) {
+    double gx[CB], gy[CB];
+#pragma unroll
+    for (int j = 0; j < CB; j++) {
+      const int el = rdlane(el_l, q0 + j < num ? q0 + j : 0);
+      gx[j] = DV2(t.tr_xy_ab, 1, nzc, el); gy[j] = DV2(t.tr_xy_ab, 2, nzc, el);
+    }
+#pragma unroll
+    for (int j = 0; j < CB; j++) {
+      if (q0 + j < num) {
+        const int rg = rdlane(rg_l, q0 + j);
+        const double ar = bcast(ar_l, q0 + j);
+        const bool on = nz >= (rg & 0xff) && nz <= (rg >> 8);
+        const double nv = tvol + ar, nx = tx + gx[j] * ar, ny = ty + gy[j] * ar;
+        tvol = on ? nv : tvol; tx = on ? nx : tx; ty = on ? ny : ty;
+      }
+    }
+  }
+  if (nz < m.ulev_n[n] || nz > m.nlev_n[n] - 1) return;
+  double *cg = m.cl_grad + (size_t)tr * 2 * m.nlm1 * m.N;
+  DV2(cg, 1, nz, n) = tx / tvol; DV2(cg, 2, nz, n) = ty / tvol;
+}
 __device__ __forceinline__ void updn_grad(const DM &m, const TV &t, int ed, int nz, double &g1, double &g2, double &g3, double &g4, bool &w1, bool &w2) {
   const UpdnIdx x = updn_index(m, ed, nz);
-  updn_values(m, t, x, nz, g1, g2, g3, g4, w1, w2);
+  updn_values<false>(m, t, 0, x, nz, g1, g2, g3, g4, w1, w2);
 }
 __global__ void __launch_bounds__(BLOCK) k_updn_grad(DM m, int tr0) {
   const int tr = tr0 + blockIdx.y;                        // grid.y = tracers of this launch
@@ -234,7 +278,8 @@ __global__ void __launch_bounds__(BLOCK) k_flux_hor(DM m, int tr0) {
   double g1, g2, g3, g4;
   if (FUSED) {
     bool w1, w2;
-    updn_grad(m, t, ed, nz, g1, g2, g3, g4, w1, w2);
+    if (m.cl_grad) { const UpdnIdx ux = updn_index(m, ed, nz); updn_values<true>(m, t, tr, ux, nz, g1, g2, g3, g4, w1, w2); }
+    else updn_grad(m, t, ed, nz, g1, g2, g3, g4, w1, w2);
     if (!w1) { g1 = DV4(t.edge_up_dn_grad, 1, nz, ed); g3 = DV4(t.edge_up_dn_grad, 3, nz, ed); }
     if (!w2) { g2 = DV4(t.edge_up_dn_grad, 2, nz, ed); g4 = DV4(t.edge_up_dn_grad, 4, nz, ed); }
   } else {
@@ -292,7 +337,8 @@ __global__ void __launch_bounds__(BLOCK) k_flux_hor_nt(DM m, int tr0) {
     if (hor == 2) continue;
     if (FUSED) {
       bool w1, w2;
-      updn_values(m, t, ux, nz, g1[q], g2[q], g3[q], g4[q], w1, w2);
+      if (m.cl_grad) updn_values<true>(m, t, tr, ux, nz, g1[q], g2[q], g3[q], g4[q], w1, w2);       // (wave-uniform: the node field of k_cluster_grad exists)
+      else updn_values<false>(m, t, tr, ux, nz, g1[q], g2[q], g3[q], g4[q], w1, w2);
       if (!w1) { g1[q] = DV4(t.edge_up_dn_grad, 1, nz, ed); g3[q] = DV4(t.edge_up_dn_grad, 3, nz, ed); }
       if (!w2) { g2[q] = DV4(t.edge_up_dn_grad, 2, nz, ed); g4[q] = DV4(t.edge_up_dn_grad, 4, nz, ed); }
     } else {
@@ -340,6 +386,7 @@ static void launch_flux_hor(const DM &m, hipStream_t s, int tr) {
   static const int env = getenv("FESOM_GPU_EXP_NT") ? atoi(getenv("FESOM_GPU_EXP_NT")) : -1;
   const bool nt2 = tr < 0 && m.ntr > 1 && (env >= 0 ? (env & 1) != 0 : true);
   const int nb = nblocks(SUBN(m, m.myD));
+  if (FUSED && m.cl_grad) hipLaunchKernelGGL(k_cluster_grad, dim3(nblocks(m.N), tr < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m, tr < 0 ? 0 : tr);
   if (nt2) hipLaunchKernelGGL((k_flux_hor_nt<FUSED, 2>), dim3(nb, (m.ntr + 1) / 2), dim3(BLOCK), 0, s, m, 0);
   else hipLaunchKernelGGL((k_flux_hor<FUSED>), dim3(nb, tr < 0 ? m.ntr : 1), dim3(BLOCK), 0, s, m, tr < 0 ? 0 : tr);
 }
