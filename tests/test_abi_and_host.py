@@ -203,3 +203,47 @@ def test_psolver_init_refuses_a_block_of_a_multi_rank_partition(tmp_path):
     for case, text in (("offset", "part[0] != 0"), ("global_cols", "column index outside"), ("rptr0", "rptr[0] must be 0")):
         r = subprocess.run([sys.executable, str(script), case], capture_output=True, text=True, timeout=120)
         assert r.returncode == 3 and text in r.stderr and "returned" not in r.stdout, (case, r.returncode, r.stderr[-400:])
+
+
+def test_psolve_mpi_adapter_compiles_against_the_header():
+    """fesom2_amd/fortran/fesom_gpu_psolve_mpi.c (the MPI host adapter of the distributed psolve) against include/fesom_gpu.h and an
+    mpi.h: it defines the reference's three entry points (src/psolve.c:16,117,152) and references only symbols the library exports."""
+    import shutil
+    mpi_inc = next((d for d in ("/opt/conda/include", "/usr/include/mpich", "/usr/include/x86_64-linux-gnu/mpich") if os.path.exists(os.path.join(d, "mpi.h"))), None)
+    if mpi_inc is None or shutil.which("gcc") is None:
+        pytest.skip("no mpi.h / gcc here")
+    src = os.path.join(REPO, "fesom2_amd", "fortran", "fesom_gpu_psolve_mpi.c")
+    obj = os.path.join(REPO, "fesom2_amd", "build", "psolve_mpi_check.o")
+    os.makedirs(os.path.dirname(obj), exist_ok=True)
+    r = subprocess.run(["gcc", "-O1", "-fPIC", "-I", mpi_inc, "-I", os.path.join(REPO, "include"), "-c", src, "-o", obj], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    nm = subprocess.run(["nm", obj], capture_output=True, text=True).stdout
+    for sym in ("psolver_init", "psolve", "psolver_final"):
+        assert f" T {sym}" in nm, sym
+    from fesom2_amd import _lib
+    wanted = {ln.split()[-1] for ln in nm.splitlines() if " U fesom_gpu_" in ln}
+    assert wanted and wanted <= set(_lib.EXPORTS), wanted - set(_lib.EXPORTS)
+
+
+def test_psolver_init_dist_validates_before_any_device_work(built):
+    """fesom_gpu_psolver_init_dist returns an error with a message (no exit: it has a status) for a rank outside the partition, a row block whose column is
+    neither owned nor in the halo list, a send-list entry outside the owned rows -- all checked before a device is touched."""
+    import ctypes as C
+    from fesom2_amd import _lib
+    lib = _lib.load()
+    lib.fesom_gpu_last_error.restype = C.c_char_p
+    I = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    part = I([0, 4, 8])
+    rptr = I([0, 2, 4, 6, 8]); cols = I([0, 1, 1, 2, 2, 3, 3, 4]); vals = np.array([2.0, -1.0] * 4)
+    rPE, rcnt, rglob, sPE, scnt, sloc = I([1]), I([1]), I([4]), I([1]), I([1]), I([0])
+    lib.fesom_gpu_psolver_init_dist.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_double] + [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] * 2 + [C.c_void_p]
+
+    def call(npes=2, mype=0, cols_=cols, rglob_=rglob, sloc_=sloc):
+        return lib.fesom_gpu_psolver_init_dist(npes, mype, P(part), P(rptr), P(cols_), P(vals), 100, 1e-10, 1, P(rPE), P(rcnt), P(rglob_), 1, P(sPE), P(scnt), P(sloc_), None)
+    assert call(npes=1) != 0 and b"npes >= 2" in lib.fesom_gpu_last_error()
+    assert call(mype=5) != 0 and b"mype" in lib.fesom_gpu_last_error()
+    assert call(rglob_=I([5])) != 0 and b"neither owned nor in the halo list" in lib.fesom_gpu_last_error()
+    assert call(sloc_=I([9])) != 0 and b"send list entry outside" in lib.fesom_gpu_last_error()
+    bad = cols.copy(); bad[0] = 1; bad[1] = 0
+    assert call(cols_=bad) != 0 and b"diagonal" in lib.fesom_gpu_last_error()
