@@ -93,16 +93,16 @@ __global__ void __launch_bounds__(DSB) k_ras_init(DM m, int NP, int nblk) {     
   ds_block_partials<1>(s, m.sv_part, nblk);
 }
 template <int W>
-__global__ void __launch_bounds__(DSB) k_ras_spmv1(DM m, int NP, int nblk) {    // v = A_s p^ ; partial r0.v
-  if (RAS_FINISHED(m)) return;
+__global__ void __launch_bounds__(DSB) k_ras_spmv1(DM m, int NP, int nblk, int bank) {    // v = A_s p^ ; partial r0.v
+  if (m.sv_kry[bank + 8] != 0.0) return;
   const int q = blockIdx.x * DSB + threadIdx.x;
   double s[1] = {0.0};
   if (q < m.myN) { const double a = ras_row<W>(m, NP, q, m.sv_ph); m.sv_v[q] = a; s[0] = m.sv_r0[q] * a; }
   ds_block_partials<1>(s, m.sv_part, nblk);
 }
 template <int W>
-__global__ void __launch_bounds__(DSB) k_ras_spmv2(DM m, int NP, int nblk) {    // t = A_s s^ ; partial t.t, t.s, r0.t, s.s
-  if (RAS_FINISHED(m)) return;
+__global__ void __launch_bounds__(DSB) k_ras_spmv2(DM m, int NP, int nblk, int bank) {    // t = A_s s^ ; partial t.t, t.s, r0.t, s.s
+  if (m.sv_kry[bank + 8] != 0.0) return;
   const int q = blockIdx.x * DSB + threadIdx.x;
   double s[4] = {0.0, 0.0, 0.0, 0.0};
   if (q < m.myN) {
@@ -169,11 +169,47 @@ __global__ void __launch_bounds__(DSB) k_ras_update(DM m) {      // x += alpha p
   m.sv_x[q] = (m.sv_x[q] + alpha * m.sv_ph[q]) + omega * m.sv_sh[q];
   if (more) m.sv_pd[q] = ri + beta * (m.sv_pd[q] - omega * m.sv_v[q]);
 }
-__global__ void __launch_bounds__(DSB) k_ras_finish(DM m) {      // back to the natural order
+// Single partition, fused form of one iteration (5 launches instead of 7): no one-workgroup kernels between the products.  Every workgroup of a consumer
+// sums the block partials of its producer itself, in the order of dm_sum_blocks, and forms the Krylov scalars locally (the same operations on the same
+// values in every workgroup: the same bits); workgroup 0 also stores them.  The scalar state ping-pongs between two banks of sv_kry (bank = 16 * (iteration
+// & 1)): a kernel reads the bank of its iteration and writes only the other one (k_ras_update_f) or a slot nobody reads in that kernel (alpha, k_ras_apply
+// MODE 1), so no workgroup sees a value change under its feet without any fence -- kernel boundaries order everything.  Slot 8 (no further iteration
+// wanted) travels with the bank: iterations enqueued behind the convergence only copy the bank forward.
+__global__ void __launch_bounds__(DSB) k_ras_update_f(DM m, int nblk, int bank, double tol2, int maxits) {
+  __shared__ double sh[4][DSB];
+  const double *kc = m.sv_kry + bank;
+  double *kn = m.sv_kry + (16 - bank);
+  if (kc[8] != 0.0) {                                           // converged earlier: the state moves on unchanged
+    if (blockIdx.x == 0 && threadIdx.x < 16) kn[threadIdx.x] = kc[threadIdx.x];
+    return;
+  }
+  double sums[4];
+  dm_sum_blocks4(m.sv_part, nblk, sh, sums);
+  const double tt = sums[0], ts = sums[1], r0t = sums[2], ss = sums[3];
+  const double alpha = kc[0];
+  const double omega = (tt > 0.0) ? ts / tt : 0.0;
+  const double rho = kc[4], rho_new = -omega * r0t;
+  const double rr = ss - omega * (2.0 * ts - omega * tt);
+  const double it = kc[6] + 1.0;
+  const bool more = (rr >= tol2 && it < (double)maxits);
+  const double beta = more ? (rho_new / rho) * (alpha / omega) : 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    kn[0] = alpha; kn[1] = omega; kn[2] = beta; kn[3] = rho; kn[4] = rho_new; kn[5] = rr; kn[6] = it; kn[7] = more ? 0.0 : 1.0; kn[8] = more ? 0.0 : 1.0;
+    m.sv_red[0] = tt; m.sv_red[1] = ts; m.sv_red[2] = r0t; m.sv_red[3] = ss;
+  }
+  const int q = blockIdx.x * DSB + threadIdx.x;
+  if (q >= m.myN) return;
+  const double si = m.sv_sn[q], ri = si - omega * m.sv_t[q];
+  m.sv_r[q] = ri;
+  m.sv_x[q] = (m.sv_x[q] + alpha * m.sv_ph[q]) + omega * m.sv_sh[q];
+  if (more) m.sv_pd[q] = ri + beta * (m.sv_pd[q] - omega * m.sv_v[q]);
+}
+__global__ void __launch_bounds__(DSB) k_ras_finish(DM m, int bank) {      // back to the natural order
   const int q = blockIdx.x * DSB + threadIdx.x;
   if (q < m.myN) m.d_eta[m.rs_perm[q]] = m.sv_x[q];
   if (q == 0) {
-    m.sv_info[0] = (int)m.sv_kry[6]; m.sv_resid[0] = sqrt(m.sv_kry[5] > 0.0 ? m.sv_kry[5] : 0.0);
+    const double *kc = m.sv_kry + bank;
+    m.sv_info[0] = (int)kc[6]; m.sv_resid[0] = sqrt(kc[5] > 0.0 ? kc[5] : 0.0);
     if (m.sv_extrap && m.sv_info[1] < 3) m.sv_info[1] = m.sv_info[1] + 1;
   }
 }
@@ -184,13 +220,26 @@ __global__ void __launch_bounds__(DSB) k_ras_finish(DM m) {      // back to the 
 // Thread t owns the rows t, t + 512, ...: their entries (fp32) and packed LDS byte offsets stay in registers, z ping-pongs between two
 // LDS images, one barrier per step.
 template <int WOFF, int RPT, int MODE>
-__global__ void __launch_bounds__(RAS_THREADS) k_ras_apply(DM m) {
-  if (RAS_FINISHED(m)) return;
+__global__ void __launch_bounds__(RAS_THREADS) k_ras_apply(DM m, int bank, int fused_nblk) {
+  if (m.sv_kry[bank + 8] != 0.0) return;
   constexpr int NS = RAS_THREADS * RPT;
   __shared__ double zb0[NS], zb1[NS];                      // two images of z: a step reads one and writes the other, one barrier per step
   const int p = blockIdx.x, t = threadIdx.x;
   const int own0 = m.rs_pinfo[4 * p], no = m.rs_pinfo[4 * p + 1], eoff = m.rs_pinfo[4 * p + 2], ne = m.rs_pinfo[4 * p + 3];
-  const double alpha = MODE ? m.sv_kry[0] : 0.0;
+  double alpha = MODE ? m.sv_kry[bank] : 0.0;
+  if (MODE == 1 && fused_nblk > 0) {                       // fused form: alpha = rho / (r0 . v) from the block partials of k_ras_spmv1, summed in the order of dm_sum_blocks
+    double a = 0.0;
+    if (t < DSB) { for (int b = t; b < fused_nblk; b += DSB) a = a + m.sv_part[b]; zb0[t] = a; }
+    __syncthreads();
+    for (int s2 = DSB / 2; s2 >= 1; s2 >>= 1) {
+      if (t < s2) zb0[t] = zb0[t] + zb0[t + s2];
+      __syncthreads();
+    }
+    const double tot = zb0[0];
+    __syncthreads();
+    alpha = m.sv_kry[bank + 4] / tot;
+    if (p == 0 && t == 0) { m.sv_kry[bank] = alpha; m.sv_red[0] = tot; }       // (slot 0 is read by the update kernel only)
+  }
   const double inv_theta = m.rs_cheb[0];
   double lv[RPT][WOFF];                                    // (fp32 in memory; widened once: a conversion per use would cost more than the multiply)
   unsigned lo[RPT][WOFF];                                  // LDS byte offsets of the columns
@@ -245,8 +294,8 @@ __global__ void __launch_bounds__(RAS_THREADS) k_ras_apply(DM m) {
 
 namespace {
 template <int MODE>
-void launch_apply(const DM &m, hipStream_t s) {
-#define RA(WO, RP) hipLaunchKernelGGL((k_ras_apply<WO, RP, MODE>), dim3(m.rs_P), dim3(RAS_THREADS), 0, s, m)
+void launch_apply(const DM &m, hipStream_t s, int bank = 0, int fused_nblk = 0) {
+#define RA(WO, RP) hipLaunchKernelGGL((k_ras_apply<WO, RP, MODE>), dim3(m.rs_P), dim3(RAS_THREADS), 0, s, m, bank, fused_nblk)
 #define RW(RP) do { if (m.rs_woff == 6) RA(6, RP); else if (m.rs_woff == 9) RA(9, RP); else RA(15, RP); } while (0)
   if (m.rs_rpt == 2) RW(2); else if (m.rs_rpt == 3) RW(3); else RW(4);
 #undef RW
@@ -263,12 +312,21 @@ Shape shape_of(const DM &m) {
 #define RASW(k, grid, blk, ...) do { if (sh.W == 8) hipLaunchKernelGGL(k<8>, grid, blk, 0, s, __VA_ARGS__); else if (sh.W == 10) hipLaunchKernelGGL(k<10>, grid, blk, 0, s, __VA_ARGS__); else hipLaunchKernelGGL(k<16>, grid, blk, 0, s, __VA_ARGS__); } while (0)
 
 // one BiCGstab iteration on a single partition: 7 launches, nothing read back
-static void ras_iteration(const DM &m, hipStream_t s, const Shape &sh) {
+static void ras_iteration(const DM &m, hipStream_t s, const Shape &sh, int it_idx, bool fused) {
+  if (fused) {       // 5 launches, the scalar state in bank 16 * (it_idx & 1)
+    const int bank = 16 * (it_idx & 1);
+    launch_apply<0>(m, s, bank, 0);
+    RASW(k_ras_spmv1, dim3(sh.nblk), dim3(DSB), m, sh.NP, sh.nblk, bank);
+    launch_apply<1>(m, s, bank, sh.nblk);
+    RASW(k_ras_spmv2, dim3(sh.nblk), dim3(DSB), m, sh.NP, sh.nblk, bank);
+    hipLaunchKernelGGL(k_ras_update_f, dim3(sh.nblk), dim3(DSB), 0, s, m, sh.nblk, bank, sh.tol2, sh.maxits);
+    return;
+  }
   launch_apply<0>(m, s);
-  RASW(k_ras_spmv1, dim3(sh.nblk), dim3(DSB), m, sh.NP, sh.nblk);
+  RASW(k_ras_spmv1, dim3(sh.nblk), dim3(DSB), m, sh.NP, sh.nblk, 0);
   hipLaunchKernelGGL((k_ras_red<1, 1, true>), dim3(1), dim3(DSB), 0, s, m, sh.nblk, sh.tol2, sh.maxits);
   launch_apply<1>(m, s);
-  RASW(k_ras_spmv2, dim3(sh.nblk), dim3(DSB), m, sh.NP, sh.nblk);
+  RASW(k_ras_spmv2, dim3(sh.nblk), dim3(DSB), m, sh.NP, sh.nblk, 0);
   hipLaunchKernelGGL((k_ras_red<4, 2, true>), dim3(1), dim3(DSB), 0, s, m, sh.nblk, sh.tol2, sh.maxits);
   hipLaunchKernelGGL(k_ras_update, dim3(sh.nblk), dim3(DSB), 0, s, m);
 }
@@ -284,18 +342,21 @@ int launch_solver_ras(const DM &m, hipStream_t s, int fuse_rhs, int scale_done) 
   hipLaunchKernelGGL((k_ras_red<1, 0, true>), dim3(1), dim3(DSB), 0, s, m, sh.nblk, sh.tol2, sh.maxits);
   static double *hk = nullptr;                                   // pinned copy of the scalar state
   static int last_its = 14;
-  if (!hk && hipHostMalloc((void **)&hk, 16 * sizeof(double)) != hipSuccess) return 1;
+  if (!hk && hipHostMalloc((void **)&hk, 32 * sizeof(double)) != hipSuccess) return 1;
+  static const bool fused = !getenv("FESOM_GPU_RAS_UNFUSED");     // (the 7-launch iteration with its two one-workgroup reduction kernels, for comparison)
   int total = 0, chunk = last_its + 2;
+  const double *cur = hk;
   for (;;) {
-    for (int k = 0; k < chunk; k++) ras_iteration(m, s, sh);
+    for (int k = 0; k < chunk; k++) ras_iteration(m, s, sh, total + k, fused);
     total += chunk;
-    if (hipMemcpyAsync(hk, m.sv_kry, 16 * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
+    if (hipMemcpyAsync(hk, m.sv_kry, 32 * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
     if (hipStreamSynchronize(s) != hipSuccess) return 1;
-    if (hk[8] != 0.0 || total >= sh.maxits) break;
+    cur = hk + (fused ? 16 * (total & 1) : 0);                    // the bank the last enqueued iteration wrote
+    if (cur[8] != 0.0 || total >= sh.maxits) break;
     chunk = 3;
   }
-  last_its = (int)hk[6];
-  hipLaunchKernelGGL(k_ras_finish, dim3(sh.nblk), dim3(DSB), 0, s, m);
+  last_its = (int)cur[6];
+  hipLaunchKernelGGL(k_ras_finish, dim3(sh.nblk), dim3(DSB), 0, s, m, fused ? 16 * (total & 1) : 0);
   return 0;
 }
 
@@ -316,17 +377,17 @@ int launch_named_ras(const DM &m, hipStream_t s, const char *name) {
   if (!strcmp(name, "dsr_prec0") || !strcmp(name, "ras_apply0")) { launch_apply<0>(m, s); return 0; }
   if (!strcmp(name, "dsr_prec1") || !strcmp(name, "ras_apply1")) { launch_apply<1>(m, s); return 0; }
   if (!strcmp(name, "dsr_spmv1")) {
-    RASW(k_ras_spmv1, dim3(sh.nblk), dim3(DSB), m, sh.NP, sh.nblk);
+    RASW(k_ras_spmv1, dim3(sh.nblk), dim3(DSB), m, sh.NP, sh.nblk, 0);
     hipLaunchKernelGGL((k_ras_red<1, 1, false>), dim3(1), dim3(DSB), 0, s, m, sh.nblk, sh.tol2, sh.maxits); return 0;
   }
   if (!strcmp(name, "dsr_spmv2")) {
-    RASW(k_ras_spmv2, dim3(sh.nblk), dim3(DSB), m, sh.NP, sh.nblk);
+    RASW(k_ras_spmv2, dim3(sh.nblk), dim3(DSB), m, sh.NP, sh.nblk, 0);
     hipLaunchKernelGGL((k_ras_red<4, 2, false>), dim3(1), dim3(DSB), 0, s, m, sh.nblk, sh.tol2, sh.maxits); return 0;
   }
   if (!strcmp(name, "dsr_update")) { hipLaunchKernelGGL(k_ras_update, dim3(sh.nblk), dim3(DSB), 0, s, m); return 0; }
-  if (!strcmp(name, "dsr_finish")) { hipLaunchKernelGGL(k_ras_finish, dim3(sh.nblk), dim3(DSB), 0, s, m); return 0; }
-  if (!strcmp(name, "ras_spmv1")) { RASW(k_ras_spmv1, dim3(sh.nblk), dim3(DSB), m, sh.NP, sh.nblk); return 0; }
-  if (!strcmp(name, "ras_spmv2")) { RASW(k_ras_spmv2, dim3(sh.nblk), dim3(DSB), m, sh.NP, sh.nblk); return 0; }
+  if (!strcmp(name, "dsr_finish")) { hipLaunchKernelGGL(k_ras_finish, dim3(sh.nblk), dim3(DSB), 0, s, m, 0); return 0; }
+  if (!strcmp(name, "ras_spmv1")) { RASW(k_ras_spmv1, dim3(sh.nblk), dim3(DSB), m, sh.NP, sh.nblk, 0); return 0; }
+  if (!strcmp(name, "ras_spmv2")) { RASW(k_ras_spmv2, dim3(sh.nblk), dim3(DSB), m, sh.NP, sh.nblk, 0); return 0; }
   if (!strcmp(name, "ras_arm")) { hipMemsetAsync(m.sv_kry + 7, 0, 2 * sizeof(double), s); return 0; }      // timing: clear the flags a finished solve leaves
   return -1;
 }
