@@ -50,20 +50,24 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 
 KERNEL_VALUES = {
     "k_vel_nodes": (2, 2, 0), "k_pressure_bv": (8, 0, 0), "k_pgf": (2, 3, 0), "k_sigma_slope": (13, 0, 0),
     "k_pp": (5, 1, 0), "k_momadv_node": (5, 2, 0),
-    "k_vel_rhs": (2, 10, 0), "k_visc_elem": (0, 4, 0), "k_visc_node": (2, 2, 0), "k_impl_visc": (3, 13, 0),
+    "k_vel_rhs": (2, 10, 0), "k_visc_elem": (0, 4, 0), "k_visc_node": (2, 2, 0), "k_impl_visc": (3, 10, 0),     # (round 3: 13 E3 still counted the scratch arrays of the separate Thomas kernel of round 1)
     "k_edge_transport": (0, 5, 0), "k_edge_transport1": (0, 3, 0), "k_update_vel": (0, 6, 0), "k_vert_vel_hbar": (8, 3, 0),
     "k_tr_ab": (3, 0, 0), "k_tr_z": (3, 0, 0), "k_tr_grad_elem": (2, 4, 0), "k_updn_grad": (0, 2, 4), "k_flux_hor": (2, 3, 6),
-    "k_fct_lo_node": (12, 0, 1), "k_fct_node": (10, 0, 1), "k_tr_update": (18, 0, 2), "k_diff_flux": (2, 6, 1),
+    "k_fct_lo_node": (12, 0, 1), "k_fct_node": (10, 0, 1), "k_tr_update": (18, 0, 2), "k_diff_flux": (0, 2, 1),     # k_diff_flux per tracer: tr_xy (2 E3) read, diff_flux written; + SHARED_ONCE
     "k_thick": (5, 1, 0), "k_dhe": (0, 0, 0),
     # KPP (kernels_kpp.hip), GM / Redi (kernels_gm.hip)
     "k_kpp_col": (15, 0, 0), "k_kpp_smooth1": (6, 0, 0), "k_kpp_smooth2": (6, 0, 0), "k_kpp_smooth3": (6, 0, 0), "k_kpp_final": (10, 0, 0),
-    "k_kpp_elem": (1, 1, 0), "k_kpp_final_elem": (11, 1, 0), "k_gm_coef": (6, 0, 0), "k_fer_gamma": (8, 0, 0), "k_fer_uv": (2, 3, 0), "k_fer_wvel": (2, 3, 0),
+    "k_kpp_elem": (1, 1, 0), "k_kpp_final_elem": (10, 1, 0), "k_gm_coef": (4, 0, 0),     # (k_gm_coef: bvfreq, zbar_3d_n read, fer_K, Ki written) "k_fer_gamma": (8, 0, 0), "k_fer_uv": (2, 3, 0), "k_fer_wvel": (2, 3, 0),
     "bolus_add": (3, 6, 0), "bolus_remove": (3, 6, 0),
     "k_toy_relax_vel": (0, 3, 0), "k_toy_relax_temp": (3, 0, 0),
     "k_flux_hor_fused": (2, 5, 2),          # fill_up_dn_grad on the fly: tr_xy_ab instead of edge_up_dn_grad (CORE2-class meshes)
 }
 PER_TRACER = ("k_tr_ab", "k_tr_z", "k_tr_grad_elem", "k_updn_grad", "k_flux_hor", "k_flux_hor_fused", "k_fct_lo_node", "k_fct_node", "k_tr_update", "k_diff_flux")
-REDI_EXTRA = {"k_tr_update": (24, 2, 2), "k_diff_flux": (10, 6, 1)}     # slope_tapered (3), Ki, tr_z, tr_xy cluster means on top
+REDI_EXTRA = {"k_tr_update": (24, 2, 2), "k_diff_flux": (1, 2, 1)}     # slope_tapered (3), Ki, tr_z, tr_xy cluster means on top (k_diff_flux per tracer: + tr_z)
+# arrays a launch over all tracers reads ONCE (round 3: the audit against the PMC traffic of the CORE2-class meshes showed k_diff_flux doubling them with the tracers):
+# k_diff_flux: Ki at the nodes, helem; with Redi also slope_tapered (3) and hnode_new
+SHARED_ONCE = {"k_diff_flux": (1, 1, 0)}
+SHARED_ONCE_REDI = {"k_diff_flux": (5, 1, 0)}
 
 
 def step_kernels(p, tile=False):
@@ -110,6 +114,8 @@ def kernel_table(core, mesh, wl):
         # per-tracer kernels: timed as the step launches them, T and S in one launch (grid.y = 2)
         times[k] = core.kernel_time_ms(name + (":all" if k in PER_TRACER else ""), 10 if big else 50) * 1e-3
         kbytes[k] = 8.0 * (a * N3 + b * E3 + c * D3) * (2 if k in PER_TRACER else 1)
+        sa, sb, sc = (SHARED_ONCE_REDI if p.Redi else SHARED_ONCE).get(k, (0, 0, 0))
+        kbytes[k] += 8.0 * (sa * N3 + sb * E3 + sc * D3)
     mult = {}
     for k in step_kernels(p, tile):
         mult[k] = mult.get(k, 0) + 1
@@ -166,7 +172,7 @@ def audit_byte_table(times, kbytes, workload_key, redi):
     above_pmc = {}
     for k in kbytes:
         tr, _ = pmc_traffic(k, workload_key, redi)
-        if tr and kbytes[k] > 1.02 * tr:
+        if tr and kbytes[k] > 1.08 * tr:      # (8 %: arrays dimensioned nl against wet cells counted over nl - 1 layers, writes that only happen inside the boundary layer)
             above_pmc[k] = {"algorithmic": kbytes[k], "pmc": tr}
     return {"over_hbm_peak": over, "algorithmic_above_pmc": above_pmc, "ok": not over and not above_pmc}
 
