@@ -55,9 +55,9 @@ KERNEL_VALUES = {
     "k_tr_ab": (3, 0, 0), "k_tr_z": (3, 0, 0), "k_tr_grad_elem": (2, 4, 0), "k_updn_grad": (0, 2, 4), "k_flux_hor": (2, 3, 6),
     "k_fct_lo_node": (12, 0, 1), "k_fct_node": (10, 0, 1), "k_tr_update": (18, 0, 2), "k_diff_flux": (0, 2, 1),     # k_diff_flux per tracer: tr_xy (2 E3) read, diff_flux written; + SHARED_ONCE
     "k_thick": (5, 1, 0), "k_dhe": (0, 0, 0),
-    # KPP (kernels_kpp.hip), GM / Redi (kernels_gm.hip)
+    # KPP (kernels_kpp.hip), GM / Redi (kernels_gm.hip); k_gm_coef: bvfreq, zbar_3d_n read, fer_K, Ki written
     "k_kpp_col": (15, 0, 0), "k_kpp_smooth1": (6, 0, 0), "k_kpp_smooth2": (6, 0, 0), "k_kpp_smooth3": (6, 0, 0), "k_kpp_final": (10, 0, 0),
-    "k_kpp_elem": (1, 1, 0), "k_kpp_final_elem": (10, 1, 0), "k_gm_coef": (4, 0, 0),     # (k_gm_coef: bvfreq, zbar_3d_n read, fer_K, Ki written) "k_fer_gamma": (8, 0, 0), "k_fer_uv": (2, 3, 0), "k_fer_wvel": (2, 3, 0),
+    "k_kpp_elem": (1, 1, 0), "k_kpp_final_elem": (10, 1, 0), "k_gm_coef": (4, 0, 0), "k_fer_gamma": (8, 0, 0), "k_fer_uv": (2, 3, 0), "k_fer_wvel": (2, 3, 0),
     "bolus_add": (3, 6, 0), "bolus_remove": (3, 6, 0),
     "k_toy_relax_vel": (0, 3, 0), "k_toy_relax_temp": (3, 0, 0),
     "k_flux_hor_fused": (2, 5, 2),          # fill_up_dn_grad on the fly: tr_xy_ab instead of edge_up_dn_grad (CORE2-class meshes)

@@ -10,6 +10,7 @@ sys.path.insert(0, REPO)
 from fesom2_amd import workloads, parallel
 from fesom2_amd.core import OceanCore
 
+MAKE = workloads.basin if os.environ.get("CHAN_WORKLOAD") == "basin" else workloads.channel      # basin: the same geometry with bathymetry and the default physics
 LEVELS = int(os.environ.get("CHAN_LEVELS", "1"))
 NSTEPS = int(os.environ.get("CHAN_NSTEPS", "12"))
 
@@ -18,9 +19,9 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     if rank == 0:
-        workloads.channel(LEVELS, workdir=os.environ.get("CHAN_WORKDIR"))
+        MAKE(LEVELS, workdir=os.environ.get("CHAN_WORKDIR"))
     dist.barrier()
-    wl = workloads.channel(LEVELS, workdir=os.environ.get("CHAN_WORKDIR"))
+    wl = MAKE(LEVELS, workdir=os.environ.get("CHAN_WORKDIR"))
     gm = wl.load_mesh()
     g = OceanCore(gm, wl.params()); wl.start(g, gm)
     g.run_steps(1, NSTEPS)

@@ -247,3 +247,22 @@ def test_psolver_init_dist_validates_before_any_device_work(built):
     assert call(sloc_=I([9])) != 0 and b"send list entry outside" in lib.fesom_gpu_last_error()
     bad = cols.copy(); bad[0] = 1; bad[1] = 0
     assert call(cols_=bad) != 0 and b"diagonal" in lib.fesom_gpu_last_error()
+
+
+def test_bench_byte_table_covers_every_kernel_of_the_step():
+    """bench.py: every kernel step_kernels() lists for an option set has an entry in KERNEL_VALUES (a missing entry would only show on the GPU box)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+
+    class P:
+        pass
+    for mix, gm, redi, toy, visc in ((1, 1, 1, 0, 5), (1, 1, 0, 0, 5), (1, 0, 1, 0, 5), (2, 0, 0, 0, 5), (2, 0, 0, 1, 5), (2, 0, 0, 0, 7)):
+        p = P()
+        p.mix_scheme, p.Fer_GM, p.Redi, p.toy_soufflet, p.visc_option = mix, gm, redi, toy, visc
+        for tile in (False, True):
+            for k in b.step_kernels(p, tile):
+                assert k in b.KERNEL_VALUES, k
+    for k in b.PER_TRACER + tuple(b.REDI_EXTRA) + tuple(b.SHARED_ONCE) + tuple(b.SHARED_ONCE_REDI):
+        assert k in b.KERNEL_VALUES, k

@@ -86,3 +86,23 @@ def test_partitioned_channel(built, tmp_path, transport):
         assert rep["d_eta"] < 5e-8 and rep["d_T"] < 2e-9 and rep["d_UV"] < 2e-9, rep
         assert rep["eta_range"][1] - rep["eta_range"][0] > 1e-3, rep          # the jet really evolves
         assert rep["owned"] > 4096
+
+
+def test_partitioned_basin_default_physics(built, tmp_path):
+    """The default-physics CORE2-class workload partitioned (what `bench.py --gpus N` reports as large_mesh_partitioned, at refinement level 1: 11 450 nodes
+    with bathymetry, JM EOS, KPP + GM + Redi): 2 ranks sharing the GPU through the built-in transport (stand-in librccl), coordinate bisection of the host mesh
+    layer, merged exchange points, interior / boundary split, RAS-Chebyshev on each rank's block.  Owned values agree with the single-partition run of the
+    same 8 steps to the solver tolerance."""
+    fake = os.path.join(REPO, "tests", "helpers", "libfake_rccl.so")
+    assert os.path.exists(fake)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", FESOM_GPU_DEVICE="0", CHAN_LEVELS="1", CHAN_NSTEPS="8", CHAN_WORKDIR=str(tmp_path), CHAN_WORKLOAD="basin",
+               FESOM_GPU_RCCL_LIB=fake, PART_TRANSPORT="rccl")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29793", os.path.join(REPO, "tests", "helpers", "partitioned_channel_worker.py")],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    reps = [json.loads(x) for x in re.findall(r"CHANREPORT (\{.*\})", r.stdout)]
+    assert len(reps) == 2
+    for rep in reps:
+        assert rep["d_eta"] < 5e-8 and rep["d_T"] < 2e-9 and rep["d_UV"] < 2e-9, rep
+        assert rep["owned"] > 4096 and rep["iters"][1] < 40, rep
