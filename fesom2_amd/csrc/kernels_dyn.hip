@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(BLOCK) k_pgf(DM m) {
 // reference; in k_pgf all 64 lanes of a wave step through them for ONE element (2 DPP moves + 1 add per level and sum: what that kernel's time is
 // made of).  Here a wave takes PG_ELEMS elements: per-level terms go through a wave-private LDS image [level][element], lane = element runs the
 // chains of all its elements at once, the results go back through the image (in place).
-#define PG_ELEMS 16
+#define PG_ELEMS 8                      // (measured on the 182 600-node meshes: 16 elements per wave 484 us, 8: 400 us, 4: 424 us -- the LDS images of a wave bound the occupancy)
 #define PG_CP (PG_ELEMS + 1)
 __global__ void __launch_bounds__(BLOCK) k_pgf_tile(DM m) {
   extern __shared__ double pg_sh[];
