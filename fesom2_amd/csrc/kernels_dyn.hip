@@ -1305,7 +1305,7 @@ __global__ void __launch_bounds__(BLOCK) k_edge_transport(DM m, int mode) {
 // all 64 lanes of a wave run the same 2 x (nl-1)-step chain for ONE edge.  Here a wave takes ET_EDGES edges: their per-level
 // terms go through a wave-private LDS image [t1 | t2][level][edge], then lane = edge runs the two chains for all its edges at
 // once (levels outside an element's range hold +0.0: c + 0.0 == c, c - 0.0 == c for the running sums, which are never -0).
-#define ET_EDGES 16
+#define ET_EDGES 4                      // (measured on the 182 600-node meshes, k_edge_transport(0) / (1): 16 edges per wave 286 / 229 us, 8: 225 / 174, 4: 198 / 151, 2: 240 / 206)
 #define ET_CP (ET_EDGES + 1)
 __global__ void __launch_bounds__(BLOCK) k_edge_transport_tile(DM m, int mode) {
   extern __shared__ double et_sh[];
