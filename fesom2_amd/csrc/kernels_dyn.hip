@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(BLOCK) k_pgf_tile(DM m) {
 }
 static void launch_pgf(const DM &m, hipStream_t s) {
   const bool shch = m.p.which_pgf == 0 && !(m.p.which_ale == 0 && !m.p.use_partial_cell);      // (cubicspline / nemo: k_pgf)
-  if (m.use_tile && shch) {
+  if (m.use_tile && shch) {                    // (on pi the tile shape is slower: 21.7 against 11.6 us)
     const int per_block = COLS_PER_BLOCK * PG_ELEMS;
     hipLaunchKernelGGL(k_pgf_tile, dim3((m.myE + per_block - 1) / per_block), dim3(BLOCK), (size_t)COLS_PER_BLOCK * 2 * m.nlm1 * PG_CP * sizeof(double), s, m);
   } else hipLaunchKernelGGL(k_pgf, dim3(nblocks(m.myE)), dim3(BLOCK), 0, s, m);
@@ -1348,7 +1348,10 @@ __global__ void __launch_bounds__(BLOCK) k_edge_transport_tile(DM m, int mode) {
   if (l < ET_EDGES && base + l < m.myD) m.edge_c12[base + l] = c1 + c2;
 }
 static void launch_edge_transport(const DM &m, hipStream_t s, int mode) {
-  if (m.use_tile) {
+  // the several-edges-per-wave shape on every mesh (round 3: with 4 edges per wave it wins on pi as well, 10.6 -> 6.4 us and 10.2 -> 5.8 us for the two calls of a
+  // step; FESOM_GPU_EXP_ET_TILE=0 keeps one edge per wave)
+  static const int env = getenv("FESOM_GPU_EXP_ET_TILE") ? atoi(getenv("FESOM_GPU_EXP_ET_TILE")) : -1;
+  if (env >= 0 ? env != 0 : true) {
     const int per_block = COLS_PER_BLOCK * ET_EDGES;
     hipLaunchKernelGGL(k_edge_transport_tile, dim3((m.myD + per_block - 1) / per_block), dim3(BLOCK), (size_t)COLS_PER_BLOCK * 2 * m.nlm1 * ET_CP * sizeof(double), s, m, mode);
   } else hipLaunchKernelGGL(k_edge_transport, dim3(nblocks(m.myD)), dim3(BLOCK), 0, s, m, mode);
