@@ -1226,7 +1226,7 @@ __global__ void __launch_bounds__(WAVE * WAVES) k_impl_visc(DM m, int apply_visc
 #define IV_SHAPE(id, C_, W_) case id: hipLaunchKernelGGL((k_impl_visc<C_, W_>), dim3((m.myE + C_ - 1) / C_), dim3(WAVE * W_), (ThTile<2, C_>::lds_bytes(m.nlm1)), s, m, av, di); break;
 static void launch_impl_visc(const DM &m, hipStream_t s, int av, int di) {
   static const int env = getenv("FESOM_GPU_EXP_IV_SHAPE") ? atoi(getenv("FESOM_GPU_EXP_IV_SHAPE")) : 0;      // (experiments: 5 = 16 columns x 8 waves, 6 = 16 x 4)
-  switch (m.use_tile && env > 0 ? env : m.use_tile) {
+  switch (env > 0 ? env : m.use_tile) {
     TILE_SHAPES(IV_SHAPE) IV_SHAPE(5, 16, 8) IV_SHAPE(6, 16, 4)
     default: hipLaunchKernelGGL((k_impl_visc<TH_COLS, TH_COLS>), dim3(nblocks_th(m.myE)), dim3(TH_BLOCK), (ThTile<2, TH_COLS>::lds_bytes(m.nlm1)), s, m, av, di);
   }

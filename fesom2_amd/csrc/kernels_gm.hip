@@ -104,7 +104,7 @@ static void launch_fer_gamma(const DM &m, hipStream_t s) {
   if (!attr) { attr = true; TILE_SHAPES(FG_ATTR) FG_ATTR(5, 16, 8) FG_ATTR(6, 16, 4) }
   static const int env = getenv("FESOM_GPU_EXP_FG_SHAPE") ? atoi(getenv("FESOM_GPU_EXP_FG_SHAPE")) : 0;
   // (default tile shape of THIS kernel: 16 columns x 8 waves -- 48 VGPRs, so the 31 KB image instead of 62 KB lets 5 workgroups share a CU: 357 -> 297 us on the basin)
-  switch (m.use_tile && env > 0 ? env : (m.use_tile == 1 ? 5 : m.use_tile)) {
+  switch (env > 0 ? env : (m.use_tile == 1 ? 5 : m.use_tile)) {
     TILE_SHAPES(FG_SHAPE) FG_SHAPE(5, 16, 8) FG_SHAPE(6, 16, 4)
     default: hipLaunchKernelGGL((k_fer_gamma<TH_COLS, TH_COLS>), dim3(nblocks_th(SUBN(m, m.myN))), dim3(TH_BLOCK), (ThTile<2, TH_COLS>::lds_bytes(m.nl)), s, m); break;
   }
