@@ -214,7 +214,8 @@ contains
           msg(i:i) = fmsg(i)
        end do
     end if
-    write(*,*) 'fesom_gpu: ', what, ' failed on rank ', mype, ' rc=', rc, ': ', trim(msg)
+    write(*,'(a,a,a,i0,a,i0,a,a)') ' fesom_gpu: ', what, ' failed on rank ', mype, ' rc=', rc, ': ', trim(msg)      ! (one line: list-directed output wraps at 80 columns)
+    flush(6)          ! status_check ends in MPI_ABORT: the message must be out before
     pe_status = 1
   end subroutine
 
@@ -224,7 +225,8 @@ contains
     logical, intent(in) :: cond
     character(*), intent(in) :: what
     if (.not. cond) return
-    if (mype == 0) write(*,*) 'fesom_gpu: not implemented on the GPU path: ', what
+    if (mype == 0) write(*,'(a,a)') ' fesom_gpu: not implemented on the GPU path: ', what
+    flush(6)
     pe_status = 1
   end subroutine
 
@@ -252,6 +254,7 @@ contains
     call MPI_ALLTOALL(scnt, 1, MPI_INTEGER, got, 1, MPI_INTEGER, MPI_COMM_FESOM, ierr)
     if (any(got /= rexp)) then
        write(*,*) 'fesom_gpu: halo plan mismatch (', what, ') on rank ', mype
+       flush(6)
        pe_status = 1
     end if
   end subroutine

@@ -189,3 +189,15 @@ def test_free_running_parity_envelope(built):
         for k in (0, 1):
             assert abs(G["content"][k] - R2["content"][k]) <= 1e-12 * abs(R2["content"][k]), (n, k)
     assert rows[(96, "eta_n")][0] > 0.0
+
+
+def test_fortran_dropin_stops_on_an_option_the_library_refuses(built):
+    """visc_option = 8 is built for one partition: on two MPI ranks fesom_gpu_init refuses it by name and the Fortran host layer stops the run through
+    status_check / par_ex (the reference's own convention, gen_comm.F90:644-657) -- it does not step on the CPU silently and it does not run something else."""
+    from oracle.ref import run_ref
+    assert os.path.exists(os.path.join(REPO, "oracle", "_ref", "fesom_gpu_dropin.x"))
+    os.environ["FESOM_GPU_DEVICE"] = "0"
+    rd, rc, lines = run_ref.run("pi_pp_visc8", 2, 2, mode="gpu", dump=(), exe_name="fesom_gpu_dropin.x")
+    log = open(os.path.join(rd, "stdout.log")).read()
+    assert rc != 0, log[-2000:]
+    assert "visc_option=8" in log and "one partition" in log, log[-2000:]
