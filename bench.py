@@ -254,8 +254,10 @@ def large_mesh_partitioned(torch, dist, pg, rank, world, transport, steps=20, wa
     """N > 1, supplementary record: the CORE2-class basin (182 600 nodes, default physics) as ONE simulation partitioned over the N GPUs (coordinate
     bisection of the host mesh layer), strong scaling against the same steps on one GPU (rank 0 runs them afterwards; the extrema of eta must agree).
     pi has 3140 surface nodes -- 390 per GPU at N = 8 -- so its partitioned run is bound by the exchanges; this is the size the partitioned path is for."""
+    import datetime
     from fesom2_amd import parallel
     from fesom2_amd.core import OceanCore
+    pg = dist.new_group(timeout=datetime.timedelta(seconds=900))      # (rank 0 builds the mesh files and later runs the single-GPU comparison while the others wait)
     if rank == 0:
         workloads.basin(levels)                       # (builds the mesh files once)
     dist.barrier(group=pg)
