@@ -221,7 +221,7 @@ def roofline_object(core, mesh, wl, sps):
     return roofline, kt
 
 
-def large_mesh_record(which="basin", steps=60, warmup=10, levels=3):
+def large_mesh_record(which="basin", steps=60, warmup=10, levels=3, with_cpu=False):
     """BASELINE config #3 in kind inside the default line: the channel geometry refined `levels` times (182 600 nodes at 3), the kernel shapes of
     CORE2-class meshes, the RAS-Chebyshev SSH solve.  which = "basin": analytic bathymetry, the reference's default physics (JM EOS, KPP + GM +
     Redi, analytic forcing); "channel": the reference's CI case test_souf refined (flat bottom, linear EOS, PP, toy hooks).  GPU figures only
@@ -241,13 +241,18 @@ def large_mesh_record(which="basin", steps=60, warmup=10, levels=3):
         roofline, kt = roofline_object(core, mesh, wl, sps)
         spy = 365 * 86400.0 / wl.dt
         N3, E3, D3 = kt["wet"]
-        return {"workload": f"{wl.text} ({mesh.nod2D} nodes, {mesh.elem2D} elements, {mesh.nl - 1} layers)", "steps": steps, "warmup": warmup,
+        core.close(); core = None
+        cpu = cpu_baseline(wl, nsteps_ref=10, ranks_only=16, allow_port=False) if with_cpu else None     # the reference on 16 ranks of the host, 10 steps
+        if cpu and cpu.get("value"):
+            cpu["gpu_over_reference"] = round((86400.0 / (365 * 86400.0 / wl.dt * sps)) / cpu["value"], 1)
+        return {"workload": f"{wl.text} ({mesh.nod2D} nodes, {mesh.elem2D} elements, {mesh.nl - 1} layers)", "steps": steps, "warmup": warmup, "cpu_baseline": cpu,
                 "ms_per_step": round(sps * 1e3, 4), "value": round(86400.0 / (spy * sps), 3), "unit": "simulated_years/day", "steps_per_day": int(round(86400.0 / wl.dt)),
                 "wet_cells": {"N3": N3, "E3": E3, "D3": D3},
                 "roofline": {k: roofline[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel_us", "whole_step", "top5_us", "solver", "launches_per_step", "byte_table_audit")},
                 "kernels_GBs": {k: v["GBs"] for k, v in roofline["kernels"].items() if v["GBs"] is not None}}
     finally:
-        core.close()
+        if core is not None:
+            core.close()
 
 
 def large_mesh_partitioned(torch, dist, pg, rank, world, transport, steps=20, warmup=5, levels=3):
@@ -318,9 +323,10 @@ def large_mesh_partitioned(torch, dist, pg, rank, world, transport, steps=20, wa
     return rec
 
 
-def cpu_baseline(wl, nsteps_ref=None):
+def cpu_baseline(wl, nsteps_ref=None, ranks_only=None, allow_port=True):
     """Reference Fortran/MPI hot path (oracle/_ref/fesom_oracle.x, built from the reference's own sources) on the host cores:
-    same mesh, options, initial state and forcing; best of 8 / 16 / 32 MPI ranks that fit the node (bounded sample)."""
+    same mesh, options, initial state and forcing; best of 8 / 16 / 32 MPI ranks that fit the node (bounded sample).  ranks_only: one rank count
+    (the large-mesh record of the default line: the reference's set-up of a 182 600-node mesh takes most of its time)."""
     ncpu = os.cpu_count() or 1
     exe = os.path.join(REPO, "oracle", "_ref", "fesom_oracle.x")
     steps_per_year = 365 * 86400.0 / wl.dt
@@ -329,6 +335,8 @@ def cpu_baseline(wl, nsteps_ref=None):
             raise RuntimeError("no reference binary")
         from oracle.ref import run_ref
         cand = [r for r in (8, 16, 32) if r <= ncpu] or [2]
+        if ranks_only:
+            cand = [min(ranks_only, max(2, ncpu))]
         tried, best = {}, None
         for ranks in cand:
             if wl.name in ("channel", "basin"):
@@ -355,6 +363,8 @@ def cpu_baseline(wl, nsteps_ref=None):
                 "host_cores": ncpu, "ms_per_step_by_ranks": tried,
                 "sample": f"{n} steps of oce_timestep_ale on the same workload, best of {cand} MPI ranks = {ranks} ({sps*1e3:.2f} ms/step), os.cpu_count() = {ncpu}"}
     except Exception as e:          # reference cannot run here: time the scalar C restatement instead
+        if not allow_port:
+            return {"error": f"{type(e).__name__}: {e}"[:500]}
         from fesom2_amd.core import OceanCore  # noqa: F401  (only to share the import error, if any)
         from oracle_lib import Oracle
         mesh = wl.load_mesh()
@@ -649,7 +659,7 @@ def main():
         if world == 1 and wl.name == "pi" and wl.levels == 0 and not args.no_large_mesh:
             core.close(); core = None
             try:
-                out["large_mesh"] = large_mesh_record("basin")
+                out["large_mesh"] = large_mesh_record("basin", with_cpu=not args.no_cpu_baseline)
             except Exception as e:      # noqa: BLE001 -- recorded, the headline stands on its own
                 out["large_mesh"] = {"error": f"{type(e).__name__}: {e}"[:1000]}
             try:
