@@ -6,7 +6,7 @@ compute_vel_nodes + oce_timestep_ale; the result is compared with the reference'
 
 Tolerance: the reference is not bit-reproducible across partitions and its pARMS solve stops at the same
 1e-10 residual from a different iterate; after 10 steps of the default physics (KPP + GM + Redi, surface forcing):
-max|d eta| < 1e-8 m, max|dT|,|dS| < 1e-8, max|dU| < 1e-8 m/s, max|d hnode| < 1e-8 m."""
+max|d eta| < 2e-9 m, max|dT|,|dS| < 2e-9, max|dU| < 2e-9 m/s, max|d hnode| < 2e-9 m (the measured differences are at most 1.0e-9)."""
 import os
 import sys
 import numpy as np
@@ -74,8 +74,9 @@ def test_fortran_dropin_matches_reference_cpu_step(built, cfg, ranks):
         import json
         json.dump({"cfg": cfg, "gpu_ranks": ranks, "steps": NSTEPS, "max_abs_diff": worst, "gpu_timing": [l for l in lines_g if "TIMING" in l],
                    "cpu_timing": [l for l in lines_c if "TIMING" in l]}, open(os.path.join(out, f"dropin_{cfg}_{ranks}rank.json"), "w"), indent=1)
-    assert worst["eta_n"] < 1e-8 and worst["tr_arr"] < 1e-8 and worst["UV"] < 1e-8 and worst["hnode"] < 1e-8 and worst["hbar"] < 1e-8, worst
-    assert worst["Wvel"] < 1e-10, worst
+    # (round 3: the bar follows the measured differences -- at most 1.0e-9 over the 37 configurations, pi_pp_linfs_cubic; Wvel at most 8e-14)
+    assert worst["eta_n"] < 2e-9 and worst["tr_arr"] < 2e-9 and worst["UV"] < 2e-9 and worst["hnode"] < 2e-9 and worst["hbar"] < 2e-9, worst
+    assert worst["Wvel"] < 1e-12, worst
     assert worst["eta_n"] > 0.0, "GPU and CPU runs are bit-identical: the two runs did not use different code paths"
 
 
