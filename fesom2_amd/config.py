@@ -12,7 +12,8 @@ def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equati
                 visc_sh_limit=5.0e-3, diff_sh_limit=5.0e-3, Ricr=0.3, concv=1.6,
                 gamma0=0.003, gamma1=0.1, gamma2=0.285, easy_bs_return=1.5, C_d=0.0025, w_max_cfl=1.0, use_sw_pene=False, visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=True,
                 solver_precond=1, solver_xinv_its=0, tra_adv_lim="FCT", Leith_c=0.05, Div_c=0.5, which_pgf="shchepetkin", use_momix=False, momix_lat=-50.0, momix_kv=0.01, mom_adv=2, use_kpp_nonlclflx=False, ref_sss_local=True, ref_sss=34.0, double_diffusion=False, smooth_bh_tra=False, use_floatice=False, l_mslp=False, use_global_tides=False, max_ice_loading=5.0, clim_relax=0.0, SPP=False, Sice=4.0, min_hnode=0.5, lzstar_lev=4,
-                c_back=0.1, K_back=600.0, uke_scaling=True, uke_scaling_factor=1.0, rosb_dis=1.0, smooth_back=2, smooth_dis=2, smooth_back_tend=4, scale_area=5.8e9):
+                c_back=0.1, K_back=600.0, uke_scaling=True, uke_scaling_factor=1.0, rosb_dis=1.0, smooth_back=2, smooth_dis=2, smooth_back_tend=4, scale_area=5.8e9,
+                use_cavity=False, use_density_ref=None, density_ref_T=2.0, density_ref_S=34.0):
     p = _lib.Params()
     p.dt = dt
     p.which_ale = WHICH_ALE[which_ale]
@@ -64,6 +65,9 @@ def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equati
     # visc_option = 8 (src/oce_modules.F90:34-41; scale_area: config/namelist.oce)
     p.c_back, p.K_back, p.uke_scaling_factor, p.rosb_dis, p.scale_area = c_back, K_back, uke_scaling_factor, rosb_dis, scale_area
     p.uke_scaling, p.smooth_back, p.smooth_dis, p.smooth_back_tend = int(uke_scaling), int(smooth_back), int(smooth_dis), int(smooth_back_tend)
+    p.use_cavity = int(use_cavity)
+    p.use_density_ref = int(use_cavity if use_density_ref is None else use_density_ref)      # (ocean_setup switches it on with cavities, oce_setup_step.F90:122)
+    p.density_ref_T, p.density_ref_S = density_ref_T, density_ref_S
     linfs = (which_ale == "linfs")
     p.use_kpp_nonlclflx, p.ref_sss_local, p.ref_sss = int(use_kpp_nonlclflx), int(ref_sss_local and linfs), (ref_sss if linfs else 0.0)   # config/namelist.oce:71-72, :83
     p.visc_sh_limit, p.diff_sh_limit, p.Ricr, p.concv = visc_sh_limit, diff_sh_limit, Ricr, concv

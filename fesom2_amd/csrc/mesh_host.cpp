@@ -44,7 +44,7 @@ struct Mesh {
   dvec grad_sca, grad_vec, edge_dxdy, edge_cross, elem_cos, metric, cori, cori_n, cen_y;
   ivec rowptr, colind, colind_loc; dvec values;
   ivec updn;
-  dvec zbar_n_bot, zbar_n_srf, bot_n_th, zbar_e_bot, zbar_e_srf, bot_e_th;
+  dvec zbar_n_bot, zbar_n_srf, bot_n_th, zbar_e_bot, zbar_e_srf, bot_e_th, cavity_depth;
   ivec list_n, list_e, list_d;
   // initial state
   dvec hnode, hnode_new, helem, zbar3, Z3, eta, d_eta, ssh_rhs, ssh_rhs_old, hbar, hbar_old, dhe;
@@ -235,6 +235,19 @@ bool load_files(Mesh &m, const std::string &dir) {
   for (int i = 0; i < m.N2; i++) m.nlev_n[i] = atoi(t[i].c_str());
   m.ulev.assign(m.E2, 1);
   m.ulev_n.assign(m.N2, 1);
+  m.cavity_depth.assign(m.N2, 0.0);
+  if (m.o.use_cavity) {        // find_levels_cavity (src/oce_mesh.F90:897-1280): upper levels of elements and nodes, draft of the ice shelf at the nodes
+    t.clear();
+    if (!read_all_tokens(dir + "/cavity_elvls.out", t) || (int)t.size() < m.E2) return false;
+    for (int i = 0; i < m.E2; i++) m.ulev[i] = atoi(t[i].c_str());
+    t.clear();
+    if (!read_all_tokens(dir + "/cavity_nlvls.out", t) || (int)t.size() < m.N2) return false;
+    for (int i = 0; i < m.N2; i++) m.ulev_n[i] = atoi(t[i].c_str());
+    t.clear();
+    if (!read_all_tokens(dir + "/cavity_depth.out", t) || (int)t.size() < m.N2) return false;
+    for (int i = 0; i < m.N2; i++) m.cavity_depth[i] = (double)atoi(t[i].c_str());       // (the reference reads it into an integer buffer, :1253)
+    t.clear();
+  }
   return true;
 }
 
@@ -314,6 +327,20 @@ void areas(Mesh &m) {
         m.area[(size_t)nl * (n - 1) + nz - 1] += m.elem_area[e - 1] / 3.0;
     }
   m.areasvol.assign((size_t)nl * m.N2, 0.0);
+  if (m.o.use_cavity) {      // :1927-1977: directly under the ice the scalar cell takes the area of its LOWER face where a cavity triangle sits on the upper one
+    std::vector<int> contrib((size_t)nl * m.N2, 0);
+    for (int n = 1; n <= m.N2; n++)
+      for (int j = 1; j <= m.nie_num[n - 1]; j++) {
+        int e = NIE(j, n);
+        for (int nz = 1; nz <= m.ulev[e - 1] - 1; nz++) contrib[(size_t)nl * (n - 1) + nz - 1]++;
+      }
+    for (int n = 1; n <= m.N2; n++) {
+      const int nzmin = m.ulev_n[n - 1], nzmax = m.nlev_n[n - 1] - 1;
+      for (int nz = nzmin; nz <= nzmax; nz++)
+        m.areasvol[(size_t)nl * (n - 1) + nz - 1] = contrib[(size_t)nl * (n - 1) + nz - 1] > 0 ? m.area[(size_t)nl * (n - 1) + std::min(nz + 1, nzmax) - 1]
+                                                                                              : m.area[(size_t)nl * (n - 1) + nz - 1];
+    }
+  } else
   for (int n = 1; n <= m.N2; n++)
     for (int nz = m.ulev_n[n - 1]; nz <= m.nlev_n[n - 1] - 1; nz++)
       m.areasvol[(size_t)nl * (n - 1) + nz - 1] = m.area[(size_t)nl * (n - 1) + nz - 1];
@@ -327,6 +354,14 @@ void areas(Mesh &m) {
       m.area_inv[(size_t)nl * (n - 1) + nz - 1] = a > 0.0 ? 1.0 / a : 0.0;
     }
   m.areasvol_inv = m.area_inv;
+  if (m.o.use_cavity) {      // :2015-2028
+    m.areasvol_inv.assign((size_t)nl * m.N2, 0.0);
+    for (int n = 1; n <= m.N2; n++)
+      for (int nz = m.ulev_n[n - 1]; nz <= m.nlev_n[n - 1] - 1; nz++) {
+        double a = m.areasvol[(size_t)nl * (n - 1) + nz - 1];
+        m.areasvol_inv[(size_t)nl * (n - 1) + nz - 1] = a > 0.0 ? 1.0 / a : 0.0;
+      }
+  }
   m.resol.resize(m.N2);
   for (int n = 1; n <= m.N2; n++)
     m.resol[n - 1] = sqrt(m.areasvol[(size_t)nl * (n - 1) + m.ulev_n[n - 1] - 1] / PI) * 2.0;
@@ -463,6 +498,10 @@ void ale_init(Mesh &m) {
     m.bot_n_th[n - 1] = m.zbar[nln - 2] - m.zbar_n_bot[n - 1];
   }
   m.zbar_n_srf.assign(m.N2, m.zbar[0]); m.zbar_e_srf.assign(m.E2, m.zbar[0]);
+  if (m.o.use_cavity) {      // init_surface_elem_depth / init_surface_node_depth (src/oce_ale.F90:420-520), use_cavity_partial_cell = .false.
+    for (int e = 1; e <= m.E2; e++) if (m.ulev[e - 1] > 1) m.zbar_e_srf[e - 1] = m.zbar[m.ulev[e - 1] - 1];
+    for (int n = 1; n <= m.N2; n++) if (m.ulev_n[n - 1] > 1) m.zbar_n_srf[n - 1] = m.zbar[m.ulev_n[n - 1] - 1];
+  }
   m.zbar3.assign((size_t)nl * m.N2, 0.0); m.Z3.assign((size_t)(nl - 1) * m.N2, 0.0);
   for (int n = 1; n <= m.N2; n++) {
     double *zb = &m.zbar3[(size_t)nl * (n - 1)] - 1;   // 1-based

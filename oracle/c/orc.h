@@ -106,6 +106,7 @@ static inline double dmax(double a, double b) { return a > b ? a : b; }
 /* routines (one per reference subroutine) */
 void orc_compute_vel_nodes(void);
 void orc_pressure_bv(void);
+void orc_init_ref_density(void);
 void orc_pressure_force(void);
 void orc_sw_alpha_beta(void);
 void orc_compute_sigma_xy(void);

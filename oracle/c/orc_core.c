@@ -387,7 +387,7 @@ void orc_step(int n) {
 int orc_call(const char *name, int arg) {
 #define CALL0(f) if (!strcmp(name, #f)) { orc_##f(); return 0; }
 #define CALL1(f) if (!strcmp(name, #f)) { orc_##f(arg); return 0; }
-  CALL0(compute_vel_nodes) CALL0(pressure_bv) CALL0(pressure_force) CALL0(sw_alpha_beta) CALL0(compute_sigma_xy)
+  CALL0(init_ref_density) CALL0(compute_vel_nodes) CALL0(pressure_bv) CALL0(pressure_force) CALL0(sw_alpha_beta) CALL0(compute_sigma_xy)
   CALL0(compute_neutral_slope) CALL0(mixing_pp) CALL0(mixing_kpp) CALL0(mo_convect) CALL0(compute_vel_rhs) CALL0(visc_filt_bcksct) CALL0(viscosity_filter)
   CALL0(impl_vert_visc_ale) CALL0(update_stiff_mat_ale) CALL0(compute_ssh_rhs_ale) CALL0(solve_ssh) CALL0(update_vel)
   CALL0(compute_hbar_ale) CALL0(eta_update) CALL0(vert_vel_ale) CALL1(init_tracers_AB) CALL1(adv_tracers_ale)

@@ -50,7 +50,25 @@ static void eos(double t, double s, double *bulk_0, double *bulk_pz, double *bul
           + s * (bs + t * (bst + t * (bst2 + t * (bst3 + t * bst4))) + s_sqrt * (bss + t * (bsst + t * bsst2)) + s * bss2);
 }
 
-/* pressure_bv: src/oce_ale_pressure_bv.F90:106-365 (no cavity: ulevels==1) */
+/* init_ref_density: src/oce_ale_pressure_bv.F90:3024-3070 (ocean_setup, once, from the initial Z_3d_n; nzmin = 1 as the reference has it) */
+void orc_init_ref_density(void) {
+  double b0, bpz, bpz2, rp;
+  eos(C_.p.density_ref_T, C_.p.density_ref_S, &b0, &bpz, &bpz2, &rp);
+  for (size_t i = 0; i < (size_t)NLM1 * C_.N; i++) C_.density_ref[i] = 0.0;
+  for (int n = 1; n <= C_.N; n++) {
+    const int nzmin = 1, nzmax = NLEVN(n) - 1;
+    double auxz = A2(C_.Z_3d_n, nzmin, n) < 0.0 ? A2(C_.Z_3d_n, nzmin, n) : 0.0;
+    double rho = b0 + auxz * bpz + auxz * bpz2;
+    A2(C_.density_ref, nzmin, n) = rho * rp / (rho + 0.1 * auxz);
+    for (int nz = nzmin + 1; nz <= nzmax; nz++) {
+      auxz = A2(C_.Z_3d_n, nz, n);
+      rho = b0 + auxz * bpz + auxz * bpz2;
+      A2(C_.density_ref, nz, n) = rho * rp / (rho + 0.1 * auxz);
+    }
+  }
+}
+
+/* pressure_bv: src/oce_ale_pressure_bv.F90:106-365 */
 void orc_pressure_bv(void) {
   int nl = NL;
   double *rhopot = malloc(sizeof(double) * (nl + 1) * 6);
@@ -78,7 +96,24 @@ void orc_pressure_bv(void) {
     }
     dbsfc1[nzmax] = dbsfc1[nzmax - 1];
     for (int nz = nzmin; nz <= nzmax; nz++) A2L(C_.dbsfc, nz, n) = dbsfc1[nz];
-    if (C_.p.which_ale == 0) {
+    if (nzmin > 1) {      /* :235-258 the levels the ice shelf occupies take the density of the water mass at the cavity-ocean interface */
+      double t = TR(nzmin, n, 1), sal = TR(nzmin, n, 2);
+      for (int nz = 1; nz <= nzmin - 1; nz++) {
+        eos(t, sal, &bulk_0[nz], &bulk_pz[nz], &bulk_pz2[nz], &rhopot[nz]);
+        double z = A2(C_.Z_3d_n, nz, n);
+        rho[nz] = bulk_0[nz] + z * (bulk_pz[nz] + z * bulk_pz2[nz]);
+        rho[nz] = rho[nz] * rhopot[nz] / (rho[nz] + 0.1 * z * seq) - A2(C_.density_ref, nz, n);
+        A2(C_.density_m_rho0, nz, n) = rho[nz];
+      }
+    }
+    if (C_.p.which_ale == 0 || C_.p.use_cavity) {      /* :262 */
+      if (nzmin > 1) {      /* :268-275 pressure at the cavity-ocean interface */
+        A2L(C_.hpressure, nzmin, n) = 0.5 * (A2L(C_.zbar_3d_n, 1, n) - A2L(C_.zbar_3d_n, 2, n)) * rho[1] * G_ACC;
+        for (int nz = 2; nz <= nzmin; nz++) {
+          double a = 0.5 * G_ACC * (rho[nz - 1] * (A2L(C_.zbar_3d_n, nz - 1, n) - A2L(C_.zbar_3d_n, nz, n)) + rho[nz] * (A2L(C_.zbar_3d_n, nz, n) - A2L(C_.zbar_3d_n, nz + 1, n)));
+          A2L(C_.hpressure, nzmin, n) = A2L(C_.hpressure, nzmin, n) + a;
+        }
+      } else
       A2L(C_.hpressure, nzmin, n) = -A2(C_.Z_3d_n, nzmin, n) * rho[nzmin] * G_ACC;
       for (int nz = nzmin + 1; nz <= nzmax - 1; nz++) {
         double a = 0.5 * G_ACC * (rho[nz - 1] * A2(C_.hnode, nz - 1, n) + rho[nz] * A2(C_.hnode, nz, n));

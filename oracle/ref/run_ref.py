@@ -58,7 +58,7 @@ include_fleapyear=.false.
 /
 &run_config
 use_ice=.false.
-use_cavity=.false.
+use_cavity={use_cavity}
 use_cavity_partial_cell=.false.
 use_floatice={use_floatice}
 use_sw_pene={use_sw_pene}
@@ -148,6 +148,11 @@ t_insitu=.false.
 """
 
 CFGS = {
+    # ice-shelf cavity: the pi mesh with a synthetic draft (tests/golden/make_cavity_mesh.py -> meshes/pi_cavity: cavity_elvls / nlvls / depth), use_cavity=.true.
+    "pi_pp_cavity": dict(mesh="pi_cavity", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                         rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                         fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                         balance_salt_water=".true.", use_cavity=".true.", synth_forcing=True),
     # pi mesh, 47 layers, zstar + partial cells, JM EOS, PP mixing, no GM/Redi (round-1 closure config)
     "pi_pp": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
                   rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
@@ -431,7 +436,7 @@ def prepare(cfg, np_, tag=""):
                 os.chmod(root, 0o755)
             partition_io.write_dist(cp, np_)
         meshdir = cp
-    open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **dict(dict(use_sw_pene=".false.", use_floatice=".false.", min_hnode="0.5", which_toy="soufflet"), **c)))
+    open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **dict(dict(use_sw_pene=".false.", use_floatice=".false.", min_hnode="0.5", which_toy="soufflet", use_cavity=".false."), **c)))
     open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0", visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=".true.", tra_adv_lim="FCT", use_momix=".false.", which_pgf="shchepetkin", mom_adv=2, use_kpp_nonlclflx=".false.", double_diffusion=".false.", smooth_bh_tra=".false.", clim_relax="0.0", SPP=".false."), **c)))
     if c["toy_ocean"] == ".false." or c.get("which_toy", "soufflet") != "soufflet":
         from fesom2_amd.synthetic import write_ic_files

@@ -58,6 +58,8 @@ class Oracle:
     def set_state(self, st):
         for k, v in st.a.items():
             self.set(k, v)
+        if getattr(self.params, "use_density_ref", 0):          # ocean_setup: init_ref_density from the initial Z_3d_n (oce_setup_step.F90:129)
+            self.call("init_ref_density")
 
     def first_step_done(self, v):
         self.lib.orc_set_first_step_done(int(v))
