@@ -24,6 +24,7 @@ extern "C" void fesom_xinv_sparsify(int n, int ld, const float *M, double tau, i
 int launch_named_ras(const DM &m, hipStream_t s, const char *name);
 void tile_prepare_tra();
 void tile_prepare_dyn();
+void launch_init_density_ref(const DM &m, hipStream_t s);
 
 namespace {
 struct Field { void *p; size_t count; int slabs; };   // slabs>1: one slab of `count` values per tracer
@@ -61,6 +62,7 @@ struct Ctx {
   // interior / boundary split of the node-column kernels behind an exchange (partitioned runs): owned nodes whose edge neighbours are all owned,
   // owned nodes with a halo neighbour, and the latter plus the halo nodes themselves
   struct ColList { const int *d = nullptr; int n = 0; } sub_int, sub_cb, sub_cbh;
+  bool dref_done = false;                             // the reference density profile has been formed (first state upload)
   bool solver_only = false;                           // the context holds the distributed SSH solver alone (fesom_gpu_psolver_init_dist): no ocean step
   bool precond_agreed = false;                        // partitioned runs: all ranks have settled on one SSH preconditioner
   int generation = 0;                                 // counts fesom_gpu_init calls (cached plans of the partitioned step belong to one)
@@ -468,8 +470,10 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   if (par->tra_adv_lim < 0 || par->tra_adv_lim > 1) { G.err = "fesom_gpu_init: tra_adv_lim must be 'FCT' (0) or 'NON' (1)"; return 3; }
   if (par->tra_adv_lim == 1 && par->w_split) { G.err = "fesom_gpu_init: tra_adv_lim='NON' together with w_split (implicit vertical advection inside the diffusion solve) is not implemented"; return 3; }
   if (par->mix_scheme < 0 || par->mix_scheme > 2) { G.err = "fesom_gpu_init: mix_scheme must be 0 (constant), 1 (KPP) or 2 (PP); the cvmix schemes are not implemented"; return 3; }
-  for (int e = 0; e < d->myDim_elem2D + d->eDim_elem2D; e++)
-    if (d->ulevels[e] != 1) { G.err = "fesom_gpu_init: cavities (ulevels>1) are not supported"; return 3; }
+  if (!par->use_cavity)
+    for (int e = 0; e < d->myDim_elem2D + d->eDim_elem2D; e++)
+      if (d->ulevels[e] != 1) { G.err = "fesom_gpu_init: the mesh has ice-shelf cavities (ulevels > 1) but use_cavity is off"; return 3; }
+  if (par->use_cavity && par->which_pgf != 0 && par->which_pgf != 3) { G.err = "fesom_gpu_init: with cavities which_pgf must be 'shchepetkin' or 'easypgf' (the scheme 'sergey', pressure_force_4_linfs_cavity, is not implemented)"; return 3; }
   if (fesom_internal_select_device(G.err)) { fprintf(stderr, "fesom_gpu: %s\n", G.err.c_str()); return 2; }
   HIPCHK(hipStreamCreate(&G.stream));
   for (int i = 0; i < 3; i++) HIPCHK(hipStreamCreateWithFlags(&G.side[i], hipStreamNonBlocking));   // (stream priorities: no effect, measured)
@@ -619,6 +623,9 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   F(pgf_x, n1 * E); F(pgf_y, n1 * E); F(helem, n1 * E); F(Av, nl * E); F(dhe, E);
   FT(adv_flux_hor, n1 * D); FT(adv_flux_raw, n1 * D); FT(flux_lo_hor, n1 * D); FT(diff_flux, n1 * D); FT(edge_up_dn_grad, 4 * n1 * D); F(edge_c12, D);
   m.cl_grad = nullptr; m.cl_need = nullptr;
+  m.density_ref = nullptr;
+  if (par->use_density_ref || par->use_cavity) F(density_ref, n1 * N);       // filled by k_init_density_ref at the first state upload (ocean_setup: init_ref_density)
+  G.dref_done = false;
   if (m.use_tile && !getenv("FESOM_GPU_NO_CLUSTER_GRAD")) {
     // k_flux_hor<FUSED> forms fill_up_dn_grad on the fly; where the two upwind triangles of an edge do not cover a node's column (ragged bottom, boundary
     // edges) it needs the cluster mean of the gradient at that node -- per NODE in k_cluster_grad instead of once per incident edge
@@ -920,6 +927,11 @@ static int copy_state(const fesom_state_desc *st, bool up) {
     if (!strcmp(t.n, "dhe")) cnt = (size_t)G.m.myE;
     if (up) HIPCHK(hipMemcpy(f.p, t.h, cnt * sizeof(double), hipMemcpyHostToDevice));
     else HIPCHK(hipMemcpy(t.h, f.p, cnt * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  if (up && G.m.density_ref && !G.dref_done && st->Z_3d_n) {      // init_ref_density of ocean_setup: from the initial layer depths, once
+    launch_init_density_ref(G.m, G.stream);
+    HIPCHK(hipStreamSynchronize(G.stream));
+    G.dref_done = true;
   }
   return 0;
 }

@@ -64,6 +64,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   double *pgf_x, *pgf_y, *helem, *Av, *dhe, *stress_surf;
   double *pgf_A, *pgf_B;                   // shchepetkin PGF: the two quotients of the density-Jacobian's vertical derivative that depend on the NODE column only (k_pressure_bv forms them once per node and level; every element around the node reads them)
   double *adv_flux_hor, *adv_flux_raw, *flux_lo_hor, *edge_up_dn_grad, *edge_c12, *diff_flux;
+  double *density_ref;        // (nl-1, N) reference density profile of init_ref_density (use_density_ref / cavities); nullptr: density_0
   double *cl_grad; const unsigned char *cl_need;       // fused up/down-wind gradients (DM::use_tile): cluster mean of the tracer gradient per node (2, nl-1, N, tracer) and the nodes some edge needs it for
   double *ssh_values;
   // Gent-McWilliams bolus velocities (kernels_gm.hip)

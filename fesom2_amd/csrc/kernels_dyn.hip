@@ -57,6 +57,23 @@ __device__ __forceinline__ void eos(const fesom_params &p, double t, double s, d
 // pressure_bv (src/oce_ale_pressure_bv.F90:106-365) fused with sw_alpha_beta (:2736-2821): both are
 // pointwise in (T,S,Z) per node column.  Vertical neighbours come from wave shuffles; MLD searches are
 // ballots.  ~150 flops/cell, 7+5 values/cell -> HBM-bound.
+// init_ref_density (src/oce_ale_pressure_bv.F90:3024-3070; ocean_setup, once): the reference density profile from (density_ref_T, density_ref_S) at the
+// depths of the initial Z_3d_n; from level 1 also under an ice shelf, as the reference has it (nzmin = 1)
+__global__ void __launch_bounds__(BLOCK) k_init_density_ref(DM m) {
+  const int n = col_id(m), nz = lane_id() + 1;
+  if (n >= m.N || nz > m.nlm1) return;
+  double b0, bpz, bpz2, rp;
+  eos(m.p, m.p.density_ref_T, m.p.density_ref_S, b0, bpz, bpz2, rp);
+  double out = 0.0;
+  if (nz <= m.nlev_n[n] - 1) {
+    double auxz = DA2(m.Z_3d_n, nz, n);
+    if (nz == 1) auxz = auxz < 0.0 ? auxz : 0.0;
+    const double rho = b0 + auxz * bpz + auxz * bpz2;
+    out = rho * rp / (rho + 0.1 * auxz);
+  }
+  DA2(m.density_ref, nz, n) = out;
+}
+void launch_init_density_ref(const DM &m, hipStream_t s) { hipLaunchKernelGGL(k_init_density_ref, dim3(nblocks(m.N)), dim3(BLOCK), 0, s, m); }
 __global__ void __launch_bounds__(BLOCK) k_pressure_bv(DM m) {
   int n = col_id(m), l = lane_id(), nz = l + 1;
   if (n >= m.N) return;
@@ -69,13 +86,22 @@ __global__ void __launch_bounds__(BLOCK) k_pressure_bv(DM m) {
   const double zmin = bcast(z, nzmin - 1);
   double dbq = 0.0;
   const double z2 = bcast(z, nzmin);          // Z_3d_n(nzmin+1)
+  // density_ref: density_0, or the profile of init_ref_density (use_density_ref; with cavities always, src/oce_setup_step.F90:120-129)
+  const double dref = (m.density_ref && nz <= m.nlm1) ? DA2(m.density_ref, nz, n) : D_RHO0;
+  if (nzmin > 1 && nz < nzmin) {      // :235-258 the levels the ice shelf occupies take the density of the water mass at the cavity-ocean interface
+    z = DA2(m.Z_3d_n, nz, n);
+    b0 = b0s; bpz = bpzs; bpz2 = bpz2s; rpot = rpots;
+    rho = b0 + z * (bpz + z * bpz2);
+    rho = rho * rpot / (rho + 0.1 * z * seq) - dref;
+    DA2(m.density_m_rho0, nz, n) = rho;
+  }
   if (wet) {
     rho = b0 + z * (bpz + z * bpz2);
-    rho = rho * rpot / (rho + 0.1 * z * seq) - D_RHO0;          // density_ref == density_0 (use_density_ref=.false.)
+    rho = rho * rpot / (rho + 0.1 * z * seq) - dref;
     DA2(m.density_m_rho0, nz, n) = rho;
     double rho_surf = b0s + z * (bpzs + z * bpz2s);
     rho_surf = rho_surf * rpots / (rho_surf + 0.1 * z * seq);
-    double rr = rho + D_RHO0;
+    double rr = rho + dref;
     double dbsfc1 = -D_G * (rho_surf - rr) / rr;
     double zk = (nz > nzmin + 1) ? z : z2;                      // Z_3d_n(max(nz,nzmin+1))
     dbq = dbsfc1 / fabs(zmin - zk);
@@ -97,12 +123,18 @@ __global__ void __launch_bounds__(BLOCK) k_pressure_bv(DM m) {
   }
   double db_max = wave_max(wet ? dmax_(dbq, 0.0) : 0.0);
   // linfs: hydrostatic pressure (sequential running sum, reference order)
-  if (m.p.which_ale == 0) {
+  if (m.p.which_ale == 0 || m.p.use_cavity) {      // :262
     double hn = wet ? DA2(m.hnode, nz, n) : 0.0;
     double rh = rho * hn;                       // rho(nz)*hnode(nz)
     double rh_up = shup(rh);
     double a = (wet && nz > nzmin) ? 0.5 * D_G * (rh_up + rh) : 0.0;
     double h0 = -zmin * bcast(rho, nzmin - 1) * D_G;
+    if (nzmin > 1) {      // :268-275 pressure at the cavity-ocean interface: the column of interface water above it, top-down
+      const double zb = (nz <= nzmin + 1) ? DA2L(m.zbar_3d_n, nz, n) : 0.0, zb_dn = shdn(zb), zb_up = shup(zb), rho_up = shup(rho);
+      const double ac = (nz >= 2 && nz <= nzmin) ? 0.5 * D_G * (rho_up * (zb_up - zb) + rho * (zb - zb_dn)) : 0.0;
+      const double hs = 0.5 * (bcast(zb, 0) - bcast(zb, 1)) * bcast(rho, 0) * D_G;
+      h0 = bcast(seq_sum_up(ac, 1, nzmin - 1, hs), nzmin - 1);
+    }
     double hp = seq_sum_up(a, nzmin, nzmax - 2, h0);            // lanes nzmin..nzmax-2 <-> levels nzmin+1..nzmax-1
     if (wet) DA2L(m.hpressure, nz, n) = (nz == nzmin) ? h0 : hp;
   }
@@ -248,7 +280,7 @@ __global__ void __launch_bounds__(BLOCK) k_pgf(DM m) {
       double b0, bpz, bpz2, rp;
       eos(m.p, ti, si, b0, bpz, bpz2, rp);
       double dens = b0 + Zn * (bpz + Zn * bpz2);
-      dens = dens * rp / (dens + 0.1 * Zn * seq) - D_RHO0;          // density_ref == density_0 (use_density_ref=.false.)
+      dens = dens * rp / (dens + 0.1 * Zn * seq) - (m.density_ref ? DA2(m.density_ref, nle, n) : D_RHO0);          // density_ref(nle, node), :611
       const int nlce = nlc < nle ? nlc : nle;
       hpb[ni] = DA2L(m.hpressure, nlce - 1, n) + 0.5 * D_G * (DA2(m.density_m_rho0, nlce - 1, n) * DA2(m.hnode, nlce - 1, n) + dens * dh);
     }
@@ -1541,7 +1573,7 @@ __global__ void __launch_bounds__(BLOCK) k_vert_vel(DM m, int fuse_hbar) {
   double c2_up = shup(c2);
   double cfl = 0.0;
   if (nz >= nzmin && nz <= nzmax + 1) {
-    if (nz == nzmin) cfl = 0.0 + c1;
+    if (nz == nzmin) cfl = (nzmin > 1 ? DA2L(m.CFL_z, nz, n) : 0.0) + c1;   // only CFL_z(1,:) is reset (src/oce_ale.F90:2141): under an ice shelf the top entry accumulates over the steps, as in the reference
     else if (nz == nzmax + 1) cfl = c2_up;
     else cfl = c2_up + c1;
     double Wl = (nz == nzmax + 1) ? 0.0 : W;

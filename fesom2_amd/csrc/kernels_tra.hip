@@ -634,6 +634,9 @@ __device__ __forceinline__ void k_fct_node_col(const DM &m, const int tr) {
     double lk = DA2(LOp, nzc, k), tk = DA2(Tp, nzc, k);
     tvmax = dmax_(tvmax, dmax_(lk, tk)); tvmin = dmin_(tvmin, dmin_(lk, tk));
   }
+  // under an ice shelf: an element around the node that starts below this level (nz < ulevels(elem)) contributes the untouched entries of the reference's
+  // scratch array -- UV_rhs, which no routine writes above an element's upper level, i.e. 0 -- to both bounds (src/oce_adv_tra_fct.F90:110-121,141-142)
+  if (wet && nz < m.ulev_n_max[n]) { tvmax = dmax_(tvmax, 0.0); tvmin = dmin_(tvmin, 0.0); }
   double mx_u = shup(tvmax), mx_d = shdn(tvmax), mn_u = shup(tvmin), mn_d = shdn(tvmin);
   double adv = (nz >= nu1 && nz <= nl1) ? DA2L(t.adv_flux_ver, nz, n) : 0.0;
   double adv_dn = shdn(adv);

@@ -1044,3 +1044,48 @@ def test_tile_shapes_chain_and_steps_bitwise(built, shape, kw):
             ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
             assert ok, msg
     gpu.close()
+
+
+def test_cavity_chain_bitwise(built):
+    """Ice-shelf cavities (use_cavity: upper levels ulevels > 1 from the cavity files of the mesh, the reference density profile of init_ref_density, the
+    interface-water fill and the cavity branch of hpressure in pressure_bv, every kernel from its column's upper level): the pi mesh with a synthetic draft
+    (tests/golden/make_cavity_mesh.py), oracle pinned on the reference run pi_pp_cavity (tests/test_oracle_vs_reference.py): HIP == oracle bit for bit after
+    every routine of 3 steps under surface forcing and after 8 further whole steps."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.core import OceanCore
+    from fesom2_amd.synthetic import analytic_ts, analytic_forcing
+    from oracle_lib import Oracle
+    D = os.path.join(os.path.dirname(PI), "pi_cavity")
+    mesh = Mesh.load(D, dt=900.0, use_cavity=True)
+    assert (mesh.ulevels_nod2D > 1).sum() > 300 and mesh.ulevels.max() > 10
+    par = make_params(dt=900.0, use_cavity=True)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(D)
+    st.tr_arr_old[...] = st.tr_arr
+    gpu, orc = OceanCore(mesh, par), Oracle(mesh, par)
+    gpu.upload_state(st); orc.set_state(st)
+    forcing = analytic_forcing(mesh)
+    gpu.set_forcing(**forcing)
+    for k, v in forcing.items():
+        orc.set(k, v)
+    ok, msg = compare("density_ref", gpu.get("density_ref", orc.count("density_ref")), orc.get("density_ref"))
+    assert ok, msg
+    failures = []
+    for step in range(1, 4):
+        for routine, arg, fields in full_chain(2):
+            gpu.call(routine, arg); orc.call(routine, arg)
+            for f in list(fields) + (["hpressure"] if routine == "pressure_bv" else []):
+                ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+                if not ok:
+                    failures.append(f"step {step} {routine}({arg}) {msg}")
+        if failures:
+            break
+    assert not failures, "\n".join(failures[:15])
+    gpu.run_steps(4, 8)
+    for n in range(4, 12):
+        orc.call("step", n)
+    for f in ("tr_arr", "UV", "eta_n", "hnode", "hbar", "Wvel"):
+        ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+        assert ok, msg
+    gpu.close()
