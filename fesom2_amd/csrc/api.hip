@@ -788,6 +788,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     m.gm_scal_static = dev_upload(sc);
     for (size_t n = 0; n < N; n++) { double q = d->mesh_resolution[n] / 100000.0; sc[n] = par->K_hor * (q * q); }
     m.redi_k0 = dev_upload(sc);
+    m.gm_nzl = d->myDim_nod2D > 0 ? d->ulevels_nod2D_max[d->myDim_nod2D - 1] : 1;
     m.MLD1_ind = dev_alloc<int>(N);
   }
   G.npes = part ? part->npes : 1; G.mype = part ? part->mype : 0;
@@ -857,6 +858,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     std::vector<double> ki(n1 * N), av(nl * E, par->A_ver), kv(nl * N, par->K_ver);
     for (size_t n = 0; n < N; n++) { double r = d->mesh_resolution[n] / 100000.0; for (size_t k = 0; k < n1; k++) ki[n * n1 + k] = par->K_hor * (r * r); }
     HIPCHK(hipMemcpy(m.Ki, ki.data(), sizeof(double) * ki.size(), hipMemcpyHostToDevice));
+    if (par->Fer_GM) { std::vector<double> fk(nl * N, 500.0); HIPCHK(hipMemcpy(m.fer_K, fk.data(), sizeof(double) * fk.size(), hipMemcpyHostToDevice)); }      // fer_K=500 (oce_setup_step.F90:359; read back only under an ice shelf, kernels_gm.hip)
     if (par->mix_scheme == 0) {
       HIPCHK(hipMemcpy(m.Av, av.data(), sizeof(double) * av.size(), hipMemcpyHostToDevice));
       HIPCHK(hipMemcpy(m.Kv, kv.data(), sizeof(double) * kv.size(), hipMemcpyHostToDevice));

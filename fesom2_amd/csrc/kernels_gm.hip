@@ -42,10 +42,22 @@ __global__ void __launch_bounds__(BLOCK) k_gm_coef(DM m) {
     int k = nz < m.nl - 1 ? nz : m.nl - 1;
     if (DV3(m.neutral_slope, 3, k, n) > 5.e-3) zs = 0.0;
   }
-  if (m.p.Fer_GM && nz >= nzmin && nz <= nzmax) DA2L(m.fer_K, nz, n) = base * zs;
-  if (m.p.Redi) {                                          // Ki: K_hor*(reso/100km)^2, or the GM coefficient when both are on (:179-186)
-    double kb = base;
-    if (!m.p.Fer_GM) kb = m.redi_k0[n];
+  double fb = base, kb = m.p.Fer_GM ? base : m.redi_k0[n];  // surface templates of fer_K and of Ki: K_hor*(reso/100km)^2, or the GM coefficient when both are on (:243-250)
+  if (m.p.use_cavity) {
+    // Under an ice shelf the reference's two loops disagree about the top level: the templates go to max(ulevels of the node's elements) (:181,232,243), the
+    // vertical scaling starts from fer_k / Ki at ulevels_nod2D (:260,313-330).  Where the two differ (nodes at the rim of the draft) the scaling reads what the
+    // previous step left there -- fer_K starts at 500 (oce_setup_step.F90:359), Ki at K_hor*(reso/100km)^2 (:330) -- and scales it again.  And "Redi equal GM",
+    // Ki(nzmin,:)=fer_k(nzmin,:), stands after the first loop (:250): it acts on every node at the upper level of the LAST owned node (gm_nzl).
+    const int nzl = m.gm_nzl;
+    const double fk_old = m.p.Fer_GM ? DA2L(m.fer_K, min(nz, m.nl), n) : 0.0, ki_old = m.p.Redi ? DA2(m.Ki, min(nz, m.nlm1), n) : 0.0;
+    if (nzmin < nzmin1) {
+      fb = bcast(fk_old, nzmin - 1);
+      kb = (m.p.Fer_GM && nzl == nzmin) ? fb : bcast(ki_old, nzmin - 1);
+    } else if (m.p.Fer_GM && nzl != nzmin) kb = m.redi_k0[n];
+    if (m.p.Fer_GM && m.p.Redi && nz == nzl && nz <= m.nlm1 && (nz < nzmin || nz > nzmax - 1)) DA2(m.Ki, nz, n) = fk_old;      // (a level outside the column: never read)
+  }
+  if (m.p.Fer_GM && nz >= nzmin && nz <= nzmax) DA2L(m.fer_K, nz, n) = fb * zs;
+  if (m.p.Redi) {
     const double zs_dn = shdn(zs);
     if (nz >= nzmin && nz <= nzmax - 1) DA2(m.Ki, nz, n) = kb * 0.5 * (zs + zs_dn);
   }

@@ -62,6 +62,7 @@ int orc_init(const fesom_mesh_desc *m, const fesom_params *p) {
   C_.toy_bpos = calloc(E ? E : 1, sizeof(int));
   C_.MLD1_ind = calloc(N ? N : 1, sizeof(int));
   for (size_t i = 0; i < n1 * N; i++) C_.density_ref[i] = DENSITY_0;
+  for (size_t i = 0; i < nl * N; i++) C_.fer_K[i] = 500.0;                              /* oce_setup_step.F90:359 (read back under an ice shelf: init_Redi_GM scales fer_k(ulevels_nod2D) where the template went to another level) */
   memcpy(C_.ssh_values, m->ssh_values, sizeof(double) * m->ssh_nza);
   /* Ki = K_hor*(mesh_resolution/100000)**2  (oce_setup_step.F90:328-331) */
   for (size_t n = 0; n < N; n++) {

@@ -38,8 +38,11 @@ void orc_init_Redi_GM(void) {
     }
     if (redi) { double q = reso / 100000.0; A2(C_.Ki, nzmin, n) = C_.p.K_hor * (q * q); }
   }
-  if (redi && gm)                                          /* "like in FESOM 1.4 we make Redi equal GM" (whole array) */
-    for (int n = 1; n <= C_.N; n++) A2(C_.Ki, ULEVN(n), n) = A2L(C_.fer_K, ULEVN(n), n);
+  if (redi && gm) {                                        /* "like in FESOM 1.4 we make Redi equal GM": Ki(nzmin,:)=fer_k(nzmin,:) OUTSIDE the node loop (:249-250), i.e.
+                                                            * at the level the loop left in nzmin -- the upper level of the LAST owned node -- for every node */
+    const int nzl = C_.m.ulevels_nod2D_max[C_.m.myDim_nod2D - 1];
+    for (int n = 1; n <= C_.N; n++) A2(C_.Ki, nzl, n) = A2L(C_.fer_K, nzl, n);
+  }
   for (int n = 1; n <= C_.m.myDim_nod2D; n++) {
     int nzmax = NLEVN(n), nzmin = ULEVN(n);
     if (C_.p.scaling_Ferreira) {

@@ -153,6 +153,11 @@ CFGS = {
                          rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                          fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
                          balance_salt_water=".true.", use_cavity=".true.", synth_forcing=True),
+    # the same cavity mesh under the reference's default physics (KPP + GM + Redi)
+    "pi_default_cavity": dict(mesh="pi_cavity", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                              rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                              fer_gm=".true.", redi=".true.", mix_scheme="KPP", k_hor="3000.", surf_relax_s="1.929e-06",
+                              balance_salt_water=".true.", use_cavity=".true.", synth_forcing=True),
     # pi mesh, 47 layers, zstar + partial cells, JM EOS, PP mixing, no GM/Redi (round-1 closure config)
     "pi_pp": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
                   rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,

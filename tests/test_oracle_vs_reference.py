@@ -564,3 +564,56 @@ def test_oracle_chain_bitwise_kv0_background(built, mix, cfg):
         orc.set(f, g["forcing/" + f])
     bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
     assert not bad, "\n".join(bad[:20])
+
+
+CAVITY = os.path.join(REPO, "tests", "golden", "meshes", "pi_cavity")
+
+
+def test_mesh_layer_bitwise_cavity(built):
+    """use_cavity=.true.: the upper levels ulevels / ulevels_nod2D(_max) and the cavity depth read from cavity_elvls / cavity_nlvls / cavity_depth
+    (src/oce_mesh.F90:897-1280), areasvol from the lower face under a shelf (mesh_areas, :1986-2050), zbar_e_srf / zbar_n_srf at the upper level
+    (src/oce_ale.F90:520-560) and everything else of the set-up == the reference run `pi_pp_cavity` on tests/golden/meshes/pi_cavity
+    (tests/golden/make_cavity_mesh.py: a synthetic draft on the pi mesh -- the reference ships no cavity mesh)."""
+    from fesom2_amd.mesh import Mesh
+    g = gold("pi_pp_cavity")
+    mesh = Mesh.load(CAVITY, dt=900.0, use_cavity=True)
+    assert (mesh.ulevels > 1).sum() > 700 and (mesh.ulevels_nod2D > 1).sum() > 300
+    bad = []
+    for f in SETUP_FIELDS + ["ulevels", "ulevels_nod2D", "ulevels_nod2D_max"]:
+        if "setup/" + f not in g:
+            continue
+        ok, msg = check_digest(getattr(mesh, f), g["setup/" + f])
+        if not ok:
+            bad.append(f"{f}: {msg}")
+    st = mesh.initial_state(2)
+    for f in ("hnode", "helem", "zbar_3d_n", "Z_3d_n", "eta_n", "hbar"):
+        ok, msg = check_digest(getattr(st, f), g["setup/" + f])
+        if not ok:
+            bad.append(f"state {f}: {msg}")
+    assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("cfg,kw", [("pi_pp_cavity", dict()), ("pi_default_cavity", dict(mix_scheme="KPP", Fer_GM=True, Redi=True))])
+def test_oracle_chain_bitwise_cavity(built, cfg, kw):
+    """Ice-shelf cavities (use_cavity=.true.): every routine of the step from its column's upper level, the reference density profile of
+    init_ref_density (src/oce_ale_pressure_bv.F90:3036-3073; use_density_ref is forced on, src/oce_setup_step.F90), pressure_bv's interface-water fill
+    above the shelf base and the cavity branch of hpressure (:214-260, :420-470), the FCT bounds that see the untouched scratch entries above an element's
+    upper level (src/oce_adv_tra_fct.F90:110-142) and CFL_z accumulating at the top of a cavity column (src/oce_ale.F90:2141-2152): reference runs
+    `pi_pp_cavity` (PP) and `pi_default_cavity` (KPP + GM + Redi), 2 ranks, surface forcing, every routine of 3 steps bit for bit."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.synthetic import analytic_ts
+    from oracle_lib import Oracle
+    from ref_chain import run_reference_chain
+    mesh = Mesh.load(CAVITY, dt=900.0, use_cavity=True)
+    par = make_params(dt=900.0, use_cavity=True, **kw)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(CAVITY)
+    st.tr_arr_old[...] = st.tr_arr
+    orc = Oracle(mesh, par)
+    orc.set_state(st)
+    g = gold(cfg)
+    for f in FORCING:
+        orc.set(f, g["forcing/" + f])
+    bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
+    assert not bad, "\n".join(bad[:20])
