@@ -79,6 +79,8 @@ module fesom_gpu_shim
      real(c_double) :: min_hnode
      real(c_double) :: c_back, K_back, uke_scaling_factor, rosb_dis, scale_area
      integer(c_int) :: uke_scaling, smooth_back, smooth_dis, smooth_back_tend
+     integer(c_int) :: use_cavity, use_density_ref
+     real(c_double) :: density_ref_T, density_ref_S
   end type
   type, bind(C) :: fesom_state_desc
      type(c_ptr) :: tr_arr, tr_arr_old, UV, UV_rhsAB, eta_n, d_eta, ssh_rhs, ssh_rhs_old, hbar, hbar_old, dhe, hnode, hnode_new, &
@@ -311,7 +313,7 @@ contains
        call status_check
     end if
 
-    call refuse(use_cavity .or. use_cavity_partial_cell, 'use_cavity / use_cavity_partial_cell (ice-shelf cavities)')
+    call refuse(use_cavity_partial_cell, 'use_cavity_partial_cell (partial cells at the ice-shelf base; cavities with full cells there are taken)')
     call refuse(use_kpp_nonlclflx .and. mix_scheme_nmb /= 1, 'use_kpp_nonlclflx with a mixing scheme other than KPP (oce_ale_tracer.F90:725)')
     call refuse(SPP .and. .not. (allocated(thdgr) .and. allocated(S_oc_array)), 'SPP without the sea-ice arrays thdgr / S_oc_array (gen_forcing_init.F90:134, ice_setup_step.F90:127)')
     call refuse(use_momix .and. .not. allocated(mixlength), 'use_momix without the ice arrays (the reference allocates mo / mixlength only with use_ice, oce_setup_step.F90:218)')
@@ -377,6 +379,7 @@ contains
     p%lzstar_lev = lzstar_lev; p%min_hnode = min_hnode
     p%c_back = c_back; p%K_back = K_back; p%uke_scaling_factor = uke_scaling_factor; p%rosb_dis = rosb_dis; p%scale_area = scale_area
     p%uke_scaling = l2i(uke_scaling); p%smooth_back = smooth_back; p%smooth_dis = smooth_dis; p%smooth_back_tend = smooth_back_tend
+    p%use_cavity = l2i(use_cavity); p%use_density_ref = l2i(use_density_ref); p%density_ref_T = density_ref_T; p%density_ref_S = density_ref_S
     p%solver_precond = 1; p%solver_xinv_its = 0     ! explicit-inverse preconditioner where it fits (pi), library default iterations
 
     transport%ctx = c_null_ptr
@@ -387,6 +390,8 @@ contains
     if (npes > 1) call setup_builtin_transport
     call state_desc(mesh, st)
     call check(c_fesom_gpu_upload_state(st), 'fesom_gpu_upload_state')
+    ! the reference density profile ocean_setup formed from the initial layer depths (init_ref_density, oce_setup_step.F90:129): the host's array, not a recomputation from a restarted state
+    if (use_density_ref .and. allocated(density_ref)) call check(c_fesom_gpu_set_field('density_ref'//c_null_char, ar(density_ref), int(size(density_ref), c_long_long)), 'fesom_gpu_set_field(density_ref)')
     if (use_momix .and. allocated(mixlength)) call check(c_fesom_gpu_set_field('mixlength'//c_null_char, ar(mixlength), int(size(mixlength), c_long_long)), 'fesom_gpu_set_field(mixlength)')
     if (clim_relax > 1.0e-8_WP .and. .not. toy_ocean) then        ! relax_to_clim: the static climatology and the nodal rate
        call check(c_fesom_gpu_set_field('Tclim'//c_null_char, ar(Tclim), int(size(Tclim), c_long_long)), 'fesom_gpu_set_field(Tclim)')

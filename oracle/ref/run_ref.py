@@ -103,6 +103,7 @@ visc_sh_limit=5.0e-3
 mix_scheme='{mix_scheme}'
 Ricr=0.3
 concv=1.6
+use_density_ref={use_density_ref}
 /
 &oce_tra
 use_momix={use_momix}
@@ -158,6 +159,11 @@ CFGS = {
                               rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                               fer_gm=".true.", redi=".true.", mix_scheme="KPP", k_hor="3000.", surf_relax_s="1.929e-06",
                               balance_salt_water=".true.", use_cavity=".true.", synth_forcing=True),
+    # use_density_ref=.true. without cavities: density_m_rho0 against the profile of init_ref_density (T=2, S=34) instead of density_0
+    "pi_pp_dref": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                       rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                       fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                       balance_salt_water=".true.", use_density_ref=".true.", synth_forcing=True),
     # pi mesh, 47 layers, zstar + partial cells, JM EOS, PP mixing, no GM/Redi (round-1 closure config)
     "pi_pp": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
                   rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
@@ -442,7 +448,7 @@ def prepare(cfg, np_, tag=""):
             partition_io.write_dist(cp, np_)
         meshdir = cp
     open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **dict(dict(use_sw_pene=".false.", use_floatice=".false.", min_hnode="0.5", which_toy="soufflet", use_cavity=".false."), **c)))
-    open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0", visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=".true.", tra_adv_lim="FCT", use_momix=".false.", which_pgf="shchepetkin", mom_adv=2, use_kpp_nonlclflx=".false.", double_diffusion=".false.", smooth_bh_tra=".false.", clim_relax="0.0", SPP=".false."), **c)))
+    open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0", visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=".true.", tra_adv_lim="FCT", use_momix=".false.", which_pgf="shchepetkin", mom_adv=2, use_kpp_nonlclflx=".false.", double_diffusion=".false.", smooth_bh_tra=".false.", clim_relax="0.0", SPP=".false.", use_density_ref=".false."), **c)))
     if c["toy_ocean"] == ".false." or c.get("which_toy", "soufflet") != "soufflet":
         from fesom2_amd.synthetic import write_ic_files
         write_ic_files(meshdir, rd)

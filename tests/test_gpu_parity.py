@@ -1099,3 +1099,43 @@ def test_cavity_chain_bitwise(built, kw):
             ok, msg = compare(f, a, b)
             assert ok, msg
     gpu.close()
+
+
+def test_density_ref_chain_bitwise(built):
+    """use_density_ref=.true. without cavities (oracle pinned on the reference run pi_pp_dref): k_init_density_ref at the first state upload, k_pressure_bv against
+    the profile: HIP == oracle bit for bit after every routine of 2 steps and after 6 further whole steps."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.core import OceanCore
+    from fesom2_amd.synthetic import analytic_ts, analytic_forcing
+    from oracle_lib import Oracle
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, use_density_ref=True)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    gpu, orc = OceanCore(mesh, par), Oracle(mesh, par)
+    gpu.upload_state(st); orc.set_state(st)
+    forcing = analytic_forcing(mesh)
+    gpu.set_forcing(**forcing)
+    for k, v in forcing.items():
+        orc.set(k, v)
+    ok, msg = compare("density_ref", gpu.get("density_ref", orc.count("density_ref")), orc.get("density_ref"))
+    assert ok, msg
+    assert np.ptp(orc.get("density_ref")) > 1.0                    # (a profile, not density_0)
+    failures = []
+    for step in range(1, 3):
+        for routine, arg, fields in full_chain(2):
+            gpu.call(routine, arg); orc.call(routine, arg)
+            for f in fields:
+                ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+                if not ok:
+                    failures.append(f"step {step} {routine}({arg}) {msg}")
+    assert not failures, "\n".join(failures[:15])
+    gpu.run_steps(3, 6)
+    for n in range(3, 9):
+        orc.call("step", n)
+    for f in ("tr_arr", "UV", "eta_n", "hnode", "density_m_rho0"):
+        ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+        assert ok, msg
+    gpu.close()

@@ -617,3 +617,26 @@ def test_oracle_chain_bitwise_cavity(built, cfg, kw):
         orc.set(f, g["forcing/" + f])
     bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
     assert not bad, "\n".join(bad[:20])
+
+
+def test_oracle_chain_bitwise_density_ref(built):
+    """use_density_ref=.true. without cavities (namelist.oce &oce_dyn): density_m_rho0 and the densities of the nemo / cubic-spline PGF against the profile
+    init_ref_density forms from (density_ref_T, density_ref_S) at the initial layer depths (src/oce_ale_pressure_bv.F90:3036-3073) instead of density_0;
+    reference run `pi_pp_dref`, every routine of 3 steps bit for bit."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.synthetic import analytic_ts
+    from oracle_lib import Oracle
+    from ref_chain import run_reference_chain
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, use_density_ref=True)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    orc = Oracle(mesh, par)
+    orc.set_state(st)
+    g = gold("pi_pp_dref")
+    for f in FORCING:
+        orc.set(f, g["forcing/" + f])
+    bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
+    assert not bad, "\n".join(bad[:20])
