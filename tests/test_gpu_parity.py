@@ -990,7 +990,8 @@ def test_kv0_background_steps(built, mix):
     gpu.close()
 
 
-@pytest.mark.parametrize("shape,kw", [(1, dict()), (3, dict()), (1, dict(mix_scheme="KPP", Fer_GM=True, Redi=True)), (2, dict(which_ale="linfs", use_partial_cell=True))])
+@pytest.mark.parametrize("shape,kw", [(1, dict()), (3, dict()), (1, dict(mix_scheme="KPP", Fer_GM=True, Redi=True)), (2, dict(which_ale="linfs", use_partial_cell=True)),
+                                      (1, dict(use_cavity=True)), (3, dict(use_cavity=True, mix_scheme="KPP", Fer_GM=True, Redi=True))])
 def test_tile_shapes_chain_and_steps_bitwise(built, shape, kw):
     """The kernel shapes of CORE2-class meshes (DM::use_tile: k_tr_update / k_impl_visc tiles, k_edge_transport_tile, k_pgf_tile, k_flux_hor with
     fill_up_dn_grad on the fly), forced on pi with FESOM_GPU_TILE=<shape>: HIP == oracle bit for bit after every routine of 2 steps and after 6
@@ -1001,11 +1002,12 @@ def test_tile_shapes_chain_and_steps_bitwise(built, shape, kw):
     from fesom2_amd.synthetic import analytic_ts, analytic_forcing
     from oracle_lib import Oracle
     kpp = kw.get("mix_scheme") == "KPP"
-    mkw = {k: v for k, v in kw.items() if k in ("which_ale", "use_partial_cell")}
-    mesh = Mesh.load(PI, dt=900.0, **mkw)
+    mkw = {k: v for k, v in kw.items() if k in ("which_ale", "use_partial_cell", "use_cavity")}
+    D = os.path.join(os.path.dirname(PI), "pi_cavity") if kw.get("use_cavity") else PI      # (cavities: the shapes with upper levels > 1)
+    mesh = Mesh.load(D, dt=900.0, **mkw)
     par = make_params(dt=900.0, **kw)
     st = mesh.initial_state(2)
-    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(D)
     st.tr_arr_old[...] = st.tr_arr
     old = os.environ.get("FESOM_GPU_TILE")
     os.environ["FESOM_GPU_TILE"] = str(shape)
