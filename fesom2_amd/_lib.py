@@ -64,7 +64,7 @@ class Params(C.Structure):
                    ("use_floatice", C.c_int), ("l_mslp", C.c_int), ("use_global_tides", C.c_int), ("max_ice_loading", C.c_double), ("SPP", C.c_int), ("Sice", C.c_double), ("clim_relax", C.c_double), ("lzstar_lev", C.c_int), ("min_hnode", C.c_double),
                    ("c_back", C.c_double), ("K_back", C.c_double), ("uke_scaling_factor", C.c_double), ("rosb_dis", C.c_double), ("scale_area", C.c_double),
                    ("uke_scaling", C.c_int), ("smooth_back", C.c_int), ("smooth_dis", C.c_int), ("smooth_back_tend", C.c_int),
-                   ("use_cavity", C.c_int), ("use_density_ref", C.c_int), ("density_ref_T", C.c_double), ("density_ref_S", C.c_double)])
+                   ("use_cavity", C.c_int), ("use_density_ref", C.c_int), ("density_ref_T", C.c_double), ("density_ref_S", C.c_double), ("use_cavity_partial_cell", C.c_int)])
 
 
 STATE_FIELDS = ("tr_arr", "tr_arr_old", "UV", "UV_rhsAB", "eta_n", "d_eta", "ssh_rhs", "ssh_rhs_old", "hbar",
@@ -105,7 +105,7 @@ class MeshOpts(C.Structure):
     _fields_ = [("force_rotation", C.c_int), ("cyclic_length_deg", C.c_double), ("alphaEuler_deg", C.c_double),
                 ("betaEuler_deg", C.c_double), ("gammaEuler_deg", C.c_double), ("use_partial_cell", C.c_int),
                 ("which_ale", C.c_int), ("dt", C.c_double), ("alpha", C.c_double), ("theta", C.c_double),
-                ("K_hor", C.c_double), ("npes", C.c_int), ("mype", C.c_int), ("use_cavity", C.c_int)]
+                ("K_hor", C.c_double), ("npes", C.c_int), ("mype", C.c_int), ("use_cavity", C.c_int), ("use_cavity_partial_cell", C.c_int), ("cavity_partial_cell_thresh", C.c_double)]
 
 
 # every symbol include/fesom_gpu.h declares

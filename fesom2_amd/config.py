@@ -13,7 +13,7 @@ def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equati
                 gamma0=0.003, gamma1=0.1, gamma2=0.285, easy_bs_return=1.5, C_d=0.0025, w_max_cfl=1.0, use_sw_pene=False, visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=True,
                 solver_precond=1, solver_xinv_its=0, tra_adv_lim="FCT", Leith_c=0.05, Div_c=0.5, which_pgf="shchepetkin", use_momix=False, momix_lat=-50.0, momix_kv=0.01, mom_adv=2, use_kpp_nonlclflx=False, ref_sss_local=True, ref_sss=34.0, double_diffusion=False, smooth_bh_tra=False, use_floatice=False, l_mslp=False, use_global_tides=False, max_ice_loading=5.0, clim_relax=0.0, SPP=False, Sice=4.0, min_hnode=0.5, lzstar_lev=4,
                 c_back=0.1, K_back=600.0, uke_scaling=True, uke_scaling_factor=1.0, rosb_dis=1.0, smooth_back=2, smooth_dis=2, smooth_back_tend=4, scale_area=5.8e9,
-                use_cavity=False, use_density_ref=None, density_ref_T=2.0, density_ref_S=34.0):
+                use_cavity=False, use_density_ref=None, density_ref_T=2.0, density_ref_S=34.0, use_cavity_partial_cell=False):
     p = _lib.Params()
     p.dt = dt
     p.which_ale = WHICH_ALE[which_ale]
@@ -52,7 +52,7 @@ def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equati
     p.solver_precond, p.solver_xinv_its = int(solver_precond), int(solver_xinv_its)
     p.tra_adv_lim = {"FCT": 0, "NON": 1}[tra_adv_lim]
     p.Leith_c, p.Div_c = Leith_c, Div_c              # config/namelist.oce:8-9
-    p.which_pgf = {"shchepetkin": 0, "cubicspline": 1, "nemo": 2, "easypgf": 3}.get(which_pgf, -1)  # oce_modules.F90:172
+    p.which_pgf = {"shchepetkin": 0, "cubicspline": 1, "nemo": 2, "easypgf": 3, "sergey": 4}.get(which_pgf, -1)  # oce_modules.F90:172
     p.use_momix, p.momix_lat, p.momix_kv = int(use_momix), momix_lat, momix_kv   # config/namelist.oce:48-50
     # ocean_setup (src/oce_setup_step.F90:42-47): unless which_ALE = 'linfs' the reference sets ref_sss_local = .false., ref_sss = 0 ("this will force the
     # virtual salinity flux to be zero"), whatever the namelist says -- the salt part of the KPP non-local transport vanishes with it
@@ -66,6 +66,7 @@ def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equati
     p.c_back, p.K_back, p.uke_scaling_factor, p.rosb_dis, p.scale_area = c_back, K_back, uke_scaling_factor, rosb_dis, scale_area
     p.uke_scaling, p.smooth_back, p.smooth_dis, p.smooth_back_tend = int(uke_scaling), int(smooth_back), int(smooth_dis), int(smooth_back_tend)
     p.use_cavity = int(use_cavity)
+    p.use_cavity_partial_cell = int(use_cavity_partial_cell)
     p.use_density_ref = int(use_cavity if use_density_ref is None else use_density_ref)      # (ocean_setup switches it on with cavities, oce_setup_step.F90:122)
     p.density_ref_T, p.density_ref_S = density_ref_T, density_ref_S
     linfs = (which_ale == "linfs")

@@ -460,8 +460,9 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   if (par->visc_option == 8 && part && part->npes > 1) { G.err = "fesom_gpu_init: visc_option=8 (backscatter with the uke budget) is built for one partition"; return 3; }
   // (mom_adv = 3 reads hpressure, which the reference forms with which_ALE='linfs' only, oce_ale_pressure_bv.F90:262; with zstar / zlevel the array keeps
   //  the zeros of array_setup, oce_setup_step.F90:384, and compute_vel_rhs_vinv runs without a baroclinic pressure term -- kept as it is: run pi_pp_vinv)
-  if (par->which_pgf != 0 && par->which_pgf != 1 && !(par->which_pgf == 2 && par->which_ale == 0) && !(par->which_pgf == 3) && !(par->which_ale == 0 && !par->use_partial_cell)) {
-    G.err = "fesom_gpu_init: which_pgf must be 'shchepetkin' (0), 'cubicspline' (1), with linfs 'nemo' (2) or 'easypgf' (3); the cavity scheme 'sergey' is not implemented"; return 3;
+  const bool pgf_cav = par->which_ale == 0 && par->use_cavity && par->use_cavity_partial_cell;       // linfs with partial cells at the shelf base: 'sergey', 'shchepetkin', 'easypgf' (src/oce_ale_pressure_bv.F90:388-403)
+  if (par->which_pgf != 0 && par->which_pgf != 1 && !(par->which_pgf == 2 && par->which_ale == 0) && !(par->which_pgf == 3) && !(par->which_pgf == 4 && pgf_cav) && !(par->which_ale == 0 && !par->use_partial_cell && !pgf_cav)) {
+    G.err = "fesom_gpu_init: which_pgf must be 'shchepetkin' (0), 'cubicspline' (1), with linfs 'nemo' (2), 'easypgf' (3), or with linfs and use_cavity_partial_cell 'sergey' (4)"; return 3;
   }
   if (par->Fer_GM && par->scaling_Rossby) { G.err = "fesom_gpu_init: scaling_Rossby=.true. (GM cut-off by the Rossby radius) is not implemented"; return 3; }
   if (par->tra_adv_ver < 0 || par->tra_adv_ver > 3 || par->tra_adv_hor < 0 || par->tra_adv_hor > 2) {
@@ -473,7 +474,8 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   if (!par->use_cavity)
     for (int e = 0; e < d->myDim_elem2D + d->eDim_elem2D; e++)
       if (d->ulevels[e] != 1) { G.err = "fesom_gpu_init: the mesh has ice-shelf cavities (ulevels > 1) but use_cavity is off"; return 3; }
-  if (par->use_cavity && par->which_pgf != 0 && par->which_pgf != 3) { G.err = "fesom_gpu_init: with cavities which_pgf must be 'shchepetkin' or 'easypgf' (the scheme 'sergey', pressure_force_4_linfs_cavity, is not implemented)"; return 3; }
+  if (par->use_cavity && par->which_pgf != 0 && par->which_pgf != 3 && par->which_pgf != 1 && !(par->which_pgf == 2 && par->which_ale == 0 && !pgf_cav) && !(par->which_pgf == 4 && pgf_cav) && !(par->which_ale == 0 && !par->use_partial_cell && !pgf_cav)) {
+    G.err = "fesom_gpu_init: with cavities which_pgf must be 'shchepetkin', 'easypgf' or (linfs with use_cavity_partial_cell) 'sergey'; 'cubicspline' and 'nemo' only with their own conditions"; return 3; }
   if (fesom_internal_select_device(G.err)) { fprintf(stderr, "fesom_gpu: %s\n", G.err.c_str()); return 2; }
   HIPCHK(hipStreamCreate(&G.stream));
   for (int i = 0; i < 3; i++) HIPCHK(hipStreamCreateWithFlags(&G.side[i], hipStreamNonBlocking));   // (stream priorities: no effect, measured)
@@ -607,7 +609,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
   m.elem_area = dev_upload_d(d->elem_area, EX); m.area = dev_upload_d(d->area, nl * N); m.areasvol = dev_upload_d(d->areasvol, nl * N);
   m.areasvol_inv = dev_upload_d(d->areasvol_inv, nl * N); m.gsca = dev_upload_d(d->gradient_sca, 6 * (size_t)m.myE);
   m.ecd = dev_upload_d(d->edge_cross_dxdy, 4 * D); m.edxy = dev_upload_d(d->edge_dxdy, 2 * D); m.elem_cos = dev_upload_d(d->elem_cos, EX);
-  m.coriolis = dev_upload_d(d->coriolis, m.myE); m.zbar_e_bot = dev_upload_d(d->zbar_e_bot, E); m.zbar_n_bot = dev_upload_d(d->zbar_n_bot, N);
+  m.coriolis = dev_upload_d(d->coriolis, m.myE); m.zbar_e_bot = dev_upload_d(d->zbar_e_bot, E); m.zbar_e_srf = dev_upload_d(d->zbar_e_srf, E); m.zbar_n_bot = dev_upload_d(d->zbar_n_bot, N);
   m.zbar = dev_upload_d(d->zbar, nl); m.Z = dev_upload_d(d->Z, n1);
   // ---- fields
 #define F(f, c) m.f = field(#f, c)
@@ -643,7 +645,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     FT(cl_grad, 2 * n1 * N);
   }
   F(ssh_values, m.nza);
-  if (par->which_pgf == 0 && !(par->which_ale == 0 && !par->use_partial_cell)) { F(pgf_A, n1 * N); F(pgf_B, n1 * N); }      // shchepetkin variants
+  if ((par->which_pgf == 0 && !(par->which_ale == 0 && !par->use_partial_cell && !pgf_cav)) || par->which_pgf == 4) { F(pgf_A, n1 * N); F(pgf_B, n1 * N); }      // shchepetkin variants, 'sergey'
   if (par->visc_option <= 3) { F(Visc, n1 * E); F(leith_aux, n1 * N); }
   if (par->visc_option == 8) {
     F(uke, n1 * E); F(v_back, n1 * E); F(uke_rhs, n1 * E); F(uke_rhs_old, n1 * E); F(uke_dif, n1 * E); F(uke_dis, n1 * E); F(uke_back, n1 * E);

@@ -40,6 +40,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   // ---- geometry
   const double *elem_area, *area, *areasvol, *areasvol_inv, *gsca, *ecd, *edxy, *elem_cos, *coriolis;
   const double *zbar_e_bot, *zbar_n_bot, *zbar, *Z;
+  const double *zbar_e_srf;                               // (E) upper face of the element column: 0, or the shelf base (pressure boundary term of the linfs cubic-spline gradient under a shelf)
   // ---- fields (same names as o_ARRAYS / o_MESH)
   double *tr_arr, *tr_arr_old, *density_m_rho0, *hnode, *hnode_new, *Z_3d_n, *sw_alpha, *sw_beta;
   double *del_ttf, *fct_LO, *fct_ttf_max, *fct_ttf_min, *fct_plus, *fct_minus, *Ki;

@@ -242,7 +242,8 @@ __global__ void __launch_bounds__(BLOCK) k_pgf(DM m) {
   const int nle = m.nlev[e] - 1, ule = m.ulev[e];
   const bool wet = (nlz >= ule && nlz <= nle);
   const int n0 = m.elem_nodes[3 * e], n1 = m.elem_nodes[3 * e + 1], n2 = m.elem_nodes[3 * e + 2];
-  if (m.p.which_ale == 0 && !m.p.use_partial_cell) {
+  const bool cav_pc = m.p.use_cavity && m.p.use_cavity_partial_cell;      // linfs: the full-cell gradient only without partial cells at the bottom AND at the shelf base (:385)
+  if (m.p.which_ale == 0 && !m.p.use_partial_cell && !cav_pc) {
     if (wet) {
       DA2(m.pgf_x, nlz, e) = DGS(1, e) * DA2L(m.hpressure, nlz, n0) / D_RHO0 + DGS(2, e) * DA2L(m.hpressure, nlz, n1) / D_RHO0 +
                              DGS(3, e) * DA2L(m.hpressure, nlz, n2) / D_RHO0;
@@ -294,13 +295,14 @@ __global__ void __launch_bounds__(BLOCK) k_pgf(DM m) {
   double zb_bot = shdn(zb_top);                                          // zbar_n(nlz+1)
   if (nlz == nle) zb_bot = m.zbar_e_bot[e];
   double Zn = zb_bot + he * 0.5;                                         // Z_n(nlz)
-  double auxx = 0.0, auxy = 0.0;
+  double auxx = 0.0, auxy = 0.0, p0x = 0.0, p0y = 0.0;
   if (wet && m.p.which_pgf == 1 && m.p.which_ale == 0) {   // 'cubicspline', linfs with partial cells (:1252-1444): flat layers, spline in the bottom layer
     double r0, r1, r2;
     if (nlz == nle && nle > ule) { r0 = pgf_cubic_rho<true>(m, n0, Zn); r1 = pgf_cubic_rho<true>(m, n1, Zn); r2 = pgf_cubic_rho<true>(m, n2, Zn); }
     else { r0 = DA2(m.density_m_rho0, nlz, n0); r1 = DA2(m.density_m_rho0, nlz, n1); r2 = DA2(m.density_m_rho0, nlz, n2); }
     const double gx = (DGS(1, e) * r0 + DGS(2, e) * r1) + DGS(3, e) * r2, gy = (DGS(4, e) * r0 + DGS(5, e) * r1) + DGS(6, e) * r2;
     auxx = gx * he * D_G / D_RHO0; auxy = gy * he * D_G / D_RHO0;
+    if (nlz == ule && ule > 1) { p0x = gx * (-m.zbar_e_srf[e]) * D_G / D_RHO0; p0y = gy * (-m.zbar_e_srf[e]) * D_G / D_RHO0; }      // pressure boundary condition at the shelf base (:1316-1335)
   } else if (wet && m.p.which_pgf == 1) {                  // 'cubicspline', zstar (:1697-1866)
     const double r0 = pgf_cubic_rho<false>(m, n0, Zn), r1 = pgf_cubic_rho<false>(m, n1, Zn), r2 = pgf_cubic_rho<false>(m, n2, Zn);
     const double gx = (DGS(1, e) * r0 + DGS(2, e) * r1) + DGS(3, e) * r2, gy = (DGS(4, e) * r0 + DGS(5, e) * r1) + DGS(6, e) * r2;
@@ -312,7 +314,7 @@ __global__ void __launch_bounds__(BLOCK) k_pgf(DM m) {
 #pragma unroll
     for (int ni = 0; ni < 3; ni++) {
       int n = en[ni], k0;
-      if (m.p.which_ale == 0 && nlz != nle) { r3[ni] = DA2(m.density_m_rho0, nlz, n); continue; }      // pressure_force_4_linfs_easypgf (:898-1245): flat above the bottom layer
+      if (m.p.which_ale == 0 && nlz != nle && !(nlz == ule && ule > 1)) { r3[ni] = DA2(m.density_m_rho0, nlz, n); continue; }      // pressure_force_4_linfs_easypgf (:898-1245): flat above the bottom layer, except directly under a shelf
       if (nlz == ule && (nlz - m.ulev_n[n]) == 0) k0 = nlz + 1;
       else if (nlz == nle && nlz != ule && (m.nlev_n[n] - 1 - nlz) == 0) k0 = nlz - 1;
       else k0 = nlz;
@@ -349,20 +351,42 @@ __global__ void __launch_bounds__(BLOCK) k_pgf(DM m) {
     double drho_dx = DGS(1, e) * rho_c[0] + DGS(2, e) * rho_c[1] + DGS(3, e) * rho_c[2];
     double dz_dx = DGS(1, e) * z_c[0] + DGS(2, e) * z_c[1] + DGS(3, e) * z_c[2];
     // pressure_force_4_linfs_shchepetkin (:647-891, linfs with partial cells): the Jacobian correction only in the bottom layer
-    const bool flat = m.p.which_ale == 0 && nlz != nle;
+    const bool flat = m.p.which_ale == 0 && nlz != nle && !(nlz == ule && ule > 1);      // (directly under a shelf the correction stays, :703-776)
     auxx = flat ? drho_dx * he * D_G / D_RHO0 : (drho_dx - s3 * dz_dx) * he * D_G / D_RHO0;
     double drho_dy = DGS(4, e) * rho_c[0] + DGS(5, e) * rho_c[1] + DGS(6, e) * rho_c[2];
     double dz_dy = DGS(4, e) * z_c[0] + DGS(5, e) * z_c[1] + DGS(6, e) * z_c[2];
     auxy = flat ? drho_dy * he * D_G / D_RHO0 : (drho_dy - s3 * dz_dy) * he * D_G / D_RHO0;
   }
+  if (m.p.which_pgf == 4) {
+    // 'sergey' = pressure_force_4_linfs_cavity (:1451-1663; linfs with partial cells at the shelf base): the gradient of the hydrostatic pressure, except
+    // directly under a shelf (half the density-Jacobian term of that layer) and, with partial cells, in the bottom layer (pressure at its upper face + half the term)
+    if (!wet) return;
+    const bool top = nlz == ule && ule > 1, bot = nlz == nle && m.p.use_partial_cell;
+    double px, py;
+    if (top) { px = auxx * 0.5; py = auxy * 0.5; }
+    else if (bot) {
+      const double h0 = (DA2L(m.hpressure, nlz - 1, n0) + 0.5 * D_G * (DA2(m.density_m_rho0, nlz - 1, n0) * DA2(m.hnode, nlz - 1, n0))),
+                   h1 = (DA2L(m.hpressure, nlz - 1, n1) + 0.5 * D_G * (DA2(m.density_m_rho0, nlz - 1, n1) * DA2(m.hnode, nlz - 1, n1))),
+                   h2 = (DA2L(m.hpressure, nlz - 1, n2) + 0.5 * D_G * (DA2(m.density_m_rho0, nlz - 1, n2) * DA2(m.hnode, nlz - 1, n2)));
+      px = (DGS(1, e) * h0 / D_RHO0 + DGS(2, e) * h1 / D_RHO0 + DGS(3, e) * h2 / D_RHO0) + auxx * 0.5;
+      py = (DGS(4, e) * h0 / D_RHO0 + DGS(5, e) * h1 / D_RHO0 + DGS(6, e) * h2 / D_RHO0) + auxy * 0.5;
+    } else {
+      px = DGS(1, e) * DA2L(m.hpressure, nlz, n0) / D_RHO0 + DGS(2, e) * DA2L(m.hpressure, nlz, n1) / D_RHO0 + DGS(3, e) * DA2L(m.hpressure, nlz, n2) / D_RHO0;
+      py = DGS(4, e) * DA2L(m.hpressure, nlz, n0) / D_RHO0 + DGS(5, e) * DA2L(m.hpressure, nlz, n1) / D_RHO0 + DGS(6, e) * DA2L(m.hpressure, nlz, n2) / D_RHO0;
+    }
+    DA2(m.pgf_x, nlz, e) = px; DA2(m.pgf_y, nlz, e) = py;
+    return;
+  }
   // int_dp_dx after level nlz: first level assigns aux, later levels add (reference order)
   double ax0 = bcast(auxx, ule - 1), ay0 = bcast(auxy, ule - 1);
+  const bool has_p0 = m.p.which_pgf == 1 && m.p.which_ale == 0 && ule > 1;                     // (linfs cubic spline under a shelf: the integral starts from the boundary term)
+  if (has_p0) { p0x = bcast(p0x, ule - 1); p0y = bcast(p0y, ule - 1); ax0 = p0x + ax0; ay0 = p0y + ay0; }
   double ix = seq_sum_up(auxx, ule, nle - 1, ax0), iy = seq_sum_up(auxy, ule, nle - 1, ay0);   // inclusive sums
   double ixp = shup(ix), iyp = shup(iy);                                                       // sum before this level
   if (nlz == ule + 1) { ixp = ax0; iyp = ay0; }
   if (wet) {
-    DA2(m.pgf_x, nlz, e) = (nlz == ule) ? auxx * 0.5 : ixp + auxx * 0.5;
-    DA2(m.pgf_y, nlz, e) = (nlz == ule) ? auxy * 0.5 : iyp + auxy * 0.5;
+    DA2(m.pgf_x, nlz, e) = (nlz == ule) ? (has_p0 ? p0x + auxx * 0.5 : auxx * 0.5) : ixp + auxx * 0.5;
+    DA2(m.pgf_y, nlz, e) = (nlz == ule) ? (has_p0 ? p0y + auxy * 0.5 : auxy * 0.5) : iyp + auxy * 0.5;
   }
 }
 
@@ -441,7 +465,7 @@ __global__ void __launch_bounds__(BLOCK) k_pgf_tile(DM m) {
       double s3 = (drho_dz[0] + drho_dz[1] + drho_dz[2]) / 3.0;
       double drho_dx = DGS(1, e) * rho_c[0] + DGS(2, e) * rho_c[1] + DGS(3, e) * rho_c[2];
       double dz_dx = DGS(1, e) * z_c[0] + DGS(2, e) * z_c[1] + DGS(3, e) * z_c[2];
-      const bool flat = m.p.which_ale == 0 && nlz != nle;
+      const bool flat = m.p.which_ale == 0 && nlz != nle && !(nlz == ule && ule > 1);
       auxx = flat ? drho_dx * he * D_G / D_RHO0 : (drho_dx - s3 * dz_dx) * he * D_G / D_RHO0;
       double drho_dy = DGS(4, e) * rho_c[0] + DGS(5, e) * rho_c[1] + DGS(6, e) * rho_c[2];
       double dz_dy = DGS(4, e) * z_c[0] + DGS(5, e) * z_c[1] + DGS(6, e) * z_c[2];
@@ -472,7 +496,7 @@ __global__ void __launch_bounds__(BLOCK) k_pgf_tile(DM m) {
   }
 }
 static void launch_pgf(const DM &m, hipStream_t s) {
-  const bool shch = m.p.which_pgf == 0 && !(m.p.which_ale == 0 && !m.p.use_partial_cell);      // (cubicspline / nemo: k_pgf)
+  const bool shch = m.p.which_pgf == 0 && !(m.p.which_ale == 0 && !m.p.use_partial_cell && !(m.p.use_cavity && m.p.use_cavity_partial_cell));      // (cubicspline / nemo / sergey / full cells: k_pgf)
   if (m.use_tile && shch) {                    // (on pi the tile shape is slower: 21.7 against 11.6 us)
     const int per_block = COLS_PER_BLOCK * PG_ELEMS;
     hipLaunchKernelGGL(k_pgf_tile, dim3((m.myE + per_block - 1) / per_block), dim3(BLOCK), (size_t)COLS_PER_BLOCK * 2 * m.nlm1 * PG_CP * sizeof(double), s, m);

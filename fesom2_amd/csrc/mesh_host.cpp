@@ -498,9 +498,27 @@ void ale_init(Mesh &m) {
     m.bot_n_th[n - 1] = m.zbar[nln - 2] - m.zbar_n_bot[n - 1];
   }
   m.zbar_n_srf.assign(m.N2, m.zbar[0]); m.zbar_e_srf.assign(m.E2, m.zbar[0]);
-  if (m.o.use_cavity) {      // init_surface_elem_depth / init_surface_node_depth (src/oce_ale.F90:420-520), use_cavity_partial_cell = .false.
-    for (int e = 1; e <= m.E2; e++) if (m.ulev[e - 1] > 1) m.zbar_e_srf[e - 1] = m.zbar[m.ulev[e - 1] - 1];
-    for (int n = 1; n <= m.N2; n++) if (m.ulev_n[n - 1] > 1) m.zbar_n_srf[n - 1] = m.zbar[m.ulev_n[n - 1] - 1];
+  if (m.o.use_cavity) {      // init_surface_elem_depth / init_surface_node_depth (src/oce_ale.F90:422-545)
+    for (int e = 1; e <= m.E2; e++) {
+      const int ule = m.ulev[e - 1];
+      if (ule == 1) continue;
+      double zs = m.zbar[ule - 1];
+      if (m.o.use_cavity_partial_cell && !(m.zbar[ule - 1] - m.zbar[ule] <= m.o.cavity_partial_cell_thresh)) {
+        // partial surface cell: the mean draft of the element, at most half a layer away from the full-cell interface (:455-486)
+        const double dd = (m.cavity_depth[EN(1, e) - 1] + m.cavity_depth[EN(2, e) - 1] + m.cavity_depth[EN(3, e) - 1]) / 3.0;
+        zs = (dd < m.zbar[ule - 1]) ? std::max(m.Z[ule - 1], dd) : std::min(m.Z[ule - 2], dd);
+      }
+      m.zbar_e_srf[e - 1] = zs;
+    }
+    for (int n = 1; n <= m.N2; n++) {
+      const int uln = m.ulev_n[n - 1];
+      if (uln == 1) continue;
+      if (m.o.use_cavity_partial_cell) {                    // the highest surface of the elements around the node (:524-538)
+        double mx = m.zbar_e_srf[NIE(1, n) - 1];
+        for (int j = 2; j <= m.nie_num[n - 1]; j++) mx = std::max(mx, m.zbar_e_srf[NIE(j, n) - 1]);
+        m.zbar_n_srf[n - 1] = mx;
+      } else m.zbar_n_srf[n - 1] = m.zbar[uln - 1];
+    }
   }
   m.zbar3.assign((size_t)nl * m.N2, 0.0); m.Z3.assign((size_t)(nl - 1) * m.N2, 0.0);
   for (int n = 1; n <= m.N2; n++) {
@@ -559,6 +577,7 @@ void ale_init(Mesh &m) {
       for (int nz = nzmin; nz <= nzmax - 1; nz++)
         he[nz] = (m.hnode[(size_t)(nl - 1) * (n1 - 1) + nz - 1] + m.hnode[(size_t)(nl - 1) * (n2 - 1) + nz - 1] +
                   m.hnode[(size_t)(nl - 1) * (n3 - 1) + nz - 1]) / 3.0;
+      if (nzmin > 1) { m.dhe[e - 1] = 0.0; he[nzmin] = m.zbar_e_srf[e - 1] - m.zbar[nzmin]; }      // under the shelf the surface is fixed (oce_ale.F90:757-763)
     }
     he[nzmax] = m.bot_e_th[e - 1];
   }

@@ -81,6 +81,7 @@ module fesom_gpu_shim
      integer(c_int) :: uke_scaling, smooth_back, smooth_dis, smooth_back_tend
      integer(c_int) :: use_cavity, use_density_ref
      real(c_double) :: density_ref_T, density_ref_S
+     integer(c_int) :: use_cavity_partial_cell
   end type
   type, bind(C) :: fesom_state_desc
      type(c_ptr) :: tr_arr, tr_arr_old, UV, UV_rhsAB, eta_n, d_eta, ssh_rhs, ssh_rhs_old, hbar, hbar_old, dhe, hnode, hnode_new, &
@@ -313,7 +314,6 @@ contains
        call status_check
     end if
 
-    call refuse(use_cavity_partial_cell, 'use_cavity_partial_cell (partial cells at the ice-shelf base; cavities with full cells there are taken)')
     call refuse(use_kpp_nonlclflx .and. mix_scheme_nmb /= 1, 'use_kpp_nonlclflx with a mixing scheme other than KPP (oce_ale_tracer.F90:725)')
     call refuse(SPP .and. .not. (allocated(thdgr) .and. allocated(S_oc_array)), 'SPP without the sea-ice arrays thdgr / S_oc_array (gen_forcing_init.F90:134, ice_setup_step.F90:127)')
     call refuse(use_momix .and. .not. allocated(mixlength), 'use_momix without the ice arrays (the reference allocates mo / mixlength only with use_ice, oce_setup_step.F90:218)')
@@ -368,6 +368,7 @@ contains
     case ('cubicspline'); p%which_pgf = 1
     case ('nemo'); p%which_pgf = 2
     case ('easypgf'); p%which_pgf = 3
+    case ('sergey'); p%which_pgf = 4
     case default; p%which_pgf = -1
     end select
     p%use_momix = l2i(use_momix); p%momix_lat = momix_lat; p%momix_kv = momix_kv
@@ -380,6 +381,7 @@ contains
     p%c_back = c_back; p%K_back = K_back; p%uke_scaling_factor = uke_scaling_factor; p%rosb_dis = rosb_dis; p%scale_area = scale_area
     p%uke_scaling = l2i(uke_scaling); p%smooth_back = smooth_back; p%smooth_dis = smooth_dis; p%smooth_back_tend = smooth_back_tend
     p%use_cavity = l2i(use_cavity); p%use_density_ref = l2i(use_density_ref); p%density_ref_T = density_ref_T; p%density_ref_S = density_ref_S
+    p%use_cavity_partial_cell = l2i(use_cavity .and. use_cavity_partial_cell)
     p%solver_precond = 1; p%solver_xinv_its = 0     ! explicit-inverse preconditioner where it fits (pi), library default iterations
 
     transport%ctx = c_null_ptr

@@ -61,10 +61,10 @@ class Mesh:
 
     @classmethod
     def load(cls, meshdir, which_ale="zstar", use_partial_cell=True, force_rotation=True, cyclic_length_deg=360.0,
-             dt=900.0, alpha=1.0, theta=1.0, K_hor=3000.0, euler=(50.0, 15.0, -90.0), npes=1, mype=0, use_cavity=False):
+             dt=900.0, alpha=1.0, theta=1.0, K_hor=3000.0, euler=(50.0, 15.0, -90.0), npes=1, mype=0, use_cavity=False, use_cavity_partial_cell=False, cavity_partial_cell_thresh=0.0):
         lib = _lib.load()
         o = _lib.MeshOpts(int(force_rotation), cyclic_length_deg, euler[0], euler[1], euler[2], int(use_partial_cell),
-                          WHICH_ALE[which_ale], dt, alpha, theta, K_hor, npes, mype, int(use_cavity))
+                          WHICH_ALE[which_ale], dt, alpha, theta, K_hor, npes, mype, int(use_cavity), int(use_cavity_partial_cell), cavity_partial_cell_thresh)
         h = lib.fesom_mesh_load(str(meshdir).encode(), C.byref(o))
         if not h:
             raise RuntimeError(f"fesom_mesh_load failed for {meshdir}")

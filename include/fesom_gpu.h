@@ -170,12 +170,14 @@ typedef struct fesom_params {
      namelist.config (the hard-coded regional mask of uke_update, :1107-1121, is not built). */
   double c_back, K_back, uke_scaling_factor, rosb_dis, scale_area;
   int    uke_scaling, smooth_back, smooth_dis, smooth_back_tend;
-  /* ice-shelf cavities (namelist.config &run_config use_cavity; use_cavity_partial_cell = .false.): the mesh carries upper levels ulevels > 1
+  /* ice-shelf cavities (namelist.config &run_config use_cavity, use_cavity_partial_cell): the mesh carries upper levels ulevels > 1
      (src/oce_mesh.F90:897-1280); ocean_setup then switches the reference density profile on (src/oce_setup_step.F90:120-129: use_density_ref,
      init_ref_density src/oce_ale_pressure_bv.F90:3024-3070 from density_ref_T / _S, defaults src/oce_modules.F90:144-146): formed on the device from the
      Z_3d_n of the first uploaded state.  use_density_ref alone (without cavities) is accepted as well. */
   int    use_cavity, use_density_ref;
   double density_ref_T, density_ref_S;
+  int    use_cavity_partial_cell;   /* partial cells at the shelf base (set-up: fesom_mesh_opts); in the step it only selects the pressure gradient of linfs:
+                                       which_pgf 0 / 3 / 4 = 'sergey' (pressure_force_4_linfs_cavity, src/oce_ale_pressure_bv.F90:385-403,1451-1663) */
 } fesom_params;
 
 /* ---- prognostic state = restart set (io_restart.F90:99-155) + ALE thickness arrays -- */
@@ -383,7 +385,9 @@ typedef struct fesom_mesh_opts {
   int    which_ale;          /* as fesom_params */
   double dt, alpha, theta, K_hor;
   int    npes, mype;         /* partition dist_<npes>/ ; npes==1 -> trivial partition, no files needed */
-  int    use_cavity;         /* ice-shelf cavities: cavity_elvls.out, cavity_nlvls.out, cavity_depth.out of the mesh directory (src/oce_mesh.F90:897-1280); use_cavity_partial_cell = .false. */
+  int    use_cavity;         /* ice-shelf cavities: cavity_elvls.out, cavity_nlvls.out, cavity_depth.out of the mesh directory (src/oce_mesh.F90:897-1280) */
+  int    use_cavity_partial_cell;       /* partial cells at the ice-shelf base: zbar_e_srf / zbar_n_srf from the draft (init_surface_elem_depth / init_surface_node_depth, src/oce_ale.F90:422-545) */
+  double cavity_partial_cell_thresh;    /* only where the full surface cell is thicker than this (namelist.config &run_config, default 0) */
 } fesom_mesh_opts;
 
 void *fesom_mesh_load(const char *meshdir, const fesom_mesh_opts *opts);     /* NULL on error */

@@ -255,6 +255,10 @@ static void pgf_linfs_cubicspline(void) {
         }
       double gx = (GS(1, e) * r3[0] + GS(2, e) * r3[1]) + GS(3, e) * r3[2], gy = (GS(4, e) * r3[0] + GS(5, e) * r3[1]) + GS(6, e) * r3[2];
       double ax = gx * A2(C_.helem, nlz, e) * G_ACC / DENSITY_0, ay = gy * A2(C_.helem, nlz, e) * G_ACC / DENSITY_0;
+      if (nlz == ule && ule > 1) {           /* pressure boundary condition at the shelf base (:1316-1335) */
+        ip[0] = ip[0] + gx * (-C_.m.zbar_e_srf[e - 1]) * G_ACC / DENSITY_0;
+        ip[1] = ip[1] + gy * (-C_.m.zbar_e_srf[e - 1]) * G_ACC / DENSITY_0;
+      }
       A2(C_.pgf_x, nlz, e) = ip[0] + ax * 0.5; ip[0] = ip[0] + ax;
       A2(C_.pgf_y, nlz, e) = ip[1] + ay * 0.5; ip[1] = ip[1] + ay;
     }
@@ -327,7 +331,7 @@ static void pgf_zxxxx_easypgf(void) {         /* also pressure_force_4_linfs_eas
       double r3[3];
       for (int ni = 0; ni < 3; ni++) {
         int n = en[ni], k0;
-        if (lin && nlz != nle) { r3[ni] = A2(C_.density_m_rho0, nlz, n); continue; }
+        if (lin && nlz != nle && !(nlz == ule && ule > 1)) { r3[ni] = A2(C_.density_m_rho0, nlz, n); continue; }      /* (directly under a shelf the interpolation stays, :957-1040) */
         if (nlz == ule && (nlz - ULEVN(n)) == 0) k0 = nlz + 1;
         else if (nlz == nle && nlz != ule && (NLEVN(n) - 1 - nlz) == 0) k0 = nlz - 1;
         else k0 = nlz;
@@ -352,8 +356,15 @@ static void pgf_zxxxx_easypgf(void) {         /* also pressure_force_4_linfs_eas
   free(zbar_n); free(Z_n);
 }
 
+static double drho_dy_of(int e, int nlz, const int *en) {
+  return GS(4, e) * A2(C_.density_m_rho0, nlz, en[0]) + GS(5, e) * A2(C_.density_m_rho0, nlz, en[1]) + GS(6, e) * A2(C_.density_m_rho0, nlz, en[2]);
+}
+static double dz_dy_of(int e, int nlz, const int *en) {
+  return GS(4, e) * A2(C_.Z_3d_n, nlz, en[0]) + GS(5, e) * A2(C_.Z_3d_n, nlz, en[1]) + GS(6, e) * A2(C_.Z_3d_n, nlz, en[2]);
+}
 void orc_pressure_force(void) {
-  if (C_.p.which_ale == 0 && !C_.p.use_partial_cell) { pgf_linfs_fullcell(); return; }
+  const int cav_pc = C_.p.use_cavity && C_.p.use_cavity_partial_cell;      /* :385-403 */
+  if (C_.p.which_ale == 0 && !C_.p.use_partial_cell && !cav_pc) { pgf_linfs_fullcell(); return; }
   if (C_.p.which_ale != 0 && C_.p.which_pgf == 1) { pgf_zxxxx_cubicspline(); return; }
   if (C_.p.which_pgf == 3) { pgf_zxxxx_easypgf(); return; }        /* zstar, and linfs with partial cells (full cells returned above) */
   if (C_.p.which_ale == 0 && C_.p.which_pgf == 1) { pgf_linfs_cubicspline(); return; }
@@ -394,13 +405,30 @@ void orc_pressure_force(void) {
       double drho_dx = GS(1, e) * A2(C_.density_m_rho0, nlz, en[0]) + GS(2, e) * A2(C_.density_m_rho0, nlz, en[1]) +
                        GS(3, e) * A2(C_.density_m_rho0, nlz, en[2]);
       double dz_dx = GS(1, e) * A2(C_.Z_3d_n, nlz, en[0]) + GS(2, e) * A2(C_.Z_3d_n, nlz, en[1]) + GS(3, e) * A2(C_.Z_3d_n, nlz, en[2]);
-      double aux = (lin && nlz != nle) ? drho_dx * A2(C_.helem, nlz, e) * G_ACC / DENSITY_0 : (drho_dx - s3 * dz_dx) * A2(C_.helem, nlz, e) * G_ACC / DENSITY_0;
+      const int flat = lin && nlz != nle && !(nlz == ule && ule > 1);      /* linfs: the correction only in the bottom layer and directly under a shelf (:703-776) */
+      double aux = flat ? drho_dx * A2(C_.helem, nlz, e) * G_ACC / DENSITY_0 : (drho_dx - s3 * dz_dx) * A2(C_.helem, nlz, e) * G_ACC / DENSITY_0;
+      if (C_.p.which_pgf == 4) {
+        /* 'sergey' = pressure_force_4_linfs_cavity (:1451-1663): hydrostatic pressure gradient; half the density-Jacobian term directly under a shelf;
+         * with partial cells the bottom layer from the pressure at its upper face + half the term */
+        double auy = (drho_dy_of(e, nlz, en) - s3 * dz_dy_of(e, nlz, en)) * A2(C_.helem, nlz, e) * G_ACC / DENSITY_0;
+        if (nlz == ule && ule > 1) { A2(C_.pgf_x, nlz, e) = aux * 0.5; A2(C_.pgf_y, nlz, e) = auy * 0.5; }
+        else if (nlz == nle && C_.p.use_partial_cell) {
+          double h[3];
+          for (int ni = 0; ni < 3; ni++) h[ni] = (A2L(C_.hpressure, nlz - 1, en[ni]) + 0.5 * G_ACC * (A2(C_.density_m_rho0, nlz - 1, en[ni]) * A2(C_.hnode, nlz - 1, en[ni])));
+          A2(C_.pgf_x, nlz, e) = (GS(1, e) * h[0] / DENSITY_0 + GS(2, e) * h[1] / DENSITY_0 + GS(3, e) * h[2] / DENSITY_0) + aux * 0.5;
+          A2(C_.pgf_y, nlz, e) = (GS(4, e) * h[0] / DENSITY_0 + GS(5, e) * h[1] / DENSITY_0 + GS(6, e) * h[2] / DENSITY_0) + auy * 0.5;
+        } else {
+          A2(C_.pgf_x, nlz, e) = GS(1, e) * A2L(C_.hpressure, nlz, en[0]) / DENSITY_0 + GS(2, e) * A2L(C_.hpressure, nlz, en[1]) / DENSITY_0 + GS(3, e) * A2L(C_.hpressure, nlz, en[2]) / DENSITY_0;
+          A2(C_.pgf_y, nlz, e) = GS(4, e) * A2L(C_.hpressure, nlz, en[0]) / DENSITY_0 + GS(5, e) * A2L(C_.hpressure, nlz, en[1]) / DENSITY_0 + GS(6, e) * A2L(C_.hpressure, nlz, en[2]) / DENSITY_0;
+        }
+        continue;
+      }
       A2(C_.pgf_x, nlz, e) = (nlz == ule) ? aux * 0.5 : int_dp_dx[0] + aux * 0.5;
       int_dp_dx[0] = (nlz == ule) ? aux : int_dp_dx[0] + aux;
       double drho_dy = GS(4, e) * A2(C_.density_m_rho0, nlz, en[0]) + GS(5, e) * A2(C_.density_m_rho0, nlz, en[1]) +
                        GS(6, e) * A2(C_.density_m_rho0, nlz, en[2]);
       double dz_dy = GS(4, e) * A2(C_.Z_3d_n, nlz, en[0]) + GS(5, e) * A2(C_.Z_3d_n, nlz, en[1]) + GS(6, e) * A2(C_.Z_3d_n, nlz, en[2]);
-      aux = (lin && nlz != nle) ? drho_dy * A2(C_.helem, nlz, e) * G_ACC / DENSITY_0 : (drho_dy - s3 * dz_dy) * A2(C_.helem, nlz, e) * G_ACC / DENSITY_0;
+      aux = flat ? drho_dy * A2(C_.helem, nlz, e) * G_ACC / DENSITY_0 : (drho_dy - s3 * dz_dy) * A2(C_.helem, nlz, e) * G_ACC / DENSITY_0;
       A2(C_.pgf_y, nlz, e) = (nlz == ule) ? aux * 0.5 : int_dp_dx[1] + aux * 0.5;
       int_dp_dx[1] = (nlz == ule) ? aux : int_dp_dx[1] + aux;
     }

@@ -59,7 +59,7 @@ include_fleapyear=.false.
 &run_config
 use_ice=.false.
 use_cavity={use_cavity}
-use_cavity_partial_cell=.false.
+use_cavity_partial_cell={use_cavity_partial_cell}
 use_floatice={use_floatice}
 use_sw_pene={use_sw_pene}
 toy_ocean={toy_ocean}
@@ -148,12 +148,28 @@ t_insitu=.false.
 /
 """
 
+_CAV = dict(mesh="pi_cavity", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+            rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+            fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+            balance_salt_water=".true.", use_cavity=".true.", synth_forcing=True)
 CFGS = {
     # ice-shelf cavity: the pi mesh with a synthetic draft (tests/golden/make_cavity_mesh.py -> meshes/pi_cavity: cavity_elvls / nlvls / depth), use_cavity=.true.
     "pi_pp_cavity": dict(mesh="pi_cavity", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
                          rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                          fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
                          balance_salt_water=".true.", use_cavity=".true.", synth_forcing=True),
+    # cavity variants on the same mesh: partial cells at the shelf base, easypgf, zlevel, linfs (full cells / partial cells / partial cells at the base with 'sergey' and 'shchepetkin')
+    "pi_pp_cavity_pc": dict(_CAV, use_cavity_partial_cell=".true."),
+    "pi_pp_cavity_easypgf": dict(_CAV, which_pgf="easypgf"),
+    "pi_pp_zlevel_cavity": dict(_CAV, which_ale="zlevel"),
+    "pi_pp_linfs_cavity": dict(_CAV, which_ale="linfs", use_partial_cell=".false."),
+    "pi_pp_linfs_pc_cavity": dict(_CAV, which_ale="linfs"),
+    "pi_pp_linfs_cavity_sergey": dict(_CAV, which_ale="linfs", use_cavity_partial_cell=".true.", which_pgf="sergey"),
+    "pi_pp_linfs_cavity_pc_shch": dict(_CAV, which_ale="linfs", use_cavity_partial_cell=".true."),
+    "pi_pp_linfs_easypgf_cavity": dict(_CAV, which_ale="linfs", which_pgf="easypgf"),
+    "pi_pp_cavity_cubicspline": dict(_CAV, which_pgf="cubicspline"),
+    "pi_pp_linfs_cubic_cavity": dict(_CAV, which_ale="linfs", which_pgf="cubicspline"),
+    "pi_pp_linfs_nemo_cavity": dict(_CAV, which_ale="linfs", which_pgf="nemo"),
     # the same cavity mesh under the reference's default physics (KPP + GM + Redi)
     "pi_default_cavity": dict(mesh="pi_cavity", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
                               rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
@@ -447,7 +463,7 @@ def prepare(cfg, np_, tag=""):
                 os.chmod(root, 0o755)
             partition_io.write_dist(cp, np_)
         meshdir = cp
-    open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **dict(dict(use_sw_pene=".false.", use_floatice=".false.", min_hnode="0.5", which_toy="soufflet", use_cavity=".false."), **c)))
+    open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **dict(dict(use_sw_pene=".false.", use_floatice=".false.", min_hnode="0.5", which_toy="soufflet", use_cavity=".false.", use_cavity_partial_cell=".false."), **c)))
     open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0", visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=".true.", tra_adv_lim="FCT", use_momix=".false.", which_pgf="shchepetkin", mom_adv=2, use_kpp_nonlclflx=".false.", double_diffusion=".false.", smooth_bh_tra=".false.", clim_relax="0.0", SPP=".false.", use_density_ref=".false."), **c)))
     if c["toy_ocean"] == ".false." or c.get("which_toy", "soufflet") != "soufflet":
         from fesom2_amd.synthetic import write_ic_files

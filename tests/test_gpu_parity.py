@@ -1141,3 +1141,72 @@ def test_density_ref_chain_bitwise(built):
         ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
         assert ok, msg
     gpu.close()
+
+
+CAVITY_VARIANTS = [
+    ("pc", dict(use_cavity_partial_cell=True), dict()),
+    ("easypgf", dict(), dict(which_pgf="easypgf")),
+    ("cubicspline", dict(), dict(which_pgf="cubicspline")),
+    ("zlevel", dict(which_ale="zlevel"), dict()),
+    ("linfs", dict(which_ale="linfs", use_partial_cell=False), dict()),
+    ("linfs_pc", dict(which_ale="linfs"), dict()),
+    ("linfs_easypgf", dict(which_ale="linfs"), dict(which_pgf="easypgf")),
+    ("linfs_cubic", dict(which_ale="linfs"), dict(which_pgf="cubicspline")),
+    ("linfs_nemo", dict(which_ale="linfs"), dict(which_pgf="nemo")),
+    ("linfs_sergey", dict(which_ale="linfs", use_cavity_partial_cell=True), dict(which_pgf="sergey")),
+    ("linfs_cavpc_shch", dict(which_ale="linfs", use_cavity_partial_cell=True), dict()),
+    ("linfs_cavpc_shch_tile", dict(which_ale="linfs", use_cavity_partial_cell=True), dict()),
+]
+
+
+@pytest.mark.parametrize("name,mkw,kw", CAVITY_VARIANTS, ids=[c[0] for c in CAVITY_VARIANTS])
+def test_cavity_variants_chain_bitwise(built, name, mkw, kw):
+    """The cavity variants the reference offers, each pinned on its own reference run in tests/test_oracle_vs_reference.py::CAVITY_CASES: partial cells at the
+    shelf base, zlevel, linfs, every pressure-gradient scheme under a shelf incl. 'sergey' (pressure_force_4_linfs_cavity): HIP == oracle bit for bit after
+    every routine of 2 steps and after 4 further whole steps (`_tile`: the CORE2-class kernel shapes forced on)."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.core import OceanCore
+    from fesom2_amd.synthetic import analytic_ts, analytic_forcing
+    from oracle_lib import Oracle
+    D = os.path.join(os.path.dirname(PI), "pi_cavity")
+    mesh = Mesh.load(D, dt=900.0, use_cavity=True, **mkw)
+    par = make_params(dt=900.0, use_cavity=True, **mkw, **kw)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(D)
+    st.tr_arr_old[...] = st.tr_arr
+    old = os.environ.get("FESOM_GPU_TILE")
+    if name.endswith("_tile"):
+        os.environ["FESOM_GPU_TILE"] = "1"
+    try:
+        gpu = OceanCore(mesh, par)
+    finally:
+        if name.endswith("_tile"):
+            if old is None:
+                os.environ.pop("FESOM_GPU_TILE", None)
+            else:
+                os.environ["FESOM_GPU_TILE"] = old
+    orc = Oracle(mesh, par)
+    gpu.upload_state(st); orc.set_state(st)
+    forcing = analytic_forcing(mesh)
+    gpu.set_forcing(**forcing)
+    for k, v in forcing.items():
+        orc.set(k, v)
+    failures = []
+    for step in range(1, 3):
+        for routine, arg, fields in full_chain(2):
+            gpu.call(routine, arg); orc.call(routine, arg)
+            for f in list(fields) + (["hpressure"] if routine == "pressure_bv" else []):
+                ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+                if not ok:
+                    failures.append(f"step {step} {routine}({arg}) {msg}")
+        if failures:
+            break
+    assert not failures, "\n".join(failures[:15])
+    gpu.run_steps(3, 4)
+    for n in range(3, 7):
+        orc.call("step", n)
+    for f in ("tr_arr", "UV", "eta_n", "hnode", "hbar", "Wvel"):
+        ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+        assert ok, msg
+    gpu.close()

@@ -593,21 +593,53 @@ def test_mesh_layer_bitwise_cavity(built):
     assert not bad, "\n".join(bad)
 
 
-@pytest.mark.parametrize("cfg,kw", [("pi_pp_cavity", dict()), ("pi_default_cavity", dict(mix_scheme="KPP", Fer_GM=True, Redi=True))])
-def test_oracle_chain_bitwise_cavity(built, cfg, kw):
+# cavity variants: (reference run, mesh options, parameters)
+CAVITY_CASES = [
+    ("pi_pp_cavity", dict(), dict()),
+    ("pi_default_cavity", dict(), dict(mix_scheme="KPP", Fer_GM=True, Redi=True)),
+    ("pi_pp_cavity_pc", dict(use_cavity_partial_cell=True), dict()),                                   # partial cells at the shelf base (set-up only with zstar)
+    ("pi_pp_cavity_easypgf", dict(), dict(which_pgf="easypgf")),
+    ("pi_pp_cavity_cubicspline", dict(), dict(which_pgf="cubicspline")),
+    ("pi_pp_zlevel_cavity", dict(which_ale="zlevel"), dict()),
+    ("pi_pp_linfs_cavity", dict(which_ale="linfs", use_partial_cell=False), dict()),                   # full cells: gradient of the hydrostatic pressure (cavity branch of pressure_bv)
+    ("pi_pp_linfs_pc_cavity", dict(which_ale="linfs"), dict()),                                        # pressure_force_4_linfs_shchepetkin: the correction stays directly under the shelf
+    ("pi_pp_linfs_easypgf_cavity", dict(which_ale="linfs"), dict(which_pgf="easypgf")),
+    ("pi_pp_linfs_cubic_cavity", dict(which_ale="linfs"), dict(which_pgf="cubicspline")),              # + pressure boundary term at the shelf base
+    ("pi_pp_linfs_nemo_cavity", dict(which_ale="linfs"), dict(which_pgf="nemo")),
+    ("pi_pp_linfs_cavity_sergey", dict(which_ale="linfs", use_cavity_partial_cell=True), dict(which_pgf="sergey")),     # pressure_force_4_linfs_cavity
+    ("pi_pp_linfs_cavity_pc_shch", dict(which_ale="linfs", use_cavity_partial_cell=True), dict()),
+]
+
+
+@pytest.mark.parametrize("cfg,mkw,kw", CAVITY_CASES, ids=[c[0] for c in CAVITY_CASES])
+def test_oracle_chain_bitwise_cavity(built, cfg, mkw, kw):
     """Ice-shelf cavities (use_cavity=.true.): every routine of the step from its column's upper level, the reference density profile of
     init_ref_density (src/oce_ale_pressure_bv.F90:3036-3073; use_density_ref is forced on, src/oce_setup_step.F90), pressure_bv's interface-water fill
     above the shelf base and the cavity branch of hpressure (:214-260, :420-470), the FCT bounds that see the untouched scratch entries above an element's
     upper level (src/oce_adv_tra_fct.F90:110-142) and CFL_z accumulating at the top of a cavity column (src/oce_ale.F90:2141-2152): reference runs
-    `pi_pp_cavity` (PP) and `pi_default_cavity` (KPP + GM + Redi), 2 ranks, surface forcing, every routine of 3 steps bit for bit."""
+    `pi_pp_cavity` (PP) and `pi_default_cavity` (KPP + GM + Redi), 2 ranks, surface forcing, every routine of 3 steps bit for bit.
+    Variants (CAVITY_CASES), each its own reference run on the same mesh, set-up arrays included: use_cavity_partial_cell (init_surface_elem_depth /
+    init_surface_node_depth, src/oce_ale.F90:422-545), which_ALE zlevel and linfs, every pressure-gradient scheme the reference offers under a shelf incl.
+    'sergey' = pressure_force_4_linfs_cavity (src/oce_ale_pressure_bv.F90:385-403, 1451-1663)."""
     from fesom2_amd.mesh import Mesh
     from fesom2_amd.config import make_params
     from fesom2_amd.synthetic import analytic_ts
     from oracle_lib import Oracle
     from ref_chain import run_reference_chain
-    mesh = Mesh.load(CAVITY, dt=900.0, use_cavity=True)
-    par = make_params(dt=900.0, use_cavity=True, **kw)
+    mesh = Mesh.load(CAVITY, dt=900.0, use_cavity=True, **mkw)
+    par = make_params(dt=900.0, use_cavity=True, **mkw, **kw)
+    g = gold(cfg)
     st = mesh.initial_state(2)
+    bad = []
+    for f in SETUP_FIELDS:
+        ok, msg = check_digest(getattr(mesh, f), g["setup/" + f])
+        if not ok:
+            bad.append(f"{f}: {msg}")
+    for f in ("hnode", "helem", "zbar_3d_n", "Z_3d_n"):
+        ok, msg = check_digest(getattr(st, f), g["setup/" + f])
+        if not ok:
+            bad.append(f"state {f}: {msg}")
+    assert not bad, "\n".join(bad)
     st.tr_arr[0], st.tr_arr[1] = analytic_ts(CAVITY)
     st.tr_arr_old[...] = st.tr_arr
     orc = Oracle(mesh, par)
