@@ -8,7 +8,7 @@ def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equati
                 mix_scheme="PP", with_diffusion=True, toy_soufflet=False, K_hor=3000.0, A_ver=1.0e-4, K_ver=1.0e-5,
                 cyclic_length_deg=360.0, w_split=False, use_instabmix=True, use_windmix=False, solver_x0_order=3,
                 Fer_GM=False, K_GM_max=2000.0, K_GM_min=2.0, K_GM_bvref=2, K_GM_rampmax=-1.0, K_GM_rampmin=-1.0,
-                K_GM_resscalorder=1.0, scaling_Ferreira=False, scaling_resolution=True, scaling_FESOM14=False, Redi=False,
+                K_GM_resscalorder=1.0, scaling_Ferreira=False, scaling_resolution=True, scaling_FESOM14=False, scaling_Rossby=False, Redi=False,
                 visc_sh_limit=5.0e-3, diff_sh_limit=5.0e-3, Ricr=0.3, concv=1.6,
                 gamma0=0.003, gamma1=0.1, gamma2=0.285, easy_bs_return=1.5, C_d=0.0025, w_max_cfl=1.0, use_sw_pene=False, visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=True,
                 solver_precond=1, solver_xinv_its=0, tra_adv_lim="FCT", Leith_c=0.05, Div_c=0.5, which_pgf="shchepetkin", use_momix=False, momix_lat=-50.0, momix_kv=0.01, mom_adv=2, use_kpp_nonlclflx=False, ref_sss_local=True, ref_sss=34.0, double_diffusion=False, smooth_bh_tra=False, use_floatice=False, l_mslp=False, use_global_tides=False, max_ice_loading=5.0, clim_relax=0.0, SPP=False, Sice=4.0, min_hnode=0.5, lzstar_lev=4,
@@ -42,7 +42,7 @@ def make_params(dt=900.0, which_ale="zstar", use_partial_cell=True, state_equati
     p.Fer_GM = int(Fer_GM)
     p.K_GM_max, p.K_GM_min, p.K_GM_bvref = K_GM_max, K_GM_min, int(K_GM_bvref)
     p.K_GM_rampmax, p.K_GM_rampmin, p.K_GM_resscalorder = K_GM_rampmax, K_GM_rampmin, K_GM_resscalorder
-    p.scaling_Ferreira, p.scaling_Rossby = int(scaling_Ferreira), 0
+    p.scaling_Ferreira, p.scaling_Rossby = int(scaling_Ferreira), int(scaling_Rossby)
     p.scaling_resolution, p.scaling_FESOM14 = int(scaling_resolution), int(scaling_FESOM14)
     p.Redi = int(Redi)
     p.use_sw_pene = int(use_sw_pene)

@@ -74,6 +74,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   const int *nb_lay;                                      // (N) nboundary_lay (oce_muscl_adv.F90:74-104), tra_adv_hor = MUSCL only
   int gm_nzl;                                             // max upper level over the elements of the LAST owned node: where init_Redi_GM copies fer_K into Ki (src/oce_fer_gm.F90:250)
   const double *redi_k0;                                  // (N) K_hor*(mesh_resolution/100km)^2: surface Ki of Redi without GM
+  const double *gm_scal_A, *gm_scal_B, *mesh_resolution;    // (N) scaling_Rossby: the resolution scaling and the ramp as separate factors (the Rossby factor is applied first), mesh_resolution
   const double *gm_scal_static;                           // (N) mesh-only part of the horizontal GM scaling
   int *MLD1_ind;                                          // (N) level index of MLD1 (pressure_bv)
   // KPP (kernels_kpp.hip): interior values, boundary layer coefficients (3 slabs of (nl,N)) + two smoothing buffers, tables
@@ -425,7 +426,7 @@ int  launch_solver(const DM &m, hipStream_t s, int fuse_rhs = 0, int scale_done 
 void launch_row_scale(const DM &m, hipStream_t s);
 void launch_dynamics_post(const DM &m, hipStream_t s);
 void launch_tracer(const DM &m, hipStream_t s, int tr);
-void launch_thickness(const DM &m, hipStream_t s);
+void launch_thickness(const DM &m, hipStream_t s, bool bolus_remove = false);
 int  launch_named_toy(const DM &m, hipStream_t s, const char *name);
 int  launch_named_gm(const DM &m, hipStream_t s, const char *name);
 int  launch_named_kpp(const DM &m, hipStream_t s, const char *name);

@@ -1657,8 +1657,16 @@ __device__ __forceinline__ void thick_elem_body(const DM &m, int e) {
 __global__ void __launch_bounds__(BLOCK) k_thick_node(DM m) { thick_node_body(m, col_id(m)); }
 __global__ void __launch_bounds__(BLOCK) k_thick_elem(DM m) { thick_elem_body(m, col_id(m)); }
 // update_thickness_ale in one launch: the first ncolN column slots are node columns, the rest element columns
-__global__ void __launch_bounds__(BLOCK) k_thick(DM m, int ncolN) {
+// bolus_slots > 0: the removal of the bolus velocities at the end of solve_tracers_ale (k_bolus, :165-169) rides in this launch (column slots from bolus_slots on;
+// update_thickness_ale reads neither UV nor the vertical velocities)
+__global__ void __launch_bounds__(BLOCK) k_thick(DM m, int ncolN, int bolus_slots) {
   const int c = col_id(m);
+  if (bolus_slots > 0 && c >= bolus_slots) {
+    const size_t i = (size_t)(c - bolus_slots) * WAVE + lane_id();
+    if (i < (size_t)2 * m.nlm1 * m.E) m.UV[i] = m.UV[i] - m.fer_UV[i];
+    if (i < (size_t)m.nl * m.N) { const double f = m.fer_Wvel[i]; m.Wvel_e[i] = m.Wvel_e[i] - f; m.Wvel[i] = m.Wvel[i] - f; }
+    return;
+  }
   if (c < ncolN) thick_node_body(m, c); else thick_elem_body(m, c - ncolN);
 }
 
@@ -1716,10 +1724,14 @@ void launch_dynamics_post(const DM &m, hipStream_t s) {
   LAUNCH_FLAT(k_dhe, m.myE, m);
   LAUNCH_COL(k_vert_vel, m.myN, m, 0);
 }
-void launch_thickness(const DM &m, hipStream_t s) {
+void launch_thickness(const DM &m, hipStream_t s, bool bolus_remove) {
   if (m.p.which_ale == 0) return;
   const int ncolN = nblocks(m.N) * COLS_PER_BLOCK;
-  hipLaunchKernelGGL(k_thick, dim3(nblocks(m.N) + nblocks(m.myE)), dim3(BLOCK), 0, s, m, ncolN);
+  if (bolus_remove) {
+    const int slots = (nblocks(m.N) + nblocks(m.myE)) * COLS_PER_BLOCK;
+    const size_t nmax = std::max((size_t)2 * m.nlm1 * m.E, (size_t)m.nl * m.N);
+    hipLaunchKernelGGL(k_thick, dim3(nblocks(m.N) + nblocks(m.myE) + nblocks((int)((nmax + WAVE - 1) / WAVE))), dim3(BLOCK), 0, s, m, ncolN, slots);
+  } else hipLaunchKernelGGL(k_thick, dim3(nblocks(m.N) + nblocks(m.myE)), dim3(BLOCK), 0, s, m, ncolN, 0);
 }
 
 int launch_named_dyn(const DM &m, hipStream_t s, const char *name, int arg, int first_step) {

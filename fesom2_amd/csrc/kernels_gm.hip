@@ -20,7 +20,16 @@ __global__ void __launch_bounds__(BLOCK) k_gm_coef(DM m) {
   double run = seq_sum_up(term, nzmin1 - 1, nzmax1 - 2, 0.0);
   double c1 = (nzmax1 - 1 >= nzmin1) ? bcast(run, nzmax1 - 2) : 0.0;
   c1 = dmax_(c_min, c1 / pi);
-  const double scal = dmin_(m.gm_scal_static[n], 1.0);
+  double scaling = m.gm_scal_static[n];
+  if (m.p.scaling_Rossby) {      // :196-200: cut K_GM off where the mesh resolves the Rossby radius (Fermi function of resolution / radius; exp: device libm)
+    const double f_min = 1.e-6, r_max = 200000., x0 = 1.5, sigma = .15;
+    const double rosb = dmin_(c1 / dmax_(fabs(m.coriolis_node[n]), f_min), r_max);
+    const double rr_ratio = dmin_(m.mesh_resolution[n] / rosb, 5.);
+    scaling = 1. / (1. + exp(-(rr_ratio - x0) / sigma));
+    scaling = scaling * m.gm_scal_A[n];
+    scaling = scaling * m.gm_scal_B[n];
+  }
+  const double scal = dmin_(scaling, 1.0);
   double base = scal * m.p.K_GM_max;
   base = dmax_(base, m.p.K_GM_min);
   if (l == 0 && m.p.Fer_GM) m.fer_c[n] = c1 * c1;

@@ -31,7 +31,16 @@ void orc_init_Redi_GM(void) {
       for (int nz = nzmin; nz <= nzmax - 1; nz++)
         c1 = c1 + A2(C_.hnode_new, nz, n) * (sqrt(fabs(dmax(A2L(C_.bvfreq, nz, n), 0.))) + sqrt(fabs(dmax(A2L(C_.bvfreq, nz + 1, n), 0.)))) / 2.;
       c1 = dmax(c_min, c1 / pi);
-      C_.fer_scal[n - 1] = dmin(C_.gm_scal_static[n - 1], 1.0);
+      double scaling = C_.gm_scal_static[n - 1];
+      if (C_.p.scaling_Rossby) {          /* :196-200: cut K_GM off where the mesh resolves the Rossby radius (Fermi function of resolution / radius) */
+        const double f_min = 1.e-6, r_max = 200000., x0 = 1.5, sigma = .15;
+        double rosb = dmin(c1 / dmax(fabs(C_.m.coriolis_node[n - 1]), f_min), r_max);
+        double rr_ratio = dmin(reso / rosb, 5.);
+        scaling = 1. / (1. + exp(-(rr_ratio - x0) / sigma));
+        if (C_.p.scaling_resolution) scaling = scaling * pow(reso / 100000., C_.p.K_GM_resscalorder);
+        if (reso / 1000.0 < C_.p.K_GM_rampmax) scaling = scaling * dmax((reso / 1000.0 - C_.p.K_GM_rampmin) / (C_.p.K_GM_rampmax - C_.p.K_GM_rampmin), 0.);
+      }
+      C_.fer_scal[n - 1] = dmin(scaling, 1.0);
       A2L(C_.fer_K, nzmin, n) = C_.fer_scal[n - 1] * C_.p.K_GM_max;
       A2L(C_.fer_K, nzmin, n) = dmax(A2L(C_.fer_K, nzmin, n), C_.p.K_GM_min);
       C_.fer_c[n - 1] = c1 * c1;

@@ -95,7 +95,7 @@ K_GM_rampmax=-1.0
 K_GM_rampmin=-1.0
 K_GM_resscalorder=1
 scaling_Ferreira=.false.
-scaling_Rossby=.false.
+scaling_Rossby={scaling_Rossby}
 scaling_resolution=.true.
 scaling_FESOM14=.false.
 Redi={redi}
@@ -200,6 +200,11 @@ CFGS = {
                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                        fer_gm=".true.", redi=".true.", mix_scheme="KPP", k_hor="3000.", surf_relax_s="1.929e-06",
                        balance_salt_water=".true.", synth_forcing=True),
+    # scaling_Rossby = .true.: K_GM cut off where the mesh resolves the first baroclinic Rossby radius
+    "pi_default_rossby": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                       rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                       fer_gm=".true.", redi=".true.", mix_scheme="KPP", k_hor="3000.", surf_relax_s="1.929e-06",
+                       balance_salt_water=".true.", synth_forcing=True, scaling_Rossby=".true."),
     # the physics of the shipped config/namelist.oce in full: KPP + GM + Redi + use_momix (analytic ice state for mo_length)
     "pi_default_momix": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
                        rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
@@ -464,7 +469,7 @@ def prepare(cfg, np_, tag=""):
             partition_io.write_dist(cp, np_)
         meshdir = cp
     open(os.path.join(rd, "namelist.config"), "w").write(CONFIG_TMPL.format(meshpath=meshdir, **dict(dict(use_sw_pene=".false.", use_floatice=".false.", min_hnode="0.5", which_toy="soufflet", use_cavity=".false.", use_cavity_partial_cell=".false."), **c)))
-    open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0", visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=".true.", tra_adv_lim="FCT", use_momix=".false.", which_pgf="shchepetkin", mom_adv=2, use_kpp_nonlclflx=".false.", double_diffusion=".false.", smooth_bh_tra=".false.", clim_relax="0.0", SPP=".false.", use_density_ref=".false."), **c)))
+    open(os.path.join(rd, "namelist.oce"), "w").write(OCE_TMPL.format(**dict(dict(w_split=".false.", w_max_cfl="1.0", visc_option=5, tra_adv_ver="QR4C", tra_adv_hor="MFCT", Kv0_const=".true.", tra_adv_lim="FCT", use_momix=".false.", which_pgf="shchepetkin", mom_adv=2, use_kpp_nonlclflx=".false.", double_diffusion=".false.", smooth_bh_tra=".false.", clim_relax="0.0", SPP=".false.", use_density_ref=".false.", scaling_Rossby=".false."), **c)))
     if c["toy_ocean"] == ".false." or c.get("which_toy", "soufflet") != "soufflet":
         from fesom2_amd.synthetic import write_ic_files
         write_ic_files(meshdir, rd)

@@ -144,6 +144,7 @@ def main():
     make("pi_pp_cavity", "pi_pp_cavity_reference.npz")  # use_cavity = .true. on meshes/pi_cavity (make_cavity_mesh.py), surface forcing
     make("pi_default_cavity", "pi_default_cavity_reference.npz")  # the same under KPP + GM + Redi
     make("pi_pp_dref", "pi_pp_dref_reference.npz")      # use_density_ref = .true. without cavities
+    make("pi_default_rossby", "pi_default_rossby_reference.npz")      # scaling_Rossby = .true.
     make("pi_pp_cdiff", "pi_pp_cdiff_reference.npz")    # tra_adv_ver = 'CDIFF'
     make("pi_pp_upw1v", "pi_pp_upw1v_reference.npz")    # tra_adv_ver = 'UPW1' with w_split
     make("pi_pp_ppm", "pi_pp_ppm_reference.npz")        # tra_adv_ver = 'PPM'

@@ -1210,3 +1210,54 @@ def test_cavity_variants_chain_bitwise(built, name, mkw, kw):
         ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
         assert ok, msg
     gpu.close()
+
+
+def test_scaling_rossby_chain(built):
+    """scaling_Rossby=.true. (oracle pinned on the reference run pi_default_rossby): the Fermi cut-off of K_GM in k_gm_coef goes through exp -- device libm against
+    glibc -- so fer_K / Ki / fer_gamma and what follows are compared to 1e-12 relative after init_Redi_GM (the oracle's fer_K, Ki and tapered slopes are then handed
+    over); every other routine of 2 steps bit for bit; 6 free-running steps to 1e-9."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.core import OceanCore
+    from fesom2_amd.synthetic import analytic_ts, analytic_forcing
+    from oracle_lib import Oracle
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, mix_scheme="KPP", Fer_GM=True, Redi=True, scaling_Rossby=True)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    gpu, orc = OceanCore(mesh, par), Oracle(mesh, par)
+    gpu.upload_state(st); orc.set_state(st)
+    forcing = analytic_forcing(mesh)
+    gpu.set_forcing(**forcing)
+    for k, v in forcing.items():
+        orc.set(k, v)
+    failures = []
+    for step in range(1, 3):
+        for routine, arg, fields in full_chain(2, gm=True, redi=True, kpp=True):
+            gpu.call(routine, arg); orc.call(routine, arg)
+            if routine == "compute_neutral_slope":
+                gpu.set("slope_tapered", orc.get("slope_tapered"))
+            if routine == "init_Redi_GM":
+                for f in ("fer_K", "Ki"):
+                    a, b = gpu.get(f, orc.count(f)), orc.get(f)
+                    err = np.abs(a - b).max() / np.abs(b).max()
+                    assert err < 1e-12, (f, err)
+                    gpu.set(f, b)
+                assert orc.get("fer_K").min() < 0.5 * orc.get("fer_K").max()
+                continue
+            for f in fields:
+                ok, msg = compare(f, gpu.get(f, orc.count(f)), orc.get(f))
+                if not ok:
+                    failures.append(f"step {step} {routine}({arg}) {msg}")
+        if failures:
+            break
+    assert not failures, "\n".join(failures[:10])
+    gpu.run_steps(3, 6)
+    for n in range(3, 9):
+        orc.call("step", n)
+    for f in ("tr_arr", "UV", "eta_n", "hnode", "fer_K"):
+        a, b = gpu.get(f, orc.count(f)), orc.get(f)
+        err = np.abs(a - b).max() / np.abs(b).max()
+        assert err < 1e-9, (f, err)
+    gpu.close()

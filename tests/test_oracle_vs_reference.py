@@ -672,3 +672,27 @@ def test_oracle_chain_bitwise_density_ref(built):
         orc.set(f, g["forcing/" + f])
     bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
     assert not bad, "\n".join(bad[:20])
+
+
+def test_oracle_chain_bitwise_scaling_rossby(built):
+    """scaling_Rossby=.true. (namelist.oce &oce_dyn): K_GM cut off by a Fermi function of mesh resolution / first baroclinic Rossby radius
+    (init_Redi_GM, src/oce_fer_gm.F90:196-200) ahead of the resolution scaling and the ramp; reference run `pi_default_rossby` (KPP + GM + Redi),
+    every routine of 3 steps bit for bit (exp: the oracle and the reference build use the same libm here)."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.synthetic import analytic_ts
+    from oracle_lib import Oracle
+    from ref_chain import run_reference_chain
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, mix_scheme="KPP", Fer_GM=True, Redi=True, scaling_Rossby=True)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    orc = Oracle(mesh, par)
+    orc.set_state(st)
+    g = gold("pi_default_rossby")
+    for f in FORCING:
+        orc.set(f, g["forcing/" + f])
+    bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
+    assert not bad, "\n".join(bad[:20])
+    assert not np.array_equal(g["s1/gm.fer_K"], gold("pi_default")["s1/gm.fer_K"])      # (the cut-off acts on pi: the reference's own fer_K differs from the run without it)
