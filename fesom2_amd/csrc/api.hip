@@ -472,7 +472,6 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     G.err = "fesom_gpu_init: tra_adv_ver must be QR4C (0), CDIFF (1), UPW1 (2) or PPM (3), tra_adv_hor MFCT (0), MUSCL (1) or UPW1 (2), tra_adv_lim='FCT'"; return 3;
   }
   if (par->tra_adv_lim < 0 || par->tra_adv_lim > 1) { G.err = "fesom_gpu_init: tra_adv_lim must be 'FCT' (0) or 'NON' (1)"; return 3; }
-  if (par->tra_adv_lim == 1 && par->w_split) { G.err = "fesom_gpu_init: tra_adv_lim='NON' together with w_split (implicit vertical advection inside the diffusion solve) is not implemented"; return 3; }
   if (par->mix_scheme < 0 || par->mix_scheme > 2) { G.err = "fesom_gpu_init: mix_scheme must be 0 (constant), 1 (KPP) or 2 (PP); the cvmix schemes are not implemented"; return 3; }
   if (!par->use_cavity)
     for (int e = 0; e < d->myDim_elem2D + d->eDim_elem2D; e++)

@@ -996,6 +996,17 @@ __device__ __forceinline__ void tru_coeffs(const DM &m, TruCol &k) {
       k.c = 0.0;
       k.b = -k.a + hnn;
     }
+    if (m.p.w_split && m.p.tra_adv_lim) {      // do_wimpl (:424, :560-572, :604-617, :641-649): without the FCT low-order solution the implicit part of the vertical velocity enters the solve, upwind
+      const double wi = DA2L(m.Wvel_i, nz, n), wi_dn = DA2L(m.Wvel_i, nz + 1, n);
+      double v_adv = zinv * (ar / asv);
+      if (nz == k.nzmin) k.b = k.b + wi * v_adv;
+      else { k.a = k.a + dmin_(0.0, wi) * v_adv; k.b = k.b + dmax_(0.0, wi) * v_adv; }
+      if (nz <= k.nzmax - 2) {
+        v_adv = zinv * ar_dn / asv;
+        k.b = k.b - dmin_(0.0, wi_dn) * v_adv;
+        k.c = k.c - dmax_(0.0, wi_dn) * v_adv;
+      }
+    }
   }
 }
 // right-hand side of the implicit vertical diffusion for T* (surface boundary condition, short-wave penetration)

@@ -603,6 +603,14 @@ static void diff_ver_part_impl_ale(int tr) {
     a[nz] = 0.0;
     c[nz] = -(A2L(C_.Kv, nz + 1, n) + Ty1) * zinv2 * zinv * AREA(nz + 1, n) / AREASVOL(nz, n);
     b[nz] = -c[nz] + A2(C_.hnode_new, nz, n);
+    const int do_wimpl = C_.p.w_split && C_.p.tra_adv_lim != 0;      /* :424: the implicit part of the vertical velocity in the solve, only without the FCT low-order solution */
+    if (do_wimpl) {                                                    /* :560-572, upwind */
+      double v_adv = zinv * (AREA(nz, n) / AREASVOL(nz, n));
+      b[nz] = b[nz] + A2L(C_.Wvel_i, nz, n) * v_adv;
+      v_adv = zinv * AREA(nz + 1, n) / AREASVOL(nz, n);
+      b[nz] = b[nz] - dmin(0.0, A2L(C_.Wvel_i, nz + 1, n)) * v_adv;
+      c[nz] = c[nz] - dmax(0.0, A2L(C_.Wvel_i, nz + 1, n)) * v_adv;
+    }
     zinv1 = zinv2;
     for (nz = nzmin + 1; nz <= nzmax - 2; nz++) {
       zinv2 = 1.0 / (Z_n[nz] - Z_n[nz + 1]);
@@ -615,6 +623,14 @@ static void diff_ver_part_impl_ale(int tr) {
       c[nz] = -(A2L(C_.Kv, nz + 1, n) + Ty1) * zinv2 * zinv * AREA(nz + 1, n) / AREASVOL(nz, n);
       b[nz] = -a[nz] - c[nz] + A2(C_.hnode_new, nz, n);
       zinv1 = zinv2;
+      if (do_wimpl) {                                                  /* :604-617 */
+        double v_adv = zinv * (AREA(nz, n) / AREASVOL(nz, n));
+        a[nz] = a[nz] + dmin(0.0, A2L(C_.Wvel_i, nz, n)) * v_adv;
+        b[nz] = b[nz] + dmax(0.0, A2L(C_.Wvel_i, nz, n)) * v_adv;
+        v_adv = zinv * AREA(nz + 1, n) / AREASVOL(nz, n);
+        b[nz] = b[nz] - dmin(0.0, A2L(C_.Wvel_i, nz + 1, n)) * v_adv;
+        c[nz] = c[nz] - dmax(0.0, A2L(C_.Wvel_i, nz + 1, n)) * v_adv;
+      }
     }
     nz = nzmax - 1;
     zinv = 1.0 * dt;
@@ -624,6 +640,11 @@ static void diff_ver_part_impl_ale(int tr) {
     a[nz] = -(A2L(C_.Kv, nz, n) + Ty) * zinv1 * zinv * (AREA(nz, n) / AREASVOL(nz, n));
     c[nz] = 0.0;
     b[nz] = -a[nz] + A2(C_.hnode_new, nz, n);
+    if (do_wimpl) {                                                    /* :641-649 */
+      double v_adv = zinv * (AREA(nz, n) / AREASVOL(nz, n));
+      a[nz] = a[nz] + dmin(0.0, A2L(C_.Wvel_i, nz, n)) * v_adv;
+      b[nz] = b[nz] + dmax(0.0, A2L(C_.Wvel_i, nz, n)) * v_adv;
+    }
     nz = nzmin;
     double dz = A2(C_.hnode_new, nz, n);
     trv[nz] = -(b[nz] - dz) * TR(nz, n, tr) - c[nz] * TR(nz + 1, n, tr);

@@ -271,6 +271,11 @@ CFGS = {
                       rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
                       fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
                       balance_salt_water=".true.", synth_forcing=True, tra_adv_lim="NON"),
+    # tra_adv_lim = 'NON' with w_split: the implicit part of the vertical velocity inside the diffusion solve (do_wimpl, oce_ale_tracer.F90:424)
+    "pi_pp_non_wsplit": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
+                      rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,
+                      fer_gm=".false.", redi=".false.", mix_scheme="PP", k_hor="3000.", surf_relax_s="1.929e-06",
+                      balance_salt_water=".true.", synth_forcing=True, tra_adv_lim="NON", w_split=".true.", w_max_cfl="0.0003"),
     # visc_option = 1, 2, 3: Leith viscosity (h_viscosity_leith) with the harmonic / harmonic + biharmonic background / biharmonic filter
     "pi_pp_visc1": dict(mesh="pi", step_per_day=96, which_ale="zstar", use_partial_cell=".true.", cyclic_length=360,
                         rotated_grid=".true.", force_rotation=".true.", toy_ocean=".false.", state_equation=1,

@@ -145,6 +145,7 @@ def main():
     make("pi_default_cavity", "pi_default_cavity_reference.npz")  # the same under KPP + GM + Redi
     make("pi_pp_dref", "pi_pp_dref_reference.npz")      # use_density_ref = .true. without cavities
     make("pi_default_rossby", "pi_default_rossby_reference.npz")      # scaling_Rossby = .true.
+    make("pi_pp_non_wsplit", "pi_pp_non_wsplit_reference.npz")        # tra_adv_lim = 'NON' with w_split
     make("pi_pp_cdiff", "pi_pp_cdiff_reference.npz")    # tra_adv_ver = 'CDIFF'
     make("pi_pp_upw1v", "pi_pp_upw1v_reference.npz")    # tra_adv_ver = 'UPW1' with w_split
     make("pi_pp_ppm", "pi_pp_ppm_reference.npz")        # tra_adv_ver = 'PPM'

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 NSTEPS = 10
 
 
-@pytest.mark.parametrize("cfg,ranks", [("pi_default", 1), ("pi_pp", 1), ("pi_default", 2), ("pi_default_sw", 2), ("pi_default", 4), ("pi_pp_momix", 1), ("pi_default_momix", 2), ("pi_pp_climrelax", 2), ("pi_pp_linfs_spp", 2), ("pi_pp_zlevel", 2), ("pi_pp_surfpot", 2), ("pi_pp_bhtra", 2), ("pi_kpp_dd", 2), ("pi_kpp_nonlcl", 2), ("pi_kpp_nonlcl_linfs", 2), ("pi_pp_linfs_vinv", 2), ("pi_pp_vinv", 2), ("pi_pp_cubicspline", 2), ("pi_pp_linfs_cubic", 2), ("pi_pp_linfs_nemo", 2), ("pi_pp_easypgf", 2), ("pi_pp_linfs_easypgf", 2), ("pi_pp_linfs_pc", 2), ("pi_pp_visc1", 2), ("pi_pp_visc2", 2), ("pi_pp_visc3", 2), ("pi_pp_visc4", 2), ("pi_pp_non", 2), ("pi_pp_visc6", 1), ("pi_pp_visc7", 2), ("pi_pp_visc8", 1), ("pi_pp_cdiff", 1), ("pi_pp_upw1v", 2), ("pi_pp_muscl", 2), ("pi_pp_upw1h", 1), ("pi_pp_ppm", 2), ("pi_kpp_kv0", 2), ("pi_pp_cavity", 1), ("pi_default_cavity", 2), ("pi_pp_dref", 2), ("pi_pp_cavity_pc", 2), ("pi_pp_linfs_cavity_sergey", 2), ("pi_pp_zlevel_cavity", 1), ("pi_default_rossby", 2)])
+@pytest.mark.parametrize("cfg,ranks", [("pi_default", 1), ("pi_pp", 1), ("pi_default", 2), ("pi_default_sw", 2), ("pi_default", 4), ("pi_pp_momix", 1), ("pi_default_momix", 2), ("pi_pp_climrelax", 2), ("pi_pp_linfs_spp", 2), ("pi_pp_zlevel", 2), ("pi_pp_surfpot", 2), ("pi_pp_bhtra", 2), ("pi_kpp_dd", 2), ("pi_kpp_nonlcl", 2), ("pi_kpp_nonlcl_linfs", 2), ("pi_pp_linfs_vinv", 2), ("pi_pp_vinv", 2), ("pi_pp_cubicspline", 2), ("pi_pp_linfs_cubic", 2), ("pi_pp_linfs_nemo", 2), ("pi_pp_easypgf", 2), ("pi_pp_linfs_easypgf", 2), ("pi_pp_linfs_pc", 2), ("pi_pp_visc1", 2), ("pi_pp_visc2", 2), ("pi_pp_visc3", 2), ("pi_pp_visc4", 2), ("pi_pp_non", 2), ("pi_pp_visc6", 1), ("pi_pp_visc7", 2), ("pi_pp_visc8", 1), ("pi_pp_cdiff", 1), ("pi_pp_upw1v", 2), ("pi_pp_muscl", 2), ("pi_pp_upw1h", 1), ("pi_pp_ppm", 2), ("pi_kpp_kv0", 2), ("pi_pp_cavity", 1), ("pi_default_cavity", 2), ("pi_pp_dref", 2), ("pi_pp_cavity_pc", 2), ("pi_pp_linfs_cavity_sergey", 2), ("pi_pp_zlevel_cavity", 1), ("pi_default_rossby", 2), ("pi_pp_non_wsplit", 2)])
 def test_fortran_dropin_matches_reference_cpu_step(built, cfg, ranks):
     """ranks = 2: two MPI ranks of the reference's own partition (dist_2) share the box's GPU; the Fortran layer hands the
     reference's com_struct lists to the library and moves the packed halo messages with MPI_Isend/Irecv (host-staged), the

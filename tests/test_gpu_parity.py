@@ -470,20 +470,35 @@ def test_profile_step_is_the_same_step(built, case):
     gpu.close()
 
 
-def test_no_limiter_chain_bitwise(built):
-    """tra_adv_lim = 'NON' (oracle pinned on the reference run pi_pp_non): HIP == oracle bit for bit after every routine of 3 steps under
-    surface forcing, and for the state after 8 further steps through fesom_gpu_run_steps."""
+@pytest.mark.parametrize("kw", [dict(), dict(w_split=True, w_max_cfl=0.0003), dict(w_split=True, w_max_cfl=0.0003, tile=1)], ids=["non", "non_wsplit", "non_wsplit_tile"])
+def test_no_limiter_chain_bitwise(built, kw):
+    """tra_adv_lim = 'NON' (oracle pinned on the reference runs pi_pp_non / pi_pp_non_wsplit): HIP == oracle bit for bit after every routine of 3 steps under
+    surface forcing, and for the state after 8 further steps through fesom_gpu_run_steps.  With w_split the implicit part of the vertical velocity enters the
+    diffusion solve (do_wimpl: tru_coeffs in kernels_tra.hip); `_tile`: the CORE2-class kernel shapes."""
     from fesom2_amd.mesh import Mesh
     from fesom2_amd.config import make_params
     from fesom2_amd.core import OceanCore
     from fesom2_amd.synthetic import analytic_ts, analytic_forcing
     from oracle_lib import Oracle
     mesh = Mesh.load(PI, dt=900.0)
-    par = make_params(dt=900.0, tra_adv_lim="NON")
+    kw = dict(kw)
+    tile = kw.pop("tile", None)
+    par = make_params(dt=900.0, tra_adv_lim="NON", **kw)
     st = mesh.initial_state(2)
     st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
     st.tr_arr_old[...] = st.tr_arr
-    gpu, orc = OceanCore(mesh, par), Oracle(mesh, par)
+    old = os.environ.get("FESOM_GPU_TILE")
+    if tile:
+        os.environ["FESOM_GPU_TILE"] = str(tile)
+    try:
+        gpu = OceanCore(mesh, par)
+    finally:
+        if tile:
+            if old is None:
+                os.environ.pop("FESOM_GPU_TILE", None)
+            else:
+                os.environ["FESOM_GPU_TILE"] = old
+    orc = Oracle(mesh, par)
     gpu.upload_state(st); orc.set_state(st)
     forcing = analytic_forcing(mesh)
     gpu.set_forcing(**forcing)

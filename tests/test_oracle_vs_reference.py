@@ -696,3 +696,27 @@ def test_oracle_chain_bitwise_scaling_rossby(built):
     bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
     assert not bad, "\n".join(bad[:20])
     assert not np.array_equal(g["s1/gm.fer_K"], gold("pi_default")["s1/gm.fer_K"])      # (the cut-off acts on pi: the reference's own fer_K differs from the run without it)
+
+
+def test_oracle_chain_bitwise_no_limiter_w_split(built):
+    """tra_adv_lim = 'NON' together with w_split: without the FCT low-order solution the implicit part of the vertical velocity, Wvel_i, enters the
+    implicit diffusion solve as upwind terms of its three diagonals (do_wimpl, src/oce_ale_tracer.F90:424, 560-572, 604-617, 641-649); reference run
+    `pi_pp_non_wsplit` (w_max_cfl = 0.0003 so that the split is active on pi), every routine of 3 steps bit for bit."""
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd.config import make_params
+    from fesom2_amd.synthetic import analytic_ts
+    from oracle_lib import Oracle
+    from ref_chain import run_reference_chain
+    mesh = Mesh.load(PI, dt=900.0)
+    par = make_params(dt=900.0, tra_adv_lim="NON", w_split=True, w_max_cfl=0.0003)
+    st = mesh.initial_state(2)
+    st.tr_arr[0], st.tr_arr[1] = analytic_ts(PI)
+    st.tr_arr_old[...] = st.tr_arr
+    orc = Oracle(mesh, par)
+    orc.set_state(st)
+    g = gold("pi_pp_non_wsplit")
+    for f in FORCING:
+        orc.set(f, g["forcing/" + f])
+    bad = run_reference_chain(orc, mesh, g, steps=(1, 2, 3))
+    assert not bad, "\n".join(bad[:20])
+    assert not np.array_equal(g["s3/tr1.end.tr_arr"], gold("pi_pp_non")["s3/tr1.end.tr_arr"])      # (the split acts)
