@@ -13,6 +13,26 @@ __global__ void __launch_bounds__(BLOCK) k_vel_nodes(DM m) {
   if (nz < m.ulev_n[n] || nz > m.nlev_n[n] - 1) return;
   double tvol = 0.0, tx = 0.0, ty = 0.0;
   int num = m.nie_num[n];
+  if (m.exp_batch & 4) {
+    // the velocities of the elements around the node in batches of independent loads (an element that does not reach this level is read inside its
+    // column all the same and dropped in the select), the sums in the reference's element order
+    constexpr int VB = 6;
+    for (int k0 = 0; k0 < num; k0 += VB) {
+      double u[VB], v[VB], a[VB]; bool on[VB];
+#pragma unroll
+      for (int j = 0; j < VB; j++) {
+        const int e = m.nie[(size_t)m.maxk * n + (k0 + j < num ? k0 + j : 0)];
+        on[j] = k0 + j < num && !(m.nlev[e] - 1 < nz || nz < m.ulev[e]);
+        a[j] = m.elem_area[e];
+        u[j] = DV2(m.UV, 1, nz, e); v[j] = DV2(m.UV, 2, nz, e);
+      }
+#pragma unroll
+      for (int j = 0; j < VB; j++) {
+        const double nv = tvol + a[j], nx = tx + u[j] * a[j], ny = ty + v[j] * a[j];
+        tvol = on[j] ? nv : tvol; tx = on[j] ? nx : tx; ty = on[j] ? ny : ty;
+      }
+    }
+  } else
   for (int k = 0; k < num; k++) {
     int e = m.nie[(size_t)m.maxk * n + k];
     if (m.nlev[e] - 1 < nz || nz < m.ulev[e]) continue;
@@ -990,6 +1010,22 @@ __global__ void __launch_bounds__(BLOCK) k_visc_node(DM m) {
   if (nz < m.ulev_n[n] || nz > m.nlev_n[n] - 1) return;
   double vi = 0.0, u1 = 0.0, v1 = 0.0;
   int num = m.nie_num[n];
+  if (m.exp_batch & 8) {                       // batches of independent loads, sums in the reference's element order (as k_vel_nodes)
+    constexpr int VB = 6;
+    for (int k0 = 0; k0 < num; k0 += VB) {
+      double u[VB], v[VB], a[VB];
+#pragma unroll
+      for (int j = 0; j < VB; j++) {
+        const int e = m.nie[(size_t)m.maxk * n + (k0 + j < num ? k0 + j : 0)];
+        a[j] = m.elem_area[e];
+        u[j] = DV2(m.U_b, 1, nz, e); v[j] = DV2(m.U_b, 2, nz, e);
+      }
+#pragma unroll
+      for (int j = 0; j < VB; j++) {
+        if (k0 + j < num) { vi = vi + a[j]; u1 = u1 + u[j] * a[j]; v1 = v1 + v[j] * a[j]; }      // (wave-uniform)
+      }
+    }
+  } else
   for (int k = 0; k < num; k++) {
     int e = m.nie[(size_t)m.maxk * n + k];
     double ar = m.elem_area[e];

@@ -152,7 +152,32 @@ __global__ void __launch_bounds__(BLOCK) k_fer_wvel(DM m) {
   if (n >= m.myN) return;
   const int nzmin = m.ulev_n[n], nzmax = m.nlev_n[n] - 1;
   double w = 0.0;
-  if (nz <= m.nlm1) {
+  if (nz <= m.nlm1 && (m.exp_batch & 16)) {
+    // the bolus velocities and thicknesses of both triangles of three edges at a time in one batch of independent loads (a triangle that does not reach
+    // this level, or is not there, is read inside a column all the same and dropped in the select); the sum keeps the edge order
+    constexpr int WB = 3;
+    const int q0 = m.ne_ptr[n], q1 = m.ne_ptr[n + 1];
+    for (int qb = q0; qb < q1; qb += WB) {
+      double c1[WB], c2[WB]; bool on1[WB], on2[WB]; int sgn[WB];
+#pragma unroll
+      for (int j = 0; j < WB; j++) {
+        const int q = qb + j < q1 ? qb + j : q0;
+        const int ed = m.ne_idx[q], e1 = m.edge_tri[2 * ed], e2 = m.edge_tri[2 * ed + 1], e2c = e2 >= 0 ? e2 : e1;
+        sgn[j] = m.ne_sgn[q];
+        on1[j] = qb + j < q1 && nz >= m.ulev[e1] && nz <= m.nlev[e1] - 1;
+        on2[j] = qb + j < q1 && e2 >= 0 && nz >= m.ulev[e2c] && nz <= m.nlev[e2c] - 1;
+        c1[j] = (DV2(m.fer_UV, 2, nz, e1) * DECD(1, ed) - DV2(m.fer_UV, 1, nz, e1) * DECD(2, ed)) * DA2(m.helem, nz, e1);
+        c2[j] = -(DV2(m.fer_UV, 2, nz, e2c) * DECD(3, ed) - DV2(m.fer_UV, 1, nz, e2c) * DECD(4, ed)) * DA2(m.helem, nz, e2c);
+      }
+#pragma unroll
+      for (int j = 0; j < WB; j++) {
+        const double a1 = (sgn[j] > 0) ? w + c1[j] : w - c1[j];
+        w = on1[j] ? a1 : w;
+        const double a2 = (sgn[j] > 0) ? w + c2[j] : w - c2[j];
+        w = on2[j] ? a2 : w;
+      }
+    }
+  } else if (nz <= m.nlm1) {
     for (int q = m.ne_ptr[n]; q < m.ne_ptr[n + 1]; q++) {
       int ed = m.ne_idx[q], sg = m.ne_sgn[q];
       int e1 = m.edge_tri[2 * ed], e2 = m.edge_tri[2 * ed + 1];

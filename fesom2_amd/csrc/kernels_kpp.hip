@@ -431,10 +431,29 @@ __device__ __forceinline__ void kpp_elem_body(const DM &m, int e) {
   if (nz < nzmin || nz > nzmax) return;
   const int n1 = m.elem_nodes[3 * e], n2 = m.elem_nodes[3 * e + 1], n3 = m.elem_nodes[3 * e + 2];
   const int k = nz < nzmax ? nz : nzmax - 1;                               // viscAE(nlevels) = viscAE(nlevels-1)
-  double av = (kpp_visc_final<FUSED>(m, k, n1) + kpp_visc_final<FUSED>(m, k, n2) + kpp_visc_final<FUSED>(m, k, n3)) / 3.0;
+  double av;
+  bool unstable;
+  if (m.exp_batch & 1) {
+    // every gather of the column in one batch of independent loads (the short-circuit forms below issue them one behind the other: on CORE2-class
+    // meshes the kernel waits for memory 84 % of its time), the conditions applied as selects afterwards: same values, same order of the sum
+    double v1 = DA2L(m.kpp_viscA, k, n1), v2 = DA2L(m.kpp_viscA, k, n2), v3 = DA2L(m.kpp_viscA, k, n3);
+    double b1 = 0.0, b2 = 0.0, b3 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
+    if (FUSED) { b1 = m.kpp_blmc[(size_t)n1 * m.nl + k - 1]; b2 = m.kpp_blmc[(size_t)n2 * m.nl + k - 1]; b3 = m.kpp_blmc[(size_t)n3 * m.nl + k - 1]; }
+    if (m.p.use_instabmix) { f1 = DA2L(m.bvfreq, nz, n1); f2 = DA2L(m.bvfreq, nz, n2); f3 = DA2L(m.bvfreq, nz, n3); }
+    if (FUSED) {
+      const bool c1 = k >= m.ulev_n[n1] + 1 && k <= m.nlev_n[n1] - 1 && k < m.kpp_kbl[n1], c2 = k >= m.ulev_n[n2] + 1 && k <= m.nlev_n[n2] - 1 && k < m.kpp_kbl[n2],
+                 c3 = k >= m.ulev_n[n3] + 1 && k <= m.nlev_n[n3] - 1 && k < m.kpp_kbl[n3];
+      v1 = c1 ? dmax_(v1, b1) : v1; v2 = c2 ? dmax_(v2, b2) : v2; v3 = c3 ? dmax_(v3, b3) : v3;
+    }
+    av = (v1 + v2 + v3) / 3.0;
+    unstable = f1 < 0. || f2 < 0. || f3 < 0.;
+  } else {
+    av = (kpp_visc_final<FUSED>(m, k, n1) + kpp_visc_final<FUSED>(m, k, n2) + kpp_visc_final<FUSED>(m, k, n3)) / 3.0;
+    unstable = m.p.use_instabmix && nz >= nzmin + 1 && nz <= nzmax - 1 && (DA2L(m.bvfreq, nz, n1) < 0. || DA2L(m.bvfreq, nz, n2) < 0. || DA2L(m.bvfreq, nz, n3) < 0.);
+  }
   if (nz == nzmin && av < 3.0e-3) av = 3.0e-3;                            // minmix on the first interface only
   if (nz >= nzmin + 1 && nz <= nzmax - 1) {
-    if (m.p.use_instabmix && (DA2L(m.bvfreq, nz, n1) < 0. || DA2L(m.bvfreq, nz, n2) < 0. || DA2L(m.bvfreq, nz, n3) < 0.))
+    if (m.p.use_instabmix && unstable)
       av = dmax_(av, m.p.instabmix_kv);
     if (m.p.use_momix && m.momix_elem[e]) av = av + ((momix_mo(m, nz, n1) + momix_mo(m, nz, n2)) + momix_mo(m, nz, n3)) / 3.0;
     if (nzmin <= 1 && m.p.use_windmix && nz <= m.p.windmix_nl + 1) av = dmax_(av, m.p.windmix_kv);

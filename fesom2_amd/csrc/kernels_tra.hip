@@ -745,7 +745,26 @@ __device__ __forceinline__ void k_diff_flux_col(const DM &m, const int tr) {
     ay = (Tz1 * DV3(m.slope_tapered, 2, nz, n1) + Tz2 * DV3(m.slope_tapered, 2, nz, n2)) / 2.0;
     ax = ax * 1.0; ay = ay * 1.0;
   }
-  if (nz >= ul12 && nz <= nl12) {
+  if (m.exp_batch & 2) {
+    // the element values of both triangles in the same batch of loads as the node values above (a level only one triangle reaches reads the other one's
+    // entry too -- inside its column, e2 < 0 falls back to e1 -- and drops it in the selects): no divergent second round of loads
+    const int e2c = e2 >= 0 ? e2 : e1;
+    const double h1 = DA2(m.helem, nz, e1), h2 = DA2(m.helem, nz, e2c);
+    const double x1 = DV2(t.tr_xy, 1, nz, e1), y1 = DV2(t.tr_xy, 2, nz, e1), x2 = DV2(t.tr_xy, 1, nz, e2c), y2 = DV2(t.tr_xy, 2, nz, e2c);
+    if (nz >= ul12 && nz <= nl12) {
+      double dz = (h1 + h2) / 2.0;
+      double Tx = 0.5 * (x1 + x2);
+      double Ty = 0.5 * (y1 + y2);
+      double Fx = Kh * (Tx + ax), Fy = Kh * (Ty + ay);
+      c = ((dX2 - dX1) * Fy - (dY2 - dY1) * Fx) * dz;
+    } else if ((nz >= ul1 && nz <= ul12 - 1) || (nz >= nl12 + 1 && nz <= nl1)) {
+      double Fx = Kh * (x1 + ax), Fy = Kh * (y1 + ay);
+      c = (-dX1 * Fy + dY1 * Fx) * h1;
+    } else {
+      double Fx = Kh * (x2 + ax), Fy = Kh * (y2 + ay);
+      c = (dX2 * Fy - dY2 * Fx) * h2;
+    }
+  } else if (nz >= ul12 && nz <= nl12) {
     double dz = (DA2(m.helem, nz, e1) + DA2(m.helem, nz, e2)) / 2.0;
     double Tx = 0.5 * (DV2(t.tr_xy, 1, nz, e1) + DV2(t.tr_xy, 1, nz, e2));
     double Ty = 0.5 * (DV2(t.tr_xy, 2, nz, e1) + DV2(t.tr_xy, 2, nz, e2));
