@@ -1708,8 +1708,8 @@ __global__ void __launch_bounds__(BLOCK) k_thick(DM m, int ncolN, int bolus_slot
 
 // ------------------------------------------------------------------------------------------------
 #define LAUNCH_COL(k, ncol, ...) hipLaunchKernelGGL(k, dim3(nblocks(ncol)), dim3(BLOCK), 0, s, __VA_ARGS__)
-// (measured, round 3: staging the distinct nodes of the cluster in LDS as k_kpp_smooth_u does changes nothing here, 399 -> 407 us on the basin: the kernel is
-//  bound by its arithmetic -- tanh, sqrt, the divisions of the slope -- not by its 36 column gathers)
+// (measured, round 3: staging the distinct nodes of the cluster in LDS as k_kpp_smooth_u does changes nothing here, 399 -> 407 us on the basin, and neither does
+//  issuing the T / S gathers of three elements as one batch, 423 -> 412 us: the kernel is bound by its arithmetic -- tanh, sqrt, the divisions of the slope)
 static void launch_sigma_slope(const DM &m, hipStream_t s) { LAUNCH_COL(k_sigma_slope, m.myN, m); }
 #define LAUNCH_FLAT(k, n, ...) hipLaunchKernelGGL(k, dim3(((n) + 255) / 256), dim3(256), 0, s, __VA_ARGS__)
 

@@ -604,27 +604,38 @@ __device__ __forceinline__ void k_fct_node_col(const DM &m, const int tr) {
     fn_l = (sg_l > 0) ? m.edges[2 * ed_l + 1] : m.edges[2 * ed_l];
   }
   const double *LOp = t.fct_LO, *Tp = m.tr_arr + (size_t)tr * m.N * m.nlm1;
-  // one batch of loads
-  double bx[GATHER_MAXD], bn[GATHER_MAXD], fh[GATHER_MAXD];
-#pragma unroll
-  for (int q = 0; q < GATHER_MAXD; q++) {
-    bx[q] = bn[q] = fh[q] = 0.0;
-    if (q < deg) {                                          // (wave-uniform: slots beyond the node's degree cost a scalar branch, no loads, no arithmetic)
-      int k = rdlane(fn_l, q);
-      double lk = DA2(LOp, nzc, k), tk = DA2(Tp, nzc, k);
-      bx[q] = dmax_(lk, tk); bn[q] = dmin_(lk, tk);
-      fh[q] = DA2(t.adv_flux_raw, nzc, rdlane(ed_l, q));
-    }
-  }
   double lo_own = DA2(LOp, nzc, n), t_own = DA2(Tp, nzc, n);
+  double adv = (nz >= nu1 && nz <= nl1) ? DA2L(t.adv_flux_ver, nz, n) : 0.0;
   double tvmax = wet ? dmax_(lo_own, t_own) : -1e3, tvmin = wet ? dmin_(lo_own, t_own) : 1e3;   // dry: the reference's -1e3 / 1e3
+  double adv_dn = shdn(adv);
+  double plus = 0.0 + (dmax_(0.0, adv) + dmax_(0.0, -adv_dn));
+  double minus = 0.0 + (dmin_(0.0, adv) + dmin_(0.0, -adv_dn));
+  // the incident edges in groups of FN_B: the 3 * FN_B column loads of a group are issued back to back (a slot beyond the node's degree re-reads slot 0 and is
+  // dropped in the selects), then folded -- a guard around every single slot (round 3, first form) made the loads of one slot wait for the previous slot's:
+  // 6+ dependent round trips per wave where this has 1 or 2.  The flux sums keep the edge order; max / min do not depend on it.
+  constexpr int FN_B = 6;
 #pragma unroll
-  for (int q = 0; q < GATHER_MAXD; q++) {
-    if (q >= deg) continue;
-    unsigned rg = (unsigned)rdlane((int)rg_l, q);
-    bool on = nz >= (int)(rg & 0xffu) && nz <= (int)((rg >> 8) & 0xffu);
-    tvmax = on ? dmax_(tvmax, bx[q]) : tvmax;
-    tvmin = on ? dmin_(tvmin, bn[q]) : tvmin;
+  for (int g0 = 0; g0 < GATHER_MAXD; g0 += FN_B) {
+    if (g0 > 0 && deg <= g0) break;                           // (wave-uniform)
+    double lk[FN_B], tk[FN_B], fh[FN_B];
+#pragma unroll
+    for (int j = 0; j < FN_B; j++) {
+      const int q = g0 + j < deg ? g0 + j : 0;
+      const int k = rdlane(fn_l, q);
+      lk[j] = DA2(LOp, nzc, k); tk[j] = DA2(Tp, nzc, k);
+      fh[j] = DA2(t.adv_flux_raw, nzc, rdlane(ed_l, q));
+    }
+#pragma unroll
+    for (int j = 0; j < FN_B; j++) {
+      const int q = g0 + j < deg ? g0 + j : 0;
+      const unsigned rg = (unsigned)rdlane((int)rg_l, q);
+      const bool on = g0 + j < deg && nz >= (int)(rg & 0xffu) && nz <= (int)((rg >> 8) & 0xffu);
+      tvmax = on ? dmax_(tvmax, dmax_(lk[j], tk[j])) : tvmax;
+      tvmin = on ? dmin_(tvmin, dmin_(lk[j], tk[j])) : tvmin;
+      const double f = (rdlane(sg_l, q) < 0) ? -fh[j] : fh[j];
+      const double np = plus + dmax_(0.0, f), nm = minus + dmin_(0.0, f);
+      plus = on ? np : plus; minus = on ? nm : minus;
+    }
   }
   for (int q = GATHER_MAXD; q < deg; q++) {                  // nodes with more incident edges than the batch (rare)
     unsigned rg = m.ne_rng[q0 + q];
@@ -633,32 +644,15 @@ __device__ __forceinline__ void k_fct_node_col(const DM &m, const int tr) {
     int k = (m.ne_sgn[q0 + q] > 0) ? m.edges[2 * ed + 1] : m.edges[2 * ed];
     double lk = DA2(LOp, nzc, k), tk = DA2(Tp, nzc, k);
     tvmax = dmax_(tvmax, dmax_(lk, tk)); tvmin = dmin_(tvmin, dmin_(lk, tk));
+    double f = DA2(t.adv_flux_raw, nz, ed);
+    if (m.ne_sgn[q0 + q] < 0) f = -f;
+    plus = plus + dmax_(0.0, f);
+    minus = minus + dmin_(0.0, f);
   }
   // under an ice shelf: an element around the node that starts below this level (nz < ulevels(elem)) contributes the untouched entries of the reference's
   // scratch array -- UV_rhs, which no routine writes above an element's upper level, i.e. 0 -- to both bounds (src/oce_adv_tra_fct.F90:110-121,141-142)
   if (wet && nz < m.ulev_n_max[n]) { tvmax = dmax_(tvmax, 0.0); tvmin = dmin_(tvmin, 0.0); }
   double mx_u = shup(tvmax), mx_d = shdn(tvmax), mn_u = shup(tvmin), mn_d = shdn(tvmin);
-  double adv = (nz >= nu1 && nz <= nl1) ? DA2L(t.adv_flux_ver, nz, n) : 0.0;
-  double adv_dn = shdn(adv);
-  double plus = 0.0 + (dmax_(0.0, adv) + dmax_(0.0, -adv_dn));
-  double minus = 0.0 + (dmin_(0.0, adv) + dmin_(0.0, -adv_dn));
-#pragma unroll
-  for (int q = 0; q < GATHER_MAXD; q++) {
-    if (q >= deg) continue;
-    unsigned rg = (unsigned)rdlane((int)rg_l, q);
-    bool on = nz >= (int)(rg & 0xffu) && nz <= (int)((rg >> 8) & 0xffu);
-    double f = (rdlane(sg_l, q) < 0) ? -fh[q] : fh[q];
-    double np = plus + dmax_(0.0, f), nm = minus + dmin_(0.0, f);
-    plus = on ? np : plus; minus = on ? nm : minus;
-  }
-  for (int q = GATHER_MAXD; q < deg; q++) {
-    unsigned rg = m.ne_rng[q0 + q];
-    if (nz < (int)(rg & 0xffu) || nz > (int)((rg >> 8) & 0xffu)) continue;
-    double f = DA2(t.adv_flux_raw, nz, m.ne_idx[q0 + q]);
-    if (m.ne_sgn[q0 + q] < 0) f = -f;
-    plus = plus + dmax_(0.0, f);
-    minus = minus + dmin_(0.0, f);
-  }
   if (wet) {
     double lo = DA2(t.fct_LO, nz, n);
     double bmax, bmin;
