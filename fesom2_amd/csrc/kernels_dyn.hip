@@ -900,6 +900,8 @@ __global__ void __launch_bounds__(BLOCK) k_leith_avg(DM m) {
 // (2) node average, (3) apply (fused into k_impl_visc).  4 N3 + 12 E3 values.
 // visc_option 4 / 6 / 7 (visc_filt_biharm(1) :275-372, visc_filt_bilapl :658-726, visc_filt_bidiff :734-801): the same gather is the first stage of the
 // biharmonic operator (the result lives in U_b, the reference's U_c/V_c), the second stage is k_visc_apply.
+// (measured, round 3: the element's own velocity once + its three neighbours in one batch of loads instead of both triangles edge by edge: 321 -> 318 us on the
+//  basin -- the kernel is bound by its square roots and divisions, 58 % VALU issue, not by its gathers)
 __global__ void __launch_bounds__(BLOCK) k_visc_elem(DM m) {
   int e = col_id(m), nz = lane_id() + 1;
   if (e >= m.E) return;
