@@ -840,8 +840,13 @@ __device__ __forceinline__ bool tru_hor(const DM &m, const TruCol &k, int tr, do
   // edge (+0.0 outside: x + 0.0 == x for the running sums below, which start at +0.0 and therefore never are -0.0) and carrying
   // the sign of this node's end of the edge (x - f == x + (-f) bit for bit), so that the ordered sums are plain additions.
   double fa[MAXD], fd[MAXD];
-  // one slot of the batch (its four loads + the limiter arithmetic)
-  auto slot = [&](int q) {
+#pragma unroll
+  for (int q = 0; q < MAXD; q++) {                       // one batch of independent loads
+    fa[q] = 0.0; fd[q] = 0.0;
+    // wave-uniform: slots beyond the node's degree cost a scalar branch instead of four loads.  Only where the batch is wider than the typical degree
+    // (pi: 10 slots, 51 -> 46 us); with the 6 slots of the tile shapes the branches break up the batch of loads and cost more than they save (1093 -> 1281 us)
+    // (one guarded GROUP for the slots beyond the sixth instead of a branch per slot, as in k_fct_node: measured, no gain on pi -- 46.1 us either way -- and 126 instead of 96 VGPRs)
+    if (GUARD && q >= k.deg) continue;
     int ed = rdlane(k.ed_l, q), kk = rdlane(k.fn_l, q);
     const bool first = rdlane(k.sg_l, q) > 0;               // this node is edges(1,ed)  (wave-uniform)
     const unsigned rg = (unsigned)rdlane((int)k.rg_l, q);
@@ -859,18 +864,6 @@ __device__ __forceinline__ bool tru_hor(const DM &m, const TruCol &k, int tr, do
     double d = dif ? UA2(t.diff_flux, nzc, ed) : 0.0;
     d = 0.0 + __hiloint2double(__double2hiint(d) ^ flip, __double2loint(d));       // (0.0 + fd) resp. (0.0 - fd) of the reference
     fd[q] = on ? d : 0.0;
-  };
-  // The first TRU_G slots (the typical degree) are ONE batch of independent loads: a slot beyond the node's degree reads edge 0 with an empty level range.
-  // The slots beyond (pi: 10 in all) are a second batch that only nodes of higher degree enter -- one wave-uniform branch for the group: a branch per slot
-  // (round 3, first form: 51 -> 46 us on pi) kept the loads of a slot behind the arithmetic of the previous one.
-  constexpr int TRU_G = MAXD < 6 ? MAXD : 6;
-#pragma unroll
-  for (int q = 0; q < MAXD; q++) { fa[q] = 0.0; fd[q] = 0.0; }
-#pragma unroll
-  for (int q = 0; q < TRU_G; q++) slot(q);
-  if (MAXD > TRU_G && (!GUARD || k.deg > TRU_G)) {
-#pragma unroll
-    for (int q = TRU_G; q < MAXD; q++) slot(q);
   }
   double adv = (nz >= nzmin && nz <= nzmax) ? UA2L(t.adv_flux_ver, nz, n) : 0.0;
   double adv_dn = shdn(adv);
