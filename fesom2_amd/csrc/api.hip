@@ -803,7 +803,7 @@ int fesom_gpu_init(const fesom_mesh_desc *d, const fesom_part_desc *part, const 
     }
     for (size_t n = 0; n < N; n++) { double q = d->mesh_resolution[n] / 100000.0; sc[n] = par->K_hor * (q * q); }
     m.redi_k0 = dev_upload(sc);
-    m.exp_batch = getenv("FESOM_GPU_EXP_BATCH") ? atoi(getenv("FESOM_GPU_EXP_BATCH")) : 31;
+    m.exp_batch = getenv("FESOM_GPU_EXP_BATCH") ? atoi(getenv("FESOM_GPU_EXP_BATCH")) : 127;
     m.gm_nzl = d->myDim_nod2D > 0 ? d->ulevels_nod2D_max[d->myDim_nod2D - 1] : 1;
     m.MLD1_ind = dev_alloc<int>(N);
   }

@@ -72,7 +72,7 @@ struct DM {   // device mesh + fields, passed BY VALUE to every kernel (kernarg 
   double *fer_K, *fer_gamma, *fer_Wvel, *fer_c, *fer_UV;   // (nl,N), (2,nl,N), (nl,N), (N), (2,nl-1,E)
   const double *lat_deg;                                  // (N) geographic latitude in degrees (geo_coord_nod2D(2,:)/rad), Kv0_const = .false. only
   const int *nb_lay;                                      // (N) nboundary_lay (oce_muscl_adv.F90:74-104), tra_adv_hor = MUSCL only
-  int exp_batch;                                          // bit mask (FESOM_GPU_EXP_BATCH, default all on): kernels that issue their column gathers as ONE batch of independent loads and select afterwards (1 k_kpp_elem, 2 k_diff_flux, 4 k_vel_nodes, 8 k_visc_node, 16 k_fer_wvel)
+  int exp_batch;                                          // bit mask (FESOM_GPU_EXP_BATCH, default all on): kernels that issue their column gathers as ONE batch of independent loads and select afterwards (1 k_kpp_elem, 2 k_diff_flux, 4 k_vel_nodes, 8 k_visc_node, 16 k_fer_wvel, 64 k_flux_hor_nt: one load per up/down-wind value through a per-lane address select)
   int gm_nzl;                                             // max upper level over the elements of the LAST owned node: where init_Redi_GM copies fer_K into Ki (src/oce_fer_gm.F90:250)
   const double *redi_k0;                                  // (N) K_hor*(mesh_resolution/100km)^2: surface Ki of Redi without GM
   const double *gm_scal_A, *gm_scal_B, *mesh_resolution;    // (N) scaling_Rossby: the resolution scaling and the ramp as separate factors (the Rossby factor is applied first), mesh_resolution

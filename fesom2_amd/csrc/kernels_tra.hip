@@ -324,6 +324,14 @@ __global__ void __launch_bounds__(BLOCK) k_flux_hor_nt(DM m, int tr0) {
   const int hor = m.p.tra_adv_hor;                          // 0 MFCT, 1 MUSCL, 2 UPW1 as the high-order scheme
   UpdnIdx ux;
   if (FUSED && !dead && hor != 2) ux = updn_index(m, ed, nz);
+  const bool sel_addr = FUSED && m.cl_grad != nullptr && hor != 2 && (m.exp_batch & 64);      // (wave-uniform)
+  // velocities and thicknesses of the two triangles: unconditional loads (a missing second triangle re-reads the first), selected below
+  const int e2c = e2 >= 0 ? e2 : e1;
+  double u1x = 0, u1y = 0, h1 = 0, u2x = 0, u2y = 0, h2 = 0;
+  if (sel_addr) {
+    u1x = DV2(m.UV, 1, nz, e1); u1y = DV2(m.UV, 2, nz, e1); h1 = DA2(m.helem, nz, e1);
+    u2x = DV2(m.UV, 1, nz, e2c); u2y = DV2(m.UV, 2, nz, e2c); h2 = DA2(m.helem, nz, e2c);
+  }
   // loads of all tracers
   double t1[NT], t2[NT], s1[NT], s2[NT], g1[NT], g2[NT], g3[NT], g4[NT];
 #pragma unroll
@@ -335,7 +343,16 @@ __global__ void __launch_bounds__(BLOCK) k_flux_hor_nt(DM m, int tr0) {
     t1[q] = DTR(m.tr_arr, nz, n1, tr); t2[q] = DTR(m.tr_arr, nz, n2, tr);
     s1[q] = DTR(m.tr_arr_old, nz, n1, tr); s2[q] = DTR(m.tr_arr_old, nz, n2, tr);
     if (hor == 2) continue;
-    if (FUSED) {
+    if (sel_addr) {
+      // each of the four up/down-wind values comes from ONE of three places -- the upwind triangle's gradient, the cluster mean of k_cluster_grad at the
+      // edge's node, or the entry of edge_up_dn_grad (a level neither covers): the ADDRESS is selected per lane and one load per value is issued
+      const double *cg = m.cl_grad + (size_t)tr * 2 * m.nlm1 * m.N;
+      const double *p1 = ux.both ? &DV2(t.tr_xy_ab, 1, nz, ux.t1) : (ux.c1 ? &DV2(cg, 1, nz, ux.n1) : &DV4(t.edge_up_dn_grad, 1, nz, ed));
+      const double *p3 = ux.both ? &DV2(t.tr_xy_ab, 2, nz, ux.t1) : (ux.c1 ? &DV2(cg, 2, nz, ux.n1) : &DV4(t.edge_up_dn_grad, 3, nz, ed));
+      const double *p2 = ux.both ? &DV2(t.tr_xy_ab, 1, nz, ux.t2) : (ux.c2 ? &DV2(cg, 1, nz, ux.n2) : &DV4(t.edge_up_dn_grad, 2, nz, ed));
+      const double *p4 = ux.both ? &DV2(t.tr_xy_ab, 2, nz, ux.t2) : (ux.c2 ? &DV2(cg, 2, nz, ux.n2) : &DV4(t.edge_up_dn_grad, 4, nz, ed));
+      g1[q] = *p1; g2[q] = *p2; g3[q] = *p3; g4[q] = *p4;
+    } else if (FUSED) {
       bool w1, w2;
       if (m.cl_grad) updn_values<true>(m, t, tr, ux, nz, g1[q], g2[q], g3[q], g4[q], w1, w2);       // (wave-uniform: the node field of k_cluster_grad exists)
       else updn_values<false>(m, t, tr, ux, nz, g1[q], g2[q], g3[q], g4[q], w1, w2);
@@ -347,7 +364,11 @@ __global__ void __launch_bounds__(BLOCK) k_flux_hor_nt(DM m, int tr0) {
     }
   }
   double vflux = 0.0;
-  if (use1 && use2)
+  if (sel_addr) {
+    if (use1 && use2) vflux = (-u1y * dX1 + u1x * dY1) * h1 + (u2y * dX2 - u2x * dY2) * h2;
+    else if (use1) vflux = (-u1y * dX1 + u1x * dY1) * h1;
+    else if (use2) vflux = (u2y * dX2 - u2x * dY2) * h2;
+  } else if (use1 && use2)
     vflux = (-DV2(m.UV, 2, nz, e1) * dX1 + DV2(m.UV, 1, nz, e1) * dY1) * DA2(m.helem, nz, e1) +
             (DV2(m.UV, 2, nz, e2) * dX2 - DV2(m.UV, 1, nz, e2) * dY2) * DA2(m.helem, nz, e2);
   else if (use1) vflux = (-DV2(m.UV, 2, nz, e1) * dX1 + DV2(m.UV, 1, nz, e1) * dY1) * DA2(m.helem, nz, e1);
