@@ -208,7 +208,7 @@ def roofline_object(core, mesh, wl, sps):
                                 "GBs": (round(kbytes[k] / times[k] / 1e9, 1) if k in kbytes and times[k] > 0 else None)}
                             for k in sorted(times, key=lambda k: -share[k])},
                 # (bolus_remove is timed as a kernel of its own above -- its bytes are real work -- but in the running step it rides in the k_thick launch)
-                "launches_per_step": int(sum(mult.values())) + solver_launches(core) - (1 if (p.Fer_GM and p.which_ale != 0) else 0),
+                "launches_per_step": int(sum(mult.values())) + solver_launches(core) - (1 if (core.params.Fer_GM and core.params.which_ale != 0) else 0),
                 "byte_table_audit": audit_byte_table(times, kbytes, wkey, redi)}
     rows = mesh.myDim_nod2D
     nnz = int(mesh.ssh_nza)

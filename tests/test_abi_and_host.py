@@ -266,3 +266,39 @@ def test_bench_byte_table_covers_every_kernel_of_the_step():
                 assert k in b.KERNEL_VALUES, k
     for k in b.PER_TRACER + tuple(b.REDI_EXTRA) + tuple(b.SHARED_ONCE) + tuple(b.SHARED_ONCE_REDI):
         assert k in b.KERNEL_VALUES, k
+
+
+def test_bench_has_no_undefined_names():
+    """bench.py only runs end to end on a GPU box: a static pass over its functions for names that are neither bound in the function (arguments, assignments,
+    loop / with / except targets, comprehensions, imports), nor at module level, nor builtins -- the class of slip a CPU-only round cannot see otherwise."""
+    import ast
+    import builtins
+    src = open(os.path.join(REPO, "bench.py")).read()
+    tree = ast.parse(src)
+
+    def bound(node):
+        names = set()
+        for n in ast.walk(node):
+            if isinstance(n, ast.Name) and isinstance(n.ctx, (ast.Store, ast.Del)):
+                names.add(n.id)
+            elif isinstance(n, ast.arg):
+                names.add(n.arg)
+            elif isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)):
+                names.add(n.name)
+            elif isinstance(n, (ast.Import, ast.ImportFrom)):
+                for a in n.names:
+                    names.add((a.asname or a.name).split(".")[0])
+            elif isinstance(n, ast.ExceptHandler) and n.name:
+                names.add(n.name)
+            elif isinstance(n, (ast.Global, ast.Nonlocal)):
+                names.update(n.names)
+        return names
+
+    module_names = bound(tree) | set(dir(builtins))
+    missing = []
+    for fn in [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef))]:
+        local = bound(fn)
+        for n in ast.walk(fn):
+            if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load) and n.id not in local and n.id not in module_names:
+                missing.append(f"{fn.name}:{n.lineno} {n.id}")
+    assert not missing, missing
