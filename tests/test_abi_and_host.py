@@ -269,36 +269,64 @@ def test_bench_byte_table_covers_every_kernel_of_the_step():
 
 
 def test_bench_has_no_undefined_names():
-    """bench.py only runs end to end on a GPU box: a static pass over its functions for names that are neither bound in the function (arguments, assignments,
-    loop / with / except targets, comprehensions, imports), nor at module level, nor builtins -- the class of slip a CPU-only round cannot see otherwise."""
+    """bench.py only runs end to end on a GPU box: a static pass over its functions for names that are neither bound in the function or an enclosing one
+    (arguments, assignments, loop / with / except targets, comprehensions, imports), nor at module level, nor builtins -- the class of slip a CPU-only
+    round cannot see otherwise."""
     import ast
     import builtins
-    src = open(os.path.join(REPO, "bench.py")).read()
-    tree = ast.parse(src)
+    FN = (ast.FunctionDef, ast.AsyncFunctionDef, ast.Lambda)
 
-    def bound(node):
+    def bound(node, top=True):
+        """names bound in the scope of `node` itself (nested function bodies excluded, their names included)"""
         names = set()
-        for n in ast.walk(node):
+        if isinstance(node, FN):
+            a = node.args
+            for x in a.posonlyargs + a.args + a.kwonlyargs + ([a.vararg] if a.vararg else []) + ([a.kwarg] if a.kwarg else []):
+                names.add(x.arg)
+        stack = list(ast.iter_child_nodes(node))
+        while stack:
+            n = stack.pop()
+            if isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)):
+                names.add(n.name)
+                continue                                   # (another scope)
+            if isinstance(n, ast.Lambda):
+                continue
             if isinstance(n, ast.Name) and isinstance(n.ctx, (ast.Store, ast.Del)):
                 names.add(n.id)
-            elif isinstance(n, ast.arg):
-                names.add(n.arg)
-            elif isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)):
-                names.add(n.name)
             elif isinstance(n, (ast.Import, ast.ImportFrom)):
-                for a in n.names:
-                    names.add((a.asname or a.name).split(".")[0])
+                for al in n.names:
+                    names.add((al.asname or al.name).split(".")[0])
             elif isinstance(n, ast.ExceptHandler) and n.name:
                 names.add(n.name)
             elif isinstance(n, (ast.Global, ast.Nonlocal)):
                 names.update(n.names)
+            stack.extend(ast.iter_child_nodes(n))
         return names
 
-    module_names = bound(tree) | set(dir(builtins))
     missing = []
-    for fn in [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef))]:
-        local = bound(fn)
-        for n in ast.walk(fn):
-            if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load) and n.id not in local and n.id not in module_names:
-                missing.append(f"{fn.name}:{n.lineno} {n.id}")
-    assert not missing, missing
+
+    def check(node, outer):
+        scope = outer | bound(node)
+        stack = list(ast.iter_child_nodes(node))
+        while stack:
+            n = stack.pop()
+            if isinstance(n, FN):
+                check(n, scope)
+                continue
+            if isinstance(n, ast.ClassDef):
+                continue
+            if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load) and n.id not in scope:
+                missing.append(f"{getattr(node, 'name', '<lambda>')}:{n.lineno} {n.id}")
+            stack.extend(ast.iter_child_nodes(n))
+
+    for fname in ("bench.py", "__graft_entry__.py", os.path.join("fesom2_amd", "workloads.py"), os.path.join("fesom2_amd", "core.py"), os.path.join("fesom2_amd", "parallel.py")):
+        tree = ast.parse(open(os.path.join(REPO, fname)).read())
+        top = bound(tree) | set(dir(builtins))
+        for n in ast.iter_child_nodes(tree):
+            if isinstance(n, FN):
+                check(n, top)
+            elif isinstance(n, ast.ClassDef):
+                for mth in ast.iter_child_nodes(n):
+                    if isinstance(mth, FN):
+                        check(mth, top)
+        assert not missing, (fname, missing)
