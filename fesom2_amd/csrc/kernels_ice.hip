@@ -37,6 +37,7 @@ struct IceDM {
   double *sig[2];            // [parity] -> 3 * myE (sigma11 | sigma12 | sigma22)
   double *ua[2], *va[2];
   double *rhs_a, *rhs_m, *invt, *mass, *pfac, *efac;
+  double *alpha, *beta;      // aEVP (whichEVP = 2): alpha_evp_array (myE), beta_evp_array (N)
   unsigned char *ice_nod, *ice_el;
   // FCT advection (src/ice_fct.F90): CSR pattern of the owned rows (= nn_pos / ssh_stiff, 0-based), consistent mass matrix, work arrays of 3 tracers
   const int *rp, *ci;
@@ -473,6 +474,152 @@ __global__ void k_ice_unpackw(double *__restrict__ base, size_t N, int W, const 
   for (int f = 0; f < W; f++) base[f * N + list[i]] = buf[(size_t)first * W + (size_t)f * cnt + (i - first)];
 }
 
+// ---- adaptive EVP, EVPdynamics_a (src/ice_maEVP.F90:785-888; whichEVP = 2, one partition).  Not the fused order of EVPdynamics_m: every sum and product as
+// ssh2rhs / stress_tensor_a / stress2rhs_m / the node loop / find_alpha_field_a / find_beta_field_a write them.  Two launches per subcycle: the element stresses
+// (in place, each element is independent), then the node gather over the node's elements in increasing index (= the order of the reference's scatter) + update.
+__global__ void k_ice_a_prep(IceDM m) {                      // u_ice_aux = u_ice; ssh2rhs (:130-202) as a node gather
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.N) return;
+  m.ua[0][i] = m.u_ice[i]; m.va[0][i] = m.v_ice[i];
+  if (i >= m.myN) return;
+  const double val3 = 1.0 / 3.0;
+  double ra = 0.0, rm = 0.0;
+  for (int k = 0; k < m.nie_num[i]; k++) {
+    const int el = m.nie[(size_t)m.maxk * i + k];
+    const int *en = m.en + 3 * el;
+    const double *gs = m.gsca + 6 * (size_t)el;
+    double e3[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      e3[q] = m.elev[en[q]];
+      if (m.p.use_floatice) {
+        double pi = (ICE_RHOICE * m.m_ice[en[q]] + ICE_RHOSNO * m.m_snow[en[q]]) * ICE_INV_RHOWAT;
+        pi = pi < m.p.max_ice_loading ? pi : m.p.max_ice_loading;
+        e3[q] = e3[q] + pi;
+      }
+    }
+    double bb = ICE_G * val3 * m.elem_area[el];
+    const double aa = bb * ((gs[0] * e3[0] + gs[1] * e3[1]) + gs[2] * e3[2]);
+    bb = bb * ((gs[3] * e3[0] + gs[4] * e3[1]) + gs[5] * e3[2]);
+    ra = ra - aa; rm = rm - bb;
+  }
+  m.rhs_a[i] = ra; m.rhs_m[i] = rm;
+}
+// strain rates of stress_tensor_a / find_alpha_field_a (:719-741, :644-662); returns false where the element carries no ice (msum <= 0.01)
+__device__ __forceinline__ bool ice_a_strain(const IceDM &m, int el, const double *uo, const double *vo, double &eps1, double &eps2, double &eps12, double &delta, double &msum) {
+  const int *en = m.en + 3 * el;
+  const double val3 = 1.0 / 3.0, vale = 1.0 / (m.p.ellipse * m.p.ellipse);
+  msum = ((m.m_ice[en[0]] + m.m_ice[en[1]]) + m.m_ice[en[2]]) * val3;
+  if (msum <= 0.01) return false;
+  const double *dx = m.gsca + 6 * (size_t)el, *dy = dx + 3;
+  const double u1 = uo[en[0]], u2 = uo[en[1]], u3 = uo[en[2]], v1 = vo[en[0]], v2 = vo[en[1]], v3 = vo[en[2]];
+  const double vsum = (v1 + v2) + v3, usum = (u1 + u2) + u3, meancos = m.metric[el];
+  double eps11 = (dx[0] * u1 + dx[1] * u2) + dx[2] * u3;
+  eps11 = eps11 - val3 * vsum * meancos;
+  const double eps22 = (dy[0] * v1 + dy[1] * v2) + dy[2] * v3;
+  eps12 = 0.5 * (((dy[0] * u1 + dx[0] * v1) + (dy[1] * u2 + dx[1] * v2)) + (dy[2] * u3 + dx[2] * v3));
+  eps12 = eps12 + 0.5 * val3 * usum * meancos;
+  eps1 = eps11 + eps22; eps2 = eps11 - eps22;
+  delta = eps1 * eps1 + vale * (eps2 * eps2 + 4.0 * (eps12 * eps12));
+  delta = sqrt(delta);
+  return true;
+}
+__global__ void k_ice_a_stress(IceDM m, int par, int sp) {    // stress_tensor_a; sp = parity of the stress buffers (in place)
+  const int el = blockIdx.x * blockDim.x + threadIdx.x;
+  if (el >= m.myE) return;
+  double eps1, eps2, eps12, delta, msum;
+  if (!ice_a_strain(m, el, m.ua[par], m.va[par], eps1, eps2, eps12, delta, msum)) return;
+  const size_t E = (size_t)m.myE;
+  double *sg = m.sig[sp];
+  const double vale = 1.0 / (m.p.ellipse * m.p.ellipse), alpha = m.alpha[el];
+  const double det2 = 1.0 / (1.0 + alpha), det1 = alpha * det2;
+  const double pressure = m.p.Pstar * msum * m.efac[el] / (delta + m.p.delta_min);      // (exp(-c_pressure (1 - asum)) from the host: efac)
+  const double r1 = pressure * (eps1 - delta), r2 = pressure * eps2 * vale, r3 = pressure * eps12 * vale;
+  double si1 = sg[el] + sg[2 * E + el], si2 = sg[el] - sg[2 * E + el];
+  si1 = det1 * si1 + det2 * r1;
+  si2 = det1 * si2 + det2 * r2;
+  sg[E + el] = det1 * sg[E + el] + det2 * r3;
+  sg[el] = 0.5 * (si1 + si2);
+  sg[2 * E + el] = 0.5 * (si1 - si2);
+}
+__global__ void k_ice_a_node(IceDM m, int par, int sp) {      // stress2rhs_m (:206-272) + the node update (:831-856) + coastal nodes (:860-867)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.N) return;
+  const double *uo = m.ua[par], *vo = m.va[par];
+  double *un = m.ua[1 - par], *vn = m.va[1 - par];
+  if (i >= m.myN) { un[i] = uo[i]; vn[i] = vo[i]; return; }
+  const size_t E = (size_t)m.myE;
+  const double *sg = m.sig[sp];
+  const double val3 = 1.0 / 3.0, rdt = m.p.ice_dt;
+  double urhs = 0.0, vrhs = 0.0;
+  for (int k = 0; k < m.nie_num[i]; k++) {
+    const int el = m.nie[(size_t)m.maxk * i + k];
+    const int n1 = m.en[3 * el], n2 = m.en[3 * el + 1], n3 = m.en[3 * el + 2];
+    if ((m.a_ice[n1] + m.a_ice[n2]) + m.a_ice[n3] < 0.01) continue;
+    const double vol = m.elem_area[el], mf = m.metric[el];
+    const double *dx = m.gsca + 6 * (size_t)el, *dy = dx + 3;
+    const double s11 = sg[el], s12 = sg[E + el], s22 = sg[2 * E + el];
+    const int pos = (n1 == i) ? 0 : ((n2 == i) ? 1 : 2);
+    urhs = urhs - vol * (s11 * dx[pos] + s12 * dy[pos]) - vol * s12 * val3 * mf;
+    vrhs = vrhs - vol * (s12 * dx[pos] + s22 * dy[pos]) + vol * s11 * val3 * mf;
+  }
+  double mass = (m.m_ice[i] * ICE_RHOICE + m.m_snow[i] * ICE_RHOSNO);
+  mass = mass / (1.0 + mass * mass);
+  urhs = (urhs * mass + m.rhs_a[i]) / m.area1[i];
+  vrhs = (vrhs * mass + m.rhs_m[i]) / m.area1[i];
+  const double ai = m.a_ice[i];
+  double thickness = (ICE_RHOICE * m.m_ice[i] + ICE_RHOSNO * m.m_snow[i]) / (ai > 0.01 ? ai : 0.01);
+  thickness = thickness > 9.0 ? thickness : 9.0;
+  const double inv_thickness = 1.0 / thickness;
+  double ua = uo[i], va = vo[i];
+  const double uw = m.u_w[i], vw = m.v_w[i];
+  const double du = ua - uw, dv = va - vw;
+  const double umod = sqrt(du * du + dv * dv);
+  const double drag = rdt * m.p.cd_oce_ice * umod * ICE_DENSITY_0 * inv_thickness;
+  double rhsu = m.u_ice[i] + drag * uw + rdt * (inv_thickness * m.tax[i] + urhs);
+  double rhsv = m.v_ice[i] + drag * vw + rdt * (inv_thickness * m.tay[i] + vrhs);
+  const double beta = m.beta[i];
+  rhsu = beta * ua + rhsu;
+  rhsv = beta * va + rhsv;
+  const double fc = rdt * m.cori_n[i];
+  double det = (1.0 + beta + drag) * (1.0 + beta + drag) + fc * fc;
+  det = (m.bnd[i] ? 0.0 : 1.0) / det;
+  ua = det * ((1.0 + beta + drag) * rhsu + fc * rhsv);
+  va = det * ((1.0 + beta + drag) * rhsv - fc * rhsu);
+  if (m.bnd[i]) { ua = 0.0; va = 0.0; }
+  un[i] = ua; vn[i] = va;
+}
+__global__ void k_ice_a_alpha(IceDM m, int par) {             // find_alpha_field_a (:611-683) on the final velocities
+  const int el = blockIdx.x * blockDim.x + threadIdx.x;
+  if (el >= m.myE) return;
+  double eps1, eps2, eps12, delta, msum;
+  if (!ice_a_strain(m, el, m.ua[par], m.va[par], eps1, eps2, eps12, delta, msum)) return;
+  const double pressure = m.p.Pstar * m.efac[el] / (delta + m.p.delta_min);
+  const double al = sqrt(m.p.ice_dt * m.p.c_aevp * pressure / ICE_RHOICE / m.elem_area[el]);
+  m.alpha[el] = al > 50.0 ? al : 50.0;
+}
+__global__ void k_ice_a_beta(IceDM m) {                       // find_beta_field_a (:892-922): the largest alpha of the node's elements
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.myN) return;
+  double b = m.alpha[m.nie[(size_t)m.maxk * i]];
+  for (int k = 1; k < m.nie_num[i]; k++) { const double a = m.alpha[m.nie[(size_t)m.maxk * i + k]]; b = a > b ? a : b; }
+  m.beta[i] = b;
+}
+// one EVPdynamics_a call: the stresses stay in sig[sp] (in place); the velocities alternate and end in u_ice / v_ice
+void enqueue_call_a(hipStream_t s, int sp) {
+  const IceDM &m = I.m;
+  hipLaunchKernelGGL(k_ice_a_prep, dim3((m.N + 255) / 256), dim3(256), 0, s, m);
+  int par = 0;
+  for (int k = 0; k < m.p.evp_rheol_steps; k++) {
+    hipLaunchKernelGGL(k_ice_a_stress, dim3((m.myE + 255) / 256), dim3(256), 0, s, m, par, sp);
+    hipLaunchKernelGGL(k_ice_a_node, dim3((m.N + 127) / 128), dim3(128), 0, s, m, par, sp);
+    par = 1 - par;
+  }
+  hipLaunchKernelGGL(k_ice_finish, dim3((m.N + 255) / 256), dim3(256), 0, s, m, par);
+  hipLaunchKernelGGL(k_ice_a_alpha, dim3((m.myE + 255) / 256), dim3(256), 0, s, m, par);
+  hipLaunchKernelGGL(k_ice_a_beta, dim3((m.myN + 255) / 256), dim3(256), 0, s, m);
+}
+
 // one EVPdynamics_m call; the stresses start in parity I.cur; returns the parity they end in
 int enqueue_call(hipStream_t s, int par) {
   const IceDM &m = I.m;
@@ -575,6 +722,13 @@ int fesom_gpu_ice_init(const fesom_mesh_desc *d, const fesom_part_desc *part, co
     m.pp = ialloc<double>(6 * N); m.flx = ialloc<double>(9 * E);
   }
   m.sig[0] = ialloc<double>(3 * E); m.sig[1] = ialloc<double>(3 * E); m.pfac = ialloc<double>(E); m.efac = ialloc<double>(E);
+  m.alpha = m.beta = nullptr;
+  if (par->whichEVP == 2) {      // alpha_evp_array = beta_evp_array = alpha_evp at the start (src/ice_setup_step.F90:85-89)
+    m.alpha = ialloc<double>(E); m.beta = ialloc<double>(N);
+    std::vector<double> ha(E, par->alpha_evp), hb(N, par->alpha_evp);
+    if (m.alpha) hipMemcpy(m.alpha, ha.data(), sizeof(double) * E, hipMemcpyHostToDevice);
+    if (m.beta) hipMemcpy(m.beta, hb.data(), sizeof(double) * N, hipMemcpyHostToDevice);
+  }
   m.ice_nod = ialloc<unsigned char>(N); m.ice_el = ialloc<unsigned char>(E);
   for (void *p : I.allocs) if (!p) { I.err = "fesom_gpu_ice_init: device allocation failed"; return 1; }
   I.h_efac.assign(E, 0.0);
@@ -609,6 +763,8 @@ int fesom_gpu_ice_upload(const fesom_ice_state *st) {
   if (st->sigma11) ICECHK(hipMemcpy(sg, st->sigma11, sizeof(double) * E, hipMemcpyHostToDevice));
   if (st->sigma12) ICECHK(hipMemcpy(sg + E, st->sigma12, sizeof(double) * E, hipMemcpyHostToDevice));
   if (st->sigma22) ICECHK(hipMemcpy(sg + 2 * E, st->sigma22, sizeof(double) * E, hipMemcpyHostToDevice));
+  if (m.alpha && st->alpha_evp_array) ICECHK(hipMemcpy(m.alpha, st->alpha_evp_array, sizeof(double) * E, hipMemcpyHostToDevice));
+  if (m.beta && st->beta_evp_array) ICECHK(hipMemcpy(m.beta, st->beta_evp_array, sizeof(double) * m.N, hipMemcpyHostToDevice));
   if (st->a_ice) {      // exp of the pressure factor on the host (glibc exp, the reference's)
     const double val3 = 1.0 / 3.0;
     for (size_t el = 0; el < E; el++) {
@@ -622,6 +778,12 @@ int fesom_gpu_ice_upload(const fesom_ice_state *st) {
 }
 int fesom_gpu_ice_evp(int ncalls) {
   ICE_READY();
+  if (I.m.p.whichEVP == 2) {                                 // adaptive EVP: EVPdynamics_a
+    if (I.npes > 1) { I.err = "ice_evp: whichEVP = 2 (adaptive EVP) is built for one partition"; return 1; }
+    for (int c = 0; c < ncalls; c++) enqueue_call_a(I.stream, I.cur);
+    ICECHK(hipGetLastError());
+    return 0;
+  }
   for (int c = 0; c < ncalls; c++) {
     if (I.m.p.evp_rheol_steps % 2 == 0 && I.cur == 0) {      // the usual case: an even number of subcycles returns to parity 0 -> one fixed graph
       if (!I.graph) {
@@ -644,6 +806,7 @@ int fesom_gpu_ice_evp(int ncalls) {
 int fesom_gpu_ice_evp_partitioned(int ncalls, const fesom_transport *t) {
   ICE_READY();
   if (I.npes < 2) return fesom_gpu_ice_evp(ncalls);
+  if (I.m.p.whichEVP == 2) { I.err = "ice_evp_partitioned: whichEVP = 2 (adaptive EVP) is built for one partition"; return 1; }
   if (t && !t->exchange) { I.err = "ice_evp_partitioned: transport callback missing"; return 1; }
   const IceDM &m = I.m;
   const int *sptr_d = I.sptr_d, *rptr_d = I.rptr_d;
@@ -773,6 +936,8 @@ int fesom_gpu_ice_download(const fesom_ice_state *st) {
   if (st->sigma11) ICECHK(hipMemcpy(st->sigma11, sg, sizeof(double) * E, hipMemcpyDeviceToHost));
   if (st->sigma12) ICECHK(hipMemcpy(st->sigma12, sg + E, sizeof(double) * E, hipMemcpyDeviceToHost));
   if (st->sigma22) ICECHK(hipMemcpy(st->sigma22, sg + 2 * E, sizeof(double) * E, hipMemcpyDeviceToHost));
+  if (m.alpha && st->alpha_evp_array) ICECHK(hipMemcpy(st->alpha_evp_array, m.alpha, sizeof(double) * E, hipMemcpyDeviceToHost));
+  if (m.beta && st->beta_evp_array) ICECHK(hipMemcpy(st->beta_evp_array, m.beta, sizeof(double) * m.N, hipMemcpyDeviceToHost));
   return 0;
 }
 int fesom_gpu_ice_time_ms(int ncalls, double *ms_per_call) {

@@ -315,7 +315,7 @@ int  fesom_gpu_set_stream(void *hip_stream);   /* run the library's kernels on t
  * and viscous-plastic stresses on elements, stress divergence gathered to nodes, implicit Coriolis / ocean-drag velocity update,
  * coastal boundary condition.  Independent of the ocean core's context (may coexist with it); partitions: fesom_gpu_ice_evp_partitioned.
  * Arrays keep the reference's extents: node fields myDim_nod2D + eDim_nod2D, stresses myDim_elem2D.  Not built: cavities
- * (ulevels > 1), icepack, the other two EVP variants (whichEVP = 0, 2). */
+ * (ulevels > 1), icepack, the classic EVP (whichEVP = 0).  whichEVP = 2 (adaptive EVP, EVPdynamics_a :785-888) is built for one partition: fesom_ice_params.whichEVP. */
 typedef struct fesom_ice_params {
   double ice_dt;             /* ice_ave_steps * dt */
   double ellipse, alpha_evp, beta_evp, Pstar, c_pressure, delta_min, cd_oce_ice;   /* namelist.ice &ice_dyn (src/ice_modules.F90:7-27) */
@@ -323,16 +323,19 @@ typedef struct fesom_ice_params {
   int    evp_rheol_steps;
   int    use_floatice;       /* use_floatice .and. which_ALE /= 'linfs' (ice_maEVP.F90:159): ice + snow load in the sea-surface slope term */
   double ice_gamma_fct;      /* smoothing parameter of the FCT advection (namelist.ice &ice_dyn, src/ice_modules.F90:27: 0.25) */
+  int    whichEVP;           /* 1 (and 0 in this struct's zero default) = mEVP, EVPdynamics_m; 2 = adaptive EVP, EVPdynamics_a (src/ice_maEVP.F90:785-888; one partition) */
+  double c_aevp;             /* aEVP: constant of the adaptive alpha (namelist.ice &ice_dyn, src/ice_modules.F90:36: 0.15) */
 } fesom_ice_params;
 typedef struct fesom_ice_state {
   double *u_ice, *v_ice;                                            /* in / out */
   double *a_ice, *m_ice, *m_snow;                                   /* in; in / out of the advection */
   double *elevation, *u_w, *v_w, *stress_atmice_x, *stress_atmice_y;   /* in */
   double *sigma11, *sigma12, *sigma22;                              /* in / out: the stresses are state across calls */
+  double *alpha_evp_array, *beta_evp_array;                         /* aEVP, in / out: (myDim_elem2D), (nodes); state across calls, = alpha_evp at the start (src/ice_setup_step.F90:85-89) */
 } fesom_ice_state;
 int  fesom_gpu_ice_init(const fesom_mesh_desc *mesh, const fesom_part_desc *part, const fesom_ice_params *par);
 int  fesom_gpu_ice_upload(const fesom_ice_state *st);     /* every non-NULL field host -> device */
-int  fesom_gpu_ice_evp(int ncalls);                       /* ncalls x EVPdynamics_m on the device-resident state; asynchronous */
+int  fesom_gpu_ice_evp(int ncalls);                       /* ncalls x EVPdynamics_m (whichEVP = 2: EVPdynamics_a) on the device-resident state; asynchronous */
 int  fesom_gpu_ice_evp_partitioned(int ncalls, const fesom_transport *t);   /* npes > 1: halo of (u_ice_aux, v_ice_aux) after every subcycle (ice_maEVP.F90:588-596); t == NULL: built-in RCCL transport */
 /* FCT advection of m_ice, a_ice, m_snow with the current ice velocities = the "Advection part" of ice_timestep (src/ice_setup_step.F90:213-232):
  * ice_TG_rhs_div, ice_fct_solve (ice_solve_high_order, ice_solve_low_order, ice_fem_fct x 3), ice_update_for_div (src/ice_fct.F90), cut_off

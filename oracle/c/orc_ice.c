@@ -1,4 +1,4 @@
-/* ORACLE (test infrastructure): CPU restatement of the sea-ice mEVP rheology, EVPdynamics_m (src/ice_maEVP.F90:273-602; whichEVP = 1,
+/* ORACLE (test infrastructure): CPU restatement of the sea-ice rheologies EVPdynamics_a (adaptive EVP, below) and mEVP, EVPdynamics_m (src/ice_maEVP.F90:273-602; whichEVP = 1,
  * no cavities, no icepack), loop for loop in the reference's order.  Pinned bitwise on a run of the reference's own routine
  * (oracle/_ref, driver mode 'ice', one MPI rank: tests/golden/ice_evp_reference.npz, tests/test_ice.py).  Stand-alone: it works
  * on a mesh descriptor and the ice arrays, not on the ocean context. */
@@ -112,6 +112,133 @@ int orc_ice_evp(const fesom_mesh_desc *m, const fesom_ice_params *p, fesom_ice_s
   }
   memcpy(s->u_ice, ua, sizeof(double) * N); memcpy(s->v_ice, va, sizeof(double) * N);
   free(ua); free(va); free(rhs_a); free(rhs_m); free(urhs); free(vrhs); free(invt); free(mass); free(pfac); free(ice_nod); free(ice_el); free(bnd);
+  return 0;
+}
+
+/* Adaptive EVP, EVPdynamics_a (src/ice_maEVP.F90:785-888; whichEVP = 2): ssh2rhs (:130-202), per subcycle stress_tensor_a (:686-784) with the element's
+ * own alpha, stress2rhs_m (:206-272), the node update with the node's beta (:831-856), coastal nodes (:860-877); after the subcycles find_alpha_field_a
+ * (:611-683) and find_beta_field_a (:892-922).  Not the fused order of EVPdynamics_m above: every sum and product as these routines write them.
+ * One partition.  Pinned bitwise on a run of the reference's own routine (tests/golden/ice_aevp_reference.npz, tests/test_ice.py). */
+int orc_ice_evp_a(const fesom_mesh_desc *m, const fesom_ice_params *p, fesom_ice_state *s) {
+  const int myN = m->myDim_nod2D, N = myN + m->eDim_nod2D, myE = m->myDim_elem2D, nl = m->nl;
+  const double val3 = 1.0 / 3.0, vale = 1.0 / (p->ellipse * p->ellipse), rdt = p->ice_dt;
+  double *ua = malloc(sizeof(double) * N), *va = malloc(sizeof(double) * N), *rhs_a = calloc(N, sizeof(double)), *rhs_m = calloc(N, sizeof(double));
+  double *urhs = calloc(N, sizeof(double)), *vrhs = calloc(N, sizeof(double));
+  char *bnd = calloc(N, 1);
+  memcpy(ua, s->u_ice, sizeof(double) * N); memcpy(va, s->v_ice, sizeof(double) * N);
+  for (int ed = 0; ed < m->myDim_edge2D; ed++)
+    if (m->myList_edge2D[ed] > m->edge2D_in) { bnd[m->edges[2 * ed] - 1] = 1; bnd[m->edges[2 * ed + 1] - 1] = 1; }
+  /* ssh2rhs */
+  for (int el = 0; el < myE; el++) {
+    if (m->ulevels[el] > 1) continue;
+    const int *en = m->elem2D_nodes + 3 * el;
+    const double *gs = m->gradient_sca + 6 * (size_t)el;
+    double e3[3];
+    for (int k = 0; k < 3; k++) {
+      e3[k] = s->elevation[en[k] - 1];
+      if (p->use_floatice) {
+        double pi = (RHOICE * s->m_ice[en[k] - 1] + RHOSNO * s->m_snow[en[k] - 1]) * INV_RHOWAT;
+        pi = pi < p->max_ice_loading ? pi : p->max_ice_loading;
+        e3[k] = e3[k] + pi;
+      }
+    }
+    double bb = G_ACC * val3 * m->elem_area[el];
+    const double aa = bb * ((gs[0] * e3[0] + gs[1] * e3[1]) + gs[2] * e3[2]);
+    bb = bb * ((gs[3] * e3[0] + gs[4] * e3[1]) + gs[5] * e3[2]);
+    for (int k = 0; k < 3; k++) { rhs_a[en[k] - 1] = rhs_a[en[k] - 1] - aa; rhs_m[en[k] - 1] = rhs_m[en[k] - 1] - bb; }
+  }
+  for (int sub = 0; sub <= p->evp_rheol_steps; sub++) {      /* the last round only evaluates find_alpha_field_a on the final velocities */
+    const int last = sub == p->evp_rheol_steps;
+    for (int el = 0; el < myE; el++) {
+      if (m->ulevels[el] > 1) continue;
+      const double alpha = s->alpha_evp_array[el];
+      const double det2 = 1.0 / (1.0 + alpha), det1 = alpha * det2;
+      const int *en = m->elem2D_nodes + 3 * el;
+      const double msum = ((s->m_ice[en[0] - 1] + s->m_ice[en[1] - 1]) + s->m_ice[en[2] - 1]) * val3;
+      if (msum <= 0.01) continue;
+      const double asum = ((s->a_ice[en[0] - 1] + s->a_ice[en[1] - 1]) + s->a_ice[en[2] - 1]) * val3;
+      const double *dx = m->gradient_sca + 6 * (size_t)el, *dy = dx + 3;
+      const double u1 = ua[en[0] - 1], u2 = ua[en[1] - 1], u3 = ua[en[2] - 1], v1 = va[en[0] - 1], v2 = va[en[1] - 1], v3 = va[en[2] - 1];
+      const double vsum = (v1 + v2) + v3, usum = (u1 + u2) + u3, meancos = m->metric_factor[el];
+      double eps11 = (dx[0] * u1 + dx[1] * u2) + dx[2] * u3;
+      eps11 = eps11 - val3 * vsum * meancos;
+      const double eps22 = (dy[0] * v1 + dy[1] * v2) + dy[2] * v3;
+      double eps12 = 0.5 * (((dy[0] * u1 + dx[0] * v1) + (dy[1] * u2 + dx[1] * v2)) + (dy[2] * u3 + dx[2] * v3));
+      eps12 = eps12 + 0.5 * val3 * usum * meancos;
+      const double eps1 = eps11 + eps22, eps2 = eps11 - eps22;
+      double delta = eps1 * eps1 + vale * (eps2 * eps2 + 4.0 * (eps12 * eps12));
+      delta = sqrt(delta);
+      if (last) {                                           /* find_alpha_field_a */
+        const double pressure = p->Pstar * exp(-p->c_pressure * (1.0 - asum)) / (delta + p->delta_min);
+        const double al = sqrt(p->ice_dt * p->c_aevp * pressure / RHOICE / m->elem_area[el]);
+        s->alpha_evp_array[el] = al > 50.0 ? al : 50.0;
+        continue;
+      }
+      const double pressure = p->Pstar * msum * exp(-p->c_pressure * (1.0 - asum)) / (delta + p->delta_min);
+      const double r1 = pressure * (eps1 - delta), r2 = pressure * eps2 * vale, r3 = pressure * eps12 * vale;
+      double si1 = s->sigma11[el] + s->sigma22[el], si2 = s->sigma11[el] - s->sigma22[el];
+      si1 = det1 * si1 + det2 * r1;
+      si2 = det1 * si2 + det2 * r2;
+      s->sigma12[el] = det1 * s->sigma12[el] + det2 * r3;
+      s->sigma11[el] = 0.5 * (si1 + si2);
+      s->sigma22[el] = 0.5 * (si1 - si2);
+    }
+    if (last) break;
+    /* stress2rhs_m */
+    for (int i = 0; i < myN; i++) { urhs[i] = 0.0; vrhs[i] = 0.0; }
+    for (int el = 0; el < myE; el++) {
+      if (m->ulevels[el] > 1) continue;
+      const int *en = m->elem2D_nodes + 3 * el;
+      if ((s->a_ice[en[0] - 1] + s->a_ice[en[1] - 1]) + s->a_ice[en[2] - 1] < 0.01) continue;
+      const double vol = m->elem_area[el], mf = m->metric_factor[el];
+      const double *dx = m->gradient_sca + 6 * (size_t)el, *dy = dx + 3;
+      const double s11 = s->sigma11[el], s12 = s->sigma12[el], s22 = s->sigma22[el];
+      for (int k = 0; k < 3; k++) {
+        const int row = en[k] - 1;
+        urhs[row] = urhs[row] - vol * (s11 * dx[k] + s12 * dy[k]) - vol * s12 * val3 * mf;
+        vrhs[row] = vrhs[row] - vol * (s12 * dx[k] + s22 * dy[k]) + vol * s11 * val3 * mf;
+      }
+    }
+    for (int i = 0; i < myN; i++) {
+      if (m->ulevels_nod2D[i] > 1) continue;
+      double mass = (s->m_ice[i] * RHOICE + s->m_snow[i] * RHOSNO);
+      mass = mass / (1.0 + mass * mass);
+      const double ar = m->area[(size_t)i * nl];
+      urhs[i] = (urhs[i] * mass + rhs_a[i]) / ar;
+      vrhs[i] = (vrhs[i] * mass + rhs_m[i]) / ar;
+    }
+    /* node update (:831-856) */
+    for (int i = 0; i < myN; i++) {
+      if (m->ulevels_nod2D[i] > 1) continue;
+      double thickness = (RHOICE * s->m_ice[i] + RHOSNO * s->m_snow[i]) / (s->a_ice[i] > 0.01 ? s->a_ice[i] : 0.01);
+      thickness = thickness > 9.0 ? thickness : 9.0;
+      const double inv_thickness = 1.0 / thickness;
+      const double du = ua[i] - s->u_w[i], dv = va[i] - s->v_w[i];
+      const double umod = sqrt(du * du + dv * dv);
+      const double drag = rdt * p->cd_oce_ice * umod * DENSITY_0 * inv_thickness;
+      double rhsu = s->u_ice[i] + drag * s->u_w[i] + rdt * (inv_thickness * s->stress_atmice_x[i] + urhs[i]);
+      double rhsv = s->v_ice[i] + drag * s->v_w[i] + rdt * (inv_thickness * s->stress_atmice_y[i] + vrhs[i]);
+      const double beta = s->beta_evp_array[i];
+      rhsu = beta * ua[i] + rhsu;
+      rhsv = beta * va[i] + rhsv;
+      const double fc = rdt * m->coriolis_node[i];
+      double det = (1.0 + beta + drag) * (1.0 + beta + drag) + fc * fc;
+      det = (bnd[i] ? 0.0 : 1.0) / det;
+      ua[i] = det * ((1.0 + beta + drag) * rhsu + fc * rhsv);
+      va[i] = det * ((1.0 + beta + drag) * rhsv - fc * rhsu);
+    }
+    for (int i = 0; i < N; i++) if (bnd[i]) { ua[i] = 0.0; va[i] = 0.0; }
+  }
+  memcpy(s->u_ice, ua, sizeof(double) * N); memcpy(s->v_ice, va, sizeof(double) * N);
+  /* find_beta_field_a */
+  for (int i = 0; i < myN; i++) {
+    if (m->ulevels_nod2D[i] > 1) continue;
+    const int num = m->nod_in_elem2D_num[i];
+    double b = s->alpha_evp_array[m->nod_in_elem2D[(size_t)i * m->max_nod_in_elem] - 1];
+    for (int k = 1; k < num; k++) { const double a = s->alpha_evp_array[m->nod_in_elem2D[(size_t)i * m->max_nod_in_elem + k] - 1]; b = a > b ? a : b; }
+    s->beta_evp_array[i] = b;
+  }
+  free(ua); free(va); free(rhs_a); free(rhs_m); free(urhs); free(vrhs); free(bnd);
   return 0;
 }
 

@@ -102,13 +102,13 @@ program oracle_driver
   character(len=16) :: mode
   character(len=256) :: dump_dir
   integer :: dump_steps(64), ndump
-  logical :: dump_mesh, do_mean, debug, synth_forcing, step_info, gpu_profile, ice_adv, mslp, tides
+  logical :: dump_mesh, do_mean, debug, synth_forcing, step_info, gpu_profile, ice_adv, mslp, tides, ice_aevp
   real(kind=WP) :: flon, flat
   integer :: fel(3)
   real(kind=WP) :: t0, t1, tloop
   character(len=64) :: tag
   namelist /clockinit/ timenew, daynew, yearnew
-  namelist /oracle/ nsteps, mode, dump_dir, dump_steps, dump_mesh, do_mean, debug, synth_forcing, step_info, gpu_profile, ice_adv, mslp, tides
+  namelist /oracle/ nsteps, mode, dump_dir, dump_steps, dump_mesh, do_mean, debug, synth_forcing, step_info, gpu_profile, ice_adv, mslp, tides, ice_aevp
   ! running sums for the fcheck-style known answer (setups/test_souf/setup.yml:82-88)
   real(kind=WP), allocatable :: mT(:,:), mS(:,:), mU(:,:), mV(:,:)
 
@@ -137,7 +137,7 @@ program oracle_driver
   read (20,NML=oce_tra)
   read (20,NML=oce_init3d)
   close (20)
-  nsteps=1; mode='step'; dump_dir='dumps'; dump_steps=-1; dump_mesh=.false.; do_mean=.false.; debug=.false.; synth_forcing=.false.; step_info=.false.; gpu_profile=.false.; ice_adv=.false.; mslp=.false.; tides=.false.
+  nsteps=1; mode='step'; dump_dir='dumps'; dump_steps=-1; dump_mesh=.false.; do_mean=.false.; debug=.false.; synth_forcing=.false.; step_info=.false.; gpu_profile=.false.; ice_adv=.false.; mslp=.false.; tides=.false.; ice_aevp=.false.
   open (20,file='namelist.oracle')
   read (20,NML=oracle)
   close (20)
@@ -399,6 +399,10 @@ contains
          use mod_mesh
          type(t_mesh), intent(in), target :: mesh
        end subroutine
+       subroutine EVPdynamics_a(mesh)
+         use mod_mesh
+         type(t_mesh), intent(in), target :: mesh
+       end subroutine
        subroutine ice_fct_init(mesh)
          use mod_mesh
          type(t_mesh), intent(in), target :: mesh
@@ -433,6 +437,10 @@ contains
     end if
     allocate(sigma11(e2), sigma12(e2), sigma22(e2), eps11(e2), eps12(e2), eps22(e2))
     ice_dt=real(ice_ave_steps,WP)*dt
+    if (ice_aevp) then          ! adaptive EVP (whichEVP = 2): the arrays of ice_array_setup (src/ice_setup_step.F90:85-89)
+       allocate(alpha_evp_array(myDim_elem2D), beta_evp_array(n2))
+       alpha_evp_array=alpha_evp; beta_evp_array=alpha_evp
+    end if
     sigma11=0.0_WP; sigma12=0.0_WP; sigma22=0.0_WP; eps11=0.0_WP; eps12=0.0_WP; eps22=0.0_WP
     rhs_a=0.0_WP; rhs_m=0.0_WP; u_rhs_ice=0.0_WP; v_rhs_ice=0.0_WP; u_ice_aux=0.0_WP; v_ice_aux=0.0_WP
     do i=1, n2
@@ -462,7 +470,11 @@ contains
     call MPI_BARRIER(MPI_COMM_FESOM, ierr)
     t0i=MPI_Wtime()
     do it=1, nsteps
-       call EVPdynamics_m(mesh)
+       if (ice_aevp) then
+          call EVPdynamics_a(mesh)
+       else
+          call EVPdynamics_m(mesh)
+       end if
        if (ice_adv) then
           if (any(dump_steps==it)) then
              write(tag,'(A,I4.4)') 'ice_adv', it
@@ -504,7 +516,10 @@ contains
     call dump('u_w', u_w); call dump('v_w', v_w); call dump('elevation', elevation)
     call dump('stress_atmice_x', stress_atmice_x); call dump('stress_atmice_y', stress_atmice_y)
     call dump('sigma11', sigma11); call dump('sigma12', sigma12); call dump('sigma22', sigma22)
-    call dump('ice_params', (/ ice_dt, ellipse, alpha_evp, beta_evp, Pstar, c_pressure, delta_min, cd_oce_ice, real(evp_rheol_steps,WP), max_ice_loading /))
+    call dump('ice_params', (/ ice_dt, ellipse, alpha_evp, beta_evp, Pstar, c_pressure, delta_min, cd_oce_ice, real(evp_rheol_steps,WP), max_ice_loading, c_aevp /))
+    if (allocated(alpha_evp_array)) then
+       call dump('alpha_evp_array', alpha_evp_array); call dump('beta_evp_array', beta_evp_array)
+    end if
   end subroutine dump_ice
 
   ! prognostic + ALE state (= restart set, io_restart.F90:99-155, plus thickness arrays)

@@ -183,3 +183,65 @@ def test_gpu_ice_step_equals_oracle_and_reference_bitwise(built):
             assert bits(fg[k], fo[k]), (n, k, float(np.abs(fg[k] - fo[k]).max()))
             assert bits(fg[k], g[f"out{n}/{k}"]), (n, k, float(np.abs(fg[k] - g[f"out{n}/{k}"]).max()))
     core.close()
+
+
+# ---- adaptive EVP (whichEVP = 2, EVPdynamics_a, src/ice_maEVP.F90:785-888) ----
+AOUT = OUT + ("alpha_evp_array", "beta_evp_array")
+
+
+def gold_a():
+    return np.load(os.path.join(REPO, "tests", "golden", "ice_aevp_reference.npz"))
+
+
+def setup_a(g):
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd import ice
+    mesh = Mesh.load(PI, dt=900.0)
+    pv = g["in/ice_params"]
+    par = ice.ice_params(ice_dt=pv[0], ellipse=pv[1], alpha_evp=pv[2], beta_evp=pv[3], Pstar=pv[4], c_pressure=pv[5], delta_min=pv[6], cd_oce_ice=pv[7],
+                         evp_rheol_steps=int(pv[8]), max_ice_loading=pv[9], whichEVP=2, c_aevp=pv[10])
+    fields = ice.IceFields(**{k: g["in/" + k] for k in STATE + ("alpha_evp_array", "beta_evp_array")})
+    return mesh, par, fields
+
+
+def test_oracle_aevp_equals_reference_bitwise(built):
+    """the oracle's restatement of EVPdynamics_a (ssh2rhs, stress_tensor_a with the element's alpha, stress2rhs_m, node update with the node's beta,
+    find_alpha_field_a, find_beta_field_a) against the reference's own routine: velocities, stresses, alpha and beta bit for bit after one, two and three
+    calls of 120 subcycles (tests/golden/make_ice_aevp_golden.py)"""
+    import oracle_lib
+    g = gold_a()
+    mesh, par, fields = setup_a(g)
+    oracle_lib.build()
+    orc = C.CDLL(oracle_lib.ORC_LIB)
+    assert np.all(fields["alpha_evp_array"] == par.alpha_evp) and np.all(fields["beta_evp_array"] == par.alpha_evp)
+    for n in (1, 2, 3):
+        assert orc.orc_ice_evp_a(mesh.desc_p, C.byref(par), C.byref(fields.desc)) == 0
+        for k in AOUT:
+            assert bits(fields[k], g[f"out{n}/{k}"]), (n, k, float(np.abs(fields[k] - g[f"out{n}/{k}"]).max()))
+    a = fields["alpha_evp_array"]
+    assert a.min() == 50.0 and (a > 50.0).sum() > 100 and np.abs(fields["u_ice"] - g["in/u_ice"]).max() > 1e-3      # (the adaptive alpha acts)
+
+
+@pytest.mark.gpu
+def test_gpu_aevp_equals_oracle_and_reference_bitwise(built):
+    """adaptive EVP on the device (k_ice_a_prep / k_ice_a_stress / k_ice_a_node per subcycle, k_ice_a_alpha / k_ice_a_beta after the call): velocities,
+    stresses, alpha_evp_array and beta_evp_array equal the oracle's and the reference's own EVPdynamics_a bit for bit after one, two and three calls;
+    the state (stresses, alpha, beta) stays on the device between the calls"""
+    from fesom2_amd import ice
+    import oracle_lib
+    g = gold_a()
+    mesh, par, fo = setup_a(g)
+    _, _, fg = setup_a(g)
+    oracle_lib.build()
+    orc = C.CDLL(oracle_lib.ORC_LIB)
+    core = ice.IceCore(mesh, par)
+    core.upload(fg)
+    for n in (1, 2, 3):
+        core.evp(1); core.download(fg)
+        assert orc.orc_ice_evp_a(mesh.desc_p, C.byref(par), C.byref(fo.desc)) == 0
+        for k in AOUT:
+            assert bits(fg[k], fo[k]), (n, k, float(np.abs(fg[k] - fo[k]).max()))
+            assert bits(fg[k], g[f"out{n}/{k}"]), (n, k)
+    ms = core.time_ms(3)
+    assert 0.0 < ms < 100.0
+    core.close()
