@@ -779,7 +779,7 @@ int fesom_gpu_ice_upload(const fesom_ice_state *st) {
 int fesom_gpu_ice_evp(int ncalls) {
   ICE_READY();
   if (I.m.p.whichEVP == 2) {                                 // adaptive EVP: EVPdynamics_a
-    if (I.npes > 1) { I.err = "ice_evp: whichEVP = 2 (adaptive EVP) is built for one partition"; return 1; }
+    if (I.npes > 1) { I.err = "fesom_gpu_ice_evp: partitioned context, call fesom_gpu_ice_evp_partitioned"; return 1; }
     for (int c = 0; c < ncalls; c++) enqueue_call_a(I.stream, I.cur);
     ICECHK(hipGetLastError());
     return 0;
@@ -806,11 +806,39 @@ int fesom_gpu_ice_evp(int ncalls) {
 int fesom_gpu_ice_evp_partitioned(int ncalls, const fesom_transport *t) {
   ICE_READY();
   if (I.npes < 2) return fesom_gpu_ice_evp(ncalls);
-  if (I.m.p.whichEVP == 2) { I.err = "ice_evp_partitioned: whichEVP = 2 (adaptive EVP) is built for one partition"; return 1; }
   if (t && !t->exchange) { I.err = "ice_evp_partitioned: transport callback missing"; return 1; }
   const IceDM &m = I.m;
   const int *sptr_d = I.sptr_d, *rptr_d = I.rptr_d;
   hipStream_t s = I.stream;
+  // halo of (u_ice_aux, v_ice_aux) in the buffers of parity `par` (exchange_nod after every subcycle)
+  auto halo = [&](int par) -> int {
+    if (I.nsend > 0) hipLaunchKernelGGL(k_ice_pack, dim3((I.nsend + 255) / 256), dim3(256), 0, s, m.ua[par], m.va[par], I.slist, sptr_d, (int)I.sPE.size(), I.nsend, I.hsend);
+    if (t) {
+      if (hipStreamSynchronize(s) != hipSuccess) { I.err = "ice_evp_partitioned: stream"; return 1; }                      // (a host transport reads the packed buffer)
+      if (t->exchange(t->ctx, 0, I.hsend, I.hrecv, 2)) { I.err = "ice_evp_partitioned: transport exchange failed"; return 1; }
+    } else if (fesom_internal_rccl_exchange((int)I.sPE.size(), I.sPE.data(), I.sptr.data(), (int)I.rPE.size(), I.rPE.data(), I.rptr.data(), I.hsend, I.hrecv, 2, s)) {
+      I.err = "ice_evp_partitioned: built-in transport failed (fesom_gpu_comm_init?)"; return 1;
+    }
+    if (I.nrecv > 0) hipLaunchKernelGGL(k_ice_unpack, dim3((I.nrecv + 255) / 256), dim3(256), 0, s, m.ua[par], m.va[par], I.rlist, rptr_d, (int)I.rPE.size(), I.nrecv, I.hrecv);
+    return 0;
+  };
+  if (m.p.whichEVP == 2) {       // adaptive EVP (EVPdynamics_a): every rank updates the stresses of all its elements, the node update of its own nodes, then the halo (:879)
+    for (int c = 0; c < ncalls; c++) {
+      hipLaunchKernelGGL(k_ice_a_prep, dim3((m.N + 255) / 256), dim3(256), 0, s, m);
+      int par = 0;
+      for (int k = 0; k < m.p.evp_rheol_steps; k++) {
+        hipLaunchKernelGGL(k_ice_a_stress, dim3((m.myE + 255) / 256), dim3(256), 0, s, m, par, I.cur);
+        hipLaunchKernelGGL(k_ice_a_node, dim3((m.N + 127) / 128), dim3(128), 0, s, m, par, I.cur);
+        par = 1 - par;
+        if (halo(par)) return 1;
+      }
+      hipLaunchKernelGGL(k_ice_finish, dim3((m.N + 255) / 256), dim3(256), 0, s, m, par);
+      hipLaunchKernelGGL(k_ice_a_alpha, dim3((m.myE + 255) / 256), dim3(256), 0, s, m, par);
+      hipLaunchKernelGGL(k_ice_a_beta, dim3((m.myN + 255) / 256), dim3(256), 0, s, m);
+    }
+    ICECHK(hipGetLastError());
+    return 0;
+  }
   for (int c = 0; c < ncalls; c++) {
     int par = I.cur;
     hipLaunchKernelGGL(k_ice_prep_node, dim3((m.N + 255) / 256), dim3(256), 0, s, m);

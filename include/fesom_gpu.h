@@ -315,7 +315,7 @@ int  fesom_gpu_set_stream(void *hip_stream);   /* run the library's kernels on t
  * and viscous-plastic stresses on elements, stress divergence gathered to nodes, implicit Coriolis / ocean-drag velocity update,
  * coastal boundary condition.  Independent of the ocean core's context (may coexist with it); partitions: fesom_gpu_ice_evp_partitioned.
  * Arrays keep the reference's extents: node fields myDim_nod2D + eDim_nod2D, stresses myDim_elem2D.  Not built: cavities
- * (ulevels > 1), icepack, the classic EVP (whichEVP = 0).  whichEVP = 2 (adaptive EVP, EVPdynamics_a :785-888) is built for one partition: fesom_ice_params.whichEVP. */
+ * (ulevels > 1), icepack, the classic EVP (whichEVP = 0).  whichEVP = 2 (adaptive EVP, EVPdynamics_a :785-888): fesom_ice_params.whichEVP. */
 typedef struct fesom_ice_params {
   double ice_dt;             /* ice_ave_steps * dt */
   double ellipse, alpha_evp, beta_evp, Pstar, c_pressure, delta_min, cd_oce_ice;   /* namelist.ice &ice_dyn (src/ice_modules.F90:7-27) */
@@ -323,7 +323,7 @@ typedef struct fesom_ice_params {
   int    evp_rheol_steps;
   int    use_floatice;       /* use_floatice .and. which_ALE /= 'linfs' (ice_maEVP.F90:159): ice + snow load in the sea-surface slope term */
   double ice_gamma_fct;      /* smoothing parameter of the FCT advection (namelist.ice &ice_dyn, src/ice_modules.F90:27: 0.25) */
-  int    whichEVP;           /* 1 (and 0 in this struct's zero default) = mEVP, EVPdynamics_m; 2 = adaptive EVP, EVPdynamics_a (src/ice_maEVP.F90:785-888; one partition) */
+  int    whichEVP;           /* 1 (and 0 in this struct's zero default) = mEVP, EVPdynamics_m; 2 = adaptive EVP, EVPdynamics_a (src/ice_maEVP.F90:785-888) */
   double c_aevp;             /* aEVP: constant of the adaptive alpha (namelist.ice &ice_dyn, src/ice_modules.F90:36: 0.15) */
 } fesom_ice_params;
 typedef struct fesom_ice_state {

@@ -21,5 +21,15 @@ for n in (1, 2, 3):
     b = read_dump(os.path.join(rd, "dumps", f"ice_out{n:04d}.r00000.bin"))
     for k in ("u_ice", "v_ice", "sigma11", "sigma12", "sigma22", "alpha_evp_array", "beta_evp_array"):
         out[f"out{n}/{k}"] = np.array(b[k])
+# the same on TWO ranks (dist_2), one call: rank-local inputs and outputs -- the pin of the partitioned GPU path
+rd2, rc2, lines2 = run_ref.run("pi_pp", 2, 1, mode="ice", dump=(1,), ice_aevp=True)
+assert rc2 == 0
+for r in range(2):
+    a = read_dump(os.path.join(rd2, "dumps", f"ice_in.r{r:05d}.bin")); b = read_dump(os.path.join(rd2, "dumps", f"ice_out0001.r{r:05d}.bin"))
+    for k in ("u_ice", "v_ice", "a_ice", "m_ice", "m_snow", "elevation", "u_w", "v_w", "stress_atmice_x", "stress_atmice_y", "sigma11", "sigma12", "sigma22", "metric_factor",
+              "alpha_evp_array", "beta_evp_array"):
+        out[f"r2/{r}/in/{k}"] = np.array(a[k])
+    for k in ("u_ice", "v_ice", "sigma11", "sigma12", "sigma22", "alpha_evp_array", "beta_evp_array"):
+        out[f"r2/{r}/out1/{k}"] = np.array(b[k])
 np.savez_compressed(os.path.join(HERE, "ice_aevp_reference.npz"), **out)
 print("wrote ice_aevp_reference.npz:", {k: v.shape for k, v in out.items() if k.startswith("out1/")}, lines)

@@ -98,7 +98,7 @@ def test_gpu_evp_equals_oracle_and_reference_bitwise(built, floatice):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("transport,adv", [("callback", False), ("builtin", False), ("callback", True), ("builtin", True)])
+@pytest.mark.parametrize("transport,adv", [("callback", False), ("builtin", False), ("callback", True), ("builtin", True), ("callback", "aevp"), ("builtin", "aevp")])
 def test_gpu_partitioned_evp_equals_reference(built, transport, adv):
     """2 ranks (the reference's dist_2 partition of pi, sharing the GPU): halo of (u_ice_aux, v_ice_aux) after every subcycle through the
     host-callback transport (gloo) or the library's built-in transport (shared-memory stand-in for librccl); every rank's u_ice, v_ice
@@ -112,10 +112,14 @@ def test_gpu_partitioned_evp_equals_reference(built, transport, adv):
         fake = os.path.join(REPO, "tests", "helpers", "libfake_rccl.so")
         assert os.path.exists(fake)
         env.update(FESOM_GPU_RCCL_LIB=fake, PART_TRANSPORT="rccl")
+    if adv == "aevp":          # the adaptive EVP, EVPdynamics_a, against the reference's 2-rank run of it (tests/golden/ice_aevp_reference.npz: r2/...)
+        env["ICE_AEVP"] = "1"; adv = False; port_off = 4
+    else:
+        port_off = 0
     if adv:
         env["ICE_ADV"] = "1"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(29830 + (1 if transport == "builtin" else 0) + (2 if adv else 0)), os.path.join(REPO, "tests", "helpers", "partitioned_ice_worker.py")],
+                        "--master-port", str(29830 + (1 if transport == "builtin" else 0) + (2 if adv else 0) + port_off), os.path.join(REPO, "tests", "helpers", "partitioned_ice_worker.py")],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     reps = [json.loads(x) for x in re.findall(r"ICEREPORT (\{.*\})", r.stdout)]
