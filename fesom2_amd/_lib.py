@@ -112,7 +112,7 @@ class MeshOpts(C.Structure):
 class IceParams(C.Structure):
     """fesom_ice_params (include/fesom_gpu.h)"""
     _fields_ = [(n, C.c_double) for n in ("ice_dt", "ellipse", "alpha_evp", "beta_evp", "Pstar", "c_pressure", "delta_min", "cd_oce_ice", "max_ice_loading")] + \
-               [("evp_rheol_steps", C.c_int), ("use_floatice", C.c_int), ("ice_gamma_fct", C.c_double), ("whichEVP", C.c_int), ("c_aevp", C.c_double)]
+               [("evp_rheol_steps", C.c_int), ("use_floatice", C.c_int), ("ice_gamma_fct", C.c_double), ("whichEVP", C.c_int), ("c_aevp", C.c_double), ("theta_io", C.c_double), ("Tevp_inv", C.c_double)]
 
 
 ICE_FIELDS = ("u_ice", "v_ice", "a_ice", "m_ice", "m_snow", "elevation", "u_w", "v_w", "stress_atmice_x", "stress_atmice_y", "sigma11", "sigma12", "sigma22", "alpha_evp_array", "beta_evp_array")

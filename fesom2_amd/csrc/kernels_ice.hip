@@ -605,6 +605,112 @@ __global__ void k_ice_a_beta(IceDM m) {                       // find_beta_field
   for (int k = 1; k < m.nie_num[i]; k++) { const double a = m.alpha[m.nie[(size_t)m.maxk * i + k]]; b = a > b ? a : b; }
   m.beta[i] = b;
 }
+// ---- classic EVP, EVPdynamics (src/ice_EVP.F90:397-667; whichEVP = 0, the default of namelist.ice).  The velocities are updated in place (a node reads only its
+// own old value; the stresses of a subcycle are formed in a launch of their own before).
+__device__ __forceinline__ bool ice_c_has_ice(const IceDM &m, const int *en) {      // (:471-474)
+  return !(m.m_ice[en[0]] <= 0. || m.m_ice[en[1]] <= 0. || m.m_ice[en[2]] <= 0. || m.a_ice[en[0]] <= 0. || m.a_ice[en[1]] <= 0. || m.a_ice[en[2]] <= 0.);
+}
+__global__ void k_ice_c_prep_node(IceDM m) {                 // inverse masses (:448-465) and the sea-surface-slope term (:467-541) as a node gather
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.myN) return;
+  const double ms = ICE_RHOICE * m.m_ice[i] + ICE_RHOSNO * m.m_snow[i];
+  m.mass[i] = ms > 1.e-3 ? 1. / (m.area1[i] * ms) : 0.;      // inv_areamass
+  double im = 0.;
+  if (!(m.a_ice[i] < 0.01)) { im = ms / m.a_ice[i]; im = 1.0 / (im > 9.0 ? im : 9.0); }
+  m.invt[i] = im;                                            // inv_mass
+  const double use_pice = m.p.use_floatice ? 1.0 : 0.0;
+  double ra = 0.0, rm = 0.0;
+  for (int k = 0; k < m.nie_num[i]; k++) {
+    const int el = m.nie[(size_t)m.maxk * i + k];
+    const int *en = m.en + 3 * el;
+    if (!ice_c_has_ice(m, en)) continue;
+    const double *gs = m.gsca + 6 * (size_t)el;
+    const double aa = 9.81 * m.elem_area[el] / 3.0;
+    double e3[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      double pi = (ICE_RHOICE * m.m_ice[en[q]] + ICE_RHOSNO * m.m_snow[en[q]]) * ICE_INV_RHOWAT;
+      pi = pi < m.p.max_ice_loading ? pi : m.p.max_ice_loading;
+      e3[q] = m.elev[en[q]] + pi * use_pice;
+    }
+    const double ex = (gs[0] * e3[0] + gs[1] * e3[1]) + gs[2] * e3[2], ey = (gs[3] * e3[0] + gs[4] * e3[1]) + gs[5] * e3[2];
+    ra = ra - aa * ex; rm = rm - aa * ey;
+  }
+  m.rhs_a[i] = ra / m.area1[i]; m.rhs_m[i] = rm / m.area1[i];
+}
+__global__ void k_ice_c_prep_elem(IceDM m) {                 // ice strength (:475-483); exp(-c_pressure (1 - asum)) from the host (efac)
+  const int el = blockIdx.x * blockDim.x + threadIdx.x;
+  if (el >= m.myE) return;
+  const int *en = m.en + 3 * el;
+  double st = 0.0;
+  if (ice_c_has_ice(m, en)) {
+    const double msum = ((m.m_ice[en[0]] + m.m_ice[en[1]]) + m.m_ice[en[2]]) / 3.0;
+    st = m.p.Pstar * msum * m.efac[el];
+    st = 0.5 * st;
+  }
+  m.pfac[el] = st;
+}
+__global__ void k_ice_c_stress(IceDM m, int sp) {             // stress_tensor (:23-134), in place
+  const int el = blockIdx.x * blockDim.x + threadIdx.x;
+  if (el >= m.myE) return;
+  const double strength = m.pfac[el];
+  if (!(strength > 0.)) return;
+  const size_t E = (size_t)m.myE;
+  double *sg = m.sig[sp];
+  const int *en = m.en + 3 * el;
+  const double *dx = m.gsca + 6 * (size_t)el, *dy = dx + 3, mf = m.metric[el];
+  const double vale = 1.0 / (m.p.ellipse * m.p.ellipse), dte = m.p.ice_dt / (1.0 * m.p.evp_rheol_steps);
+  const double det1 = 1.0 / (1.0 + 0.5 * m.p.Tevp_inv * dte), det2 = 1.0 / (1.0 + 0.5 * m.p.Tevp_inv * dte);
+  const double u1 = m.u_ice[en[0]], u2 = m.u_ice[en[1]], u3 = m.u_ice[en[2]], v1 = m.v_ice[en[0]], v2 = m.v_ice[en[1]], v3 = m.v_ice[en[2]];
+  const double e11 = ((dx[0] * u1 + dx[1] * u2) + dx[2] * u3) - mf * ((v1 + v2) + v3) / 3.0;
+  const double e22 = (dy[0] * v1 + dy[1] * v2) + dy[2] * v3;
+  const double e12 = 0.5 * ((((dy[0] * u1 + dy[1] * u2) + dy[2] * u3) + ((dx[0] * v1 + dx[1] * v2) + dx[2] * v3)) + mf * ((u1 + u2) + u3) / 3.0);
+  const double delta = sqrt((e11 * e11 + e22 * e22) * (1.0 + vale) + 4.0 * vale * e12 * e12 + 2.0 * e11 * e22 * (1.0 - vale));
+  const double delta_inv = 1.0 / (delta > m.p.delta_min ? delta : m.p.delta_min);
+  double zeta = strength * delta_inv;
+  zeta = zeta * m.p.Tevp_inv;
+  const double r1 = zeta * (e11 + e22) - strength * m.p.Tevp_inv, r2 = zeta * (e11 - e22) * vale, r3 = zeta * e12 * vale;
+  const double si1 = det1 * (sg[el] + sg[2 * E + el] + dte * r1), si2 = det2 * (sg[el] - sg[2 * E + el] + dte * r2);
+  sg[E + el] = det2 * (sg[E + el] + dte * r3);
+  sg[el] = 0.5 * (si1 + si2);
+  sg[2 * E + el] = 0.5 * (si1 - si2);
+}
+__global__ void k_ice_c_node(IceDM m, int sp, double ax, double ay) {      // stress2rhs (:323-396) as a node gather + the node update (:556-585) + coastal nodes
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.N) return;
+  if (i >= m.myN) { if (m.bnd[i]) { m.u_ice[i] = 0.0; m.v_ice[i] = 0.0; } return; }
+  const size_t E = (size_t)m.myE;
+  const double *sg = m.sig[sp];
+  const double val3 = 1 / 3.0, rdt = m.p.ice_dt / (1.0 * m.p.evp_rheol_steps);
+  double urhs = 0.0, vrhs = 0.0;
+  for (int k = 0; k < m.nie_num[i]; k++) {
+    const int el = m.nie[(size_t)m.maxk * i + k];
+    if (!(m.pfac[el] > 0.)) continue;
+    const int n1 = m.en[3 * el], n2 = m.en[3 * el + 1];
+    const int pos = (n1 == i) ? 0 : ((n2 == i) ? 1 : 2);
+    const double *gs = m.gsca + 6 * (size_t)el;
+    const double ar = m.elem_area[el], mf = m.metric[el], s11 = sg[el], s12 = sg[E + el], s22 = sg[2 * E + el];
+    urhs = urhs - ar * (s11 * gs[pos] + s12 * gs[pos + 3] + s12 * val3 * mf);
+    vrhs = vrhs - ar * (s12 * gs[pos] + s22 * gs[pos + 3] - s11 * val3 * mf);
+  }
+  const double iam = m.mass[i];
+  if (iam > 0.) { urhs = urhs * iam + m.rhs_a[i]; vrhs = vrhs * iam + m.rhs_m[i]; } else { urhs = 0.; vrhs = 0.; }
+  double U = m.u_ice[i], V = m.v_ice[i];
+  if (m.a_ice[i] >= 0.01) {
+    const double uw = m.u_w[i], vw = m.v_w[i], im = m.invt[i];
+    const double du = U - uw, dv = V - vw;
+    const double umod = sqrt(du * du + dv * dv);
+    const double drag = m.p.cd_oce_ice * umod * ICE_DENSITY_0 * im;
+    const double rhsu = U + rdt * (drag * (ax * uw - ay * vw) + im * m.tax[i] + urhs);
+    const double rhsv = V + rdt * (drag * (ax * vw + ay * uw) + im * m.tay[i] + vrhs);
+    const double r_a = 1. + ax * drag * rdt, r_b = rdt * (m.cori_n[i] + ay * drag);
+    const double det = 1.0 / (r_a * r_a + r_b * r_b);
+    U = det * (r_a * rhsu + r_b * rhsv);
+    V = det * (r_a * rhsv - r_b * rhsu);
+  } else { U = 0.0; V = 0.0; }
+  if (m.bnd[i]) { U = 0.0; V = 0.0; }
+  m.u_ice[i] = U; m.v_ice[i] = V;
+}
 // one EVPdynamics_a call: the stresses stay in sig[sp] (in place); the velocities alternate and end in u_ice / v_ice
 void enqueue_call_a(hipStream_t s, int sp) {
   const IceDM &m = I.m;
@@ -769,7 +875,8 @@ int fesom_gpu_ice_upload(const fesom_ice_state *st) {
     const double val3 = 1.0 / 3.0;
     for (size_t el = 0; el < E; el++) {
       const int *en = &I.h_en[3 * el];
-      const double asum = ((st->a_ice[en[0]] + st->a_ice[en[1]]) + st->a_ice[en[2]]) * val3;
+      double asum = ((st->a_ice[en[0]] + st->a_ice[en[1]]) + st->a_ice[en[2]]) * val3;
+      if (m.p.whichEVP == 0) asum = ((st->a_ice[en[0]] + st->a_ice[en[1]]) + st->a_ice[en[2]]) / 3.0;      // (the classic EVP divides, ice_EVP.F90:478)
       I.h_efac[el] = exp(-m.p.c_pressure * (1.0 - asum));
     }
     ICECHK(hipMemcpy(m.efac, I.h_efac.data(), sizeof(double) * E, hipMemcpyHostToDevice));
@@ -778,9 +885,21 @@ int fesom_gpu_ice_upload(const fesom_ice_state *st) {
 }
 int fesom_gpu_ice_evp(int ncalls) {
   ICE_READY();
-  if (I.m.p.whichEVP == 2) {                                 // adaptive EVP: EVPdynamics_a
+  if (I.m.p.whichEVP == 2 || I.m.p.whichEVP == 0) {          // adaptive EVP: EVPdynamics_a; classic EVP: EVPdynamics
     if (I.npes > 1) { I.err = "fesom_gpu_ice_evp: partitioned context, call fesom_gpu_ice_evp_partitioned"; return 1; }
-    for (int c = 0; c < ncalls; c++) enqueue_call_a(I.stream, I.cur);
+    for (int c = 0; c < ncalls; c++) {
+      if (I.m.p.whichEVP == 2) enqueue_call_a(I.stream, I.cur);
+      else {
+        const IceDM &m = I.m;
+        const double ax = cos(m.p.theta_io), ay = sin(m.p.theta_io);      // (host libm, as the reference's)
+        hipLaunchKernelGGL(k_ice_c_prep_node, dim3((m.myN + 255) / 256), dim3(256), 0, I.stream, m);
+        hipLaunchKernelGGL(k_ice_c_prep_elem, dim3((m.myE + 255) / 256), dim3(256), 0, I.stream, m);
+        for (int k = 0; k < m.p.evp_rheol_steps; k++) {
+          hipLaunchKernelGGL(k_ice_c_stress, dim3((m.myE + 255) / 256), dim3(256), 0, I.stream, m, I.cur);
+          hipLaunchKernelGGL(k_ice_c_node, dim3((m.N + 127) / 128), dim3(128), 0, I.stream, m, I.cur, ax, ay);
+        }
+      }
+    }
     ICECHK(hipGetLastError());
     return 0;
   }
@@ -811,17 +930,32 @@ int fesom_gpu_ice_evp_partitioned(int ncalls, const fesom_transport *t) {
   const int *sptr_d = I.sptr_d, *rptr_d = I.rptr_d;
   hipStream_t s = I.stream;
   // halo of (u_ice_aux, v_ice_aux) in the buffers of parity `par` (exchange_nod after every subcycle)
-  auto halo = [&](int par) -> int {
-    if (I.nsend > 0) hipLaunchKernelGGL(k_ice_pack, dim3((I.nsend + 255) / 256), dim3(256), 0, s, m.ua[par], m.va[par], I.slist, sptr_d, (int)I.sPE.size(), I.nsend, I.hsend);
+  auto halo_uv = [&](double *hu, double *hv) -> int {
+    if (I.nsend > 0) hipLaunchKernelGGL(k_ice_pack, dim3((I.nsend + 255) / 256), dim3(256), 0, s, (const double *)hu, (const double *)hv, I.slist, sptr_d, (int)I.sPE.size(), I.nsend, I.hsend);
     if (t) {
       if (hipStreamSynchronize(s) != hipSuccess) { I.err = "ice_evp_partitioned: stream"; return 1; }                      // (a host transport reads the packed buffer)
       if (t->exchange(t->ctx, 0, I.hsend, I.hrecv, 2)) { I.err = "ice_evp_partitioned: transport exchange failed"; return 1; }
     } else if (fesom_internal_rccl_exchange((int)I.sPE.size(), I.sPE.data(), I.sptr.data(), (int)I.rPE.size(), I.rPE.data(), I.rptr.data(), I.hsend, I.hrecv, 2, s)) {
       I.err = "ice_evp_partitioned: built-in transport failed (fesom_gpu_comm_init?)"; return 1;
     }
-    if (I.nrecv > 0) hipLaunchKernelGGL(k_ice_unpack, dim3((I.nrecv + 255) / 256), dim3(256), 0, s, m.ua[par], m.va[par], I.rlist, rptr_d, (int)I.rPE.size(), I.nrecv, I.hrecv);
+    if (I.nrecv > 0) hipLaunchKernelGGL(k_ice_unpack, dim3((I.nrecv + 255) / 256), dim3(256), 0, s, hu, hv, I.rlist, rptr_d, (int)I.rPE.size(), I.nrecv, I.hrecv);
     return 0;
   };
+  auto halo = [&](int par) -> int { return halo_uv(m.ua[par], m.va[par]); };
+  if (m.p.whichEVP == 0) {       // classic EVP (EVPdynamics): the velocities themselves are exchanged after every subcycle (ice_EVP.F90:600)
+    const double ax = cos(m.p.theta_io), ay = sin(m.p.theta_io);
+    for (int c = 0; c < ncalls; c++) {
+      hipLaunchKernelGGL(k_ice_c_prep_node, dim3((m.myN + 255) / 256), dim3(256), 0, s, m);
+      hipLaunchKernelGGL(k_ice_c_prep_elem, dim3((m.myE + 255) / 256), dim3(256), 0, s, m);
+      for (int k = 0; k < m.p.evp_rheol_steps; k++) {
+        hipLaunchKernelGGL(k_ice_c_stress, dim3((m.myE + 255) / 256), dim3(256), 0, s, m, I.cur);
+        hipLaunchKernelGGL(k_ice_c_node, dim3((m.N + 127) / 128), dim3(128), 0, s, m, I.cur, ax, ay);
+        if (halo_uv(m.u_ice, m.v_ice)) return 1;
+      }
+    }
+    ICECHK(hipGetLastError());
+    return 0;
+  }
   if (m.p.whichEVP == 2) {       // adaptive EVP (EVPdynamics_a): every rank updates the stresses of all its elements, the node update of its own nodes, then the halo (:879)
     for (int c = 0; c < ncalls; c++) {
       hipLaunchKernelGGL(k_ice_a_prep, dim3((m.N + 255) / 256), dim3(256), 0, s, m);
@@ -876,7 +1010,8 @@ static int ice_refresh_efac() {
   const double val3 = 1.0 / 3.0;
   for (size_t el = 0; el < (size_t)m.myE; el++) {
     const int *en = &I.h_en[3 * el];
-    const double asum = ((I.h_aice[en[0]] + I.h_aice[en[1]]) + I.h_aice[en[2]]) * val3;
+    double asum = ((I.h_aice[en[0]] + I.h_aice[en[1]]) + I.h_aice[en[2]]) * val3;
+    if (m.p.whichEVP == 0) asum = ((I.h_aice[en[0]] + I.h_aice[en[1]]) + I.h_aice[en[2]]) / 3.0;
     I.h_efac[el] = exp(-m.p.c_pressure * (1.0 - asum));
   }
   ICECHK(hipMemcpy(m.efac, I.h_efac.data(), sizeof(double) * m.myE, hipMemcpyHostToDevice));

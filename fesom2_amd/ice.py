@@ -1,5 +1,5 @@
 """Host-side handle on the sea-ice dynamics of libfesom_gpu.so (fesom_gpu_ice_*, include/fesom_gpu.h): the subcycled
-momentum solve EVPdynamics_m of the reference (src/ice_maEVP.F90:273-602; whichEVP = 2: the adaptive EVPdynamics_a, :785-888) and the FCT advection of the ice fields (src/ice_fct.F90).
+momentum solve EVPdynamics_m of the reference (src/ice_maEVP.F90:273-602; whichEVP = 2: the adaptive EVPdynamics_a, :785-888; whichEVP = 0: the classic EVPdynamics, src/ice_EVP.F90:397-667) and the FCT advection of the ice fields (src/ice_fct.F90).
 No CPU fallback."""
 import ctypes as C
 import numpy as np
@@ -7,13 +7,14 @@ from . import _lib
 
 
 def ice_params(ice_dt=900.0, ellipse=2.0, alpha_evp=250.0, beta_evp=250.0, Pstar=30000.0, c_pressure=20.0, delta_min=1.0e-11, cd_oce_ice=5.5e-3,
-               max_ice_loading=5.0, evp_rheol_steps=120, use_floatice=False, ice_gamma_fct=0.25, whichEVP=1, c_aevp=0.15):
+               max_ice_loading=5.0, evp_rheol_steps=120, use_floatice=False, ice_gamma_fct=0.25, whichEVP=1, c_aevp=0.15, theta_io=0.0, Tevp_inv=None):
     """defaults = src/ice_modules.F90:7-27 (i_PARAM) and gen_modules_config.F90:67"""
     p = _lib.IceParams()
     p.ice_dt, p.ellipse, p.alpha_evp, p.beta_evp, p.Pstar, p.c_pressure = ice_dt, ellipse, alpha_evp, beta_evp, Pstar, c_pressure
     p.delta_min, p.cd_oce_ice, p.max_ice_loading = delta_min, cd_oce_ice, max_ice_loading
     p.evp_rheol_steps, p.use_floatice = int(evp_rheol_steps), int(use_floatice)
     p.ice_gamma_fct = ice_gamma_fct
+    p.theta_io, p.Tevp_inv = theta_io, (3.0 / ice_dt if Tevp_inv is None else Tevp_inv)      # classic EVP (whichEVP = 0): src/ice_modules.F90:32, ice_setup_step.F90:33
     p.whichEVP, p.c_aevp = int(whichEVP), c_aevp          # 2 = adaptive EVP (EVPdynamics_a, src/ice_maEVP.F90:785-888; c_aevp: ice_modules.F90:36)
     return p
 

@@ -315,7 +315,8 @@ int  fesom_gpu_set_stream(void *hip_stream);   /* run the library's kernels on t
  * and viscous-plastic stresses on elements, stress divergence gathered to nodes, implicit Coriolis / ocean-drag velocity update,
  * coastal boundary condition.  Independent of the ocean core's context (may coexist with it); partitions: fesom_gpu_ice_evp_partitioned.
  * Arrays keep the reference's extents: node fields myDim_nod2D + eDim_nod2D, stresses myDim_elem2D.  Not built: cavities
- * (ulevels > 1), icepack, the classic EVP (whichEVP = 0).  whichEVP = 2 (adaptive EVP, EVPdynamics_a :785-888): fesom_ice_params.whichEVP. */
+ * (ulevels > 1), icepack.  The other two rheologies of the reference -- the classic EVP (whichEVP = 0, src/ice_EVP.F90) and the adaptive EVP (whichEVP = 2,
+ * EVPdynamics_a :785-888) -- are selected by fesom_ice_params.whichEVP. */
 typedef struct fesom_ice_params {
   double ice_dt;             /* ice_ave_steps * dt */
   double ellipse, alpha_evp, beta_evp, Pstar, c_pressure, delta_min, cd_oce_ice;   /* namelist.ice &ice_dyn (src/ice_modules.F90:7-27) */
@@ -323,8 +324,11 @@ typedef struct fesom_ice_params {
   int    evp_rheol_steps;
   int    use_floatice;       /* use_floatice .and. which_ALE /= 'linfs' (ice_maEVP.F90:159): ice + snow load in the sea-surface slope term */
   double ice_gamma_fct;      /* smoothing parameter of the FCT advection (namelist.ice &ice_dyn, src/ice_modules.F90:27: 0.25) */
-  int    whichEVP;           /* 1 (and 0 in this struct's zero default) = mEVP, EVPdynamics_m; 2 = adaptive EVP, EVPdynamics_a (src/ice_maEVP.F90:785-888) */
+  int    whichEVP;           /* as namelist.ice &ice_dyn (src/ice_modules.F90:42): 0 = the classic EVP, EVPdynamics (src/ice_EVP.F90:397-667; the reference's default),
+                                1 = mEVP, EVPdynamics_m, 2 = adaptive EVP, EVPdynamics_a (src/ice_maEVP.F90:785-888) */
   double c_aevp;             /* aEVP: constant of the adaptive alpha (namelist.ice &ice_dyn, src/ice_modules.F90:36: 0.15) */
+  double theta_io;           /* classic EVP: ice-ocean turning angle (src/ice_modules.F90:32: 0) */
+  double Tevp_inv;           /* classic EVP: inverse relaxation time, 3 / ice_dt (ice_setup, src/ice_setup_step.F90:33) */
 } fesom_ice_params;
 typedef struct fesom_ice_state {
   double *u_ice, *v_ice;                                            /* in / out */

@@ -1,4 +1,4 @@
-/* ORACLE (test infrastructure): CPU restatement of the sea-ice rheologies EVPdynamics_a (adaptive EVP, below) and mEVP, EVPdynamics_m (src/ice_maEVP.F90:273-602; whichEVP = 1,
+/* ORACLE (test infrastructure): CPU restatement of the sea-ice rheologies EVPdynamics (classic EVP) and EVPdynamics_a (adaptive EVP), both below, and mEVP, EVPdynamics_m (src/ice_maEVP.F90:273-602; whichEVP = 1,
  * no cavities, no icepack), loop for loop in the reference's order.  Pinned bitwise on a run of the reference's own routine
  * (oracle/_ref, driver mode 'ice', one MPI rank: tests/golden/ice_evp_reference.npz, tests/test_ice.py).  Stand-alone: it works
  * on a mesh descriptor and the ice arrays, not on the ocean context. */
@@ -239,6 +239,109 @@ int orc_ice_evp_a(const fesom_mesh_desc *m, const fesom_ice_params *p, fesom_ice
     s->beta_evp_array[i] = b;
   }
   free(ua); free(va); free(rhs_a); free(rhs_m); free(urhs); free(vrhs); free(bnd);
+  return 0;
+}
+
+/* Classic EVP, EVPdynamics (src/ice_EVP.F90:397-667; whichEVP = 0, the default of namelist.ice): inverse masses, ice strength and the sea-surface-slope term
+ * (:448-541), per subcycle stress_tensor (:23-134), stress2rhs (:323-396) and the node update (:556-585; the velocities are updated in place), coastal nodes.
+ * One partition.  Pinned bitwise on a run of the reference's own routine (tests/golden/ice_evp0_reference.npz, tests/test_ice.py). */
+int orc_ice_evp0(const fesom_mesh_desc *m, const fesom_ice_params *p, fesom_ice_state *s) {
+  const int myN = m->myDim_nod2D, N = myN + m->eDim_nod2D, myE = m->myDim_elem2D, nl = m->nl;
+  const double rdt = p->ice_dt / (1.0 * p->evp_rheol_steps), ax = cos(p->theta_io), ay = sin(p->theta_io);
+  const double vale = 1.0 / (p->ellipse * p->ellipse), dte = p->ice_dt / (1.0 * p->evp_rheol_steps);
+  const double det1 = 1.0 / (1.0 + 0.5 * p->Tevp_inv * dte), det2 = 1.0 / (1.0 + 0.5 * p->Tevp_inv * dte), val3 = 1 / 3.0;
+  double *inv_areamass = calloc(myN, sizeof(double)), *inv_mass = calloc(myN, sizeof(double)), *rhs_a = calloc(N, sizeof(double)), *rhs_m = calloc(N, sizeof(double));
+  double *urhs = calloc(N, sizeof(double)), *vrhs = calloc(N, sizeof(double)), *strength = calloc(myE, sizeof(double));
+  char *bnd = calloc(N, 1);
+  for (int ed = 0; ed < m->myDim_edge2D; ed++)
+    if (m->myList_edge2D[ed] > m->edge2D_in) { bnd[m->edges[2 * ed] - 1] = 1; bnd[m->edges[2 * ed + 1] - 1] = 1; }
+  for (int n = 0; n < myN; n++) {
+    if (m->ulevels_nod2D[n] > 1) continue;
+    const double ms = RHOICE * s->m_ice[n] + RHOSNO * s->m_snow[n];
+    inv_areamass[n] = ms > 1.e-3 ? 1. / (m->area[(size_t)n * nl] * ms) : 0.;
+    if (s->a_ice[n] < 0.01) inv_mass[n] = 0.;
+    else { inv_mass[n] = ms / s->a_ice[n]; inv_mass[n] = 1.0 / (inv_mass[n] > 9.0 ? inv_mass[n] : 9.0); }
+  }
+  const double use_pice = p->use_floatice ? 1.0 : 0.0;      /* (use_floatice of this struct = use_floatice .and. which_ALE /= 'linfs') */
+  for (int el = 0; el < myE; el++) {
+    if (m->ulevels[el] > 1) continue;
+    const int *en = m->elem2D_nodes + 3 * el;
+    const double m1 = s->m_ice[en[0] - 1], m2 = s->m_ice[en[1] - 1], m3 = s->m_ice[en[2] - 1], a1 = s->a_ice[en[0] - 1], a2 = s->a_ice[en[1] - 1], a3 = s->a_ice[en[2] - 1];
+    if (m1 <= 0. || m2 <= 0. || m3 <= 0. || a1 <= 0. || a2 <= 0. || a3 <= 0.) continue;
+    const double msum = ((m1 + m2) + m3) / 3.0, asum = ((a1 + a2) + a3) / 3.0;
+    strength[el] = p->Pstar * msum * exp(-p->c_pressure * (1.0 - asum));
+    strength[el] = 0.5 * strength[el];
+    const double aa = 9.81 * m->elem_area[el] / 3.0;
+    const double *gs = m->gradient_sca + 6 * (size_t)el;
+    double e3[3];
+    for (int k = 0; k < 3; k++) {
+      e3[k] = s->elevation[en[k] - 1];
+      {                                    /* (the ice load enters through p_ice * use_pice; with which_ALE = 'linfs' use_floatice of this struct is 0) */
+        double pi = (RHOICE * s->m_ice[en[k] - 1] + RHOSNO * s->m_snow[en[k] - 1]) * INV_RHOWAT;
+        pi = pi < p->max_ice_loading ? pi : p->max_ice_loading;
+        e3[k] = e3[k] + pi * use_pice;
+      }
+    }
+    const double ex = (gs[0] * e3[0] + gs[1] * e3[1]) + gs[2] * e3[2], ey = (gs[3] * e3[0] + gs[4] * e3[1]) + gs[5] * e3[2];
+    for (int k = 0; k < 3; k++) { rhs_a[en[k] - 1] = rhs_a[en[k] - 1] - aa * ex; rhs_m[en[k] - 1] = rhs_m[en[k] - 1] - aa * ey; }
+  }
+  for (int n = 0; n < myN; n++) {
+    if (m->ulevels_nod2D[n] > 1) continue;
+    rhs_a[n] = rhs_a[n] / m->area[(size_t)n * nl]; rhs_m[n] = rhs_m[n] / m->area[(size_t)n * nl];
+  }
+  double *U = s->u_ice, *V = s->v_ice;
+  for (int sub = 0; sub < p->evp_rheol_steps; sub++) {
+    for (int el = 0; el < myE; el++) {                        /* stress_tensor */
+      if (m->ulevels[el] > 1 || !(strength[el] > 0.)) continue;
+      const int *en = m->elem2D_nodes + 3 * el;
+      const double *dx = m->gradient_sca + 6 * (size_t)el, *dy = dx + 3, mf = m->metric_factor[el];
+      const double u1 = U[en[0] - 1], u2 = U[en[1] - 1], u3 = U[en[2] - 1], v1 = V[en[0] - 1], v2 = V[en[1] - 1], v3 = V[en[2] - 1];
+      const double e11 = ((dx[0] * u1 + dx[1] * u2) + dx[2] * u3) - mf * ((v1 + v2) + v3) / 3.0;
+      const double e22 = (dy[0] * v1 + dy[1] * v2) + dy[2] * v3;
+      const double e12 = 0.5 * ((((dy[0] * u1 + dy[1] * u2) + dy[2] * u3) + ((dx[0] * v1 + dx[1] * v2) + dx[2] * v3)) + mf * ((u1 + u2) + u3) / 3.0);
+      const double delta = sqrt((e11 * e11 + e22 * e22) * (1.0 + vale) + 4.0 * vale * e12 * e12 + 2.0 * e11 * e22 * (1.0 - vale));
+      const double delta_inv = 1.0 / (delta > p->delta_min ? delta : p->delta_min);
+      double zeta = strength[el] * delta_inv;
+      zeta = zeta * p->Tevp_inv;
+      const double r1 = zeta * (e11 + e22) - strength[el] * p->Tevp_inv, r2 = zeta * (e11 - e22) * vale, r3 = zeta * e12 * vale;
+      const double si1 = det1 * (s->sigma11[el] + s->sigma22[el] + dte * r1), si2 = det2 * (s->sigma11[el] - s->sigma22[el] + dte * r2);
+      s->sigma12[el] = det2 * (s->sigma12[el] + dte * r3);
+      s->sigma11[el] = 0.5 * (si1 + si2);
+      s->sigma22[el] = 0.5 * (si1 - si2);
+    }
+    for (int n = 0; n < myN; n++) { urhs[n] = 0.0; vrhs[n] = 0.0; }      /* stress2rhs */
+    for (int el = 0; el < myE; el++) {
+      if (m->ulevels[el] > 1 || !(strength[el] > 0.)) continue;
+      const int *en = m->elem2D_nodes + 3 * el;
+      const double *gs = m->gradient_sca + 6 * (size_t)el, ar = m->elem_area[el], mf = m->metric_factor[el];
+      const double s11 = s->sigma11[el], s12 = s->sigma12[el], s22 = s->sigma22[el];
+      for (int k = 0; k < 3; k++) {
+        urhs[en[k] - 1] = urhs[en[k] - 1] - ar * (s11 * gs[k] + s12 * gs[k + 3] + s12 * val3 * mf);
+        vrhs[en[k] - 1] = vrhs[en[k] - 1] - ar * (s12 * gs[k] + s22 * gs[k + 3] - s11 * val3 * mf);
+      }
+    }
+    for (int n = 0; n < myN; n++) {
+      if (m->ulevels_nod2D[n] > 1) continue;
+      if (inv_areamass[n] > 0.) { urhs[n] = urhs[n] * inv_areamass[n] + rhs_a[n]; vrhs[n] = vrhs[n] * inv_areamass[n] + rhs_m[n]; }
+      else { urhs[n] = 0.; vrhs[n] = 0.; }
+    }
+    for (int n = 0; n < myN; n++) {                           /* node update (:556-585) */
+      if (m->ulevels_nod2D[n] > 1) continue;
+      if (s->a_ice[n] >= 0.01) {
+        const double du = U[n] - s->u_w[n], dv = V[n] - s->v_w[n];
+        const double umod = sqrt(du * du + dv * dv);
+        const double drag = p->cd_oce_ice * umod * DENSITY_0 * inv_mass[n];
+        const double rhsu = U[n] + rdt * (drag * (ax * s->u_w[n] - ay * s->v_w[n]) + inv_mass[n] * s->stress_atmice_x[n] + urhs[n]);
+        const double rhsv = V[n] + rdt * (drag * (ax * s->v_w[n] + ay * s->u_w[n]) + inv_mass[n] * s->stress_atmice_y[n] + vrhs[n]);
+        const double r_a = 1. + ax * drag * rdt, r_b = rdt * (m->coriolis_node[n] + ay * drag);
+        const double det = 1.0 / (r_a * r_a + r_b * r_b);
+        U[n] = det * (r_a * rhsu + r_b * rhsv);
+        V[n] = det * (r_a * rhsv - r_b * rhsu);
+      } else { U[n] = 0.0; V[n] = 0.0; }
+    }
+    for (int i = 0; i < N; i++) if (bnd[i]) { U[i] = 0.0; V[i] = 0.0; }
+  }
+  free(inv_areamass); free(inv_mass); free(rhs_a); free(rhs_m); free(urhs); free(vrhs); free(strength); free(bnd);
   return 0;
 }
 

@@ -52,7 +52,7 @@ $S/gen_modules_cvmix_idemix.F90 $S/gen_modules_cvmix_tke.F90 $S/cvmix_math.F90 $
 $S/cvmix_tidal.F90 $S/gen_modules_cvmix_tidal.F90 $S/cvmix_shear.F90 $S/gen_modules_cvmix_pp.F90
 $S/toy_channel_soufflet.F90 $S/gen_comm.F90 $S/oce_setup_step.F90 $S/oce_mesh.F90 $S/oce_dyn.F90 $S/oce_ale_vel_rhs.F90
 $S/oce_vel_rhs_vinv.F90 $S/oce_ale_pressure_bv.F90 $S/oce_fer_gm.F90 $S/oce_muscl_adv.F90 $S/oce_ale.F90 $S/oce_ale_tracer.F90
-$S/write_step_info.F90 $S/oce_mo_conv.F90 $S/oce_spp.F90 $S/cavity_param.F90 $S/ice_maEVP.F90 $S/ice_fct.F90 $S/ice_thermo_oce.F90
+$S/write_step_info.F90 $S/oce_mo_conv.F90 $S/oce_spp.F90 $S/cavity_param.F90 $S/ice_maEVP.F90 $S/ice_EVP.F90 $S/ice_fct.F90 $S/ice_thermo_oce.F90
 $HERE/driver.F90"
 OBJS=""
 for f in $LIST; do

@@ -102,13 +102,13 @@ program oracle_driver
   character(len=16) :: mode
   character(len=256) :: dump_dir
   integer :: dump_steps(64), ndump
-  logical :: dump_mesh, do_mean, debug, synth_forcing, step_info, gpu_profile, ice_adv, mslp, tides, ice_aevp
+  logical :: dump_mesh, do_mean, debug, synth_forcing, step_info, gpu_profile, ice_adv, mslp, tides, ice_aevp, ice_evp0
   real(kind=WP) :: flon, flat
   integer :: fel(3)
   real(kind=WP) :: t0, t1, tloop
   character(len=64) :: tag
   namelist /clockinit/ timenew, daynew, yearnew
-  namelist /oracle/ nsteps, mode, dump_dir, dump_steps, dump_mesh, do_mean, debug, synth_forcing, step_info, gpu_profile, ice_adv, mslp, tides, ice_aevp
+  namelist /oracle/ nsteps, mode, dump_dir, dump_steps, dump_mesh, do_mean, debug, synth_forcing, step_info, gpu_profile, ice_adv, mslp, tides, ice_aevp, ice_evp0
   ! running sums for the fcheck-style known answer (setups/test_souf/setup.yml:82-88)
   real(kind=WP), allocatable :: mT(:,:), mS(:,:), mU(:,:), mV(:,:)
 
@@ -137,7 +137,7 @@ program oracle_driver
   read (20,NML=oce_tra)
   read (20,NML=oce_init3d)
   close (20)
-  nsteps=1; mode='step'; dump_dir='dumps'; dump_steps=-1; dump_mesh=.false.; do_mean=.false.; debug=.false.; synth_forcing=.false.; step_info=.false.; gpu_profile=.false.; ice_adv=.false.; mslp=.false.; tides=.false.; ice_aevp=.false.
+  nsteps=1; mode='step'; dump_dir='dumps'; dump_steps=-1; dump_mesh=.false.; do_mean=.false.; debug=.false.; synth_forcing=.false.; step_info=.false.; gpu_profile=.false.; ice_adv=.false.; mslp=.false.; tides=.false.; ice_aevp=.false.; ice_evp0=.false.
   open (20,file='namelist.oracle')
   read (20,NML=oracle)
   close (20)
@@ -403,6 +403,10 @@ contains
          use mod_mesh
          type(t_mesh), intent(in), target :: mesh
        end subroutine
+       subroutine EVPdynamics(mesh)
+         use mod_mesh
+         type(t_mesh), intent(in), target :: mesh
+       end subroutine
        subroutine ice_fct_init(mesh)
          use mod_mesh
          type(t_mesh), intent(in), target :: mesh
@@ -437,6 +441,11 @@ contains
     end if
     allocate(sigma11(e2), sigma12(e2), sigma22(e2), eps11(e2), eps12(e2), eps22(e2))
     ice_dt=real(ice_ave_steps,WP)*dt
+    Tevp_inv=3.0_WP/ice_dt      ! ice_setup (src/ice_setup_step.F90:33): the classic EVP's relaxation time
+    if (ice_evp0) then          ! classic EVP (whichEVP = 0, the default of namelist.ice): work arrays of ice_array_setup
+       allocate(u_ice_old(n2), v_ice_old(n2))
+       u_ice_old=0.0_WP; v_ice_old=0.0_WP
+    end if
     if (ice_aevp) then          ! adaptive EVP (whichEVP = 2): the arrays of ice_array_setup (src/ice_setup_step.F90:85-89)
        allocate(alpha_evp_array(myDim_elem2D), beta_evp_array(n2))
        alpha_evp_array=alpha_evp; beta_evp_array=alpha_evp
@@ -472,6 +481,8 @@ contains
     do it=1, nsteps
        if (ice_aevp) then
           call EVPdynamics_a(mesh)
+       else if (ice_evp0) then
+          call EVPdynamics(mesh)
        else
           call EVPdynamics_m(mesh)
        end if
@@ -516,7 +527,7 @@ contains
     call dump('u_w', u_w); call dump('v_w', v_w); call dump('elevation', elevation)
     call dump('stress_atmice_x', stress_atmice_x); call dump('stress_atmice_y', stress_atmice_y)
     call dump('sigma11', sigma11); call dump('sigma12', sigma12); call dump('sigma22', sigma22)
-    call dump('ice_params', (/ ice_dt, ellipse, alpha_evp, beta_evp, Pstar, c_pressure, delta_min, cd_oce_ice, real(evp_rheol_steps,WP), max_ice_loading, c_aevp /))
+    call dump('ice_params', (/ ice_dt, ellipse, alpha_evp, beta_evp, Pstar, c_pressure, delta_min, cd_oce_ice, real(evp_rheol_steps,WP), max_ice_loading, c_aevp, theta_io, Tevp_inv /))
     if (allocated(alpha_evp_array)) then
        call dump('alpha_evp_array', alpha_evp_array); call dump('beta_evp_array', beta_evp_array)
     end if

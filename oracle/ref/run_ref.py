@@ -481,14 +481,14 @@ def prepare(cfg, np_, tag=""):
     return rd
 
 
-def run(cfg, np_, nsteps, mode="step", dump=(), mean=False, dump_mesh=True, quiet=True, exe_name="fesom_oracle.x", step_info=False, gpu_profile=False, ice_adv=False, ice_aevp=False):
+def run(cfg, np_, nsteps, mode="step", dump=(), mean=False, dump_mesh=True, quiet=True, exe_name="fesom_oracle.x", step_info=False, gpu_profile=False, ice_adv=False, ice_aevp=False, ice_evp0=False):
     forcing = CFGS[cfg].get("synth_forcing", False)
     rd = prepare(cfg, np_, "" if exe_name == "fesom_oracle.x" else "_" + exe_name.split(".")[0])
     ds = ",".join(str(d) for d in dump) if dump else "-1"
     open(os.path.join(rd, "namelist.oracle"), "w").write(
         f"&oracle\nnsteps={nsteps}\nmode='{mode}'\ndump_dir='dumps'\ndump_steps={ds}\n"
         f"dump_mesh={'.true.' if dump_mesh else '.false.'}\ndo_mean={'.true.' if mean else '.false.'}\n"
-        f"synth_forcing={'.true.' if forcing else '.false.'}\nstep_info={'.true.' if step_info else '.false.'}\ngpu_profile={'.true.' if gpu_profile else '.false.'}\nice_adv={'.true.' if ice_adv else '.false.'}\nice_aevp={'.true.' if ice_aevp else '.false.'}\nmslp={'.true.' if CFGS[cfg].get('mslp') else '.false.'}\ntides={'.true.' if CFGS[cfg].get('tides') else '.false.'}\n/\n")
+        f"synth_forcing={'.true.' if forcing else '.false.'}\nstep_info={'.true.' if step_info else '.false.'}\ngpu_profile={'.true.' if gpu_profile else '.false.'}\nice_adv={'.true.' if ice_adv else '.false.'}\nice_aevp={'.true.' if ice_aevp else '.false.'}\nice_evp0={'.true.' if ice_evp0 else '.false.'}\nmslp={'.true.' if CFGS[cfg].get('mslp') else '.false.'}\ntides={'.true.' if CFGS[cfg].get('tides') else '.false.'}\n/\n")
     exe = os.path.join(OUT, exe_name)
     cmd = ["/opt/conda/bin/mpiexec", "-n", str(np_), exe]
     def big_stack():        # the reference keeps (nl, nodes) work arrays on the stack: larger meshes overflow the default 8 MB

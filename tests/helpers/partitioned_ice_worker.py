@@ -24,13 +24,14 @@ def main():
     rank = dist.get_rank()
     adv = os.environ.get("ICE_ADV") == "1"                    # + the FCT advection after the EVP call (tests/golden/ice_adv_reference.npz)
     aevp = os.environ.get("ICE_AEVP") == "1"                  # the adaptive EVP, EVPdynamics_a (tests/golden/ice_aevp_reference.npz)
-    g = np.load(os.path.join(REPO, "tests", "golden", "ice_aevp_reference.npz" if aevp else ("ice_adv_reference.npz" if adv else "ice_evp_reference.npz")))
+    evp0 = os.environ.get("ICE_EVP0") == "1"                  # the classic EVP, EVPdynamics (tests/golden/ice_evp0_reference.npz)
+    g = np.load(os.path.join(REPO, "tests", "golden", "ice_evp0_reference.npz" if evp0 else ("ice_aevp_reference.npz" if aevp else ("ice_adv_reference.npz" if adv else "ice_evp_reference.npz"))))
     transport = os.environ.get("PART_TRANSPORT") or None
     pc = parallel.PartitionedCore(PI, make_params(dt=900.0), dt=900.0, transport=transport)     # the partition's transport (ocean context = same com lists)
     mesh = pc.mesh
     pv = g["in/ice_params"]
     par = ice.ice_params(ice_dt=pv[0], ellipse=pv[1], alpha_evp=pv[2], beta_evp=pv[3], Pstar=pv[4], c_pressure=pv[5], delta_min=pv[6], cd_oce_ice=pv[7],
-                         evp_rheol_steps=int(pv[8]), max_ice_loading=pv[9], **(dict(whichEVP=2, c_aevp=pv[10]) if aevp else {}))
+                         evp_rheol_steps=int(pv[8]), max_ice_loading=pv[9], **(dict(whichEVP=2, c_aevp=pv[10]) if aevp else (dict(whichEVP=0, theta_io=pv[11], Tevp_inv=pv[12]) if evp0 else {})))
     myE, N = mesh.myDim_elem2D, mesh.myDim_nod2D + mesh.eDim_nod2D
     names = STATE + (("alpha_evp_array", "beta_evp_array") if aevp else ())
     fields = ice.IceFields(**{k: (g[f"r2/{rank}/in/{k}"][:myE] if (k.startswith("sigma") or k.startswith("alpha")) else g[f"r2/{rank}/in/{k}"]) for k in names})

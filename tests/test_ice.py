@@ -98,7 +98,7 @@ def test_gpu_evp_equals_oracle_and_reference_bitwise(built, floatice):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("transport,adv", [("callback", False), ("builtin", False), ("callback", True), ("builtin", True), ("callback", "aevp"), ("builtin", "aevp")])
+@pytest.mark.parametrize("transport,adv", [("callback", False), ("builtin", False), ("callback", True), ("builtin", True), ("callback", "aevp"), ("builtin", "aevp"), ("callback", "evp0"), ("builtin", "evp0")])
 def test_gpu_partitioned_evp_equals_reference(built, transport, adv):
     """2 ranks (the reference's dist_2 partition of pi, sharing the GPU): halo of (u_ice_aux, v_ice_aux) after every subcycle through the
     host-callback transport (gloo) or the library's built-in transport (shared-memory stand-in for librccl); every rank's u_ice, v_ice
@@ -114,6 +114,8 @@ def test_gpu_partitioned_evp_equals_reference(built, transport, adv):
         env.update(FESOM_GPU_RCCL_LIB=fake, PART_TRANSPORT="rccl")
     if adv == "aevp":          # the adaptive EVP, EVPdynamics_a, against the reference's 2-rank run of it (tests/golden/ice_aevp_reference.npz: r2/...)
         env["ICE_AEVP"] = "1"; adv = False; port_off = 4
+    elif adv == "evp0":        # the classic EVP, EVPdynamics (tests/golden/ice_evp0_reference.npz: r2/...)
+        env["ICE_EVP0"] = "1"; adv = False; port_off = 6
     else:
         port_off = 0
     if adv:
@@ -244,6 +246,63 @@ def test_gpu_aevp_equals_oracle_and_reference_bitwise(built):
         core.evp(1); core.download(fg)
         assert orc.orc_ice_evp_a(mesh.desc_p, C.byref(par), C.byref(fo.desc)) == 0
         for k in AOUT:
+            assert bits(fg[k], fo[k]), (n, k, float(np.abs(fg[k] - fo[k]).max()))
+            assert bits(fg[k], g[f"out{n}/{k}"]), (n, k)
+    ms = core.time_ms(3)
+    assert 0.0 < ms < 100.0
+    core.close()
+
+
+# ---- classic EVP (whichEVP = 0, the default of namelist.ice: EVPdynamics, src/ice_EVP.F90:397-667) ----
+def gold_0():
+    return np.load(os.path.join(REPO, "tests", "golden", "ice_evp0_reference.npz"))
+
+
+def setup_0(g):
+    from fesom2_amd.mesh import Mesh
+    from fesom2_amd import ice
+    mesh = Mesh.load(PI, dt=900.0)
+    pv = g["in/ice_params"]
+    par = ice.ice_params(ice_dt=pv[0], ellipse=pv[1], alpha_evp=pv[2], beta_evp=pv[3], Pstar=pv[4], c_pressure=pv[5], delta_min=pv[6], cd_oce_ice=pv[7],
+                         evp_rheol_steps=int(pv[8]), max_ice_loading=pv[9], whichEVP=0, theta_io=pv[11], Tevp_inv=pv[12])
+    fields = ice.IceFields(**{k: g["in/" + k] for k in STATE})
+    return mesh, par, fields
+
+
+def test_oracle_evp0_equals_reference_bitwise(built):
+    """the oracle's restatement of the classic EVP (ice strength and sea-surface-slope term, stress_tensor, stress2rhs, node update in place) against the
+    reference's own EVPdynamics: velocities and stresses bit for bit after one and after two calls of 120 subcycles (tests/golden/make_ice_evp0_golden.py)"""
+    import oracle_lib
+    g = gold_0()
+    mesh, par, fields = setup_0(g)
+    assert par.Tevp_inv == 3.0 / par.ice_dt
+    oracle_lib.build()
+    orc = C.CDLL(oracle_lib.ORC_LIB)
+    for n in (1, 2):
+        assert orc.orc_ice_evp0(mesh.desc_p, C.byref(par), C.byref(fields.desc)) == 0
+        for k in OUT:
+            assert bits(fields[k], g[f"out{n}/{k}"]), (n, k, float(np.abs(fields[k] - g[f"out{n}/{k}"]).max()))
+    assert np.abs(fields["u_ice"] - g["in/u_ice"]).max() > 1e-3 and np.abs(fields["sigma11"]).max() > 1e2
+    assert not bits(fields["u_ice"], gold()["out2/u_ice"])                 # (not the mEVP answer)
+
+
+@pytest.mark.gpu
+def test_gpu_evp0_equals_oracle_and_reference_bitwise(built):
+    """the classic EVP on the device (k_ice_c_prep_node / _elem once per call, k_ice_c_stress + k_ice_c_node per subcycle, velocities in place): velocities and
+    stresses equal the oracle's and the reference's own EVPdynamics bit for bit after one and after two calls"""
+    from fesom2_amd import ice
+    import oracle_lib
+    g = gold_0()
+    mesh, par, fo = setup_0(g)
+    _, _, fg = setup_0(g)
+    oracle_lib.build()
+    orc = C.CDLL(oracle_lib.ORC_LIB)
+    core = ice.IceCore(mesh, par)
+    core.upload(fg)
+    for n in (1, 2):
+        core.evp(1); core.download(fg)
+        assert orc.orc_ice_evp0(mesh.desc_p, C.byref(par), C.byref(fo.desc)) == 0
+        for k in OUT:
             assert bits(fg[k], fo[k]), (n, k, float(np.abs(fg[k] - fo[k]).max()))
             assert bits(fg[k], g[f"out{n}/{k}"]), (n, k)
     ms = core.time_ms(3)
