@@ -887,7 +887,7 @@ int fesom_gpu_ice_evp(int ncalls) {
   ICE_READY();
   if (I.m.p.whichEVP == 2 || I.m.p.whichEVP == 0) {          // adaptive EVP: EVPdynamics_a; classic EVP: EVPdynamics
     if (I.npes > 1) { I.err = "fesom_gpu_ice_evp: partitioned context, call fesom_gpu_ice_evp_partitioned"; return 1; }
-    for (int c = 0; c < ncalls; c++) {
+    auto enqueue = [&]() {
       if (I.m.p.whichEVP == 2) enqueue_call_a(I.stream, I.cur);
       else {
         const IceDM &m = I.m;
@@ -899,6 +899,20 @@ int fesom_gpu_ice_evp(int ncalls) {
           hipLaunchKernelGGL(k_ice_c_node, dim3((m.N + 127) / 128), dim3(128), 0, I.stream, m, I.cur, ax, ay);
         }
       }
+    };
+    // the stresses stay in sig[I.cur] (in place): the launches of a call never change -> one fixed graph (2 launches per subcycle, launch-bound on pi)
+    static const bool no_graph = getenv("FESOM_GPU_ICE_NO_GRAPH") != nullptr;
+    for (int c = 0; c < ncalls; c++) {
+      if (no_graph) { enqueue(); continue; }
+      if (!I.graph) {
+        hipGraph_t g;
+        ICECHK(hipStreamBeginCapture(I.stream, hipStreamCaptureModeGlobal));
+        enqueue();
+        ICECHK(hipStreamEndCapture(I.stream, &g));
+        ICECHK(hipGraphInstantiate(&I.graph, g, nullptr, nullptr, 0));
+        hipGraphDestroy(g);
+      }
+      ICECHK(hipGraphLaunch(I.graph, I.stream));
     }
     ICECHK(hipGetLastError());
     return 0;

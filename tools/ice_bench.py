@@ -48,14 +48,45 @@ def gpu(mesh, dt):
             "ms_per_ice_step_evp_plus_advection_wall": round(step_ms, 4), "ms_advection_wall": round(step_ms - ms, 4)}
 
 
+def gpu_rheology(mesh, dt, which):
+    """device time per call of the classic (0) / adaptive (2) EVP on the analytic state"""
+    par = ice.ice_params(ice_dt=dt, whichEVP=which)
+    core = ice.IceCore(mesh, par)
+    st = analytic_state(mesh)
+    if which == 2:
+        st = ice.IceFields(**dict(st.a, alpha_evp_array=np.full(mesh.myDim_elem2D, par.alpha_evp), beta_evp_array=np.full(mesh.myDim_nod2D + mesh.eDim_nod2D, par.alpha_evp)))
+    core.upload(st)
+    ms = core.time_ms(10)
+    core.download(st)
+    assert np.isfinite(st["u_ice"]).all()
+    core.close()
+    return {"ms_per_call": round(ms, 4), "us_per_subcycle": round(ms * 1e3 / 120, 3), "umax": float(np.abs(st["u_ice"]).max())}
+
+
 def main():
     out = {"what": "EVPdynamics_m (src/ice_maEVP.F90:273-602), one call = 120 subcycles, fp64, analytic ice state"}
     pim = Mesh.load(os.path.join(REPO, "tests", "golden", "meshes", "pi"), dt=900.0)
     out["pi"] = gpu(pim, 900.0)
     wl = workloads.channel(3)
     out["channel_r3"] = gpu(wl.load_mesh(), wl.dt)
+    out["other_rheologies"] = {"what": "whichEVP = 0: classic EVP, EVPdynamics (src/ice_EVP.F90:397-667, the default of namelist.ice); whichEVP = 2: adaptive EVP, EVPdynamics_a "
+                                       "(src/ice_maEVP.F90:785-888); two launches per subcycle, thread per node / element"}
+    for which, name in ((0, "classic_evp"), (2, "adaptive_evp")):
+        out["other_rheologies"][name] = {"pi": gpu_rheology(pim, 900.0, which), "channel_r3": gpu_rheology(wl.load_mesh(), wl.dt, which)}
     try:
         from oracle.ref import run_ref
+        for name, kw in (("classic_evp", dict(ice_evp0=True)), ("adaptive_evp", dict(ice_aevp=True))):
+            tr = {}
+            for ranks in (1, 8, 16):
+                if ranks > (os.cpu_count() or 1):
+                    continue
+                rd, rc, lines = run_ref.run("pi_pp", ranks, 20, mode="ice", dump=(), **kw)
+                tl = [l for l in lines if l.startswith("ORACLE_TIMING_ICE")]
+                if rc == 0 and tl:
+                    tr[ranks] = round(float(tl[0].split("s_per_call=")[1].split()[0]) * 1e3, 3)
+            if tr:
+                b = min(tr, key=tr.get)
+                out["other_rheologies"][name]["cpu_reference_pi"] = {"ms_per_call_by_ranks": tr, "best_ranks": b, "gpu_over_cpu": round(tr[b] / out["other_rheologies"][name]["pi"]["ms_per_call"], 1)}
         tried, tried_adv = {}, {}
         for ranks in (1, 8, 16):
             if ranks > (os.cpu_count() or 1):
