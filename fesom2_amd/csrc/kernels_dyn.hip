@@ -657,7 +657,7 @@ __global__ void __launch_bounds__(BLOCK) k_momadv_node(DM m) {
   if (n >= m.myN) return;
   const int nl1 = m.nlev_n[n] - 1, ul1 = m.ulev_n[n];
   const int nzc = nz <= m.nlm1 ? nz : m.nlm1, nzm = nzc > 1 ? nzc - 1 : 1;
-  constexpr int MA_B = 6;
+  constexpr int MA_B = 3;
   double wu = 0.0, wv = 0.0;                 // wu(nz), nz = 1..nl1+1
   {
     const int num = m.nie_num[n];
@@ -1551,7 +1551,7 @@ __global__ void __launch_bounds__(BLOCK) k_vert_vel(DM m, int fuse_hbar) {
       x1_l = DECD(1, ed); x2_l = DECD(2, ed); x3_l = DECD(3, ed); x4_l = DECD(4, ed);
     }
     const int nzc = nz <= m.nlm1 ? nz : m.nlm1;
-    constexpr int VW_B = 6;
+    constexpr int VW_B = 3;
     for (int k0 = 0; k0 < deg; k0 += VW_B) {
       double u1[VW_B], v1[VW_B], h1[VW_B], u2[VW_B], v2[VW_B], h2[VW_B];
 #pragma unroll
