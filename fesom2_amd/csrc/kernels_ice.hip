@@ -711,6 +711,201 @@ __global__ void k_ice_c_node(IceDM m, int sp, double ax, double ay) {      // st
   if (m.bnd[i]) { U = 0.0; V = 0.0; }
   m.u_ice[i] = U; m.v_ice[i] = V;
 }
+// The classic subcycle FUSED as k_ice_sub8 is (eight lanes per node, lane (node, k) evaluates element k of the node from the stresses and velocities of parity `par`,
+// the element's first owned node stores its new stresses to parity 1 - par, the node's first lane subtracts the stress-divergence terms in element order and updates the
+// node): one launch per subcycle instead of two, the dependent loads of a node's elements side by side.  Same operations in the same order as k_ice_c_stress + k_ice_c_node.
+__global__ void __launch_bounds__(256) k_ice_c_sub8(IceDM m, int par, double ax, double ay) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t >> 3, k0 = t & 7;
+  const bool live = i < m.N;
+  const double *uo = m.ua[par], *vo = m.va[par];
+  double *un = m.ua[1 - par], *vn = m.va[1 - par];
+  const bool owned = live && i < m.myN;
+  const double *so = m.sig[par];
+  double *sn = m.sig[1 - par];
+  const size_t E = (size_t)m.myE;
+  const double val3 = 1 / 3.0, vale = 1.0 / (m.p.ellipse * m.p.ellipse), dte = m.p.ice_dt / (1.0 * m.p.evp_rheol_steps), rdt = dte;
+  const double det1 = 1.0 / (1.0 + 0.5 * m.p.Tevp_inv * dte), det2 = 1.0 / (1.0 + 0.5 * m.p.Tevp_inv * dte);
+  const int num = owned ? m.nie_num[i] : 0;
+  int nmax = num;
+  for (int sft = 32; sft >= 1; sft >>= 1) nmax = max(nmax, __shfl_xor(nmax, sft, 64));
+  double urhs = 0.0, vrhs = 0.0;
+  for (int base = 0; base < nmax; base += 8) {
+    const int k = base + k0;
+    double tu = 0.0, tv = 0.0;
+    if (k < num) {
+      const int el = m.nie[(size_t)m.maxk * i + k];
+      const int n1 = m.en[3 * el], n2 = m.en[3 * el + 1], n3 = m.en[3 * el + 2];
+      const bool writer = (n1 < m.myN) ? (n1 == i) : ((n2 < m.myN) ? (n2 == i) : (n3 == i));
+      double s11 = so[el], s12 = so[E + el], s22 = so[2 * E + el];
+      const double strength = m.pfac[el];
+      if (strength > 0.) {
+        const double *dx = m.gsca + 6 * (size_t)el, *dy = dx + 3, mf = m.metric[el];
+        const double u1 = uo[n1], u2 = uo[n2], u3 = uo[n3], v1 = vo[n1], v2 = vo[n2], v3 = vo[n3];
+        const double e11 = ((dx[0] * u1 + dx[1] * u2) + dx[2] * u3) - mf * ((v1 + v2) + v3) / 3.0;
+        const double e22 = (dy[0] * v1 + dy[1] * v2) + dy[2] * v3;
+        const double e12 = 0.5 * ((((dy[0] * u1 + dy[1] * u2) + dy[2] * u3) + ((dx[0] * v1 + dx[1] * v2) + dx[2] * v3)) + mf * ((u1 + u2) + u3) / 3.0);
+        const double delta = sqrt((e11 * e11 + e22 * e22) * (1.0 + vale) + 4.0 * vale * e12 * e12 + 2.0 * e11 * e22 * (1.0 - vale));
+        const double delta_inv = 1.0 / (delta > m.p.delta_min ? delta : m.p.delta_min);
+        double zeta = strength * delta_inv;
+        zeta = zeta * m.p.Tevp_inv;
+        const double r1 = zeta * (e11 + e22) - strength * m.p.Tevp_inv, r2 = zeta * (e11 - e22) * vale, r3 = zeta * e12 * vale;
+        const double si1 = det1 * (s11 + s22 + dte * r1), si2 = det2 * (s11 - s22 + dte * r2);
+        s12 = det2 * (s12 + dte * r3);
+        s11 = 0.5 * (si1 + si2);
+        s22 = 0.5 * (si1 - si2);
+        const int pos = (n1 == i) ? 0 : ((n2 == i) ? 1 : 2);
+        const double *gs = m.gsca + 6 * (size_t)el;
+        const double ar = m.elem_area[el];
+        tu = ar * (s11 * gs[pos] + s12 * gs[pos + 3] + s12 * val3 * mf);
+        tv = ar * (s12 * gs[pos] + s22 * gs[pos + 3] - s11 * val3 * mf);
+      }
+      if (writer) { sn[el] = s11; sn[E + el] = s12; sn[2 * E + el] = s22; }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const double qu = __shfl(tu, q, 8), qv = __shfl(tv, q, 8);
+      urhs = urhs - qu; vrhs = vrhs - qv;
+    }
+  }
+  if (!live || k0 != 0) return;
+  if (!owned) { double U = uo[i], V = vo[i]; if (m.bnd[i]) { U = 0.0; V = 0.0; } un[i] = U; vn[i] = V; return; }
+  const double iam = m.mass[i];
+  if (iam > 0.) { urhs = urhs * iam + m.rhs_a[i]; vrhs = vrhs * iam + m.rhs_m[i]; } else { urhs = 0.; vrhs = 0.; }
+  double U = uo[i], V = vo[i];
+  if (m.a_ice[i] >= 0.01) {
+    const double uw = m.u_w[i], vw = m.v_w[i], im = m.invt[i];
+    const double du = U - uw, dv = V - vw;
+    const double umod = sqrt(du * du + dv * dv);
+    const double drag = m.p.cd_oce_ice * umod * ICE_DENSITY_0 * im;
+    const double rhsu = U + rdt * (drag * (ax * uw - ay * vw) + im * m.tax[i] + urhs);
+    const double rhsv = V + rdt * (drag * (ax * vw + ay * uw) + im * m.tay[i] + vrhs);
+    const double r_a = 1. + ax * drag * rdt, r_b = rdt * (m.cori_n[i] + ay * drag);
+    const double det = 1.0 / (r_a * r_a + r_b * r_b);
+    U = det * (r_a * rhsu + r_b * rhsv);
+    V = det * (r_a * rhsv - r_b * rhsu);
+  } else { U = 0.0; V = 0.0; }
+  if (m.bnd[i]) { U = 0.0; V = 0.0; }
+  un[i] = U; vn[i] = V;
+}
+__global__ void k_ice_c_start(IceDM m, int par) {            // the solver copies of the velocities (the fused subcycles alternate between two buffers)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.N) return;
+  m.ua[par][i] = m.u_ice[i]; m.va[par][i] = m.v_ice[i];
+}
+// one EVPdynamics call, fused subcycles; the stresses start in parity `par`; returns the parity they end in
+int enqueue_call_c(hipStream_t s, int par) {
+  const IceDM &m = I.m;
+  const double ax = cos(m.p.theta_io), ay = sin(m.p.theta_io);      // (host libm, as the reference's)
+  hipLaunchKernelGGL(k_ice_c_prep_node, dim3((m.myN + 255) / 256), dim3(256), 0, s, m);
+  hipLaunchKernelGGL(k_ice_c_prep_elem, dim3((m.myE + 255) / 256), dim3(256), 0, s, m);
+  hipLaunchKernelGGL(k_ice_c_start, dim3((m.N + 255) / 256), dim3(256), 0, s, m, par);
+  for (int k = 0; k < m.p.evp_rheol_steps; k++) {
+    hipLaunchKernelGGL(k_ice_c_sub8, dim3((unsigned)(((size_t)m.N * 8 + 255) / 256)), dim3(256), 0, s, m, par, ax, ay);
+    par = 1 - par;
+  }
+  hipLaunchKernelGGL(k_ice_finish, dim3((m.N + 255) / 256), dim3(256), 0, s, m, par);
+  return par;
+}
+// The adaptive subcycle fused the same way (k_ice_a_stress + k_ice_a_node in one launch, eight lanes per node).  stress2rhs_m subtracts TWO terms per element
+// (:246-253): both travel to the node's first lane, ((urhs - A) - B) and ((vrhs - C) + D) in element order.
+__global__ void __launch_bounds__(256) k_ice_a_sub8(IceDM m, int par) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t >> 3, k0 = t & 7;
+  const bool live = i < m.N;
+  const double *uo = m.ua[par], *vo = m.va[par];
+  double *un = m.ua[1 - par], *vn = m.va[1 - par];
+  const bool owned = live && i < m.myN;
+  const double *so = m.sig[par];
+  double *sn = m.sig[1 - par];
+  const size_t E = (size_t)m.myE;
+  const double val3 = 1.0 / 3.0, vale = 1.0 / (m.p.ellipse * m.p.ellipse), rdt = m.p.ice_dt;
+  const int num = owned ? m.nie_num[i] : 0;
+  int nmax = num;
+  for (int sft = 32; sft >= 1; sft >>= 1) nmax = max(nmax, __shfl_xor(nmax, sft, 64));
+  double urhs = 0.0, vrhs = 0.0;
+  for (int base = 0; base < nmax; base += 8) {
+    const int k = base + k0;
+    double tA = 0.0, tB = 0.0, tC = 0.0, tD = 0.0;
+    if (k < num) {
+      const int el = m.nie[(size_t)m.maxk * i + k];
+      const int n1 = m.en[3 * el], n2 = m.en[3 * el + 1], n3 = m.en[3 * el + 2];
+      const bool writer = (n1 < m.myN) ? (n1 == i) : ((n2 < m.myN) ? (n2 == i) : (n3 == i));
+      double s11 = so[el], s12 = so[E + el], s22 = so[2 * E + el];
+      double eps1, eps2, eps12, delta, msum;
+      if (ice_a_strain(m, el, uo, vo, eps1, eps2, eps12, delta, msum)) {
+        const double alpha = m.alpha[el];
+        const double det2 = 1.0 / (1.0 + alpha), det1 = alpha * det2;
+        const double pressure = m.p.Pstar * msum * m.efac[el] / (delta + m.p.delta_min);
+        const double r1 = pressure * (eps1 - delta), r2 = pressure * eps2 * vale, r3 = pressure * eps12 * vale;
+        double si1 = s11 + s22, si2 = s11 - s22;
+        si1 = det1 * si1 + det2 * r1;
+        si2 = det1 * si2 + det2 * r2;
+        s12 = det1 * s12 + det2 * r3;
+        s11 = 0.5 * (si1 + si2);
+        s22 = 0.5 * (si1 - si2);
+      }
+      if (writer) { sn[el] = s11; sn[E + el] = s12; sn[2 * E + el] = s22; }
+      if (!((m.a_ice[n1] + m.a_ice[n2]) + m.a_ice[n3] < 0.01)) {
+        const double vol = m.elem_area[el], mf = m.metric[el];
+        const double *dx = m.gsca + 6 * (size_t)el, *dy = dx + 3;
+        const int pos = (n1 == i) ? 0 : ((n2 == i) ? 1 : 2);
+        tA = vol * (s11 * dx[pos] + s12 * dy[pos]); tB = vol * s12 * val3 * mf;
+        tC = vol * (s12 * dx[pos] + s22 * dy[pos]); tD = vol * s11 * val3 * mf;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const double qa = __shfl(tA, q, 8), qb = __shfl(tB, q, 8), qc = __shfl(tC, q, 8), qd = __shfl(tD, q, 8);
+      urhs = urhs - qa - qb; vrhs = vrhs - qc + qd;
+    }
+  }
+  if (!live || k0 != 0) return;
+  if (!owned) { un[i] = uo[i]; vn[i] = vo[i]; return; }
+  double mass = (m.m_ice[i] * ICE_RHOICE + m.m_snow[i] * ICE_RHOSNO);
+  mass = mass / (1.0 + mass * mass);
+  urhs = (urhs * mass + m.rhs_a[i]) / m.area1[i];
+  vrhs = (vrhs * mass + m.rhs_m[i]) / m.area1[i];
+  const double ai = m.a_ice[i];
+  double thickness = (ICE_RHOICE * m.m_ice[i] + ICE_RHOSNO * m.m_snow[i]) / (ai > 0.01 ? ai : 0.01);
+  thickness = thickness > 9.0 ? thickness : 9.0;
+  const double inv_thickness = 1.0 / thickness;
+  double ua = uo[i], va = vo[i];
+  const double uw = m.u_w[i], vw = m.v_w[i];
+  const double du = ua - uw, dv = va - vw;
+  const double umod = sqrt(du * du + dv * dv);
+  const double drag = rdt * m.p.cd_oce_ice * umod * ICE_DENSITY_0 * inv_thickness;
+  double rhsu = m.u_ice[i] + drag * uw + rdt * (inv_thickness * m.tax[i] + urhs);
+  double rhsv = m.v_ice[i] + drag * vw + rdt * (inv_thickness * m.tay[i] + vrhs);
+  const double beta = m.beta[i];
+  rhsu = beta * ua + rhsu;
+  rhsv = beta * va + rhsv;
+  const double fc = rdt * m.cori_n[i];
+  double det = (1.0 + beta + drag) * (1.0 + beta + drag) + fc * fc;
+  det = (m.bnd[i] ? 0.0 : 1.0) / det;
+  ua = det * ((1.0 + beta + drag) * rhsu + fc * rhsv);
+  va = det * ((1.0 + beta + drag) * rhsv - fc * rhsu);
+  if (m.bnd[i]) { ua = 0.0; va = 0.0; }
+  un[i] = ua; vn[i] = va;
+}
+// one EVPdynamics_a call, fused subcycles; the stresses start in parity `sp` and (even number of subcycles) return to it; returns the parity they end in
+int enqueue_call_a8(hipStream_t s, int sp) {
+  const IceDM &m = I.m;
+  hipLaunchKernelGGL(k_ice_a_prep, dim3((m.N + 255) / 256), dim3(256), 0, s, m);      // (u_ice_aux in ua[0])
+  int par = sp;
+  if (par == 1) {
+    hipMemcpyAsync(m.ua[1], m.ua[0], sizeof(double) * m.N, hipMemcpyDeviceToDevice, s);
+    hipMemcpyAsync(m.va[1], m.va[0], sizeof(double) * m.N, hipMemcpyDeviceToDevice, s);
+  }
+  for (int k = 0; k < m.p.evp_rheol_steps; k++) {
+    hipLaunchKernelGGL(k_ice_a_sub8, dim3((unsigned)(((size_t)m.N * 8 + 255) / 256)), dim3(256), 0, s, m, par);
+    par = 1 - par;
+  }
+  hipLaunchKernelGGL(k_ice_finish, dim3((m.N + 255) / 256), dim3(256), 0, s, m, par);
+  hipLaunchKernelGGL(k_ice_a_alpha, dim3((m.myE + 255) / 256), dim3(256), 0, s, m, par);
+  hipLaunchKernelGGL(k_ice_a_beta, dim3((m.myN + 255) / 256), dim3(256), 0, s, m);
+  return par;
+}
 // one EVPdynamics_a call: the stresses stay in sig[sp] (in place); the velocities alternate and end in u_ice / v_ice
 void enqueue_call_a(hipStream_t s, int sp) {
   const IceDM &m = I.m;
@@ -887,6 +1082,25 @@ int fesom_gpu_ice_evp(int ncalls) {
   ICE_READY();
   if (I.m.p.whichEVP == 2 || I.m.p.whichEVP == 0) {          // adaptive EVP: EVPdynamics_a; classic EVP: EVPdynamics
     if (I.npes > 1) { I.err = "fesom_gpu_ice_evp: partitioned context, call fesom_gpu_ice_evp_partitioned"; return 1; }
+    static const bool unfused = getenv("FESOM_GPU_ICE_UNFUSED") != nullptr;      // (the two-launch form of the classic subcycle, kept for comparison)
+    if (!unfused) {
+      const bool adaptive = I.m.p.whichEVP == 2;
+      for (int c = 0; c < ncalls; c++) {
+        if (I.m.p.evp_rheol_steps % 2 == 0 && I.cur == 0) {      // an even number of subcycles returns to parity 0 -> one fixed graph
+          if (!I.graph) {
+            hipGraph_t g;
+            ICECHK(hipStreamBeginCapture(I.stream, hipStreamCaptureModeGlobal));
+            if (adaptive) enqueue_call_a8(I.stream, 0); else enqueue_call_c(I.stream, 0);
+            ICECHK(hipStreamEndCapture(I.stream, &g));
+            ICECHK(hipGraphInstantiate(&I.graph, g, nullptr, nullptr, 0));
+            hipGraphDestroy(g);
+          }
+          ICECHK(hipGraphLaunch(I.graph, I.stream));
+        } else I.cur = adaptive ? enqueue_call_a8(I.stream, I.cur) : enqueue_call_c(I.stream, I.cur);
+      }
+      ICECHK(hipGetLastError());
+      return 0;
+    }
     auto enqueue = [&]() {
       if (I.m.p.whichEVP == 2) enqueue_call_a(I.stream, I.cur);
       else {
