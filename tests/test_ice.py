@@ -308,3 +308,29 @@ def test_gpu_evp0_equals_oracle_and_reference_bitwise(built):
     ms = core.time_ms(3)
     assert 0.0 < ms < 100.0
     core.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", [0, 2])
+def test_gpu_ice_step_other_rheologies_equals_oracle_bitwise(built, which):
+    """Whole ice steps (rheology + FCT advection on the device-resident state, the pressure factor following the advected concentration) with the classic and the
+    adaptive EVP: u_ice, v_ice, stresses, m_ice, a_ice, m_snow (and alpha / beta) equal the oracle's sequence orc_ice_evp0 / orc_ice_evp_a + orc_ice_adv bit for bit
+    after each of three steps.  (Each routine is pinned on the reference by itself; the reference run of this combination exists for mEVP: the test above.)"""
+    from fesom2_amd import ice
+    import oracle_lib
+    g = gold_0() if which == 0 else gold_a()
+    mesh, par, fo = (setup_0 if which == 0 else setup_a)(g)
+    _, _, fg = (setup_0 if which == 0 else setup_a)(g)
+    oracle_lib.build()
+    orc = C.CDLL(oracle_lib.ORC_LIB)
+    core = ice.IceCore(mesh, par)
+    core.upload(fg)
+    names = ("u_ice", "v_ice", "a_ice", "m_ice", "m_snow", "sigma11", "sigma12", "sigma22") + (("alpha_evp_array", "beta_evp_array") if which == 2 else ())
+    for n in (1, 2, 3):
+        core.step(1); core.download(fg)
+        assert (orc.orc_ice_evp0 if which == 0 else orc.orc_ice_evp_a)(mesh.desc_p, C.byref(par), C.byref(fo.desc)) == 0
+        oracle_adv(mesh, par, fo, par.ice_gamma_fct)
+        for k in names:
+            assert bits(fg[k], fo[k]), (n, k, float(np.abs(fg[k] - fo[k]).max()))
+    assert np.abs(fg["m_ice"] - g["in/m_ice"]).max() > 1e-4
+    core.close()
